@@ -1,0 +1,296 @@
+"""ctypes mirror of include/akari_hip.h (struct layouts only; no library is loaded here).
+
+`SceneData` is a plain numpy container for a flattened scene; `SceneData.to_desc()` builds the
+`akr_scene_desc` the C ABI takes (and keeps the numpy arrays alive for as long as the desc lives).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+c_f32p = C.POINTER(C.c_float)
+c_u32p = C.POINTER(C.c_uint32)
+
+
+class MeshDesc(C.Structure):
+    _fields_ = [
+        ("n_vertices", C.c_uint32),
+        ("n_triangles", C.c_uint32),
+        ("vertices", c_f32p),
+        ("indices", c_u32p),
+        ("uvs", c_f32p),
+        ("normals", c_f32p),
+        ("tangents", c_f32p),
+        ("material_slots", c_u32p),
+    ]
+
+
+class InstanceDesc(C.Structure):
+    _fields_ = [
+        ("mesh", C.c_uint32),
+        ("n_materials", C.c_uint32),
+        ("materials", c_u32p),
+        ("transform", C.c_float * 16),
+    ]
+
+
+MAT_PRINCIPLED, MAT_DIFFUSE, MAT_GLASS, MAT_EMISSION = 0, 1, 2, 3
+
+
+class MaterialDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_uint32),
+        ("base_color", C.c_float * 3),
+        ("base_alpha", C.c_float),
+        ("metallic", C.c_float),
+        ("roughness", C.c_float),
+        ("ior", C.c_float),
+        ("specular_ior_level", C.c_float),
+        ("specular_tint", C.c_float * 3),
+        ("transmission_weight", C.c_float),
+        ("coat_weight", C.c_float),
+        ("coat_roughness", C.c_float),
+        ("coat_ior", C.c_float),
+        ("coat_tint", C.c_float * 3),
+        ("emission_color", C.c_float * 3),
+        ("emission_strength", C.c_float),
+        ("normal", C.c_float * 3),
+    ]
+
+
+class CameraDesc(C.Structure):
+    _fields_ = [("c2w", C.c_float * 16), ("fov", C.c_float), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [
+        ("n_meshes", C.c_uint32),
+        ("n_instances", C.c_uint32),
+        ("n_materials", C.c_uint32),
+        ("_pad", C.c_uint32),
+        ("meshes", C.POINTER(MeshDesc)),
+        ("instances", C.POINTER(InstanceDesc)),
+        ("materials", C.POINTER(MaterialDesc)),
+        ("camera", CameraDesc),
+        ("ggx_dielectric_table", c_f32p),
+    ]
+
+
+FILTER_BOX, FILTER_GAUSSIAN = 0, 1
+SAMPLER_INDEPENDENT = 0
+
+
+class PtConfig(C.Structure):
+    """akr_pt_config = pt::Config (pt.rs:916-944) + filter + sampler + shard."""
+
+    _fields_ = [
+        ("spp", C.c_uint32),
+        ("max_depth", C.c_uint32),
+        ("spp_per_pass", C.c_uint32),
+        ("rr_depth", C.c_uint32),
+        ("use_nee", C.c_uint32),
+        ("indirect_only", C.c_uint32),
+        ("force_diffuse", C.c_uint32),
+        ("pixel_offset", C.c_int32 * 2),
+        ("debug_depth", C.c_int32),
+        ("filter_type", C.c_uint32),
+        ("filter_radius", C.c_float),
+        ("sampler_type", C.c_uint32),
+        ("_pad", C.c_uint32),
+        ("sampler_seed", C.c_uint64),
+        ("shard_rank", C.c_uint32),
+        ("shard_count", C.c_uint32),
+        ("tile_w", C.c_uint32),
+        ("tile_h", C.c_uint32),
+    ]
+
+    @staticmethod
+    def default() -> "PtConfig":
+        """pt::Config::default() (pt.rs:930-944), PixelFilter::default() (film.rs:50-54),
+        SamplerConfig::default() (sampler/mod.rs:290-294)."""
+        c = PtConfig()
+        c.spp, c.max_depth, c.spp_per_pass, c.rr_depth = 256, 7, 64, 5
+        c.use_nee, c.indirect_only, c.force_diffuse = 1, 0, 0
+        c.pixel_offset[0] = c.pixel_offset[1] = 0
+        c.debug_depth = -1
+        c.filter_type, c.filter_radius = FILTER_GAUSSIAN, 1.5
+        c.sampler_type, c.sampler_seed = SAMPLER_INDEPENDENT, 0
+        c.shard_rank, c.shard_count, c.tile_w, c.tile_h = 0, 1, 32, 32
+        return c
+
+    def copy(self) -> "PtConfig":
+        c = PtConfig()
+        C.memmove(C.byref(c), C.byref(self), C.sizeof(PtConfig))
+        return c
+
+
+class PtStats(C.Structure):
+    _fields_ = [
+        ("n_samples", C.c_uint64),
+        ("n_closest", C.c_uint64),
+        ("n_shadow", C.c_uint64),
+        ("n_shaded", C.c_uint64),
+        ("n_node_visits", C.c_uint64),
+        ("n_tri_tests", C.c_uint64),
+        ("kernel_ms", C.c_double),
+        ("n_launches", C.c_uint32),
+        ("_pad", C.c_uint32),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("_")}
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+        ("n_instances", C.c_uint32),
+        ("n_triangles", C.c_uint32),
+        ("n_materials", C.c_uint32),
+        ("n_lights", C.c_uint32),
+        ("n_bvh_nodes", C.c_uint32),
+        ("uses_bvh", C.c_uint32),
+        ("device_bytes", C.c_uint64),
+    ]
+
+
+# ------------------------------------------------------------------------------------------------------
+@dataclass
+class MeshData:
+    vertices: np.ndarray  # (nv,3) f32
+    indices: np.ndarray  # (nt,3) u32
+    uvs: Optional[np.ndarray] = None  # (nt,3,2) f32
+    normals: Optional[np.ndarray] = None  # (nt,3,3) f32
+    tangents: Optional[np.ndarray] = None  # (nt,3,3) f32
+    material_slots: Optional[np.ndarray] = None  # (nt,) u32
+
+
+@dataclass
+class InstanceData:
+    mesh: int
+    materials: List[int]
+    transform: np.ndarray  # (16,) f32 column-major
+
+
+@dataclass
+class MaterialData:
+    kind: int = MAT_PRINCIPLED
+    base_color: tuple = (0.8, 0.8, 0.8)
+    base_alpha: float = 1.0
+    metallic: float = 0.0
+    roughness: float = 0.5
+    ior: float = 1.45
+    specular_ior_level: float = 0.5
+    specular_tint: tuple = (1.0, 1.0, 1.0)
+    transmission_weight: float = 0.0
+    coat_weight: float = 0.0
+    coat_roughness: float = 0.03
+    coat_ior: float = 1.5
+    coat_tint: tuple = (1.0, 1.0, 1.0)
+    emission_color: tuple = (0.0, 0.0, 0.0)
+    emission_strength: float = 0.0
+    normal: tuple = (0.0, 0.0, 0.0)
+
+    def to_struct(self) -> MaterialDesc:
+        m = MaterialDesc()
+        m.kind = self.kind
+        for name in ("base_color", "specular_tint", "coat_tint", "emission_color", "normal"):
+            v = np.asarray(getattr(self, name), dtype=np.float32)
+            arr = getattr(m, name)
+            for i in range(3):
+                arr[i] = float(v[i])
+        for name in (
+            "base_alpha",
+            "metallic",
+            "roughness",
+            "ior",
+            "specular_ior_level",
+            "transmission_weight",
+            "coat_weight",
+            "coat_roughness",
+            "coat_ior",
+            "emission_strength",
+        ):
+            setattr(m, name, float(np.float32(getattr(self, name))))
+        return m
+
+
+@dataclass
+class CameraData:
+    c2w: np.ndarray  # (16,) f32 column-major
+    fov: float  # radians
+    width: int
+    height: int
+
+
+@dataclass
+class SceneData:
+    meshes: List[MeshData]
+    instances: List[InstanceData]
+    materials: List[MaterialData]
+    camera: CameraData
+    ggx_table: Optional[np.ndarray] = None  # (4096,) f32
+    instance_names: List[str] = field(default_factory=list)
+    material_names: List[str] = field(default_factory=list)
+
+    def n_triangles(self) -> int:
+        return sum(self.meshes[i.mesh].indices.shape[0] for i in self.instances)
+
+    def to_desc(self):
+        """Returns (SceneDesc, keepalive). The desc points into numpy arrays held by `keepalive`."""
+        keep = []
+
+        def fptr(a, shape_tail=None):
+            if a is None:
+                return c_f32p()
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            keep.append(a)
+            return a.ctypes.data_as(c_f32p)
+
+        def uptr(a):
+            if a is None:
+                return c_u32p()
+            a = np.ascontiguousarray(a, dtype=np.uint32)
+            keep.append(a)
+            return a.ctypes.data_as(c_u32p)
+
+        meshes = (MeshDesc * max(1, len(self.meshes)))()
+        for i, m in enumerate(self.meshes):
+            md = meshes[i]
+            md.n_vertices = int(np.asarray(m.vertices).reshape(-1, 3).shape[0])
+            md.n_triangles = int(np.asarray(m.indices).reshape(-1, 3).shape[0])
+            md.vertices = fptr(m.vertices)
+            md.indices = uptr(m.indices)
+            md.uvs = fptr(m.uvs)
+            md.normals = fptr(m.normals)
+            md.tangents = fptr(m.tangents)
+            md.material_slots = uptr(m.material_slots)
+        insts = (InstanceDesc * max(1, len(self.instances)))()
+        for i, inst in enumerate(self.instances):
+            d = insts[i]
+            d.mesh = inst.mesh
+            d.n_materials = len(inst.materials)
+            d.materials = uptr(np.asarray(inst.materials, dtype=np.uint32))
+            t = np.asarray(inst.transform, dtype=np.float32).reshape(16)
+            for k in range(16):
+                d.transform[k] = float(t[k])
+        mats = (MaterialDesc * max(1, len(self.materials)))()
+        for i, m in enumerate(self.materials):
+            mats[i] = m.to_struct()
+        desc = SceneDesc()
+        desc.n_meshes, desc.n_instances, desc.n_materials = len(self.meshes), len(self.instances), len(self.materials)
+        desc.meshes = C.cast(meshes, C.POINTER(MeshDesc))
+        desc.instances = C.cast(insts, C.POINTER(InstanceDesc))
+        desc.materials = C.cast(mats, C.POINTER(MaterialDesc))
+        c2w = np.asarray(self.camera.c2w, dtype=np.float32).reshape(16)
+        for k in range(16):
+            desc.camera.c2w[k] = float(c2w[k])
+        desc.camera.fov = float(np.float32(self.camera.fov))
+        desc.camera.width, desc.camera.height = int(self.camera.width), int(self.camera.height)
+        desc.ggx_dielectric_table = fptr(self.ggx_table)
+        keep += [meshes, insts, mats]
+        return desc, keep

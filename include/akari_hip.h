@@ -1,0 +1,270 @@
+/* akari_hip.h -- C ABI of libakari_hip.so: an MI355X (gfx950) implementation of akari_render's `pt`
+ * path-tracing integrator.
+ *
+ * This is the boundary a Rust `impl Integrator for HipPathTracer` would bind (INTEGRATION.md shows the
+ * `extern "C"` block). The reference has no C ABI for integrators; the path sits behind
+ *   trait Integrator::render(&self, scene, sampler, color_pipeline, film, session)
+ *                                              crates/akari_integrator/src/lib.rs:38-47
+ *   pt::render(device, scene, sampler, color_pipeline, film, &Config, &RenderSession)
+ *                                              crates/akari_integrator/src/pt.rs:1161-1172
+ * and each entry point below names the reference item it replaces. Conventions follow the reference's
+ * own FFI precedent (crates/akari_api/src/lib.rs:6-26: plain pointers + lengths, paired create/free):
+ *   - every function returns an int32 status (AKR_OK or a negative akr_status); nothing throws or aborts
+ *     across the ABI; akr_last_error() returns a thread-local, library-owned message;
+ *   - the caller owns every input array (the library copies during *_create) and every output buffer;
+ *   - handles are opaque and owned by the library until the matching *_destroy;
+ *   - one context = one HIP device + one stream; calls on one context must be serialised by the caller,
+ *     distinct contexts may be used from distinct threads / processes (one process per GPU).
+ * No PyTorch / C++ types appear in any signature.
+ */
+#ifndef AKARI_HIP_H
+#define AKARI_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(_WIN32)
+#define AKR_API
+#else
+#define AKR_API __attribute__((visibility("default")))
+#endif
+
+typedef enum {
+    AKR_OK = 0,
+    AKR_ERR_INVALID_ARGUMENT = -1,
+    AKR_ERR_HIP = -2,          /* a HIP runtime call failed (message has hipGetErrorString) */
+    AKR_ERR_NO_DEVICE = -3,    /* no gfx950 device / HIP runtime unavailable */
+    AKR_ERR_IO = -4,           /* scene / method file could not be read */
+    AKR_ERR_PARSE = -5,        /* malformed JSON or unsupported node */
+    AKR_ERR_UNSUPPORTED = -6,  /* feature of the reference that this build does not cover */
+    AKR_ERR_OUT_OF_MEMORY = -7
+} akr_status;
+
+typedef struct akr_context akr_context;
+typedef struct akr_scene akr_scene;
+typedef struct akr_film akr_film;
+typedef struct akr_pt_session akr_pt_session;
+
+/* ---------------------------------------------------------------------------------------------------
+ * Scene description: the flat form of the reference's scene graph after load.rs has resolved buffers.
+ * ------------------------------------------------------------------------------------------------- */
+
+/* One `Mesh` (crates/akari_render/src/mesh.rs:14-25; on disk crates/akari_scenegraph/src/scene.rs:333-340). */
+typedef struct {
+    uint32_t n_vertices, n_triangles;
+    const float *vertices;          /* 3 * n_vertices, object space */
+    const uint32_t *indices;        /* 3 * n_triangles */
+    const float *uvs;               /* 2 * 3 * n_triangles, per corner, or NULL */
+    const float *normals;           /* 3 * 3 * n_triangles, per corner, or NULL */
+    const float *tangents;          /* 3 * 3 * n_triangles, per corner, or NULL */
+    const uint32_t *material_slots; /* n_triangles, or NULL (= slot 0) */
+} akr_mesh_desc;
+
+/* One `MeshInstanceHost` (mesh.rs:197-204); instance index = order in this array
+ * (the reference iterates its BTreeMap, i.e. lexicographic node-id order, load.rs:287-292). */
+typedef struct {
+    uint32_t mesh;
+    uint32_t n_materials;
+    const uint32_t *materials;      /* indices into akr_scene_desc.materials, one per material slot */
+    float transform[16];            /* column-major object->world (AffineTransform.m, geometry.rs:203-209) */
+} akr_instance_desc;
+
+/* A surface shader graph whose inputs are constants (all of scenes/cbox), already folded:
+ * svm/compiler.rs:116-337 + svm/eval.rs:97-269 applied on the host. Colours are linear RGB in the
+ * pipeline's colour space (svm/texture/mod.rs:9-40). */
+typedef enum {
+    AKR_MAT_PRINCIPLED = 0,  /* ShaderNode::PrincipledBsdf, svm/surface/principled.rs */
+    AKR_MAT_DIFFUSE = 1,     /* ShaderNode::DiffuseBsdf,    svm/surface/diffuse.rs:83-104 */
+    AKR_MAT_GLASS = 2,       /* ShaderNode::GlassBsdf,      svm/surface/glass.rs */
+    AKR_MAT_EMISSION = 3     /* ShaderNode::Emission,       svm/mod.rs:114-123 */
+} akr_material_kind;
+
+typedef struct {
+    uint32_t kind;
+    float base_color[3];
+    float base_alpha;
+    float metallic, roughness, ior, specular_ior_level;
+    float specular_tint[3];
+    float transmission_weight;
+    float coat_weight, coat_roughness, coat_ior;
+    float coat_tint[3];
+    float emission_color[3];
+    float emission_strength;
+    float normal[3];
+} akr_material_desc;
+
+/* PerspectiveCamera (camera/mod.rs:15-66): only the fields generate_ray uses. */
+typedef struct {
+    float c2w[16];           /* column-major camera->world */
+    float fov;               /* radians; spans the larger image side */
+    uint32_t width, height;
+} akr_camera_desc;
+
+typedef struct {
+    uint32_t n_meshes, n_instances, n_materials, _pad;
+    const akr_mesh_desc *meshes;
+    const akr_instance_desc *instances;
+    const akr_material_desc *materials;
+    akr_camera_desc camera;
+    /* Optional 16x16x16 f32 "ggx_dielectric_s" table (svm/surface/precompute.rs:133-145). NULL = the
+     * library computes it on the GPU the first time a material needs it (same definition, 2^20 samples). */
+    const float *ggx_dielectric_table;
+} akr_scene_desc;
+
+/* ---------------------------------------------------------------------------------------------------
+ * Render configuration = pt::Config (pt.rs:916-944) + RenderConfig.sampler / .film.filter (lib.rs:75-102).
+ * ------------------------------------------------------------------------------------------------- */
+typedef enum { AKR_FILTER_BOX = 0, AKR_FILTER_GAUSSIAN = 1 } akr_filter_type;   /* film.rs:22-54 */
+typedef enum { AKR_SAMPLER_INDEPENDENT = 0 } akr_sampler_type;                  /* sampler/mod.rs:282-295 */
+
+typedef struct {
+    uint32_t spp, max_depth, spp_per_pass, rr_depth;
+    uint32_t use_nee, indirect_only, force_diffuse;
+    int32_t pixel_offset[2];
+    int32_t debug_depth;      /* -1 = None */
+    uint32_t filter_type;
+    float filter_radius;
+    uint32_t sampler_type;
+    uint32_t _pad;
+    uint64_t sampler_seed;
+    /* Multi-GPU sharding (no reference counterpart): rank r of n renders the pixel tiles t with
+     * t % n == r (tiles of tile_w x tile_h in row-major tile order; 0 = 32). shard_count <= 1 renders all.
+     * Pixels a rank does not own are left untouched in its film, so a sum-reduce assembles the frame. */
+    uint32_t shard_rank, shard_count, tile_w, tile_h;
+} akr_pt_config;
+
+/* Device counters of one render call (the n_* of the algorithmic-bytes model). */
+typedef struct {
+    uint64_t n_samples;       /* camera paths */
+    uint64_t n_closest;       /* closest-hit queries (scene.rs:131-153) */
+    uint64_t n_shadow;        /* any-hit queries (scene.rs:155-185) */
+    uint64_t n_shaded;        /* path vertices that ran NEE + BSDF sampling (pt.rs:471-513) */
+    uint64_t n_node_visits;   /* BVH nodes fetched (0 on the exhaustive small-scene path) */
+    uint64_t n_tri_tests;     /* ray-triangle tests */
+    double kernel_ms;         /* sum of the path-tracing kernels' durations, HIP events on the context stream */
+    uint32_t n_launches;
+    uint32_t _pad;
+} akr_pt_stats;
+
+/* ---------------------------------------------------------------------------------------------------
+ * Entry points
+ * ------------------------------------------------------------------------------------------------- */
+
+/* Thread-local description of the last failure on this thread ("" if none). Never NULL. */
+AKR_API const char *akr_last_error(void);
+
+/* Replaces luisa::Context::create_device(-d ...) (akari_api/src/bin/akari_cli.rs:61-62).
+ * `device` is the HIP device ordinal. Fails with AKR_ERR_NO_DEVICE when no GPU is visible:
+ * there is no CPU fallback in this library. */
+AKR_API int32_t akr_context_create(int32_t device, akr_context **out);
+AKR_API int32_t akr_context_destroy(akr_context *ctx);
+/* Blocks until all work queued on the context's stream is done. */
+AKR_API int32_t akr_context_synchronize(akr_context *ctx);
+/* Device name / compute units / HBM bytes of the context's GPU. `name` gets at most name_len-1 chars. */
+AKR_API int32_t akr_context_device_info(akr_context *ctx, char *name, uint32_t name_len, uint32_t *compute_units,
+                                        uint64_t *hbm_bytes);
+
+/* Replaces SceneLoader::do_load after buffers are resolved (load.rs:238-456): uploads geometry, builds the
+ * BVH (replacing rtx::Accel, mesh.rs:288-294,331-333), folds materials, runs the emission-power estimate
+ * and builds the light alias tables (load.rs:308-444). */
+AKR_API int32_t akr_scene_create(akr_context *ctx, const akr_scene_desc *desc, akr_scene **out);
+/* Replaces akari_render::load::load_from_path (load.rs:63-72 -> MmapScene::open, scenegraph scene.rs:603-647):
+ * parses the reference's scene.json (+ its binary buffers, resolved relative to the JSON's directory, falling
+ * back to the basename for the absolute Windows paths found in scenes/cbox). width/height override the
+ * camera's sensor resolution when non-zero (Camera::set_resolution, camera/mod.rs:54-65). */
+AKR_API int32_t akr_scene_load(akr_context *ctx, const char *scene_json_path, uint32_t width, uint32_t height,
+                               akr_scene **out);
+AKR_API int32_t akr_scene_destroy(akr_scene *scene);
+/* Camera::set_resolution (camera/mod.rs:54-65). */
+AKR_API int32_t akr_scene_set_resolution(akr_scene *scene, uint32_t width, uint32_t height);
+
+typedef struct {
+    uint32_t width, height;
+    uint32_t n_instances, n_triangles, n_materials, n_lights;
+    uint32_t n_bvh_nodes;     /* 0 when the scene uses the exhaustive small-scene intersector */
+    uint32_t uses_bvh;
+    uint64_t device_bytes;    /* HBM held by the scene */
+} akr_scene_info;
+AKR_API int32_t akr_scene_get_info(const akr_scene *scene, akr_scene_info *info);
+/* Light `light` of LightAggregate (light/mod.rs:87-98): owning instance, total power, selection pdf. */
+AKR_API int32_t akr_scene_get_light(const akr_scene *scene, uint32_t light, uint32_t *instance, float *power, float *pdf);
+/* The folded ggx_dielectric_s table in use (4096 floats), for comparison with a golden copy. */
+AKR_API int32_t akr_scene_get_ggx_table(const akr_scene *scene, float *dst4096);
+/* Host-side copy of the flattened description akr_scene_load produced (for loader tests):
+ * counts first, then the caller sizes its buffers and asks for the arrays. */
+AKR_API int32_t akr_scene_get_desc_counts(const akr_scene *scene, uint32_t *n_meshes, uint32_t *n_instances, uint32_t *n_materials);
+AKR_API int32_t akr_scene_get_mesh(const akr_scene *scene, uint32_t mesh, akr_mesh_desc *out /* pointers owned by scene */);
+AKR_API int32_t akr_scene_get_instance(const akr_scene *scene, uint32_t instance, akr_instance_desc *out);
+AKR_API int32_t akr_scene_get_material(const akr_scene *scene, uint32_t material, akr_material_desc *out);
+AKR_API int32_t akr_scene_get_camera(const akr_scene *scene, akr_camera_desc *out);
+
+/* Replaces Film::new (film.rs:93-151): f32[(1 + 2*3) * W * H] on the device, laid out exactly as the
+ * reference's buffer [rgb * N | splat * N | weight * N] (film.rs:69, 85-90), zero-initialised. */
+AKR_API int32_t akr_film_create(akr_context *ctx, uint32_t width, uint32_t height, akr_film **out);
+AKR_API int32_t akr_film_destroy(akr_film *film);
+AKR_API int32_t akr_film_clear(akr_film *film);                       /* Film::clear, film.rs:231-233 */
+/* Copies the raw accumulator (7 * W * H floats, reference layout) to host memory. */
+AKR_API int32_t akr_film_read(akr_film *film, float *dst);
+/* Overwrites the raw accumulator from host memory (7 * W * H floats). */
+AKR_API int32_t akr_film_write(akr_film *film, const float *src);
+/* Film resolve = the copy_to_rgba_image kernel with hdr = true (film.rs:120-148): rgb / (w == 0 ? 1 : w)
+ * + splat * splat_scale; writes 3 * W * H floats of linear RGB to host memory. */
+AKR_API int32_t akr_film_resolve(akr_film *film, float *dst_rgb);
+/* Device pointer + byte size of the accumulator, for an RCCL reduce issued by the host application
+ * (one process per GPU). The pointer stays valid until akr_film_destroy. */
+AKR_API int32_t akr_film_device_ptr(akr_film *film, void **ptr, uint64_t *bytes);
+
+/* Fills *cfg with pt::Config::default() (pt.rs:930-944), the default filter (film.rs:50-54) and sampler
+ * (sampler/mod.rs:290-294). */
+AKR_API int32_t akr_pt_config_default(akr_pt_config *cfg);
+/* Parses a reference method file (RenderTask / RenderConfig JSON, akari_integrator/src/lib.rs:93-109;
+ * example scenes/cbox/pt.json). Only "type":"pt" is accepted. `film_out` (may be NULL) receives film.out. */
+AKR_API int32_t akr_pt_config_from_json(const char *json_text, akr_pt_config *cfg, char *film_out, uint32_t film_out_len);
+
+/* Replaces pt::render / PathTracer::render (pt.rs:1056-1172): initialises the per-pixel PCG32 states from
+ * cfg->sampler_seed (init_pcg32_buffer_with_seed, sampler/mod.rs:148-160), then runs
+ * ceil(spp / spp_per_pass) passes, accumulating into `film`. Blocks until the film is complete on the device.
+ * `stats` may be NULL. */
+AKR_API int32_t akr_pt_render(akr_context *ctx, akr_scene *scene, const akr_pt_config *cfg, akr_film *film,
+                              akr_pt_stats *stats);
+
+/* The same render split at the reference's own pass granularity (the body of the `while cnt < spp` loop,
+ * pt.rs:1126-1149), so a host can interleave its progress bar / intermediate saves / benchmark timing:
+ *   begin  -> sampler state buffer created and seeded;
+ *   passes -> runs up to n_passes further passes (fewer if spp is reached), asynchronously on the context
+ *             stream unless `blocking` is non-zero; *spp_done receives the cumulative sample count;
+ *   end    -> waits, returns accumulated counters, frees the session. */
+AKR_API int32_t akr_pt_begin(akr_context *ctx, akr_scene *scene, const akr_pt_config *cfg, akr_film *film,
+                             akr_pt_session **out);
+AKR_API int32_t akr_pt_passes(akr_pt_session *session, uint32_t n_passes, int32_t blocking, uint32_t *spp_done);
+AKR_API int32_t akr_pt_end(akr_pt_session *session, akr_pt_stats *stats);
+/* Copies the session's Pcg32 state buffer (2 x u64 per pixel: state, inc) to the host. */
+AKR_API int32_t akr_pt_read_sampler_states(akr_pt_session *session, uint64_t *dst);
+
+/* Library / build identification: "akari_hip <version> gfx950". */
+AKR_API const char *akr_version(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Device-function probes (used by the parity tests to compare single device functions with the oracle;
+ * they launch tiny kernels on the context's stream and block).
+ * ------------------------------------------------------------------------------------------------- */
+/* sin/cos/log of the kernels' elementary functions for n inputs. */
+AKR_API int32_t akr_probe_math(akr_context *ctx, uint32_t n, const float *x, float *sin_out, float *cos_out, float *log_out);
+/* BSDF of material `m` on a flat surface (normal +z, world == local; cf. akari_test.rs:16-439):
+ * mode 0: in = wi (3 floats / item)  -> out = f.rgb, pdf (4 floats / item)
+ * mode 1: in = u  (3 floats / item)  -> out = wi.xyz, f.rgb, pdf, valid (8 floats / item) */
+AKR_API int32_t akr_probe_bsdf(akr_context *ctx, const akr_material_desc *m, const float *ggx_table4096, int32_t mode,
+                               const float *wo, uint32_t n, const float *in, float *out);
+/* Closest hit of n rays (o.xyz, d.xyz, tmin, tmax = 8 floats / ray) -> hit(0/1), inst, prim as u32 and u, v. */
+AKR_API int32_t akr_probe_intersect(akr_context *ctx, akr_scene *scene, uint32_t n, const float *rays, uint32_t *hit_inst_prim,
+                                    float *bary);
+/* SurfaceInteraction of (inst, prim, u, v): out 19 floats / item = p, ng, n, t, s, uv, area, material. */
+AKR_API int32_t akr_probe_surface_interaction(akr_context *ctx, akr_scene *scene, uint32_t n, const uint32_t *inst_prim,
+                                              const float *bary, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AKARI_HIP_H */

@@ -1,0 +1,81 @@
+/* or_api.h -- input/output structs of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+ *
+ * The scene/material/config structs are layout-identical to the product's public C ABI
+ * (include/akari_hip.h: akr_mesh_desc, akr_instance_desc, akr_material_desc, akr_camera_desc,
+ * akr_scene_desc, akr_pt_config) so a test can hand the very same ctypes objects to both sides.
+ * The oracle deliberately re-declares them instead of including the product header: the two
+ * implementations share no code.
+ */
+#ifndef OR_API_H
+#define OR_API_H
+#include <stdint.h>
+
+typedef struct {
+    uint32_t n_vertices, n_triangles;
+    const float *vertices;          /* 3 * n_vertices, object space (mesh.rs:14-25) */
+    const uint32_t *indices;        /* 3 * n_triangles */
+    const float *uvs;               /* 2 * 3 * n_triangles (per corner) or NULL */
+    const float *normals;           /* 3 * 3 * n_triangles (per corner) or NULL */
+    const float *tangents;          /* 3 * 3 * n_triangles (per corner) or NULL */
+    const uint32_t *material_slots; /* n_triangles or NULL (= slot 0) */
+} or_mesh_desc;
+
+typedef struct {
+    uint32_t mesh;           /* index into meshes */
+    uint32_t n_materials;
+    const uint32_t *materials; /* indices into materials, one per slot */
+    float transform[16];     /* column-major object->world (glam Mat4 / AffineTransform.m) */
+} or_instance_desc;
+
+enum { OR_MAT_PRINCIPLED = 0, OR_MAT_DIFFUSE = 1, OR_MAT_GLASS = 2, OR_MAT_EMISSION = 3 };
+typedef struct {
+    uint32_t kind;
+    float base_color[3];     /* principled base_color / diffuse color / glass color (linear, target RGB space) */
+    float base_alpha;        /* alpha of the base-colour node (1 for constants, svm/eval.rs:125-135) */
+    float metallic, roughness, ior, specular_ior_level;
+    float specular_tint[3];
+    float transmission_weight;
+    float coat_weight, coat_roughness, coat_ior;
+    float coat_tint[3];
+    float emission_color[3];
+    float emission_strength;
+    float normal[3];         /* principled `normal` socket (0,0,0 = unperturbed) */
+} or_material_desc;
+
+typedef struct {
+    float c2w[16];           /* column-major camera->world (load.rs:129-171 applied to the camera TRS) */
+    float fov;               /* radians, spans the larger image side (camera/mod.rs:135-140) */
+    uint32_t width, height;
+} or_camera_desc;
+
+typedef struct {
+    uint32_t n_meshes, n_instances, n_materials, _pad;
+    const or_mesh_desc *meshes;
+    const or_instance_desc *instances;
+    const or_material_desc *materials;
+    or_camera_desc camera;
+    const float *ggx_dielectric_table; /* 16^3 f32 ("ggx_dielectric_s", precompute.rs:133-145) or NULL */
+} or_scene_desc;
+
+enum { OR_FILTER_BOX = 0, OR_FILTER_GAUSSIAN = 1 };
+enum { OR_SAMPLER_INDEPENDENT = 0 };
+typedef struct {
+    /* pt::Config, pt.rs:916-944 */
+    uint32_t spp, max_depth, spp_per_pass, rr_depth;
+    uint32_t use_nee, indirect_only, force_diffuse;
+    int32_t pixel_offset[2];
+    int32_t debug_depth;     /* -1 = None */
+    /* film.filter (film.rs:22-54) and sampler (sampler/mod.rs:282-295) of RenderConfig */
+    uint32_t filter_type;
+    float filter_radius;
+    uint32_t sampler_type;
+    uint32_t _pad;
+    uint64_t sampler_seed;
+    /* pixel-tile sharding (rank r of n renders tiles t with t % n == r); n = 1 renders everything */
+    uint32_t shard_rank, shard_count, tile_w, tile_h;
+} or_pt_config;
+
+typedef struct {
+    uint64_t n_samples, n_closest, n_shadow, n_shaded, n_tri_tests;
+} or_stats;
+#endif

@@ -1,0 +1,181 @@
+"""ctypes binding of oracle/liborakr.so (TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from akari_render_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+class OrStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_samples", "n_closest", "n_shadow", "n_shaded", "n_tri_tests")]
+
+
+def build(force: bool = False) -> None:
+    """Compiles the oracle with gcc (oracle/Makefile)."""
+    if force:
+        subprocess.check_call(["make", "-C", _HERE, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+
+
+def _cpu_has_fma() -> bool:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    fl = line.split()
+                    return "fma" in fl and "avx2" in fl
+    except OSError:
+        pass
+    return False
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    name = "liborakr.so" if _cpu_has_fma() else "liborakr_generic.so"
+    path = os.path.join(_HERE, name)
+    if not os.path.exists(path):
+        build()
+    L = C.CDLL(path)
+    vp, u32, u64, f32, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_int32
+    fp, up, u64p = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+    L.or_scene_create.restype = vp
+    L.or_scene_create.argtypes = [C.POINTER(abi.SceneDesc)]
+    L.or_scene_destroy.argtypes = [vp]
+    L.or_pt_render.restype = i32
+    L.or_pt_render.argtypes = [vp, C.POINTER(abi.PtConfig), fp, u64p, u32, C.POINTER(OrStats)]
+    L.or_film_resolve.argtypes = [fp, u32, u32, fp]
+    L.or_init_pcg32_buffer_with_seed.argtypes = [u64, u64, u64p]
+    L.or_ggx_dielectric_table_entry.restype = f32
+    L.or_ggx_dielectric_table_entry.argtypes = [u32, u32, u32, u32]
+    L.or_kat_pcg32.argtypes = [u64, u64, u32, up]
+    L.or_kat_pcg32_advance.argtypes = [u64p, u64, C.c_int64]
+    L.or_kat_pcg32_new_seq.argtypes = [u64, u64p, u64p]
+    L.or_kat_next_1d.restype = f32
+    L.or_kat_next_1d.argtypes = [u64p, u64]
+    L.or_kat_chacha_block.argtypes = [up, u64, u64, i32, up]
+    L.or_kat_stdrng_u64.argtypes = [u64, u32, u64p]
+    L.or_kat_xxhash32_4.restype = u32
+    L.or_kat_xxhash32_4.argtypes = [u32, u32, u32, u32]
+    L.or_kat_mix_bits.restype = u64
+    L.or_kat_mix_bits.argtypes = [u64]
+    L.or_kat_sincos.argtypes = [f32, fp, fp]
+    L.or_kat_log.restype = f32
+    L.or_kat_log.argtypes = [f32]
+    L.or_kat_alias_build.argtypes = [fp, u32, up, fp, fp]
+    L.or_kat_offset_ray_origin.argtypes = [fp, fp, fp]
+    L.or_kat_uniform_sample_triangle.argtypes = [f32, f32, fp]
+    L.or_kat_cos_sample_hemisphere.argtypes = [f32, f32, fp]
+    L.or_scene_num_lights.restype = u32
+    L.or_scene_num_lights.argtypes = [vp]
+    L.or_scene_num_triangles.restype = u32
+    L.or_scene_num_triangles.argtypes = [vp]
+    L.or_scene_light_info.argtypes = [vp, u32, up, fp, fp]
+    L.or_scene_camera.argtypes = [vp, fp, fp, C.POINTER(i32)]
+    L.or_scene_surface_interaction.argtypes = [vp, u32, u32, f32, f32, fp]
+    L.or_scene_intersect.restype = i32
+    L.or_scene_intersect.argtypes = [vp, fp, fp, f32, f32, up, up, fp]
+    L.or_bsdf_probe_many.argtypes = [C.POINTER(abi.MaterialDesc), fp, fp, u32, fp, fp]
+    L.or_bsdf_eval_many.argtypes = [C.POINTER(abi.MaterialDesc), fp, fp, u32, fp, fp]
+    for n in ("or_sizeof_material", "or_sizeof_config", "or_sizeof_scene_desc"):
+        getattr(L, n).restype = u32
+    assert L.or_sizeof_material() == C.sizeof(abi.MaterialDesc)
+    assert L.or_sizeof_config() == C.sizeof(abi.PtConfig)
+    assert L.or_sizeof_scene_desc() == C.sizeof(abi.SceneDesc)
+    _lib = L
+    return L
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class OracleScene:
+    def __init__(self, scene: abi.SceneData):
+        self.data = scene
+        desc, self._keep = scene.to_desc()
+        self._desc = desc
+        self.h = lib().or_scene_create(C.byref(desc))
+        self.width, self.height = scene.camera.width, scene.camera.height
+
+    def close(self):
+        if self.h:
+            lib().or_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def num_lights(self):
+        return lib().or_scene_num_lights(self.h)
+
+    def light_info(self, i):
+        inst, power, pdf = C.c_uint32(), C.c_float(), C.c_float()
+        lib().or_scene_light_info(self.h, i, C.byref(inst), C.byref(power), C.byref(pdf))
+        return inst.value, power.value, pdf.value
+
+    def surface_interaction(self, inst, prim, u, v):
+        out = np.zeros(19, dtype=np.float32)
+        lib().or_scene_surface_interaction(self.h, inst, prim, u, v, _fp(out))
+        return out
+
+    def intersect(self, o, d, tmin=0.0, tmax=1e20):
+        o = np.asarray(o, dtype=np.float32)
+        d = np.asarray(d, dtype=np.float32)
+        inst, prim = C.c_uint32(), C.c_uint32()
+        bary = np.zeros(2, dtype=np.float32)
+        hit = lib().or_scene_intersect(self.h, _fp(o), _fp(d), tmin, tmax, C.byref(inst), C.byref(prim), _fp(bary))
+        return bool(hit), inst.value, prim.value, bary
+
+    def render(self, cfg: abi.PtConfig, n_threads: int = 0, film: np.ndarray | None = None, states: np.ndarray | None = None):
+        """Returns (film f32[7*N] in the reference layout, stats dict)."""
+        N = self.width * self.height
+        if film is None:
+            film = np.zeros(7 * N, dtype=np.float32)
+        if n_threads <= 0:
+            n_threads = os.cpu_count() or 1
+        st = OrStats()
+        sp = states.ctypes.data_as(C.POINTER(C.c_uint64)) if states is not None else C.POINTER(C.c_uint64)()
+        rc = lib().or_pt_render(self.h, C.byref(cfg), _fp(film), sp, n_threads, C.byref(st))
+        assert rc == 0
+        return film, {k: getattr(st, k) for k, _ in OrStats._fields_}
+
+
+def resolve(film: np.ndarray, width: int, height: int) -> np.ndarray:
+    out = np.zeros(3 * width * height, dtype=np.float32)
+    lib().or_film_resolve(_fp(film), width, height, _fp(out))
+    return out.reshape(height, width, 3)
+
+
+def init_pcg32_states(count: int, seed: int) -> np.ndarray:
+    st = np.zeros(2 * count, dtype=np.uint64)
+    lib().or_init_pcg32_buffer_with_seed(count, seed, st.ctypes.data_as(C.POINTER(C.c_uint64)))
+    return st
+
+
+def bsdf_sample_many(m: abi.MaterialData, wo, u: np.ndarray, table: np.ndarray | None = None) -> np.ndarray:
+    ms = m.to_struct()
+    wo = np.asarray(wo, dtype=np.float32)
+    u = np.ascontiguousarray(u, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros((u.shape[0], 8), dtype=np.float32)
+    tp = _fp(np.ascontiguousarray(table, dtype=np.float32)) if table is not None else C.POINTER(C.c_float)()
+    lib().or_bsdf_probe_many(C.byref(ms), tp, _fp(wo), u.shape[0], _fp(u), _fp(out))
+    return out
+
+
+def bsdf_eval_many(m: abi.MaterialData, wo, wi: np.ndarray, table: np.ndarray | None = None) -> np.ndarray:
+    ms = m.to_struct()
+    wo = np.asarray(wo, dtype=np.float32)
+    wi = np.ascontiguousarray(wi, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros((wi.shape[0], 4), dtype=np.float32)
+    tp = _fp(np.ascontiguousarray(table, dtype=np.float32)) if table is not None else C.POINTER(C.c_float)()
+    lib().or_bsdf_eval_many(C.byref(ms), tp, _fp(wo), wi.shape[0], _fp(wi), _fp(out))
+    return out
