@@ -1,0 +1,60 @@
+"""Builds libakari_hip.so in-tree with hipcc for gfx950 (no JIT cache: the .so travels with the repo)."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libakari_hip.so")
+
+SOURCES = [
+    "pt_kernels.hip",
+    "host/api.cpp",
+    "host/scene_build.cpp",
+    "host/scene_json.cpp",
+    "host/bvh.cpp",
+]
+HEADERS = [
+    "kernels.h",
+    "device/dmath.h", "device/drng.h", "device/dgeom.h", "device/dbsdf.h", "device/dscene.h", "device/disect.h",
+    "host/scene_build.h", "host/json.h", "host/stdrng.h",
+    "../../include/akari_hip.h",
+]
+# -ffp-contract=off + correctly rounded div/sqrt: the arithmetic contract of DESIGN.md ("AKR-F32")
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+    "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
+    "-Wall", "-Wno-unused-function", "-x", "hip",
+]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    for f in SOURCES + HEADERS + ["../build.py"]:
+        p = os.path.normpath(os.path.join(CSRC, f))
+        if os.path.exists(p) and os.path.getmtime(p) > t:
+            return True
+    return False
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-I", CSRC, "-o", LIB]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout)
+    if verbose and res.stdout.strip():
+        print(res.stdout, file=sys.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

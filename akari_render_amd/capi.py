@@ -1,0 +1,412 @@
+"""ctypes binding of libakari_hip.so (the C ABI in include/akari_hip.h).
+
+This is the only way Python reaches the path tracer: there is no Python or PyTorch fallback. If the shared
+library is missing it is built with hipcc (akari_render_amd/build.py); if there is no GPU, `Context()` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import abi
+from .build import LIB, build
+
+AKR_OK = 0
+ERR_INVALID_ARGUMENT, ERR_HIP, ERR_NO_DEVICE, ERR_IO, ERR_PARSE, ERR_UNSUPPORTED, ERR_OOM = -1, -2, -3, -4, -5, -6, -7
+
+(ARRAY_WOOP, ARRAY_TRI_GID, ARRAY_SHADE, ARRAY_INSTANCES, ARRAY_MATERIALS, ARRAY_BVH_NODES, ARRAY_LIGHT_ENTRIES,
+ ARRAY_LIGHT_PDF, ARRAY_AREA_ENTRIES, ARRAY_AREA_PDF, ARRAY_INST_TRI_OFFSET, ARRAY_R2C, ARRAY_C2W) = range(13)
+
+# every symbol include/akari_hip.h declares (checked by tests/test_abi.py against the header text)
+EXPORTS = [
+    "akr_last_error", "akr_version",
+    "akr_context_create", "akr_context_destroy", "akr_context_synchronize", "akr_context_device_info",
+    "akr_scene_create", "akr_scene_load", "akr_scene_destroy", "akr_scene_set_resolution", "akr_scene_get_info",
+    "akr_scene_get_light", "akr_scene_get_ggx_table", "akr_scene_get_desc_counts", "akr_scene_get_mesh",
+    "akr_scene_get_instance", "akr_scene_get_material", "akr_scene_get_camera", "akr_scene_get_array",
+    "akr_film_create", "akr_film_wrap", "akr_film_destroy", "akr_film_clear", "akr_film_read", "akr_film_write",
+    "akr_film_resolve", "akr_film_device_ptr",
+    "akr_pt_config_default", "akr_pt_config_from_json", "akr_pt_render", "akr_pt_begin", "akr_pt_passes", "akr_pt_end",
+    "akr_pt_read_sampler_states",
+    "akr_host_stdrng_u64", "akr_host_chacha_block", "akr_host_pcg32_states", "akr_host_pcg_start", "akr_host_alias_table",
+    "akr_probe_math", "akr_probe_bsdf", "akr_probe_intersect", "akr_probe_surface_interaction",
+]
+
+
+class AkariError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"akari_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Loads (building first if needed) libakari_hip.so and declares the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        build()
+    L = C.CDLL(LIB)
+    vp, u32, u64, i32, f32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_float
+    fp, up, u64p, vpp = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p)
+    L.akr_last_error.restype = C.c_char_p
+    L.akr_version.restype = C.c_char_p
+
+    def proto(name, *args):
+        fn = getattr(L, name)
+        fn.restype = i32
+        fn.argtypes = list(args)
+
+    proto("akr_context_create", i32, vpp)
+    proto("akr_context_destroy", vp)
+    proto("akr_context_synchronize", vp)
+    proto("akr_context_device_info", vp, C.c_char_p, u32, up, u64p)
+    proto("akr_scene_create", vp, C.POINTER(abi.SceneDesc), vpp)
+    proto("akr_scene_load", vp, C.c_char_p, u32, u32, vpp)
+    proto("akr_scene_destroy", vp)
+    proto("akr_scene_set_resolution", vp, u32, u32)
+    proto("akr_scene_get_info", vp, C.POINTER(abi.SceneInfo))
+    proto("akr_scene_get_light", vp, u32, up, fp, fp)
+    proto("akr_scene_get_ggx_table", vp, fp)
+    proto("akr_scene_get_desc_counts", vp, up, up, up)
+    proto("akr_scene_get_mesh", vp, u32, C.POINTER(abi.MeshDesc))
+    proto("akr_scene_get_instance", vp, u32, C.POINTER(abi.InstanceDesc))
+    proto("akr_scene_get_material", vp, u32, C.POINTER(abi.MaterialDesc))
+    proto("akr_scene_get_camera", vp, C.POINTER(abi.CameraDesc))
+    proto("akr_scene_get_array", vp, i32, vpp, u64p)
+    proto("akr_film_create", vp, u32, u32, vpp)
+    proto("akr_film_wrap", vp, u32, u32, vp, vpp)
+    proto("akr_film_destroy", vp)
+    proto("akr_film_clear", vp)
+    proto("akr_film_read", vp, fp)
+    proto("akr_film_write", vp, fp)
+    proto("akr_film_resolve", vp, fp)
+    proto("akr_film_device_ptr", vp, vpp, u64p)
+    proto("akr_pt_config_default", C.POINTER(abi.PtConfig))
+    proto("akr_pt_config_from_json", C.c_char_p, C.POINTER(abi.PtConfig), C.c_char_p, u32)
+    proto("akr_pt_render", vp, vp, C.POINTER(abi.PtConfig), vp, C.POINTER(abi.PtStats))
+    proto("akr_pt_begin", vp, vp, C.POINTER(abi.PtConfig), vp, vpp)
+    proto("akr_pt_passes", vp, u32, i32, up)
+    proto("akr_pt_end", vp, C.POINTER(abi.PtStats))
+    proto("akr_pt_read_sampler_states", vp, u64p)
+    proto("akr_host_stdrng_u64", u64, u32, u64p)
+    proto("akr_host_chacha_block", up, u64, u64, i32, up)
+    proto("akr_host_pcg32_states", u64, u64, u64p)
+    proto("akr_host_pcg_start", u64p, u64)
+    proto("akr_host_alias_table", fp, u32, up, fp, fp)
+    proto("akr_probe_math", vp, u32, fp, fp, fp, fp)
+    proto("akr_probe_bsdf", vp, C.POINTER(abi.MaterialDesc), fp, i32, fp, u32, fp, fp)
+    proto("akr_probe_intersect", vp, vp, u32, fp, up, fp)
+    proto("akr_probe_surface_interaction", vp, vp, u32, up, fp, fp)
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != AKR_OK:
+        raise AkariError(rc, lib().akr_last_error().decode("utf-8", "replace"))
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _up(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+class Context:
+    """akr_context: one HIP device + stream. Raises AkariError(ERR_NO_DEVICE) without a GPU."""
+
+    def __init__(self, device: int = 0):
+        self.h = C.c_void_p()
+        check(lib().akr_context_create(device, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().akr_context_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(lib().akr_context_synchronize(self.h))
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, mem = C.c_uint32(), C.c_uint64()
+        check(lib().akr_context_device_info(self.h, name, 256, C.byref(cus), C.byref(mem)))
+        return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": mem.value}
+
+
+class Scene:
+    """akr_scene. ctx=None compiles on the host only (inspectable, not renderable)."""
+
+    def __init__(self, ctx: Optional[Context], source, width: int = 0, height: int = 0):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        ch = ctx.h if ctx is not None else C.c_void_p()
+        if isinstance(source, (str, os.PathLike)):
+            check(lib().akr_scene_load(ch, os.fspath(source).encode(), width, height, C.byref(self.h)))
+        else:
+            desc, keep = source.to_desc()
+            if width and height:
+                desc.camera.width, desc.camera.height = width, height
+            check(lib().akr_scene_create(ch, C.byref(desc), C.byref(self.h)))
+            del keep
+
+    def close(self):
+        if self.h:
+            lib().akr_scene_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self) -> abi.SceneInfo:
+        i = abi.SceneInfo()
+        check(lib().akr_scene_get_info(self.h, C.byref(i)))
+        return i
+
+    def set_resolution(self, w: int, h: int):
+        check(lib().akr_scene_set_resolution(self.h, w, h))
+
+    def light(self, i: int):
+        inst, power, pdf = C.c_uint32(), C.c_float(), C.c_float()
+        check(lib().akr_scene_get_light(self.h, i, C.byref(inst), C.byref(power), C.byref(pdf)))
+        return inst.value, power.value, pdf.value
+
+    def ggx_table(self) -> np.ndarray:
+        t = np.zeros(4096, dtype=np.float32)
+        check(lib().akr_scene_get_ggx_table(self.h, _fp(t)))
+        return t
+
+    def array(self, which: int, dtype) -> np.ndarray:
+        p, n = C.c_void_p(), C.c_uint64()
+        check(lib().akr_scene_get_array(self.h, which, C.byref(p), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, dtype=dtype)
+        buf = (C.c_char * n.value).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype).copy()
+
+    def to_scene_data(self) -> abi.SceneData:
+        """The flattened description the library holds (what akr_scene_load produced)."""
+        nm, ni, nmat = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(lib().akr_scene_get_desc_counts(self.h, C.byref(nm), C.byref(ni), C.byref(nmat)))
+        meshes, instances, materials = [], [], []
+
+        def arr(ptr, n, dtype):
+            if not ptr or n == 0:
+                return None
+            return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+
+        for i in range(nm.value):
+            m = abi.MeshDesc()
+            check(lib().akr_scene_get_mesh(self.h, i, C.byref(m)))
+            nt = m.n_triangles
+            uv = arr(m.uvs, 6 * nt, np.float32)
+            nr = arr(m.normals, 9 * nt, np.float32)
+            tg = arr(m.tangents, 9 * nt, np.float32)
+            meshes.append(abi.MeshData(
+                vertices=arr(m.vertices, 3 * m.n_vertices, np.float32).reshape(-1, 3),
+                indices=arr(m.indices, 3 * nt, np.uint32).reshape(-1, 3),
+                uvs=None if uv is None else uv.reshape(-1, 3, 2),
+                normals=None if nr is None else nr.reshape(-1, 3, 3),
+                tangents=None if tg is None else tg.reshape(-1, 3, 3),
+                material_slots=arr(m.material_slots, nt, np.uint32)))
+        for i in range(ni.value):
+            d = abi.InstanceDesc()
+            check(lib().akr_scene_get_instance(self.h, i, C.byref(d)))
+            instances.append(abi.InstanceData(d.mesh, [int(d.materials[k]) for k in range(d.n_materials)],
+                                              np.array(list(d.transform), dtype=np.float32)))
+        for i in range(nmat.value):
+            d = abi.MaterialDesc()
+            check(lib().akr_scene_get_material(self.h, i, C.byref(d)))
+            md = abi.MaterialData()
+            md.kind = d.kind
+            for name in ("base_color", "specular_tint", "coat_tint", "emission_color", "normal"):
+                setattr(md, name, tuple(float(x) for x in getattr(d, name)))
+            for name in ("base_alpha", "metallic", "roughness", "ior", "specular_ior_level", "transmission_weight",
+                         "coat_weight", "coat_roughness", "coat_ior", "emission_strength"):
+                setattr(md, name, float(getattr(d, name)))
+            materials.append(md)
+        c = abi.CameraDesc()
+        check(lib().akr_scene_get_camera(self.h, C.byref(c)))
+        cam = abi.CameraData(np.array(list(c.c2w), dtype=np.float32), float(c.fov), c.width, c.height)
+        return abi.SceneData(meshes, instances, materials, cam)
+
+
+class Film:
+    """akr_film: f32[7*W*H] on the device in the reference layout [rgb*N | splat*N | weight*N]."""
+
+    def __init__(self, ctx: Context, width: int, height: int, device_ptr: Optional[int] = None):
+        self.ctx, self.width, self.height = ctx, width, height
+        self.h = C.c_void_p()
+        if device_ptr is None:
+            check(lib().akr_film_create(ctx.h, width, height, C.byref(self.h)))
+        else:
+            check(lib().akr_film_wrap(ctx.h, width, height, C.c_void_p(device_ptr), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().akr_film_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def clear(self):
+        check(lib().akr_film_clear(self.h))
+
+    def read(self) -> np.ndarray:
+        out = np.zeros(7 * self.width * self.height, dtype=np.float32)
+        check(lib().akr_film_read(self.h, _fp(out)))
+        return out
+
+    def write(self, data: np.ndarray):
+        data = np.ascontiguousarray(data, dtype=np.float32)
+        assert data.size == 7 * self.width * self.height
+        check(lib().akr_film_write(self.h, _fp(data)))
+
+    def resolve(self) -> np.ndarray:
+        out = np.zeros(3 * self.width * self.height, dtype=np.float32)
+        check(lib().akr_film_resolve(self.h, _fp(out)))
+        return out.reshape(self.height, self.width, 3)
+
+    def device_ptr(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        check(lib().akr_film_device_ptr(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+
+class PtSession:
+    """akr_pt_begin / akr_pt_passes / akr_pt_end (the reference's `while cnt < spp` loop, pt.rs:1126-1149)."""
+
+    def __init__(self, ctx: Context, scene: Scene, cfg: abi.PtConfig, film: Film):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        self._cfg = cfg.copy()
+        check(lib().akr_pt_begin(ctx.h, scene.h, C.byref(self._cfg), film.h, C.byref(self.h)))
+
+    def passes(self, n: int = 1, blocking: bool = False) -> int:
+        done = C.c_uint32()
+        check(lib().akr_pt_passes(self.h, n, 1 if blocking else 0, C.byref(done)))
+        return done.value
+
+    def sampler_states(self, n_pixels: int) -> np.ndarray:
+        st = np.zeros(2 * n_pixels, dtype=np.uint64)
+        check(lib().akr_pt_read_sampler_states(self.h, st.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return st
+
+    def end(self) -> dict:
+        st = abi.PtStats()
+        h, self.h = self.h, C.c_void_p()
+        check(lib().akr_pt_end(h, C.byref(st)))
+        return st.as_dict()
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().akr_pt_end(self.h, None)
+        except Exception:
+            pass
+
+
+def pt_render(ctx: Context, scene: Scene, cfg: abi.PtConfig, film: Film) -> dict:
+    """pt::render (pt.rs:1161-1172): all passes, blocking; returns the device counters."""
+    st = abi.PtStats()
+    c = cfg.copy()
+    check(lib().akr_pt_render(ctx.h, scene.h, C.byref(c), film.h, C.byref(st)))
+    return st.as_dict()
+
+
+def config_from_json(text: str):
+    cfg = abi.PtConfig()
+    out = C.create_string_buffer(1024)
+    check(lib().akr_pt_config_from_json(text.encode(), C.byref(cfg), out, 1024))
+    return cfg, out.value.decode()
+
+
+# ---- host-side known-answer hooks -------------------------------------------------------------------------
+def host_stdrng_u64(seed: int, n: int) -> np.ndarray:
+    out = np.zeros(n, dtype=np.uint64)
+    check(lib().akr_host_stdrng_u64(seed, n, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+    return out
+
+
+def host_chacha_block(key, counter: int, stream: int, rounds: int) -> np.ndarray:
+    key = np.ascontiguousarray(key, dtype=np.uint32)
+    out = np.zeros(16, dtype=np.uint32)
+    check(lib().akr_host_chacha_block(_up(key), counter, stream, rounds, _up(out)))
+    return out
+
+
+def host_pcg32_states(seed: int, n: int) -> np.ndarray:
+    out = np.zeros(2 * n, dtype=np.uint64)
+    check(lib().akr_host_pcg32_states(seed, n, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+    return out
+
+
+def host_pcg_start(state: int, inc: int) -> int:
+    s = C.c_uint64(state)
+    check(lib().akr_host_pcg_start(C.byref(s), inc))
+    return s.value
+
+
+def host_alias_table(weights):
+    w = np.ascontiguousarray(weights, dtype=np.float32)
+    j = np.zeros(w.size, dtype=np.uint32)
+    t = np.zeros(w.size, dtype=np.float32)
+    pdf = np.zeros(w.size, dtype=np.float32)
+    check(lib().akr_host_alias_table(_fp(w), w.size, _up(j), _fp(t), _fp(pdf)))
+    return j, t, pdf
+
+
+# ---- device probes ------------------------------------------------------------------------------------------
+def probe_math(ctx: Context, x: np.ndarray):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    s, c, l = (np.zeros_like(x) for _ in range(3))
+    check(lib().akr_probe_math(ctx.h, x.size, _fp(x), _fp(s), _fp(c), _fp(l)))
+    return s, c, l
+
+
+def probe_bsdf(ctx: Context, m: abi.MaterialData, mode: int, wo, data: np.ndarray, table: Optional[np.ndarray] = None) -> np.ndarray:
+    ms = m.to_struct()
+    wo = np.ascontiguousarray(wo, dtype=np.float32)
+    data = np.ascontiguousarray(data, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros((data.shape[0], 4 if mode == 0 else 8), dtype=np.float32)
+    tp = _fp(np.ascontiguousarray(table, dtype=np.float32)) if table is not None else C.POINTER(C.c_float)()
+    check(lib().akr_probe_bsdf(ctx.h, C.byref(ms), tp, mode, _fp(wo), data.shape[0], _fp(data), _fp(out)))
+    return out
+
+
+def probe_intersect(ctx: Context, scene: Scene, rays: np.ndarray):
+    rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+    out = np.zeros((rays.shape[0], 3), dtype=np.uint32)
+    bary = np.zeros((rays.shape[0], 2), dtype=np.float32)
+    check(lib().akr_probe_intersect(ctx.h, scene.h, rays.shape[0], _fp(rays), _up(out), _fp(bary)))
+    return out, bary
+
+
+def probe_surface_interaction(ctx: Context, scene: Scene, inst_prim: np.ndarray, bary: np.ndarray) -> np.ndarray:
+    ip = np.ascontiguousarray(inst_prim, dtype=np.uint32).reshape(-1, 2)
+    b = np.ascontiguousarray(bary, dtype=np.float32).reshape(-1, 2)
+    out = np.zeros((ip.shape[0], 19), dtype=np.float32)
+    check(lib().akr_probe_surface_interaction(ctx.h, scene.h, ip.shape[0], _up(ip), _fp(b), _fp(out)))
+    return out

@@ -1,0 +1,489 @@
+// dbsdf.h -- BSDF evaluation / sampling of the HIP path tracer.
+//
+// The reference builds, per shading point, a tree of `Rc<dyn Surface>` closures and walks it three times
+// (crates/akari_render/src/svm/surface/{mod,principled,diffuse,glass}.rs, microfacet.rs). Here every
+// material's constant inputs are folded on the host into one DMaterial record (host/scene_build.cpp) and the
+// tree is evaluated as straight-line code; lobes whose weight is exactly zero for the whole material are
+// skipped through per-material flags (bit-identical as long as the skipped lobe is finite).
+// file:line references are to the reference tree the arithmetic follows.
+#pragma once
+#include "dgeom.h"
+
+namespace akr {
+
+enum : uint32_t {
+    MF_SPEC = 1u << 0,        // specular layer present: f0 != 0                       (principled.rs:55-83)
+    MF_COAT = 1u << 1,        // coat_weight != 0                                      (principled.rs:84-100)
+    MF_EVAL_BASE = 1u << 2,   // Mix(metallic) evaluates its `a` side: metallic < 1 - 1e-4   (mod.rs:611-615)
+    MF_EVAL_METAL = 1u << 3,  // Mix(metallic) evaluates its `b` side: metallic > 1e-4
+    MF_EVAL_DIFF = 1u << 4,   // Mix(transmission) evaluates diffuse: transmission < 1 - 1e-4
+    MF_EVAL_DIEL = 1u << 5,   // Mix(transmission) evaluates the dielectric: transmission > 1e-4
+    MF_NORMAL_MAP = 1u << 6,  // principled `normal` socket is non-zero                 (mod.rs:1380-1417)
+    MF_EMISSIVE = 1u << 7,    // emission != 0
+};
+
+enum : uint32_t { MAT_PRINCIPLED = 0, MAT_DIFFUSE = 1, MAT_GLASS = 2, MAT_EMISSION = 3 };
+
+// One folded material. 64 x 4 B = 256 B, 16-byte aligned rows.
+struct alignas(16) DMaterial {
+    uint32_t kind, flags;
+    float base_alpha, metallic;
+    vec3 color;               float transmission;
+    vec3 diffuse_refl;        float eta;            // color * FRAC_1_PI            (principled.rs:39-41)
+    vec3 transmission_color;  float f0;             // sqrt(color)                  (principled.rs:25)
+    vec3 emission;            float eta_s;          // emission_color * strength    (principled.rs:29-30)
+    vec3 spec_color;          float roughness;      // specular_tint * f0           (principled.rs:71)
+    vec3 spec_tint;           float coat_weight;
+    vec3 coat_scale;          float coat_roughness; // lerp(1, coat_tint, coat_weight) (principled.rs:195-198)
+    vec3 metal_n;             float coat_eta;
+    vec3 metal_k;             float _pad0;
+    vec2 alpha;               vec2 coat_alpha;      // max(roughness^2, 1e-4)       (microfacet.rs:29-43)
+    vec3 nm_normal;           float _pad1;          // normalize((-nx, -ny, nz))
+    float _pad2[16];
+};
+static_assert(sizeof(DMaterial) == 256, "DMaterial layout");
+
+struct BsdfEval {
+    vec3 f;
+    float pdf;
+};
+
+// ---- Frame trig (geometry.rs:80-151); the reference's cos_phi uses w.y and sin_phi uses w.x ----
+AKR_HD float cos_theta(vec3 w) { return w.z; }
+AKR_HD float cos2_theta(vec3 w) { return w.z * w.z; }
+AKR_HD float abs_cos_theta(vec3 w) { return abs_f(w.z); }
+AKR_HD float sin2_theta(vec3 w) { return max_f(1.0f - cos2_theta(w), 0.0f); }
+AKR_HD float sin_theta(vec3 w) { return __builtin_sqrtf(max_f(1.0f - cos2_theta(w), 0.0f)); }
+AKR_HD float tan2_theta(vec3 w) { return sin2_theta(w) / cos2_theta(w); }
+AKR_HD float tan_theta(vec3 w) { return sin_theta(w) / cos_theta(w); }
+AKR_HD float sin_phi(vec3 w) {
+    float st = sin_theta(w);
+    return st == 0.0f ? 0.0f : clamp_f(w.x / st, -1.0f, 1.0f);
+}
+AKR_HD float cos_phi(vec3 w) {
+    float st = sin_theta(w);
+    return st == 0.0f ? 1.0f : clamp_f(w.y / st, -1.0f, 1.0f);
+}
+AKR_HD bool same_hemisphere(vec3 a, vec3 b) { return (a.z * b.z) >= 0.0f; }
+
+// ---- Trowbridge-Reitz (microfacet.rs:45-66, 117-138, 196-206) ----
+AKR_HD float tr_d(vec3 wh, vec2 alpha) {
+    float tan2 = tan2_theta(wh);
+    float cos4 = sqr(cos2_theta(wh));
+    float e = tan2 * (sqr(cos_phi(wh) / alpha.x) + sqr(sin_phi(wh) / alpha.y));
+    float inv_d = kPi * alpha.x * alpha.y * cos4 * sqr(1.0f + e);
+    if (!is_finite(tan2) || !is_finite(inv_d) || inv_d == 0.0f) return 0.0f;
+    return 1.0f / inv_d;
+}
+AKR_HD float tr_lambda(vec3 w, vec2 alpha) {
+    float abs_tan = abs_f(tan_theta(w));
+    float alpha2 = sqr(cos_phi(w)) * sqr(alpha.x) + sqr(sin_phi(w)) * sqr(alpha.y);
+    float a2t2 = alpha2 * sqr(abs_tan);
+    float l = (-1.0f + __builtin_sqrtf(1.0f + a2t2)) * 0.5f;
+    return !is_finite(abs_tan) ? 0.0f : l;
+}
+AKR_HD float tr_g1(vec3 w, vec2 alpha) { return 1.0f / (1.0f + tr_lambda(w, alpha)); }
+AKR_HD float tr_g(vec3 wo, vec3 wi, vec2 alpha) { return 1.0f / (1.0f + tr_lambda(wo, alpha) + tr_lambda(wi, alpha)); }
+AKR_HD vec3 tr_sample_wh(vec3 w, vec2 u, vec2 alpha) {  // visible-normal sampling, Heitz 2018
+    vec3 wh = normalize(mk3(alpha.x * w.x, alpha.y * w.y, w.z));
+    if (wh.z < 0.0f) wh = -wh;
+    vec3 t1 = (wh.z < 0.99999f) ? normalize(cross(mk3(0, 0, 1), wh)) : mk3(1, 0, 0);
+    vec3 t2 = normalize(cross(wh, t1));
+    vec2 p = uniform_sample_disk(u);
+    float h = __builtin_sqrtf(1.0f - sqr(p.x));
+    p.y = lerp_f(h, p.y, (1.0f + wh.z) * 0.5f);
+    float pz = __builtin_sqrtf(max_f(1.0f - (p.x * p.x + p.y * p.y), 0.0f));
+    vec3 nh = (t1 * p.x + t2 * p.y) + wh * pz;
+    return normalize(mk3(alpha.x * nh.x, alpha.y * nh.y, max_f(nh.z, 1e-6f)));
+}
+AKR_HD float tr_pdf(vec3 wo, vec3 wh, vec2 alpha) {
+    return tr_d(wh, alpha) * tr_g1(wo, alpha) * abs_f(dot(wo, wh)) / abs_cos_theta(wo);
+}
+
+// ---- Fresnel (svm/surface/mod.rs:1009-1098) ----
+AKR_HD float fr_dielectric(float cos_i, float eta) {
+    cos_i = clamp_f(cos_i, -1.0f, 1.0f);
+    eta = cos_i > 0.0f ? eta : 1.0f / eta;
+    cos_i = abs_f(cos_i);
+    float sin2_i = 1.0f - sqr(cos_i);
+    float sin2_t = sin2_i / sqr(eta);
+    if (sin2_t >= 1.0f) return 1.0f;
+    float cos_t = __builtin_sqrtf(max_f(1.0f - sin2_t, 0.0f));
+    float r_parl = (eta * cos_i - cos_t) / (eta * cos_i + cos_t);
+    float r_perp = (cos_i - eta * cos_t) / (cos_i + eta * cos_t);
+    float fr = (sqr(r_parl) + sqr(r_perp)) * 0.5f;
+    return clamp_f(fr, 0.0f, 1.0f);
+}
+struct Cplx {  // util/mod.rs:517-604
+    float re, im;
+};
+AKR_HD Cplx cx(float re, float im) { return Cplx{re, im}; }
+AKR_HD float cx_norm(Cplx a) { return a.re * a.re + a.im * a.im; }
+AKR_HD Cplx cx_add(Cplx a, Cplx b) { return cx(a.re + b.re, a.im + b.im); }
+AKR_HD Cplx cx_sub(Cplx a, Cplx b) { return cx(a.re - b.re, a.im - b.im); }
+AKR_HD Cplx cx_mul(Cplx a, Cplx b) { return cx(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+AKR_HD Cplx cx_muls(Cplx a, float s) { return cx(a.re * s, a.im * s); }
+AKR_HD Cplx cx_div(Cplx a, Cplx b) {
+    float scale = 1.0f / (b.re * b.re + b.im * b.im);
+    return cx((a.re * b.re + a.im * b.im) * scale, (a.im * b.re - a.re * b.im) * scale);
+}
+AKR_HD Cplx cx_sqrt(Cplx a) {
+    float n = __builtin_sqrtf(cx_norm(a));
+    float t1 = __builtin_sqrtf(0.5f * (n + abs_f(a.re)));
+    float t2 = 0.5f * a.im / t1;
+    if (n == 0.0f) return cx(0.0f, 0.0f);
+    if (a.re >= 0.0f) return cx(t1, t2);
+    return cx(abs_f(t2), __builtin_copysignf(t1, a.im));
+}
+AKR_HD float fr_complex(float cos_i, Cplx eta) {
+    cos_i = clamp_f(cos_i, 0.0f, 0.999f);
+    float sin2 = 1.0f - sqr(cos_i);
+    Cplx sin2_t = cx_div(cx(sin2, 0.0f), cx_mul(eta, eta));
+    Cplx cos_t = cx_sqrt(cx_sub(cx(1.0f, 0.0f), sin2_t));
+    Cplx r_parl = cx_div(cx_sub(cx_muls(eta, cos_i), cos_t), cx_add(cx_muls(eta, cos_i), cos_t));
+    Cplx r_perp = cx_div(cx_sub(cx(cos_i, 0.0f), cx_mul(eta, cos_t)), cx_add(cx(cos_i, 0.0f), cx_mul(eta, cos_t)));
+    return (cx_norm(r_parl) + cx_norm(r_perp)) * 0.5f;
+}
+AKR_HD void artistic_to_conductor(vec3 color, vec3 tint, vec3& n_out, vec3& k_out) {  // Gulbrandsen, mod.rs:1040-1052
+    float rr[3] = {clamp_f(color.x, 0.0f, 0.99f), clamp_f(color.y, 0.0f, 0.99f), clamp_f(color.z, 0.0f, 0.99f)};
+    float g[3] = {tint.x, tint.y, tint.z};
+    float n[3], k[3];
+    for (int i = 0; i < 3; i++) {
+        float r = rr[i];
+        float r_sqrt = __builtin_sqrtf(r);
+        float n_min = (1.0f - r) / (1.0f + r);
+        float n_max = (1.0f + r_sqrt) / (1.0f - r_sqrt);
+        n[i] = lerp_f(n_max, n_min, g[i]);
+        float k2 = ((n[i] + 1.0f) * (n[i] + 1.0f) * r - (n[i] - 1.0f) * (n[i] - 1.0f)) / (1.0f - r);
+        k2 = max_f(k2, 0.0f);
+        k[i] = __builtin_sqrtf(k2);
+    }
+    n_out = mk3(n[0], n[1], n[2]);
+    k_out = mk3(k[0], k[1], k[2]);
+}
+AKR_HD float ior_from_f0(float f0) {
+    float s = __builtin_sqrtf(clamp_f(f0, 0.0f, 0.99f));
+    return (1.0f + s) / (1.0f - s);
+}
+AKR_HD float f0_from_ior(float ior) {
+    float f0 = (ior - 1.0f) / (ior + 1.0f);
+    return sqr(f0);
+}
+
+// ---- ggx_dielectric_s table lookup (svm/surface/mod.rs:1145-1154, 1211-1261), 16 x 16 x 16 ----
+AKR_HD float table_read_1d(const float* __restrict__ buf, float x, uint32_t offset, uint32_t size) {
+    x = clamp_f(x, 0.0f, 1.0f) * ((float)size - 1.0f);
+    uint32_t index = (uint32_t)__builtin_floorf(x);
+    uint32_t nindex = index + 1 < size - 1 ? index + 1 : size - 1;
+    float t = x - (float)index;
+    return (1.0f - t) * buf[offset + index] + t * buf[offset + nindex];
+}
+AKR_HD float table_read_2d(const float* __restrict__ buf, float x, float y, uint32_t offset, uint32_t xs, uint32_t ys) {
+    y = clamp_f(y, 0.0f, 1.0f) * ((float)ys - 1.0f);
+    uint32_t index = (uint32_t)__builtin_floorf(y);
+    uint32_t nindex = index + 1 < ys - 1 ? index + 1 : ys - 1;
+    float t = y - (float)index;
+    float d0 = table_read_1d(buf, x, offset + xs * index, xs);
+    float d1 = table_read_1d(buf, x, offset + xs * nindex, xs);
+    return (1.0f - t) * d0 + t * d1;
+}
+AKR_HD float table_read_3d(const float* __restrict__ buf, float x, float y, float z) {
+    const uint32_t xs = 16, ys = 16, zs = 16;
+    z = clamp_f(z, 0.0f, 1.0f) * ((float)zs - 1.0f);
+    uint32_t index = (uint32_t)__builtin_floorf(z);
+    uint32_t nindex = index + 1 < zs - 1 ? index + 1 : zs - 1;
+    float t = z - (float)index;
+    float d0 = table_read_2d(buf, x, y, xs * ys * index, xs, ys);
+    float d1 = table_read_2d(buf, x, y, xs * ys * nindex, xs, ys);
+    return (1.0f - t) * d0 + t * d1;
+}
+AKR_HD float ggx_dielectric_albedo(const float* __restrict__ table, float roughness, float cos_i, float eta) {
+    float z = __builtin_sqrtf(abs_f((eta - 1.0f) / (eta + 1.0f)));
+    cos_i = abs_f(clamp_f(cos_i, -0.999f, 0.999f));
+    return table_read_3d(table, roughness, abs_f(cos_i), z);
+}
+
+// ---- lobes, in local shading space (z = normal) ----
+enum FresnelKind { FR_DIELECTRIC = 0, FR_COMPLEX = 1 };
+
+AKR_HD BsdfEval eval_diffuse(vec3 reflectance, vec3 wo, vec3 wi) {  // diffuse.rs:22-38
+    BsdfEval r{mk3(0, 0, 0), 0.0f};
+    if (same_hemisphere(wo, wi)) {
+        r.pdf = abs_cos_theta(wi) * kInvPi;
+        r.f = reflectance * abs_cos_theta(wi);
+    }
+    return r;
+}
+// MicrofacetReflection::evaluate_impl, svm/surface/mod.rs:831-858
+template <FresnelKind FK>
+AKR_HD BsdfEval eval_reflection(vec3 color, float eta, vec3 fn, vec3 fk, vec2 alpha, vec3 wo, vec3 wi) {
+    BsdfEval r{mk3(0, 0, 0), 0.0f};
+    vec3 wh = wo + wi;
+    float cos_o = cos_theta(wo), cos_i = cos_theta(wi);
+    if ((dot(wh, wo) * dot(wi, wh)) < 0.0f || (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) || cos_i == 0.0f ||
+        cos_o == 0.0f || !same_hemisphere(wo, wi))
+        return r;
+    wh = normalize(wh);
+    float c = dot(wi, face_forward(wh, mk3(0, 0, 1)));
+    vec3 fr;
+    if (FK == FR_DIELECTRIC) {
+        float f = fr_dielectric(c, eta);
+        fr = mk3(1.0f * f, 1.0f * f, 1.0f * f);
+    } else {
+        float ca = abs_f(c);  // FresnelComplex::evaluate passes |cos| (mod.rs:1181-1184)
+        fr = mk3(fr_complex(ca, cx(fn.x, fk.x)), fr_complex(ca, cx(fn.y, fk.y)), fr_complex(ca, cx(fn.z, fk.z)));
+    }
+    float d = tr_d(wh, alpha);
+    float g = tr_g(wo, wi, alpha);
+    float k = abs_f(0.25f * d * g / (cos_i * cos_o));
+    r.f = ((color * fr) * k) * abs_f(cos_i);
+    r.pdf = tr_pdf(wo, wh, alpha) / (4.0f * abs_f(dot(wo, wh)));
+    return r;
+}
+// MicrofacetTransmission::evaluate_impl, svm/surface/mod.rs:914-967 (Fresnel is always dielectric here)
+AKR_HD BsdfEval eval_transmission(vec3 color, float eta_mat, vec2 alpha, vec3 wo, vec3 wi) {
+    BsdfEval r{mk3(0, 0, 0), 0.0f};
+    float cos_o = cos_theta(wo), cos_i = cos_theta(wi);
+    float eta = cos_o > 0.0f ? eta_mat : 1.0f / eta_mat;
+    vec3 wh = normalize(wo + wi * eta);
+    wh = face_forward(wh, mk3(0, 0, 1));
+    bool backfacing = (dot(wh, wi) * cos_i) < 0.0f || (dot(wh, wo) * cos_o) < 0.0f;
+    if ((dot(wh, wo) * dot(wi, wh)) > 0.0f || cos_i == 0.0f || cos_o == 0.0f || backfacing || same_hemisphere(wo, wi)) return r;
+    float f = fr_dielectric(dot(wo, wh), eta_mat);
+    vec3 fr = mk3(1.0f * f, 1.0f * f, 1.0f * f);
+    float denom = sqr(dot(wi, wh) + dot(wo, wh) / eta) * cos_i * cos_o;
+    if (denom == 0.0f) {
+        r.f = mk3(0, 0, 0);
+    } else {
+        float k = abs_f(tr_d(wh, alpha) * tr_g(wo, wi, alpha) / sqr(eta) * abs_f(dot(wi, wh)) * abs_f(dot(wo, wh)) / denom);
+        vec3 omf = mk3(1.0f - fr.x, 1.0f - fr.y, 1.0f - fr.z);
+        r.f = ((omf * color) * k) * abs_f(cos_i);
+    }
+    float denom2 = sqr(dot(wi, wh) + dot(wo, wh) / eta);
+    float dwh_dwi = abs_f(dot(wi, wh)) / denom2;
+    r.pdf = denom2 == 0.0f ? 0.0f : tr_pdf(wo, wh, alpha) * dwh_dwi;
+    return r;
+}
+// BsdfMixture{Addictive, frac = fr_dielectric(cos wo, eta), a = transmission(kt), b = reflection(kr)}:
+// the `dielectric` of principled.rs:101-131 and the whole of glass.rs:13-45
+AKR_HD BsdfEval eval_dielectric(vec3 kr, vec3 kt, float eta, vec2 alpha, vec3 wo, vec3 wi) {
+    float frac = fr_dielectric(cos_theta(wo), eta);
+    BsdfEval a = eval_transmission(kt, eta, alpha, wo, wi);
+    BsdfEval b = eval_reflection<FR_DIELECTRIC>(kr, eta, mk3(0, 0, 0), mk3(0, 0, 0), alpha, wo, wi);
+    return BsdfEval{a.f + b.f, lerp_f(a.pdf, b.pdf, frac)};
+}
+
+// CoatedBsdf.e_top(w) of the specular layer / of the coat (principled.rs:158-162, 188-193)
+AKR_HD vec3 etop_spec(const DMaterial& m, const float* __restrict__ table, vec3 w) {
+    float albedo = ggx_dielectric_albedo(table, m.roughness, abs_cos_theta(w), m.eta_s);
+    return (m.spec_tint * albedo) * m.f0;
+}
+AKR_HD vec3 etop_coat(const DMaterial& m, const float* __restrict__ table, vec3 w) {
+    float albedo = ggx_dielectric_albedo(table, m.coat_roughness, abs_cos_theta(w), m.coat_eta);
+    return (mk3(1, 1, 1) * albedo) * m.coat_weight;
+}
+AKR_HD float avg3(vec3 e) { return ((e.x + e.y) + e.z) / 3.0f; }
+
+// The Principled closure tree of principled.rs:133-202 (inside the wrapper), evaluated for (wo, wi).
+AKR_HD BsdfEval principled_eval(const DMaterial& m, const float* __restrict__ table, vec3 wo, vec3 wi) {
+    const uint32_t fl = m.flags;
+    BsdfEval b2{mk3(0, 0, 0), 0.0f};
+    if (fl & MF_EVAL_BASE) {
+        // Mix(transmission){diffuse, dielectric}
+        BsdfEval a{mk3(0, 0, 0), 0.0f}, b{mk3(0, 0, 0), 0.0f};
+        if (fl & MF_EVAL_DIFF) a = eval_diffuse(m.diffuse_refl, wo, wi);
+        if (fl & MF_EVAL_DIEL) b = eval_dielectric(m.color, m.transmission_color, m.eta, m.alpha, wo, wi);
+        BsdfEval b1{lerp3(a.f, b.f, m.transmission), lerp_f(a.pdf, b.pdf, m.transmission)};
+        // Coated{top: specular, bottom: b1}
+        if (fl & MF_SPEC) {
+            BsdfEval top = eval_reflection<FR_DIELECTRIC>(m.spec_color, m.eta_s, mk3(0, 0, 0), mk3(0, 0, 0), m.alpha, wo, wi);
+            vec3 eo = etop_spec(m, table, wo), ei = etop_spec(m, table, wi);
+            float ps_top = avg3(eo);
+            float ps_bottom = 1.0f - ps_top;
+            b2.pdf = top.pdf * ps_top + b1.pdf * ps_bottom;
+            vec3 mn = mk3(min_f(1.0f - eo.x, 1.0f - ei.x), min_f(1.0f - eo.y, 1.0f - ei.y), min_f(1.0f - eo.z, 1.0f - ei.z));
+            b2.f = top.f + b1.f * mn;
+        } else {
+            b2 = b1;
+        }
+    }
+    // Mix(metallic){b2, metal}
+    BsdfEval mt{mk3(0, 0, 0), 0.0f};
+    if (fl & MF_EVAL_METAL) mt = eval_reflection<FR_COMPLEX>(mk3(1, 1, 1), 0.0f, m.metal_n, m.metal_k, m.alpha, wo, wi);
+    BsdfEval b3{lerp3(b2.f, mt.f, m.metallic), lerp_f(b2.pdf, mt.pdf, m.metallic)};
+    // Emissive{b3} passes through; Scaled{lerp(1, coat_tint, coat_weight)}
+    BsdfEval sc{b3.f * m.coat_scale, b3.pdf};
+    if (!(fl & MF_COAT)) return sc;
+    // Coated{top: coat, bottom: scaled}
+    BsdfEval top = eval_reflection<FR_DIELECTRIC>(splat3(1.0f) * m.coat_weight, m.coat_eta, mk3(0, 0, 0), mk3(0, 0, 0), m.coat_alpha, wo, wi);
+    vec3 eo = etop_coat(m, table, wo), ei = etop_coat(m, table, wi);
+    float ps_top = avg3(eo);
+    float ps_bottom = 1.0f - ps_top;
+    BsdfEval r;
+    r.pdf = top.pdf * ps_top + sc.pdf * ps_bottom;
+    vec3 mn = mk3(min_f(1.0f - eo.x, 1.0f - ei.x), min_f(1.0f - eo.y, 1.0f - ei.y), min_f(1.0f - eo.z, 1.0f - ei.z));
+    r.f = top.f + sc.f * mn;
+    return r;
+}
+
+// Lobe selection of the same tree (sample_wi_impl of CoatedBsdf mod.rs:504-522 and BsdfMixture mod.rs:627-644),
+// followed by one lobe sampler. Every stochastic choice consumes and remaps u_select exactly like the reference
+// (including u_select == 1.0, which the PCG stream can produce).
+enum LobeKind { LOBE_DIFFUSE = 0, LOBE_REFLECT = 1, LOBE_TRANSMIT = 2 };
+AKR_HD bool sample_lobe(LobeKind lobe, vec2 alpha, float eta, vec3 wo, vec2 u, vec3& wi) {
+    if (lobe == LOBE_DIFFUSE) {  // diffuse.rs:40-52
+        vec3 w = cos_sample_hemisphere(u);
+        wi = same_hemisphere(wo, w) ? w : -w;
+        return true;
+    }
+    vec3 wh = tr_sample_wh(wo, u, alpha);
+    if (lobe == LOBE_REFLECT) {  // mod.rs:860-873
+        wi = reflect(wo, wh);
+        return same_hemisphere(wo, wi);
+    }
+    bool refracted = refract(wo, wh, eta, wi);  // mod.rs:969-982
+    return refracted && !same_hemisphere(wo, wi);
+}
+AKR_HD bool principled_sample_wi(const DMaterial& m, const float* __restrict__ table, vec3 wo, float u, vec2 u2, vec3& wi) {
+    const uint32_t fl = m.flags;
+    LobeKind lobe = LOBE_DIFFUSE;
+    vec2 alpha = m.alpha;
+    float r;
+    // Coated{coat | Scaled{Emissive{...}}}: top iff u < avg(E_coat(wo))
+    float p_coat = (fl & MF_COAT) ? avg3(etop_coat(m, table, wo)) : 0.0f;
+    if (weighted_choice2_and_remap(p_coat, u, r)) {
+        lobe = LOBE_REFLECT;
+        alpha = m.coat_alpha;
+    } else {
+        u = r;
+        // Mix(metallic): b (metal) iff u < metallic
+        if (weighted_choice2_and_remap(m.metallic, u, r)) {
+            lobe = LOBE_REFLECT;
+        } else {
+            u = r;
+            // Coated{specular | Mix(transmission)}: top iff u < avg(E_spec(wo))
+            float p_spec = (fl & MF_SPEC) ? avg3(etop_spec(m, table, wo)) : 0.0f;
+            if (weighted_choice2_and_remap(p_spec, u, r)) {
+                lobe = LOBE_REFLECT;
+            } else {
+                u = r;
+                // Mix(transmission): b (dielectric) iff u < transmission
+                if (weighted_choice2_and_remap(m.transmission, u, r)) {
+                    u = r;
+                    // Addictive{transmission, reflection}: b (reflection) iff u < fr_dielectric(cos wo, eta)
+                    float frac = fr_dielectric(cos_theta(wo), m.eta);
+                    lobe = weighted_choice2_and_remap(frac, u, r) ? LOBE_REFLECT : LOBE_TRANSMIT;
+                } else {
+                    lobe = LOBE_DIFFUSE;
+                }
+            }
+        }
+    }
+    return sample_lobe(lobe, alpha, m.eta, wo, u2, wi);
+}
+
+// ---- SurfaceClosure (svm/surface/mod.rs:697-816): light-leak guard + world <-> local ----
+AKR_HD bool check_wo_wi_valid(vec3 ns, vec3 ng, vec3 wo, vec3 wi) {
+    auto sgn = [](float x) { return x > 0.0f ? 1.0f : -1.0f; };
+    float flipped = sgn(dot(ng, ns));
+    bool a = sgn(flipped * dot(wo, ns)) * sgn(dot(wo, ng)) > 0.0f;
+    bool b = sgn(flipped * dot(wi, ns)) * sgn(dot(wi, ng)) > 0.0f;
+    return a & b;
+}
+
+// Everything the shading functions need at one path vertex.
+struct ShadePoint {
+    Frame frame;        // si.frame
+    vec3 ng;            // si.ng
+    Frame nm_frame;     // inner (normal-map) frame in local space; identity when !MF_NORMAL_MAP
+    vec3 ng_local;      // frame.to_local(ng)  (normal_map(): ng of the inner SurfaceClosure)
+    bool force_diffuse;
+};
+
+// normal_map(), svm/surface/mod.rs:1380-1417, for a constant `normal` input
+AKR_HD void shade_point_init(ShadePoint& sp, const DMaterial& m, Frame frame, vec3 ng, bool force_diffuse) {
+    sp.frame = frame;
+    sp.ng = ng;
+    sp.force_diffuse = force_diffuse;
+    sp.ng_local = to_local(frame, ng);
+    sp.nm_frame = Frame{mk3(0, 0, 1), mk3(1, 0, 0), mk3(0, 1, 0)};
+    if (!force_diffuse && m.kind == MAT_PRINCIPLED && (m.flags & MF_NORMAL_MAP)) {
+        vec3 n_world = to_world(frame, m.nm_normal);
+        Frame nf = frame_from_n_t(n_world, frame.t);
+        sp.nm_frame.t = to_local(frame, nf.t);
+        sp.nm_frame.s = to_local(frame, nf.s);
+        sp.nm_frame.n = to_local(frame, nf.n);
+    }
+}
+
+// closure.evaluate(wo, wi) for world-space directions -> (f * |cos|, pdf); pt.rs:268-279 for force_diffuse
+AKR_HD BsdfEval shade_evaluate(const ShadePoint& sp, const DMaterial& m, const float* __restrict__ table, vec3 wo, vec3 wi) {
+    BsdfEval zero{mk3(0, 0, 0), 0.0f};
+    if (!check_wo_wi_valid(sp.frame.n, sp.ng, wo, wi)) return zero;
+    vec3 lo = to_local(sp.frame, wo), li = to_local(sp.frame, wi);
+    if (sp.force_diffuse) {
+        float r = (1.0f * kInvPi) * 0.8f;
+        return eval_diffuse(splat3(r), lo, li);
+    }
+    switch (m.kind) {
+        case MAT_PRINCIPLED: {
+            if (!check_wo_wi_valid(sp.nm_frame.n, sp.ng_local, lo, li)) return zero;
+            if (m.flags & MF_NORMAL_MAP) {
+                lo = to_local(sp.nm_frame, lo);
+                li = to_local(sp.nm_frame, li);
+            }
+            return principled_eval(m, table, lo, li);
+        }
+        case MAT_DIFFUSE: return eval_diffuse(m.diffuse_refl, lo, li);
+        case MAT_GLASS: return eval_dielectric(m.color, m.color, m.eta, m.alpha, lo, li);
+        default: return zero;  // Emission node: EmissiveSurface{inner: None}
+    }
+}
+
+struct BsdfSample {  // svm/surface/mod.rs:35-51
+    vec3 wi;
+    float pdf;
+    vec3 color;
+    bool valid;
+};
+// SurfaceClosure::sample, svm/surface/mod.rs:795-815
+AKR_HD BsdfSample shade_sample(const ShadePoint& sp, const DMaterial& m, const float* __restrict__ table, vec3 wo, float u_select,
+                               vec2 u_sample) {
+    BsdfSample s{mk3(0, 0, 0), 0.0f, mk3(0, 0, 0), false};
+    vec3 lo = to_local(sp.frame, wo);
+    vec3 wl = mk3(0, 0, 0);
+    bool valid;
+    if (sp.force_diffuse) {
+        valid = sample_lobe(LOBE_DIFFUSE, mk2(0, 0), 1.0f, lo, u_sample, wl);
+    } else {
+        switch (m.kind) {
+            case MAT_PRINCIPLED: {
+                vec3 lo2 = (m.flags & MF_NORMAL_MAP) ? to_local(sp.nm_frame, lo) : lo;
+                vec3 w2;
+                valid = principled_sample_wi(m, table, lo2, u_select, u_sample, w2);
+                wl = (m.flags & MF_NORMAL_MAP) ? to_world(sp.nm_frame, w2) : w2;
+                valid = valid & check_wo_wi_valid(sp.nm_frame.n, sp.ng_local, lo, wl);
+                break;
+            }
+            case MAT_DIFFUSE: valid = sample_lobe(LOBE_DIFFUSE, mk2(0, 0), 1.0f, lo, u_sample, wl); break;
+            case MAT_GLASS: {
+                float frac = fr_dielectric(cos_theta(lo), m.eta), r;
+                LobeKind lobe = weighted_choice2_and_remap(frac, u_select, r) ? LOBE_REFLECT : LOBE_TRANSMIT;
+                valid = sample_lobe(lobe, m.alpha, m.eta, lo, u_sample, wl);
+                break;
+            }
+            default: valid = false; break;
+        }
+    }
+    vec3 wi = to_world(sp.frame, wl);
+    valid = valid & check_wo_wi_valid(sp.frame.n, sp.ng, wo, wi);
+    if (!valid) return s;
+    BsdfEval e = shade_evaluate(sp, m, table, wo, wi);
+    s.wi = wi;
+    s.color = e.f;
+    s.pdf = e.pdf;
+    s.valid = valid & (e.pdf > 0.0f);
+    return s;
+}
+
+}  // namespace akr

@@ -1,0 +1,203 @@
+// disect.h -- ray/triangle test and the two scene intersectors (exhaustive for tiny scenes, BVH4 otherwise).
+//
+// Replaces LuisaCompute's rtx::Accel ray queries (crates/akari_render/src/scene.rs:88-185). Semantics kept from
+// the reference: a candidate is rejected when its (inst, prim) equals one of the ray's two exclusion slots
+// (scene.rs:98-100) or fails the stochastic alpha test (scene.rs:49-86); closest hit = smallest t.
+// Added so that results do not depend on traversal order: ties in t go to the lowest global triangle id.
+#pragma once
+#include "drng.h"
+#include "dscene.h"
+
+namespace akr {
+
+struct Hit {
+    float t, u, v;
+    uint32_t gid;
+};
+
+// Triangle test in Woop's precomputed-transform form. (r0|c0), (r1|c1), (r2|c2) map world space to the space in
+// which the triangle is (0,0,0),(1,0,0),(0,1,0); 27 flops + one division, no cross products at run time.
+AKR_HD bool tri_test(vec3 o, vec3 d, float4 r0, float4 r1, float4 r2, float tmin, float tmax, float& t_out, float& u_out,
+                     float& v_out) {
+    float dz = __builtin_fmaf(r2.x, d.x, __builtin_fmaf(r2.y, d.y, r2.z * d.z));
+    float oz = __builtin_fmaf(r2.x, o.x, __builtin_fmaf(r2.y, o.y, __builtin_fmaf(r2.z, o.z, r2.w)));
+    float t = -oz / dz;
+    float dx = __builtin_fmaf(r0.x, d.x, __builtin_fmaf(r0.y, d.y, r0.z * d.z));
+    float ox = __builtin_fmaf(r0.x, o.x, __builtin_fmaf(r0.y, o.y, __builtin_fmaf(r0.z, o.z, r0.w)));
+    float dy = __builtin_fmaf(r1.x, d.x, __builtin_fmaf(r1.y, d.y, r1.z * d.z));
+    float oy = __builtin_fmaf(r1.x, o.x, __builtin_fmaf(r1.y, o.y, __builtin_fmaf(r1.z, o.z, r1.w)));
+    float u = __builtin_fmaf(t, dx, ox);
+    float v = __builtin_fmaf(t, dy, oy);
+    bool hit = (t >= tmin) & (t <= tmax) & (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f);
+    t_out = t;
+    u_out = u;
+    v_out = v;
+    return hit;
+}
+
+// scene.rs:49-86 for folded materials: alpha = alpha channel of the base-colour node
+AKR_D bool alpha_test(const DScene& sc, uint32_t gid, float u, float v) {
+    const float4* r = sc.shade + (size_t)gid * SHADE_ROWS;
+    float4 q6 = r[6];
+    const DMaterial& m = sc.materials[f2u(q6.y)];
+    float alpha = (m.kind == MAT_PRINCIPLED || m.kind == MAT_DIFFUSE) ? m.base_alpha : 1.0f;
+    if (alpha >= 1.0f) return true;
+    uint32_t inst = f2u(q6.z);
+    uint32_t prim = gid - sc.inst_tri_offset[inst];
+    float h = (float)xxhash32_4(inst, prim, f2u(u), f2u(v)) * 2.3283064365386963e-10f;
+    return alpha > h;
+}
+
+// Exhaustive intersector: every lane of the wave walks the same triangle list, so the 48-byte records are
+// wave-uniform and come in through the scalar cache (s_load_dwordx4 x3), leaving the VALU for the test itself.
+template <bool ANY_HIT>
+AKR_D bool trace_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmin, float tmax, uint32_t ex0, uint32_t ex1, Hit& hit) {
+    float best_t = tmax;
+    uint32_t best = kInvalid;
+    float best_u = 0.0f, best_v = 0.0f;
+    const uint32_t n = sc.n_tris;
+    for (uint32_t k = 0; k < n; k++) {
+        float4 r0 = sc.woop[3 * k + 0], r1 = sc.woop[3 * k + 1], r2 = sc.woop[3 * k + 2];
+        float t, u, v;
+        bool h = tri_test(o, d, r0, r1, r2, tmin, tmax, t, u, v);
+        h = h & (k != ex0) & (k != ex1);
+        if (sc.has_alpha) {
+            if (h) h = alpha_test(sc, k, u, v);
+        }
+        if (ANY_HIT) {
+            if (h) best = k;
+            if (__builtin_amdgcn_ballot_w64(best == kInvalid) == 0) break;  // every lane of the wave is occluded
+        } else {
+            // ascending k: a strict '<' keeps the lowest id among equal t; the first hit needs t <= tmax only
+            bool better = h & ((best == kInvalid) | (t < best_t));
+            best_t = better ? t : best_t;
+            best_u = better ? u : best_u;
+            best_v = better ? v : best_v;
+            best = better ? k : best;
+        }
+    }
+    hit.t = best_t;
+    hit.u = best_u;
+    hit.v = best_v;
+    hit.gid = best;
+    return best != kInvalid;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// BVH4 traversal (one ray per lane, while-while). Node layout: host/bvh.cpp. The per-lane stack lives in LDS,
+// strided by the workgroup size so that lane i of every wave touches bank i (no conflicts): 4 B x depth x 256.
+constexpr uint32_t kBvhStackDepth = 48;
+constexpr uint32_t kBvhLeafBit = 0x80000000u;
+constexpr uint32_t kBvhDone = 0xfffffffeu;
+
+struct TraceCounters {
+    uint32_t nodes, tris, overflow;
+};
+
+AKR_D float safe_inv(float d) {  // 1/d with |d| floored at 1e-20 so that 0 * inf never appears in the slab test
+    float a = abs_f(d) < 1e-20f ? __builtin_copysignf(1e-20f, d) : d;
+    return 1.0f / a;
+}
+
+template <bool ANY_HIT>
+AKR_D bool trace_bvh4(const DScene& sc, vec3 o, vec3 d, float tmin, float tmax, uint32_t ex0, uint32_t ex1, Hit& hit,
+                      uint32_t* __restrict__ stack, TraceCounters& cnt) {
+    const vec3 inv = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+    float best_t = tmax;
+    uint32_t best = kInvalid;
+    float best_u = 0.0f, best_v = 0.0f;
+    uint32_t sp = 0;
+    uint32_t cur = 0;  // root is always an inner node
+#define AKR_PUSH(ref)                                  \
+    {                                                  \
+        if (sp < kBvhStackDepth) {                     \
+            stack[sp * 256u] = (ref);                  \
+            sp++;                                      \
+        } else {                                       \
+            cnt.overflow = 1;                          \
+        }                                              \
+    }
+    for (;;) {
+        while (!(cur & kBvhLeafBit)) {
+            const float4* n = sc.bvh_nodes + (size_t)cur * 8;
+            float4 lx = n[0], hx = n[1], ly = n[2], hy = n[3], lz = n[4], hz = n[5], cr = n[6];
+            cnt.nodes++;
+            float tn[4];
+            uint32_t ch[4] = {f2u(cr.x), f2u(cr.y), f2u(cr.z), f2u(cr.w)};
+            const float lxs[4] = {lx.x, lx.y, lx.z, lx.w}, hxs[4] = {hx.x, hx.y, hx.z, hx.w};
+            const float lys[4] = {ly.x, ly.y, ly.z, ly.w}, hys[4] = {hy.x, hy.y, hy.z, hy.w};
+            const float lzs[4] = {lz.x, lz.y, lz.z, lz.w}, hzs[4] = {hz.x, hz.y, hz.z, hz.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float t0 = (lxs[i] - o.x) * inv.x, t1 = (hxs[i] - o.x) * inv.x;
+                float near = min_f(t0, t1), far = max_f(t0, t1);
+                t0 = (lys[i] - o.y) * inv.y; t1 = (hys[i] - o.y) * inv.y;
+                near = max_f(near, min_f(t0, t1)); far = min_f(far, max_f(t0, t1));
+                t0 = (lzs[i] - o.z) * inv.z; t1 = (hzs[i] - o.z) * inv.z;
+                near = max_f(near, min_f(t0, t1)); far = min_f(far, max_f(t0, t1));
+                near = max_f(near, tmin);
+                far = min_f(far, best_t);
+                tn[i] = (near <= far) ? near : __builtin_inff();  // empty slots have inverted boxes -> never entered
+            }
+            if (!ANY_HIT) {
+                // sort the four (tn, ch) pairs ascending with a 5-comparator network
+#define AKR_CSWAP(a, b)                                          \
+    {                                                            \
+        bool sw = tn[b] < tn[a];                                 \
+        float tf = sw ? tn[b] : tn[a], tg = sw ? tn[a] : tn[b];  \
+        uint32_t cf = sw ? ch[b] : ch[a], cg = sw ? ch[a] : ch[b]; \
+        tn[a] = tf; tn[b] = tg; ch[a] = cf; ch[b] = cg;          \
+    }
+                AKR_CSWAP(0, 1) AKR_CSWAP(2, 3) AKR_CSWAP(0, 2) AKR_CSWAP(1, 3) AKR_CSWAP(1, 2)
+#undef AKR_CSWAP
+                // push far-to-near so that the nearest is popped first
+                if (tn[3] < __builtin_inff()) AKR_PUSH(ch[3])
+                if (tn[2] < __builtin_inff()) AKR_PUSH(ch[2])
+                if (tn[1] < __builtin_inff()) AKR_PUSH(ch[1])
+                if (tn[0] < __builtin_inff()) {
+                    cur = ch[0];
+                } else if (sp > 0) {
+                    sp--; cur = stack[sp * 256u];
+                } else {
+                    cur = kBvhDone;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (tn[i] < __builtin_inff()) AKR_PUSH(ch[i])
+                if (sp > 0) { sp--; cur = stack[sp * 256u]; } else { cur = kBvhDone; }
+            }
+        }
+        if (cur == kBvhDone) break;
+        {   // leaf: up to 4 triangles, 48 B each
+            const uint32_t first = cur & 0x0fffffffu, count = (cur >> 28) & 7u;
+            for (uint32_t i = 0; i < count; i++) {
+                const uint32_t k = first + i;
+                float4 r0 = sc.woop[3 * (size_t)k + 0], r1 = sc.woop[3 * (size_t)k + 1], r2 = sc.woop[3 * (size_t)k + 2];
+                cnt.tris++;
+                float t, u, v;
+                bool h = tri_test(o, d, r0, r1, r2, tmin, tmax, t, u, v);
+                if (h) {
+                    uint32_t gid = sc.tri_gid[k];
+                    h = (gid != ex0) & (gid != ex1);
+                    if (h && sc.has_alpha) h = alpha_test(sc, gid, u, v);
+                    if (h) {
+                        if (ANY_HIT) {
+                            best = gid;
+                        } else {
+                            bool better = (best == kInvalid) | (t < best_t) | ((t == best_t) & (gid < best));
+                            if (better) { best_t = t; best_u = u; best_v = v; best = gid; }
+                        }
+                    }
+                }
+            }
+            if (ANY_HIT && best != kInvalid) break;
+            if (sp > 0) { sp--; cur = stack[sp * 256u]; } else break;
+        }
+    }
+#undef AKR_PUSH
+    hit.t = best_t; hit.u = best_u; hit.v = best_v; hit.gid = best;
+    return best != kInvalid;
+}
+
+}  // namespace akr

@@ -1,0 +1,128 @@
+// dmath.h -- f32 vector type and elementary functions of the HIP path tracer (gfx950).
+//
+// Arithmetic contract (DESIGN.md "AKR-F32"): IEEE binary32, round-to-nearest-even, no implicit contraction
+// (the library is built with -ffp-contract=off; fused multiply-adds appear only where fmaf is written),
+// correctly rounded division and sqrt (-fhip-fp32-correctly-rounded-divide-sqrt), and sin/cos/log given by
+// the polynomial kernels below instead of the device math library -- so a film rendered here is a pure
+// function of (scene, config, seed), reproducible bit-for-bit on any IEEE machine that follows the same text.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define AKR_HD __host__ __device__ __forceinline__
+#define AKR_D __device__ __forceinline__
+
+namespace akr {
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kInvPi = 0.31830988618379067154f;
+
+struct vec2 {
+    float x, y;
+};
+struct vec3 {
+    float x, y, z;
+};
+
+AKR_HD vec2 mk2(float x, float y) { return vec2{x, y}; }
+AKR_HD vec3 mk3(float x, float y, float z) { return vec3{x, y, z}; }
+AKR_HD vec3 splat3(float v) { return vec3{v, v, v}; }
+AKR_HD vec3 operator+(vec3 a, vec3 b) { return vec3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+AKR_HD vec3 operator-(vec3 a, vec3 b) { return vec3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+AKR_HD vec3 operator*(vec3 a, vec3 b) { return vec3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+AKR_HD vec3 operator*(vec3 a, float s) { return vec3{a.x * s, a.y * s, a.z * s}; }
+AKR_HD vec3 operator-(vec3 a) { return vec3{-a.x, -a.y, -a.z}; }
+AKR_HD float dot(vec3 a, vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+AKR_HD vec3 cross(vec3 a, vec3 b) { return vec3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+AKR_HD float length2(vec3 a) { return dot(a, a); }
+AKR_HD float length(vec3 a) { return __builtin_sqrtf(dot(a, a)); }
+// vec / scalar := vec * (1 / scalar): one IEEE division
+AKR_HD vec3 div_s(vec3 a, float s) {
+    float inv = 1.0f / s;
+    return a * inv;
+}
+AKR_HD vec3 normalize(vec3 a) { return div_s(a, length(a)); }
+AKR_HD float min_f(float a, float b) { return a < b ? a : b; }  // b when a is NaN
+AKR_HD float max_f(float a, float b) { return a > b ? a : b; }  // b when a is NaN
+AKR_HD float clamp_f(float x, float lo, float hi) { return min_f(max_f(x, lo), hi); }
+AKR_HD float sqr(float x) { return x * x; }
+AKR_HD float lerp_f(float a, float b, float t) { return a + (b - a) * t; }
+AKR_HD vec3 lerp3(vec3 a, vec3 b, float t) { return vec3{lerp_f(a.x, b.x, t), lerp_f(a.y, b.y, t), lerp_f(a.z, b.z, t)}; }
+AKR_HD float max3(vec3 a) { return max_f(max_f(a.x, a.y), a.z); }
+AKR_HD float min3(vec3 a) { return min_f(min_f(a.x, a.y), a.z); }
+AKR_HD float abs_f(float x) { return __builtin_fabsf(x); }
+
+AKR_HD uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+AKR_HD float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+AKR_HD bool is_finite(float x) { return (f2u(x) & 0x7f800000u) != 0x7f800000u; }
+AKR_HD bool is_nan(float x) { return x != x; }
+
+// sin and cos of x (radians): Cody-Waite reduction by pi/2, then the Cephes single-precision kernels.
+AKR_HD void sincos_f(float x, float& s_out, float& c_out) {
+    const float kTwoOverPi = 0.636619772367581343f;
+    const float P1 = 1.5703125f, P2 = 4.837512969970703125e-4f, P3 = 7.54978995489188216e-8f;
+    float kf = __builtin_rintf(x * kTwoOverPi);
+    float r = __builtin_fmaf(-kf, P1, x);
+    r = __builtin_fmaf(-kf, P2, r);
+    r = __builtin_fmaf(-kf, P3, r);
+    float z = r * r;
+    float ps = __builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    float sn = __builtin_fmaf(r * z, ps, r);
+    float pc = __builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    float cs = __builtin_fmaf(z * z, pc, __builtin_fmaf(-0.5f, z, 1.0f));
+    int k = (int)kf;
+    float s = (k & 1) ? cs : sn;
+    float c = (k & 1) ? sn : cs;
+    if (k & 2) s = -s;
+    if ((k + 1) & 2) c = -c;
+    s_out = s;
+    c_out = c;
+}
+
+// natural log (Cephes logf); log(0) = -inf, log(x < 0) = NaN
+AKR_HD float log_f(float x) {
+    if (x == 0.0f) return -__builtin_inff();
+    if (!(x > 0.0f)) return __builtin_nanf("");
+    uint32_t ux = f2u(x);
+    int e = (int)(ux >> 23) - 126;
+    float m = u2f((ux & 0x007fffffu) | 0x3f000000u);
+    if ((ux >> 23) == 0) {
+        float xs = x * 16777216.0f;
+        ux = f2u(xs);
+        e = (int)(ux >> 23) - 126 - 24;
+        m = u2f((ux & 0x007fffffu) | 0x3f000000u);
+    }
+    if (m < 0.707106781186547524f) {
+        e -= 1;
+        m = (m + m) - 1.0f;
+    } else {
+        m = m - 1.0f;
+    }
+    float z = m * m;
+    float p = 7.0376836292e-2f;
+    p = __builtin_fmaf(p, m, -1.1514610310e-1f);
+    p = __builtin_fmaf(p, m, 1.1676998740e-1f);
+    p = __builtin_fmaf(p, m, -1.2420140846e-1f);
+    p = __builtin_fmaf(p, m, 1.4249322787e-1f);
+    p = __builtin_fmaf(p, m, -1.6668057665e-1f);
+    p = __builtin_fmaf(p, m, 2.0000714765e-1f);
+    p = __builtin_fmaf(p, m, -2.4999993993e-1f);
+    p = __builtin_fmaf(p, m, 3.3333331174e-1f);
+    float y = (m * z) * p;
+    float fe = (float)e;
+    y = __builtin_fmaf(-2.12194440e-4f, fe, y);
+    y = __builtin_fmaf(-0.5f, z, y);
+    float r = m + y;
+    r = __builtin_fmaf(0.693359375f, fe, r);
+    return r;
+}
+
+// a*b - c*d with the rounding error of c*d folded back in (reference util/mod.rs:326-331)
+AKR_HD float difference_of_products(float a, float b, float c, float d) {
+    float cd = c * d;
+    float diff = __builtin_fmaf(a, b, -cd);
+    float err = __builtin_fmaf(-c, d, cd);
+    return diff + err;
+}
+
+}  // namespace akr

@@ -1,0 +1,82 @@
+// drng.h -- the reference's PCG32 variant (crates/akari_render/src/sampler/mod.rs:73-217) on the device,
+// plus xxhash32_4 (util/hash.rs:44-60) and mix_bits (util/mod.rs:305-319).
+#pragma once
+#include "dmath.h"
+
+namespace akr {
+
+constexpr uint64_t kPcgMult = 0x5851f42d4c957f2dull;
+
+struct Pcg32 {
+    uint64_t state, inc;
+};
+
+AKR_HD uint32_t pcg_gen_u32(Pcg32& p) {  // sampler/mod.rs:101-113
+    uint64_t old = p.state;
+    p.state = old * kPcgMult + p.inc;
+    uint32_t xorshifted = (uint32_t)(((old >> 18) ^ old) >> 27);
+    uint32_t rot = (uint32_t)(old >> 59);
+    return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31u));
+}
+AKR_HD Pcg32 pcg_new_seq_offset(uint64_t seq, uint64_t seed) {  // sampler/mod.rs:88-94
+    Pcg32 p{0, (seq << 1) | 1u};
+    pcg_gen_u32(p);
+    p.state += seed;
+    pcg_gen_u32(p);
+    return p;
+}
+AKR_HD uint64_t mix_bits(uint64_t v) {
+    v ^= v >> 31;
+    v *= 0x7fb5d329728ea185ull;
+    v ^= v >> 27;
+    v *= 0x81dadef4bc2dd44dull;
+    v ^= v >> 33;
+    return v;
+}
+AKR_HD Pcg32 pcg_new_seq(uint64_t seq) { return pcg_new_seq_offset(seq, mix_bits(seq)); }
+
+// sampler/mod.rs:115-131, restated verbatim: this is NOT the canonical PCG jump-ahead, but it is what
+// defines the reference's sample stream (start() = advance(16384), drop = advance(-dim)).
+AKR_HD void pcg_advance(Pcg32& p, int64_t idelta) {
+    uint64_t cur_mult = kPcgMult, cur_plus = p.inc, acc_mult = 1, acc_plus = 0;
+    uint64_t delta = (uint64_t)idelta;
+    while (delta > 0) {
+        if (delta & 1) {
+            acc_mult *= cur_mult;
+            acc_plus = acc_plus + cur_mult + cur_plus;
+        }
+        cur_plus = (cur_mult + 1) * cur_plus;
+        cur_mult *= cur_mult;
+        delta >>= 1;
+    }
+    p.state = acc_mult * p.state + acc_plus;
+}
+
+// advance(16384) in closed form. 16384 = 1 << 14 has one set bit, so the loop above reduces to
+//   state' = A * state + (A + C * inc),  A = MULT^(2^14),  C = prod_{k<14} (MULT^(2^k) + 1)   (mod 2^64)
+// A and C are constants of the generator; they are computed once on the host with the loop itself
+// (host/scene_build.cpp: pcg_start_constants) and checked against pcg_advance in the tests.
+struct PcgStartConsts {
+    uint64_t A, C;
+};
+AKR_HD void pcg_start(Pcg32& p, PcgStartConsts k) { p.state = k.A * p.state + (k.A + k.C * p.inc); }
+
+AKR_HD float pcg_next_1d(Pcg32& p) {  // sampler/mod.rs:194-198; can return exactly 1.0
+    uint32_t n = pcg_gen_u32(p);
+    return (float)n * 2.3283064365386963e-10f;  // f32(1.0 / u32::MAX as f64) == 2^-32
+}
+
+AKR_HD uint32_t xxhash32_4(uint32_t px, uint32_t py, uint32_t pz, uint32_t pw) {
+    const uint32_t PRIME32_2 = 2246822519u, PRIME32_3 = 3266489917u, PRIME32_4 = 668265263u, PRIME32_5 = 374761393u;
+    uint32_t h32 = pw + PRIME32_5 + px * PRIME32_3;
+    h32 = PRIME32_4 * ((h32 << 17) | (h32 >> (32 - 17)));
+    h32 = h32 + py * PRIME32_3;
+    h32 = PRIME32_4 * ((h32 << 17) | (h32 >> (32 - 17)));
+    h32 = h32 + pz * PRIME32_3;
+    h32 = PRIME32_4 * ((h32 << 17) | (h32 >> (32 - 17)));
+    h32 = PRIME32_2 * (h32 ^ (h32 >> 15));
+    h32 = PRIME32_3 * (h32 ^ (h32 >> 13));
+    return h32 ^ (h32 >> 16);
+}
+
+}  // namespace akr

@@ -1,0 +1,103 @@
+// dscene.h -- the scene as it lives in HBM, and the hit -> SurfaceInteraction reconstruction.
+//
+// Layout (all arrays 16-byte aligned, read with 16-byte vector loads):
+//   woop      3 x float4 per triangle, in traversal order      : the ray-triangle test's 48 B record
+//   tri_gid   u32 per triangle in traversal order              : global triangle id = inst_tri_offset[inst] + prim
+//   shade     8 x float4 per triangle, indexed by global id    : everything surface_interaction needs (128 B)
+//   inst      8 x float4 per instance                          : object->world matrix and its cofactors (128 B)
+//   materials DMaterial[ ]                                     : folded shader graphs (256 B)
+//   lights    alias tables (8 B entries + 4 B pdfs)            : LightAggregate + per-light triangle samplers
+// The reference gathers the same information through five dependent bindless-buffer reads per hit
+// (crates/akari_render/src/mesh.rs:499-653); here the per-triangle part is folded on the host.
+#pragma once
+#include "dbsdf.h"
+
+namespace akr {
+
+constexpr uint32_t kInvalid = 0xffffffffu;
+
+// shade record rows (float4 each):
+//  0: v0.xyz | uv0.x     1: v1.xyz | uv0.y     2: v2.xyz | uv1.x     (object-space vertices)
+//  3: ng.xyz | uv1.y     4: frame.t.xyz | uv2.x   5: frame.s.xyz | uv2.y   (world-space, flat-shaded frame)
+//  6: prim_area | material (u32) | instance (u32) | light id (i32, -1 = none)
+//  7: tt.xyz (world dpdu, for meshes with shading normals) | flags
+enum : uint32_t { SHADE_ROWS = 8, INST_ROWS = 8 };
+enum : uint32_t { TRI_HAS_NORMALS = 1u, TRI_HAS_TANGENTS = 2u };
+
+struct DScene {
+    const float4* __restrict__ woop;
+    const uint32_t* __restrict__ tri_gid;   // nullptr = identity (exhaustive path)
+    const float4* __restrict__ shade;
+    const float4* __restrict__ normals;     // 6 x float4 per global triangle (per-corner normals, tangents) or nullptr
+    const float4* __restrict__ inst;
+    const DMaterial* __restrict__ materials;
+    const float* __restrict__ ggx_table;
+    const AliasEntry* __restrict__ light_entries;
+    const float* __restrict__ light_pdf;
+    const uint32_t* __restrict__ light_inst;        // light id -> instance
+    const uint32_t* __restrict__ light_tri_offset;  // light id -> first entry in area_entries / area_pdf
+    const uint32_t* __restrict__ light_n_tris;
+    const AliasEntry* __restrict__ area_entries;
+    const float* __restrict__ area_pdf;
+    const uint32_t* __restrict__ inst_tri_offset;   // instance -> first global triangle id
+    const float4* __restrict__ bvh_nodes;           // nullptr on the exhaustive path
+    uint32_t n_tris, n_lights, n_nodes, has_alpha;
+};
+
+struct SurfacePoint {  // interaction.rs:15-48, minus what this path never reads
+    Frame frame;
+    vec3 p, ng;
+    float prim_area;
+    uint32_t material;
+    int32_t light;
+    uint32_t inst;
+};
+
+AKR_HD vec3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
+// TriangleInterpolate: (1 - u - v) a + u b + v c
+AKR_HD vec3 interp3(vec2 b, vec3 a0, vec3 a1, vec3 a2) {
+    float w = 1.0f - b.x - b.y;
+    return (a0 * w + a1 * b.x) + a2 * b.y;
+}
+AKR_HD vec3 xf_point(vec3 c0, vec3 c1, vec3 c2, vec3 t, vec3 p) { return ((c0 * p.x + c1 * p.y) + c2 * p.z) + t; }
+AKR_HD vec3 xf_vector(vec3 c0, vec3 c1, vec3 c2, vec3 v) { return (c0 * v.x + c1 * v.y) + c2 * v.z; }
+
+// MeshAggregate::surface_interaction (mesh.rs:487-654) from the folded records.
+AKR_D SurfacePoint surface_interaction(const DScene& sc, uint32_t gid, vec2 bary) {
+    const float4* r = sc.shade + (size_t)gid * SHADE_ROWS;
+    float4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3], q4 = r[4], q5 = r[5], q6 = r[6];
+    SurfacePoint s;
+    s.prim_area = q6.x;
+    s.material = f2u(q6.y);
+    s.inst = f2u(q6.z);
+    s.light = (int32_t)f2u(q6.w);
+    const float4* m = sc.inst + (size_t)s.inst * INST_ROWS;
+    float4 c0 = m[0], c1 = m[1], c2 = m[2], t = m[3];
+    vec3 p_local = interp3(bary, xyz(q0), xyz(q1), xyz(q2));
+    s.p = xf_point(xyz(c0), xyz(c1), xyz(c2), xyz(t), p_local);
+    s.ng = xyz(q3);
+    s.frame = Frame{s.ng, xyz(q4), xyz(q5)};
+    if (sc.normals != nullptr) {
+        float4 q7 = r[7];
+        const uint32_t tf = f2u(q7.w);
+        if (tf & (TRI_HAS_NORMALS | TRI_HAS_TANGENTS)) {  // mesh.rs:557-571, 591-602, 619-640
+            const float4* nr = sc.normals + (size_t)gid * 6;
+            vec3 ns = s.ng;
+            if (tf & TRI_HAS_NORMALS) {
+                vec3 ns_local = interp3(bary, xyz(nr[0]), xyz(nr[1]), xyz(nr[2]));
+                float4 k0 = m[4], k1 = m[5], k2 = m[6];
+                vec3 rr = (xyz(k0) * ns_local.x + xyz(k1) * ns_local.y) + xyz(k2) * ns_local.z;
+                ns = normalize(rr * k0.w);  // k0.w = 1 / det
+            }
+            vec3 tt = xyz(q7);
+            if (tf & TRI_HAS_TANGENTS) {
+                vec3 tt_local = normalize(interp3(bary, xyz(nr[3]), xyz(nr[4]), xyz(nr[5])));
+                tt = xf_vector(xyz(c0), xyz(c1), xyz(c2), tt_local);
+            }
+            s.frame = (tt.x != 0.0f || tt.y != 0.0f || tt.z != 0.0f) ? frame_from_n_t(ns, tt) : frame_from_n(ns);
+        }
+    }
+    return s;
+}
+
+}  // namespace akr

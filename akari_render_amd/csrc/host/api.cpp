@@ -1,0 +1,769 @@
+// api.cpp -- the C ABI of libakari_hip.so (include/akari_hip.h).
+//
+// Every entry point catches C++ exceptions and HIP errors and turns them into an akr_status plus a thread-local
+// message; nothing throws or aborts across the boundary. There is no CPU path here: without a GPU
+// akr_context_create fails with AKR_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "scene_build.h"
+#include "stdrng.h"
+
+using namespace akr;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct HipError : std::runtime_error {
+    explicit HipError(const std::string& s) : std::runtime_error(s) {}
+};
+struct Unsupported : std::runtime_error {
+    explicit Unsupported(const std::string& s) : std::runtime_error(s) {}
+};
+struct IoError : std::runtime_error {
+    explicit IoError(const std::string& s) : std::runtime_error(s) {}
+};
+
+#define HIP_CHECK(expr)                                                                                         \
+    do {                                                                                                        \
+        hipError_t _e = (expr);                                                                                 \
+        if (_e != hipSuccess) throw HipError(std::string(#expr) + ": " + hipGetErrorString(_e));                \
+    } while (0)
+
+int32_t fail(int32_t code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+template <typename F>
+int32_t guarded(F&& f) {
+    try {
+        g_last_error.clear();
+        f();
+        return AKR_OK;
+    } catch (const HipError& e) {
+        return fail(AKR_ERR_HIP, e.what());
+    } catch (const Unsupported& e) {
+        return fail(AKR_ERR_UNSUPPORTED, e.what());
+    } catch (const IoError& e) {
+        return fail(AKR_ERR_IO, e.what());
+    } catch (const std::invalid_argument& e) {
+        return fail(AKR_ERR_INVALID_ARGUMENT, e.what());
+    } catch (const std::bad_alloc&) {
+        return fail(AKR_ERR_OUT_OF_MEMORY, "out of host memory");
+    } catch (const std::exception& e) {
+        std::string w = e.what();
+        if (w.rfind("unsupported", 0) == 0 || w.find("unsupported:") != std::string::npos) return fail(AKR_ERR_UNSUPPORTED, w);
+        if (w.rfind("cannot open", 0) == 0) return fail(AKR_ERR_IO, w);
+        return fail(AKR_ERR_PARSE, w);
+    } catch (...) {
+        return fail(AKR_ERR_INVALID_ARGUMENT, "unknown error");
+    }
+}
+
+// RAII device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    void alloc(size_t n) {
+        release();
+        if (n == 0) return;
+        HIP_CHECK(hipMalloc(&p, n));
+        bytes = n;
+    }
+    template <typename T>
+    void upload(const std::vector<T>& v) {
+        alloc(v.size() * sizeof(T));
+        if (!v.empty()) HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    }
+    template <typename T>
+    T* as() const { return (T*)p; }
+};
+
+}  // namespace
+
+struct akr_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t props;
+    void bind() const { HIP_CHECK(hipSetDevice(device)); }
+};
+
+struct akr_scene {
+    akr_context* ctx = nullptr;
+    FlatScene flat;
+    CompiledScene cs;
+    DevBuf woop, tri_gid, shade, normals, inst, materials, ggx_table, light_entries, light_pdf, light_inst, light_tri_offset,
+        light_n_tris, area_entries, area_pdf, inst_tri_offset, bvh_nodes;
+    std::vector<float> ggx_host;
+    DScene dscene;
+    float r2c[16], c2w[16];
+    uint32_t c2w_identity = 0;
+    uint64_t device_bytes = 0;
+};
+
+struct akr_film {
+    akr_context* ctx = nullptr;
+    uint32_t width = 0, height = 0;
+    DevBuf own;
+    float* data = nullptr;  // 7 * W * H floats
+    size_t n_floats() const { return 7ull * width * height; }
+};
+
+struct akr_pt_session {
+    akr_context* ctx = nullptr;
+    akr_scene* scene = nullptr;
+    akr_film* film = nullptr;
+    akr_pt_config cfg;
+    DevBuf states, counters;
+    uint32_t spp_done = 0, n_launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    PtParams params;
+};
+
+static void ensure_ggx_table(akr_scene* s) {
+    akr_context* ctx = s->ctx;
+    if (!s->flat.ggx_table.empty()) {
+        s->ggx_host = s->flat.ggx_table;
+    } else if (s->cs.needs_ggx_table) {
+        // PreComputedTables::init (svm/surface/precompute.rs:133-145): seeds = StdRng(0) stream, one per entry
+        std::vector<uint64_t> seeds(4096);
+        StdRng rng(0);
+        for (auto& v : seeds) v = rng.next_u64();
+        DevBuf dseeds;
+        dseeds.upload(seeds);
+        s->ggx_table.alloc(4096 * sizeof(float));
+        HIP_CHECK(launch_ggx_table(dseeds.as<uint64_t>(), s->ggx_table.as<float>(), 1u << 20, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        s->ggx_host.resize(4096);
+        HIP_CHECK(hipMemcpy(s->ggx_host.data(), s->ggx_table.p, 4096 * sizeof(float), hipMemcpyDeviceToHost));
+        return;
+    } else {
+        s->ggx_host.assign(4096, 0.0f);  // never read with a non-zero weight
+    }
+    s->ggx_table.upload(s->ggx_host);
+}
+
+static void scene_finish(akr_scene* s) {
+    akr_context* ctx = s->ctx;
+    compile_scene(s->flat, s->cs);
+    CompiledScene& cs = s->cs;
+    camera_matrices(s->flat.camera, s->r2c, s->c2w, &s->c2w_identity);
+    if (!ctx) {  // host-only scene: inspectable, not renderable
+        s->ggx_host = s->flat.ggx_table.empty() ? std::vector<float>(4096, 0.0f) : s->flat.ggx_table;
+        std::memset(&s->dscene, 0, sizeof s->dscene);
+        return;
+    }
+    ctx->bind();
+    s->woop.upload(cs.woop);
+    s->tri_gid.upload(cs.tri_gid);
+    s->shade.upload(cs.shade);
+    s->normals.upload(cs.normals);
+    s->inst.upload(cs.inst);
+    s->materials.upload(cs.materials);
+    s->light_entries.upload(cs.light_entries);
+    s->light_pdf.upload(cs.light_pdf);
+    s->light_inst.upload(cs.light_inst);
+    s->light_tri_offset.upload(cs.light_tri_offset);
+    s->light_n_tris.upload(cs.light_n_tris);
+    s->area_entries.upload(cs.area_entries);
+    s->area_pdf.upload(cs.area_pdf);
+    s->inst_tri_offset.upload(cs.inst_tri_offset);
+    s->bvh_nodes.upload(cs.bvh_nodes);
+    ensure_ggx_table(s);
+    DScene& d = s->dscene;
+    std::memset(&d, 0, sizeof d);
+    d.woop = s->woop.as<float4>();
+    d.tri_gid = s->tri_gid.as<uint32_t>();
+    d.shade = s->shade.as<float4>();
+    d.normals = s->normals.as<float4>();
+    d.inst = s->inst.as<float4>();
+    d.materials = s->materials.as<DMaterial>();
+    d.ggx_table = s->ggx_table.as<float>();
+    d.light_entries = s->light_entries.as<AliasEntry>();
+    d.light_pdf = s->light_pdf.as<float>();
+    d.light_inst = s->light_inst.as<uint32_t>();
+    d.light_tri_offset = s->light_tri_offset.as<uint32_t>();
+    d.light_n_tris = s->light_n_tris.as<uint32_t>();
+    d.area_entries = s->area_entries.as<AliasEntry>();
+    d.area_pdf = s->area_pdf.as<float>();
+    d.inst_tri_offset = s->inst_tri_offset.as<uint32_t>();
+    d.bvh_nodes = s->bvh_nodes.as<float4>();
+    d.n_tris = cs.n_tris;
+    d.n_lights = cs.n_lights;
+    d.n_nodes = (uint32_t)(cs.bvh_nodes.size() / 32);
+    d.has_alpha = cs.has_alpha ? 1u : 0u;
+    s->device_bytes = 0;
+    for (const DevBuf* b : {&s->woop, &s->tri_gid, &s->shade, &s->normals, &s->inst, &s->materials, &s->ggx_table, &s->light_entries,
+                            &s->light_pdf, &s->light_inst, &s->light_tri_offset, &s->light_n_tris, &s->area_entries, &s->area_pdf,
+                            &s->inst_tri_offset, &s->bvh_nodes})
+        s->device_bytes += b->bytes;
+}
+
+static void fill_params(akr_pt_session* se, uint32_t pass_spp) {
+    PtParams& p = se->params;
+    const akr_scene* s = se->scene;
+    const akr_pt_config& c = se->cfg;
+    std::memset(&p, 0, sizeof p);
+    p.sc = s->dscene;
+    std::memcpy(p.r2c, s->r2c, 64);
+    std::memcpy(p.c2w, s->c2w, 64);
+    p.c2w_identity = s->c2w_identity;
+    p.width = s->flat.camera.width;
+    p.height = s->flat.camera.height;
+    p.max_depth = c.max_depth;
+    p.rr_depth = c.rr_depth;
+    p.use_nee = c.use_nee;
+    p.indirect_only = c.indirect_only;
+    p.force_diffuse = c.force_diffuse;
+    p.debug_depth = c.debug_depth;
+    p.pixel_offset[0] = c.pixel_offset[0];
+    p.pixel_offset[1] = c.pixel_offset[1];
+    p.filter_type = c.filter_type;
+    p.filter_radius = c.filter_radius;
+    p.pass_spp = pass_spp;
+    p.start = pcg_start_constants();
+    p.states = se->states.as<Pcg32>();
+    p.film = se->film->data;
+    p.counters = se->counters.as<uint64_t>();
+    p.shard_rank = c.shard_count > 1 ? c.shard_rank : 0;
+    p.shard_count = c.shard_count > 1 ? c.shard_count : 1;
+    p.tile_w = c.tile_w ? c.tile_w : 32;
+    p.tile_h = c.tile_h ? c.tile_h : 32;
+    p.tiles_x = (p.width + p.tile_w - 1) / p.tile_w;
+    p.tiles_y = (p.height + p.tile_h - 1) / p.tile_h;
+    uint32_t n_tiles = p.tiles_x * p.tiles_y;
+    uint32_t owned = p.shard_rank < n_tiles ? (n_tiles - p.shard_rank + p.shard_count - 1) / p.shard_count : 0;
+    p.n_items = owned * p.tile_w * p.tile_h;
+}
+
+static void validate_config(const akr_pt_config& c) {
+    if (c.spp_per_pass == 0) throw std::invalid_argument("akr_pt_config: spp_per_pass must be > 0");
+    if (c.filter_type > AKR_FILTER_GAUSSIAN) throw std::invalid_argument("akr_pt_config: unknown filter_type");
+    if (c.sampler_type != AKR_SAMPLER_INDEPENDENT) throw Unsupported("unsupported: only the independent sampler is available");
+    uint32_t tw = c.tile_w ? c.tile_w : 32, th = c.tile_h ? c.tile_h : 32;
+    if ((tw % 8) || (th % 8)) throw std::invalid_argument("akr_pt_config: tile_w and tile_h must be multiples of 8");
+    if (c.shard_count > 1 && c.shard_rank >= c.shard_count) throw std::invalid_argument("akr_pt_config: shard_rank >= shard_count");
+}
+
+extern "C" {
+
+AKR_API const char* akr_last_error(void) { return g_last_error.c_str(); }
+AKR_API const char* akr_version(void) { return "akari_hip 0.1.0 gfx950"; }
+
+AKR_API int32_t akr_context_create(int32_t device, akr_context** out) {
+    if (!out) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_context_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(AKR_ERR_NO_DEVICE, std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "0 devices") +
+                                           "); libakari_hip has no CPU path");
+    if (device < 0 || device >= count) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_context_create: device ordinal out of range");
+    return guarded([&] {
+        auto ctx = std::make_unique<akr_context>();
+        ctx->device = device;
+        ctx->bind();
+        HIP_CHECK(hipGetDeviceProperties(&ctx->props, device));
+        HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        *out = ctx.release();
+    });
+}
+AKR_API int32_t akr_context_destroy(akr_context* ctx) {
+    if (!ctx) return AKR_OK;
+    return guarded([&] {
+        (void)hipSetDevice(ctx->device);
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+    });
+}
+AKR_API int32_t akr_context_synchronize(akr_context* ctx) {
+    if (!ctx) return fail(AKR_ERR_INVALID_ARGUMENT, "context is NULL");
+    return guarded([&] {
+        ctx->bind();
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+AKR_API int32_t akr_context_device_info(akr_context* ctx, char* name, uint32_t name_len, uint32_t* compute_units, uint64_t* hbm_bytes) {
+    if (!ctx) return fail(AKR_ERR_INVALID_ARGUMENT, "context is NULL");
+    if (name && name_len) {
+        std::snprintf(name, name_len, "%s (%s)", ctx->props.name, ctx->props.gcnArchName);
+    }
+    if (compute_units) *compute_units = (uint32_t)ctx->props.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (uint64_t)ctx->props.totalGlobalMem;
+    return AKR_OK;
+}
+
+AKR_API int32_t akr_scene_create(akr_context* ctx, const akr_scene_desc* desc, akr_scene** out) {
+    if (!desc || !out) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_scene_create: NULL argument");
+    *out = nullptr;
+    return guarded([&] {
+        auto s = std::make_unique<akr_scene>();
+        s->ctx = ctx;
+        s->flat = FlatScene::from_desc(*desc);
+        scene_finish(s.get());
+        *out = s.release();
+    });
+}
+AKR_API int32_t akr_scene_load(akr_context* ctx, const char* path, uint32_t width, uint32_t height, akr_scene** out) {
+    if (!path || !out) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_scene_load: NULL argument");
+    *out = nullptr;
+    return guarded([&] {
+        auto s = std::make_unique<akr_scene>();
+        s->ctx = ctx;
+        s->flat = load_scene_json(path);
+        if (width && height) {
+            s->flat.camera.width = width;
+            s->flat.camera.height = height;
+        }
+        scene_finish(s.get());
+        *out = s.release();
+    });
+}
+AKR_API int32_t akr_scene_destroy(akr_scene* scene) {
+    if (!scene) return AKR_OK;
+    return guarded([&] {
+        if (scene->ctx) (void)hipSetDevice(scene->ctx->device);
+        delete scene;
+    });
+}
+AKR_API int32_t akr_scene_set_resolution(akr_scene* s, uint32_t width, uint32_t height) {
+    if (!s || !width || !height) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_scene_set_resolution: bad argument");
+    s->flat.camera.width = width;
+    s->flat.camera.height = height;
+    camera_matrices(s->flat.camera, s->r2c, s->c2w, &s->c2w_identity);
+    return AKR_OK;
+}
+AKR_API int32_t akr_scene_get_info(const akr_scene* s, akr_scene_info* info) {
+    if (!s || !info) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_scene_get_info: NULL argument");
+    info->width = s->flat.camera.width;
+    info->height = s->flat.camera.height;
+    info->n_instances = (uint32_t)s->flat.instances.size();
+    info->n_triangles = s->cs.n_tris;
+    info->n_materials = (uint32_t)s->flat.materials.size();
+    info->n_lights = s->cs.n_lights;
+    info->n_bvh_nodes = (uint32_t)(s->cs.bvh_nodes.size() / 32);
+    info->uses_bvh = s->cs.bvh_nodes.empty() ? 0u : 1u;
+    info->device_bytes = s->device_bytes;
+    return AKR_OK;
+}
+AKR_API int32_t akr_scene_get_light(const akr_scene* s, uint32_t light, uint32_t* instance, float* power, float* pdf) {
+    if (!s || light >= s->cs.n_lights) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_scene_get_light: bad argument");
+    if (instance) *instance = s->cs.light_inst[light];
+    if (power) *power = s->cs.light_power[light];
+    if (pdf) *pdf = s->cs.light_pdf[light];
+    return AKR_OK;
+}
+AKR_API int32_t akr_scene_get_ggx_table(const akr_scene* s, float* dst) {
+    if (!s || !dst) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_scene_get_ggx_table: NULL argument");
+    std::memcpy(dst, s->ggx_host.data(), 4096 * sizeof(float));
+    return AKR_OK;
+}
+AKR_API int32_t akr_scene_get_desc_counts(const akr_scene* s, uint32_t* n_meshes, uint32_t* n_instances, uint32_t* n_materials) {
+    if (!s) return fail(AKR_ERR_INVALID_ARGUMENT, "scene is NULL");
+    if (n_meshes) *n_meshes = (uint32_t)s->flat.meshes.size();
+    if (n_instances) *n_instances = (uint32_t)s->flat.instances.size();
+    if (n_materials) *n_materials = (uint32_t)s->flat.materials.size();
+    return AKR_OK;
+}
+AKR_API int32_t akr_scene_get_mesh(const akr_scene* s, uint32_t i, akr_mesh_desc* out) {
+    if (!s || !out || i >= s->flat.meshes.size()) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_scene_get_mesh: bad argument");
+    const HostMesh& m = s->flat.meshes[i];
+    out->n_vertices = (uint32_t)(m.vertices.size() / 3);
+    out->n_triangles = m.n_triangles();
+    out->vertices = m.vertices.data();
+    out->indices = m.indices.data();
+    out->uvs = m.uvs.empty() ? nullptr : m.uvs.data();
+    out->normals = m.normals.empty() ? nullptr : m.normals.data();
+    out->tangents = m.tangents.empty() ? nullptr : m.tangents.data();
+    out->material_slots = m.slots.empty() ? nullptr : m.slots.data();
+    return AKR_OK;
+}
+AKR_API int32_t akr_scene_get_instance(const akr_scene* s, uint32_t i, akr_instance_desc* out) {
+    if (!s || !out || i >= s->flat.instances.size()) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_scene_get_instance: bad argument");
+    const HostInstance& h = s->flat.instances[i];
+    out->mesh = h.mesh;
+    out->n_materials = (uint32_t)h.materials.size();
+    out->materials = h.materials.data();
+    std::memcpy(out->transform, h.transform, sizeof out->transform);
+    return AKR_OK;
+}
+AKR_API int32_t akr_scene_get_material(const akr_scene* s, uint32_t i, akr_material_desc* out) {
+    if (!s || !out || i >= s->flat.materials.size()) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_scene_get_material: bad argument");
+    *out = s->flat.materials[i];
+    return AKR_OK;
+}
+AKR_API int32_t akr_scene_get_camera(const akr_scene* s, akr_camera_desc* out) {
+    if (!s || !out) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_scene_get_camera: NULL argument");
+    *out = s->flat.camera;
+    return AKR_OK;
+}
+
+AKR_API int32_t akr_scene_get_array(const akr_scene* s, int32_t which, const void** ptr, uint64_t* bytes) {
+    if (!s || !ptr || !bytes) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_scene_get_array: NULL argument");
+    const CompiledScene& cs = s->cs;
+    auto set = [&](const void* p, size_t n) { *ptr = n ? p : nullptr; *bytes = n; };
+    switch (which) {
+        case AKR_ARRAY_WOOP: set(cs.woop.data(), cs.woop.size() * 4); break;
+        case AKR_ARRAY_TRI_GID: set(cs.tri_gid.data(), cs.tri_gid.size() * 4); break;
+        case AKR_ARRAY_SHADE: set(cs.shade.data(), cs.shade.size() * 4); break;
+        case AKR_ARRAY_INSTANCES: set(cs.inst.data(), cs.inst.size() * 4); break;
+        case AKR_ARRAY_MATERIALS: set(cs.materials.data(), cs.materials.size() * sizeof(DMaterial)); break;
+        case AKR_ARRAY_BVH_NODES: set(cs.bvh_nodes.data(), cs.bvh_nodes.size() * 4); break;
+        case AKR_ARRAY_LIGHT_ENTRIES: set(cs.light_entries.data(), cs.light_entries.size() * sizeof(AliasEntry)); break;
+        case AKR_ARRAY_LIGHT_PDF: set(cs.light_pdf.data(), cs.light_pdf.size() * 4); break;
+        case AKR_ARRAY_AREA_ENTRIES: set(cs.area_entries.data(), cs.area_entries.size() * sizeof(AliasEntry)); break;
+        case AKR_ARRAY_AREA_PDF: set(cs.area_pdf.data(), cs.area_pdf.size() * 4); break;
+        case AKR_ARRAY_INST_TRI_OFFSET: set(cs.inst_tri_offset.data(), cs.inst_tri_offset.size() * 4); break;
+        case AKR_ARRAY_R2C: set(s->r2c, 64); break;
+        case AKR_ARRAY_C2W: set(s->c2w, 64); break;
+        default: return fail(AKR_ERR_INVALID_ARGUMENT, "akr_scene_get_array: unknown array id");
+    }
+    return AKR_OK;
+}
+
+AKR_API int32_t akr_film_create(akr_context* ctx, uint32_t width, uint32_t height, akr_film** out) {
+    if (!ctx || !out || !width || !height) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_film_create: bad argument");
+    *out = nullptr;
+    return guarded([&] {
+        ctx->bind();
+        auto f = std::make_unique<akr_film>();
+        f->ctx = ctx;
+        f->width = width;
+        f->height = height;
+        f->own.alloc(f->n_floats() * sizeof(float));
+        f->data = f->own.as<float>();
+        HIP_CHECK(hipMemsetAsync(f->data, 0, f->n_floats() * sizeof(float), ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        *out = f.release();
+    });
+}
+AKR_API int32_t akr_film_wrap(akr_context* ctx, uint32_t width, uint32_t height, void* device_ptr, akr_film** out) {
+    if (!ctx || !out || !width || !height || !device_ptr) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_film_wrap: bad argument");
+    auto* f = new (std::nothrow) akr_film();
+    if (!f) return fail(AKR_ERR_OUT_OF_MEMORY, "out of host memory");
+    f->ctx = ctx;
+    f->width = width;
+    f->height = height;
+    f->data = (float*)device_ptr;
+    *out = f;
+    return AKR_OK;
+}
+AKR_API int32_t akr_film_destroy(akr_film* film) {
+    if (!film) return AKR_OK;
+    return guarded([&] {
+        (void)hipSetDevice(film->ctx->device);
+        delete film;
+    });
+}
+AKR_API int32_t akr_film_clear(akr_film* f) {
+    if (!f) return fail(AKR_ERR_INVALID_ARGUMENT, "film is NULL");
+    return guarded([&] {
+        f->ctx->bind();
+        HIP_CHECK(hipMemsetAsync(f->data, 0, f->n_floats() * sizeof(float), f->ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
+    });
+}
+AKR_API int32_t akr_film_read(akr_film* f, float* dst) {
+    if (!f || !dst) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_film_read: NULL argument");
+    return guarded([&] {
+        f->ctx->bind();
+        HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
+        HIP_CHECK(hipMemcpy(dst, f->data, f->n_floats() * sizeof(float), hipMemcpyDeviceToHost));
+    });
+}
+AKR_API int32_t akr_film_write(akr_film* f, const float* src) {
+    if (!f || !src) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_film_write: NULL argument");
+    return guarded([&] {
+        f->ctx->bind();
+        HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
+        HIP_CHECK(hipMemcpy(f->data, src, f->n_floats() * sizeof(float), hipMemcpyHostToDevice));
+    });
+}
+AKR_API int32_t akr_film_resolve(akr_film* f, float* dst_rgb) {
+    if (!f || !dst_rgb) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_film_resolve: NULL argument");
+    return guarded([&] {
+        f->ctx->bind();
+        uint64_t n = (uint64_t)f->width * f->height;
+        DevBuf tmp;
+        tmp.alloc(3 * n * sizeof(float));
+        HIP_CHECK(launch_film_resolve(f->data, n, tmp.as<float>(), f->ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
+        HIP_CHECK(hipMemcpy(dst_rgb, tmp.p, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+    });
+}
+AKR_API int32_t akr_film_device_ptr(akr_film* f, void** ptr, uint64_t* bytes) {
+    if (!f) return fail(AKR_ERR_INVALID_ARGUMENT, "film is NULL");
+    if (ptr) *ptr = f->data;
+    if (bytes) *bytes = f->n_floats() * sizeof(float);
+    return AKR_OK;
+}
+
+AKR_API int32_t akr_pt_config_default(akr_pt_config* c) {
+    if (!c) return fail(AKR_ERR_INVALID_ARGUMENT, "config is NULL");
+    std::memset(c, 0, sizeof *c);
+    c->spp = 256; c->max_depth = 7; c->rr_depth = 5; c->spp_per_pass = 64;  // pt.rs:930-944
+    c->use_nee = 1; c->indirect_only = 0; c->force_diffuse = 0;
+    c->debug_depth = -1;
+    c->filter_type = AKR_FILTER_GAUSSIAN; c->filter_radius = 1.5f;          // film.rs:50-54
+    c->sampler_type = AKR_SAMPLER_INDEPENDENT; c->sampler_seed = 0;         // sampler/mod.rs:290-294
+    c->shard_rank = 0; c->shard_count = 1; c->tile_w = 32; c->tile_h = 32;
+    return AKR_OK;
+}
+AKR_API int32_t akr_pt_config_from_json(const char* text, akr_pt_config* cfg, char* film_out, uint32_t film_out_len) {
+    if (!text || !cfg) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_pt_config_from_json: NULL argument");
+    return guarded([&] {
+        std::string out;
+        parse_method_json(text, cfg, &out);
+        if (film_out && film_out_len) std::snprintf(film_out, film_out_len, "%s", out.c_str());
+    });
+}
+
+AKR_API int32_t akr_pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_config* cfg, akr_film* film, akr_pt_session** out) {
+    if (!ctx || !scene || !cfg || !film || !out) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_pt_begin: NULL argument");
+    *out = nullptr;
+    if (scene->ctx != ctx) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_pt_begin: the scene was not created on this context (host-only scenes cannot render)");
+    return guarded([&] {
+        validate_config(*cfg);
+        if (film->width != scene->flat.camera.width || film->height != scene->flat.camera.height)
+            throw std::invalid_argument("film resolution does not match the scene camera (pt.rs:1072-1073)");
+        ctx->bind();
+        auto se = std::make_unique<akr_pt_session>();
+        se->ctx = ctx;
+        se->scene = scene;
+        se->film = film;
+        se->cfg = *cfg;
+        const uint64_t n = (uint64_t)film->width * film->height;
+        // init_pcg32_buffer_with_seed (sampler/mod.rs:148-160): host StdRng(seed) u64 per pixel, device new_seq_offset
+        std::vector<uint64_t> seeds(n);
+        StdRng rng(cfg->sampler_seed);
+        for (auto& v : seeds) v = rng.next_u64();
+        DevBuf dseeds;
+        dseeds.upload(seeds);
+        se->states.alloc(n * sizeof(Pcg32));
+        HIP_CHECK(launch_init_pcg32(dseeds.as<uint64_t>(), se->states.p, n, ctx->stream));
+        se->counters.alloc(8 * sizeof(uint64_t));
+        HIP_CHECK(hipMemsetAsync(se->counters.p, 0, 8 * sizeof(uint64_t), ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        *out = se.release();
+    });
+}
+AKR_API int32_t akr_pt_passes(akr_pt_session* se, uint32_t n_passes, int32_t blocking, uint32_t* spp_done) {
+    if (!se) return fail(AKR_ERR_INVALID_ARGUMENT, "session is NULL");
+    return guarded([&] {
+        se->ctx->bind();
+        for (uint32_t k = 0; k < n_passes && se->spp_done < se->cfg.spp; k++) {
+            uint32_t cur = std::min(se->cfg.spp - se->spp_done, se->cfg.spp_per_pass);  // pt.rs:1127
+            fill_params(se, cur);
+            hipEvent_t e0, e1;
+            HIP_CHECK(hipEventCreate(&e0));
+            HIP_CHECK(hipEventCreate(&e1));
+            HIP_CHECK(hipEventRecord(e0, se->ctx->stream));
+            HIP_CHECK(launch_pt_pass(se->params, se->ctx->stream));
+            HIP_CHECK(hipEventRecord(e1, se->ctx->stream));
+            se->events.emplace_back(e0, e1);
+            se->spp_done += cur;
+            se->n_launches++;
+        }
+        if (blocking) HIP_CHECK(hipStreamSynchronize(se->ctx->stream));
+        if (spp_done) *spp_done = se->spp_done;
+    });
+}
+AKR_API int32_t akr_pt_read_sampler_states(akr_pt_session* se, uint64_t* dst) {
+    if (!se || !dst) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_pt_read_sampler_states: NULL argument");
+    return guarded([&] {
+        se->ctx->bind();
+        HIP_CHECK(hipStreamSynchronize(se->ctx->stream));
+        HIP_CHECK(hipMemcpy(dst, se->states.p, se->states.bytes, hipMemcpyDeviceToHost));
+    });
+}
+AKR_API int32_t akr_pt_end(akr_pt_session* se, akr_pt_stats* stats) {
+    if (!se) return AKR_OK;
+    int32_t rc = guarded([&] {
+        se->ctx->bind();
+        HIP_CHECK(hipStreamSynchronize(se->ctx->stream));
+        uint64_t c[8];
+        HIP_CHECK(hipMemcpy(c, se->counters.p, sizeof c, hipMemcpyDeviceToHost));
+        double ms = 0.0;
+        for (auto& ev : se->events) {
+            float t = 0.0f;
+            HIP_CHECK(hipEventElapsedTime(&t, ev.first, ev.second));
+            ms += t;
+        }
+        if (stats) {
+            stats->n_samples = c[0];
+            stats->n_closest = c[1];
+            stats->n_shadow = c[2];
+            stats->n_shaded = c[3];
+            stats->n_node_visits = c[4];
+            stats->n_tri_tests = c[5];
+            stats->kernel_ms = ms;
+            stats->n_launches = se->n_launches;
+            stats->_pad = (uint32_t)c[6];  // non-zero = a traversal stack overflowed (results invalid)
+        }
+        if (c[6] != 0) throw std::runtime_error("BVH traversal stack overflow: the render is incomplete");
+    });
+    for (auto& ev : se->events) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    (void)hipSetDevice(se->ctx->device);
+    delete se;
+    return rc;
+}
+AKR_API int32_t akr_pt_render(akr_context* ctx, akr_scene* scene, const akr_pt_config* cfg, akr_film* film, akr_pt_stats* stats) {
+    akr_pt_session* se = nullptr;
+    int32_t rc = akr_pt_begin(ctx, scene, cfg, film, &se);
+    if (rc != AKR_OK) return rc;
+    uint32_t n_passes = (cfg->spp + cfg->spp_per_pass - 1) / cfg->spp_per_pass;
+    rc = akr_pt_passes(se, n_passes, 1, nullptr);
+    std::string err = g_last_error;
+    int32_t rc2 = akr_pt_end(se, stats);
+    if (rc != AKR_OK) {
+        g_last_error = err;
+        return rc;
+    }
+    return rc2;
+}
+
+// ------------------------------------------------------------------------------------------------ host KAT hooks
+AKR_API int32_t akr_host_stdrng_u64(uint64_t seed, uint32_t n, uint64_t* out) {
+    if (!out) return fail(AKR_ERR_INVALID_ARGUMENT, "out is NULL");
+    StdRng rng(seed);
+    for (uint32_t i = 0; i < n; i++) out[i] = rng.next_u64();
+    return AKR_OK;
+}
+AKR_API int32_t akr_host_chacha_block(const uint32_t* key8, uint64_t counter, uint64_t stream, int32_t rounds, uint32_t* out16) {
+    if (!key8 || !out16) return fail(AKR_ERR_INVALID_ARGUMENT, "NULL argument");
+    StdRng::chacha_block(key8, counter, stream, rounds, out16);
+    return AKR_OK;
+}
+AKR_API int32_t akr_host_pcg32_states(uint64_t seed, uint64_t n, uint64_t* out2n) {
+    if (!out2n) return fail(AKR_ERR_INVALID_ARGUMENT, "out is NULL");
+    StdRng rng(seed);
+    for (uint64_t i = 0; i < n; i++) {
+        Pcg32 p = pcg_new_seq_offset(i, rng.next_u64());
+        out2n[2 * i] = p.state;
+        out2n[2 * i + 1] = p.inc;
+    }
+    return AKR_OK;
+}
+AKR_API int32_t akr_host_pcg_start(uint64_t* state, uint64_t inc) {
+    if (!state) return fail(AKR_ERR_INVALID_ARGUMENT, "state is NULL");
+    Pcg32 p{*state, inc};
+    pcg_start(p, pcg_start_constants());
+    *state = p.state;
+    return AKR_OK;
+}
+AKR_API int32_t akr_host_alias_table(const float* weights, uint32_t n, uint32_t* j, float* t, float* pdf) {
+    if (!weights || !j || !t || !pdf || n == 0) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_host_alias_table: bad argument");
+    return guarded([&] {
+        std::vector<float> w(weights, weights + n), p;
+        std::vector<AliasEntry> e;
+        build_alias_table(w, e, p);
+        for (uint32_t i = 0; i < n; i++) { j[i] = e[i].j; t[i] = e[i].t; pdf[i] = p[i]; }
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ probes
+AKR_API int32_t akr_probe_math(akr_context* ctx, uint32_t n, const float* x, float* s, float* c, float* l) {
+    if (!ctx || !x || !s || !c || !l) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_probe_math: NULL argument");
+    return guarded([&] {
+        ctx->bind();
+        DevBuf dx, ds, dc, dl;
+        std::vector<float> xv(x, x + n);
+        dx.upload(xv);
+        ds.alloc(n * 4); dc.alloc(n * 4); dl.alloc(n * 4);
+        if (n) HIP_CHECK(launch_probe_math(n, dx.as<float>(), ds.as<float>(), dc.as<float>(), dl.as<float>(), ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (n) {
+            HIP_CHECK(hipMemcpy(s, ds.p, n * 4, hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(c, dc.p, n * 4, hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(l, dl.p, n * 4, hipMemcpyDeviceToHost));
+        }
+    });
+}
+AKR_API int32_t akr_probe_bsdf(akr_context* ctx, const akr_material_desc* m, const float* table, int32_t mode, const float* wo, uint32_t n,
+                               const float* in, float* out) {
+    if (!ctx || !m || !wo || !in || !out) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_probe_bsdf: NULL argument");
+    return guarded([&] {
+        ctx->bind();
+        std::vector<DMaterial> dm(1, fold_material(*m));
+        DevBuf dmat, dtab, din, dout;
+        dmat.upload(dm);
+        std::vector<float> tab(4096, 0.0f);
+        if (table) tab.assign(table, table + 4096);
+        dtab.upload(tab);
+        std::vector<float> inv(in, in + 3ull * n);
+        din.upload(inv);
+        size_t out_n = (mode == 0 ? 4ull : 8ull) * n;
+        dout.alloc(out_n * 4);
+        if (n) HIP_CHECK(launch_probe_bsdf(dmat.as<DMaterial>(), dtab.as<float>(), mode, wo, n, din.as<float>(), dout.as<float>(), ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (n) HIP_CHECK(hipMemcpy(out, dout.p, out_n * 4, hipMemcpyDeviceToHost));
+    });
+}
+static PtParams probe_params(akr_scene* s) {
+    PtParams p;
+    std::memset(&p, 0, sizeof p);
+    p.sc = s->dscene;
+    return p;
+}
+AKR_API int32_t akr_probe_intersect(akr_context* ctx, akr_scene* scene, uint32_t n, const float* rays, uint32_t* hit_inst_prim, float* bary) {
+    if (!ctx || !scene || !rays || !hit_inst_prim || !bary) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_probe_intersect: NULL argument");
+    return guarded([&] {
+        ctx->bind();
+        DevBuf dr, dout, db;
+        std::vector<float> rv(rays, rays + 8ull * n);
+        dr.upload(rv);
+        dout.alloc(3ull * n * 4);
+        db.alloc(2ull * n * 4);
+        if (n) HIP_CHECK(launch_probe_intersect(probe_params(scene), n, dr.as<float>(), dout.as<uint32_t>(), db.as<float>(), ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (n) {
+            HIP_CHECK(hipMemcpy(hit_inst_prim, dout.p, 3ull * n * 4, hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(bary, db.p, 2ull * n * 4, hipMemcpyDeviceToHost));
+        }
+    });
+}
+AKR_API int32_t akr_probe_surface_interaction(akr_context* ctx, akr_scene* scene, uint32_t n, const uint32_t* inst_prim, const float* bary,
+                                              float* out) {
+    if (!ctx || !scene || !inst_prim || !bary || !out) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_probe_surface_interaction: NULL argument");
+    return guarded([&] {
+        ctx->bind();
+        for (uint32_t i = 0; i < n; i++) {
+            uint32_t inst = inst_prim[2 * i], prim = inst_prim[2 * i + 1];
+            if (inst >= scene->flat.instances.size() || prim >= scene->flat.meshes[scene->flat.instances[inst].mesh].n_triangles())
+                throw std::invalid_argument("akr_probe_surface_interaction: (inst, prim) out of range");
+        }
+        DevBuf dip, db, dout;
+        std::vector<uint32_t> ipv(inst_prim, inst_prim + 2ull * n);
+        std::vector<float> bv(bary, bary + 2ull * n);
+        dip.upload(ipv);
+        db.upload(bv);
+        dout.alloc(19ull * n * 4);
+        if (n) HIP_CHECK(launch_probe_si(probe_params(scene), n, dip.as<uint32_t>(), db.as<float>(), dout.as<float>(), ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (n) HIP_CHECK(hipMemcpy(out, dout.p, 19ull * n * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+}  // extern "C"

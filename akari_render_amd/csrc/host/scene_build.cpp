@@ -1,0 +1,440 @@
+// scene_build.cpp -- host-side scene compiler: FlatScene -> CompiledScene.
+//
+// Mirrors what the reference does between "buffers resolved" and "kernel can run":
+//   MeshAggregate::new            crates/akari_render/src/mesh.rs:259-348   (instance table, transform_det)
+//   surface_interaction, per-triangle part   mesh.rs:499-653                (folded here, once per triangle)
+//   svm compile + constant eval   svm/compiler.rs:116-337, svm/eval.rs:97-269, svm/surface/principled.rs:23-131
+//   light discovery               load.rs:308-444  (power estimate, alias tables, light list)
+//   AliasTable::new               util/distribution.rs:35-78
+// All f32 arithmetic here uses the same akr:: helpers as the kernels (this file is compiled with
+// -ffp-contract=off too), so a quantity folded on the host has the bits the device would have computed.
+#include "scene_build.h"
+
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <stdexcept>
+
+#include "../device/dgeom.h"
+
+namespace akr {
+
+FlatScene FlatScene::from_desc(const akr_scene_desc& d) {
+    FlatScene s;
+    if ((d.n_meshes && !d.meshes) || (d.n_instances && !d.instances) || (d.n_materials && !d.materials))
+        throw std::invalid_argument("akr_scene_desc: null array with non-zero count");
+    s.meshes.resize(d.n_meshes);
+    for (uint32_t i = 0; i < d.n_meshes; i++) {
+        const akr_mesh_desc& m = d.meshes[i];
+        if (!m.vertices || !m.indices || m.n_triangles == 0) throw std::invalid_argument("akr_mesh_desc: empty mesh");
+        HostMesh& h = s.meshes[i];
+        h.vertices.assign(m.vertices, m.vertices + 3ull * m.n_vertices);
+        h.indices.assign(m.indices, m.indices + 3ull * m.n_triangles);
+        for (uint32_t idx : h.indices)
+            if (idx >= m.n_vertices) throw std::invalid_argument("akr_mesh_desc: vertex index out of range");
+        if (m.uvs) h.uvs.assign(m.uvs, m.uvs + 6ull * m.n_triangles);
+        if (m.normals) h.normals.assign(m.normals, m.normals + 9ull * m.n_triangles);
+        if (m.tangents) h.tangents.assign(m.tangents, m.tangents + 9ull * m.n_triangles);
+        if (m.material_slots) h.slots.assign(m.material_slots, m.material_slots + m.n_triangles);
+    }
+    s.materials.assign(d.materials, d.materials + d.n_materials);
+    s.instances.resize(d.n_instances);
+    for (uint32_t i = 0; i < d.n_instances; i++) {
+        const akr_instance_desc& in = d.instances[i];
+        if (in.mesh >= d.n_meshes) throw std::invalid_argument("akr_instance_desc: mesh index out of range");
+        if (in.n_materials == 0 || !in.materials) throw std::invalid_argument("akr_instance_desc: no materials");
+        HostInstance& h = s.instances[i];
+        h.mesh = in.mesh;
+        h.materials.assign(in.materials, in.materials + in.n_materials);
+        for (uint32_t m : h.materials)
+            if (m >= d.n_materials) throw std::invalid_argument("akr_instance_desc: material index out of range");
+        std::memcpy(h.transform, in.transform, sizeof h.transform);
+    }
+    s.camera = d.camera;
+    if (d.camera.width == 0 || d.camera.height == 0) throw std::invalid_argument("akr_camera_desc: zero resolution");
+    if (d.ggx_dielectric_table) s.ggx_table.assign(d.ggx_dielectric_table, d.ggx_dielectric_table + 4096);
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------ materials
+static vec3 v3(const float* p) { return mk3(p[0], p[1], p[2]); }
+
+DMaterial fold_material(const akr_material_desc& m) {
+    DMaterial d;
+    std::memset(&d, 0, sizeof d);
+    d.kind = m.kind;
+    d.base_alpha = m.base_alpha;
+    vec3 color = v3(m.base_color);
+    d.color = color;
+    d.emission = v3(m.emission_color) * m.emission_strength;
+    d.nm_normal = mk3(0, 0, 1);
+    switch (m.kind) {
+        case AKR_MAT_PRINCIPLED: {  // principled.rs:23-131
+            d.metallic = m.metallic;
+            d.transmission = m.transmission_weight;
+            d.roughness = m.roughness;
+            d.eta = m.ior;
+            d.transmission_color = mk3(__builtin_sqrtf(color.x), __builtin_sqrtf(color.y), __builtin_sqrtf(color.z));
+            d.diffuse_refl = color * kInvPi;
+            d.spec_tint = v3(m.specular_tint);
+            float eta_s = m.ior, f0 = f0_from_ior(eta_s);
+            if (m.specular_ior_level != 0.5f) {
+                f0 *= 2.0f * m.specular_ior_level;
+                eta_s = ior_from_f0(f0);
+            }
+            d.f0 = f0;
+            d.eta_s = eta_s;
+            d.spec_color = d.spec_tint * f0;
+            d.coat_weight = m.coat_weight;
+            d.coat_roughness = m.coat_roughness;
+            d.coat_eta = m.coat_ior;
+            d.coat_scale = lerp3(mk3(1, 1, 1), v3(m.coat_tint), m.coat_weight);
+            d.alpha = mk2(max_f(m.roughness * m.roughness, 1e-4f), max_f(m.roughness * m.roughness, 1e-4f));
+            d.coat_alpha = mk2(max_f(m.coat_roughness * m.coat_roughness, 1e-4f), max_f(m.coat_roughness * m.coat_roughness, 1e-4f));
+            artistic_to_conductor(color, d.spec_tint, d.metal_n, d.metal_k);
+            uint32_t fl = 0;
+            if (f0 != 0.0f) fl |= MF_SPEC;
+            if (m.coat_weight != 0.0f) fl |= MF_COAT;
+            if (m.metallic < 1.0f - 1e-4f) fl |= MF_EVAL_BASE;
+            if (m.metallic > 1e-4f) fl |= MF_EVAL_METAL;
+            if (m.transmission_weight < 1.0f - 1e-4f) fl |= MF_EVAL_DIFF;
+            if (m.transmission_weight > 1e-4f) fl |= MF_EVAL_DIEL;
+            vec3 normal = mk3(-m.normal[0], -m.normal[1], m.normal[2]);  // principled.rs:203-205
+            if (!(normal.x == 0.0f && normal.y == 0.0f && normal.z == 0.0f)) {
+                fl |= MF_NORMAL_MAP;
+                d.nm_normal = normalize(normal);
+            }
+            d.flags = fl;
+            break;
+        }
+        case AKR_MAT_DIFFUSE:  // diffuse.rs:83-104
+            d.diffuse_refl = color * kInvPi;
+            d.emission = mk3(0, 0, 0);
+            break;
+        case AKR_MAT_GLASS:  // glass.rs:13-45
+            d.eta = m.ior;
+            d.roughness = m.roughness;
+            d.alpha = mk2(max_f(m.roughness * m.roughness, 1e-4f), max_f(m.roughness * m.roughness, 1e-4f));
+            d.emission = mk3(0, 0, 0);
+            d.base_alpha = 1.0f;
+            break;
+        case AKR_MAT_EMISSION:  // svm/mod.rs:114-123
+            d.base_alpha = 1.0f;
+            break;
+        default: throw std::invalid_argument("akr_material_desc: unknown kind");
+    }
+    if (d.emission.x != 0.0f || d.emission.y != 0.0f || d.emission.z != 0.0f) d.flags |= MF_EMISSIVE;
+    return d;
+}
+
+// ------------------------------------------------------------------------------------------------ alias table
+void build_alias_table(const std::vector<float>& weights, std::vector<AliasEntry>& table, std::vector<float>& pdf) {
+    const size_t n = weights.size();
+    if (n == 0) throw std::invalid_argument("alias table needs at least one weight");
+    float sum = 0.0f;
+    for (float w : weights) sum += w;
+    std::vector<float> prob(n);
+    for (size_t i = 0; i < n; i++) prob[i] = weights[i] / sum * (float)n;
+    std::deque<uint32_t> small, large;
+    for (size_t i = 0; i < n; i++) (prob[i] >= 1.0f ? large : small).push_back((uint32_t)i);
+    table.assign(n, AliasEntry{0, 0.0f});
+    while (!small.empty() && !large.empty()) {
+        uint32_t l = small.front(), g = large.front();
+        small.pop_front();
+        large.pop_front();
+        table[l].t = prob[l];
+        table[l].j = g;
+        prob[g] = (prob[g] + prob[l]) - 1.0f;
+        (prob[g] < 1.0f ? small : large).push_back(g);
+    }
+    while (!large.empty()) {
+        uint32_t g = large.front();
+        large.pop_front();
+        table[g] = AliasEntry{g, 1.0f};
+    }
+    while (!small.empty()) {
+        uint32_t l = small.front();
+        small.pop_front();
+        table[l] = AliasEntry{l, 1.0f};
+    }
+    pdf.resize(n);
+    for (size_t i = 0; i < n; i++) pdf[i] = weights[i] / sum;
+}
+
+// ------------------------------------------------------------------------------------------------ camera
+static void m4_mul(const float* a, const float* b, float* out) {  // out = a * b, column-major, un-fused
+    float r[16];
+    for (int c = 0; c < 4; c++)
+        for (int i = 0; i < 4; i++)
+            r[c * 4 + i] = ((a[0 * 4 + i] * b[c * 4 + 0] + a[1 * 4 + i] * b[c * 4 + 1]) + a[2 * 4 + i] * b[c * 4 + 2]) + a[3 * 4 + i] * b[c * 4 + 3];
+    std::memcpy(out, r, sizeof r);
+}
+static void m4_scale(float x, float y, float z, float* m) {
+    std::memset(m, 0, 64);
+    m[0] = x; m[5] = y; m[10] = z; m[15] = 1.0f;
+}
+static void m4_translate(float x, float y, float z, float* m) {
+    m4_scale(1, 1, 1, m);
+    m[12] = x; m[13] = y; m[14] = z;
+}
+void camera_matrices(const akr_camera_desc& cam, float r2c[16], float c2w[16], uint32_t* c2w_identity) {
+    float m[16], s[16];
+    float fw = (float)cam.width, fh = (float)cam.height;
+    m4_scale(1, 1, 1, m);
+    m4_scale(1.0f / fw, 1.0f / fh, 1.0f, s); m4_mul(s, m, m);
+    m4_scale(2.0f, 2.0f, 1.0f, s); m4_mul(s, m, m);
+    m4_translate(-1.0f, -1.0f, 0.0f, s); m4_mul(s, m, m);
+    m4_scale(1.0f, -1.0f, 1.0f, s); m4_mul(s, m, m);
+    float t = tanf(cam.fov / 2.0f);
+    if (cam.width > cam.height) m4_scale(t, t * fh / fw, 1.0f, s); else m4_scale(t * fw / fh, t, 1.0f, s);
+    m4_mul(s, m, m);
+    m4_translate(0.0f, 0.0f, -1.0f, s); m4_mul(s, m, m);
+    std::memcpy(r2c, m, 64);
+    std::memcpy(c2w, cam.c2w, 64);
+    uint32_t ident = 1;  // glam abs_diff_eq(IDENTITY, 1e-4), geometry.rs:212-218
+    for (int i = 0; i < 16; i++) {
+        float id = (i % 5 == 0) ? 1.0f : 0.0f;
+        if (!(std::fabs(cam.c2w[i] - id) <= 1e-4f)) ident = 0;
+    }
+    *c2w_identity = ident;
+}
+
+PcgStartConsts pcg_start_constants() {
+    // run the reference's advance() loop (sampler/mod.rs:115-131) symbolically for delta = 16384 = 1 << 14:
+    // state' = acc_mult * state + acc_plus with acc_mult = cur_mult_14, acc_plus = cur_mult_14 + cur_plus_14,
+    // cur_plus_14 = inc * prod_{k<14}(cur_mult_k + 1)
+    uint64_t cur_mult = kPcgMult, c = 1;
+    for (int k = 0; k < 14; k++) {
+        c = (cur_mult + 1) * c;
+        cur_mult *= cur_mult;
+    }
+    return PcgStartConsts{cur_mult, c};
+}
+
+// ------------------------------------------------------------------------------------------------ geometry
+struct Xform {
+    vec3 c0, c1, c2, t, k0, k1, k2;
+    float det, inv_det;
+};
+static Xform make_xform(const float* m) {
+    Xform x;
+    x.c0 = mk3(m[0], m[1], m[2]);
+    x.c1 = mk3(m[4], m[5], m[6]);
+    x.c2 = mk3(m[8], m[9], m[10]);
+    x.t = mk3(m[12], m[13], m[14]);
+    x.k0 = cross(x.c1, x.c2);
+    x.k1 = cross(x.c2, x.c0);
+    x.k2 = cross(x.c0, x.c1);
+    x.det = dot(x.c0, cross(x.c1, x.c2));  // MeshInstance.transform_det, mesh.rs:309-310
+    x.inv_det = 1.0f / x.det;
+    return x;
+}
+static vec3 xf_normal(const Xform& x, vec3 n) {  // (M^T)^-1 n
+    vec3 r = (x.k0 * n.x + x.k1 * n.y) + x.k2 * n.z;
+    return r * x.inv_det;
+}
+static vec3 ld3(const std::vector<float>& v, size_t i) { return mk3(v[3 * i], v[3 * i + 1], v[3 * i + 2]); }
+
+// Woop's precomputed transform, in double, from the f32 world-space vertices.
+static void woop_precompute(vec3 A, vec3 B, vec3 C, float* w) {
+    double ax = A.x, ay = A.y, az = A.z;
+    double e1x = (double)B.x - ax, e1y = (double)B.y - ay, e1z = (double)B.z - az;
+    double e2x = (double)C.x - ax, e2y = (double)C.y - ay, e2z = (double)C.z - az;
+    double nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
+    double det = nx * nx + ny * ny + nz * nz;
+    if (!(det > 0.0)) {
+        for (int i = 0; i < 12; i++) w[i] = 0.0f;
+        return;
+    }
+    double r0x = (e2y * nz - e2z * ny) / det, r0y = (e2z * nx - e2x * nz) / det, r0z = (e2x * ny - e2y * nx) / det;
+    double r1x = (ny * e1z - nz * e1y) / det, r1y = (nz * e1x - nx * e1z) / det, r1z = (nx * e1y - ny * e1x) / det;
+    double r2x = nx / det, r2y = ny / det, r2z = nz / det;
+    w[0] = (float)r0x; w[1] = (float)r0y; w[2] = (float)r0z; w[3] = (float)(-(r0x * ax + r0y * ay + r0z * az));
+    w[4] = (float)r1x; w[5] = (float)r1y; w[6] = (float)r1z; w[7] = (float)(-(r1x * ax + r1y * ay + r1z * az));
+    w[8] = (float)r2x; w[9] = (float)r2y; w[10] = (float)r2z; w[11] = (float)(-(r2x * ax + r2y * ay + r2z * az));
+}
+
+void build_bvh4(const std::vector<float>& tri_bounds, uint32_t n_tris, float pad, std::vector<uint32_t>& order, std::vector<float>& nodes);
+
+void compile_scene(const FlatScene& flat, CompiledScene& out) {
+    const size_t n_inst = flat.instances.size();
+    out = CompiledScene();
+    out.materials.reserve(flat.materials.size());
+    for (const auto& m : flat.materials) {
+        DMaterial d = fold_material(m);
+        if ((d.kind == MAT_PRINCIPLED || d.kind == MAT_DIFFUSE) && d.base_alpha < 1.0f) out.has_alpha = true;
+        if (d.kind == MAT_PRINCIPLED && (d.flags & (MF_SPEC | MF_COAT))) out.needs_ggx_table = true;
+        out.materials.push_back(d);
+    }
+    // instance table
+    std::vector<Xform> xf(n_inst);
+    out.inst.assign(32 * n_inst, 0.0f);
+    out.inst_tri_offset.resize(n_inst + 1);
+    uint32_t n_tris = 0;
+    bool any_normals = false;
+    for (size_t i = 0; i < n_inst; i++) {
+        const HostInstance& in = flat.instances[i];
+        xf[i] = make_xform(in.transform);
+        const Xform& x = xf[i];
+        float* r = &out.inst[32 * i];
+        r[0] = x.c0.x; r[1] = x.c0.y; r[2] = x.c0.z; r[3] = x.det;
+        r[4] = x.c1.x; r[5] = x.c1.y; r[6] = x.c1.z;
+        r[8] = x.c2.x; r[9] = x.c2.y; r[10] = x.c2.z;
+        r[12] = x.t.x; r[13] = x.t.y; r[14] = x.t.z;
+        r[16] = x.k0.x; r[17] = x.k0.y; r[18] = x.k0.z; r[19] = x.inv_det;
+        r[20] = x.k1.x; r[21] = x.k1.y; r[22] = x.k1.z;
+        r[24] = x.k2.x; r[25] = x.k2.y; r[26] = x.k2.z;
+        out.inst_tri_offset[i] = n_tris;
+        n_tris += flat.meshes[in.mesh].n_triangles();
+        if (!flat.meshes[in.mesh].normals.empty() || !flat.meshes[in.mesh].tangents.empty()) any_normals = true;
+    }
+    out.inst_tri_offset[n_inst] = n_tris;
+    out.n_tris = n_tris;
+    out.woop.assign(12ull * n_tris, 0.0f);
+    out.shade.assign(32ull * n_tris, 0.0f);
+    if (any_normals) out.normals.assign(24ull * n_tris, 0.0f);  // 3 float4 normals + 3 float4 tangents per triangle
+    std::vector<float> bounds(6ull * n_tris);
+    std::vector<float> tri_power(n_tris, 0.0f);
+    for (int a = 0; a < 3; a++) { out.scene_lo[a] = INFINITY; out.scene_hi[a] = -INFINITY; }
+
+    for (size_t i = 0; i < n_inst; i++) {
+        const HostInstance& in = flat.instances[i];
+        const HostMesh& g = flat.meshes[in.mesh];
+        const Xform& x = xf[i];
+        for (uint32_t prim = 0; prim < g.n_triangles(); prim++) {
+            const uint32_t gid = out.inst_tri_offset[i] + prim;
+            // material: mats[slots[prim]] when the slot buffer has more than one entry, else mats[0] (mesh.rs:508-521)
+            uint32_t slot = (g.slots.size() > 1) ? g.slots[prim] : 0;
+            if (slot >= in.materials.size()) throw std::invalid_argument("material slot out of range for instance");
+            uint32_t material = in.materials[slot];
+            vec3 v0 = ld3(g.vertices, g.indices[3 * prim]), v1 = ld3(g.vertices, g.indices[3 * prim + 1]), v2 = ld3(g.vertices, g.indices[3 * prim + 2]);
+            // mesh.rs:527-535
+            vec3 ngc = cross(v1 - v0, v2 - v0);
+            float len = length(ngc);
+            float area_local = len * 0.5f;
+            vec3 ng_local = div_s(ngc, len);
+            vec2 uv0 = mk2(0.0f, 0.0f), uv1 = mk2(1.0f, 0.0f), uv2 = mk2(1.0f, 0.1f);  // mesh.rs:541-546
+            if (!g.uvs.empty()) {
+                uv0 = mk2(g.uvs[6 * prim + 0], g.uvs[6 * prim + 1]);
+                uv1 = mk2(g.uvs[6 * prim + 2], g.uvs[6 * prim + 3]);
+                uv2 = mk2(g.uvs[6 * prim + 4], g.uvs[6 * prim + 5]);
+            }
+            // default tangent = dpdu (mesh.rs:572-589)
+            vec3 tt_local = mk3(0, 0, 0);
+            {
+                vec2 duv02 = mk2(uv0.x - uv2.x, uv0.y - uv2.y), duv12 = mk2(uv1.x - uv2.x, uv1.y - uv2.y);
+                vec3 dp02 = v0 - v2, dp12 = v1 - v2;
+                float determinant = difference_of_products(duv02.x, duv12.y, duv02.y, duv12.x);
+                bool degenerate_uv = abs_f(determinant) < 1e-8f;
+                if (!degenerate_uv) {
+                    float inv_det = 1.0f / determinant;
+                    tt_local.x = difference_of_products(duv12.y, dp02.x, duv02.y, dp12.x) * inv_det;
+                    tt_local.y = difference_of_products(duv12.y, dp02.y, duv02.y, dp12.y) * inv_det;
+                    tt_local.z = difference_of_products(duv12.y, dp02.z, duv02.y, dp12.z) * inv_det;
+                }
+                if (degenerate_uv || length2(tt_local) == 0.0f) tt_local = frame_from_n(ng_local).t;
+            }
+            uint32_t tri_flags = 0;
+            bool tangents_ok = false;
+            if (!g.tangents.empty()) {  // mesh.rs:557-571: per-corner tangents are used only if all nine are finite
+                tangents_ok = true;
+                for (int k = 0; k < 9; k++) tangents_ok = tangents_ok && is_finite(g.tangents[9 * prim + k]);
+            }
+            // world space (mesh.rs:608-635)
+            vec3 tt = xf_vector(x.c0, x.c1, x.c2, tt_local);
+            vec3 c = xf_vector(x.c0, x.c1, x.c2, ng_local);
+            vec3 ng = normalize(xf_normal(x, ng_local));
+            float area = (area_local == 0.0f || x.det == 0.0f) ? 0.0f : abs_f(area_local * x.det / dot(ng, c));
+            Frame fr = (tt.x != 0.0f || tt.y != 0.0f || tt.z != 0.0f) ? frame_from_n_t(ng, tt) : frame_from_n(ng);
+            if (!g.normals.empty()) tri_flags |= TRI_HAS_NORMALS;
+            if (tangents_ok) tri_flags |= 2u;  // TRI_HAS_TANGENTS
+            float* r = &out.shade[32ull * gid];
+            r[0] = v0.x; r[1] = v0.y; r[2] = v0.z; r[3] = uv0.x;
+            r[4] = v1.x; r[5] = v1.y; r[6] = v1.z; r[7] = uv0.y;
+            r[8] = v2.x; r[9] = v2.y; r[10] = v2.z; r[11] = uv1.x;
+            r[12] = ng.x; r[13] = ng.y; r[14] = ng.z; r[15] = uv1.y;
+            r[16] = fr.t.x; r[17] = fr.t.y; r[18] = fr.t.z; r[19] = uv2.x;
+            r[20] = fr.s.x; r[21] = fr.s.y; r[22] = fr.s.z; r[23] = uv2.y;
+            r[24] = area; r[25] = u2f(material); r[26] = u2f((uint32_t)i); r[27] = u2f(0xffffffffu);
+            r[28] = tt.x; r[29] = tt.y; r[30] = tt.z; r[31] = u2f(tri_flags);
+            if (any_normals) {
+                float* nr = &out.normals[24ull * gid];
+                for (int k = 0; k < 3; k++) {
+                    vec3 nk = g.normals.empty() ? ng_local : mk3(g.normals[9 * prim + 3 * k], g.normals[9 * prim + 3 * k + 1], g.normals[9 * prim + 3 * k + 2]);
+                    nr[4 * k] = nk.x; nr[4 * k + 1] = nk.y; nr[4 * k + 2] = nk.z;
+                    if (tangents_ok) {
+                        nr[12 + 4 * k] = g.tangents[9 * prim + 3 * k]; nr[12 + 4 * k + 1] = g.tangents[9 * prim + 3 * k + 1];
+                        nr[12 + 4 * k + 2] = g.tangents[9 * prim + 3 * k + 2];
+                    }
+                }
+            }
+            // world-space triangle for the intersector
+            vec3 A = xf_point(x.c0, x.c1, x.c2, x.t, v0), B = xf_point(x.c0, x.c1, x.c2, x.t, v1), C = xf_point(x.c0, x.c1, x.c2, x.t, v2);
+            woop_precompute(A, B, C, &out.woop[12ull * gid]);
+            float* bb = &bounds[6ull * gid];
+            bb[0] = min_f(min_f(A.x, B.x), C.x); bb[1] = min_f(min_f(A.y, B.y), C.y); bb[2] = min_f(min_f(A.z, B.z), C.z);
+            bb[3] = max_f(max_f(A.x, B.x), C.x); bb[4] = max_f(max_f(A.y, B.y), C.y); bb[5] = max_f(max_f(A.z, B.z), C.z);
+            for (int a = 0; a < 3; a++) {
+                out.scene_lo[a] = min_f(out.scene_lo[a], bb[a]);
+                out.scene_hi[a] = max_f(out.scene_hi[a], bb[3 + a]);
+            }
+            // emission power estimate, load.rs:312-343: 16 x (max(emission) * prim_area) / 16. For the folded
+            // (constant) emitters supported here the emission does not depend on the sampled point or direction,
+            // so the RNG of the reference kernel does not influence the value; the f32 accumulation is kept.
+            const DMaterial& dm = out.materials[material];
+            vec3 e = (dm.kind == MAT_PRINCIPLED || dm.kind == MAT_EMISSION) ? dm.emission : mk3(0, 0, 0);
+            float acc = 0.0f;
+            for (int k = 0; k < 16; k++) acc += max3(e) * area;
+            tri_power[gid] = acc / 16.0f;
+        }
+    }
+    // lights, load.rs:345-444
+    std::vector<float> light_weights;
+    for (size_t i = 0; i < n_inst; i++) {
+        const HostInstance& in = flat.instances[i];
+        bool any = false;  // has_potential_surface_emission, load.rs:94-127
+        for (uint32_t mi : in.materials) {
+            const akr_material_desc& m = flat.materials[mi];
+            if (m.kind != AKR_MAT_PRINCIPLED && m.kind != AKR_MAT_EMISSION) { any = true; continue; }
+            float power = max_f(max_f(m.emission_color[0], m.emission_color[1]), m.emission_color[2]);
+            if (!(power * m.emission_strength == 0.0f)) any = true;
+        }
+        if (!any) continue;
+        uint32_t first = out.inst_tri_offset[i], count = out.inst_tri_offset[i + 1] - first;
+        std::vector<float> powers(tri_power.begin() + first, tri_power.begin() + first + count);
+        float total = 0.0f;
+        for (float pw : powers) total += pw;
+        if (total > 1e-4f) {
+            uint32_t light_id = (uint32_t)out.light_inst.size();
+            out.light_inst.push_back((uint32_t)i);
+            out.light_power.push_back(total);
+            light_weights.push_back(total);
+            std::vector<AliasEntry> ent;
+            std::vector<float> pdf;
+            build_alias_table(powers, ent, pdf);
+            out.light_tri_offset.push_back((uint32_t)out.area_entries.size());
+            out.light_n_tris.push_back(count);
+            out.area_entries.insert(out.area_entries.end(), ent.begin(), ent.end());
+            out.area_pdf.insert(out.area_pdf.end(), pdf.begin(), pdf.end());
+            for (uint32_t k = 0; k < count; k++) out.shade[32ull * (first + k) + 27] = u2f(light_id);
+        }
+    }
+    out.n_lights = (uint32_t)out.light_inst.size();
+    if (out.n_lights > 0) build_alias_table(light_weights, out.light_entries, out.light_pdf);
+
+    // acceleration structure: tiny scenes are intersected exhaustively from the scalar cache, others get a BVH4
+    const uint32_t kExhaustiveMax = 64;
+    if (n_tris > kExhaustiveMax) {
+        float diag2 = 0.0f;
+        for (int a = 0; a < 3; a++) diag2 += sqr(out.scene_hi[a] - out.scene_lo[a]);
+        float pad = 4e-6f * __builtin_sqrtf(diag2);
+        std::vector<uint32_t> order;
+        build_bvh4(bounds, n_tris, pad, order, out.bvh_nodes);
+        std::vector<float> woop2(out.woop.size());
+        for (uint32_t k = 0; k < n_tris; k++) std::memcpy(&woop2[12ull * k], &out.woop[12ull * order[k]], 48);
+        out.woop.swap(woop2);
+        out.tri_gid = order;
+    }
+}
+
+}  // namespace akr

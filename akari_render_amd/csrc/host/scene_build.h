@@ -1,0 +1,72 @@
+// scene_build.h -- host side of the scene: the flat description (what load.rs resolves the scene graph to)
+// and its compiled, device-ready form.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../../include/akari_hip.h"
+#include "../kernels.h"
+
+namespace akr {
+
+struct HostMesh {
+    std::vector<float> vertices;     // 3 / vertex
+    std::vector<uint32_t> indices;   // 3 / triangle
+    std::vector<float> uvs;          // 6 / triangle or empty
+    std::vector<float> normals;      // 9 / triangle or empty
+    std::vector<float> tangents;     // 9 / triangle or empty
+    std::vector<uint32_t> slots;     // 1 / triangle or empty
+    uint32_t n_triangles() const { return (uint32_t)(indices.size() / 3); }
+};
+struct HostInstance {
+    uint32_t mesh = 0;
+    std::vector<uint32_t> materials;
+    float transform[16];
+};
+// Owning copy of an akr_scene_desc.
+struct FlatScene {
+    std::vector<HostMesh> meshes;
+    std::vector<HostInstance> instances;
+    std::vector<akr_material_desc> materials;
+    akr_camera_desc camera;
+    std::vector<float> ggx_table;  // 4096 or empty
+    static FlatScene from_desc(const akr_scene_desc& d);
+};
+
+// Output of the host-side scene compiler: plain arrays ready for hipMemcpy.
+struct CompiledScene {
+    uint32_t n_tris = 0, n_lights = 0;
+    std::vector<float> woop;             // 12 / triangle, traversal order
+    std::vector<uint32_t> tri_gid;       // empty = identity
+    std::vector<float> shade;            // 32 / triangle (8 float4), by global id
+    std::vector<float> normals;          // 12 / triangle (3 float4) or empty
+    std::vector<float> inst;             // 32 / instance
+    std::vector<DMaterial> materials;
+    std::vector<uint32_t> inst_tri_offset;
+    // lights
+    std::vector<AliasEntry> light_entries;
+    std::vector<float> light_pdf, light_power;
+    std::vector<uint32_t> light_inst, light_tri_offset, light_n_tris;
+    std::vector<AliasEntry> area_entries;
+    std::vector<float> area_pdf;
+    // BVH4 nodes (8 float4 each) or empty for the exhaustive path
+    std::vector<float> bvh_nodes;
+    bool has_alpha = false;
+    bool needs_ggx_table = false;
+    float scene_lo[3], scene_hi[3];
+};
+
+DMaterial fold_material(const akr_material_desc& m);
+void build_alias_table(const std::vector<float>& weights, std::vector<AliasEntry>& entries, std::vector<float>& pdf);
+void compile_scene(const FlatScene& flat, CompiledScene& out);
+// PerspectiveCameraData::new (camera/mod.rs:119-153)
+void camera_matrices(const akr_camera_desc& cam, float r2c[16], float c2w[16], uint32_t* c2w_identity);
+PcgStartConsts pcg_start_constants();
+
+// scene.json / method.json readers (host/scene_json.cpp); throw std::runtime_error on failure
+FlatScene load_scene_json(const std::string& path);
+void parse_method_json(const std::string& text, akr_pt_config* cfg, std::string* film_out);
+
+}  // namespace akr

@@ -1,0 +1,369 @@
+// scene_json.cpp -- readers for the reference's on-disk formats.
+//
+//   scene.json   crates/akari_scenegraph/src/scene.rs:86-117 (Scene, Buffer, BufferView), :333-347 (Mesh/Geometry),
+//                :22-57 (TRS / Transform / PerspectiveCamera), shader.rs:117-219 (ShaderNode)
+//   loading      crates/akari_render/src/load.rs:129-194 (load_transform, load_camera), :195-237 (load_instance),
+//                akari_scenegraph/src/scene.rs:603-647 (MmapScene::open: buffers resolved relative to the JSON)
+//   method.json  crates/akari_integrator/src/lib.rs:75-109 (RenderConfig / RenderTask), pt.rs:916-944 (Config)
+// Shader graphs are folded to constants here (svm/compiler.rs:116-337 + svm/eval.rs:97-269 for constant
+// inputs); graphs with texture nodes are reported as AKR_ERR_UNSUPPORTED by the caller.
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+
+#include "json.h"
+#include "scene_build.h"
+
+namespace akr {
+
+namespace {
+
+std::string read_file(const std::string& path, bool binary) {
+    std::ifstream f(path, binary ? std::ios::binary : std::ios::in);
+    if (!f) throw std::runtime_error("cannot open '" + path + "'");
+    std::stringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+std::string dirname_of(const std::string& p) {
+    size_t k = p.find_last_of('/');
+    return k == std::string::npos ? std::string(".") : p.substr(0, k);
+}
+std::string basename_any(const std::string& p) {  // handles '/' and '\\' (scenes/cbox stores a Windows path)
+    size_t k = p.find_last_of("/\\");
+    return k == std::string::npos ? p : p.substr(k + 1);
+}
+bool file_exists(const std::string& p) {
+    std::ifstream f(p, std::ios::binary);
+    return (bool)f;
+}
+std::string base64_decode(const std::string& in) {
+    static const std::string tbl = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+    std::string out;
+    int val = 0, bits = -8;
+    for (unsigned char c : in) {
+        if (c == '=' || c == '\n' || c == '\r') continue;
+        size_t p = tbl.find((char)c);
+        if (p == std::string::npos) throw std::runtime_error("bad base64 buffer");
+        val = (val << 6) + (int)p;
+        bits += 6;
+        if (bits >= 0) {
+            out.push_back((char)((val >> bits) & 0xFF));
+            bits -= 8;
+        }
+    }
+    return out;
+}
+
+// 4x4 f32, column-major, glam semantics
+struct M4 {
+    float m[16];
+};
+M4 m4_identity() {
+    M4 r;
+    std::memset(r.m, 0, sizeof r.m);
+    r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0f;
+    return r;
+}
+M4 m4_mul(const M4& a, const M4& b) {
+    M4 r;
+    for (int c = 0; c < 4; c++)
+        for (int i = 0; i < 4; i++)
+            r.m[c * 4 + i] = ((a.m[0 * 4 + i] * b.m[c * 4 + 0] + a.m[1 * 4 + i] * b.m[c * 4 + 1]) + a.m[2 * 4 + i] * b.m[c * 4 + 2]) +
+                             a.m[3 * 4 + i] * b.m[c * 4 + 3];
+    return r;
+}
+M4 m4_scale(float x, float y, float z) {
+    M4 r = m4_identity();
+    r.m[0] = x; r.m[5] = y; r.m[10] = z;
+    return r;
+}
+M4 m4_translation(float x, float y, float z) {
+    M4 r = m4_identity();
+    r.m[12] = x; r.m[13] = y; r.m[14] = z;
+    return r;
+}
+M4 m4_axis_angle(float ax, float ay, float az, float angle) {  // glam Mat4::from_axis_angle
+    float s = sinf(angle), c = cosf(angle);
+    float sx = ax * s, sy = ay * s, sz = az * s;
+    float qx = ax * ax, qy = ay * ay, qz = az * az;
+    float omc = 1.0f - c;
+    float xyomc = ax * ay * omc, xzomc = ax * az * omc, yzomc = ay * az * omc;
+    M4 r = m4_identity();
+    r.m[0] = qx * omc + c; r.m[1] = xyomc + sz; r.m[2] = xzomc - sy;
+    r.m[4] = xyomc - sz; r.m[5] = qy * omc + c; r.m[6] = yzomc + sx;
+    r.m[8] = xzomc + sy; r.m[9] = yzomc - sx; r.m[10] = qz * omc + c;
+    return r;
+}
+
+// load.rs:129-171
+M4 load_transform(const JsonValue& t, bool is_camera) {
+    const std::string& ty = t.at("type").as_string();
+    const JsonValue& data = t.at("data");
+    if (ty == "matrix") {
+        // glam::Mat4::from_cols_array_2d(m).transpose(): the JSON rows are the matrix rows
+        M4 r;
+        for (int row = 0; row < 4; row++)
+            for (int col = 0; col < 4; col++) r.m[col * 4 + row] = data.at(row).at(col).as_f32();
+        return r;
+    }
+    if (ty != "trs") throw std::runtime_error("unknown transform type '" + ty + "'");
+    float tr[3], ro[3], sc[3];
+    for (int i = 0; i < 3; i++) {
+        tr[i] = data.at("translation").at(i).as_f32();
+        ro[i] = data.at("rotation").at(i).as_f32();
+        sc[i] = data.at("scale").at(i).as_f32();
+    }
+    const std::string& cs = data.at("coordinate_system").as_string();
+    M4 m = m4_identity();
+    if (!is_camera) m = m4_mul(m4_scale(sc[0], sc[1], sc[2]), m);
+    const float kPiF = 3.14159265358979323846f;
+    if (cs == "Akari") {
+        m = m4_mul(m4_axis_angle(0, 0, 1, ro[2]), m);
+        m = m4_mul(m4_axis_angle(1, 0, 0, ro[0]), m);
+        m = m4_mul(m4_axis_angle(0, 1, 0, ro[1]), m);
+        m = m4_mul(m4_translation(tr[0], tr[1], tr[2]), m);
+    } else if (cs == "Blender") {
+        if (is_camera) m = m4_mul(m4_axis_angle(1, 0, 0, -kPiF / 2.0f), m);  // Blender cameras look down -Z
+        m = m4_mul(m4_axis_angle(1, 0, 0, ro[0]), m);
+        m = m4_mul(m4_axis_angle(0, 0, 1, -ro[1]), m);
+        m = m4_mul(m4_axis_angle(0, 1, 0, ro[2]), m);
+        m = m4_mul(m4_translation(tr[0], tr[2], -tr[1]), m);
+    } else {
+        throw std::runtime_error("unknown coordinate system '" + cs + "'");
+    }
+    return m;
+}
+
+struct BufferStore {
+    const JsonValue& scene;
+    std::string base_dir;
+    std::map<std::string, std::string> cache;
+    const std::string& buffer(const std::string& id) {
+        auto it = cache.find(id);
+        if (it != cache.end()) return it->second;
+        const JsonValue& b = scene.at("buffers").at(id);
+        const std::string& ty = b.at("type").as_string();
+        std::string data;
+        if (ty == "path") {
+            const std::string& p = b.at("path").as_string();
+            std::string cand = (!p.empty() && p[0] == '/') ? p : base_dir + "/" + p;
+            if (!file_exists(cand)) cand = base_dir + "/" + basename_any(p);
+            data = read_file(cand, true);
+        } else if (ty == "base64") {
+            data = base64_decode(b.at("data").as_string());
+        } else if (ty == "binary") {
+            for (const auto& v : b.at("data").arr) data.push_back((char)(unsigned char)v->as_number());
+        } else {
+            throw std::runtime_error("unsupported buffer type '" + ty + "'");
+        }
+        return cache[id] = std::move(data);
+    }
+    template <typename T>
+    std::vector<T> view(const JsonValue& ref) {
+        const JsonValue& v = scene.at("buffer_views").at(ref.at("id").as_string());
+        const std::string& data = buffer(v.at("buffer").at("id").as_string());
+        size_t off = (size_t)v.at("offset").as_number(), len = (size_t)v.at("length").as_number();
+        if (off + len > data.size()) throw std::runtime_error("buffer view out of range");
+        std::vector<T> out(len / sizeof(T));
+        std::memcpy(out.data(), data.data() + off, out.size() * sizeof(T));
+        return out;
+    }
+};
+
+struct ConstVal {
+    float v[4];
+    int n;
+};
+// constant evaluation of a shader node (svm/eval.rs:97-135): Float, Float3, Rgb (+alpha 1), SpectralUplift
+ConstVal fold_const(const JsonValue& nodes, const JsonValue& ref) {
+    const JsonValue& n = nodes.at(ref.at("id").as_string());
+    const std::string& ty = n.at("type").as_string();
+    ConstVal c{{0, 0, 0, 1}, 1};
+    if (ty == "float") {
+        c.v[0] = n.at("value").as_f32();
+        c.n = 1;
+    } else if (ty == "float3") {
+        for (int i = 0; i < 3; i++) c.v[i] = n.at("value").at(i).as_f32();
+        c.n = 3;
+    } else if (ty == "rgb") {
+        const std::string cs = n.has("colorspace") ? n.at("colorspace").as_string() : std::string("srgb");
+        if (cs != "srgb") throw std::runtime_error("unsupported: constant colour in colour space '" + cs + "'");
+        for (int i = 0; i < 3; i++) c.v[i] = n.at("value").at(i).as_f32();
+        c.v[3] = 1.0f;
+        c.n = 4;
+    } else if (ty == "spectral_uplift") {
+        return fold_const(nodes, n.at("rgb"));
+    } else {
+        throw std::runtime_error("unsupported: shader node '" + ty + "' (only constant inputs are folded)");
+    }
+    return c;
+}
+float fold_float(const JsonValue& nodes, const JsonValue& ref) { return fold_const(nodes, ref).v[0]; }  // eval_float_auto_convert
+void fold_color(const JsonValue& nodes, const JsonValue& ref, float* rgb, float* alpha) {
+    ConstVal c = fold_const(nodes, ref);
+    if (c.n >= 3) { rgb[0] = c.v[0]; rgb[1] = c.v[1]; rgb[2] = c.v[2]; }
+    else { rgb[0] = c.v[0]; rgb[1] = 0.0f; rgb[2] = 0.0f; }
+    if (alpha) *alpha = c.n == 4 ? c.v[3] : 1.0f;
+}
+
+akr_material_desc fold_shader(const JsonValue& shader) {
+    const JsonValue& nodes = shader.at("nodes");
+    const JsonValue& out = nodes.at(shader.at("output").at("id").as_string());
+    if (out.at("type").as_string() != "output") throw std::runtime_error("shader graph output is not an output node");
+    const JsonValue& n = nodes.at(out.at("node").at("id").as_string());
+    const std::string& ty = n.at("type").as_string();
+    akr_material_desc m;
+    std::memset(&m, 0, sizeof m);
+    m.base_alpha = 1.0f;
+    m.ior = 1.0f;
+    for (int i = 0; i < 3; i++) m.specular_tint[i] = m.coat_tint[i] = 1.0f;
+    m.specular_ior_level = 0.5f;
+    if (ty == "principled") {
+        m.kind = AKR_MAT_PRINCIPLED;
+        fold_color(nodes, n.at("base_color"), m.base_color, &m.base_alpha);
+        m.metallic = fold_float(nodes, n.at("metallic"));
+        m.roughness = fold_float(nodes, n.at("roughness"));
+        m.ior = fold_float(nodes, n.at("ior"));
+        m.specular_ior_level = fold_float(nodes, n.at("specular_ior_level"));
+        fold_color(nodes, n.at("specular_tint"), m.specular_tint, nullptr);
+        m.transmission_weight = fold_float(nodes, n.at("transmission_weight"));
+        m.coat_weight = fold_float(nodes, n.at("coat_weight"));
+        m.coat_roughness = fold_float(nodes, n.at("coat_roughness"));
+        m.coat_ior = fold_float(nodes, n.at("coat_ior"));
+        fold_color(nodes, n.at("coat_tint"), m.coat_tint, nullptr);
+        fold_color(nodes, n.at("emission_color"), m.emission_color, nullptr);
+        m.emission_strength = fold_float(nodes, n.at("emission_strength"));
+        fold_color(nodes, n.at("normal"), m.normal, nullptr);
+    } else if (ty == "diffuse") {
+        m.kind = AKR_MAT_DIFFUSE;
+        fold_color(nodes, n.at("color"), m.base_color, &m.base_alpha);
+    } else if (ty == "glass") {
+        m.kind = AKR_MAT_GLASS;
+        fold_color(nodes, n.at("color"), m.base_color, nullptr);
+        m.ior = fold_float(nodes, n.at("ior"));
+        m.roughness = fold_float(nodes, n.at("roughness"));
+    } else if (ty == "emission") {
+        m.kind = AKR_MAT_EMISSION;
+        fold_color(nodes, n.at("color"), m.emission_color, nullptr);
+        m.emission_strength = fold_float(nodes, n.at("strength"));
+    } else {
+        throw std::runtime_error("unsupported: surface shader '" + ty + "'");
+    }
+    return m;
+}
+
+}  // namespace
+
+FlatScene load_scene_json(const std::string& path) {
+    JsonPtr root = JsonParser::parse(read_file(path, false));
+    const JsonValue& scene = *root;
+    BufferStore bufs{scene, dirname_of(path), {}};
+    FlatScene flat;
+    // geometries (BTreeMap order)
+    std::map<std::string, uint32_t> geom_index, mat_index;
+    for (const auto& kv : scene.at("geometries").obj) {
+        const JsonValue& g = *kv.second;
+        if (g.at("type").as_string() != "mesh") throw std::runtime_error("unsupported geometry type");
+        HostMesh m;
+        m.vertices = bufs.view<float>(g.at("vertices"));
+        m.indices = bufs.view<uint32_t>(g.at("indices"));
+        if (g.has("uvs")) m.uvs = bufs.view<float>(g.at("uvs"));
+        if (g.has("normals")) m.normals = bufs.view<float>(g.at("normals"));
+        if (g.has("tangents")) m.tangents = bufs.view<float>(g.at("tangents"));
+        if (g.has("materials")) m.slots = bufs.view<uint32_t>(g.at("materials"));
+        const size_t nt = m.indices.size() / 3;
+        if (m.indices.empty() || m.indices.size() % 3) throw std::runtime_error("mesh '" + kv.first + "': bad index buffer");
+        if (!m.uvs.empty() && m.uvs.size() != 6 * nt) throw std::runtime_error("mesh '" + kv.first + "': uvs must be per corner");
+        if (!m.normals.empty() && m.normals.size() != 9 * nt) throw std::runtime_error("mesh '" + kv.first + "': normals must be per corner");
+        if (!m.tangents.empty() && m.tangents.size() != 9 * nt) throw std::runtime_error("mesh '" + kv.first + "': tangents must be per corner");
+        if (m.slots.size() <= 1) m.slots.clear();  // one entry = slot 0 for all triangles (mesh.rs:139)
+        else if (m.slots.size() != nt) throw std::runtime_error("mesh '" + kv.first + "': material slots must be 1 or per triangle");
+        for (uint32_t idx : m.indices)
+            if (idx >= m.vertices.size() / 3) throw std::runtime_error("mesh '" + kv.first + "': vertex index out of range");
+        geom_index[kv.first] = (uint32_t)flat.meshes.size();
+        flat.meshes.push_back(std::move(m));
+    }
+    for (const auto& kv : scene.at("materials").obj) {
+        mat_index[kv.first] = (uint32_t)flat.materials.size();
+        try {
+            flat.materials.push_back(fold_shader(kv.second->at("shader")));
+        } catch (const std::exception& e) {
+            throw std::runtime_error("material '" + kv.first + "': " + e.what());
+        }
+    }
+    for (const auto& kv : scene.at("instances").obj) {
+        const JsonValue& in = *kv.second;
+        HostInstance h;
+        auto gi = geom_index.find(in.at("geometry").at("id").as_string());
+        if (gi == geom_index.end()) throw std::runtime_error("instance '" + kv.first + "': unknown geometry");
+        h.mesh = gi->second;
+        for (const auto& mref : in.at("materials").arr) {
+            auto mi = mat_index.find(mref->at("id").as_string());
+            if (mi == mat_index.end()) throw std::runtime_error("instance '" + kv.first + "': unknown material");
+            h.materials.push_back(mi->second);
+        }
+        if (h.materials.empty()) throw std::runtime_error("instance '" + kv.first + "': no materials");
+        M4 t = load_transform(in.at("transform"), false);
+        std::memcpy(h.transform, t.m, sizeof h.transform);
+        flat.instances.push_back(std::move(h));
+    }
+    if (!scene.has("camera")) throw std::runtime_error("scene has no camera");
+    const JsonValue& cam = scene.at("camera");
+    if (cam.at("type").as_string() != "perspective") throw std::runtime_error("unsupported camera type");
+    const JsonValue& cd = cam.at("data");
+    M4 c2w = load_transform(cd.at("transform"), true);
+    std::memcpy(flat.camera.c2w, c2w.m, sizeof flat.camera.c2w);
+    const float kPiF = 3.14159265358979323846f;
+    flat.camera.fov = cd.at("fov").as_f32() * (kPiF / 180.0f);  // f32::to_radians
+    flat.camera.width = (uint32_t)cd.at("sensor_width").as_number();
+    flat.camera.height = (uint32_t)cd.at("sensor_height").as_number();
+    return flat;
+}
+
+void parse_method_json(const std::string& text, akr_pt_config* cfg, std::string* film_out) {
+    JsonPtr root = JsonParser::parse(text);
+    const JsonValue* j = root.get();
+    if (j->type == JsonValue::Array) {  // RenderTask::Multi: take the first task
+        if (j->arr.empty()) throw std::runtime_error("empty render task list");
+        j = j->arr[0].get();
+    }
+    akr_pt_config_default(cfg);
+    if (j->has("method")) {
+        const JsonValue& m = j->at("method");
+        const std::string ty = m.has("type") ? m.at("type").as_string() : std::string("pt");
+        if (ty != "pt") throw std::runtime_error("unsupported: method type '" + ty + "' (only \"pt\")");
+        auto u32 = [&](const char* k, uint32_t& dst) { if (m.has(k)) dst = (uint32_t)m.at(k).as_number(); };
+        auto b32 = [&](const char* k, uint32_t& dst) { if (m.has(k)) dst = m.at(k).as_bool() ? 1u : 0u; };
+        u32("spp", cfg->spp); u32("max_depth", cfg->max_depth); u32("spp_per_pass", cfg->spp_per_pass); u32("rr_depth", cfg->rr_depth);
+        b32("use_nee", cfg->use_nee); b32("indirect_only", cfg->indirect_only); b32("force_diffuse", cfg->force_diffuse);
+        if (m.has("pixel_offset")) {
+            cfg->pixel_offset[0] = (int32_t)m.at("pixel_offset").at(0).as_number();
+            cfg->pixel_offset[1] = (int32_t)m.at("pixel_offset").at(1).as_number();
+        }
+        if (m.has("debug_depth")) cfg->debug_depth = (int32_t)m.at("debug_depth").as_number();
+    }
+    if (j->has("sampler")) {
+        const JsonValue& s = j->at("sampler");
+        const std::string ty = s.has("type") ? s.at("type").as_string() : std::string("independent");
+        if (ty == "independent") cfg->sampler_type = AKR_SAMPLER_INDEPENDENT;
+        else throw std::runtime_error("unsupported: sampler '" + ty + "' (pmj02bn needs tables absent from the reference tree)");
+        if (s.has("seed")) cfg->sampler_seed = (uint64_t)s.at("seed").as_number();
+    }
+    if (j->has("film")) {
+        const JsonValue& f = j->at("film");
+        if (f.has("filter")) {
+            const JsonValue& fl = f.at("filter");
+            const std::string& ty = fl.at("type").as_string();
+            if (ty == "box") cfg->filter_type = AKR_FILTER_BOX;
+            else if (ty == "gaussian") cfg->filter_type = AKR_FILTER_GAUSSIAN;
+            else throw std::runtime_error("unknown pixel filter '" + ty + "'");
+            cfg->filter_radius = fl.at("radius").as_f32();
+        }
+        if (film_out && f.has("out")) *film_out = f.at("out").as_string();
+    }
+}
+
+}  // namespace akr

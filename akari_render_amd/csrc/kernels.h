@@ -1,0 +1,46 @@
+// kernels.h -- kernel parameter block and host-callable launchers (implemented in pt_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device/drng.h"
+#include "device/dscene.h"
+
+namespace akr {
+
+// Everything one pass of the path tracer needs; passed by value as the kernel argument (lands in SGPRs).
+struct PtParams {
+    DScene sc;
+    // PerspectiveCameraData (camera/mod.rs:105-118): raster->camera and camera->world, column-major
+    float r2c[16];
+    float c2w[16];
+    uint32_t c2w_identity;
+    uint32_t width, height;
+    // pt::Config (pt.rs:916-929)
+    uint32_t max_depth, rr_depth, use_nee, indirect_only, force_diffuse;
+    int32_t debug_depth;
+    int32_t pixel_offset[2];
+    uint32_t filter_type;
+    float filter_radius;
+    uint32_t pass_spp;  // samples per pixel in this launch (<= spp_per_pass)
+    PcgStartConsts start;
+    // per-pixel sampler states (Pcg32[N]), film accumulator (f32[7N], reference layout), counters (u64[8])
+    Pcg32* states;
+    float* film;
+    uint64_t* counters;
+    // work distribution
+    uint32_t n_items;
+    uint32_t shard_rank, shard_count;
+    uint32_t tile_w, tile_h, tiles_x, tiles_y;
+};
+
+hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream);
+hipError_t launch_init_pcg32(const uint64_t* seeds, void* states, uint64_t n, hipStream_t stream);
+hipError_t launch_film_resolve(const float* film, uint64_t n, float* rgb, hipStream_t stream);
+hipError_t launch_ggx_table(const uint64_t* seeds, float* table, uint32_t samples, hipStream_t stream);
+hipError_t launch_probe_math(uint32_t n, const float* x, float* s, float* c, float* l, hipStream_t stream);
+hipError_t launch_probe_bsdf(const DMaterial* m, const float* table, int mode, const float* wo, uint32_t n, const float* in, float* out,
+                             hipStream_t stream);
+hipError_t launch_probe_intersect(const PtParams& p, uint32_t n, const float* rays, uint32_t* out, float* bary, hipStream_t stream);
+hipError_t launch_probe_si(const PtParams& p, uint32_t n, const uint32_t* inst_prim, const float* bary, float* out, hipStream_t stream);
+
+}  // namespace akr

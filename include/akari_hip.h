@@ -170,6 +170,8 @@ AKR_API int32_t akr_context_device_info(akr_context *ctx, char *name, uint32_t n
  * BVH (replacing rtx::Accel, mesh.rs:288-294,331-333), folds materials, runs the emission-power estimate
  * and builds the light alias tables (load.rs:308-444). */
 AKR_API int32_t akr_scene_create(akr_context *ctx, const akr_scene_desc *desc, akr_scene **out);
+/* Both scene constructors accept ctx == NULL: the scene is then compiled on the host only (flattening, material
+ * folding, light tables, BVH) and can be inspected with the akr_scene_get_* calls but not rendered. */
 /* Replaces akari_render::load::load_from_path (load.rs:63-72 -> MmapScene::open, scenegraph scene.rs:603-647):
  * parses the reference's scene.json (+ its binary buffers, resolved relative to the JSON's directory, falling
  * back to the basename for the absolute Windows paths found in scenes/cbox). width/height override the
@@ -199,6 +201,24 @@ AKR_API int32_t akr_scene_get_mesh(const akr_scene *scene, uint32_t mesh, akr_me
 AKR_API int32_t akr_scene_get_instance(const akr_scene *scene, uint32_t instance, akr_instance_desc *out);
 AKR_API int32_t akr_scene_get_material(const akr_scene *scene, uint32_t material, akr_material_desc *out);
 AKR_API int32_t akr_scene_get_camera(const akr_scene *scene, akr_camera_desc *out);
+/* Read-only views of the compiled, device-ready arrays (owned by the scene): see akari_render_amd/csrc/device/dscene.h
+ * for the record layouts. */
+typedef enum {
+    AKR_ARRAY_WOOP = 0,          /* f32[12 * n_tris]  ray-triangle records in traversal order */
+    AKR_ARRAY_TRI_GID = 1,       /* u32[n_tris]       traversal order -> global triangle id (empty = identity) */
+    AKR_ARRAY_SHADE = 2,         /* f32[32 * n_tris]  shading records by global triangle id */
+    AKR_ARRAY_INSTANCES = 3,     /* f32[32 * n_instances] */
+    AKR_ARRAY_MATERIALS = 4,     /* folded materials, 256 B each */
+    AKR_ARRAY_BVH_NODES = 5,     /* f32[32 * n_bvh_nodes] */
+    AKR_ARRAY_LIGHT_ENTRIES = 6, /* {u32 j, f32 t}[n_lights] */
+    AKR_ARRAY_LIGHT_PDF = 7,     /* f32[n_lights] */
+    AKR_ARRAY_AREA_ENTRIES = 8,  /* {u32 j, f32 t}[sum of light triangle counts] */
+    AKR_ARRAY_AREA_PDF = 9,      /* f32[sum of light triangle counts] */
+    AKR_ARRAY_INST_TRI_OFFSET = 10, /* u32[n_instances + 1] */
+    AKR_ARRAY_R2C = 11,          /* f32[16] raster->camera, column-major (camera/mod.rs:119-153) */
+    AKR_ARRAY_C2W = 12           /* f32[16] */
+} akr_array_id;
+AKR_API int32_t akr_scene_get_array(const akr_scene *scene, int32_t which, const void **ptr, uint64_t *bytes);
 
 /* Replaces Film::new (film.rs:93-151): f32[(1 + 2*3) * W * H] on the device, laid out exactly as the
  * reference's buffer [rgb * N | splat * N | weight * N] (film.rs:69, 85-90), zero-initialised. */
@@ -212,6 +232,9 @@ AKR_API int32_t akr_film_write(akr_film *film, const float *src);
 /* Film resolve = the copy_to_rgba_image kernel with hdr = true (film.rs:120-148): rgb / (w == 0 ? 1 : w)
  * + splat * splat_scale; writes 3 * W * H floats of linear RGB to host memory. */
 AKR_API int32_t akr_film_resolve(akr_film *film, float *dst_rgb);
+/* Wraps caller-owned device memory (7 * W * H floats, reference layout, e.g. a torch tensor that a
+ * torch.distributed/RCCL reduce will run on) as a film; akr_film_destroy then leaves the memory alone. */
+AKR_API int32_t akr_film_wrap(akr_context *ctx, uint32_t width, uint32_t height, void *device_ptr, akr_film **out);
 /* Device pointer + byte size of the accumulator, for an RCCL reduce issued by the host application
  * (one process per GPU). The pointer stays valid until akr_film_destroy. */
 AKR_API int32_t akr_film_device_ptr(akr_film *film, void **ptr, uint64_t *bytes);
@@ -242,6 +265,18 @@ AKR_API int32_t akr_pt_passes(akr_pt_session *session, uint32_t n_passes, int32_
 AKR_API int32_t akr_pt_end(akr_pt_session *session, akr_pt_stats *stats);
 /* Copies the session's Pcg32 state buffer (2 x u64 per pixel: state, inc) to the host. */
 AKR_API int32_t akr_pt_read_sampler_states(akr_pt_session *session, uint64_t *dst);
+
+/* Host-side pieces exposed for known-answer tests (no GPU needed):
+ *   akr_host_stdrng_u64      rand 0.8 StdRng::seed_from_u64(seed) then n x gen::<u64>() (sampler/mod.rs:150-151)
+ *   akr_host_chacha_block    one ChaCha block with `rounds` rounds (RFC 7539 / zero-key vectors pin the core)
+ *   akr_host_pcg32_states    init_pcg32_buffer_with_seed on the host: 2 x u64 (state, inc) per entry
+ *   akr_host_pcg_start       the closed form the kernels use for sampler.start() = advance(16384)
+ *   akr_host_alias_table     AliasTable::new (util/distribution.rs:35-78) */
+AKR_API int32_t akr_host_stdrng_u64(uint64_t seed, uint32_t n, uint64_t *out);
+AKR_API int32_t akr_host_chacha_block(const uint32_t *key8, uint64_t counter, uint64_t stream, int32_t rounds, uint32_t *out16);
+AKR_API int32_t akr_host_pcg32_states(uint64_t seed, uint64_t n, uint64_t *out2n);
+AKR_API int32_t akr_host_pcg_start(uint64_t *state, uint64_t inc);
+AKR_API int32_t akr_host_alias_table(const float *weights, uint32_t n, uint32_t *j, float *t, float *pdf);
 
 /* Library / build identification: "akari_hip <version> gfx950". */
 AKR_API const char *akr_version(void);

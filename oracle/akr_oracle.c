@@ -119,7 +119,8 @@ static v2 interp2(v2 b, v2 a0, v2 a1, v2 a2) {
 static or_si or_surface_interaction(const or_scene *sc, uint32_t inst_id, uint32_t prim_id, v2 bary) {
     const or_instance *inst = &sc->instances[inst_id];
     const or_mesh_desc *g = &sc->meshes[inst->mesh].d;
-    uint32_t slot = g->material_slots ? g->material_slots[prim_id] : 0;
+    /* mats[slots[prim]] when the slot buffer has more than one entry, else mats[0] (mesh.rs:508-521, load.rs:227-229) */
+    uint32_t slot = (g->material_slots && g->n_triangles > 1) ? g->material_slots[prim_id] : 0;
     uint32_t material = inst->materials[slot < inst->n_materials ? slot : 0];
     uint32_t i0 = g->indices[3 * prim_id], i1 = g->indices[3 * prim_id + 1], i2 = g->indices[3 * prim_id + 2];
     v3 v0 = ld3(g->vertices, i0), v1 = ld3(g->vertices, i1), v2_ = ld3(g->vertices, i2);
@@ -211,7 +212,7 @@ static void or_woop_precompute(v3 A, v3 B, v3 C, float *w) {
 static inline int or_alpha_test(const or_scene *sc, uint32_t inst, uint32_t prim, float u, float v) {
     const or_instance *in = &sc->instances[inst];
     const or_mesh_desc *g = &sc->meshes[in->mesh].d;
-    uint32_t slot = g->material_slots ? g->material_slots[prim] : 0;
+    uint32_t slot = (g->material_slots && g->n_triangles > 1) ? g->material_slots[prim] : 0;
     const or_material_desc *m = &sc->materials[in->materials[slot < in->n_materials ? slot : 0]];
     float alpha = (m->kind == OR_MAT_PRINCIPLED || m->kind == OR_MAT_DIFFUSE) ? m->base_alpha : 1.0f;
     if (alpha >= 1.0f) return 1;

@@ -214,11 +214,13 @@ def load_scene(path: str, width: int = 0, height: int = 0) -> SceneData:
                 indices=bufs.view(g["indices"], np.uint32, 3),
                 uvs=None if uvs is None else uvs.reshape(-1, 3, 2),
                 normals=None if normals is None else normals.reshape(-1, 3, 3),
-                tangents=None,  # generated/loaded tangents are never bound (mesh.rs:182 vs 277-281)
-                material_slots=None if slots is None else slots.reshape(-1),
+                # supplied tangents are bound (mesh.rs:145-165, has_tangents = args.tangents.is_some()); the
+                # mikktspace ones the reference generates when they are absent never are (mesh.rs:182 vs 277-281)
+                tangents=None if tangents is None else tangents.reshape(-1, 3, 3),
+                # a one-entry slot buffer means "slot 0 for every triangle" (mesh.rs:139, load.rs:227-229)
+                material_slots=None if (slots is None or slots.size <= 1) else slots.reshape(-1),
             )
         )
-        del tangents
     mat_ids = sorted(scene["materials"].keys())
     mat_index = {m: i for i, m in enumerate(mat_ids)}
     materials = [_fold_material(scene["materials"][m]["shader"]) for m in mat_ids]
