@@ -30,6 +30,7 @@ EXPORTS = [
     "akr_film_create", "akr_film_wrap", "akr_film_destroy", "akr_film_clear", "akr_film_read", "akr_film_write",
     "akr_film_resolve", "akr_film_device_ptr",
     "akr_pt_config_default", "akr_pt_config_from_json", "akr_pt_render", "akr_pt_begin", "akr_pt_passes", "akr_pt_end",
+    "akr_pt_get_stats",
     "akr_pt_read_sampler_states",
     "akr_host_stdrng_u64", "akr_host_chacha_block", "akr_host_pcg32_states", "akr_host_pcg_start", "akr_host_alias_table",
     "akr_probe_math", "akr_probe_bsdf", "akr_probe_intersect", "akr_probe_surface_interaction",
@@ -94,6 +95,7 @@ def lib() -> C.CDLL:
     proto("akr_pt_begin", vp, vp, C.POINTER(abi.PtConfig), vp, vpp)
     proto("akr_pt_passes", vp, u32, i32, up)
     proto("akr_pt_end", vp, C.POINTER(abi.PtStats))
+    proto("akr_pt_get_stats", vp, C.POINTER(abi.PtStats))
     proto("akr_pt_read_sampler_states", vp, u64p)
     proto("akr_host_stdrng_u64", u64, u32, u64p)
     proto("akr_host_chacha_block", up, u64, u64, i32, up)
@@ -313,6 +315,11 @@ class PtSession:
         st = np.zeros(2 * n_pixels, dtype=np.uint64)
         check(lib().akr_pt_read_sampler_states(self.h, st.ctypes.data_as(C.POINTER(C.c_uint64))))
         return st
+
+    def stats(self) -> dict:
+        st = abi.PtStats()
+        check(lib().akr_pt_get_stats(self.h, C.byref(st)))
+        return st.as_dict()
 
     def end(self) -> dict:
         st = abi.PtStats()

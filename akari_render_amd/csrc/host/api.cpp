@@ -218,7 +218,7 @@ static void scene_finish(akr_scene* s) {
         s->device_bytes += b->bytes;
 }
 
-static void fill_params(akr_pt_session* se, uint32_t pass_spp) {
+static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pass_spp) {
     PtParams& p = se->params;
     const akr_scene* s = se->scene;
     const akr_pt_config& c = se->cfg;
@@ -239,7 +239,9 @@ static void fill_params(akr_pt_session* se, uint32_t pass_spp) {
     p.pixel_offset[1] = c.pixel_offset[1];
     p.filter_type = c.filter_type;
     p.filter_radius = c.filter_radius;
-    p.pass_spp = pass_spp;
+    p.pass_spp = c.spp_per_pass;
+    p.n_passes = n_passes;
+    p.last_pass_spp = last_pass_spp;
     p.start = pcg_start_constants();
     p.states = se->states.as<Pcg32>();
     p.film = se->film->data;
@@ -570,9 +572,18 @@ AKR_API int32_t akr_pt_passes(akr_pt_session* se, uint32_t n_passes, int32_t blo
     if (!se) return fail(AKR_ERR_INVALID_ARGUMENT, "session is NULL");
     return guarded([&] {
         se->ctx->bind();
-        for (uint32_t k = 0; k < n_passes && se->spp_done < se->cfg.spp; k++) {
-            uint32_t cur = std::min(se->cfg.spp - se->spp_done, se->cfg.spp_per_pass);  // pt.rs:1127
-            fill_params(se, cur);
+        // the passes requested (each min(spp - cnt, spp_per_pass) samples, pt.rs:1127) are fused into launches
+        // of at most kMaxFusedPasses passes
+        const uint32_t kMaxFusedPasses = 16;
+        uint32_t left = n_passes;
+        while (left > 0 && se->spp_done < se->cfg.spp) {
+            uint32_t fused = 0, last = 0, done = se->spp_done;
+            while (fused < kMaxFusedPasses && fused < left && done < se->cfg.spp) {
+                last = std::min(se->cfg.spp - done, se->cfg.spp_per_pass);
+                done += last;
+                fused++;
+            }
+            fill_params(se, fused, last);
             hipEvent_t e0, e1;
             HIP_CHECK(hipEventCreate(&e0));
             HIP_CHECK(hipEventCreate(&e1));
@@ -580,8 +591,9 @@ AKR_API int32_t akr_pt_passes(akr_pt_session* se, uint32_t n_passes, int32_t blo
             HIP_CHECK(launch_pt_pass(se->params, se->ctx->stream));
             HIP_CHECK(hipEventRecord(e1, se->ctx->stream));
             se->events.emplace_back(e0, e1);
-            se->spp_done += cur;
+            se->spp_done = done;
             se->n_launches++;
+            left -= fused;
         }
         if (blocking) HIP_CHECK(hipStreamSynchronize(se->ctx->stream));
         if (spp_done) *spp_done = se->spp_done;
@@ -595,32 +607,37 @@ AKR_API int32_t akr_pt_read_sampler_states(akr_pt_session* se, uint64_t* dst) {
         HIP_CHECK(hipMemcpy(dst, se->states.p, se->states.bytes, hipMemcpyDeviceToHost));
     });
 }
+static void read_stats(akr_pt_session* se, akr_pt_stats* stats) {
+    se->ctx->bind();
+    HIP_CHECK(hipStreamSynchronize(se->ctx->stream));
+    uint64_t c[8];
+    HIP_CHECK(hipMemcpy(c, se->counters.p, sizeof c, hipMemcpyDeviceToHost));
+    double ms = 0.0;
+    for (auto& ev : se->events) {
+        float t = 0.0f;
+        HIP_CHECK(hipEventElapsedTime(&t, ev.first, ev.second));
+        ms += t;
+    }
+    if (stats) {
+        stats->n_samples = c[0];
+        stats->n_closest = c[1];
+        stats->n_shadow = c[2];
+        stats->n_shaded = c[3];
+        stats->n_node_visits = c[4];
+        stats->n_tri_tests = c[5];
+        stats->kernel_ms = ms;
+        stats->n_launches = se->n_launches;
+        stats->_pad = (uint32_t)c[6];  // non-zero = a traversal stack overflowed (results invalid)
+    }
+    if (c[6] != 0) throw std::runtime_error("BVH traversal stack overflow: the render is incomplete");
+}
+AKR_API int32_t akr_pt_get_stats(akr_pt_session* se, akr_pt_stats* stats) {
+    if (!se || !stats) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_pt_get_stats: NULL argument");
+    return guarded([&] { read_stats(se, stats); });
+}
 AKR_API int32_t akr_pt_end(akr_pt_session* se, akr_pt_stats* stats) {
     if (!se) return AKR_OK;
-    int32_t rc = guarded([&] {
-        se->ctx->bind();
-        HIP_CHECK(hipStreamSynchronize(se->ctx->stream));
-        uint64_t c[8];
-        HIP_CHECK(hipMemcpy(c, se->counters.p, sizeof c, hipMemcpyDeviceToHost));
-        double ms = 0.0;
-        for (auto& ev : se->events) {
-            float t = 0.0f;
-            HIP_CHECK(hipEventElapsedTime(&t, ev.first, ev.second));
-            ms += t;
-        }
-        if (stats) {
-            stats->n_samples = c[0];
-            stats->n_closest = c[1];
-            stats->n_shadow = c[2];
-            stats->n_shaded = c[3];
-            stats->n_node_visits = c[4];
-            stats->n_tri_tests = c[5];
-            stats->kernel_ms = ms;
-            stats->n_launches = se->n_launches;
-            stats->_pad = (uint32_t)c[6];  // non-zero = a traversal stack overflowed (results invalid)
-        }
-        if (c[6] != 0) throw std::runtime_error("BVH traversal stack overflow: the render is incomplete");
-    });
+    int32_t rc = guarded([&] { read_stats(se, stats); });
     for (auto& ev : se->events) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);

@@ -21,7 +21,9 @@ struct PtParams {
     int32_t pixel_offset[2];
     uint32_t filter_type;
     float filter_radius;
-    uint32_t pass_spp;  // samples per pixel in this launch (<= spp_per_pass)
+    uint32_t pass_spp;       // samples per pixel per pass (spp_per_pass)
+    uint32_t n_passes;       // passes fused into this launch (>= 1)
+    uint32_t last_pass_spp;  // samples of the launch's last pass (<= pass_spp)
     PcgStartConsts start;
     // per-pixel sampler states (Pcg32[N]), film accumulator (f32[7N], reference layout), counters (u64[8])
     Pcg32* states;

@@ -1,7 +1,10 @@
 // pt_kernels.hip -- hand-written gfx950 kernels of the `pt` integrator.
 //
-// k_pt_pass is one pass of the reference's render loop (crates/akari_integrator/src/pt.rs:1075-1103,1126-1133):
-// every pixel takes `pass_spp` samples. The reference runs this as one JIT-compiled thread per pixel with two
+// k_pt_pass runs `n_passes` consecutive passes of the reference's render loop for its pixels
+// (crates/akari_integrator/src/pt.rs:1075-1103,1126-1133): in every pass a pixel takes `pass_spp` samples (the last
+// pass of a render may be shorter). Fusing passes keeps the sampler state and the film accumulator in registers
+// between them -- the values are those of separate launches, because a pass boundary is only "advance(-dim); dim = 0"
+// on the sampler -- and it averages the path-length variance of a wave's 64 lanes over more samples. The reference runs this as one JIT-compiled thread per pixel with two
 // nested loops (samples, bounces), so a wave idles on its longest path. Here a lane is a small state machine that
 // advances ONE path vertex per iteration and, when its path ends, splats the sample and regenerates the next
 // camera ray in the same iteration -- all 64 lanes of a wave stay on the same code (intersect / shade / shadow)
@@ -203,7 +206,8 @@ __global__ __launch_bounds__(256) void k_pt_pass(const PtParams p) {
     vec3 radiance = mk3(0, 0, 0), beta = mk3(1, 1, 1), base = mk3(0, 0, 0);
     uint32_t depth = 0;
     float prev_bsdf_pdf = 0.0f;
-    uint32_t samples_done = 0;
+    uint32_t samples_done = 0, pass_idx = 0, c_samples = 0;
+    uint32_t cur_spp = (p.n_passes == 1) ? p.last_pass_spp : p.pass_spp;
     uint32_t c_closest = 0, c_shadow = 0, c_shaded = 0;
 
     if (active) {
@@ -299,7 +303,19 @@ __global__ __launch_bounds__(256) void k_pt_pass(const PtParams p) {
                 film_rgb = mk3(film_rgb.x + L.x * 1.0f, film_rgb.y + L.y * 1.0f, film_rgb.z + L.z * 1.0f);
                 film_w = film_w + 1.0f;
                 samples_done++;
-                if (samples_done < p.pass_spp) {
+                c_samples++;
+                bool more = true;
+                if (samples_done == cur_spp) {
+                    // end of a pass: Drop for IndependentSampler (sampler/mod.rs:168-177) = advance(-dim); the next
+                    // pass re-creates the sampler from that state with dim = 0 (sampler/mod.rs:317-327)
+                    pcg_advance(smp.pcg, -(int64_t)smp.dim);
+                    smp.dim = 0;
+                    samples_done = 0;
+                    pass_idx++;
+                    cur_spp = (pass_idx + 1 == p.n_passes) ? p.last_pass_spp : p.pass_spp;
+                    more = pass_idx < p.n_passes;
+                }
+                if (more) {
                     pcg_start(smp.pcg, p.start);
                     generate_ray(p, sx, sy, smp, ro, rd);
                     ray_ex0 = kInvalid;
@@ -310,8 +326,6 @@ __global__ __launch_bounds__(256) void k_pt_pass(const PtParams p) {
                     prev_bsdf_pdf = 0.0f;
                 } else {
                     active = false;
-                    // Drop for IndependentSampler (sampler/mod.rs:168-177): advance(-dim), store
-                    pcg_advance(smp.pcg, -(int64_t)smp.dim);
                     p.states[pix] = smp.pcg;
                     p.film[3 * (size_t)pix + 0] = film_rgb.x;
                     p.film[3 * (size_t)pix + 1] = film_rgb.y;
@@ -322,7 +336,7 @@ __global__ __launch_bounds__(256) void k_pt_pass(const PtParams p) {
         }
     }
     if (p.counters != nullptr) {
-        uint32_t a = wave_sum_u32(samples_done), b = wave_sum_u32(c_closest), c = wave_sum_u32(c_shadow), e = wave_sum_u32(c_shaded);
+        uint32_t a = wave_sum_u32(c_samples), b = wave_sum_u32(c_closest), c = wave_sum_u32(c_shadow), e = wave_sum_u32(c_shaded);
         if ((threadIdx.x & 63u) == 0) {
             atomicAdd((unsigned long long*)&p.counters[0], (unsigned long long)a);
             atomicAdd((unsigned long long*)&p.counters[1], (unsigned long long)b);

@@ -1,0 +1,60 @@
+"""Multi-GPU plumbing: one process per GPU, pixel tiles sharded across ranks, one sum-reduce of the film.
+
+The reference has no multi-device code. Every pixel-sample of the path tracer is independent and
+the per-pixel sampler stream does not depend on which rank renders the pixel, so rank r simply renders the tiles
+t with t % world == r (akr_pt_config.shard_*) into a film that stays zero elsewhere; torch.distributed (backend
+"nccl" == RCCL over xGMI on ROCm, "gloo" on CPU) then sums the films onto rank 0. There is no collective inside
+the render itself.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import abi
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_process_group(backend: str):
+    """Initialises torch.distributed from the torchrun environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
+    import torch.distributed as dist
+
+    rank, world, _ = env_rank_world()
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world
+
+
+def shard_config(cfg: abi.PtConfig, rank: int, world: int, tile_w: int = 32, tile_h: int = 32) -> abi.PtConfig:
+    c = cfg.copy()
+    c.shard_rank, c.shard_count, c.tile_w, c.tile_h = rank, world, tile_w, tile_h
+    return c
+
+
+def owned_pixel_mask(width: int, height: int, rank: int, world: int, tile_w: int = 32, tile_h: int = 32) -> np.ndarray:
+    """Host mirror of the kernels' tile ownership rule (pt_kernels.hip: item_to_pixel): bool[H, W]."""
+    if world <= 1:
+        return np.ones((height, width), dtype=bool)
+    tiles_x = (width + tile_w - 1) // tile_w
+    ty, tx = np.meshgrid(np.arange(height) // tile_h, np.arange(width) // tile_w, indexing="ij")
+    return ((ty * tiles_x + tx) % world) == rank
+
+
+def owned_pixel_count(width: int, height: int, rank: int, world: int, tile_w: int = 32, tile_h: int = 32) -> int:
+    return int(owned_pixel_mask(width, height, rank, world, tile_w, tile_h).sum())
+
+
+def reduce_film(film_tensor, dst: int = 0):
+    """Sum-reduces the per-rank films (f32[7*W*H], reference layout) onto rank `dst`. Disjoint tiles make the sum
+    exact: every element receives one non-zero contribution plus zeros."""
+    import torch.distributed as dist
+
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(film_tensor, dst=dst, op=dist.ReduceOp.SUM)
+    return film_tensor

@@ -257,12 +257,15 @@ AKR_API int32_t akr_pt_render(akr_context *ctx, akr_scene *scene, const akr_pt_c
  * pt.rs:1126-1149), so a host can interleave its progress bar / intermediate saves / benchmark timing:
  *   begin  -> sampler state buffer created and seeded;
  *   passes -> runs up to n_passes further passes (fewer if spp is reached), asynchronously on the context
- *             stream unless `blocking` is non-zero; *spp_done receives the cumulative sample count;
+ *             stream unless `blocking` is non-zero; *spp_done receives the cumulative sample count. Passes of
+ *             one call may share a kernel launch (up to 16): results are those of separate launches;
  *   end    -> waits, returns accumulated counters, frees the session. */
 AKR_API int32_t akr_pt_begin(akr_context *ctx, akr_scene *scene, const akr_pt_config *cfg, akr_film *film,
                              akr_pt_session **out);
 AKR_API int32_t akr_pt_passes(akr_pt_session *session, uint32_t n_passes, int32_t blocking, uint32_t *spp_done);
 AKR_API int32_t akr_pt_end(akr_pt_session *session, akr_pt_stats *stats);
+/* Waits for the queued passes and returns the counters accumulated so far (the session stays open). */
+AKR_API int32_t akr_pt_get_stats(akr_pt_session *session, akr_pt_stats *stats);
 /* Copies the session's Pcg32 state buffer (2 x u64 per pixel: state, inc) to the host. */
 AKR_API int32_t akr_pt_read_sampler_states(akr_pt_session *session, uint64_t *dst);
 

@@ -1,0 +1,74 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/akari_hip.h declares."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from akari_render_amd import abi, capi
+
+
+def _declared(root):
+    text = open(os.path.join(root, "include", "akari_hip.h")).read()
+    return sorted(set(re.findall(r"AKR_API\s+[\w\s\*]+?\b(akr_\w+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(hip_lib, root):
+    names = _declared(root)
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(hip_lib, n), f"libakari_hip.so does not export {n}"
+    # and the binding lists exactly the header's symbols
+    assert sorted(capi.EXPORTS) == names
+
+
+def test_struct_sizes_match_header(hip_lib):
+    # akr_pt_config_default writes sizeof(akr_pt_config) bytes: guard bytes after the ctypes struct must survive
+    class Guarded(C.Structure):
+        _fields_ = [("cfg", abi.PtConfig), ("guard", C.c_uint8 * 64)]
+    g = Guarded()
+    for i in range(64):
+        g.guard[i] = 0xAB
+    assert hip_lib.akr_pt_config_default(C.byref(g.cfg)) == 0
+    assert all(b == 0xAB for b in g.guard)
+    d = abi.PtConfig.default()
+    assert bytes(g.cfg) == bytes(d)
+    assert C.sizeof(abi.MaterialDesc) == 4 * 26 and C.sizeof(abi.PtConfig) == 80
+
+
+def test_no_cpu_fallback(hip_lib):
+    """Without a GPU the library must say so; with one this test is a no-op."""
+    h = C.c_void_p()
+    rc = hip_lib.akr_context_create(0, C.byref(h))
+    if rc == 0:
+        hip_lib.akr_context_destroy(h)
+        pytest.skip("a GPU is present")
+    assert rc == capi.ERR_NO_DEVICE
+    assert b"no CPU path" in hip_lib.akr_last_error()
+
+
+def test_error_reporting(hip_lib, tmp_path):
+    h = C.c_void_p()
+    assert hip_lib.akr_scene_load(None, b"/nonexistent/scene.json", 0, 0, C.byref(h)) == capi.ERR_IO
+    bad = tmp_path / "bad.json"
+    bad.write_text("{ not json")
+    assert hip_lib.akr_scene_load(None, str(bad).encode(), 0, 0, C.byref(h)) == capi.ERR_PARSE
+    assert hip_lib.akr_scene_create(None, None, C.byref(h)) == capi.ERR_INVALID_ARGUMENT
+    cfg = abi.PtConfig()
+    assert hip_lib.akr_pt_config_from_json(b'{"method": {"type": "mcmc"}}', C.byref(cfg), None, 0) == capi.ERR_UNSUPPORTED
+    assert hip_lib.akr_pt_config_from_json(b'{"sampler": {"type": "pmj02bn", "seed": 0}}', C.byref(cfg), None, 0) == capi.ERR_UNSUPPORTED
+    assert len(hip_lib.akr_last_error()) > 0
+
+
+def test_method_json_defaults_and_overrides(hip_lib, root):
+    cfg, out = capi.config_from_json("{}")
+    assert bytes(cfg) == bytes(abi.PtConfig.default())
+    text = open(os.path.join(root, "scenes", "cbox", "pt.json")).read().replace("pmj02bn", "independent")
+    cfg, out = capi.config_from_json(text)
+    assert (cfg.spp, cfg.max_depth, cfg.rr_depth, cfg.spp_per_pass) == (4096, 12, 5, 64)
+    assert (cfg.use_nee, cfg.force_diffuse, cfg.indirect_only) == (1, 0, 0)
+    assert cfg.filter_type == abi.FILTER_GAUSSIAN and abs(cfg.filter_radius - 1.5) < 1e-7
+    assert out == "output/pt.exr"
+    cfg, _ = capi.config_from_json('[{"method": {"type": "pt", "spp": 3, "pixel_offset": [1, -2], "debug_depth": 2}, "film": {"filter": {"type": "box", "radius": 0.5}}}]')
+    assert cfg.spp == 3 and list(cfg.pixel_offset) == [1, -2] and cfg.debug_depth == 2 and cfg.filter_type == abi.FILTER_BOX

@@ -1,0 +1,205 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerance contract: relRMSE < 1e-3 on the resolved film at fixed seed. The build's arithmetic is
+designed to be reproducible bit for bit (DESIGN.md "AKR-F32"), so these tests additionally require the raw film
+accumulators to be identical -- any drift shows up as a count of differing floats before it shows up in relRMSE.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from akari_render_amd import abi, capi, distributed
+from oracle import pyoracle, scene_json
+from tests.helpers import box_scene, cbox_variant, grid_scene, make_config, n_bit_diff, rel_rmse, resolve_np
+
+pytestmark = pytest.mark.gpu
+
+REL_RMSE_TOL = 1e-3  # BASELINE.md / BASELINE.json north_star: "L2 error vs CPU reference < 1e-3"
+
+
+def render_both(ctx, sd, cfg, want_states=False):
+    scene = capi.Scene(ctx, sd)
+    w, h = sd.camera.width, sd.camera.height
+    film = capi.Film(ctx, w, h)
+    if want_states:
+        se = capi.PtSession(ctx, scene, cfg, film)
+        se.passes((cfg.spp + cfg.spp_per_pass - 1) // cfg.spp_per_pass, blocking=True)
+        gstates = se.sampler_states(w * h)
+        gst = se.end()
+    else:
+        gst = capi.pt_render(ctx, scene, cfg, film)
+        gstates = None
+    g = film.read()
+    osc = pyoracle.OracleScene(sd)
+    ostates = pyoracle.init_pcg32_states(w * h, cfg.sampler_seed) if want_states else None
+    o, ost = osc.render(cfg, states=ostates)
+    return g, o, gst, ost, gstates, ostates
+
+
+def assert_parity(g, o, w, h, gst=None, ost=None):
+    gi, oi = resolve_np(g, w, h), resolve_np(o, w, h)
+    assert np.all(np.isfinite(gi))
+    err = rel_rmse(gi, oi)
+    assert err < REL_RMSE_TOL, f"relRMSE {err}"
+    nd = n_bit_diff(g, o)
+    assert nd == 0, f"{nd} of {g.size} film floats differ (relRMSE {err:.3e}, max abs {np.max(np.abs(gi - oi)):.3e})"
+    if gst is not None:
+        for k in ("n_samples", "n_closest", "n_shadow", "n_shaded"):
+            assert gst[k] == ost[k], k
+
+
+def test_c1_cbox_256x256_64spp_full_graph(ctx, cbox_path):
+    """BASELINE.json configs[0]: scenes/cbox 256x256, 64 spp, fixed seed, full shader graph."""
+    sd = scene_json.load_scene(cbox_path, 256, 256)
+    cfg = make_config(spp=64, spp_per_pass=64, max_depth=12, rr_depth=5)
+    g, o, gst, ost, gs, os_ = render_both(ctx, sd, cfg, want_states=True)
+    assert_parity(g, o, 256, 256, gst, ost)
+    assert np.array_equal(gs, os_)  # per-pixel sampler states after the pass (sampler/mod.rs:168-177)
+    assert gst["n_samples"] == 256 * 256 * 64
+
+
+def test_c1_force_diffuse(ctx, cbox_path):
+    sd = scene_json.load_scene(cbox_path, 256, 256)
+    g, o, gst, ost, _, _ = render_both(ctx, sd, make_config(spp=64, force_diffuse=1))
+    assert_parity(g, o, 256, 256, gst, ost)
+
+
+def test_golden_fixture(ctx, cbox_path, root):
+    gold = np.load(os.path.join(root, "tests", "golden", "cbox_64x64_16spp.npz"))
+    sd = scene_json.load_scene(cbox_path, 64, 64)
+    for key, fd in (("full", 0), ("force_diffuse", 1)):
+        scene = capi.Scene(ctx, sd)
+        film = capi.Film(ctx, 64, 64)
+        capi.pt_render(ctx, scene, make_config(spp=16, spp_per_pass=16, force_diffuse=fd), film)
+        assert n_bit_diff(film.read(), gold[key]) == 0
+
+
+def test_scene_loaded_by_the_library(ctx, cbox_path):
+    """End to end through akr_scene_load (C++ JSON reader) instead of the flat description."""
+    scene = capi.Scene(ctx, cbox_path, 96, 64)
+    film = capi.Film(ctx, 96, 64)
+    cfg = make_config(spp=8, spp_per_pass=8)
+    capi.pt_render(ctx, scene, cfg, film)
+    o, _ = pyoracle.OracleScene(scene_json.load_scene(cbox_path, 96, 64)).render(cfg)
+    # the two readers may differ by one ulp in the camera matrix (host libm sin/cos): tolerance, not bits
+    assert rel_rmse(resolve_np(film.read(), 96, 64), resolve_np(o, 96, 64)) < REL_RMSE_TOL
+
+
+CONFIG_CASES = {
+    "multi_pass_ragged": dict(spp=11, spp_per_pass=4),
+    "no_nee": dict(spp=8, use_nee=0),
+    "indirect_only": dict(spp=8, indirect_only=1),
+    "depth0": dict(spp=4, max_depth=0),
+    "depth1": dict(spp=8, max_depth=1),
+    "rr_from_start": dict(spp=8, rr_depth=0, max_depth=20),
+    "box_filter": dict(spp=8, filter_type=abi.FILTER_BOX, filter_radius=0.5),
+    "pixel_offset": dict(spp=4, pixel_offset=(3, -2)),
+    "debug_depth": dict(spp=8, debug_depth=2),
+    "seed": dict(spp=8, sampler_seed=12345678901234567),
+}
+
+
+@pytest.mark.parametrize("name", list(CONFIG_CASES))
+def test_config_variants(ctx, cbox_path, name):
+    sd = scene_json.load_scene(cbox_path, 80, 56)
+    kw = dict(CONFIG_CASES[name])
+    cfg = make_config(**kw)
+    g, o, gst, ost, gs, os_ = render_both(ctx, sd, cfg, want_states=True)
+    assert_parity(g, o, 80, 56, gst, ost)
+    assert np.array_equal(gs, os_)
+
+
+@pytest.mark.parametrize("which", ["glass_coat", "kinds", "alpha"])
+def test_material_variants(ctx, cbox_path, root, which):
+    """Principled branches the stock cbox folds away (transmission, coat, specular layer, partial metal, normal
+    socket), the other shader kinds (glass, diffuse, emission) and the stochastic alpha test."""
+    sd = cbox_variant(scene_json.load_scene(cbox_path, 96, 96), which)
+    tpath = os.path.join(root, "tests", "golden", "ggx_dielectric_s.f32")
+    sd.ggx_table = np.fromfile(tpath, dtype=np.float32) if os.path.exists(tpath) else (np.random.default_rng(0).random(4096) * 0.8).astype(np.float32)
+    g, o, gst, ost, _, _ = render_both(ctx, sd, make_config(spp=32, spp_per_pass=16))
+    assert_parity(g, o, 96, 96, gst, ost)
+
+
+@pytest.mark.parametrize("normals", [False, True])
+def test_bvh_scene(ctx, normals):
+    """> 64 triangles: BVH4 traversal on the GPU against the oracle's exhaustive loop; instance transform with
+    rotation + scale, per-triangle material slots, optional shading normals."""
+    sd = grid_scene(n=24, width=96, height=64, with_normals=normals)
+    scene = capi.Scene(ctx, sd)
+    assert scene.info().uses_bvh == 1
+    g, o, gst, ost, _, _ = render_both(ctx, sd, make_config(spp=16, spp_per_pass=8, max_depth=6))
+    assert_parity(g, o, 96, 64, gst, ost)
+    assert gst["n_node_visits"] > 0
+
+
+def test_white_furnace_on_gpu(ctx):
+    sd = box_scene(albedo=0.5, emission=1.0, width=16, height=16)
+    scene = capi.Scene(ctx, sd)
+    film = capi.Film(ctx, 16, 16)
+    capi.pt_render(ctx, scene, make_config(spp=256, max_depth=12), film)
+    img = film.resolve()
+    expect = (1 - 0.5**13) / (1 - 0.5)
+    assert abs(img.mean() - expect) < 0.01 * expect
+    assert np.array_equal(img, resolve_np(film.read(), 16, 16))  # device resolve == film.rs:128-143
+
+
+def test_sharded_films_sum_to_the_full_frame(ctx, cbox_path):
+    sd = scene_json.load_scene(cbox_path, 200, 120)
+    scene = capi.Scene(ctx, sd)
+    cfg = make_config(spp=8, spp_per_pass=4)
+    full = capi.Film(ctx, 200, 120)
+    capi.pt_render(ctx, scene, cfg, full)
+    acc = np.zeros(7 * 200 * 120, dtype=np.float32)
+    for r in range(3):
+        f = capi.Film(ctx, 200, 120)
+        capi.pt_render(ctx, scene, distributed.shard_config(cfg, r, 3, 32, 16), f)
+        part = f.read()
+        assert np.array_equal(part[6 * 200 * 120 :] > 0, distributed.owned_pixel_mask(200, 120, r, 3, 32, 16).ravel())
+        acc += part
+    assert n_bit_diff(acc, full.read()) == 0
+
+
+def test_progressive_passes_equal_one_shot(ctx, cbox_path):
+    sd = scene_json.load_scene(cbox_path, 64, 64)
+    scene = capi.Scene(ctx, sd)
+    cfg = make_config(spp=24, spp_per_pass=8)
+    a = capi.Film(ctx, 64, 64)
+    capi.pt_render(ctx, scene, cfg, a)
+    b = capi.Film(ctx, 64, 64)
+    se = capi.PtSession(ctx, scene, cfg, b)
+    assert se.passes(1, blocking=True) == 8
+    assert se.passes(1) == 16
+    assert se.passes(5, blocking=True) == 24
+    st = se.end()
+    assert st["n_samples"] == 64 * 64 * 24 and st["n_launches"] >= 1
+    assert n_bit_diff(a.read(), b.read()) == 0
+
+
+def test_full_size_properties_1080p(ctx, cbox_path):
+    """BASELINE.json configs[1] geometry (1920x1080, force_diffuse) at one pass: size-independent properties."""
+    sd = scene_json.load_scene(cbox_path, 1920, 1080)
+    scene = capi.Scene(ctx, sd)
+    cfg = make_config(spp=64, spp_per_pass=64, force_diffuse=1)
+    film = capi.Film(ctx, 1920, 1080)
+    st = capi.pt_render(ctx, scene, cfg, film)
+    f = film.read()
+    n = 1920 * 1080
+    assert st["n_samples"] == n * 64
+    assert np.all(f[6 * n :] == 64.0)            # weight == spp for every pixel
+    assert np.all(f[3 * n : 6 * n] == 0.0)       # splat plane untouched
+    assert np.all(np.isfinite(f)) and np.all(f[: 3 * n] >= 0)
+    film2 = capi.Film(ctx, 1920, 1080)
+    capi.pt_render(ctx, scene, cfg, film2)
+    assert n_bit_diff(f, film2.read()) == 0      # deterministic
+    # a 64-row band against the oracle (the band's pixels are complete paths: exact comparison)
+    band = slice(500, 564)
+    osc = pyoracle.OracleScene(sd)
+    # oracle renders only tiles of rows 480..575 via sharding trick: 1 shard owning all, too slow at full size,
+    # so compare against a smaller independent statistic instead: mean radiance of the frame within 1 %
+    small = scene_json.load_scene(cbox_path, 480, 270)
+    o, _ = pyoracle.OracleScene(small).render(make_config(spp=64, force_diffuse=1))
+    m_big = resolve_np(f, 1920, 1080).mean(axis=(0, 1))
+    m_small = resolve_np(o, 480, 270).mean(axis=(0, 1))
+    assert np.all(np.abs(m_big - m_small) < 0.01 * m_small)
+    del band, osc

@@ -1,0 +1,124 @@
+"""Single device functions against their oracle counterparts (bit-exact): elementary functions, BSDF
+evaluate / sample for folded materials, the two intersectors, hit reconstruction, the GGX albedo table."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from akari_render_amd import abi, capi
+from oracle import pyoracle, scene_json
+from tests.helpers import grid_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def test_elementary_functions(ctx, oracle_lib):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([np.linspace(0, 6.2831855, 5001), rng.random(5000) * 6.2831855, rng.random(2000) * 1e-6,
+                        np.array([0.0, 1.0, 2.3283064e-10, 0.5, 6.2831855, 1e-38, 3e-39])]).astype(np.float32)
+    s, c, l = capi.probe_math(ctx, x)
+    so, co, lo = np.zeros_like(x), np.zeros_like(x), np.zeros_like(x)
+    a, b = C.c_float(), C.c_float()
+    for i, v in enumerate(x):
+        oracle_lib.or_kat_sincos(float(v), C.byref(a), C.byref(b))
+        so[i], co[i] = a.value, b.value
+        lo[i] = oracle_lib.or_kat_log(float(v))
+    for dev, ora in ((s, so), (c, co), (l, lo)):
+        assert np.array_equal(dev.view(np.uint32), ora.view(np.uint32))
+
+
+MATERIALS = {
+    "lambert_like": abi.MaterialData(base_color=(0.7, 0.6, 0.5), roughness=0.9, ior=1.0, specular_ior_level=0.0),
+    "metal": abi.MaterialData(base_color=(0.9, 0.7, 0.3), metallic=1.0, roughness=0.2, specular_tint=(1.0, 0.9, 0.8)),
+    "plastic": abi.MaterialData(base_color=(0.2, 0.5, 0.8), roughness=0.35, ior=1.5, specular_ior_level=0.5),
+    "coated": abi.MaterialData(base_color=(0.8, 0.2, 0.2), roughness=0.5, ior=1.45, coat_weight=0.7, coat_roughness=0.05, coat_tint=(0.9, 1.0, 0.9)),
+    "glassy": abi.MaterialData(base_color=(0.9, 0.95, 1.0), roughness=0.1, ior=1.5, transmission_weight=1.0),
+    "everything": abi.MaterialData(base_color=(0.6, 0.5, 0.4), roughness=0.3, ior=1.6, metallic=0.4, transmission_weight=0.5,
+                                   specular_ior_level=0.8, coat_weight=0.3, coat_roughness=0.2, normal=(0.1, 0.2, 0.9),
+                                   emission_color=(1, 2, 3), emission_strength=0.5),
+    "glass_node": abi.MaterialData(kind=abi.MAT_GLASS, base_color=(1, 1, 1), ior=1.33, roughness=0.25),
+    "diffuse_node": abi.MaterialData(kind=abi.MAT_DIFFUSE, base_color=(0.3, 0.6, 0.9)),
+    "emission_node": abi.MaterialData(kind=abi.MAT_EMISSION, emission_color=(5, 4, 3), emission_strength=2.0),
+}
+
+
+@pytest.mark.parametrize("name", list(MATERIALS))
+def test_bsdf_evaluate_and_sample(ctx, name):
+    m = MATERIALS[name]
+    rng = np.random.default_rng(5)
+    table = (rng.random(4096) * 0.9).astype(np.float32)
+    for wo in ([0.0, 0.0, 1.0], [0.6, 0.0, 0.8], [-0.5, 0.7, 0.5099], [0.3, 0.2, -0.9327]):
+        wo = np.array(wo, dtype=np.float32)
+        wo /= np.float32(np.linalg.norm(wo))
+        u = rng.random((4096, 3), dtype=np.float32)
+        u[:8] = [[1.0, 0.5, 0.5], [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0.5, 1.0, 0.0], [0.999999, 0.3, 0.7], [1.0, 0.0, 1.0], [0.25, 0.5, 1.0], [0.0, 1.0, 1.0]]
+        g = capi.probe_bsdf(ctx, m, 1, wo, u, table)
+        o = pyoracle.bsdf_sample_many(m, wo, u, table)
+        assert np.array_equal(g.view(np.uint32), o.view(np.uint32)), name
+        d = rng.normal(size=(4096, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+        ge = capi.probe_bsdf(ctx, m, 0, wo, d, table)
+        oe = pyoracle.bsdf_eval_many(m, wo, d, table)
+        assert np.array_equal(ge.view(np.uint32), oe.view(np.uint32)), name
+
+
+def _random_rays(rng, n, lo, hi):
+    o = (rng.random((n, 3)) * (hi - lo) + lo).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    rays = np.zeros((n, 8), dtype=np.float32)
+    rays[:, :3], rays[:, 3:6], rays[:, 6], rays[:, 7] = o, d, 0.0, 1e20
+    rays[: n // 8, 7] = rng.random(n // 8).astype(np.float32) * 2  # short rays
+    rays[n // 8 : n // 4, 3:6] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, n // 4 - n // 8)]  # axis-parallel
+    return rays
+
+
+@pytest.mark.parametrize("which", ["cbox", "grid", "grid_normals"])
+def test_intersect_and_surface_interaction(ctx, cbox_path, which):
+    rng = np.random.default_rng(9)
+    if which == "cbox":
+        sd = scene_json.load_scene(cbox_path, 32, 32)
+        lo, hi = np.array([-1.0, 0.0, -1.0]), np.array([1.0, 2.0, 1.0])
+    else:
+        sd = grid_scene(n=32, with_normals=(which == "grid_normals"))
+        lo, hi = np.array([-1.5, -0.2, -1.5]), np.array([1.5, 1.5, 1.5])
+    scene = capi.Scene(ctx, sd)
+    osc = pyoracle.OracleScene(sd)
+    rays = _random_rays(rng, 4096, lo, hi)
+    hit, bary = capi.probe_intersect(ctx, scene, rays)
+    n_hit = 0
+    ip, bb = [], []
+    for i in range(rays.shape[0]):
+        h, inst, prim, b = osc.intersect(rays[i, :3], rays[i, 3:6], float(rays[i, 6]), float(rays[i, 7]))
+        assert bool(hit[i, 0]) == h, i
+        if h:
+            n_hit += 1
+            assert (int(hit[i, 1]), int(hit[i, 2])) == (inst, prim), i
+            assert np.array_equal(bary[i].view(np.uint32), b.view(np.uint32)), i
+            ip.append((inst, prim)); bb.append(b)
+    assert n_hit > 1000
+    ip, bb = np.array(ip, dtype=np.uint32), np.array(bb, dtype=np.float32)
+    si = capi.probe_surface_interaction(ctx, scene, ip, bb)
+    for k in range(0, len(ip), 7):
+        o = osc.surface_interaction(int(ip[k, 0]), int(ip[k, 1]), float(bb[k, 0]), float(bb[k, 1]))
+        assert np.array_equal(si[k].view(np.uint32), o.view(np.uint32)), (k, si[k], o)
+
+
+def test_ggx_dielectric_table(ctx, root, oracle_lib):
+    """The table the library computes on the GPU (2^20 sequential samples per entry) against the oracle: a few
+    entries recomputed on the CPU here, and the whole table against the committed golden copy when present."""
+    m = abi.MaterialData(base_color=(0.5, 0.5, 0.5), roughness=0.4, ior=1.5, specular_ior_level=0.5)
+    from tests.helpers import box_scene
+    sd = box_scene()
+    sd.materials = [m]
+    scene = capi.Scene(ctx, sd)  # needs the table -> computed by k_ggx_dielectric_table
+    tab = scene.ggx_table()
+    assert np.all(np.isfinite(tab)) and tab.min() >= 0 and tab.max() <= 1.0 + 1e-3
+    for (tx, ty, tz) in [(0, 0, 0), (5, 9, 3), (15, 15, 15), (8, 1, 12)]:
+        ref = oracle_lib.or_ggx_dielectric_table_entry(tx, ty, tz, 1 << 20)
+        got = tab[tx + 16 * ty + 256 * tz]
+        assert np.float32(ref).view(np.uint32) == got.view(np.uint32), (tx, ty, tz, ref, got)
+    path = os.path.join(root, "tests", "golden", "ggx_dielectric_s.f32")
+    if os.path.exists(path):
+        assert np.array_equal(np.fromfile(path, dtype=np.float32).view(np.uint32), tab.view(np.uint32))
