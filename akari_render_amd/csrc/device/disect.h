@@ -137,7 +137,7 @@ AKR_D bool trace_bvh4(const DScene& sc, vec3 o, vec3 d, float tmin, float tmax, 
                 near = max_f(near, min_f(t0, t1)); far = min_f(far, max_f(t0, t1));
                 near = max_f(near, tmin);
                 far = min_f(far, best_t);
-                tn[i] = (near <= far) ? near : __builtin_inff();  // empty slots have inverted boxes -> never entered
+                tn[i] = ((near <= far) & (ch[i] != kInvalid)) ? near : __builtin_inff();  // empty slots carry ref 0xffffffff
             }
             if (!ANY_HIT) {
                 // sort the four (tn, ch) pairs ascending with a 5-comparator network

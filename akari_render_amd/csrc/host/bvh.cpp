@@ -7,7 +7,7 @@
 //   row 0/1: lo.x[4] / hi.x[4]   row 2/3: lo.y[4] / hi.y[4]   row 4/5: lo.z[4] / hi.z[4]
 //   row 6  : child reference [4] (u32 bits)      row 7: unused
 // child reference: inner node -> node index; leaf -> 0x80000000 | count << 28 | first triangle (count 1..4);
-// empty slot -> box (+inf, -inf), which no ray enters.
+// empty slot -> reference 0xffffffff (its box is (+inf, -inf)); traversal skips it by reference.
 // Boxes are padded by `pad` so that every triangle the exhaustive test would report is reached by traversal
 // (the triangle test itself has an absolute slop of a few ulp(t); see DESIGN.md "BVH conservativeness").
 #include <algorithm>

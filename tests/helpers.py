@@ -30,6 +30,8 @@ def resolve_np(film: np.ndarray, w: int, h: int) -> np.ndarray:
 def rel_rmse(img: np.ndarray, ref: np.ndarray) -> float:
     """BASELINE.md parity metric: sqrt(mean_p |rgb - ref|^2) / mean_p luminance(ref)."""
     lum = ref.astype(np.float64) @ np.array([0.2126, 0.7152, 0.0722])
+    if np.mean(lum) == 0.0:  # black reference (e.g. max_depth = 0 with no emitter in view): absolute error
+        return float(np.sqrt(np.mean(np.sum((img.astype(np.float64) - ref.astype(np.float64)) ** 2, axis=-1))))
     return float(np.sqrt(np.mean(np.sum((img.astype(np.float64) - ref.astype(np.float64)) ** 2, axis=-1))) / np.mean(lum))
 
 
