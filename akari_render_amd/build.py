@@ -45,7 +45,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-I", CSRC, "-o", LIB]
+    extra = os.environ.get("AKR_EXTRA_HIPCC_FLAGS", "").split()
+    cmd = [hipcc] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-I", CSRC, "-o", LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -56,8 +56,23 @@ AKR_D bool trace_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmin, float 
     uint32_t best = kInvalid;
     float best_u = 0.0f, best_v = 0.0f;
     const uint32_t n = sc.n_tris;
+    // constant address space (4) + wave-uniform index => s_load_dwordx4 into SGPRs; the records are read-only for
+    // the whole launch, which is what makes the scalar (non-coherent) cache legal here
+    typedef const float __attribute__((address_space(4))) * ConstF;
+    ConstF recs = (ConstF)(uintptr_t)sc.woop;
+    auto load_rec = [&](uint32_t k, float4& a, float4& b, float4& c) {
+        ConstF r = recs + 12 * (size_t)k;
+        a = make_float4(r[0], r[1], r[2], r[3]);
+        b = make_float4(r[4], r[5], r[6], r[7]);
+        c = make_float4(r[8], r[9], r[10], r[11]);
+    };
+    // software prefetch: the record of triangle k+1 is requested before triangle k is tested, so the scalar-cache
+    // latency overlaps the ~40 VALU instructions of the test (the buffer is padded by one record, scene_build.cpp)
+    float4 n0, n1, n2;
+    load_rec(0, n0, n1, n2);
     for (uint32_t k = 0; k < n; k++) {
-        float4 r0 = sc.woop[3 * k + 0], r1 = sc.woop[3 * k + 1], r2 = sc.woop[3 * k + 2];
+        const float4 r0 = n0, r1 = n1, r2 = n2;
+        load_rec(k + 1, n0, n1, n2);
         float t, u, v;
         bool h = tri_test(o, d, r0, r1, r2, tmin, tmax, t, u, v);
         h = h & (k != ex0) & (k != ex1);

@@ -435,6 +435,8 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
         out.woop.swap(woop2);
         out.tri_gid = order;
     }
+    // one all-zero record of padding: the exhaustive intersector prefetches record k+1 while testing k
+    out.woop.resize(out.woop.size() + 12, 0.0f);
 }
 
 }  // namespace akr

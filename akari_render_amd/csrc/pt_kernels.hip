@@ -171,8 +171,11 @@ AKR_D uint32_t wave_sum_u32(uint32_t v) {
 }
 
 // ----------------------------------------------------------------------------------------------------------
+#ifndef AKR_PT_MIN_WAVES
+#define AKR_PT_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for (occupancy)
+#endif
 template <bool BVH>
-__global__ __launch_bounds__(256) void k_pt_pass(const PtParams p) {
+__global__ __launch_bounds__(256, AKR_PT_MIN_WAVES) void k_pt_pass(const PtParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: kBvhStackDepth x 256 words
     TraceCtx tc;
     tc.stack = lds_stack + threadIdx.x;
