@@ -66,6 +66,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--full-graph", action="store_true", help="configs[2]: full Cycles-subset shader graph instead of force_diffuse")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only for smoke-testing the "
+                         "multi-rank path on a box with fewer GPUs than ranks: all ranks then share device 0)")
     args = ap.parse_args()
 
     import torch
@@ -76,8 +79,10 @@ def main():
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus} (WORLD_SIZE={world})"
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.backend == "gloo":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        distributed.init_process_group("nccl")
+        distributed.init_process_group(args.backend)
     import torch.distributed as dist
 
     ctx = capi.Context(local_rank if world > 1 else 0)
@@ -110,7 +115,12 @@ def main():
     t0 = time.perf_counter()
     se.passes(args.steps, blocking=True)
     if world > 1:
-        distributed.reduce_film(film_t, dst=0)
+        if args.backend == "gloo":
+            host = film_t.cpu()
+            distributed.reduce_film(host, dst=0)
+            film_t.copy_(host)
+        else:
+            distributed.reduce_film(film_t, dst=0)
     sync()
     t1 = time.perf_counter()
     s1 = se.end()
@@ -120,10 +130,11 @@ def main():
     d["kernel_ms"] = s1["kernel_ms"] - s0["kernel_ms"]
     d["n_launches"] = s1["n_launches"] - s0["n_launches"]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = dev if args.backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([d["n_samples"], d["n_closest"], d["n_shadow"], d["n_shaded"]], dtype=torch.float64, device=dev)
+        c = torch.tensor([d["n_samples"], d["n_closest"], d["n_shadow"], d["n_shaded"]], dtype=torch.float64, device=cdev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         total_samples = int(c[0].item())
     else:

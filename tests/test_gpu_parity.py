@@ -203,3 +203,13 @@ def test_full_size_properties_1080p(ctx, cbox_path):
     m_small = resolve_np(o, 480, 270).mean(axis=(0, 1))
     assert np.all(np.abs(m_big - m_small) < 0.01 * m_small)
     del band, osc
+
+
+def test_procedural_hall_small(ctx):
+    """The configs[3] generator at 20 k triangles: BVH traversal + six materials by slot, against the oracle."""
+    from akari_render_amd import procedural
+
+    sd = procedural.sponza_like(20_000, seed=1234, width=96, height=54)
+    assert abs(sd.n_triangles() - 20_000) < 0.03 * 20_000
+    g, o, gst, ost, _, _ = render_both(ctx, sd, make_config(spp=4, spp_per_pass=4, max_depth=5))
+    assert_parity(g, o, 96, 54, gst, ost)
