@@ -98,10 +98,59 @@ AKR_D bool trace_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmin, float 
     return best != kInvalid;
 }
 
+// Exhaustive intersector for a PAIR of rays per lane: the closest-hit ray of the next path vertex and the shadow ray
+// of the current one are both known once a vertex has been shaded, so one walk over the (wave-uniform, scalar-cache
+// resident) records serves both: half the scalar loads and loop overhead of two separate walks, and two independent
+// dependency chains per record for the VALU to overlap. A ray that does not exist for a lane is passed with
+// tmax < tmin and can never hit.
+AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, uint32_t ex0, vec3 so, vec3 sd, float stmax,
+                                 uint32_t sex0, uint32_t sex1, Hit& hit, bool& found, bool& occluded) {
+    float best_t = tmax;
+    uint32_t best = kInvalid;
+    float best_u = 0.0f, best_v = 0.0f;
+    bool occ = false;
+    const uint32_t n = sc.n_tris;
+    typedef const float __attribute__((address_space(4))) * ConstF;
+    ConstF recs = (ConstF)(uintptr_t)sc.woop;
+    auto load_rec = [&](uint32_t k, float4& a, float4& b, float4& c) {
+        ConstF r = recs + 12 * (size_t)k;
+        a = make_float4(r[0], r[1], r[2], r[3]);
+        b = make_float4(r[4], r[5], r[6], r[7]);
+        c = make_float4(r[8], r[9], r[10], r[11]);
+    };
+    float4 n0, n1, n2;
+    load_rec(0, n0, n1, n2);
+    for (uint32_t k = 0; k < n; k++) {
+        const float4 r0 = n0, r1 = n1, r2 = n2;
+        load_rec(k + 1, n0, n1, n2);  // prefetch (buffer padded by one record)
+        float t, u, v, st, su, sv;
+        bool h = tri_test(o, d, r0, r1, r2, 0.0f, tmax, t, u, v);
+        bool sh = tri_test(so, sd, r0, r1, r2, 0.0f, stmax, st, su, sv);
+        h = h & (k != ex0);
+        sh = sh & (k != sex0) & (k != sex1);
+        if (sc.has_alpha) {
+            if (h) h = alpha_test(sc, k, u, v);
+            if (sh) sh = alpha_test(sc, k, su, sv);
+        }
+        bool better = h & ((best == kInvalid) | (t < best_t));
+        best_t = better ? t : best_t;
+        best_u = better ? u : best_u;
+        best_v = better ? v : best_v;
+        best = better ? k : best;
+        occ = occ | sh;
+    }
+    hit.t = best_t;
+    hit.u = best_u;
+    hit.v = best_v;
+    hit.gid = best;
+    found = best != kInvalid;
+    occluded = occ;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // BVH4 traversal (one ray per lane, while-while). Node layout: host/bvh.cpp. The per-lane stack lives in LDS,
 // strided by the workgroup size so that lane i of every wave touches bank i (no conflicts): 4 B x depth x 256.
-constexpr uint32_t kBvhStackDepth = 48;
+constexpr uint32_t kBvhStackDepth = 32;
 constexpr uint32_t kBvhLeafBit = 0x80000000u;
 constexpr uint32_t kBvhDone = 0xfffffffeu;
 
@@ -109,15 +158,18 @@ struct TraceCounters {
     uint32_t nodes, tris, overflow;
 };
 
-AKR_D float safe_inv(float d) {  // 1/d with |d| floored at 1e-20 so that 0 * inf never appears in the slab test
+// 1/d for the slab test, |d| floored at 1e-20 so that 0 * inf never appears. The box test only culls: it does not
+// have to follow the AKR-F32 contract (the oracle has no BVH), it only has to be conservative, which the padding of
+// the boxes (host/bvh.cpp) guarantees with a margin of ~10^4 ulp; so it may use v_rcp_f32, fma and v_min3/v_max3.
+AKR_D float safe_inv(float d) {
     float a = abs_f(d) < 1e-20f ? __builtin_copysignf(1e-20f, d) : d;
-    return 1.0f / a;
+    return __builtin_amdgcn_rcpf(a);
 }
-
 template <bool ANY_HIT>
 AKR_D bool trace_bvh4(const DScene& sc, vec3 o, vec3 d, float tmin, float tmax, uint32_t ex0, uint32_t ex1, Hit& hit,
                       uint32_t* __restrict__ stack, TraceCounters& cnt) {
     const vec3 inv = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+    const vec3 noi = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);  // t = plane * inv + noi
     float best_t = tmax;
     uint32_t best = kInvalid;
     float best_u = 0.0f, best_v = 0.0f;
@@ -144,14 +196,13 @@ AKR_D bool trace_bvh4(const DScene& sc, vec3 o, vec3 d, float tmin, float tmax, 
             const float lzs[4] = {lz.x, lz.y, lz.z, lz.w}, hzs[4] = {hz.x, hz.y, hz.z, hz.w};
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                float t0 = (lxs[i] - o.x) * inv.x, t1 = (hxs[i] - o.x) * inv.x;
-                float near = min_f(t0, t1), far = max_f(t0, t1);
-                t0 = (lys[i] - o.y) * inv.y; t1 = (hys[i] - o.y) * inv.y;
-                near = max_f(near, min_f(t0, t1)); far = min_f(far, max_f(t0, t1));
-                t0 = (lzs[i] - o.z) * inv.z; t1 = (hzs[i] - o.z) * inv.z;
-                near = max_f(near, min_f(t0, t1)); far = min_f(far, max_f(t0, t1));
-                near = max_f(near, tmin);
-                far = min_f(far, best_t);
+                float ax = __builtin_fmaf(lxs[i], inv.x, noi.x), bx = __builtin_fmaf(hxs[i], inv.x, noi.x);
+                float ay = __builtin_fmaf(lys[i], inv.y, noi.y), by = __builtin_fmaf(hys[i], inv.y, noi.y);
+                float az = __builtin_fmaf(lzs[i], inv.z, noi.z), bz = __builtin_fmaf(hzs[i], inv.z, noi.z);
+                float near = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
+                                             __builtin_fmaxf(__builtin_fminf(az, bz), tmin));
+                float far = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
+                                            __builtin_fminf(__builtin_fmaxf(az, bz), best_t));
                 tn[i] = ((near <= far) & (ch[i] != kInvalid)) ? near : __builtin_inff();  // empty slots carry ref 0xffffffff
             }
             if (!ANY_HIT) {

@@ -174,8 +174,11 @@ AKR_D uint32_t wave_sum_u32(uint32_t v) {
 #ifndef AKR_PT_MIN_WAVES
 #define AKR_PT_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for (occupancy)
 #endif
+#ifndef AKR_PT_MIN_WAVES_BVH
+#define AKR_PT_MIN_WAVES_BVH 4
+#endif
 template <bool BVH>
-__global__ __launch_bounds__(256, AKR_PT_MIN_WAVES) void k_pt_pass(const PtParams p) {
+__global__ __launch_bounds__(256, BVH ? AKR_PT_MIN_WAVES_BVH : AKR_PT_MIN_WAVES) void k_pt_pass(const PtParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: kBvhStackDepth x 256 words
     TraceCtx tc;
     tc.stack = lds_stack + threadIdx.x;
@@ -209,6 +212,12 @@ __global__ __launch_bounds__(256, AKR_PT_MIN_WAVES) void k_pt_pass(const PtParam
     vec3 radiance = mk3(0, 0, 0), beta = mk3(1, 1, 1), base = mk3(0, 0, 0);
     uint32_t depth = 0;
     float prev_bsdf_pdf = 0.0f;
+    // the shadow ray of the vertex shaded last iteration, traced together with the next closest-hit ray
+    vec3 s_o = mk3(0, 0, 0), s_d = mk3(0, 0, 1), s_contrib = mk3(0, 0, 0);
+    float s_tmax = -1.0f;
+    uint32_t s_ex0 = kInvalid, s_ex1 = kInvalid;
+    bool has_ray = active, has_shadow = false, s_add = false, s_depth1 = false;
+    bool finalize = false, lane_done = false;
     uint32_t samples_done = 0, pass_idx = 0, c_samples = 0;
     uint32_t cur_spp = (p.n_passes == 1) ? p.last_pass_spp : p.pass_spp;
     uint32_t c_closest = 0, c_shadow = 0, c_shaded = 0;
@@ -220,84 +229,29 @@ __global__ __launch_bounds__(256, AKR_PT_MIN_WAVES) void k_pt_pass(const PtParam
 
     while (__builtin_amdgcn_ballot_w64(active) != 0) {
         if (active) {
-            bool terminated = false;
+            // ---- 1. intersection: next closest-hit ray + pending shadow ray ----
             Hit hit;
-            c_closest++;
-            bool found = trace<BVH, false>(p, tc, ro, rd, 0.0f, 1e20f, ray_ex0, kInvalid, hit);
-            if (!found) {
-                terminated = true;  // pt.rs:381-396 (hit_envmap adds zero)
+            bool found = false, occluded = false;
+            c_closest += has_ray ? 1u : 0u;
+            c_shadow += has_shadow ? 1u : 0u;
+            if (BVH) {
+                if (has_ray) found = trace_bvh4<false>(sc, ro, rd, 0.0f, 1e20f, ray_ex0, kInvalid, hit, tc.stack, tc.cnt);
+                if (has_shadow) {
+                    Hit sh;
+                    occluded = trace_bvh4<true>(sc, s_o, s_d, 0.0f, s_tmax, s_ex0, s_ex1, sh, tc.stack, tc.cnt);
+                }
             } else {
-                SurfacePoint si = surface_interaction(sc, hit.gid, mk2(hit.u, hit.v));
-                const DMaterial& mat = sc.materials[si.material];
-                vec3 wo = -rd;
-                {  // handle_surface_light, pt.rs:230-258
-                    vec3 direct = mk3(0, 0, 0);
-                    float w = 0.0f;
-                    if (si.light >= 0 && (!p.indirect_only || depth > 1)) {
-                        vec3 emission = material_emission(mat);
-                        direct = dot(si.ng, rd) < 0.0f ? emission : mk3(0, 0, 0);
-                        if (depth == 0 || !p.use_nee)
-                            w = 1.0f;
-                        else
-                            w = mis_weight(prev_bsdf_pdf, pdf_direct(sc, si, hit.gid, ro));
-                    }
-                    if (p.debug_depth < 0 || depth == (uint32_t)p.debug_depth) radiance = radiance + beta * (direct * w);
-                }
-                if (depth == 0) base = radiance;
-                if (depth >= p.max_depth) {
-                    terminated = true;
-                } else {
-                    depth += 1;
-                    c_shaded++;
-                    vec3 u_direct = next_3d(smp);
-                    LightSample dl;
-                    dl.valid = false;
-                    if (p.use_nee && (!p.indirect_only || depth > 1))
-                        dl = sample_direct(sc, si.p, si.ng, u_direct.x, mk2(u_direct.y, u_direct.z));
-                    vec3 u_bsdf = next_3d(smp);
-                    // sample_surface_and_shade_direct, pt.rs:297-323
-                    ShadePoint sp;
-                    shade_point_init(sp, mat, si.frame, si.ng, p.force_diffuse != 0);
-                    vec3 direct = mk3(0, 0, 0);
-                    if (dl.valid) {
-                        BsdfEval e = shade_evaluate(sp, mat, sc.ggx_table, wo, dl.wi);
-                        float w = mis_weight(dl.pdf, e.pdf);
-                        direct = div_s((dl.li * e.f) * w, dl.pdf);
-                    }
-                    BsdfSample bs = shade_sample(sp, mat, sc.ggx_table, wo, u_bsdf.x, mk2(u_bsdf.y, u_bsdf.z));
-                    if (dl.valid) {  // pt.rs:504-513
-                        c_shadow++;
-                        Hit sh;
-                        bool occluded = trace<BVH, true>(p, tc, dl.ro, dl.wi, 0.0f, dl.tmax, hit.gid, dl.ex1, sh);
-                        if (!occluded) {
-                            if (p.debug_depth < 0 || depth == (uint32_t)p.debug_depth) radiance = radiance + beta * direct;
-                        }
-                        if (depth == 1) base = radiance;
-                    }
-                    beta = beta * div_s(bs.color, bs.pdf);  // pt.rs:783
-                    if (bs.pdf <= 0.0f || !bs.valid || min3(bs.color) < 0.0f) {
-                        terminated = true;  // pt.rs:832-842
-                    } else {
-                        bool cont = true;
-                        if (depth > p.rr_depth) {  // pt.rs:211-224, 843-850
-                            float cont_prob = clamp_f(max3(beta), 0.0f, 1.0f) * 0.95f;
-                            if (next_1d(smp) >= cont_prob)
-                                cont = false;
-                            else
-                                beta = beta * div_s(mk3(1, 1, 1), cont_prob);
-                        }
-                        if (!cont) {
-                            terminated = true;
-                        } else {  // pt.rs:851-865
-                            prev_bsdf_pdf = bs.pdf;
-                            ro = offset_ray_origin(si.p, face_forward(si.ng, bs.wi));
-                            rd = bs.wi;
-                            ray_ex0 = hit.gid;
-                        }
-                    }
-                }
+                trace_pair_exhaustive(sc, ro, rd, has_ray ? 1e20f : -1.0f, ray_ex0, s_o, s_d, has_shadow ? s_tmax : -1.0f, s_ex0, s_ex1, hit,
+                                      found, occluded);
             }
-            if (terminated) {
+            // ---- 2. resolve the shadow ray (pt.rs:504-513) ----
+            if (has_shadow) {
+                if (!occluded && s_add) radiance = radiance + s_contrib;
+                if (s_depth1) base = radiance;
+                has_shadow = false;
+            }
+            // ---- 3. finish the sample whose last vertex was shaded in the previous iteration ----
+            if (finalize) {
                 // pt.rs:871-876 (clamp_indirect = 1000), then film.add_sample with weight 1 (film.rs:196-229)
                 vec3 ind = radiance - base;
                 ind = mk3(clamp_f(ind.x, 0.0f, 1000.0f), clamp_f(ind.y, 0.0f, 1000.0f), clamp_f(ind.z, 0.0f, 1000.0f));
@@ -305,29 +259,13 @@ __global__ __launch_bounds__(256, AKR_PT_MIN_WAVES) void k_pt_pass(const PtParam
                 if (is_nan(L.x) || is_nan(L.y) || is_nan(L.z)) L = mk3(0, 0, 0);
                 film_rgb = mk3(film_rgb.x + L.x * 1.0f, film_rgb.y + L.y * 1.0f, film_rgb.z + L.z * 1.0f);
                 film_w = film_w + 1.0f;
-                samples_done++;
-                c_samples++;
-                bool more = true;
-                if (samples_done == cur_spp) {
-                    // end of a pass: Drop for IndependentSampler (sampler/mod.rs:168-177) = advance(-dim); the next
-                    // pass re-creates the sampler from that state with dim = 0 (sampler/mod.rs:317-327)
-                    pcg_advance(smp.pcg, -(int64_t)smp.dim);
-                    smp.dim = 0;
-                    samples_done = 0;
-                    pass_idx++;
-                    cur_spp = (pass_idx + 1 == p.n_passes) ? p.last_pass_spp : p.pass_spp;
-                    more = pass_idx < p.n_passes;
-                }
-                if (more) {
-                    pcg_start(smp.pcg, p.start);
-                    generate_ray(p, sx, sy, smp, ro, rd);
-                    ray_ex0 = kInvalid;
-                    radiance = mk3(0, 0, 0);
-                    beta = mk3(1, 1, 1);
-                    base = mk3(0, 0, 0);
-                    depth = 0;
-                    prev_bsdf_pdf = 0.0f;
-                } else {
+                radiance = mk3(0, 0, 0);
+                beta = mk3(1, 1, 1);
+                base = mk3(0, 0, 0);
+                depth = 0;
+                prev_bsdf_pdf = 0.0f;
+                finalize = false;
+                if (lane_done) {
                     active = false;
                     p.states[pix] = smp.pcg;
                     p.film[3 * (size_t)pix + 0] = film_rgb.x;
@@ -336,18 +274,119 @@ __global__ __launch_bounds__(256, AKR_PT_MIN_WAVES) void k_pt_pass(const PtParam
                     p.film[6 * N + pix] = film_w;
                 }
             }
+            // ---- 4. shade the vertex the closest-hit ray found ----
+            if (active && has_ray) {
+                bool terminated = false;
+                if (!found) {
+                    terminated = true;  // pt.rs:381-396 (hit_envmap adds zero)
+                } else {
+                    SurfacePoint si = surface_interaction(sc, hit.gid, mk2(hit.u, hit.v));
+                    const DMaterial& mat = sc.materials[si.material];
+                    vec3 wo = -rd;
+                    {  // handle_surface_light, pt.rs:230-258
+                        vec3 direct = mk3(0, 0, 0);
+                        float w = 0.0f;
+                        if (si.light >= 0 && (!p.indirect_only || depth > 1)) {
+                            vec3 emission = material_emission(mat);
+                            direct = dot(si.ng, rd) < 0.0f ? emission : mk3(0, 0, 0);
+                            if (depth == 0 || !p.use_nee)
+                                w = 1.0f;
+                            else
+                                w = mis_weight(prev_bsdf_pdf, pdf_direct(sc, si, hit.gid, ro));
+                        }
+                        if (p.debug_depth < 0 || depth == (uint32_t)p.debug_depth) radiance = radiance + beta * (direct * w);
+                    }
+                    if (depth == 0) base = radiance;
+                    if (depth >= p.max_depth) {
+                        terminated = true;
+                    } else {
+                        depth += 1;
+                        c_shaded++;
+                        vec3 u_direct = next_3d(smp);
+                        LightSample dl;
+                        dl.valid = false;
+                        if (p.use_nee && (!p.indirect_only || depth > 1))
+                            dl = sample_direct(sc, si.p, si.ng, u_direct.x, mk2(u_direct.y, u_direct.z));
+                        vec3 u_bsdf = next_3d(smp);
+                        // sample_surface_and_shade_direct, pt.rs:297-323
+                        ShadePoint sp;
+                        shade_point_init(sp, mat, si.frame, si.ng, p.force_diffuse != 0);
+                        if (dl.valid) {
+                            BsdfEval e = shade_evaluate(sp, mat, sc.ggx_table, wo, dl.wi);
+                            float w = mis_weight(dl.pdf, e.pdf);
+                            vec3 direct = div_s((dl.li * e.f) * w, dl.pdf);
+                            // the shadow ray is traced next iteration; what it would add is fixed now (beta of THIS vertex)
+                            s_contrib = beta * direct;
+                            s_add = p.debug_depth < 0 || depth == (uint32_t)p.debug_depth;
+                            s_depth1 = depth == 1;
+                            s_o = dl.ro;
+                            s_d = dl.wi;
+                            s_tmax = dl.tmax;
+                            s_ex0 = hit.gid;
+                            s_ex1 = dl.ex1;
+                            has_shadow = true;
+                        }
+                        BsdfSample bs = shade_sample(sp, mat, sc.ggx_table, wo, u_bsdf.x, mk2(u_bsdf.y, u_bsdf.z));
+                        beta = beta * div_s(bs.color, bs.pdf);  // pt.rs:783
+                        if (bs.pdf <= 0.0f || !bs.valid || min3(bs.color) < 0.0f) {
+                            terminated = true;  // pt.rs:832-842
+                        } else {
+                            bool cont = true;
+                            if (depth > p.rr_depth) {  // pt.rs:211-224, 843-850
+                                float cont_prob = clamp_f(max3(beta), 0.0f, 1.0f) * 0.95f;
+                                if (next_1d(smp) >= cont_prob)
+                                    cont = false;
+                                else
+                                    beta = beta * div_s(mk3(1, 1, 1), cont_prob);
+                            }
+                            if (!cont) {
+                                terminated = true;
+                            } else {  // pt.rs:851-865
+                                prev_bsdf_pdf = bs.pdf;
+                                ro = offset_ray_origin(si.p, face_forward(si.ng, bs.wi));
+                                rd = bs.wi;
+                                ray_ex0 = hit.gid;
+                            }
+                        }
+                    }
+                }
+                if (terminated) {
+                    // this sample draws no more random numbers: account for it and start the next camera ray now; its
+                    // radiance is finished (step 3) after the shadow ray still pending has been resolved
+                    finalize = true;
+                    samples_done++;
+                    c_samples++;
+                    bool more = true;
+                    if (samples_done == cur_spp) {
+                        // end of a pass: Drop for IndependentSampler (sampler/mod.rs:168-177) = advance(-dim); the next
+                        // pass re-creates the sampler from that state with dim = 0 (sampler/mod.rs:317-327)
+                        pcg_advance(smp.pcg, -(int64_t)smp.dim);
+                        smp.dim = 0;
+                        samples_done = 0;
+                        pass_idx++;
+                        cur_spp = (pass_idx + 1 == p.n_passes) ? p.last_pass_spp : p.pass_spp;
+                        more = pass_idx < p.n_passes;
+                    }
+                    if (more) {
+                        pcg_start(smp.pcg, p.start);
+                        generate_ray(p, sx, sy, smp, ro, rd);
+                        ray_ex0 = kInvalid;
+                    } else {
+                        has_ray = false;
+                        lane_done = true;
+                    }
+                }
+            }
         }
     }
     if (p.counters != nullptr) {
         uint32_t a = wave_sum_u32(c_samples), b = wave_sum_u32(c_closest), c = wave_sum_u32(c_shadow), e = wave_sum_u32(c_shaded);
+        uint32_t nn = wave_sum_u32(tc.cnt.nodes), nt = wave_sum_u32(tc.cnt.tris), ov = wave_sum_u32(tc.cnt.overflow);
         if ((threadIdx.x & 63u) == 0) {
             atomicAdd((unsigned long long*)&p.counters[0], (unsigned long long)a);
             atomicAdd((unsigned long long*)&p.counters[1], (unsigned long long)b);
             atomicAdd((unsigned long long*)&p.counters[2], (unsigned long long)c);
             atomicAdd((unsigned long long*)&p.counters[3], (unsigned long long)e);
-        }
-        uint32_t nn = wave_sum_u32(tc.cnt.nodes), nt = wave_sum_u32(tc.cnt.tris), ov = wave_sum_u32(tc.cnt.overflow);
-        if ((threadIdx.x & 63u) == 0) {
             atomicAdd((unsigned long long*)&p.counters[4], (unsigned long long)nn);
             atomicAdd((unsigned long long*)&p.counters[5], BVH ? (unsigned long long)nt : (unsigned long long)(b + c) * p.sc.n_tris);
             if (ov) atomicAdd((unsigned long long*)&p.counters[6], (unsigned long long)ov);
