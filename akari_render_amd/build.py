@@ -15,6 +15,7 @@ SOURCES = [
     "host/scene_build.cpp",
     "host/scene_json.cpp",
     "host/bvh.cpp",
+    "host/image_io.cpp",
 ]
 HEADERS = [
     "kernels.h",
@@ -43,8 +44,25 @@ def _stale() -> bool:
     return False
 
 
+CLI = os.path.join(HERE, "akari-cli")
+
+
+def build_cli(verbose: bool = False) -> str:
+    """akari-cli: the reference's command line (crates/akari_api/src/bin/akari_cli.rs) over libakari_hip.so."""
+    src = os.path.join(CSRC, "host", "cli_main.cpp")
+    if os.path.exists(CLI) and os.path.getmtime(CLI) > max(os.path.getmtime(src), os.path.getmtime(LIB)):
+        return CLI
+    cmd = ["g++", "-O2", "-std=c++17", src, "-I", os.path.join(HERE, "..", "include"), "-L", HERE, "-lakari_hip",
+           "-Wl,-rpath,$ORIGIN", "-o", CLI]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("g++ failed:\n" + res.stdout)
+    return CLI
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
+        build_cli(verbose)
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = os.environ.get("AKR_EXTRA_HIPCC_FLAGS", "").split()
@@ -56,6 +74,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         raise RuntimeError("hipcc failed:\n" + res.stdout)
     if verbose and res.stdout.strip():
         print(res.stdout, file=sys.stderr)
+    build_cli(verbose)
     return LIB
 
 

@@ -30,11 +30,18 @@ EXPORTS = [
     "akr_film_create", "akr_film_wrap", "akr_film_destroy", "akr_film_clear", "akr_film_read", "akr_film_write",
     "akr_film_resolve", "akr_film_device_ptr",
     "akr_pt_config_default", "akr_pt_config_from_json", "akr_pt_render", "akr_pt_begin", "akr_pt_passes", "akr_pt_end",
-    "akr_pt_get_stats",
+    "akr_pt_get_stats", "akr_render_task", "akr_image_write",
     "akr_pt_read_sampler_states",
     "akr_host_stdrng_u64", "akr_host_chacha_block", "akr_host_pcg32_states", "akr_host_pcg_start", "akr_host_alias_table",
     "akr_probe_math", "akr_probe_bsdf", "akr_probe_intersect", "akr_probe_surface_interaction",
 ]
+
+
+class RenderSession(C.Structure):
+    """akr_render_session = RenderSession of the reference (akari_integrator/src/lib.rs:8-23) minus the GUI channel."""
+
+    _fields_ = [("save_intermediate", C.c_int32), ("save_stats", C.c_int32), ("name", C.c_char_p),
+                ("override_sampler_independent", C.c_int32), ("verbose", C.c_int32)]
 
 
 class AkariError(RuntimeError):
@@ -96,6 +103,8 @@ def lib() -> C.CDLL:
     proto("akr_pt_passes", vp, u32, i32, up)
     proto("akr_pt_end", vp, C.POINTER(abi.PtStats))
     proto("akr_pt_get_stats", vp, C.POINTER(abi.PtStats))
+    proto("akr_render_task", vp, vp, C.c_char_p, C.POINTER(RenderSession), C.POINTER(abi.PtStats))
+    proto("akr_image_write", C.c_char_p, fp, u32, u32)
     proto("akr_pt_read_sampler_states", vp, u64p)
     proto("akr_host_stdrng_u64", u64, u32, u64p)
     proto("akr_host_chacha_block", up, u64, u64, i32, up)
@@ -341,6 +350,22 @@ def pt_render(ctx: Context, scene: Scene, cfg: abi.PtConfig, film: Film) -> dict
     c = cfg.copy()
     check(lib().akr_pt_render(ctx.h, scene.h, C.byref(c), film.h, C.byref(st)))
     return st.as_dict()
+
+
+def render_task(ctx: Context, scene: Scene, method_json: str, name: Optional[str] = None, save_intermediate: bool = False,
+                save_stats: bool = False, override_sampler_independent: bool = False, verbose: bool = False) -> dict:
+    """akari_integrator::render (lib.rs:111-207): every task of the method file, film.out written at the end."""
+    ses = RenderSession(1 if save_intermediate else 0, 1 if save_stats else 0, name.encode() if name else None,
+                        1 if override_sampler_independent else 0, 1 if verbose else 0)
+    st = abi.PtStats()
+    check(lib().akr_render_task(ctx.h, scene.h, method_json.encode(), C.byref(ses), C.byref(st)))
+    return st.as_dict()
+
+
+def image_write(path: str, rgb: np.ndarray) -> None:
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    h, w = rgb.shape[0], rgb.shape[1]
+    check(lib().akr_image_write(os.fspath(path).encode(), _fp(rgb), w, h))
 
 
 def config_from_json(text: str):

@@ -661,6 +661,71 @@ AKR_API int32_t akr_pt_render(akr_context* ctx, akr_scene* scene, const akr_pt_c
     return rc2;
 }
 
+// ------------------------------------------------------------------------------------------------ render driver
+AKR_API int32_t akr_image_write(const char* path, const float* rgb, uint32_t width, uint32_t height) {
+    if (!path || !rgb || !width || !height) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_image_write: bad argument");
+    return guarded([&] { write_image(path, rgb, width, height); });
+}
+
+AKR_API int32_t akr_render_task(akr_context* ctx, akr_scene* scene, const char* method_json_text, const akr_render_session* session,
+                                akr_pt_stats* stats_out) {
+    if (!ctx || !scene || !method_json_text) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_render_task: NULL argument");
+    akr_render_session ses{0, 0, nullptr, 0, 0};
+    if (session) ses = *session;
+    const std::string name = ses.name ? ses.name : "default";
+    return guarded([&] {
+        std::vector<ParsedTask> tasks = parse_render_tasks(method_json_text, ses.override_sampler_independent != 0);
+        const uint32_t w = scene->flat.camera.width, h = scene->flat.camera.height;
+        std::vector<float> rgb(3ull * w * h);
+        for (size_t ti = 0; ti < tasks.size(); ti++) {  // render_single, lib.rs:112-193
+            const ParsedTask& task = tasks[ti];
+            if (ses.verbose) std::fprintf(stderr, "[akari_hip] task %zu/%zu: %ux%u, %u spp -> %s\n", ti + 1, tasks.size(), w, h, task.cfg.spp, task.film_out.c_str());
+            akr_film* film = nullptr;
+            akr_pt_session* se = nullptr;
+            auto check = [&](int32_t rc) { if (rc != AKR_OK) { std::string m = g_last_error; if (se) akr_pt_end(se, nullptr); if (film) akr_film_destroy(film); throw std::runtime_error(m); } };
+            check(akr_film_create(ctx, w, h, &film));
+            check(akr_pt_begin(ctx, scene, &task.cfg, film, &se));
+            std::string stats_json = "{\"intermediate\":[";
+            uint32_t cnt = 0;
+            bool first = true;
+            while (cnt < task.cfg.spp) {  // pt.rs:1126-1149
+                if (ses.save_intermediate) {
+                    check(akr_pt_passes(se, 1, 1, &cnt));
+                    akr_pt_stats st;
+                    check(akr_pt_get_stats(se, &st));
+                    check(akr_film_resolve(film, rgb.data()));
+                    std::string path = name + "-" + std::to_string(cnt) + ".exr";
+                    write_image(path, rgb.data(), w, h);
+                    char buf[512];
+                    std::snprintf(buf, sizeof buf, "%s{\"path\":\"%s\",\"time\":%.9g,\"spp\":%u}", first ? "" : ",", path.c_str(), st.kernel_ms * 1e-3, cnt);
+                    stats_json += buf;
+                    first = false;
+                } else {
+                    check(akr_pt_passes(se, 16, 1, &cnt));
+                }
+            }
+            stats_json += "]}";
+            akr_pt_stats st;
+            int32_t rc = akr_pt_end(se, &st);
+            se = nullptr;
+            check(rc);
+            if (ses.save_stats) {  // pt.rs:1150-1155
+                std::string path = name + ".json";
+                FILE* f = std::fopen(path.c_str(), "wb");
+                if (!f) throw std::runtime_error("cannot open '" + path + "' for writing");
+                std::fwrite(stats_json.data(), 1, stats_json.size(), f);
+                std::fclose(f);
+            }
+            if (ses.verbose) std::fprintf(stderr, "[akari_hip] Rendering finished in %.2fs (%.1f Msamples/s)\n", st.kernel_ms * 1e-3, st.n_samples / (st.kernel_ms * 1e3));
+            check(akr_film_resolve(film, rgb.data()));  // film.copy_to_rgba_image(hdr = true), lib.rs:191
+            akr_film_destroy(film);
+            film = nullptr;
+            write_image(task.film_out, rgb.data(), w, h);  // util::write_image(&output_image, &config.film.out), lib.rs:192
+            if (stats_out) *stats_out = st;
+        }
+    });
+}
+
 // ------------------------------------------------------------------------------------------------ host KAT hooks
 AKR_API int32_t akr_host_stdrng_u64(uint64_t seed, uint32_t n, uint64_t* out) {
     if (!out) return fail(AKR_ERR_INVALID_ARGUMENT, "out is NULL");

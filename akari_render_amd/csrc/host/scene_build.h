@@ -68,5 +68,13 @@ PcgStartConsts pcg_start_constants();
 // scene.json / method.json readers (host/scene_json.cpp); throw std::runtime_error on failure
 FlatScene load_scene_json(const std::string& path);
 void parse_method_json(const std::string& text, akr_pt_config* cfg, std::string* film_out);
+// all tasks of a RenderTask file (Single | Multi), lib.rs:103-109; allow_sampler_override: pmj02bn -> independent
+struct ParsedTask {
+    akr_pt_config cfg;
+    std::string film_out;
+};
+std::vector<ParsedTask> parse_render_tasks(const std::string& text, bool allow_sampler_override);
+// image writers (host/image_io.cpp)
+void write_image(const std::string& path, const float* rgb, uint32_t w, uint32_t h);
 
 }  // namespace akr

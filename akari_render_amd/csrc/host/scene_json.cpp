@@ -323,14 +323,9 @@ FlatScene load_scene_json(const std::string& path) {
     return flat;
 }
 
-void parse_method_json(const std::string& text, akr_pt_config* cfg, std::string* film_out) {
-    JsonPtr root = JsonParser::parse(text);
-    const JsonValue* j = root.get();
-    if (j->type == JsonValue::Array) {  // RenderTask::Multi: take the first task
-        if (j->arr.empty()) throw std::runtime_error("empty render task list");
-        j = j->arr[0].get();
-    }
+static void parse_one_task(const JsonValue* j, akr_pt_config* cfg, std::string* film_out, bool allow_sampler_override) {
     akr_pt_config_default(cfg);
+    if (film_out) *film_out = "out.png";  // FilmConfig::default, lib.rs:84-91
     if (j->has("method")) {
         const JsonValue& m = j->at("method");
         const std::string ty = m.has("type") ? m.at("type").as_string() : std::string("pt");
@@ -348,7 +343,7 @@ void parse_method_json(const std::string& text, akr_pt_config* cfg, std::string*
     if (j->has("sampler")) {
         const JsonValue& s = j->at("sampler");
         const std::string ty = s.has("type") ? s.at("type").as_string() : std::string("independent");
-        if (ty == "independent") cfg->sampler_type = AKR_SAMPLER_INDEPENDENT;
+        if (ty == "independent" || (ty == "pmj02bn" && allow_sampler_override)) cfg->sampler_type = AKR_SAMPLER_INDEPENDENT;
         else throw std::runtime_error("unsupported: sampler '" + ty + "' (pmj02bn needs tables absent from the reference tree)");
         if (s.has("seed")) cfg->sampler_seed = (uint64_t)s.at("seed").as_number();
     }
@@ -364,6 +359,30 @@ void parse_method_json(const std::string& text, akr_pt_config* cfg, std::string*
         }
         if (film_out && f.has("out")) *film_out = f.at("out").as_string();
     }
+}
+
+std::vector<ParsedTask> parse_render_tasks(const std::string& text, bool allow_sampler_override) {
+    JsonPtr root = JsonParser::parse(text);
+    std::vector<ParsedTask> out;
+    if (root->type == JsonValue::Array) {  // RenderTask::Multi
+        for (const auto& t : root->arr) {
+            ParsedTask p;
+            parse_one_task(t.get(), &p.cfg, &p.film_out, allow_sampler_override);
+            out.push_back(p);
+        }
+    } else {
+        ParsedTask p;
+        parse_one_task(root.get(), &p.cfg, &p.film_out, allow_sampler_override);
+        out.push_back(p);
+    }
+    if (out.empty()) throw std::runtime_error("empty render task list");
+    return out;
+}
+
+void parse_method_json(const std::string& text, akr_pt_config* cfg, std::string* film_out) {
+    std::vector<ParsedTask> tasks = parse_render_tasks(text, false);
+    *cfg = tasks[0].cfg;
+    if (film_out) *film_out = tasks[0].film_out;
 }
 
 }  // namespace akr

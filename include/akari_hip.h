@@ -269,6 +269,26 @@ AKR_API int32_t akr_pt_get_stats(akr_pt_session *session, akr_pt_stats *stats);
 /* Copies the session's Pcg32 state buffer (2 x u64 per pixel: state, inc) to the host. */
 AKR_API int32_t akr_pt_read_sampler_states(akr_pt_session *session, uint64_t *dst);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Render driver = akari_integrator::render / render_single (akari_integrator/src/lib.rs:111-207) with its
+ * RenderSession (lib.rs:8-23): runs every task of a method file and writes film.out; with save_intermediate it writes
+ * "{name}-{spp}.exr" after every pass (pt.rs:1138-1147), with save_stats "{name}.json" = RenderStats (lib.rs:24-37,
+ * pt.rs:1150-1155). `override_sampler_independent` != 0 replaces an unsupported sampler (pmj02bn: tables absent from
+ * the reference tree) by {independent, same seed} instead of failing.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t save_intermediate;
+    int32_t save_stats;
+    const char *name;                      /* NULL = "default" */
+    int32_t override_sampler_independent;
+    int32_t verbose;                       /* log to stderr */
+} akr_render_session;
+AKR_API int32_t akr_render_task(akr_context *ctx, akr_scene *scene, const char *method_json_text, const akr_render_session *session,
+                                akr_pt_stats *stats_of_last_task);
+/* util::write_image (akari_render/src/util/mod.rs:57-127): ".exr" -> linear RGB f32 OpenEXR (uncompressed scanlines),
+ * ".png" -> 8-bit sRGB. rgb = 3 * W * H floats, row-major, top row first. Creates parent directories. */
+AKR_API int32_t akr_image_write(const char *path, const float *rgb, uint32_t width, uint32_t height);
+
 /* Host-side pieces exposed for known-answer tests (no GPU needed):
  *   akr_host_stdrng_u64      rand 0.8 StdRng::seed_from_u64(seed) then n x gen::<u64>() (sampler/mod.rs:150-151)
  *   akr_host_chacha_block    one ChaCha block with `rounds` rounds (RFC 7539 / zero-key vectors pin the core)
