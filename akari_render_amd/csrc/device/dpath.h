@@ -1,0 +1,380 @@
+// dpath.h -- per-path state and the "one path vertex" step shared by the two schedules of the path tracer:
+// the persistent-lane megakernel (pt_kernels.hip: k_pt_pass) and the wavefront pipeline (wf_kernels.hip).
+// Everything here follows crates/akari_integrator/src/pt.rs:95-323,329-900 (shift_mapping = None), camera/mod.rs,
+// film.rs, sampler/mod.rs, light/{mod,area}.rs of the reference; file:line cited per function.
+#pragma once
+#include "disect.h"
+#include "drng.h"
+#include "../kernels.h"
+
+namespace akr {
+
+
+// ----------------------------------------------------------------------------------------------------------
+// work distribution: item index -> pixel. Items enumerate the pixels of the tiles this rank owns
+// (tile t belongs to rank t % shard_count), tile by tile, and inside a tile in 8x8 blocks so that one wave
+// covers an 8x8 pixel square (coherent primary rays, one film cache line per row segment).
+AKR_D bool item_to_pixel(const PtParams& p, uint32_t item, uint32_t& px, uint32_t& py) {
+    const uint32_t tile_px = p.tile_w * p.tile_h;
+    uint32_t j = item / tile_px, within = item - j * tile_px;
+    uint32_t tile = p.shard_rank + j * p.shard_count;
+    if (tile >= p.tiles_x * p.tiles_y) return false;
+    uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+    uint32_t block = within >> 6, lane = within & 63u;
+    uint32_t bpr = p.tile_w >> 3;  // 8x8 blocks per tile row
+    uint32_t by = block / bpr, bx = block - by * bpr;
+    px = tx * p.tile_w + bx * 8 + (lane & 7u);
+    py = ty * p.tile_h + by * 8 + (lane >> 3);
+    return px < p.width && py < p.height;
+}
+
+// film.rs:32-49
+AKR_D vec2 filter_sample(const PtParams& p, vec2 u) {
+    if (p.filter_type == 0) return mk2((u.x - 0.5f) * p.filter_radius, (u.y - 0.5f) * p.filter_radius);
+    float width = p.filter_radius;
+    float sigma = width / 3.0f;
+    float r = __builtin_sqrtf(-2.0f * log_f(u.x));
+    float theta = 2.0f * kPi * u.y;
+    float sn, cs;
+    sincos_f(theta, sn, cs);
+    vec2 off = mk2((r * cs) * sigma, (r * sn) * sigma);
+    return mk2(clamp_f(off.x, -width, width), clamp_f(off.y, -width, width));
+}
+
+struct Sampler {  // IndependentSampler, sampler/mod.rs:161-217
+    Pcg32 pcg;
+    uint32_t dim;
+};
+AKR_D float next_1d(Sampler& s) {
+    s.dim += 1;
+    return pcg_next_1d(s.pcg);
+}
+AKR_D vec2 next_2d(Sampler& s) {
+    float a = next_1d(s);
+    float b = next_1d(s);
+    return mk2(a, b);
+}
+AKR_D vec3 next_3d(Sampler& s) {
+    float a = next_1d(s);
+    vec2 b = next_2d(s);
+    return mk3(a, b.x, b.y);
+}
+
+// camera/mod.rs:70-103
+AKR_D void generate_ray(const PtParams& p, uint32_t px, uint32_t py, Sampler& smp, vec3& o, vec3& d) {
+    vec2 fpixel = mk2((float)px + 0.5f, (float)py + 0.5f);
+    vec2 offset = filter_sample(p, next_2d(smp));
+    vec2 pf = mk2(fpixel.x + offset.x, fpixel.y + offset.y);
+    const float* m = p.r2c;
+    float qx = ((m[0] * pf.x + m[4] * pf.y) + m[8] * 0.0f) + m[12] * 1.0f;
+    float qy = ((m[1] * pf.x + m[5] * pf.y) + m[9] * 0.0f) + m[13] * 1.0f;
+    float qz = ((m[2] * pf.x + m[6] * pf.y) + m[10] * 0.0f) + m[14] * 1.0f;
+    float qw = ((m[3] * pf.x + m[7] * pf.y) + m[11] * 0.0f) + m[15] * 1.0f;
+    d = normalize(div_s(mk3(qx, qy, qz), qw));
+    o = mk3(0, 0, 0);
+    if (!p.c2w_identity) {
+        const float* c = p.c2w;
+        o = div_s(mk3(c[12], c[13], c[14]), c[15]);
+        d = mk3((c[0] * d.x + c[4] * d.y) + c[8] * d.z, (c[1] * d.x + c[5] * d.y) + c[9] * d.z,
+                (c[2] * d.x + c[6] * d.y) + c[10] * d.z);
+    }
+}
+
+AKR_D float mis_weight(float a, float b) {  // pt.rs:962-973 with power = 1
+    float pa = 1.0f * a, pb = 1.0f * b;
+    return pa / (pa + pb);
+}
+
+// emission of the material at a surface point (AreaLightExpr::emission, light/area.rs:19-31): Principled returns
+// its emission constant (principled.rs:267-274), an Emission node likewise, everything else is black.
+AKR_D vec3 material_emission(const DMaterial& m) {
+    return (m.kind == MAT_PRINCIPLED || m.kind == MAT_EMISSION) ? m.emission : mk3(0, 0, 0);
+}
+
+struct LightSample {
+    vec3 li, wi;
+    float pdf;
+    vec3 ro;
+    float tmax;
+    uint32_t ex1;
+    bool valid;
+};
+// LightAggregate::sample_direct (light/mod.rs:115-132) + AreaLight::sample_direct (light/area.rs:51-107)
+AKR_D LightSample sample_direct(const DScene& sc, vec3 pn_p, vec3 pn_n, float u_select, vec2 u_sample) {
+    LightSample s;
+    s.li = mk3(0, 0, 0);
+    s.wi = mk3(0, 0, 0);
+    s.pdf = 0.0f;
+    s.ro = mk3(0, 0, 0);
+    s.tmax = 0.0f;
+    s.ex1 = kInvalid;
+    s.valid = false;
+    if (sc.n_lights == 0) return s;
+    float light_choice_pdf, u_sel2, pdf_prim, u_unused;
+    uint32_t light = alias_sample_and_remap(sc.light_entries, sc.light_pdf, sc.n_lights, u_select, light_choice_pdf, u_sel2);
+    uint32_t off = sc.light_tri_offset[light];
+    uint32_t prim = alias_sample_and_remap(sc.area_entries + off, sc.area_pdf + off, sc.light_n_tris[light], u_sel2, pdf_prim, u_unused);
+    uint32_t gid = sc.inst_tri_offset[sc.light_inst[light]] + prim;
+    vec2 bary = uniform_sample_triangle(u_sample);
+    SurfacePoint y = surface_interaction(sc, gid, bary);
+    vec3 wi = y.p - pn_p;
+    if (length2(wi) == 0.0f) return s;
+    float dist2 = length2(wi);
+    wi = div_s(wi, __builtin_sqrtf(dist2));
+    vec3 emission = material_emission(sc.materials[y.material]);
+    s.li = dot(wi, y.ng) < 0.0f ? emission : mk3(0, 0, 0);
+    float cos_theta_i = abs_f(dot(y.ng, wi));
+    float pdf = pdf_prim / y.prim_area * dist2 / cos_theta_i;
+    s.ro = offset_ray_origin(pn_p, face_forward(pn_n, wi));
+    float dist = __builtin_sqrtf(dist2);
+    s.tmax = dist * (1.0f - 1e-3f);
+    s.ex1 = gid;
+    s.wi = wi;
+    s.valid = is_finite(pdf);
+    s.pdf = pdf * light_choice_pdf;
+    return s;
+}
+// LightAggregate::pdf_direct (light/mod.rs:134-147) + AreaLight::pdf_direct (light/area.rs:109-130)
+AKR_D float pdf_direct(const DScene& sc, const SurfacePoint& si, uint32_t gid, vec3 pn_p) {
+    uint32_t light = (uint32_t)si.light;
+    float light_choice_pdf = sc.light_pdf[light];
+    uint32_t prim = gid - sc.inst_tri_offset[si.inst];
+    float prim_pdf = sc.area_pdf[sc.light_tri_offset[light] + prim];
+    vec3 wi = si.p - pn_p;
+    float dist2 = length2(wi);
+    wi = div_s(wi, __builtin_sqrtf(dist2));
+    float pdf = prim_pdf / si.prim_area * dist2 / max_f(abs_f(dot(si.ng, wi)), 1e-6f);
+    return light_choice_pdf * pdf;
+}
+
+// Per-thread intersection context: the LDS stack slot of this lane and the traversal counters.
+struct TraceCtx {
+    uint32_t* stack;
+    TraceCounters cnt;
+};
+template <bool BVH, bool ANY_HIT>
+AKR_D bool trace(const PtParams& p, TraceCtx& tc, vec3 o, vec3 d, float tmin, float tmax, uint32_t ex0, uint32_t ex1, Hit& hit) {
+    if (BVH) return trace_bvh4<ANY_HIT>(p.sc, o, d, tmin, tmax, ex0, ex1, hit, tc.stack, tc.cnt);
+    return trace_exhaustive<ANY_HIT>(p.sc, o, d, tmin, tmax, ex0, ex1, hit);
+}
+
+AKR_D uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+
+// ----------------------------------------------------------------------------------------------------------
+// One lane's path-tracing state (PathTracerBase, pt.rs:28-57, plus the bookkeeping of the kernel closure
+// pt.rs:1077-1102). The megakernel keeps it in registers; the wavefront pipeline streams it through HBM.
+struct PathRegs {
+    vec3 ro, rd;            // next closest-hit ray
+    uint32_t ray_ex0;
+    vec3 radiance, beta, base;
+    uint32_t depth;
+    float prev_bsdf_pdf;
+    // shadow ray of the vertex shaded last, traced together with the next closest-hit ray
+    vec3 s_o, s_d, s_contrib;
+    float s_tmax;
+    uint32_t s_ex0, s_ex1;
+    bool has_ray, has_shadow, s_add, s_depth1, finalize, lane_done, active;
+    uint32_t samples_done, pass_idx, cur_spp;
+    Sampler smp;
+    vec3 film_rgb;
+    float film_w;
+    uint32_t c_samples, c_closest, c_shadow, c_shaded;
+};
+
+AKR_D void path_regs_init(PathRegs& r, const PtParams& p, bool active, uint32_t pix, uint32_t sx, uint32_t sy) {
+    const size_t N = (size_t)p.width * p.height;
+    r.ro = mk3(0, 0, 0); r.rd = mk3(0, 0, 1); r.ray_ex0 = kInvalid;
+    r.radiance = mk3(0, 0, 0); r.beta = mk3(1, 1, 1); r.base = mk3(0, 0, 0);
+    r.depth = 0; r.prev_bsdf_pdf = 0.0f;
+    r.s_o = mk3(0, 0, 0); r.s_d = mk3(0, 0, 1); r.s_contrib = mk3(0, 0, 0);
+    r.s_tmax = -1.0f; r.s_ex0 = kInvalid; r.s_ex1 = kInvalid;
+    r.active = active; r.has_ray = active; r.has_shadow = false; r.s_add = false; r.s_depth1 = false;
+    r.finalize = false; r.lane_done = false;
+    r.samples_done = 0; r.pass_idx = 0; r.c_samples = 0;
+    r.cur_spp = (p.n_passes == 1) ? p.last_pass_spp : p.pass_spp;
+    r.c_closest = 0; r.c_shadow = 0; r.c_shaded = 0;
+    r.smp.pcg = Pcg32{0, 1}; r.smp.dim = 0;
+    r.film_rgb = mk3(0, 0, 0); r.film_w = 0.0f;
+    if (active) {
+        r.smp.pcg = p.states[pix];  // SamplerCreator::create, sampler/mod.rs:317-327
+        r.film_rgb = mk3(p.film[3 * (size_t)pix + 0], p.film[3 * (size_t)pix + 1], p.film[3 * (size_t)pix + 2]);
+        r.film_w = p.film[6 * N + pix];
+        pcg_start(r.smp.pcg, p.start);  // sampler.start(), sampler/mod.rs:199-203
+        generate_ray(p, sx, sy, r.smp, r.ro, r.rd);
+    }
+}
+
+// shifted pixel (pt.rs:1084-1088)
+AKR_D void shifted_pixel(const PtParams& p, uint32_t px, uint32_t py, uint32_t& sx, uint32_t& sy) {
+    int32_t sxi = (int32_t)px + p.pixel_offset[0], syi = (int32_t)py + p.pixel_offset[1];
+    sxi = sxi < 0 ? 0 : (sxi > (int32_t)p.width - 1 ? (int32_t)p.width - 1 : sxi);
+    syi = syi < 0 ? 0 : (syi > (int32_t)p.height - 1 ? (int32_t)p.height - 1 : syi);
+    sx = (uint32_t)sxi;
+    sy = (uint32_t)syi;
+}
+
+// Everything between two intersection phases for one lane: resolve the shadow ray traced together with `hit`, finish
+// the previous sample if it ended, shade the vertex found by the closest-hit ray (emission + MIS, light sample, BSDF
+// evaluate + sample, Russian roulette), and prepare the next pair of rays or the next camera ray.
+AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found, bool occluded, uint32_t pix, uint32_t sx, uint32_t sy) {
+    const DScene& sc = p.sc;
+    const size_t N = (size_t)p.width * p.height;
+    // ---- resolve the shadow ray (pt.rs:504-513) ----
+    if (r.has_shadow) {
+        if (!occluded && r.s_add) r.radiance = r.radiance + r.s_contrib;
+        if (r.s_depth1) r.base = r.radiance;
+        r.has_shadow = false;
+    }
+    // ---- finish the sample whose last vertex was shaded in the previous step ----
+    if (r.finalize) {
+        // pt.rs:871-876 (clamp_indirect = 1000), then film.add_sample with weight 1 (film.rs:196-229)
+        vec3 ind = r.radiance - r.base;
+        ind = mk3(clamp_f(ind.x, 0.0f, 1000.0f), clamp_f(ind.y, 0.0f, 1000.0f), clamp_f(ind.z, 0.0f, 1000.0f));
+        vec3 L = r.base + ind;
+        if (is_nan(L.x) || is_nan(L.y) || is_nan(L.z)) L = mk3(0, 0, 0);
+        r.film_rgb = mk3(r.film_rgb.x + L.x * 1.0f, r.film_rgb.y + L.y * 1.0f, r.film_rgb.z + L.z * 1.0f);
+        r.film_w = r.film_w + 1.0f;
+        r.radiance = mk3(0, 0, 0);
+        r.beta = mk3(1, 1, 1);
+        r.base = mk3(0, 0, 0);
+        r.depth = 0;
+        r.prev_bsdf_pdf = 0.0f;
+        r.finalize = false;
+        if (r.lane_done) {
+            r.active = false;
+            p.states[pix] = r.smp.pcg;
+            p.film[3 * (size_t)pix + 0] = r.film_rgb.x;
+            p.film[3 * (size_t)pix + 1] = r.film_rgb.y;
+            p.film[3 * (size_t)pix + 2] = r.film_rgb.z;
+            p.film[6 * N + pix] = r.film_w;
+        }
+    }
+    // ---- shade the vertex the closest-hit ray found ----
+    if (r.active && r.has_ray) {
+        bool terminated = false;
+        if (!found) {
+            terminated = true;  // pt.rs:381-396 (hit_envmap adds zero)
+        } else {
+            SurfacePoint si = surface_interaction(sc, hit.gid, mk2(hit.u, hit.v));
+            const DMaterial& mat = sc.materials[si.material];
+            vec3 wo = -r.rd;
+            {  // handle_surface_light, pt.rs:230-258
+                vec3 direct = mk3(0, 0, 0);
+                float w = 0.0f;
+                if (si.light >= 0 && (!p.indirect_only || r.depth > 1)) {
+                    vec3 emission = material_emission(mat);
+                    direct = dot(si.ng, r.rd) < 0.0f ? emission : mk3(0, 0, 0);
+                    if (r.depth == 0 || !p.use_nee)
+                        w = 1.0f;
+                    else
+                        w = mis_weight(r.prev_bsdf_pdf, pdf_direct(sc, si, hit.gid, r.ro));
+                }
+                if (p.debug_depth < 0 || r.depth == (uint32_t)p.debug_depth) r.radiance = r.radiance + r.beta * (direct * w);
+            }
+            if (r.depth == 0) r.base = r.radiance;
+            if (r.depth >= p.max_depth) {
+                terminated = true;
+            } else {
+                r.depth += 1;
+                r.c_shaded++;
+                vec3 u_direct = next_3d(r.smp);
+                LightSample dl;
+                dl.valid = false;
+                if (p.use_nee && (!p.indirect_only || r.depth > 1))
+                    dl = sample_direct(sc, si.p, si.ng, u_direct.x, mk2(u_direct.y, u_direct.z));
+                vec3 u_bsdf = next_3d(r.smp);
+                // sample_surface_and_shade_direct, pt.rs:297-323
+                ShadePoint sp;
+                shade_point_init(sp, mat, si.frame, si.ng, p.force_diffuse != 0);
+                if (dl.valid) {
+                    BsdfEval e = shade_evaluate(sp, mat, sc.ggx_table, wo, dl.wi);
+                    float w = mis_weight(dl.pdf, e.pdf);
+                    vec3 direct = div_s((dl.li * e.f) * w, dl.pdf);
+                    // the shadow ray is traced in the next intersection phase; what it would add is fixed now
+                    // (radiance += beta * direct with the beta of THIS vertex, pt.rs:134-138,508)
+                    r.s_contrib = r.beta * direct;
+                    r.s_add = p.debug_depth < 0 || r.depth == (uint32_t)p.debug_depth;
+                    r.s_depth1 = r.depth == 1;
+                    r.s_o = dl.ro;
+                    r.s_d = dl.wi;
+                    r.s_tmax = dl.tmax;
+                    r.s_ex0 = hit.gid;
+                    r.s_ex1 = dl.ex1;
+                    r.has_shadow = true;
+                }
+                BsdfSample bs = shade_sample(sp, mat, sc.ggx_table, wo, u_bsdf.x, mk2(u_bsdf.y, u_bsdf.z));
+                r.beta = r.beta * div_s(bs.color, bs.pdf);  // pt.rs:783
+                if (bs.pdf <= 0.0f || !bs.valid || min3(bs.color) < 0.0f) {
+                    terminated = true;  // pt.rs:832-842
+                } else {
+                    bool cont = true;
+                    if (r.depth > p.rr_depth) {  // pt.rs:211-224, 843-850
+                        float cont_prob = clamp_f(max3(r.beta), 0.0f, 1.0f) * 0.95f;
+                        if (next_1d(r.smp) >= cont_prob)
+                            cont = false;
+                        else
+                            r.beta = r.beta * div_s(mk3(1, 1, 1), cont_prob);
+                    }
+                    if (!cont) {
+                        terminated = true;
+                    } else {  // pt.rs:851-865
+                        r.prev_bsdf_pdf = bs.pdf;
+                        r.ro = offset_ray_origin(si.p, face_forward(si.ng, bs.wi));
+                        r.rd = bs.wi;
+                        r.ray_ex0 = hit.gid;
+                    }
+                }
+            }
+        }
+        if (terminated) {
+            // this sample draws no more random numbers: account for it and start the next camera ray now; its
+            // radiance is finished (above) after the shadow ray still pending has been resolved
+            r.finalize = true;
+            r.samples_done++;
+            r.c_samples++;
+            bool more = true;
+            if (r.samples_done == r.cur_spp) {
+                // end of a pass: Drop for IndependentSampler (sampler/mod.rs:168-177) = advance(-dim); the next
+                // pass re-creates the sampler from that state with dim = 0 (sampler/mod.rs:317-327)
+                pcg_advance(r.smp.pcg, -(int64_t)r.smp.dim);
+                r.smp.dim = 0;
+                r.samples_done = 0;
+                r.pass_idx++;
+                r.cur_spp = (r.pass_idx + 1 == p.n_passes) ? p.last_pass_spp : p.pass_spp;
+                more = r.pass_idx < p.n_passes;
+            }
+            if (more) {
+                pcg_start(r.smp.pcg, p.start);
+                generate_ray(p, sx, sy, r.smp, r.ro, r.rd);
+                r.ray_ex0 = kInvalid;
+            } else {
+                r.has_ray = false;
+                r.lane_done = true;
+            }
+        }
+    }
+}
+
+// per-launch counters (akr_pt_stats): one atomic per wave
+AKR_D void flush_counters(const PtParams& p, const PathRegs& r, const TraceCounters& tc, bool bvh) {
+    if (p.counters == nullptr) return;
+    uint32_t a = wave_sum_u32(r.c_samples), b = wave_sum_u32(r.c_closest), c = wave_sum_u32(r.c_shadow), e = wave_sum_u32(r.c_shaded);
+    uint32_t nn = wave_sum_u32(tc.nodes), nt = wave_sum_u32(tc.tris), ov = wave_sum_u32(tc.overflow);
+    if ((threadIdx.x & 63u) == 0) {
+        if (a) atomicAdd((unsigned long long*)&p.counters[0], (unsigned long long)a);
+        if (b) atomicAdd((unsigned long long*)&p.counters[1], (unsigned long long)b);
+        if (c) atomicAdd((unsigned long long*)&p.counters[2], (unsigned long long)c);
+        if (e) atomicAdd((unsigned long long*)&p.counters[3], (unsigned long long)e);
+        if (nn) atomicAdd((unsigned long long*)&p.counters[4], (unsigned long long)nn);
+        unsigned long long tt = bvh ? (unsigned long long)nt : (unsigned long long)(b + c) * p.sc.n_tris;
+        if (tt) atomicAdd((unsigned long long*)&p.counters[5], tt);
+        if (ov) atomicAdd((unsigned long long*)&p.counters[6], (unsigned long long)ov);
+    }
+}
+
+}  // namespace akr
