@@ -11,6 +11,7 @@ LIB = os.path.join(HERE, "libakari_hip.so")
 
 SOURCES = [
     "pt_kernels.hip",
+    "wf_kernels.hip",
     "host/api.cpp",
     "host/scene_build.cpp",
     "host/scene_json.cpp",
@@ -19,7 +20,7 @@ SOURCES = [
 ]
 HEADERS = [
     "kernels.h",
-    "device/dmath.h", "device/drng.h", "device/dgeom.h", "device/dbsdf.h", "device/dscene.h", "device/disect.h",
+    "device/dmath.h", "device/drng.h", "device/dgeom.h", "device/dbsdf.h", "device/dscene.h", "device/disect.h", "device/dpath.h",
     "host/scene_build.h", "host/json.h", "host/stdrng.h",
     "../../include/akari_hip.h",
 ]

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -134,6 +135,11 @@ struct akr_pt_session {
     akr_film* film = nullptr;
     akr_pt_config cfg;
     DevBuf states, counters;
+    // wavefront schedule (wf_kernels.hip): path state SoA + ray queues
+    bool wavefront = false;
+    DevBuf wf_state, wf_queues, wf_ctrl;
+    WfBuffers wf;
+    uint32_t wf_slots = 0, wf_trace_blocks = 0;
     uint32_t spp_done = 0, n_launches = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     PtParams params;
@@ -255,6 +261,70 @@ static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pas
     uint32_t n_tiles = p.tiles_x * p.tiles_y;
     uint32_t owned = p.shard_rank < n_tiles ? (n_tiles - p.shard_rank + p.shard_count - 1) / p.shard_count : 0;
     p.n_items = owned * p.tile_w * p.tile_h;
+}
+
+// Which schedule renders this session: "mega" = persistent-lane megakernel (pt_kernels.hip), "wavefront" = trace /
+// shade kernels with the path state in HBM (wf_kernels.hip; needs a BVH scene). AKR_PT_MODE selects; the default is the
+// megakernel, which measured faster on every configuration so far (on the 10 M-triangle hall both
+// schedules trace ~2 G rays/s -- the traversal is bound by the L1/L2 request rate of the node fetches, not by occupancy --
+// and the wavefront schedule pays for streaming the path state and for its per-iteration tail on top).
+static bool choose_wavefront(const akr_scene* scene) {
+    const char* env = std::getenv("AKR_PT_MODE");
+    std::string mode = env ? env : "auto";
+    const bool has_bvh = !scene->cs.bvh_nodes.empty();
+    if (mode == "mega") return false;
+    if (mode == "wavefront") {
+        if (!has_bvh) throw std::invalid_argument("AKR_PT_MODE=wavefront needs a BVH scene (more than 64 triangles, or AKR_FORCE_BVH=1)");
+        return true;
+    }
+    return false;
+}
+
+static void wf_allocate(akr_pt_session* se, uint32_t n_slots) {
+    se->wf_slots = n_slots;
+    const size_t n = n_slots ? n_slots : 1;
+    se->wf_state.alloc(12 * n * 16);  // 10 float4 + 2 uint4 arrays
+    char* base = (char*)se->wf_state.p;
+    auto take = [&](size_t k) { void* p = base + k * n * 16; return p; };
+    WfBuffers& w = se->wf;
+    w.ray_o = (float4*)take(0); w.ray_d = (float4*)take(1); w.sh_o = (float4*)take(2); w.sh_d = (float4*)take(3);
+    w.sh_c = (float4*)take(4); w.hit = (float4*)take(5); w.beta = (float4*)take(6); w.rad = (float4*)take(7);
+    w.base = (float4*)take(8); w.film = (float4*)take(9); w.rng = (uint4*)take(10); w.misc = (uint4*)take(11);
+    se->wf_queues.alloc(4 * n * sizeof(uint32_t));
+    uint32_t* q = (uint32_t*)se->wf_queues.p;
+    w.queue_closest[0] = q; w.queue_closest[1] = q + n; w.queue_shadow[0] = q + 2 * n; w.queue_shadow[1] = q + 3 * n;
+    se->wf_ctrl.alloc(8 * sizeof(uint32_t));
+    uint32_t* c = (uint32_t*)se->wf_ctrl.p;
+    w.qcount = c; w.qhead = c + 4; w.n_active = c + 5;
+    // persistent trace kernel: enough workgroups to fill every CU at its occupancy (LDS stack: 32 KB per workgroup)
+    se->wf_trace_blocks = (uint32_t)se->ctx->props.multiProcessorCount * 5u;
+}
+
+// One launch group of the wavefront schedule = `fused` passes for every slot: init, then trace/shade iterations until
+// no slot is active. The host only looks at the device every kCheckEvery iterations.
+static void wf_run(akr_pt_session* se) {
+    hipStream_t st = se->ctx->stream;
+    const PtParams& p = se->params;
+    uint32_t* ctrl = (uint32_t*)se->wf_ctrl.p;
+    HIP_CHECK(hipMemsetAsync(ctrl, 0, 8 * sizeof(uint32_t), st));
+    HIP_CHECK(launch_wf_init(p, se->wf, st));
+    const int kCheckEvery = 16;
+    uint32_t q = 0;
+    for (uint64_t iter = 0;; iter++) {
+        // queue q holds the rays to trace; reset the head, the other queue's counts and the active counter
+        HIP_CHECK(hipMemsetAsync(ctrl + 2 * (1 - q), 0, 2 * sizeof(uint32_t), st));
+        HIP_CHECK(hipMemsetAsync(ctrl + 4, 0, 2 * sizeof(uint32_t), st));
+        HIP_CHECK(launch_wf_trace(p, se->wf, q, se->wf_trace_blocks, st));
+        HIP_CHECK(launch_wf_shade(p, se->wf, 1 - q, st));
+        q = 1 - q;
+        if ((iter + 1) % kCheckEvery == 0) {
+            uint32_t n_active = 0;
+            HIP_CHECK(hipMemcpyAsync(&n_active, ctrl + 5, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            if (n_active == 0) break;
+        }
+        if (iter > (1ull << 26)) throw std::runtime_error("wavefront schedule did not terminate");
+    }
 }
 
 static void validate_config(const akr_pt_config& c) {
@@ -564,6 +634,11 @@ AKR_API int32_t akr_pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_co
         HIP_CHECK(launch_init_pcg32(dseeds.as<uint64_t>(), se->states.p, n, ctx->stream));
         se->counters.alloc(8 * sizeof(uint64_t));
         HIP_CHECK(hipMemsetAsync(se->counters.p, 0, 8 * sizeof(uint64_t), ctx->stream));
+        se->wavefront = choose_wavefront(scene);
+        if (se->wavefront) {
+            fill_params(se.get(), 1, cfg->spp_per_pass);  // for n_items
+            wf_allocate(se.get(), se->params.n_items);
+        }
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         *out = se.release();
     });
@@ -588,7 +663,8 @@ AKR_API int32_t akr_pt_passes(akr_pt_session* se, uint32_t n_passes, int32_t blo
             HIP_CHECK(hipEventCreate(&e0));
             HIP_CHECK(hipEventCreate(&e1));
             HIP_CHECK(hipEventRecord(e0, se->ctx->stream));
-            HIP_CHECK(launch_pt_pass(se->params, se->ctx->stream));
+            if (se->wavefront) wf_run(se);
+            else HIP_CHECK(launch_pt_pass(se->params, se->ctx->stream));
             HIP_CHECK(hipEventRecord(e1, se->ctx->stream));
             se->events.emplace_back(e0, e1);
             se->spp_done = done;

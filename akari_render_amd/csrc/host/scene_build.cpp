@@ -11,6 +11,7 @@
 #include "scene_build.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <stdexcept>
@@ -423,7 +424,9 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
     if (out.n_lights > 0) build_alias_table(light_weights, out.light_entries, out.light_pdf);
 
     // acceleration structure: tiny scenes are intersected exhaustively from the scalar cache, others get a BVH4
-    const uint32_t kExhaustiveMax = 64;
+    // (AKR_FORCE_BVH=1 builds the BVH for tiny scenes too: lets the tests run both intersectors on scenes/cbox)
+    const char* force = std::getenv("AKR_FORCE_BVH");
+    const uint32_t kExhaustiveMax = (force && force[0] == '1') ? 0u : 64u;
     if (n_tris > kExhaustiveMax) {
         float diag2 = 0.0f;
         for (int a = 0; a < 3; a++) diag2 += sqr(out.scene_hi[a] - out.scene_lo[a]);

@@ -35,7 +35,25 @@ struct PtParams {
     uint32_t tile_w, tile_h, tiles_x, tiles_y;
 };
 
+// Path state of the wavefront schedule (wf_kernels.hip): structure-of-arrays, one slot per pixel of the launch.
+struct WfBuffers {
+    float4 *ray_o, *ray_d;          // next closest-hit ray: o | exclude id ; d
+    float4 *sh_o, *sh_d, *sh_c;     // pending shadow ray: o | exclude0 ; d | tmax ; contribution | exclude1
+    float4* hit;                    // written by k_wf_trace: gid, u, v | occluded
+    float4 *beta, *rad, *base;      // beta | prev_bsdf_pdf ; radiance | depth ; base | flags
+    float4* film;                   // film accumulator of the slot's pixel: rgb | weight
+    uint4 *rng, *misc;              // pcg state, dim, samples_done ; pass_idx, cur_spp, pcg inc
+    uint32_t* queue_closest[2];     // ray queues (slot ids), double-buffered
+    uint32_t* queue_shadow[2];
+    uint32_t* qcount;               // [4]: closest/shadow counts of queue 0, of queue 1
+    uint32_t* qhead;                // next unclaimed ray id of the queue being traced
+    uint32_t* n_active;             // slots still active after the last shade
+};
+
 hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream);
+hipError_t launch_wf_init(const PtParams& p, const WfBuffers& wf, hipStream_t stream);
+hipError_t launch_wf_shade(const PtParams& p, const WfBuffers& wf, uint32_t q_out, hipStream_t stream);
+hipError_t launch_wf_trace(const PtParams& p, const WfBuffers& wf, uint32_t q_in, uint32_t n_blocks, hipStream_t stream);
 hipError_t launch_init_pcg32(const uint64_t* seeds, void* states, uint64_t n, hipStream_t stream);
 hipError_t launch_film_resolve(const float* film, uint64_t n, float* rgb, hipStream_t stream);
 hipError_t launch_ggx_table(const uint64_t* seeds, float* table, uint32_t samples, hipStream_t stream);

@@ -1,0 +1,291 @@
+// wf_kernels.hip -- wavefront schedule of the same path tracer, for scenes whose intersection cost is dominated by
+// BVH traversal (BASELINE configs[3], 10 M triangles).
+//
+// The megakernel (pt_kernels.hip) keeps a whole path in one lane's registers; with a BVH that means ~120 live
+// registers around a divergent traversal loop (4 waves/SIMD, 26 % VALU lane utilisation, 69 % of wave cycles waiting
+// on memory on the 10 M-triangle hall). Here the two halves are separate kernels and the path state streams through
+// HBM between them (structure-of-arrays, 16-byte records, one slot per pixel):
+//   k_wf_trace  persistent waves pull ray ids from a queue: when a lane's ray ends it takes the next id immediately
+//               (wave64 __ballot + popcount prefix + one atomicAdd per wave) instead of idling until the slowest
+//               lane of its wave is done; only ray + traversal registers are live, so 7-8 waves/SIMD hide latency;
+//   k_wf_shade  one thread per path slot: path_step() of device/dpath.h (identical arithmetic to the megakernel),
+//               then stream compaction of the rays it produced into the next queue (ballot/prefix-sum again).
+// The reference's author sketched the same decomposition in crates/akari_integrator/src/wfpt.rs:59-225,315-494
+// (PathState SoA, KernelWorkQueue, raygen / intersect / shade / test_shadow); that file never runs there.
+#include "device/dpath.h"
+
+namespace akr {
+
+enum : uint32_t {
+    WF_ACTIVE = 1u, WF_HAS_RAY = 2u, WF_HAS_SHADOW = 4u, WF_S_ADD = 8u, WF_S_DEPTH1 = 16u, WF_FINALIZE = 32u, WF_LANE_DONE = 64u
+};
+
+AKR_D void wf_store(const WfBuffers& wf, uint32_t slot, const PathRegs& r) {
+    wf.ray_o[slot] = make_float4(r.ro.x, r.ro.y, r.ro.z, u2f(r.ray_ex0));
+    wf.ray_d[slot] = make_float4(r.rd.x, r.rd.y, r.rd.z, 0.0f);
+    wf.sh_o[slot] = make_float4(r.s_o.x, r.s_o.y, r.s_o.z, u2f(r.s_ex0));
+    wf.sh_d[slot] = make_float4(r.s_d.x, r.s_d.y, r.s_d.z, r.s_tmax);
+    wf.sh_c[slot] = make_float4(r.s_contrib.x, r.s_contrib.y, r.s_contrib.z, u2f(r.s_ex1));
+    wf.beta[slot] = make_float4(r.beta.x, r.beta.y, r.beta.z, r.prev_bsdf_pdf);
+    wf.rad[slot] = make_float4(r.radiance.x, r.radiance.y, r.radiance.z, u2f(r.depth));
+    uint32_t fl = (r.active ? WF_ACTIVE : 0u) | (r.has_ray ? WF_HAS_RAY : 0u) | (r.has_shadow ? WF_HAS_SHADOW : 0u) |
+                  (r.s_add ? WF_S_ADD : 0u) | (r.s_depth1 ? WF_S_DEPTH1 : 0u) | (r.finalize ? WF_FINALIZE : 0u) |
+                  (r.lane_done ? WF_LANE_DONE : 0u);
+    wf.base[slot] = make_float4(r.base.x, r.base.y, r.base.z, u2f(fl));
+    wf.film[slot] = make_float4(r.film_rgb.x, r.film_rgb.y, r.film_rgb.z, r.film_w);
+    wf.rng[slot] = make_uint4((uint32_t)r.smp.pcg.state, (uint32_t)(r.smp.pcg.state >> 32), r.smp.dim, r.samples_done);
+    wf.misc[slot] = make_uint4(r.pass_idx, r.cur_spp, (uint32_t)r.smp.pcg.inc, (uint32_t)(r.smp.pcg.inc >> 32));
+}
+AKR_D void wf_load(const WfBuffers& wf, uint32_t slot, PathRegs& r) {
+    float4 a = wf.ray_o[slot], b = wf.ray_d[slot], c = wf.sh_o[slot], d = wf.sh_d[slot], e = wf.sh_c[slot];
+    float4 f = wf.beta[slot], g = wf.rad[slot], h = wf.base[slot], fm = wf.film[slot];
+    uint4 rg = wf.rng[slot], ms = wf.misc[slot];
+    r.ro = xyz(a); r.ray_ex0 = f2u(a.w);
+    r.rd = xyz(b);
+    r.s_o = xyz(c); r.s_ex0 = f2u(c.w);
+    r.s_d = xyz(d); r.s_tmax = d.w;
+    r.s_contrib = xyz(e); r.s_ex1 = f2u(e.w);
+    r.beta = xyz(f); r.prev_bsdf_pdf = f.w;
+    r.radiance = xyz(g); r.depth = f2u(g.w);
+    r.base = xyz(h);
+    uint32_t fl = f2u(h.w);
+    r.active = fl & WF_ACTIVE; r.has_ray = fl & WF_HAS_RAY; r.has_shadow = fl & WF_HAS_SHADOW; r.s_add = fl & WF_S_ADD;
+    r.s_depth1 = fl & WF_S_DEPTH1; r.finalize = fl & WF_FINALIZE; r.lane_done = fl & WF_LANE_DONE;
+    r.film_rgb = xyz(fm); r.film_w = fm.w;
+    r.smp.pcg.state = (uint64_t)rg.x | ((uint64_t)rg.y << 32);
+    r.smp.dim = rg.z;
+    r.samples_done = rg.w;
+    r.pass_idx = ms.x; r.cur_spp = ms.y;
+    r.smp.pcg.inc = (uint64_t)ms.z | ((uint64_t)ms.w << 32);
+    r.c_samples = r.c_closest = r.c_shadow = r.c_shaded = 0;
+}
+
+// wave64 stream compaction: every lane with `want` gets a distinct index into the queue; one atomicAdd per wave
+AKR_D uint32_t wave_enqueue_index(bool want, uint32_t* counter) {
+    const uint64_t mask = __builtin_amdgcn_ballot_w64(want);
+    if (mask == 0) return 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(mask));
+    base = __shfl(base, __builtin_ctzll(mask), 64);
+    return base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+}
+
+AKR_D void wf_enqueue(const WfBuffers& wf, uint32_t q, uint32_t slot, PathRegs& r) {
+    // closest-hit rays and shadow rays go to separate queues so that waves of the trace kernel are homogeneous
+    bool want_c = r.active && r.has_ray, want_s = r.active && r.has_shadow;
+    uint32_t ic = wave_enqueue_index(want_c, &wf.qcount[2 * q + 0]);
+    if (want_c) { wf.queue_closest[q][ic] = slot; r.c_closest++; }
+    uint32_t is = wave_enqueue_index(want_s, &wf.qcount[2 * q + 1]);
+    if (want_s) { wf.queue_shadow[q][is] = slot; r.c_shadow++; }
+    uint32_t na = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(r.active));
+    if ((threadIdx.x & 63u) == 0 && na) atomicAdd(wf.n_active, na);
+}
+
+__global__ __launch_bounds__(256) void k_wf_init(const PtParams p, const WfBuffers wf) {
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    uint32_t px = 0, py = 0;
+    const bool in_frame = slot < p.n_items && item_to_pixel(p, slot, px, py);
+    const uint32_t pix = px + py * p.width;
+    uint32_t sx, sy;
+    shifted_pixel(p, px, py, sx, sy);
+    PathRegs r;
+    path_regs_init(r, p, in_frame, pix, sx, sy);
+    if (slot < p.n_items) wf_store(wf, slot, r);
+    wf_enqueue(wf, 0, slot, r);
+    flush_counters(p, r, TraceCounters{0, 0, 0}, true);
+}
+
+__global__ __launch_bounds__(256) void k_wf_shade(const PtParams p, const WfBuffers wf, uint32_t q_out) {
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    PathRegs r;
+    r.active = false; r.has_ray = false; r.has_shadow = false;
+    r.c_samples = r.c_closest = r.c_shadow = r.c_shaded = 0;
+    bool live = false;
+    if (slot < p.n_items) live = (f2u(wf.base[slot].w) & WF_ACTIVE) != 0;
+    if (live) {
+        uint32_t px = 0, py = 0;
+        item_to_pixel(p, slot, px, py);
+        const uint32_t pix = px + py * p.width;
+        uint32_t sx, sy;
+        shifted_pixel(p, px, py, sx, sy);
+        wf_load(wf, slot, r);
+        float4 hv = wf.hit[slot];
+        Hit hit;
+        hit.gid = f2u(hv.x); hit.u = hv.y; hit.v = hv.z; hit.t = 0.0f;
+        bool found = hit.gid != kInvalid, occluded = f2u(hv.w) != 0;
+        path_step(p, r, hit, found, occluded, pix, sx, sy);
+        wf_store(wf, slot, r);
+    }
+    wf_enqueue(wf, q_out, slot, r);
+    flush_counters(p, r, TraceCounters{0, 0, 0}, true);
+}
+
+// Persistent traversal kernel. Ray id = slot; ids [0, n_closest) come from the closest-hit queue, the rest from the
+// shadow queue. A lane that finishes its ray writes the result and becomes idle; when enough lanes of the wave are
+// idle (or all), the wave refills them from the queue head.
+#ifndef AKR_WF_REFILL_IDLE
+#define AKR_WF_REFILL_IDLE 20  // refill when at least this many of the 64 lanes are idle
+#endif
+__global__ __launch_bounds__(256) void k_wf_trace(const PtParams p, const WfBuffers wf, uint32_t q_in) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+    uint32_t* stack = lds_stack + threadIdx.x;
+    const DScene& sc = p.sc;
+    const uint32_t n_closest = wf.qcount[2 * q_in + 0], n_total = n_closest + wf.qcount[2 * q_in + 1];
+    const uint32_t lane = threadIdx.x & 63u;
+    TraceCounters cnt{0, 0, 0};
+    bool has = false, exhausted = false, any = false;
+    uint32_t slot = 0, e0 = kInvalid, e1 = kInvalid, sp = 0, cur = kBvhDone, best = kInvalid;
+    vec3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), inv = mk3(0, 0, 0), noi = mk3(0, 0, 0);
+    float tmax = 0.0f, best_t = 0.0f, best_u = 0.0f, best_v = 0.0f;
+#define AKR_PUSH(ref)                                  \
+    {                                                  \
+        if (sp < kBvhStackDepth) {                     \
+            stack[sp * 256u] = (ref);                  \
+            sp++;                                      \
+        } else {                                       \
+            cnt.overflow = 1;                          \
+        }                                              \
+    }
+    for (;;) {
+        if (!exhausted) {  // refill idle lanes from the queue head
+            const uint64_t idle = __builtin_amdgcn_ballot_w64(!has);
+            if (idle != 0) {
+                const uint32_t n = (uint32_t)__builtin_popcountll(idle);
+                uint32_t base = 0;
+                if (lane == (uint32_t)__builtin_ctzll(idle)) base = atomicAdd(wf.qhead, n);
+                base = __shfl(base, __builtin_ctzll(idle), 64);
+                const uint32_t my = base + (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
+                if (!has && my < n_total) {
+                    any = my >= n_closest;
+                    slot = any ? wf.queue_shadow[q_in][my - n_closest] : wf.queue_closest[q_in][my];
+                    float4 a = any ? wf.sh_o[slot] : wf.ray_o[slot];
+                    float4 b = any ? wf.sh_d[slot] : wf.ray_d[slot];
+                    o = xyz(a); d = xyz(b);
+                    e0 = f2u(a.w);
+                    e1 = any ? f2u(wf.sh_c[slot].w) : kInvalid;
+                    tmax = any ? b.w : 1e20f;
+                    inv = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+                    noi = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+                    best_t = tmax; best = kInvalid; best_u = 0.0f; best_v = 0.0f;
+                    sp = 0; cur = 0;
+                    has = true;
+                }
+                if (base + n >= n_total) exhausted = true;
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(has) == 0) break;
+        for (;;) {
+            while (has && !(cur & kBvhLeafBit)) {  // inner nodes
+                const float4* n = sc.bvh_nodes + (size_t)cur * 8;
+                float4 lx = n[0], hx = n[1], ly = n[2], hy = n[3], lz = n[4], hz = n[5], cr = n[6];
+                cnt.nodes++;
+                float tn[4];
+                uint32_t ch[4] = {f2u(cr.x), f2u(cr.y), f2u(cr.z), f2u(cr.w)};
+                const float lxs[4] = {lx.x, lx.y, lx.z, lx.w}, hxs[4] = {hx.x, hx.y, hx.z, hx.w};
+                const float lys[4] = {ly.x, ly.y, ly.z, ly.w}, hys[4] = {hy.x, hy.y, hy.z, hy.w};
+                const float lzs[4] = {lz.x, lz.y, lz.z, lz.w}, hzs[4] = {hz.x, hz.y, hz.z, hz.w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    float ax = __builtin_fmaf(lxs[i], inv.x, noi.x), bx = __builtin_fmaf(hxs[i], inv.x, noi.x);
+                    float ay = __builtin_fmaf(lys[i], inv.y, noi.y), by = __builtin_fmaf(hys[i], inv.y, noi.y);
+                    float az = __builtin_fmaf(lzs[i], inv.z, noi.z), bz = __builtin_fmaf(hzs[i], inv.z, noi.z);
+                    float near = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
+                                                 __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
+                    float far = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
+                                                __builtin_fminf(__builtin_fmaxf(az, bz), best_t));
+                    tn[i] = ((near <= far) & (ch[i] != kInvalid)) ? near : __builtin_inff();
+                }
+#define AKR_CSWAP(a, b)                                            \
+    {                                                              \
+        bool sw = tn[b] < tn[a];                                   \
+        float tf = sw ? tn[b] : tn[a], tg = sw ? tn[a] : tn[b];    \
+        uint32_t cf = sw ? ch[b] : ch[a], cg = sw ? ch[a] : ch[b]; \
+        tn[a] = tf; tn[b] = tg; ch[a] = cf; ch[b] = cg;            \
+    }
+                AKR_CSWAP(0, 1) AKR_CSWAP(2, 3) AKR_CSWAP(0, 2) AKR_CSWAP(1, 3) AKR_CSWAP(1, 2)
+#undef AKR_CSWAP
+                if (tn[3] < __builtin_inff()) AKR_PUSH(ch[3])
+                if (tn[2] < __builtin_inff()) AKR_PUSH(ch[2])
+                if (tn[1] < __builtin_inff()) AKR_PUSH(ch[1])
+                if (tn[0] < __builtin_inff()) {
+                    cur = ch[0];
+                } else if (sp > 0) {
+                    sp--; cur = stack[sp * 256u];
+                } else {
+                    cur = kBvhDone;
+                }
+            }
+            if (has && cur != kBvhDone) {  // leaf
+                const uint32_t first = cur & 0x0fffffffu, count = (cur >> 28) & 7u;
+                bool stop = false;
+                for (uint32_t i = 0; i < count; i++) {
+                    const uint32_t k = first + i;
+                    float4 r0 = sc.woop[3 * (size_t)k + 0], r1 = sc.woop[3 * (size_t)k + 1], r2 = sc.woop[3 * (size_t)k + 2];
+                    cnt.tris++;
+                    float t, u, v;
+                    bool h = tri_test(o, d, r0, r1, r2, 0.0f, tmax, t, u, v);
+                    if (h) {
+                        uint32_t gid = sc.tri_gid[k];
+                        h = (gid != e0) & (gid != e1);
+                        if (h && sc.has_alpha) h = alpha_test(sc, gid, u, v);
+                        if (h) {
+                            if (any) {
+                                best = gid;
+                                stop = true;
+                            } else {
+                                bool better = (best == kInvalid) | (t < best_t) | ((t == best_t) & (gid < best));
+                                if (better) { best_t = t; best_u = u; best_v = v; best = gid; }
+                            }
+                        }
+                    }
+                }
+                if (stop) cur = kBvhDone;
+                else if (sp > 0) { sp--; cur = stack[sp * 256u]; }
+                else cur = kBvhDone;
+            }
+            if (has && cur == kBvhDone) {  // ray finished: publish the result for k_wf_shade
+                float* hp = (float*)&wf.hit[slot];
+                if (any) {
+                    hp[3] = u2f(best != kInvalid ? 1u : 0u);
+                } else {
+                    hp[0] = u2f(best); hp[1] = best_u; hp[2] = best_v;
+                }
+                has = false;
+            }
+            const uint32_t n_idle = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(!has));
+            if (n_idle == 64u) break;
+            if (!exhausted && n_idle >= AKR_WF_REFILL_IDLE) break;
+        }
+    }
+#undef AKR_PUSH
+    // traversal counters
+    if (p.counters != nullptr) {
+        uint32_t nn = wave_sum_u32(cnt.nodes), nt = wave_sum_u32(cnt.tris), ov = wave_sum_u32(cnt.overflow);
+        if (lane == 0) {
+            if (nn) atomicAdd((unsigned long long*)&p.counters[4], (unsigned long long)nn);
+            if (nt) atomicAdd((unsigned long long*)&p.counters[5], (unsigned long long)nt);
+            if (ov) atomicAdd((unsigned long long*)&p.counters[6], (unsigned long long)ov);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- launchers
+hipError_t launch_wf_init(const PtParams& p, const WfBuffers& wf, hipStream_t stream) {
+    uint32_t blocks = (p.n_items + 255u) / 256u;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_wf_init, dim3(blocks), dim3(256), 0, stream, p, wf);
+    return hipGetLastError();
+}
+hipError_t launch_wf_shade(const PtParams& p, const WfBuffers& wf, uint32_t q_out, hipStream_t stream) {
+    uint32_t blocks = (p.n_items + 255u) / 256u;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_wf_shade, dim3(blocks), dim3(256), 0, stream, p, wf, q_out);
+    return hipGetLastError();
+}
+hipError_t launch_wf_trace(const PtParams& p, const WfBuffers& wf, uint32_t q_in, uint32_t n_blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(k_wf_trace, dim3(n_blocks), dim3(256), kBvhStackDepth * 256 * 4, stream, p, wf, q_in);
+    return hipGetLastError();
+}
+
+}  // namespace akr

@@ -213,3 +213,46 @@ def test_procedural_hall_small(ctx):
     assert abs(sd.n_triangles() - 20_000) < 0.03 * 20_000
     g, o, gst, ost, _, _ = render_both(ctx, sd, make_config(spp=4, spp_per_pass=4, max_depth=5))
     assert_parity(g, o, 96, 54, gst, ost)
+
+
+# ---- the wavefront schedule (wf_kernels.hip): same arithmetic, different kernels -> same bits ----
+@pytest.fixture
+def wavefront_mode(monkeypatch):
+    monkeypatch.setenv("AKR_PT_MODE", "wavefront")
+    monkeypatch.setenv("AKR_FORCE_BVH", "1")
+
+
+@pytest.mark.parametrize("case", ["cbox_full", "cbox_diffuse", "glass_coat", "kinds", "alpha", "grid_normals", "hall", "ragged_passes", "no_nee"])
+def test_wavefront_schedule_matches_oracle(ctx, cbox_path, root, wavefront_mode, case):
+    cfg = make_config(spp=16, spp_per_pass=8, max_depth=8)
+    if case in ("cbox_full", "cbox_diffuse", "ragged_passes", "no_nee"):
+        sd = scene_json.load_scene(cbox_path, 96, 72)
+        if case == "cbox_diffuse":
+            cfg = make_config(spp=16, spp_per_pass=8, force_diffuse=1)
+        if case == "ragged_passes":
+            cfg = make_config(spp=11, spp_per_pass=4)
+        if case == "no_nee":
+            cfg = make_config(spp=8, use_nee=0)
+    elif case in ("glass_coat", "kinds", "alpha"):
+        sd = cbox_variant(scene_json.load_scene(cbox_path, 64, 64), case)
+        sd.ggx_table = np.fromfile(os.path.join(root, "tests", "golden", "ggx_dielectric_s.f32"), dtype=np.float32)
+    elif case == "grid_normals":
+        sd = grid_scene(n=24, width=80, height=48, with_normals=True)
+    else:
+        from akari_render_amd import procedural
+        sd = procedural.sponza_like(20_000, seed=1234, width=96, height=54)
+        cfg = make_config(spp=4, spp_per_pass=4, max_depth=5)
+    g, o, gst, ost, gs, os_ = render_both(ctx, sd, cfg, want_states=True)
+    assert gst["n_node_visits"] > 0  # went through the BVH / wavefront kernels
+    assert_parity(g, o, sd.camera.width, sd.camera.height, gst, ost)
+    assert np.array_equal(gs, os_)
+
+
+def test_wavefront_equals_megakernel_sharded(ctx, cbox_path, wavefront_mode):
+    sd = scene_json.load_scene(cbox_path, 120, 80)
+    scene = capi.Scene(ctx, sd)
+    cfg = distributed.shard_config(make_config(spp=8, spp_per_pass=4), 1, 3, 32, 16)
+    a = capi.Film(ctx, 120, 80)
+    capi.pt_render(ctx, scene, cfg, a)
+    o, _ = pyoracle.OracleScene(sd).render(cfg)
+    assert n_bit_diff(a.read(), o) == 0
