@@ -165,6 +165,33 @@ AKR_D float safe_inv(float d) {
     float a = abs_f(d) < 1e-20f ? __builtin_copysignf(1e-20f, d) : d;
     return __builtin_amdgcn_rcpf(a);
 }
+// One BVH4 node: 64 bytes = 4 x 16-byte loads (host/bvh.cpp). Child boxes are 8-bit offsets from the node's own
+// (padded) lower corner in units of a per-axis power of two, rounded outwards, so the decoded boxes contain the exact
+// ones: lo = origin + q_lo * 2^e, hi = origin + q_hi * 2^e. With t = plane * inv + noi the slab distances become
+// t = q * (2^e * inv) + (origin * inv + noi): one v_cvt_f32_ubyte + one fma per plane.
+// Writes the entry distance of every child the ray enters within [tmin, tlimit] (inf otherwise) and the child refs.
+AKR_D void bvh4_node_test(const DScene& sc, uint32_t node, vec3 inv, vec3 noi, float tmin, float tlimit, float tn[4], uint32_t ch[4]) {
+    const uint4* n = (const uint4*)sc.bvh_nodes + (size_t)node * 4;
+    const uint4 r0 = n[0], r1 = n[1], r2 = n[2], r3 = n[3];
+    const float sx = u2f((r0.w & 0xffu) << 23), sy = u2f(((r0.w >> 8) & 0xffu) << 23), sz = u2f(((r0.w >> 16) & 0xffu) << 23);
+    const float ax = __builtin_fmaf(u2f(r0.x), inv.x, noi.x), ay = __builtin_fmaf(u2f(r0.y), inv.y, noi.y), az = __builtin_fmaf(u2f(r0.z), inv.z, noi.z);
+    const float bx = sx * inv.x, by = sy * inv.y, bz = sz * inv.z;
+    ch[0] = r2.z; ch[1] = r2.w; ch[2] = r3.x; ch[3] = r3.y;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float lx = (float)((r1.x >> (8 * i)) & 0xffu), ly = (float)((r1.y >> (8 * i)) & 0xffu), lz = (float)((r1.z >> (8 * i)) & 0xffu);
+        const float hx = (float)((r1.w >> (8 * i)) & 0xffu), hy = (float)((r2.x >> (8 * i)) & 0xffu), hz = (float)((r2.y >> (8 * i)) & 0xffu);
+        float t0x = __builtin_fmaf(lx, bx, ax), t1x = __builtin_fmaf(hx, bx, ax);
+        float t0y = __builtin_fmaf(ly, by, ay), t1y = __builtin_fmaf(hy, by, ay);
+        float t0z = __builtin_fmaf(lz, bz, az), t1z = __builtin_fmaf(hz, bz, az);
+        float near = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
+                                     __builtin_fmaxf(__builtin_fminf(t0z, t1z), tmin));
+        float far = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),
+                                    __builtin_fminf(__builtin_fmaxf(t0z, t1z), tlimit));
+        tn[i] = ((near <= far) & (ch[i] != kInvalid)) ? near : __builtin_inff();  // empty slots carry ref 0xffffffff
+    }
+}
+
 template <bool ANY_HIT>
 AKR_D bool trace_bvh4(const DScene& sc, vec3 o, vec3 d, float tmin, float tmax, uint32_t ex0, uint32_t ex1, Hit& hit,
                       uint32_t* __restrict__ stack, TraceCounters& cnt) {
@@ -186,25 +213,10 @@ AKR_D bool trace_bvh4(const DScene& sc, vec3 o, vec3 d, float tmin, float tmax, 
     }
     for (;;) {
         while (!(cur & kBvhLeafBit)) {
-            const float4* n = sc.bvh_nodes + (size_t)cur * 8;
-            float4 lx = n[0], hx = n[1], ly = n[2], hy = n[3], lz = n[4], hz = n[5], cr = n[6];
             cnt.nodes++;
             float tn[4];
-            uint32_t ch[4] = {f2u(cr.x), f2u(cr.y), f2u(cr.z), f2u(cr.w)};
-            const float lxs[4] = {lx.x, lx.y, lx.z, lx.w}, hxs[4] = {hx.x, hx.y, hx.z, hx.w};
-            const float lys[4] = {ly.x, ly.y, ly.z, ly.w}, hys[4] = {hy.x, hy.y, hy.z, hy.w};
-            const float lzs[4] = {lz.x, lz.y, lz.z, lz.w}, hzs[4] = {hz.x, hz.y, hz.z, hz.w};
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                float ax = __builtin_fmaf(lxs[i], inv.x, noi.x), bx = __builtin_fmaf(hxs[i], inv.x, noi.x);
-                float ay = __builtin_fmaf(lys[i], inv.y, noi.y), by = __builtin_fmaf(hys[i], inv.y, noi.y);
-                float az = __builtin_fmaf(lzs[i], inv.z, noi.z), bz = __builtin_fmaf(hzs[i], inv.z, noi.z);
-                float near = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
-                                             __builtin_fmaxf(__builtin_fminf(az, bz), tmin));
-                float far = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
-                                            __builtin_fminf(__builtin_fmaxf(az, bz), best_t));
-                tn[i] = ((near <= far) & (ch[i] != kInvalid)) ? near : __builtin_inff();  // empty slots carry ref 0xffffffff
-            }
+            uint32_t ch[4];
+            bvh4_node_test(sc, cur, inv, noi, tmin, best_t, tn, ch);
             if (!ANY_HIT) {
                 // sort the four (tn, ch) pairs ascending with a 5-comparator network
 #define AKR_CSWAP(a, b)                                          \

@@ -215,7 +215,7 @@ static void scene_finish(akr_scene* s) {
     d.bvh_nodes = s->bvh_nodes.as<float4>();
     d.n_tris = cs.n_tris;
     d.n_lights = cs.n_lights;
-    d.n_nodes = (uint32_t)(cs.bvh_nodes.size() / 32);
+    d.n_nodes = (uint32_t)(cs.bvh_nodes.size() / 16);
     d.has_alpha = cs.has_alpha ? 1u : 0u;
     s->device_bytes = 0;
     for (const DevBuf* b : {&s->woop, &s->tri_gid, &s->shade, &s->normals, &s->inst, &s->materials, &s->ggx_table, &s->light_entries,
@@ -432,7 +432,7 @@ AKR_API int32_t akr_scene_get_info(const akr_scene* s, akr_scene_info* info) {
     info->n_triangles = s->cs.n_tris;
     info->n_materials = (uint32_t)s->flat.materials.size();
     info->n_lights = s->cs.n_lights;
-    info->n_bvh_nodes = (uint32_t)(s->cs.bvh_nodes.size() / 32);
+    info->n_bvh_nodes = (uint32_t)(s->cs.bvh_nodes.size() / 16);
     info->uses_bvh = s->cs.bvh_nodes.empty() ? 0u : 1u;
     info->device_bytes = s->device_bytes;
     return AKR_OK;

@@ -51,7 +51,7 @@ struct CompiledScene {
     std::vector<uint32_t> light_inst, light_tri_offset, light_n_tris;
     std::vector<AliasEntry> area_entries;
     std::vector<float> area_pdf;
-    // BVH4 nodes (8 float4 each) or empty for the exhaustive path
+    // BVH4 nodes (16 words = 64 B each, host/bvh.cpp) or empty for the exhaustive path
     std::vector<float> bvh_nodes;
     bool has_alpha = false;
     bool needs_ggx_table = false;

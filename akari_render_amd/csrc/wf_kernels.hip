@@ -177,25 +177,10 @@ __global__ __launch_bounds__(256) void k_wf_trace(const PtParams p, const WfBuff
         if (__builtin_amdgcn_ballot_w64(has) == 0) break;
         for (;;) {
             while (has && !(cur & kBvhLeafBit)) {  // inner nodes
-                const float4* n = sc.bvh_nodes + (size_t)cur * 8;
-                float4 lx = n[0], hx = n[1], ly = n[2], hy = n[3], lz = n[4], hz = n[5], cr = n[6];
                 cnt.nodes++;
                 float tn[4];
-                uint32_t ch[4] = {f2u(cr.x), f2u(cr.y), f2u(cr.z), f2u(cr.w)};
-                const float lxs[4] = {lx.x, lx.y, lx.z, lx.w}, hxs[4] = {hx.x, hx.y, hx.z, hx.w};
-                const float lys[4] = {ly.x, ly.y, ly.z, ly.w}, hys[4] = {hy.x, hy.y, hy.z, hy.w};
-                const float lzs[4] = {lz.x, lz.y, lz.z, lz.w}, hzs[4] = {hz.x, hz.y, hz.z, hz.w};
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    float ax = __builtin_fmaf(lxs[i], inv.x, noi.x), bx = __builtin_fmaf(hxs[i], inv.x, noi.x);
-                    float ay = __builtin_fmaf(lys[i], inv.y, noi.y), by = __builtin_fmaf(hys[i], inv.y, noi.y);
-                    float az = __builtin_fmaf(lzs[i], inv.z, noi.z), bz = __builtin_fmaf(hzs[i], inv.z, noi.z);
-                    float near = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
-                                                 __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
-                    float far = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
-                                                __builtin_fminf(__builtin_fmaxf(az, bz), best_t));
-                    tn[i] = ((near <= far) & (ch[i] != kInvalid)) ? near : __builtin_inff();
-                }
+                uint32_t ch[4];
+                bvh4_node_test(sc, cur, inv, noi, 0.0f, best_t, tn, ch);
 #define AKR_CSWAP(a, b)                                            \
     {                                                              \
         bool sw = tn[b] < tn[a];                                   \

@@ -209,7 +209,7 @@ typedef enum {
     AKR_ARRAY_SHADE = 2,         /* f32[32 * n_tris]  shading records by global triangle id */
     AKR_ARRAY_INSTANCES = 3,     /* f32[32 * n_instances] */
     AKR_ARRAY_MATERIALS = 4,     /* folded materials, 256 B each */
-    AKR_ARRAY_BVH_NODES = 5,     /* f32[32 * n_bvh_nodes] */
+    AKR_ARRAY_BVH_NODES = 5,     /* u32[16 * n_bvh_nodes]: 64-byte quantised BVH4 nodes (csrc/host/bvh.cpp) */
     AKR_ARRAY_LIGHT_ENTRIES = 6, /* {u32 j, f32 t}[n_lights] */
     AKR_ARRAY_LIGHT_PDF = 7,     /* f32[n_lights] */
     AKR_ARRAY_AREA_ENTRIES = 8,  /* {u32 j, f32 t}[sum of light triangle counts] */

@@ -110,42 +110,56 @@ def test_material_flags(hip_lib, cbox_path):
 
 
 def test_bvh_structure(hip_lib):
+    """64-byte quantised BVH4 nodes (csrc/host/bvh.cpp): every triangle in exactly one leaf, decoded child boxes
+    contain their triangles and nest inside the parent's decoded box."""
     sd = grid_scene(n=20)
     sc = capi.Scene(None, sd)
-    nodes = sc.array(capi.ARRAY_BVH_NODES, np.float32).reshape(-1, 32)
+    nodes = sc.array(capi.ARRAY_BVH_NODES, np.uint32).reshape(-1, 16)
+    assert nodes.shape[0] == sc.info().n_bvh_nodes
     gid = sc.array(capi.ARRAY_TRI_GID, np.uint32)
     woop = sc.array(capi.ARRAY_WOOP, np.float32).reshape(-1, 12)
     n_tris = sc.info().n_triangles
     assert sorted(gid.tolist()) == list(range(n_tris))
-    # world-space vertices from the oracle's view: reconstruct from shade records + instance matrices
     shade = sc.array(capi.ARRAY_SHADE, np.float32).reshape(-1, 32)
     inst = sc.array(capi.ARRAY_INSTANCES, np.float32).reshape(-1, 32)
     def world(g):
         r = shade[g]; m = inst[int(r[26:27].view(np.uint32)[0])]
         M = np.stack([m[0:3], m[4:7], m[8:11]], axis=1); t = m[12:15]
         return np.stack([M @ r[0:3] + t, M @ r[4:7] + t, M @ r[8:11] + t])
+    def decode(nd):
+        origin = nd[0:3].view(np.float32).astype(np.float32)
+        e = np.array([(int(nd[3]) >> (8 * a)) & 0xFF for a in range(3)])
+        scale = np.array([np.float32(2.0) ** np.float32(int(x) - 127) for x in e], dtype=np.float32)
+        q = [[(int(nd[4 + k]) >> (8 * i)) & 0xFF for i in range(4)] for k in range(6)]  # lo.x lo.y lo.z hi.x hi.y hi.z
+        refs = [int(nd[10]), int(nd[11]), int(nd[12]), int(nd[13])]
+        boxes = []
+        for i in range(4):
+            lo = np.array([origin[a] + np.float32(q[a][i]) * scale[a] for a in range(3)], dtype=np.float32)
+            hi = np.array([origin[a] + np.float32(q[3 + a][i]) * scale[a] for a in range(3)], dtype=np.float32)
+            boxes.append((lo, hi))
+        return boxes, refs
     seen = np.zeros(n_tris, dtype=int)
     stack = [(0, np.full(3, -np.inf), np.full(3, np.inf))]
     n_visited = 0
     while stack:
         ni, plo, phi = stack.pop()
         n_visited += 1
-        nd = nodes[ni]
-        refs = nd[24:28].view(np.uint32)
-        for c in range(4):
-            lo = np.array([nd[0 + c], nd[8 + c], nd[16 + c]]); hi = np.array([nd[4 + c], nd[12 + c], nd[20 + c]])
-            ref = int(refs[c])
+        boxes, refs = decode(nodes[ni])
+        for (lo, hi), ref in zip(boxes, refs):
             if ref == 0xFFFFFFFF:
                 assert np.all(lo > hi)  # empty slot: inverted box
                 continue
-            assert np.all(lo >= plo - 1e-4) and np.all(hi <= phi + 1e-4)
+            # children are quantised in their own node's frame: they nest in the parent's decoded box up to one step
+            if np.all(np.isfinite(plo)):
+                tol = (phi - plo) / 100.0 + 1e-3
+                assert np.all(lo >= plo - tol) and np.all(hi <= phi + tol)
             if ref & 0x80000000:
                 first, count = ref & 0x0FFFFFFF, (ref >> 28) & 7
                 assert 1 <= count <= 4
                 for k in range(first, first + count):
                     seen[k] += 1
                     w = world(int(gid[k]))
-                    assert np.all(w >= lo - 1e-6) and np.all(w <= hi + 1e-6)
+                    assert np.all(w >= lo - 1e-6) and np.all(w <= hi + 1e-6)  # conservative: decoded box contains the triangle
             else:
                 stack.append((ref, lo, hi))
     assert np.all(seen == 1) and n_visited == nodes.shape[0]
