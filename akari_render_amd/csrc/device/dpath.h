@@ -221,7 +221,12 @@ AKR_D void shifted_pixel(const PtParams& p, uint32_t px, uint32_t py, uint32_t& 
 // Everything between two intersection phases for one lane: resolve the shadow ray traced together with `hit`, finish
 // the previous sample if it ended, shade the vertex found by the closest-hit ray (emission + MIS, light sample, BSDF
 // evaluate + sample, Russian roulette), and prepare the next pair of rays or the next camera ray.
+// FD: 1 / 0 = force_diffuse known at compile time (the reference's JIT also specialises the kernel on it: the branch
+// at pt.rs:268 is taken while tracing the kernel, so a force_diffuse kernel contains no Principled code); -1 = read
+// p.force_diffuse at run time.
+template <int FD = -1>
 AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found, bool occluded, uint32_t pix, uint32_t sx, uint32_t sy) {
+    const bool force_diffuse = FD < 0 ? (p.force_diffuse != 0) : (FD != 0);
     const DScene& sc = p.sc;
     const size_t N = (size_t)p.width * p.height;
     // ---- resolve the shadow ray (pt.rs:504-513) ----
@@ -290,7 +295,7 @@ AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found,
                 vec3 u_bsdf = next_3d(r.smp);
                 // sample_surface_and_shade_direct, pt.rs:297-323
                 ShadePoint sp;
-                shade_point_init(sp, mat, si.frame, si.ng, p.force_diffuse != 0);
+                shade_point_init(sp, mat, si.frame, si.ng, force_diffuse);
                 if (dl.valid) {
                     BsdfEval e = shade_evaluate(sp, mat, sc.ggx_table, wo, dl.wi);
                     float w = mis_weight(dl.pdf, e.pdf);

@@ -21,8 +21,11 @@ namespace akr {
 #ifndef AKR_PT_MIN_WAVES_BVH
 #define AKR_PT_MIN_WAVES_BVH 4
 #endif
-template <bool BVH>
-__global__ __launch_bounds__(256, BVH ? AKR_PT_MIN_WAVES_BVH : AKR_PT_MIN_WAVES) void k_pt_pass(const PtParams p) {
+#ifndef AKR_PT_MIN_WAVES_FD
+#define AKR_PT_MIN_WAVES_FD 4  // force_diffuse specialisation of the exhaustive kernel
+#endif
+template <bool BVH, bool FD>
+__global__ __launch_bounds__(256, BVH ? AKR_PT_MIN_WAVES_BVH : (FD ? AKR_PT_MIN_WAVES_FD : AKR_PT_MIN_WAVES)) void k_pt_pass(const PtParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: kBvhStackDepth x 256 words
     TraceCtx tc;
     tc.stack = lds_stack + threadIdx.x;
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256, BVH ? AKR_PT_MIN_WAVES_BVH : AKR_PT_MIN_WAVES)
                 trace_pair_exhaustive(sc, r.ro, r.rd, r.has_ray ? 1e20f : -1.0f, r.ray_ex0, r.s_o, r.s_d, r.has_shadow ? r.s_tmax : -1.0f,
                                       r.s_ex0, r.s_ex1, hit, found, occluded);
             }
-            path_step(p, r, hit, found, occluded, pix, sx, sy);
+            path_step<FD ? 1 : 0>(p, r, hit, found, occluded, pix, sx, sy);
         }
     }
     flush_counters(p, r, tc.cnt, BVH);
@@ -191,10 +194,14 @@ __global__ void k_probe_si(PtParams p, uint32_t n, const uint32_t* __restrict__ 
 hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream) {
     uint32_t blocks = (p.n_items + 255u) / 256u;
     if (blocks == 0) return hipSuccess;
-    if (p.sc.bvh_nodes != nullptr)
-        hipLaunchKernelGGL(k_pt_pass<true>, dim3(blocks), dim3(256), kBvhStackDepth * 256 * 4, stream, p);
-    else
-        hipLaunchKernelGGL(k_pt_pass<false>, dim3(blocks), dim3(256), 0, stream, p);
+    const bool fd = p.force_diffuse != 0;
+    if (p.sc.bvh_nodes != nullptr) {
+        if (fd) hipLaunchKernelGGL((k_pt_pass<true, true>), dim3(blocks), dim3(256), kBvhStackDepth * 256 * 4, stream, p);
+        else hipLaunchKernelGGL((k_pt_pass<true, false>), dim3(blocks), dim3(256), kBvhStackDepth * 256 * 4, stream, p);
+    } else {
+        if (fd) hipLaunchKernelGGL((k_pt_pass<false, true>), dim3(blocks), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((k_pt_pass<false, false>), dim3(blocks), dim3(256), 0, stream, p);
+    }
     return hipGetLastError();
 }
 hipError_t launch_init_pcg32(const uint64_t* seeds, void* states, uint64_t n, hipStream_t stream) {
