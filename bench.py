@@ -59,6 +59,25 @@ def cpu_baseline(n_threads):
             "sample": f"cbox {W}x{H} force_diffuse {cfg.spp} spp ({st['n_samples']} camera paths, {dt:.1f} s), CPU oracle (C, pthreads)"}
 
 
+def measured_traffic(args, d):
+    """HBM bytes of one timed launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes,
+    tools/pmc_run.sh; unit + gfx950 corrections of MI355X_MICROARCH.md "HBM" applied there). A counter pass cannot run
+    inside this process, so the number is the one committed under profiles/ for exactly this launch shape (same
+    workload, same number of fused passes); anything else reports null."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    if args.gpus != 1 or not os.path.exists(path):
+        return None
+    try:
+        t = json.load(open(path))
+    except Exception:
+        return None
+    key = "full_graph" if args.full_graph else "force_diffuse"
+    e = t.get(key)
+    if not e or e.get("steps") != args.steps or d["n_launches"] != 1:
+        return None
+    return e.get("hbm_bytes_per_launch")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,7 +196,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic(args, d),
                 "kernel": "k_pt_pass",
                 "launches": d["n_launches"],
                 "avg_launch_ms": avg_launch_s * 1e3,
