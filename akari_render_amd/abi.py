@@ -61,6 +61,33 @@ class MaterialDesc(C.Structure):
     ]
 
 
+# shader graphs / textures (akr_node_op, akr_material_input, akr_image_desc)
+NODE_NONE = 0xFFFFFFFF
+(NODE_CONST, NODE_RGB, NODE_TEXCOORDS, NODE_IMAGE, NODE_MAPPING, NODE_CHECKERBOARD, NODE_SPECTRAL_UPLIFT, NODE_SEPARATE_COLOR,
+ NODE_EXTRACT, NODE_NORMAL_MAP) = range(10)
+MAPPING_POINT, MAPPING_TEXTURE = 0, 1
+FIELD_RED, FIELD_GREEN, FIELD_BLUE, FIELD_UV = 0, 1, 2, 3
+INPUT_NAMES = ("base_color", "metallic", "roughness", "ior", "specular_ior_level", "specular_tint", "transmission_weight",
+               "coat_weight", "coat_roughness", "coat_ior", "coat_tint", "emission_color", "emission_strength", "normal")
+IN_COUNT = len(INPUT_NAMES)
+IMAGE_RGBA8, IMAGE_RGBA32F = 0, 1
+TEX_FILTER_NEAREST, TEX_FILTER_LINEAR = 0, 1
+TEX_REPEAT, TEX_CLIP, TEX_MIRROR, TEX_EXTEND = 0, 1, 2, 3
+
+
+class ShaderNode(C.Structure):
+    _fields_ = [("op", C.c_uint32), ("arg", C.c_uint32 * 4), ("k", C.c_float * 3)]
+
+
+class MaterialGraph(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("_pad", C.c_uint32), ("nodes", C.POINTER(ShaderNode)), ("input", C.c_uint32 * IN_COUNT)]
+
+
+class ImageDesc(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_uint32), ("filter", C.c_uint32),
+                ("address", C.c_uint32), ("_pad", C.c_uint32), ("texels", C.c_void_p)]
+
+
 class CameraDesc(C.Structure):
     _fields_ = [("c2w", C.c_float * 16), ("fov", C.c_float), ("width", C.c_uint32), ("height", C.c_uint32)]
 
@@ -76,6 +103,10 @@ class SceneDesc(C.Structure):
         ("materials", C.POINTER(MaterialDesc)),
         ("camera", CameraDesc),
         ("ggx_dielectric_table", c_f32p),
+        ("n_images", C.c_uint32),
+        ("_pad2", C.c_uint32),
+        ("images", C.POINTER(ImageDesc)),
+        ("material_graphs", C.POINTER(MaterialGraph)),
     ]
 
 
@@ -194,6 +225,7 @@ class MaterialData:
     emission_color: tuple = (0.0, 0.0, 0.0)
     emission_strength: float = 0.0
     normal: tuple = (0.0, 0.0, 0.0)
+    graph: Optional["GraphData"] = None
 
     def to_struct(self) -> MaterialDesc:
         m = MaterialDesc()
@@ -220,6 +252,28 @@ class MaterialData:
 
 
 @dataclass
+class NodeData:
+    """One akr_shader_node: op, up to four arguments (node indices / immediates, NODE_NONE = absent), three constants."""
+    op: int
+    args: tuple = ()
+    k: tuple = (0.0, 0.0, 0.0)
+
+
+@dataclass
+class GraphData:
+    """Node list of a material + which node feeds which input (by name, see INPUT_NAMES)."""
+    nodes: List[NodeData] = field(default_factory=list)
+    inputs: dict = field(default_factory=dict)  # input name -> node index
+
+
+@dataclass
+class ImageData:
+    texels: np.ndarray  # (H, W, 4) uint8 or float32; row 0 is v = 0
+    filter: int = TEX_FILTER_LINEAR
+    address: int = TEX_REPEAT
+
+
+@dataclass
 class CameraData:
     c2w: np.ndarray  # (16,) f32 column-major
     fov: float  # radians
@@ -236,6 +290,7 @@ class SceneData:
     ggx_table: Optional[np.ndarray] = None  # (4096,) f32
     instance_names: List[str] = field(default_factory=list)
     material_names: List[str] = field(default_factory=list)
+    images: List["ImageData"] = field(default_factory=list)
 
     def n_triangles(self) -> int:
         return sum(self.meshes[i.mesh].indices.shape[0] for i in self.instances)
@@ -293,4 +348,40 @@ class SceneData:
         desc.camera.width, desc.camera.height = int(self.camera.width), int(self.camera.height)
         desc.ggx_dielectric_table = fptr(self.ggx_table)
         keep += [meshes, insts, mats]
+        if self.images:
+            imgs = (ImageDesc * len(self.images))()
+            for i, im in enumerate(self.images):
+                t = np.asarray(im.texels)
+                assert t.ndim == 3 and t.shape[2] == 4 and t.dtype in (np.uint8, np.float32), "image texels: (H, W, 4) uint8 / float32"
+                t = np.ascontiguousarray(t)
+                keep.append(t)
+                imgs[i].height, imgs[i].width = int(t.shape[0]), int(t.shape[1])
+                imgs[i].format = IMAGE_RGBA8 if t.dtype == np.uint8 else IMAGE_RGBA32F
+                imgs[i].filter, imgs[i].address = int(im.filter), int(im.address)
+                imgs[i].texels = t.ctypes.data
+            desc.n_images = len(self.images)
+            desc.images = C.cast(imgs, C.POINTER(ImageDesc))
+            keep.append(imgs)
+        if any(m.graph is not None for m in self.materials):
+            graphs = (MaterialGraph * len(self.materials))()
+            for i, m in enumerate(self.materials):
+                g = graphs[i]
+                for k in range(IN_COUNT):
+                    g.input[k] = NODE_NONE
+                if m.graph is None or not m.graph.nodes:
+                    continue
+                nodes = (ShaderNode * len(m.graph.nodes))()
+                for j, nd in enumerate(m.graph.nodes):
+                    nodes[j].op = int(nd.op)
+                    for a in range(4):
+                        nodes[j].arg[a] = int(nd.args[a]) if a < len(nd.args) and nd.args[a] is not None else NODE_NONE
+                    for a in range(3):
+                        nodes[j].k[a] = float(np.float32(nd.k[a])) if a < len(nd.k) else 0.0
+                g.n_nodes = len(m.graph.nodes)
+                g.nodes = C.cast(nodes, C.POINTER(ShaderNode))
+                for name, node in m.graph.inputs.items():
+                    g.input[INPUT_NAMES.index(name)] = int(node)
+                keep.append(nodes)
+            desc.material_graphs = C.cast(graphs, C.POINTER(MaterialGraph))
+            keep.append(graphs)
         return desc, keep

@@ -27,13 +27,15 @@ EXPORTS = [
     "akr_scene_create", "akr_scene_load", "akr_scene_destroy", "akr_scene_set_resolution", "akr_scene_get_info",
     "akr_scene_get_light", "akr_scene_get_ggx_table", "akr_scene_get_desc_counts", "akr_scene_get_mesh",
     "akr_scene_get_instance", "akr_scene_get_material", "akr_scene_get_camera", "akr_scene_get_array",
+    "akr_scene_get_image_count", "akr_scene_get_image", "akr_scene_get_material_graph",
     "akr_film_create", "akr_film_wrap", "akr_film_destroy", "akr_film_clear", "akr_film_read", "akr_film_write",
     "akr_film_resolve", "akr_film_device_ptr",
     "akr_pt_config_default", "akr_pt_config_from_json", "akr_pt_render", "akr_pt_begin", "akr_pt_passes", "akr_pt_end",
     "akr_pt_get_stats", "akr_render_task", "akr_image_write",
     "akr_pt_read_sampler_states",
     "akr_host_stdrng_u64", "akr_host_chacha_block", "akr_host_pcg32_states", "akr_host_pcg_start", "akr_host_alias_table",
-    "akr_probe_math", "akr_probe_bsdf", "akr_probe_intersect", "akr_probe_surface_interaction",
+    "akr_probe_math", "akr_probe_bsdf", "akr_probe_intersect", "akr_probe_surface_interaction", "akr_probe_material_inputs",
+    "akr_host_decode_png",
 ]
 
 
@@ -88,6 +90,9 @@ def lib() -> C.CDLL:
     proto("akr_scene_get_material", vp, u32, C.POINTER(abi.MaterialDesc))
     proto("akr_scene_get_camera", vp, C.POINTER(abi.CameraDesc))
     proto("akr_scene_get_array", vp, i32, vpp, u64p)
+    proto("akr_scene_get_image_count", vp, up)
+    proto("akr_scene_get_image", vp, u32, C.POINTER(abi.ImageDesc))
+    proto("akr_scene_get_material_graph", vp, u32, C.POINTER(abi.MaterialGraph))
     proto("akr_film_create", vp, u32, u32, vpp)
     proto("akr_film_wrap", vp, u32, u32, vp, vpp)
     proto("akr_film_destroy", vp)
@@ -115,6 +120,8 @@ def lib() -> C.CDLL:
     proto("akr_probe_bsdf", vp, C.POINTER(abi.MaterialDesc), fp, i32, fp, u32, fp, fp)
     proto("akr_probe_intersect", vp, vp, u32, fp, up, fp)
     proto("akr_probe_surface_interaction", vp, vp, u32, up, fp, fp)
+    proto("akr_probe_material_inputs", vp, vp, u32, u32, fp, fp)
+    proto("akr_host_decode_png", C.c_char_p, u64, up, up, C.POINTER(C.c_uint8), u64)
     _lib = L
     return L
 
@@ -253,11 +260,30 @@ class Scene:
             for name in ("base_alpha", "metallic", "roughness", "ior", "specular_ior_level", "transmission_weight",
                          "coat_weight", "coat_roughness", "coat_ior", "emission_strength"):
                 setattr(md, name, float(getattr(d, name)))
+            g = abi.MaterialGraph()
+            check(lib().akr_scene_get_material_graph(self.h, i, C.byref(g)))
+            if g.n_nodes:
+                nodes = [abi.NodeData(int(g.nodes[j].op), tuple(int(a) for a in g.nodes[j].arg), tuple(float(x) for x in g.nodes[j].k))
+                         for j in range(g.n_nodes)]
+                inputs = {abi.INPUT_NAMES[k]: int(g.input[k]) for k in range(abi.IN_COUNT) if g.input[k] != abi.NODE_NONE}
+                md.graph = abi.GraphData(nodes, inputs)
             materials.append(md)
+        images = []
+        nimg = C.c_uint32()
+        check(lib().akr_scene_get_image_count(self.h, C.byref(nimg)))
+        for i in range(nimg.value):
+            d = abi.ImageDesc()
+            check(lib().akr_scene_get_image(self.h, i, C.byref(d)))
+            n = d.width * d.height * 4
+            if d.format == abi.IMAGE_RGBA8:
+                t = np.frombuffer((C.c_uint8 * n).from_address(d.texels), dtype=np.uint8).copy()
+            else:
+                t = np.frombuffer((C.c_float * n).from_address(d.texels), dtype=np.float32).copy()
+            images.append(abi.ImageData(t.reshape(d.height, d.width, 4), d.filter, d.address))
         c = abi.CameraDesc()
         check(lib().akr_scene_get_camera(self.h, C.byref(c)))
         cam = abi.CameraData(np.array(list(c.c2w), dtype=np.float32), float(c.fov), c.width, c.height)
-        return abi.SceneData(meshes, instances, materials, cam)
+        return abi.SceneData(meshes, instances, materials, cam, images=images)
 
 
 class Film:
@@ -441,4 +467,22 @@ def probe_surface_interaction(ctx: Context, scene: Scene, inst_prim: np.ndarray,
     b = np.ascontiguousarray(bary, dtype=np.float32).reshape(-1, 2)
     out = np.zeros((ip.shape[0], 19), dtype=np.float32)
     check(lib().akr_probe_surface_interaction(ctx.h, scene.h, ip.shape[0], _up(ip), _fp(b), _fp(out)))
+    return out
+
+
+def probe_material_inputs(ctx: Optional[Context], scene: Scene, material: int, uv: np.ndarray) -> np.ndarray:
+    """Evaluated inputs (akr_material_desc words, as float32 view) of `material` at uv points; ctx=None runs the host build
+    of the same code."""
+    u = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
+    out = np.zeros((u.shape[0], 26), dtype=np.float32)
+    check(lib().akr_probe_material_inputs(ctx.h if ctx is not None else C.c_void_p(), scene.h, material, u.shape[0], _fp(u), _fp(out)))
+    return out
+
+
+def host_decode_png(data: bytes) -> np.ndarray:
+    """PNG -> (H, W, 4) uint8 in file order (top row first), the image crate's to_rgba8 conventions."""
+    w, h = C.c_uint32(), C.c_uint32()
+    check(lib().akr_host_decode_png(data, len(data), C.byref(w), C.byref(h), None, 0))
+    out = np.zeros((h.value, w.value, 4), dtype=np.uint8)
+    check(lib().akr_host_decode_png(data, len(data), C.byref(w), C.byref(h), out.ctypes.data_as(C.POINTER(C.c_uint8)), out.size))
     return out

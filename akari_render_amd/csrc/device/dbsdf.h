@@ -20,6 +20,7 @@ enum : uint32_t {
     MF_EVAL_DIEL = 1u << 5,   // Mix(transmission) evaluates the dielectric: transmission > 1e-4
     MF_NORMAL_MAP = 1u << 6,  // principled `normal` socket is non-zero                 (mod.rs:1380-1417)
     MF_EMISSIVE = 1u << 7,    // emission != 0
+    MF_TEXTURED = 1u << 8,    // at least one input is fed by a texture expression: re-folded per hit (dtex.h)
 };
 
 enum : uint32_t { MAT_PRINCIPLED = 0, MAT_DIFFUSE = 1, MAT_GLASS = 2, MAT_EMISSION = 3 };
@@ -39,9 +40,26 @@ struct alignas(16) DMaterial {
     vec3 metal_k;             float _pad0;
     vec2 alpha;               vec2 coat_alpha;      // max(roughness^2, 1e-4)       (microfacet.rs:29-43)
     vec3 nm_normal;           float _pad1;          // normalize((-nx, -ny, nz))
-    float _pad2[16];
+    uint32_t tex_first_node, tex_n_nodes;           // MF_TEXTURED: pruned node list in DScene.tex.nodes
+    uint32_t tex_input[14];                         // node feeding each input (dtex.h IN_*), kNodeNone = constant
 };
 static_assert(sizeof(DMaterial) == 256, "DMaterial layout");
+
+// The evaluated inputs of a surface node = akr_material_desc (include/akari_hip.h), 26 words.
+struct MatInputs {
+    uint32_t kind;
+    float base_color[3];
+    float base_alpha;
+    float metallic, roughness, ior, specular_ior_level;
+    float specular_tint[3];
+    float transmission_weight;
+    float coat_weight, coat_roughness, coat_ior;
+    float coat_tint[3];
+    float emission_color[3];
+    float emission_strength;
+    float normal[3];
+};
+static_assert(sizeof(MatInputs) == 104, "MatInputs = akr_material_desc");
 
 struct BsdfEval {
     vec3 f;
@@ -274,6 +292,82 @@ AKR_HD BsdfEval eval_dielectric(vec3 kr, vec3 kt, float eta, vec2 alpha, vec3 wo
 }
 
 // CoatedBsdf.e_top(w) of the specular layer / of the coat (principled.rs:158-162, 188-193)
+// Folds evaluated inputs into the record the closure code reads: the part of SvmPrincipledBsdf::closure
+// (principled.rs:23-131,195-205), DiffuseBsdf (diffuse.rs:83-104), SvmGlassBsdf (glass.rs:13-45) and SvmEmission
+// (svm/mod.rs:114-123) that does not depend on wo / wi. One definition for the host (constant materials, once) and
+// the device (textured materials, per hit). Returns false for an unknown kind. Does not touch the tex_* fields.
+AKR_HD bool fold_inputs(const MatInputs& m, DMaterial& d) {
+    const vec3 color = mk3(m.base_color[0], m.base_color[1], m.base_color[2]);
+    d.kind = m.kind;
+    d.flags = 0;
+    d.base_alpha = m.base_alpha;
+    d.metallic = 0.0f; d.transmission = 0.0f; d.eta = 0.0f; d.f0 = 0.0f; d.eta_s = 0.0f; d.roughness = 0.0f;
+    d.coat_weight = 0.0f; d.coat_roughness = 0.0f; d.coat_eta = 0.0f; d._pad0 = 0.0f; d._pad1 = 0.0f;
+    d.color = color;
+    d.diffuse_refl = mk3(0, 0, 0); d.transmission_color = mk3(0, 0, 0); d.spec_color = mk3(0, 0, 0); d.spec_tint = mk3(0, 0, 0);
+    d.coat_scale = mk3(0, 0, 0); d.metal_n = mk3(0, 0, 0); d.metal_k = mk3(0, 0, 0);
+    d.alpha = mk2(0, 0); d.coat_alpha = mk2(0, 0);
+    d.emission = mk3(m.emission_color[0], m.emission_color[1], m.emission_color[2]) * m.emission_strength;
+    d.nm_normal = mk3(0, 0, 1);
+    switch (m.kind) {
+        case MAT_PRINCIPLED: {
+            d.metallic = m.metallic;
+            d.transmission = m.transmission_weight;
+            d.roughness = m.roughness;
+            d.eta = m.ior;
+            d.transmission_color = mk3(__builtin_sqrtf(color.x), __builtin_sqrtf(color.y), __builtin_sqrtf(color.z));
+            d.diffuse_refl = color * kInvPi;
+            d.spec_tint = mk3(m.specular_tint[0], m.specular_tint[1], m.specular_tint[2]);
+            float eta_s = m.ior, f0 = f0_from_ior(eta_s);
+            if (m.specular_ior_level != 0.5f) {
+                f0 *= 2.0f * m.specular_ior_level;
+                eta_s = ior_from_f0(f0);
+            }
+            d.f0 = f0;
+            d.eta_s = eta_s;
+            d.spec_color = d.spec_tint * f0;
+            d.coat_weight = m.coat_weight;
+            d.coat_roughness = m.coat_roughness;
+            d.coat_eta = m.coat_ior;
+            d.coat_scale = lerp3(mk3(1, 1, 1), mk3(m.coat_tint[0], m.coat_tint[1], m.coat_tint[2]), m.coat_weight);
+            d.alpha = mk2(max_f(m.roughness * m.roughness, 1e-4f), max_f(m.roughness * m.roughness, 1e-4f));
+            d.coat_alpha = mk2(max_f(m.coat_roughness * m.coat_roughness, 1e-4f), max_f(m.coat_roughness * m.coat_roughness, 1e-4f));
+            artistic_to_conductor(color, d.spec_tint, d.metal_n, d.metal_k);
+            uint32_t fl = 0;
+            if (f0 != 0.0f) fl |= MF_SPEC;
+            if (m.coat_weight != 0.0f) fl |= MF_COAT;
+            if (m.metallic < 1.0f - 1e-4f) fl |= MF_EVAL_BASE;
+            if (m.metallic > 1e-4f) fl |= MF_EVAL_METAL;
+            if (m.transmission_weight < 1.0f - 1e-4f) fl |= MF_EVAL_DIFF;
+            if (m.transmission_weight > 1e-4f) fl |= MF_EVAL_DIEL;
+            vec3 normal = mk3(-m.normal[0], -m.normal[1], m.normal[2]);  // principled.rs:203-205
+            if (!(normal.x == 0.0f && normal.y == 0.0f && normal.z == 0.0f)) {
+                fl |= MF_NORMAL_MAP;
+                d.nm_normal = normalize(normal);
+            }
+            d.flags = fl;
+            break;
+        }
+        case MAT_DIFFUSE:
+            d.diffuse_refl = color * kInvPi;
+            d.emission = mk3(0, 0, 0);
+            break;
+        case MAT_GLASS:
+            d.eta = m.ior;
+            d.roughness = m.roughness;
+            d.alpha = mk2(max_f(m.roughness * m.roughness, 1e-4f), max_f(m.roughness * m.roughness, 1e-4f));
+            d.emission = mk3(0, 0, 0);
+            d.base_alpha = 1.0f;
+            break;
+        case MAT_EMISSION:
+            d.base_alpha = 1.0f;
+            break;
+        default: return false;
+    }
+    if (d.emission.x != 0.0f || d.emission.y != 0.0f || d.emission.z != 0.0f) d.flags |= MF_EMISSIVE;
+    return true;
+}
+
 AKR_HD vec3 etop_spec(const DMaterial& m, const float* __restrict__ table, vec3 w) {
     float albedo = ggx_dielectric_albedo(table, m.roughness, abs_cos_theta(w), m.eta_s);
     return (m.spec_tint * albedo) * m.f0;

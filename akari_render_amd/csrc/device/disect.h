@@ -35,12 +35,28 @@ AKR_HD bool tri_test(vec3 o, vec3 d, float4 r0, float4 r1, float4 r2, float tmin
     return hit;
 }
 
+// SvmEvalMode::Alpha for a texture-fed base colour (principled.rs:15-21): the graph at the candidate's uv
+// (surface_interaction_for_alpha_test, mesh.rs:426-485), alpha = w of the node feeding base_color. Kept out of line:
+// it is the cold side of a branch inside the traversal loops.
+__device__ __attribute__((noinline)) static float textured_alpha(const DScene& sc, const float4* r, uint32_t material, float u, float v) {
+    float w = 1.0f - u - v;
+    vec2 uv = mk2((r[0].w * w + r[2].w * u) + r[4].w * v, (r[1].w * w + r[3].w * u) + r[5].w * v);
+    const DMaterial& m = sc.materials[material];
+    TexVal val[kMaxGraphNodes];
+    eval_graph(sc.tex, m.tex_first_node, m.tex_n_nodes, uv, val);
+    return val[m.tex_input[IN_BASE_COLOR]].w;
+}
 // scene.rs:49-86 for folded materials: alpha = alpha channel of the base-colour node
+template <bool TEX>
 AKR_D bool alpha_test(const DScene& sc, uint32_t gid, float u, float v) {
     const float4* r = sc.shade + (size_t)gid * SHADE_ROWS;
     float4 q6 = r[6];
     const DMaterial& m = sc.materials[f2u(q6.y)];
     float alpha = (m.kind == MAT_PRINCIPLED || m.kind == MAT_DIFFUSE) ? m.base_alpha : 1.0f;
+    if (TEX) {  // only the TEX kernels carry the graph evaluation (and its scratch array)
+        if ((m.flags & MF_TEXTURED) && m.tex_input[IN_BASE_COLOR] != kNodeNone && (m.kind == MAT_PRINCIPLED || m.kind == MAT_DIFFUSE))
+            alpha = textured_alpha(sc, r, f2u(q6.y), u, v);
+    }
     if (alpha >= 1.0f) return true;
     uint32_t inst = f2u(q6.z);
     uint32_t prim = gid - sc.inst_tri_offset[inst];
@@ -50,7 +66,7 @@ AKR_D bool alpha_test(const DScene& sc, uint32_t gid, float u, float v) {
 
 // Exhaustive intersector: every lane of the wave walks the same triangle list, so the 48-byte records are
 // wave-uniform and come in through the scalar cache (s_load_dwordx4 x3), leaving the VALU for the test itself.
-template <bool ANY_HIT>
+template <bool ANY_HIT, bool TEX = false>
 AKR_D bool trace_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmin, float tmax, uint32_t ex0, uint32_t ex1, Hit& hit) {
     float best_t = tmax;
     uint32_t best = kInvalid;
@@ -77,7 +93,7 @@ AKR_D bool trace_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmin, float 
         bool h = tri_test(o, d, r0, r1, r2, tmin, tmax, t, u, v);
         h = h & (k != ex0) & (k != ex1);
         if (sc.has_alpha) {
-            if (h) h = alpha_test(sc, k, u, v);
+            if (h) h = alpha_test<TEX>(sc, k, u, v);
         }
         if (ANY_HIT) {
             if (h) best = k;
@@ -103,6 +119,7 @@ AKR_D bool trace_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmin, float 
 // resident) records serves both: half the scalar loads and loop overhead of two separate walks, and two independent
 // dependency chains per record for the VALU to overlap. A ray that does not exist for a lane is passed with
 // tmax < tmin and can never hit.
+template <bool TEX = false>
 AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, uint32_t ex0, vec3 so, vec3 sd, float stmax,
                                  uint32_t sex0, uint32_t sex1, Hit& hit, bool& found, bool& occluded) {
     float best_t = tmax;
@@ -129,8 +146,8 @@ AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, u
         h = h & (k != ex0);
         sh = sh & (k != sex0) & (k != sex1);
         if (sc.has_alpha) {
-            if (h) h = alpha_test(sc, k, u, v);
-            if (sh) sh = alpha_test(sc, k, su, sv);
+            if (h) h = alpha_test<TEX>(sc, k, u, v);
+            if (sh) sh = alpha_test<TEX>(sc, k, su, sv);
         }
         bool better = h & ((best == kInvalid) | (t < best_t));
         best_t = better ? t : best_t;
@@ -192,7 +209,7 @@ AKR_D void bvh4_node_test(const DScene& sc, uint32_t node, vec3 inv, vec3 noi, f
     }
 }
 
-template <bool ANY_HIT>
+template <bool ANY_HIT, bool TEX = false>
 AKR_D bool trace_bvh4(const DScene& sc, vec3 o, vec3 d, float tmin, float tmax, uint32_t ex0, uint32_t ex1, Hit& hit,
                       uint32_t* __restrict__ stack, TraceCounters& cnt) {
     const vec3 inv = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
@@ -258,7 +275,7 @@ AKR_D bool trace_bvh4(const DScene& sc, vec3 o, vec3 d, float tmin, float tmax, 
                 if (h) {
                     uint32_t gid = sc.tri_gid[k];
                     h = (gid != ex0) & (gid != ex1);
-                    if (h && sc.has_alpha) h = alpha_test(sc, gid, u, v);
+                    if (h && sc.has_alpha) h = alpha_test<TEX>(sc, gid, u, v);
                     if (h) {
                         if (ANY_HIT) {
                             best = gid;

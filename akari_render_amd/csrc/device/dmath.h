@@ -117,6 +117,30 @@ AKR_HD float log_f(float x) {
     return r;
 }
 
+// e^x (Cephes expf: x = g + n ln2, degree-5 polynomial on g, scale by 2^n in two exact steps)
+AKR_HD float exp_f(float x) {
+    if (x != x) return x;
+    if (x > 88.72283905206835f) return __builtin_inff();
+    if (x < -103.278929903431851103f) return 0.0f;
+    float fn = __builtin_floorf(1.44269504088896341f * x + 0.5f);
+    float g = __builtin_fmaf(-0.693359375f, fn, x);
+    g = __builtin_fmaf(2.12194440e-4f, fn, g);
+    float z = g * g;
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, g, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, g, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, g, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, g, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, g, 5.0000001201e-1f);
+    float r = __builtin_fmaf(p, z, g) + 1.0f;
+    int n = (int)fn;                      // |n| <= 150
+    int n1 = n / 2, n2 = n - n1;          // both in [-75, 75]: 2^n1 and 2^n2 are normal numbers
+    r = r * u2f((uint32_t)(n1 + 127) << 23);
+    return r * u2f((uint32_t)(n2 + 127) << 23);
+}
+// x^y for x > 0 as exp(y log x); pow_f(0, y > 0) = 0. This is what `powf` means in the AKR-F32 contract.
+AKR_HD float pow_f(float x, float y) { return x == 0.0f ? 0.0f : exp_f(y * log_f(x)); }
+
 // a*b - c*d with the rounding error of c*d folded back in (reference util/mod.rs:326-331)
 AKR_HD float difference_of_products(float a, float b, float c, float d) {
     float cd = c * d;

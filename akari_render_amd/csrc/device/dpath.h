@@ -90,6 +90,22 @@ AKR_D float mis_weight(float a, float b) {  // pt.rs:962-973 with power = 1
 AKR_D vec3 material_emission(const DMaterial& m) {
     return (m.kind == MAT_PRINCIPLED || m.kind == MAT_EMISSION) ? m.emission : mk3(0, 0, 0);
 }
+// the same at a point of a material whose emission inputs may be texture-fed (TEX kernels only)
+template <bool TEX>
+AKR_D vec3 material_emission_at(const DScene& sc, uint32_t material, vec2 uv) {
+    const DMaterial& m = sc.materials[material];
+    if (TEX) {
+        if ((m.flags & MF_TEXTURED) && (m.tex_input[IN_EMISSION_COLOR] != kNodeNone || m.tex_input[IN_EMISSION_STRENGTH] != kNodeNone)) {
+            if (!(m.kind == MAT_PRINCIPLED || m.kind == MAT_EMISSION)) return mk3(0, 0, 0);
+            TexVal val[kMaxGraphNodes];
+            eval_graph(sc.tex, m.tex_first_node, m.tex_n_nodes, uv, val);
+            MatInputs in = sc.tex.mat_inputs[material];
+            apply_inputs(m.tex_input, val, in);
+            return mk3(in.emission_color[0], in.emission_color[1], in.emission_color[2]) * in.emission_strength;
+        }
+    }
+    return material_emission(m);
+}
 
 struct LightSample {
     vec3 li, wi;
@@ -100,6 +116,7 @@ struct LightSample {
     bool valid;
 };
 // LightAggregate::sample_direct (light/mod.rs:115-132) + AreaLight::sample_direct (light/area.rs:51-107)
+template <bool TEX>
 AKR_D LightSample sample_direct(const DScene& sc, vec3 pn_p, vec3 pn_n, float u_select, vec2 u_sample) {
     LightSample s;
     s.li = mk3(0, 0, 0);
@@ -121,7 +138,7 @@ AKR_D LightSample sample_direct(const DScene& sc, vec3 pn_p, vec3 pn_n, float u_
     if (length2(wi) == 0.0f) return s;
     float dist2 = length2(wi);
     wi = div_s(wi, __builtin_sqrtf(dist2));
-    vec3 emission = material_emission(sc.materials[y.material]);
+    vec3 emission = material_emission_at<TEX>(sc, y.material, y.uv);
     s.li = dot(wi, y.ng) < 0.0f ? emission : mk3(0, 0, 0);
     float cos_theta_i = abs_f(dot(y.ng, wi));
     float pdf = pdf_prim / y.prim_area * dist2 / cos_theta_i;
@@ -224,7 +241,7 @@ AKR_D void shifted_pixel(const PtParams& p, uint32_t px, uint32_t py, uint32_t& 
 // FD: 1 / 0 = force_diffuse known at compile time (the reference's JIT also specialises the kernel on it: the branch
 // at pt.rs:268 is taken while tracing the kernel, so a force_diffuse kernel contains no Principled code); -1 = read
 // p.force_diffuse at run time.
-template <int FD = -1>
+template <int FD = -1, bool TEX = false>
 AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found, bool occluded, uint32_t pix, uint32_t sx, uint32_t sy) {
     const bool force_diffuse = FD < 0 ? (p.force_diffuse != 0) : (FD != 0);
     const DScene& sc = p.sc;
@@ -266,7 +283,14 @@ AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found,
             terminated = true;  // pt.rs:381-396 (hit_envmap adds zero)
         } else {
             SurfacePoint si = surface_interaction(sc, hit.gid, mk2(hit.u, hit.v));
-            const DMaterial& mat = sc.materials[si.material];
+            // the material at this point: the folded record, or (TEX kernels, texture-fed inputs) its graph evaluated
+            // at si.uv and folded here
+            DMaterial mat_here;
+            if (TEX) {
+                mat_here = sc.materials[si.material];
+                material_at(sc.tex, si.material, si.uv, mat_here);
+            }
+            const DMaterial& mat = TEX ? mat_here : sc.materials[si.material];
             vec3 wo = -r.rd;
             {  // handle_surface_light, pt.rs:230-258
                 vec3 direct = mk3(0, 0, 0);
@@ -291,7 +315,7 @@ AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found,
                 LightSample dl;
                 dl.valid = false;
                 if (p.use_nee && (!p.indirect_only || r.depth > 1))
-                    dl = sample_direct(sc, si.p, si.ng, u_direct.x, mk2(u_direct.y, u_direct.z));
+                    dl = sample_direct<TEX>(sc, si.p, si.ng, u_direct.x, mk2(u_direct.y, u_direct.z));
                 vec3 u_bsdf = next_3d(r.smp);
                 // sample_surface_and_shade_direct, pt.rs:297-323
                 ShadePoint sp;

@@ -10,7 +10,7 @@
 // The reference gathers the same information through five dependent bindless-buffer reads per hit
 // (crates/akari_render/src/mesh.rs:499-653); here the per-triangle part is folded on the host.
 #pragma once
-#include "dbsdf.h"
+#include "dtex.h"
 
 namespace akr {
 
@@ -42,6 +42,7 @@ struct DScene {
     const uint32_t* __restrict__ inst_tri_offset;   // instance -> first global triangle id
     const float4* __restrict__ bvh_nodes;           // nullptr on the exhaustive path
     uint32_t n_tris, n_lights, n_nodes, has_alpha;
+    TexScene tex;                                   // textures + shader-graph node lists (all nullptr without textures)
 };
 
 struct SurfacePoint {  // interaction.rs:15-48, minus what this path never reads
@@ -51,6 +52,7 @@ struct SurfacePoint {  // interaction.rs:15-48, minus what this path never reads
     uint32_t material;
     int32_t light;
     uint32_t inst;
+    vec2 uv;
 };
 
 AKR_HD vec3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
@@ -77,6 +79,10 @@ AKR_D SurfacePoint surface_interaction(const DScene& sc, uint32_t gid, vec2 bary
     s.p = xf_point(xyz(c0), xyz(c1), xyz(c2), xyz(t), p_local);
     s.ng = xyz(q3);
     s.frame = Frame{s.ng, xyz(q4), xyz(q5)};
+    {  // uv = TriangleInterpolate(uv0, uv1, uv2), mesh.rs:527-546
+        float w = 1.0f - bary.x - bary.y;
+        s.uv = mk2((q0.w * w + q2.w * bary.x) + q4.w * bary.y, (q1.w * w + q3.w * bary.x) + q5.w * bary.y);
+    }
     if (sc.normals != nullptr) {
         float4 q7 = r[7];
         const uint32_t tf = f2u(q7.w);

@@ -1,0 +1,208 @@
+// dtex.h -- textures and non-constant shader-graph inputs.
+//
+// The reference evaluates, per shading point, every node of the material's compiled bytecode
+// (crates/akari_render/src/svm/eval.rs:97-269,363-380) and then builds the closure from the evaluated inputs
+// (svm/surface/principled.rs:13-131). Constant inputs are folded on the host (host/scene_build.cpp); a material
+// with at least one texture-fed input keeps a pruned node list in HBM: this file evaluates it at the hit's uv,
+// overrides the fed inputs of the material's raw input record and folds the record exactly as the host does
+// (fold_inputs below is the one definition both sides use).
+//
+// Texture sampling is LuisaCompute's `tex2d.sample` in the reference (third party, source absent): the definition
+// here -- texel centres at +0.5, bilinear weights from the fractional part, lerp as a + (b - a) t, unorm8 as
+// byte / 255 -- is the AKR-F32 restatement the oracle follows (oracle/or_tex.h).
+#pragma once
+#include "dbsdf.h"
+
+namespace akr {
+
+// ---- images ------------------------------------------------------------------------------------------------------
+enum : uint32_t { IMG_RGBA8 = 0, IMG_RGBA32F = 1 };
+enum : uint32_t { TEXF_NEAREST = 0, TEXF_LINEAR = 1 };
+enum : uint32_t { TEXA_REPEAT = 0, TEXA_CLIP = 1, TEXA_MIRROR = 2, TEXA_EXTEND = 3 };
+
+struct DImage {  // 32 B
+    uint32_t offset_lo, offset_hi;  // first texel, in 4-byte words from the start of the texel buffer
+    uint32_t width, height;
+    uint32_t format, filter, address, _pad;
+};
+
+struct TexVal {
+    float x, y, z, w;
+};
+AKR_HD TexVal tv(float x, float y, float z, float w) { return TexVal{x, y, z, w}; }
+
+// SamplerAddress (load.rs:684-689): maps a texel index into [0, n) or reports "outside" (Zero)
+AKR_HD bool tex_wrap(int& i, int n, uint32_t mode) {
+    if (mode == TEXA_REPEAT) {
+        i = i % n;
+        if (i < 0) i += n;
+    } else if (mode == TEXA_MIRROR) {
+        int p = 2 * n;
+        i = i % p;
+        if (i < 0) i += p;
+        if (i >= n) i = p - 1 - i;
+    } else if (mode == TEXA_EXTEND) {
+        i = i < 0 ? 0 : (i >= n ? n - 1 : i);
+    } else {
+        if (i < 0 || i >= n) return false;
+    }
+    return true;
+}
+AKR_HD TexVal tex_fetch(const uint32_t* __restrict__ texels, const DImage& im, int i, int j) {
+    if (!tex_wrap(i, (int)im.width, im.address) || !tex_wrap(j, (int)im.height, im.address)) return tv(0, 0, 0, 0);
+    const uint64_t base = ((uint64_t)im.offset_hi << 32) | im.offset_lo;
+    const uint64_t t = (uint64_t)j * im.width + (uint64_t)i;
+    if (im.format == IMG_RGBA8) {
+        uint32_t p = texels[base + t];
+        return tv((float)(p & 0xffu) / 255.0f, (float)((p >> 8) & 0xffu) / 255.0f, (float)((p >> 16) & 0xffu) / 255.0f,
+                  (float)(p >> 24) / 255.0f);
+    }
+    const uint32_t* q = texels + base + 4 * t;
+    return tv(u2f(q[0]), u2f(q[1]), u2f(q[2]), u2f(q[3]));
+}
+AKR_HD int tex_floor_to_int(float x, float& fl) {
+    if (!(x > -1.0e9f)) x = -1.0e9f;  // also NaN
+    if (x > 1.0e9f) x = 1.0e9f;
+    fl = __builtin_floorf(x);
+    return (int)fl;
+}
+AKR_HD float tex_lerp(float a, float b, float t) { return a + (b - a) * t; }
+AKR_HD TexVal tex_sample(const uint32_t* __restrict__ texels, const DImage& im, vec2 uv) {
+    float x = uv.x * (float)im.width, y = uv.y * (float)im.height;
+    float fx, fy;
+    if (im.filter == TEXF_NEAREST) {
+        int i = tex_floor_to_int(x, fx), j = tex_floor_to_int(y, fy);
+        return tex_fetch(texels, im, i, j);
+    }
+    x = x - 0.5f;
+    y = y - 0.5f;
+    int i = tex_floor_to_int(x, fx), j = tex_floor_to_int(y, fy);
+    float tx = x - fx, ty = y - fy;
+    if (!(tx >= 0.0f)) tx = 0.0f;  // x was clamped / NaN
+    if (!(ty >= 0.0f)) ty = 0.0f;
+    if (tx > 1.0f) tx = 1.0f;
+    if (ty > 1.0f) ty = 1.0f;
+    TexVal a = tex_fetch(texels, im, i, j), b = tex_fetch(texels, im, i + 1, j);
+    TexVal c = tex_fetch(texels, im, i, j + 1), d = tex_fetch(texels, im, i + 1, j + 1);
+    TexVal r0 = tv(tex_lerp(a.x, b.x, tx), tex_lerp(a.y, b.y, tx), tex_lerp(a.z, b.z, tx), tex_lerp(a.w, b.w, tx));
+    TexVal r1 = tv(tex_lerp(c.x, d.x, tx), tex_lerp(c.y, d.y, tx), tex_lerp(c.z, d.z, tx), tex_lerp(c.w, d.w, tx));
+    return tv(tex_lerp(r0.x, r1.x, ty), tex_lerp(r0.y, r1.y, ty), tex_lerp(r0.z, r1.z, ty), tex_lerp(r0.w, r1.w, ty));
+}
+// srgb_to_linear (color.rs:555-558)
+AKR_HD float srgb_to_linear1(float s) { return s <= 0.04045f ? s / 12.92f : pow_f((s + 0.055f) / 1.055f, 2.4f); }
+
+// ---- node list ---------------------------------------------------------------------------------------------------
+enum : uint32_t {
+    NODE_CONST = 0, NODE_RGB = 1, NODE_TEXCOORDS = 2, NODE_IMAGE = 3, NODE_MAPPING = 4, NODE_CHECKERBOARD = 5,
+    NODE_SPECTRAL_UPLIFT = 6, NODE_SEPARATE_COLOR = 7, NODE_EXTRACT = 8, NODE_NORMAL_MAP = 9
+};
+constexpr uint32_t kNodeNone = 0xffffffffu;
+constexpr uint32_t kMaxGraphNodes = 24;  // after pruning to the texture-fed inputs (host/scene_build.cpp)
+struct DNode {                           // = akr_shader_node, 32 B
+    uint32_t op;
+    uint32_t arg[4];
+    float k[3];
+};
+enum : uint32_t {
+    IN_BASE_COLOR = 0, IN_METALLIC, IN_ROUGHNESS, IN_IOR, IN_SPECULAR_IOR_LEVEL, IN_SPECULAR_TINT, IN_TRANSMISSION_WEIGHT,
+    IN_COAT_WEIGHT, IN_COAT_ROUGHNESS, IN_COAT_IOR, IN_COAT_TINT, IN_EMISSION_COLOR, IN_EMISSION_STRENGTH, IN_NORMAL, IN_COUNT
+};
+static_assert(IN_COUNT == 14, "DMaterial keeps the input map in 14 of its 16 spare words");
+
+struct TexScene {  // the texture part of DScene
+    const DNode* __restrict__ nodes;
+    const DImage* __restrict__ images;
+    const uint32_t* __restrict__ texels;
+    const MatInputs* __restrict__ mat_inputs;  // raw (unfolded) inputs, one per material
+};
+
+// eval_shader (eval.rs:363-380): every node of the (pruned) list in order; values are float4, narrower types
+// zero-extended, so the auto-convert rules of eval.rs:301-349 are component reads.
+AKR_HD void eval_graph(const TexScene& ts, uint32_t first, uint32_t count, vec2 uv, TexVal* val) {
+    for (uint32_t i = 0; i < count; i++) {
+        const DNode nd = ts.nodes[first + i];
+        TexVal v = tv(0, 0, 0, 0);
+        switch (nd.op) {
+            case NODE_CONST: v = tv(nd.k[0], nd.k[1], nd.k[2], 0.0f); break;
+            case NODE_RGB: v = tv(nd.k[0], nd.k[1], nd.k[2], 1.0f); break;  // sRGB -> sRGB pipeline: identity (texture/mod.rs:9-30)
+            case NODE_TEXCOORDS: v = tv(uv.x, uv.y, 0.0f, 0.0f); break;
+            case NODE_IMAGE: {
+                vec2 st = nd.arg[1] == kNodeNone ? uv : mk2(val[nd.arg[1]].x, val[nd.arg[1]].y);
+                v = tex_sample(ts.texels, ts.images[nd.arg[0]], st);
+                if (nd.arg[2]) v = tv(srgb_to_linear1(v.x), srgb_to_linear1(v.y), srgb_to_linear1(v.z), v.w);
+                break;
+            }
+            case NODE_MAPPING: {
+                TexVal a = val[nd.arg[0]], loc = val[nd.arg[1]], sc = val[nd.arg[2]];
+                if (nd.arg[3] == 0) v = tv(a.x * sc.x + loc.x, a.y * sc.y + loc.y, a.z * sc.z + loc.z, 0.0f);
+                else v = tv((a.x - loc.x) / sc.x, (a.y - loc.y) / sc.y, (a.z - loc.z) / sc.z, 0.0f);
+                break;
+            }
+            case NODE_CHECKERBOARD: {
+                vec2 st = nd.arg[0] == kNodeNone ? uv : mk2(val[nd.arg[0]].x, val[nd.arg[0]].y);
+                float scale = val[nd.arg[1]].x, fx, fy;
+                int px = tex_floor_to_int((st.x * scale) * 2.0f, fx), py = tex_floor_to_int((st.y * scale) * 2.0f, fy);
+                v = (((px + py) & 1) == 0) ? val[nd.arg[2]] : val[nd.arg[3]];
+                break;
+            }
+            case NODE_SPECTRAL_UPLIFT: v = val[nd.arg[0]]; break;
+            case NODE_SEPARATE_COLOR: v = val[nd.arg[0]]; break;
+            case NODE_EXTRACT: {
+                TexVal a = val[nd.arg[0]];
+                uint32_t f = nd.arg[1];
+                v = f == 0 ? tv(a.x, 0, 0, 0) : f == 1 ? tv(a.y, 0, 0, 0) : f == 2 ? tv(a.z, 0, 0, 0) : tv(a.x, a.y, 0, 0);
+                break;
+            }
+            case NODE_NORMAL_MAP: {
+                TexVal a = val[nd.arg[0]];
+                float s = val[nd.arg[1]].x;
+                float nx = 2.0f * a.x - 1.0f, ny = 2.0f * a.y - 1.0f, nz = 2.0f * a.z - 1.0f;
+                if (s != 1.0f) { nx = nx * s; ny = ny * s; nz = nz * 1.0f; }
+                v = tv(nx, ny, nz, 0.0f);
+                break;
+            }
+            default: break;
+        }
+        val[i] = v;
+    }
+}
+
+// Overrides the texture-fed inputs of `in` with the node values (principled.rs:13-131 read rules: colours through
+// eval_color_alpha -> xyz + alpha, scalars through eval_float_auto_convert -> x, normal through float3 -> xyz).
+AKR_HD void apply_inputs(const uint32_t* __restrict__ map, const TexVal* val, MatInputs& in) {
+    uint32_t n;
+    if ((n = map[IN_BASE_COLOR]) != kNodeNone) { in.base_color[0] = val[n].x; in.base_color[1] = val[n].y; in.base_color[2] = val[n].z; in.base_alpha = val[n].w; }
+    if ((n = map[IN_METALLIC]) != kNodeNone) in.metallic = val[n].x;
+    if ((n = map[IN_ROUGHNESS]) != kNodeNone) in.roughness = val[n].x;
+    if ((n = map[IN_IOR]) != kNodeNone) in.ior = val[n].x;
+    if ((n = map[IN_SPECULAR_IOR_LEVEL]) != kNodeNone) in.specular_ior_level = val[n].x;
+    if ((n = map[IN_SPECULAR_TINT]) != kNodeNone) { in.specular_tint[0] = val[n].x; in.specular_tint[1] = val[n].y; in.specular_tint[2] = val[n].z; }
+    if ((n = map[IN_TRANSMISSION_WEIGHT]) != kNodeNone) in.transmission_weight = val[n].x;
+    if ((n = map[IN_COAT_WEIGHT]) != kNodeNone) in.coat_weight = val[n].x;
+    if ((n = map[IN_COAT_ROUGHNESS]) != kNodeNone) in.coat_roughness = val[n].x;
+    if ((n = map[IN_COAT_IOR]) != kNodeNone) in.coat_ior = val[n].x;
+    if ((n = map[IN_COAT_TINT]) != kNodeNone) { in.coat_tint[0] = val[n].x; in.coat_tint[1] = val[n].y; in.coat_tint[2] = val[n].z; }
+    if ((n = map[IN_EMISSION_COLOR]) != kNodeNone) { in.emission_color[0] = val[n].x; in.emission_color[1] = val[n].y; in.emission_color[2] = val[n].z; }
+    if ((n = map[IN_EMISSION_STRENGTH]) != kNodeNone) in.emission_strength = val[n].x;
+    if ((n = map[IN_NORMAL]) != kNodeNone) { in.normal[0] = val[n].x; in.normal[1] = val[n].y; in.normal[2] = val[n].z; }
+}
+
+// The material at a shading point: the folded record as is, or -- for MF_TEXTURED materials -- its graph evaluated at
+// `uv` and folded. `m` must hold the material's folded record on entry.
+AKR_HD void material_at(const TexScene& ts, uint32_t material, vec2 uv, DMaterial& m) {
+    if (!(m.flags & MF_TEXTURED)) return;
+    TexVal val[kMaxGraphNodes];
+    const uint32_t first = m.tex_first_node, count = m.tex_n_nodes;
+    uint32_t map[IN_COUNT];
+    for (uint32_t i = 0; i < IN_COUNT; i++) map[i] = m.tex_input[i];
+    eval_graph(ts, first, count, uv, val);
+    MatInputs in = ts.mat_inputs[material];
+    apply_inputs(map, val, in);
+    fold_inputs(in, m);
+    m.flags |= MF_TEXTURED;
+    m.tex_first_node = first;
+    m.tex_n_nodes = count;
+    for (uint32_t i = 0; i < IN_COUNT; i++) m.tex_input[i] = map[i];
+}
+
+}  // namespace akr

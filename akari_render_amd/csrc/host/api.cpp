@@ -113,7 +113,7 @@ struct akr_scene {
     FlatScene flat;
     CompiledScene cs;
     DevBuf woop, tri_gid, shade, normals, inst, materials, ggx_table, light_entries, light_pdf, light_inst, light_tri_offset,
-        light_n_tris, area_entries, area_pdf, inst_tri_offset, bvh_nodes;
+        light_n_tris, area_entries, area_pdf, inst_tri_offset, bvh_nodes, tex_nodes, tex_images, tex_texels, tex_mat_inputs;
     std::vector<float> ggx_host;
     DScene dscene;
     float r2c[16], c2w[16];
@@ -194,6 +194,12 @@ static void scene_finish(akr_scene* s) {
     s->area_pdf.upload(cs.area_pdf);
     s->inst_tri_offset.upload(cs.inst_tri_offset);
     s->bvh_nodes.upload(cs.bvh_nodes);
+    if (cs.has_textures) {
+        s->tex_nodes.upload(cs.tex_nodes);
+        s->tex_images.upload(cs.images);
+        s->tex_texels.upload(cs.texels);
+        s->tex_mat_inputs.upload(cs.mat_inputs);
+    }
     ensure_ggx_table(s);
     DScene& d = s->dscene;
     std::memset(&d, 0, sizeof d);
@@ -217,10 +223,16 @@ static void scene_finish(akr_scene* s) {
     d.n_lights = cs.n_lights;
     d.n_nodes = (uint32_t)(cs.bvh_nodes.size() / 16);
     d.has_alpha = cs.has_alpha ? 1u : 0u;
+    if (cs.has_textures) {
+        d.tex.nodes = s->tex_nodes.as<DNode>();
+        d.tex.images = s->tex_images.as<DImage>();
+        d.tex.texels = s->tex_texels.as<uint32_t>();
+        d.tex.mat_inputs = s->tex_mat_inputs.as<MatInputs>();
+    }
     s->device_bytes = 0;
     for (const DevBuf* b : {&s->woop, &s->tri_gid, &s->shade, &s->normals, &s->inst, &s->materials, &s->ggx_table, &s->light_entries,
                             &s->light_pdf, &s->light_inst, &s->light_tri_offset, &s->light_n_tris, &s->area_entries, &s->area_pdf,
-                            &s->inst_tri_offset, &s->bvh_nodes})
+                            &s->inst_tri_offset, &s->bvh_nodes, &s->tex_nodes, &s->tex_images, &s->tex_texels, &s->tex_mat_inputs})
         s->device_bytes += b->bytes;
 }
 
@@ -481,6 +493,30 @@ AKR_API int32_t akr_scene_get_instance(const akr_scene* s, uint32_t i, akr_insta
 AKR_API int32_t akr_scene_get_material(const akr_scene* s, uint32_t i, akr_material_desc* out) {
     if (!s || !out || i >= s->flat.materials.size()) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_scene_get_material: bad argument");
     *out = s->flat.materials[i];
+    return AKR_OK;
+}
+AKR_API int32_t akr_scene_get_image_count(const akr_scene* s, uint32_t* n) {
+    if (!s || !n) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_scene_get_image_count: NULL argument");
+    *n = (uint32_t)s->flat.images.size();
+    return AKR_OK;
+}
+AKR_API int32_t akr_scene_get_image(const akr_scene* s, uint32_t i, akr_image_desc* out) {
+    if (!s || !out || i >= s->flat.images.size()) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_scene_get_image: bad argument");
+    const HostImage& h = s->flat.images[i];
+    out->width = h.width; out->height = h.height; out->format = h.format; out->filter = h.filter; out->address = h.address; out->_pad = 0;
+    out->texels = h.words.data();
+    return AKR_OK;
+}
+AKR_API int32_t akr_scene_get_material_graph(const akr_scene* s, uint32_t i, akr_material_graph* out) {
+    if (!s || !out || i >= s->flat.materials.size()) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_scene_get_material_graph: bad argument");
+    std::memset(out, 0, sizeof *out);
+    for (uint32_t& k : out->input) k = AKR_NODE_NONE;
+    if (i < s->flat.graphs.size()) {
+        const HostGraph& g = s->flat.graphs[i];
+        out->n_nodes = (uint32_t)g.nodes.size();
+        out->nodes = g.nodes.empty() ? nullptr : g.nodes.data();
+        std::memcpy(out->input, g.input, sizeof out->input);
+    }
     return AKR_OK;
 }
 AKR_API int32_t akr_scene_get_camera(const akr_scene* s, akr_camera_desc* out) {
@@ -921,6 +957,54 @@ AKR_API int32_t akr_probe_surface_interaction(akr_context* ctx, akr_scene* scene
         if (n) HIP_CHECK(launch_probe_si(probe_params(scene), n, dip.as<uint32_t>(), db.as<float>(), dout.as<float>(), ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         if (n) HIP_CHECK(hipMemcpy(out, dout.p, 19ull * n * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+// PNG reader of the scene loader, exposed for tests: rgba == NULL returns the size only.
+AKR_API int32_t akr_host_decode_png(const uint8_t* data, uint64_t len, uint32_t* width, uint32_t* height, uint8_t* rgba, uint64_t capacity) {
+    if (!data || !width || !height) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_host_decode_png: NULL argument");
+    return guarded([&] {
+        std::vector<uint8_t> px;
+        decode_png(data, (size_t)len, *width, *height, px);
+        if (rgba) {
+            if (capacity < px.size()) throw std::invalid_argument("akr_host_decode_png: output buffer too small");
+            std::memcpy(rgba, px.data(), px.size());
+        }
+    });
+}
+// Evaluated inputs of a material at uv points: on the device (ctx != NULL; needs a scene with textures) or with the
+// same code on the host (ctx == NULL).
+AKR_API int32_t akr_probe_material_inputs(akr_context* ctx, akr_scene* scene, uint32_t material, uint32_t n, const float* uv, float* out26) {
+    if (!scene || !uv || !out26) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_probe_material_inputs: NULL argument");
+    if (material >= scene->flat.materials.size()) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_probe_material_inputs: material out of range");
+    return guarded([&] {
+        const CompiledScene& cs = scene->cs;
+        if (!ctx) {
+            const TexScene ts{cs.tex_nodes.data(), cs.images.data(), cs.texels.data(), cs.mat_inputs.data()};
+            const DMaterial& m = cs.materials[material];
+            for (uint32_t i = 0; i < n; i++) {
+                MatInputs in;
+                if (cs.has_textures) in = cs.mat_inputs[material];
+                else std::memcpy(&in, &scene->flat.materials[material], sizeof in);
+                if (m.flags & MF_TEXTURED) {
+                    TexVal val[kMaxGraphNodes];
+                    eval_graph(ts, m.tex_first_node, m.tex_n_nodes, mk2(uv[2 * i], uv[2 * i + 1]), val);
+                    apply_inputs(m.tex_input, val, in);
+                }
+                std::memcpy(out26 + 26ull * i, &in, sizeof in);
+            }
+            return;
+        }
+        if (!cs.has_textures) throw std::invalid_argument("akr_probe_material_inputs: the scene has no textured material");
+        if (scene->ctx != ctx) throw std::invalid_argument("akr_probe_material_inputs: scene belongs to another context");
+        ctx->bind();
+        DevBuf duv, dout;
+        std::vector<float> uvv(uv, uv + 2ull * n);
+        duv.upload(uvv);
+        dout.alloc(26ull * n * 4);
+        if (n) HIP_CHECK(launch_probe_material(probe_params(scene), material, n, duv.as<float>(), dout.as<uint32_t>(), ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (n) HIP_CHECK(hipMemcpy(out26, dout.p, 26ull * n * 4, hipMemcpyDeviceToHost));
     });
 }
 

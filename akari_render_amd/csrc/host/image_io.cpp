@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
@@ -159,6 +160,266 @@ void write_image(const std::string& path, const float* rgb, uint32_t w, uint32_t
     if (ends_with(".exr")) write_exr_rgb(path, rgb, w, h);
     else if (ends_with(".png")) write_png_srgb8(path, rgb, w, h);
     else throw std::runtime_error("unsupported: image format of '" + path + "' (use .exr or .png)");
+}
+
+// ------------------------------------------------------------------------------------------------ PNG reader
+// What `image::io::Reader::decode()` + `to_rgba8()` give the reference for a PNG texture (load.rs:583-604): expanded
+// palette / low bit depths / tRNS, 16-bit samples rounded to 8, grey replicated, alpha 255 when absent. Interlaced
+// files are rejected. Rows come out in file order (top first); the caller flips (load.rs:596).
+namespace {
+struct BitReader {
+    const uint8_t* p;
+    size_t n, pos = 0;
+    uint32_t buf = 0;
+    int cnt = 0;
+    uint32_t bits(int k) {
+        while (cnt < k) {
+            if (pos >= n) throw std::runtime_error("png: truncated deflate stream");
+            buf |= (uint32_t)p[pos++] << cnt;
+            cnt += 8;
+        }
+        uint32_t v = buf & ((1u << k) - 1u);
+        buf >>= k;
+        cnt -= k;
+        return v;
+    }
+    void align() { buf = 0; cnt = 0; }
+};
+struct Huffman {
+    uint16_t count[16] = {0}, symbol[320] = {0};
+    void build(const uint8_t* len, int n) {
+        for (int i = 0; i < 16; i++) count[i] = 0;
+        for (int i = 0; i < n; i++) count[len[i]]++;
+        count[0] = 0;
+        uint16_t offs[16];
+        offs[1] = 0;
+        for (int i = 1; i < 15; i++) offs[i + 1] = (uint16_t)(offs[i] + count[i]);
+        for (int i = 0; i < n; i++)
+            if (len[i]) symbol[offs[len[i]]++] = (uint16_t)i;
+    }
+    int decode(BitReader& br) const {
+        int code = 0, first = 0, index = 0;
+        for (int l = 1; l < 16; l++) {
+            code |= (int)br.bits(1);
+            int c = count[l];
+            if (code - c < first) return symbol[index + (code - first)];
+            index += c;
+            first += c;
+            first <<= 1;
+            code <<= 1;
+        }
+        throw std::runtime_error("png: bad Huffman code");
+    }
+};
+std::vector<uint8_t> inflate_zlib(const uint8_t* data, size_t n) {
+    if (n < 6) throw std::runtime_error("png: zlib stream too short");
+    if ((data[0] & 0x0f) != 8 || ((data[0] << 8) | data[1]) % 31 != 0 || (data[1] & 0x20)) throw std::runtime_error("png: bad zlib header");
+    BitReader br{data + 2, n - 2};
+    std::vector<uint8_t> out;
+    static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    for (;;) {
+        uint32_t last = br.bits(1), type = br.bits(2);
+        if (type == 0) {
+            br.align();
+            if (br.pos + 4 > br.n) throw std::runtime_error("png: truncated stored block");
+            uint32_t len = br.p[br.pos] | (br.p[br.pos + 1] << 8), nlen = br.p[br.pos + 2] | (br.p[br.pos + 3] << 8);
+            br.pos += 4;
+            if ((len ^ 0xffffu) != nlen || br.pos + len > br.n) throw std::runtime_error("png: bad stored block");
+            out.insert(out.end(), br.p + br.pos, br.p + br.pos + len);
+            br.pos += len;
+        } else if (type == 1 || type == 2) {
+            Huffman hl, hd;
+            uint8_t lens[320];
+            if (type == 1) {
+                for (int i = 0; i < 144; i++) lens[i] = 8;
+                for (int i = 144; i < 256; i++) lens[i] = 9;
+                for (int i = 256; i < 280; i++) lens[i] = 7;
+                for (int i = 280; i < 288; i++) lens[i] = 8;
+                hl.build(lens, 288);
+                for (int i = 0; i < 30; i++) lens[i] = 5;
+                hd.build(lens, 30);
+            } else {
+                int nlen = (int)br.bits(5) + 257, ndist = (int)br.bits(5) + 1, ncode = (int)br.bits(4) + 4;
+                static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                uint8_t cl[19] = {0};
+                for (int i = 0; i < ncode; i++) cl[order[i]] = (uint8_t)br.bits(3);
+                Huffman hc;
+                hc.build(cl, 19);
+                int idx = 0;
+                while (idx < nlen + ndist) {
+                    int sym = hc.decode(br);
+                    if (sym < 16) {
+                        lens[idx++] = (uint8_t)sym;
+                    } else {
+                        int rep, val = 0;
+                        if (sym == 16) {
+                            if (idx == 0) throw std::runtime_error("png: bad code lengths");
+                            val = lens[idx - 1];
+                            rep = 3 + (int)br.bits(2);
+                        } else if (sym == 17) {
+                            rep = 3 + (int)br.bits(3);
+                        } else {
+                            rep = 11 + (int)br.bits(7);
+                        }
+                        if (idx + rep > nlen + ndist) throw std::runtime_error("png: bad code lengths");
+                        while (rep--) lens[idx++] = (uint8_t)val;
+                    }
+                }
+                hl.build(lens, nlen);
+                hd.build(lens + nlen, ndist);
+            }
+            for (;;) {
+                int sym = hl.decode(br);
+                if (sym < 256) {
+                    out.push_back((uint8_t)sym);
+                } else if (sym == 256) {
+                    break;
+                } else {
+                    sym -= 257;
+                    if (sym >= 29) throw std::runtime_error("png: bad length symbol");
+                    uint32_t len = lbase[sym] + br.bits(lext[sym]);
+                    int ds = hd.decode(br);
+                    if (ds >= 30) throw std::runtime_error("png: bad distance symbol");
+                    uint32_t dist = dbase[ds] + br.bits(dext[ds]);
+                    if (dist > out.size()) throw std::runtime_error("png: distance too far back");
+                    size_t from = out.size() - dist;
+                    for (uint32_t i = 0; i < len; i++) out.push_back(out[from + i]);
+                }
+            }
+        } else {
+            throw std::runtime_error("png: bad block type");
+        }
+        if (last) break;
+    }
+    // adler32 trailer
+    br.align();
+    if (br.pos + 4 <= br.n) {
+        uint32_t want = ((uint32_t)br.p[br.pos] << 24) | ((uint32_t)br.p[br.pos + 1] << 16) | ((uint32_t)br.p[br.pos + 2] << 8) | br.p[br.pos + 3];
+        uint32_t a = 1, b = 0;
+        for (uint8_t c : out) {
+            a = (a + c) % 65521u;
+            b = (b + a) % 65521u;
+        }
+        if (((b << 16) | a) != want) throw std::runtime_error("png: adler32 mismatch");
+    }
+    return out;
+}
+uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+int paeth(int a, int b, int c) {
+    int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+}  // namespace
+
+void decode_png(const uint8_t* data, size_t n, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba) {
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (n < 8 || std::memcmp(data, sig, 8) != 0) throw std::runtime_error("png: bad signature");
+    size_t pos = 8;
+    uint32_t depth = 0, ctype = 0;
+    bool have_hdr = false;
+    std::vector<uint8_t> idat, plte, trns;
+    while (pos + 12 <= n) {
+        uint32_t len = be32(data + pos);
+        const uint8_t* type = data + pos + 4;
+        if (pos + 12 + (size_t)len > n) throw std::runtime_error("png: truncated chunk");
+        const uint8_t* body = data + pos + 8;
+        if (!std::memcmp(type, "IHDR", 4)) {
+            if (len != 13) throw std::runtime_error("png: bad IHDR");
+            w = be32(body); h = be32(body + 4); depth = body[8]; ctype = body[9];
+            if (body[10] != 0 || body[11] != 0) throw std::runtime_error("png: unknown compression / filter method");
+            if (body[12] != 0) throw std::runtime_error("unsupported: interlaced PNG");
+            have_hdr = true;
+        } else if (!std::memcmp(type, "PLTE", 4)) {
+            plte.assign(body, body + len);
+        } else if (!std::memcmp(type, "tRNS", 4)) {
+            trns.assign(body, body + len);
+        } else if (!std::memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), body, body + len);
+        } else if (!std::memcmp(type, "IEND", 4)) {
+            break;
+        }
+        pos += 12 + (size_t)len;
+    }
+    if (!have_hdr || w == 0 || h == 0) throw std::runtime_error("png: missing IHDR");
+    int channels;
+    switch (ctype) {
+        case 0: channels = 1; break;
+        case 2: channels = 3; break;
+        case 3: channels = 1; break;
+        case 4: channels = 2; break;
+        case 6: channels = 4; break;
+        default: throw std::runtime_error("png: bad colour type");
+    }
+    bool depth_ok = (ctype == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) ||
+                    (ctype == 3 && (depth == 1 || depth == 2 || depth == 4 || depth == 8)) ||
+                    ((ctype == 2 || ctype == 4 || ctype == 6) && (depth == 8 || depth == 16));
+    if (!depth_ok) throw std::runtime_error("png: bad bit depth");
+    if (ctype == 3 && plte.size() < 3) throw std::runtime_error("png: palette image without PLTE");
+    const size_t bpp_bits = (size_t)channels * depth, stride = ((size_t)w * bpp_bits + 7) / 8, bpp = (bpp_bits + 7) / 8;
+    std::vector<uint8_t> raw = inflate_zlib(idat.data(), idat.size());
+    if (raw.size() < (stride + 1) * (size_t)h) throw std::runtime_error("png: image data too short");
+    std::vector<uint8_t> img(stride * (size_t)h);
+    for (uint32_t y = 0; y < h; y++) {  // unfilter
+        const uint8_t* src = raw.data() + (stride + 1) * (size_t)y;
+        uint8_t ft = src[0];
+        src++;
+        uint8_t* cur = img.data() + stride * (size_t)y;
+        const uint8_t* up = y ? cur - stride : nullptr;
+        for (size_t x = 0; x < stride; x++) {
+            int a = x >= bpp ? cur[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= bpp) ? up[x - bpp] : 0, v = src[x];
+            switch (ft) {
+                case 0: break;
+                case 1: v += a; break;
+                case 2: v += b; break;
+                case 3: v += (a + b) >> 1; break;
+                case 4: v += paeth(a, b, c); break;
+                default: throw std::runtime_error("png: bad filter type");
+            }
+            cur[x] = (uint8_t)v;
+        }
+    }
+    rgba.assign(4ull * w * h, 255);
+    auto sample = [&](const uint8_t* row, size_t idx) -> uint32_t {  // idx-th sample of the row, raw value
+        if (depth == 8) return row[idx];
+        if (depth == 16) return ((uint32_t)row[2 * idx] << 8) | row[2 * idx + 1];
+        size_t bit = idx * depth;
+        return (row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1u);
+    };
+    auto to8 = [&](uint32_t v) -> uint8_t {
+        if (depth == 8) return (uint8_t)v;
+        if (depth == 16) return (uint8_t)((v + 128u) / 257u);
+        return (uint8_t)(v * 255u / ((1u << depth) - 1u));  // 1/2/4-bit grey expanded to 8 bits
+    };
+    for (uint32_t y = 0; y < h; y++) {
+        const uint8_t* row = img.data() + stride * (size_t)y;
+        uint8_t* o = rgba.data() + 4ull * w * y;
+        for (uint32_t x = 0; x < w; x++, o += 4) {
+            if (ctype == 3) {
+                uint32_t i = sample(row, x);
+                if (3 * (size_t)i + 2 >= plte.size()) throw std::runtime_error("png: palette index out of range");
+                o[0] = plte[3 * i]; o[1] = plte[3 * i + 1]; o[2] = plte[3 * i + 2];
+                o[3] = i < trns.size() ? trns[i] : 255;
+            } else if (ctype == 0) {
+                uint32_t v = sample(row, x);
+                o[0] = o[1] = o[2] = to8(v);
+                if (trns.size() >= 2 && v == (((uint32_t)trns[0] << 8) | trns[1])) o[3] = 0;
+            } else if (ctype == 4) {
+                o[0] = o[1] = o[2] = to8(sample(row, 2 * (size_t)x));
+                o[3] = to8(sample(row, 2 * (size_t)x + 1));
+            } else if (ctype == 2) {
+                uint32_t r = sample(row, 3 * (size_t)x), g = sample(row, 3 * (size_t)x + 1), b = sample(row, 3 * (size_t)x + 2);
+                o[0] = to8(r); o[1] = to8(g); o[2] = to8(b);
+                if (trns.size() >= 6 && r == (((uint32_t)trns[0] << 8) | trns[1]) && g == (((uint32_t)trns[2] << 8) | trns[3]) &&
+                    b == (((uint32_t)trns[4] << 8) | trns[5]))
+                    o[3] = 0;
+            } else {
+                for (int c = 0; c < 4; c++) o[c] = to8(sample(row, 4 * (size_t)x + c));
+            }
+        }
+    }
 }
 
 }  // namespace akr

@@ -54,78 +54,158 @@ FlatScene FlatScene::from_desc(const akr_scene_desc& d) {
     s.camera = d.camera;
     if (d.camera.width == 0 || d.camera.height == 0) throw std::invalid_argument("akr_camera_desc: zero resolution");
     if (d.ggx_dielectric_table) s.ggx_table.assign(d.ggx_dielectric_table, d.ggx_dielectric_table + 4096);
+    if (d.n_images && !d.images) throw std::invalid_argument("akr_scene_desc: null image array with non-zero count");
+    s.images.resize(d.n_images);
+    for (uint32_t i = 0; i < d.n_images; i++) {
+        const akr_image_desc& im = d.images[i];
+        if (im.width == 0 || im.height == 0 || !im.texels) throw std::invalid_argument("akr_image_desc: empty image");
+        if (im.format > AKR_IMAGE_RGBA32F || im.filter > AKR_TEX_FILTER_LINEAR || im.address > AKR_TEX_EXTEND)
+            throw std::invalid_argument("akr_image_desc: unknown format / filter / address mode");
+        if ((uint64_t)im.width * im.height > (1ull << 30)) throw std::invalid_argument("akr_image_desc: image too large");
+        HostImage& h = s.images[i];
+        h.width = im.width; h.height = im.height; h.format = im.format; h.filter = im.filter; h.address = im.address;
+        size_t words = (size_t)im.width * im.height * (im.format == AKR_IMAGE_RGBA32F ? 4 : 1);
+        h.words.resize(words);
+        std::memcpy(h.words.data(), im.texels, words * 4);
+    }
+    if (d.material_graphs) {
+        s.graphs.resize(d.n_materials);
+        for (uint32_t i = 0; i < d.n_materials; i++) {
+            const akr_material_graph& g = d.material_graphs[i];
+            if (g.n_nodes && !g.nodes) throw std::invalid_argument("akr_material_graph: null node array with non-zero count");
+            s.graphs[i].nodes.assign(g.nodes, g.nodes + g.n_nodes);
+            std::memcpy(s.graphs[i].input, g.input, sizeof g.input);
+        }
+    }
     return s;
 }
 
 // ------------------------------------------------------------------------------------------------ materials
 static vec3 v3(const float* p) { return mk3(p[0], p[1], p[2]); }
 
+static_assert(sizeof(MatInputs) == sizeof(akr_material_desc), "MatInputs mirrors akr_material_desc");
 DMaterial fold_material(const akr_material_desc& m) {
     DMaterial d;
     std::memset(&d, 0, sizeof d);
-    d.kind = m.kind;
-    d.base_alpha = m.base_alpha;
-    vec3 color = v3(m.base_color);
-    d.color = color;
-    d.emission = v3(m.emission_color) * m.emission_strength;
-    d.nm_normal = mk3(0, 0, 1);
-    switch (m.kind) {
-        case AKR_MAT_PRINCIPLED: {  // principled.rs:23-131
-            d.metallic = m.metallic;
-            d.transmission = m.transmission_weight;
-            d.roughness = m.roughness;
-            d.eta = m.ior;
-            d.transmission_color = mk3(__builtin_sqrtf(color.x), __builtin_sqrtf(color.y), __builtin_sqrtf(color.z));
-            d.diffuse_refl = color * kInvPi;
-            d.spec_tint = v3(m.specular_tint);
-            float eta_s = m.ior, f0 = f0_from_ior(eta_s);
-            if (m.specular_ior_level != 0.5f) {
-                f0 *= 2.0f * m.specular_ior_level;
-                eta_s = ior_from_f0(f0);
-            }
-            d.f0 = f0;
-            d.eta_s = eta_s;
-            d.spec_color = d.spec_tint * f0;
-            d.coat_weight = m.coat_weight;
-            d.coat_roughness = m.coat_roughness;
-            d.coat_eta = m.coat_ior;
-            d.coat_scale = lerp3(mk3(1, 1, 1), v3(m.coat_tint), m.coat_weight);
-            d.alpha = mk2(max_f(m.roughness * m.roughness, 1e-4f), max_f(m.roughness * m.roughness, 1e-4f));
-            d.coat_alpha = mk2(max_f(m.coat_roughness * m.coat_roughness, 1e-4f), max_f(m.coat_roughness * m.coat_roughness, 1e-4f));
-            artistic_to_conductor(color, d.spec_tint, d.metal_n, d.metal_k);
-            uint32_t fl = 0;
-            if (f0 != 0.0f) fl |= MF_SPEC;
-            if (m.coat_weight != 0.0f) fl |= MF_COAT;
-            if (m.metallic < 1.0f - 1e-4f) fl |= MF_EVAL_BASE;
-            if (m.metallic > 1e-4f) fl |= MF_EVAL_METAL;
-            if (m.transmission_weight < 1.0f - 1e-4f) fl |= MF_EVAL_DIFF;
-            if (m.transmission_weight > 1e-4f) fl |= MF_EVAL_DIEL;
-            vec3 normal = mk3(-m.normal[0], -m.normal[1], m.normal[2]);  // principled.rs:203-205
-            if (!(normal.x == 0.0f && normal.y == 0.0f && normal.z == 0.0f)) {
-                fl |= MF_NORMAL_MAP;
-                d.nm_normal = normalize(normal);
-            }
-            d.flags = fl;
-            break;
-        }
-        case AKR_MAT_DIFFUSE:  // diffuse.rs:83-104
-            d.diffuse_refl = color * kInvPi;
-            d.emission = mk3(0, 0, 0);
-            break;
-        case AKR_MAT_GLASS:  // glass.rs:13-45
-            d.eta = m.ior;
-            d.roughness = m.roughness;
-            d.alpha = mk2(max_f(m.roughness * m.roughness, 1e-4f), max_f(m.roughness * m.roughness, 1e-4f));
-            d.emission = mk3(0, 0, 0);
-            d.base_alpha = 1.0f;
-            break;
-        case AKR_MAT_EMISSION:  // svm/mod.rs:114-123
-            d.base_alpha = 1.0f;
-            break;
-        default: throw std::invalid_argument("akr_material_desc: unknown kind");
-    }
-    if (d.emission.x != 0.0f || d.emission.y != 0.0f || d.emission.z != 0.0f) d.flags |= MF_EMISSIVE;
+    MatInputs in;
+    std::memcpy(&in, &m, sizeof in);
+    if (!fold_inputs(in, d)) throw std::invalid_argument("akr_material_desc: unknown kind");
+    for (uint32_t i = 0; i < 14; i++) d.tex_input[i] = 0xffffffffu;
     return d;
+}
+
+// ------------------------------------------------------------------------------------------------ shader graphs
+static_assert(sizeof(DNode) == sizeof(akr_shader_node), "DNode mirrors akr_shader_node");
+static uint32_t node_n_args(uint32_t op) {
+    switch (op) {
+        case AKR_NODE_CONST: case AKR_NODE_RGB: case AKR_NODE_TEXCOORDS: return 0;
+        case AKR_NODE_IMAGE: return 2;  // arg0 is an image id, arg1 the optional uv node
+        case AKR_NODE_MAPPING: return 3;
+        case AKR_NODE_CHECKERBOARD: return 4;
+        case AKR_NODE_SPECTRAL_UPLIFT: case AKR_NODE_SEPARATE_COLOR: case AKR_NODE_EXTRACT: return 1;
+        case AKR_NODE_NORMAL_MAP: return 2;
+        default: throw std::invalid_argument("akr_shader_node: unknown op");
+    }
+}
+// node argument slots that refer to other nodes (the rest are immediates)
+static void node_refs(const akr_shader_node& n, uint32_t out[4], uint32_t& count) {
+    count = 0;
+    uint32_t na = node_n_args(n.op);
+    for (uint32_t a = 0; a < na; a++) {
+        if (n.op == AKR_NODE_IMAGE && a == 0) continue;
+        if (n.arg[a] != AKR_NODE_NONE) out[count++] = n.arg[a];
+    }
+}
+// Splits a material's graph into the inputs that are constant after all (folded into `desc`, the way the reference
+// would evaluate them to the same value at every point) and the texture-fed rest (pruned node list appended to
+// `out.tex_nodes`, input map into `dm`).
+static void compile_graph(const HostGraph& g, uint32_t n_images, akr_material_desc& desc, DMaterial& dm, CompiledScene& out) {
+    const uint32_t n = (uint32_t)g.nodes.size();
+    std::vector<uint8_t> varying(n, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        const akr_shader_node& nd = g.nodes[i];
+        uint32_t refs[4], nr;
+        node_refs(nd, refs, nr);
+        for (uint32_t r = 0; r < nr; r++)
+            if (refs[r] >= i) throw std::invalid_argument("akr_shader_node: arguments must refer to earlier nodes");
+        if (nd.op == AKR_NODE_IMAGE && nd.arg[0] >= n_images) throw std::invalid_argument("akr_shader_node: image index out of range");
+        if (nd.op == AKR_NODE_MAPPING && (nd.arg[0] == AKR_NODE_NONE || nd.arg[1] == AKR_NODE_NONE || nd.arg[2] == AKR_NODE_NONE || nd.arg[3] > 1))
+            throw std::invalid_argument("akr_shader_node: mapping needs vector, location, scale and a mapping type");
+        if (nd.op == AKR_NODE_CHECKERBOARD && (nd.arg[1] == AKR_NODE_NONE || nd.arg[2] == AKR_NODE_NONE || nd.arg[3] == AKR_NODE_NONE))
+            throw std::invalid_argument("akr_shader_node: checkerboard needs scale, color1, color2");
+        if ((nd.op == AKR_NODE_SPECTRAL_UPLIFT || nd.op == AKR_NODE_SEPARATE_COLOR || nd.op == AKR_NODE_EXTRACT) && nd.arg[0] == AKR_NODE_NONE)
+            throw std::invalid_argument("akr_shader_node: missing argument");
+        if (nd.op == AKR_NODE_EXTRACT && nd.arg[1] > AKR_FIELD_UV) throw std::invalid_argument("akr_shader_node: unknown extract field");
+        if (nd.op == AKR_NODE_NORMAL_MAP && (nd.arg[0] == AKR_NODE_NONE || nd.arg[1] == AKR_NODE_NONE))
+            throw std::invalid_argument("akr_shader_node: normal_map needs normal and strength");
+        bool v = nd.op == AKR_NODE_TEXCOORDS || nd.op == AKR_NODE_IMAGE || (nd.op == AKR_NODE_CHECKERBOARD && nd.arg[0] == AKR_NODE_NONE);
+        for (uint32_t r = 0; r < nr; r++) v = v || varying[refs[r]];
+        varying[i] = v;
+    }
+    // constant inputs: evaluate the whole list once (the varying nodes see uv = 0 and are not read)
+    std::vector<TexVal> val(n ? n : 1);
+    TexScene none{reinterpret_cast<const DNode*>(g.nodes.data()), nullptr, nullptr, nullptr};
+    {
+        // images are not available here; constant inputs never read an image node
+        std::vector<akr_shader_node> tmp(g.nodes);
+        for (auto& nd : tmp)
+            if (nd.op == AKR_NODE_IMAGE) nd.op = AKR_NODE_CONST;
+        TexScene ts{reinterpret_cast<const DNode*>(tmp.data()), nullptr, nullptr, nullptr};
+        eval_graph(ts, 0, n, mk2(0, 0), val.data());
+    }
+    (void)none;
+    uint32_t map[AKR_IN_COUNT];
+    bool any_varying = false;
+    MatInputs in;
+    std::memcpy(&in, &desc, sizeof in);
+    {
+        uint32_t cmap[AKR_IN_COUNT];
+        for (uint32_t k = 0; k < AKR_IN_COUNT; k++) {
+            uint32_t node = g.input[k];
+            if (node != AKR_NODE_NONE && node >= n) throw std::invalid_argument("akr_material_graph: input node out of range");
+            bool v = node != AKR_NODE_NONE && varying[node];
+            cmap[k] = (node != AKR_NODE_NONE && !v) ? node : AKR_NODE_NONE;
+            map[k] = v ? node : AKR_NODE_NONE;
+            any_varying = any_varying || v;
+        }
+        apply_inputs(cmap, val.data(), in);
+        std::memcpy(&desc, &in, sizeof in);
+    }
+    dm = fold_material(desc);
+    if (!any_varying) return;
+    // prune: nodes reachable from the varying inputs, in index order
+    std::vector<uint8_t> keep(n, 0);
+    for (uint32_t k = 0; k < AKR_IN_COUNT; k++)
+        if (map[k] != AKR_NODE_NONE) keep[map[k]] = 1;
+    for (uint32_t i = n; i-- > 0;) {
+        if (!keep[i]) continue;
+        uint32_t refs[4], nr;
+        node_refs(g.nodes[i], refs, nr);
+        for (uint32_t r = 0; r < nr; r++) keep[refs[r]] = 1;
+    }
+    std::vector<uint32_t> remap(n, AKR_NODE_NONE);
+    const uint32_t first = (uint32_t)out.tex_nodes.size();
+    uint32_t count = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (!keep[i]) continue;
+        remap[i] = count++;
+        akr_shader_node nd = g.nodes[i];
+        uint32_t na = node_n_args(nd.op);
+        for (uint32_t a = 0; a < na; a++) {
+            if (nd.op == AKR_NODE_IMAGE && a == 0) continue;
+            if (nd.arg[a] != AKR_NODE_NONE) nd.arg[a] = remap[nd.arg[a]];
+        }
+        DNode dn;
+        std::memcpy(&dn, &nd, sizeof dn);
+        out.tex_nodes.push_back(dn);
+    }
+    if (count > kMaxGraphNodes)
+        throw std::invalid_argument("unsupported: shader graph needs more than " + std::to_string(kMaxGraphNodes) + " texture nodes");
+    dm.flags |= MF_TEXTURED;
+    dm.tex_first_node = first;
+    dm.tex_n_nodes = count;
+    for (uint32_t k = 0; k < AKR_IN_COUNT; k++) dm.tex_input[k] = map[k] == AKR_NODE_NONE ? AKR_NODE_NONE : remap[map[k]];
+    out.has_textures = true;
 }
 
 // ------------------------------------------------------------------------------------------------ alias table
@@ -261,12 +341,37 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
     const size_t n_inst = flat.instances.size();
     out = CompiledScene();
     out.materials.reserve(flat.materials.size());
-    for (const auto& m : flat.materials) {
-        DMaterial d = fold_material(m);
-        if ((d.kind == MAT_PRINCIPLED || d.kind == MAT_DIFFUSE) && d.base_alpha < 1.0f) out.has_alpha = true;
-        if (d.kind == MAT_PRINCIPLED && (d.flags & (MF_SPEC | MF_COAT))) out.needs_ggx_table = true;
+    if (!flat.graphs.empty() && flat.graphs.size() != flat.materials.size())
+        throw std::invalid_argument("material graphs: one per material expected");
+    // images: headers + one texel buffer (float4 images 16-byte aligned)
+    for (const HostImage& im : flat.images) {
+        while (im.format == AKR_IMAGE_RGBA32F && (out.texels.size() & 3u)) out.texels.push_back(0u);
+        DImage d{};
+        uint64_t off = out.texels.size();
+        d.offset_lo = (uint32_t)off; d.offset_hi = (uint32_t)(off >> 32);
+        d.width = im.width; d.height = im.height; d.format = im.format; d.filter = im.filter; d.address = im.address;
+        out.images.push_back(d);
+        out.texels.insert(out.texels.end(), im.words.begin(), im.words.end());
+    }
+    std::vector<akr_material_desc> descs(flat.materials);  // constants after folding the constant graph inputs
+    for (size_t mi = 0; mi < flat.materials.size(); mi++) {
+        DMaterial d;
+        if (!flat.graphs.empty() && !flat.graphs[mi].nodes.empty())
+            compile_graph(flat.graphs[mi], (uint32_t)flat.images.size(), descs[mi], d, out);
+        else
+            d = fold_material(descs[mi]);
+        const bool tex = (d.flags & MF_TEXTURED) != 0;
+        if ((d.kind == MAT_PRINCIPLED || d.kind == MAT_DIFFUSE) && (d.base_alpha < 1.0f || (tex && d.tex_input[IN_BASE_COLOR] != kNodeNone)))
+            out.has_alpha = true;
+        // a textured material may switch the specular / coat layers on at any point
+        if (d.kind == MAT_PRINCIPLED && ((d.flags & (MF_SPEC | MF_COAT)) || tex)) out.needs_ggx_table = true;
         out.materials.push_back(d);
     }
+    if (out.has_textures) {
+        out.mat_inputs.resize(descs.size());
+        std::memcpy(out.mat_inputs.data(), descs.data(), descs.size() * sizeof(MatInputs));
+    }
+    const TexScene host_tex{out.tex_nodes.data(), out.images.data(), out.texels.data(), out.mat_inputs.data()};
     // instance table
     std::vector<Xform> xf(n_inst);
     out.inst.assign(32 * n_inst, 0.0f);
@@ -385,7 +490,26 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
             const DMaterial& dm = out.materials[material];
             vec3 e = (dm.kind == MAT_PRINCIPLED || dm.kind == MAT_EMISSION) ? dm.emission : mk3(0, 0, 0);
             float acc = 0.0f;
-            for (int k = 0; k < 16; k++) acc += max3(e) * area;
+            const bool tex_emission = (dm.flags & MF_TEXTURED) && (dm.kind == MAT_PRINCIPLED || dm.kind == MAT_EMISSION) &&
+                                      (dm.tex_input[IN_EMISSION_COLOR] != kNodeNone || dm.tex_input[IN_EMISSION_STRENGTH] != kNodeNone);
+            if (tex_emission) {
+                // the kernel of load.rs:312-343 as is: Pcg32::new_seq(prim), per sample next_2d -> barycentrics,
+                // next_2d -> wo (drawn, unused by the emission of these closures)
+                Pcg32 rng = pcg_new_seq((uint64_t)prim);
+                for (int k = 0; k < 16; k++) {
+                    float u0 = pcg_next_1d(rng), u1 = pcg_next_1d(rng);
+                    vec2 bary = uniform_sample_triangle(mk2(u0, u1));
+                    (void)pcg_next_1d(rng);
+                    (void)pcg_next_1d(rng);
+                    float w = 1.0f - bary.x - bary.y;
+                    vec2 uv = mk2((uv0.x * w + uv1.x * bary.x) + uv2.x * bary.y, (uv0.y * w + uv1.y * bary.x) + uv2.y * bary.y);
+                    DMaterial at = dm;
+                    material_at(host_tex, material, uv, at);
+                    acc += max3(at.emission) * area;
+                }
+            } else {
+                for (int k = 0; k < 16; k++) acc += max3(e) * area;
+            }
             tri_power[gid] = acc / 16.0f;
         }
     }
@@ -395,8 +519,13 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
         const HostInstance& in = flat.instances[i];
         bool any = false;  // has_potential_surface_emission, load.rs:94-127
         for (uint32_t mi : in.materials) {
-            const akr_material_desc& m = flat.materials[mi];
+            const akr_material_desc& m = descs[mi];
             if (m.kind != AKR_MAT_PRINCIPLED && m.kind != AKR_MAT_EMISSION) { any = true; continue; }
+            const DMaterial& dm = out.materials[mi];
+            if ((dm.flags & MF_TEXTURED) && (dm.tex_input[IN_EMISSION_COLOR] != kNodeNone || dm.tex_input[IN_EMISSION_STRENGTH] != kNodeNone)) {
+                any = true;  // estimate_emission_tex_intensity_fast gives None for texture nodes (load.rs:76-92)
+                continue;
+            }
             float power = max_f(max_f(m.emission_color[0], m.emission_color[1]), m.emission_color[2]);
             if (!(power * m.emission_strength == 0.0f)) any = true;
         }

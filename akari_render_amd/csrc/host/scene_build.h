@@ -25,6 +25,15 @@ struct HostInstance {
     std::vector<uint32_t> materials;
     float transform[16];
 };
+struct HostImage {
+    uint32_t width = 0, height = 0, format = 0, filter = 0, address = 0;
+    std::vector<uint32_t> words;  // RGBA8: one word per texel; RGBA32F: four
+};
+struct HostGraph {
+    std::vector<akr_shader_node> nodes;  // empty = constant material
+    uint32_t input[AKR_IN_COUNT];
+    HostGraph() { for (uint32_t& i : input) i = AKR_NODE_NONE; }
+};
 // Owning copy of an akr_scene_desc.
 struct FlatScene {
     std::vector<HostMesh> meshes;
@@ -32,6 +41,8 @@ struct FlatScene {
     std::vector<akr_material_desc> materials;
     akr_camera_desc camera;
     std::vector<float> ggx_table;  // 4096 or empty
+    std::vector<HostImage> images;
+    std::vector<HostGraph> graphs;  // empty, or one per material
     static FlatScene from_desc(const akr_scene_desc& d);
 };
 
@@ -53,6 +64,12 @@ struct CompiledScene {
     std::vector<float> area_pdf;
     // BVH4 nodes (16 words = 64 B each, host/bvh.cpp) or empty for the exhaustive path
     std::vector<float> bvh_nodes;
+    // textures: pruned node lists of the materials with texture-fed inputs, image headers, texel words, raw inputs
+    std::vector<DNode> tex_nodes;
+    std::vector<DImage> images;
+    std::vector<uint32_t> texels;
+    std::vector<MatInputs> mat_inputs;   // one per material when any material is textured, else empty
+    bool has_textures = false;
     bool has_alpha = false;
     bool needs_ggx_table = false;
     float scene_lo[3], scene_hi[3];
@@ -76,5 +93,7 @@ struct ParsedTask {
 std::vector<ParsedTask> parse_render_tasks(const std::string& text, bool allow_sampler_override);
 // image writers (host/image_io.cpp)
 void write_image(const std::string& path, const float* rgb, uint32_t w, uint32_t h);
+// PNG -> RGBA8 in file order (image crate `decode().to_rgba8()` conventions); throws std::runtime_error
+void decode_png(const uint8_t* data, size_t n, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba);
 
 }  // namespace akr

@@ -209,50 +209,185 @@ void fold_color(const JsonValue& nodes, const JsonValue& ref, float* rgb, float*
     if (alpha) *alpha = c.n == 4 ? c.v[3] : 1.0f;
 }
 
-akr_material_desc fold_shader(const JsonValue& shader) {
+// true when the node evaluates to the same value everywhere and fold_const can do it
+bool is_const_tree(const JsonValue& nodes, const JsonValue& ref) {
+    const JsonValue& n = nodes.at(ref.at("id").as_string());
+    const std::string& ty = n.at("type").as_string();
+    if (ty == "float" || ty == "float3" || ty == "rgb") return true;
+    if (ty == "spectral_uplift") return is_const_tree(nodes, n.at("rgb"));
+    return false;
+}
+
+// Translates the non-constant part of a shader graph into akr_shader_node lists and registers its images.
+struct GraphBuilder {
+    const JsonValue& nodes;
+    BufferStore& bufs;
+    FlatScene& flat;
+    std::map<std::string, uint32_t>& image_index;  // (buffer view + sampler) key -> image
+    HostGraph graph;
+    std::map<std::string, uint32_t> memo;
+
+    uint32_t push(uint32_t op, uint32_t a0 = AKR_NODE_NONE, uint32_t a1 = AKR_NODE_NONE, uint32_t a2 = AKR_NODE_NONE, uint32_t a3 = AKR_NODE_NONE,
+                  float k0 = 0.0f, float k1 = 0.0f, float k2 = 0.0f) {
+        akr_shader_node nd;
+        nd.op = op;
+        nd.arg[0] = a0; nd.arg[1] = a1; nd.arg[2] = a2; nd.arg[3] = a3;
+        nd.k[0] = k0; nd.k[1] = k1; nd.k[2] = k2;
+        graph.nodes.push_back(nd);
+        return (uint32_t)graph.nodes.size() - 1;
+    }
+    uint32_t image(const JsonValue& im) {  // load.rs:477-489, 543-611
+        const std::string view = im.at("data").at("id").as_string();
+        const std::string fmt = im.at("format").as_string(), ext = im.at("extension").as_string(), interp = im.at("interpolation").as_string();
+        const uint32_t w = (uint32_t)im.at("width").as_number(), h = (uint32_t)im.at("height").as_number(), ch = (uint32_t)im.at("channels").as_number();
+        const std::string key = view + "|" + fmt + "|" + ext + "|" + interp + "|" + std::to_string(w) + "x" + std::to_string(h) + "x" + std::to_string(ch);
+        auto it = image_index.find(key);
+        if (it != image_index.end()) return it->second;
+        HostImage hi;
+        hi.address = ext == "repeat" ? AKR_TEX_REPEAT : ext == "clip" ? AKR_TEX_CLIP : ext == "mirror" ? AKR_TEX_MIRROR : ext == "extend" ? AKR_TEX_EXTEND : 99u;
+        if (hi.address == 99u) throw std::runtime_error("unknown image extension '" + ext + "'");
+        if (interp == "linear" || interp == "cubic") hi.filter = AKR_TEX_FILTER_LINEAR;  // load.rs:690-699
+        else if (interp == "nearest") hi.filter = AKR_TEX_FILTER_NEAREST;
+        else throw std::runtime_error("unknown image interpolation '" + interp + "'");
+        std::vector<uint8_t> bytes = bufs.view<uint8_t>(im.at("data"));
+        if (fmt == "float") {
+            if (ch == 0 || ch > 4) throw std::runtime_error("image: invalid number of channels");
+            if (bytes.size() != (size_t)w * h * ch * 4) throw std::runtime_error("float image: buffer size does not match width * height * channels");
+            hi.width = w; hi.height = h; hi.format = AKR_IMAGE_RGBA32F;
+            hi.words.resize(4ull * w * h);
+            const uint32_t one = 0x3f800000u;
+            for (size_t t = 0; t < (size_t)w * h; t++)
+                for (uint32_t c = 0; c < 4; c++) {
+                    uint32_t v = c == 3 ? one : 0u;
+                    if (c < ch) std::memcpy(&v, bytes.data() + 4 * (t * ch + c), 4);
+                    hi.words[4 * t + c] = v;
+                }
+        } else if (fmt == "png") {
+            uint32_t pw = 0, ph = 0;
+            std::vector<uint8_t> px;
+            decode_png(bytes.data(), bytes.size(), pw, ph, px);
+            hi.width = pw; hi.height = ph; hi.format = AKR_IMAGE_RGBA8;
+            hi.words.resize((size_t)pw * ph);
+            for (uint32_t y = 0; y < ph; y++)  // flipv (load.rs:596): row 0 of the texture is the bottom row of the file
+                std::memcpy(hi.words.data() + (size_t)y * pw, px.data() + 4ull * pw * (ph - 1 - y), 4ull * pw);
+        } else {
+            throw std::runtime_error("unsupported: image format '" + fmt + "' (decode it on the host and pass texels through akr_image_desc; float and png are read here)");
+        }
+        uint32_t idx = (uint32_t)flat.images.size();
+        flat.images.push_back(std::move(hi));
+        image_index[key] = idx;
+        return idx;
+    }
+    uint32_t emit(const JsonValue& ref) {
+        const std::string& id = ref.at("id").as_string();
+        auto it = memo.find(id);
+        if (it != memo.end()) return it->second;
+        const JsonValue& n = nodes.at(id);
+        const std::string& ty = n.at("type").as_string();
+        uint32_t r;
+        if (ty == "float") {
+            r = push(AKR_NODE_CONST, AKR_NODE_NONE, AKR_NODE_NONE, AKR_NODE_NONE, AKR_NODE_NONE, n.at("value").as_f32());
+        } else if (ty == "float3") {
+            r = push(AKR_NODE_CONST, AKR_NODE_NONE, AKR_NODE_NONE, AKR_NODE_NONE, AKR_NODE_NONE, n.at("value").at(0).as_f32(), n.at("value").at(1).as_f32(),
+                     n.at("value").at(2).as_f32());
+        } else if (ty == "rgb") {
+            const std::string cs = n.has("colorspace") ? n.at("colorspace").as_string() : std::string("srgb");
+            if (cs != "srgb") throw std::runtime_error("unsupported: constant colour in colour space '" + cs + "'");
+            r = push(AKR_NODE_RGB, AKR_NODE_NONE, AKR_NODE_NONE, AKR_NODE_NONE, AKR_NODE_NONE, n.at("value").at(0).as_f32(), n.at("value").at(1).as_f32(),
+                     n.at("value").at(2).as_f32());
+        } else if (ty == "spectral_uplift") {
+            r = push(AKR_NODE_SPECTRAL_UPLIFT, emit(n.at("rgb")));
+        } else if (ty == "texcoords") {
+            r = push(AKR_NODE_TEXCOORDS);
+        } else if (ty == "image") {
+            const JsonValue& im = n.at("image");
+            uint32_t uv = (n.has("uv") && !n.at("uv").is_null()) ? emit(n.at("uv")) : AKR_NODE_NONE;
+            const std::string cs = im.at("colorspace").as_string();
+            if (cs != "srgb" && cs != "none") throw std::runtime_error("unsupported: image colour space '" + cs + "'");
+            r = push(AKR_NODE_IMAGE, image(im), uv, cs == "srgb" ? 1u : 0u);
+        } else if (ty == "mapping") {
+            const std::string& mt = n.at("mapping").as_string();
+            if (mt != "point" && mt != "texture") throw std::runtime_error("unknown mapping type '" + mt + "'");
+            uint32_t v = emit(n.at("vector")), loc = emit(n.at("location")), sc = emit(n.at("scale"));
+            r = push(AKR_NODE_MAPPING, v, loc, sc, mt == "point" ? AKR_MAPPING_POINT : AKR_MAPPING_TEXTURE);
+        } else if (ty == "checkerboard") {
+            uint32_t v = (n.has("vector") && !n.at("vector").is_null()) ? emit(n.at("vector")) : AKR_NODE_NONE;
+            uint32_t sc = emit(n.at("scale")), c1 = emit(n.at("color1")), c2 = emit(n.at("color2"));
+            r = push(AKR_NODE_CHECKERBOARD, v, sc, c1, c2);
+        } else if (ty == "normal_map") {
+            if (n.at("space").as_string() != "tangent") throw std::runtime_error("unsupported: only tangent space normal maps (svm/eval.rs:185-189)");
+            uint32_t nn = emit(n.at("normal")), st = emit(n.at("strength"));
+            r = push(AKR_NODE_NORMAL_MAP, nn, st);
+        } else if (ty == "separate_color") {
+            if (n.at("mode").as_string() != "rgb") throw std::runtime_error("unknown separate_color mode");
+            r = push(AKR_NODE_SEPARATE_COLOR, emit(n.at("color")));
+        } else if (ty == "extract") {
+            const std::string& f = n.at("field").as_string();
+            uint32_t field = f == "Red" ? AKR_FIELD_RED : f == "Green" ? AKR_FIELD_GREEN : f == "Blue" ? AKR_FIELD_BLUE : (f == "uv" || f == "UV") ? AKR_FIELD_UV : 99u;
+            if (field == 99u) throw std::runtime_error("unsupported: extract field '" + f + "'");
+            r = push(AKR_NODE_EXTRACT, emit(n.at("node")), field);
+        } else {
+            throw std::runtime_error("unsupported: shader node '" + ty + "'");
+        }
+        memo[id] = r;
+        return r;
+    }
+};
+
+void load_shader(const JsonValue& shader, BufferStore& bufs, FlatScene& flat, std::map<std::string, uint32_t>& image_index, akr_material_desc& m,
+                 HostGraph& graph_out) {
     const JsonValue& nodes = shader.at("nodes");
     const JsonValue& out = nodes.at(shader.at("output").at("id").as_string());
     if (out.at("type").as_string() != "output") throw std::runtime_error("shader graph output is not an output node");
     const JsonValue& n = nodes.at(out.at("node").at("id").as_string());
     const std::string& ty = n.at("type").as_string();
-    akr_material_desc m;
     std::memset(&m, 0, sizeof m);
     m.base_alpha = 1.0f;
     m.ior = 1.0f;
     for (int i = 0; i < 3; i++) m.specular_tint[i] = m.coat_tint[i] = 1.0f;
     m.specular_ior_level = 0.5f;
+    GraphBuilder gb{nodes, bufs, flat, image_index, HostGraph(), {}};
+    // constant inputs are folded here (svm/eval.rs:97-135), everything else becomes graph nodes
+    auto color = [&](const char* key, uint32_t input, float* rgb, float* alpha) {
+        if (is_const_tree(nodes, n.at(key))) fold_color(nodes, n.at(key), rgb, alpha);
+        else gb.graph.input[input] = gb.emit(n.at(key));
+    };
+    auto scalar = [&](const char* key, uint32_t input, float* v) {
+        if (is_const_tree(nodes, n.at(key))) *v = fold_float(nodes, n.at(key));
+        else gb.graph.input[input] = gb.emit(n.at(key));
+    };
     if (ty == "principled") {
         m.kind = AKR_MAT_PRINCIPLED;
-        fold_color(nodes, n.at("base_color"), m.base_color, &m.base_alpha);
-        m.metallic = fold_float(nodes, n.at("metallic"));
-        m.roughness = fold_float(nodes, n.at("roughness"));
-        m.ior = fold_float(nodes, n.at("ior"));
-        m.specular_ior_level = fold_float(nodes, n.at("specular_ior_level"));
-        fold_color(nodes, n.at("specular_tint"), m.specular_tint, nullptr);
-        m.transmission_weight = fold_float(nodes, n.at("transmission_weight"));
-        m.coat_weight = fold_float(nodes, n.at("coat_weight"));
-        m.coat_roughness = fold_float(nodes, n.at("coat_roughness"));
-        m.coat_ior = fold_float(nodes, n.at("coat_ior"));
-        fold_color(nodes, n.at("coat_tint"), m.coat_tint, nullptr);
-        fold_color(nodes, n.at("emission_color"), m.emission_color, nullptr);
-        m.emission_strength = fold_float(nodes, n.at("emission_strength"));
-        fold_color(nodes, n.at("normal"), m.normal, nullptr);
+        color("base_color", AKR_IN_BASE_COLOR, m.base_color, &m.base_alpha);
+        scalar("metallic", AKR_IN_METALLIC, &m.metallic);
+        scalar("roughness", AKR_IN_ROUGHNESS, &m.roughness);
+        scalar("ior", AKR_IN_IOR, &m.ior);
+        scalar("specular_ior_level", AKR_IN_SPECULAR_IOR_LEVEL, &m.specular_ior_level);
+        color("specular_tint", AKR_IN_SPECULAR_TINT, m.specular_tint, nullptr);
+        scalar("transmission_weight", AKR_IN_TRANSMISSION_WEIGHT, &m.transmission_weight);
+        scalar("coat_weight", AKR_IN_COAT_WEIGHT, &m.coat_weight);
+        scalar("coat_roughness", AKR_IN_COAT_ROUGHNESS, &m.coat_roughness);
+        scalar("coat_ior", AKR_IN_COAT_IOR, &m.coat_ior);
+        color("coat_tint", AKR_IN_COAT_TINT, m.coat_tint, nullptr);
+        color("emission_color", AKR_IN_EMISSION_COLOR, m.emission_color, nullptr);
+        scalar("emission_strength", AKR_IN_EMISSION_STRENGTH, &m.emission_strength);
+        color("normal", AKR_IN_NORMAL, m.normal, nullptr);
     } else if (ty == "diffuse") {
         m.kind = AKR_MAT_DIFFUSE;
-        fold_color(nodes, n.at("color"), m.base_color, &m.base_alpha);
+        color("color", AKR_IN_BASE_COLOR, m.base_color, &m.base_alpha);
     } else if (ty == "glass") {
         m.kind = AKR_MAT_GLASS;
-        fold_color(nodes, n.at("color"), m.base_color, nullptr);
-        m.ior = fold_float(nodes, n.at("ior"));
-        m.roughness = fold_float(nodes, n.at("roughness"));
+        color("color", AKR_IN_BASE_COLOR, m.base_color, nullptr);
+        scalar("ior", AKR_IN_IOR, &m.ior);
+        scalar("roughness", AKR_IN_ROUGHNESS, &m.roughness);
     } else if (ty == "emission") {
         m.kind = AKR_MAT_EMISSION;
-        fold_color(nodes, n.at("color"), m.emission_color, nullptr);
-        m.emission_strength = fold_float(nodes, n.at("strength"));
+        color("color", AKR_IN_EMISSION_COLOR, m.emission_color, nullptr);
+        scalar("strength", AKR_IN_EMISSION_STRENGTH, &m.emission_strength);
     } else {
         throw std::runtime_error("unsupported: surface shader '" + ty + "'");
     }
-    return m;
+    graph_out = std::move(gb.graph);
 }
 
 }  // namespace
@@ -286,14 +421,23 @@ FlatScene load_scene_json(const std::string& path) {
         geom_index[kv.first] = (uint32_t)flat.meshes.size();
         flat.meshes.push_back(std::move(m));
     }
+    std::map<std::string, uint32_t> image_index;
+    bool any_graph = false;
+    std::vector<HostGraph> graphs;
     for (const auto& kv : scene.at("materials").obj) {
         mat_index[kv.first] = (uint32_t)flat.materials.size();
         try {
-            flat.materials.push_back(fold_shader(kv.second->at("shader")));
+            akr_material_desc m;
+            HostGraph g;
+            load_shader(kv.second->at("shader"), bufs, flat, image_index, m, g);
+            flat.materials.push_back(m);
+            any_graph = any_graph || !g.nodes.empty();
+            graphs.push_back(std::move(g));
         } catch (const std::exception& e) {
             throw std::runtime_error("material '" + kv.first + "': " + e.what());
         }
     }
+    if (any_graph) flat.graphs = std::move(graphs);
     for (const auto& kv : scene.at("instances").obj) {
         const JsonValue& in = *kv.second;
         HostInstance h;

@@ -54,6 +54,7 @@ hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream);
 hipError_t launch_wf_init(const PtParams& p, const WfBuffers& wf, hipStream_t stream);
 hipError_t launch_wf_shade(const PtParams& p, const WfBuffers& wf, uint32_t q_out, hipStream_t stream);
 hipError_t launch_wf_trace(const PtParams& p, const WfBuffers& wf, uint32_t q_in, uint32_t n_blocks, hipStream_t stream);
+hipError_t launch_probe_material(const PtParams& p, uint32_t material, uint32_t n, const float* uv, uint32_t* out, hipStream_t stream);
 hipError_t launch_init_pcg32(const uint64_t* seeds, void* states, uint64_t n, hipStream_t stream);
 hipError_t launch_film_resolve(const float* film, uint64_t n, float* rgb, hipStream_t stream);
 hipError_t launch_ggx_table(const uint64_t* seeds, float* table, uint32_t samples, hipStream_t stream);

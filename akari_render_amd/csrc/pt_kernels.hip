@@ -24,7 +24,7 @@ namespace akr {
 #ifndef AKR_PT_MIN_WAVES_FD
 #define AKR_PT_MIN_WAVES_FD 4  // force_diffuse specialisation of the exhaustive kernel
 #endif
-template <bool BVH, bool FD>
+template <bool BVH, bool FD, bool TEX>
 __global__ __launch_bounds__(256, BVH ? AKR_PT_MIN_WAVES_BVH : (FD ? AKR_PT_MIN_WAVES_FD : AKR_PT_MIN_WAVES)) void k_pt_pass(const PtParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: kBvhStackDepth x 256 words
     TraceCtx tc;
@@ -48,16 +48,16 @@ __global__ __launch_bounds__(256, BVH ? AKR_PT_MIN_WAVES_BVH : (FD ? AKR_PT_MIN_
             r.c_closest += r.has_ray ? 1u : 0u;
             r.c_shadow += r.has_shadow ? 1u : 0u;
             if (BVH) {
-                if (r.has_ray) found = trace_bvh4<false>(sc, r.ro, r.rd, 0.0f, 1e20f, r.ray_ex0, kInvalid, hit, tc.stack, tc.cnt);
+                if (r.has_ray) found = trace_bvh4<false, TEX>(sc, r.ro, r.rd, 0.0f, 1e20f, r.ray_ex0, kInvalid, hit, tc.stack, tc.cnt);
                 if (r.has_shadow) {
                     Hit sh;
-                    occluded = trace_bvh4<true>(sc, r.s_o, r.s_d, 0.0f, r.s_tmax, r.s_ex0, r.s_ex1, sh, tc.stack, tc.cnt);
+                    occluded = trace_bvh4<true, TEX>(sc, r.s_o, r.s_d, 0.0f, r.s_tmax, r.s_ex0, r.s_ex1, sh, tc.stack, tc.cnt);
                 }
             } else {
-                trace_pair_exhaustive(sc, r.ro, r.rd, r.has_ray ? 1e20f : -1.0f, r.ray_ex0, r.s_o, r.s_d, r.has_shadow ? r.s_tmax : -1.0f,
+                trace_pair_exhaustive<TEX>(sc, r.ro, r.rd, r.has_ray ? 1e20f : -1.0f, r.ray_ex0, r.s_o, r.s_d, r.has_shadow ? r.s_tmax : -1.0f,
                                       r.s_ex0, r.s_ex1, hit, found, occluded);
             }
-            path_step<FD ? 1 : 0>(p, r, hit, found, occluded, pix, sx, sy);
+            path_step<FD ? 1 : 0, TEX>(p, r, hit, found, occluded, pix, sx, sy);
         }
     }
     flush_counters(p, r, tc.cnt, BVH);
@@ -190,18 +190,41 @@ __global__ void k_probe_si(PtParams p, uint32_t n, const uint32_t* __restrict__ 
     o[18] = (float)s.material;
 }
 
+// evaluated inputs (26 words = akr_material_desc) of `material` at n uv points
+__global__ void k_probe_material(PtParams p, uint32_t material, uint32_t n, const float* __restrict__ uv, uint32_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DMaterial& m = p.sc.materials[material];
+    MatInputs in = p.sc.tex.mat_inputs[material];
+    if (m.flags & MF_TEXTURED) {
+        TexVal val[kMaxGraphNodes];
+        eval_graph(p.sc.tex, m.tex_first_node, m.tex_n_nodes, mk2(uv[2 * i], uv[2 * i + 1]), val);
+        apply_inputs(m.tex_input, val, in);
+    }
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(&in);
+    for (uint32_t k = 0; k < 26; k++) out[26 * (size_t)i + k] = w[k];
+}
+
 // ---------------------------------------------------------------------------------------------------- launchers
+hipError_t launch_probe_material(const PtParams& p, uint32_t material, uint32_t n, const float* uv, uint32_t* out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_probe_material, dim3((n + 127) / 128), dim3(128), 0, stream, p, material, n, uv, out);
+    return hipGetLastError();
+}
 hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream) {
     uint32_t blocks = (p.n_items + 255u) / 256u;
     if (blocks == 0) return hipSuccess;
-    const bool fd = p.force_diffuse != 0;
-    if (p.sc.bvh_nodes != nullptr) {
-        if (fd) hipLaunchKernelGGL((k_pt_pass<true, true>), dim3(blocks), dim3(256), kBvhStackDepth * 256 * 4, stream, p);
-        else hipLaunchKernelGGL((k_pt_pass<true, false>), dim3(blocks), dim3(256), kBvhStackDepth * 256 * 4, stream, p);
+    const bool fd = p.force_diffuse != 0, tex = p.sc.tex.nodes != nullptr;
+    const bool bvh = p.sc.bvh_nodes != nullptr;
+    const size_t lds = bvh ? kBvhStackDepth * 256 * 4 : 0;
+#define AKR_LAUNCH(B, F, T) hipLaunchKernelGGL((k_pt_pass<B, F, T>), dim3(blocks), dim3(256), lds, stream, p)
+    if (bvh) {
+        if (tex) { if (fd) AKR_LAUNCH(true, true, true); else AKR_LAUNCH(true, false, true); }
+        else { if (fd) AKR_LAUNCH(true, true, false); else AKR_LAUNCH(true, false, false); }
     } else {
-        if (fd) hipLaunchKernelGGL((k_pt_pass<false, true>), dim3(blocks), dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((k_pt_pass<false, false>), dim3(blocks), dim3(256), 0, stream, p);
+        if (tex) { if (fd) AKR_LAUNCH(false, true, true); else AKR_LAUNCH(false, false, true); }
+        else { if (fd) AKR_LAUNCH(false, true, false); else AKR_LAUNCH(false, false, false); }
     }
+#undef AKR_LAUNCH
     return hipGetLastError();
 }
 hipError_t launch_init_pcg32(const uint64_t* seeds, void* states, uint64_t n, hipStream_t stream) {

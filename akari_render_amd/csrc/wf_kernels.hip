@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256) void k_wf_init(const PtParams p, const WfBuffe
     flush_counters(p, r, TraceCounters{0, 0, 0}, true);
 }
 
+template <bool TEX>
 __global__ __launch_bounds__(256) void k_wf_shade(const PtParams p, const WfBuffers wf, uint32_t q_out) {
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     PathRegs r;
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(const PtParams p, const WfBuff
         Hit hit;
         hit.gid = f2u(hv.x); hit.u = hv.y; hit.v = hv.z; hit.t = 0.0f;
         bool found = hit.gid != kInvalid, occluded = f2u(hv.w) != 0;
-        path_step(p, r, hit, found, occluded, pix, sx, sy);
+        path_step<-1, TEX>(p, r, hit, found, occluded, pix, sx, sy);
         wf_store(wf, slot, r);
     }
     wf_enqueue(wf, q_out, slot, r);
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(const PtParams p, const WfBuff
 #ifndef AKR_WF_REFILL_IDLE
 #define AKR_WF_REFILL_IDLE 20  // refill when at least this many of the 64 lanes are idle
 #endif
+template <bool TEX>
 __global__ __launch_bounds__(256) void k_wf_trace(const PtParams p, const WfBuffers wf, uint32_t q_in) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     uint32_t* stack = lds_stack + threadIdx.x;
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256) void k_wf_trace(const PtParams p, const WfBuff
                     if (h) {
                         uint32_t gid = sc.tri_gid[k];
                         h = (gid != e0) & (gid != e1);
-                        if (h && sc.has_alpha) h = alpha_test(sc, gid, u, v);
+                        if (h && sc.has_alpha) h = alpha_test<TEX>(sc, gid, u, v);
                         if (h) {
                             if (any) {
                                 best = gid;
@@ -265,11 +267,13 @@ hipError_t launch_wf_init(const PtParams& p, const WfBuffers& wf, hipStream_t st
 hipError_t launch_wf_shade(const PtParams& p, const WfBuffers& wf, uint32_t q_out, hipStream_t stream) {
     uint32_t blocks = (p.n_items + 255u) / 256u;
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_wf_shade, dim3(blocks), dim3(256), 0, stream, p, wf, q_out);
+    if (p.sc.tex.nodes != nullptr) hipLaunchKernelGGL(k_wf_shade<true>, dim3(blocks), dim3(256), 0, stream, p, wf, q_out);
+    else hipLaunchKernelGGL(k_wf_shade<false>, dim3(blocks), dim3(256), 0, stream, p, wf, q_out);
     return hipGetLastError();
 }
 hipError_t launch_wf_trace(const PtParams& p, const WfBuffers& wf, uint32_t q_in, uint32_t n_blocks, hipStream_t stream) {
-    hipLaunchKernelGGL(k_wf_trace, dim3(n_blocks), dim3(256), kBvhStackDepth * 256 * 4, stream, p, wf, q_in);
+    if (p.sc.tex.nodes != nullptr) hipLaunchKernelGGL(k_wf_trace<true>, dim3(n_blocks), dim3(256), kBvhStackDepth * 256 * 4, stream, p, wf, q_in);
+    else hipLaunchKernelGGL(k_wf_trace<false>, dim3(n_blocks), dim3(256), kBvhStackDepth * 256 * 4, stream, p, wf, q_in);
     return hipGetLastError();
 }
 

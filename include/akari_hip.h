@@ -95,6 +95,62 @@ typedef struct {
     float normal[3];
 } akr_material_desc;
 
+/* ---- Shader graphs with non-constant inputs (textures) -------------------------------------------------------
+ * A material whose inputs are all constants is fully described by akr_material_desc. When an input of the surface
+ * node is fed by a texture expression, the material additionally carries its node list (the reference's compiled
+ * bytecode, svm/compiler.rs:116-337: one entry per node in topological order, arguments refer to EARLIER entries)
+ * and, per input of the surface node, the index of the node that feeds it (AKR_NODE_NONE = use the constant in
+ * akr_material_desc). Every node value is a float4; narrower values are zero-extended, so the reference's
+ * eval_float*_auto_convert rules (svm/eval.rs:301-349) are plain .x / .xy / .xyz reads. */
+#define AKR_NODE_NONE 0xffffffffu
+typedef enum {
+    AKR_NODE_CONST = 0,          /* Float / Float3: (k0,k1,k2,0)                           eval.rs:109-116 */
+    AKR_NODE_RGB = 1,            /* Rgb (colorspace srgb): (k0,k1,k2,1)                    eval.rs:123-133 */
+    AKR_NODE_TEXCOORDS = 2,      /* si.uv: (u,v,0,0)                                       eval.rs:219-226 */
+    AKR_NODE_IMAGE = 3,          /* arg0 image, arg1 uv node | NONE, arg2 1 = sRGB decode  eval.rs:134-154 */
+    AKR_NODE_MAPPING = 4,        /* arg0 vector, arg1 location, arg2 scale, arg3 akr_mapping_type (rotation is
+                                    ignored by the reference)                              eval.rs:192-207 */
+    AKR_NODE_CHECKERBOARD = 5,   /* arg0 vector | NONE, arg1 scale, arg2 color1, arg3 color2   eval.rs:227-240 */
+    AKR_NODE_SPECTRAL_UPLIFT = 6,/* arg0 rgb: identity in the RGB/sRGB pipeline            eval.rs:155-175 */
+    AKR_NODE_SEPARATE_COLOR = 7, /* arg0 colour (carries the value for AKR_NODE_EXTRACT)   eval.rs:241-256 */
+    AKR_NODE_EXTRACT = 8,        /* arg0 node, arg1 akr_extract_field                      eval.rs:208-218 */
+    AKR_NODE_NORMAL_MAP = 9      /* arg0 normal, arg1 strength (tangent space)             eval.rs:176-191 */
+} akr_node_op;
+typedef enum { AKR_MAPPING_POINT = 0, AKR_MAPPING_TEXTURE = 1 } akr_mapping_type;
+typedef enum { AKR_FIELD_RED = 0, AKR_FIELD_GREEN = 1, AKR_FIELD_BLUE = 2, AKR_FIELD_UV = 3 } akr_extract_field;
+typedef struct {
+    uint32_t op;
+    uint32_t arg[4];
+    float k[3];
+} akr_shader_node;   /* 32 bytes */
+
+/* Inputs of the surface node a texture expression may feed (order of akr_material_graph.input). Diffuse / Glass /
+ * Emission use BASE_COLOR for `color`; Glass ROUGHNESS, IOR; Emission EMISSION_STRENGTH for `strength` and
+ * EMISSION_COLOR for `color`. */
+typedef enum {
+    AKR_IN_BASE_COLOR = 0, AKR_IN_METALLIC, AKR_IN_ROUGHNESS, AKR_IN_IOR, AKR_IN_SPECULAR_IOR_LEVEL, AKR_IN_SPECULAR_TINT,
+    AKR_IN_TRANSMISSION_WEIGHT, AKR_IN_COAT_WEIGHT, AKR_IN_COAT_ROUGHNESS, AKR_IN_COAT_IOR, AKR_IN_COAT_TINT,
+    AKR_IN_EMISSION_COLOR, AKR_IN_EMISSION_STRENGTH, AKR_IN_NORMAL, AKR_IN_COUNT
+} akr_material_input;
+typedef struct {
+    uint32_t n_nodes;                 /* 0 = constant material */
+    uint32_t _pad;
+    const akr_shader_node *nodes;
+    uint32_t input[AKR_IN_COUNT];     /* node index or AKR_NODE_NONE */
+} akr_material_graph;
+
+/* One (texture, sampler) pair of the reference's bindless heap (load.rs:477-489,680-702): texels are what ends up in
+ * the Tex2d -- row 0 is v = 0 (encoded images are flipped vertically on load, load.rs:596; raw float images are not),
+ * always 4 channels (load.rs:552-569). */
+typedef enum { AKR_IMAGE_RGBA8 = 0 /* PixelStorage::Byte4 */, AKR_IMAGE_RGBA32F = 1 /* PixelStorage::Float4 */ } akr_image_format;
+typedef enum { AKR_TEX_FILTER_NEAREST = 0, AKR_TEX_FILTER_LINEAR = 1 } akr_tex_filter;       /* load.rs:690-699 */
+typedef enum { AKR_TEX_REPEAT = 0, AKR_TEX_CLIP = 1 /* zero */, AKR_TEX_MIRROR = 2, AKR_TEX_EXTEND = 3 /* edge */ } akr_tex_address;
+typedef struct {
+    uint32_t width, height;
+    uint32_t format, filter, address, _pad;
+    const void *texels;               /* 4 * width * height bytes (RGBA8) or floats (RGBA32F) */
+} akr_image_desc;
+
 /* PerspectiveCamera (camera/mod.rs:15-66): only the fields generate_ray uses. */
 typedef struct {
     float c2w[16];           /* column-major camera->world */
@@ -111,6 +167,10 @@ typedef struct {
     /* Optional 16x16x16 f32 "ggx_dielectric_s" table (svm/surface/precompute.rs:133-145). NULL = the
      * library computes it on the GPU the first time a material needs it (same definition, 2^20 samples). */
     const float *ggx_dielectric_table;
+    /* Textures (optional): n_images = 0 and material_graphs = NULL for scenes with constant materials. */
+    uint32_t n_images, _pad2;
+    const akr_image_desc *images;
+    const akr_material_graph *material_graphs;   /* n_materials entries, or NULL */
 } akr_scene_desc;
 
 /* ---------------------------------------------------------------------------------------------------
@@ -201,6 +261,9 @@ AKR_API int32_t akr_scene_get_mesh(const akr_scene *scene, uint32_t mesh, akr_me
 AKR_API int32_t akr_scene_get_instance(const akr_scene *scene, uint32_t instance, akr_instance_desc *out);
 AKR_API int32_t akr_scene_get_material(const akr_scene *scene, uint32_t material, akr_material_desc *out);
 AKR_API int32_t akr_scene_get_camera(const akr_scene *scene, akr_camera_desc *out);
+AKR_API int32_t akr_scene_get_image_count(const akr_scene *scene, uint32_t *n_images);
+AKR_API int32_t akr_scene_get_image(const akr_scene *scene, uint32_t image, akr_image_desc *out /* texels owned by scene */);
+AKR_API int32_t akr_scene_get_material_graph(const akr_scene *scene, uint32_t material, akr_material_graph *out /* nodes owned by scene */);
 /* Read-only views of the compiled, device-ready arrays (owned by the scene): see akari_render_amd/csrc/device/dscene.h
  * for the record layouts. */
 typedef enum {
@@ -319,6 +382,12 @@ AKR_API int32_t akr_probe_bsdf(akr_context *ctx, const akr_material_desc *m, con
 AKR_API int32_t akr_probe_intersect(akr_context *ctx, akr_scene *scene, uint32_t n, const float *rays, uint32_t *hit_inst_prim,
                                     float *bary);
 /* SurfaceInteraction of (inst, prim, u, v): out 19 floats / item = p, ng, n, t, s, uv, area, material. */
+/* The PNG reader of akr_scene_load (8/16-bit, all colour types, tRNS, no interlacing), image crate `to_rgba8` rules
+ * (load.rs:583-604). Rows in file order. rgba == NULL: only the size is returned. */
+AKR_API int32_t akr_host_decode_png(const uint8_t *data, uint64_t len, uint32_t *width, uint32_t *height, uint8_t *rgba, uint64_t capacity);
+/* Evaluated inputs of `material` (26 words each = akr_material_desc) at n uv points: shader-graph evaluation + texture
+ * sampling on the device, or -- ctx == NULL -- the same code on the host. */
+AKR_API int32_t akr_probe_material_inputs(akr_context *ctx, akr_scene *scene, uint32_t material, uint32_t n, const float *uv, float *out26);
 AKR_API int32_t akr_probe_surface_interaction(akr_context *ctx, akr_scene *scene, uint32_t n, const uint32_t *inst_prim,
                                               const float *bary, float *out);
 

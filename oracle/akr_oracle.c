@@ -25,6 +25,7 @@
 #define _GNU_SOURCE
 #include "or_api.h"
 #include "or_bsdf.h"
+#include "or_tex.h"
 #include "or_geom.h"
 #include "or_math.h"
 #include "or_rng.h"
@@ -57,6 +58,9 @@ typedef struct {
     or_mesh *meshes;
     or_instance *instances;
     or_material_desc *materials;
+    or_material_graph *graphs;   /* n_materials entries (deep copies) or NULL */
+    or_image_desc *images;       /* deep copies */
+    uint32_t n_images;
     /* world-space triangles for intersection */
     float *woop; /* 12 floats per triangle */
     uint32_t *tri_inst, *tri_prim;
@@ -213,8 +217,22 @@ static inline int or_alpha_test(const or_scene *sc, uint32_t inst, uint32_t prim
     const or_instance *in = &sc->instances[inst];
     const or_mesh_desc *g = &sc->meshes[in->mesh].d;
     uint32_t slot = (g->material_slots && g->n_triangles > 1) ? g->material_slots[prim] : 0;
-    const or_material_desc *m = &sc->materials[in->materials[slot < in->n_materials ? slot : 0]];
+    uint32_t mid = in->materials[slot < in->n_materials ? slot : 0];
+    const or_material_desc *m = &sc->materials[mid];
     float alpha = (m->kind == OR_MAT_PRINCIPLED || m->kind == OR_MAT_DIFFUSE) ? m->base_alpha : 1.0f;
+    if (sc->graphs && sc->graphs[mid].n_nodes && sc->graphs[mid].input[OR_IN_BASE_COLOR] != OR_NODE_NONE &&
+        (m->kind == OR_MAT_PRINCIPLED || m->kind == OR_MAT_DIFFUSE)) {
+        /* SvmEvalMode::Alpha (principled.rs:15-21) at the candidate's uv (mesh.rs:426-485; this restatement uses the
+         * uv defaults of surface_interaction for meshes without uvs) */
+        uint32_t p3 = prim * 3;
+        v2 uv0, uv1, uv2;
+        if (g->uvs) { uv0 = ld2(g->uvs, p3); uv1 = ld2(g->uvs, p3 + 1); uv2 = ld2(g->uvs, p3 + 2); }
+        else { uv0 = V2(0.0f, 0.0f); uv1 = V2(1.0f, 0.0f); uv2 = V2(1.0f, 0.1f); }
+        v2 uv = interp2(V2(u, v), uv0, uv1, uv2);
+        or_material_desc at;
+        or_material_at(m, &sc->graphs[mid], sc->images, uv.x, uv.y, &at);
+        alpha = at.base_alpha;
+    }
     if (alpha >= 1.0f) return 1;
     float h = (float)or_xxhash32_4(inst, prim, f2u(u), f2u(v)) * (float)(1.0 / 4294967295.0);
     return alpha > h;
@@ -323,7 +341,9 @@ static or_surface *or_build_closure(or_closure_pool *p, const or_scene *sc, cons
         float r = (1.0f * OR_INV_PI) * 0.8f;
         inner->color = V3(r, r, r);
     } else {
-        const or_material_desc *m = &sc->materials[si->material];
+        or_material_desc at;
+        or_material_at(&sc->materials[si->material], sc->graphs ? &sc->graphs[si->material] : 0, sc->images, si->uv.x, si->uv.y, &at);
+        const or_material_desc *m = &at;
         switch (m->kind) {
         case OR_MAT_PRINCIPLED: inner = or_build_principled(p, sc, m, si); break;
         case OR_MAT_DIFFUSE: /* diffuse.rs:83-104 */
@@ -469,6 +489,19 @@ OR_EXPORT or_scene *or_scene_create(const or_scene_desc *d) {
         m->material_slots = (uint32_t *)or_dup(s->material_slots, 4ull * s->n_triangles);
     }
     sc->materials = (or_material_desc *)or_dup(d->materials, sizeof(or_material_desc) * d->n_materials);
+    sc->n_images = d->n_images;
+    if (d->n_images) {
+        sc->images = (or_image_desc *)or_dup(d->images, sizeof(or_image_desc) * d->n_images);
+        for (uint32_t i = 0; i < d->n_images; i++) {
+            size_t bytes = (size_t)d->images[i].width * d->images[i].height * (d->images[i].format == OR_IMAGE_RGBA32F ? 16 : 4);
+            sc->images[i].texels = or_dup(d->images[i].texels, bytes);
+        }
+    }
+    if (d->material_graphs) {
+        sc->graphs = (or_material_graph *)or_dup(d->material_graphs, sizeof(or_material_graph) * d->n_materials);
+        for (uint32_t i = 0; i < d->n_materials; i++)
+            sc->graphs[i].nodes = (or_shader_node *)or_dup(d->material_graphs[i].nodes, sizeof(or_shader_node) * d->material_graphs[i].n_nodes);
+    }
     sc->instances = (or_instance *)calloc(d->n_instances ? d->n_instances : 1, sizeof(or_instance));
     uint32_t n_tris = 0;
     for (uint32_t i = 0; i < d->n_instances; i++) {
@@ -507,7 +540,19 @@ OR_EXPORT or_scene *or_scene_create(const or_scene_desc *d) {
     for (uint32_t i = 0; i < d->n_instances; i++) {
         or_instance *in = &sc->instances[i];
         int any = 0;
-        for (uint32_t k = 0; k < in->n_materials; k++) any |= or_has_potential_emission(&sc->materials[in->materials[k]]);
+        for (uint32_t k = 0; k < in->n_materials; k++) {
+            uint32_t mid = in->materials[k];
+            const or_material_desc *md = &sc->materials[mid];
+            const or_material_graph *gr = sc->graphs ? &sc->graphs[mid] : 0;
+            if (gr && gr->n_nodes && (md->kind == OR_MAT_PRINCIPLED || md->kind == OR_MAT_EMISSION) &&
+                (or_node_varies(gr, gr->input[OR_IN_EMISSION_COLOR]) || or_node_varies(gr, gr->input[OR_IN_EMISSION_STRENGTH]))) {
+                any |= 1; /* estimate_emission_tex_intensity_fast -> None (load.rs:76-92) */
+            } else {
+                or_material_desc at; /* constant nodes feeding the emission inputs are folded first */
+                or_material_at(md, gr, sc->images, 0.0f, 0.0f, &at);
+                any |= or_has_potential_emission(&at);
+            }
+        }
         if (!any) continue;
         uint32_t nt = sc->meshes[in->mesh].d.n_triangles;
         float *powers = (float *)malloc(4ull * nt + 4);
@@ -538,6 +583,9 @@ OR_EXPORT void or_scene_destroy(or_scene *sc) {
         if (sc->instances[i].light >= 0) or_alias_free(&sc->instances[i].area_sampler);
     }
     if (sc->n_lights > 0) or_alias_free(&sc->light_dist);
+    for (uint32_t i = 0; i < sc->n_images; i++) free((void *)sc->images[i].texels);
+    if (sc->graphs) for (uint32_t i = 0; i < sc->n_materials; i++) free((void *)sc->graphs[i].nodes);
+    free(sc->images); free(sc->graphs);
     free(sc->meshes); free(sc->instances); free(sc->materials);
     free(sc->woop); free(sc->tri_inst); free(sc->tri_prim);
     free(sc->light_inst); free(sc->light_power);
@@ -819,6 +867,22 @@ OR_EXPORT uint32_t or_kat_xxhash32_4(uint32_t a, uint32_t b, uint32_t c, uint32_
 OR_EXPORT uint64_t or_kat_mix_bits(uint64_t v) { return or_mix_bits(v); }
 OR_EXPORT void or_kat_sincos(float x, float *s, float *c) { or_sincosf(x, s, c); }
 OR_EXPORT float or_kat_log(float x) { return or_logf(x); }
+OR_EXPORT float or_kat_exp(float x) { return or_expf(x); }
+OR_EXPORT float or_kat_pow(float x, float y) { return or_powf(x, y); }
+/* evaluated inputs (26 words each) of `material` at n uv points */
+OR_EXPORT void or_material_inputs(const or_scene *sc, uint32_t material, uint32_t n, const float *uv, float *out26) {
+    for (uint32_t i = 0; i < n; i++) {
+        or_material_desc at;
+        or_material_at(&sc->materials[material], sc->graphs ? &sc->graphs[material] : 0, sc->images, uv[2 * i], uv[2 * i + 1], &at);
+        memcpy(out26 + 26 * (size_t)i, &at, sizeof at);
+    }
+}
+OR_EXPORT void or_tex_sample_many(const or_image_desc *im, uint32_t n, const float *uv, float *out4) {
+    for (uint32_t i = 0; i < n; i++) {
+        or_val r = or_tex_sample(im, uv[2 * i], uv[2 * i + 1]);
+        memcpy(out4 + 4 * (size_t)i, r.v, 16);
+    }
+}
 OR_EXPORT void or_kat_alias_build(const float *w, uint32_t n, uint32_t *j, float *t, float *pdf) {
     or_alias_table at;
     or_alias_build(&at, w, n);

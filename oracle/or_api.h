@@ -42,6 +42,21 @@ typedef struct {
     float normal[3];         /* principled `normal` socket (0,0,0 = unperturbed) */
 } or_material_desc;
 
+/* Shader graphs with texture-fed inputs and the images they sample: layout-identical to akr_shader_node,
+ * akr_material_graph, akr_image_desc (include/akari_hip.h). Node semantics: svm/eval.rs:97-269. */
+#define OR_NODE_NONE 0xffffffffu
+enum { OR_NODE_CONST = 0, OR_NODE_RGB, OR_NODE_TEXCOORDS, OR_NODE_IMAGE, OR_NODE_MAPPING, OR_NODE_CHECKERBOARD,
+       OR_NODE_SPECTRAL_UPLIFT, OR_NODE_SEPARATE_COLOR, OR_NODE_EXTRACT, OR_NODE_NORMAL_MAP };
+enum { OR_IN_BASE_COLOR = 0, OR_IN_METALLIC, OR_IN_ROUGHNESS, OR_IN_IOR, OR_IN_SPECULAR_IOR_LEVEL, OR_IN_SPECULAR_TINT,
+       OR_IN_TRANSMISSION_WEIGHT, OR_IN_COAT_WEIGHT, OR_IN_COAT_ROUGHNESS, OR_IN_COAT_IOR, OR_IN_COAT_TINT,
+       OR_IN_EMISSION_COLOR, OR_IN_EMISSION_STRENGTH, OR_IN_NORMAL, OR_IN_COUNT };
+typedef struct { uint32_t op; uint32_t arg[4]; float k[3]; } or_shader_node;
+typedef struct { uint32_t n_nodes, _pad; const or_shader_node *nodes; uint32_t input[OR_IN_COUNT]; } or_material_graph;
+enum { OR_IMAGE_RGBA8 = 0, OR_IMAGE_RGBA32F = 1 };
+enum { OR_TEX_NEAREST = 0, OR_TEX_LINEAR = 1 };
+enum { OR_TEX_REPEAT = 0, OR_TEX_CLIP = 1, OR_TEX_MIRROR = 2, OR_TEX_EXTEND = 3 };
+typedef struct { uint32_t width, height, format, filter, address, _pad; const void *texels; } or_image_desc;
+
 typedef struct {
     float c2w[16];           /* column-major camera->world (load.rs:129-171 applied to the camera TRS) */
     float fov;               /* radians, spans the larger image side (camera/mod.rs:135-140) */
@@ -55,6 +70,9 @@ typedef struct {
     const or_material_desc *materials;
     or_camera_desc camera;
     const float *ggx_dielectric_table; /* 16^3 f32 ("ggx_dielectric_s", precompute.rs:133-145) or NULL */
+    uint32_t n_images, _pad2;
+    const or_image_desc *images;
+    const or_material_graph *material_graphs; /* n_materials entries or NULL */
 } or_scene_desc;
 
 enum { OR_FILTER_BOX = 0, OR_FILTER_GAUSSIAN = 1 };

@@ -115,6 +115,29 @@ static inline float or_logf(float x) {
 }
 
 /* util/mod.rs:326-331 difference_of_products(a,b,c,d) = a*b - c*d with one-ulp error term */
+/* e^x: range reduction x = g + n ln2 (two-constant Cody-Waite), Cephes expf polynomial, exact two-step scaling.
+ * Part of the AKR-F32 contract: this is what "exp" / "powf" mean on both sides. */
+static inline float or_expf(float x) {
+    if (or_isnan(x)) return x;
+    if (x > 88.72283905206835f) return INFINITY;
+    if (x < -103.278929903431851103f) return 0.0f;
+    float fn = floorf(1.44269504088896341f * x + 0.5f);
+    float g = fmaf(-0.693359375f, fn, x);
+    g = fmaf(2.12194440e-4f, fn, g);
+    float z = g * g;
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, g, 1.3981999507e-3f);
+    p = fmaf(p, g, 8.3334519073e-3f);
+    p = fmaf(p, g, 4.1665795894e-2f);
+    p = fmaf(p, g, 1.6666665459e-1f);
+    p = fmaf(p, g, 5.0000001201e-1f);
+    float r = fmaf(p, z, g) + 1.0f;
+    int n = (int)fn, n1 = n / 2, n2 = n - n1;
+    r = r * u2f((uint32_t)(n1 + 127) << 23);
+    return r * u2f((uint32_t)(n2 + 127) << 23);
+}
+static inline float or_powf(float x, float y) { return x == 0.0f ? 0.0f : or_expf(y * or_logf(x)); }
+
 static inline float or_dop(float a, float b, float c, float d) {
     float cd = c * d;
     float diff = fmaf(a, b, -cd);

@@ -70,6 +70,12 @@ def lib() -> C.CDLL:
     L.or_kat_sincos.argtypes = [f32, fp, fp]
     L.or_kat_log.restype = f32
     L.or_kat_log.argtypes = [f32]
+    L.or_kat_exp.restype = f32
+    L.or_kat_exp.argtypes = [f32]
+    L.or_kat_pow.restype = f32
+    L.or_kat_pow.argtypes = [f32, f32]
+    L.or_material_inputs.argtypes = [vp, u32, u32, fp, fp]
+    L.or_tex_sample_many.argtypes = [C.POINTER(abi.ImageDesc), u32, fp, fp]
     L.or_kat_alias_build.argtypes = [fp, u32, up, fp, fp]
     L.or_kat_offset_ray_origin.argtypes = [fp, fp, fp]
     L.or_kat_uniform_sample_triangle.argtypes = [f32, f32, fp]
@@ -121,6 +127,12 @@ class OracleScene:
         inst, power, pdf = C.c_uint32(), C.c_float(), C.c_float()
         lib().or_scene_light_info(self.h, i, C.byref(inst), C.byref(power), C.byref(pdf))
         return inst.value, power.value, pdf.value
+
+    def material_inputs(self, material: int, uv) -> np.ndarray:
+        u = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
+        out = np.zeros((u.shape[0], 26), dtype=np.float32)
+        lib().or_material_inputs(self.h, material, u.shape[0], _fp(u), _fp(out))
+        return out
 
     def surface_interaction(self, inst, prim, u, v):
         out = np.zeros(19, dtype=np.float32)
@@ -178,4 +190,18 @@ def bsdf_eval_many(m: abi.MaterialData, wo, wi: np.ndarray, table: np.ndarray | 
     out = np.zeros((wi.shape[0], 4), dtype=np.float32)
     tp = _fp(np.ascontiguousarray(table, dtype=np.float32)) if table is not None else C.POINTER(C.c_float)()
     lib().or_bsdf_eval_many(C.byref(ms), tp, _fp(wo), wi.shape[0], _fp(wi), _fp(out))
+    return out
+
+
+def tex_sample(image: abi.ImageData, uv) -> np.ndarray:
+    """or_tex_sample of one image at uv points -> (n, 4) float32."""
+    t = np.ascontiguousarray(image.texels)
+    d = abi.ImageDesc()
+    d.height, d.width = t.shape[0], t.shape[1]
+    d.format = abi.IMAGE_RGBA8 if t.dtype == np.uint8 else abi.IMAGE_RGBA32F
+    d.filter, d.address = image.filter, image.address
+    d.texels = t.ctypes.data
+    u = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
+    out = np.zeros((u.shape[0], 4), dtype=np.float32)
+    lib().or_tex_sample_many(C.byref(d), u.shape[0], _fp(u), _fp(out))
     return out

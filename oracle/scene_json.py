@@ -11,10 +11,11 @@ import base64
 import json
 import math
 import os
-from typing import Dict
+from typing import Dict, List
 
 import numpy as np
 
+from akari_render_amd import abi
 from akari_render_amd.abi import (
     MAT_DIFFUSE,
     MAT_EMISSION,
@@ -127,8 +128,202 @@ class _Buffers:
         return np.frombuffer(raw, dtype=dtype).reshape(-1, cols).copy()
 
 
-def _fold_material(shader: dict) -> MaterialData:
+def decode_png(data: bytes) -> np.ndarray:
+    """PNG -> (H, W, 4) uint8, file order, with the expansions of the image crate's decode().to_rgba8()
+    (palette, tRNS, low bit depths, 16 -> 8 bit with rounding). Independent of the C++ reader: zlib does the inflate."""
+    import struct
+    import zlib
+
+    assert data[:8] == b"\x89PNG\r\n\x1a\n", "bad PNG signature"
+    pos, idat, plte, trns, hdr = 8, b"", b"", b"", None
+    while pos + 12 <= len(data):
+        (ln,) = struct.unpack(">I", data[pos : pos + 4])
+        ty = data[pos + 4 : pos + 8]
+        body = data[pos + 8 : pos + 8 + ln]
+        if ty == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif ty == b"PLTE":
+            plte = body
+        elif ty == b"tRNS":
+            trns = body
+        elif ty == b"IDAT":
+            idat += body
+        elif ty == b"IEND":
+            break
+        pos += 12 + ln
+    w, h, depth, ctype, _, _, interlace = hdr
+    if interlace:
+        raise NotImplementedError("interlaced PNG")
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    bits = ch * depth
+    stride, bpp = (w * bits + 7) // 8, (bits + 7) // 8
+    raw = zlib.decompress(idat)
+    img = np.zeros((h, stride), dtype=np.uint8)
+    prev = np.zeros(stride, dtype=np.int32)
+    for y in range(h):
+        ft = raw[(stride + 1) * y]
+        line = np.frombuffer(raw[(stride + 1) * y + 1 : (stride + 1) * (y + 1)], dtype=np.uint8).astype(np.int32)
+        cur = np.zeros(stride, dtype=np.int32)
+        if ft == 0:
+            cur = line.copy()
+        elif ft == 2:
+            cur = (line + prev) & 255
+        else:
+            for x in range(stride):
+                a = cur[x - bpp] if x >= bpp else 0
+                b = prev[x]
+                c = prev[x - bpp] if x >= bpp else 0
+                if ft == 1:
+                    p_ = a
+                elif ft == 3:
+                    p_ = (a + b) >> 1
+                elif ft == 4:
+                    pp = a + b - c
+                    pa, pb, pc = abs(pp - a), abs(pp - b), abs(pp - c)
+                    p_ = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                else:
+                    raise ValueError("bad PNG filter")
+                cur[x] = (line[x] + p_) & 255
+        img[y] = cur.astype(np.uint8)
+        prev = cur
+    # samples as integers
+    if depth == 8:
+        smp = img.astype(np.uint32)
+    elif depth == 16:
+        smp = (img[:, 0::2].astype(np.uint32) << 8) | img[:, 1::2].astype(np.uint32)
+    else:
+        bitsarr = np.unpackbits(img, axis=1)[:, : w * ch * depth].reshape(h, w * ch, depth)
+        smp = np.zeros((h, w * ch), dtype=np.uint32)
+        for k in range(depth):
+            smp = (smp << 1) | bitsarr[:, :, k]
+    smp = smp[:, : w * ch].reshape(h, w, ch)
+
+    def to8(v):
+        if depth == 8:
+            return v.astype(np.uint8)
+        if depth == 16:
+            return ((v + 128) // 257).astype(np.uint8)
+        return (v * 255 // ((1 << depth) - 1)).astype(np.uint8)
+
+    out = np.full((h, w, 4), 255, dtype=np.uint8)
+    if ctype == 3:
+        pal = np.frombuffer(plte, dtype=np.uint8).reshape(-1, 3)
+        idx = smp[:, :, 0]
+        out[:, :, :3] = pal[idx]
+        al = np.full(256, 255, dtype=np.uint8)
+        al[: len(trns)] = np.frombuffer(trns, dtype=np.uint8)
+        out[:, :, 3] = al[idx]
+    elif ctype == 0:
+        out[:, :, 0] = out[:, :, 1] = out[:, :, 2] = to8(smp[:, :, 0])
+        if len(trns) >= 2:
+            key = (trns[0] << 8) | trns[1]
+            out[:, :, 3] = np.where(smp[:, :, 0] == key, 0, 255)
+    elif ctype == 4:
+        out[:, :, 0] = out[:, :, 1] = out[:, :, 2] = to8(smp[:, :, 0])
+        out[:, :, 3] = to8(smp[:, :, 1])
+    elif ctype == 2:
+        out[:, :, :3] = to8(smp)
+        if len(trns) >= 6:
+            key = [(trns[2 * k] << 8) | trns[2 * k + 1] for k in range(3)]
+            hit = (smp[:, :, 0] == key[0]) & (smp[:, :, 1] == key[1]) & (smp[:, :, 2] == key[2])
+            out[:, :, 3] = np.where(hit, 0, 255)
+    else:
+        out[:, :, :] = to8(smp)
+    return out
+
+
+class _Graph:
+    """Translation of the texture-fed inputs of a surface node (svm/compiler.rs:116-337) into abi.GraphData."""
+
+    def __init__(self, nodes: dict, bufs: "_Buffers", images: list, image_index: dict):
+        self.nodes, self.bufs, self.images, self.image_index = nodes, bufs, images, image_index
+        self.out: List[abi.NodeData] = []
+        self.inputs: dict = {}
+        self.memo: dict = {}
+
+    def is_const(self, ref) -> bool:
+        n = self.nodes[ref["id"]]
+        if n["type"] in ("float", "float3", "rgb"):
+            return True
+        if n["type"] == "spectral_uplift":
+            return self.is_const(n["rgb"])
+        return False
+
+    def push(self, op, args=(), k=(0.0, 0.0, 0.0)) -> int:
+        self.out.append(abi.NodeData(op, tuple(args), tuple(k)))
+        return len(self.out) - 1
+
+    def image(self, im: dict) -> int:
+        key = (im["data"]["id"], im["format"], im["extension"], im["interpolation"], im["width"], im["height"], im["channels"])
+        if key in self.image_index:
+            return self.image_index[key]
+        address = {"repeat": abi.TEX_REPEAT, "clip": abi.TEX_CLIP, "mirror": abi.TEX_MIRROR, "extend": abi.TEX_EXTEND}[im["extension"]]
+        filt = {"linear": abi.TEX_FILTER_LINEAR, "cubic": abi.TEX_FILTER_LINEAR, "nearest": abi.TEX_FILTER_NEAREST}[im["interpolation"]]
+        v = self.bufs.scene["buffer_views"][im["data"]["id"]]
+        raw = self.bufs.buffer(v["buffer"]["id"])[v["offset"] : v["offset"] + v["length"]]
+        if im["format"] == "float":
+            w, h, ch = im["width"], im["height"], im["channels"]
+            src = np.frombuffer(raw, dtype=np.float32).reshape(h, w, ch)
+            tex = np.zeros((h, w, 4), dtype=np.float32)
+            tex[:, :, 3] = 1.0
+            tex[:, :, :ch] = src  # load.rs:552-569; not flipped
+        elif im["format"] == "png":
+            tex = decode_png(raw)[::-1].copy()  # flipv, load.rs:596
+        else:
+            raise NotImplementedError(f"image format '{im['format']}'")
+        self.images.append(abi.ImageData(tex, filt, address))
+        self.image_index[key] = len(self.images) - 1
+        return self.image_index[key]
+
+    def emit(self, ref) -> int:
+        nid = ref["id"]
+        if nid in self.memo:
+            return self.memo[nid]
+        n = self.nodes[nid]
+        ty = n["type"]
+        opt = lambda key: self.emit(n[key]) if n.get(key) is not None else abi.NODE_NONE  # noqa: E731
+        if ty == "float":
+            r = self.push(abi.NODE_CONST, (), (n["value"], 0.0, 0.0))
+        elif ty == "float3":
+            r = self.push(abi.NODE_CONST, (), tuple(n["value"]))
+        elif ty == "rgb":
+            if n.get("colorspace", "srgb") != "srgb":
+                raise NotImplementedError("non-sRGB constant colours")
+            r = self.push(abi.NODE_RGB, (), tuple(n["value"]))
+        elif ty == "spectral_uplift":
+            r = self.push(abi.NODE_SPECTRAL_UPLIFT, (self.emit(n["rgb"]),))
+        elif ty == "texcoords":
+            r = self.push(abi.NODE_TEXCOORDS)
+        elif ty == "image":
+            uv = opt("uv")
+            cs = n["image"]["colorspace"]
+            assert cs in ("srgb", "none"), cs
+            r = self.push(abi.NODE_IMAGE, (self.image(n["image"]), uv, 1 if cs == "srgb" else 0))
+        elif ty == "mapping":
+            v, loc, sc = self.emit(n["vector"]), self.emit(n["location"]), self.emit(n["scale"])
+            r = self.push(abi.NODE_MAPPING, (v, loc, sc, {"point": abi.MAPPING_POINT, "texture": abi.MAPPING_TEXTURE}[n["mapping"]]))
+        elif ty == "checkerboard":
+            v = opt("vector")
+            sc, c1, c2 = self.emit(n["scale"]), self.emit(n["color1"]), self.emit(n["color2"])
+            r = self.push(abi.NODE_CHECKERBOARD, (v, sc, c1, c2))
+        elif ty == "normal_map":
+            assert n["space"] == "tangent"
+            nn, st = self.emit(n["normal"]), self.emit(n["strength"])
+            r = self.push(abi.NODE_NORMAL_MAP, (nn, st))
+        elif ty == "separate_color":
+            r = self.push(abi.NODE_SEPARATE_COLOR, (self.emit(n["color"]),))
+        elif ty == "extract":
+            field_ = {"Red": abi.FIELD_RED, "Green": abi.FIELD_GREEN, "Blue": abi.FIELD_BLUE, "uv": abi.FIELD_UV, "UV": abi.FIELD_UV}[n["field"]]
+            r = self.push(abi.NODE_EXTRACT, (self.emit(n["node"]), field_))
+        else:
+            raise NotImplementedError(f"shader node '{ty}'")
+        self.memo[nid] = r
+        return r
+
+
+def _fold_material(shader: dict, bufs: "_Buffers" = None, images: list = None, image_index: dict = None) -> MaterialData:
     nodes = shader["nodes"]
+    graph = _Graph(nodes, bufs, images if images is not None else [], image_index if image_index is not None else {})
 
     def const(ref):
         """Evaluate a constant node the way svm/eval.rs does; returns (values[list], alpha)."""
@@ -146,50 +341,71 @@ def _fold_material(shader: dict) -> MaterialData:
             return const(n["rgb"])
         raise NotImplementedError(f"shader node '{ty}' (only constant inputs are supported)")
 
-    def f(ref):  # eval_float_auto_convert
+    current = [None]  # name of the input being read (abi.INPUT_NAMES)
+
+    def f(ref, default=0.0):  # eval_float_auto_convert
+        if not graph.is_const(ref):
+            graph.inputs[current[0]] = graph.emit(ref)
+            return default
         return float(const(ref)[0][0])
 
-    def c3(ref):
+    def c3(ref, default=(0.0, 0.0, 0.0)):
+        if not graph.is_const(ref):
+            graph.inputs[current[0]] = graph.emit(ref)
+            return default
         v = const(ref)[0]
         return tuple(v[:3]) if len(v) >= 3 else (v[0], 0.0, 0.0)
+
+    def alpha(ref):
+        return const(ref)[1] if graph.is_const(ref) else 1.0
+
+    def rd(name, fn, ref, *a):
+        current[0] = name
+        return fn(ref, *a)
 
     out = nodes[shader["output"]["id"]]
     assert out["type"] == "output"
     n = nodes[out["node"]["id"]]
     ty = n["type"]
     m = MaterialData()
+    # the library's loader initialises every input it does not fold: same defaults here
+    m.base_color, m.base_alpha, m.metallic, m.roughness, m.ior, m.specular_ior_level = (0.0, 0.0, 0.0), 1.0, 0.0, 0.0, 1.0, 0.5
+    m.specular_tint, m.transmission_weight, m.coat_weight, m.coat_roughness, m.coat_ior = (1.0, 1.0, 1.0), 0.0, 0.0, 0.0, 0.0
+    m.coat_tint, m.emission_color, m.emission_strength, m.normal = (1.0, 1.0, 1.0), (0.0, 0.0, 0.0), 0.0, (0.0, 0.0, 0.0)
     if ty == "principled":
         m.kind = MAT_PRINCIPLED
-        m.base_color = c3(n["base_color"])
-        m.base_alpha = const(n["base_color"])[1]
-        m.metallic = f(n["metallic"])
-        m.roughness = f(n["roughness"])
-        m.ior = f(n["ior"])
-        m.specular_ior_level = f(n["specular_ior_level"])
-        m.specular_tint = c3(n["specular_tint"])
-        m.transmission_weight = f(n["transmission_weight"])
-        m.coat_weight = f(n["coat_weight"])
-        m.coat_roughness = f(n["coat_roughness"])
-        m.coat_ior = f(n["coat_ior"])
-        m.coat_tint = c3(n["coat_tint"])
-        m.emission_color = c3(n["emission_color"])
-        m.emission_strength = f(n["emission_strength"])
-        m.normal = c3(n["normal"])
+        m.base_color = rd("base_color", c3, n["base_color"])
+        m.base_alpha = alpha(n["base_color"])
+        m.metallic = rd("metallic", f, n["metallic"])
+        m.roughness = rd("roughness", f, n["roughness"])
+        m.ior = rd("ior", f, n["ior"], 1.0)
+        m.specular_ior_level = rd("specular_ior_level", f, n["specular_ior_level"], 0.5)
+        m.specular_tint = rd("specular_tint", c3, n["specular_tint"], (1.0, 1.0, 1.0))
+        m.transmission_weight = rd("transmission_weight", f, n["transmission_weight"])
+        m.coat_weight = rd("coat_weight", f, n["coat_weight"])
+        m.coat_roughness = rd("coat_roughness", f, n["coat_roughness"])
+        m.coat_ior = rd("coat_ior", f, n["coat_ior"])
+        m.coat_tint = rd("coat_tint", c3, n["coat_tint"], (1.0, 1.0, 1.0))
+        m.emission_color = rd("emission_color", c3, n["emission_color"])
+        m.emission_strength = rd("emission_strength", f, n["emission_strength"])
+        m.normal = rd("normal", c3, n["normal"])
     elif ty == "diffuse":
         m.kind = MAT_DIFFUSE
-        m.base_color = c3(n["color"])
-        m.base_alpha = const(n["color"])[1]
+        m.base_color = rd("base_color", c3, n["color"])
+        m.base_alpha = alpha(n["color"])
     elif ty == "glass":
         m.kind = MAT_GLASS
-        m.base_color = c3(n["color"])
-        m.ior = f(n["ior"])
-        m.roughness = f(n["roughness"])
+        m.base_color = rd("base_color", c3, n["color"])
+        m.ior = rd("ior", f, n["ior"], 1.0)
+        m.roughness = rd("roughness", f, n["roughness"])
     elif ty == "emission":
         m.kind = MAT_EMISSION
-        m.emission_color = c3(n["color"])
-        m.emission_strength = f(n["strength"])
+        m.emission_color = rd("emission_color", c3, n["color"])
+        m.emission_strength = rd("emission_strength", f, n["strength"])
     else:
         raise NotImplementedError(f"surface shader '{ty}'")
+    if graph.out:
+        m.graph = abi.GraphData(graph.out, graph.inputs)
     return m
 
 
@@ -223,7 +439,8 @@ def load_scene(path: str, width: int = 0, height: int = 0) -> SceneData:
         )
     mat_ids = sorted(scene["materials"].keys())
     mat_index = {m: i for i, m in enumerate(mat_ids)}
-    materials = [_fold_material(scene["materials"][m]["shader"]) for m in mat_ids]
+    images, image_index = [], {}
+    materials = [_fold_material(scene["materials"][m]["shader"], bufs, images, image_index) for m in mat_ids]
     inst_ids = sorted(scene["instances"].keys())
     instances = []
     for iid in inst_ids:
@@ -246,7 +463,7 @@ def load_scene(path: str, width: int = 0, height: int = 0) -> SceneData:
         width=int(width or cd["sensor_width"]),
         height=int(height or cd["sensor_height"]),
     )
-    return SceneData(meshes, instances, materials, camera, None, inst_ids, mat_ids)
+    return SceneData(meshes, instances, materials, camera, None, inst_ids, mat_ids, images)
 
 
 def load_method(path_or_text: str) -> dict:

@@ -121,3 +121,152 @@ def cbox_variant(sd: abi.SceneData, which: str) -> abi.SceneData:
     else:
         raise ValueError(which)
     return sd
+
+
+# ---------------------------------------------------------------------------------------------- textured scenes
+def make_png(pixels: np.ndarray, color_type: int, depth: int = 8, filters=None, palette=None, trns: bytes = None, level: int = 6) -> bytes:
+    """Encodes a PNG from raw samples: pixels (H, W, C) of integer samples (or (H, W) palette indices / grey).
+    `filters` = per-row filter types (default: cycling 0..4), encoded exactly as the PNG spec defines them."""
+    import struct
+    import zlib
+
+    px = np.asarray(pixels)
+    if px.ndim == 2:
+        px = px[:, :, None]
+    h, w, ch = px.shape
+    bits = ch * depth
+    stride, bpp = (w * bits + 7) // 8, max(1, bits // 8)
+    rows = []
+    for y in range(h):
+        if depth == 8:
+            row = px[y].astype(np.uint8).reshape(-1)
+        elif depth == 16:
+            row = np.stack([(px[y] >> 8) & 255, px[y] & 255], axis=-1).astype(np.uint8).reshape(-1)
+        else:
+            b = ((px[y].reshape(-1)[:, None] >> np.arange(depth - 1, -1, -1)) & 1).astype(np.uint8).reshape(-1)
+            row = np.packbits(b)
+        assert row.size == stride
+        rows.append(row.astype(np.int32))
+    out = bytearray()
+    prev = np.zeros(stride, dtype=np.int32)
+    for y, row in enumerate(rows):
+        ft = (filters[y] if filters is not None else y % 5)
+        a = np.concatenate([np.zeros(bpp, dtype=np.int32), row[:-bpp]]) if stride > bpp else np.zeros(stride, dtype=np.int32)
+        c = np.concatenate([np.zeros(bpp, dtype=np.int32), prev[:-bpp]]) if stride > bpp else np.zeros(stride, dtype=np.int32)
+        if ft == 0:
+            f = row
+        elif ft == 1:
+            f = row - a
+        elif ft == 2:
+            f = row - prev
+        elif ft == 3:
+            f = row - ((a + prev) >> 1)
+        else:
+            p = a + prev - c
+            pa, pb, pc = np.abs(p - a), np.abs(p - prev), np.abs(p - c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+            f = row - pred
+        out.append(ft)
+        out += bytes((f & 255).astype(np.uint8))
+        prev = row
+
+    def chunk(ty, body):
+        return struct.pack(">I", len(body)) + ty + body + struct.pack(">I", zlib.crc32(ty + body) & 0xFFFFFFFF)
+
+    data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color_type, 0, 0, 0))
+    if palette is not None:
+        data += chunk(b"PLTE", bytes(np.asarray(palette, dtype=np.uint8).reshape(-1)))
+    if trns is not None:
+        data += chunk(b"tRNS", trns)
+    comp = zlib.compress(bytes(out), level)
+    half = len(comp) // 2
+    data += chunk(b"IDAT", comp[:half]) + chunk(b"IDAT", comp[half:]) + chunk(b"IEND", b"")
+    return data
+
+
+def textured_room(width=48, height=48, n_floor=1, seed=11, alpha_cutout=False, textured_light=True) -> abi.SceneData:
+    """A closed room with per-corner uvs and texture-fed materials: checkerboard floor (colours + roughness from a
+    separate_color channel), sRGB byte image on the back wall through a mapping node, float image with a normal map on
+    a side wall, a textured emitter on the ceiling, optionally an alpha-cutout quad in front of the camera.
+    n_floor > 1 tessellates the floor (n_floor^2 quads) so that the scene takes the BVH path."""
+    rng = np.random.default_rng(seed)
+    N = abi.NodeData
+    meshes, insts, mats = [], [], []
+    eye = np.eye(4, dtype=np.float32).T.reshape(16).copy()
+
+    def quad(p0, p1, p2, p3, nu=1, nv=1, uv_scale=1.0):
+        """quad p0->p1 (u) x p0->p3 (v), tessellated nu x nv; normals = (p1-p0) x (p3-p0)"""
+        p0, p1, p3 = np.asarray(p0, np.float32), np.asarray(p1, np.float32), np.asarray(p3, np.float32)
+        verts, idx, uvs = [], [], []
+        for j in range(nv + 1):
+            for i in range(nu + 1):
+                verts.append(p0 + (p1 - p0) * np.float32(i / nu) + (p3 - p0) * np.float32(j / nv))
+        uvf = lambda i, j: (np.float32(uv_scale * i / nu), np.float32(uv_scale * j / nv))  # noqa: E731
+        for j in range(nv):
+            for i in range(nu):
+                a, b, c, d = j * (nu + 1) + i, j * (nu + 1) + i + 1, (j + 1) * (nu + 1) + i + 1, (j + 1) * (nu + 1) + i
+                idx += [[a, b, c], [a, c, d]]
+                uvs += [[uvf(i, j), uvf(i + 1, j), uvf(i + 1, j + 1)], [uvf(i, j), uvf(i + 1, j + 1), uvf(i, j + 1)]]
+        return abi.MeshData(vertices=np.array(verts, np.float32), indices=np.array(idx, np.uint32), uvs=np.array(uvs, np.float32))
+
+    def add(mesh, mat):
+        meshes.append(mesh)
+        mats.append(mat)
+        insts.append(abi.InstanceData(len(meshes) - 1, [len(mats) - 1], eye))
+
+    # images
+    img8 = rng.integers(0, 256, size=(16, 24, 4), dtype=np.uint8)
+    img8[:, :, 3] = np.where(rng.random((16, 24)) < 0.4, 0, 255).astype(np.uint8) if alpha_cutout else 255
+    imgf = rng.random((8, 8, 4)).astype(np.float32)
+    imgf[:, :, 2] = 0.5 + 0.5 * imgf[:, :, 2]  # normal-map-ish: z > 0.5
+    imgf[:, :, 3] = 1.0
+    img_e = (rng.random((4, 4, 4)) * 6.0).astype(np.float32)
+    img_e[:, :, 3] = 1.0
+    images = [abi.ImageData(img8, abi.TEX_FILTER_LINEAR, abi.TEX_REPEAT), abi.ImageData(imgf, abi.TEX_FILTER_LINEAR, abi.TEX_MIRROR),
+              abi.ImageData(img_e, abi.TEX_FILTER_NEAREST, abi.TEX_EXTEND), abi.ImageData(img8, abi.TEX_FILTER_NEAREST, abi.TEX_CLIP)]
+
+    # floor (y = -1, normal +y): checkerboard colours, roughness = green channel of the float image
+    g = abi.GraphData([
+        N(abi.NODE_RGB, (), (0.9, 0.85, 0.8)), N(abi.NODE_SPECTRAL_UPLIFT, (0,)),          # 0, 1 colour 1
+        N(abi.NODE_RGB, (), (0.15, 0.2, 0.3)), N(abi.NODE_SPECTRAL_UPLIFT, (2,)),          # 2, 3 colour 2
+        N(abi.NODE_CONST, (), (3.0, 0.0, 0.0)),                                            # 4 scale
+        N(abi.NODE_CHECKERBOARD, (abi.NODE_NONE, 4, 1, 3)),                                # 5 checker on si.uv
+        N(abi.NODE_IMAGE, (1, abi.NODE_NONE, 0)), N(abi.NODE_SEPARATE_COLOR, (6,)), N(abi.NODE_EXTRACT, (7, abi.FIELD_GREEN)),  # 6, 7, 8
+        N(abi.NODE_CONST, (), (0.25, 0.0, 0.0)),                                           # 9 constant metallic through the graph
+    ], {"base_color": 5, "roughness": 8, "metallic": 9})
+    add(quad([-1, -1, 1], [1, -1, 1], [1, -1, -1], [-1, -1, -1], n_floor, n_floor, 2.0),
+        abi.MaterialData(base_color=(0.5, 0.5, 0.5), roughness=0.5, ior=1.5, graph=g))
+    # back wall (z = -1, normal +z): sRGB byte image through texcoords -> mapping(point)
+    g = abi.GraphData([
+        N(abi.NODE_TEXCOORDS), N(abi.NODE_EXTRACT, (0, abi.FIELD_UV)),
+        N(abi.NODE_CONST, (), (0.125, -0.25, 0.0)), N(abi.NODE_CONST, (), (1.5, 2.0, 1.0)),
+        N(abi.NODE_MAPPING, (1, 2, 3, abi.MAPPING_POINT)),
+        N(abi.NODE_IMAGE, (0, 4, 1)), N(abi.NODE_SPECTRAL_UPLIFT, (5,)),
+    ], {"base_color": 6})
+    add(quad([-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1]), abi.MaterialData(roughness=0.9, ior=1.0, specular_ior_level=0.0, graph=g))
+    # left wall (x = -1, normal +x): normal map from the float image (mapping type texture), glossy
+    g = abi.GraphData([
+        N(abi.NODE_TEXCOORDS), N(abi.NODE_CONST, (), (0.1, 0.2, 0.0)), N(abi.NODE_CONST, (), (0.5, 0.25, 1.0)),
+        N(abi.NODE_MAPPING, (0, 1, 2, abi.MAPPING_TEXTURE)),
+        N(abi.NODE_IMAGE, (1, 3, 0)), N(abi.NODE_CONST, (), (0.7, 0.0, 0.0)), N(abi.NODE_NORMAL_MAP, (4, 5)),
+    ], {"normal": 6})
+    add(quad([-1, -1, 1], [-1, -1, -1], [-1, 1, -1], [-1, 1, 1]), abi.MaterialData(base_color=(0.7, 0.3, 0.25), roughness=0.35, ior=1.45, graph=g))
+    # right wall, front wall, ceiling: constant diffuse-ish principled
+    plain = lambda c: abi.MaterialData(base_color=c, roughness=1.0, ior=1.0, specular_ior_level=0.0)  # noqa: E731
+    add(quad([1, -1, -1], [1, -1, 1], [1, 1, 1], [1, 1, -1]), plain((0.25, 0.6, 0.3)))
+    add(quad([1, -1, 1], [-1, -1, 1], [-1, 1, 1], [1, 1, 1]), plain((0.7, 0.7, 0.7)))
+    add(quad([-1, 1, -1], [1, 1, -1], [1, 1, 1], [-1, 1, 1]), plain((0.8, 0.8, 0.8)))
+    # ceiling light (y = 0.98, normal -y): emission colour from a float image (nearest), strength constant
+    if textured_light:
+        g = abi.GraphData([N(abi.NODE_IMAGE, (2, abi.NODE_NONE, 0)), N(abi.NODE_SPECTRAL_UPLIFT, (0,))], {"emission_color": 1})
+        lm = abi.MaterialData(base_color=(0.8, 0.8, 0.8), ior=1.0, specular_ior_level=0.0, emission_strength=2.0, graph=g)
+    else:
+        lm = abi.MaterialData(base_color=(0.8, 0.8, 0.8), ior=1.0, specular_ior_level=0.0, emission_color=(9.0, 8.0, 7.0), emission_strength=1.0)
+    add(quad([-0.4, 0.98, -0.4], [0.4, 0.98, -0.4], [0.4, 0.98, 0.4], [-0.4, 0.98, 0.4], 2, 2), lm)
+    if alpha_cutout:  # quad at z = 0.2 facing the camera, base colour + alpha from the byte image (clip addressing)
+        g = abi.GraphData([N(abi.NODE_IMAGE, (3, abi.NODE_NONE, 1)), N(abi.NODE_SPECTRAL_UPLIFT, (0,))], {"base_color": 1})
+        add(quad([-0.6, -0.6, 0.2], [0.6, -0.6, 0.2], [0.6, 0.6, 0.2], [-0.6, 0.6, 0.2], 1, 1, 1.2), abi.MaterialData(roughness=0.8, ior=1.0, specular_ior_level=0.0, graph=g))
+    c2w = np.eye(4, dtype=np.float32)
+    c2w[:3, 3] = [0.0, 0.0, 0.95]
+    cam = abi.CameraData(c2w=c2w.T.reshape(16).copy(), fov=1.3, width=width, height=height)
+    return abi.SceneData(meshes, insts, mats, cam, images=images)

@@ -1,0 +1,75 @@
+"""Shader graphs with texture-fed inputs on the GPU: the TEX instantiations of the kernels against
+the oracle, film accumulators bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+from akari_render_amd import abi, capi
+from oracle import pyoracle
+from tests.helpers import make_config, n_bit_diff, textured_room
+from tests.test_gpu_parity import assert_parity, render_both
+
+pytestmark = pytest.mark.gpu
+
+
+def with_table(sd, root):
+    """Both sides read the committed ggx_dielectric_s table (the oracle has no GPU to compute it on)."""
+    sd.ggx_table = np.fromfile(os.path.join(root, "tests", "golden", "ggx_dielectric_s.f32"), dtype=np.float32)
+    return sd
+
+
+def test_node_evaluation_on_device_matches_oracle(ctx):
+    sd = textured_room(alpha_cutout=True)
+    scene = capi.Scene(ctx, sd)
+    osc = pyoracle.OracleScene(sd)
+    rng = np.random.default_rng(4)
+    uv = np.concatenate([rng.uniform(-1.5, 3.0, size=(20000, 2)), [[0, 0], [1, 1], [0.5, 0.5], [1e9, -1e9], [np.nan, 0.3]]]).astype(np.float32)
+    for m in range(len(sd.materials)):
+        d = capi.probe_material_inputs(ctx, scene, m, uv)
+        o = osc.material_inputs(m, uv)
+        h = capi.probe_material_inputs(None, scene, m, uv)
+        assert n_bit_diff(d, o) == 0, f"material {m}: device vs oracle"
+        assert n_bit_diff(d, h) == 0, f"material {m}: device vs host build"
+
+
+@pytest.mark.parametrize("variant", ["exhaustive", "bvh", "cutout", "cutout_bvh", "constant_light"])
+def test_textured_room_parity(ctx, root, variant):
+    sd = with_table(textured_room(48, 48, n_floor=8 if "bvh" in variant else 1, alpha_cutout="cutout" in variant, textured_light=variant != "constant_light"), root)
+    scene = capi.Scene(ctx, sd)
+    assert bool(scene.info().uses_bvh) == ("bvh" in variant)
+    g, o, gst, ost, _, _ = render_both(ctx, sd, make_config(spp=16, spp_per_pass=8, max_depth=8))
+    assert_parity(g, o, 48, 48, gst, ost)
+    # the textures are visible: the floor is not uniform
+    img = (g[: 3 * 48 * 48].reshape(48, 48, 3) / np.maximum(g[6 * 48 * 48 :].reshape(48, 48, 1), 1)).astype(np.float32)
+    assert img[40:, :, :].std() > 0.01
+
+
+def test_textured_room_force_diffuse_keeps_textured_emission_and_alpha(ctx, root):
+    sd = with_table(textured_room(40, 40, alpha_cutout=True), root)
+    g, o, gst, ost, _, _ = render_both(ctx, sd, make_config(spp=8, spp_per_pass=8, max_depth=6, force_diffuse=1))
+    assert_parity(g, o, 40, 40, gst, ost)
+
+
+def test_textured_room_wavefront_schedule(ctx, root, monkeypatch):
+    sd = with_table(textured_room(40, 40, n_floor=8, alpha_cutout=True), root)
+    cfg = make_config(spp=8, spp_per_pass=4, max_depth=8)
+    monkeypatch.setenv("AKR_PT_MODE", "wavefront")
+    g, o, gst, ost, _, _ = render_both(ctx, sd, cfg)
+    assert_parity(g, o, 40, 40, gst, ost)
+
+
+def test_textured_scene_through_the_json_loader(ctx, root, tmp_path):
+    from tests.test_textures import _scene_json_with_textures
+    from oracle import scene_json
+
+    rng = np.random.default_rng(3)
+    from tests.helpers import make_png
+    path = _scene_json_with_textures(tmp_path, make_png(rng.integers(0, 256, size=(5, 6, 3)), 2, 8), rng.random((4, 3, 3)).astype(np.float32))
+    sd = with_table(scene_json.load_scene(path, 40, 30), root)
+    scene = capi.Scene(ctx, sd)  # the library's own reader is compared with this one in tests/test_textures.py
+    film = capi.Film(ctx, 40, 30)
+    cfg = make_config(spp=16, spp_per_pass=16, max_depth=5)
+    gst = capi.pt_render(ctx, scene, cfg, film)
+    o, ost = pyoracle.OracleScene(sd).render(cfg)
+    assert_parity(film.read(), o, 40, 30, gst, ost)

@@ -1,0 +1,325 @@
+"""Shader graphs with texture-fed inputs: PNG reader, sampler, node evaluation, loaders, light tables.
+CPU only: the library's host build of device/dtex.h against the oracle (oracle/or_tex.h) and numpy."""
+import base64
+import json
+import zlib
+
+import numpy as np
+import pytest
+
+from akari_render_amd import abi, capi
+from oracle import pyoracle, scene_json
+
+from tests.helpers import make_png, n_bit_diff, textured_room
+
+
+def ulp_diff(a, b):
+    a = np.asarray(a, dtype=np.float32).view(np.int32).astype(np.int64)
+    b = np.asarray(b, dtype=np.float32).view(np.int32).astype(np.int64)
+    return np.abs(a - b)
+
+
+def test_exp_pow_accuracy():
+    L = pyoracle.lib()
+    xs = np.concatenate([np.linspace(-87.0, 88.0, 4001), np.linspace(-1.0, 1.0, 2001), [-103.0, -100.0, 0.0, 88.7]]).astype(np.float32)
+    got = np.array([L.or_kat_exp(float(x)) for x in xs], dtype=np.float32)
+    want = np.exp(xs.astype(np.float64)).astype(np.float32)
+    ok = np.isfinite(want) & (want > 1e-37)
+    assert ulp_diff(got[ok], want[ok]).max() <= 2
+    assert L.or_kat_exp(float("inf")) == float("inf") and L.or_kat_exp(-200.0) == 0.0 and np.isnan(L.or_kat_exp(float("nan")))
+    # the sRGB decode range
+    s = np.linspace(0.04046, 1.0, 5000).astype(np.float32)
+    base = ((s + np.float32(0.055)) / np.float32(1.055)).astype(np.float32)
+    got = np.array([L.or_kat_pow(float(b), 2.4) for b in base], dtype=np.float32)
+    want = np.power(base.astype(np.float64), 2.4)
+    assert np.max(np.abs(got - want) / want) < 1e-6
+    assert L.or_kat_pow(0.0, 2.4) == 0.0
+
+
+PNG_CASES = [
+    ("rgba8", 6, 8, 4), ("rgb8", 2, 8, 3), ("grey8", 0, 8, 1), ("greya8", 4, 8, 2), ("rgb16", 2, 16, 3), ("rgba16", 6, 16, 4),
+    ("grey16", 0, 16, 1), ("grey1", 0, 1, 1), ("grey2", 0, 2, 1), ("grey4", 0, 4, 1), ("pal8", 3, 8, 1), ("pal4", 3, 4, 1), ("pal2", 3, 2, 1),
+]
+
+
+@pytest.mark.parametrize("name,ctype,depth,ch", PNG_CASES)
+def test_png_reader(name, ctype, depth, ch):
+    rng = np.random.default_rng(hash(name) & 0xFFFF)
+    h, w = 13, 11
+    palette = trns = None
+    if ctype == 3:
+        n_pal = min(1 << depth, 23)
+        palette = rng.integers(0, 256, size=(n_pal, 3), dtype=np.uint8)
+        trns = bytes(rng.integers(0, 256, size=n_pal - 3, dtype=np.uint8))
+        px = rng.integers(0, n_pal, size=(h, w, 1))
+    else:
+        px = rng.integers(0, 1 << depth, size=(h, w, ch))
+    if name == "grey8":
+        trns = bytes([0, int(px[3, 4, 0])])
+    if name == "rgb16":
+        trns = b"".join(int(v).to_bytes(2, "big") for v in px[2, 5])
+    data = make_png(px, ctype, depth, palette=palette, trns=trns)
+    got = capi.host_decode_png(data)
+    ref = scene_json.decode_png(data)
+    assert got.shape == (h, w, 4) and np.array_equal(got, ref)
+    # against the definition
+    to8 = (lambda v: v) if depth == 8 else (lambda v: (v + 128) // 257) if depth == 16 else (lambda v: v * 255 // ((1 << depth) - 1))
+    want = np.full((h, w, 4), 255, dtype=np.int64)
+    if ctype == 3:
+        want[:, :, :3] = palette[px[:, :, 0]]
+        al = np.full(256, 255)
+        al[: len(trns)] = list(trns)
+        want[:, :, 3] = al[px[:, :, 0]]
+    elif ctype == 0:
+        want[:, :, :3] = to8(px[:, :, :1])
+        if trns is not None:
+            want[:, :, 3] = np.where(px[:, :, 0] == int.from_bytes(trns, "big"), 0, 255)
+    elif ctype == 4:
+        want[:, :, :3] = to8(px[:, :, :1])
+        want[:, :, 3] = to8(px[:, :, 1])
+    elif ctype == 2:
+        want[:, :, :3] = to8(px)
+        if trns is not None:
+            key = [int.from_bytes(trns[2 * k : 2 * k + 2], "big") for k in range(3)]
+            want[:, :, 3] = np.where((px[:, :, 0] == key[0]) & (px[:, :, 1] == key[1]) & (px[:, :, 2] == key[2]), 0, 255)
+    else:
+        want[:, :, :] = to8(px)
+    assert np.array_equal(got.astype(np.int64), want)
+
+
+def test_png_reader_stored_and_fixed_blocks_and_errors():
+    px = np.arange(5 * 7 * 3, dtype=np.int64).reshape(5, 7, 3) % 256
+    for level in (0, 1, 9):  # stored blocks, fast (mostly fixed Huffman on tiny inputs), dynamic
+        assert np.array_equal(capi.host_decode_png(make_png(px, 2, 8, level=level))[:, :, :3], px)
+    big = (np.arange(200 * 300 * 4).reshape(200, 300, 4) * 7919 % 251).astype(np.int64)
+    assert np.array_equal(capi.host_decode_png(make_png(big, 6, 8, level=9)), big)
+    with pytest.raises(capi.AkariError):
+        capi.host_decode_png(b"not a png at all")
+    bad = bytearray(make_png(px, 2, 8))
+    bad[60] ^= 0xFF
+    with pytest.raises(capi.AkariError):
+        capi.host_decode_png(bytes(bad))
+
+
+def np_sample(img: abi.ImageData, uv):
+    """float32 restatement of the sampler definition (dtex.h / or_tex.h) in numpy."""
+    t = img.texels
+    h, w = t.shape[:2]
+    f32 = np.float32
+
+    def wrap(i, n):
+        if img.address == abi.TEX_REPEAT:
+            return i % n, True
+        if img.address == abi.TEX_MIRROR:
+            r = i % (2 * n)
+            return (2 * n - 1 - r if r >= n else r), True
+        if img.address == abi.TEX_EXTEND:
+            return min(max(i, 0), n - 1), True
+        return i, 0 <= i < n
+
+    def fetch(i, j):
+        i, oki = wrap(i, w)
+        j, okj = wrap(j, h)
+        if not (oki and okj):
+            return np.zeros(4, dtype=f32)
+        p = t[j, i]
+        return (p.astype(f32) / f32(255.0)).astype(f32) if t.dtype == np.uint8 else p.astype(f32)
+
+    out = []
+    for u, v in np.asarray(uv, dtype=f32):
+        x, y = f32(u * f32(w)), f32(v * f32(h))
+        if img.filter == abi.TEX_FILTER_NEAREST:
+            out.append(fetch(int(np.floor(x)), int(np.floor(y))))
+            continue
+        x, y = f32(x - f32(0.5)), f32(y - f32(0.5))
+        i, j = int(np.floor(x)), int(np.floor(y))
+        tx, ty = f32(x - f32(i)), f32(y - f32(j))
+        lerp = lambda a, b, s: (a + (b - a).astype(f32) * s).astype(f32)  # noqa: E731
+        r0, r1 = lerp(fetch(i, j), fetch(i + 1, j), tx), lerp(fetch(i, j + 1), fetch(i + 1, j + 1), tx)
+        out.append(lerp(r0, r1, ty))
+    return np.array(out, dtype=f32)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("filt", [abi.TEX_FILTER_NEAREST, abi.TEX_FILTER_LINEAR])
+@pytest.mark.parametrize("address", [abi.TEX_REPEAT, abi.TEX_CLIP, abi.TEX_MIRROR, abi.TEX_EXTEND])
+def test_sampler_matches_numpy_definition(dtype, filt, address):
+    rng = np.random.default_rng(5)
+    tex = rng.integers(0, 256, size=(5, 7, 4)).astype(np.uint8) if dtype == np.uint8 else rng.random((5, 7, 4)).astype(np.float32)
+    img = abi.ImageData(tex, filt, address)
+    uv = np.concatenate([rng.uniform(-2.5, 3.5, size=(400, 2)), [[0.0, 0.0], [1.0, 1.0], [0.5 / 7, 0.5 / 5], [-0.0, 2.0], [6.5 / 7, 4.5 / 5]]]).astype(np.float32)
+    got = pyoracle.tex_sample(img, uv)
+    want = np_sample(img, uv)
+    assert n_bit_diff(got, want) == 0
+
+
+def test_graph_evaluation_host_build_matches_oracle():
+    sd = textured_room(alpha_cutout=True)
+    osc = pyoracle.OracleScene(sd)
+    sc = capi.Scene(None, sd)
+    rng = np.random.default_rng(2)
+    uv = np.concatenate([rng.uniform(-1.0, 3.0, size=(2000, 2)), [[0, 0], [1, 1], [0.5, 0.5]]]).astype(np.float32)
+    for m in range(len(sd.materials)):
+        a = capi.probe_material_inputs(None, sc, m, uv)
+        b = osc.material_inputs(m, uv)
+        assert n_bit_diff(a, b) == 0, f"material {m}"
+    # the graph really drives the inputs: floor colour takes both checker colours, roughness varies, metallic is the folded constant
+    fl = capi.probe_material_inputs(None, sc, 0, uv)
+    assert len(np.unique(fl[:, 1])) == 2 and fl[:, 6].std() > 0.05 and np.all(fl[:, 5] == np.float32(0.25))
+    # back wall: sRGB-decoded bytes in [0, 1]; left wall: normal = 2 c - 1 scaled by strength
+    bw = capi.probe_material_inputs(None, sc, 1, uv)
+    assert bw[:, 1:4].min() >= 0.0 and bw[:, 1:4].max() <= 1.0 and bw[:, 1].std() > 0.05
+    lw = capi.probe_material_inputs(None, sc, 2, uv)
+    assert np.all(np.abs(lw[:, 23:25]) <= 0.7 + 1e-6) and lw[:, 25].min() >= -1e-6
+
+
+def test_light_tables_with_textured_emission_match_oracle():
+    sd = textured_room()
+    osc = pyoracle.OracleScene(sd)
+    sc = capi.Scene(None, sd)
+    info = sc.info()
+    assert info.n_lights == osc.num_lights() == 1
+    inst, power, pdf = sc.light(0)
+    oi, op, opdf = osc.light_info(0)
+    assert (inst, np.float32(power).view(np.uint32), np.float32(pdf).view(np.uint32)) == (oi, np.float32(op).view(np.uint32), np.float32(opdf).view(np.uint32))
+    area_pdf = sc.array(9, np.float32)  # AKR_ARRAY_AREA_PDF
+    assert area_pdf.size == 8 and abs(float(area_pdf.sum()) - 1.0) < 1e-5 and area_pdf.std() > 1e-3  # the texture modulates the per-triangle power
+
+
+def _scene_json_with_textures(tmp_path, png_bytes, float_img):
+    """A two-quad scene in the reference's scene-graph format whose materials use image / checkerboard / mapping /
+    separate_color / normal_map nodes, with base64 and binary buffers."""
+    verts = np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1], [-1, 0.5, -1], [1, 0.5, -1], [1, 2, -1], [-1, 2, -1]], dtype=np.float32)
+    idx = np.array([[0, 1, 2], [0, 2, 3]], dtype=np.uint32)
+    uvs = np.array([[[0, 0], [1, 0], [1, 1]], [[0, 0], [1, 1], [0, 1]]], dtype=np.float32)
+    blob = verts.tobytes() + idx.tobytes() + uvs.tobytes() + np.zeros(1, np.uint32).tobytes()
+    off = [0, verts.nbytes, verts.nbytes + idx.nbytes, verts.nbytes + idx.nbytes + uvs.nbytes]
+
+    def view(buf, o, ln):
+        return {"buffer": {"id": buf}, "offset": o, "length": ln}
+
+    def const_f(v):
+        return {"type": "float", "value": v}
+
+    def principled(nodes, **over):
+        defaults = {"base_color": "c_base", "metallic": "f0", "roughness": "f_half", "ior": "f_ior", "alpha": "f1", "normal": "n0",
+                    "subsurface_weight": "f0", "subsurface_radius": "n0", "subsurface_scale": "f0", "subsurface_ior": "f_ior",
+                    "subsurface_anisotropy": "f0", "specular_ior_level": "f_half", "specular_tint": "c_white", "anisotropic": "f0",
+                    "anisotropic_rotation": "f0", "tangent": "n0", "transmission_weight": "f0", "sheen_weight": "f0", "sheen_tint": "c_white",
+                    "coat_weight": "f0", "coat_roughness": "f0", "coat_ior": "f_ior", "coat_tint": "c_white", "coat_normal": "n0",
+                    "emission_color": "c_black", "emission_strength": "f0"}
+        defaults.update(over)
+        nodes.update({"f0": const_f(0.0), "f1": const_f(1.0), "f_half": const_f(0.5), "f_ior": const_f(1.45), "n0": {"type": "float3", "value": [0, 0, 0]},
+                      "rgb_base": {"type": "rgb", "value": [0.8, 0.7, 0.6], "colorspace": "srgb"}, "c_base": {"type": "spectral_uplift", "rgb": {"id": "rgb_base"}},
+                      "rgb_white": {"type": "rgb", "value": [1, 1, 1], "colorspace": "srgb"}, "c_white": {"type": "spectral_uplift", "rgb": {"id": "rgb_white"}},
+                      "rgb_black": {"type": "rgb", "value": [0, 0, 0], "colorspace": "srgb"}, "c_black": {"type": "spectral_uplift", "rgb": {"id": "rgb_black"}}})
+        p = {"type": "principled"}
+        p.update({k: {"id": v} for k, v in defaults.items()})
+        nodes["bsdf"] = p
+        nodes["out"] = {"type": "output", "node": {"id": "bsdf"}}
+        return {"shader": {"kind": "surface", "nodes": nodes, "output": {"id": "out"}}}
+
+    png_image = {"data": {"id": "v_png"}, "format": "png", "colorspace": "srgb", "extension": "repeat", "interpolation": "cubic",
+                 "width": 6, "height": 5, "channels": 3}
+    flt_image = {"data": {"id": "v_flt"}, "format": "float", "colorspace": "none", "extension": "mirror", "interpolation": "nearest",
+                 "width": float_img.shape[1], "height": float_img.shape[0], "channels": float_img.shape[2]}
+    m_floor = principled({
+        "tc": {"type": "texcoords"}, "tc_uv": {"type": "extract", "node": {"id": "tc"}, "field": "UV"},
+        "loc": {"type": "float3", "value": [0.25, 0.5, 0]}, "rot": {"type": "float3", "value": [0, 0, 0]}, "scl": {"type": "float3", "value": [2, 3, 1]},
+        "map": {"type": "mapping", "vector": {"id": "tc_uv"}, "mapping": "point", "location": {"id": "loc"}, "rotation": {"id": "rot"}, "scale": {"id": "scl"}},
+        "img": {"type": "image", "image": png_image, "uv": {"id": "map"}}, "img_c": {"type": "spectral_uplift", "rgb": {"id": "img"}},
+        "img2": {"type": "image", "image": flt_image}, "sep": {"type": "separate_color", "mode": "rgb", "color": {"id": "img2"}},
+        "rough": {"type": "extract", "node": {"id": "sep"}, "field": "Blue"},
+        "nm_s": const_f(0.5), "nm": {"type": "normal_map", "normal": {"id": "img2"}, "strength": {"id": "nm_s"}, "space": "tangent"},
+    }, base_color="img_c", roughness="rough", normal="nm")
+    m_wall = principled({
+        "cs": const_f(4.0), "chk": {"type": "checkerboard", "vector": None, "scale": {"id": "cs"}, "color1": {"id": "c_base"}, "color2": {"id": "c_black"}},
+        "img": {"type": "image", "image": png_image}, "img_c": {"type": "spectral_uplift", "rgb": {"id": "img"}},
+        "es": const_f(3.0),
+    }, base_color="chk", emission_color="img_c", emission_strength="es")
+    trs = {"type": "trs", "data": {"translation": [0, 0, 0], "rotation": [0, 0, 0], "scale": [1, 1, 1], "coordinate_system": "Akari"}}
+    scene = {
+        "camera": {"type": "perspective", "data": {"transform": {"type": "trs", "data": {"translation": [0, 1, 3], "rotation": [0, 0, 0], "scale": [1, 1, 1], "coordinate_system": "Akari"}},
+                                                  "fov": 50.0, "focal_distance": 1.0, "fstop": 2.8, "sensor_width": 40, "sensor_height": 30}},
+        "instances": {"a_floor": {"geometry": {"id": "g_floor"}, "transform": trs, "materials": [{"id": "m_floor"}]},
+                      "b_wall": {"geometry": {"id": "g_wall"}, "transform": trs, "materials": [{"id": "m_wall"}]}},
+        "geometries": {"g_floor": {"type": "mesh", "vertices": {"id": "v_pos0"}, "indices": {"id": "v_idx"}, "uvs": {"id": "v_uv"}, "materials": {"id": "v_slot"}},
+                       "g_wall": {"type": "mesh", "vertices": {"id": "v_pos1"}, "indices": {"id": "v_idx"}, "uvs": {"id": "v_uv"}, "materials": {"id": "v_slot"}}},
+        "materials": {"m_floor": m_floor, "m_wall": m_wall},
+        "lights": {}, "images": {},
+        "buffers": {"b_geo": {"type": "base64", "data": base64.b64encode(blob).decode(), "length": len(blob)},
+                    "b_png": {"type": "binary", "data": list(png_bytes), "length": len(png_bytes)},
+                    "b_flt": {"type": "base64", "data": base64.b64encode(float_img.tobytes()).decode(), "length": float_img.nbytes}},
+        "buffer_views": {"v_pos0": view("b_geo", 0, 48), "v_pos1": view("b_geo", 48, 48), "v_idx": view("b_geo", off[1], idx.nbytes),
+                         "v_uv": view("b_geo", off[2], uvs.nbytes), "v_slot": view("b_geo", off[3], 4),
+                         "v_png": view("b_png", 0, len(png_bytes)), "v_flt": view("b_flt", 0, float_img.nbytes)},
+    }
+    path = tmp_path / "scene.json"
+    path.write_text(json.dumps(scene))
+    return str(path)
+
+
+def test_scene_loader_reads_shader_graphs_and_images(tmp_path):
+    rng = np.random.default_rng(9)
+    px = rng.integers(0, 256, size=(5, 6, 3))
+    png = make_png(px, 2, 8)
+    fimg = rng.random((4, 3, 3)).astype(np.float32)
+    path = _scene_json_with_textures(tmp_path, png, fimg)
+    ref = scene_json.load_scene(path)
+    sc = capi.Scene(None, path)
+    got = sc.to_scene_data()
+    assert len(got.images) == len(ref.images) == 2
+    for a, b in zip(got.images, ref.images):
+        assert a.texels.dtype == b.texels.dtype and np.array_equal(a.texels, b.texels) and (a.filter, a.address) == (b.filter, b.address)
+    # png: flipped vertically, alpha 255, "cubic" -> linear; float: not flipped, alpha 1
+    ipng = [im for im in got.images if im.texels.dtype == np.uint8][0]
+    assert np.array_equal(ipng.texels[:, :, :3], px[::-1]) and np.all(ipng.texels[:, :, 3] == 255) and ipng.filter == abi.TEX_FILTER_LINEAR
+    iflt = [im for im in got.images if im.texels.dtype == np.float32][0]
+    assert np.array_equal(iflt.texels[:, :, :3], fimg) and np.all(iflt.texels[:, :, 3] == 1.0) and iflt.address == abi.TEX_MIRROR
+    for mg, mr in zip(got.materials, ref.materials):
+        assert (mg.graph is None) == (mr.graph is None)
+        assert mg.graph.inputs == mr.graph.inputs
+        assert len(mg.graph.nodes) == len(mr.graph.nodes)
+        for x, y in zip(mg.graph.nodes, mr.graph.nodes):
+            na = {abi.NODE_CONST: 0, abi.NODE_RGB: 0, abi.NODE_TEXCOORDS: 0, abi.NODE_IMAGE: 3, abi.NODE_MAPPING: 4, abi.NODE_CHECKERBOARD: 4,
+                  abi.NODE_SPECTRAL_UPLIFT: 1, abi.NODE_SEPARATE_COLOR: 1, abi.NODE_EXTRACT: 2, abi.NODE_NORMAL_MAP: 2}[x.op]
+            pad = lambda t: tuple(t) + (abi.NODE_NONE,) * (4 - len(t))  # noqa: E731
+            assert x.op == y.op and pad(x.args)[:na] == pad(y.args)[:na]
+            assert np.array_equal(np.float32(x.k), np.float32(y.k))
+        for f in ("kind", "base_alpha", "metallic", "ior", "specular_ior_level", "emission_strength"):
+            assert np.float32(getattr(mg, f)) == np.float32(getattr(mr, f)), f
+    assert set(got.materials[0].graph.inputs) == {"base_color", "roughness", "normal"}
+    assert set(got.materials[1].graph.inputs) == {"base_color", "emission_color"}  # the constant strength was folded
+    assert got.materials[1].emission_strength == 3.0
+    # both loaders drive identical evaluations
+    osc = pyoracle.OracleScene(ref)
+    uv = rng.uniform(-1, 2, size=(500, 2)).astype(np.float32)
+    for m in range(2):
+        assert n_bit_diff(capi.probe_material_inputs(None, sc, m, uv), osc.material_inputs(m, uv)) == 0
+    # the wall became a light through its textured emission
+    assert sc.info().n_lights == 1 and osc.num_lights() == 1
+    assert np.float32(sc.light(0)[1]).view(np.uint32) == np.float32(osc.light_info(0)[1]).view(np.uint32)
+
+
+def test_loader_rejects_unsupported_texture_inputs(tmp_path):
+    rng = np.random.default_rng(1)
+    path = _scene_json_with_textures(tmp_path, make_png(rng.integers(0, 256, size=(5, 6, 3)), 2, 8), rng.random((4, 3, 3)).astype(np.float32))
+    scene = json.loads(open(path).read())
+    nodes = scene["materials"]["m_wall"]["shader"]["nodes"]
+    nodes["img"]["image"]["format"] = "jpeg"
+    bad = tmp_path / "bad.json"
+    bad.write_text(json.dumps(scene))
+    with pytest.raises(capi.AkariError) as e:
+        capi.Scene(None, str(bad))
+    assert "jpeg" in str(e.value) and e.value.code == -6  # AKR_ERR_UNSUPPORTED
+
+
+def test_graph_validation_errors():
+    sd = textured_room()
+    sd.materials[0].graph.nodes[5] = abi.NodeData(abi.NODE_CHECKERBOARD, (abi.NODE_NONE, 7, 1, 3))  # forward reference
+    with pytest.raises(capi.AkariError):
+        capi.Scene(None, sd)
+    sd = textured_room()
+    sd.materials[1].graph.nodes[5] = abi.NodeData(abi.NODE_IMAGE, (17, 4, 1))  # image index out of range
+    with pytest.raises(capi.AkariError):
+        capi.Scene(None, sd)
