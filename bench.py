@@ -122,6 +122,13 @@ def main():
     se = capi.PtSession(ctx, scene, cfg, film)
     if args.warmup > 0:
         se.passes(args.warmup, blocking=True)
+    if world > 1 and args.backend == "nccl":
+        # warm the collective up too (RCCL builds its rings / proxy connections on the first reduce of a given size):
+        # same message size as the film, on a scratch tensor, outside the timed region
+        scratch = torch.zeros_like(film_t)
+        distributed.reduce_film(scratch, dst=0)
+        torch.cuda.synchronize(dev)
+        del scratch
     s0 = se.stats()
 
     def sync():
