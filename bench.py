@@ -6,8 +6,12 @@ pt.rs:1126-1133).
     python bench.py --gpus 1 --steps 16 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0. With N > 1 the same frame is sharded by pixel tiles over the ranks (strong
-scaling) and the per-rank films are sum-reduced onto rank 0 over RCCL inside the timed region.
+Prints ONE JSON line on rank 0. The path shards by independent units -- pixels and sample sets -- with no collective in
+the render itself. N > 1, default (--scaling weak, per-GPU work fixed): every GPU renders the whole frame with its own
+sampler seed, i.e. N independent sample sets of the same workload (N x 1024 spp at N GPUs, the spp of BASELINE's 8-GPU
+config), and the films are sum-reduced onto rank 0 over RCCL inside the timed region. --scaling strong shards the ONE
+frame's 32x32 pixel tiles over the ranks instead (same image for every N; DESIGN.md section 5 explains why its
+efficiency is bounded by the per-pixel sequential sample streams: ~0.75 at 8 GPUs for 1080p).
 """
 import argparse
 import json
@@ -85,6 +89,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--full-graph", action="store_true", help="configs[2]: full Cycles-subset shader graph instead of force_diffuse")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = every GPU renders the whole 1080p frame with its own sampler seed (N independent sample "
+                         "sets, N x the samples; per-GPU work fixed), films sum-reduced; strong = the one frame's 32x32 pixel "
+                         "tiles round-robin over the GPUs (identical image for every N)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only for smoke-testing the "
                          "multi-rank path on a box with fewer GPUs than ranks: all ranks then share device 0)")
@@ -116,8 +124,12 @@ def main():
     cfg.spp_per_pass, cfg.max_depth, cfg.rr_depth, cfg.use_nee = SPP_PER_PASS, 12, 5, 1
     cfg.force_diffuse = 0 if args.full_graph else 1
     cfg.filter_type, cfg.filter_radius = abi.FILTER_GAUSSIAN, 1.5
-    cfg.sampler_seed = 0
-    cfg = distributed.shard_config(cfg, rank, world)
+    weak = world > 1 and args.scaling == "weak"
+    if weak:
+        cfg.sampler_seed = rank  # independent sample set per GPU (sampler/mod.rs:148-160 seeds the per-pixel streams from it)
+    else:
+        cfg.sampler_seed = 0
+        cfg = distributed.shard_config(cfg, rank, world)
 
     se = capi.PtSession(ctx, scene, cfg, film)
     if args.warmup > 0:
@@ -165,12 +177,13 @@ def main():
         total_samples = int(c[0].item())
     else:
         total_samples = d["n_samples"]
-    assert total_samples == W * H * SPP_PER_PASS * args.steps, (total_samples, W * H * SPP_PER_PASS * args.steps)
+    n_sets = world if weak else 1
+    assert total_samples == n_sets * W * H * SPP_PER_PASS * args.steps, (total_samples, n_sets * W * H * SPP_PER_PASS * args.steps)
 
     if rank == 0:
         # frame sanity inside the bench: every pixel got its samples, film finite
         wsum = float(film_t[6 * W * H :].sum().item())
-        assert wsum == float(W * H) * (args.warmup + args.steps) * SPP_PER_PASS, wsum
+        assert wsum == float(n_sets * W * H) * (args.warmup + args.steps) * SPP_PER_PASS, wsum
         assert bool(torch.isfinite(film_t).all().item())
         # dominant kernel (k_pt_pass) of THIS rank: algorithmic bytes per launch / average launch duration (HIP events
         # recorded around each launch on the context's stream)
@@ -187,15 +200,17 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic: scenes/cbox (36 triangles, reference scene data) at 1920x1080, independent sampler seed 0",
+            "data": "synthetic: scenes/cbox (36 triangles, reference scene data) at 1920x1080, independent sampler, seed " + ("= rank" if weak else "0"),
             "config": {
                 "workload": ("cbox 1920x1080, full Cycles-subset shader graph" if args.full_graph else "cbox 1920x1080, diffuse-only BSDF (force_diffuse)")
                             + f", {SPP_PER_PASS} spp per step, max_depth 12, rr_depth 5, NEE, gaussian filter r=1.5",
-                "spp_total": args.steps * SPP_PER_PASS,
-                "parallelism": f"pixel tiles 32x32 round-robin over {args.gpus} GPU(s), film sum-reduce (RCCL)" if args.gpus > 1 else "single GPU",
+                "spp_total": args.steps * SPP_PER_PASS * n_sets,
+                "parallelism": ("single GPU" if args.gpus == 1 else
+                                f"{args.gpus} independent sample sets of {args.steps * SPP_PER_PASS} spp (sampler seed = rank), one per GPU, films sum-reduced (RCCL)" if weak else
+                                f"pixel tiles 32x32 round-robin over {args.gpus} GPU(s), film sum-reduce (RCCL)"),
             },
             "roofline": {
                 "bound": "hbm",
