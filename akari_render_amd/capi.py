@@ -35,7 +35,7 @@ EXPORTS = [
     "akr_pt_read_sampler_states",
     "akr_host_stdrng_u64", "akr_host_chacha_block", "akr_host_pcg32_states", "akr_host_pcg_start", "akr_host_alias_table",
     "akr_probe_math", "akr_probe_bsdf", "akr_probe_intersect", "akr_probe_surface_interaction", "akr_probe_material_inputs",
-    "akr_host_decode_png",
+    "akr_host_decode_png", "akr_host_decode_jpeg",
 ]
 
 
@@ -122,6 +122,7 @@ def lib() -> C.CDLL:
     proto("akr_probe_surface_interaction", vp, vp, u32, up, fp, fp)
     proto("akr_probe_material_inputs", vp, vp, u32, u32, fp, fp)
     proto("akr_host_decode_png", C.c_char_p, u64, up, up, C.POINTER(C.c_uint8), u64)
+    proto("akr_host_decode_jpeg", C.c_char_p, u64, up, up, C.POINTER(C.c_uint8), u64)
     _lib = L
     return L
 
@@ -479,10 +480,19 @@ def probe_material_inputs(ctx: Optional[Context], scene: Scene, material: int, u
     return out
 
 
+def _host_decode(fn, data: bytes) -> np.ndarray:
+    w, h = C.c_uint32(), C.c_uint32()
+    check(fn(data, len(data), C.byref(w), C.byref(h), None, 0))
+    out = np.zeros((h.value, w.value, 4), dtype=np.uint8)
+    check(fn(data, len(data), C.byref(w), C.byref(h), out.ctypes.data_as(C.POINTER(C.c_uint8)), out.size))
+    return out
+
+
 def host_decode_png(data: bytes) -> np.ndarray:
     """PNG -> (H, W, 4) uint8 in file order (top row first), the image crate's to_rgba8 conventions."""
-    w, h = C.c_uint32(), C.c_uint32()
-    check(lib().akr_host_decode_png(data, len(data), C.byref(w), C.byref(h), None, 0))
-    out = np.zeros((h.value, w.value, 4), dtype=np.uint8)
-    check(lib().akr_host_decode_png(data, len(data), C.byref(w), C.byref(h), out.ctypes.data_as(C.POINTER(C.c_uint8)), out.size))
-    return out
+    return _host_decode(lib().akr_host_decode_png, data)
+
+
+def host_decode_jpeg(data: bytes) -> np.ndarray:
+    """JPEG -> (H, W, 4) uint8 in file order."""
+    return _host_decode(lib().akr_host_decode_jpeg, data)

@@ -5,6 +5,7 @@
 #include <sys/stat.h>
 
 #include <cmath>
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <cstdio>
@@ -417,6 +418,525 @@ void decode_png(const uint8_t* data, size_t n, uint32_t& w, uint32_t& h, std::ve
                     o[3] = 0;
             } else {
                 for (int c = 0; c < 4; c++) o[c] = to8(sample(row, 4 * (size_t)x + c));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ JPEG reader
+// Baseline / extended-sequential and progressive Huffman JPEG, 8 bit, grey or three components with any sampling
+// factors, restart intervals. What `image::io::Reader::decode().to_rgba8()` yields for a JPEG texture in the reference
+// comes from the jpeg-decoder crate (0.3.0 per Cargo.lock), whose integer IDCT, triangle-filter chroma upsampling and
+// fixed-point YCbCr conversion follow the well-known public-domain formulation (12-bit constants, 10/17-bit descaling;
+// (3a + b + 2) >> 2 upsampling; 20-bit BT.601). The same formulation is used here; bit parity with that crate is
+// UNPINNED (its source is not in the mount). Rows in file order.
+namespace {
+struct JpegHuff {
+    uint8_t fast[512];
+    uint16_t code[256];
+    uint8_t values[256], size[257];
+    uint32_t maxcode[18];
+    int delta[17];
+    bool present = false;
+    void build(const uint8_t* counts, const uint8_t* vals, int nvals) {
+        int k = 0;
+        for (int i = 0; i < 16; i++)
+            for (int j = 0; j < counts[i]; j++) size[k++] = (uint8_t)(i + 1);
+        size[k] = 0;
+        if (k != nvals || k > 256) throw std::runtime_error("jpeg: bad Huffman table");
+        std::memcpy(values, vals, (size_t)nvals);
+        int c = 0;
+        k = 0;
+        for (int j = 1; j <= 16; j++) {
+            delta[j] = k - c;
+            if (size[k] == j) {
+                while (size[k] == j) code[k++] = (uint16_t)(c++);
+                if (c - 1 >= (1 << j)) throw std::runtime_error("jpeg: bad Huffman code lengths");
+            }
+            maxcode[j] = (uint32_t)c << (16 - j);
+            c <<= 1;
+        }
+        maxcode[17] = 0xffffffffu;
+        std::memset(fast, 255, sizeof fast);
+        for (int i = 0; i < k; i++) {
+            int s = size[i];
+            if (s <= 9) {
+                int c0 = code[i] << (9 - s), m = 1 << (9 - s);
+                for (int j = 0; j < m; j++) fast[c0 + j] = (uint8_t)i;
+            }
+        }
+        present = true;
+    }
+};
+struct JpegBits {
+    const uint8_t* p;
+    size_t n, pos;
+    uint32_t buf = 0;
+    int cnt = 0;
+    uint8_t marker = 0;  // a marker met while filling (0 = none)
+    bool nomore = false;
+    void reset() { buf = 0; cnt = 0; marker = 0; nomore = false; }
+    void grow() {
+        do {
+            uint32_t b = 0;
+            if (!nomore && pos < n) {
+                b = p[pos++];
+                if (b == 0xff) {
+                    uint8_t c = pos < n ? p[pos++] : 0xd9;
+                    while (c == 0xff && pos < n) c = p[pos++];
+                    if (c != 0) {
+                        marker = c;
+                        nomore = true;
+                        b = 0;
+                    }
+                }
+            }
+            buf |= b << (24 - cnt);
+            cnt += 8;
+        } while (cnt <= 24);
+    }
+    int huff(const JpegHuff& h) {
+        if (cnt < 16) grow();
+        int c = (int)((buf >> 23) & 511u);
+        int k = h.fast[c];
+        if (k < 255) {
+            int s = h.size[k];
+            if (s > cnt) throw std::runtime_error("jpeg: truncated entropy data");
+            buf <<= s;
+            cnt -= s;
+            return h.values[k];
+        }
+        uint32_t temp = buf >> 16;
+        int s;
+        for (s = 10;; s++)
+            if (temp < h.maxcode[s]) break;
+        if (s >= 17 || s > cnt) throw std::runtime_error("jpeg: bad Huffman code");
+        int idx = (int)((buf >> (32 - s)) & ((1u << s) - 1u)) + h.delta[s];
+        if (idx < 0 || idx > 255) throw std::runtime_error("jpeg: bad Huffman code");
+        buf <<= s;
+        cnt -= s;
+        return h.values[idx];
+    }
+    int extend(int n_) {  // receive n bits and sign-extend (JPEG F.2.2.1)
+        if (n_ == 0) return 0;
+        if (cnt < n_) grow();
+        uint32_t v = buf >> (32 - n_);
+        buf <<= n_;
+        cnt -= n_;
+        int sgn = (int)(v >> (n_ - 1));  // 1 = positive
+        return sgn ? (int)v : (int)v - ((1 << n_) - 1);
+    }
+    int bits(int n_) {
+        if (n_ == 0) return 0;
+        if (cnt < n_) grow();
+        uint32_t v = buf >> (32 - n_);
+        buf <<= n_;
+        cnt -= n_;
+        return (int)v;
+    }
+    int bit() { return bits(1); }
+};
+const uint8_t kZigzag[64 + 15] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,
+                                  6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31,
+                                  39, 46, 53, 60, 61, 54, 47, 55, 62, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63};
+struct JpegComp {
+    int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
+    int bw = 0, bh = 0;  // blocks per row / column (padded to whole MCUs)
+    int dc_pred = 0;
+    std::vector<int16_t> coef;  // 64 per block
+    std::vector<uint8_t> plane; // bw*8 x bh*8 after the IDCT
+};
+inline uint8_t clamp8(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+#define AKR_F2F(x) ((int)(((x) * 4096 + 0.5)))
+#define AKR_FSH(x) ((x) * 4096)
+#define AKR_IDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7)                         \
+    int t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                  \
+    p2 = s2; p3 = s6;                                                        \
+    p1 = (p2 + p3) * AKR_F2F(0.5411961f);                                    \
+    t2 = p1 + p3 * AKR_F2F(-1.847759065f);                                   \
+    t3 = p1 + p2 * AKR_F2F(0.765366865f);                                    \
+    p2 = s0; p3 = s4;                                                        \
+    t0 = AKR_FSH(p2 + p3); t1 = AKR_FSH(p2 - p3);                            \
+    x0 = t0 + t3; x3 = t0 - t3; x1 = t1 + t2; x2 = t1 - t2;                  \
+    t0 = s7; t1 = s5; t2 = s3; t3 = s1;                                      \
+    p3 = t0 + t2; p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2;                  \
+    p5 = (p3 + p4) * AKR_F2F(1.175875602f);                                  \
+    t0 = t0 * AKR_F2F(0.298631336f); t1 = t1 * AKR_F2F(2.053119869f);        \
+    t2 = t2 * AKR_F2F(3.072711026f); t3 = t3 * AKR_F2F(1.501321110f);        \
+    p1 = p5 + p1 * AKR_F2F(-0.899976223f); p2 = p5 + p2 * AKR_F2F(-2.562915447f); \
+    p3 = p3 * AKR_F2F(-1.961570560f); p4 = p4 * AKR_F2F(-0.390180644f);      \
+    t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
+void idct_block(uint8_t* out, int stride, const int16_t* coef, const uint16_t* q) {
+    int val[64], *v = val, d[64];
+    for (int i = 0; i < 64; i++) d[i] = coef[i] * (int)q[i];
+    const int* dd = d;
+    for (int i = 0; i < 8; i++, dd++, v++) {
+        if (dd[8] == 0 && dd[16] == 0 && dd[24] == 0 && dd[32] == 0 && dd[40] == 0 && dd[48] == 0 && dd[56] == 0) {
+            int dcterm = dd[0] * 4;
+            v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dcterm;
+        } else {
+            AKR_IDCT_1D(dd[0], dd[8], dd[16], dd[24], dd[32], dd[40], dd[48], dd[56])
+            x0 += 512; x1 += 512; x2 += 512; x3 += 512;
+            v[0] = (x0 + t3) >> 10; v[56] = (x0 - t3) >> 10;
+            v[8] = (x1 + t2) >> 10; v[48] = (x1 - t2) >> 10;
+            v[16] = (x2 + t1) >> 10; v[40] = (x2 - t1) >> 10;
+            v[24] = (x3 + t0) >> 10; v[32] = (x3 - t0) >> 10;
+        }
+    }
+    v = val;
+    for (int i = 0; i < 8; i++, v += 8, out += stride) {
+        AKR_IDCT_1D(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])
+        x0 += 65536 + (128 << 17); x1 += 65536 + (128 << 17); x2 += 65536 + (128 << 17); x3 += 65536 + (128 << 17);
+        out[0] = clamp8((x0 + t3) >> 17); out[7] = clamp8((x0 - t3) >> 17);
+        out[1] = clamp8((x1 + t2) >> 17); out[6] = clamp8((x1 - t2) >> 17);
+        out[2] = clamp8((x2 + t1) >> 17); out[5] = clamp8((x2 - t1) >> 17);
+        out[3] = clamp8((x3 + t0) >> 17); out[4] = clamp8((x3 - t0) >> 17);
+    }
+}
+#undef AKR_IDCT_1D
+// triangle-filter upsampling of one output row
+void upsample_h2(uint8_t* out, const uint8_t* in, int w) {  // w input samples -> 2w
+    if (w == 1) { out[0] = out[1] = in[0]; return; }
+    out[0] = in[0];
+    out[1] = (uint8_t)((in[0] * 3 + in[1] + 2) >> 2);
+    int i;
+    for (i = 1; i < w - 1; i++) {
+        int n = 3 * in[i] + 2;
+        out[i * 2 + 0] = (uint8_t)((n + in[i - 1]) >> 2);
+        out[i * 2 + 1] = (uint8_t)((n + in[i + 1]) >> 2);
+    }
+    out[i * 2 + 0] = (uint8_t)((in[w - 1] * 3 + in[w - 2] + 2) >> 2);
+    out[i * 2 + 1] = in[w - 1];
+}
+void upsample_v2(uint8_t* out, const uint8_t* near_, const uint8_t* far_, int w) {
+    for (int i = 0; i < w; i++) out[i] = (uint8_t)((3 * near_[i] + far_[i] + 2) >> 2);
+}
+void upsample_hv2(uint8_t* out, const uint8_t* near_, const uint8_t* far_, int w) {
+    if (w == 1) { out[0] = out[1] = (uint8_t)((3 * near_[0] + far_[0] + 2) >> 2); return; }
+    int t0, t1 = 3 * near_[0] + far_[0];
+    out[0] = (uint8_t)((t1 + 2) >> 2);
+    for (int i = 1; i < w; i++) {
+        t0 = t1;
+        t1 = 3 * near_[i] + far_[i];
+        out[i * 2 - 1] = (uint8_t)((3 * t0 + t1 + 8) >> 4);
+        out[i * 2] = (uint8_t)((3 * t1 + t0 + 8) >> 4);
+    }
+    out[w * 2 - 1] = (uint8_t)((t1 + 2) >> 2);
+}
+}  // namespace
+
+void decode_jpeg(const uint8_t* data, size_t n, uint32_t& width, uint32_t& height, std::vector<uint8_t>& rgba) {
+    if (n < 4 || data[0] != 0xff || data[1] != 0xd8) throw std::runtime_error("jpeg: bad signature");
+    size_t pos = 2;
+    uint16_t qt[4][64];
+    bool qt_present[4] = {false, false, false, false};
+    JpegHuff hdc[4], hac[4];
+    std::vector<JpegComp> comps;
+    bool progressive = false, have_frame = false;
+    int hmax = 1, vmax = 1, mcux = 0, mcuy = 0, restart_interval = 0;
+    int adobe_transform = -1;
+    int eobrun = 0;
+    auto be16 = [&](size_t p) -> int {
+        if (p + 2 > n) throw std::runtime_error("jpeg: truncated");
+        return (data[p] << 8) | data[p + 1];
+    };
+    for (;;) {
+        // next marker
+        while (pos < n && data[pos] != 0xff) pos++;
+        while (pos < n && data[pos] == 0xff) pos++;
+        if (pos >= n) break;
+        uint8_t m = data[pos++];
+        if (m == 0xd9) break;                      // EOI
+        if (m == 0x01 || (m >= 0xd0 && m <= 0xd7)) continue;  // TEM, stray RSTn
+        int len = be16(pos);
+        if (len < 2 || pos + (size_t)len > n) throw std::runtime_error("jpeg: bad segment length");
+        const uint8_t* seg = data + pos + 2;
+        int sl = len - 2;
+        if (m == 0xdb) {  // DQT
+            int i = 0;
+            while (i < sl) {
+                int pq = seg[i] >> 4, tq = seg[i] & 15;
+                i++;
+                if (tq > 3 || pq > 1 || i + 64 * (pq + 1) > sl) throw std::runtime_error("jpeg: bad DQT");
+                for (int k = 0; k < 64; k++) {
+                    qt[tq][kZigzag[k]] = pq ? (uint16_t)((seg[i] << 8) | seg[i + 1]) : seg[i];
+                    i += pq + 1;
+                }
+                qt_present[tq] = true;
+            }
+        } else if (m == 0xc4) {  // DHT
+            int i = 0;
+            while (i < sl) {
+                if (i + 17 > sl) throw std::runtime_error("jpeg: bad DHT");
+                int tc = seg[i] >> 4, th = seg[i] & 15;
+                if (tc > 1 || th > 3) throw std::runtime_error("jpeg: bad DHT");
+                int nv = 0;
+                for (int k = 0; k < 16; k++) nv += seg[i + 1 + k];
+                if (i + 17 + nv > sl || nv > 256) throw std::runtime_error("jpeg: bad DHT");
+                (tc ? hac[th] : hdc[th]).build(seg + i + 1, seg + i + 17, nv);
+                i += 17 + nv;
+            }
+        } else if (m == 0xc0 || m == 0xc1 || m == 0xc2) {  // SOF0/1/2
+            if (have_frame) throw std::runtime_error("jpeg: multiple frames");
+            progressive = m == 0xc2;
+            if (sl < 6 || seg[0] != 8) throw std::runtime_error("unsupported: JPEG sample precision other than 8 bits");
+            height = (uint32_t)((seg[1] << 8) | seg[2]);
+            width = (uint32_t)((seg[3] << 8) | seg[4]);
+            int nc = seg[5];
+            if (width == 0 || height == 0) throw std::runtime_error("jpeg: zero-sized image");
+            if (nc != 1 && nc != 3) throw std::runtime_error("unsupported: JPEG with " + std::to_string(nc) + " components");
+            if (sl < 6 + 3 * nc) throw std::runtime_error("jpeg: bad SOF");
+            comps.resize((size_t)nc);
+            for (int c = 0; c < nc; c++) {
+                comps[c].id = seg[6 + 3 * c];
+                comps[c].h = seg[7 + 3 * c] >> 4;
+                comps[c].v = seg[7 + 3 * c] & 15;
+                comps[c].tq = seg[8 + 3 * c];
+                if (comps[c].h < 1 || comps[c].h > 4 || comps[c].v < 1 || comps[c].v > 4 || comps[c].tq > 3) throw std::runtime_error("jpeg: bad SOF");
+                hmax = std::max(hmax, comps[c].h);
+                vmax = std::max(vmax, comps[c].v);
+            }
+            mcux = ((int)width + 8 * hmax - 1) / (8 * hmax);
+            mcuy = ((int)height + 8 * vmax - 1) / (8 * vmax);
+            for (auto& c : comps) {
+                c.bw = mcux * c.h;
+                c.bh = mcuy * c.v;
+                c.coef.assign((size_t)c.bw * c.bh * 64, 0);
+            }
+            have_frame = true;
+        } else if (m == 0xc3 || (m >= 0xc5 && m <= 0xcf && m != 0xc8 && m != 0xcc)) {
+            throw std::runtime_error("unsupported: JPEG process (lossless / hierarchical / arithmetic coding)");
+        } else if (m == 0xdd) {  // DRI
+            if (sl < 2) throw std::runtime_error("jpeg: bad DRI");
+            restart_interval = (seg[0] << 8) | seg[1];
+        } else if (m == 0xee) {  // APP14 "Adobe"
+            if (sl >= 12 && !std::memcmp(seg, "Adobe", 5)) adobe_transform = seg[11];
+        } else if (m == 0xda) {  // SOS + entropy-coded data
+            if (!have_frame) throw std::runtime_error("jpeg: SOS before SOF");
+            int ns = seg[0];
+            if (ns < 1 || ns > (int)comps.size() || sl < 4 + 2 * ns) throw std::runtime_error("jpeg: bad SOS");
+            int order[3];
+            for (int i = 0; i < ns; i++) {
+                int which = -1;
+                for (size_t c = 0; c < comps.size(); c++)
+                    if (comps[c].id == seg[1 + 2 * i]) which = (int)c;
+                if (which < 0) throw std::runtime_error("jpeg: bad component in SOS");
+                comps[which].td = seg[2 + 2 * i] >> 4;
+                comps[which].ta = seg[2 + 2 * i] & 15;
+                if (comps[which].td > 3 || comps[which].ta > 3) throw std::runtime_error("jpeg: bad table index in SOS");
+                order[i] = which;
+            }
+            int ss = seg[1 + 2 * ns], se = seg[2 + 2 * ns], ah = seg[3 + 2 * ns] >> 4, al = seg[3 + 2 * ns] & 15;
+            if (!progressive) { ss = 0; se = 63; ah = al = 0; }
+            else if (ss > 63 || se > 63 || ss > se || ah > 13 || al > 13 || (ss == 0 && se != 0)) throw std::runtime_error("jpeg: bad progressive scan");
+            JpegBits br{data, n, pos + (size_t)len};
+            for (auto& c : comps) c.dc_pred = 0;
+            eobrun = 0;
+            auto need = [&](const JpegHuff& h) -> const JpegHuff& {
+                if (!h.present) throw std::runtime_error("jpeg: missing Huffman table");
+                return h;
+            };
+            auto decode_block = [&](JpegComp& c, int16_t* blk) {
+                if (!progressive) {
+                    const JpegHuff& dc = need(hdc[c.td]);
+                    const JpegHuff& ac = need(hac[c.ta]);
+                    int t = br.huff(dc);
+                    if (t > 15) throw std::runtime_error("jpeg: bad DC code");
+                    int diff = t ? br.extend(t) : 0;
+                    c.dc_pred += diff;
+                    blk[0] = (int16_t)c.dc_pred;
+                    int k = 1;
+                    do {
+                        int rs = br.huff(ac), s = rs & 15, r = rs >> 4;
+                        if (s == 0) {
+                            if (rs != 0xf0) break;
+                            k += 16;
+                        } else {
+                            k += r;
+                            if (k > 63) throw std::runtime_error("jpeg: bad AC run");
+                            blk[kZigzag[k++]] = (int16_t)br.extend(s);
+                        }
+                    } while (k < 64);
+                } else if (ss == 0) {  // DC scan
+                    if (ah == 0) {
+                        const JpegHuff& dc = need(hdc[c.td]);
+                        int t = br.huff(dc);
+                        if (t > 15) throw std::runtime_error("jpeg: bad DC code");
+                        int diff = t ? br.extend(t) : 0;
+                        c.dc_pred += diff;
+                        blk[0] = (int16_t)(c.dc_pred * (1 << al));
+                    } else if (br.bit()) {
+                        blk[0] = (int16_t)(blk[0] + (1 << al));
+                    }
+                } else if (ah == 0) {  // AC first pass
+                    const JpegHuff& ac = need(hac[c.ta]);
+                    if (eobrun) { eobrun--; return; }
+                    int k = ss;
+                    do {
+                        int rs = br.huff(ac), s = rs & 15, r = rs >> 4;
+                        if (s == 0) {
+                            if (r < 15) {
+                                eobrun = 1 << r;
+                                if (r) eobrun += br.bits(r);
+                                eobrun--;
+                                break;
+                            }
+                            k += 16;
+                        } else {
+                            k += r;
+                            if (k > 63) throw std::runtime_error("jpeg: bad AC run");
+                            blk[kZigzag[k++]] = (int16_t)(br.extend(s) * (1 << al));
+                        }
+                    } while (k <= se);
+                } else {  // AC refinement
+                    const JpegHuff& ac = need(hac[c.ta]);
+                    const int16_t bitv = (int16_t)(1 << al);
+                    auto refine = [&](int16_t* p) {
+                        if (*p != 0 && br.bit() && (*p & bitv) == 0) *p = (int16_t)(*p > 0 ? *p + bitv : *p - bitv);
+                    };
+                    if (eobrun) {
+                        eobrun--;
+                        for (int k = ss; k <= se; k++) refine(&blk[kZigzag[k]]);
+                        return;
+                    }
+                    int k = ss;
+                    do {
+                        int rs = br.huff(ac), s = rs & 15, r = rs >> 4;
+                        int newv = 0;
+                        if (s == 0) {
+                            if (r < 15) {
+                                eobrun = (1 << r) - 1;
+                                if (r) eobrun += br.bits(r);
+                                r = 64;  // force end of block
+                            }
+                        } else {
+                            if (s != 1) throw std::runtime_error("jpeg: bad refinement code");
+                            newv = br.bit() ? bitv : -bitv;
+                        }
+                        while (k <= se) {
+                            int16_t* p = &blk[kZigzag[k++]];
+                            if (*p != 0) {
+                                refine(p);
+                            } else {
+                                if (r == 0) {
+                                    *p = (int16_t)newv;
+                                    break;
+                                }
+                                r--;
+                            }
+                        }
+                    } while (k <= se);
+                }
+            };
+            int todo = restart_interval ? restart_interval : 0x7fffffff;
+            auto restart_check = [&]() {
+                if (--todo <= 0) {
+                    if (br.cnt < 24) br.grow();
+                    // a restart marker must follow
+                    if (!(br.marker >= 0xd0 && br.marker <= 0xd7)) {
+                        // look for it in the byte stream (bits of the current byte are padding)
+                        size_t q = br.pos;
+                        while (q + 1 < n && !(data[q] == 0xff && data[q + 1] >= 0xd0 && data[q + 1] <= 0xd7)) {
+                            if (data[q] == 0xff && data[q + 1] != 0 && data[q + 1] != 0xff) return false;
+                            q++;
+                        }
+                        if (q + 1 >= n) return false;
+                        br.pos = q + 2;
+                    }
+                    br.reset();
+                    for (auto& c : comps) c.dc_pred = 0;
+                    eobrun = 0;
+                    todo = restart_interval;
+                }
+                return true;
+            };
+            bool more = true;
+            if (ns == 1) {  // non-interleaved: the component's own blocks in raster order, without the MCU padding
+                JpegComp& c = comps[order[0]];
+                int w = (((int)width * c.h + hmax - 1) / hmax + 7) >> 3, h = (((int)height * c.v + vmax - 1) / vmax + 7) >> 3;
+                for (int j = 0; j < h && more; j++)
+                    for (int i = 0; i < w && more; i++) {
+                        decode_block(c, &c.coef[64 * ((size_t)j * c.bw + i)]);
+                        more = restart_check();
+                    }
+            } else {
+                for (int j = 0; j < mcuy && more; j++)
+                    for (int i = 0; i < mcux && more; i++) {
+                        for (int k = 0; k < ns; k++) {
+                            JpegComp& c = comps[order[k]];
+                            for (int y = 0; y < c.v; y++)
+                                for (int x = 0; x < c.h; x++)
+                                    decode_block(c, &c.coef[64 * ((size_t)(j * c.v + y) * c.bw + (i * c.h + x))]);
+                        }
+                        more = restart_check();
+                    }
+            }
+            // continue after the entropy-coded segment: at the marker the bit reader ran into, or just scan forward
+            pos = br.pos;
+            if (br.marker) {
+                // step back so that the marker loop sees it again
+                pos = br.pos >= 2 ? br.pos - 2 : 0;
+                while (pos < n && !(data[pos] == 0xff && pos + 1 < n && data[pos + 1] == br.marker)) pos++;
+            }
+            continue;
+        }
+        pos += (size_t)len;
+    }
+    if (!have_frame) throw std::runtime_error("jpeg: no frame");
+    // dequantise + IDCT
+    for (auto& c : comps) {
+        if (!qt_present[c.tq]) throw std::runtime_error("jpeg: missing quantisation table");
+        const int stride = c.bw * 8;
+        c.plane.assign((size_t)stride * c.bh * 8, 0);
+        for (int j = 0; j < c.bh; j++)
+            for (int i = 0; i < c.bw; i++) idct_block(&c.plane[(size_t)j * 8 * stride + (size_t)i * 8], stride, &c.coef[64 * ((size_t)j * c.bw + i)], qt[c.tq]);
+    }
+    // upsample to full resolution, one output row at a time
+    const int W = (int)width, H = (int)height;
+    rgba.assign(4ull * W * H, 255);
+    std::vector<std::vector<uint8_t>> line(comps.size());
+    for (auto& l : line) l.resize((size_t)W + 16 * 4 + 8);
+    bool rgb_direct = comps.size() == 3 && (adobe_transform == 0 || (comps[0].id == 'R' && comps[1].id == 'G' && comps[2].id == 'B'));
+    for (int y = 0; y < H; y++) {
+        for (size_t ci = 0; ci < comps.size(); ci++) {
+            JpegComp& c = comps[ci];
+            const int hs = hmax / c.h, vs = vmax / c.v;
+            const int stride = c.bw * 8;
+            const int cw = (W * c.h + hmax - 1) / hmax, chh = (H * c.v + vmax - 1) / vmax;  // samples of this component
+            uint8_t* out = line[ci].data();
+            if (hmax % c.h || vmax % c.v) throw std::runtime_error("unsupported: JPEG with fractional sampling ratios");
+            if (hs == 1 && vs == 1) {
+                std::memcpy(out, &c.plane[(size_t)y * stride], (size_t)W);
+            } else if ((hs == 2 && vs == 1) || (hs == 1 && vs == 2) || (hs == 2 && vs == 2)) {
+                int sy = vs == 2 ? y >> 1 : y;
+                const uint8_t* near_ = &c.plane[(size_t)sy * stride];
+                const uint8_t* far_ = near_;
+                if (vs == 2) {
+                    int fy = (y & 1) ? sy + 1 : sy - 1;
+                    fy = fy < 0 ? 0 : (fy > chh - 1 ? chh - 1 : fy);
+                    far_ = &c.plane[(size_t)fy * stride];
+                }
+                if (hs == 2 && vs == 1) upsample_h2(out, near_, cw);
+                else if (hs == 1) upsample_v2(out, near_, far_, cw);
+                else upsample_hv2(out, near_, far_, cw);
+            } else {  // other ratios: replication
+                const uint8_t* src = &c.plane[(size_t)(y / vs) * stride];
+                for (int x = 0; x < W; x++) out[x] = src[x / hs];
+            }
+        }
+        uint8_t* o = &rgba[4ull * W * y];
+        if (comps.size() == 1) {
+            for (int x = 0; x < W; x++, o += 4) o[0] = o[1] = o[2] = line[0][x];
+        } else if (rgb_direct) {
+            for (int x = 0; x < W; x++, o += 4) { o[0] = line[0][x]; o[1] = line[1][x]; o[2] = line[2][x]; }
+        } else {
+            for (int x = 0; x < W; x++, o += 4) {  // BT.601, 20-bit fixed point
+                int yf = (line[0][x] << 20) + (1 << 19);
+                int cb = line[1][x] - 128, cr = line[2][x] - 128;
+                int r = yf + cr * (int)(1.40200f * 4096.0f + 0.5f) * 256;
+                int g = yf + (cr * -((int)(0.71414f * 4096.0f + 0.5f) * 256)) + ((cb * -((int)(0.34414f * 4096.0f + 0.5f) * 256)) & (int)0xffff0000);
+                int b = yf + cb * (int)(1.77200f * 4096.0f + 0.5f) * 256;
+                o[0] = clamp8(r >> 20); o[1] = clamp8(g >> 20); o[2] = clamp8(b >> 20);
             }
         }
     }

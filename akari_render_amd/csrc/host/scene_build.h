@@ -95,5 +95,7 @@ std::vector<ParsedTask> parse_render_tasks(const std::string& text, bool allow_s
 void write_image(const std::string& path, const float* rgb, uint32_t w, uint32_t h);
 // PNG -> RGBA8 in file order (image crate `decode().to_rgba8()` conventions); throws std::runtime_error
 void decode_png(const uint8_t* data, size_t n, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba);
+// JPEG (baseline + progressive Huffman, 8 bit, 1 or 3 components) -> RGBA8 in file order
+void decode_jpeg(const uint8_t* data, size_t n, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba);
 
 }  // namespace akr

@@ -270,8 +270,15 @@ struct GraphBuilder {
             hi.words.resize((size_t)pw * ph);
             for (uint32_t y = 0; y < ph; y++)  // flipv (load.rs:596): row 0 of the texture is the bottom row of the file
                 std::memcpy(hi.words.data() + (size_t)y * pw, px.data() + 4ull * pw * (ph - 1 - y), 4ull * pw);
+        } else if (fmt == "jpeg") {
+            uint32_t pw = 0, ph = 0;
+            std::vector<uint8_t> px;
+            decode_jpeg(bytes.data(), bytes.size(), pw, ph, px);
+            hi.width = pw; hi.height = ph; hi.format = AKR_IMAGE_RGBA8;
+            hi.words.resize((size_t)pw * ph);
+            for (uint32_t y = 0; y < ph; y++) std::memcpy(hi.words.data() + (size_t)y * pw, px.data() + 4ull * pw * (ph - 1 - y), 4ull * pw);
         } else {
-            throw std::runtime_error("unsupported: image format '" + fmt + "' (decode it on the host and pass texels through akr_image_desc; float and png are read here)");
+            throw std::runtime_error("unsupported: image format '" + fmt + "' (decode it on the host and pass texels through akr_image_desc; float, png and jpeg are read here)");
         }
         uint32_t idx = (uint32_t)flat.images.size();
         flat.images.push_back(std::move(hi));

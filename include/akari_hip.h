@@ -385,6 +385,9 @@ AKR_API int32_t akr_probe_intersect(akr_context *ctx, akr_scene *scene, uint32_t
 /* The PNG reader of akr_scene_load (8/16-bit, all colour types, tRNS, no interlacing), image crate `to_rgba8` rules
  * (load.rs:583-604). Rows in file order. rgba == NULL: only the size is returned. */
 AKR_API int32_t akr_host_decode_png(const uint8_t *data, uint64_t len, uint32_t *width, uint32_t *height, uint8_t *rgba, uint64_t capacity);
+/* The JPEG reader of akr_scene_load (baseline + progressive Huffman, 8 bit, grey / YCbCr / RGB, any integer sampling
+ * ratios, restart intervals). Same calling convention as akr_host_decode_png. */
+AKR_API int32_t akr_host_decode_jpeg(const uint8_t *data, uint64_t len, uint32_t *width, uint32_t *height, uint8_t *rgba, uint64_t capacity);
 /* Evaluated inputs of `material` (26 words each = akr_material_desc) at n uv points: shader-graph evaluation + texture
  * sampling on the device, or -- ctx == NULL -- the same code on the host. */
 AKR_API int32_t akr_probe_material_inputs(akr_context *ctx, akr_scene *scene, uint32_t material, uint32_t n, const float *uv, float *out26);

@@ -269,6 +269,12 @@ class _Graph:
             tex[:, :, :ch] = src  # load.rs:552-569; not flipped
         elif im["format"] == "png":
             tex = decode_png(raw)[::-1].copy()  # flipv, load.rs:596
+        elif im["format"] == "jpeg":
+            import io
+
+            from PIL import Image  # independent decoder (libjpeg); texels may differ from the library's by a few LSB
+
+            tex = np.asarray(Image.open(io.BytesIO(raw)).convert("RGBA"), dtype=np.uint8)[::-1].copy()
         else:
             raise NotImplementedError(f"image format '{im['format']}'")
         self.images.append(abi.ImageData(tex, filt, address))

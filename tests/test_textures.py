@@ -306,12 +306,12 @@ def test_loader_rejects_unsupported_texture_inputs(tmp_path):
     path = _scene_json_with_textures(tmp_path, make_png(rng.integers(0, 256, size=(5, 6, 3)), 2, 8), rng.random((4, 3, 3)).astype(np.float32))
     scene = json.loads(open(path).read())
     nodes = scene["materials"]["m_wall"]["shader"]["nodes"]
-    nodes["img"]["image"]["format"] = "jpeg"
+    nodes["img"]["image"]["format"] = "tiff"
     bad = tmp_path / "bad.json"
     bad.write_text(json.dumps(scene))
     with pytest.raises(capi.AkariError) as e:
         capi.Scene(None, str(bad))
-    assert "jpeg" in str(e.value) and e.value.code == -6  # AKR_ERR_UNSUPPORTED
+    assert "tiff" in str(e.value) and e.value.code == -6  # AKR_ERR_UNSUPPORTED
 
 
 def test_graph_validation_errors():
@@ -323,3 +323,82 @@ def test_graph_validation_errors():
     sd.materials[1].graph.nodes[5] = abi.NodeData(abi.NODE_IMAGE, (17, 4, 1))  # image index out of range
     with pytest.raises(capi.AkariError):
         capi.Scene(None, sd)
+
+
+# ---------------------------------------------------------------------------------------------- JPEG reader
+def _jpeg_cases():
+    cases = []
+    for (h, w) in [(16, 16), (33, 47), (7, 5)]:
+        for sub in (0, 1, 2):
+            for prog in (False, True):
+                cases.append((h, w, sub, prog, "RGB", {}))
+    cases += [(40, 50, 2, False, "L", {}), (40, 50, 0, True, "L", {}), (70, 90, 2, False, "RGB", {"restart_marker_blocks": 3}),
+              (70, 90, 1, True, "RGB", {"restart_marker_rows": 1}), (31, 29, 2, False, "RGB", {"quality": 30}),
+              (31, 29, 2, True, "RGB", {"quality": 98, "optimize": True}), (24, 40, 0, False, "RGB", {"keep_rgb": True})]
+    return cases
+
+
+def _make_jpeg(h, w, sub, prog, mode, kw, seed=1):
+    import io
+
+    from PIL import Image
+
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 100 * np.sin(x / 7.0) * np.cos(y / 5.0), 128 + 90 * np.cos(x / 11.0 + y / 9.0), 100 + 60 * np.sin((x + y) / 13.0)], -1)
+    img = np.clip(img + rng.normal(0, 6, img.shape), 0, 255).astype(np.uint8)
+    kw = dict(kw)
+    args = dict(quality=kw.pop("quality", 90), subsampling=sub, progressive=prog)
+    args.update(kw)
+    if mode == "L":
+        args.pop("subsampling")
+    buf = io.BytesIO()
+    Image.fromarray(img if mode == "RGB" else img[:, :, 0], mode).save(buf, "JPEG", **args)
+    data = buf.getvalue()
+    ref = np.asarray(Image.open(io.BytesIO(data)).convert("RGBA"))
+    return data, ref
+
+
+@pytest.mark.parametrize("case", _jpeg_cases(), ids=lambda c: f"{c[0]}x{c[1]}-s{c[2]}-{'prog' if c[3] else 'base'}-{c[4]}-{'-'.join(c[5])}")
+def test_jpeg_reader_against_libjpeg(case):
+    """Baseline and progressive files, 4:4:4 / 4:2:2 / 4:2:0, grey, restart intervals, RGB-coded: within 3 LSB of libjpeg
+    (the IDCT and the chroma filter differ in their rounding; parity with the reference's jpeg-decoder crate is unpinned)."""
+    pytest.importorskip("PIL")
+    data, ref = _make_jpeg(*case)
+    got = capi.host_decode_jpeg(data)
+    assert got.shape == ref.shape and np.all(got[:, :, 3] == 255)
+    d = np.abs(got.astype(int) - ref.astype(int))
+    assert d.max() <= 3 and d.mean() < 0.5
+
+
+def test_jpeg_reader_errors():
+    pytest.importorskip("PIL")
+    data, _ = _make_jpeg(33, 47, 2, False, "RGB", {})
+    with pytest.raises(capi.AkariError):
+        capi.host_decode_jpeg(b"\xff\xd8 nothing here")
+    with pytest.raises(capi.AkariError):
+        capi.host_decode_jpeg(data[:3] + data[40:])  # tables cut out
+    for cut in (len(data) // 2, len(data) * 3 // 4, len(data) - 5):  # truncated files: an error or the part that is there, never a crash
+        try:
+            assert capi.host_decode_jpeg(data[:cut]).shape == (33, 47, 4)
+        except capi.AkariError:
+            pass
+
+
+def test_scene_loader_reads_jpeg_textures(tmp_path):
+    pytest.importorskip("PIL")
+    rng = np.random.default_rng(9)
+    data, ref = _make_jpeg(20, 24, 2, True, "RGB", {})
+    path = _scene_json_with_textures(tmp_path, data, rng.random((4, 3, 3)).astype(np.float32))
+    scene = json.loads(open(path).read())
+    for m in ("m_floor", "m_wall"):
+        scene["materials"][m]["shader"]["nodes"]["img"]["image"].update(format="jpeg", width=24, height=20)
+    p2 = tmp_path / "jpeg_scene.json"
+    p2.write_text(json.dumps(scene))
+    got = capi.Scene(None, str(p2)).to_scene_data()
+    pyl = scene_json.load_scene(str(p2))
+    a = [im for im in got.images if im.texels.dtype == np.uint8][0].texels
+    b = [im for im in pyl.images if im.texels.dtype == np.uint8][0].texels
+    assert a.shape == b.shape == (20, 24, 4)
+    assert np.abs(a.astype(int) - b.astype(int)).max() <= 3          # two decoders (this library's, libjpeg)
+    assert np.abs(a.astype(int) - ref[::-1].astype(int)).max() <= 3  # flipped vertically like every encoded image
