@@ -18,12 +18,15 @@ SOURCES = [
     "host/bvh.cpp",
     "host/image_io.cpp",
 ]
-HEADERS = [
-    "kernels.h",
-    "device/dmath.h", "device/drng.h", "device/dgeom.h", "device/dbsdf.h", "device/dscene.h", "device/disect.h", "device/dpath.h",
-    "host/scene_build.h", "host/json.h", "host/stdrng.h",
-    "../../include/akari_hip.h",
-]
+def _headers():
+    """Every header the sources can include: all of csrc/ and the public header (a forgotten entry in a hand-kept list
+    means a stale library that still loads)."""
+    out = []
+    for d, _, files in os.walk(CSRC):
+        out += [os.path.relpath(os.path.join(d, f), CSRC) for f in files if f.endswith(".h")]
+    return sorted(out) + ["../../include/akari_hip.h"]
+
+
 # -ffp-contract=off + correctly rounded div/sqrt: the arithmetic contract of DESIGN.md ("AKR-F32")
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
@@ -38,7 +41,7 @@ def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    for f in SOURCES + HEADERS + ["../build.py"]:
+    for f in SOURCES + _headers() + ["../build.py"]:
         p = os.path.normpath(os.path.join(CSRC, f))
         if os.path.exists(p) and os.path.getmtime(p) > t:
             return True

@@ -36,9 +36,9 @@ AKR_HD bool tri_test(vec3 o, vec3 d, float4 r0, float4 r1, float4 r2, float tmin
 }
 
 // SvmEvalMode::Alpha for a texture-fed base colour (principled.rs:15-21): the graph at the candidate's uv
-// (surface_interaction_for_alpha_test, mesh.rs:426-485), alpha = w of the node feeding base_color. Kept out of line:
-// it is the cold side of a branch inside the traversal loops.
-__device__ __attribute__((noinline)) static float textured_alpha(const DScene& sc, const float4* r, uint32_t material, float u, float v) {
+// (surface_interaction_for_alpha_test, mesh.rs:426-485), alpha = w of the node feeding base_color. Inlined on purpose: a
+// call inside the triangle loop makes the compiler give up the scalar (SGPR) path of the wave-uniform record loads.
+AKR_D float textured_alpha(const DScene& sc, const float4* r, uint32_t material, float u, float v) {
     float w = 1.0f - u - v;
     vec2 uv = mk2((r[0].w * w + r[2].w * u) + r[4].w * v, (r[1].w * w + r[3].w * u) + r[5].w * v);
     const DMaterial& m = sc.materials[material];

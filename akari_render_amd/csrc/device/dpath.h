@@ -283,15 +283,11 @@ AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found,
             terminated = true;  // pt.rs:381-396 (hit_envmap adds zero)
         } else {
             SurfacePoint si = surface_interaction(sc, hit.gid, mk2(hit.u, hit.v));
-            // the material at this point: the folded record, or (TEX kernels, texture-fed inputs) its graph evaluated
-            // at si.uv and folded here
-            DMaterial mat_here;
-            if (TEX) {
-                mat_here = sc.materials[si.material];
-                material_at(sc.tex, si.material, si.uv, mat_here);
-            }
-            const DMaterial& mat = TEX ? mat_here : sc.materials[si.material];
             vec3 wo = -r.rd;
+            // Everything that reads the material, as a function of where the record lives: the folded record in HBM, or --
+            // TEX kernels, texture-fed inputs -- a per-hit record (graph evaluated at si.uv, folded here). Two instantiations
+            // in the TEX kernels: lanes on constant materials keep the register-only path and no 256-byte private copy.
+            auto shade_vertex = [&](const DMaterial& mat) {
             {  // handle_surface_light, pt.rs:230-258
                 vec3 direct = mk3(0, 0, 0);
                 float w = 0.0f;
@@ -358,6 +354,19 @@ AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found,
                         r.ray_ex0 = hit.gid;
                     }
                 }
+            }
+            };  // shade_vertex
+            const DMaterial& folded = sc.materials[si.material];
+            if (TEX) {
+                if (folded.flags & MF_TEXTURED) {
+                    DMaterial mat_here = folded;
+                    material_at(sc.tex, si.material, si.uv, mat_here);
+                    shade_vertex(mat_here);
+                } else {
+                    shade_vertex(folded);
+                }
+            } else {
+                shade_vertex(folded);
             }
         }
         if (terminated) {

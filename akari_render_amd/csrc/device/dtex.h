@@ -31,17 +31,22 @@ struct TexVal {
 };
 AKR_HD TexVal tv(float x, float y, float z, float w) { return TexVal{x, y, z, w}; }
 
-// SamplerAddress (load.rs:684-689): maps a texel index into [0, n) or reports "outside" (Zero)
+// SamplerAddress (load.rs:684-689). Repeat and mirror first reduce the COORDINATE to one period in floating point
+// (u - floor(u); the triangle wave of period 2), so that the texel indices the filter then asks for lie in [-1, n] and
+// wrap with two compares -- no integer division per tap. Edge clamps the index, Zero reports "outside".
+AKR_HD float tex_wrap_coord(float u, uint32_t mode) {
+    if (mode == TEXA_REPEAT) return u - __builtin_floorf(u);
+    if (mode == TEXA_MIRROR) {
+        float t = u - 2.0f * __builtin_floorf(u * 0.5f);  // [0, 2]
+        return t > 1.0f ? 2.0f - t : t;
+    }
+    return u;
+}
 AKR_HD bool tex_wrap(int& i, int n, uint32_t mode) {
     if (mode == TEXA_REPEAT) {
-        i = i % n;
-        if (i < 0) i += n;
-    } else if (mode == TEXA_MIRROR) {
-        int p = 2 * n;
-        i = i % p;
-        if (i < 0) i += p;
-        if (i >= n) i = p - 1 - i;
-    } else if (mode == TEXA_EXTEND) {
+        i = i < 0 ? i + n : (i >= n ? i - n : i);
+        i = i < 0 ? 0 : (i >= n ? n - 1 : i);  // NaN / out-of-range coordinates (never after tex_wrap_coord of a finite u)
+    } else if (mode == TEXA_MIRROR || mode == TEXA_EXTEND) {
         i = i < 0 ? 0 : (i >= n ? n - 1 : i);
     } else {
         if (i < 0 || i >= n) return false;
@@ -68,7 +73,7 @@ AKR_HD int tex_floor_to_int(float x, float& fl) {
 }
 AKR_HD float tex_lerp(float a, float b, float t) { return a + (b - a) * t; }
 AKR_HD TexVal tex_sample(const uint32_t* __restrict__ texels, const DImage& im, vec2 uv) {
-    float x = uv.x * (float)im.width, y = uv.y * (float)im.height;
+    float x = tex_wrap_coord(uv.x, im.address) * (float)im.width, y = tex_wrap_coord(uv.y, im.address) * (float)im.height;
     float fx, fy;
     if (im.filter == TEXF_NEAREST) {
         int i = tex_floor_to_int(x, fx), j = tex_floor_to_int(y, fy);

@@ -13,13 +13,19 @@
 
 typedef struct { float v[4]; } or_val;
 
+/* Repeat / mirror reduce the coordinate to one period first (u - floor(u); triangle wave of period 2): the filter's texel
+ * indices then lie in [-1, n] and wrap without integer division. Edge clamps, Zero reports "outside". */
+static inline float or_tex_wrap_coord(float u, uint32_t mode) {
+    if (mode == OR_TEX_REPEAT) return u - floorf(u);
+    if (mode == OR_TEX_MIRROR) { float t = u - 2.0f * floorf(u * 0.5f); return t > 1.0f ? 2.0f - t : t; }
+    return u;
+}
 static inline int or_tex_wrap(int *i, int n, uint32_t mode) {
-    switch (mode) {
-    case OR_TEX_REPEAT: { int r = *i % n; *i = r < 0 ? r + n : r; return 1; }
-    case OR_TEX_MIRROR: { int p = 2 * n, r = *i % p; if (r < 0) r += p; *i = r >= n ? p - 1 - r : r; return 1; }
-    case OR_TEX_EXTEND: *i = *i < 0 ? 0 : (*i > n - 1 ? n - 1 : *i); return 1;
-    default: return *i >= 0 && *i < n; /* Zero */
-    }
+    int k = *i;
+    if (mode == OR_TEX_CLIP) return k >= 0 && k < n; /* Zero */
+    if (mode == OR_TEX_REPEAT) k = k < 0 ? k + n : (k >= n ? k - n : k);
+    *i = k < 0 ? 0 : (k > n - 1 ? n - 1 : k); /* mirror, edge; repeat: what is still outside (NaN coordinates) */
+    return 1;
 }
 static inline or_val or_tex_fetch(const or_image_desc *im, int i, int j) {
     or_val r = {{0, 0, 0, 0}};
@@ -41,7 +47,7 @@ static inline int or_floor_int(float x, float *fl) {
     return (int)*fl;
 }
 static inline or_val or_tex_sample(const or_image_desc *im, float u, float v) {
-    float x = u * (float)im->width, y = v * (float)im->height, fx, fy;
+    float x = or_tex_wrap_coord(u, im->address) * (float)im->width, y = or_tex_wrap_coord(v, im->address) * (float)im->height, fx, fy;
     if (im->filter == OR_TEX_NEAREST) {
         int i = or_floor_int(x, &fx), j = or_floor_int(y, &fy);
         return or_tex_fetch(im, i, j);

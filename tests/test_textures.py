@@ -107,13 +107,19 @@ def np_sample(img: abi.ImageData, uv):
     h, w = t.shape[:2]
     f32 = np.float32
 
+    def wrap_coord(u):
+        if img.address == abi.TEX_REPEAT:
+            return f32(u - np.floor(u))
+        if img.address == abi.TEX_MIRROR:
+            t = f32(u - f32(f32(2.0) * np.floor(f32(u * f32(0.5)))))
+            return f32(f32(2.0) - t) if t > 1.0 else t
+        return u
+
     def wrap(i, n):
         if img.address == abi.TEX_REPEAT:
-            return i % n, True
-        if img.address == abi.TEX_MIRROR:
-            r = i % (2 * n)
-            return (2 * n - 1 - r if r >= n else r), True
-        if img.address == abi.TEX_EXTEND:
+            i = i + n if i < 0 else (i - n if i >= n else i)
+            return min(max(i, 0), n - 1), True
+        if img.address in (abi.TEX_MIRROR, abi.TEX_EXTEND):
             return min(max(i, 0), n - 1), True
         return i, 0 <= i < n
 
@@ -127,7 +133,7 @@ def np_sample(img: abi.ImageData, uv):
 
     out = []
     for u, v in np.asarray(uv, dtype=f32):
-        x, y = f32(u * f32(w)), f32(v * f32(h))
+        x, y = f32(wrap_coord(u) * f32(w)), f32(wrap_coord(v) * f32(h))
         if img.filter == abi.TEX_FILTER_NEAREST:
             out.append(fetch(int(np.floor(x)), int(np.floor(y))))
             continue

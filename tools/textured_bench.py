@@ -1,0 +1,37 @@
+"""Throughput of the TEX kernels: the textured room of tests/helpers.py at 1920x1080 with large images
+(4096^2 RGBA8 = 64 MB, 2048^2 RGBA32F = 64 MB). python tools/textured_bench.py [steps]"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from akari_render_amd import abi, capi
+from tests.helpers import textured_room
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+rng = np.random.default_rng(0)
+sd = textured_room(1920, 1080, n_floor=1)
+big8 = rng.integers(0, 256, size=(4096, 4096, 4), dtype=np.uint8); big8[:, :, 3] = 255
+bigf = rng.random((2048, 2048, 4)).astype(np.float32); bigf[:, :, 2] = 0.5 + 0.5 * bigf[:, :, 2]; bigf[:, :, 3] = 1.0
+sd.images[0] = abi.ImageData(big8, abi.TEX_FILTER_LINEAR, abi.TEX_REPEAT)
+sd.images[1] = abi.ImageData(bigf, abi.TEX_FILTER_LINEAR, abi.TEX_MIRROR)
+sd.ggx_table = np.fromfile(os.path.join(ROOT, "tests/golden/ggx_dielectric_s.f32"), dtype=np.float32)
+ctx = capi.Context(0)
+out = {}
+for name, variant in (("textured", sd), ("same room, constant materials", None)):
+    if variant is None:
+        variant = textured_room(1920, 1080, n_floor=1)
+        for m in variant.materials:
+            m.graph = None
+        variant.materials[6].emission_color = (6.0, 6.0, 6.0)
+        variant.images = []
+        variant.ggx_table = sd.ggx_table
+    scene = capi.Scene(ctx, variant)
+    film = capi.Film(ctx, 1920, 1080)
+    cfg = abi.PtConfig.default(); cfg.spp = 64 * (steps + 1); cfg.spp_per_pass = 64; cfg.max_depth = 12
+    se = capi.PtSession(ctx, scene, cfg, film)
+    se.passes(1, blocking=True); s0 = se.stats()
+    t0 = time.perf_counter(); se.passes(steps, blocking=True); t1 = time.perf_counter()
+    s1 = se.end()
+    out[name] = {"msamples_per_s": (s1["n_samples"] - s0["n_samples"]) / (t1 - t0) / 1e6, "device_MB": scene.info().device_bytes / 1e6,
+                 "shaded_per_sample": (s1["n_shaded"] - s0["n_shaded"]) / (s1["n_samples"] - s0["n_samples"])}
+print(json.dumps(out))
