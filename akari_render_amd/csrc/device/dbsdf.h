@@ -21,6 +21,7 @@ enum : uint32_t {
     MF_NORMAL_MAP = 1u << 6,  // principled `normal` socket is non-zero                 (mod.rs:1380-1417)
     MF_EMISSIVE = 1u << 7,    // emission != 0
     MF_TEXTURED = 1u << 8,    // at least one input is fed by a texture expression: re-folded per hit (dtex.h)
+    MF_ALPHA_TEXTURED = 1u << 9,  // ... and the alpha of the base colour is not provably 1 everywhere (alpha test evaluates the graph)
 };
 
 enum : uint32_t { MAT_PRINCIPLED = 0, MAT_DIFFUSE = 1, MAT_GLASS = 2, MAT_EMISSION = 3 };

@@ -54,7 +54,7 @@ AKR_D bool alpha_test(const DScene& sc, uint32_t gid, float u, float v) {
     const DMaterial& m = sc.materials[f2u(q6.y)];
     float alpha = (m.kind == MAT_PRINCIPLED || m.kind == MAT_DIFFUSE) ? m.base_alpha : 1.0f;
     if (TEX) {  // only the TEX kernels carry the graph evaluation (and its scratch array)
-        if ((m.flags & MF_TEXTURED) && m.tex_input[IN_BASE_COLOR] != kNodeNone && (m.kind == MAT_PRINCIPLED || m.kind == MAT_DIFFUSE))
+        if (m.flags & MF_ALPHA_TEXTURED)
             alpha = textured_alpha(sc, r, f2u(q6.y), u, v);
     }
     if (alpha >= 1.0f) return true;

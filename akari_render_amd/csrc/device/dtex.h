@@ -203,8 +203,9 @@ AKR_HD void material_at(const TexScene& ts, uint32_t material, vec2 uv, DMateria
     eval_graph(ts, first, count, uv, val);
     MatInputs in = ts.mat_inputs[material];
     apply_inputs(map, val, in);
+    const uint32_t keep = m.flags & (MF_TEXTURED | MF_ALPHA_TEXTURED);
     fold_inputs(in, m);
-    m.flags |= MF_TEXTURED;
+    m.flags |= keep;
     m.tex_first_node = first;
     m.tex_n_nodes = count;
     for (uint32_t i = 0; i < IN_COUNT; i++) m.tex_input[i] = map[i];

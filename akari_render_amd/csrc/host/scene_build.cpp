@@ -119,7 +119,34 @@ static void node_refs(const akr_shader_node& n, uint32_t out[4], uint32_t& count
 // Splits a material's graph into the inputs that are constant after all (folded into `desc`, the way the reference
 // would evaluate them to the same value at every point) and the texture-fed rest (pruned node list appended to
 // `out.tex_nodes`, input map into `dm`).
-static void compile_graph(const HostGraph& g, uint32_t n_images, akr_material_desc& desc, DMaterial& dm, CompiledScene& out) {
+// Is the alpha (w) of this node's value 1 at every point? Only then may the any-hit alpha test skip the graph: constant
+// colours carry alpha 1 (svm/eval.rs:123-133), an image carries its alpha channel (bilinear filtering of all-ones is
+// exactly one; Zero addressing returns 0 outside), checkerboards pick one of their colours, uplift / separate pass it on.
+static bool alpha_is_one(const HostGraph& g, const std::vector<HostImage>& images, uint32_t node) {
+    if (node == AKR_NODE_NONE) return false;
+    const akr_shader_node& n = g.nodes[node];
+    switch (n.op) {
+        case AKR_NODE_RGB: return true;
+        case AKR_NODE_IMAGE: {
+            const HostImage& im = images[n.arg[0]];
+            if (im.address == AKR_TEX_CLIP) return false;
+            const size_t nt = (size_t)im.width * im.height;
+            if (im.format == AKR_IMAGE_RGBA8) {
+                for (size_t t = 0; t < nt; t++)
+                    if ((im.words[t] >> 24) != 0xffu) return false;
+            } else {
+                for (size_t t = 0; t < nt; t++)
+                    if (im.words[4 * t + 3] != 0x3f800000u) return false;
+            }
+            return true;
+        }
+        case AKR_NODE_SPECTRAL_UPLIFT: case AKR_NODE_SEPARATE_COLOR: return alpha_is_one(g, images, n.arg[0]);
+        case AKR_NODE_CHECKERBOARD: return alpha_is_one(g, images, n.arg[2]) && alpha_is_one(g, images, n.arg[3]);
+        default: return false;  // float / float3 / texcoords / mapping / extract / normal_map values have w = 0
+    }
+}
+static void compile_graph(const HostGraph& g, const std::vector<HostImage>& images, akr_material_desc& desc, DMaterial& dm, CompiledScene& out) {
+    const uint32_t n_images = (uint32_t)images.size();
     const uint32_t n = (uint32_t)g.nodes.size();
     std::vector<uint8_t> varying(n, 0);
     for (uint32_t i = 0; i < n; i++) {
@@ -202,6 +229,8 @@ static void compile_graph(const HostGraph& g, uint32_t n_images, akr_material_de
     if (count > kMaxGraphNodes)
         throw std::invalid_argument("unsupported: shader graph needs more than " + std::to_string(kMaxGraphNodes) + " texture nodes");
     dm.flags |= MF_TEXTURED;
+    if (map[AKR_IN_BASE_COLOR] != AKR_NODE_NONE && (dm.kind == MAT_PRINCIPLED || dm.kind == MAT_DIFFUSE) && !alpha_is_one(g, images, map[AKR_IN_BASE_COLOR]))
+        dm.flags |= MF_ALPHA_TEXTURED;
     dm.tex_first_node = first;
     dm.tex_n_nodes = count;
     for (uint32_t k = 0; k < AKR_IN_COUNT; k++) dm.tex_input[k] = map[k] == AKR_NODE_NONE ? AKR_NODE_NONE : remap[map[k]];
@@ -357,12 +386,11 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
     for (size_t mi = 0; mi < flat.materials.size(); mi++) {
         DMaterial d;
         if (!flat.graphs.empty() && !flat.graphs[mi].nodes.empty())
-            compile_graph(flat.graphs[mi], (uint32_t)flat.images.size(), descs[mi], d, out);
+            compile_graph(flat.graphs[mi], flat.images, descs[mi], d, out);
         else
             d = fold_material(descs[mi]);
         const bool tex = (d.flags & MF_TEXTURED) != 0;
-        if ((d.kind == MAT_PRINCIPLED || d.kind == MAT_DIFFUSE) && (d.base_alpha < 1.0f || (tex && d.tex_input[IN_BASE_COLOR] != kNodeNone)))
-            out.has_alpha = true;
+        if ((d.kind == MAT_PRINCIPLED || d.kind == MAT_DIFFUSE) && (d.base_alpha < 1.0f || (d.flags & MF_ALPHA_TEXTURED))) out.has_alpha = true;
         // a textured material may switch the specular / coat layers on at any point
         if (d.kind == MAT_PRINCIPLED && ((d.flags & (MF_SPEC | MF_COAT)) || tex)) out.needs_ggx_table = true;
         out.materials.push_back(d);
