@@ -408,3 +408,21 @@ def test_scene_loader_reads_jpeg_textures(tmp_path):
     assert a.shape == b.shape == (20, 24, 4)
     assert np.abs(a.astype(int) - b.astype(int)).max() <= 3          # two decoders (this library's, libjpeg)
     assert np.abs(a.astype(int) - ref[::-1].astype(int)).max() <= 3  # flipped vertically like every encoded image
+
+
+def test_alpha_textured_flag_is_exact():
+    """MF_ALPHA_TEXTURED (bit 9 of DMaterial.flags) only where the alpha of a fed base colour can differ from 1: opaque images and
+    constant checkerboards are provably opaque, an image with transparent texels or Zero addressing is not."""
+    def flags(sd):
+        mats = capi.Scene(None, sd).array(capi.ARRAY_MATERIALS, np.uint32).reshape(-1, 64)
+        return [(int(f) >> 8) & 3 for f in mats[:, 1]]  # bit 0: MF_TEXTURED, bit 1: MF_ALPHA_TEXTURED
+
+    opaque = flags(textured_room())
+    assert opaque[:3] == [1, 1, 1] and opaque[6] == 1 and opaque[3:6] == [0, 0, 0]
+    cut = flags(textured_room(alpha_cutout=True))
+    assert cut[1] == 3            # the back wall samples the byte image whose alpha now has zeros
+    assert cut[7] == 3            # the cut-out quad (Zero addressing as well)
+    assert cut[0] == 1 and cut[2] == 1  # checkerboard of constants / normal map only
+    sd = textured_room()
+    sd.images[0].address = abi.TEX_CLIP  # opaque texels, but outside [0, 1]^2 the sampler returns alpha 0
+    assert flags(sd)[1] == 3
