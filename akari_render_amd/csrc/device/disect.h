@@ -22,12 +22,10 @@ AKR_HD bool tri_test(vec3 o, vec3 d, float4 r0, float4 r1, float4 r2, float tmin
     float dz = __builtin_fmaf(r2.x, d.x, __builtin_fmaf(r2.y, d.y, r2.z * d.z));
     float oz = __builtin_fmaf(r2.x, o.x, __builtin_fmaf(r2.y, o.y, __builtin_fmaf(r2.z, o.z, r2.w)));
     float t = -oz / dz;
-    float dx = __builtin_fmaf(r0.x, d.x, __builtin_fmaf(r0.y, d.y, r0.z * d.z));
-    float ox = __builtin_fmaf(r0.x, o.x, __builtin_fmaf(r0.y, o.y, __builtin_fmaf(r0.z, o.z, r0.w)));
-    float dy = __builtin_fmaf(r1.x, d.x, __builtin_fmaf(r1.y, d.y, r1.z * d.z));
-    float oy = __builtin_fmaf(r1.x, o.x, __builtin_fmaf(r1.y, o.y, __builtin_fmaf(r1.z, o.z, r1.w)));
-    float u = __builtin_fmaf(t, dx, ox);
-    float v = __builtin_fmaf(t, dy, oy);
+    // the hit point, then its two affine coordinates in the triangle's frame
+    float px = __builtin_fmaf(t, d.x, o.x), py = __builtin_fmaf(t, d.y, o.y), pz = __builtin_fmaf(t, d.z, o.z);
+    float u = __builtin_fmaf(r0.x, px, __builtin_fmaf(r0.y, py, __builtin_fmaf(r0.z, pz, r0.w)));
+    float v = __builtin_fmaf(r1.x, px, __builtin_fmaf(r1.y, py, __builtin_fmaf(r1.z, pz, r1.w)));
     bool hit = (t >= tmin) & (t <= tmax) & (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f);
     t_out = t;
     u_out = u;

@@ -187,12 +187,10 @@ static inline int or_tri_test(v3 o, v3 d, const float *w, float tmin, float tmax
     float dz = fmaf(w[8], d.x, fmaf(w[9], d.y, w[10] * d.z));
     float oz = fmaf(w[8], o.x, fmaf(w[9], o.y, fmaf(w[10], o.z, w[11])));
     float t = -oz / dz;
-    float dx = fmaf(w[0], d.x, fmaf(w[1], d.y, w[2] * d.z));
-    float ox = fmaf(w[0], o.x, fmaf(w[1], o.y, fmaf(w[2], o.z, w[3])));
-    float dy = fmaf(w[4], d.x, fmaf(w[5], d.y, w[6] * d.z));
-    float oy = fmaf(w[4], o.x, fmaf(w[5], o.y, fmaf(w[6], o.z, w[7])));
-    float u = fmaf(t, dx, ox);
-    float v = fmaf(t, dy, oy);
+    /* hit point, then its affine coordinates in the triangle's frame (rows 0 and 1) */
+    float px = fmaf(t, d.x, o.x), py = fmaf(t, d.y, o.y), pz = fmaf(t, d.z, o.z);
+    float u = fmaf(w[0], px, fmaf(w[1], py, fmaf(w[2], pz, w[3])));
+    float v = fmaf(w[4], px, fmaf(w[5], py, fmaf(w[6], pz, w[7])));
     if (!((t >= tmin) & (t <= tmax) & (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f))) return 0;
     *t_out = t; *u_out = u; *v_out = v;
     return 1;
