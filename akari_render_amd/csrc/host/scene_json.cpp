@@ -476,7 +476,7 @@ FlatScene load_scene_json(const std::string& path) {
 
 static void parse_one_task(const JsonValue* j, akr_pt_config* cfg, std::string* film_out, bool allow_sampler_override) {
     akr_pt_config_default(cfg);
-    if (film_out) *film_out = "out.png";  // FilmConfig::default, lib.rs:84-91
+    if (film_out) *film_out = "out.exr";  // FilmConfig::default, lib.rs:82-90
     if (j->has("method")) {
         const JsonValue& m = j->at("method");
         const std::string ty = m.has("type") ? m.at("type").as_string() : std::string("pt");

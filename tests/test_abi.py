@@ -64,6 +64,7 @@ def test_error_reporting(hip_lib, tmp_path):
 def test_method_json_defaults_and_overrides(hip_lib, root):
     cfg, out = capi.config_from_json("{}")
     assert bytes(cfg) == bytes(abi.PtConfig.default())
+    assert out == "out.exr"  # FilmConfig::default (akari_integrator/src/lib.rs:82-90)
     text = open(os.path.join(root, "scenes", "cbox", "pt.json")).read().replace("pmj02bn", "independent")
     cfg, out = capi.config_from_json(text)
     assert (cfg.spp, cfg.max_depth, cfg.rr_depth, cfg.spp_per_pass) == (4096, 12, 5, 64)
