@@ -498,8 +498,20 @@ static void parse_one_task(const JsonValue* j, akr_pt_config* cfg, std::string* 
         else throw std::runtime_error("unsupported: sampler '" + ty + "' (pmj02bn needs tables absent from the reference tree)");
         if (s.has("seed")) cfg->sampler_seed = (uint64_t)s.at("seed").as_number();
     }
+    if (j->has("color")) {  // ColorPipeline (color.rs:663-676): only the default RGB / sRGB pipeline is implemented
+        const JsonValue& c = j->at("color");
+        if (c.has("rgb_colorspace") && c.at("rgb_colorspace").as_string() != "srgb")
+            throw std::runtime_error("unsupported: rgb_colorspace '" + c.at("rgb_colorspace").as_string() + "' (only \"srgb\")");
+        if (c.has("color_repr") && c.at("color_repr").has("type") && c.at("color_repr").at("type").as_string() != "rgb")
+            throw std::runtime_error("unsupported: color_repr '" + c.at("color_repr").at("type").as_string() + "' (spectral rendering is todo!() in the reference as well)");
+    }
     if (j->has("film")) {
         const JsonValue& f = j->at("film");
+        if (f.has("color")) {  // FilmColorRepr (film.rs:12-19)
+            const JsonValue& fc = f.at("color");
+            const std::string repr = fc.type == JsonValue::String ? fc.as_string() : std::string("spectral");
+            if (repr != "srgb") throw std::runtime_error("unsupported: film colour representation '" + repr + "' (only \"srgb\")");
+        }
         if (f.has("filter")) {
             const JsonValue& fl = f.at("filter");
             const std::string& ty = fl.at("type").as_string();
