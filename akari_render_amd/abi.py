@@ -158,6 +158,37 @@ class PtConfig(C.Structure):
         return c
 
 
+AOV_NS, AOV_NG, AOV_TANGENT, AOV_BITANGENT, AOV_ALBEDO, AOV_ROUGHNESS = range(6)
+AOV_NAMES = ("ns", "ng", "tangent", "bitangent", "albedo", "roughness")
+
+
+class AovConfig(C.Structure):
+    """akr_aov_config = aov::Config (aov.rs:23-39) + filter + sampler + shard."""
+
+    _fields_ = [
+        ("spp", C.c_uint32),
+        ("aov", C.c_uint32),
+        ("remap", C.c_uint32),
+        ("filter_type", C.c_uint32),
+        ("filter_radius", C.c_float),
+        ("sampler_type", C.c_uint32),
+        ("sampler_seed", C.c_uint64),
+        ("shard_rank", C.c_uint32),
+        ("shard_count", C.c_uint32),
+        ("tile_w", C.c_uint32),
+        ("tile_h", C.c_uint32),
+    ]
+
+    @staticmethod
+    def default() -> "AovConfig":
+        c = AovConfig()
+        c.spp, c.aov, c.remap = 256, AOV_NS, 1
+        c.filter_type, c.filter_radius = FILTER_GAUSSIAN, 1.5
+        c.sampler_type, c.sampler_seed = SAMPLER_INDEPENDENT, 0
+        c.shard_rank, c.shard_count, c.tile_w, c.tile_h = 0, 1, 32, 32
+        return c
+
+
 class PtStats(C.Structure):
     _fields_ = [
         ("n_samples", C.c_uint64),

@@ -31,7 +31,7 @@ EXPORTS = [
     "akr_film_create", "akr_film_wrap", "akr_film_destroy", "akr_film_clear", "akr_film_read", "akr_film_write",
     "akr_film_resolve", "akr_film_device_ptr",
     "akr_pt_config_default", "akr_pt_config_from_json", "akr_pt_render", "akr_pt_begin", "akr_pt_passes", "akr_pt_end",
-    "akr_pt_get_stats", "akr_render_task", "akr_image_write",
+    "akr_pt_get_stats", "akr_render_task", "akr_image_write", "akr_aov_config_default", "akr_aov_render",
     "akr_pt_read_sampler_states",
     "akr_host_stdrng_u64", "akr_host_chacha_block", "akr_host_pcg32_states", "akr_host_pcg_start", "akr_host_alias_table",
     "akr_probe_math", "akr_probe_bsdf", "akr_probe_intersect", "akr_probe_surface_interaction", "akr_probe_material_inputs",
@@ -102,6 +102,8 @@ def lib() -> C.CDLL:
     proto("akr_film_resolve", vp, fp)
     proto("akr_film_device_ptr", vp, vpp, u64p)
     proto("akr_pt_config_default", C.POINTER(abi.PtConfig))
+    proto("akr_aov_config_default", C.POINTER(abi.AovConfig))
+    proto("akr_aov_render", vp, vp, C.POINTER(abi.AovConfig), vp, C.POINTER(abi.PtStats))
     proto("akr_pt_config_from_json", C.c_char_p, C.POINTER(abi.PtConfig), C.c_char_p, u32)
     proto("akr_pt_render", vp, vp, C.POINTER(abi.PtConfig), vp, C.POINTER(abi.PtStats))
     proto("akr_pt_begin", vp, vp, C.POINTER(abi.PtConfig), vp, vpp)
@@ -496,3 +498,10 @@ def host_decode_png(data: bytes) -> np.ndarray:
 def host_decode_jpeg(data: bytes) -> np.ndarray:
     """JPEG -> (H, W, 4) uint8 in file order."""
     return _host_decode(lib().akr_host_decode_jpeg, data)
+
+
+def aov_render(ctx: Context, scene: Scene, cfg: abi.AovConfig, film: Film) -> dict:
+    """akr_aov_render: the `aov` integrator (akari_integrator/src/aov.rs)."""
+    st = abi.PtStats()
+    check(lib().akr_aov_render(ctx.h, scene.h, C.byref(cfg), film.h, C.byref(st)))
+    return st.as_dict()

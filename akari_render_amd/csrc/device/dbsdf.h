@@ -439,16 +439,19 @@ AKR_HD bool sample_lobe(LobeKind lobe, vec2 alpha, float eta, vec3 wo, vec2 u, v
     bool refracted = refract(wo, wh, eta, wi);  // mod.rs:969-982
     return refracted && !same_hemisphere(wo, wi);
 }
-AKR_HD bool principled_sample_wi(const DMaterial& m, const float* __restrict__ table, vec3 wo, float u, vec2 u2, vec3& wi) {
+// which lobe, which alpha, and -- for the roughness AOV -- whether it is the coat
+AKR_HD void principled_select_lobe(const DMaterial& m, const float* __restrict__ table, vec3 wo, float u, LobeKind& lobe, vec2& alpha, bool& coat) {
     const uint32_t fl = m.flags;
-    LobeKind lobe = LOBE_DIFFUSE;
-    vec2 alpha = m.alpha;
+    lobe = LOBE_DIFFUSE;
+    alpha = m.alpha;
+    coat = false;
     float r;
     // Coated{coat | Scaled{Emissive{...}}}: top iff u < avg(E_coat(wo))
     float p_coat = (fl & MF_COAT) ? avg3(etop_coat(m, table, wo)) : 0.0f;
     if (weighted_choice2_and_remap(p_coat, u, r)) {
         lobe = LOBE_REFLECT;
         alpha = m.coat_alpha;
+        coat = true;
     } else {
         u = r;
         // Mix(metallic): b (metal) iff u < metallic
@@ -474,6 +477,12 @@ AKR_HD bool principled_sample_wi(const DMaterial& m, const float* __restrict__ t
             }
         }
     }
+}
+AKR_HD bool principled_sample_wi(const DMaterial& m, const float* __restrict__ table, vec3 wo, float u, vec2 u2, vec3& wi) {
+    LobeKind lobe;
+    vec2 alpha;
+    bool coat;
+    principled_select_lobe(m, table, wo, u, lobe, alpha, coat);
     return sample_lobe(lobe, alpha, m.eta, wo, u2, wi);
 }
 
@@ -579,6 +588,46 @@ AKR_HD BsdfSample shade_sample(const ShadePoint& sp, const DMaterial& m, const f
     s.pdf = e.pdf;
     s.valid = valid & (e.pdf > 0.0f);
     return s;
+}
+
+// ---- AOVs of the closure (akari_integrator/src/aov.rs:100-160) --------------------------------------------------
+// closure.ns(): SurfaceClosure::ns = frame.to_world(inner.ns()) (mod.rs:724-727). Inner: the Principled wrapper sits in the
+// normal-map closure (its ns = (0,0,1) seen through nm_frame, principled.rs:224-226, mod.rs:1380-1417); Diffuse, the
+// reflection / transmission lobes and an Emission node report (0,0,1); Glass is an additive mixture: normalize(a + b)
+// (mod.rs:588-590).
+AKR_HD vec3 shade_ns(const ShadePoint& sp, const DMaterial& m) {
+    vec3 ns = mk3(0, 0, 1);
+    if (m.kind == MAT_PRINCIPLED) ns = to_world(sp.nm_frame, mk3(0, 0, 1));
+    else if (m.kind == MAT_GLASS) ns = normalize(mk3(0, 0, 1) + mk3(0, 0, 1));
+    return to_world(sp.frame, ns);
+}
+// closure.albedo(wo) + closure.emission(wo): the Principled wrapper answers with its base colour and emission
+// (principled.rs:227-274); Diffuse reflectance * PI (diffuse.rs:56-63); Glass kt + kr (mod.rs:659-675,875-882,981-988);
+// an Emission node has no inner surface: albedo 0 (mod.rs:372-383).
+AKR_HD vec3 shade_albedo_plus_emission(const DMaterial& m) {
+    switch (m.kind) {
+        case MAT_PRINCIPLED: return m.color + m.emission;
+        case MAT_DIFFUSE: return m.diffuse_refl * kPi + mk3(0, 0, 0);
+        case MAT_GLASS: return (m.color + m.color) + (mk3(0, 0, 0) + mk3(0, 0, 0));
+        default: return mk3(0, 0, 0) + m.emission;
+    }
+}
+// closure.roughness(wo, u): the lobe `u` would select, then that lobe's roughness; diffuse lobes report 1
+// (mod.rs:537-556,642-657, diffuse.rs:64-72, microfacet.rs:208-210)
+AKR_HD float shade_roughness(const ShadePoint& sp, const DMaterial& m, const float* __restrict__ table, vec3 wo, float u) {
+    vec3 lo = to_local(sp.frame, wo);
+    switch (m.kind) {
+        case MAT_PRINCIPLED: {
+            vec3 lo2 = (m.flags & MF_NORMAL_MAP) ? to_local(sp.nm_frame, lo) : lo;
+            LobeKind lobe;
+            vec2 alpha;
+            bool coat;
+            principled_select_lobe(m, table, lo2, u, lobe, alpha, coat);
+            return lobe == LOBE_DIFFUSE ? 1.0f : (coat ? m.coat_roughness : m.roughness);
+        }
+        case MAT_GLASS: return m.roughness;  // both sides of the mixture carry the same distribution
+        default: return 1.0f;
+    }
 }
 
 }  // namespace akr

@@ -773,6 +773,51 @@ AKR_API int32_t akr_pt_render(akr_context* ctx, akr_scene* scene, const akr_pt_c
     return rc2;
 }
 
+// ------------------------------------------------------------------------------------------------ aov integrator
+AKR_API int32_t akr_aov_config_default(akr_aov_config* c) {  // aov::Config::default (aov.rs:30-39) + RenderConfig defaults
+    if (!c) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_aov_config_default: NULL argument");
+    std::memset(c, 0, sizeof *c);
+    c->spp = 256; c->aov = AKR_AOV_NS; c->remap = 1;
+    c->filter_type = AKR_FILTER_GAUSSIAN; c->filter_radius = 1.5f;
+    c->sampler_type = AKR_SAMPLER_INDEPENDENT; c->sampler_seed = 0;
+    c->shard_rank = 0; c->shard_count = 1; c->tile_w = 32; c->tile_h = 32;
+    return AKR_OK;
+}
+AKR_API int32_t akr_aov_render(akr_context* ctx, akr_scene* scene, const akr_aov_config* cfg, akr_film* film, akr_pt_stats* stats) {
+    if (!ctx || !scene || !cfg || !film) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_aov_render: NULL argument");
+    if (cfg->aov > AKR_AOV_ROUGHNESS) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_aov_render: unknown aov");
+    // the session machinery of the path tracer provides sampler states, counters, sharding and the kernel parameters
+    akr_pt_config pc;
+    akr_pt_config_default(&pc);
+    pc.spp = cfg->spp; pc.spp_per_pass = cfg->spp ? cfg->spp : 1;
+    pc.filter_type = cfg->filter_type; pc.filter_radius = cfg->filter_radius;
+    pc.sampler_type = cfg->sampler_type; pc.sampler_seed = cfg->sampler_seed;
+    pc.shard_rank = cfg->shard_rank; pc.shard_count = cfg->shard_count; pc.tile_w = cfg->tile_w; pc.tile_h = cfg->tile_h;
+    akr_pt_session* se = nullptr;
+    int32_t rc = akr_pt_begin(ctx, scene, &pc, film, &se);
+    if (rc != AKR_OK) return rc;
+    rc = guarded([&] {
+        if (cfg->spp == 0) return;
+        fill_params(se, 1, cfg->spp);
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, ctx->stream));
+        HIP_CHECK(launch_aov(se->params, cfg->spp, cfg->aov, cfg->remap ? 1u : 0u, ctx->stream));
+        HIP_CHECK(hipEventRecord(e1, ctx->stream));
+        se->events.emplace_back(e0, e1);
+        se->n_launches++;
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+    std::string err = g_last_error;
+    int32_t rc2 = akr_pt_end(se, stats);
+    if (rc != AKR_OK) {
+        g_last_error = err;
+        return rc;
+    }
+    return rc2;
+}
+
 // ------------------------------------------------------------------------------------------------ render driver
 AKR_API int32_t akr_image_write(const char* path, const float* rgb, uint32_t width, uint32_t height) {
     if (!path || !rgb || !width || !height) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_image_write: bad argument");
@@ -791,11 +836,22 @@ AKR_API int32_t akr_render_task(akr_context* ctx, akr_scene* scene, const char* 
         std::vector<float> rgb(3ull * w * h);
         for (size_t ti = 0; ti < tasks.size(); ti++) {  // render_single, lib.rs:112-193
             const ParsedTask& task = tasks[ti];
-            if (ses.verbose) std::fprintf(stderr, "[akari_hip] task %zu/%zu: %ux%u, %u spp -> %s\n", ti + 1, tasks.size(), w, h, task.cfg.spp, task.film_out.c_str());
+            if (ses.verbose) std::fprintf(stderr, "[akari_hip] task %zu/%zu (%s): %ux%u, %u spp -> %s\n", ti + 1, tasks.size(), task.is_aov ? "aov" : "pt", w, h, task.is_aov ? task.aov.spp : task.cfg.spp, task.film_out.c_str());
             akr_film* film = nullptr;
             akr_pt_session* se = nullptr;
             auto check = [&](int32_t rc) { if (rc != AKR_OK) { std::string m = g_last_error; if (se) akr_pt_end(se, nullptr); if (film) akr_film_destroy(film); throw std::runtime_error(m); } };
             check(akr_film_create(ctx, w, h, &film));
+            if (task.is_aov) {  // Method::NormalVis: one blocking dispatch, no intermediates (aov.rs:161-171)
+                akr_pt_stats st;
+                check(akr_aov_render(ctx, scene, &task.aov, film, &st));
+                if (ses.verbose) std::fprintf(stderr, "[akari_hip] Rendered in %.2fms\n", st.kernel_ms);
+                check(akr_film_resolve(film, rgb.data()));
+                akr_film_destroy(film);
+                film = nullptr;
+                write_image(task.film_out, rgb.data(), w, h);
+                if (stats_out) *stats_out = st;
+                continue;
+            }
             check(akr_pt_begin(ctx, scene, &task.cfg, film, &se));
             std::string stats_json = "{\"intermediate\":[";
             uint32_t cnt = 0;

@@ -87,7 +87,9 @@ FlatScene load_scene_json(const std::string& path);
 void parse_method_json(const std::string& text, akr_pt_config* cfg, std::string* film_out);
 // all tasks of a RenderTask file (Single | Multi), lib.rs:103-109; allow_sampler_override: pmj02bn -> independent
 struct ParsedTask {
+    bool is_aov = false;     // Method::NormalVis instead of Method::PathTracer
     akr_pt_config cfg;
+    akr_aov_config aov;
     std::string film_out;
 };
 std::vector<ParsedTask> parse_render_tasks(const std::string& text, bool allow_sampler_override);

@@ -474,13 +474,28 @@ FlatScene load_scene_json(const std::string& path) {
     return flat;
 }
 
-static void parse_one_task(const JsonValue* j, akr_pt_config* cfg, std::string* film_out, bool allow_sampler_override) {
+static void parse_one_task(const JsonValue* j, akr_pt_config* cfg, std::string* film_out, bool allow_sampler_override, ParsedTask* task = nullptr) {
     akr_pt_config_default(cfg);
+    if (task) akr_aov_config_default(&task->aov);
     if (film_out) *film_out = "out.exr";  // FilmConfig::default, lib.rs:82-90
     if (j->has("method")) {
         const JsonValue& m = j->at("method");
         const std::string ty = m.has("type") ? m.at("type").as_string() : std::string("pt");
-        if (ty != "pt") throw std::runtime_error("unsupported: method type '" + ty + "' (only \"pt\")");
+        if (ty == "aov" && task) {  // aov::Config (aov.rs:23-39)
+            task->is_aov = true;
+            if (m.has("spp")) task->aov.spp = (uint32_t)m.at("spp").as_number();
+            if (m.has("remap")) task->aov.remap = m.at("remap").as_bool() ? 1u : 0u;
+            if (m.has("aov")) {
+                const std::string& a = m.at("aov").as_string();
+                static const char* names[6] = {"ns", "ng", "tangent", "bitangent", "albedo", "roughness"};
+                uint32_t k = 0;
+                while (k < 6 && a != names[k]) k++;
+                if (k == 6) throw std::runtime_error("unknown aov '" + a + "'");
+                task->aov.aov = k;
+            }
+        } else if (ty != "pt") {
+            throw std::runtime_error("unsupported: method type '" + ty + "' (\"pt\" and \"aov\" are implemented" + (task ? ")" : "; this entry point takes \"pt\" only)"));
+        }
         auto u32 = [&](const char* k, uint32_t& dst) { if (m.has(k)) dst = (uint32_t)m.at(k).as_number(); };
         auto b32 = [&](const char* k, uint32_t& dst) { if (m.has(k)) dst = m.at(k).as_bool() ? 1u : 0u; };
         u32("spp", cfg->spp); u32("max_depth", cfg->max_depth); u32("spp_per_pass", cfg->spp_per_pass); u32("rr_depth", cfg->rr_depth);
@@ -522,6 +537,12 @@ static void parse_one_task(const JsonValue* j, akr_pt_config* cfg, std::string* 
         }
         if (film_out && f.has("out")) *film_out = f.at("out").as_string();
     }
+    if (task) {  // sampler and film filter are per RenderConfig, whatever the method
+        task->aov.filter_type = cfg->filter_type;
+        task->aov.filter_radius = cfg->filter_radius;
+        task->aov.sampler_type = cfg->sampler_type;
+        task->aov.sampler_seed = cfg->sampler_seed;
+    }
 }
 
 std::vector<ParsedTask> parse_render_tasks(const std::string& text, bool allow_sampler_override) {
@@ -530,12 +551,12 @@ std::vector<ParsedTask> parse_render_tasks(const std::string& text, bool allow_s
     if (root->type == JsonValue::Array) {  // RenderTask::Multi
         for (const auto& t : root->arr) {
             ParsedTask p;
-            parse_one_task(t.get(), &p.cfg, &p.film_out, allow_sampler_override);
+            parse_one_task(t.get(), &p.cfg, &p.film_out, allow_sampler_override, &p);
             out.push_back(p);
         }
     } else {
         ParsedTask p;
-        parse_one_task(root.get(), &p.cfg, &p.film_out, allow_sampler_override);
+        parse_one_task(root.get(), &p.cfg, &p.film_out, allow_sampler_override, &p);
         out.push_back(p);
     }
     if (out.empty()) throw std::runtime_error("empty render task list");
@@ -544,6 +565,7 @@ std::vector<ParsedTask> parse_render_tasks(const std::string& text, bool allow_s
 
 void parse_method_json(const std::string& text, akr_pt_config* cfg, std::string* film_out) {
     std::vector<ParsedTask> tasks = parse_render_tasks(text, false);
+    if (tasks[0].is_aov) throw std::runtime_error("unsupported: method type 'aov' here (akr_pt_config_from_json fills a pt::Config; use akr_render_task)");
     *cfg = tasks[0].cfg;
     if (film_out) *film_out = tasks[0].film_out;
 }

@@ -51,6 +51,7 @@ struct WfBuffers {
 };
 
 hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream);
+hipError_t launch_aov(const PtParams& p, uint32_t spp, uint32_t aov, uint32_t remap, hipStream_t stream);
 hipError_t launch_wf_init(const PtParams& p, const WfBuffers& wf, hipStream_t stream);
 hipError_t launch_wf_shade(const PtParams& p, const WfBuffers& wf, uint32_t q_out, hipStream_t stream);
 hipError_t launch_wf_trace(const PtParams& p, const WfBuffers& wf, uint32_t q_in, uint32_t n_blocks, hipStream_t stream);

@@ -348,6 +348,32 @@ typedef struct {
 } akr_render_session;
 AKR_API int32_t akr_render_task(akr_context *ctx, akr_scene *scene, const char *method_json_text, const akr_render_session *session,
                                 akr_pt_stats *stats_of_last_task);
+/* ---------------------------------------------------------------------------------------------------
+ * `aov` integrator (Method::NormalVis, akari_integrator/src/aov.rs:57-173; "type": "aov" in a method file): per pixel
+ * `spp` camera rays, one attribute of the first hit accumulated in the film like a radiance sample.
+ * ------------------------------------------------------------------------------------------------- */
+typedef enum {
+    AKR_AOV_NS = 0,         /* "ns"        closure.ns(), remapped v * 0.5 + 0.5 when `remap`   aov.rs:103-113 */
+    AKR_AOV_NG = 1,         /* "ng"        si.ng                                                aov.rs:114-118 */
+    AKR_AOV_TANGENT = 2,    /* "tangent"   si.frame.t                                           aov.rs:119-123 */
+    AKR_AOV_BITANGENT = 3,  /* "bitangent" si.frame.s                                           aov.rs:124-128 */
+    AKR_AOV_ALBEDO = 4,     /* "albedo"    closure.albedo(wo) + closure.emission(wo)            aov.rs:129-143 */
+    AKR_AOV_ROUGHNESS = 5   /* "roughness" closure.roughness(wo, sampler.next_1d())             aov.rs:145-158 */
+} akr_aov_kind;
+typedef struct {
+    uint32_t spp;            /* aov::Config::default: 256 */
+    uint32_t aov;            /* akr_aov_kind, default ns */
+    uint32_t remap;          /* default 1 */
+    uint32_t filter_type;    /* film.filter, as in akr_pt_config */
+    float filter_radius;
+    uint32_t sampler_type;
+    uint64_t sampler_seed;
+    uint32_t shard_rank, shard_count, tile_w, tile_h;
+} akr_aov_config;
+AKR_API int32_t akr_aov_config_default(akr_aov_config *cfg);
+/* Renders into `film` (accumulates: clear it first for a fresh image). stats: n_samples = n_closest = camera rays. */
+AKR_API int32_t akr_aov_render(akr_context *ctx, akr_scene *scene, const akr_aov_config *cfg, akr_film *film, akr_pt_stats *stats);
+
 /* util::write_image (akari_render/src/util/mod.rs:57-127): ".exr" -> linear RGB f32 OpenEXR (uncompressed scanlines),
  * ".png" -> 8-bit sRGB. rgb = 3 * W * H floats, row-major, top row first. Creates parent directories. */
 AKR_API int32_t akr_image_write(const char *path, const float *rgb, uint32_t width, uint32_t height);

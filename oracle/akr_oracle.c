@@ -265,6 +265,7 @@ static or_surface *pool_new(or_closure_pool *p, int kind) {
 static or_surface *mk_refl(or_closure_pool *p, v3 color, int fresnel, float eta, float roughness) {
     or_surface *s = pool_new(p, OR_S_MF_REFL);
     s->color = color; s->fresnel = fresnel; s->eta = eta; s->alpha = tr_alpha_from_roughness(roughness, roughness);
+    s->roughness = roughness;
     return s;
 }
 /* principled.rs:11-216 */
@@ -286,7 +287,7 @@ static or_surface *or_build_principled(or_closure_pool *p, const or_scene *sc, c
     or_surface *d_refl = mk_refl(p, color, OR_FR_DIELECTRIC, eta, roughness);
     or_surface *d_trans = pool_new(p, OR_S_MF_TRANS);
     d_trans->color = transmission_color; d_trans->fresnel = OR_FR_DIELECTRIC; d_trans->eta = eta;
-    d_trans->alpha = tr_alpha_from_roughness(roughness, roughness);
+    d_trans->alpha = tr_alpha_from_roughness(roughness, roughness); d_trans->roughness = roughness;
     or_surface *dielectric = pool_new(p, OR_S_MIXTURE);
     dielectric->mode = OR_BLEND_ADDICTIVE; dielectric->frac_kind = OR_FRAC_FR_DIELECTRIC; dielectric->frac_eta = eta;
     dielectric->a = d_trans; dielectric->b = d_refl;
@@ -353,7 +354,7 @@ static or_surface *or_build_closure(or_closure_pool *p, const or_scene *sc, cons
             or_surface *refl = mk_refl(p, k, OR_FR_DIELECTRIC, m->ior, m->roughness);
             or_surface *trans = pool_new(p, OR_S_MF_TRANS);
             trans->color = k; trans->fresnel = OR_FR_DIELECTRIC; trans->eta = m->ior;
-            trans->alpha = tr_alpha_from_roughness(m->roughness, m->roughness);
+            trans->alpha = tr_alpha_from_roughness(m->roughness, m->roughness); trans->roughness = m->roughness;
             inner = pool_new(p, OR_S_MIXTURE);
             inner->mode = OR_BLEND_ADDICTIVE; inner->frac_kind = OR_FRAC_FR_DIELECTRIC; inner->frac_eta = m->ior;
             inner->a = trans; inner->b = refl;
@@ -807,6 +808,86 @@ OR_EXPORT int or_pt_render(const or_scene *sc, const or_pt_config *cfg, float *f
     if (stats_out) *stats_out = total;
     return 0;
 }
+
+/* ---------------------------------- aov integrator, akari_integrator/src/aov.rs:57-173 -------------- */
+typedef struct {
+    uint32_t spp, aov, remap, filter_type; float filter_radius; uint32_t sampler_type; uint64_t sampler_seed;
+    uint32_t shard_rank, shard_count, tile_w, tile_h;
+} or_aov_config; /* = akr_aov_config */
+enum { OR_AOV_NS = 0, OR_AOV_NG, OR_AOV_TANGENT, OR_AOV_BITANGENT, OR_AOV_ALBEDO, OR_AOV_ROUGHNESS };
+typedef struct { const or_scene *sc; const or_aov_config *cfg; or_pt_config pc; float *film; or_pcg32 *states; volatile uint32_t *next_row; uint64_t n_rays; } or_aov_job;
+static v3 or_aov_remap(const or_aov_config *c, v3 v) { return c->remap ? v3add(v3scale(v, 0.5f), V3(0.5f, 0.5f, 0.5f)) : v; }
+static void or_aov_pixel(or_aov_job *j, uint32_t x, uint32_t y) { /* kernel body, aov.rs:78-160 */
+    const or_scene *sc = j->sc; const or_aov_config *cfg = j->cfg;
+    uint32_t W = sc->width, H = sc->height, i = x + y * W;
+    uint64_t N = (uint64_t)W * H;
+    or_sampler smp = {j->states[i], 0};
+    for (uint32_t s = 0; s < cfg->spp; s++) {
+        pcg_advance(&smp.pcg, 16384);
+        or_ray ray = or_generate_ray(sc, &j->pc, x, y, &smp);
+        j->n_rays++;
+        uint32_t inst, prim; v2 bary;
+        v3 c = V3(0, 0, 0);
+        if (or_trace(sc, &ray, 0, &inst, &prim, &bary, 0)) {
+            or_si si = or_surface_interaction(sc, inst, prim, bary);
+            if (cfg->aov == OR_AOV_NG) c = or_aov_remap(cfg, si.ng);
+            else if (cfg->aov == OR_AOV_TANGENT) c = or_aov_remap(cfg, si.frame.t);
+            else if (cfg->aov == OR_AOV_BITANGENT) c = or_aov_remap(cfg, si.frame.s);
+            else {
+                or_closure_pool pool;
+                or_surface *cl = or_build_closure(&pool, sc, &si, 0);
+                v3 wo = v3neg(ray.d);
+                if (cfg->aov == OR_AOV_NS) c = or_aov_remap(cfg, or_surf_ns(cl));
+                else if (cfg->aov == OR_AOV_ALBEDO) c = v3add(or_surf_albedo(cl, wo), or_surf_emission(cl, wo));
+                else { float r = or_surf_roughness(cl, wo, smp_1d(&smp)); c = v3scale(V3(1, 1, 1), r); }
+            }
+        }
+        if (or_isnan(c.x) || or_isnan(c.y) || or_isnan(c.z)) c = V3(0, 0, 0);
+        const float w = 1.0f;
+        j->film[3 * (uint64_t)i + 0] += c.x * w;
+        j->film[3 * (uint64_t)i + 1] += c.y * w;
+        j->film[3 * (uint64_t)i + 2] += c.z * w;
+        j->film[6 * N + i] += w;
+    }
+    pcg_advance(&smp.pcg, -(int64_t)smp.dim);
+    j->states[i] = smp.pcg;
+}
+static void *or_aov_worker(void *arg) {
+    or_aov_job *j = (or_aov_job *)arg;
+    uint32_t H = j->sc->height, W = j->sc->width;
+    for (;;) {
+        uint32_t y = __sync_fetch_and_add(j->next_row, 1);
+        if (y >= H) break;
+        for (uint32_t x = 0; x < W; x++)
+            if (or_pixel_owned(&j->pc, W, x, y)) or_aov_pixel(j, x, y);
+    }
+    return 0;
+}
+OR_EXPORT int or_aov_render(const or_scene *sc, const or_aov_config *cfg, float *film, uint32_t n_threads, uint64_t *n_rays_out) {
+    uint64_t N = (uint64_t)sc->width * sc->height;
+    or_pcg32 *states = (or_pcg32 *)malloc(sizeof(or_pcg32) * N);
+    or_init_pcg32_buffer_with_seed(N, cfg->sampler_seed, (uint64_t *)states);
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    volatile uint32_t next_row = 0;
+    or_aov_job jobs[256];
+    pthread_t th[256];
+    for (uint32_t t = 0; t < n_threads; t++) {
+        memset(&jobs[t], 0, sizeof(or_aov_job));
+        jobs[t].sc = sc; jobs[t].cfg = cfg; jobs[t].film = film; jobs[t].states = states; jobs[t].next_row = &next_row;
+        jobs[t].pc.filter_type = cfg->filter_type; jobs[t].pc.filter_radius = cfg->filter_radius;
+        jobs[t].pc.shard_rank = cfg->shard_rank; jobs[t].pc.shard_count = cfg->shard_count; jobs[t].pc.tile_w = cfg->tile_w; jobs[t].pc.tile_h = cfg->tile_h;
+    }
+    for (uint32_t t = 1; t < n_threads; t++) pthread_create(&th[t], 0, or_aov_worker, &jobs[t]);
+    or_aov_worker(&jobs[0]);
+    for (uint32_t t = 1; t < n_threads; t++) pthread_join(th[t], 0);
+    uint64_t total = 0;
+    for (uint32_t t = 0; t < n_threads; t++) total += jobs[t].n_rays;
+    if (n_rays_out) *n_rays_out = total;
+    free(states);
+    return 0;
+}
+OR_EXPORT uint32_t or_sizeof_aov_config(void) { return (uint32_t)sizeof(or_aov_config); }
 
 /* Film resolve, film.rs:120-148 with hdr = true and splat_scale = 1: rgb / (w == 0 ? 1 : w) + splat */
 OR_EXPORT void or_film_resolve(const float *film, uint32_t width, uint32_t height, float *rgb_out) {

@@ -33,6 +33,7 @@ typedef struct or_surface {
     float eta;           /* FresnelDielectric.eta; MicrofacetTransmission.eta */
     v3 fn, fk;           /* FresnelComplex */
     v2 alpha;            /* TrowbridgeReitzDistribution.alpha */
+    float roughness;     /* TrowbridgeReitzDistribution.roughness (what from_roughness was given), microfacet.rs:27,208-210 */
     /* combinators */
     struct or_surface *a, *b; /* MIXTURE: bsdf_a/bsdf_b; COATED: a = top, b = bottom; others: a = inner */
     int mode, frac_kind;
@@ -394,6 +395,60 @@ static v3 or_surf_emission(const or_surface *s, v3 wo) {
     case OR_S_PRINCIPLED: return s->emission; /* principled.rs:267-274 */
     case OR_S_CLOSURE: return or_surf_emission(s->a, or_to_local(&s->frame, wo));
     default: return V3(0, 0, 0);
+    }
+}
+
+/* ---- AOV queries of the closure tree (trait Surface: ns / albedo / roughness) ---------------------------------- */
+static v3 or_surf_ns(const or_surface *s) {
+    switch (s->kind) {
+    case OR_S_MIXTURE: return v3normalize(v3add(or_surf_ns(s->a), or_surf_ns(s->b))); /* mod.rs:588-590 */
+    case OR_S_COATED: return or_surf_ns(s->b);                                          /* bottom, mod.rs:482-484 */
+    case OR_S_SCALED: return or_surf_ns(s->a);
+    case OR_S_EMISSIVE: return s->a ? or_surf_ns(s->a) : V3(0, 0, 1);                  /* mod.rs:338-342 */
+    case OR_S_CLOSURE: return or_to_world(&s->frame, or_surf_ns(s->a));                 /* mod.rs:724-727 */
+    default: return V3(0, 0, 1); /* null, diffuse, microfacet lobes, the Principled wrapper (principled.rs:224-226) */
+    }
+}
+static v3 or_surf_albedo(const or_surface *s, v3 wo) {
+    switch (s->kind) {
+    case OR_S_DIFFUSE: return v3scale(s->color, OR_PI);           /* reflectance * PI, diffuse.rs:56-63 */
+    case OR_S_MF_REFL: case OR_S_MF_TRANS: return s->color;      /* mod.rs:875-882, 981-988 */
+    case OR_S_MIXTURE: { /* mod.rs:659-675 */
+        float frac = or_frac(s, wo);
+        v3 aa = or_surf_albedo(s->a, wo), ab = or_surf_albedo(s->b, wo);
+        if (s->mode == OR_BLEND_ADDICTIVE) return v3add(aa, ab);
+        return v3add(v3scale(aa, 1.0f - frac), v3scale(ab, frac));
+    }
+    case OR_S_COATED: { /* mod.rs:524-535 */
+        v3 eo = or_etop(s, wo);
+        v3 at = or_surf_albedo(s->a, wo), ab = or_surf_albedo(s->b, wo);
+        return v3add(v3mul(at, eo), v3mul(ab, V3(1.0f - eo.x, 1.0f - eo.y, 1.0f - eo.z)));
+    }
+    case OR_S_SCALED: return v3mul(or_surf_albedo(s->a, wo), s->color);                 /* mod.rs:446-454 */
+    case OR_S_EMISSIVE: return s->a ? or_surf_albedo(s->a, wo) : V3(0, 0, 0);           /* mod.rs:372-383 */
+    case OR_S_PRINCIPLED: return s->color;                                              /* wrapper albedo, principled.rs:227-234 */
+    case OR_S_CLOSURE: return or_surf_albedo(s->a, or_to_local(&s->frame, wo));         /* mod.rs:766-773 */
+    default: return V3(0, 0, 0);
+    }
+}
+static float or_surf_roughness(const or_surface *s, v3 wo, float u_select) {
+    switch (s->kind) {
+    case OR_S_MF_REFL: case OR_S_MF_TRANS: return s->roughness;
+    case OR_S_MIXTURE: { /* mod.rs:642-657: which = 0 (-> bsdf_a) iff NOT (u < frac) */
+        float frac = or_frac(s, wo), remapped;
+        int pick_b = or_weighted_choice2_and_remap(frac, u_select, &remapped);
+        return or_surf_roughness(pick_b ? s->b : s->a, wo, remapped);
+    }
+    case OR_S_COATED: { /* mod.rs:537-556 */
+        v3 eo = or_etop(s, wo);
+        float pdf_select_top = ((eo.x + eo.y) + eo.z) / 3.0f, remapped;
+        int pick_top = or_weighted_choice2_and_remap(pdf_select_top, u_select, &remapped);
+        return or_surf_roughness(pick_top ? s->a : s->b, wo, remapped);
+    }
+    case OR_S_SCALED: case OR_S_PRINCIPLED: return or_surf_roughness(s->a, wo, u_select);
+    case OR_S_EMISSIVE: return s->a ? or_surf_roughness(s->a, wo, u_select) : 1.0f;
+    case OR_S_CLOSURE: return or_surf_roughness(s->a, or_to_local(&s->frame, wo), u_select);
+    default: return 1.0f; /* null, diffuse (diffuse.rs:64-72) */
     }
 }
 

@@ -91,11 +91,14 @@ def lib() -> C.CDLL:
     L.or_scene_intersect.argtypes = [vp, fp, fp, f32, f32, up, up, fp]
     L.or_bsdf_probe_many.argtypes = [C.POINTER(abi.MaterialDesc), fp, fp, u32, fp, fp]
     L.or_bsdf_eval_many.argtypes = [C.POINTER(abi.MaterialDesc), fp, fp, u32, fp, fp]
-    for n in ("or_sizeof_material", "or_sizeof_config", "or_sizeof_scene_desc"):
+    L.or_aov_render.restype = i32
+    L.or_aov_render.argtypes = [vp, C.POINTER(abi.AovConfig), fp, u32, u64p]
+    for n in ("or_sizeof_material", "or_sizeof_config", "or_sizeof_scene_desc", "or_sizeof_aov_config"):
         getattr(L, n).restype = u32
     assert L.or_sizeof_material() == C.sizeof(abi.MaterialDesc)
     assert L.or_sizeof_config() == C.sizeof(abi.PtConfig)
     assert L.or_sizeof_scene_desc() == C.sizeof(abi.SceneDesc)
+    assert L.or_sizeof_aov_config() == C.sizeof(abi.AovConfig)
     _lib = L
     return L
 
@@ -127,6 +130,14 @@ class OracleScene:
         inst, power, pdf = C.c_uint32(), C.c_float(), C.c_float()
         lib().or_scene_light_info(self.h, i, C.byref(inst), C.byref(power), C.byref(pdf))
         return inst.value, power.value, pdf.value
+
+    def aov_render(self, cfg: abi.AovConfig, n_threads: int = 0):
+        """The aov integrator (aov.rs): returns (film f32[7*N], camera rays traced)."""
+        film = np.zeros(7 * self.width * self.height, dtype=np.float32)
+        n = C.c_uint64()
+        rc = lib().or_aov_render(self.h, C.byref(cfg), _fp(film), n_threads if n_threads > 0 else (os.cpu_count() or 1), C.byref(n))
+        assert rc == 0
+        return film, n.value
 
     def material_inputs(self, material: int, uv) -> np.ndarray:
         u = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)

@@ -76,3 +76,13 @@ def test_method_json_defaults_and_overrides(hip_lib, root):
     assert out == "output/pt.exr"
     cfg, _ = capi.config_from_json('[{"method": {"type": "pt", "spp": 3, "pixel_offset": [1, -2], "debug_depth": 2}, "film": {"filter": {"type": "box", "radius": 0.5}}}]')
     assert cfg.spp == 3 and list(cfg.pixel_offset) == [1, -2] and cfg.debug_depth == 2 and cfg.filter_type == abi.FILTER_BOX
+
+
+def test_aov_method_json_and_config(hip_lib):
+    """Method::NormalVis ("type": "aov", aov.rs:9-39): accepted by the render-task parser, rejected by the pt-config entry point."""
+    c = abi.AovConfig()
+    assert hip_lib.akr_aov_config_default(C.byref(c)) == 0
+    assert bytes(c) == bytes(abi.AovConfig.default()) and (c.spp, c.aov, c.remap) == (256, abi.AOV_NS, 1)
+    cfg = abi.PtConfig()
+    assert hip_lib.akr_pt_config_from_json(b'{"method": {"type": "aov", "aov": "ng"}}', C.byref(cfg), None, 0) == capi.ERR_UNSUPPORTED
+    assert C.sizeof(abi.AovConfig) == 48
