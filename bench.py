@@ -39,7 +39,34 @@ def algorithmic_bytes(d):
             64 * d["n_node_visits"] + (48 * d["n_tri_tests"] if d["n_node_visits"] else 0))
 
 
-def cpu_baseline(n_threads):
+def host_threads():
+    """Threads for the CPU baseline: the container may be limited by a cgroup CPU quota far below os.cpu_count() (the GPU
+    box: 256 logical CPUs visible, cpu.max = 16 cores; 256 threads then run 40 % slower than 32). Two threads per core of
+    quota, capped by the visible CPUs."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None and quota < n:
+        return max(1, min(n, int(round(2 * quota)))), quota
+    return n, None
+
+
+def cpu_baseline(n_threads, quota=None):
     """The CPU oracle (restatement of the reference algorithm; the reference binary cannot run here) on the same
     workload, bounded sample: 1920x1080, force_diffuse, 4 spp."""
     from akari_render_amd import abi
@@ -60,7 +87,8 @@ def cpu_baseline(n_threads):
         _, st = sc.render(cfg, n_threads=n_threads)
         dt = time.time() - t0
     return {"value": st["n_samples"] / dt / 1e6, "unit": "Msamples/s", "cores": n_threads, "kind": "port",
-            "sample": f"cbox {W}x{H} force_diffuse {cfg.spp} spp ({st['n_samples']} camera paths, {dt:.1f} s), CPU oracle (C, pthreads)"}
+            "sample": f"cbox {W}x{H} force_diffuse {cfg.spp} spp ({st['n_samples']} camera paths, {dt:.1f} s), CPU oracle (C, pthreads)"
+                      + (f", cgroup CPU quota {quota:g} cores" if quota is not None else "")}
 
 
 def measured_traffic(args, d):
@@ -228,7 +256,7 @@ def main():
             "counters": {k: d[k] for k in ("n_samples", "n_closest", "n_shadow", "n_shaded")},
         }
         if args.gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(*host_threads())
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

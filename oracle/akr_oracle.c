@@ -712,7 +712,8 @@ static v3 or_radiance(const or_scene *sc, const or_pt_config *cfg, or_ray ray, o
 typedef struct {
     const or_scene *sc; const or_pt_config *cfg; float *film; or_pcg32 *states;
     uint32_t pass_spp; volatile uint32_t *next_row; or_stats stats;
-} or_job;
+    char pad[128]; /* one cache line (and its neighbour) per worker: the counters are bumped per ray */
+} __attribute__((aligned(128))) or_job;
 
 static int or_pixel_owned(const or_pt_config *cfg, uint32_t width, uint32_t x, uint32_t y) {
     if (cfg->shard_count <= 1) return 1;
@@ -815,7 +816,7 @@ typedef struct {
     uint32_t shard_rank, shard_count, tile_w, tile_h;
 } or_aov_config; /* = akr_aov_config */
 enum { OR_AOV_NS = 0, OR_AOV_NG, OR_AOV_TANGENT, OR_AOV_BITANGENT, OR_AOV_ALBEDO, OR_AOV_ROUGHNESS };
-typedef struct { const or_scene *sc; const or_aov_config *cfg; or_pt_config pc; float *film; or_pcg32 *states; volatile uint32_t *next_row; uint64_t n_rays; } or_aov_job;
+typedef struct { const or_scene *sc; const or_aov_config *cfg; or_pt_config pc; float *film; or_pcg32 *states; volatile uint32_t *next_row; uint64_t n_rays; char pad[128]; } __attribute__((aligned(128))) or_aov_job;
 static v3 or_aov_remap(const or_aov_config *c, v3 v) { return c->remap ? v3add(v3scale(v, 0.5f), V3(0.5f, 0.5f, 0.5f)) : v; }
 static void or_aov_pixel(or_aov_job *j, uint32_t x, uint32_t y) { /* kernel body, aov.rs:78-160 */
     const or_scene *sc = j->sc; const or_aov_config *cfg = j->cfg;
