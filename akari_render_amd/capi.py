@@ -35,7 +35,7 @@ EXPORTS = [
     "akr_pt_read_sampler_states",
     "akr_host_stdrng_u64", "akr_host_chacha_block", "akr_host_pcg32_states", "akr_host_pcg_start", "akr_host_alias_table",
     "akr_probe_math", "akr_probe_bsdf", "akr_probe_intersect", "akr_probe_surface_interaction", "akr_probe_material_inputs",
-    "akr_host_decode_png", "akr_host_decode_jpeg",
+    "akr_host_decode_png", "akr_host_decode_jpeg", "akr_host_decode_exr",
 ]
 
 
@@ -125,6 +125,7 @@ def lib() -> C.CDLL:
     proto("akr_probe_material_inputs", vp, vp, u32, u32, fp, fp)
     proto("akr_host_decode_png", C.c_char_p, u64, up, up, C.POINTER(C.c_uint8), u64)
     proto("akr_host_decode_jpeg", C.c_char_p, u64, up, up, C.POINTER(C.c_uint8), u64)
+    proto("akr_host_decode_exr", C.c_char_p, u64, up, up, fp, u64)
     _lib = L
     return L
 
@@ -505,3 +506,12 @@ def aov_render(ctx: Context, scene: Scene, cfg: abi.AovConfig, film: Film) -> di
     st = abi.PtStats()
     check(lib().akr_aov_render(ctx.h, scene.h, C.byref(cfg), film.h, C.byref(st)))
     return st.as_dict()
+
+
+def host_decode_exr(data: bytes) -> np.ndarray:
+    """OpenEXR -> (H, W, 4) float32 in file order."""
+    w, h = C.c_uint32(), C.c_uint32()
+    check(lib().akr_host_decode_exr(data, len(data), C.byref(w), C.byref(h), None, 0))
+    out = np.zeros((h.value, w.value, 4), dtype=np.float32)
+    check(lib().akr_host_decode_exr(data, len(data), C.byref(w), C.byref(h), _fp(out), out.size))
+    return out

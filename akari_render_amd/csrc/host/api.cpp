@@ -1039,6 +1039,17 @@ AKR_API int32_t akr_host_decode_jpeg(const uint8_t* data, uint64_t len, uint32_t
         }
     });
 }
+AKR_API int32_t akr_host_decode_exr(const uint8_t* data, uint64_t len, uint32_t* width, uint32_t* height, float* rgba, uint64_t capacity_floats) {
+    if (!data || !width || !height) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_host_decode_exr: NULL argument");
+    return guarded([&] {
+        std::vector<float> px;
+        decode_exr(data, (size_t)len, *width, *height, px);
+        if (rgba) {
+            if (capacity_floats < px.size()) throw std::invalid_argument("akr_host_decode_exr: output buffer too small");
+            std::memcpy(rgba, px.data(), px.size() * sizeof(float));
+        }
+    });
+}
 // Evaluated inputs of a material at uv points: on the device (ctx != NULL; needs a scene with textures) or with the
 // same code on the host (ctx == NULL).
 AKR_API int32_t akr_probe_material_inputs(akr_context* ctx, akr_scene* scene, uint32_t material, uint32_t n, const float* uv, float* out26) {

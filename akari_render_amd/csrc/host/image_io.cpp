@@ -942,4 +942,170 @@ void decode_jpeg(const uint8_t* data, size_t n, uint32_t& width, uint32_t& heigh
     }
 }
 
+// ------------------------------------------------------------------------------------------------ OpenEXR reader
+// Single-part scanline files with NO / RLE / ZIPS / ZIP compression and HALF / FLOAT / UINT channels: what the reference
+// gets from `image` (exr crate 1.6.4) as `to_rgba32f()` for an "exr" texture (load.rs:583-611): R, G, B (a lone Y is
+// replicated), A = 1 when absent. Tiled, multi-part, deep and PIZ / PXR24 / B44 / DWA files are rejected. Rows in file order
+// of the data window (top first).
+namespace {
+float half_to_float(uint16_t h) {
+    uint32_t sign = (uint32_t)(h >> 15) << 31, e = (h >> 10) & 31u, m = h & 1023u, bits;
+    if (e == 0) {
+        if (m == 0) {
+            bits = sign;
+        } else {  // subnormal: normalise
+            int sh = 0;
+            while (!(m & 1024u)) { m <<= 1; sh++; }
+            bits = sign | ((uint32_t)(113 - sh) << 23) | ((m & 1023u) << 13);
+        }
+    } else if (e == 31) {
+        bits = sign | 0x7f800000u | (m << 13);
+    } else {
+        bits = sign | ((e + 112u) << 23) | (m << 13);
+    }
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
+}
+std::vector<uint8_t> exr_unpredict(const std::vector<uint8_t>& in) {  // delta predictor + even/odd byte interleave of ZIP and RLE
+    std::vector<uint8_t> t(in);
+    for (size_t i = 1; i < t.size(); i++) t[i] = (uint8_t)(t[i - 1] + t[i] - 128);
+    std::vector<uint8_t> out(t.size());
+    size_t half = (t.size() + 1) / 2, a = 0, b = half;
+    for (size_t i = 0; i < t.size(); i++) out[i] = (i & 1) ? t[b++] : t[a++];
+    return out;
+}
+std::vector<uint8_t> exr_rle_decode(const uint8_t* p, size_t n, size_t expect) {
+    std::vector<uint8_t> out;
+    size_t i = 0;
+    while (i < n) {
+        int8_t c = (int8_t)p[i++];
+        if (c < 0) {
+            size_t cnt = (size_t)(-(int)c);
+            if (i + cnt > n) throw std::runtime_error("exr: truncated RLE data");
+            out.insert(out.end(), p + i, p + i + cnt);
+            i += cnt;
+        } else {
+            if (i >= n) throw std::runtime_error("exr: truncated RLE data");
+            out.insert(out.end(), (size_t)c + 1, p[i++]);
+        }
+        if (out.size() > expect) throw std::runtime_error("exr: RLE data too long");
+    }
+    return out;
+}
+}  // namespace
+
+void decode_exr(const uint8_t* data, size_t n, uint32_t& width, uint32_t& height, std::vector<float>& rgba) {
+    auto need = [&](size_t pos, size_t len) { if (pos + len > n) throw std::runtime_error("exr: truncated file"); };
+    auto rd32 = [&](size_t pos) { need(pos, 4); uint32_t v; std::memcpy(&v, data + pos, 4); return v; };
+    auto rd64 = [&](size_t pos) { need(pos, 8); uint64_t v; std::memcpy(&v, data + pos, 8); return v; };
+    if (n < 8 || rd32(0) != 20000630u) throw std::runtime_error("exr: bad magic number");
+    uint32_t version = rd32(4);
+    if ((version & 0xffu) != 2u) throw std::runtime_error("exr: unknown version");
+    if (version & 0x200u) throw std::runtime_error("unsupported: tiled OpenEXR file");
+    if (version & 0x1800u) throw std::runtime_error("unsupported: deep / multi-part OpenEXR file");
+    size_t pos = 8;
+    struct Chan { std::string name; uint32_t type; };
+    std::vector<Chan> chans;
+    int compression = -1, line_order = 0;
+    int32_t dw[4] = {0, 0, -1, -1};
+    for (;;) {  // attributes
+        need(pos, 1);
+        if (data[pos] == 0) { pos++; break; }
+        auto cstr = [&]() { size_t s0 = pos; while (pos < n && data[pos]) pos++; need(pos, 1); std::string r((const char*)data + s0, pos - s0); pos++; return r; };
+        std::string name = cstr(), type = cstr();
+        uint32_t size = rd32(pos);
+        pos += 4;
+        need(pos, size);
+        const uint8_t* v = data + pos;
+        if (name == "channels") {
+            size_t q = 0;
+            while (q < size && v[q]) {
+                size_t s0 = q;
+                while (q < size && v[q]) q++;
+                Chan c{std::string((const char*)v + s0, q - s0), 0};
+                q++;
+                if (q + 16 > size) throw std::runtime_error("exr: bad channel list");
+                std::memcpy(&c.type, v + q, 4);
+                uint32_t xs, ys;
+                std::memcpy(&xs, v + q + 8, 4);
+                std::memcpy(&ys, v + q + 12, 4);
+                if (xs != 1 || ys != 1) throw std::runtime_error("unsupported: sub-sampled OpenEXR channels");
+                if (c.type > 2) throw std::runtime_error("exr: bad channel type");
+                q += 16;
+                chans.push_back(c);
+            }
+        } else if (name == "compression") {
+            compression = size ? v[0] : -1;
+        } else if (name == "dataWindow") {
+            if (size != 16) throw std::runtime_error("exr: bad dataWindow");
+            std::memcpy(dw, v, 16);
+        } else if (name == "lineOrder") {
+            line_order = size ? v[0] : 0;
+        }
+        pos += size;
+    }
+    if (chans.empty() || dw[2] < dw[0] || dw[3] < dw[1]) throw std::runtime_error("exr: missing channels or data window");
+    if (compression < 0 || compression > 3) throw std::runtime_error("unsupported: OpenEXR compression method " + std::to_string(compression) + " (none, RLE, ZIPS and ZIP are read)");
+    (void)line_order;  // the offset table is indexed by scanline block in increasing y whatever the order on disk
+    const uint64_t W = (uint64_t)(dw[2] - dw[0]) + 1, H = (uint64_t)(dw[3] - dw[1]) + 1;
+    if (W > 65535 || H > 65535) throw std::runtime_error("exr: image too large");
+    width = (uint32_t)W;
+    height = (uint32_t)H;
+    const uint32_t lines_per_block = compression == 3 ? 16u : 1u;
+    const uint64_t n_blocks = (H + lines_per_block - 1) / lines_per_block;
+    size_t bytes_per_pixel_row = 0;
+    for (const Chan& c : chans) bytes_per_pixel_row += (size_t)W * (c.type == 1 ? 2 : 4);
+    // which file channel feeds which of R, G, B, A
+    int src[4] = {-1, -1, -1, -1}, y_chan = -1;
+    for (size_t i = 0; i < chans.size(); i++) {
+        const std::string& nm = chans[i].name;
+        if (nm == "R") src[0] = (int)i; else if (nm == "G") src[1] = (int)i; else if (nm == "B") src[2] = (int)i; else if (nm == "A") src[3] = (int)i;
+        else if (nm == "Y") y_chan = (int)i;
+    }
+    if (src[0] < 0 && src[1] < 0 && src[2] < 0 && y_chan >= 0) src[0] = src[1] = src[2] = y_chan;
+    if (src[0] < 0 && src[1] < 0 && src[2] < 0) throw std::runtime_error("unsupported: OpenEXR file without R, G, B or Y channels");
+    rgba.assign(4ull * W * H, 0.0f);
+    for (uint64_t i = 0; i < W * H; i++) rgba[4 * i + 3] = 1.0f;
+    const size_t table = pos;
+    need(table, 8 * n_blocks);
+    for (uint64_t blk = 0; blk < n_blocks; blk++) {
+        uint64_t off = rd64(table + 8 * blk);
+        need(off, 8);
+        int32_t y0;
+        std::memcpy(&y0, data + off, 4);
+        uint32_t csize = rd32(off + 4);
+        need(off + 8, csize);
+        if (y0 < dw[1] || y0 > dw[3]) throw std::runtime_error("exr: scanline outside the data window");
+        const uint64_t rows = std::min<uint64_t>(lines_per_block, (uint64_t)(dw[3] - y0) + 1);
+        const size_t raw_size = bytes_per_pixel_row * rows;
+        std::vector<uint8_t> raw;
+        const uint8_t* src_bytes = data + off + 8;
+        if (csize == raw_size || compression == 0) {  // stored uncompressed (also when compression did not help)
+            if (csize != raw_size) throw std::runtime_error("exr: bad block size");
+            raw.assign(src_bytes, src_bytes + csize);
+        } else if (compression == 1) {
+            raw = exr_unpredict(exr_rle_decode(src_bytes, csize, raw_size));
+        } else {
+            raw = exr_unpredict(inflate_zlib(src_bytes, csize));
+        }
+        if (raw.size() != raw_size) throw std::runtime_error("exr: decompressed block has the wrong size");
+        size_t p = 0;
+        for (uint64_t r = 0; r < rows; r++) {
+            const uint64_t y = (uint64_t)(y0 - dw[1]) + r;
+            for (size_t ci = 0; ci < chans.size(); ci++) {  // channels are stored one after the other within a scanline
+                const uint32_t ty = chans[ci].type;
+                for (uint64_t x = 0; x < W; x++) {
+                    float f;
+                    if (ty == 1) { uint16_t hbits; std::memcpy(&hbits, &raw[p], 2); p += 2; f = half_to_float(hbits); }
+                    else if (ty == 2) { std::memcpy(&f, &raw[p], 4); p += 4; }
+                    else { uint32_t u; std::memcpy(&u, &raw[p], 4); p += 4; f = (float)u; }
+                    for (int k = 0; k < 4; k++)
+                        if (src[k] == (int)ci) rgba[4 * (y * W + x) + k] = f;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace akr

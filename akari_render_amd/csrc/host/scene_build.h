@@ -99,5 +99,7 @@ void write_image(const std::string& path, const float* rgb, uint32_t w, uint32_t
 void decode_png(const uint8_t* data, size_t n, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba);
 // JPEG (baseline + progressive Huffman, 8 bit, 1 or 3 components) -> RGBA8 in file order
 void decode_jpeg(const uint8_t* data, size_t n, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba);
+// OpenEXR (single-part scanline; none / RLE / ZIPS / ZIP; half / float / uint channels) -> RGBA f32 in file order
+void decode_exr(const uint8_t* data, size_t n, uint32_t& w, uint32_t& h, std::vector<float>& rgba);
 
 }  // namespace akr

@@ -277,8 +277,15 @@ struct GraphBuilder {
             hi.width = pw; hi.height = ph; hi.format = AKR_IMAGE_RGBA8;
             hi.words.resize((size_t)pw * ph);
             for (uint32_t y = 0; y < ph; y++) std::memcpy(hi.words.data() + (size_t)y * pw, px.data() + 4ull * pw * (ph - 1 - y), 4ull * pw);
+        } else if (fmt == "exr") {  // to_rgba32f, flipped like every encoded image (load.rs:596-611)
+            uint32_t pw = 0, ph = 0;
+            std::vector<float> px;
+            decode_exr(bytes.data(), bytes.size(), pw, ph, px);
+            hi.width = pw; hi.height = ph; hi.format = AKR_IMAGE_RGBA32F;
+            hi.words.resize(4ull * pw * ph);
+            for (uint32_t y = 0; y < ph; y++) std::memcpy(hi.words.data() + 4ull * pw * y, px.data() + 4ull * pw * (ph - 1 - y), 16ull * pw);
         } else {
-            throw std::runtime_error("unsupported: image format '" + fmt + "' (decode it on the host and pass texels through akr_image_desc; float, png and jpeg are read here)");
+            throw std::runtime_error("unsupported: image format '" + fmt + "' (decode it on the host and pass texels through akr_image_desc; float, png, jpeg and exr are read here)");
         }
         uint32_t idx = (uint32_t)flat.images.size();
         flat.images.push_back(std::move(hi));

@@ -414,6 +414,9 @@ AKR_API int32_t akr_host_decode_png(const uint8_t *data, uint64_t len, uint32_t 
 /* The JPEG reader of akr_scene_load (baseline + progressive Huffman, 8 bit, grey / YCbCr / RGB, any integer sampling
  * ratios, restart intervals). Same calling convention as akr_host_decode_png. */
 AKR_API int32_t akr_host_decode_jpeg(const uint8_t *data, uint64_t len, uint32_t *width, uint32_t *height, uint8_t *rgba, uint64_t capacity);
+/* The OpenEXR reader of akr_scene_load (single-part scanline; none / RLE / ZIPS / ZIP; half / float / uint channels R G B A
+ * or Y), RGBA f32 out, rows in file order. rgba == NULL: only the size is returned. */
+AKR_API int32_t akr_host_decode_exr(const uint8_t *data, uint64_t len, uint32_t *width, uint32_t *height, float *rgba, uint64_t capacity_floats);
 /* Evaluated inputs of `material` (26 words each = akr_material_desc) at n uv points: shader-graph evaluation + texture
  * sampling on the device, or -- ctx == NULL -- the same code on the host. */
 AKR_API int32_t akr_probe_material_inputs(akr_context *ctx, akr_scene *scene, uint32_t material, uint32_t n, const float *uv, float *out26);

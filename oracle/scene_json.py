@@ -232,6 +232,88 @@ def decode_png(data: bytes) -> np.ndarray:
     return out
 
 
+def decode_exr(data: bytes) -> np.ndarray:
+    """OpenEXR (single-part scanline, none / RLE / ZIPS / ZIP, half / float / uint channels) -> (H, W, 4) float32 in file
+    order; R, G, B (a lone Y is replicated), A = 1 when absent. Independent of the C++ reader (numpy + zlib)."""
+    import struct
+    import zlib
+
+    assert struct.unpack_from("<I", data, 0)[0] == 20000630, "bad EXR magic"
+    version = struct.unpack_from("<I", data, 4)[0]
+    if version & 0x1A00:
+        raise NotImplementedError("tiled / deep / multi-part EXR")
+    pos, chans, comp, dw = 8, [], None, None
+    while data[pos] != 0:
+        e = data.index(b"\0", pos); name = data[pos:e].decode(); pos = e + 1
+        e = data.index(b"\0", pos); pos = e + 1
+        (size,) = struct.unpack_from("<I", data, pos); pos += 4
+        v = data[pos : pos + size]; pos += size
+        if name == "channels":
+            q = 0
+            while v[q] != 0:
+                e = v.index(b"\0", q); cn = v[q:e].decode(); q = e + 1
+                ty, _, xs, ys = struct.unpack_from("<IIII", v, q); q += 16
+                assert xs == 1 and ys == 1
+                chans.append((cn, ty))
+        elif name == "compression":
+            comp = v[0]
+        elif name == "dataWindow":
+            dw = struct.unpack("<iiii", v)
+    pos += 1
+    if comp not in (0, 1, 2, 3):
+        raise NotImplementedError(f"EXR compression {comp}")
+    W, H = dw[2] - dw[0] + 1, dw[3] - dw[1] + 1
+    lpb = 16 if comp == 3 else 1
+    nblk = (H + lpb - 1) // lpb
+    sizes = [2 if ty == 1 else 4 for _, ty in chans]
+    row_bytes = W * sum(sizes)
+    planes = {cn: np.zeros((H, W), dtype=np.float32) for cn, _ in chans}
+
+    def unpredict(b: bytes) -> bytes:
+        t = np.frombuffer(b, dtype=np.uint8).astype(np.int64)
+        t[1:] -= 128
+        t = np.cumsum(t) & 255
+        half = (len(t) + 1) // 2
+        out = np.zeros(len(t), dtype=np.uint8)
+        out[0::2] = t[:half]
+        out[1::2] = t[half:]
+        return out.tobytes()
+
+    def unrle(b: bytes) -> bytes:
+        out, i = bytearray(), 0
+        while i < len(b):
+            c = b[i] - 256 if b[i] > 127 else b[i]
+            i += 1
+            if c < 0:
+                out += b[i : i - c]; i += -c
+            else:
+                out += bytes([b[i]]) * (c + 1); i += 1
+        return bytes(out)
+
+    for k in range(nblk):
+        (off,) = struct.unpack_from("<Q", data, pos + 8 * k)
+        y0, csize = struct.unpack_from("<iI", data, off)
+        rows = min(lpb, dw[3] - y0 + 1)
+        blob = data[off + 8 : off + 8 + csize]
+        if comp != 0 and csize != row_bytes * rows:
+            blob = unpredict(unrle(blob) if comp == 1 else zlib.decompress(blob))
+        p = 0
+        for r in range(rows):
+            for (cn, ty), sz in zip(chans, sizes):
+                seg = blob[p : p + W * sz]; p += W * sz
+                arr = np.frombuffer(seg, dtype={0: np.uint32, 1: np.float16, 2: np.float32}[ty]).astype(np.float32)
+                planes[cn][y0 - dw[1] + r] = arr
+    out = np.zeros((H, W, 4), dtype=np.float32)
+    out[:, :, 3] = 1.0
+    names = [cn for cn, _ in chans]
+    if not any(c in names for c in "RGB") and "Y" in names:
+        out[:, :, 0] = out[:, :, 1] = out[:, :, 2] = planes["Y"]
+    for k, cn in enumerate("RGBA"):
+        if cn in planes:
+            out[:, :, k] = planes[cn]
+    return out
+
+
 class _Graph:
     """Translation of the texture-fed inputs of a surface node (svm/compiler.rs:116-337) into abi.GraphData."""
 
@@ -269,6 +351,8 @@ class _Graph:
             tex[:, :, :ch] = src  # load.rs:552-569; not flipped
         elif im["format"] == "png":
             tex = decode_png(raw)[::-1].copy()  # flipv, load.rs:596
+        elif im["format"] == "exr":
+            tex = decode_exr(raw)[::-1].copy()
         elif im["format"] == "jpeg":
             import io
 

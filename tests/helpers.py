@@ -270,3 +270,65 @@ def textured_room(width=48, height=48, n_floor=1, seed=11, alpha_cutout=False, t
     c2w[:3, 3] = [0.0, 0.0, 0.95]
     cam = abi.CameraData(c2w=c2w.T.reshape(16).copy(), fov=1.3, width=width, height=height)
     return abi.SceneData(meshes, insts, mats, cam, images=images)
+
+
+def make_exr(planes: dict, compression: int = 3, line_order: int = 0) -> bytes:
+    """Single-part scanline OpenEXR from {channel name: (H, W) array of float16 / float32 / uint32}; compression 0 none,
+    1 RLE, 2 ZIPS, 3 ZIP (the file-format definitions: per block, channel rows one after the other, byte de-interleave,
+    delta predictor, then RLE / deflate; a block that does not shrink is stored raw)."""
+    import struct
+    import zlib
+
+    names = sorted(planes)
+    h, w = planes[names[0]].shape
+    tcode = {np.dtype(np.uint32): 0, np.dtype(np.float16): 1, np.dtype(np.float32): 2}
+
+    def attr(name, ty, v):
+        return name.encode() + b"\0" + ty.encode() + b"\0" + struct.pack("<I", len(v)) + v
+
+    chl = b"".join(n.encode() + b"\0" + struct.pack("<IIII", tcode[planes[n].dtype], 0, 1, 1) for n in names) + b"\0"
+    head = struct.pack("<II", 20000630, 2)
+    head += attr("channels", "chlist", chl) + attr("compression", "compression", bytes([compression]))
+    box = struct.pack("<iiii", 0, 0, w - 1, h - 1)
+    head += attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", bytes([line_order]))
+    head += attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0))
+    head += attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
+    lpb = 16 if compression == 3 else 1
+    blocks = []
+    for y0 in range(0, h, lpb):
+        raw = b"".join(planes[n][y].tobytes() for y in range(y0, min(h, y0 + lpb)) for n in names)
+        blob = raw
+        if compression:
+            t = np.frombuffer(raw, dtype=np.uint8)
+            t = np.concatenate([t[0::2], t[1::2]]).astype(np.int64)
+            d = t.copy()
+            d[1:] = (t[1:] - t[:-1] + 128 + 256) & 255
+            pre = d.astype(np.uint8).tobytes()
+            if compression == 1:
+                out, i = bytearray(), 0
+                while i < len(pre):  # runs of >= 3 equal bytes, literals otherwise
+                    j = i
+                    while j + 1 < len(pre) and pre[j + 1] == pre[i] and j - i < 126:
+                        j += 1
+                    if j - i >= 2:
+                        out += bytes([j - i, pre[i]]); i = j + 1
+                    else:
+                        k = i
+                        while k < len(pre) and k - i < 127 and not (k + 2 < len(pre) and pre[k] == pre[k + 1] == pre[k + 2]):
+                            k += 1
+                        out += bytes([(256 - (k - i)) & 255]) + pre[i:k]; i = k
+                comp = bytes(out)
+            else:
+                comp = zlib.compress(pre, 6)
+            blob = comp if len(comp) < len(raw) else raw
+        blocks.append(struct.pack("<iI", y0, len(blob)) + blob)
+    order = range(len(blocks)) if line_order == 0 else reversed(range(len(blocks)))
+    table_pos = len(head)
+    offsets = [0] * len(blocks)
+    body = b""
+    cur = table_pos + 8 * len(blocks)
+    for k in order:
+        offsets[k] = cur
+        body += blocks[k]
+        cur += len(blocks[k])
+    return head + b"".join(struct.pack("<Q", o) for o in offsets) + body

@@ -426,3 +426,75 @@ def test_alpha_textured_flag_is_exact():
     sd = textured_room()
     sd.images[0].address = abi.TEX_CLIP  # opaque texels, but outside [0, 1]^2 the sampler returns alpha 0
     assert flags(sd)[1] == 3
+
+
+# ---------------------------------------------------------------------------------------------- OpenEXR reader
+@pytest.mark.parametrize("compression", [0, 1, 2, 3], ids=["none", "rle", "zips", "zip"])
+@pytest.mark.parametrize("layout", ["rgb_half", "rgba_float", "y_half", "mixed"])
+def test_exr_reader(compression, layout):
+    from tests.helpers import make_exr
+
+    rng = np.random.default_rng(compression * 7 + len(layout))
+    h, w = 37, 21
+    smooth = lambda: (np.linspace(0, 4, w)[None, :] * np.linspace(0.5, 2, h)[:, None] + rng.random((h, w)) * 0.01)  # noqa: E731
+    if layout == "rgb_half":
+        planes = {c: smooth().astype(np.float16) for c in "RGB"}
+    elif layout == "rgba_float":
+        planes = {c: smooth().astype(np.float32) for c in "RGBA"}
+    elif layout == "y_half":
+        planes = {"Y": smooth().astype(np.float16)}
+    else:
+        planes = {"R": smooth().astype(np.float32), "G": smooth().astype(np.float16), "B": (smooth() * 100).astype(np.uint32),
+                  "Z": smooth().astype(np.float32)}
+        planes["G"][3, 4] = np.float16(6e-6)  # a subnormal half
+        planes["G"][5, 6] = np.float16(np.inf)
+    data = make_exr(planes, compression, line_order=compression % 2)
+    got = capi.host_decode_exr(data)
+    ref = scene_json.decode_exr(data)
+    assert got.shape == (h, w, 4) and n_bit_diff(got, ref) == 0
+    want = np.zeros((h, w, 4), dtype=np.float32)
+    want[:, :, 3] = 1.0
+    for k, c in enumerate("RGBA"):
+        if c in planes:
+            want[:, :, k] = planes[c].astype(np.float32)
+    if layout == "y_half":
+        want[:, :, :3] = planes["Y"].astype(np.float32)[:, :, None]
+    assert n_bit_diff(got, want) == 0
+
+
+def test_exr_reader_reads_the_writer_and_rejects_what_it_cannot_read(tmp_path):
+    rgb = np.random.default_rng(0).random((9, 14, 3)).astype(np.float32)
+    path = str(tmp_path / "out.exr")
+    capi.image_write(path, rgb)  # the library's own uncompressed writer
+    got = capi.host_decode_exr(open(path, "rb").read())
+    assert np.array_equal(got[:, :, :3], rgb) and np.all(got[:, :, 3] == 1.0)
+    from tests.helpers import make_exr
+
+    data = bytearray(make_exr({"R": np.zeros((4, 4), np.float32)}, 2))
+    i = data.index(b"compression\0compression\0") + len(b"compression\0compression\0") + 4
+    data[i] = 4  # PIZ
+    with pytest.raises(capi.AkariError) as e:
+        capi.host_decode_exr(bytes(data))
+    assert e.value.code == -6
+    with pytest.raises(capi.AkariError):
+        capi.host_decode_exr(b"v/1\x01 not an exr")
+
+
+def test_scene_loader_reads_exr_textures(tmp_path):
+    from tests.helpers import make_exr
+
+    rng = np.random.default_rng(4)
+    planes = {c: rng.random((6, 5)).astype(np.float16) for c in "RGB"}
+    data = make_exr(planes, 3)
+    path = _scene_json_with_textures(tmp_path, data, rng.random((4, 3, 3)).astype(np.float32))
+    scene = json.loads(open(path).read())
+    for m in ("m_floor", "m_wall"):
+        scene["materials"][m]["shader"]["nodes"]["img"]["image"].update(format="exr", width=5, height=6, colorspace="none")
+    p2 = tmp_path / "exr_scene.json"
+    p2.write_text(json.dumps(scene))
+    got = capi.Scene(None, str(p2)).to_scene_data()
+    pyl = scene_json.load_scene(str(p2))
+    a = [im.texels for im in got.images if im.texels.shape[:2] == (6, 5)][0]
+    b = [im.texels for im in pyl.images if im.texels.shape[:2] == (6, 5)][0]
+    assert a.dtype == np.float32 and n_bit_diff(a, b) == 0
+    assert np.array_equal(a[::-1, :, 0], planes["R"].astype(np.float32))  # flipped vertically
