@@ -15,6 +15,15 @@ c_f32p = C.POINTER(C.c_float)
 c_u32p = C.POINTER(C.c_uint32)
 
 
+class _Struct(C.Structure):
+    """ctypes.Structure that refuses attributes which are not fields (a misspelt field would otherwise be a silent no-op)."""
+
+    def __setattr__(self, name, value):
+        if not any(f[0] == name for f in self._fields_):
+            raise AttributeError("%s has no field %r" % (type(self).__name__, name))
+        super().__setattr__(name, value)
+
+
 class MeshDesc(C.Structure):
     _fields_ = [
         ("n_vertices", C.c_uint32),
@@ -111,10 +120,10 @@ class SceneDesc(C.Structure):
 
 
 FILTER_BOX, FILTER_GAUSSIAN = 0, 1
-SAMPLER_INDEPENDENT = 0
+SAMPLER_INDEPENDENT, SAMPLER_PMJ02BN = 0, 1
 
 
-class PtConfig(C.Structure):
+class PtConfig(_Struct):
     """akr_pt_config = pt::Config (pt.rs:916-944) + filter + sampler + shard."""
 
     _fields_ = [
@@ -162,7 +171,7 @@ AOV_NS, AOV_NG, AOV_TANGENT, AOV_BITANGENT, AOV_ALBEDO, AOV_ROUGHNESS = range(6)
 AOV_NAMES = ("ns", "ng", "tangent", "bitangent", "albedo", "roughness")
 
 
-class AovConfig(C.Structure):
+class AovConfig(_Struct):
     """akr_aov_config = aov::Config (aov.rs:23-39) + filter + sampler + shard."""
 
     _fields_ = [

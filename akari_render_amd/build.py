@@ -18,6 +18,7 @@ SOURCES = [
     "host/scene_json.cpp",
     "host/bvh.cpp",
     "host/image_io.cpp",
+    "host/pmj_tables.cpp",
 ]
 def _headers():
     """Every header the sources can include: all of csrc/ and the public header (a forgotten entry in a hand-kept list

@@ -35,7 +35,7 @@ EXPORTS = [
     "akr_pt_read_sampler_states",
     "akr_host_stdrng_u64", "akr_host_chacha_block", "akr_host_pcg32_states", "akr_host_pcg_start", "akr_host_alias_table",
     "akr_probe_math", "akr_probe_bsdf", "akr_probe_intersect", "akr_probe_surface_interaction", "akr_probe_material_inputs",
-    "akr_host_decode_png", "akr_host_decode_jpeg", "akr_host_decode_exr",
+    "akr_host_decode_png", "akr_host_decode_jpeg", "akr_host_decode_exr", "akr_host_pmj02bn_tables",
 ]
 
 
@@ -126,6 +126,7 @@ def lib() -> C.CDLL:
     proto("akr_host_decode_png", C.c_char_p, u64, up, up, C.POINTER(C.c_uint8), u64)
     proto("akr_host_decode_jpeg", C.c_char_p, u64, up, up, C.POINTER(C.c_uint8), u64)
     proto("akr_host_decode_exr", C.c_char_p, u64, up, up, fp, u64)
+    proto("akr_host_pmj02bn_tables", up, C.POINTER(C.c_uint16))
     _lib = L
     return L
 
@@ -515,3 +516,11 @@ def host_decode_exr(data: bytes) -> np.ndarray:
     out = np.zeros((h.value, w.value, 4), dtype=np.float32)
     check(lib().akr_host_decode_exr(data, len(data), C.byref(w), C.byref(h), _fp(out), out.size))
     return out
+
+
+def host_pmj02bn_tables():
+    """(sets u32[5, 65536, 2], bluenoise u16[48, 128, 128]) exactly as the library's pmj02bn sampler reads them."""
+    sets = np.zeros((5, 65536, 2), dtype=np.uint32)
+    bn = np.zeros((48, 128, 128), dtype=np.uint16)
+    check(lib().akr_host_pmj02bn_tables(_up(sets), bn.ctypes.data_as(C.POINTER(C.c_uint16))))
+    return sets, bn

@@ -7,7 +7,7 @@ namespace akr {
 
 enum : uint32_t { AOV_NS = 0, AOV_NG = 1, AOV_TANGENT = 2, AOV_BITANGENT = 3, AOV_ALBEDO = 4, AOV_ROUGHNESS = 5 };
 
-template <bool BVH, bool TEX>
+template <bool BVH, bool TEX, bool PMJ>
 __global__ __launch_bounds__(256) void k_aov(const PtParams p, uint32_t spp, uint32_t aov, uint32_t remap) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     TraceCtx tc;
@@ -27,9 +27,9 @@ __global__ __launch_bounds__(256) void k_aov(const PtParams p, uint32_t spp, uin
         vec3 acc = mk3(p.film[3 * (size_t)pix + 0], p.film[3 * (size_t)pix + 1], p.film[3 * (size_t)pix + 2]);
         float wsum = p.film[6 * N + pix];
         for (uint32_t s = 0; s < spp; s++) {
-            pcg_start(smp.pcg, p.start);  // sampler.start(), aov.rs:86
+            sampler_start<PMJ>(p, smp);  // sampler.start(), aov.rs:86
             vec3 o, d;
-            generate_ray(p, px, py, smp, o, d);
+            generate_ray<PMJ>(p, px, py, smp, o, d);
             Hit hit;
             n_closest++;
             bool found = BVH ? trace_bvh4<false, TEX>(sc, o, d, 0.0f, 1e20f, kInvalid, kInvalid, hit, tc.stack, tc.cnt)
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_aov(const PtParams p, uint32_t spp, uin
                     shade_point_init(sp, mat, si.frame, si.ng, false);
                     if (aov == AOV_NS) c = remapped(shade_ns(sp, mat));
                     else if (aov == AOV_ALBEDO) c = shade_albedo_plus_emission(mat);
-                    else c = mk3(1, 1, 1) * shade_roughness(sp, mat, sc.ggx_table, -d, next_1d(smp));
+                    else c = mk3(1, 1, 1) * shade_roughness(sp, mat, sc.ggx_table, -d, next_1d<PMJ>(p, smp));
                 }
             }
             // film.add_sample(p, color, swl, ray_w = 1), film.rs:196-229
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k_aov(const PtParams p, uint32_t spp, uin
             acc = mk3(acc.x + c.x * 1.0f, acc.y + c.y * 1.0f, acc.z + c.z * 1.0f);
             wsum = wsum + 1.0f;
         }
-        pcg_advance(smp.pcg, -(int64_t)smp.dim);  // Drop for IndependentSampler, sampler/mod.rs:168-177
+        sampler_end_pass<PMJ>(p, smp);  // Drop of the sampler
         p.states[pix] = smp.pcg;
         p.film[3 * (size_t)pix + 0] = acc.x;
         p.film[3 * (size_t)pix + 1] = acc.y;
@@ -86,13 +86,14 @@ hipError_t launch_aov(const PtParams& p, uint32_t spp, uint32_t aov, uint32_t re
     if (blocks == 0) return hipSuccess;
     const bool bvh = p.sc.bvh_nodes != nullptr, tex = p.sc.tex.nodes != nullptr;
     const size_t lds = bvh ? kBvhStackDepth * 256 * 4 : 0;
-    if (bvh) {
-        if (tex) hipLaunchKernelGGL((k_aov<true, true>), dim3(blocks), dim3(256), lds, stream, p, spp, aov, remap);
-        else hipLaunchKernelGGL((k_aov<true, false>), dim3(blocks), dim3(256), lds, stream, p, spp, aov, remap);
-    } else {
-        if (tex) hipLaunchKernelGGL((k_aov<false, true>), dim3(blocks), dim3(256), lds, stream, p, spp, aov, remap);
-        else hipLaunchKernelGGL((k_aov<false, false>), dim3(blocks), dim3(256), lds, stream, p, spp, aov, remap);
+#define AKR_AOV(B, T)                                                                                                  \
+    {                                                                                                                \
+        if (p.sampler) hipLaunchKernelGGL((k_aov<B, T, true>), dim3(blocks), dim3(256), lds, stream, p, spp, aov, remap); \
+        else hipLaunchKernelGGL((k_aov<B, T, false>), dim3(blocks), dim3(256), lds, stream, p, spp, aov, remap);      \
     }
+    if (bvh) { if (tex) AKR_AOV(true, true) else AKR_AOV(true, false) }
+    else { if (tex) AKR_AOV(false, true) else AKR_AOV(false, false) }
+#undef AKR_AOV
     return hipGetLastError();
 }
 

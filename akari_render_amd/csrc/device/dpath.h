@@ -41,29 +41,111 @@ AKR_D vec2 filter_sample(const PtParams& p, vec2 u) {
     return mk2(clamp_f(off.x, -width, width), clamp_f(off.y, -width, width));
 }
 
-struct Sampler {  // IndependentSampler, sampler/mod.rs:161-217
+// The sampler of one pixel. Independent (sampler/mod.rs:161-217): PCG32 state + dimensions drawn so far. Pmj02Bn
+// (sampler/mod.rs:329-700, Pmj02BnState): pcg.state = sample index (u32::MAX before the first start()), pcg.inc =
+// x | y << 32 of the pixel the sampler was created for, dim = dimension counter; seed / spp / w and the tables come from
+// PtParams. Which one is a template parameter of the kernels (PMJ): the PCG path carries none of the table code.
+struct Sampler {
     Pcg32 pcg;
     uint32_t dim;
 };
-AKR_D float next_1d(Sampler& s) {
+constexpr uint32_t kPmjSets = 5, kPmjSamples = 65536, kBlueNoiseTextures = 48, kBlueNoiseRes = 128;
+// permute_element (sampler/mod.rs:473-507; Kensler's hashed permutation of [0, l))
+AKR_D uint32_t permute_element(uint32_t i, uint32_t l, uint32_t w, uint32_t p) {
+    do {
+        i ^= p;
+        i *= 0xe170893du;
+        i ^= p >> 16;
+        i ^= (i & w) >> 4;
+        i ^= p >> 8;
+        i *= 0x0929eb3fu;
+        i ^= p >> 23;
+        i ^= (i & w) >> 1;
+        i *= 1u | p >> 27;
+        i *= 0x6935fa69u;
+        i ^= (i & w) >> 11;
+        i *= 0x74dcb303u;
+        i ^= (i & w) >> 2;
+        i *= 0x9e501cc3u;
+        i ^= (i & w) >> 2;
+        i *= 0xc860a3dfu;
+        i &= w;
+        i ^= i >> 5;
+    } while (i >= l);
+    return (i + p) % l;
+}
+// bluenoise(tex_index, p): uv = p.yx() % 128 of texture tex_index % 48 (sampler/mod.rs:545-553), unorm16 -> float
+AKR_D float pmj_bluenoise(const PtParams& p, uint32_t tex, uint32_t px, uint32_t py) {
+    uint32_t tx = py % kBlueNoiseRes, ty = px % kBlueNoiseRes;  // uv = (p.y, p.x)
+    uint16_t v = p.bluenoise[((size_t)(tex % kBlueNoiseTextures) * kBlueNoiseRes + ty) * kBlueNoiseRes + tx];
+    return (float)v / 65535.0f;
+}
+constexpr float kOneMinusEpsilon = 0.99999994f;
+template <bool PMJ>
+AKR_D float next_1d(const PtParams& p, Sampler& s) {
+    if (!PMJ) {
+        s.dim += 1;
+        return pcg_next_1d(s.pcg);
+    }
+    // Pmj02BnSampler::next_1d (sampler/mod.rs:555-580)
+    const uint32_t px = (uint32_t)s.pcg.inc, py = (uint32_t)(s.pcg.inc >> 32), sample_index = (uint32_t)s.pcg.state;
+    uint32_t hash = xxhash32_4(px, py, s.dim, p.smp_seed);
+    uint32_t index = permute_element(sample_index, p.smp_spp, p.smp_w, hash);
+    float delta = pmj_bluenoise(p, s.dim, px, py);
     s.dim += 1;
-    return pcg_next_1d(s.pcg);
+    return min_f(((float)index + delta) / (float)p.smp_spp, kOneMinusEpsilon);
 }
-AKR_D vec2 next_2d(Sampler& s) {
-    float a = next_1d(s);
-    float b = next_1d(s);
-    return mk2(a, b);
+template <bool PMJ>
+AKR_D vec2 next_2d(const PtParams& p, Sampler& s) {
+    if (!PMJ) {
+        float a = next_1d<PMJ>(p, s);
+        float b = next_1d<PMJ>(p, s);
+        return mk2(a, b);
+    }
+    // Pmj02BnSampler::next_2d (sampler/mod.rs:582-630)
+    const uint32_t px = (uint32_t)s.pcg.inc, py = (uint32_t)(s.pcg.inc >> 32);
+    uint32_t index = (uint32_t)s.pcg.state;
+    const uint32_t dim = s.dim, pmj_instance = dim / 2;
+    if (pmj_instance >= kPmjSets) index = permute_element(index, p.smp_spp, p.smp_w, xxhash32_4(px, py, dim, p.smp_seed));
+    const uint32_t* smp = p.pmj_sets + 2 * ((size_t)kPmjSamples * (pmj_instance % kPmjSets) + (index % kPmjSamples));
+    vec2 u = mk2((float)smp[0] * 2.3283064365386963e-10f, (float)smp[1] * 2.3283064365386963e-10f);
+    float dx = pmj_bluenoise(p, dim, px, py), dy = pmj_bluenoise(p, dim + 1, px, py);
+    u = mk2(u.x + dx, u.y + dy);
+    s.dim += 2;
+    u = mk2(u.x - __builtin_floorf(u.x), u.y - __builtin_floorf(u.y));
+    return mk2(min_f(u.x, kOneMinusEpsilon), min_f(u.y, kOneMinusEpsilon));
 }
-AKR_D vec3 next_3d(Sampler& s) {
-    float a = next_1d(s);
-    vec2 b = next_2d(s);
+template <bool PMJ>
+AKR_D vec3 next_3d(const PtParams& p, Sampler& s) {  // trait default: (next_1d, next_2d), sampler/mod.rs:22-27
+    float a = next_1d<PMJ>(p, s);
+    vec2 b = next_2d<PMJ>(p, s);
     return mk3(a, b.x, b.y);
+}
+// sampler.start() (sampler/mod.rs:199-203 / 650-663)
+template <bool PMJ>
+AKR_D void sampler_start(const PtParams& p, Sampler& s) {
+    if (!PMJ) {
+        pcg_start(s.pcg, p.start);
+    } else {
+        s.dim = 4;
+        uint32_t idx = (uint32_t)s.pcg.state;
+        s.pcg.state = idx == 0xffffffffu ? 0u : idx + 1u;
+    }
+}
+// end of a pass: Drop of the sampler (sampler/mod.rs:168-177 / 633-640) and its re-creation from the stored state
+template <bool PMJ>
+AKR_D void sampler_end_pass(const PtParams& p, Sampler& s) {
+    if (!PMJ) {
+        pcg_advance(s.pcg, -(int64_t)s.dim);
+        s.dim = 0;
+    }  // pmj02bn: the state is stored as it is; dim is reset by the next start()
 }
 
 // camera/mod.rs:70-103
+template <bool PMJ>
 AKR_D void generate_ray(const PtParams& p, uint32_t px, uint32_t py, Sampler& smp, vec3& o, vec3& d) {
     vec2 fpixel = mk2((float)px + 0.5f, (float)py + 0.5f);
-    vec2 offset = filter_sample(p, next_2d(smp));
+    vec2 offset = filter_sample(p, next_2d<PMJ>(p, smp));
     vec2 pf = mk2(fpixel.x + offset.x, fpixel.y + offset.y);
     const float* m = p.r2c;
     float qx = ((m[0] * pf.x + m[4] * pf.y) + m[8] * 0.0f) + m[12] * 1.0f;
@@ -203,6 +285,7 @@ struct PathRegs {
     uint32_t c_samples, c_closest, c_shadow, c_shaded;
 };
 
+template <bool PMJ = false>
 AKR_D void path_regs_init(PathRegs& r, const PtParams& p, bool active, uint32_t pix, uint32_t sx, uint32_t sy) {
     const size_t N = (size_t)p.width * p.height;
     r.ro = mk3(0, 0, 0); r.rd = mk3(0, 0, 1); r.ray_ex0 = kInvalid;
@@ -221,8 +304,8 @@ AKR_D void path_regs_init(PathRegs& r, const PtParams& p, bool active, uint32_t 
         r.smp.pcg = p.states[pix];  // SamplerCreator::create, sampler/mod.rs:317-327
         r.film_rgb = mk3(p.film[3 * (size_t)pix + 0], p.film[3 * (size_t)pix + 1], p.film[3 * (size_t)pix + 2]);
         r.film_w = p.film[6 * N + pix];
-        pcg_start(r.smp.pcg, p.start);  // sampler.start(), sampler/mod.rs:199-203
-        generate_ray(p, sx, sy, r.smp, r.ro, r.rd);
+        sampler_start<PMJ>(p, r.smp);  // sampler.start()
+        generate_ray<PMJ>(p, sx, sy, r.smp, r.ro, r.rd);
     }
 }
 
@@ -241,7 +324,7 @@ AKR_D void shifted_pixel(const PtParams& p, uint32_t px, uint32_t py, uint32_t& 
 // FD: 1 / 0 = force_diffuse known at compile time (the reference's JIT also specialises the kernel on it: the branch
 // at pt.rs:268 is taken while tracing the kernel, so a force_diffuse kernel contains no Principled code); -1 = read
 // p.force_diffuse at run time.
-template <int FD = -1, bool TEX = false>
+template <int FD = -1, bool TEX = false, bool PMJ = false>
 AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found, bool occluded, uint32_t pix, uint32_t sx, uint32_t sy) {
     const bool force_diffuse = FD < 0 ? (p.force_diffuse != 0) : (FD != 0);
     const DScene& sc = p.sc;
@@ -307,12 +390,12 @@ AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found,
             } else {
                 r.depth += 1;
                 r.c_shaded++;
-                vec3 u_direct = next_3d(r.smp);
+                vec3 u_direct = next_3d<PMJ>(p, r.smp);
                 LightSample dl;
                 dl.valid = false;
                 if (p.use_nee && (!p.indirect_only || r.depth > 1))
                     dl = sample_direct<TEX>(sc, si.p, si.ng, u_direct.x, mk2(u_direct.y, u_direct.z));
-                vec3 u_bsdf = next_3d(r.smp);
+                vec3 u_bsdf = next_3d<PMJ>(p, r.smp);
                 // sample_surface_and_shade_direct, pt.rs:297-323
                 ShadePoint sp;
                 shade_point_init(sp, mat, si.frame, si.ng, force_diffuse);
@@ -340,7 +423,7 @@ AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found,
                     bool cont = true;
                     if (r.depth > p.rr_depth) {  // pt.rs:211-224, 843-850
                         float cont_prob = clamp_f(max3(r.beta), 0.0f, 1.0f) * 0.95f;
-                        if (next_1d(r.smp) >= cont_prob)
+                        if (next_1d<PMJ>(p, r.smp) >= cont_prob)
                             cont = false;
                         else
                             r.beta = r.beta * div_s(mk3(1, 1, 1), cont_prob);
@@ -379,16 +462,15 @@ AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found,
             if (r.samples_done == r.cur_spp) {
                 // end of a pass: Drop for IndependentSampler (sampler/mod.rs:168-177) = advance(-dim); the next
                 // pass re-creates the sampler from that state with dim = 0 (sampler/mod.rs:317-327)
-                pcg_advance(r.smp.pcg, -(int64_t)r.smp.dim);
-                r.smp.dim = 0;
+                sampler_end_pass<PMJ>(p, r.smp);
                 r.samples_done = 0;
                 r.pass_idx++;
                 r.cur_spp = (r.pass_idx + 1 == p.n_passes) ? p.last_pass_spp : p.pass_spp;
                 more = r.pass_idx < p.n_passes;
             }
             if (more) {
-                pcg_start(r.smp.pcg, p.start);
-                generate_ray(p, sx, sy, r.smp, r.ro, r.rd);
+                sampler_start<PMJ>(p, r.smp);
+                generate_ray<PMJ>(p, sx, sy, r.smp, r.ro, r.rd);
                 r.ray_ex0 = kInvalid;
             } else {
                 r.has_ray = false;

@@ -106,6 +106,17 @@ struct akr_context {
     hipStream_t stream = nullptr;
     hipDeviceProp_t props;
     void bind() const { HIP_CHECK(hipSetDevice(device)); }
+    // tables of the pmj02bn sampler, uploaded when the first session asks for it
+    DevBuf pmj_sets, bluenoise;
+    void ensure_pmj_tables() {
+        if (pmj_sets.p && bluenoise.p) return;
+        std::vector<uint32_t> sets;
+        std::vector<uint16_t> bn;
+        make_pmj02_sets(sets);
+        load_bluenoise(bn);
+        pmj_sets.upload(sets);
+        bluenoise.upload(bn);
+    }
 };
 
 struct akr_scene {
@@ -141,6 +152,7 @@ struct akr_pt_session {
     WfBuffers wf;
     uint32_t wf_slots = 0, wf_trace_blocks = 0;
     uint32_t spp_done = 0, n_launches = 0;
+    uint32_t pmj_spp = 1;  // the spp the pmj02bn sampler stratifies for (the method's total spp)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     PtParams params;
 };
@@ -264,6 +276,16 @@ static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pas
     p.states = se->states.as<Pcg32>();
     p.film = se->film->data;
     p.counters = se->counters.as<uint64_t>();
+    p.sampler = c.sampler_type;
+    if (c.sampler_type == AKR_SAMPLER_PMJ02BN) {  // Pmj02BnSamplerCreator::new (sampler/mod.rs:376-395)
+        p.smp_seed = (uint32_t)c.sampler_seed;
+        p.smp_spp = se->pmj_spp;
+        uint32_t w = se->pmj_spp - 1;
+        w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
+        p.smp_w = w;
+        p.pmj_sets = se->ctx->pmj_sets.as<uint32_t>();
+        p.bluenoise = se->ctx->bluenoise.as<uint16_t>();
+    }
     p.shard_rank = c.shard_count > 1 ? c.shard_rank : 0;
     p.shard_count = c.shard_count > 1 ? c.shard_count : 1;
     p.tile_w = c.tile_w ? c.tile_w : 32;
@@ -342,7 +364,9 @@ static void wf_run(akr_pt_session* se) {
 static void validate_config(const akr_pt_config& c) {
     if (c.spp_per_pass == 0) throw std::invalid_argument("akr_pt_config: spp_per_pass must be > 0");
     if (c.filter_type > AKR_FILTER_GAUSSIAN) throw std::invalid_argument("akr_pt_config: unknown filter_type");
-    if (c.sampler_type != AKR_SAMPLER_INDEPENDENT) throw Unsupported("unsupported: only the independent sampler is available");
+    if (c.sampler_type > AKR_SAMPLER_PMJ02BN) throw std::invalid_argument("akr_pt_config: unknown sampler_type");
+    if (c.sampler_type == AKR_SAMPLER_PMJ02BN && c.spp > 65536u)
+        throw std::invalid_argument("Pmj02BnSampler supports up to 65536 spp (sampler/mod.rs:381-387)");
     uint32_t tw = c.tile_w ? c.tile_w : 32, th = c.tile_h ? c.tile_h : 32;
     if ((tw % 8) || (th % 8)) throw std::invalid_argument("akr_pt_config: tile_w and tile_h must be multiples of 8");
     if (c.shard_count > 1 && c.shard_rank >= c.shard_count) throw std::invalid_argument("akr_pt_config: shard_rank >= shard_count");
@@ -661,13 +685,23 @@ AKR_API int32_t akr_pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_co
         se->cfg = *cfg;
         const uint64_t n = (uint64_t)film->width * film->height;
         // init_pcg32_buffer_with_seed (sampler/mod.rs:148-160): host StdRng(seed) u64 per pixel, device new_seq_offset
-        std::vector<uint64_t> seeds(n);
-        StdRng rng(cfg->sampler_seed);
-        for (auto& v : seeds) v = rng.next_u64();
-        DevBuf dseeds;
-        dseeds.upload(seeds);
-        se->states.alloc(n * sizeof(Pcg32));
-        HIP_CHECK(launch_init_pcg32(dseeds.as<uint64_t>(), se->states.p, n, ctx->stream));
+        if (cfg->sampler_type == AKR_SAMPLER_PMJ02BN) {
+            // Pmj02BnState per pixel (sampler/mod.rs:451-466): sample_index = u32::MAX, pixel = (x, y), kept in a Pcg32 slot
+            ctx->ensure_pmj_tables();
+            se->pmj_spp = cfg->spp ? cfg->spp : 1;
+            std::vector<Pcg32> init(n);
+            for (uint64_t i = 0; i < n; i++) init[i] = Pcg32{0xffffffffull, (i % film->width) | ((i / film->width) << 32)};
+            se->states.upload(init);
+        } else {
+            std::vector<uint64_t> seeds(n);
+            StdRng rng(cfg->sampler_seed);
+            for (auto& v : seeds) v = rng.next_u64();
+            DevBuf dseeds;
+            dseeds.upload(seeds);
+            se->states.alloc(n * sizeof(Pcg32));
+            HIP_CHECK(launch_init_pcg32(dseeds.as<uint64_t>(), se->states.p, n, ctx->stream));
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));  // dseeds goes out of scope
+        }
         se->counters.alloc(8 * sizeof(uint64_t));
         HIP_CHECK(hipMemsetAsync(se->counters.p, 0, 8 * sizeof(uint64_t), ctx->stream));
         se->wavefront = choose_wavefront(scene);
@@ -1016,6 +1050,20 @@ AKR_API int32_t akr_probe_surface_interaction(akr_context* ctx, akr_scene* scene
     });
 }
 
+AKR_API int32_t akr_host_pmj02bn_tables(uint32_t* sets, uint16_t* bluenoise) {
+    return guarded([&] {
+        if (sets) {
+            std::vector<uint32_t> v;
+            make_pmj02_sets(v);
+            std::memcpy(sets, v.data(), v.size() * 4);
+        }
+        if (bluenoise) {
+            std::vector<uint16_t> v;
+            load_bluenoise(v);
+            std::memcpy(bluenoise, v.data(), v.size() * 2);
+        }
+    });
+}
 // PNG reader of the scene loader, exposed for tests: rgba == NULL returns the size only.
 AKR_API int32_t akr_host_decode_png(const uint8_t* data, uint64_t len, uint32_t* width, uint32_t* height, uint8_t* rgba, uint64_t capacity) {
     if (!data || !width || !height) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_host_decode_png: NULL argument");

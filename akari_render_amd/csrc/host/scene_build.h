@@ -93,6 +93,9 @@ struct ParsedTask {
     std::string film_out;
 };
 std::vector<ParsedTask> parse_render_tasks(const std::string& text, bool allow_sampler_override);
+// tables of the pmj02bn sampler (host/pmj_tables.cpp): 5 x 65536 x 2 u32 points; 48 x 128 x 128 u16 blue-noise arrays
+void make_pmj02_sets(std::vector<uint32_t>& out);
+void load_bluenoise(std::vector<uint16_t>& out);
 // image writers (host/image_io.cpp)
 void write_image(const std::string& path, const float* rgb, uint32_t w, uint32_t h);
 // PNG -> RGBA8 in file order (image crate `decode().to_rgba8()` conventions); throws std::runtime_error

@@ -517,7 +517,8 @@ static void parse_one_task(const JsonValue* j, akr_pt_config* cfg, std::string* 
         const JsonValue& s = j->at("sampler");
         const std::string ty = s.has("type") ? s.at("type").as_string() : std::string("independent");
         if (ty == "independent" || (ty == "pmj02bn" && allow_sampler_override)) cfg->sampler_type = AKR_SAMPLER_INDEPENDENT;
-        else throw std::runtime_error("unsupported: sampler '" + ty + "' (pmj02bn needs tables absent from the reference tree)");
+        else if (ty == "pmj02bn") cfg->sampler_type = AKR_SAMPLER_PMJ02BN;  // on regenerated tables, see pmj_tables.cpp
+        else throw std::runtime_error("unknown sampler '" + ty + "'");
         if (s.has("seed")) cfg->sampler_seed = (uint64_t)s.at("seed").as_number();
     }
     if (j->has("color")) {  // ColorPipeline (color.rs:663-676): only the default RGB / sRGB pipeline is implemented

@@ -29,6 +29,12 @@ struct PtParams {
     Pcg32* states;
     float* film;
     uint64_t* counters;
+    // sampler (sampler/mod.rs:282-295): 0 = independent (PCG32 state per pixel), 1 = pmj02bn (index-based: point sets +
+    // blue-noise offsets; states[pix].state holds the pixel's sample index, .inc its coordinates)
+    uint32_t sampler;
+    uint32_t smp_seed, smp_spp, smp_w;      // Pmj02BnState.{seed, spp, w}
+    const uint32_t* pmj_sets;               // [5][65536][2] u32 fixed point
+    const uint16_t* bluenoise;              // [48][128][128] unorm16
     // work distribution
     uint32_t n_items;
     uint32_t shard_rank, shard_count;

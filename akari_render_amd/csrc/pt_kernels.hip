@@ -24,7 +24,7 @@ namespace akr {
 #ifndef AKR_PT_MIN_WAVES_FD
 #define AKR_PT_MIN_WAVES_FD 4  // force_diffuse specialisation of the exhaustive kernel
 #endif
-template <bool BVH, bool FD, bool TEX>
+template <bool BVH, bool FD, bool TEX, bool PMJ>
 __global__ __launch_bounds__(256, BVH ? AKR_PT_MIN_WAVES_BVH : (FD ? AKR_PT_MIN_WAVES_FD : AKR_PT_MIN_WAVES)) void k_pt_pass(const PtParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: kBvhStackDepth x 256 words
     TraceCtx tc;
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256, BVH ? AKR_PT_MIN_WAVES_BVH : (FD ? AKR_PT_MIN_
     uint32_t sx, sy;
     shifted_pixel(p, px, py, sx, sy);
     PathRegs r;
-    path_regs_init(r, p, in_frame, pix, sx, sy);
+    path_regs_init<PMJ>(r, p, in_frame, pix, sx, sy);
 
     while (__builtin_amdgcn_ballot_w64(r.active) != 0) {
         if (r.active) {
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, BVH ? AKR_PT_MIN_WAVES_BVH : (FD ? AKR_PT_MIN_
                 trace_pair_exhaustive<TEX>(sc, r.ro, r.rd, r.has_ray ? 1e20f : -1.0f, r.ray_ex0, r.s_o, r.s_d, r.has_shadow ? r.s_tmax : -1.0f,
                                       r.s_ex0, r.s_ex1, hit, found, occluded);
             }
-            path_step<FD ? 1 : 0, TEX>(p, r, hit, found, occluded, pix, sx, sy);
+            path_step<FD ? 1 : 0, TEX, PMJ>(p, r, hit, found, occluded, pix, sx, sy);
         }
     }
     flush_counters(p, r, tc.cnt, BVH);
@@ -216,14 +216,20 @@ hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream) {
     const bool fd = p.force_diffuse != 0, tex = p.sc.tex.nodes != nullptr;
     const bool bvh = p.sc.bvh_nodes != nullptr;
     const size_t lds = bvh ? kBvhStackDepth * 256 * 4 : 0;
-#define AKR_LAUNCH(B, F, T) hipLaunchKernelGGL((k_pt_pass<B, F, T>), dim3(blocks), dim3(256), lds, stream, p)
-    if (bvh) {
-        if (tex) { if (fd) AKR_LAUNCH(true, true, true); else AKR_LAUNCH(true, false, true); }
-        else { if (fd) AKR_LAUNCH(true, true, false); else AKR_LAUNCH(true, false, false); }
-    } else {
-        if (tex) { if (fd) AKR_LAUNCH(false, true, true); else AKR_LAUNCH(false, false, true); }
-        else { if (fd) AKR_LAUNCH(false, true, false); else AKR_LAUNCH(false, false, false); }
+#define AKR_LAUNCH2(B, F, T)                                                                                        \
+    {                                                                                                               \
+        if (p.sampler) hipLaunchKernelGGL((k_pt_pass<B, F, T, true>), dim3(blocks), dim3(256), lds, stream, p);      \
+        else hipLaunchKernelGGL((k_pt_pass<B, F, T, false>), dim3(blocks), dim3(256), lds, stream, p);              \
     }
+#define AKR_LAUNCH(B, F, T) AKR_LAUNCH2(B, F, T)
+    if (bvh) {
+        if (tex) { if (fd) AKR_LAUNCH(true, true, true) else AKR_LAUNCH(true, false, true) }
+        else { if (fd) AKR_LAUNCH(true, true, false) else AKR_LAUNCH(true, false, false) }
+    } else {
+        if (tex) { if (fd) AKR_LAUNCH(false, true, true) else AKR_LAUNCH(false, false, true) }
+        else { if (fd) AKR_LAUNCH(false, true, false) else AKR_LAUNCH(false, false, false) }
+    }
+#undef AKR_LAUNCH2
 #undef AKR_LAUNCH
     return hipGetLastError();
 }

@@ -82,6 +82,7 @@ AKR_D void wf_enqueue(const WfBuffers& wf, uint32_t q, uint32_t slot, PathRegs& 
     if ((threadIdx.x & 63u) == 0 && na) atomicAdd(wf.n_active, na);
 }
 
+template <bool PMJ>
 __global__ __launch_bounds__(256) void k_wf_init(const PtParams p, const WfBuffers wf) {
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     uint32_t px = 0, py = 0;
@@ -90,13 +91,13 @@ __global__ __launch_bounds__(256) void k_wf_init(const PtParams p, const WfBuffe
     uint32_t sx, sy;
     shifted_pixel(p, px, py, sx, sy);
     PathRegs r;
-    path_regs_init(r, p, in_frame, pix, sx, sy);
+    path_regs_init<PMJ>(r, p, in_frame, pix, sx, sy);
     if (slot < p.n_items) wf_store(wf, slot, r);
     wf_enqueue(wf, 0, slot, r);
     flush_counters(p, r, TraceCounters{0, 0, 0}, true);
 }
 
-template <bool TEX>
+template <bool TEX, bool PMJ>
 __global__ __launch_bounds__(256) void k_wf_shade(const PtParams p, const WfBuffers wf, uint32_t q_out) {
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     PathRegs r;
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(const PtParams p, const WfBuff
         Hit hit;
         hit.gid = f2u(hv.x); hit.u = hv.y; hit.v = hv.z; hit.t = 0.0f;
         bool found = hit.gid != kInvalid, occluded = f2u(hv.w) != 0;
-        path_step<-1, TEX>(p, r, hit, found, occluded, pix, sx, sy);
+        path_step<-1, TEX, PMJ>(p, r, hit, found, occluded, pix, sx, sy);
         wf_store(wf, slot, r);
     }
     wf_enqueue(wf, q_out, slot, r);
@@ -261,14 +262,21 @@ __global__ __launch_bounds__(256) void k_wf_trace(const PtParams p, const WfBuff
 hipError_t launch_wf_init(const PtParams& p, const WfBuffers& wf, hipStream_t stream) {
     uint32_t blocks = (p.n_items + 255u) / 256u;
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_wf_init, dim3(blocks), dim3(256), 0, stream, p, wf);
+    if (p.sampler) hipLaunchKernelGGL(k_wf_init<true>, dim3(blocks), dim3(256), 0, stream, p, wf);
+    else hipLaunchKernelGGL(k_wf_init<false>, dim3(blocks), dim3(256), 0, stream, p, wf);
     return hipGetLastError();
 }
 hipError_t launch_wf_shade(const PtParams& p, const WfBuffers& wf, uint32_t q_out, hipStream_t stream) {
     uint32_t blocks = (p.n_items + 255u) / 256u;
     if (blocks == 0) return hipSuccess;
-    if (p.sc.tex.nodes != nullptr) hipLaunchKernelGGL(k_wf_shade<true>, dim3(blocks), dim3(256), 0, stream, p, wf, q_out);
-    else hipLaunchKernelGGL(k_wf_shade<false>, dim3(blocks), dim3(256), 0, stream, p, wf, q_out);
+    const bool tex = p.sc.tex.nodes != nullptr, pmj = p.sampler != 0;
+    if (tex) {
+        if (pmj) hipLaunchKernelGGL((k_wf_shade<true, true>), dim3(blocks), dim3(256), 0, stream, p, wf, q_out);
+        else hipLaunchKernelGGL((k_wf_shade<true, false>), dim3(blocks), dim3(256), 0, stream, p, wf, q_out);
+    } else {
+        if (pmj) hipLaunchKernelGGL((k_wf_shade<false, true>), dim3(blocks), dim3(256), 0, stream, p, wf, q_out);
+        else hipLaunchKernelGGL((k_wf_shade<false, false>), dim3(blocks), dim3(256), 0, stream, p, wf, q_out);
+    }
     return hipGetLastError();
 }
 hipError_t launch_wf_trace(const PtParams& p, const WfBuffers& wf, uint32_t q_in, uint32_t n_blocks, hipStream_t stream) {

@@ -177,7 +177,9 @@ typedef struct {
  * Render configuration = pt::Config (pt.rs:916-944) + RenderConfig.sampler / .film.filter (lib.rs:75-102).
  * ------------------------------------------------------------------------------------------------- */
 typedef enum { AKR_FILTER_BOX = 0, AKR_FILTER_GAUSSIAN = 1 } akr_filter_type;   /* film.rs:22-54 */
-typedef enum { AKR_SAMPLER_INDEPENDENT = 0 } akr_sampler_type;                  /* sampler/mod.rs:282-295 */
+/* sampler/mod.rs:282-295. PMJ02BN runs on REGENERATED tables (the reference's copies of pbrt-v4's are not in its tree):
+ * same algorithm, different point sets / blue-noise arrays, so its images are not bit-comparable with the reference's. */
+typedef enum { AKR_SAMPLER_INDEPENDENT = 0, AKR_SAMPLER_PMJ02BN = 1 } akr_sampler_type;
 
 typedef struct {
     uint32_t spp, max_depth, spp_per_pass, rr_depth;
@@ -408,6 +410,8 @@ AKR_API int32_t akr_probe_bsdf(akr_context *ctx, const akr_material_desc *m, con
 AKR_API int32_t akr_probe_intersect(akr_context *ctx, akr_scene *scene, uint32_t n, const float *rays, uint32_t *hit_inst_prim,
                                     float *bary);
 /* SurfaceInteraction of (inst, prim, u, v): out 19 floats / item = p, ng, n, t, s, uv, area, material. */
+/* The tables of the pmj02bn sampler as the library uses them: sets = u32[5 * 65536 * 2], bluenoise = u16[48 * 128 * 128]. */
+AKR_API int32_t akr_host_pmj02bn_tables(uint32_t *sets, uint16_t *bluenoise);
 /* The PNG reader of akr_scene_load (8/16-bit, all colour types, tRNS, no interlacing), image crate `to_rgba8` rules
  * (load.rs:583-604). Rows in file order. rgba == NULL: only the size is returned. */
 AKR_API int32_t akr_host_decode_png(const uint8_t *data, uint64_t len, uint32_t *width, uint32_t *height, uint8_t *rgba, uint64_t capacity);

@@ -592,10 +592,71 @@ OR_EXPORT void or_scene_destroy(or_scene *sc) {
 }
 
 /* ---------------------------------- camera + filter ---------------------------------------------- */
-typedef struct { or_pcg32 pcg; uint32_t dim; } or_sampler; /* IndependentSampler, sampler/mod.rs:161-217 */
-static inline float smp_1d(or_sampler *s) { s->dim += 1; return pcg_next_1d(&s->pcg); }
-static inline v2 smp_2d(or_sampler *s) { float a = smp_1d(s); float b = smp_1d(s); return V2(a, b); }
+/* IndependentSampler (sampler/mod.rs:161-217): pcg + dim. Pmj02BnSampler (sampler/mod.rs:329-700): pmj != 0, state =
+ * Pmj02BnState {seed, dim, pixel, sample_index, spp, w}. The two tables are handed in by the test (or_set_pmj_tables): the
+ * reference's own are absent from its tree, the build regenerates them (akari_render_amd/csrc/host/pmj_tables.cpp). */
+typedef struct { or_pcg32 pcg; uint32_t dim; int pmj; uint32_t seed, px, py, sample_index, spp, w; } or_sampler;
+static const uint32_t *g_pmj_sets;   /* [5][65536][2] */
+static const uint16_t *g_bluenoise;  /* [48][128][128] */
+OR_EXPORT void or_set_pmj_tables(const uint32_t *sets, const uint16_t *bluenoise) { g_pmj_sets = sets; g_bluenoise = bluenoise; }
+static uint32_t or_permute_element(uint32_t i, uint32_t l, uint32_t w, uint32_t p) { /* sampler/mod.rs:473-507 */
+    do {
+        i ^= p; i *= 0xe170893du; i ^= p >> 16; i ^= (i & w) >> 4; i ^= p >> 8; i *= 0x0929eb3fu; i ^= p >> 23;
+        i ^= (i & w) >> 1; i *= 1u | p >> 27; i *= 0x6935fa69u; i ^= (i & w) >> 11; i *= 0x74dcb303u; i ^= (i & w) >> 2;
+        i *= 0x9e501cc3u; i ^= (i & w) >> 2; i *= 0xc860a3dfu; i &= w; i ^= i >> 5;
+    } while (i >= l);
+    return (i + p) % l;
+}
+static float or_bluenoise(uint32_t tex, uint32_t px, uint32_t py) { /* uv = p.yx() % 128, texture tex % 48, unorm16 */
+    uint32_t tx = py % 128u, ty = px % 128u;
+    return (float)g_bluenoise[((size_t)(tex % 48u) * 128u + ty) * 128u + tx] / 65535.0f;
+}
+#define OR_ONE_MINUS_EPSILON 0.99999994f
+static inline float smp_1d(or_sampler *s) {
+    if (!s->pmj) { s->dim += 1; return pcg_next_1d(&s->pcg); }
+    uint32_t hash = or_xxhash32_4(s->px, s->py, s->dim, s->seed);
+    uint32_t index = or_permute_element(s->sample_index, s->spp, s->w, hash);
+    float delta = or_bluenoise(s->dim, s->px, s->py);
+    s->dim += 1;
+    return or_min(((float)index + delta) / (float)s->spp, OR_ONE_MINUS_EPSILON);
+}
+static inline v2 smp_2d(or_sampler *s) {
+    if (!s->pmj) { float a = smp_1d(s); float b = smp_1d(s); return V2(a, b); }
+    uint32_t index = s->sample_index, dim = s->dim, inst = dim / 2;
+    if (inst >= 5u) index = or_permute_element(s->sample_index, s->spp, s->w, or_xxhash32_4(s->px, s->py, dim, s->seed));
+    const uint32_t *p = g_pmj_sets + 2 * ((size_t)65536 * (inst % 5u) + (index % 65536u));
+    float ux = (float)p[0] * 2.3283064365386963e-10f, uy = (float)p[1] * 2.3283064365386963e-10f;
+    float dx = or_bluenoise(dim, s->px, s->py), dy = or_bluenoise(dim + 1, s->px, s->py);
+    ux = ux + dx; uy = uy + dy;
+    s->dim += 2;
+    ux = ux - floorf(ux); uy = uy - floorf(uy);
+    return V2(or_min(ux, OR_ONE_MINUS_EPSILON), or_min(uy, OR_ONE_MINUS_EPSILON));
+}
 static inline v3 smp_3d(or_sampler *s) { float a = smp_1d(s); v2 b = smp_2d(s); return V3(a, b.x, b.y); }
+static inline void smp_start(or_sampler *s) { /* sampler.start() */
+    if (!s->pmj) { pcg_advance(&s->pcg, 16384); return; }
+    s->dim = 4;
+    s->sample_index = s->sample_index == 0xffffffffu ? 0u : s->sample_index + 1u;
+}
+/* creation from the per-pixel state buffer + Drop at the end of a pass; for pmj02bn the Pcg32 slot carries
+ * {state = sample_index, inc = x | y << 32} (the layout the HIP side uses, so that sampler states can be compared) */
+static inline or_sampler smp_create(const or_pt_config *cfg, or_pcg32 st, uint32_t spp_total) {
+    or_sampler s;
+    memset(&s, 0, sizeof s);
+    s.pcg = st;
+    if (cfg->sampler_type == 1) {
+        s.pmj = 1; s.seed = (uint32_t)cfg->sampler_seed; s.spp = spp_total ? spp_total : 1;
+        uint32_t w = s.spp - 1; w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
+        s.w = w;
+        s.sample_index = (uint32_t)st.state; s.px = (uint32_t)st.inc; s.py = (uint32_t)(st.inc >> 32);
+    }
+    return s;
+}
+static inline or_pcg32 smp_drop(or_sampler *s) {
+    if (!s->pmj) { pcg_advance(&s->pcg, -(int64_t)s->dim); return s->pcg; }
+    or_pcg32 st = {s->sample_index, (uint64_t)s->px | ((uint64_t)s->py << 32)};
+    return st;
+}
 
 static v2 or_filter_sample(const or_pt_config *cfg, v2 u) { /* film.rs:32-49 */
     if (cfg->filter_type == OR_FILTER_BOX) return V2((u.x - 0.5f) * cfg->filter_radius, (u.y - 0.5f) * cfg->filter_radius);
@@ -726,9 +787,9 @@ static void or_render_pixel(or_job *j, uint32_t x, uint32_t y) { /* kernel body,
     const or_scene *sc = j->sc; const or_pt_config *cfg = j->cfg;
     uint32_t W = sc->width, H = sc->height, i = x + y * W;
     uint64_t N = (uint64_t)W * H;
-    or_sampler smp = {j->states[i], 0};
+    or_sampler smp = smp_create(cfg, j->states[i], cfg->spp);
     for (uint32_t s = 0; s < j->pass_spp; s++) {
-        pcg_advance(&smp.pcg, 16384); /* sampler.start(), sampler/mod.rs:199-203 */
+        smp_start(&smp); /* sampler.start() */
         int32_t sx = (int32_t)x + cfg->pixel_offset[0], sy = (int32_t)y + cfg->pixel_offset[1];
         if (sx < 0) sx = 0; if (sx > (int32_t)W - 1) sx = (int32_t)W - 1;
         if (sy < 0) sy = 0; if (sy > (int32_t)H - 1) sy = (int32_t)H - 1;
@@ -743,8 +804,7 @@ static void or_render_pixel(or_job *j, uint32_t x, uint32_t y) { /* kernel body,
         j->film[3 * (uint64_t)i + 2] += L.z * w;
         j->film[6 * N + i] += w;
     }
-    pcg_advance(&smp.pcg, -(int64_t)smp.dim); /* Drop for IndependentSampler, sampler/mod.rs:168-177 */
-    j->states[i] = smp.pcg;
+    j->states[i] = smp_drop(&smp); /* Drop of the sampler, sampler/mod.rs:168-177 / 633-640 */
 }
 static void *or_worker(void *arg) {
     or_job *j = (or_job *)arg;
@@ -768,6 +828,14 @@ OR_EXPORT void or_init_pcg32_buffer_with_seed(uint64_t count, uint64_t seed, uin
     }
 }
 
+/* SamplerConfig::creator (sampler/mod.rs:702-718): per-pixel states of either sampler */
+static void or_init_sampler_states(uint32_t sampler_type, uint64_t n, uint32_t width, uint64_t seed, or_pcg32 *states) {
+    if (sampler_type == 1) {
+        for (uint64_t i = 0; i < n; i++) { states[i].state = 0xffffffffull; states[i].inc = (i % width) | ((i / width) << 32); }
+    } else {
+        or_init_pcg32_buffer_with_seed(n, seed, (uint64_t *)states);
+    }
+}
 /* film: f32[7*N] in the reference layout [rgb*N | splat*N | weight*N] (film.rs:69, 85-90), accumulated into.
  * states: Pcg32[N] in/out (pass NULL to have them initialised from cfg->sampler_seed). Runs ceil(spp/spp_per_pass)
  * passes exactly like the host loop at pt.rs:1126-1149. */
@@ -777,7 +845,7 @@ OR_EXPORT int or_pt_render(const or_scene *sc, const or_pt_config *cfg, float *f
     int own_states = 0;
     if (!states) {
         states = (or_pcg32 *)malloc(sizeof(or_pcg32) * N);
-        or_init_pcg32_buffer_with_seed(N, cfg->sampler_seed, (uint64_t *)states);
+        or_init_sampler_states(cfg->sampler_type, N, sc->width, cfg->sampler_seed, states);
         own_states = 1;
     }
     if (n_threads < 1) n_threads = 1;
@@ -822,9 +890,9 @@ static void or_aov_pixel(or_aov_job *j, uint32_t x, uint32_t y) { /* kernel body
     const or_scene *sc = j->sc; const or_aov_config *cfg = j->cfg;
     uint32_t W = sc->width, H = sc->height, i = x + y * W;
     uint64_t N = (uint64_t)W * H;
-    or_sampler smp = {j->states[i], 0};
+    or_sampler smp = smp_create(&j->pc, j->states[i], cfg->spp);
     for (uint32_t s = 0; s < cfg->spp; s++) {
-        pcg_advance(&smp.pcg, 16384);
+        smp_start(&smp);
         or_ray ray = or_generate_ray(sc, &j->pc, x, y, &smp);
         j->n_rays++;
         uint32_t inst, prim; v2 bary;
@@ -850,8 +918,7 @@ static void or_aov_pixel(or_aov_job *j, uint32_t x, uint32_t y) { /* kernel body
         j->film[3 * (uint64_t)i + 2] += c.z * w;
         j->film[6 * N + i] += w;
     }
-    pcg_advance(&smp.pcg, -(int64_t)smp.dim);
-    j->states[i] = smp.pcg;
+    j->states[i] = smp_drop(&smp);
 }
 static void *or_aov_worker(void *arg) {
     or_aov_job *j = (or_aov_job *)arg;
@@ -867,7 +934,7 @@ static void *or_aov_worker(void *arg) {
 OR_EXPORT int or_aov_render(const or_scene *sc, const or_aov_config *cfg, float *film, uint32_t n_threads, uint64_t *n_rays_out) {
     uint64_t N = (uint64_t)sc->width * sc->height;
     or_pcg32 *states = (or_pcg32 *)malloc(sizeof(or_pcg32) * N);
-    or_init_pcg32_buffer_with_seed(N, cfg->sampler_seed, (uint64_t *)states);
+    or_init_sampler_states(cfg->sampler_type, N, sc->width, cfg->sampler_seed, states);
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 256) n_threads = 256;
     volatile uint32_t next_row = 0;
@@ -877,6 +944,7 @@ OR_EXPORT int or_aov_render(const or_scene *sc, const or_aov_config *cfg, float 
         memset(&jobs[t], 0, sizeof(or_aov_job));
         jobs[t].sc = sc; jobs[t].cfg = cfg; jobs[t].film = film; jobs[t].states = states; jobs[t].next_row = &next_row;
         jobs[t].pc.filter_type = cfg->filter_type; jobs[t].pc.filter_radius = cfg->filter_radius;
+        jobs[t].pc.sampler_type = cfg->sampler_type; jobs[t].pc.sampler_seed = cfg->sampler_seed;
         jobs[t].pc.shard_rank = cfg->shard_rank; jobs[t].pc.shard_count = cfg->shard_count; jobs[t].pc.tile_w = cfg->tile_w; jobs[t].pc.tile_h = cfg->tile_h;
     }
     for (uint32_t t = 1; t < n_threads; t++) pthread_create(&th[t], 0, or_aov_worker, &jobs[t]);

@@ -91,6 +91,7 @@ def lib() -> C.CDLL:
     L.or_scene_intersect.argtypes = [vp, fp, fp, f32, f32, up, up, fp]
     L.or_bsdf_probe_many.argtypes = [C.POINTER(abi.MaterialDesc), fp, fp, u32, fp, fp]
     L.or_bsdf_eval_many.argtypes = [C.POINTER(abi.MaterialDesc), fp, fp, u32, fp, fp]
+    L.or_set_pmj_tables.argtypes = [up, C.POINTER(C.c_uint16)]
     L.or_aov_render.restype = i32
     L.or_aov_render.argtypes = [vp, C.POINTER(abi.AovConfig), fp, u32, u64p]
     for n in ("or_sizeof_material", "or_sizeof_config", "or_sizeof_scene_desc", "or_sizeof_aov_config"):
@@ -216,3 +217,15 @@ def tex_sample(image: abi.ImageData, uv) -> np.ndarray:
     out = np.zeros((u.shape[0], 4), dtype=np.float32)
     lib().or_tex_sample_many(C.byref(d), u.shape[0], _fp(u), _fp(out))
     return out
+
+
+_pmj_keep = None
+
+
+def set_pmj_tables(sets: np.ndarray, bluenoise: np.ndarray) -> None:
+    """Hands the pmj02bn tables to the oracle (it has none of its own: the reference's are absent from its tree)."""
+    global _pmj_keep
+    sets = np.ascontiguousarray(sets, dtype=np.uint32)
+    bluenoise = np.ascontiguousarray(bluenoise, dtype=np.uint16)
+    _pmj_keep = (sets, bluenoise)
+    lib().or_set_pmj_tables(sets.ctypes.data_as(C.POINTER(C.c_uint32)), bluenoise.ctypes.data_as(C.POINTER(C.c_uint16)))

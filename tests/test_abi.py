@@ -57,7 +57,7 @@ def test_error_reporting(hip_lib, tmp_path):
     assert hip_lib.akr_scene_create(None, None, C.byref(h)) == capi.ERR_INVALID_ARGUMENT
     cfg = abi.PtConfig()
     assert hip_lib.akr_pt_config_from_json(b'{"method": {"type": "mcmc"}}', C.byref(cfg), None, 0) == capi.ERR_UNSUPPORTED
-    assert hip_lib.akr_pt_config_from_json(b'{"sampler": {"type": "pmj02bn", "seed": 0}}', C.byref(cfg), None, 0) == capi.ERR_UNSUPPORTED
+    assert hip_lib.akr_pt_config_from_json(b'{"sampler": {"type": "sobol", "seed": 0}}', C.byref(cfg), None, 0) == capi.ERR_PARSE
     assert hip_lib.akr_pt_config_from_json(b'{"color": {"color_repr": {"type": "rgb"}, "rgb_colorspace": "aces"}}', C.byref(cfg), None, 0) == capi.ERR_UNSUPPORTED
     assert hip_lib.akr_pt_config_from_json(b'{"color": {"rgb_colorspace": "srgb"}, "film": {"color": "srgb"}}', C.byref(cfg), None, 0) == 0
     assert hip_lib.akr_pt_config_from_json(b'{"film": {"color": "xyz"}}', C.byref(cfg), None, 0) == capi.ERR_UNSUPPORTED

@@ -97,6 +97,13 @@ def test_cli_end_to_end(ctx, root, tmp_path):
     film = capi.Film(ctx, 64, 48)
     capi.pt_render(ctx, scene, cfg, film)
     assert np.array_equal(film.resolve(), img)
-    # without --independent-sampler the shipped pmj02bn method file is refused, loudly
+    # without --independent-sampler the method file's pmj02bn sampler is used: same scene, different sample streams
     res = subprocess.run(cmd[:-2], cwd=tmp_path, capture_output=True, text=True)
-    assert res.returncode != 0 and "pmj02bn" in res.stderr
+    assert res.returncode == 0, res.stderr
+    img_pmj = read_exr_rgb(str(tmp_path / "out" / "img.exr"))
+    assert np.all(np.isfinite(img_pmj)) and not np.array_equal(img_pmj, img)
+    assert abs(img_pmj.mean() - img.mean()) < 0.05 * img.mean()
+    cfg.sampler_type = abi.SAMPLER_PMJ02BN
+    film.clear()
+    capi.pt_render(ctx, scene, cfg, film)
+    assert np.array_equal(film.resolve(), img_pmj)
