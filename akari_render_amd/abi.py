@@ -198,6 +198,35 @@ class AovConfig(_Struct):
         return c
 
 
+GPT_RECON_NONE, GPT_RECON_UNIFORM, GPT_RECON_WEIGHTED = 0, 1, 2
+GPT_RECON_NAMES = ("none", "uniform", "weighted")
+
+
+class GptConfig(_Struct):
+    """akr_gpt_config = gpt::Config (gpt.rs:32-65) + filter + sampler."""
+
+    _fields_ = [
+        ("spp", C.c_uint32), ("max_depth", C.c_uint32), ("rr_depth", C.c_uint32), ("spp_per_pass", C.c_uint32),
+        ("use_nee", C.c_uint32), ("indirect_only", C.c_uint32), ("reconnect", C.c_uint32), ("stride", C.c_uint32),
+        ("separate_weights", C.c_uint32), ("reconstruction", C.c_uint32), ("reconstruction_iter", C.c_uint32),
+        ("filter_type", C.c_uint32),
+        ("filter_radius", C.c_float),
+        ("sampler_type", C.c_uint32),
+        ("sampler_seed", C.c_uint64),
+        ("seed", C.c_uint64),
+    ]
+
+    @staticmethod
+    def default() -> "GptConfig":
+        c = GptConfig()
+        c.spp, c.max_depth, c.rr_depth, c.spp_per_pass = 256, 7, 5, 64
+        c.use_nee, c.indirect_only, c.reconnect, c.stride = 1, 0, 1, 1
+        c.separate_weights, c.reconstruction, c.reconstruction_iter = 0, GPT_RECON_NONE, 30
+        c.filter_type, c.filter_radius = FILTER_GAUSSIAN, 1.5
+        c.sampler_type, c.sampler_seed, c.seed = SAMPLER_INDEPENDENT, 0, 0
+        return c
+
+
 class PtStats(C.Structure):
     _fields_ = [
         ("n_samples", C.c_uint64),

@@ -32,6 +32,7 @@ EXPORTS = [
     "akr_film_resolve", "akr_film_device_ptr",
     "akr_pt_config_default", "akr_pt_config_from_json", "akr_pt_render", "akr_pt_begin", "akr_pt_passes", "akr_pt_end",
     "akr_pt_get_stats", "akr_render_task", "akr_image_write", "akr_aov_config_default", "akr_aov_render",
+    "akr_gpt_config_default", "akr_gpt_render", "akr_film_set_splat_scale", "akr_film_get_splat_scale",
     "akr_pt_read_sampler_states",
     "akr_host_stdrng_u64", "akr_host_chacha_block", "akr_host_pcg32_states", "akr_host_pcg_start", "akr_host_alias_table",
     "akr_probe_math", "akr_probe_bsdf", "akr_probe_intersect", "akr_probe_surface_interaction", "akr_probe_material_inputs",
@@ -104,6 +105,10 @@ def lib() -> C.CDLL:
     proto("akr_pt_config_default", C.POINTER(abi.PtConfig))
     proto("akr_aov_config_default", C.POINTER(abi.AovConfig))
     proto("akr_aov_render", vp, vp, C.POINTER(abi.AovConfig), vp, C.POINTER(abi.PtStats))
+    proto("akr_gpt_config_default", C.POINTER(abi.GptConfig))
+    proto("akr_gpt_render", vp, vp, C.POINTER(abi.GptConfig), vp, fp, C.POINTER(abi.PtStats))
+    proto("akr_film_set_splat_scale", vp, C.c_float)
+    proto("akr_film_get_splat_scale", vp, fp)
     proto("akr_pt_config_from_json", C.c_char_p, C.POINTER(abi.PtConfig), C.c_char_p, u32)
     proto("akr_pt_render", vp, vp, C.POINTER(abi.PtConfig), vp, C.POINTER(abi.PtStats))
     proto("akr_pt_begin", vp, vp, C.POINTER(abi.PtConfig), vp, vpp)
@@ -331,6 +336,16 @@ class Film:
         check(lib().akr_film_resolve(self.h, _fp(out)))
         return out.reshape(self.height, self.width, 3)
 
+    @property
+    def splat_scale(self) -> float:
+        v = C.c_float()
+        check(lib().akr_film_get_splat_scale(self.h, C.byref(v)))
+        return v.value
+
+    @splat_scale.setter
+    def splat_scale(self, scale: float):
+        check(lib().akr_film_set_splat_scale(self.h, scale))
+
     def device_ptr(self):
         p, n = C.c_void_p(), C.c_uint64()
         check(lib().akr_film_device_ptr(self.h, C.byref(p), C.byref(n)))
@@ -507,6 +522,19 @@ def aov_render(ctx: Context, scene: Scene, cfg: abi.AovConfig, film: Film) -> di
     st = abi.PtStats()
     check(lib().akr_aov_render(ctx.h, scene.h, C.byref(cfg), film.h, C.byref(st)))
     return st.as_dict()
+
+
+def gpt_render(ctx: Context, scene: Scene, cfg: abi.GptConfig, film: Film, want_aux: bool = False):
+    """akr_gpt_render: the `gpt` integrator (akari_integrator/src/gpt.rs). Returns the counters, or (counters, (primal sums
+    (H, W, 3), Gx sums (H+1, W+1, 3), Gy sums)) with want_aux (reconstruction != none)."""
+    st = abi.PtStats()
+    w, h = film.width, film.height
+    n, ng = w * h, (w + 1) * (h + 1)
+    aux = np.zeros(3 * n + 6 * ng, dtype=np.float32) if want_aux else None
+    check(lib().akr_gpt_render(ctx.h, scene.h, C.byref(cfg), film.h, _fp(aux) if want_aux else None, C.byref(st)))
+    if not want_aux:
+        return st.as_dict()
+    return st.as_dict(), (aux[:3 * n].reshape(h, w, 3), aux[3 * n:3 * n + 3 * ng].reshape(h + 1, w + 1, 3), aux[3 * n + 3 * ng:].reshape(h + 1, w + 1, 3))
 
 
 def host_decode_exr(data: bytes) -> np.ndarray:

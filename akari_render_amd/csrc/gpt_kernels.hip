@@ -1,0 +1,482 @@
+// gpt_kernels.hip -- the `gpt` integrator (crates/akari_integrator/src/gpt.rs) on gfx950: gradient-domain path tracing with
+// the reconnection shift mapping of PathTracerBase::run_pt_hybrid_shift_mapping (crates/akari_integrator/src/pt.rs:329-900,
+// the `Some(sm)` branches the plain path tracer never takes). One lane per pixel per sample: the base path, then the four
+// offset paths through the neighbouring pixels on the same random numbers (gpt.rs:144-351). Shares camera, sampler,
+// intersectors, hit reconstruction, light sampling and material records with the path tracer (device/*.h).
+//
+// The reference splats the five contributions with float atomics into a scratch film and lets a second kernel fold the
+// scratch film into the accumulators (gpt.rs:424-461); the order in which a pixel's own and its neighbours' splats arrive is
+// whatever the hardware does. Here k_gpt_sample writes what a pixel splats onto itself (`own`) and what it splats for each
+// neighbour (`shifted[i]`) to per-pixel slots and k_gpt_update gathers them in a fixed order -- no atomics, reproducible.
+#include "device/dpath.h"
+
+namespace akr {
+
+enum : uint32_t { RECON_NONE = 0, RECON_UNIFORM = 1, RECON_WEIGHTED = 2 };
+enum : uint32_t { VT_INVALID = 0, VT_LAST_HIT_LIGHT = 1, VT_LAST_NEE = 2, VT_INTERIOR = 3 };  // pt.rs:975-980
+
+struct ReconVertex {  // ReconnectionVertex, pt.rs:981-1000; (inst_id, prim_id) = global triangle id here
+    vec3 direct, indirect;
+    vec2 bary;
+    vec3 direct_wi;
+    float direct_light_pdf;
+    vec3 wo;
+    uint32_t gid;
+    vec3 wi;
+    float prev_bsdf_pdf, bsdf_pdf, u_bsdf_select, dist;
+    uint32_t depth, type;
+};
+struct ShiftMapping {  // ReconnectionShiftMapping, pt.rs:1008-1017
+    float min_dist, min_roughness;
+    bool enabled, is_base, success;
+    float jacobian;
+};
+
+AKR_D uint32_t gpt_reflect(int32_t x, uint32_t r) {  // gpt.rs:131-139
+    return x < 0 ? (uint32_t)(-x) : ((uint32_t)x >= r ? r - ((uint32_t)x - r) - 1u : (uint32_t)x);
+}
+AKR_D void gpt_shifted(const GptParams& g, uint32_t W, uint32_t H, uint32_t x, uint32_t y, uint32_t i, uint32_t& sx, uint32_t& sy) {
+    const int32_t ox = i == 0 ? 1 : (i == 2 ? -1 : 0), oy = i == 1 ? 1 : (i == 3 ? -1 : 0);
+    sx = gpt_reflect((int32_t)x + ox * (int32_t)g.stride, W);
+    sy = gpt_reflect((int32_t)y + oy * (int32_t)g.stride, H);
+}
+AKR_D vec3 splat_value(vec3 c, float weight) {  // Film::add_splat: color.remove_nan() * weight, NaN components flushed
+    if (is_nan(c.x) || is_nan(c.y) || is_nan(c.z)) c = mk3(0, 0, 0);
+    c = c * weight;
+    return mk3(is_nan(c.x) ? 0.0f : c.x, is_nan(c.y) ? 0.0f : c.y, is_nan(c.z) ? 0.0f : c.z);
+}
+
+// run_pt_hybrid_shift_mapping with min_reconnect_depth = 1, no denoising features, no cached first hit.
+template <bool BVH, bool TEX>
+AKR_D vec3 gpt_radiance(const PtParams& p, TraceCtx& tc, vec3 ro, vec3 rd, Sampler& smp, ShiftMapping& sm, ReconVertex& vx, vec3& base_out,
+                        uint32_t& n_rays) {
+    const DScene& sc = p.sc;
+    auto closest = [&](vec3 o, vec3 d, uint32_t ex0, Hit& h) {
+        n_rays++;
+        return BVH ? trace_bvh4<false, TEX>(sc, o, d, 0.0f, 1e20f, ex0, kInvalid, h, tc.stack, tc.cnt)
+                   : trace_exhaustive<false, TEX>(sc, o, d, 0.0f, 1e20f, ex0, kInvalid, h);
+    };
+    auto occluded_ray = [&](vec3 o, vec3 d, float tmax, uint32_t ex0, uint32_t ex1) {
+        Hit h;
+        n_rays++;
+        return BVH ? trace_bvh4<true, TEX>(sc, o, d, 0.0f, tmax, ex0, ex1, h, tc.stack, tc.cnt)
+                   : trace_exhaustive<true, TEX>(sc, o, d, 0.0f, tmax, ex0, ex1, h);
+    };
+    auto material_of = [&](const SurfacePoint& s, DMaterial& m) {
+        m = sc.materials[s.material];
+        if (TEX) material_at(sc.tex, s.material, s.uv, m);
+    };
+    vec3 radiance = mk3(0, 0, 0), beta = mk3(1, 1, 1), rrad = mk3(0, 0, 0), rbeta = mk3(1, 1, 1), base = mk3(0, 0, 0);
+    uint32_t depth = 0, ray_ex0 = kInvalid;
+    float prev_bsdf_pdf = 0.0f, prev_roughness = 0.0f;
+    vec3 prev_p = mk3(0, 0, 0);
+    bool rejected = false;
+    const bool use_sm = sm.enabled;
+    if (use_sm && !sm.is_base) {
+        sm.success = false;
+        sm.jacobian = 0.0f;
+    }
+    auto add_radiance = [&](vec3 r) {  // pt.rs:134-149
+        radiance = radiance + beta * r;
+        if (use_sm) rrad = rrad + rbeta * r;
+    };
+    auto mul_beta = [&](vec3 r) {  // pt.rs:150-155
+        beta = beta * r;
+        if (use_sm) rbeta = rbeta * r;
+    };
+    for (;;) {
+        Hit hit;
+        if (!closest(ro, rd, ray_ex0, hit)) break;
+        SurfacePoint si = surface_interaction(sc, hit.gid, mk2(hit.u, hit.v));
+        DMaterial mat;
+        material_of(si, mat);
+        const vec3 wo = -rd;
+        {  // handle_surface_light, pt.rs:230-258
+            vec3 direct = mk3(0, 0, 0);
+            float w = 0.0f;
+            if (si.light >= 0 && (!p.indirect_only || depth > 1)) {
+                vec3 emission = material_emission(mat);
+                direct = dot(si.ng, rd) < 0.0f ? emission : mk3(0, 0, 0);
+                if (depth == 0 || !p.use_nee) w = 1.0f;
+                else w = mis_weight(prev_bsdf_pdf, pdf_direct(sc, si, hit.gid, ro));
+            }
+            add_radiance(direct * w);
+        }
+        if (depth == 0) base = radiance;
+        const float dist_prev = length(prev_p - si.p);
+        const bool dist_crit = use_sm && dist_prev >= sm.min_dist, prev_rough_crit = use_sm && prev_roughness >= sm.min_roughness;
+        if (use_sm) {  // the last segment hit a light: that hit is the reconnection vertex, pt.rs:418-464
+            const bool is_last = depth == p.max_depth, can_connect = dist_crit && prev_rough_crit;
+            if (depth >= 1 && can_connect) {
+                if (vx.type == VT_INVALID && sm.is_base && is_last) {
+                    vx.direct = mk3(0, 0, 0); vx.indirect = mk3(0, 0, 0); vx.bary = mk2(hit.u, hit.v); vx.direct_wi = mk3(0, 0, 0);
+                    vx.direct_light_pdf = 0.0f; vx.wo = wo; vx.gid = hit.gid; vx.wi = mk3(0, 0, 0); vx.prev_bsdf_pdf = prev_bsdf_pdf;
+                    vx.bsdf_pdf = 0.0f; vx.u_bsdf_select = 0.0f; vx.dist = dist_prev; vx.depth = depth; vx.type = VT_LAST_HIT_LIGHT;
+                } else if (!sm.is_base && is_last) {
+                    rejected = true;
+                    break;
+                }
+            }
+        }
+        if (depth >= p.max_depth) break;
+        depth += 1;
+        const vec3 u_direct = next_3d<false>(p, smp);
+        LightSample dl;
+        dl.valid = false;
+        if (p.use_nee && (!p.indirect_only || depth > 1)) dl = sample_direct<TEX>(sc, si.p, si.ng, u_direct.x, mk2(u_direct.y, u_direct.z));
+        if (!dl.valid) {  // DirectLighting::invalid, pt.rs:67-77
+            dl.li = mk3(0, 0, 0); dl.wi = mk3(0, 0, 0); dl.pdf = 0.0f;
+        }
+        bool occluded = true;
+        const vec3 u_bsdf = next_3d<false>(p, smp);
+        ShadePoint sp;
+        shade_point_init(sp, mat, si.frame, si.ng, false);
+        vec3 direct = mk3(0, 0, 0);
+        if (dl.valid) {  // sample_surface_and_shade_direct, pt.rs:297-323
+            BsdfEval e = shade_evaluate(sp, mat, sc.ggx_table, wo, dl.wi);
+            float w = mis_weight(dl.pdf, e.pdf);
+            direct = div_s((dl.li * e.f) * w, dl.pdf);
+        }
+        const BsdfSample bs = shade_sample(sp, mat, sc.ggx_table, wo, u_bsdf.x, mk2(u_bsdf.y, u_bsdf.z));
+        const float u_select = u_bsdf.x;
+        const float roughness = shade_roughness(sp, mat, sc.ggx_table, wo, u_bsdf.x);
+        const bool rough_crit = use_sm && roughness >= sm.min_roughness;
+        if (dl.valid) {  // pt.rs:504-513
+            occluded = occluded_ray(dl.ro, dl.wi, dl.tmax, hit.gid, dl.ex1);
+            if (!occluded) add_radiance(direct);
+            if (depth == 1) base = radiance;
+        }
+        if (use_sm && !sm.is_base && vx.type != VT_INVALID) {  // perform the reconnection, pt.rs:515-774
+            if (depth > 1 && dist_crit && prev_rough_crit && rough_crit) {  // a vertex the base path would have picked: not reversible
+                rejected = true;
+                break;
+            }
+            if (vx.depth == depth) {
+                const SurfacePoint rsi = surface_interaction(sc, vx.gid, vx.bary);
+                const vec3 dvec = rsi.p - si.p;
+                const float dist = length(dvec);
+                const vec3 wi = normalize(dvec);
+                if (!(dist >= sm.min_dist && rough_crit)) { rejected = true; break; }
+                const vec3 vis_o = offset_ray_origin(si.p, face_forward(si.ng, wi));
+                const float cos_y2 = abs_f(dot(rsi.ng, wi)), cos_x2 = abs_f(dot(rsi.ng, vx.wo));
+                if (cos_y2 == 0.0f) { rejected = true; break; }
+                if (occluded_ray(vis_o, wi, dist * (1.0f - 1e-3f), hit.gid, vx.gid)) { rejected = true; break; }
+                const BsdfEval e1 = shade_evaluate(sp, mat, sc.ggx_table, wo, wi);
+                const vec3 f1 = e1.f;
+                const float pdf_y1 = e1.pdf;
+                DMaterial mat_y;
+                material_of(rsi, mat_y);
+                ShadePoint sp_y;
+                shade_point_init(sp_y, mat_y, rsi.frame, rsi.ng, false);
+                float roughness_y = 0.0f, pdf_y2 = 0.0f;
+                vec3 f2 = mk3(0, 0, 0), direct_f = mk3(0, 0, 0);
+                if (vx.type != VT_LAST_HIT_LIGHT) {
+                    BsdfEval e2 = shade_evaluate(sp_y, mat_y, sc.ggx_table, -wi, vx.wi);
+                    f2 = e2.f;
+                    pdf_y2 = e2.pdf;
+                    roughness_y = shade_roughness(sp_y, mat_y, sc.ggx_table, -wi, vx.u_bsdf_select);
+                }
+                if (vx.direct_wi.x != 0.0f || vx.direct_wi.y != 0.0f || vx.direct_wi.z != 0.0f) {
+                    BsdfEval ed = shade_evaluate(sp_y, mat_y, sc.ggx_table, -wi, vx.direct_wi);
+                    direct_f = ed.f * mis_weight(vx.direct_light_pdf, ed.pdf);
+                }
+                if (vx.type != VT_LAST_HIT_LIGHT && roughness_y < sm.min_roughness) { rejected = true; break; }  // reversibility
+                float pdf_ratio = pdf_y1 / vx.prev_bsdf_pdf;
+                if (vx.type != VT_LAST_HIT_LIGHT)
+                    pdf_ratio *= vx.bsdf_pdf == 0.0f ? (pdf_y2 == 0.0f ? 1.0f : 0.0f) : pdf_y2 / vx.bsdf_pdf;
+                if (pdf_ratio <= 0.0f) { rejected = true; break; }
+                vec3 le = mk3(0, 0, 0);
+                float light_pdf = 0.0f;
+                if (rsi.light >= 0) {
+                    le = dot(rsi.ng, wi) < 0.0f ? material_emission(mat_y) : mk3(0, 0, 0);
+                    light_pdf = pdf_direct(sc, rsi, vx.gid, si.p);
+                }
+                const float w = p.use_nee ? mis_weight(pdf_y1, light_pdf) : 1.0f;
+                vec3 vertex_le = le * w;
+                if (p.indirect_only && depth == 1) vertex_le = mk3(0, 0, 0);
+                const vec3 f_pdf = div_s(f1, pdf_y1);
+                float cont_prob = 1.0f;  // compute_contibue_prob(vertex.depth, reconnect_beta * f_pdf), pt.rs:211-218
+                if (vx.depth > p.rr_depth) cont_prob = clamp_f(max3(rbeta * f_pdf), 0.0f, 1.0f) * 0.95f;
+                vec3 sum = vertex_le + direct_f * vx.direct;
+                sum = sum + (pdf_y2 > 0.0f ? div_s(f2 * vx.indirect, pdf_y2) : mk3(0, 0, 0));
+                add_radiance(div_s(f_pdf * sum, cont_prob));
+                float jac = (pdf_ratio * abs_f(cos_y2 / cos_x2)) * sqr(vx.dist / dist);
+                if (!is_finite(jac)) jac = 0.0f;
+                sm.success = jac > 0.0f;
+                sm.jacobian = jac;
+                if (!sm.success) rejected = true;
+                break;
+            }
+        }
+        mul_beta(div_s(bs.color, bs.pdf));  // pt.rs:783
+        if (use_sm && depth > 1) {  // the base path picks its reconnection vertex, pt.rs:784-831
+            const bool can_connect = dist_crit && prev_rough_crit && rough_crit;
+            if (vx.type == VT_INVALID && sm.is_base && can_connect) {
+                vx.direct = (dl.valid && !occluded) ? div_s(dl.li, dl.pdf) : mk3(0, 0, 0);
+                vx.indirect = mk3(0, 0, 0); vx.bary = mk2(hit.u, hit.v); vx.direct_wi = dl.wi; vx.direct_light_pdf = dl.pdf; vx.wo = wo;
+                vx.gid = hit.gid; vx.wi = bs.wi; vx.prev_bsdf_pdf = prev_bsdf_pdf; vx.bsdf_pdf = bs.pdf; vx.u_bsdf_select = u_select;
+                vx.dist = dist_prev; vx.depth = depth - 1; vx.type = VT_LAST_NEE;
+                rbeta = mk3(1, 1, 1);
+                rrad = mk3(0, 0, 0);
+            }
+            if (!sm.is_base && can_connect) {
+                rejected = true;
+                break;
+            }
+        }
+        if (bs.pdf <= 0.0f || !bs.valid || min3(bs.color) < 0.0f) break;  // pt.rs:832-842
+        if (depth > p.rr_depth) {                                          // pt.rs:843-850
+            float cont_prob = clamp_f(max3(beta), 0.0f, 1.0f) * 0.95f;
+            if (next_1d<false>(p, smp) >= cont_prob) break;
+            mul_beta(div_s(mk3(1, 1, 1), cont_prob));
+        }
+        prev_bsdf_pdf = bs.pdf;
+        prev_p = si.p;
+        prev_roughness = roughness;
+        ro = offset_ray_origin(si.p, face_forward(si.ng, bs.wi));
+        rd = bs.wi;
+        ray_ex0 = hit.gid;
+    }
+    {  // pt.rs:871-876
+        vec3 ind = radiance - base;
+        ind = mk3(clamp_f(ind.x, 0.0f, 1000.0f), clamp_f(ind.y, 0.0f, 1000.0f), clamp_f(ind.z, 0.0f, 1000.0f));
+        radiance = base + ind;
+    }
+    if (use_sm) {  // pt.rs:878-899
+        if (vx.type != VT_INVALID && vx.type != VT_LAST_HIT_LIGHT && sm.is_base) vx.indirect = rrad;
+        if (!sm.is_base && vx.type == VT_INVALID) {
+            sm.success = !rejected;
+            sm.jacobian = sm.success ? 1.0f : 0.0f;
+        }
+    }
+    base_out = base;
+    return radiance;
+}
+
+// render_one_spp, gpt.rs:144-351
+template <bool BVH, bool TEX>
+__global__ __launch_bounds__(256) void k_gpt_sample(const PtParams p, const GptParams g) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+    TraceCtx tc;
+    tc.stack = lds_stack + threadIdx.x;
+    tc.cnt = TraceCounters{0, 0, 0};
+    const uint32_t item = blockIdx.x * 256u + threadIdx.x;
+    uint32_t px = 0, py = 0;
+    const bool in_frame = item < p.n_items && item_to_pixel(p, item, px, py);
+    uint32_t n_rays = 0;
+    if (in_frame) {
+        const uint32_t pix = px + py * p.width;
+        const Pcg32 backup = p.states[pix];  // sampler_backup = sampler_creator.create(px)
+        ReconVertex vx;
+        vx.type = VT_INVALID;
+        vx.depth = 0;
+        vx.indirect = mk3(0, 0, 0);
+        ShiftMapping sm{0.03f, 0.2f, g.reconnect != 0, true, false, 0.0f};
+        vec3 l0 = mk3(0, 0, 0), rec0 = mk3(0, 0, 0), own = mk3(0, 0, 0);
+        for (uint32_t k = 0; k < 5; k++) {  // trace(is_primary, pixel, shift_mapping), gpt.rs:153-203
+            uint32_t qx = px, qy = py;
+            if (k > 0) gpt_shifted(g, p.width, p.height, px, py, k - 1, qx, qy);
+            Sampler smp;
+            smp.pcg = backup;  // sampler_backup.clone_box()
+            smp.dim = 0;
+            sampler_start<false>(p, smp);
+            vec3 ro, rd;
+            generate_ray<false>(p, qx, qy, smp, ro, rd);
+            sm.is_base = k == 0;
+            if (k > 0) {
+                sm.success = false;
+                sm.jacobian = 0.0f;
+            }
+            vec3 base;
+            const vec3 rad = gpt_radiance<BVH, TEX>(p, tc, ro, rd, smp, sm, vx, base, n_rays);
+            vec3 l = rad, rec = mk3(0, 0, 0);
+            float jac = 1.0f;
+            bool ok = false;
+            if (sm.enabled) {
+                l = g.separate_weights ? base : rad;
+                jac = sm.jacobian;
+                ok = sm.success;
+                rec = rad - l;
+            }
+            if (k == 0) {
+                l0 = l;
+                rec0 = rec;
+                if (g.reconstruction != RECON_NONE) own = splat_value(l0 + rec0, 1.0f);
+                continue;
+            }
+            vec3 out;
+            if (g.reconstruction == RECON_NONE) {  // gpt.rs:275-307
+                const float wp = ok ? 1.0f / (1.0f + jac) : 1.0f, ws = ok ? 1.0f / (1.0f + jac) : 0.0f;
+                vec3 a, b;
+                if (g.separate_weights) {
+                    a = l0 * 0.5f + rec0 * wp;
+                    b = l * 0.5f + (rec * ws) * jac;
+                } else {
+                    a = l0 * wp;
+                    b = (l * ws) * jac;
+                }
+                own = own + splat_value(a, 1.0f);
+                out = splat_value(b, 1.0f);
+            } else {  // gpt.rs:308-346
+                vec3 grad;
+                if (sm.enabled) {
+                    if (g.separate_weights) {
+                        vec3 gr = ok ? div_s(rec * jac - rec0, 1.0f + jac) : mk3(0, 0, 0) - rec0;
+                        grad = (l - l0) * 0.5f + gr;
+                    } else {
+                        grad = ok ? div_s(l * jac - l0, 1.0f + jac) : mk3(0, 0, 0) - l0;
+                    }
+                } else {
+                    grad = (l - l0) * 0.5f;
+                }
+                out = splat_value(grad, k <= 2 ? 1.0f : -1.0f);
+            }
+            float* dst = g.shifted[k - 1] + 3 * (size_t)pix;
+            dst[0] = out.x; dst[1] = out.y; dst[2] = out.z;
+        }
+        g.own[3 * (size_t)pix + 0] = own.x;
+        g.own[3 * (size_t)pix + 1] = own.y;
+        g.own[3 * (size_t)pix + 2] = own.z;
+        Sampler b;  // sampler_backup.start(); its Drop stores the state with dim = 0
+        b.pcg = backup;
+        b.dim = 0;
+        sampler_start<false>(p, b);
+        p.states[pix] = b.pcg;
+    }
+    if (p.counters != nullptr) {
+        uint32_t a = wave_sum_u32(in_frame ? 5u : 0u), r = wave_sum_u32(n_rays), nn = wave_sum_u32(tc.cnt.nodes), nt = wave_sum_u32(tc.cnt.tris),
+                 ov = wave_sum_u32(tc.cnt.overflow);
+        if ((threadIdx.x & 63u) == 0) {
+            if (a) atomicAdd((unsigned long long*)&p.counters[0], (unsigned long long)a);
+            if (r) atomicAdd((unsigned long long*)&p.counters[1], (unsigned long long)r);
+            if (nn) atomicAdd((unsigned long long*)&p.counters[4], (unsigned long long)nn);
+            unsigned long long tt = BVH ? (unsigned long long)nt : (unsigned long long)r * p.sc.n_tris;
+            if (tt) atomicAdd((unsigned long long*)&p.counters[5], tt);
+            if (ov) atomicAdd((unsigned long long*)&p.counters[6], (unsigned long long)ov);
+        }
+    }
+}
+
+// The pixels whose neighbour along one axis (offset o, size r) is coordinate cp: the inverse of gpt_reflect(c + o), in
+// the fixed order [unreflected, mirrored at 0, mirrored at r].
+AKR_D int gpt_sources(int32_t cp, int32_t o, uint32_t r, uint32_t out[3]) {
+    int n = 0;
+    const int64_t cand[3] = {(int64_t)cp - o, -(int64_t)cp - o, 2 * (int64_t)r - 1 - cp - o};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int64_t c = cand[k];
+        if (c < 0 || c >= (int64_t)r) continue;
+        const int64_t q = c + o;
+        const int cls = q < 0 ? 1 : (q >= (int64_t)r ? 2 : 0);
+        if (cls == k) out[n++] = (uint32_t)c;
+    }
+    return n;
+}
+
+// update_kernel, gpt.rs:424-461: fold one sample's splats into the film (reconstruction none: film.splat += v / 4) or into
+// the primal / gradient sums and sums of squares.
+__global__ __launch_bounds__(256) void k_gpt_update(const GptParams g, uint32_t W, uint32_t H, float* __restrict__ film) {
+    const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const size_t N = (size_t)W * H, q = x + (size_t)y * W, gq = x + (size_t)y * (W + 1);
+    for (int c = 0; c < 3; c++) {
+        if (g.reconstruction == RECON_NONE) {
+            float v = 0.0f;
+            v += g.own[3 * q + c];
+            for (int i = 0; i < 4; i++) {
+                const int32_t ox = i == 0 ? 1 : (i == 2 ? -1 : 0), oy = i == 1 ? 1 : (i == 3 ? -1 : 0);
+                uint32_t src[3];
+                if (ox) {
+                    int n = gpt_sources((int32_t)x, ox * (int32_t)g.stride, W, src);
+                    for (int k = 0; k < n; k++) v += g.shifted[i][3 * (src[k] + (size_t)y * W) + c];
+                } else {
+                    int n = gpt_sources((int32_t)y, oy * (int32_t)g.stride, H, src);
+                    for (int k = 0; k < n; k++) v += g.shifted[i][3 * (x + (size_t)src[k] * W) + c];
+                }
+            }
+            film[3 * N + 3 * q + c] += v * 0.25f;
+        } else {
+            float v = 0.0f, gx = 0.0f, gy = 0.0f;
+            v += g.own[3 * q + c];
+            if (x >= 1) gx += g.shifted[0][3 * (q - 1) + c];
+            gx += g.shifted[2][3 * q + c];
+            if (y >= 1) gy += g.shifted[1][3 * (q - W) + c];
+            gy += g.shifted[3][3 * q + c];
+            g.acc_p[3 * q + c] += v;
+            g.acc_gx[3 * gq + c] += gx;
+            g.acc_gy[3 * gq + c] += gy;
+            g.sqr_p[3 * q + c] += v * v;
+            g.sqr_gx[3 * gq + c] += gx * gx;
+            g.sqr_gy[3 * gq + c] += gy * gy;
+        }
+    }
+}
+
+// recon_old = acc.primal / spp (gpt.rs:498-511)
+__global__ void k_gpt_recon_init(const float* __restrict__ acc_p, float* __restrict__ old, uint64_t n3, float spp) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n3) old[i] = acc_p[i] / spp;
+}
+// one Jacobi sweep of the reconstruction (gpt.rs:525-602): old -> cur (the film's splat channels)
+__global__ __launch_bounds__(256) void k_gpt_recon(const GptParams g, uint32_t W, uint32_t H, const float* __restrict__ old, float* __restrict__ cur,
+                                                   float scaling, float spp) {
+    const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const size_t q = x + (size_t)y * W;
+    for (int c = 0; c < 3; c++) {
+        const float primal = old[3 * q + c];
+        const float primal2 = g.sqr_p[3 * q + c] / spp;
+        const float primal_var = max_f(primal2 - sqr(g.acc_p[3 * q + c] / spp), 1e-6f) / spp;
+        const float pw = g.reconstruction == RECON_UNIFORM ? 1.0f : 1.0f / (primal_var * scaling);
+        float v = 0.0f, sum_w = 0.0f;
+        v += primal * pw;
+        sum_w += pw;
+        for (uint32_t i = 0; i < 4; i++) {
+            const bool is_x = (i & 1u) == 0;
+            const float sign = i < 2 ? 1.0f : -1.0f;
+            const uint32_t gx_ = x + (i == 0 ? 1u : 0u), gy_ = y + (i == 1 ? 1u : 0u);
+            uint32_t sx, sy;
+            gpt_shifted(g, W, H, x, y, i, sx, sy);
+            const size_t gi = 3 * (gx_ + (size_t)gy_ * (W + 1)) + c;
+            const float grad = (is_x ? g.acc_gx[gi] : g.acc_gy[gi]) / spp;
+            const float grad2 = (is_x ? g.sqr_gx[gi] : g.sqr_gy[gi]) / spp;
+            const float grad_var = max_f((grad2 - sqr(grad)) / spp, 1e-6f);
+            const float nb = old[3 * (sx + (size_t)sy * W) + c];
+            const float var = primal_var + grad_var;
+            const float w = g.reconstruction == RECON_UNIFORM ? 1.0f : 1.0f / var;
+            v += (nb - sign * grad) * w;
+            sum_w += w;
+        }
+        cur[3 * q + c] = v / sum_w;
+    }
+}
+
+hipError_t launch_gpt_sample(const PtParams& p, const GptParams& g, hipStream_t stream) {
+    uint32_t blocks = (p.n_items + 255u) / 256u;
+    if (blocks == 0) return hipSuccess;
+    const bool bvh = p.sc.bvh_nodes != nullptr, tex = p.sc.tex.nodes != nullptr;
+    const size_t lds = bvh ? kBvhStackDepth * 256 * 4 : 0;
+    if (bvh) {
+        if (tex) hipLaunchKernelGGL((k_gpt_sample<true, true>), dim3(blocks), dim3(256), lds, stream, p, g);
+        else hipLaunchKernelGGL((k_gpt_sample<true, false>), dim3(blocks), dim3(256), lds, stream, p, g);
+    } else {
+        if (tex) hipLaunchKernelGGL((k_gpt_sample<false, true>), dim3(blocks), dim3(256), lds, stream, p, g);
+        else hipLaunchKernelGGL((k_gpt_sample<false, false>), dim3(blocks), dim3(256), lds, stream, p, g);
+    }
+    return hipGetLastError();
+}
+hipError_t launch_gpt_update(const GptParams& g, uint32_t W, uint32_t H, float* film, hipStream_t stream) {
+    hipLaunchKernelGGL(k_gpt_update, dim3((W + 63u) / 64u, (H + 3u) / 4u), dim3(256), 0, stream, g, W, H, film);
+    return hipGetLastError();
+}
+hipError_t launch_gpt_recon_init(const GptParams& g, uint32_t W, uint32_t H, float* old, float spp, hipStream_t stream) {
+    const uint64_t n3 = 3ull * W * H;
+    hipLaunchKernelGGL(k_gpt_recon_init, dim3((uint32_t)((n3 + 255) / 256)), dim3(256), 0, stream, g.acc_p, old, n3, spp);
+    return hipGetLastError();
+}
+hipError_t launch_gpt_recon(const GptParams& g, uint32_t W, uint32_t H, const float* old, float* cur, float scaling, float spp, hipStream_t stream) {
+    hipLaunchKernelGGL(k_gpt_recon, dim3((W + 63u) / 64u, (H + 3u) / 4u), dim3(256), 0, stream, g, W, H, old, cur, scaling, spp);
+    return hipGetLastError();
+}
+
+}  // namespace akr

@@ -137,6 +137,7 @@ struct akr_film {
     uint32_t width = 0, height = 0;
     DevBuf own;
     float* data = nullptr;  // 7 * W * H floats
+    float splat_scale = 1.0f;  // Film.splat_scale, film.rs:73,117
     size_t n_floats() const { return 7ull * width * height; }
 };
 
@@ -637,10 +638,20 @@ AKR_API int32_t akr_film_resolve(akr_film* f, float* dst_rgb) {
         uint64_t n = (uint64_t)f->width * f->height;
         DevBuf tmp;
         tmp.alloc(3 * n * sizeof(float));
-        HIP_CHECK(launch_film_resolve(f->data, n, tmp.as<float>(), f->ctx->stream));
+        HIP_CHECK(launch_film_resolve(f->data, n, f->splat_scale, tmp.as<float>(), f->ctx->stream));
         HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
         HIP_CHECK(hipMemcpy(dst_rgb, tmp.p, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
     });
+}
+AKR_API int32_t akr_film_set_splat_scale(akr_film* f, float scale) {  // film.rs:152-154
+    if (!f) return fail(AKR_ERR_INVALID_ARGUMENT, "film is NULL");
+    f->splat_scale = scale;
+    return AKR_OK;
+}
+AKR_API int32_t akr_film_get_splat_scale(const akr_film* f, float* scale) {
+    if (!f || !scale) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_film_get_splat_scale: NULL argument");
+    *scale = f->splat_scale;
+    return AKR_OK;
 }
 AKR_API int32_t akr_film_device_ptr(akr_film* f, void** ptr, uint64_t* bytes) {
     if (!f) return fail(AKR_ERR_INVALID_ARGUMENT, "film is NULL");
@@ -852,6 +863,99 @@ AKR_API int32_t akr_aov_render(akr_context* ctx, akr_scene* scene, const akr_aov
     return rc2;
 }
 
+// ------------------------------------------------------------------------------------------------ gpt integrator
+AKR_API int32_t akr_gpt_config_default(akr_gpt_config* c) {  // gpt::Config::default (gpt.rs:48-65) + RenderConfig defaults
+    if (!c) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_gpt_config_default: NULL argument");
+    std::memset(c, 0, sizeof *c);
+    c->spp = 256; c->max_depth = 7; c->rr_depth = 5; c->spp_per_pass = 64;
+    c->use_nee = 1; c->indirect_only = 0; c->reconnect = 1; c->stride = 1;
+    c->separate_weights = 0; c->reconstruction = AKR_GPT_RECON_NONE; c->reconstruction_iter = 30;
+    c->filter_type = AKR_FILTER_GAUSSIAN; c->filter_radius = 1.5f;
+    c->sampler_type = AKR_SAMPLER_INDEPENDENT; c->sampler_seed = 0; c->seed = 0;
+    return AKR_OK;
+}
+AKR_API int32_t akr_gpt_render(akr_context* ctx, akr_scene* scene, const akr_gpt_config* cfg, akr_film* film, float* aux, akr_pt_stats* stats) {
+    if (!ctx || !scene || !cfg || !film) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_gpt_render: NULL argument");
+    const uint32_t W = scene->flat.camera.width, H = scene->flat.camera.height;
+    if (cfg->reconstruction > AKR_GPT_RECON_WEIGHTED) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_gpt_render: unknown reconstruction");
+    if (cfg->stride < 1 || cfg->stride >= W || cfg->stride >= H) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_gpt_render: stride must be in [1, min(width, height))");
+    if (cfg->reconstruction == AKR_GPT_RECON_NONE && !cfg->reconnect)  // shift_mapping.as_ref().unwrap(), gpt.rs:276
+        return fail(AKR_ERR_INVALID_ARGUMENT, "akr_gpt_render: reconstruction 'none' needs reconnect = true (the reference panics)");
+    if (cfg->sampler_type != AKR_SAMPLER_INDEPENDENT)  // Pmj02BnSampler::clone_box is todo!(), sampler/mod.rs:677
+        return fail(AKR_ERR_UNSUPPORTED, "akr_gpt_render: gpt needs the independent sampler (the reference's pmj02bn sampler cannot be cloned)");
+    akr_pt_config pc;
+    akr_pt_config_default(&pc);
+    pc.spp = cfg->spp; pc.spp_per_pass = 1; pc.max_depth = cfg->max_depth; pc.rr_depth = cfg->rr_depth;
+    pc.use_nee = cfg->use_nee; pc.indirect_only = cfg->indirect_only;
+    pc.filter_type = cfg->filter_type; pc.filter_radius = cfg->filter_radius;
+    pc.sampler_type = cfg->sampler_type; pc.sampler_seed = cfg->sampler_seed;
+    akr_pt_session* se = nullptr;
+    int32_t rc = akr_pt_begin(ctx, scene, &pc, film, &se);
+    if (rc != AKR_OK) return rc;
+    rc = guarded([&] {
+        const size_t N = (size_t)W * H, NG = (size_t)(W + 1) * (H + 1);
+        const bool recon = cfg->reconstruction != AKR_GPT_RECON_NONE;
+        DevBuf scratch, sums, old;
+        scratch.alloc(15 * N * sizeof(float));
+        GptParams g;
+        std::memset(&g, 0, sizeof g);
+        g.own = scratch.as<float>();
+        for (int i = 0; i < 4; i++) g.shifted[i] = scratch.as<float>() + 3 * N * (size_t)(1 + i);
+        g.reconnect = cfg->reconnect ? 1u : 0u; g.stride = cfg->stride; g.separate_weights = cfg->separate_weights ? 1u : 0u;
+        g.reconstruction = cfg->reconstruction;
+        if (recon) {
+            sums.alloc((6 * N + 12 * NG) * sizeof(float));
+            HIP_CHECK(hipMemsetAsync(sums.p, 0, sums.bytes, ctx->stream));
+            float* b = sums.as<float>();
+            g.acc_p = b; g.sqr_p = b + 3 * N; g.acc_gx = b + 6 * N; g.acc_gy = g.acc_gx + 3 * NG; g.sqr_gx = g.acc_gy + 3 * NG; g.sqr_gy = g.sqr_gx + 3 * NG;
+        }
+        fill_params(se, 1, 1);
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, ctx->stream));
+        for (uint32_t s = 0; s < cfg->spp; s++) {  // gpt.rs:468-485: kernel + update_kernel per sample
+            HIP_CHECK(launch_gpt_sample(se->params, g, ctx->stream));
+            HIP_CHECK(launch_gpt_update(g, W, H, film->data, ctx->stream));
+        }
+        if (!recon) {
+            film->splat_scale = 1.0f / (float)cfg->spp;  // gpt.rs:463-466
+        } else if (cfg->spp > 0) {  // gpt.rs:495-606
+            const float spp = (float)cfg->spp;
+            old.alloc(3 * N * sizeof(float));
+            HIP_CHECK(launch_gpt_recon_init(g, W, H, old.as<float>(), spp, ctx->stream));
+            std::vector<float> prefix(std::max(cfg->reconstruction_iter, 1u), 1.0f);
+            const float eps = 0.01f;
+            for (uint32_t i = 1; i < cfg->reconstruction_iter; i++) {
+                float p2 = 1.0f;
+                for (uint32_t k = 0; k + 1 < i; k++) p2 *= 0.5f;  // 0.5f32.powi(i - 1)
+                prefix[i] = prefix[i - 1] * (1.0f / ((eps + 1.0f) + 4.0f * p2));
+            }
+            float* cur = film->data + 3 * N;
+            for (uint32_t it = 0; it < cfg->reconstruction_iter; it++) {
+                HIP_CHECK(launch_gpt_recon(g, W, H, old.as<float>(), cur, prefix[it], spp, ctx->stream));
+                HIP_CHECK(hipMemcpyAsync(old.p, cur, 3 * N * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+            }
+        }
+        HIP_CHECK(hipEventRecord(e1, ctx->stream));
+        se->events.emplace_back(e0, e1);
+        se->n_launches += 2 * cfg->spp;
+        se->spp_done = cfg->spp;
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (aux && recon) {
+            HIP_CHECK(hipMemcpy(aux, g.acc_p, 3 * N * sizeof(float), hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(aux + 3 * N, g.acc_gx, 6 * NG * sizeof(float), hipMemcpyDeviceToHost));
+        }
+    });
+    std::string err = g_last_error;
+    int32_t rc2 = akr_pt_end(se, stats);
+    if (rc != AKR_OK) {
+        g_last_error = err;
+        return rc;
+    }
+    return rc2;
+}
+
 // ------------------------------------------------------------------------------------------------ render driver
 AKR_API int32_t akr_image_write(const char* path, const float* rgb, uint32_t width, uint32_t height) {
     if (!path || !rgb || !width || !height) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_image_write: bad argument");
@@ -870,7 +974,7 @@ AKR_API int32_t akr_render_task(akr_context* ctx, akr_scene* scene, const char* 
         std::vector<float> rgb(3ull * w * h);
         for (size_t ti = 0; ti < tasks.size(); ti++) {  // render_single, lib.rs:112-193
             const ParsedTask& task = tasks[ti];
-            if (ses.verbose) std::fprintf(stderr, "[akari_hip] task %zu/%zu (%s): %ux%u, %u spp -> %s\n", ti + 1, tasks.size(), task.is_aov ? "aov" : "pt", w, h, task.is_aov ? task.aov.spp : task.cfg.spp, task.film_out.c_str());
+            if (ses.verbose) std::fprintf(stderr, "[akari_hip] task %zu/%zu (%s): %ux%u, %u spp -> %s\n", ti + 1, tasks.size(), task.is_aov ? "aov" : (task.is_gpt ? "gpt" : "pt"), w, h, task.is_aov ? task.aov.spp : (task.is_gpt ? task.gpt.spp : task.cfg.spp), task.film_out.c_str());
             akr_film* film = nullptr;
             akr_pt_session* se = nullptr;
             auto check = [&](int32_t rc) { if (rc != AKR_OK) { std::string m = g_last_error; if (se) akr_pt_end(se, nullptr); if (film) akr_film_destroy(film); throw std::runtime_error(m); } };
@@ -882,6 +986,27 @@ AKR_API int32_t akr_render_task(akr_context* ctx, akr_scene* scene, const char* 
                 check(akr_film_resolve(film, rgb.data()));
                 akr_film_destroy(film);
                 film = nullptr;
+                write_image(task.film_out, rgb.data(), w, h);
+                if (stats_out) *stats_out = st;
+                continue;
+            }
+            if (task.is_gpt) {  // GradientPathTracer::render: no intermediates; with a reconstruction also output/gpt_*.exr (gpt.rs:609-636)
+                akr_pt_stats st;
+                const bool recon = task.gpt.reconstruction != AKR_GPT_RECON_NONE;
+                const size_t N = (size_t)w * h, NG = (size_t)(w + 1) * (h + 1);
+                std::vector<float> aux(recon ? 3 * N + 6 * NG : 0);
+                check(akr_gpt_render(ctx, scene, &task.gpt, film, recon ? aux.data() : nullptr, &st));
+                if (ses.verbose) std::fprintf(stderr, "[akari_hip] Rendering finished in %.2fs\n", st.kernel_ms * 1e-3);
+                check(akr_film_resolve(film, rgb.data()));
+                akr_film_destroy(film);
+                film = nullptr;
+                if (recon) {
+                    const float scale = 1.0f / (float)task.gpt.spp;  // set_splat_scale(1 / spp) on the accumulators
+                    for (float& v : aux) v = v * scale;
+                    write_image("output/gpt_primal.exr", aux.data(), w, h);
+                    write_image("output/gpt_gx.exr", aux.data() + 3 * N, w + 1, h + 1);
+                    write_image("output/gpt_gy.exr", aux.data() + 3 * N + 3 * NG, w + 1, h + 1);
+                }
                 write_image(task.film_out, rgb.data(), w, h);
                 if (stats_out) *stats_out = st;
                 continue;

@@ -90,6 +90,8 @@ struct ParsedTask {
     bool is_aov = false;     // Method::NormalVis instead of Method::PathTracer
     akr_pt_config cfg;
     akr_aov_config aov;
+    bool is_gpt = false;     // Method::GradientPathTracer
+    akr_gpt_config gpt;
     std::string film_out;
 };
 std::vector<ParsedTask> parse_render_tasks(const std::string& text, bool allow_sampler_override);

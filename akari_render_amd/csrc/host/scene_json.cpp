@@ -483,7 +483,10 @@ FlatScene load_scene_json(const std::string& path) {
 
 static void parse_one_task(const JsonValue* j, akr_pt_config* cfg, std::string* film_out, bool allow_sampler_override, ParsedTask* task = nullptr) {
     akr_pt_config_default(cfg);
-    if (task) akr_aov_config_default(&task->aov);
+    if (task) {
+        akr_aov_config_default(&task->aov);
+        akr_gpt_config_default(&task->gpt);
+    }
     if (film_out) *film_out = "out.exr";  // FilmConfig::default, lib.rs:82-90
     if (j->has("method")) {
         const JsonValue& m = j->at("method");
@@ -500,8 +503,24 @@ static void parse_one_task(const JsonValue* j, akr_pt_config* cfg, std::string* 
                 if (k == 6) throw std::runtime_error("unknown aov '" + a + "'");
                 task->aov.aov = k;
             }
+        } else if (ty == "gpt" && task) {  // gpt::Config (gpt.rs:32-65)
+            task->is_gpt = true;
+            akr_gpt_config& g = task->gpt;
+            auto gu = [&](const char* k, uint32_t& dst) { if (m.has(k)) dst = (uint32_t)m.at(k).as_number(); };
+            auto gb = [&](const char* k, uint32_t& dst) { if (m.has(k)) dst = m.at(k).as_bool() ? 1u : 0u; };
+            gu("spp", g.spp); gu("max_depth", g.max_depth); gu("spp_per_pass", g.spp_per_pass); gu("rr_depth", g.rr_depth);
+            gu("stride", g.stride); gu("reconstruction_iter", g.reconstruction_iter);
+            gb("use_nee", g.use_nee); gb("indirect_only", g.indirect_only); gb("reconnect", g.reconnect); gb("separate_weights", g.separate_weights);
+            if (m.has("seed")) g.seed = (uint64_t)m.at("seed").as_number();
+            if (m.has("reconstruction")) {
+                const std::string& r = m.at("reconstruction").as_string();
+                if (r == "none") g.reconstruction = AKR_GPT_RECON_NONE;
+                else if (r == "uniform") g.reconstruction = AKR_GPT_RECON_UNIFORM;
+                else if (r == "weighted") g.reconstruction = AKR_GPT_RECON_WEIGHTED;
+                else throw std::runtime_error("unknown reconstruction '" + r + "'");
+            }
         } else if (ty != "pt") {
-            throw std::runtime_error("unsupported: method type '" + ty + "' (\"pt\" and \"aov\" are implemented" + (task ? ")" : "; this entry point takes \"pt\" only)"));
+            throw std::runtime_error("unsupported: method type '" + ty + "' (\"pt\", \"aov\" and \"gpt\" are implemented" + (task ? ")" : "; this entry point takes \"pt\" only)"));
         }
         auto u32 = [&](const char* k, uint32_t& dst) { if (m.has(k)) dst = (uint32_t)m.at(k).as_number(); };
         auto b32 = [&](const char* k, uint32_t& dst) { if (m.has(k)) dst = m.at(k).as_bool() ? 1u : 0u; };
@@ -550,6 +569,10 @@ static void parse_one_task(const JsonValue* j, akr_pt_config* cfg, std::string* 
         task->aov.filter_radius = cfg->filter_radius;
         task->aov.sampler_type = cfg->sampler_type;
         task->aov.sampler_seed = cfg->sampler_seed;
+        task->gpt.filter_type = cfg->filter_type;
+        task->gpt.filter_radius = cfg->filter_radius;
+        task->gpt.sampler_type = cfg->sampler_type;
+        task->gpt.sampler_seed = cfg->sampler_seed;
     }
 }
 
@@ -573,6 +596,7 @@ std::vector<ParsedTask> parse_render_tasks(const std::string& text, bool allow_s
 
 void parse_method_json(const std::string& text, akr_pt_config* cfg, std::string* film_out) {
     std::vector<ParsedTask> tasks = parse_render_tasks(text, false);
+    if (tasks[0].is_gpt) throw std::runtime_error("unsupported: method type 'gpt' here (akr_pt_config_from_json fills a pt::Config; use akr_render_task)");
     if (tasks[0].is_aov) throw std::runtime_error("unsupported: method type 'aov' here (akr_pt_config_from_json fills a pt::Config; use akr_render_task)");
     *cfg = tasks[0].cfg;
     if (film_out) *film_out = tasks[0].film_out;

@@ -56,14 +56,27 @@ struct WfBuffers {
     uint32_t* n_active;             // slots still active after the last shade
 };
 
+// Scratch and accumulators of the gpt integrator (gpt_kernels.hip), all f32 RGB: per-pixel splat slots of one sample (own,
+// shifted[i]); with a reconstruction, the sums / sums of squares of the primal image and the (W+1) x (H+1) gradient images.
+struct GptParams {
+    float* own;
+    float* shifted[4];
+    float *acc_p, *acc_gx, *acc_gy, *sqr_p, *sqr_gx, *sqr_gy;
+    uint32_t reconnect, stride, separate_weights, reconstruction;
+};
+
 hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream);
+hipError_t launch_gpt_sample(const PtParams& p, const GptParams& g, hipStream_t stream);
+hipError_t launch_gpt_update(const GptParams& g, uint32_t W, uint32_t H, float* film, hipStream_t stream);
+hipError_t launch_gpt_recon_init(const GptParams& g, uint32_t W, uint32_t H, float* old, float spp, hipStream_t stream);
+hipError_t launch_gpt_recon(const GptParams& g, uint32_t W, uint32_t H, const float* old, float* cur, float scaling, float spp, hipStream_t stream);
 hipError_t launch_aov(const PtParams& p, uint32_t spp, uint32_t aov, uint32_t remap, hipStream_t stream);
 hipError_t launch_wf_init(const PtParams& p, const WfBuffers& wf, hipStream_t stream);
 hipError_t launch_wf_shade(const PtParams& p, const WfBuffers& wf, uint32_t q_out, hipStream_t stream);
 hipError_t launch_wf_trace(const PtParams& p, const WfBuffers& wf, uint32_t q_in, uint32_t n_blocks, hipStream_t stream);
 hipError_t launch_probe_material(const PtParams& p, uint32_t material, uint32_t n, const float* uv, uint32_t* out, hipStream_t stream);
 hipError_t launch_init_pcg32(const uint64_t* seeds, void* states, uint64_t n, hipStream_t stream);
-hipError_t launch_film_resolve(const float* film, uint64_t n, float* rgb, hipStream_t stream);
+hipError_t launch_film_resolve(const float* film, uint64_t n, float splat_scale, float* rgb, hipStream_t stream);
 hipError_t launch_ggx_table(const uint64_t* seeds, float* table, uint32_t samples, hipStream_t stream);
 hipError_t launch_probe_math(uint32_t n, const float* x, float* s, float* c, float* l, hipStream_t stream);
 hipError_t launch_probe_bsdf(const DMaterial* m, const float* table, int mode, const float* wo, uint32_t n, const float* in, float* out,

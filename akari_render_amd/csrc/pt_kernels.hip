@@ -69,14 +69,14 @@ __global__ void k_init_pcg32(const uint64_t* __restrict__ seeds, Pcg32* __restri
     if (i < n) states[i] = pcg_new_seq_offset(i, seeds[i]);
 }
 
-// Film resolve: copy_to_rgba_image with hdr = true, splat_scale = 1 (film.rs:120-148)
-__global__ void k_film_resolve(const float* __restrict__ film, uint64_t n, float* __restrict__ rgb) {
+// Film resolve: copy_to_rgba_image with hdr = true (film.rs:120-148)
+__global__ void k_film_resolve(const float* __restrict__ film, uint64_t n, float splat_scale, float* __restrict__ rgb) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float w = film[6 * n + i];
     float inv = w == 0.0f ? 1.0f : w;
 #pragma unroll
-    for (int c = 0; c < 3; c++) rgb[3 * i + c] = film[3 * i + c] / inv + film[3 * n + 3 * i + c] * 1.0f;
+    for (int c = 0; c < 3; c++) rgb[3 * i + c] = film[3 * i + c] / inv + film[3 * n + 3 * i + c] * splat_scale;
 }
 
 // PreComputedTables::init "ggx_dielectric_s" (svm/surface/precompute.rs:56-94,133-145; mod.rs:1336-1356):
@@ -239,10 +239,10 @@ hipError_t launch_init_pcg32(const uint64_t* seeds, void* states, uint64_t n, hi
     hipLaunchKernelGGL(k_init_pcg32, dim3(blocks), dim3(256), 0, stream, seeds, (Pcg32*)states, n);
     return hipGetLastError();
 }
-hipError_t launch_film_resolve(const float* film, uint64_t n, float* rgb, hipStream_t stream) {
+hipError_t launch_film_resolve(const float* film, uint64_t n, float splat_scale, float* rgb, hipStream_t stream) {
     uint32_t blocks = (uint32_t)((n + 255) / 256);
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_film_resolve, dim3(blocks), dim3(256), 0, stream, film, n, rgb);
+    hipLaunchKernelGGL(k_film_resolve, dim3(blocks), dim3(256), 0, stream, film, n, splat_scale, rgb);
     return hipGetLastError();
 }
 hipError_t launch_ggx_table(const uint64_t* seeds, float* table, uint32_t samples, hipStream_t stream) {

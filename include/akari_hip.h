@@ -297,6 +297,10 @@ AKR_API int32_t akr_film_write(akr_film *film, const float *src);
 /* Film resolve = the copy_to_rgba_image kernel with hdr = true (film.rs:120-148): rgb / (w == 0 ? 1 : w)
  * + splat * splat_scale; writes 3 * W * H floats of linear RGB to host memory. */
 AKR_API int32_t akr_film_resolve(akr_film *film, float *dst_rgb);
+/* Film::set_splat_scale (film.rs:152-154): the factor of the splat channels in the resolve; 1 after akr_film_create
+ * (akr_film_clear leaves it alone, as Film::clear does). The gpt integrator sets 1 / spp like the reference (gpt.rs:463-466). */
+AKR_API int32_t akr_film_set_splat_scale(akr_film *film, float scale);
+AKR_API int32_t akr_film_get_splat_scale(const akr_film *film, float *scale);
 /* Wraps caller-owned device memory (7 * W * H floats, reference layout, e.g. a torch tensor that a
  * torch.distributed/RCCL reduce will run on) as a film; akr_film_destroy then leaves the memory alone. */
 AKR_API int32_t akr_film_wrap(akr_context *ctx, uint32_t width, uint32_t height, void *device_ptr, akr_film **out);
@@ -375,6 +379,31 @@ typedef struct {
 AKR_API int32_t akr_aov_config_default(akr_aov_config *cfg);
 /* Renders into `film` (accumulates: clear it first for a fresh image). stats: n_samples = n_closest = camera rays. */
 AKR_API int32_t akr_aov_render(akr_context *ctx, akr_scene *scene, const akr_aov_config *cfg, akr_film *film, akr_pt_stats *stats);
+
+/* ---------------------------------------------------------------------------------------------------
+ * `gpt` integrator (Method::GradientPathTracer, akari_integrator/src/gpt.rs; "type": "gpt"): gradient-domain path tracing.
+ * Per sample one base path and four offset paths through the neighbouring pixels (stride apart, mirrored at the border)
+ * on the same random numbers; the offset paths rejoin the base path through the reconnection shift mapping of
+ * run_pt_hybrid_shift_mapping (pt.rs:329-900: min_dist 0.03, min_roughness 0.2). reconstruction = none: the five paths are
+ * MIS-combined into the film's splat channels (resolve scale 1 / spp); uniform / weighted: primal + gradient images are
+ * accumulated and `reconstruction_iter` Jacobi sweeps of the screened Poisson problem write the film (gpt.rs:495-606).
+ * The reference lets float atomics order a pixel's splats; here the order is fixed (own terms, then neighbours 0..3).
+ * Independent sampler only (the reference's Pmj02BnSampler::clone_box is todo!()). Not sharded: one GPU per frame.
+ * ------------------------------------------------------------------------------------------------- */
+typedef enum { AKR_GPT_RECON_NONE = 0, AKR_GPT_RECON_UNIFORM = 1, AKR_GPT_RECON_WEIGHTED = 2 } akr_gpt_reconstruction;
+typedef struct {
+    uint32_t spp, max_depth, rr_depth, spp_per_pass;        /* gpt::Config::default: 256, 7, 5, 64  (gpt.rs:48-65) */
+    uint32_t use_nee, indirect_only, reconnect, stride;     /* 1, 0, 1, 1 */
+    uint32_t separate_weights, reconstruction, reconstruction_iter, filter_type; /* 0, none, 30; film.filter */
+    float filter_radius;
+    uint32_t sampler_type;
+    uint64_t sampler_seed;
+    uint64_t seed;                                          /* gpt::Config.seed: carried, never read by the reference either */
+} akr_gpt_config;
+AKR_API int32_t akr_gpt_config_default(akr_gpt_config *cfg);
+/* Renders into `film` (clear it first; sets its splat scale). aux (host memory, optional, reconstruction != none):
+ * [primal 3 N | Gx 3 (W+1)(H+1) | Gy 3 (W+1)(H+1)] floats, the sums the reference writes / spp to output/gpt_*.exr. */
+AKR_API int32_t akr_gpt_render(akr_context *ctx, akr_scene *scene, const akr_gpt_config *cfg, akr_film *film, float *aux, akr_pt_stats *stats);
 
 /* util::write_image (akari_render/src/util/mod.rs:57-127): ".exr" -> linear RGB f32 OpenEXR (uncompressed scanlines),
  * ".png" -> 8-bit sRGB. rgb = 3 * W * H floats, row-major, top row first. Creates parent directories. */

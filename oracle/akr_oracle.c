@@ -958,15 +958,421 @@ OR_EXPORT int or_aov_render(const or_scene *sc, const or_aov_config *cfg, float 
 }
 OR_EXPORT uint32_t or_sizeof_aov_config(void) { return (uint32_t)sizeof(or_aov_config); }
 
-/* Film resolve, film.rs:120-148 with hdr = true and splat_scale = 1: rgb / (w == 0 ? 1 : w) + splat */
-OR_EXPORT void or_film_resolve(const float *film, uint32_t width, uint32_t height, float *rgb_out) {
+/* ---------------------------------- gpt integrator, akari_integrator/src/gpt.rs ------------------------ */
+/* Gradient-domain path tracing: per sample one base path and four offset paths through the neighbouring pixels, all on
+ * the SAME random numbers, the offset paths reconnected to the base path by the reconnection shift mapping that lives
+ * inside run_pt_hybrid_shift_mapping (pt.rs:329-900, the `Some(sm)` branches). */
+typedef struct {
+    uint32_t spp, max_depth, rr_depth, spp_per_pass;
+    uint32_t use_nee, indirect_only, reconnect, stride;
+    uint32_t separate_weights, reconstruction, reconstruction_iter, filter_type;
+    float filter_radius; uint32_t sampler_type;
+    uint64_t sampler_seed, seed;
+} or_gpt_config; /* = akr_gpt_config */
+enum { OR_RECON_NONE = 0, OR_RECON_UNIFORM = 1, OR_RECON_WEIGHTED = 2 };
+enum { OR_VT_INVALID = 0, OR_VT_LAST_HIT_LIGHT = 1, OR_VT_LAST_NEE = 2, OR_VT_INTERIOR = 3 }; /* pt.rs:975-980 */
+typedef struct { /* ReconnectionVertex, pt.rs:981-1000 */
+    v3 direct, indirect; v2 bary; v3 direct_wi; float direct_light_pdf; v3 wo; uint32_t inst_id; v3 wi; uint32_t prim_id;
+    float prev_bsdf_pdf, bsdf_pdf, u_bsdf_select, dist; uint32_t depth, type;
+} or_recon_vertex;
+typedef struct { float min_dist, min_roughness; int is_base; or_recon_vertex *vertex; float jacobian; int success; } or_shift_mapping;
+
+/* PathTracerBase::run_pt_hybrid_shift_mapping with need_shift_mapping = (sm != NULL), min_reconnect_depth = 1,
+ * shift_mapping_no_nee = shift_mapping_no_first_nee = false, no denoising features, no cached first hit (pt.rs:329-900).
+ * Returns the radiance after the indirect clamp; *base_out = base_replay_throughput. */
+static v3 or_radiance_sm(const or_scene *sc, const or_gpt_config *g, or_ray ray, or_sampler *smp, or_shift_mapping *sm, v3 *base_out) {
+    v3 radiance = V3(0, 0, 0), beta = V3(1, 1, 1), rrad = V3(0, 0, 0), rbeta = V3(1, 1, 1), base = V3(0, 0, 0);
+    uint32_t depth = 0;
+    float prev_bsdf_pdf = 0.0f, prev_roughness = 0.0f;
+    v3 prev_p = V3(0, 0, 0);
+    const int use_nee = g->use_nee != 0, indirect_only = g->indirect_only != 0;
+    int rejected = 0;
+    or_stats st_; memset(&st_, 0, sizeof st_);
+    if (sm && !sm->is_base) { sm->success = 0; sm->jacobian = 0.0f; }
+    /* add_radiance / mul_beta, pt.rs:134-155 */
+#define ADD_RADIANCE(r) do { v3 r_ = (r); radiance = v3add(radiance, v3mul(beta, r_)); if (sm) rrad = v3add(rrad, v3mul(rbeta, r_)); } while (0)
+#define MUL_BETA(r) do { v3 r_ = (r); beta = v3mul(beta, r_); if (sm) rbeta = v3mul(rbeta, r_); } while (0)
+    for (;;) {
+        uint32_t h_inst = 0, h_prim = 0; v2 h_bary = V2(0, 0);
+        if (!or_trace(sc, &ray, 0, &h_inst, &h_prim, &h_bary, &st_)) break;
+        or_si si = or_surface_interaction(sc, h_inst, h_prim, h_bary);
+        v3 wo = v3neg(ray.d);
+        { /* handle_surface_light, pt.rs:230-258 */
+            const or_instance *inst = &sc->instances[si.inst];
+            v3 direct = V3(0, 0, 0); float w = 0.0f;
+            if (inst->light >= 0 && (!indirect_only || depth > 1)) {
+                v3 emission = or_material_emission(sc, &si, v3neg(ray.d));
+                direct = v3dot(si.ng, ray.d) < 0.0f ? emission : V3(0, 0, 0);
+                if (depth == 0 || !use_nee) w = 1.0f;
+                else w = or_mis_weight(prev_bsdf_pdf, or_pdf_direct(sc, &si, ray.o));
+            }
+            ADD_RADIANCE(v3scale(direct, w));
+        }
+        if (depth == 0) base = radiance;
+        const float dist_prev = v3len(v3sub(prev_p, si.p));
+        const int dist_crit = sm ? dist_prev >= sm->min_dist : 0, prev_rough_crit = sm ? prev_roughness >= sm->min_roughness : 0;
+        if (sm) { /* the reconnection vertex is a light hit by the last segment, pt.rs:418-464 */
+            const int is_last = depth == g->max_depth, can_connect = dist_crit && prev_rough_crit;
+            if (depth >= 1 && can_connect) {
+                if (sm->vertex->type == OR_VT_INVALID && sm->is_base && is_last) {
+                    or_recon_vertex v; memset(&v, 0, sizeof v);
+                    v.bary = h_bary; v.wo = wo; v.inst_id = si.inst; v.prim_id = si.prim; v.prev_bsdf_pdf = prev_bsdf_pdf;
+                    v.dist = dist_prev; v.depth = depth; v.type = OR_VT_LAST_HIT_LIGHT;
+                    *sm->vertex = v;
+                } else if (!sm->is_base && is_last) { rejected = 1; break; }
+            }
+        }
+        if (depth >= g->max_depth) break;
+        depth += 1;
+        v3 u_direct = smp_3d(smp);
+        or_light_sample dl;
+        memset(&dl, 0, sizeof dl);
+        if (use_nee && (!indirect_only || depth > 1)) {
+            dl = or_sample_direct(sc, si.p, si.ng, u_direct.x, V2(u_direct.y, u_direct.z));
+            if (dl.valid) { dl.shadow_ray.ex0_inst = si.inst; dl.shadow_ray.ex0_prim = si.prim; }
+            else { memset(&dl, 0, sizeof dl); }
+        }
+        int occluded = 1;
+        v3 u_bsdf = smp_3d(smp);
+        or_closure_pool pool;
+        or_surface *closure = or_build_closure(&pool, sc, &si, 0);
+        v3 direct = V3(0, 0, 0);
+        if (dl.valid) { /* sample_surface_and_shade_direct, pt.rs:297-323 */
+            v3 f; float pdf;
+            or_surf_evaluate(closure, wo, dl.wi, &f, &pdf);
+            float w = or_mis_weight(dl.pdf, pdf);
+            direct = v3divs(v3scale(v3mul(dl.li, f), w), dl.pdf);
+        }
+        or_bsdf_sample bs = or_closure_sample(closure, wo, u_bsdf.x, V2(u_bsdf.y, u_bsdf.z));
+        const float u_select = u_bsdf.x;
+        const float roughness = or_surf_roughness(closure, wo, u_bsdf.x);
+        const int rough_crit = sm ? roughness >= sm->min_roughness : 0;
+        if (dl.valid) {
+            occluded = or_trace(sc, &dl.shadow_ray, 1, 0, 0, 0, &st_);
+            if (!occluded) ADD_RADIANCE(direct);
+            if (depth == 1) base = radiance;
+        }
+        if (sm && !sm->is_base && sm->vertex->type != OR_VT_INVALID) { /* perform the reconnection, pt.rs:515-774 */
+            const or_recon_vertex rv = *sm->vertex;
+            if (depth > 1 && dist_crit && prev_rough_crit && rough_crit) { rejected = 1; break; } /* not reversible */
+            if (rv.depth == depth) {
+                or_si rsi = or_surface_interaction(sc, rv.inst_id, rv.prim_id, rv.bary);
+                const v3 dvec = v3sub(rsi.p, si.p);
+                const float dist = v3len(dvec);
+                const v3 wi = v3normalize(dvec);
+                if (!(dist >= sm->min_dist && rough_crit)) { rejected = 1; break; }
+                or_ray vis = {or_offset_ray_origin(si.p, or_face_forward(si.ng, wi)), wi, 0.0f, dist * (1.0f - 1e-3f), si.inst, si.prim, rsi.inst, rsi.prim};
+                const float cos_y2 = fabsf(v3dot(rsi.ng, wi)), cos_x2 = fabsf(v3dot(rsi.ng, rv.wo));
+                if (cos_y2 == 0.0f) { rejected = 1; break; }
+                if (or_trace(sc, &vis, 1, 0, 0, 0, &st_)) { rejected = 1; break; }
+                v3 f1; float pdf_y1;
+                or_surf_evaluate(closure, wo, wi, &f1, &pdf_y1);
+                or_closure_pool pool_y;
+                or_surface *cy = or_build_closure(&pool_y, sc, &rsi, 0);
+                float roughness_y = 0.0f, pdf_y2 = 0.0f; v3 f2 = V3(0, 0, 0), direct_f = V3(0, 0, 0);
+                if (rv.type != OR_VT_LAST_HIT_LIGHT) {
+                    or_surf_evaluate(cy, v3neg(wi), rv.wi, &f2, &pdf_y2);
+                    roughness_y = or_surf_roughness(cy, v3neg(wi), rv.u_bsdf_select);
+                }
+                if (rv.direct_wi.x != 0.0f || rv.direct_wi.y != 0.0f || rv.direct_wi.z != 0.0f) {
+                    v3 f; float bsdf_pdf;
+                    or_surf_evaluate(cy, v3neg(wi), rv.direct_wi, &f, &bsdf_pdf);
+                    direct_f = v3scale(f, or_mis_weight(rv.direct_light_pdf, bsdf_pdf));
+                }
+                if (rv.type != OR_VT_LAST_HIT_LIGHT && roughness_y < sm->min_roughness) { rejected = 1; break; }
+                float pdf_ratio = pdf_y1 / rv.prev_bsdf_pdf;
+                if (rv.type != OR_VT_LAST_HIT_LIGHT)
+                    pdf_ratio *= rv.bsdf_pdf == 0.0f ? (pdf_y2 == 0.0f ? 1.0f : 0.0f) : pdf_y2 / rv.bsdf_pdf;
+                if (pdf_ratio <= 0.0f) { rejected = 1; break; }
+                v3 throughput;
+                {
+                    const or_instance *rinst = &sc->instances[rsi.inst];
+                    v3 le = V3(0, 0, 0); float light_pdf = 0.0f;
+                    if (rinst->light >= 0) {
+                        v3 emission = or_material_emission(sc, &rsi, v3neg(vis.d));
+                        le = v3dot(rsi.ng, vis.d) < 0.0f ? emission : V3(0, 0, 0);
+                        light_pdf = or_pdf_direct(sc, &rsi, si.p);
+                    }
+                    const float w = use_nee ? or_mis_weight(pdf_y1, light_pdf) : 1.0f;
+                    v3 vertex_le = v3scale(le, w);
+                    if (indirect_only && depth == 1) vertex_le = V3(0, 0, 0);
+                    const v3 f_pdf = v3divs(f1, pdf_y1);
+                    float cont_prob = 1.0f; /* compute_contibue_prob(vertex.depth, reconnect_beta * f_pdf), pt.rs:211-218 */
+                    if (rv.depth > g->rr_depth) cont_prob = or_clamp(v3max(v3mul(rbeta, f_pdf)), 0.0f, 1.0f) * 0.95f;
+                    v3 sum = v3add(vertex_le, v3mul(direct_f, rv.direct));
+                    sum = v3add(sum, pdf_y2 > 0.0f ? v3divs(v3mul(f2, rv.indirect), pdf_y2) : V3(0, 0, 0));
+                    throughput = v3divs(v3mul(f_pdf, sum), cont_prob);
+                }
+                ADD_RADIANCE(throughput);
+                float jac = (pdf_ratio * fabsf(cos_y2 / cos_x2)) * or_sqr(rv.dist / dist);
+                if (!or_isfinite(jac)) jac = 0.0f;
+                sm->success = jac > 0.0f;
+                sm->jacobian = jac;
+                if (!sm->success) rejected = 1;
+                break;
+            }
+        }
+        MUL_BETA(v3divs(bs.color, bs.pdf));
+        if (sm && depth > 1) { /* the base path picks its reconnection vertex, pt.rs:784-831 */
+            const int can_connect = dist_crit && prev_rough_crit && rough_crit;
+            if (sm->vertex->type == OR_VT_INVALID && sm->is_base && can_connect) {
+                or_recon_vertex v; memset(&v, 0, sizeof v);
+                if (dl.valid && !occluded) v.direct = v3divs(dl.li, dl.pdf);
+                v.bary = h_bary; v.direct_wi = dl.wi; v.direct_light_pdf = dl.pdf; v.wo = wo; v.inst_id = si.inst; v.wi = bs.wi;
+                v.prim_id = si.prim; v.prev_bsdf_pdf = prev_bsdf_pdf; v.bsdf_pdf = bs.pdf; v.u_bsdf_select = u_select;
+                v.dist = dist_prev; v.depth = depth - 1; v.type = OR_VT_LAST_NEE;
+                *sm->vertex = v;
+                rbeta = V3(1, 1, 1); rrad = V3(0, 0, 0);
+            }
+            if (!sm->is_base && can_connect) { rejected = 1; break; }
+        }
+        if (bs.pdf <= 0.0f || !bs.valid || v3min(bs.color) < 0.0f) break;
+        if (depth > g->rr_depth) {
+            float cont_prob = or_clamp(v3max(beta), 0.0f, 1.0f) * 0.95f;
+            if (smp_1d(smp) >= cont_prob) break;
+            MUL_BETA(v3divs(V3(1, 1, 1), cont_prob));
+        }
+        prev_bsdf_pdf = bs.pdf; prev_p = si.p; prev_roughness = roughness;
+        ray.o = or_offset_ray_origin(si.p, or_face_forward(si.ng, bs.wi));
+        ray.d = bs.wi; ray.t_min = 0.0f; ray.t_max = 1e20f;
+        ray.ex0_inst = si.inst; ray.ex0_prim = si.prim; ray.ex1_inst = OR_INVALID; ray.ex1_prim = OR_INVALID;
+    }
+#undef ADD_RADIANCE
+#undef MUL_BETA
+    {
+        v3 ind = v3sub(radiance, base);
+        ind = V3(or_clamp(ind.x, 0.0f, 1000.0f), or_clamp(ind.y, 0.0f, 1000.0f), or_clamp(ind.z, 0.0f, 1000.0f));
+        radiance = v3add(base, ind);
+    }
+    if (sm) { /* pt.rs:878-899 */
+        if (sm->vertex->type != OR_VT_INVALID && sm->vertex->type != OR_VT_LAST_HIT_LIGHT && sm->is_base) sm->vertex->indirect = rrad;
+        if (!sm->is_base && sm->vertex->type == OR_VT_INVALID) { sm->success = !rejected; sm->jacobian = sm->success ? 1.0f : 0.0f; }
+    }
+    *base_out = base;
+    return radiance;
+}
+
+/* GradientPathTracer::get_shifted (gpt.rs:118-142): neighbour i of a pixel, mirrored at the image border */
+static uint32_t or_gpt_reflect(int32_t x, uint32_t r) { return x < 0 ? (uint32_t)(-x) : ((uint32_t)x >= r ? r - ((uint32_t)x - r) - 1 : (uint32_t)x); }
+static void or_gpt_shifted(const or_gpt_config *g, uint32_t W, uint32_t H, uint32_t x, uint32_t y, uint32_t i, uint32_t *sx, uint32_t *sy) {
+    static const int ox[4] = {1, 0, -1, 0}, oy[4] = {0, 1, 0, -1};
+    *sx = or_gpt_reflect((int32_t)x + ox[i] * (int32_t)g->stride, W);
+    *sy = or_gpt_reflect((int32_t)y + oy[i] * (int32_t)g->stride, H);
+}
+static v3 or_remove_nan(v3 c) { return (or_isnan(c.x) || or_isnan(c.y) || or_isnan(c.z)) ? V3(0, 0, 0) : c; }
+/* what one add_splat adds: color.remove_nan() * weight, each component's NaN flushed again (film.rs:167-194) */
+static v3 or_splat_value(v3 c, float weight) {
+    c = v3scale(or_remove_nan(c), weight);
+    return V3(or_isnan(c.x) ? 0.0f : c.x, or_isnan(c.y) ? 0.0f : c.y, or_isnan(c.z) ? 0.0f : c.z);
+}
+typedef struct {
+    const or_scene *sc; const or_gpt_config *g; or_pt_config pc; or_pcg32 *states; float *own, *shifted[4];
+    volatile uint32_t *next_row; char pad[128];
+} __attribute__((aligned(128))) or_gpt_job;
+/* render_one_spp (gpt.rs:144-351) for one pixel, minus the film writes: own = what this pixel splats onto itself
+ * (reconstruction none: the four primal terms summed in order; otherwise the primal sample), shifted[i] = what it splats for
+ * neighbour i (none: onto the neighbour pixel; otherwise the gradient sample, sign not yet applied). */
+static void or_gpt_pixel(or_gpt_job *j, uint32_t x, uint32_t y) {
+    const or_scene *sc = j->sc; const or_gpt_config *g = j->g;
+    const uint32_t W = sc->width, H = sc->height, pix = x + y * W;
+    const or_pcg32 backup = j->states[pix];
+    or_recon_vertex vertex; memset(&vertex, 0, sizeof vertex);
+    or_shift_mapping sm_ = {0.03f, 0.2f, 1, &vertex, 0.0f, 0};
+    or_shift_mapping *sm = g->reconnect ? &sm_ : 0;
+    v3 l[5], rec[5]; float jac[5]; int ok[5];
+    for (uint32_t k = 0; k < 5; k++) { /* trace(is_primary, pixel, shift_mapping), gpt.rs:153-203 */
+        uint32_t qx = x, qy = y;
+        if (k > 0) or_gpt_shifted(g, W, H, x, y, k - 1, &qx, &qy);
+        or_sampler smp = smp_create(&j->pc, backup, g->spp); /* sampler_backup.clone_box() */
+        smp_start(&smp);
+        or_ray ray = or_generate_ray(sc, &j->pc, qx, qy, &smp);
+        if (sm) { sm->is_base = k == 0; if (k > 0) { sm->success = 0; sm->jacobian = 0.0f; } }
+        v3 base, rad = or_radiance_sm(sc, g, ray, &smp, sm, &base);
+        if (sm) {
+            l[k] = g->separate_weights ? base : rad;
+            jac[k] = sm->jacobian; ok[k] = sm->success;
+            rec[k] = v3sub(rad, l[k]);
+        } else { l[k] = rad; jac[k] = 1.0f; ok[k] = 0; rec[k] = V3(0, 0, 0); }
+    }
+    v3 own = V3(0, 0, 0);
+    if (g->reconstruction != OR_RECON_NONE) own = or_splat_value(v3add(l[0], rec[0]), 1.0f);
+    for (uint32_t i = 0; i < 4; i++) {
+        const uint32_t k = i + 1;
+        v3 out;
+        if (g->reconstruction == OR_RECON_NONE) {
+            const float wp = ok[k] ? 1.0f / (1.0f + jac[k]) : 1.0f, ws = ok[k] ? 1.0f / (1.0f + jac[k]) : 0.0f;
+            v3 a, b;
+            if (g->separate_weights) {
+                a = v3add(v3scale(l[0], 0.5f), v3scale(rec[0], wp));
+                b = v3add(v3scale(l[k], 0.5f), v3scale(v3scale(rec[k], ws), jac[k]));
+            } else {
+                a = v3scale(l[0], wp);
+                b = v3scale(v3scale(l[k], ws), jac[k]);
+            }
+            own = v3add(own, or_splat_value(a, 1.0f));
+            out = or_splat_value(b, 1.0f);
+        } else {
+            v3 grad;
+            if (sm) {
+                if (g->separate_weights) {
+                    v3 gr = ok[k] ? v3divs(v3sub(v3scale(rec[k], jac[k]), rec[0]), 1.0f + jac[k]) : v3sub(V3(0, 0, 0), rec[0]);
+                    grad = v3add(v3scale(v3sub(l[k], l[0]), 0.5f), gr);
+                } else {
+                    grad = ok[k] ? v3divs(v3sub(v3scale(l[k], jac[k]), l[0]), 1.0f + jac[k]) : v3sub(V3(0, 0, 0), l[0]);
+                }
+            } else grad = v3scale(v3sub(l[k], l[0]), 0.5f);
+            out = or_splat_value(grad, i < 2 ? 1.0f : -1.0f);
+        }
+        j->shifted[i][3 * (uint64_t)pix + 0] = out.x; j->shifted[i][3 * (uint64_t)pix + 1] = out.y; j->shifted[i][3 * (uint64_t)pix + 2] = out.z;
+    }
+    j->own[3 * (uint64_t)pix + 0] = own.x; j->own[3 * (uint64_t)pix + 1] = own.y; j->own[3 * (uint64_t)pix + 2] = own.z;
+    or_sampler b = smp_create(&j->pc, backup, g->spp); /* sampler_backup.start(); its Drop stores the state (dim = 0) */
+    smp_start(&b);
+    j->states[pix] = smp_drop(&b);
+}
+static void *or_gpt_worker(void *arg) {
+    or_gpt_job *j = (or_gpt_job *)arg;
+    for (;;) {
+        uint32_t y = __sync_fetch_and_add(j->next_row, 1);
+        if (y >= j->sc->height) break;
+        for (uint32_t x = 0; x < j->sc->width; x++) or_gpt_pixel(j, x, y);
+    }
+    return 0;
+}
+/* The pixels whose neighbour i is pixel c' along one axis of size r: the inverse of or_gpt_reflect(c + o). The reference
+ * lets float atomics decide the summation order of a pixel's splats; both implementations here fix it: own terms first, then
+ * neighbours i = 0..3, each in the order [unreflected, mirrored at 0, mirrored at r]. */
+static int or_gpt_sources(int32_t cp, int32_t o, uint32_t r, uint32_t out[3]) {
+    int n = 0;
+    const int64_t cand[3] = {(int64_t)cp - o, -(int64_t)cp - o, 2 * (int64_t)r - 1 - cp - o};
+    for (int k = 0; k < 3; k++) {
+        const int64_t c = cand[k];
+        if (c < 0 || c >= (int64_t)r) continue;
+        const int64_t q = c + o;
+        const int cls = q < 0 ? 1 : (q >= (int64_t)r ? 2 : 0);
+        if (cls == k) out[n++] = (uint32_t)c;
+    }
+    return n;
+}
+/* film: f32[7N], splat region accumulated into (reconstruction none: += v / 4 per sample, resolve with splat_scale = 1/spp;
+ * otherwise written with the reconstructed image, splat_scale = 1). aux (optional, reconstruction != none):
+ * [primal 3N | Gx 3(W+1)(H+1) | Gy 3(W+1)(H+1)] = the accumulated sums of gpt.rs:441-455 (divide by spp for the mean). */
+OR_EXPORT int or_gpt_render(const or_scene *sc, const or_gpt_config *g, float *film, float *aux, uint32_t n_threads) {
+    const uint32_t W = sc->width, H = sc->height;
+    const uint64_t N = (uint64_t)W * H, NG = (uint64_t)(W + 1) * (H + 1);
+    if (g->stride < 1 || g->stride >= W || g->stride >= H) return -1;
+    if (g->reconstruction == OR_RECON_NONE && !g->reconnect) return -1; /* shift_mapping.unwrap() panics, gpt.rs:276 */
+    if (g->sampler_type != 0) return -1;                                /* Pmj02BnSampler::clone_box is todo!() */
+    or_pcg32 *states = (or_pcg32 *)malloc(sizeof(or_pcg32) * N);
+    or_init_sampler_states(0, N, W, g->sampler_seed, states);
+    float *own = (float *)calloc(3 * N, 4), *sh[4];
+    for (int i = 0; i < 4; i++) sh[i] = (float *)calloc(3 * N, 4);
+    float *acc_p = 0, *acc_gx = 0, *acc_gy = 0, *sqr_p = 0, *sqr_gx = 0, *sqr_gy = 0;
+    if (g->reconstruction != OR_RECON_NONE) {
+        acc_p = (float *)calloc(3 * N, 4); sqr_p = (float *)calloc(3 * N, 4);
+        acc_gx = (float *)calloc(3 * NG, 4); acc_gy = (float *)calloc(3 * NG, 4); sqr_gx = (float *)calloc(3 * NG, 4); sqr_gy = (float *)calloc(3 * NG, 4);
+    }
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    static const int ox[4] = {1, 0, -1, 0}, oy[4] = {0, 1, 0, -1};
+    for (uint32_t s = 0; s < g->spp; s++) {
+        volatile uint32_t next_row = 0;
+        or_gpt_job jobs[256];
+        pthread_t th[256];
+        for (uint32_t t = 0; t < n_threads; t++) {
+            memset(&jobs[t], 0, sizeof(or_gpt_job));
+            jobs[t].sc = sc; jobs[t].g = g; jobs[t].states = states; jobs[t].own = own; jobs[t].next_row = &next_row;
+            for (int i = 0; i < 4; i++) jobs[t].shifted[i] = sh[i];
+            jobs[t].pc.filter_type = g->filter_type; jobs[t].pc.filter_radius = g->filter_radius;
+            jobs[t].pc.sampler_type = 0; jobs[t].pc.sampler_seed = g->sampler_seed;
+        }
+        for (uint32_t t = 1; t < n_threads; t++) pthread_create(&th[t], 0, or_gpt_worker, &jobs[t]);
+        or_gpt_worker(&jobs[0]);
+        for (uint32_t t = 1; t < n_threads; t++) pthread_join(th[t], 0);
+        /* update_kernel, gpt.rs:424-461 */
+        for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) {
+            const uint64_t q = x + (uint64_t)y * W, gq = x + (uint64_t)y * (W + 1);
+            for (int c = 0; c < 3; c++) {
+                if (g->reconstruction == OR_RECON_NONE) {
+                    float v = 0.0f;
+                    v += own[3 * q + c];
+                    for (int i = 0; i < 4; i++) {
+                        uint32_t src[3];
+                        if (ox[i]) { int n = or_gpt_sources((int32_t)x, ox[i] * (int32_t)g->stride, W, src); for (int k = 0; k < n; k++) v += sh[i][3 * (src[k] + (uint64_t)y * W) + c]; }
+                        else { int n = or_gpt_sources((int32_t)y, oy[i] * (int32_t)g->stride, H, src); for (int k = 0; k < n; k++) v += sh[i][3 * (x + (uint64_t)src[k] * W) + c]; }
+                    }
+                    film[3 * N + 3 * q + c] += v * 0.25f;
+                } else {
+                    float v = 0.0f, gx = 0.0f, gy = 0.0f;
+                    v += own[3 * q + c];
+                    if (x >= 1) gx += sh[0][3 * (q - 1) + c];
+                    gx += sh[2][3 * q + c];
+                    if (y >= 1) gy += sh[1][3 * (q - W) + c];
+                    gy += sh[3][3 * q + c];
+                    acc_p[3 * q + c] += v; acc_gx[3 * gq + c] += gx; acc_gy[3 * gq + c] += gy;
+                    sqr_p[3 * q + c] += v * v; sqr_gx[3 * gq + c] += gx * gx; sqr_gy[3 * gq + c] += gy * gy;
+                }
+            }
+        }
+    }
+    if (g->reconstruction != OR_RECON_NONE) { /* gpt.rs:495-606 */
+        const float spp = (float)g->spp;
+        float *old = (float *)malloc(3 * N * 4), *cur = film + 3 * N;
+        for (uint64_t k = 0; k < 3 * N; k++) old[k] = acc_p[k] / spp;
+        float *prefix = (float *)malloc(4 * (g->reconstruction_iter + 1));
+        {
+            const float eps = 0.01f;
+            prefix[0] = 1.0f;
+            for (uint32_t i = 1; i < g->reconstruction_iter; i++) {
+                float p2 = 1.0f; for (uint32_t k = 0; k < i - 1; k++) p2 *= 0.5f; /* 0.5f32.powi(i - 1) */
+                prefix[i] = prefix[i - 1] * (1.0f / ((eps + 1.0f) + 4.0f * p2));
+            }
+        }
+        for (uint32_t it = 0; it < g->reconstruction_iter; it++) {
+            for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) for (int c = 0; c < 3; c++) {
+                const uint64_t q = x + (uint64_t)y * W;
+                const float primal = old[3 * q + c];
+                const float primal2 = sqr_p[3 * q + c] / spp;
+                const float primal_var = or_max(primal2 - or_sqr(acc_p[3 * q + c] / spp), 1e-6f) / spp;
+                const float pw = g->reconstruction == OR_RECON_UNIFORM ? 1.0f : 1.0f / (primal_var * prefix[it]);
+                float v = 0.0f, sum_w = 0.0f;
+                v += primal * pw; sum_w += pw;
+                for (uint32_t i = 0; i < 4; i++) {
+                    const int is_x = (i & 1u) == 0; const float sign = i < 2 ? 1.0f : -1.0f;
+                    const uint32_t gx_ = x + (i == 0 ? 1u : 0u), gy_ = y + (i == 1 ? 1u : 0u);
+                    uint32_t sx, sy; or_gpt_shifted(g, W, H, x, y, i, &sx, &sy);
+                    const uint64_t gi = 3 * (gx_ + (uint64_t)gy_ * (W + 1)) + c;
+                    const float grad = (is_x ? acc_gx[gi] : acc_gy[gi]) / spp;
+                    const float grad2 = (is_x ? sqr_gx[gi] : sqr_gy[gi]) / spp;
+                    const float grad_var = or_max((grad2 - or_sqr(grad)) / spp, 1e-6f);
+                    const float nb = old[3 * (sx + (uint64_t)sy * W) + c];
+                    const float var = primal_var + grad_var;
+                    const float w = g->reconstruction == OR_RECON_UNIFORM ? 1.0f : 1.0f / var;
+                    v += (nb - sign * grad) * w; sum_w += w;
+                }
+                cur[3 * q + c] = v / sum_w;
+            }
+            memcpy(old, cur, 3 * N * 4);
+        }
+        if (aux) { memcpy(aux, acc_p, 3 * N * 4); memcpy(aux + 3 * N, acc_gx, 3 * NG * 4); memcpy(aux + 3 * N + 3 * NG, acc_gy, 3 * NG * 4); }
+        free(old); free(prefix);
+    }
+    free(states); free(own); for (int i = 0; i < 4; i++) free(sh[i]);
+    free(acc_p); free(acc_gx); free(acc_gy); free(sqr_p); free(sqr_gx); free(sqr_gy);
+    return 0;
+}
+OR_EXPORT uint32_t or_sizeof_gpt_config(void) { return (uint32_t)sizeof(or_gpt_config); }
+
+/* Film resolve, film.rs:120-148 with hdr = true: rgb / (w == 0 ? 1 : w) + splat * splat_scale */
+OR_EXPORT void or_film_resolve_scaled(const float *film, uint32_t width, uint32_t height, float splat_scale, float *rgb_out) {
     uint64_t N = (uint64_t)width * height;
     for (uint64_t i = 0; i < N; i++) {
         float w = film[6 * N + i];
         float inv = w == 0.0f ? 1.0f : w;
-        for (int c = 0; c < 3; c++) rgb_out[3 * i + c] = film[3 * i + c] / inv + film[3 * N + 3 * i + c] * 1.0f;
+        for (int c = 0; c < 3; c++) rgb_out[3 * i + c] = film[3 * i + c] / inv + film[3 * N + 3 * i + c] * splat_scale;
     }
 }
+OR_EXPORT void or_film_resolve(const float *film, uint32_t width, uint32_t height, float *rgb_out) { or_film_resolve_scaled(film, width, height, 1.0f, rgb_out); }
 
 /* ---------------------------------- precomputed table, precompute.rs:56-94,133-145 ---------------- */
 static float or_precompute_ggx_dielectric_sample(float roughness, float mu, float ior, or_pcg32 *rng) {

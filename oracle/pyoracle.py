@@ -53,6 +53,9 @@ def lib() -> C.CDLL:
     L.or_pt_render.restype = i32
     L.or_pt_render.argtypes = [vp, C.POINTER(abi.PtConfig), fp, u64p, u32, C.POINTER(OrStats)]
     L.or_film_resolve.argtypes = [fp, u32, u32, fp]
+    L.or_film_resolve_scaled.argtypes = [fp, u32, u32, f32, fp]
+    L.or_gpt_render.restype = i32
+    L.or_gpt_render.argtypes = [vp, C.POINTER(abi.GptConfig), fp, fp, u32]
     L.or_init_pcg32_buffer_with_seed.argtypes = [u64, u64, u64p]
     L.or_ggx_dielectric_table_entry.restype = f32
     L.or_ggx_dielectric_table_entry.argtypes = [u32, u32, u32, u32]
@@ -140,6 +143,18 @@ class OracleScene:
         assert rc == 0
         return film, n.value
 
+    def gpt_render(self, cfg: abi.GptConfig, n_threads: int = 0):
+        """The gpt integrator (gpt.rs): returns (film f32[7*N], (primal, gx, gy) sums or None)."""
+        w, h = self.width, self.height
+        n, ng = w * h, (w + 1) * (h + 1)
+        film = np.zeros(7 * n, dtype=np.float32)
+        aux = np.zeros(3 * n + 6 * ng, dtype=np.float32)
+        rc = lib().or_gpt_render(self.h, C.byref(cfg), _fp(film), _fp(aux), n_threads if n_threads > 0 else (os.cpu_count() or 1))
+        assert rc == 0, "or_gpt_render rejected the configuration"
+        if cfg.reconstruction == 0:
+            return film, None
+        return film, (aux[:3 * n].reshape(h, w, 3), aux[3 * n:3 * n + 3 * ng].reshape(h + 1, w + 1, 3), aux[3 * n + 3 * ng:].reshape(h + 1, w + 1, 3))
+
     def material_inputs(self, material: int, uv) -> np.ndarray:
         u = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
         out = np.zeros((u.shape[0], 26), dtype=np.float32)
@@ -173,9 +188,9 @@ class OracleScene:
         return film, {k: getattr(st, k) for k, _ in OrStats._fields_}
 
 
-def resolve(film: np.ndarray, width: int, height: int) -> np.ndarray:
+def resolve(film: np.ndarray, width: int, height: int, splat_scale: float = 1.0) -> np.ndarray:
     out = np.zeros(3 * width * height, dtype=np.float32)
-    lib().or_film_resolve(_fp(film), width, height, _fp(out))
+    lib().or_film_resolve_scaled(_fp(film), width, height, C.c_float(splat_scale), _fp(out))
     return out.reshape(height, width, 3)
 
 
