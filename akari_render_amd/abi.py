@@ -227,6 +227,40 @@ class GptConfig(_Struct):
         return c
 
 
+class McmcConfig(_Struct):
+    """akr_mcmc_config = mcmc::Config + Method::Kelemen (mcmc.rs:8-80) + filter + sampler of the direct pass."""
+
+    _fields_ = [
+        ("spp", C.c_uint32), ("max_depth", C.c_uint32), ("rr_depth", C.c_uint32), ("spp_per_pass", C.c_uint32),
+        ("use_nee", C.c_uint32), ("mcmc_depth", C.c_uint32), ("n_chains", C.c_uint32), ("n_bootstrap", C.c_uint32),
+        ("direct_spp", C.c_int32), ("exponential_mutation", C.c_uint32),
+        ("small_sigma", C.c_float), ("large_step_prob", C.c_float), ("image_mutation_prob", C.c_float), ("image_mutation_size", C.c_float),
+        ("adaptive", C.c_uint32), ("wis", C.c_uint32),
+        ("seed", C.c_uint64),
+        ("filter_type", C.c_uint32), ("filter_radius", C.c_float), ("sampler_type", C.c_uint32), ("_pad", C.c_uint32),
+        ("sampler_seed", C.c_uint64),
+    ]
+
+    @staticmethod
+    def default() -> "McmcConfig":
+        c = McmcConfig()
+        c.spp, c.max_depth, c.rr_depth, c.spp_per_pass, c.use_nee = 256, 7, 5, 64, 1
+        c.mcmc_depth, c.n_chains, c.n_bootstrap, c.direct_spp = 0xFFFFFFFF, 512, 100000, 64
+        c.exponential_mutation, c.small_sigma, c.large_step_prob, c.image_mutation_prob, c.image_mutation_size = 1, 0.01, 0.1, 0.0, 0.0
+        c.filter_type, c.filter_radius = FILTER_GAUSSIAN, 1.5
+        c.sampler_type, c.sampler_seed = SAMPLER_INDEPENDENT, 0
+        return c
+
+
+class McmcResult(C.Structure):
+    _fields_ = [("normalization", C.c_double), ("acceptance_rate", C.c_double), ("splat_scale", C.c_float), ("contribution", C.c_float),
+                ("n_mutations", C.c_uint64), ("sample_dimension", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+MARKOV_STATE_DTYPE = [("cur_pixel", "<u4", (2,)), ("chain_id", "<u4"), ("cur_f", "<f4"), ("b", "<f4"), ("b_cnt", "<u4"), ("n_accepted", "<u4"),
+                      ("n_mutations", "<u4"), ("cur_iter", "<u4"), ("last_large_iter", "<u4")]
+
+
 class PtStats(C.Structure):
     _fields_ = [
         ("n_samples", C.c_uint64),

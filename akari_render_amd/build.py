@@ -12,7 +12,7 @@ LIB = os.path.join(HERE, "libakari_hip.so")
 SOURCES = [
     "pt_kernels.hip",
     "wf_kernels.hip",
-    "aov_kernels.hip", "gpt_kernels.hip",
+    "aov_kernels.hip", "gpt_kernels.hip", "mcmc_kernels.hip",
     "host/api.cpp",
     "host/scene_build.cpp",
     "host/scene_json.cpp",

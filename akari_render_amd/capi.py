@@ -32,7 +32,7 @@ EXPORTS = [
     "akr_film_resolve", "akr_film_device_ptr",
     "akr_pt_config_default", "akr_pt_config_from_json", "akr_pt_render", "akr_pt_begin", "akr_pt_passes", "akr_pt_end",
     "akr_pt_get_stats", "akr_render_task", "akr_image_write", "akr_aov_config_default", "akr_aov_render",
-    "akr_gpt_config_default", "akr_gpt_render", "akr_film_set_splat_scale", "akr_film_get_splat_scale",
+    "akr_gpt_config_default", "akr_gpt_render", "akr_mcmc_config_default", "akr_mcmc_render", "akr_film_set_splat_scale", "akr_film_get_splat_scale",
     "akr_pt_read_sampler_states",
     "akr_host_stdrng_u64", "akr_host_chacha_block", "akr_host_pcg32_states", "akr_host_pcg_start", "akr_host_alias_table",
     "akr_probe_math", "akr_probe_bsdf", "akr_probe_intersect", "akr_probe_surface_interaction", "akr_probe_material_inputs",
@@ -107,6 +107,8 @@ def lib() -> C.CDLL:
     proto("akr_aov_render", vp, vp, C.POINTER(abi.AovConfig), vp, C.POINTER(abi.PtStats))
     proto("akr_gpt_config_default", C.POINTER(abi.GptConfig))
     proto("akr_gpt_render", vp, vp, C.POINTER(abi.GptConfig), vp, fp, C.POINTER(abi.PtStats))
+    proto("akr_mcmc_config_default", C.POINTER(abi.McmcConfig))
+    proto("akr_mcmc_render", vp, vp, C.POINTER(abi.McmcConfig), vp, C.POINTER(abi.McmcResult), up, C.POINTER(abi.PtStats))
     proto("akr_film_set_splat_scale", vp, C.c_float)
     proto("akr_film_get_splat_scale", vp, fp)
     proto("akr_pt_config_from_json", C.c_char_p, C.POINTER(abi.PtConfig), C.c_char_p, u32)
@@ -535,6 +537,14 @@ def gpt_render(ctx: Context, scene: Scene, cfg: abi.GptConfig, film: Film, want_
     if not want_aux:
         return st.as_dict()
     return st.as_dict(), (aux[:3 * n].reshape(h, w, 3), aux[3 * n:3 * n + 3 * ng].reshape(h + 1, w + 1, 3), aux[3 * n + 3 * ng:].reshape(h + 1, w + 1, 3))
+
+
+def mcmc_render(ctx: Context, scene: Scene, cfg: abi.McmcConfig, film: Film):
+    """akr_mcmc_render: the `mcmc_opt` integrator. Returns (counters, result dict, chain states as a structured array)."""
+    st, res = abi.PtStats(), abi.McmcResult()
+    chains = np.zeros(cfg.n_chains, dtype=abi.MARKOV_STATE_DTYPE)
+    check(lib().akr_mcmc_render(ctx.h, scene.h, C.byref(cfg), film.h, C.byref(res), chains.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(st)))
+    return st.as_dict(), {k: getattr(res, k) for k, _ in abi.McmcResult._fields_ if k != "_pad"}, chains
 
 
 def host_decode_exr(data: bytes) -> np.ndarray:

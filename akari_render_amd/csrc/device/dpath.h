@@ -142,10 +142,9 @@ AKR_D void sampler_end_pass(const PtParams& p, Sampler& s) {
 }
 
 // camera/mod.rs:70-103
-template <bool PMJ>
-AKR_D void generate_ray(const PtParams& p, uint32_t px, uint32_t py, Sampler& smp, vec3& o, vec3& d) {
+AKR_D void generate_ray_from(const PtParams& p, uint32_t px, uint32_t py, vec2 u_filter, vec3& o, vec3& d) {
     vec2 fpixel = mk2((float)px + 0.5f, (float)py + 0.5f);
-    vec2 offset = filter_sample(p, next_2d<PMJ>(p, smp));
+    vec2 offset = filter_sample(p, u_filter);
     vec2 pf = mk2(fpixel.x + offset.x, fpixel.y + offset.y);
     const float* m = p.r2c;
     float qx = ((m[0] * pf.x + m[4] * pf.y) + m[8] * 0.0f) + m[12] * 1.0f;
@@ -160,6 +159,10 @@ AKR_D void generate_ray(const PtParams& p, uint32_t px, uint32_t py, Sampler& sm
         d = mk3((c[0] * d.x + c[4] * d.y) + c[8] * d.z, (c[1] * d.x + c[5] * d.y) + c[9] * d.z,
                 (c[2] * d.x + c[6] * d.y) + c[10] * d.z);
     }
+}
+template <bool PMJ>
+AKR_D void generate_ray(const PtParams& p, uint32_t px, uint32_t py, Sampler& smp, vec3& o, vec3& d) {
+    generate_ray_from(p, px, py, next_2d<PMJ>(p, smp), o, d);
 }
 
 AKR_D float mis_weight(float a, float b) {  // pt.rs:962-973 with power = 1

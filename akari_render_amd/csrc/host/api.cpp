@@ -956,6 +956,148 @@ AKR_API int32_t akr_gpt_render(akr_context* ctx, akr_scene* scene, const akr_gpt
     return rc2;
 }
 
+// ------------------------------------------------------------------------------------------------ mcmc_opt integrator
+AKR_API int32_t akr_mcmc_config_default(akr_mcmc_config* c) {  // mcmc::Config::default (mcmc.rs:60-79), Method::default (mcmc.rs:21-32)
+    if (!c) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_mcmc_config_default: NULL argument");
+    std::memset(c, 0, sizeof *c);
+    c->spp = 256; c->max_depth = 7; c->rr_depth = 5; c->spp_per_pass = 64; c->use_nee = 1;
+    c->mcmc_depth = 0xffffffffu; c->n_chains = 512; c->n_bootstrap = 100000; c->direct_spp = 64;
+    c->exponential_mutation = 1; c->small_sigma = 0.01f; c->large_step_prob = 0.1f; c->image_mutation_prob = 0.0f; c->image_mutation_size = 0.0f;
+    c->adaptive = 0; c->wis = 0; c->seed = 0;
+    c->filter_type = AKR_FILTER_GAUSSIAN; c->filter_radius = 1.5f;
+    c->sampler_type = AKR_SAMPLER_INDEPENDENT; c->sampler_seed = 0;
+    return AKR_OK;
+}
+AKR_API int32_t akr_mcmc_render(akr_context* ctx, akr_scene* scene, const akr_mcmc_config* cfg, akr_film* film, akr_mcmc_result* result,
+                                uint32_t* chain_states, akr_pt_stats* stats) {
+    if (!ctx || !scene || !cfg || !film) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_mcmc_render: NULL argument");
+    if (cfg->n_chains == 0 || cfg->n_bootstrap == 0) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_mcmc_render: n_chains and n_bootstrap must be positive");
+    if (cfg->spp_per_pass == 0) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_mcmc_render: spp_per_pass must be positive");
+    const uint32_t W = scene->flat.camera.width, H = scene->flat.camera.height;
+    if (cfg->direct_spp > 0) {  // direct illumination by the path tracer, mcmc_opt.rs:704-729
+        akr_pt_config d;
+        akr_pt_config_default(&d);
+        d.max_depth = 1; d.rr_depth = 1; d.spp = (uint32_t)cfg->direct_spp; d.indirect_only = 0; d.spp_per_pass = cfg->spp_per_pass; d.use_nee = cfg->use_nee;
+        d.filter_type = cfg->filter_type; d.filter_radius = cfg->filter_radius; d.sampler_type = cfg->sampler_type; d.sampler_seed = cfg->sampler_seed;
+        int32_t rc = akr_pt_render(ctx, scene, &d, film, nullptr);
+        if (rc != AKR_OK) return rc;
+    }
+    akr_pt_config pc;  // the PathTracer inside McmcOpt::new, mcmc_opt.rs:233-252
+    akr_pt_config_default(&pc);
+    pc.spp = 1; pc.spp_per_pass = 1; pc.max_depth = cfg->max_depth; pc.rr_depth = cfg->rr_depth; pc.use_nee = cfg->use_nee;
+    pc.indirect_only = cfg->direct_spp >= 0 ? 1u : 0u;
+    pc.filter_type = cfg->filter_type; pc.filter_radius = cfg->filter_radius;
+    akr_pt_session* se = nullptr;
+    int32_t rc = akr_pt_begin(ctx, scene, &pc, film, &se);
+    if (rc != AKR_OK) return rc;
+    rc = guarded([&] {
+        const uint32_t depth = cfg->mcmc_depth == 0xffffffffu ? cfg->max_depth : cfg->mcmc_depth;
+        const uint32_t dim = 4 + 1 + (1 + depth) * (3 + 3 + 1);  // sample_dimension, mcmc_opt.rs:230-232
+        const uint32_t n_chains = cfg->n_chains, n_boot = cfg->n_bootstrap;
+        fill_params(se, 1, 1);
+        // init_pcg32_buffer_with_seed(n, seed): the bootstrap seeds and the chains' samplers are prefixes of the same stream
+        const size_t n_seeds = std::max(n_chains, n_boot);
+        std::vector<Pcg32> seeds(n_seeds);
+        {
+            StdRng rng(cfg->seed);
+            for (size_t i = 0; i < n_seeds; i++) seeds[i] = pcg_new_seq_offset(i, rng.next_u64());
+        }
+        DevBuf d_seeds, d_fs, d_resampled, d_pss, d_states, d_colors, d_rngs;
+        d_seeds.upload(seeds);
+        d_fs.alloc(n_boot * sizeof(float));
+        d_pss.alloc((size_t)dim * n_chains * sizeof(PssSample));
+        d_states.alloc(n_chains * sizeof(MarkovState));
+        d_colors.alloc(n_chains * sizeof(float4));
+        d_rngs.alloc(n_chains * sizeof(Pcg32));
+        HIP_CHECK(hipMemcpyAsync(d_rngs.p, seeds.data(), n_chains * sizeof(Pcg32), hipMemcpyHostToDevice, ctx->stream));
+        McmcParams m;
+        std::memset(&m, 0, sizeof m);
+        m.pss = d_pss.as<PssSample>(); m.states = d_states.as<MarkovState>(); m.cur_colors = d_colors.as<float4>(); m.rngs = d_rngs.as<Pcg32>();
+        m.seeds = d_seeds.as<Pcg32>(); m.fs = d_fs.as<float>(); m.film = film->data;
+        m.n_chains = n_chains; m.n_bootstrap = n_boot; m.dim = dim; m.width = W; m.height = H;
+        m.exponential_mutation = cfg->exponential_mutation ? 1u : 0u;
+        m.small_sigma = cfg->small_sigma; m.large_step_prob = cfg->large_step_prob; m.image_mutation_prob = cfg->image_mutation_prob;
+        m.image_mutation_size = cfg->image_mutation_size;
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, ctx->stream));
+        HIP_CHECK(launch_mcmc_bootstrap(se->params, m, ctx->stream));
+        std::vector<float> fs(n_boot);
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        HIP_CHECK(hipMemcpy(fs.data(), d_fs.p, n_boot * sizeof(float), hipMemcpyDeviceToHost));
+        // resample_with_f64 (util/distribution.rs:92-115); the reference sums with rayon, here in index order
+        double sum = 0.0;
+        for (float f : fs) sum += (double)f;
+        if (!(sum > 0.0)) throw std::runtime_error("Bootstrap failed, please retry with more samples (mcmc_opt.rs:352)");
+        std::vector<double> cdf(n_boot);
+        for (uint32_t i = 0; i < n_boot; i++) {
+            double pr = (double)fs[i] / sum;
+            cdf[i] = i == 0 ? pr : cdf[i - 1] + pr;
+        }
+        std::vector<uint32_t> resampled(n_chains);
+        {
+            StdRng rng(0);
+            for (uint32_t k = 0; k < n_chains; k++) {
+                double u = (double)(rng.next_u64() >> 11) * (1.0 / 9007199254740992.0);  // rand 0.8.5 Standard f64: 53 random bits
+                uint32_t lo = 0, hi = n_boot;  // partition_point(|x| u >= *x)
+                while (lo < hi) {
+                    uint32_t mid = lo + (hi - lo) / 2;
+                    if (u >= cdf[mid]) lo = mid + 1; else hi = mid;
+                }
+                resampled[k] = std::min(lo, n_boot - 1);
+            }
+        }
+        d_resampled.upload(resampled);
+        m.resampled = d_resampled.as<uint32_t>();
+        HIP_CHECK(launch_mcmc_init(se->params, m, ctx->stream));
+        // render_loop, mcmc_opt.rs:554-683
+        const uint64_t npixels = (uint64_t)W * H;
+        float contribution;
+        {
+            const uint64_t n_mut = npixels * (uint64_t)cfg->spp;
+            const uint64_t per = std::max<uint64_t>(n_mut / n_chains, 1);
+            contribution = (float)((double)n_mut / ((double)per * (double)n_chains));
+        }
+        uint32_t cnt = 0;
+        uint64_t total_mutations = 0;
+        while (cnt < cfg->spp) {
+            const uint32_t cur_pass = std::min(cfg->spp - cnt, cfg->spp_per_pass);
+            const uint64_t per = std::max<uint64_t>(npixels * (uint64_t)cur_pass / n_chains, 1);
+            if (per > 0xffffffffull) throw std::invalid_argument("Number of mutations per chain exceeds u32::MAX, please reduce spp per pass or increase number of chains");
+            HIP_CHECK(launch_mcmc_advance(se->params, m, (uint32_t)per, contribution, ctx->stream));
+            total_mutations += per * n_chains;
+            cnt += cur_pass;
+        }
+        HIP_CHECK(hipEventRecord(e1, ctx->stream));
+        se->events.emplace_back(e0, e1);
+        se->n_launches += 2 + (cfg->spp + cfg->spp_per_pass - 1) / cfg->spp_per_pass;
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        // reconstruct, mcmc_opt.rs:587-611
+        std::vector<MarkovState> states(n_chains);
+        HIP_CHECK(hipMemcpy(states.data(), d_states.p, n_chains * sizeof(MarkovState), hipMemcpyDeviceToHost));
+        double b = sum;
+        uint64_t b_cnt = n_boot, accepted = 0, mutations = 0;
+        for (const MarkovState& st : states) {
+            b += (double)st.b; b_cnt += st.b_cnt; accepted += st.n_accepted; mutations += st.n_mutations;
+        }
+        b = b / (double)b_cnt;
+        film->splat_scale = (float)b / (float)cfg->spp;
+        if (result) {
+            result->normalization = b; result->acceptance_rate = (double)accepted / (double)mutations; result->splat_scale = film->splat_scale;
+            result->contribution = contribution; result->n_mutations = total_mutations; result->sample_dimension = dim; result->_pad = 0;
+        }
+        if (chain_states) std::memcpy(chain_states, states.data(), n_chains * sizeof(MarkovState));
+    });
+    std::string err = g_last_error;
+    int32_t rc2 = akr_pt_end(se, stats);
+    if (rc != AKR_OK) {
+        g_last_error = err;
+        return rc;
+    }
+    return rc2;
+}
+
 // ------------------------------------------------------------------------------------------------ render driver
 AKR_API int32_t akr_image_write(const char* path, const float* rgb, uint32_t width, uint32_t height) {
     if (!path || !rgb || !width || !height) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_image_write: bad argument");
@@ -974,7 +1116,7 @@ AKR_API int32_t akr_render_task(akr_context* ctx, akr_scene* scene, const char* 
         std::vector<float> rgb(3ull * w * h);
         for (size_t ti = 0; ti < tasks.size(); ti++) {  // render_single, lib.rs:112-193
             const ParsedTask& task = tasks[ti];
-            if (ses.verbose) std::fprintf(stderr, "[akari_hip] task %zu/%zu (%s): %ux%u, %u spp -> %s\n", ti + 1, tasks.size(), task.is_aov ? "aov" : (task.is_gpt ? "gpt" : "pt"), w, h, task.is_aov ? task.aov.spp : (task.is_gpt ? task.gpt.spp : task.cfg.spp), task.film_out.c_str());
+            if (ses.verbose) std::fprintf(stderr, "[akari_hip] task %zu/%zu (%s): %ux%u, %u spp -> %s\n", ti + 1, tasks.size(), task.is_aov ? "aov" : (task.is_gpt ? "gpt" : (task.is_mcmc ? "mcmc_opt" : "pt")), w, h, task.is_aov ? task.aov.spp : (task.is_gpt ? task.gpt.spp : (task.is_mcmc ? task.mcmc.spp : task.cfg.spp)), task.film_out.c_str());
             akr_film* film = nullptr;
             akr_pt_session* se = nullptr;
             auto check = [&](int32_t rc) { if (rc != AKR_OK) { std::string m = g_last_error; if (se) akr_pt_end(se, nullptr); if (film) akr_film_destroy(film); throw std::runtime_error(m); } };
@@ -983,6 +1125,20 @@ AKR_API int32_t akr_render_task(akr_context* ctx, akr_scene* scene, const char* 
                 akr_pt_stats st;
                 check(akr_aov_render(ctx, scene, &task.aov, film, &st));
                 if (ses.verbose) std::fprintf(stderr, "[akari_hip] Rendered in %.2fms\n", st.kernel_ms);
+                check(akr_film_resolve(film, rgb.data()));
+                akr_film_destroy(film);
+                film = nullptr;
+                write_image(task.film_out, rgb.data(), w, h);
+                if (stats_out) *stats_out = st;
+                continue;
+            }
+            if (task.is_mcmc) {  // McmcOpt::render: one image at the end (intermediates are not written by this build)
+                akr_pt_stats st;
+                akr_mcmc_result res;
+                check(akr_mcmc_render(ctx, scene, &task.mcmc, film, &res, nullptr, &st));
+                if (ses.verbose)
+                    std::fprintf(stderr, "[akari_hip] Normalization factor: %g\n[akari_hip] Acceptance rate: %.2f%%\n[akari_hip] Rendering finished in %.2fs\n",
+                                 res.normalization, res.acceptance_rate * 100.0, st.kernel_ms * 1e-3);
                 check(akr_film_resolve(film, rgb.data()));
                 akr_film_destroy(film);
                 film = nullptr;

@@ -92,6 +92,8 @@ struct ParsedTask {
     akr_aov_config aov;
     bool is_gpt = false;     // Method::GradientPathTracer
     akr_gpt_config gpt;
+    bool is_mcmc = false;    // Method::McmcOpt
+    akr_mcmc_config mcmc;
     std::string film_out;
 };
 std::vector<ParsedTask> parse_render_tasks(const std::string& text, bool allow_sampler_override);

@@ -486,6 +486,7 @@ static void parse_one_task(const JsonValue* j, akr_pt_config* cfg, std::string* 
     if (task) {
         akr_aov_config_default(&task->aov);
         akr_gpt_config_default(&task->gpt);
+        akr_mcmc_config_default(&task->mcmc);
     }
     if (film_out) *film_out = "out.exr";  // FilmConfig::default, lib.rs:82-90
     if (j->has("method")) {
@@ -519,8 +520,28 @@ static void parse_one_task(const JsonValue* j, akr_pt_config* cfg, std::string* 
                 else if (r == "weighted") g.reconstruction = AKR_GPT_RECON_WEIGHTED;
                 else throw std::runtime_error("unknown reconstruction '" + r + "'");
             }
+        } else if (ty == "mcmc_opt" && task) {  // mcmc::Config (mcmc.rs:44-80), Method::Kelemen (mcmc.rs:8-32)
+            task->is_mcmc = true;
+            akr_mcmc_config& g = task->mcmc;
+            auto gu = [&](const char* k, uint32_t& dst) { if (m.has(k)) dst = (uint32_t)m.at(k).as_number(); };
+            auto gb = [&](const JsonValue& o, const char* k, uint32_t& dst) { if (o.has(k)) dst = o.at(k).as_bool() ? 1u : 0u; };
+            gu("spp", g.spp); gu("max_depth", g.max_depth); gu("spp_per_pass", g.spp_per_pass); gu("rr_depth", g.rr_depth);
+            gu("n_chains", g.n_chains); gu("n_bootstrap", g.n_bootstrap);
+            gb(m, "use_nee", g.use_nee); gb(m, "wis", g.wis);
+            if (m.has("mcmc_depth") && m.at("mcmc_depth").type != JsonValue::Null) g.mcmc_depth = (uint32_t)m.at("mcmc_depth").as_number();
+            if (m.has("direct_spp")) g.direct_spp = (int32_t)m.at("direct_spp").as_number();
+            if (m.has("seed")) g.seed = (uint64_t)m.at("seed").as_number();
+            if (m.has("method")) {
+                const JsonValue& k = m.at("method");
+                if (k.has("type") && k.at("type").as_string() != "kelemen") throw std::runtime_error("unknown mcmc method '" + k.at("type").as_string() + "'");
+                gb(k, "exponential_mutation", g.exponential_mutation); gb(k, "adaptive", g.adaptive);
+                if (k.has("small_sigma")) g.small_sigma = k.at("small_sigma").as_f32();
+                if (k.has("large_step_prob")) g.large_step_prob = k.at("large_step_prob").as_f32();
+                if (k.has("image_mutation_prob")) g.image_mutation_prob = k.at("image_mutation_prob").as_f32();
+                if (k.has("image_mutation_size") && k.at("image_mutation_size").type != JsonValue::Null) g.image_mutation_size = k.at("image_mutation_size").as_f32();
+            }
         } else if (ty != "pt") {
-            throw std::runtime_error("unsupported: method type '" + ty + "' (\"pt\", \"aov\" and \"gpt\" are implemented" + (task ? ")" : "; this entry point takes \"pt\" only)"));
+            throw std::runtime_error("unsupported: method type '" + ty + "' (\"pt\", \"aov\", \"gpt\" and \"mcmc_opt\" are implemented" + (task ? ")" : "; this entry point takes \"pt\" only)"));
         }
         auto u32 = [&](const char* k, uint32_t& dst) { if (m.has(k)) dst = (uint32_t)m.at(k).as_number(); };
         auto b32 = [&](const char* k, uint32_t& dst) { if (m.has(k)) dst = m.at(k).as_bool() ? 1u : 0u; };
@@ -573,6 +594,10 @@ static void parse_one_task(const JsonValue* j, akr_pt_config* cfg, std::string* 
         task->gpt.filter_radius = cfg->filter_radius;
         task->gpt.sampler_type = cfg->sampler_type;
         task->gpt.sampler_seed = cfg->sampler_seed;
+        task->mcmc.filter_type = cfg->filter_type;
+        task->mcmc.filter_radius = cfg->filter_radius;
+        task->mcmc.sampler_type = cfg->sampler_type;
+        task->mcmc.sampler_seed = cfg->sampler_seed;
     }
 }
 
@@ -596,6 +621,7 @@ std::vector<ParsedTask> parse_render_tasks(const std::string& text, bool allow_s
 
 void parse_method_json(const std::string& text, akr_pt_config* cfg, std::string* film_out) {
     std::vector<ParsedTask> tasks = parse_render_tasks(text, false);
+    if (tasks[0].is_mcmc) throw std::runtime_error("unsupported: method type 'mcmc_opt' here (akr_pt_config_from_json fills a pt::Config; use akr_render_task)");
     if (tasks[0].is_gpt) throw std::runtime_error("unsupported: method type 'gpt' here (akr_pt_config_from_json fills a pt::Config; use akr_render_task)");
     if (tasks[0].is_aov) throw std::runtime_error("unsupported: method type 'aov' here (akr_pt_config_from_json fills a pt::Config; use akr_render_task)");
     *cfg = tasks[0].cfg;

@@ -65,6 +65,33 @@ struct GptParams {
     uint32_t reconnect, stride, separate_weights, reconstruction;
 };
 
+// mcmc_opt integrator (mcmc_kernels.hip)
+struct PssSample {  // mcmc_opt.rs:21-26
+    float cur, backup;
+    uint32_t last_modified, modified_backup;
+};
+struct MarkovState {  // mcmc_opt.rs:41-51
+    uint32_t cur_pixel[2], chain_id;
+    float cur_f, b;
+    uint32_t b_cnt, n_accepted, n_mutations, cur_iter, last_large_iter;
+};
+struct McmcParams {
+    PssSample* pss;          // [dim][n_chains]
+    MarkovState* states;     // [n_chains]
+    float4* cur_colors;      // [n_chains]
+    Pcg32* rngs;             // [n_chains] the chains' independent samplers
+    const Pcg32* seeds;      // [max(n_bootstrap, n_chains)] init_pcg32_buffer_with_seed(seed)
+    float* fs;               // [n_bootstrap] bootstrap contributions
+    const uint32_t* resampled;  // [n_chains] bootstrap path each chain starts from
+    float* film;             // the film (7 N floats); the chains splat into its splat channels
+    uint32_t n_chains, n_bootstrap, dim, width, height;
+    uint32_t exponential_mutation;
+    float small_sigma, large_step_prob, image_mutation_prob, image_mutation_size;
+};
+hipError_t launch_mcmc_bootstrap(const PtParams& p, const McmcParams& m, hipStream_t stream);
+hipError_t launch_mcmc_init(const PtParams& p, const McmcParams& m, hipStream_t stream);
+hipError_t launch_mcmc_advance(const PtParams& p, const McmcParams& m, uint32_t mutations_per_chain, float contribution, hipStream_t stream);
+
 hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream);
 hipError_t launch_gpt_sample(const PtParams& p, const GptParams& g, hipStream_t stream);
 hipError_t launch_gpt_update(const GptParams& g, uint32_t W, uint32_t H, float* film, hipStream_t stream);

@@ -405,6 +405,45 @@ AKR_API int32_t akr_gpt_config_default(akr_gpt_config *cfg);
  * [primal 3 N | Gx 3 (W+1)(H+1) | Gy 3 (W+1)(H+1)] floats, the sums the reference writes / spp to output/gpt_*.exr. */
 AKR_API int32_t akr_gpt_render(akr_context *ctx, akr_scene *scene, const akr_gpt_config *cfg, akr_film *film, float *aux, akr_pt_stats *stats);
 
+/* ---------------------------------------------------------------------------------------------------
+ * `mcmc_opt` integrator (Method::McmcOpt, akari_integrator/src/mcmc_opt.rs + mcmc.rs:8-80; "type": "mcmc_opt"): primary-sample-
+ * space Metropolis light transport. An optional direct-illumination pass of the path tracer (direct_spp > 0: max_depth 1
+ * into the film's rgb / weight channels; the chains then render indirect light only), n_bootstrap independent paths to
+ * estimate the normalisation and seed n_chains Markov chains, then W * H * spp mutations spread over the chains (Kelemen
+ * large / small steps on lazily mutated sample vectors of 5 + 7 (1 + mcmc_depth) dimensions), every mutation splatting the
+ * proposed and the current path with their acceptance weights; resolve scale b / spp.
+ * Splats are float atomics as in the reference: each chain is reproducible bit for bit, the summation order per pixel is not.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t spp, max_depth, rr_depth, spp_per_pass;        /* mcmc::Config::default = pt defaults: 256, 7, 5, 64 (mcmc.rs:60-79) */
+    uint32_t use_nee;                                       /* 1 */
+    uint32_t mcmc_depth;                                    /* 0xffffffff = None = max_depth */
+    uint32_t n_chains, n_bootstrap;                         /* 512, 100000 */
+    int32_t direct_spp;                                     /* 64; 0 = no direct pass but indirect-only chains; < 0 = chains render everything */
+    uint32_t exponential_mutation;                          /* Method::Kelemen (mcmc.rs:10-32): 1 */
+    float small_sigma, large_step_prob, image_mutation_prob;/* 0.01, 0.1, 0 */
+    float image_mutation_size;                              /* <= 0 = None */
+    uint32_t adaptive, wis;                                 /* carried, unused by mcmc_opt.rs */
+    uint64_t seed;                                          /* 0 */
+    uint32_t filter_type;
+    float filter_radius;
+    uint32_t sampler_type, _pad;                            /* sampler of the direct pass */
+    uint64_t sampler_seed;
+} akr_mcmc_config;
+typedef struct {
+    double normalization;      /* b = (sum of bootstrap + large-step contributions) / their count */
+    double acceptance_rate;    /* accepted / proposed small steps */
+    float splat_scale;         /* (float)b / (float)spp, also set on the film */
+    float contribution;        /* weight of one mutation */
+    uint64_t n_mutations;      /* mutations executed, all chains */
+    uint32_t sample_dimension, _pad;
+} akr_mcmc_result;
+AKR_API int32_t akr_mcmc_config_default(akr_mcmc_config *cfg);
+/* Renders into `film` (clear it first; sets its splat scale). chain_states (host memory, optional): n_chains records of 10
+ * u32 = MarkovState {cur_pixel[2], chain_id, cur_f, b, b_cnt, n_accepted, n_mutations, cur_iter, last_large_iter}. */
+AKR_API int32_t akr_mcmc_render(akr_context *ctx, akr_scene *scene, const akr_mcmc_config *cfg, akr_film *film, akr_mcmc_result *result,
+                                uint32_t *chain_states, akr_pt_stats *stats);
+
 /* util::write_image (akari_render/src/util/mod.rs:57-127): ".exr" -> linear RGB f32 OpenEXR (uncompressed scanlines),
  * ".png" -> 8-bit sRGB. rgb = 3 * W * H floats, row-major, top row first. Creates parent directories. */
 AKR_API int32_t akr_image_write(const char *path, const float *rgb, uint32_t width, uint32_t height);

@@ -595,7 +595,9 @@ OR_EXPORT void or_scene_destroy(or_scene *sc) {
 /* IndependentSampler (sampler/mod.rs:161-217): pcg + dim. Pmj02BnSampler (sampler/mod.rs:329-700): pmj != 0, state =
  * Pmj02BnState {seed, dim, pixel, sample_index, spp, w}. The two tables are handed in by the test (or_set_pmj_tables): the
  * reference's own are absent from its tree, the build regenerates them (akari_render_amd/csrc/host/pmj_tables.cpp). */
-typedef struct { or_pcg32 pcg; uint32_t dim; int pmj; uint32_t seed, px, py, sample_index, spp, w; } or_sampler;
+struct or_mcmc_smp;
+typedef struct { or_pcg32 pcg; uint32_t dim; int pmj; uint32_t seed, px, py, sample_index, spp, w; struct or_mcmc_smp *mc; } or_sampler;
+static float or_mcmc_next_1d(or_sampler *s); /* LazyMcmcSampler (mcmc_opt.rs:61-119), further down */
 static const uint32_t *g_pmj_sets;   /* [5][65536][2] */
 static const uint16_t *g_bluenoise;  /* [48][128][128] */
 OR_EXPORT void or_set_pmj_tables(const uint32_t *sets, const uint16_t *bluenoise) { g_pmj_sets = sets; g_bluenoise = bluenoise; }
@@ -613,6 +615,7 @@ static float or_bluenoise(uint32_t tex, uint32_t px, uint32_t py) { /* uv = p.yx
 }
 #define OR_ONE_MINUS_EPSILON 0.99999994f
 static inline float smp_1d(or_sampler *s) {
+    if (s->mc) return or_mcmc_next_1d(s);
     if (!s->pmj) { s->dim += 1; return pcg_next_1d(&s->pcg); }
     uint32_t hash = or_xxhash32_4(s->px, s->py, s->dim, s->seed);
     uint32_t index = or_permute_element(s->sample_index, s->spp, s->w, hash);
@@ -1362,6 +1365,258 @@ OR_EXPORT int or_gpt_render(const or_scene *sc, const or_gpt_config *g, float *f
     return 0;
 }
 OR_EXPORT uint32_t or_sizeof_gpt_config(void) { return (uint32_t)sizeof(or_gpt_config); }
+
+/* ---------------------------------- mcmc_opt integrator, akari_integrator/src/mcmc_opt.rs ------------ */
+/* Primary-sample-space Metropolis light transport (Kelemen et al.) with lazily mutated samples: n_chains Markov chains, each
+ * a vector of `sample_dimension` primary samples that the path tracer reads instead of random numbers. */
+typedef struct {
+    uint32_t spp, max_depth, rr_depth, spp_per_pass;
+    uint32_t use_nee, mcmc_depth /* 0xffffffff = None -> max_depth */, n_chains, n_bootstrap;
+    int32_t direct_spp; uint32_t exponential_mutation;
+    float small_sigma, large_step_prob, image_mutation_prob, image_mutation_size /* <= 0 = None */;
+    uint32_t adaptive, wis;
+    uint64_t seed;
+    uint32_t filter_type; float filter_radius; uint32_t sampler_type, _pad;
+    uint64_t sampler_seed;
+} or_mcmc_config; /* = akr_mcmc_config */
+typedef struct { float cur, backup; uint32_t last_modified, modified_backup; } or_pss; /* PssSample, mcmc_opt.rs:21-26 */
+typedef struct { /* MarkovState, mcmc_opt.rs:41-51 */
+    uint32_t cur_pixel[2], chain_id; float cur_f, b; uint32_t b_cnt, n_accepted, n_mutations, cur_iter, last_large_iter;
+} or_markov_state;
+typedef struct or_mcmc_smp {
+    or_pss *samples;              /* this chain's sample_dimension entries */
+    uint32_t cur_dim, mcmc_dim;
+    int mutate;                   /* Some(mutator) */
+    int is_large_step, is_image_mutation; uint32_t last_large_iter, cur_iter; float res_x, res_y;
+    const or_mcmc_config *cfg;
+} or_mcmc_smp;
+static float or_erf_inv(float x) { /* util/mod.rs:149-186 */
+    float cx = or_clamp(x, -0.99999f, 0.99999f);
+    float w = -or_logf((1.0f - cx) * (1.0f + cx));
+    float p;
+    if (w < 0.5f) {
+        w -= 2.5f;
+        p = 2.81022636e-08f; p = 3.43273939e-07f + p * w; p = -3.5233877e-06f + p * w; p = -4.39150654e-06f + p * w;
+        p = 0.00021858087f + p * w; p = -0.00125372503f + p * w; p = -0.00417768164f + p * w; p = 0.246640727f + p * w; p = 1.50140941f + p * w;
+    } else {
+        w = sqrtf(w) - 3.0f;
+        p = -0.000200214257f; p = 0.000100950558f + p * w; p = 0.00134934322f + p * w; p = -0.00367342844f + p * w;
+        p = 0.00573950773f + p * w; p = -0.0076224613f + p * w; p = 0.00943887047f + p * w; p = 1.00167406f + p * w; p = 2.83297682f + p * w;
+    }
+    return p * cx;
+}
+static float or_kelemen_mutate(float cur, float u) { /* KELEMEN_MUTATE, sampler/mcmc.rs:111-134; sizes 1/1024 .. 1/64 */
+    const float size_high = 1.0f / 64.0f, log_ratio = -2.7725887f; /* -(size_high / size_low).ln() = -ln 16 */
+    int add = u < 0.5f;
+    u = add ? u * 2.0f : (u - 0.5f) * 2.0f;
+    float dv = size_high * or_expf(log_ratio * u);
+    if (add) { float n = cur + dv; return n > 1.0f ? n - 1.0f : n; }
+    float n = cur - dv;
+    return n < 0.0f ? n + 1.0f : n;
+}
+static or_pss or_mutate_one(or_mcmc_smp *m, uint32_t i, or_pcg32 *rng) { /* Mutator::mutate_one, mcmc_opt.rs:131-226 */
+    const or_mcmc_config *c = m->cfg;
+    or_pss sp = m->samples[i];
+    float u = pcg_next_1d(rng);
+    if (sp.last_modified < m->last_large_iter) { sp.cur = pcg_next_1d(rng); sp.last_modified = m->last_large_iter; }
+    sp.backup = sp.cur; sp.modified_backup = sp.last_modified;
+    if (m->is_large_step) sp.cur = u;
+    else {
+        const int has_img = c->image_mutation_size > 0.0f;
+        const int under_image = has_img && m->is_image_mutation;
+        const int should_mutate = !under_image || i < 2;
+        const uint32_t target_iter = should_mutate ? m->cur_iter : m->cur_iter - 1;
+        const uint32_t n_small = target_iter - sp.last_modified;
+        if (c->exponential_mutation) {
+            float x = sp.cur;
+            for (uint32_t k = 0; k < n_small; k++) {
+                float v = pcg_next_1d(rng);
+                if (v < 1.0f - c->image_mutation_prob) x = or_kelemen_mutate(x, v / (1.0f - c->image_mutation_prob));
+            }
+            sp.cur = x;
+        } else if (n_small > 0) {
+            float dv = sqrtf(2.0f) * or_erf_inv(2.0f * u - 1.0f); /* sample_gaussian(u), sampling.rs:46-48 */
+            float n = sp.cur + (dv * c->small_sigma) * sqrtf((1.0f - c->image_mutation_prob) * (float)n_small);
+            n = n - floorf(n);
+            sp.cur = or_isfinite(n) ? n : 0.0f;
+        }
+        if (has_img && m->is_image_mutation && i < 2) { /* mutate_image_space_single, sampler/mcmc.rs:180-200 */
+            float v = pcg_next_1d(rng);
+            int add = v < 0.5f;
+            v = add ? v * 2.0f : (v - 0.5f) * 2.0f;
+            float off = v * c->image_mutation_size;
+            off = add ? off : -off;
+            float n = sp.cur + off / (i == 0 ? m->res_x : m->res_y);
+            sp.cur = n - floorf(n);
+        }
+    }
+    sp.last_modified = m->cur_iter;
+    m->samples[i] = sp;
+    return sp;
+}
+static float or_mcmc_next_1d(or_sampler *s) { /* LazyMcmcSampler::next_1d, mcmc_opt.rs:88-103 */
+    or_mcmc_smp *m = s->mc;
+    if (m->cur_dim < m->mcmc_dim) {
+        float r = m->mutate ? or_mutate_one(m, m->cur_dim, &s->pcg).cur : m->samples[m->cur_dim].cur;
+        m->cur_dim += 1;
+        return r;
+    }
+    m->cur_dim += 1;
+    return pcg_next_1d(&s->pcg);
+}
+static uint32_t or_mcmc_dim(const or_mcmc_config *c) { /* sample_dimension, mcmc_opt.rs:230-232 */
+    uint32_t d = c->mcmc_depth == 0xffffffffu ? c->max_depth : c->mcmc_depth;
+    return 4 + 1 + (1 + d) * (3 + 3 + 1);
+}
+typedef struct { uint32_t px, py; v3 l; float f; uint32_t dim; } or_mcmc_eval;
+/* McmcOpt::evaluate, mcmc_opt.rs:253-305. rng = the independent sampler underneath; samples = the chain's primary samples */
+static or_mcmc_eval or_mcmc_evaluate(const or_scene *sc, const or_mcmc_config *c, const or_gpt_config *pt, const or_pt_config *pc, or_pss *samples,
+                                     or_pcg32 *rng, or_mcmc_smp *mut /* NULL or a filled-in mutator */, int is_bootstrap) {
+    or_mcmc_smp m;
+    if (mut) m = *mut; else memset(&m, 0, sizeof m);
+    m.samples = samples; m.cur_dim = 0; m.mcmc_dim = is_bootstrap ? 0 : or_mcmc_dim(c); m.mutate = mut != 0; m.cfg = c;
+    or_sampler smp; memset(&smp, 0, sizeof smp);
+    smp.pcg = *rng; smp.mc = &m;
+    v2 u = smp_2d(&smp);
+    int32_t ix = (int32_t)(u.x * (float)sc->width), iy = (int32_t)(u.y * (float)sc->height);
+    ix = ix < 0 ? 0 : (ix > (int32_t)sc->width - 1 ? (int32_t)sc->width - 1 : ix);
+    iy = iy < 0 ? 0 : (iy > (int32_t)sc->height - 1 ? (int32_t)sc->height - 1 : iy);
+    or_ray ray = or_generate_ray(sc, pc, (uint32_t)ix, (uint32_t)iy, &smp);
+    v3 base;
+    v3 l = or_radiance_sm(sc, pt, ray, &smp, 0, &base); /* PathTracer::radiance = run_megakernel, shift_mapping None */
+    l = v3scale(l, 1.0f);                                /* * ray_w */
+    or_mcmc_eval e = {(uint32_t)ix, (uint32_t)iy, l, or_clamp(v3max(l), 0.0f, 1e5f), m.cur_dim}; /* scalar_contribution */
+    *rng = smp.pcg;
+    return e;
+}
+/* out: film (7N floats; the direct pass fills rgb + weight, the chains the splat channels), result[4] = {b (normalisation),
+ * acceptance rate, splat scale as f32 bits, contribution as f32 bits} (doubles / reinterpreted), chain_states (10 u32 each). */
+OR_EXPORT int or_mcmc_render(const or_scene *sc, const or_mcmc_config *c, float *film, double *result, uint32_t *chain_states, uint32_t n_threads) {
+    const uint32_t W = sc->width, H = sc->height;
+    const uint64_t N = (uint64_t)W * H;
+    if (c->n_chains == 0 || c->n_bootstrap == 0 || c->sampler_type > 1) return -1;
+    if (c->direct_spp > 0) { /* mcmc_opt.rs:704-729 */
+        or_pt_config d; memset(&d, 0, sizeof d);
+        d.spp = (uint32_t)c->direct_spp; d.max_depth = 1; d.rr_depth = 1; d.spp_per_pass = c->spp_per_pass; d.use_nee = c->use_nee;
+        d.debug_depth = -1; d.filter_type = c->filter_type; d.filter_radius = c->filter_radius; d.sampler_type = c->sampler_type;
+        d.sampler_seed = c->sampler_seed; d.shard_count = 1;
+        if (or_pt_render(sc, &d, film, 0, n_threads, 0) != 0) return -1;
+    }
+    or_gpt_config pt; memset(&pt, 0, sizeof pt); /* the PathTracer inside McmcOpt::new, mcmc_opt.rs:233-252 */
+    pt.max_depth = c->max_depth; pt.rr_depth = c->rr_depth; pt.use_nee = c->use_nee; pt.indirect_only = c->direct_spp >= 0;
+    or_pt_config pc; memset(&pc, 0, sizeof pc);
+    pc.filter_type = c->filter_type; pc.filter_radius = c->filter_radius;
+    const uint32_t dim = or_mcmc_dim(c);
+    /* bootstrap, mcmc_opt.rs:310-398 */
+    or_pcg32 *seeds = (or_pcg32 *)malloc(sizeof(or_pcg32) * c->n_bootstrap);
+    or_init_pcg32_buffer_with_seed(c->n_bootstrap, c->seed, (uint64_t *)seeds);
+    float *fs = (float *)malloc(4 * (size_t)c->n_bootstrap);
+    for (uint32_t i = 0; i < c->n_bootstrap; i++) {
+        or_pcg32 rng = seeds[i];
+        fs[i] = or_mcmc_evaluate(sc, c, &pt, &pc, 0, &rng, 0, 1).f;
+    }
+    /* resample_with_f64, util/distribution.rs:92-115 (the reference sums with rayon; here in index order) */
+    double sum = 0.0;
+    for (uint32_t i = 0; i < c->n_bootstrap; i++) sum += (double)fs[i];
+    if (!(sum > 0.0)) { free(seeds); free(fs); return -2; } /* "Bootstrap failed" */
+    double *cdf = (double *)malloc(8 * (size_t)c->n_bootstrap);
+    for (uint32_t i = 0; i < c->n_bootstrap; i++) { double p = (double)fs[i] / sum; cdf[i] = i == 0 ? p : cdf[i - 1] + p; }
+    uint32_t *resampled = (uint32_t *)malloc(4 * (size_t)c->n_chains);
+    {
+        or_stdrng rng; or_stdrng_seed_from_u64(&rng, 0);
+        for (uint32_t k = 0; k < c->n_chains; k++) {
+            double u = (double)(or_stdrng_next_u64(&rng) >> 11) * (1.0 / 9007199254740992.0); /* Standard f64: 53 bits */
+            uint32_t lo = 0, hi = c->n_bootstrap; /* partition_point(|x| u >= *x) */
+            while (lo < hi) { uint32_t mid = lo + (hi - lo) / 2; if (u >= cdf[mid]) lo = mid + 1; else hi = mid; }
+            resampled[k] = lo < c->n_bootstrap - 1 ? lo : c->n_bootstrap - 1;
+        }
+    }
+    or_pss *samples = (or_pss *)calloc((size_t)dim * c->n_chains, sizeof(or_pss));
+    or_markov_state *states = (or_markov_state *)calloc(c->n_chains, sizeof(or_markov_state));
+    v3 *cur_colors = (v3 *)calloc(c->n_chains, sizeof(v3));
+    for (uint32_t i = 0; i < c->n_chains; i++) { /* mcmc_opt.rs:356-386 */
+        or_pcg32 rng = seeds[resampled[i]];
+        or_pss *sp = samples + (size_t)i * dim;
+        for (uint32_t j = 0; j < dim; j++) { sp[j].cur = pcg_next_1d(&rng); sp[j].backup = 0.0f; sp[j].last_modified = 0; sp[j].modified_backup = 0; }
+        or_mcmc_eval e = or_mcmc_evaluate(sc, c, &pt, &pc, sp, &rng, 0, 0);
+        cur_colors[i] = e.l;
+        or_markov_state st = {{e.px, e.py}, i, e.f, 0.0f, 0, 0, 0, 0, 0};
+        states[i] = st;
+    }
+    or_pcg32 *rngs = (or_pcg32 *)malloc(sizeof(or_pcg32) * c->n_chains);
+    or_init_pcg32_buffer_with_seed(c->n_chains, c->seed, (uint64_t *)rngs);
+    /* render_loop, mcmc_opt.rs:554-683 */
+    const uint64_t npixels = N;
+    float contribution;
+    {
+        uint64_t n_mut = npixels * (uint64_t)c->spp, per = n_mut / c->n_chains; if (per < 1) per = 1;
+        contribution = (float)((double)n_mut / ((double)per * (double)c->n_chains));
+    }
+    uint32_t cnt = 0;
+    while (cnt < c->spp) {
+        uint32_t cur_pass = c->spp - cnt < c->spp_per_pass ? c->spp - cnt : c->spp_per_pass;
+        uint64_t per = npixels * (uint64_t)cur_pass / c->n_chains; if (per < 1) per = 1;
+        if (per > 0xffffffffull) return -3;
+        for (uint32_t i = 0; i < c->n_chains; i++) { /* advance_chain, mcmc_opt.rs:505-552; chains in index order */
+            or_pcg32 rng = rngs[i];
+            or_markov_state st = states[i];
+            v3 cur_color = cur_colors[i];
+            or_pss *sp = samples + (size_t)i * dim;
+            for (uint64_t it = 0; it < per; it++) {
+                if (st.cur_iter == 0xffffffffu - 1) { /* about to overflow */
+                    for (uint32_t j = 0; j < dim; j++) { if (sp[j].last_modified < st.last_large_iter) sp[j].cur = pcg_next_1d(&rng); sp[j].last_modified = 0; }
+                    st.cur_iter -= st.last_large_iter; st.last_large_iter = 0;
+                }
+                /* mutate_chain, mcmc_opt.rs:409-503 */
+                st.cur_iter += 1;
+                or_mcmc_smp mut; memset(&mut, 0, sizeof mut);
+                float u = pcg_next_1d(&rng);
+                mut.is_large_step = u < c->large_step_prob;
+                mut.is_image_mutation = pcg_next_1d(&rng) < c->image_mutation_prob;
+                mut.last_large_iter = st.last_large_iter; mut.cur_iter = st.cur_iter; mut.res_x = (float)W; mut.res_y = (float)H;
+                or_mcmc_eval e = or_mcmc_evaluate(sc, c, &pt, &pc, sp, &rng, &mut, 0);
+                const float proposal_f = e.f;
+                if (mut.is_large_step && st.b_cnt < 1024u * 1024u) { st.b += proposal_f; st.b_cnt += 1; }
+                const float cur_f = st.cur_f;
+                float accept = 0.0f;
+                if (or_isfinite(proposal_f)) accept = (cur_f == 0.0f || !or_isfinite(cur_f)) ? 1.0f : or_clamp(proposal_f / cur_f, 0.0f, 1.0f);
+                {
+                    v3 a = or_splat_value(v3divs(e.l, proposal_f), accept * contribution);
+                    float *d = film + 3 * N + 3 * ((uint64_t)e.px + (uint64_t)e.py * W);
+                    d[0] += a.x; d[1] += a.y; d[2] += a.z;
+                    v3 b = or_splat_value(v3divs(cur_color, cur_f), (1.0f - accept) * contribution);
+                    d = film + 3 * N + 3 * ((uint64_t)st.cur_pixel[0] + (uint64_t)st.cur_pixel[1] * W);
+                    d[0] += b.x; d[1] += b.y; d[2] += b.z;
+                }
+                if (pcg_next_1d(&rng) < accept) {
+                    st.cur_f = proposal_f; cur_color = e.l; st.cur_pixel[0] = e.px; st.cur_pixel[1] = e.py;
+                    if (!mut.is_large_step) st.n_accepted += 1; else st.last_large_iter = st.cur_iter;
+                } else {
+                    st.cur_iter -= 1;
+                    uint32_t nd = e.dim < dim ? e.dim : dim;
+                    for (uint32_t j = 0; j < nd; j++) { sp[j].cur = sp[j].backup; sp[j].last_modified = sp[j].modified_backup; }
+                }
+                if (!mut.is_large_step) st.n_mutations += 1;
+            }
+            cur_colors[i] = cur_color; rngs[i] = rng; states[i] = st;
+        }
+        cnt += cur_pass;
+    }
+    { /* reconstruct, mcmc_opt.rs:587-611 */
+        double b = sum; uint64_t b_cnt = c->n_bootstrap, acc = 0, mut = 0;
+        for (uint32_t i = 0; i < c->n_chains; i++) { b += (double)states[i].b; b_cnt += states[i].b_cnt; acc += states[i].n_accepted; mut += states[i].n_mutations; }
+        b = b / (double)b_cnt;
+        if (result) {
+            result[0] = b; result[1] = (double)acc / (double)mut;
+            float scale = (float)b / (float)c->spp;
+            result[2] = (double)scale; result[3] = (double)contribution;
+        }
+    }
+    if (chain_states) memcpy(chain_states, states, sizeof(or_markov_state) * c->n_chains);
+    free(seeds); free(fs); free(cdf); free(resampled); free(samples); free(states); free(cur_colors); free(rngs);
+    return 0;
+}
+OR_EXPORT uint32_t or_sizeof_mcmc_config(void) { return (uint32_t)sizeof(or_mcmc_config); }
 
 /* Film resolve, film.rs:120-148 with hdr = true: rgb / (w == 0 ? 1 : w) + splat * splat_scale */
 OR_EXPORT void or_film_resolve_scaled(const float *film, uint32_t width, uint32_t height, float splat_scale, float *rgb_out) {

@@ -54,6 +54,8 @@ def lib() -> C.CDLL:
     L.or_pt_render.argtypes = [vp, C.POINTER(abi.PtConfig), fp, u64p, u32, C.POINTER(OrStats)]
     L.or_film_resolve.argtypes = [fp, u32, u32, fp]
     L.or_film_resolve_scaled.argtypes = [fp, u32, u32, f32, fp]
+    L.or_mcmc_render.restype = i32
+    L.or_mcmc_render.argtypes = [vp, C.POINTER(abi.McmcConfig), fp, C.POINTER(C.c_double), up, u32]
     L.or_gpt_render.restype = i32
     L.or_gpt_render.argtypes = [vp, C.POINTER(abi.GptConfig), fp, fp, u32]
     L.or_init_pcg32_buffer_with_seed.argtypes = [u64, u64, u64p]
@@ -154,6 +156,16 @@ class OracleScene:
         if cfg.reconstruction == 0:
             return film, None
         return film, (aux[:3 * n].reshape(h, w, 3), aux[3 * n:3 * n + 3 * ng].reshape(h + 1, w + 1, 3), aux[3 * n + 3 * ng:].reshape(h + 1, w + 1, 3))
+
+    def mcmc_render(self, cfg: abi.McmcConfig, n_threads: int = 0):
+        """The mcmc_opt integrator: (film f32[7*N], {normalization, acceptance_rate, splat_scale, contribution}, chain states)."""
+        film = np.zeros(7 * self.width * self.height, dtype=np.float32)
+        res = np.zeros(4, dtype=np.float64)
+        chains = np.zeros(cfg.n_chains, dtype=abi.MARKOV_STATE_DTYPE)
+        rc = lib().or_mcmc_render(self.h, C.byref(cfg), _fp(film), res.ctypes.data_as(C.POINTER(C.c_double)), chains.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                  n_threads if n_threads > 0 else (os.cpu_count() or 1))
+        assert rc == 0, f"or_mcmc_render failed ({rc})"
+        return film, {"normalization": res[0], "acceptance_rate": res[1], "splat_scale": np.float32(res[2]), "contribution": np.float32(res[3])}, chains
 
     def material_inputs(self, material: int, uv) -> np.ndarray:
         u = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
