@@ -61,6 +61,23 @@ AKR_D uint32_t alias_sample_and_remap(const AliasEntry* __restrict__ entries, co
     return idx;
 }
 
+// The same table with both candidate probabilities next to the entry: one 16-byte load per level instead of the entry
+// followed by a dependent pdfs[idx] load (the shading phase is a chain of dependent gathers; every link is ~a cache latency).
+struct AliasPacked {
+    uint32_t j;
+    float t, pdf_i, pdf_j;
+};
+AKR_D uint32_t alias_sample_and_remap(const AliasPacked* __restrict__ entries, uint32_t n, float u, float& pdf, float& remapped) {
+    float u1;
+    uint32_t idx = uniform_discrete_choice_and_remap(n, u, u1);
+    AliasPacked e = entries[idx];
+    float u2;
+    bool first = weighted_choice2_and_remap(e.t, u1, u2);
+    pdf = first ? e.pdf_i : e.pdf_j;
+    remapped = u2;
+    return first ? idx : e.j;
+}
+
 struct Frame {  // geometry.rs:72-78
     vec3 n, t, s;
 };

@@ -213,10 +213,10 @@ AKR_D LightSample sample_direct(const DScene& sc, vec3 pn_p, vec3 pn_n, float u_
     s.valid = false;
     if (sc.n_lights == 0) return s;
     float light_choice_pdf, u_sel2, pdf_prim, u_unused;
-    uint32_t light = alias_sample_and_remap(sc.light_entries, sc.light_pdf, sc.n_lights, u_select, light_choice_pdf, u_sel2);
-    uint32_t off = sc.light_tri_offset[light];
-    uint32_t prim = alias_sample_and_remap(sc.area_entries + off, sc.area_pdf + off, sc.light_n_tris[light], u_sel2, pdf_prim, u_unused);
-    uint32_t gid = sc.inst_tri_offset[sc.light_inst[light]] + prim;
+    uint32_t light = alias_sample_and_remap(sc.light_alias, sc.n_lights, u_select, light_choice_pdf, u_sel2);
+    const LightRec L = sc.lights[light];
+    uint32_t prim = alias_sample_and_remap(sc.area_alias + L.tri_offset, L.n_tris, u_sel2, pdf_prim, u_unused);
+    uint32_t gid = L.first_gid + prim;
     vec2 bary = uniform_sample_triangle(u_sample);
     SurfacePoint y = surface_interaction(sc, gid, bary);
     vec3 wi = y.p - pn_p;
@@ -240,8 +240,9 @@ AKR_D LightSample sample_direct(const DScene& sc, vec3 pn_p, vec3 pn_n, float u_
 AKR_D float pdf_direct(const DScene& sc, const SurfacePoint& si, uint32_t gid, vec3 pn_p) {
     uint32_t light = (uint32_t)si.light;
     float light_choice_pdf = sc.light_pdf[light];
-    uint32_t prim = gid - sc.inst_tri_offset[si.inst];
-    float prim_pdf = sc.area_pdf[sc.light_tri_offset[light] + prim];
+    const LightRec L = sc.lights[light];
+    uint32_t prim = gid - L.first_gid;
+    float prim_pdf = sc.area_pdf[L.tri_offset + prim];
     vec3 wi = si.p - pn_p;
     float dist2 = length2(wi);
     wi = div_s(wi, __builtin_sqrtf(dist2));

@@ -24,6 +24,10 @@ constexpr uint32_t kInvalid = 0xffffffffu;
 enum : uint32_t { SHADE_ROWS = 8, INST_ROWS = 8 };
 enum : uint32_t { TRI_HAS_NORMALS = 1u, TRI_HAS_TANGENTS = 2u };
 
+struct LightRec {  // one light = one emissive instance: where its triangles sit in the area table and in the global triangle order
+    uint32_t tri_offset, n_tris, first_gid, inst;
+};
+
 struct DScene {
     const float4* __restrict__ woop;
     const uint32_t* __restrict__ tri_gid;   // nullptr = identity (exhaustive path)
@@ -40,6 +44,9 @@ struct DScene {
     const AliasEntry* __restrict__ area_entries;
     const float* __restrict__ area_pdf;
     const uint32_t* __restrict__ inst_tri_offset;   // instance -> first global triangle id
+    const AliasPacked* __restrict__ light_alias;    // light_entries + light_pdf, packed
+    const AliasPacked* __restrict__ area_alias;     // area_entries + area_pdf, packed
+    const LightRec* __restrict__ lights;            // light_tri_offset + light_n_tris + light_inst (+ inst_tri_offset), packed
     const float4* __restrict__ bvh_nodes;           // nullptr on the exhaustive path
     uint32_t n_tris, n_lights, n_nodes, has_alpha;
     TexScene tex;                                   // textures + shader-graph node lists (all nullptr without textures)

@@ -123,6 +123,7 @@ struct akr_scene {
     akr_context* ctx = nullptr;
     FlatScene flat;
     CompiledScene cs;
+    DevBuf light_alias, area_alias, lights;
     DevBuf woop, tri_gid, shade, normals, inst, materials, ggx_table, light_entries, light_pdf, light_inst, light_tri_offset,
         light_n_tris, area_entries, area_pdf, inst_tri_offset, bvh_nodes, tex_nodes, tex_images, tex_texels, tex_mat_inputs;
     std::vector<float> ggx_host;
@@ -206,6 +207,21 @@ static void scene_finish(akr_scene* s) {
     s->area_entries.upload(cs.area_entries);
     s->area_pdf.upload(cs.area_pdf);
     s->inst_tri_offset.upload(cs.inst_tri_offset);
+    {  // the light tables once more, packed so that each level of light sampling is ONE gather (device/dgeom.h, dscene.h)
+        auto pack = [](const std::vector<AliasEntry>& e, const std::vector<float>& pdf, size_t first, size_t n, std::vector<AliasPacked>& out) {
+            for (size_t i = 0; i < n; i++) out.push_back(AliasPacked{e[first + i].j, e[first + i].t, pdf[first + i], pdf[first + e[first + i].j]});
+        };
+        std::vector<AliasPacked> la, aa;
+        std::vector<LightRec> lr;
+        pack(cs.light_entries, cs.light_pdf, 0, cs.n_lights, la);
+        for (uint32_t l = 0; l < cs.n_lights; l++) {
+            pack(cs.area_entries, cs.area_pdf, cs.light_tri_offset[l], cs.light_n_tris[l], aa);
+            lr.push_back(LightRec{cs.light_tri_offset[l], cs.light_n_tris[l], cs.inst_tri_offset[cs.light_inst[l]], cs.light_inst[l]});
+        }
+        s->light_alias.upload(la);
+        s->area_alias.upload(aa);
+        s->lights.upload(lr);
+    }
     s->bvh_nodes.upload(cs.bvh_nodes);
     if (cs.has_textures) {
         s->tex_nodes.upload(cs.tex_nodes);
@@ -231,6 +247,9 @@ static void scene_finish(akr_scene* s) {
     d.area_entries = s->area_entries.as<AliasEntry>();
     d.area_pdf = s->area_pdf.as<float>();
     d.inst_tri_offset = s->inst_tri_offset.as<uint32_t>();
+    d.light_alias = s->light_alias.as<AliasPacked>();
+    d.area_alias = s->area_alias.as<AliasPacked>();
+    d.lights = s->lights.as<LightRec>();
     d.bvh_nodes = s->bvh_nodes.as<float4>();
     d.n_tris = cs.n_tris;
     d.n_lights = cs.n_lights;
@@ -245,7 +264,7 @@ static void scene_finish(akr_scene* s) {
     s->device_bytes = 0;
     for (const DevBuf* b : {&s->woop, &s->tri_gid, &s->shade, &s->normals, &s->inst, &s->materials, &s->ggx_table, &s->light_entries,
                             &s->light_pdf, &s->light_inst, &s->light_tri_offset, &s->light_n_tris, &s->area_entries, &s->area_pdf,
-                            &s->inst_tri_offset, &s->bvh_nodes, &s->tex_nodes, &s->tex_images, &s->tex_texels, &s->tex_mat_inputs})
+                            &s->inst_tri_offset, &s->light_alias, &s->area_alias, &s->lights, &s->bvh_nodes, &s->tex_nodes, &s->tex_images, &s->tex_texels, &s->tex_mat_inputs})
         s->device_bytes += b->bytes;
 }
 
