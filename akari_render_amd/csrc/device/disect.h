@@ -62,11 +62,24 @@ AKR_D bool alpha_test(const DScene& sc, uint32_t gid, float u, float v) {
     return alpha > h;
 }
 
+// The five conditions of the test as ONE number: inside the triangle and inside (0, tmax) <=> margin >= 0. For finite values
+// this is the comparison chain of tri_test exactly (a - b >= 0 <=> a >= b in IEEE arithmetic, and the minimum of numbers
+// is >= 0 iff all of them are); a NaN t makes u, v and every operand NaN, and NaN >= 0 is false, as in the chain. Why: each
+// comparison of the chain leaves a lane mask in SGPRs and the masks are combined on the scalar unit, which the four SIMDs of a
+// CU share -- at 60 scalar instructions per record the loops below were bound by that unit, not by the VALU.
+AKR_D float next_up(float x) {  // the next float above a finite x
+    uint32_t b = f2u(x);
+    return x > 0.0f ? u2f(b + 1u) : (x < 0.0f ? u2f(b - 1u) : u2f(1u));
+}
+AKR_D float hit_margin(float t, float u, float v, float tmax) {
+    return __builtin_fminf(__builtin_fminf(__builtin_fminf(u, v), 1.0f - (u + v)), __builtin_fminf(t, tmax - t));
+}
+
 // Exhaustive intersector: every lane of the wave walks the same triangle list, so the 48-byte records are
 // wave-uniform and come in through the scalar cache (s_load_dwordx4 x3), leaving the VALU for the test itself.
 template <bool ANY_HIT, bool TEX = false>
 AKR_D bool trace_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmin, float tmax, uint32_t ex0, uint32_t ex1, Hit& hit) {
-    float best_t = tmax;
+    float best_t = next_up(tmax);  // see trace_pair_exhaustive
     uint32_t best = kInvalid;
     float best_u = 0.0f, best_v = 0.0f;
     const uint32_t n = sc.n_tris;
@@ -88,24 +101,27 @@ AKR_D bool trace_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmin, float 
         const float4 r0 = n0, r1 = n1, r2 = n2;
         load_rec(k + 1, n0, n1, n2);
         float t, u, v;
-        bool h = tri_test(o, d, r0, r1, r2, tmin, tmax, t, u, v);
-        h = h & (k != ex0) & (k != ex1);
+        tri_test(o, d, r0, r1, r2, tmin, tmax, t, u, v);
+        float m = __builtin_fminf(hit_margin(t, u, v, tmax), t - tmin);
+        m = (k == ex0) ? -1.0f : m;
+        m = (k == ex1) ? -1.0f : m;
         if (sc.has_alpha) {
-            if (h) h = alpha_test<TEX>(sc, k, u, v);
+            if (m >= 0.0f && !alpha_test<TEX>(sc, k, u, v)) m = -1.0f;
         }
         if (ANY_HIT) {
-            if (h) best = k;
+            if (m >= 0.0f) best = k;
             if (__builtin_amdgcn_ballot_w64(best == kInvalid) == 0) break;  // every lane of the wave is occluded
         } else {
-            // ascending k: a strict '<' keeps the lowest id among equal t; the first hit needs t <= tmax only
-            bool better = h & ((best == kInvalid) | (t < best_t));
-            best_t = better ? t : best_t;
+            // ascending k: a strict '<' keeps the lowest id among equal t
+            const float tc = (m >= 0.0f) ? t : __builtin_inff();
+            const bool better = tc < best_t;
+            best_t = better ? tc : best_t;
             best_u = better ? u : best_u;
             best_v = better ? v : best_v;
             best = better ? k : best;
         }
     }
-    hit.t = best_t;
+    hit.t = best != kInvalid ? best_t : tmax;
     hit.u = best_u;
     hit.v = best_v;
     hit.gid = best;
@@ -120,10 +136,12 @@ AKR_D bool trace_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmin, float 
 template <bool TEX = false>
 AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, uint32_t ex0, vec3 so, vec3 sd, float stmax,
                                  uint32_t sex0, uint32_t sex1, Hit& hit, bool& found, bool& occluded) {
-    float best_t = tmax;
+    // best_t starts one ulp above tmax: "t < best_t" then admits a first hit at t == tmax and keeps, among equal t, the
+    // lowest id afterwards (ascending k, strict '<') without a separate "no hit yet" test
+    float best_t = next_up(tmax);
     uint32_t best = kInvalid;
     float best_u = 0.0f, best_v = 0.0f;
-    bool occ = false;
+    float occ_margin = -1.0f;  // max over the records of the shadow ray's margin: >= 0 <=> something occludes
     const uint32_t n = sc.n_tris;
     typedef const float __attribute__((address_space(4))) * ConstF;
     ConstF recs = (ConstF)(uintptr_t)sc.woop;
@@ -139,27 +157,30 @@ AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, u
         const float4 r0 = n0, r1 = n1, r2 = n2;
         load_rec(k + 1, n0, n1, n2);  // prefetch (buffer padded by one record)
         float t, u, v, st, su, sv;
-        bool h = tri_test(o, d, r0, r1, r2, 0.0f, tmax, t, u, v);
-        bool sh = tri_test(so, sd, r0, r1, r2, 0.0f, stmax, st, su, sv);
-        h = h & (k != ex0);
-        sh = sh & (k != sex0) & (k != sex1);
+        tri_test(o, d, r0, r1, r2, 0.0f, tmax, t, u, v);
+        tri_test(so, sd, r0, r1, r2, 0.0f, stmax, st, su, sv);
+        float m = hit_margin(t, u, v, tmax), sm = hit_margin(st, su, sv, stmax);
+        m = (k == ex0) ? -1.0f : m;
+        sm = (k == sex0) ? -1.0f : sm;
+        sm = (k == sex1) ? -1.0f : sm;
         if (sc.has_alpha) {
-            if (h) h = alpha_test<TEX>(sc, k, u, v);
-            if (sh) sh = alpha_test<TEX>(sc, k, su, sv);
+            if (m >= 0.0f && !alpha_test<TEX>(sc, k, u, v)) m = -1.0f;
+            if (sm >= 0.0f && !alpha_test<TEX>(sc, k, su, sv)) sm = -1.0f;
         }
-        bool better = h & ((best == kInvalid) | (t < best_t));
-        best_t = better ? t : best_t;
+        const float tc = (m >= 0.0f) ? t : __builtin_inff();
+        const bool better = tc < best_t;
+        best_t = better ? tc : best_t;
         best_u = better ? u : best_u;
         best_v = better ? v : best_v;
         best = better ? k : best;
-        occ = occ | sh;
+        occ_margin = sm > occ_margin ? sm : occ_margin;  // (not fmaxf: that costs two canonicalising v_max per record)
     }
-    hit.t = best_t;
+    found = best != kInvalid;
+    hit.t = found ? best_t : tmax;
     hit.u = best_u;
     hit.v = best_v;
     hit.gid = best;
-    found = best != kInvalid;
-    occluded = occ;
+    occluded = occ_margin >= 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------------------------
