@@ -164,8 +164,11 @@ AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, u
         sm = (k == sex0) ? -1.0f : sm;
         sm = (k == sex1) ? -1.0f : sm;
         if (sc.has_alpha) {
-            if (m >= 0.0f && !alpha_test<TEX>(sc, k, u, v)) m = -1.0f;
-            if (sm >= 0.0f && !alpha_test<TEX>(sc, k, su, sv)) sm = -1.0f;
+            // k through readfirstlane: opaque to loop strength reduction, which otherwise keeps this block's record pointer and
+            // hash constant as induction variables updated on the scalar unit every trip, alpha or not
+            const uint32_t ka = __builtin_amdgcn_readfirstlane(k);
+            if (m >= 0.0f && !alpha_test<TEX>(sc, ka, u, v)) m = -1.0f;
+            if (sm >= 0.0f && !alpha_test<TEX>(sc, ka, su, sv)) sm = -1.0f;
         }
         const float tc = (m >= 0.0f) ? t : __builtin_inff();
         const bool better = tc < best_t;
