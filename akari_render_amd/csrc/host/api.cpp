@@ -306,6 +306,19 @@ static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pas
         p.pmj_sets = se->ctx->pmj_sets.as<uint32_t>();
         p.bluenoise = se->ctx->bluenoise.as<uint16_t>();
     }
+    {  // LDS staging of a small scene's gather tables (pt_kernels.hip); scenes on the BVH path read them from HBM
+        const CompiledScene& cs = s->cs;
+        const size_t bytes[9] = {cs.shade.size() * 4, cs.normals.size() * 4, cs.inst.size() * 4, cs.materials.size() * sizeof(DMaterial),
+                                 (size_t)cs.n_lights * sizeof(AliasPacked), cs.area_entries.size() * sizeof(AliasPacked), (size_t)cs.n_lights * sizeof(LightRec),
+                                 cs.light_pdf.size() * 4, cs.area_pdf.size() * 4};
+        size_t total = 0;
+        for (int i = 0; i < 9; i++) total += (bytes[i] + 15) & ~(size_t)15;
+        p.stage_total = 0;
+        if (cs.bvh_nodes.empty() && total <= kStageMaxBytes) {
+            for (int i = 0; i < 9; i++) p.stage_bytes[i] = (uint32_t)bytes[i];
+            p.stage_total = (uint32_t)total;
+        }
+    }
     p.shard_rank = c.shard_count > 1 ? c.shard_rank : 0;
     p.shard_count = c.shard_count > 1 ? c.shard_count : 1;
     p.tile_w = c.tile_w ? c.tile_w : 32;

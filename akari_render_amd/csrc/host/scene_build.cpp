@@ -584,7 +584,12 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
     // (AKR_FORCE_BVH=1 builds the BVH for tiny scenes too: lets the tests run both intersectors on scenes/cbox)
     const char* force = std::getenv("AKR_FORCE_BVH");
     const uint32_t kExhaustiveMax = (force && force[0] == '1') ? 0u : 64u;
-    if (n_tris > kExhaustiveMax) {
+    // the exhaustive kernels stage the shading tables in LDS (pt_kernels.hip): a tiny mesh with a huge material list goes the BVH way
+    size_t stage = 0;
+    for (size_t b : {out.shade.size() * 4, out.normals.size() * 4, out.inst.size() * 4, out.materials.size() * sizeof(DMaterial),
+                     (size_t)out.n_lights * 32, out.area_entries.size() * 16, out.light_pdf.size() * 4, out.area_pdf.size() * 4})
+        stage += (b + 15) & ~(size_t)15;
+    if (n_tris > kExhaustiveMax || stage > kStageMaxBytes) {
         float diag2 = 0.0f;
         for (int a = 0; a < 3; a++) diag2 += sqr(out.scene_hi[a] - out.scene_lo[a]);
         float pad = 4e-6f * __builtin_sqrtf(diag2);

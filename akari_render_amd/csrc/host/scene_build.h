@@ -86,6 +86,9 @@ PcgStartConsts pcg_start_constants();
 FlatScene load_scene_json(const std::string& path);
 void parse_method_json(const std::string& text, akr_pt_config* cfg, std::string* film_out);
 // all tasks of a RenderTask file (Single | Multi), lib.rs:103-109; allow_sampler_override: pmj02bn -> independent
+// most LDS a workgroup of the exhaustive path tracer kernels spends on staged scene tables (4 workgroups per CU, 160 KB of LDS)
+constexpr size_t kStageMaxBytes = 32 * 1024;
+
 struct ParsedTask {
     bool is_aov = false;     // Method::NormalVis instead of Method::PathTracer
     akr_pt_config cfg;

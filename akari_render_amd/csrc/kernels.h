@@ -35,6 +35,10 @@ struct PtParams {
     uint32_t smp_seed, smp_spp, smp_w;      // Pmj02BnState.{seed, spp, w}
     const uint32_t* pmj_sets;               // [5][65536][2] u32 fixed point
     const uint16_t* bluenoise;              // [48][128][128] unorm16
+    // Small scenes (exhaustive path): the tables the shading phase gathers from, staged in LDS by k_pt_pass. Bytes per table
+    // in the order shade, normals, inst, materials, light_alias, area_alias, lights, light_pdf, area_pdf; 0 total = not staged.
+    uint32_t stage_bytes[9];
+    uint32_t stage_total;
     // work distribution
     uint32_t n_items;
     uint32_t shard_rank, shard_count;

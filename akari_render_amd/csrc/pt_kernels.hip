@@ -26,11 +26,42 @@ namespace akr {
 #endif
 template <bool BVH, bool FD, bool TEX, bool PMJ>
 __global__ __launch_bounds__(256, BVH ? AKR_PT_MIN_WAVES_BVH : (FD ? AKR_PT_MIN_WAVES_FD : AKR_PT_MIN_WAVES)) void k_pt_pass(const PtParams p) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: kBvhStackDepth x 256 words
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: kBvhStackDepth x 256 words; else: staged tables
     TraceCtx tc;
     tc.stack = lds_stack + threadIdx.x;
     tc.cnt = TraceCounters{0, 0, 0};
-    const DScene& sc = p.sc;
+    // Exhaustive path = small scene: the tables the shading phase gathers from (shading records, instance transforms,
+    // materials, light tables: ~11 KB for the cbox) are copied to LDS once per workgroup -- a workgroup lives for the whole
+    // launch, 16 passes x 64 spp -- and the kernel works on a parameter block whose pointers aim at the copies. The shading
+    // phase is a chain of dependent gathers; from LDS each link costs ~1/3 of an L1 hit through the texture path.
+    PtParams staged = p;
+    if (!BVH) {  // (the host sends a scene down the exhaustive path only if its tables fit, scene_build.cpp)
+        const void* src[9] = {p.sc.shade,      p.sc.normals, p.sc.inst,      p.sc.materials, p.sc.light_alias,
+                              p.sc.area_alias, p.sc.lights,  p.sc.light_pdf, p.sc.area_pdf};
+        uint32_t* dst[9];
+        uint32_t off = 0;
+#pragma unroll
+        for (int e = 0; e < 9; e++) {
+            const uint32_t n = p.stage_bytes[e] >> 2;
+            const uint32_t* g = (const uint32_t*)src[e];
+            uint32_t* l = lds_stack + off;
+            for (uint32_t i = threadIdx.x; i < n; i += 256u) l[i] = g[i];
+            dst[e] = l;  // unconditionally an LDS address: the compiler then reads the tables with ds_read, not flat loads
+            off += ((p.stage_bytes[e] + 15u) & ~15u) >> 2;
+        }
+        __syncthreads();
+        staged.sc.shade = (const float4*)dst[0];
+        staged.sc.normals = (const float4*)dst[1];  // non-null even without normals: only gates reading the flags in shade row 7
+        staged.sc.inst = (const float4*)dst[2];
+        staged.sc.materials = (const DMaterial*)dst[3];
+        staged.sc.light_alias = (const AliasPacked*)dst[4];
+        staged.sc.area_alias = (const AliasPacked*)dst[5];
+        staged.sc.lights = (const LightRec*)dst[6];
+        staged.sc.light_pdf = (const float*)dst[7];
+        staged.sc.area_pdf = (const float*)dst[8];
+    }
+    const PtParams& q = (!BVH) ? staged : p;
+    const DScene& sc = q.sc;
     const uint32_t item = blockIdx.x * 256u + threadIdx.x;
     uint32_t px = 0, py = 0;
     const bool in_frame = item < p.n_items && item_to_pixel(p, item, px, py);
@@ -38,7 +69,7 @@ __global__ __launch_bounds__(256, BVH ? AKR_PT_MIN_WAVES_BVH : (FD ? AKR_PT_MIN_
     uint32_t sx, sy;
     shifted_pixel(p, px, py, sx, sy);
     PathRegs r;
-    path_regs_init<PMJ>(r, p, in_frame, pix, sx, sy);
+    path_regs_init<PMJ>(r, q, in_frame, pix, sx, sy);
 
     while (__builtin_amdgcn_ballot_w64(r.active) != 0) {
         if (r.active) {
@@ -57,7 +88,7 @@ __global__ __launch_bounds__(256, BVH ? AKR_PT_MIN_WAVES_BVH : (FD ? AKR_PT_MIN_
                 trace_pair_exhaustive<TEX>(sc, r.ro, r.rd, r.has_ray ? 1e20f : -1.0f, r.ray_ex0, r.s_o, r.s_d, r.has_shadow ? r.s_tmax : -1.0f,
                                       r.s_ex0, r.s_ex1, hit, found, occluded);
             }
-            path_step<FD ? 1 : 0, TEX, PMJ>(p, r, hit, found, occluded, pix, sx, sy);
+            path_step<FD ? 1 : 0, TEX, PMJ>(q, r, hit, found, occluded, pix, sx, sy);
         }
     }
     flush_counters(p, r, tc.cnt, BVH);
@@ -215,7 +246,7 @@ hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream) {
     if (blocks == 0) return hipSuccess;
     const bool fd = p.force_diffuse != 0, tex = p.sc.tex.nodes != nullptr;
     const bool bvh = p.sc.bvh_nodes != nullptr;
-    const size_t lds = bvh ? kBvhStackDepth * 256 * 4 : 0;
+    const size_t lds = bvh ? kBvhStackDepth * 256 * 4 : p.stage_total;
 #define AKR_LAUNCH2(B, F, T)                                                                                        \
     {                                                                                                               \
         if (p.sampler) hipLaunchKernelGGL((k_pt_pass<B, F, T, true>), dim3(blocks), dim3(256), lds, stream, p);      \
