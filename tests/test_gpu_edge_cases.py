@@ -87,3 +87,43 @@ def test_4k_film_one_pass(ctx, cbox_path):
     assert st["n_samples"] == W * H * 2 and np.all(f[6 * W * H :] == 2.0) and np.all(np.isfinite(f))
     rgb = f[: 3 * W * H].reshape(H, W, 3)
     assert rgb[H // 2 - 100 : H // 2 + 100, W // 2 - 100 : W // 2 + 100].mean() > 0.05  # the box is in the middle of the frame
+
+
+@pytest.mark.parametrize("n_extra", [0, 80], ids=["exhaustive", "bvh"])
+def test_extreme_triangle_scales_hit_like_the_oracle(ctx, n_extra):
+    """Triangles from 1e-18 to 1e+12 units across, some far from the origin: the coefficients of the precomputed transform
+    span 1e-24 .. 1e+36 and the hit point's coordinates overflow for some rays. Hit / miss, triangle and barycentrics must
+    still be the oracle's (the comparison chain of the oracle and the min-margin of the kernels treat inf / NaN alike)."""
+    rng = np.random.default_rng(5)
+    verts, idx = [], []
+    sizes = [1e-18, 1e-12, 1e-6, 1e-3, 1.0, 1e3, 1e6, 1e12] + [1.0] * n_extra
+    for s in sizes:
+        c = rng.normal(size=3) * (1.0 if s < 1e3 else s) + (1e8 if s == 1e-6 else 0.0)
+        a, b = rng.normal(size=3) * s, rng.normal(size=3) * s
+        k = len(verts)
+        verts += [c, c + a, c + b]
+        idx.append([k, k + 1, k + 2])
+    sd = box_scene()
+    sd.meshes[0] = abi.MeshData(vertices=np.array(verts, dtype=np.float32), indices=np.array(idx, dtype=np.uint32))
+    scene = capi.Scene(ctx, sd)
+    assert scene.info().uses_bvh == (1 if n_extra else 0)
+    osc = pyoracle.OracleScene(sd)
+    v32 = np.array(verts, dtype=np.float32).reshape(-1, 3, 3)
+    n = 1536
+    rays = np.zeros((n, 8), dtype=np.float32)
+    for i in range(n):  # aim at a point of a random triangle from a random origin, so that small triangles are hit at all
+        t = v32[rng.integers(0, len(sizes))]
+        w = rng.dirichlet((1, 1, 1)) if i % 3 else np.array([1.0, 0.0, 0.0])  # every third ray through a vertex
+        target = (w[:, None] * t.astype(np.float64)).sum(0)
+        o = target + rng.normal(size=3) * max(1.0, float(np.abs(t).max()) * 1e-3)
+        d = target - o
+        rays[i, :3], rays[i, 3:6], rays[i, 6], rays[i, 7] = o, d / np.linalg.norm(d), 0.0, 1e20
+    hit, bary = capi.probe_intersect(ctx, scene, rays)
+    n_hit = 0
+    for i in range(n):
+        h, inst, prim, b = osc.intersect(rays[i, :3], rays[i, 3:6], 0.0, 1e20)
+        assert bool(hit[i, 0]) == h, (i, rays[i])
+        if h:
+            n_hit += 1
+            assert int(hit[i, 2]) == prim and np.array_equal(bary[i].view(np.uint32), b.view(np.uint32)), (i, rays[i])
+    assert n_hit > n // 4
