@@ -8,7 +8,9 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <new>
 #include <stdexcept>
@@ -1000,8 +1002,10 @@ AKR_API int32_t akr_mcmc_config_default(akr_mcmc_config* c) {  // mcmc::Config::
     c->sampler_type = AKR_SAMPLER_INDEPENDENT; c->sampler_seed = 0;
     return AKR_OK;
 }
-AKR_API int32_t akr_mcmc_render(akr_context* ctx, akr_scene* scene, const akr_mcmc_config* cfg, akr_film* film, akr_mcmc_result* result,
-                                uint32_t* chain_states, akr_pt_stats* stats) {
+// on_pass(spp so far, seconds of rendering so far): called after every pass with the film's splat scale already set for that
+// many samples (reconstruct(film, cnt), mcmc_opt.rs:644-662); used by akr_render_task for --save-intermediate
+static int32_t mcmc_render_impl(akr_context* ctx, akr_scene* scene, const akr_mcmc_config* cfg, akr_film* film, akr_mcmc_result* result,
+                                uint32_t* chain_states, akr_pt_stats* stats, const std::function<void(uint32_t, double)>& on_pass) {
     if (!ctx || !scene || !cfg || !film) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_mcmc_render: NULL argument");
     if (cfg->n_chains == 0 || cfg->n_bootstrap == 0) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_mcmc_render: n_chains and n_bootstrap must be positive");
     if (cfg->spp_per_pass == 0) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_mcmc_render: spp_per_pass must be positive");
@@ -1091,30 +1095,43 @@ AKR_API int32_t akr_mcmc_render(akr_context* ctx, akr_scene* scene, const akr_mc
             const uint64_t per = std::max<uint64_t>(n_mut / n_chains, 1);
             contribution = (float)((double)n_mut / ((double)per * (double)n_chains));
         }
+        // reconstruct(film, spp), mcmc_opt.rs:587-611: normalisation from the bootstrap and the chains' large steps
+        std::vector<MarkovState> states(n_chains);
+        double b = 0.0;
+        uint64_t accepted = 0, mutations = 0;
+        auto reconstruct = [&](uint32_t spp_done) {
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            HIP_CHECK(hipMemcpy(states.data(), d_states.p, n_chains * sizeof(MarkovState), hipMemcpyDeviceToHost));
+            b = sum;
+            uint64_t b_cnt = n_boot;
+            accepted = 0; mutations = 0;
+            for (const MarkovState& st : states) {
+                b += (double)st.b; b_cnt += st.b_cnt; accepted += st.n_accepted; mutations += st.n_mutations;
+            }
+            b = b / (double)b_cnt;
+            film->splat_scale = (float)b / (float)spp_done;
+        };
         uint32_t cnt = 0;
         uint64_t total_mutations = 0;
+        double acc_s = 0.0;
         while (cnt < cfg->spp) {
             const uint32_t cur_pass = std::min(cfg->spp - cnt, cfg->spp_per_pass);
             const uint64_t per = std::max<uint64_t>(npixels * (uint64_t)cur_pass / n_chains, 1);
             if (per > 0xffffffffull) throw std::invalid_argument("Number of mutations per chain exceeds u32::MAX, please reduce spp per pass or increase number of chains");
+            const auto tic = std::chrono::steady_clock::now();
             HIP_CHECK(launch_mcmc_advance(se->params, m, (uint32_t)per, contribution, ctx->stream));
             total_mutations += per * n_chains;
             cnt += cur_pass;
+            if (on_pass) {
+                reconstruct(cnt);
+                acc_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tic).count();
+                on_pass(cnt, acc_s);
+            }
         }
         HIP_CHECK(hipEventRecord(e1, ctx->stream));
         se->events.emplace_back(e0, e1);
         se->n_launches += 2 + (cfg->spp + cfg->spp_per_pass - 1) / cfg->spp_per_pass;
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        // reconstruct, mcmc_opt.rs:587-611
-        std::vector<MarkovState> states(n_chains);
-        HIP_CHECK(hipMemcpy(states.data(), d_states.p, n_chains * sizeof(MarkovState), hipMemcpyDeviceToHost));
-        double b = sum;
-        uint64_t b_cnt = n_boot, accepted = 0, mutations = 0;
-        for (const MarkovState& st : states) {
-            b += (double)st.b; b_cnt += st.b_cnt; accepted += st.n_accepted; mutations += st.n_mutations;
-        }
-        b = b / (double)b_cnt;
-        film->splat_scale = (float)b / (float)cfg->spp;
+        reconstruct(cfg->spp);
         if (result) {
             result->normalization = b; result->acceptance_rate = (double)accepted / (double)mutations; result->splat_scale = film->splat_scale;
             result->contribution = contribution; result->n_mutations = total_mutations; result->sample_dimension = dim; result->_pad = 0;
@@ -1128,6 +1145,11 @@ AKR_API int32_t akr_mcmc_render(akr_context* ctx, akr_scene* scene, const akr_mc
         return rc;
     }
     return rc2;
+}
+
+AKR_API int32_t akr_mcmc_render(akr_context* ctx, akr_scene* scene, const akr_mcmc_config* cfg, akr_film* film, akr_mcmc_result* result,
+                                uint32_t* chain_states, akr_pt_stats* stats) {
+    return mcmc_render_impl(ctx, scene, cfg, film, result, chain_states, stats, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ render driver
@@ -1164,10 +1186,31 @@ AKR_API int32_t akr_render_task(akr_context* ctx, akr_scene* scene, const char* 
                 if (stats_out) *stats_out = st;
                 continue;
             }
-            if (task.is_mcmc) {  // McmcOpt::render: one image at the end (intermediates are not written by this build)
+            if (task.is_mcmc) {  // McmcOpt::render; --save-intermediate / --save-stats as render_loop does (mcmc_opt.rs:640-676)
                 akr_pt_stats st;
                 akr_mcmc_result res;
-                check(akr_mcmc_render(ctx, scene, &task.mcmc, film, &res, nullptr, &st));
+                std::string stats_json = "{\"intermediate\":[";
+                bool first = true;
+                std::function<void(uint32_t, double)> on_pass;
+                if (ses.save_intermediate)
+                    on_pass = [&](uint32_t cnt, double time_s) {
+                        check(akr_film_resolve(film, rgb.data()));
+                        std::string path = name + "-" + std::to_string(cnt) + ".exr";
+                        write_image(path, rgb.data(), w, h);
+                        char buf[512];
+                        std::snprintf(buf, sizeof buf, "%s{\"path\":\"%s\",\"time\":%.9g,\"spp\":%u}", first ? "" : ",", path.c_str(), time_s, cnt);
+                        stats_json += buf;
+                        first = false;
+                    };
+                check(mcmc_render_impl(ctx, scene, &task.mcmc, film, &res, nullptr, &st, on_pass));
+                stats_json += "]}";
+                if (ses.save_stats) {
+                    std::string path = name + ".json";
+                    FILE* f = std::fopen(path.c_str(), "wb");
+                    if (!f) throw std::runtime_error("cannot open '" + path + "' for writing");
+                    std::fwrite(stats_json.data(), 1, stats_json.size(), f);
+                    std::fclose(f);
+                }
                 if (ses.verbose)
                     std::fprintf(stderr, "[akari_hip] Normalization factor: %g\n[akari_hip] Acceptance rate: %.2f%%\n[akari_hip] Rendering finished in %.2fs\n",
                                  res.normalization, res.acceptance_rate * 100.0, st.kernel_ms * 1e-3);

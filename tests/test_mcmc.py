@@ -138,3 +138,12 @@ def test_mcmc_rejections_and_render_task(ctx, cbox_path, tmp_path, monkeypatch):
     film.clear()
     capi.mcmc_render(ctx, scene, mcmc_config(spp=8, n_chains=128, n_bootstrap=2000, direct_spp=4, large_step_prob=0.2), film)
     assert rel_rmse(img, film.resolve()) < 1e-4 and img.mean() > 0.02
+    # --save-intermediate / --save-stats (mcmc_opt.rs:640-676): one image per pass, resolved with b / spp-so-far
+    method["method"]["spp_per_pass"] = 4
+    capi.render_task(ctx, scene, json.dumps(method), name="run", save_intermediate=True, save_stats=True)
+    stats = json.load(open(tmp_path / "run.json"))
+    assert [e["spp"] for e in stats["intermediate"]] == [4, 8] and [e["path"] for e in stats["intermediate"]] == ["run-4.exr", "run-8.exr"]
+    assert stats["intermediate"][1]["time"] >= stats["intermediate"][0]["time"] > 0
+    last, final, half = read_exr_rgb(str(tmp_path / "run-8.exr")), read_exr_rgb(str(tmp_path / "mcmc.exr")), read_exr_rgb(str(tmp_path / "run-4.exr"))
+    assert np.array_equal(last, final) and not np.array_equal(half, final) and abs(half.mean() - final.mean()) < 0.2 * final.mean()
+
