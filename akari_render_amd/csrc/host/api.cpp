@@ -308,17 +308,20 @@ static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pas
         p.pmj_sets = se->ctx->pmj_sets.as<uint32_t>();
         p.bluenoise = se->ctx->bluenoise.as<uint16_t>();
     }
-    {  // LDS staging of a small scene's gather tables (pt_kernels.hip); scenes on the BVH path read them from HBM
+    {  // LDS staging of the tables the shading phase gathers from (pt_kernels.hip: STAGE)
         const CompiledScene& cs = s->cs;
-        const size_t bytes[9] = {cs.shade.size() * 4, cs.normals.size() * 4, cs.inst.size() * 4, cs.materials.size() * sizeof(DMaterial),
+        const bool bvh = !cs.bvh_nodes.empty();
+        // exhaustive path: everything, per-triangle records included (scene_build.cpp guarantees the fit);
+        // BVH path: the per-scene tables only, if they fit beside the traversal stacks
+        const size_t bytes[9] = {bvh ? 0 : cs.shade.size() * 4, bvh ? 0 : cs.normals.size() * 4, cs.inst.size() * 4, cs.materials.size() * sizeof(DMaterial),
                                  (size_t)cs.n_lights * sizeof(AliasPacked), cs.area_entries.size() * sizeof(AliasPacked), (size_t)cs.n_lights * sizeof(LightRec),
                                  cs.light_pdf.size() * 4, cs.area_pdf.size() * 4};
         size_t total = 0;
         for (int i = 0; i < 9; i++) total += (bytes[i] + 15) & ~(size_t)15;
         p.stage_total = 0;
-        if (cs.bvh_nodes.empty() && total <= kStageMaxBytes) {
+        if (total <= (bvh ? kStageMaxBytesBvh : kStageMaxBytes)) {
             for (int i = 0; i < 9; i++) p.stage_bytes[i] = (uint32_t)bytes[i];
-            p.stage_total = (uint32_t)total;
+            p.stage_total = (uint32_t)std::max<size_t>(total, 16);
         }
     }
     p.shard_rank = c.shard_count > 1 ? c.shard_rank : 0;

@@ -88,6 +88,8 @@ void parse_method_json(const std::string& text, akr_pt_config* cfg, std::string*
 // all tasks of a RenderTask file (Single | Multi), lib.rs:103-109; allow_sampler_override: pmj02bn -> independent
 // most LDS a workgroup of the exhaustive path tracer kernels spends on staged scene tables (4 workgroups per CU, 160 KB of LDS)
 constexpr size_t kStageMaxBytes = 32 * 1024;
+// the same for the BVH path, whose workgroups already hold 32 KB of traversal stacks each
+constexpr size_t kStageMaxBytesBvh = 8 * 1024;
 
 struct ParsedTask {
     bool is_aov = false;     // Method::NormalVis instead of Method::PathTracer

@@ -24,24 +24,27 @@ namespace akr {
 #ifndef AKR_PT_MIN_WAVES_FD
 #define AKR_PT_MIN_WAVES_FD 4  // force_diffuse specialisation of the exhaustive kernel
 #endif
-template <bool BVH, bool FD, bool TEX, bool PMJ>
+template <bool BVH, bool FD, bool TEX, bool PMJ, bool STAGE>
 __global__ __launch_bounds__(256, BVH ? AKR_PT_MIN_WAVES_BVH : (FD ? AKR_PT_MIN_WAVES_FD : AKR_PT_MIN_WAVES)) void k_pt_pass(const PtParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: kBvhStackDepth x 256 words; else: staged tables
     TraceCtx tc;
     tc.stack = lds_stack + threadIdx.x;
     tc.cnt = TraceCounters{0, 0, 0};
-    // Exhaustive path = small scene: the tables the shading phase gathers from (shading records, instance transforms,
-    // materials, light tables: ~11 KB for the cbox) are copied to LDS once per workgroup -- a workgroup lives for the whole
+    // STAGE: the tables the shading phase gathers from are copied to LDS once per workgroup -- a workgroup lives for the whole
     // launch, 16 passes x 64 spp -- and the kernel works on a parameter block whose pointers aim at the copies. The shading
-    // phase is a chain of dependent gathers; from LDS each link costs ~1/3 of an L1 hit through the texture path.
+    // phase is a chain of dependent gathers; from LDS each link costs a fraction of an L1 hit through the texture path, let
+    // alone of an L2 / HBM round trip. Exhaustive path (small scene, always staged; the host sends a scene down this path
+    // only if everything fits, scene_build.cpp): shading records, normals, instance transforms, materials, light tables --
+    // 11.5 KB for the cbox. BVH path: instance transforms, materials and light tables when they fit beside the traversal
+    // stacks (the per-triangle records stay in HBM); otherwise the unstaged variant of the kernel runs.
     PtParams staged = p;
-    if (!BVH) {  // (the host sends a scene down the exhaustive path only if its tables fit, scene_build.cpp)
+    if (STAGE) {
         const void* src[9] = {p.sc.shade,      p.sc.normals, p.sc.inst,      p.sc.materials, p.sc.light_alias,
                               p.sc.area_alias, p.sc.lights,  p.sc.light_pdf, p.sc.area_pdf};
         uint32_t* dst[9];
-        uint32_t off = 0;
+        uint32_t off = BVH ? kBvhStackDepth * 256u : 0u;  // in words, behind the stacks
 #pragma unroll
-        for (int e = 0; e < 9; e++) {
+        for (int e = BVH ? 2 : 0; e < 9; e++) {
             const uint32_t n = p.stage_bytes[e] >> 2;
             const uint32_t* g = (const uint32_t*)src[e];
             uint32_t* l = lds_stack + off;
@@ -50,8 +53,10 @@ __global__ __launch_bounds__(256, BVH ? AKR_PT_MIN_WAVES_BVH : (FD ? AKR_PT_MIN_
             off += ((p.stage_bytes[e] + 15u) & ~15u) >> 2;
         }
         __syncthreads();
-        staged.sc.shade = (const float4*)dst[0];
-        staged.sc.normals = (const float4*)dst[1];  // non-null even without normals: only gates reading the flags in shade row 7
+        if (!BVH) {
+            staged.sc.shade = (const float4*)dst[0];
+            staged.sc.normals = (const float4*)dst[1];  // non-null even without normals: only gates reading the flags in shade row 7
+        }
         staged.sc.inst = (const float4*)dst[2];
         staged.sc.materials = (const DMaterial*)dst[3];
         staged.sc.light_alias = (const AliasPacked*)dst[4];
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(256, BVH ? AKR_PT_MIN_WAVES_BVH : (FD ? AKR_PT_MIN_
         staged.sc.light_pdf = (const float*)dst[7];
         staged.sc.area_pdf = (const float*)dst[8];
     }
-    const PtParams& q = (!BVH) ? staged : p;
+    const PtParams& q = STAGE ? staged : p;
     const DScene& sc = q.sc;
     const uint32_t item = blockIdx.x * 256u + threadIdx.x;
     uint32_t px = 0, py = 0;
@@ -246,13 +251,17 @@ hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream) {
     if (blocks == 0) return hipSuccess;
     const bool fd = p.force_diffuse != 0, tex = p.sc.tex.nodes != nullptr;
     const bool bvh = p.sc.bvh_nodes != nullptr;
-    const size_t lds = bvh ? kBvhStackDepth * 256 * 4 : p.stage_total;
-#define AKR_LAUNCH2(B, F, T)                                                                                        \
-    {                                                                                                               \
-        if (p.sampler) hipLaunchKernelGGL((k_pt_pass<B, F, T, true>), dim3(blocks), dim3(256), lds, stream, p);      \
-        else hipLaunchKernelGGL((k_pt_pass<B, F, T, false>), dim3(blocks), dim3(256), lds, stream, p);              \
+    const size_t lds = (bvh ? kBvhStackDepth * 256 * 4 : 0) + p.stage_total;
+    const bool stage = p.stage_total != 0;
+#define AKR_LAUNCH2(B, F, T, S)                                                                                        \
+    {                                                                                                                  \
+        if (p.sampler) hipLaunchKernelGGL((k_pt_pass<B, F, T, true, S>), dim3(blocks), dim3(256), lds, stream, p);      \
+        else hipLaunchKernelGGL((k_pt_pass<B, F, T, false, S>), dim3(blocks), dim3(256), lds, stream, p);              \
     }
-#define AKR_LAUNCH(B, F, T) AKR_LAUNCH2(B, F, T)
+#define AKR_LAUNCH(B, F, T)                                                  \
+    {                                                                        \
+        if (!B || stage) AKR_LAUNCH2(B, F, T, true) else AKR_LAUNCH2(B, F, T, !B) \
+    }
     if (bvh) {
         if (tex) { if (fd) AKR_LAUNCH(true, true, true) else AKR_LAUNCH(true, false, true) }
         else { if (fd) AKR_LAUNCH(true, true, false) else AKR_LAUNCH(true, false, false) }
