@@ -31,7 +31,7 @@ def _headers():
 
 # -ffp-contract=off + correctly rounded div/sqrt: the arithmetic contract of DESIGN.md ("AKR-F32")
 FLAGS = [
-    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
     "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
     # packed-f32 SLP vectorisation costs s_mov shuffles of the SGPR triangle records (-5 % on the bench)
     "-fno-slp-vectorize",
@@ -66,20 +66,48 @@ def build_cli(verbose: bool = False) -> str:
     return CLI
 
 
+OBJ = os.path.join(HERE, "build", "obj")  # git-ignored; objects are rebuilt per source file, in parallel
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         build_cli(verbose)
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
+
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = os.environ.get("AKR_EXTRA_HIPCC_FLAGS", "").split()
-    cmd = [hipcc] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-I", CSRC, "-o", LIB]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
+    os.makedirs(OBJ, exist_ok=True)
+    tag = os.path.join(OBJ, "flags.txt")  # objects built with other flags are stale
+    flags_now = " ".join(FLAGS + extra)
+    if force or not os.path.exists(tag) or open(tag).read() != flags_now:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    newest_header = max([os.path.getmtime(os.path.normpath(os.path.join(CSRC, h))) for h in _headers()] + [os.path.getmtime(os.path.abspath(__file__))])
+
+    def compile_one(src: str):
+        obj = os.path.join(OBJ, src.replace("/", "_") + ".o")
+        path = os.path.join(CSRC, src)
+        if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), newest_header):
+            return obj, 0, ""
+        cmd = [hipcc] + FLAGS + extra + ["-c", path, "-I", CSRC, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        return obj, res.returncode, res.stdout
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        results = list(ex.map(compile_one, SOURCES))
+    log = "".join(out for _, _, out in results)
+    if any(rc != 0 for _, rc, _ in results):
+        raise RuntimeError("hipcc failed:\n" + log)
+    open(tag, "w").write(flags_now)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [o for o, _, _ in results] + ["-o", LIB]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout)
-    if verbose and res.stdout.strip():
-        print(res.stdout, file=sys.stderr)
+        raise RuntimeError("hipcc (link) failed:\n" + log + res.stdout)
+    if verbose and (log + res.stdout).strip():
+        print(log + res.stdout, file=sys.stderr)
     build_cli(verbose)
     return LIB
 
