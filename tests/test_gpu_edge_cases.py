@@ -127,3 +127,23 @@ def test_extreme_triangle_scales_hit_like_the_oracle(ctx, n_extra):
             n_hit += 1
             assert int(hit[i, 2]) == prim and np.array_equal(bary[i].view(np.uint32), b.view(np.uint32)), (i, rays[i])
     assert n_hit > n // 4
+
+
+def test_small_mesh_with_a_long_material_list_takes_the_bvh_path(ctx):
+    """The exhaustive kernels stage a small scene's tables in LDS; a 12-triangle box with 300 materials (75 KB of records) does
+    not fit and is rendered through the BVH instead -- same film."""
+    import copy
+
+    sd = box_scene(albedo=0.5, emission=0.8, width=24, height=24)
+    assert capi.Scene(ctx, sd).info().uses_bvh == 0
+    for k in range(299):
+        m = copy.deepcopy(sd.materials[0])
+        m.base_color = (0.2 + 0.002 * k, 0.5, 0.7 - 0.002 * k)
+        sd.materials.append(m)
+    mesh = sd.meshes[0]
+    mesh.material_slots = (np.arange(12, dtype=np.uint32) * 23) % 300
+    sd.instances[0].materials = list(range(300))
+    scene = capi.Scene(ctx, sd)
+    assert scene.info().uses_bvh == 1
+    g, o, gst, ost, _, _ = render_both(ctx, sd, make_config(spp=8, max_depth=6))
+    assert_parity(g, o, 24, 24, gst, ost)
