@@ -8,7 +8,9 @@
  *   akari_render/src/scene.rs:49-185, mesh.rs:426-654, camera/mod.rs:70-180, film.rs:32-49,196-229,
  *   sampler/mod.rs:73-217,299-328, light/mod.rs:100-147, light/area.rs:36-130, sampling.rs,
  *   util/distribution.rs:35-88, load.rs:308-444, svm/surface/{mod,diffuse,principled,glass}.rs,
- *   microfacet.rs (see or_bsdf.h).
+ *   microfacet.rs (see or_bsdf.h); further down, each with its own citation block: svm/eval.rs + image sampling (or_tex.h),
+ *   akari_integrator/src/aov.rs, gpt.rs (+ the shift-mapping branches of pt.rs:329-900), mcmc_opt.rs (+ mcmc.rs,
+ *   sampler/mcmc.rs, util/distribution.rs:92-115), sampler/mod.rs:329-700 (pmj02bn; the two tables are handed in by the tests).
  *
  * Parity status: the reference cannot be built or run here (no Rust toolchain; LuisaCompute is an
  * un-vendored path dependency) and its tests hold no numeric fixtures for this path, so
