@@ -8,8 +8,11 @@ namespace akr {
 enum : uint32_t { AOV_NS = 0, AOV_NG = 1, AOV_TANGENT = 2, AOV_BITANGENT = 3, AOV_ALBEDO = 4, AOV_ROUGHNESS = 5 };
 
 template <bool BVH, bool TEX, bool PMJ>
-__global__ __launch_bounds__(256) void k_aov(const PtParams p, uint32_t spp, uint32_t aov, uint32_t remap) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+__global__ __launch_bounds__(256) void k_aov(const PtParams p_in, uint32_t spp, uint32_t aov, uint32_t remap) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: traversal stacks; else: the staged scene tables
+    PtParams staged = p_in;
+    if (!BVH) stage_scene_tables<false>(p_in, lds_stack, staged);
+    const PtParams& p = BVH ? p_in : staged;
     TraceCtx tc;
     tc.stack = lds_stack + threadIdx.x;
     tc.cnt = TraceCounters{0, 0, 0};
@@ -85,7 +88,7 @@ hipError_t launch_aov(const PtParams& p, uint32_t spp, uint32_t aov, uint32_t re
     uint32_t blocks = (p.n_items + 255u) / 256u;
     if (blocks == 0) return hipSuccess;
     const bool bvh = p.sc.bvh_nodes != nullptr, tex = p.sc.tex.nodes != nullptr;
-    const size_t lds = bvh ? kBvhStackDepth * 256 * 4 : 0;
+    const size_t lds = bvh ? kBvhStackDepth * 256 * 4 : p.stage_total;
 #define AKR_AOV(B, T)                                                                                                  \
     {                                                                                                                \
         if (p.sampler) hipLaunchKernelGGL((k_aov<B, T, true>), dim3(blocks), dim3(256), lds, stream, p, spp, aov, remap); \

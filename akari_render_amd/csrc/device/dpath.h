@@ -250,6 +250,42 @@ AKR_D float pdf_direct(const DScene& sc, const SurfacePoint& si, uint32_t gid, v
     return light_choice_pdf * pdf;
 }
 
+// The tables the shading phase gathers from, copied to LDS once per workgroup; `staged` (a copy of `p`) gets pointers to the
+// copies. The shading phase is a chain of dependent gathers; from LDS each link costs a fraction of an L1 hit through the
+// texture path, let alone of an L2 / HBM round trip, and a workgroup of the path tracer lives for a whole launch (16 passes x
+// 64 spp). Exhaustive path (BVH = false: small scene; the host sends a scene down this path only if everything fits,
+// scene_build.cpp): shading records, normals, instance transforms, materials, light tables -- 11.5 KB for the cbox.
+// BVH path: instance transforms, materials and light tables, behind the traversal stacks, when the host found that they fit
+// (PtParams.stage_total != 0); the per-triangle records stay in HBM. Must be called by every thread of the workgroup.
+template <bool BVH>
+AKR_D void stage_scene_tables(const PtParams& p, uint32_t* lds, PtParams& staged) {
+    const void* src[9] = {p.sc.shade,      p.sc.normals, p.sc.inst,      p.sc.materials, p.sc.light_alias,
+                          p.sc.area_alias, p.sc.lights,  p.sc.light_pdf, p.sc.area_pdf};
+    uint32_t* dst[9];
+    uint32_t off = BVH ? kBvhStackDepth * 256u : 0u;  // in words, behind the stacks
+#pragma unroll
+    for (int e = BVH ? 2 : 0; e < 9; e++) {
+        const uint32_t n = p.stage_bytes[e] >> 2;
+        const uint32_t* g = (const uint32_t*)src[e];
+        uint32_t* l = lds + off;
+        for (uint32_t i = threadIdx.x; i < n; i += 256u) l[i] = g[i];
+        dst[e] = l;  // unconditionally an LDS address: the compiler then reads the tables with ds_read, not flat loads
+        off += ((p.stage_bytes[e] + 15u) & ~15u) >> 2;
+    }
+    __syncthreads();
+    if (!BVH) {
+        staged.sc.shade = (const float4*)dst[0];
+        staged.sc.normals = (const float4*)dst[1];  // non-null even without normals: only gates reading the flags in shade row 7
+    }
+    staged.sc.inst = (const float4*)dst[2];
+    staged.sc.materials = (const DMaterial*)dst[3];
+    staged.sc.light_alias = (const AliasPacked*)dst[4];
+    staged.sc.area_alias = (const AliasPacked*)dst[5];
+    staged.sc.lights = (const LightRec*)dst[6];
+    staged.sc.light_pdf = (const float*)dst[7];
+    staged.sc.area_pdf = (const float*)dst[8];
+}
+
 // Per-thread intersection context: the LDS stack slot of this lane and the traversal counters.
 struct TraceCtx {
     uint32_t* stack;

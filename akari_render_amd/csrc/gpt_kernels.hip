@@ -26,8 +26,11 @@ AKR_D void gpt_shifted(const GptParams& g, uint32_t W, uint32_t H, uint32_t x, u
 // 2 waves 810, 4 waves (128 VGPRs, 330 spilled) 630. Running a lane's five paths through one flattened loop (a finished
 // path starts the next one while the neighbours still bounce) was slower than the nested loops: 716 at 2 waves.
 template <bool BVH, bool TEX>
-__global__ __launch_bounds__(256, 2) void k_gpt_sample(const PtParams p, const GptParams g) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+__global__ __launch_bounds__(256, 2) void k_gpt_sample(const PtParams p_in, const GptParams g) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: traversal stacks; else: the staged scene tables
+    PtParams staged = p_in;
+    if (!BVH) stage_scene_tables<false>(p_in, lds_stack, staged);
+    const PtParams& p = BVH ? p_in : staged;
     TraceCtx tc;
     tc.stack = lds_stack + threadIdx.x;
     tc.cnt = TraceCounters{0, 0, 0};
@@ -226,7 +229,7 @@ hipError_t launch_gpt_sample(const PtParams& p, const GptParams& g, hipStream_t 
     uint32_t blocks = (p.n_items + 255u) / 256u;
     if (blocks == 0) return hipSuccess;
     const bool bvh = p.sc.bvh_nodes != nullptr, tex = p.sc.tex.nodes != nullptr;
-    const size_t lds = bvh ? kBvhStackDepth * 256 * 4 : 0;
+    const size_t lds = bvh ? kBvhStackDepth * 256 * 4 : p.stage_total;
     if (bvh) {
         if (tex) hipLaunchKernelGGL((k_gpt_sample<true, true>), dim3(blocks), dim3(256), lds, stream, p, g);
         else hipLaunchKernelGGL((k_gpt_sample<true, false>), dim3(blocks), dim3(256), lds, stream, p, g);

@@ -134,8 +134,11 @@ AKR_D McmcEval mcmc_evaluate(const PtParams& p, TraceCtx& tc, McmcSampler& s, ui
 
 // bootstrap (mcmc_opt.rs:331-349): the contribution of n_bootstrap independent paths
 template <bool BVH, bool TEX>
-__global__ __launch_bounds__(256, 2) void k_mcmc_bootstrap(const PtParams p, const McmcParams m) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+__global__ __launch_bounds__(256, 2) void k_mcmc_bootstrap(const PtParams p_in, const McmcParams m) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: traversal stacks; else: the staged scene tables
+    PtParams staged = p_in;
+    if (!BVH) stage_scene_tables<false>(p_in, lds_stack, staged);
+    const PtParams& p = BVH ? p_in : staged;
     TraceCtx tc;
     tc.stack = lds_stack + threadIdx.x;
     tc.cnt = TraceCounters{0, 0, 0};
@@ -150,8 +153,11 @@ __global__ __launch_bounds__(256, 2) void k_mcmc_bootstrap(const PtParams p, con
 }
 // the chains' initial states (mcmc_opt.rs:356-386): chain i starts from bootstrap path resampled[i]
 template <bool BVH, bool TEX>
-__global__ __launch_bounds__(256, 2) void k_mcmc_init(const PtParams p, const McmcParams m) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+__global__ __launch_bounds__(256, 2) void k_mcmc_init(const PtParams p_in, const McmcParams m) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: traversal stacks; else: the staged scene tables
+    PtParams staged = p_in;
+    if (!BVH) stage_scene_tables<false>(p_in, lds_stack, staged);
+    const PtParams& p = BVH ? p_in : staged;
     TraceCtx tc;
     tc.stack = lds_stack + threadIdx.x;
     tc.cnt = TraceCounters{0, 0, 0};
@@ -169,8 +175,11 @@ __global__ __launch_bounds__(256, 2) void k_mcmc_init(const PtParams p, const Mc
 }
 // advance_chain + mutate_chain (mcmc_opt.rs:409-552)
 template <bool BVH, bool TEX>
-__global__ __launch_bounds__(256, 2) void k_mcmc_advance(const PtParams p, const McmcParams m, uint32_t mutations_per_chain, float contribution) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+__global__ __launch_bounds__(256, 2) void k_mcmc_advance(const PtParams p_in, const McmcParams m, uint32_t mutations_per_chain, float contribution) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: traversal stacks; else: the staged scene tables
+    PtParams staged = p_in;
+    if (!BVH) stage_scene_tables<false>(p_in, lds_stack, staged);
+    const PtParams& p = BVH ? p_in : staged;
     TraceCtx tc;
     tc.stack = lds_stack + threadIdx.x;
     tc.cnt = TraceCounters{0, 0, 0};
@@ -262,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void k_mcmc_advance(const PtParams p, const
         uint32_t blocks = ((COUNT) + 255u) / 256u;                                                                \
         if (blocks == 0) return hipSuccess;                                                                       \
         const bool bvh = p.sc.bvh_nodes != nullptr, tex = p.sc.tex.nodes != nullptr;                              \
-        const size_t lds = bvh ? kBvhStackDepth * 256 * 4 : 0;                                                    \
+        const size_t lds = bvh ? kBvhStackDepth * 256 * 4 : p.stage_total;                                        \
         if (bvh) {                                                                                                \
             if (tex) hipLaunchKernelGGL((KERNEL<true, true>), dim3(blocks), dim3(256), lds, stream, __VA_ARGS__);   \
             else hipLaunchKernelGGL((KERNEL<true, false>), dim3(blocks), dim3(256), lds, stream, __VA_ARGS__);      \

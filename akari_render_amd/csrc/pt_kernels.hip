@@ -30,41 +30,9 @@ __global__ __launch_bounds__(256, BVH ? AKR_PT_MIN_WAVES_BVH : (FD ? AKR_PT_MIN_
     TraceCtx tc;
     tc.stack = lds_stack + threadIdx.x;
     tc.cnt = TraceCounters{0, 0, 0};
-    // STAGE: the tables the shading phase gathers from are copied to LDS once per workgroup -- a workgroup lives for the whole
-    // launch, 16 passes x 64 spp -- and the kernel works on a parameter block whose pointers aim at the copies. The shading
-    // phase is a chain of dependent gathers; from LDS each link costs a fraction of an L1 hit through the texture path, let
-    // alone of an L2 / HBM round trip. Exhaustive path (small scene, always staged; the host sends a scene down this path
-    // only if everything fits, scene_build.cpp): shading records, normals, instance transforms, materials, light tables --
-    // 11.5 KB for the cbox. BVH path: instance transforms, materials and light tables when they fit beside the traversal
-    // stacks (the per-triangle records stay in HBM); otherwise the unstaged variant of the kernel runs.
+    // STAGE: the kernel works on a parameter block whose table pointers aim at LDS copies (stage_scene_tables, dpath.h)
     PtParams staged = p;
-    if (STAGE) {
-        const void* src[9] = {p.sc.shade,      p.sc.normals, p.sc.inst,      p.sc.materials, p.sc.light_alias,
-                              p.sc.area_alias, p.sc.lights,  p.sc.light_pdf, p.sc.area_pdf};
-        uint32_t* dst[9];
-        uint32_t off = BVH ? kBvhStackDepth * 256u : 0u;  // in words, behind the stacks
-#pragma unroll
-        for (int e = BVH ? 2 : 0; e < 9; e++) {
-            const uint32_t n = p.stage_bytes[e] >> 2;
-            const uint32_t* g = (const uint32_t*)src[e];
-            uint32_t* l = lds_stack + off;
-            for (uint32_t i = threadIdx.x; i < n; i += 256u) l[i] = g[i];
-            dst[e] = l;  // unconditionally an LDS address: the compiler then reads the tables with ds_read, not flat loads
-            off += ((p.stage_bytes[e] + 15u) & ~15u) >> 2;
-        }
-        __syncthreads();
-        if (!BVH) {
-            staged.sc.shade = (const float4*)dst[0];
-            staged.sc.normals = (const float4*)dst[1];  // non-null even without normals: only gates reading the flags in shade row 7
-        }
-        staged.sc.inst = (const float4*)dst[2];
-        staged.sc.materials = (const DMaterial*)dst[3];
-        staged.sc.light_alias = (const AliasPacked*)dst[4];
-        staged.sc.area_alias = (const AliasPacked*)dst[5];
-        staged.sc.lights = (const LightRec*)dst[6];
-        staged.sc.light_pdf = (const float*)dst[7];
-        staged.sc.area_pdf = (const float*)dst[8];
-    }
+    if (STAGE) stage_scene_tables<BVH>(p, lds_stack, staged);
     const PtParams& q = STAGE ? staged : p;
     const DScene& sc = q.sc;
     const uint32_t item = blockIdx.x * 256u + threadIdx.x;
