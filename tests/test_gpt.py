@@ -168,3 +168,33 @@ def test_gpt_rejections_and_render_task(ctx, cbox_path, tmp_path, monkeypatch):
     method["sampler"] = {"type": "pmj02bn", "seed": 0}
     with pytest.raises(capi.AkariError):
         capi.render_task(ctx, scene, json.dumps(method))
+
+
+@pytest.mark.gpu
+def test_gpt_and_mcmc_at_1080p_agree_with_the_path_tracer(ctx, cbox_path, root):
+    """Full frame size (BASELINE configs' 1920x1080), through a size-independent property: the three estimators agree on the
+    image's mean radiance per channel, and gpt's splat bookkeeping conserves it (sum over the frame of the MIS-combined
+    contributions = sum of the base paths' radiance in expectation)."""
+    from tests.test_mcmc import mcmc_config
+
+    w, h = 1920, 1080
+    sd = scene_json.load_scene(cbox_path, w, h)
+    sd.ggx_table = table(root)
+    scene = capi.Scene(ctx, sd)
+    film = capi.Film(ctx, w, h)
+    pc = abi.PtConfig.default()
+    pc.spp, pc.spp_per_pass, pc.max_depth = 16, 16, 7
+    capi.pt_render(ctx, scene, pc, film)
+    ref = film.resolve().reshape(-1, 3).astype(np.float64).mean(0)
+    film.clear()
+    capi.gpt_render(ctx, scene, gpt_config(spp=4), film)
+    img = film.resolve()
+    assert np.all(np.isfinite(img)) and film.splat_scale == 0.25
+    g = img.reshape(-1, 3).astype(np.float64).mean(0)
+    assert np.all(np.abs(g - ref) < 0.02 * ref), (g, ref)
+    film.clear()
+    film.splat_scale = 1.0
+    st, res, chains = capi.mcmc_render(ctx, scene, mcmc_config(spp=8, n_chains=262144, n_bootstrap=100000, direct_spp=8), film)
+    m = film.resolve().reshape(-1, 3).astype(np.float64).mean(0)
+    assert res["n_mutations"] >= w * h * 8 - 262144 and 0.5 < res["acceptance_rate"] < 0.99
+    assert np.all(np.abs(m - ref) < 0.04 * ref), (m, ref)
