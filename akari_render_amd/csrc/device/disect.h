@@ -17,20 +17,33 @@ struct Hit {
 
 // Triangle test in Woop's precomputed-transform form. (r0|c0), (r1|c1), (r2|c2) map world space to the space in
 // which the triangle is (0,0,0),(1,0,0),(0,1,0); 27 flops + one division, no cross products at run time.
-AKR_HD bool tri_test(vec3 o, vec3 d, float4 r0, float4 r1, float4 r2, float tmin, float tmax, float& t_out, float& u_out,
-                     float& v_out) {
+struct PlaneHit {  // the plane solve: t and the hit point from the third row
+    float t, px, py, pz;
+};
+AKR_HD PlaneHit tri_plane(vec3 o, vec3 d, float4 r2) {
     float dz = __builtin_fmaf(r2.x, d.x, __builtin_fmaf(r2.y, d.y, r2.z * d.z));
     float oz = __builtin_fmaf(r2.x, o.x, __builtin_fmaf(r2.y, o.y, __builtin_fmaf(r2.z, o.z, r2.w)));
-    float t = -oz / dz;
-    // the hit point, then its two affine coordinates in the triangle's frame
-    float px = __builtin_fmaf(t, d.x, o.x), py = __builtin_fmaf(t, d.y, o.y), pz = __builtin_fmaf(t, d.z, o.z);
-    float u = __builtin_fmaf(r0.x, px, __builtin_fmaf(r0.y, py, __builtin_fmaf(r0.z, pz, r0.w)));
-    float v = __builtin_fmaf(r1.x, px, __builtin_fmaf(r1.y, py, __builtin_fmaf(r1.z, pz, r1.w)));
-    bool hit = (t >= tmin) & (t <= tmax) & (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f);
-    t_out = t;
+    PlaneHit h;
+    h.t = -oz / dz;
+    h.px = __builtin_fmaf(h.t, d.x, o.x);
+    h.py = __builtin_fmaf(h.t, d.y, o.y);
+    h.pz = __builtin_fmaf(h.t, d.z, o.z);
+    return h;
+}
+// the inside test: the two affine coordinates of the hit point in the triangle's frame, from the first two rows
+AKR_HD void tri_uv(const PlaneHit& h, float4 r0, float4 r1, float& u, float& v) {
+    u = __builtin_fmaf(r0.x, h.px, __builtin_fmaf(r0.y, h.py, __builtin_fmaf(r0.z, h.pz, r0.w)));
+    v = __builtin_fmaf(r1.x, h.px, __builtin_fmaf(r1.y, h.py, __builtin_fmaf(r1.z, h.pz, r1.w)));
+}
+AKR_HD bool tri_test(vec3 o, vec3 d, float4 r0, float4 r1, float4 r2, float tmin, float tmax, float& t_out, float& u_out,
+                     float& v_out) {
+    PlaneHit h = tri_plane(o, d, r2);
+    float u, v;
+    tri_uv(h, r0, r1, u, v);
+    t_out = h.t;
     u_out = u;
     v_out = v;
-    return hit;
+    return (h.t >= tmin) & (h.t <= tmax) & (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f);
 }
 
 // SvmEvalMode::Alpha for a texture-fed base colour (principled.rs:15-21): the graph at the candidate's uv
@@ -97,11 +110,14 @@ AKR_D bool trace_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmin, float 
     // latency overlaps the ~40 VALU instructions of the test (the buffer is padded by one record, scene_build.cpp)
     float4 n0, n1, n2;
     load_rec(0, n0, n1, n2);
+    PlaneHit ph{0.0f, 0.0f, 0.0f, 0.0f};
     for (uint32_t k = 0; k < n; k++) {
         const float4 r0 = n0, r1 = n1, r2 = n2;
         load_rec(k + 1, n0, n1, n2);
-        float t, u, v;
-        tri_test(o, d, r0, r1, r2, tmin, tmax, t, u, v);
+        if (!((sc.plane_share_mask >> k) & 1ull)) ph = tri_plane(o, d, r2);  // wave-uniform: one solve per coplanar pair of records
+        float u, v;
+        const float t = ph.t;
+        tri_uv(ph, r0, r1, u, v);
         float m = __builtin_fminf(hit_margin(t, u, v, tmax), t - tmin);
         m = (k == ex0) ? -1.0f : m;
         m = (k == ex1) ? -1.0f : m;
@@ -153,12 +169,18 @@ AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, u
     };
     float4 n0, n1, n2;
     load_rec(0, n0, n1, n2);
+    PlaneHit ph{0.0f, 0.0f, 0.0f, 0.0f}, sph{0.0f, 0.0f, 0.0f, 0.0f};
     for (uint32_t k = 0; k < n; k++) {
         const float4 r0 = n0, r1 = n1, r2 = n2;
         load_rec(k + 1, n0, n1, n2);  // prefetch (buffer padded by one record)
-        float t, u, v, st, su, sv;
-        tri_test(o, d, r0, r1, r2, 0.0f, tmax, t, u, v);
-        tri_test(so, sd, r0, r1, r2, 0.0f, stmax, st, su, sv);
+        if (!((sc.plane_share_mask >> k) & 1ull)) {  // wave-uniform: one plane solve per ray per coplanar pair of records
+            ph = tri_plane(o, d, r2);
+            sph = tri_plane(so, sd, r2);
+        }
+        float u, v, su, sv;
+        const float t = ph.t, st = sph.t;
+        tri_uv(ph, r0, r1, u, v);
+        tri_uv(sph, r0, r1, su, sv);
         float m = hit_margin(t, u, v, tmax), sm = hit_margin(st, su, sv, stmax);
         m = (k == ex0) ? -1.0f : m;
         sm = (k == sex0) ? -1.0f : sm;

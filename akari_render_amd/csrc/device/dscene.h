@@ -49,6 +49,7 @@ struct DScene {
     const LightRec* __restrict__ lights;            // light_tri_offset + light_n_tris + light_inst (+ inst_tri_offset), packed
     const float4* __restrict__ bvh_nodes;           // nullptr on the exhaustive path
     uint32_t n_tris, n_lights, n_nodes, has_alpha;
+    uint64_t plane_share_mask;                      // exhaustive path: bit k = record k carries the plane row of record k-1
     TexScene tex;                                   // textures + shader-graph node lists (all nullptr without textures)
 };
 

@@ -257,6 +257,10 @@ static void scene_finish(akr_scene* s) {
     d.n_lights = cs.n_lights;
     d.n_nodes = (uint32_t)(cs.bvh_nodes.size() / 16);
     d.has_alpha = cs.has_alpha ? 1u : 0u;
+    d.plane_share_mask = 0;
+    if (cs.bvh_nodes.empty())  // exhaustive path (<= 64 triangles): which records repeat their predecessor's plane row
+        for (uint32_t k = 1; k < d.n_tris && k < 64; k++)
+            if (std::memcmp(&cs.woop[12ull * k + 8], &cs.woop[12ull * (k - 1) + 8], 16) == 0) d.plane_share_mask |= 1ull << k;
     if (cs.has_textures) {
         d.tex.nodes = s->tex_nodes.as<DNode>();
         d.tex.images = s->tex_images.as<DImage>();

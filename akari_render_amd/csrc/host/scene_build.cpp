@@ -364,6 +364,24 @@ static void woop_precompute(vec3 A, vec3 B, vec3 C, float* w) {
     w[8] = (float)r2x; w[9] = (float)r2y; w[10] = (float)r2z; w[11] = (float)(-(r2x * ax + r2y * ay + r2z * az));
 }
 
+// Coplanar neighbours share a plane row: triangles 2j and 2j+1 of an instance -- the two halves of a quad in every mesh an
+// exporter triangulated -- get the SAME third row (plane equation) when the second one's vertices lie in the first one's
+// plane to within 1e-6 of the triangle's size: the second record's row is overwritten with the first's. Every intersector
+// then computes bit-identical t and hit point for the two (same ray, same row), which the exhaustive pair walk uses to
+// solve the plane once per quad (disect.h). A data-level definition: the oracle applies the same rule when it builds its
+// scene (oracle/akr_oracle.c: or_share_plane_row); nothing in either tracer depends on it.
+static void share_plane_row(const float* wa, float* wb, const vec3 vb[3]) {
+    const double rx = wa[8], ry = wa[9], rz = wa[10], c = wa[11];
+    const double len = std::sqrt(rx * rx + ry * ry + rz * rz);  // = 1 / |n| = 1 / (2 area)
+    if (!(len > 0.0) || (wb[8] == 0.0f && wb[9] == 0.0f && wb[10] == 0.0f)) return;  // a degenerate triangle on either side
+    const double tol = 1e-6 * std::sqrt(len);  // height / sqrt(|n|) <= 1e-6
+    for (int i = 0; i < 3; i++) {
+        const double s = ((rx * (double)vb[i].x + ry * (double)vb[i].y) + rz * (double)vb[i].z) + c;
+        if (!(std::fabs(s) <= tol)) return;
+    }
+    wb[8] = wa[8]; wb[9] = wa[9]; wb[10] = wa[10]; wb[11] = wa[11];
+}
+
 void build_bvh4(const std::vector<float>& tri_bounds, uint32_t n_tris, float pad, std::vector<uint32_t>& order, std::vector<float>& nodes);
 
 void compile_scene(const FlatScene& flat, CompiledScene& out) {
@@ -505,6 +523,10 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
             // world-space triangle for the intersector
             vec3 A = xf_point(x.c0, x.c1, x.c2, x.t, v0), B = xf_point(x.c0, x.c1, x.c2, x.t, v1), C = xf_point(x.c0, x.c1, x.c2, x.t, v2);
             woop_precompute(A, B, C, &out.woop[12ull * gid]);
+            if (prim & 1u) {
+                const vec3 vb[3] = {A, B, C};
+                share_plane_row(&out.woop[12ull * (gid - 1)], &out.woop[12ull * gid], vb);
+            }
             float* bb = &bounds[6ull * gid];
             bb[0] = min_f(min_f(A.x, B.x), C.x); bb[1] = min_f(min_f(A.y, B.y), C.y); bb[2] = min_f(min_f(A.z, B.z), C.z);
             bb[3] = max_f(max_f(A.x, B.x), C.x); bb[4] = max_f(max_f(A.y, B.y), C.y); bb[5] = max_f(max_f(A.z, B.z), C.z);

@@ -212,6 +212,21 @@ static void or_woop_precompute(v3 A, v3 B, v3 C, float *w) {
     w[4] = (float)r1x; w[5] = (float)r1y; w[6] = (float)r1z; w[7] = (float)(-(r1x * ax + r1y * ay + r1z * az));
     w[8] = (float)r2x; w[9] = (float)r2y; w[10] = (float)r2z; w[11] = (float)(-(r2x * ax + r2y * ay + r2z * az));
 }
+/* Coplanar neighbours share a plane row: triangles 2j and 2j+1 of an instance get the same third row when the second one's
+ * vertices lie in the first one's plane to within 1e-6 of the triangle's size (the same rule, stated independently, as
+ * akari_render_amd/csrc/host/scene_build.cpp: share_plane_row). Pure data: the tracer below does not know about it. */
+static void or_share_plane_row(const float *wa, float *wb, v3 a, v3 b, v3 c) {
+    const double rx = wa[8], ry = wa[9], rz = wa[10], cc = wa[11];
+    const double len = sqrt(rx * rx + ry * ry + rz * rz);
+    if (!(len > 0.0) || (wb[8] == 0.0f && wb[9] == 0.0f && wb[10] == 0.0f)) return;
+    const double tol = 1e-6 * sqrt(len);
+    const v3 vb[3] = {a, b, c};
+    for (int i = 0; i < 3; i++) {
+        const double s = ((rx * (double)vb[i].x + ry * (double)vb[i].y) + rz * (double)vb[i].z) + cc;
+        if (!(fabs(s) <= tol)) return;
+    }
+    wb[8] = wa[8]; wb[9] = wa[9]; wb[10] = wa[10]; wb[11] = wa[11];
+}
 /* scene.rs:49-86 stochastic alpha test; alpha = alpha of the base-colour node of the hit material */
 static inline int or_alpha_test(const or_scene *sc, uint32_t inst, uint32_t prim, float u, float v) {
     const or_instance *in = &sc->instances[inst];
@@ -530,6 +545,7 @@ OR_EXPORT or_scene *or_scene_create(const or_scene_desc *d) {
             v3 b = xf_point(&in->xf, ld3(g->vertices, g->indices[3 * p + 1]));
             v3 c = xf_point(&in->xf, ld3(g->vertices, g->indices[3 * p + 2]));
             or_woop_precompute(a, b, c, sc->woop + 12 * k);
+            if (p & 1u) or_share_plane_row(sc->woop + 12 * (k - 1), sc->woop + 12 * k, a, b, c);
             sc->tri_inst[k] = i; sc->tri_prim[k] = p;
         }
     }
@@ -1619,6 +1635,14 @@ OR_EXPORT int or_mcmc_render(const or_scene *sc, const or_mcmc_config *c, float 
     return 0;
 }
 OR_EXPORT uint32_t or_sizeof_mcmc_config(void) { return (uint32_t)sizeof(or_mcmc_config); }
+
+/* number of triangles whose plane row was taken from their even neighbour (or_share_plane_row) */
+OR_EXPORT uint32_t or_scene_shared_plane_rows(const or_scene *sc) {
+    uint32_t n = 0;
+    for (uint32_t k = 1; k < sc->n_tris; k++)
+        if (sc->tri_inst[k] == sc->tri_inst[k - 1] && (sc->tri_prim[k] & 1u) && memcmp(sc->woop + 12 * k + 8, sc->woop + 12 * (k - 1) + 8, 16) == 0) n++;
+    return n;
+}
 
 /* Film resolve, film.rs:120-148 with hdr = true: rgb / (w == 0 ? 1 : w) + splat * splat_scale */
 OR_EXPORT void or_film_resolve_scaled(const float *film, uint32_t width, uint32_t height, float splat_scale, float *rgb_out) {

@@ -54,6 +54,8 @@ def lib() -> C.CDLL:
     L.or_pt_render.argtypes = [vp, C.POINTER(abi.PtConfig), fp, u64p, u32, C.POINTER(OrStats)]
     L.or_film_resolve.argtypes = [fp, u32, u32, fp]
     L.or_film_resolve_scaled.argtypes = [fp, u32, u32, f32, fp]
+    L.or_scene_shared_plane_rows.restype = u32
+    L.or_scene_shared_plane_rows.argtypes = [vp]
     L.or_mcmc_render.restype = i32
     L.or_mcmc_render.argtypes = [vp, C.POINTER(abi.McmcConfig), fp, C.POINTER(C.c_double), up, u32]
     L.or_gpt_render.restype = i32
@@ -128,6 +130,9 @@ class OracleScene:
 
     def __del__(self):
         self.close()
+
+    def shared_plane_rows(self) -> int:
+        return lib().or_scene_shared_plane_rows(self.h)
 
     def num_lights(self):
         return lib().or_scene_num_lights(self.h)

@@ -169,3 +169,21 @@ def test_bvh_structure(hip_lib):
         R = woop[k].reshape(3, 4).astype(np.float64)
         loc = (R[:, :3] @ w.T + R[:, 3:4]).T
         assert np.allclose(loc, [[0, 0, 0], [1, 0, 0], [0, 1, 0]], atol=2e-4)
+
+
+def test_coplanar_neighbours_share_their_plane_row(hip_lib, cbox_path):
+    """Triangles 2j, 2j+1 of an instance whose vertices are coplanar to 1e-6 of their size carry the same third row (the
+    exhaustive intersector solves the plane once per such pair); the oracle applies the same rule independently."""
+    from tests.helpers import box_scene
+
+    sd = scene_json.load_scene(cbox_path, 32, 32)
+    sc = capi.Scene(None, sd)
+    w = sc.array(capi.ARRAY_WOOP, np.float32)[: 12 * 36].reshape(36, 12)
+    same = [k for k in range(1, 36, 2) if np.array_equal(w[k, 8:].view(np.uint32), w[k - 1, 8:].view(np.uint32))]
+    osc = pyoracle.OracleScene(sd)
+    assert len(same) == osc.shared_plane_rows() == 17  # every quad of the Cornell box but one whose halves are 3e-6 apart
+    # the first two rows stay the triangle's own
+    assert all(not np.array_equal(w[k, :8], w[k - 1, :8]) for k in same)
+    # a cube of exact rectangles: all six faces; a grid of displaced vertices: (almost) none
+    assert pyoracle.OracleScene(box_scene()).shared_plane_rows() == 6
+    assert pyoracle.OracleScene(grid_scene(n=12)).shared_plane_rows() <= 2
