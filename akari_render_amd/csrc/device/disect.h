@@ -149,7 +149,7 @@ AKR_D bool trace_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmin, float 
 // resident) records serves both: half the scalar loads and loop overhead of two separate walks, and two independent
 // dependency chains per record for the VALU to overlap. A ray that does not exist for a lane is passed with
 // tmax < tmin and can never hit.
-template <bool TEX = false>
+template <bool TEX = false, bool UNROLL = false>
 AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, uint32_t ex0, vec3 so, vec3 sd, float stmax,
                                  uint32_t sex0, uint32_t sex1, Hit& hit, bool& found, bool& occluded) {
     // best_t starts one ulp above tmax: "t < best_t" then admits a first hit at t == tmax and keeps, among equal t, the
@@ -167,12 +167,8 @@ AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, u
         b = make_float4(r[4], r[5], r[6], r[7]);
         c = make_float4(r[8], r[9], r[10], r[11]);
     };
-    float4 n0, n1, n2;
-    load_rec(0, n0, n1, n2);
     PlaneHit ph{0.0f, 0.0f, 0.0f, 0.0f}, sph{0.0f, 0.0f, 0.0f, 0.0f};
-    for (uint32_t k = 0; k < n; k++) {
-        const float4 r0 = n0, r1 = n1, r2 = n2;
-        load_rec(k + 1, n0, n1, n2);  // prefetch (buffer padded by one record)
+    auto record = [&](uint32_t k, const float4& r0, const float4& r1, const float4& r2) {
         if (!((sc.plane_share_mask >> k) & 1ull)) {  // wave-uniform: one plane solve per ray per coplanar pair of records
             ph = tri_plane(o, d, r2);
             sph = tri_plane(so, sd, r2);
@@ -199,6 +195,29 @@ AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, u
         best_v = better ? v : best_v;
         best = better ? k : best;
         occ_margin = sm > occ_margin ? sm : occ_margin;  // (not fmaxf: that costs two canonicalising v_max per record)
+    };
+    if (UNROLL) {
+        // two records per trip on alternating register sets: the one-record software prefetch without the scalar moves that
+        // rotating a single pair of sets costs per record (buffer padded by two records). +5 % in the small force_diffuse
+        // kernel, -3 % in the full-graph kernel, whose 111 KB of code already overflow the instruction cache.
+        float4 a0, a1, a2, b0, b1, b2;
+        load_rec(0, a0, a1, a2);
+        uint32_t k = 0;
+        for (; k + 1 < n; k += 2) {
+            load_rec(k + 1, b0, b1, b2);
+            record(k, a0, a1, a2);
+            load_rec(k + 2, a0, a1, a2);
+            record(k + 1, b0, b1, b2);
+        }
+        if (k < n) record(k, a0, a1, a2);
+    } else {
+        float4 n0, n1, n2;
+        load_rec(0, n0, n1, n2);
+        for (uint32_t k = 0; k < n; k++) {
+            const float4 r0 = n0, r1 = n1, r2 = n2;
+            load_rec(k + 1, n0, n1, n2);  // prefetch
+            record(k, r0, r1, r2);
+        }
     }
     found = best != kInvalid;
     hit.t = found ? best_t : tmax;

@@ -622,8 +622,8 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
         out.woop.swap(woop2);
         out.tri_gid = order;
     }
-    // one all-zero record of padding: the exhaustive intersector prefetches record k+1 while testing k
-    out.woop.resize(out.woop.size() + 12, 0.0f);
+    // two all-zero records of padding: the exhaustive intersectors prefetch up to record n + 1
+    out.woop.resize(out.woop.size() + 24, 0.0f);
 }
 
 }  // namespace akr

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256, BVH ? AKR_PT_MIN_WAVES_BVH : (FD ? AKR_PT_MIN_
                     occluded = trace_bvh4<true, TEX>(sc, r.s_o, r.s_d, 0.0f, r.s_tmax, r.s_ex0, r.s_ex1, sh, tc.stack, tc.cnt);
                 }
             } else {
-                trace_pair_exhaustive<TEX>(sc, r.ro, r.rd, r.has_ray ? 1e20f : -1.0f, r.ray_ex0, r.s_o, r.s_d, r.has_shadow ? r.s_tmax : -1.0f,
+                trace_pair_exhaustive<TEX, FD>(sc, r.ro, r.rd, r.has_ray ? 1e20f : -1.0f, r.ray_ex0, r.s_o, r.s_d, r.has_shadow ? r.s_tmax : -1.0f,
                                       r.s_ex0, r.s_ex1, hit, found, occluded);
             }
             path_step<FD ? 1 : 0, TEX, PMJ>(q, r, hit, found, occluded, pix, sx, sy);
