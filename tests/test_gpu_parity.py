@@ -256,3 +256,23 @@ def test_wavefront_equals_megakernel_sharded(ctx, cbox_path, wavefront_mode):
     capi.pt_render(ctx, scene, cfg, a)
     o, _ = pyoracle.OracleScene(sd).render(cfg)
     assert n_bit_diff(a.read(), o) == 0
+
+
+def test_convergence_follows_one_over_sqrt_spp(ctx, cbox_path):
+    """SURVEY 8d's convergence sanity: against a 16384-spp image of the same scene the error of N-spp images falls like
+    1/sqrt(N) (independent sampler: no correlation between samples), and images rendered with different seeds agree within it."""
+    w = h = 64
+    scene = capi.Scene(ctx, cbox_path, w, h)
+
+    def render(spp, seed):
+        film = capi.Film(ctx, w, h)
+        cfg = make_config(spp=spp, spp_per_pass=min(spp, 256), max_depth=12, sampler_seed=seed)
+        capi.pt_render(ctx, scene, cfg, film)
+        return film.resolve().astype(np.float64)
+
+    ref = render(16384, 1)
+    errs = {n: np.sqrt(np.mean((render(n, 2) - ref) ** 2)) for n in (16, 64, 256, 1024)}
+    for a, b in ((16, 64), (64, 256), (256, 1024)):
+        ratio = errs[a] / errs[b]
+        assert 1.6 < ratio < 2.5, (errs, ratio)  # x4 samples -> error / 2
+    assert abs(render(1024, 3).mean() - ref.mean()) < 0.01 * ref.mean()
