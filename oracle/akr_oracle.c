@@ -76,6 +76,7 @@ typedef struct {
     uint32_t width, height;
     float table[16 * 16 * 16];
     int has_table;
+    struct or_bvh *bvh;          /* optional, checker-side only (or_accel.h); NULL = the exhaustive loop below */
 } or_scene;
 
 typedef struct { v3 o, d; float t_min, t_max; uint32_t ex0_inst, ex0_prim, ex1_inst, ex1_prim; } or_ray;
@@ -215,6 +216,9 @@ static void or_woop_precompute(v3 A, v3 B, v3 C, float *w) {
 /* Coplanar neighbours share a plane row: triangles 2j and 2j+1 of an instance get the same third row when the second one's
  * vertices lie in the first one's plane to within 1e-6 of the triangle's size (the same rule, stated independently, as
  * akari_render_amd/csrc/host/scene_build.cpp: share_plane_row). Pure data: the tracer below does not know about it. */
+static int g_or_share_plane_rows = 1; /* 0: every triangle keeps the plane row computed from its own vertices (the records as
+                                       * they were before the rule existed); read by or_scene_create */
+OR_EXPORT void or_set_share_plane_rows(int enable) { g_or_share_plane_rows = enable; }
 static void or_share_plane_row(const float *wa, float *wb, v3 a, v3 b, v3 c) {
     const double rx = wa[8], ry = wa[9], rz = wa[10], cc = wa[11];
     const double len = sqrt(rx * rx + ry * ry + rz * rz);
@@ -252,8 +256,11 @@ static inline int or_alpha_test(const or_scene *sc, uint32_t inst, uint32_t prim
     float h = (float)or_xxhash32_4(inst, prim, f2u(u), f2u(v)) * (float)(1.0 / 4294967295.0);
     return alpha > h;
 }
-/* closest hit: scene.rs:88-110,131-153; any hit: scene.rs:155-185 */
+/* closest hit: scene.rs:88-110,131-153; any hit: scene.rs:155-185. THE definition of a hit: every triangle, in global order.
+ * (or_trace_bvh, or_accel.h, skips triangles that cannot pass and is checked against this loop ray by ray.) */
+static int or_trace_bvh(const or_scene *sc, const or_ray *r, int any_hit, uint32_t *o_inst, uint32_t *o_prim, v2 *o_bary, or_stats *st);
 static int or_trace(const or_scene *sc, const or_ray *r, int any_hit, uint32_t *o_inst, uint32_t *o_prim, v2 *o_bary, or_stats *st) {
+    if (sc->bvh) return or_trace_bvh(sc, r, any_hit, o_inst, o_prim, o_bary, st);
     float best_t = 0.0f; uint32_t best = OR_INVALID; v2 best_b = V2(0, 0);
     for (uint32_t k = 0; k < sc->n_tris; k++) {
         float t, u, v;
@@ -269,6 +276,7 @@ static int or_trace(const or_scene *sc, const or_ray *r, int any_hit, uint32_t *
     *o_inst = sc->tri_inst[best]; *o_prim = sc->tri_prim[best]; *o_bary = best_b;
     return 1;
 }
+#include "or_accel.h"
 
 /* ---------------------------------- materials -> closure trees ----------------------------------- */
 #define OR_MAX_NODES 24
@@ -545,7 +553,7 @@ OR_EXPORT or_scene *or_scene_create(const or_scene_desc *d) {
             v3 b = xf_point(&in->xf, ld3(g->vertices, g->indices[3 * p + 1]));
             v3 c = xf_point(&in->xf, ld3(g->vertices, g->indices[3 * p + 2]));
             or_woop_precompute(a, b, c, sc->woop + 12 * k);
-            if (p & 1u) or_share_plane_row(sc->woop + 12 * (k - 1), sc->woop + 12 * k, a, b, c);
+            if ((p & 1u) && g_or_share_plane_rows) or_share_plane_row(sc->woop + 12 * (k - 1), sc->woop + 12 * k, a, b, c);
             sc->tri_inst[k] = i; sc->tri_prim[k] = p;
         }
     }
@@ -606,6 +614,7 @@ OR_EXPORT void or_scene_destroy(or_scene *sc) {
     free(sc->meshes); free(sc->instances); free(sc->materials);
     free(sc->woop); free(sc->tri_inst); free(sc->tri_prim);
     free(sc->light_inst); free(sc->light_power);
+    or_scene_free_bvh(sc);
     free(sc);
 }
 

@@ -56,6 +56,13 @@ def lib() -> C.CDLL:
     L.or_film_resolve_scaled.argtypes = [fp, u32, u32, f32, fp]
     L.or_scene_shared_plane_rows.restype = u32
     L.or_scene_shared_plane_rows.argtypes = [vp]
+    L.or_set_share_plane_rows.argtypes = [i32]
+    L.or_scene_build_bvh.restype = u32
+    L.or_scene_build_bvh.argtypes = [vp]
+    L.or_scene_free_bvh.argtypes = [vp]
+    L.or_scene_intersect_many.argtypes = [vp, u32, fp, i32, up, fp, u32]
+    L.or_mt_f64_many.argtypes = [vp, u32, fp, up, up, C.POINTER(C.c_double), u32]
+    L.or_scene_world_vertices.argtypes = [vp, fp]
     L.or_mcmc_render.restype = i32
     L.or_mcmc_render.argtypes = [vp, C.POINTER(abi.McmcConfig), fp, C.POINTER(C.c_double), up, u32]
     L.or_gpt_render.restype = i32
@@ -116,12 +123,53 @@ def _fp(a):
 
 
 class OracleScene:
-    def __init__(self, scene: abi.SceneData):
+    def __init__(self, scene: abi.SceneData, bvh: bool = False, share_plane_rows: bool = True):
+        """bvh: build the oracle-side hierarchy (or_accel.h; same hits as the exhaustive loop, checked in
+        tests/test_oracle_accel.py) -- for the 1 M / 10 M-triangle configurations. share_plane_rows = False: every triangle
+        keeps the plane row of its own vertices (the records as they were before the coplanar-neighbour rule)."""
         self.data = scene
         desc, self._keep = scene.to_desc()
         self._desc = desc
-        self.h = lib().or_scene_create(C.byref(desc))
+        lib().or_set_share_plane_rows(1 if share_plane_rows else 0)
+        try:
+            self.h = lib().or_scene_create(C.byref(desc))
+        finally:
+            lib().or_set_share_plane_rows(1)
         self.width, self.height = scene.camera.width, scene.camera.height
+        self.n_bvh_nodes = lib().or_scene_build_bvh(self.h) if bvh else 0
+
+    def intersect_many(self, rays: np.ndarray, any_hit: bool = False, n_threads: int = 0):
+        """rays (n, 8) = o, d, tmin, tmax -> (hit/inst/prim u32 (n, 3), t/u/v f32 (n, 3)); through or_trace."""
+        r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        out = np.zeros((r.shape[0], 3), dtype=np.uint32)
+        tuv = np.zeros((r.shape[0], 3), dtype=np.float32)
+        lib().or_scene_intersect_many(self.h, r.shape[0], _fp(r), 1 if any_hit else 0, out.ctypes.data_as(C.POINTER(C.c_uint32)), _fp(tuv),
+                                      n_threads if n_threads > 0 else (os.cpu_count() or 1))
+        return out, tuv
+
+    def mt_f64(self, rays: np.ndarray, gids: np.ndarray | None = None, n_threads: int = 0):
+        """Independent f64 Moeller-Trumbore from the f32 world-space vertices. gids None: closest hit over all triangles ->
+        (gid u32 (n,), (t, u, v, margin) f64 (n, 4)); gids given: the solve for that triangle, no range test."""
+        r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        out = np.zeros((r.shape[0], 4), dtype=np.float64)
+        og = np.zeros(r.shape[0], dtype=np.uint32)
+        gp = C.POINTER(C.c_uint32)()
+        if gids is not None:
+            gids = np.ascontiguousarray(gids, dtype=np.uint32)
+            gp = gids.ctypes.data_as(C.POINTER(C.c_uint32))
+        lib().or_mt_f64_many(self.h, r.shape[0], _fp(r), gp, og.ctypes.data_as(C.POINTER(C.c_uint32)), out.ctypes.data_as(C.POINTER(C.c_double)),
+                             n_threads if n_threads > 0 else (os.cpu_count() or 1))
+        return (og if gids is None else gids), out
+
+    def world_vertices(self) -> np.ndarray:
+        out = np.zeros((lib().or_scene_num_triangles(self.h), 3, 3), dtype=np.float32)
+        lib().or_scene_world_vertices(self.h, _fp(out))
+        return out
+
+    def tri_offsets(self) -> np.ndarray:
+        """first global triangle id of every instance"""
+        n = [self.data.meshes[i.mesh].indices.reshape(-1, 3).shape[0] for i in self.data.instances]
+        return np.concatenate([[0], np.cumsum(n)[:-1]]).astype(np.uint32)
 
     def close(self):
         if self.h:
