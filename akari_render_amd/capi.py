@@ -15,7 +15,7 @@ from . import abi
 from .build import LIB, build
 
 AKR_OK = 0
-ERR_INVALID_ARGUMENT, ERR_HIP, ERR_NO_DEVICE, ERR_IO, ERR_PARSE, ERR_UNSUPPORTED, ERR_OOM = -1, -2, -3, -4, -5, -6, -7
+ERR_INVALID_ARGUMENT, ERR_HIP, ERR_NO_DEVICE, ERR_IO, ERR_PARSE, ERR_UNSUPPORTED, ERR_OOM, ERR_RENDER = -1, -2, -3, -4, -5, -6, -7, -8
 
 (ARRAY_WOOP, ARRAY_TRI_GID, ARRAY_SHADE, ARRAY_INSTANCES, ARRAY_MATERIALS, ARRAY_BVH_NODES, ARRAY_LIGHT_ENTRIES,
  ARRAY_LIGHT_PDF, ARRAY_AREA_ENTRIES, ARRAY_AREA_PDF, ARRAY_INST_TRI_OFFSET, ARRAY_R2C, ARRAY_C2W) = range(13)

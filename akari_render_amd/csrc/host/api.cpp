@@ -35,6 +35,9 @@ struct Unsupported : std::runtime_error {
 struct IoError : std::runtime_error {
     explicit IoError(const std::string& s) : std::runtime_error(s) {}
 };
+struct RenderError : std::runtime_error {  // the device ran, but the result is not a valid render (not an input-file problem)
+    explicit RenderError(const std::string& s) : std::runtime_error(s) {}
+};
 
 #define HIP_CHECK(expr)                                                                                         \
     do {                                                                                                        \
@@ -59,6 +62,8 @@ int32_t guarded(F&& f) {
         return fail(AKR_ERR_UNSUPPORTED, e.what());
     } catch (const IoError& e) {
         return fail(AKR_ERR_IO, e.what());
+    } catch (const RenderError& e) {
+        return fail(AKR_ERR_RENDER, e.what());
     } catch (const std::invalid_argument& e) {
         return fail(AKR_ERR_INVALID_ARGUMENT, e.what());
     } catch (const std::bad_alloc&) {
@@ -157,9 +162,59 @@ struct akr_pt_session {
     uint32_t wf_slots = 0, wf_trace_blocks = 0;
     uint32_t spp_done = 0, n_launches = 0;
     uint32_t pmj_spp = 1;  // the spp the pmj02bn sampler stratifies for (the method's total spp)
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    // timed regions on the context's stream: pairs still in flight, and the elapsed time of the completed ones (folded in and
+    // destroyed as they complete, so a long progressive session holds a bounded number of events)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double kernel_ms = 0.0;
     PtParams params;
+    void fold_events(bool all) {  // all: the stream has been synchronised
+        size_t keep = 0;
+        for (size_t i = 0; i < pending.size(); i++) {
+            auto& ev = pending[i];
+            if (all || hipEventQuery(ev.second) == hipSuccess) {
+                float t = 0.0f;
+                if (hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess) kernel_ms += t;
+                (void)hipEventDestroy(ev.first);
+                (void)hipEventDestroy(ev.second);
+            } else {
+                pending[keep++] = ev;
+            }
+        }
+        pending.resize(keep);
+    }
+    ~akr_pt_session() {
+        for (auto& ev : pending) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+    }
 };
+
+namespace {
+// One timed region on a session's stream. The event pair is handed to the session by stop(); if the region is left by an
+// exception the pair is destroyed here.
+struct LaunchTimer {
+    akr_pt_session* se;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    explicit LaunchTimer(akr_pt_session* s) : se(s) {
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, se->ctx->stream));
+    }
+    LaunchTimer(const LaunchTimer&) = delete;
+    LaunchTimer& operator=(const LaunchTimer&) = delete;
+    void stop() {
+        HIP_CHECK(hipEventRecord(e1, se->ctx->stream));
+        se->pending.emplace_back(e0, e1);
+        e0 = e1 = nullptr;
+        if (se->pending.size() > 16) se->fold_events(false);
+    }
+    ~LaunchTimer() {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+};
+}  // namespace
 
 static void ensure_ggx_table(akr_scene* s) {
     akr_context* ctx = s->ctx;
@@ -399,7 +454,7 @@ static void wf_run(akr_pt_session* se) {
             HIP_CHECK(hipStreamSynchronize(st));
             if (n_active == 0) break;
         }
-        if (iter > (1ull << 26)) throw std::runtime_error("wavefront schedule did not terminate");
+        if (iter > (1ull << 26)) throw RenderError("wavefront schedule did not terminate");
     }
 }
 
@@ -632,6 +687,19 @@ AKR_API int32_t akr_film_create(akr_context* ctx, uint32_t width, uint32_t heigh
 }
 AKR_API int32_t akr_film_wrap(akr_context* ctx, uint32_t width, uint32_t height, void* device_ptr, akr_film** out) {
     if (!ctx || !out || !width || !height || !device_ptr) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_film_wrap: bad argument");
+    *out = nullptr;
+    {   // The gpt / mcmc_opt kernels splat with hardware float atomics (global_atomic_add_f32), which CDNA silently drops on
+        // host-mapped, managed or fine-grained memory: only plain device allocations (hipMalloc) of this context's GPU pass.
+        hipPointerAttribute_t attr;
+        hipError_t e = hipPointerGetAttributes(&attr, device_ptr);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(AKR_ERR_INVALID_ARGUMENT, "akr_film_wrap: device_ptr is not a HIP allocation");
+        }
+        if (attr.type != hipMemoryTypeDevice || attr.isManaged)
+            return fail(AKR_ERR_INVALID_ARGUMENT, "akr_film_wrap: device_ptr must be plain device memory (hipMalloc), not host-mapped or managed memory");
+        if (attr.device != ctx->device) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_film_wrap: device_ptr belongs to another GPU than the context");
+    }
     auto* f = new (std::nothrow) akr_film();
     if (!f) return fail(AKR_ERR_OUT_OF_MEMORY, "out of host memory");
     f->ctx = ctx;
@@ -781,14 +849,10 @@ AKR_API int32_t akr_pt_passes(akr_pt_session* se, uint32_t n_passes, int32_t blo
                 fused++;
             }
             fill_params(se, fused, last);
-            hipEvent_t e0, e1;
-            HIP_CHECK(hipEventCreate(&e0));
-            HIP_CHECK(hipEventCreate(&e1));
-            HIP_CHECK(hipEventRecord(e0, se->ctx->stream));
+            LaunchTimer timer(se);
             if (se->wavefront) wf_run(se);
             else HIP_CHECK(launch_pt_pass(se->params, se->ctx->stream));
-            HIP_CHECK(hipEventRecord(e1, se->ctx->stream));
-            se->events.emplace_back(e0, e1);
+            timer.stop();
             se->spp_done = done;
             se->n_launches++;
             left -= fused;
@@ -810,12 +874,8 @@ static void read_stats(akr_pt_session* se, akr_pt_stats* stats) {
     HIP_CHECK(hipStreamSynchronize(se->ctx->stream));
     uint64_t c[8];
     HIP_CHECK(hipMemcpy(c, se->counters.p, sizeof c, hipMemcpyDeviceToHost));
-    double ms = 0.0;
-    for (auto& ev : se->events) {
-        float t = 0.0f;
-        HIP_CHECK(hipEventElapsedTime(&t, ev.first, ev.second));
-        ms += t;
-    }
+    se->fold_events(true);
+    const double ms = se->kernel_ms;
     if (stats) {
         stats->n_samples = c[0];
         stats->n_closest = c[1];
@@ -827,7 +887,7 @@ static void read_stats(akr_pt_session* se, akr_pt_stats* stats) {
         stats->n_launches = se->n_launches;
         stats->_pad = (uint32_t)c[6];  // non-zero = a traversal stack overflowed (results invalid)
     }
-    if (c[6] != 0) throw std::runtime_error("BVH traversal stack overflow: the render is incomplete");
+    if (c[6] != 0) throw RenderError("BVH traversal stack overflow: the render is incomplete");
 }
 AKR_API int32_t akr_pt_get_stats(akr_pt_session* se, akr_pt_stats* stats) {
     if (!se || !stats) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_pt_get_stats: NULL argument");
@@ -836,10 +896,6 @@ AKR_API int32_t akr_pt_get_stats(akr_pt_session* se, akr_pt_stats* stats) {
 AKR_API int32_t akr_pt_end(akr_pt_session* se, akr_pt_stats* stats) {
     if (!se) return AKR_OK;
     int32_t rc = guarded([&] { read_stats(se, stats); });
-    for (auto& ev : se->events) {
-        (void)hipEventDestroy(ev.first);
-        (void)hipEventDestroy(ev.second);
-    }
     (void)hipSetDevice(se->ctx->device);
     delete se;
     return rc;
@@ -885,13 +941,9 @@ AKR_API int32_t akr_aov_render(akr_context* ctx, akr_scene* scene, const akr_aov
     rc = guarded([&] {
         if (cfg->spp == 0) return;
         fill_params(se, 1, cfg->spp);
-        hipEvent_t e0, e1;
-        HIP_CHECK(hipEventCreate(&e0));
-        HIP_CHECK(hipEventCreate(&e1));
-        HIP_CHECK(hipEventRecord(e0, ctx->stream));
+        LaunchTimer timer(se);
         HIP_CHECK(launch_aov(se->params, cfg->spp, cfg->aov, cfg->remap ? 1u : 0u, ctx->stream));
-        HIP_CHECK(hipEventRecord(e1, ctx->stream));
-        se->events.emplace_back(e0, e1);
+        timer.stop();
         se->n_launches++;
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
     });
@@ -951,10 +1003,7 @@ AKR_API int32_t akr_gpt_render(akr_context* ctx, akr_scene* scene, const akr_gpt
             g.acc_p = b; g.sqr_p = b + 3 * N; g.acc_gx = b + 6 * N; g.acc_gy = g.acc_gx + 3 * NG; g.sqr_gx = g.acc_gy + 3 * NG; g.sqr_gy = g.sqr_gx + 3 * NG;
         }
         fill_params(se, 1, 1);
-        hipEvent_t e0, e1;
-        HIP_CHECK(hipEventCreate(&e0));
-        HIP_CHECK(hipEventCreate(&e1));
-        HIP_CHECK(hipEventRecord(e0, ctx->stream));
+        LaunchTimer timer(se);
         for (uint32_t s = 0; s < cfg->spp; s++) {  // gpt.rs:468-485: kernel + update_kernel per sample
             HIP_CHECK(launch_gpt_sample(se->params, g, ctx->stream));
             HIP_CHECK(launch_gpt_update(g, W, H, film->data, ctx->stream));
@@ -978,8 +1027,7 @@ AKR_API int32_t akr_gpt_render(akr_context* ctx, akr_scene* scene, const akr_gpt
                 HIP_CHECK(hipMemcpyAsync(old.p, cur, 3 * N * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
             }
         }
-        HIP_CHECK(hipEventRecord(e1, ctx->stream));
-        se->events.emplace_back(e0, e1);
+        timer.stop();
         se->n_launches += 2 * cfg->spp;
         se->spp_done = cfg->spp;
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1061,10 +1109,7 @@ static int32_t mcmc_render_impl(akr_context* ctx, akr_scene* scene, const akr_mc
         m.exponential_mutation = cfg->exponential_mutation ? 1u : 0u;
         m.small_sigma = cfg->small_sigma; m.large_step_prob = cfg->large_step_prob; m.image_mutation_prob = cfg->image_mutation_prob;
         m.image_mutation_size = cfg->image_mutation_size;
-        hipEvent_t e0, e1;
-        HIP_CHECK(hipEventCreate(&e0));
-        HIP_CHECK(hipEventCreate(&e1));
-        HIP_CHECK(hipEventRecord(e0, ctx->stream));
+        LaunchTimer timer(se);
         HIP_CHECK(launch_mcmc_bootstrap(se->params, m, ctx->stream));
         std::vector<float> fs(n_boot);
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1072,7 +1117,7 @@ static int32_t mcmc_render_impl(akr_context* ctx, akr_scene* scene, const akr_mc
         // resample_with_f64 (util/distribution.rs:92-115); the reference sums with rayon, here in index order
         double sum = 0.0;
         for (float f : fs) sum += (double)f;
-        if (!(sum > 0.0)) throw std::runtime_error("Bootstrap failed, please retry with more samples (mcmc_opt.rs:352)");
+        if (!(sum > 0.0)) throw RenderError("Bootstrap failed, please retry with more samples (mcmc_opt.rs:352)");
         std::vector<double> cdf(n_boot);
         for (uint32_t i = 0; i < n_boot; i++) {
             double pr = (double)fs[i] / sum;
@@ -1135,8 +1180,7 @@ static int32_t mcmc_render_impl(akr_context* ctx, akr_scene* scene, const akr_mc
                 on_pass(cnt, acc_s);
             }
         }
-        HIP_CHECK(hipEventRecord(e1, ctx->stream));
-        se->events.emplace_back(e0, e1);
+        timer.stop();
         se->n_launches += 2 + (cfg->spp + cfg->spp_per_pass - 1) / cfg->spp_per_pass;
         reconstruct(cfg->spp);
         if (result) {

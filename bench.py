@@ -1,17 +1,21 @@
 #!/usr/bin/env python
-"""Benchmark of the `pt` hot path on MI355X: Msamples/s on scenes/cbox 1920x1080, force_diffuse (BASELINE.json
-configs[1]); one step = one pass of spp_per_pass = 64 samples per pixel (the reference's kernel.dispatch,
-pt.rs:1126-1133).
+"""Benchmark of the `pt` hot path on MI355X (BASELINE.json metric: Msamples/s, whole node, 1080p Cornell box 1024 spp).
 
-    python bench.py --gpus 1 --steps 16 --warmup 2
+    python bench.py                                   # N = 1: configs[1] (C2) timed, then C3 and C4 once each, CPU baseline
+    python bench.py --gpus 1 --steps 20 --warmup 5    # what the driver runs
+    python bench.py --config c3|c4                    # another BASELINE configuration as the timed workload
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0. The path shards by independent units -- pixels and sample sets -- with no collective in
-the render itself. N > 1, default (--scaling weak, per-GPU work fixed): every GPU renders the whole frame with its own
-sampler seed, i.e. N independent sample sets of the same workload (N x 1024 spp at N GPUs, the spp of BASELINE's 8-GPU
-config), and the films are sum-reduced onto rank 0 over RCCL inside the timed region. --scaling strong shards the ONE
-frame's 32x32 pixel tiles over the ranks instead (same image for every N; DESIGN.md section 5 explains why its
-efficiency is bounded by the per-pixel sequential sample streams: ~0.75 at 8 GPUs for 1080p).
+ONE STEP = ONE RENDER OF THE NAMED WORKLOAD'S SAMPLE BATCH: 1024 samples per pixel of the 1920x1080 frame, i.e. 16 passes
+of spp_per_pass = 64 (the reference's kernel.dispatch granularity, pt.rs:1126-1133) which the library fuses into one
+k_pt_pass launch. C2 = scenes/cbox, force_diffuse (configs[1], the configuration the metric is quoted on); C3 = the same
+frame with the full Cycles-subset shader graph (configs[2]; its 4096 spp are 4 steps); C4 = procedural 10 M-triangle hall
+(configs[3]). Inputs (scene, sampler states, film) are resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0. N > 1: the path shards by pixel tiles (32x32, round-robin over the ranks; a pixel's sample
+stream does not depend on who renders it), the image is the same for every N ("scaling": "strong", the default), and the
+films are sum-reduced onto rank 0 over RCCL inside the timed region. --scaling weak instead gives every GPU the whole frame
+with its own sampler seed (N independent sample sets; the metric name says so).
 """
 import argparse
 import json
@@ -24,8 +28,18 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-W, H, SPP_PER_PASS = 1920, 1080, 64
+W, H, SPP_PER_PASS, PASSES_PER_STEP = 1920, 1080, 64, 16
+SPP_PER_STEP = SPP_PER_PASS * PASSES_PER_STEP
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+CONFIGS = {
+    "c2": dict(name="C2", baseline_config=1, force_diffuse=1, scene="cbox",
+               workload="scenes/cbox 1920x1080, diffuse-only BSDF (force_diffuse), 1024 spp per step"),
+    "c3": dict(name="C3", baseline_config=2, force_diffuse=0, scene="cbox",
+               workload="scenes/cbox 1920x1080, full Cycles-subset shader graph, 1024 spp per step (configs[2] = 4 steps)"),
+    "c4": dict(name="C4", baseline_config=3, force_diffuse=0, scene="hall",
+               workload="procedural Sponza-like hall, 10 M triangles (generator seed 1234), 1920x1080, 1024 spp per step"),
+}
+HALL_TRIS = 10_000_000
 
 
 def log(*a):
@@ -33,16 +47,17 @@ def log(*a):
 
 
 def algorithmic_bytes(d):
-    """SURVEY.md 8(d) byte model: per-event record sizes x device counters. The BVH terms
-    are zero for cbox (36 triangles, cache-resident) and counted in full for BVH scenes."""
+    """SURVEY.md 8(d) byte model: per-event record sizes x device counters. The BVH terms are zero
+    for cbox (36 triangles, cache-resident: no node visits are counted) and counted in full for BVH scenes, with the node
+    and triangle record sizes the scene actually uses (d["node_bytes"], d["tri_bytes"])."""
     return (56 * d["n_closest"] + 292 * d["n_shaded"] + 64 * d["n_shadow"] + 156 * d["n_samples"] +
-            64 * d["n_node_visits"] + (48 * d["n_tri_tests"] if d["n_node_visits"] else 0))
+            d.get("node_bytes", 64) * d["n_node_visits"] + (d.get("tri_bytes", 48) * d["n_tri_tests"] if d["n_node_visits"] else 0))
 
 
 def host_threads():
-    """Threads for the CPU baseline: the container may be limited by a cgroup CPU quota far below os.cpu_count() (the GPU
-    box: 256 logical CPUs visible, cpu.max = 16 cores; 256 threads then run 40 % slower than 32). Two threads per core of
-    quota, capped by the visible CPUs."""
+    """(threads, cores) for the CPU baseline. The container may be limited by a cgroup CPU quota far below os.cpu_count()
+    (the GPU box: 256 logical CPUs visible, cpu.max = 16 cores; 256 threads then run 40 % slower than 32): two threads
+    per core of quota, capped by the visible CPUs. `cores` = what the quota grants (the number to quote)."""
     n = os.cpu_count() or 1
     try:
         n = min(n, len(os.sched_getaffinity(0)))
@@ -63,96 +78,88 @@ def host_threads():
             pass
     if quota is not None and quota < n:
         return max(1, min(n, int(round(2 * quota)))), quota
-    return n, None
+    return n, float(n)
 
 
-def cpu_baseline(n_threads, quota=None):
-    """The CPU oracle (restatement of the reference algorithm; the reference binary cannot run here) on the same
-    workload, bounded sample: 1920x1080, force_diffuse, 4 spp."""
+def cpu_baseline(key, n_threads, cores):
+    """The CPU oracle (C restatement of the reference algorithm; the reference binary cannot run here: Rust + LuisaCompute)
+    on bounded samples of the same workloads: the timed configuration's 1080p frame at a few spp (~10-15 s), and C1
+    (256x256, 64 spp, full graph: BASELINE configs[0], the reference's own CPU-runnable case) in full."""
     from akari_render_amd import abi
     from oracle import pyoracle, scene_json
 
-    sd = scene_json.load_scene(os.path.join(ROOT, "scenes", "cbox", "scene.json"), W, H)
-    cfg = abi.PtConfig.default()
-    cfg.spp, cfg.spp_per_pass, cfg.max_depth, cfg.rr_depth, cfg.force_diffuse = 4, 4, 12, 5, 1
-    sc = pyoracle.OracleScene(sd)
-    # calibrate the sample size to ~10-20 s of CPU work
-    t0 = time.time()
-    _, st = sc.render(cfg, n_threads=n_threads)
-    dt = time.time() - t0
-    spp = int(max(4, min(64, 4 * 12.0 / max(dt, 1e-3))))
-    if spp > 4:
-        cfg.spp = cfg.spp_per_pass = spp
+    def run(w, h, spp, fd, budget_s):
+        sd = scene_json.load_scene(os.path.join(ROOT, "scenes", "cbox", "scene.json"), w, h)
+        cfg = abi.PtConfig.default()
+        cfg.spp, cfg.spp_per_pass, cfg.max_depth, cfg.rr_depth, cfg.force_diffuse = spp, spp, 12, 5, fd
+        sc = pyoracle.OracleScene(sd)
         t0 = time.time()
         _, st = sc.render(cfg, n_threads=n_threads)
         dt = time.time() - t0
-    return {"value": st["n_samples"] / dt / 1e6, "unit": "Msamples/s", "cores": n_threads, "kind": "port",
-            "sample": f"cbox {W}x{H} force_diffuse {cfg.spp} spp ({st['n_samples']} camera paths, {dt:.1f} s), CPU oracle (C, pthreads)"
-                      + (f", cgroup CPU quota {quota:g} cores" if quota is not None else "")}
+        if budget_s:
+            more = int(max(spp, min(64, spp * budget_s / max(dt, 1e-3))))
+            if more > spp:
+                cfg.spp = cfg.spp_per_pass = more
+                t0 = time.time()
+                _, st = sc.render(cfg, n_threads=n_threads)
+                dt = time.time() - t0
+        return st["n_samples"] / dt / 1e6, cfg.spp, st["n_samples"], dt
+
+    fd = CONFIGS[key]["force_diffuse"] if CONFIGS[key]["scene"] == "cbox" else 1
+    v, spp, ns, dt = run(W, H, 4, fd, 11.0)
+    c1v, _, c1n, c1dt = run(256, 256, 64, 0, 0)
+    what = "force_diffuse" if fd else "full graph"
+    return {"value": v, "unit": "Msamples/s", "cores": cores, "threads": n_threads, "kind": "port",
+            "sample": f"cbox {W}x{H} {what} {spp} spp ({ns} camera paths, {dt:.1f} s), CPU oracle (C, pthreads); cores = cgroup CPU quota",
+            "c1": {"value": c1v, "unit": "Msamples/s", "sample": f"C1: cbox 256x256 64 spp full graph ({c1n} camera paths, {c1dt:.1f} s)"}}
 
 
-def measured_traffic(args, d):
-    """HBM bytes of one timed launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes,
-    tools/pmc_run.sh; unit + gfx950 corrections of MI355X_MICROARCH.md "HBM" applied there). A counter pass cannot run
-    inside this process, so the number is the one committed under profiles/ for exactly this launch shape (same
-    workload, same number of fused passes); anything else reports null."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-    if args.gpus != 1 or not os.path.exists(path):
-        return None
-    try:
-        t = json.load(open(path))
-    except Exception:
-        return None
-    key = "full_graph" if args.full_graph else "force_diffuse"
-    e = t.get(key)
-    if not e or e.get("steps") != args.steps or d["n_launches"] != 1:
-        return None
-    return e.get("hbm_bytes_per_launch")
+def measured_counters(key, passes_per_launch, n_items_full):
+    """What rocprofv3's PMC passes measured for this launch shape (they cannot run inside this process): the committed
+    summary profiles/r2_pmc_<config>.json -- HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes, unit
+    and gfx950 corrections of MI355X_MICROARCH.md "HBM"), VALU busy share, lane utilisation -- or None. A launch of the cbox
+    kernels reads and writes the per-pixel sampler states and film once, whatever the number of fused passes; the hall's
+    traffic is per ray, so that file stores bytes per sample."""
+    for rnd in ("r2", "r1"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{key}.json")
+        if os.path.exists(path):
+            try:
+                return json.load(open(path))
+            except Exception:
+                return None
+    return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--full-graph", action="store_true", help="configs[2]: full Cycles-subset shader graph instead of force_diffuse")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1: weak = every GPU renders the whole 1080p frame with its own sampler seed (N independent sample "
-                         "sets, N x the samples; per-GPU work fixed), films sum-reduced; strong = the one frame's 32x32 pixel "
-                         "tiles round-robin over the GPUs (identical image for every N)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only for smoke-testing the "
-                         "multi-rank path on a box with fewer GPUs than ranks: all ranks then share device 0)")
-    args = ap.parse_args()
+def build_scene(ctx, key):
+    from akari_render_amd import capi
 
-    import torch
+    if CONFIGS[key]["scene"] == "cbox":
+        return capi.Scene(ctx, os.path.join(ROOT, "scenes", "cbox", "scene.json"), W, H), {}  # akr_scene_load: C++ reader
+    from akari_render_amd import procedural
 
+    t0 = time.time()
+    sd = procedural.sponza_like(HALL_TRIS, seed=1234, width=W, height=H)
+    t1 = time.time()
+    scene = capi.Scene(ctx, sd)
+    info = scene.info()
+    return scene, {"n_triangles": int(info.n_triangles), "n_bvh_nodes": int(info.n_bvh_nodes), "scene_device_MB": info.device_bytes / 1e6,
+                   "generate_s": t1 - t0, "compile_upload_s": time.time() - t1}
+
+
+def run_config(ctx, key, steps, warmup, rank, world, scaling, film_t, torch, dist, backend, dev):
+    """Times `steps` steps of configuration `key` on this rank. Returns (elapsed_s, per-rank counter deltas, extra info)."""
     from akari_render_amd import abi, capi, distributed
 
-    rank, world, local_rank = distributed.env_rank_world()
-    if args.gpus > 1 or world > 1:
-        assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus} (WORLD_SIZE={world})"
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.backend == "gloo":
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        distributed.init_process_group(args.backend)
-    import torch.distributed as dist
-
-    ctx = capi.Context(local_rank if world > 1 else 0)
-    scene = capi.Scene(ctx, os.path.join(ROOT, "scenes", "cbox", "scene.json"), W, H)  # akr_scene_load: C++ reader
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
-    film_t = torch.zeros(7 * W * H, dtype=torch.float32, device=dev)
+    scene, sinfo = build_scene(ctx, key)
+    film_t.zero_()
     torch.cuda.synchronize(dev)
     film = capi.Film(ctx, W, H, device_ptr=film_t.data_ptr())
-
     cfg = abi.PtConfig.default()
-    cfg.spp = (args.warmup + args.steps) * SPP_PER_PASS
+    cfg.spp = (warmup + steps) * SPP_PER_STEP
     cfg.spp_per_pass, cfg.max_depth, cfg.rr_depth, cfg.use_nee = SPP_PER_PASS, 12, 5, 1
-    cfg.force_diffuse = 0 if args.full_graph else 1
+    cfg.force_diffuse = CONFIGS[key]["force_diffuse"]
     cfg.filter_type, cfg.filter_radius = abi.FILTER_GAUSSIAN, 1.5
-    weak = world > 1 and args.scaling == "weak"
+    weak = world > 1 and scaling == "weak"
     if weak:
         cfg.sampler_seed = rank  # independent sample set per GPU (sampler/mod.rs:148-160 seeds the per-pixel streams from it)
     else:
@@ -160,9 +167,9 @@ def main():
         cfg = distributed.shard_config(cfg, rank, world)
 
     se = capi.PtSession(ctx, scene, cfg, film)
-    if args.warmup > 0:
-        se.passes(args.warmup, blocking=True)
-    if world > 1 and args.backend == "nccl":
+    if warmup > 0:
+        se.passes(warmup * PASSES_PER_STEP, blocking=True)
+    if world > 1 and backend == "nccl":
         # warm the collective up too (RCCL builds its rings / proxy connections on the first reduce of a given size):
         # same message size as the film, on a scratch tensor, outside the timed region
         scratch = torch.zeros_like(film_t)
@@ -179,9 +186,9 @@ def main():
 
     sync()
     t0 = time.perf_counter()
-    se.passes(args.steps, blocking=True)
+    se.passes(steps * PASSES_PER_STEP, blocking=True)
     if world > 1:
-        if args.backend == "gloo":
+        if backend == "gloo":
             host = film_t.cpu()
             distributed.reduce_film(host, dst=0)
             film_t.copy_(host)
@@ -190,11 +197,97 @@ def main():
     sync()
     t1 = time.perf_counter()
     s1 = se.end()
-
-    elapsed = t1 - t0
     d = {k: s1[k] - s0[k] for k in ("n_samples", "n_closest", "n_shadow", "n_shaded", "n_node_visits", "n_tri_tests")}
     d["kernel_ms"] = s1["kernel_ms"] - s0["kernel_ms"]
     d["n_launches"] = s1["n_launches"] - s0["n_launches"]
+    info = scene.info()
+    d["node_bytes"] = int(getattr(info, "node_bytes", 64) or 64)
+    d["tri_bytes"] = int(getattr(info, "tri_bytes", 48) or 48)
+    sinfo["weak"] = weak
+    sinfo["spp_done"] = (warmup + steps) * SPP_PER_STEP
+    del film, scene
+    return t1 - t0, d, sinfo
+
+
+def roofline_block(key, d):
+    """The dominant kernel (k_pt_pass) of this rank: algorithmic bytes per launch / average launch duration (HIP events
+    around each launch on the context's own stream), next to what the PMC counters measured for the same launch shape."""
+    launches = max(1, d["n_launches"])
+    model_bytes = algorithmic_bytes(d)
+    bytes_per_launch = model_bytes / launches
+    avg_launch_s = d["kernel_ms"] * 1e-3 / launches
+    achieved = bytes_per_launch / avg_launch_s / 1e9
+    out = {
+        "bound": "hbm",
+        "achieved": achieved,
+        "achieved_is": "ALGORITHMIC bytes of the SURVEY.md 8(d) byte model (device counters x record sizes) / launch time -- not measured traffic",
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": None,
+        "kernel": "k_pt_pass",
+        "launches": d["n_launches"],
+        "avg_launch_ms": avg_launch_s * 1e3,
+        "algorithmic_bytes_per_launch": bytes_per_launch,
+        "algorithmic_bytes_per_sample": model_bytes / max(1, d["n_samples"]),
+    }
+    m = measured_counters(key, PASSES_PER_STEP, W * H)
+    samples_per_launch = d["n_samples"] / launches
+    if m:
+        if m.get("hbm_bytes_per_launch") is not None and m.get("samples_per_launch") == samples_per_launch:
+            out["traffic"] = m["hbm_bytes_per_launch"]
+        elif m.get("hbm_bytes_per_sample") is not None:
+            out["traffic"] = m["hbm_bytes_per_sample"] * samples_per_launch
+        if out["traffic"] is not None:
+            out["hbm_measured_gbs"] = out["traffic"] / avg_launch_s / 1e9
+            out["hbm_measured_frac"] = out["hbm_measured_gbs"] / HBM_PEAK_GBS
+        for k in ("valu_busy", "valu_lane_utilisation", "wait_share", "binding_limiter", "source"):
+            if k in m:
+                out[k] = m[k]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c2", choices=list(CONFIGS), help="the timed workload (BASELINE.json configs[1..3])")
+    ap.add_argument("--also", default=None, help="comma list of further configs measured once each after the timed one, reported under "
+                                                   "extra_configs (default at N = 1 with --config c2: c3,c4; 'none' to skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-graph", action="store_true", help="same as --config c3")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong (default) = the ONE frame's 32x32 pixel tiles round-robin over the GPUs, identical image for "
+                         "every N; weak = every GPU renders the whole frame with its own sampler seed (N independent sample sets)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only for smoke-testing the "
+                         "multi-rank path on a box with fewer GPUs than ranks: all ranks then share device 0)")
+    args = ap.parse_args()
+    if args.full_graph:
+        args.config = "c3"
+
+    import torch
+
+    from akari_render_amd import capi, distributed
+
+    rank, world, local_rank = distributed.env_rank_world()
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus} (WORLD_SIZE={world})"
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.backend == "gloo":
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
+        distributed.init_process_group(args.backend)
+    import torch.distributed as dist
+
+    ctx = capi.Context(local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    film_t = torch.zeros(7 * W * H, dtype=torch.float32, device=dev)
+    key = args.config
+    elapsed, d, sinfo = run_config(ctx, key, args.steps, args.warmup, rank, world, args.scaling, film_t, torch, dist, args.backend, dev)
+    weak = sinfo["weak"]
+
     if world > 1:
         cdev = dev if args.backend == "nccl" else torch.device("cpu")
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -206,21 +299,18 @@ def main():
     else:
         total_samples = d["n_samples"]
     n_sets = world if weak else 1
-    assert total_samples == n_sets * W * H * SPP_PER_PASS * args.steps, (total_samples, n_sets * W * H * SPP_PER_PASS * args.steps)
+    assert total_samples == n_sets * W * H * SPP_PER_STEP * args.steps, (total_samples, n_sets * W * H * SPP_PER_STEP * args.steps)
 
     if rank == 0:
-        # frame sanity inside the bench: every pixel got its samples, film finite
-        wsum = float(film_t[6 * W * H :].sum().item())
-        assert wsum == float(n_sets * W * H) * (args.warmup + args.steps) * SPP_PER_PASS, wsum
+        # frame sanity inside the bench: every pixel got its samples (exact per-pixel comparison), film finite
+        expect_w = float(n_sets * sinfo["spp_done"])
+        wplane = film_t[6 * W * H:]
+        assert bool((wplane == expect_w).all().item()), (float(wplane.min().item()), float(wplane.max().item()), expect_w)
         assert bool(torch.isfinite(film_t).all().item())
-        # dominant kernel (k_pt_pass) of THIS rank: algorithmic bytes per launch / average launch duration (HIP events
-        # recorded around each launch on the context's stream)
-        launches = max(1, d["n_launches"])
-        bytes_per_launch = algorithmic_bytes(d) / launches
-        avg_launch_s = d["kernel_ms"] * 1e-3 / launches
-        achieved = bytes_per_launch / avg_launch_s / 1e9
+        cfgd = CONFIGS[key]
+        scal = "weak" if weak else "strong"
         out = {
-            "metric": "Msamples/s (whole node), 1080p Cornell box, path tracer",
+            "metric": "Msamples/s (whole node), 1080p path tracer, " + cfgd["name"] + (" -- weak scaling: N independent sample sets" if weak else ""),
             "value": total_samples / elapsed / 1e6,
             "unit": "Msamples/s",
             "n_gpus": args.gpus,
@@ -228,35 +318,43 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True,
-            "scaling": args.scaling,
+            "scaling": scal,
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic: scenes/cbox (36 triangles, reference scene data) at 1920x1080, independent sampler, seed " + ("= rank" if weak else "0"),
+            "data": "synthetic: " + ("scenes/cbox (36 triangles, reference scene data)" if cfgd["scene"] == "cbox" else "procedural hall, generator seed 1234")
+                    + f" at {W}x{H}, independent sampler, seed " + ("= rank" if weak else "0"),
             "config": {
-                "workload": ("cbox 1920x1080, full Cycles-subset shader graph" if args.full_graph else "cbox 1920x1080, diffuse-only BSDF (force_diffuse)")
-                            + f", {SPP_PER_PASS} spp per step, max_depth 12, rr_depth 5, NEE, gaussian filter r=1.5",
-                "spp_total": args.steps * SPP_PER_PASS * n_sets,
+                "workload": cfgd["workload"] + ", max_depth 12, rr_depth 5, NEE, gaussian filter r=1.5",
+                "baseline_config": f"BASELINE.json configs[{cfgd['baseline_config']}]",
+                "spp_per_step": SPP_PER_STEP,
+                "spp_total": args.steps * SPP_PER_STEP * n_sets,
                 "parallelism": ("single GPU" if args.gpus == 1 else
-                                f"{args.gpus} independent sample sets of {args.steps * SPP_PER_PASS} spp (sampler seed = rank), one per GPU, films sum-reduced (RCCL)" if weak else
-                                f"pixel tiles 32x32 round-robin over {args.gpus} GPU(s), film sum-reduce (RCCL)"),
+                                f"{args.gpus} independent sample sets of {args.steps * SPP_PER_STEP} spp (sampler seed = rank), one per GPU, films sum-reduced (RCCL)" if weak else
+                                f"pixel tiles 32x32 round-robin over {args.gpus} GPUs, film sum-reduce (RCCL)"),
+                **{k: v for k, v in sinfo.items() if k not in ("weak", "spp_done")},
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(args, d),
-                "kernel": "k_pt_pass",
-                "launches": d["n_launches"],
-                "avg_launch_ms": avg_launch_s * 1e3,
-                "algorithmic_bytes_per_sample": algorithmic_bytes(d) / max(1, d["n_samples"]),
-                "note": "byte model of SURVEY.md 8(d); on the 36-triangle cbox the kernel keeps path state in registers, so real HBM traffic is far below the model (see DESIGN.md)",
-            },
-            "counters": {k: d[k] for k in ("n_samples", "n_closest", "n_shadow", "n_shaded")},
+            "roofline": roofline_block(key, d),
+            "counters": {k: d[k] for k in ("n_samples", "n_closest", "n_shadow", "n_shaded", "n_node_visits", "n_tri_tests")},
         }
+        also = args.also
+        if also is None:
+            also = "c3,c4" if (args.gpus == 1 and key == "c2") else "none"
+        extra = {}
+        for k2 in [k for k in also.split(",") if k and k != "none" and k != key]:
+            try:
+                e2, d2, si2 = run_config(ctx, k2, 1, 0 if k2 == "c4" else 1, 0, 1, "strong", film_t, torch, dist, args.backend, dev)
+                extra[k2] = {"metric": "Msamples/s, " + CONFIGS[k2]["name"], "value": d2["n_samples"] / e2 / 1e6, "unit": "Msamples/s",
+                             "steps": 1, "ms_per_step": e2 * 1e3, "workload": CONFIGS[k2]["workload"],
+                             "rays_per_s_G": (d2["n_closest"] + d2["n_shadow"]) / e2 / 1e9,
+                             "roofline": roofline_block(k2, d2),
+                             "counters": {k: d2[k] for k in ("n_samples", "n_closest", "n_shadow", "n_shaded", "n_node_visits", "n_tri_tests")},
+                             **{k: v for k, v in si2.items() if k not in ("weak", "spp_done")}}
+            except Exception as ex:  # a secondary leg must not cost the headline line
+                extra[k2] = {"error": f"{type(ex).__name__}: {ex}"}
+        if extra:
+            out["extra_configs"] = extra
         if args.gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(*host_threads())
+            out["cpu_baseline"] = cpu_baseline(key, *host_threads())
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -39,7 +39,8 @@ typedef enum {
     AKR_ERR_IO = -4,           /* scene / method file could not be read */
     AKR_ERR_PARSE = -5,        /* malformed JSON or unsupported node */
     AKR_ERR_UNSUPPORTED = -6,  /* feature of the reference that this build does not cover */
-    AKR_ERR_OUT_OF_MEMORY = -7
+    AKR_ERR_OUT_OF_MEMORY = -7,
+    AKR_ERR_RENDER = -8        /* the device ran but the result is not a valid render (e.g. mcmc bootstrap found no light path) */
 } akr_status;
 
 typedef struct akr_context akr_context;
@@ -302,7 +303,10 @@ AKR_API int32_t akr_film_resolve(akr_film *film, float *dst_rgb);
 AKR_API int32_t akr_film_set_splat_scale(akr_film *film, float scale);
 AKR_API int32_t akr_film_get_splat_scale(const akr_film *film, float *scale);
 /* Wraps caller-owned device memory (7 * W * H floats, reference layout, e.g. a torch tensor that a
- * torch.distributed/RCCL reduce will run on) as a film; akr_film_destroy then leaves the memory alone. */
+ * torch.distributed/RCCL reduce will run on) as a film; akr_film_destroy then leaves the memory alone. The memory must
+ * be a plain device allocation (hipMalloc) on the context's GPU: host-mapped, managed or fine-grained memory is rejected
+ * with AKR_ERR_INVALID_ARGUMENT, because the splatting integrators (gpt, mcmc_opt) use hardware float atomics, which
+ * such memory silently drops. */
 AKR_API int32_t akr_film_wrap(akr_context *ctx, uint32_t width, uint32_t height, void *device_ptr, akr_film **out);
 /* Device pointer + byte size of the accumulator, for an RCCL reduce issued by the host application
  * (one process per GPU). The pointer stays valid until akr_film_destroy. */
