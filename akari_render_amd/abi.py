@@ -289,6 +289,10 @@ class SceneInfo(C.Structure):
         ("n_bvh_nodes", C.c_uint32),
         ("uses_bvh", C.c_uint32),
         ("device_bytes", C.c_uint64),
+        ("node_bytes", C.c_uint32),
+        ("node_stride_bytes", C.c_uint32),
+        ("tri_bytes", C.c_uint32),
+        ("bvh_depth", C.c_uint32),
     ]
 
 

@@ -112,5 +112,37 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_variant(name: str, extra_flags, verbose: bool = False) -> str:
+    """An A/B build of the library with extra compiler flags (e.g. -DAKR_BVH_NODE_WORDS=32) next to the product:
+    akari_render_amd/variants/libakari_hip_<name>.so, selected at run time with AKR_HIP_LIB=<path> (measurement only)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    obj = os.path.join(HERE, "build", "obj_" + name)
+    out_dir = os.path.join(HERE, "variants")
+    os.makedirs(obj, exist_ok=True)
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, f"libakari_hip_{name}.so")
+
+    def compile_one(src: str):
+        o = os.path.join(obj, src.replace("/", "_") + ".o")
+        res = subprocess.run([hipcc] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-I", CSRC, "-o", o],
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        return o, res.returncode, res.stdout
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        results = list(ex.map(compile_one, SOURCES))
+    if any(rc != 0 for _, rc, _ in results):
+        raise RuntimeError("hipcc failed:\n" + "".join(o for _, _, o in results))
+    res = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [o for o, _, _ in results] + ["-o", out],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc (link) failed:\n" + res.stdout)
+    return out
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":
+        print(build_variant(sys.argv[2], sys.argv[3:], verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

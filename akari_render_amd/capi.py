@@ -63,7 +63,8 @@ def lib() -> C.CDLL:
         return _lib
     if not os.path.exists(LIB):
         build()
-    L = C.CDLL(LIB)
+    # AKR_HIP_LIB: an A/B build of the same library (build.build_variant) for measurements; the product is LIB
+    L = C.CDLL(os.environ.get("AKR_HIP_LIB") or LIB)
     vp, u32, u64, i32, f32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_float
     fp, up, u64p, vpp = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p)
     L.akr_last_error.restype = C.c_char_p

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void k_aov(const PtParams p_in, uint32_t spp, 
             generate_ray<PMJ>(p, px, py, smp, o, d);
             Hit hit;
             n_closest++;
-            bool found = BVH ? trace_bvh4<false, TEX>(sc, o, d, 0.0f, 1e20f, kInvalid, kInvalid, hit, tc.stack, tc.cnt)
+            bool found = BVH ? trace_bvh<false, TEX>(sc, o, d, 0.0f, 1e20f, kInvalid, kInvalid, hit, tc.stack, tc.cnt)
                              : trace_exhaustive<false, TEX>(sc, o, d, 0.0f, 1e20f, kInvalid, kInvalid, hit);
             vec3 c = mk3(0, 0, 0);
             if (found) {

@@ -228,134 +228,152 @@ AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, u
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// BVH4 traversal (one ray per lane, while-while). Node layout: host/bvh.cpp. The per-lane stack lives in LDS,
-// strided by the workgroup size so that lane i of every wave touches bank i (no conflicts): 4 B x depth x 256.
-constexpr uint32_t kBvhStackDepth = 32;
-constexpr uint32_t kBvhLeafBit = 0x80000000u;
+// 8-wide compressed BVH traversal (node layout and builder: host/bvh.cpp; after Ylitie, Karras & Laine, HPG 2017).
+//
+// One ray per lane. A lane's state is a NODE GROUP G = child_base (24 bits) | hit bits of up to 8 sibling nodes, in
+// visiting order (bits 24..31), a TRIANGLE GROUP (tbase, T) = up to 24 pending triangles of the node visited last, and a
+// stack of node groups in LDS (strided by the workgroup size: lane i of every wave touches bank i). A node's children are
+// tested together; those the ray enters become the new G, ordered by octant: slot s sits at bit 24 + (s ^ octinv), the
+// highest bit is the nearest child, so "pop the nearest" is one count-leading-zeros and nothing is sorted. The siblings
+// left over go to the stack as ONE entry: a traversal holds at most one entry per tree level and the stack
+// (kBvhStackDepth levels, checked against the tree's depth when the scene is built) cannot overflow.
+//
+// Every step a lane does ONE thing -- test its next pending triangle, or fetch and test its next node -- and both kinds
+// of lane fetch through the SAME five 16-byte loads from a per-lane address (64-byte triangle record: Woop rows + global
+// id; 80-byte node). The wave waits once per step whatever mix of nodes and triangles its lanes are at: on the
+// 10 M-triangle hall the previous while-while BVH4 loop ran at 26 % lane utilisation, all of it waiting on dependent
+// fetches.
+// The box test only culls and does not have to follow the AKR-F32 contract (the oracle has no BVH): it must be conservative,
+// which the padding of the boxes (host/bvh.cpp) guarantees; so it may use v_rcp_f32, fma and min3 / max3.
 constexpr uint32_t kBvhDone = 0xfffffffeu;
 
 struct TraceCounters {
     uint32_t nodes, tris, overflow;
 };
 
-// 1/d for the slab test, |d| floored at 1e-20 so that 0 * inf never appears. The box test only culls: it does not
-// have to follow the AKR-F32 contract (the oracle has no BVH), it only has to be conservative, which the padding of
-// the boxes (host/bvh.cpp) guarantees with a margin of ~10^4 ulp; so it may use v_rcp_f32, fma and v_min3/v_max3.
+// 1/d for the slab test, |d| floored at 1e-20 so that 0 * inf never appears.
 AKR_D float safe_inv(float d) {
     float a = abs_f(d) < 1e-20f ? __builtin_copysignf(1e-20f, d) : d;
     return __builtin_amdgcn_rcpf(a);
 }
-// One BVH4 node: 64 bytes = 4 x 16-byte loads (host/bvh.cpp). Child boxes are 8-bit offsets from the node's own
-// (padded) lower corner in units of a per-axis power of two, rounded outwards, so the decoded boxes contain the exact
-// ones: lo = origin + q_lo * 2^e, hi = origin + q_hi * 2^e. With t = plane * inv + noi the slab distances become
-// t = q * (2^e * inv) + (origin * inv + noi): one v_cvt_f32_ubyte + one fma per plane.
-// Writes the entry distance of every child the ray enters within [tmin, tlimit] (inf otherwise) and the child refs.
-AKR_D void bvh4_node_test(const DScene& sc, uint32_t node, vec3 inv, vec3 noi, float tmin, float tlimit, float tn[4], uint32_t ch[4]) {
-    const uint4* n = (const uint4*)sc.bvh_nodes + (size_t)node * 4;
-    const uint4 r0 = n[0], r1 = n[1], r2 = n[2], r3 = n[3];
-    const float sx = u2f((r0.w & 0xffu) << 23), sy = u2f(((r0.w >> 8) & 0xffu) << 23), sz = u2f(((r0.w >> 16) & 0xffu) << 23);
-    const float ax = __builtin_fmaf(u2f(r0.x), inv.x, noi.x), ay = __builtin_fmaf(u2f(r0.y), inv.y, noi.y), az = __builtin_fmaf(u2f(r0.z), inv.z, noi.z);
-    const float bx = sx * inv.x, by = sy * inv.y, bz = sz * inv.z;
-    ch[0] = r2.z; ch[1] = r2.w; ch[2] = r3.x; ch[3] = r3.y;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const float lx = (float)((r1.x >> (8 * i)) & 0xffu), ly = (float)((r1.y >> (8 * i)) & 0xffu), lz = (float)((r1.z >> (8 * i)) & 0xffu);
-        const float hx = (float)((r1.w >> (8 * i)) & 0xffu), hy = (float)((r2.x >> (8 * i)) & 0xffu), hz = (float)((r2.y >> (8 * i)) & 0xffu);
-        float t0x = __builtin_fmaf(lx, bx, ax), t1x = __builtin_fmaf(hx, bx, ax);
-        float t0y = __builtin_fmaf(ly, by, ay), t1y = __builtin_fmaf(hy, by, ay);
-        float t0z = __builtin_fmaf(lz, bz, az), t1z = __builtin_fmaf(hz, bz, az);
-        float near = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
-                                     __builtin_fmaxf(__builtin_fminf(t0z, t1z), tmin));
-        float far = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),
-                                    __builtin_fminf(__builtin_fmaxf(t0z, t1z), tlimit));
-        tn[i] = ((near <= far) & (ch[i] != kInvalid)) ? near : __builtin_inff();  // empty slots carry ref 0xffffffff
+AKR_D uint32_t byte_of(uint32_t w, int i) { return (w >> (8 * i)) & 0xffu; }
+
+struct Trav {  // one ray in flight
+    vec3 o, d, inv, noi;   // t = plane * inv + noi
+    float tmin, tmax, best_t, best_u, best_v;
+    uint32_t ex0, ex1, best;
+    uint32_t G, T, tbase, sp, octinv4;
+    bool active;
+};
+AKR_D void trav_begin(Trav& s, vec3 o, vec3 d, float tmin, float tmax, uint32_t ex0, uint32_t ex1) {
+    s.o = o; s.d = d;
+    s.inv = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+    s.noi = mk3(-o.x * s.inv.x, -o.y * s.inv.y, -o.z * s.inv.z);
+    s.tmin = tmin; s.tmax = tmax;
+    s.best_t = tmax; s.best_u = 0.0f; s.best_v = 0.0f; s.best = kInvalid;
+    s.ex0 = ex0; s.ex1 = ex1;
+    // octinv: bit a set = the ray travels towards +a, i.e. meets the children on the low side of axis a first
+    const uint32_t oi = (s.inv.x >= 0.0f ? 1u : 0u) | (s.inv.y >= 0.0f ? 2u : 0u) | (s.inv.z >= 0.0f ? 4u : 0u);
+    s.octinv4 = oi * 0x01010101u;
+    s.G = 1u << (24u + oi);  // the group {root}: base 0, slot 0 at bit 24 + (0 ^ oi)
+    s.T = 0; s.tbase = 0; s.sp = 0;
+    s.active = tmax >= tmin;
+}
+
+// One step of one lane: a triangle test if one is pending, else the next node. MODE 0: closest hit, 1: any hit, 2: `any_rt`
+// decides per lane (the wavefront schedule traces both kinds of ray in one loop).
+template <int MODE, bool TEX>
+AKR_D void trav_step(const DScene& sc, Trav& s, uint32_t* __restrict__ stack, TraceCounters& cnt, bool any_rt = false) {
+    const bool any_hit = MODE == 2 ? any_rt : (MODE == 1);
+    const bool do_tri = s.T != 0;
+    const uint4* p;
+    if (do_tri) {
+        const uint32_t b = (uint32_t)__builtin_ctz(s.T);
+        s.T &= s.T - 1u;
+        p = (const uint4*)sc.woop + (size_t)(s.tbase + b) * (kBvhTriWords / 4);
+    } else {
+        if ((s.G >> 24) == 0) {  // the caller guarantees sp > 0 here
+            s.sp--;
+            s.G = stack[s.sp * 256u];
+        }
+        const uint32_t j = 31u - (uint32_t)__builtin_clz(s.G);  // nearest pending sibling
+        s.G &= ~(1u << j);
+        if ((s.G >> 24) != 0) {  // the others wait as one entry
+            if (s.sp < kBvhStackDepth) {
+                stack[s.sp * 256u] = s.G;
+                s.sp++;
+            } else {
+                cnt.overflow = 1;  // unreachable for a tree scene_build.cpp accepted; kept as a tripwire (akr_pt_stats)
+            }
+        }
+        const uint32_t slot = (j - 24u) ^ (s.octinv4 & 7u);
+        p = sc.bvh_nodes + (size_t)((s.G & 0xffffffu) + slot) * (kBvhNodeWords / 4);
     }
+    // the one fetch of the step; a triangle record is 64 bytes, so its lanes re-read word 0 instead of running into the next line
+    const uint4 w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3], w4 = p[do_tri ? 0 : 4];
+    if (do_tri) {
+        cnt.tris++;
+        float t, u, v;
+        bool h = tri_test(s.o, s.d, make_float4(u2f(w0.x), u2f(w0.y), u2f(w0.z), u2f(w0.w)), make_float4(u2f(w1.x), u2f(w1.y), u2f(w1.z), u2f(w1.w)),
+                          make_float4(u2f(w2.x), u2f(w2.y), u2f(w2.z), u2f(w2.w)), s.tmin, s.tmax, t, u, v);
+        if (h) {
+            const uint32_t gid = w3.x;
+            h = (gid != s.ex0) & (gid != s.ex1);
+            if (h && sc.has_alpha) h = alpha_test<TEX>(sc, gid, u, v);
+            if (h) {
+                if (any_hit) {
+                    s.best = gid;
+                    s.T = 0; s.G = 0; s.sp = 0;  // any hit: done
+                } else {
+                    const bool better = (s.best == kInvalid) | (t < s.best_t) | ((t == s.best_t) & (gid < s.best));
+                    if (better) { s.best_t = t; s.best_u = u; s.best_v = v; s.best = gid; }
+                }
+            }
+        }
+    } else {
+        cnt.nodes++;
+        const float limit = s.best_t;  // closest hit: culls with the best distance so far (non-strict: equal-t lower ids stay reachable)
+        const float bx = u2f((w0.w & 0xffu) << 23) * s.inv.x, by = u2f(((w0.w >> 8) & 0xffu) << 23) * s.inv.y, bz = u2f(((w0.w >> 16) & 0xffu) << 23) * s.inv.z;
+        const float ax = __builtin_fmaf(u2f(w0.x), s.inv.x, s.noi.x), ay = __builtin_fmaf(u2f(w0.y), s.inv.y, s.noi.y), az = __builtin_fmaf(u2f(w0.z), s.inv.z, s.noi.z);
+        // per axis: the byte planes the ray enters through (near) and leaves through (far)
+        const bool nx = s.inv.x < 0.0f, ny = s.inv.y < 0.0f, nz = s.inv.z < 0.0f;
+        const uint32_t qnx[2] = {nx ? w3.z : w2.x, nx ? w3.w : w2.y}, qfx[2] = {nx ? w2.x : w3.z, nx ? w2.y : w3.w};
+        const uint32_t qny[2] = {ny ? w4.x : w2.z, ny ? w4.y : w2.w}, qfy[2] = {ny ? w2.z : w4.x, ny ? w2.w : w4.y};
+        const uint32_t qnz[2] = {nz ? w4.z : w3.x, nz ? w4.w : w3.y}, qfz[2] = {nz ? w3.x : w4.z, nz ? w3.y : w4.w};
+        uint32_t hitmask = 0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t meta4 = h ? w1.w : w1.z;
+            // inner children (index bits 3 and 4 set: 24..31) get their bit position xor-ed with the ray's octant
+            const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+            const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xffu;
+            const uint32_t bit_index4 = (meta4 ^ (s.octinv4 & inner_mask4)) & 0x1f1f1f1fu;
+            const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float tnx = __builtin_fmaf((float)byte_of(qnx[h], i), bx, ax), tfx = __builtin_fmaf((float)byte_of(qfx[h], i), bx, ax);
+                const float tny = __builtin_fmaf((float)byte_of(qny[h], i), by, ay), tfy = __builtin_fmaf((float)byte_of(qfy[h], i), by, ay);
+                const float tnz = __builtin_fmaf((float)byte_of(qnz[h], i), bz, az), tfz = __builtin_fmaf((float)byte_of(qfz[h], i), bz, az);
+                const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, s.tmin));
+                const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, limit));
+                if (tn <= tf) hitmask |= byte_of(child_bits4, i) << byte_of(bit_index4, i);  // empty slots have no child bits
+            }
+        }
+        s.G = (w1.x & 0xffffffu) | (hitmask & 0xff000000u);
+        s.T = hitmask & 0x00ffffffu;
+        s.tbase = w1.y;
+    }
+    s.active = (s.T != 0) | ((s.G >> 24) != 0) | (s.sp != 0);
 }
 
 template <bool ANY_HIT, bool TEX = false>
-AKR_D bool trace_bvh4(const DScene& sc, vec3 o, vec3 d, float tmin, float tmax, uint32_t ex0, uint32_t ex1, Hit& hit,
-                      uint32_t* __restrict__ stack, TraceCounters& cnt) {
-    const vec3 inv = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
-    const vec3 noi = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);  // t = plane * inv + noi
-    float best_t = tmax;
-    uint32_t best = kInvalid;
-    float best_u = 0.0f, best_v = 0.0f;
-    uint32_t sp = 0;
-    uint32_t cur = 0;  // root is always an inner node
-#define AKR_PUSH(ref)                                  \
-    {                                                  \
-        if (sp < kBvhStackDepth) {                     \
-            stack[sp * 256u] = (ref);                  \
-            sp++;                                      \
-        } else {                                       \
-            cnt.overflow = 1;                          \
-        }                                              \
-    }
-    for (;;) {
-        while (!(cur & kBvhLeafBit)) {
-            cnt.nodes++;
-            float tn[4];
-            uint32_t ch[4];
-            bvh4_node_test(sc, cur, inv, noi, tmin, best_t, tn, ch);
-            if (!ANY_HIT) {
-                // sort the four (tn, ch) pairs ascending with a 5-comparator network
-#define AKR_CSWAP(a, b)                                          \
-    {                                                            \
-        bool sw = tn[b] < tn[a];                                 \
-        float tf = sw ? tn[b] : tn[a], tg = sw ? tn[a] : tn[b];  \
-        uint32_t cf = sw ? ch[b] : ch[a], cg = sw ? ch[a] : ch[b]; \
-        tn[a] = tf; tn[b] = tg; ch[a] = cf; ch[b] = cg;          \
-    }
-                AKR_CSWAP(0, 1) AKR_CSWAP(2, 3) AKR_CSWAP(0, 2) AKR_CSWAP(1, 3) AKR_CSWAP(1, 2)
-#undef AKR_CSWAP
-                // push far-to-near so that the nearest is popped first
-                if (tn[3] < __builtin_inff()) AKR_PUSH(ch[3])
-                if (tn[2] < __builtin_inff()) AKR_PUSH(ch[2])
-                if (tn[1] < __builtin_inff()) AKR_PUSH(ch[1])
-                if (tn[0] < __builtin_inff()) {
-                    cur = ch[0];
-                } else if (sp > 0) {
-                    sp--; cur = stack[sp * 256u];
-                } else {
-                    cur = kBvhDone;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    if (tn[i] < __builtin_inff()) AKR_PUSH(ch[i])
-                if (sp > 0) { sp--; cur = stack[sp * 256u]; } else { cur = kBvhDone; }
-            }
-        }
-        if (cur == kBvhDone) break;
-        {   // leaf: up to 4 triangles, 48 B each
-            const uint32_t first = cur & 0x0fffffffu, count = (cur >> 28) & 7u;
-            for (uint32_t i = 0; i < count; i++) {
-                const uint32_t k = first + i;
-                float4 r0 = sc.woop[3 * (size_t)k + 0], r1 = sc.woop[3 * (size_t)k + 1], r2 = sc.woop[3 * (size_t)k + 2];
-                cnt.tris++;
-                float t, u, v;
-                bool h = tri_test(o, d, r0, r1, r2, tmin, tmax, t, u, v);
-                if (h) {
-                    uint32_t gid = sc.tri_gid[k];
-                    h = (gid != ex0) & (gid != ex1);
-                    if (h && sc.has_alpha) h = alpha_test<TEX>(sc, gid, u, v);
-                    if (h) {
-                        if (ANY_HIT) {
-                            best = gid;
-                        } else {
-                            bool better = (best == kInvalid) | (t < best_t) | ((t == best_t) & (gid < best));
-                            if (better) { best_t = t; best_u = u; best_v = v; best = gid; }
-                        }
-                    }
-                }
-            }
-            if (ANY_HIT && best != kInvalid) break;
-            if (sp > 0) { sp--; cur = stack[sp * 256u]; } else break;
-        }
-    }
-#undef AKR_PUSH
-    hit.t = best_t; hit.u = best_u; hit.v = best_v; hit.gid = best;
-    return best != kInvalid;
+AKR_D bool trace_bvh(const DScene& sc, vec3 o, vec3 d, float tmin, float tmax, uint32_t ex0, uint32_t ex1, Hit& hit,
+                     uint32_t* __restrict__ stack, TraceCounters& cnt) {
+    Trav s;
+    trav_begin(s, o, d, tmin, tmax, ex0, ex1);
+    while (s.active) trav_step<ANY_HIT ? 1 : 0, TEX>(sc, s, stack, cnt);
+    hit.t = s.best_t; hit.u = s.best_u; hit.v = s.best_v; hit.gid = s.best;
+    return s.best != kInvalid;
 }
 
 }  // namespace akr

@@ -293,7 +293,7 @@ struct TraceCtx {
 };
 template <bool BVH, bool ANY_HIT>
 AKR_D bool trace(const PtParams& p, TraceCtx& tc, vec3 o, vec3 d, float tmin, float tmax, uint32_t ex0, uint32_t ex1, Hit& hit) {
-    if (BVH) return trace_bvh4<ANY_HIT>(p.sc, o, d, tmin, tmax, ex0, ex1, hit, tc.stack, tc.cnt);
+    if (BVH) return trace_bvh<ANY_HIT>(p.sc, o, d, tmin, tmax, ex0, ex1, hit, tc.stack, tc.cnt);
     return trace_exhaustive<ANY_HIT>(p.sc, o, d, tmin, tmax, ex0, ex1, hit);
 }
 

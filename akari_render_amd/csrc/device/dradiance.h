@@ -55,13 +55,13 @@ AKR_D vec3 radiance_sm(const PtParams& p, TraceCtx& tc, vec3 ro, vec3 rd, S& smp
     const DScene& sc = p.sc;
     auto closest = [&](vec3 o, vec3 d, uint32_t ex0, Hit& h) {
         n_rays++;
-        return BVH ? trace_bvh4<false, TEX>(sc, o, d, 0.0f, 1e20f, ex0, kInvalid, h, tc.stack, tc.cnt)
+        return BVH ? trace_bvh<false, TEX>(sc, o, d, 0.0f, 1e20f, ex0, kInvalid, h, tc.stack, tc.cnt)
                    : trace_exhaustive<false, TEX>(sc, o, d, 0.0f, 1e20f, ex0, kInvalid, h);
     };
     auto occluded_ray = [&](vec3 o, vec3 d, float tmax, uint32_t ex0, uint32_t ex1) {
         Hit h;
         n_rays++;
-        return BVH ? trace_bvh4<true, TEX>(sc, o, d, 0.0f, tmax, ex0, ex1, h, tc.stack, tc.cnt)
+        return BVH ? trace_bvh<true, TEX>(sc, o, d, 0.0f, tmax, ex0, ex1, h, tc.stack, tc.cnt)
                    : trace_exhaustive<true, TEX>(sc, o, d, 0.0f, tmax, ex0, ex1, h);
     };
     auto material_of = [&](const SurfacePoint& s, DMaterial& m) {

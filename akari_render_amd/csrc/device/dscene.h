@@ -1,8 +1,10 @@
 // dscene.h -- the scene as it lives in HBM, and the hit -> SurfaceInteraction reconstruction.
 //
 // Layout (all arrays 16-byte aligned, read with 16-byte vector loads):
-//   woop      3 x float4 per triangle, in traversal order      : the ray-triangle test's 48 B record
-//   tri_gid   u32 per triangle in traversal order              : global triangle id = inst_tri_offset[inst] + prim
+//   woop      exhaustive path: 3 x float4 per triangle (the ray-triangle test's 48 B record), global order;
+//             BVH path: 4 x float4 per triangle in traversal order = the 48 B record | global triangle id | 12 B unused
+//             (one 64-byte fetch per test; global id = inst_tri_offset[inst] + prim)
+//   bvh_nodes 8-wide compressed nodes, 80 B used of a kBvhNodeWords-word stride (host/bvh.cpp)
 //   shade     8 x float4 per triangle, indexed by global id    : everything surface_interaction needs (128 B)
 //   inst      8 x float4 per instance                          : object->world matrix and its cofactors (128 B)
 //   materials DMaterial[ ]                                     : folded shader graphs (256 B)
@@ -15,6 +17,16 @@
 namespace akr {
 
 constexpr uint32_t kInvalid = 0xffffffffu;
+
+// BVH record geometry shared by the host builder (host/bvh.cpp, scene_build.cpp) and the traversal (disect.h)
+#ifndef AKR_BVH_NODE_WORDS
+#define AKR_BVH_NODE_WORDS 20  // 20 = packed 80-byte nodes; 32 = one node per 128-byte line
+#endif
+constexpr uint32_t kBvhNodeWords = AKR_BVH_NODE_WORDS;  // u32 words from one node to the next (20 used)
+constexpr uint32_t kBvhTriWords = 16;                   // BVH path: 12 words Woop record + global id + 3 unused
+// Traversal stack entries per lane. A pending group of sibling nodes is ONE entry and a traversal holds at most one group
+// per tree level, so a tree of depth <= kBvhStackDepth can never overflow; scene_build.cpp rejects deeper trees.
+constexpr uint32_t kBvhStackDepth = 24;
 
 // shade record rows (float4 each):
 //  0: v0.xyz | uv0.x     1: v1.xyz | uv0.y     2: v2.xyz | uv1.x     (object-space vertices)
@@ -29,8 +41,8 @@ struct LightRec {  // one light = one emissive instance: where its triangles sit
 };
 
 struct DScene {
-    const float4* __restrict__ woop;
-    const uint32_t* __restrict__ tri_gid;   // nullptr = identity (exhaustive path)
+    const float4* __restrict__ woop;        // 3 float4 per triangle (exhaustive path) or 4 (BVH path: + global id)
+    const uint32_t* __restrict__ tri_gid;   // traversal order -> global id (host-side tests; the BVH path reads the id from the record)
     const float4* __restrict__ shade;
     const float4* __restrict__ normals;     // 6 x float4 per global triangle (per-corner normals, tangents) or nullptr
     const float4* __restrict__ inst;
@@ -47,7 +59,7 @@ struct DScene {
     const AliasPacked* __restrict__ light_alias;    // light_entries + light_pdf, packed
     const AliasPacked* __restrict__ area_alias;     // area_entries + area_pdf, packed
     const LightRec* __restrict__ lights;            // light_tri_offset + light_n_tris + light_inst (+ inst_tri_offset), packed
-    const float4* __restrict__ bvh_nodes;           // nullptr on the exhaustive path
+    const uint4* __restrict__ bvh_nodes;            // nullptr on the exhaustive path
     uint32_t n_tris, n_lights, n_nodes, has_alpha;
     uint64_t plane_share_mask;                      // exhaustive path: bit k = record k carries the plane row of record k-1
     TexScene tex;                                   // textures + shader-graph node lists (all nullptr without textures)

@@ -307,10 +307,10 @@ static void scene_finish(akr_scene* s) {
     d.light_alias = s->light_alias.as<AliasPacked>();
     d.area_alias = s->area_alias.as<AliasPacked>();
     d.lights = s->lights.as<LightRec>();
-    d.bvh_nodes = s->bvh_nodes.as<float4>();
+    d.bvh_nodes = s->bvh_nodes.as<uint4>();
     d.n_tris = cs.n_tris;
     d.n_lights = cs.n_lights;
-    d.n_nodes = (uint32_t)(cs.bvh_nodes.size() / 16);
+    d.n_nodes = (uint32_t)(cs.bvh_nodes.size() / kBvhNodeWords);
     d.has_alpha = cs.has_alpha ? 1u : 0u;
     d.plane_share_mask = 0;
     if (cs.bvh_nodes.empty())  // exhaustive path (<= 64 triangles): which records repeat their predecessor's plane row
@@ -565,9 +565,13 @@ AKR_API int32_t akr_scene_get_info(const akr_scene* s, akr_scene_info* info) {
     info->n_triangles = s->cs.n_tris;
     info->n_materials = (uint32_t)s->flat.materials.size();
     info->n_lights = s->cs.n_lights;
-    info->n_bvh_nodes = (uint32_t)(s->cs.bvh_nodes.size() / 16);
+    info->n_bvh_nodes = (uint32_t)(s->cs.bvh_nodes.size() / kBvhNodeWords);
     info->uses_bvh = s->cs.bvh_nodes.empty() ? 0u : 1u;
     info->device_bytes = s->device_bytes;
+    info->node_bytes = s->cs.bvh_nodes.empty() ? 0u : 80u;   // bytes a traversal reads per node visit
+    info->node_stride_bytes = s->cs.bvh_nodes.empty() ? 0u : kBvhNodeWords * 4u;
+    info->tri_bytes = s->cs.bvh_nodes.empty() ? 48u : kBvhTriWords * 4u;
+    info->bvh_depth = s->cs.bvh_depth;
     return AKR_OK;
 }
 AKR_API int32_t akr_scene_get_light(const akr_scene* s, uint32_t light, uint32_t* instance, float* power, float* pdf) {

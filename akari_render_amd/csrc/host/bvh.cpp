@@ -1,18 +1,24 @@
-// bvh.cpp -- host BVH4 builder (replaces the BLAS/TLAS build the reference delegates to LuisaCompute,
-// crates/akari_render/src/mesh.rs:288-294,331-333).
+// bvh.cpp -- host builder of the 8-wide compressed BVH (replaces the BLAS/TLAS build the reference delegates to
+// LuisaCompute, crates/akari_render/src/mesh.rs:288-294,331-333).
 //
-// Binned-SAH binary build over world-space triangle boxes (instances are flattened: every triangle is stored
-// once per instance, which is exact for the rigid/affine instance transforms of the scene graph), collapsed to
-// a 4-wide tree. Node = 64 B = 4 x 16-byte words (half of an f32 SoA node, so twice as many nodes per cache line
-// and four instead of seven loads per visit):
-//   word 0: origin.xyz (f32, the node's own padded lower corner) | exponent bytes ex, ey, ez (scale_a = 2^(e_a - 127))
-//   word 1: q_lo.x[4] | q_lo.y[4] | q_lo.z[4] | q_hi.x[4]      (one byte per child)
-//   word 2: q_hi.y[4] | q_hi.z[4] | child[0] | child[1]
-//   word 3: child[2] | child[3] | unused | unused
-// child box = origin + q * scale per axis, q_lo rounded down and q_hi rounded up (and verified in double), so the
-// decoded box always contains the exact padded box.
-// child reference: inner node -> node index; leaf -> 0x80000000 | count << 28 | first triangle (count 1..4);
-// empty slot -> reference 0xffffffff (its box is (+inf, -inf)); traversal skips it by reference.
+// Binned-SAH binary build over world-space triangle boxes (instances are flattened: every triangle is stored once per
+// instance, which is exact for the rigid/affine instance transforms of the scene graph), leaves of at most 3 triangles,
+// collapsed to an 8-wide tree in the compressed layout of Ylitie, Karras & Laine, "Efficient Incoherent Ray Traversal on
+// GPUs Through Compressed Wide BVHs" (HPG 2017), with one change: a node's inner children live at child_base + slot (unused
+// slots of the block are holes), so that a group of pending children is ONE 32-bit stack entry (24-bit base | 8 hit bits).
+//
+// Node = 80 bytes = 5 x 16-byte words, stored with a stride of kBvhNodeWords words (device/disect.h):
+//   word 0: p.xyz (f32, the node's own padded lower corner) | exponent bytes ex, ey, ez (scale_a = 2^(e_a - 127)), 0
+//   word 1: child_base (u32, < 2^24) | tri_base (u32) | meta[0..3] | meta[4..7]
+//   word 2: q_lo.x[0..7] | q_lo.y[0..7]          (one byte per child slot)
+//   word 3: q_lo.z[0..7] | q_hi.x[0..7]
+//   word 4: q_hi.y[0..7] | q_hi.z[0..7]
+// child box = p + q * scale per axis, q_lo rounded down and q_hi rounded up (verified in double), so the decoded box always
+// contains the exact padded box. meta byte of slot s: 0 = empty; inner child: 0x20 | (24 + s) -- its node is child_base + s;
+// leaf: (unary triangle count 1 / 3 / 7) << 5 | offset -- its triangles are tri_base + offset .. (at most 24 triangles under
+// one node). Children are assigned to slots so that bit a of the slot number says on which side of the node's centre along
+// axis a the child lies: a ray then visits the slots in the order slot ^ octant, near to far, without sorting distances.
+// Triangles are re-ordered so that every node's leaf triangles are contiguous (`order`).
 // Boxes are padded by `pad` so that every triangle the exhaustive test would report is reached by traversal
 // (the triangle test itself has an absolute slop of a few ulp(t); see DESIGN.md "BVH conservativeness").
 #include <algorithm>
@@ -21,6 +27,7 @@
 #include <cstring>
 #include <limits>
 #include <numeric>
+#include <stdexcept>
 #include <vector>
 
 namespace akr {
@@ -59,10 +66,11 @@ struct BinNode {
 };
 
 constexpr int kBins = 16;
-constexpr uint32_t kLeafMax = 4;
+constexpr uint32_t kLeafMax = 3;
 
 struct Builder {
     const float* bounds;
+    bool balanced = false;  // object-median splits only: depth = ceil(log2(n / leaf)), whatever the geometry
     std::vector<uint32_t>& order;
     std::vector<float> centroid;  // 3 / tri
     std::vector<BinNode> nodes;
@@ -100,6 +108,24 @@ struct Builder {
             nodes[it.node].first = it.first;
             nodes[it.node].count = it.count;
             if (it.count <= kLeafMax) continue;
+            if (balanced) {  // median of the centroids along their widest axis
+                int axis = 0;
+                for (int a = 1; a < 3; a++)
+                    if (cbox.hi[a] - cbox.lo[a] > cbox.hi[axis] - cbox.lo[axis]) axis = a;
+                auto* beg = order.data() + it.first;
+                std::nth_element(beg, beg + it.count / 2, beg + it.count,
+                                 [&](uint32_t x, uint32_t y) { return centroid[3ull * x + axis] < centroid[3ull * y + axis]; });
+                const uint32_t mid = it.first + it.count / 2;
+                int32_t l = (int32_t)nodes.size();
+                nodes.emplace_back();
+                int32_t r = (int32_t)nodes.size();
+                nodes.emplace_back();
+                nodes[it.node].left = l;
+                nodes[it.node].right = r;
+                stack.push_back({l, it.first, mid - it.first});
+                stack.push_back({r, mid, it.first + it.count - mid});
+                continue;
+            }
             // binned SAH over the three axes
             float best_cost = std::numeric_limits<float>::infinity();
             int best_axis = -1, best_split = -1;
@@ -171,38 +197,45 @@ struct Builder {
 };
 }  // namespace
 
-void build_bvh4(const std::vector<float>& tri_bounds, uint32_t n_tris, float pad, std::vector<uint32_t>& order, std::vector<float>& out_nodes) {
+// Result of the build. nodes: `stride` words per node (20 used). order[k] = source triangle of traversal-order triangle k.
+// depth = levels of the wide tree (root = 1) = the most stack entries a traversal can need (device/disect.h).
+// balanced = true: median splits and widest-subtree-first collapse instead of SAH: a tree of depth ~ log8(n), the fallback for
+// geometry whose SAH tree would be deeper than the traversal stack.
+void build_bvh8(const std::vector<float>& tri_bounds, uint32_t n_tris, float pad, uint32_t stride, bool balanced, std::vector<uint32_t>& order_out,
+                std::vector<uint32_t>& out_nodes, uint32_t& depth_out) {
+    std::vector<uint32_t> order;
     Builder b(tri_bounds.data(), n_tris, order);
+    b.balanced = balanced;
     b.build(0, n_tris);
     const auto& bn = b.nodes;
-    // collapse: each BVH4 node adopts up to 4 descendants of a binary node, always opening the child with the
-    // largest surface area first
-    struct Pending { int32_t bin; uint32_t out; };
+    struct Pending { int32_t bin; uint32_t out; uint32_t depth; };
     std::vector<Pending> queue;
-    out_nodes.clear();
-    out_nodes.resize(16, 0.0f);  // 16 words per node
-    queue.push_back({0, 0});
-    auto put_u32 = [](float* p, uint32_t v) { std::memcpy(p, &v, 4); };
-    // depth-first emission (LIFO): a node's inner children get consecutive slots right after the nodes emitted so far and
-    // each subtree is laid out before its siblings' subtrees, so a ray that descends stays within a few DRAM pages / L2
-    // lines instead of jumping level by level through the array as a breadth-first layout would make it do
+    out_nodes.assign(stride, 0u);
+    order_out.clear();
+    order_out.reserve(n_tris);
+    depth_out = 0;
+    queue.push_back({0, 0, 1});
+    auto fbits = [](float v) { uint32_t u; std::memcpy(&u, &v, 4); return u; };
+    // depth-first emission: a node's child block is allocated when the node is emitted and each subtree is laid out before
+    // its siblings' subtrees, so a ray that descends stays within a few DRAM pages / L2 lines
     while (!queue.empty()) {
         Pending pe = queue.back();
         queue.pop_back();
-        int32_t kids[4];
+        depth_out = std::max(depth_out, pe.depth);
+        int32_t kids[8];
         int nk = 0;
         const BinNode& root = bn[pe.bin];
         if (root.left < 0) {
-            kids[nk++] = pe.bin;  // the whole tree is a single leaf
+            kids[nk++] = pe.bin;  // the whole (sub)tree is a single leaf
         } else {
             kids[nk++] = root.left;
             kids[nk++] = root.right;
-            while (nk < 4) {
+            while (nk < 8) {  // open the inner child with the largest surface area (balanced: with the most triangles)
                 int pick = -1;
                 float best = -1.0f;
                 for (int i = 0; i < nk; i++) {
                     if (bn[kids[i]].left < 0) continue;
-                    float a = bn[kids[i]].box.half_area();
+                    float a = balanced ? (float)bn[kids[i]].count : bn[kids[i]].box.half_area();
                     if (a > best) { best = a; pick = i; }
                 }
                 if (pick < 0) break;
@@ -212,7 +245,7 @@ void build_bvh4(const std::vector<float>& tri_bounds, uint32_t n_tris, float pad
             }
         }
         // padded child boxes and their union (= this node's frame)
-        float clo[4][3], chi[4][3], origin[3], top[3];
+        float clo[8][3], chi[8][3], origin[3], top[3];
         for (int a = 0; a < 3; a++) { origin[a] = std::numeric_limits<float>::infinity(); top[a] = -origin[a]; }
         for (int i = 0; i < nk; i++)
             for (int a = 0; a < 3; a++) {
@@ -221,6 +254,36 @@ void build_bvh4(const std::vector<float>& tri_bounds, uint32_t n_tris, float pad
                 origin[a] = std::min(origin[a], clo[i][a]);
                 top[a] = std::max(top[a], chi[i][a]);
             }
+        // slot assignment: child c -> slot s maximising sum_a (s_a ? +1 : -1) * (centre_c - centre_node)_a, greedily by
+        // the largest remaining gain (the pairing the paper's reference implementation uses as well)
+        int slot_of[8], child_in[8];
+        for (int i = 0; i < 8; i++) { slot_of[i] = -1; child_in[i] = -1; }
+        {
+            float cost[8][8];
+            for (int c = 0; c < nk; c++)
+                for (int sl = 0; sl < 8; sl++) {
+                    float v = 0.0f;
+                    for (int a = 0; a < 3; a++) {
+                        float ext = top[a] - origin[a];
+                        float rel = ext > 0.0f ? (0.5f * (clo[c][a] + chi[c][a]) - 0.5f * (origin[a] + top[a])) / ext : 0.0f;
+                        v += ((sl >> a) & 1) ? rel : -rel;
+                    }
+                    cost[c][sl] = v;
+                }
+            for (int it = 0; it < nk; it++) {
+                int bc = -1, bs = -1;
+                float bv = -std::numeric_limits<float>::infinity();
+                for (int c = 0; c < nk; c++) {
+                    if (slot_of[c] >= 0) continue;
+                    for (int sl = 0; sl < 8; sl++) {
+                        if (child_in[sl] >= 0) continue;
+                        if (cost[c][sl] > bv) { bv = cost[c][sl]; bc = c; bs = sl; }
+                    }
+                }
+                slot_of[bc] = bs;
+                child_in[bs] = bc;
+            }
+        }
         uint32_t ebits[3];
         double scale[3];
         for (int a = 0; a < 3; a++) {
@@ -234,42 +297,53 @@ void build_bvh4(const std::vector<float>& tri_bounds, uint32_t n_tris, float pad
             ebits[a] = (uint32_t)(e + 127);
             scale[a] = std::ldexp(1.0, e);
         }
-        uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0}, refs[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-        for (int i = 0; i < 4; i++) {
-            uint32_t lo_q[3] = {255, 255, 255}, hi_q[3] = {0, 0, 0};  // empty slot: inverted
-            if (i < nk) {
-                const BinNode& c = bn[kids[i]];
-                for (int a = 0; a < 3; a++) {
-                    double l = std::floor(((double)clo[i][a] - (double)origin[a]) / scale[a]);
-                    double h = std::ceil(((double)chi[i][a] - (double)origin[a]) / scale[a]);
-                    l = std::max(0.0, std::min(255.0, l));
-                    h = std::max(0.0, std::min(255.0, h));
-                    // the f32 decode origin + q * scale rounds to nearest: step outwards until it is conservative
-                    while (l > 0.0 && (float)((double)origin[a] + l * scale[a]) > clo[i][a]) l -= 1.0;
-                    while (h < 255.0 && (float)((double)origin[a] + h * scale[a]) < chi[i][a]) h += 1.0;
-                    lo_q[a] = (uint32_t)l;
-                    hi_q[a] = (uint32_t)h;
-                }
-                if (c.left < 0) {
-                    refs[i] = 0x80000000u | (c.count << 28) | c.first;
-                } else {
-                    uint32_t idx = (uint32_t)(out_nodes.size() / 16);
-                    out_nodes.resize(out_nodes.size() + 16, 0.0f);
-                    queue.push_back({kids[i], idx});
-                    refs[i] = idx;
-                }
-            }
+        // children block: inner child in slot s lives at child_base + s
+        int max_inner_slot = -1;
+        for (int sl = 0; sl < 8; sl++)
+            if (child_in[sl] >= 0 && bn[kids[child_in[sl]]].left >= 0) max_inner_slot = sl;
+        uint32_t child_base = 0;
+        if (max_inner_slot >= 0) {
+            child_base = (uint32_t)(out_nodes.size() / stride);
+            out_nodes.resize(out_nodes.size() + (size_t)stride * (size_t)(max_inner_slot + 1), 0u);
+            if (out_nodes.size() / stride > (1u << 24)) throw std::runtime_error("unsupported: scene needs more than 2^24 BVH node slots");
+        }
+        const uint32_t tri_base = (uint32_t)order_out.size();
+        uint8_t meta[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[6][8];
+        for (int k = 0; k < 6; k++)
+            for (int sl = 0; sl < 8; sl++) q[k][sl] = k < 3 ? 255 : 0;  // empty slot: inverted box
+        for (int sl = 0; sl < 8; sl++) {
+            const int c = child_in[sl];
+            if (c < 0) continue;
+            const BinNode& cn = bn[kids[c]];
             for (int a = 0; a < 3; a++) {
-                qlo[a] |= lo_q[a] << (8 * i);
-                qhi[a] |= hi_q[a] << (8 * i);
+                double l = std::floor(((double)clo[c][a] - (double)origin[a]) / scale[a]);
+                double h = std::ceil(((double)chi[c][a] - (double)origin[a]) / scale[a]);
+                l = std::max(0.0, std::min(255.0, l));
+                h = std::max(0.0, std::min(255.0, h));
+                // the f32 decode origin + q * scale rounds to nearest: step outwards until it is conservative
+                while (l > 0.0 && (float)((double)origin[a] + l * scale[a]) > clo[c][a]) l -= 1.0;
+                while (h < 255.0 && (float)((double)origin[a] + h * scale[a]) < chi[c][a]) h += 1.0;
+                q[a][sl] = (uint8_t)l;
+                q[3 + a][sl] = (uint8_t)h;
+            }
+            if (cn.left < 0) {  // leaf: its triangles follow the node's earlier leaves
+                const uint32_t offset = (uint32_t)order_out.size() - tri_base;
+                for (uint32_t t = 0; t < cn.count; t++) order_out.push_back(order[cn.first + t]);
+                const uint32_t unary = cn.count >= 3 ? 7u : (cn.count == 2 ? 3u : 1u);
+                meta[sl] = (uint8_t)((unary << 5) | offset);
+            } else {
+                meta[sl] = (uint8_t)(0x20u | (24u + (uint32_t)sl));
+                queue.push_back({kids[c], child_base + (uint32_t)sl, pe.depth + 1});
             }
         }
-        float* n = &out_nodes[16ull * pe.out];
-        n[0] = origin[0]; n[1] = origin[1]; n[2] = origin[2];
-        put_u32(&n[3], ebits[0] | (ebits[1] << 8) | (ebits[2] << 16));
-        put_u32(&n[4], qlo[0]); put_u32(&n[5], qlo[1]); put_u32(&n[6], qlo[2]); put_u32(&n[7], qhi[0]);
-        put_u32(&n[8], qhi[1]); put_u32(&n[9], qhi[2]); put_u32(&n[10], refs[0]); put_u32(&n[11], refs[1]);
-        put_u32(&n[12], refs[2]); put_u32(&n[13], refs[3]); put_u32(&n[14], 0); put_u32(&n[15], 0);
+        auto pack4 = [](const uint8_t* v) { return (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24); };
+        uint32_t* n = &out_nodes[(size_t)stride * pe.out];
+        n[0] = fbits(origin[0]); n[1] = fbits(origin[1]); n[2] = fbits(origin[2]);
+        n[3] = ebits[0] | (ebits[1] << 8) | (ebits[2] << 16);
+        n[4] = child_base; n[5] = tri_base; n[6] = pack4(meta); n[7] = pack4(meta + 4);
+        n[8] = pack4(q[0]); n[9] = pack4(q[0] + 4); n[10] = pack4(q[1]); n[11] = pack4(q[1] + 4);
+        n[12] = pack4(q[2]); n[13] = pack4(q[2] + 4); n[14] = pack4(q[3]); n[15] = pack4(q[3] + 4);
+        n[16] = pack4(q[4]); n[17] = pack4(q[4] + 4); n[18] = pack4(q[5]); n[19] = pack4(q[5] + 4);
     }
 }
 

@@ -382,7 +382,8 @@ static void share_plane_row(const float* wa, float* wb, const vec3 vb[3]) {
     wb[8] = wa[8]; wb[9] = wa[9]; wb[10] = wa[10]; wb[11] = wa[11];
 }
 
-void build_bvh4(const std::vector<float>& tri_bounds, uint32_t n_tris, float pad, std::vector<uint32_t>& order, std::vector<float>& nodes);
+void build_bvh8(const std::vector<float>& tri_bounds, uint32_t n_tris, float pad, uint32_t stride, bool balanced, std::vector<uint32_t>& order,
+                std::vector<uint32_t>& nodes, uint32_t& depth);
 
 void compile_scene(const FlatScene& flat, CompiledScene& out) {
     const size_t n_inst = flat.instances.size();
@@ -616,14 +617,27 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
         for (int a = 0; a < 3; a++) diag2 += sqr(out.scene_hi[a] - out.scene_lo[a]);
         float pad = 4e-6f * __builtin_sqrtf(diag2);
         std::vector<uint32_t> order;
-        build_bvh4(bounds, n_tris, pad, order, out.bvh_nodes);
-        std::vector<float> woop2(out.woop.size());
-        for (uint32_t k = 0; k < n_tris; k++) std::memcpy(&woop2[12ull * k], &out.woop[12ull * order[k]], 48);
-        out.woop.swap(woop2);
+        const char* bal = std::getenv("AKR_BVH_BALANCED");  // test hook: take the fallback builder
+        const bool force_balanced = bal && bal[0] == '1';
+        build_bvh8(bounds, n_tris, pad, kBvhNodeWords, force_balanced, order, out.bvh_nodes, out.bvh_depth);
+        // A traversal keeps at most one stack entry per tree level (device/disect.h): a tree that fits the stack cannot
+        // overflow it. An SAH tree deeper than that (pathological geometry) is replaced by a median-split tree of depth
+        // ~log8(n); if even that does not fit the scene is refused rather than rendered wrongly.
+        if (out.bvh_depth > kBvhStackDepth) build_bvh8(bounds, n_tris, pad, kBvhNodeWords, true, order, out.bvh_nodes, out.bvh_depth);
+        if (out.bvh_depth > kBvhStackDepth)
+            throw std::runtime_error("unsupported: BVH depth " + std::to_string(out.bvh_depth) + " exceeds the traversal stack (" +
+                                     std::to_string(kBvhStackDepth) + " levels)");
+        // triangle records in traversal order: the 48-byte test record, then the global id (one 64-byte fetch per test)
+        std::vector<float> rec((size_t)kBvhTriWords * n_tris, 0.0f);
+        for (uint32_t k = 0; k < n_tris; k++) {
+            std::memcpy(&rec[(size_t)kBvhTriWords * k], &out.woop[12ull * order[k]], 48);
+            rec[(size_t)kBvhTriWords * k + 12] = u2f(order[k]);
+        }
+        out.woop.swap(rec);
         out.tri_gid = order;
     }
     // two all-zero records of padding: the exhaustive intersectors prefetch up to record n + 1
-    out.woop.resize(out.woop.size() + 24, 0.0f);
+    out.woop.resize(out.woop.size() + 32, 0.0f);
 }
 
 }  // namespace akr

@@ -49,8 +49,8 @@ struct FlatScene {
 // Output of the host-side scene compiler: plain arrays ready for hipMemcpy.
 struct CompiledScene {
     uint32_t n_tris = 0, n_lights = 0;
-    std::vector<float> woop;             // 12 / triangle, traversal order
-    std::vector<uint32_t> tri_gid;       // empty = identity
+    std::vector<float> woop;             // exhaustive path: 12 / triangle; BVH path: kBvhTriWords / triangle (record | gid | pad), traversal order
+    std::vector<uint32_t> tri_gid;       // BVH path: traversal order -> global id; empty = identity
     std::vector<float> shade;            // 32 / triangle (8 float4), by global id
     std::vector<float> normals;          // 12 / triangle (3 float4) or empty
     std::vector<float> inst;             // 32 / instance
@@ -62,8 +62,9 @@ struct CompiledScene {
     std::vector<uint32_t> light_inst, light_tri_offset, light_n_tris;
     std::vector<AliasEntry> area_entries;
     std::vector<float> area_pdf;
-    // BVH4 nodes (16 words = 64 B each, host/bvh.cpp) or empty for the exhaustive path
-    std::vector<float> bvh_nodes;
+    // 8-wide compressed BVH nodes (kBvhNodeWords words each, host/bvh.cpp) or empty for the exhaustive path
+    std::vector<uint32_t> bvh_nodes;
+    uint32_t bvh_depth = 0;              // levels of the wide tree = the most stack entries a traversal can need
     // textures: pruned node lists of the materials with texture-fed inputs, image headers, texel words, raw inputs
     std::vector<DNode> tex_nodes;
     std::vector<DImage> images;
@@ -88,8 +89,8 @@ void parse_method_json(const std::string& text, akr_pt_config* cfg, std::string*
 // all tasks of a RenderTask file (Single | Multi), lib.rs:103-109; allow_sampler_override: pmj02bn -> independent
 // most LDS a workgroup of the exhaustive path tracer kernels spends on staged scene tables (4 workgroups per CU, 160 KB of LDS)
 constexpr size_t kStageMaxBytes = 32 * 1024;
-// the same for the BVH path, whose workgroups already hold 32 KB of traversal stacks each
-constexpr size_t kStageMaxBytesBvh = 8 * 1024;
+// the same for the BVH path, whose workgroups already hold 24 KB of traversal stacks each
+constexpr size_t kStageMaxBytesBvh = 12 * 1024;
 
 struct ParsedTask {
     bool is_aov = false;     // Method::NormalVis instead of Method::PathTracer

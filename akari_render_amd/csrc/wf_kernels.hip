@@ -138,18 +138,9 @@ __global__ __launch_bounds__(256) void k_wf_trace(const PtParams p, const WfBuff
     const uint32_t lane = threadIdx.x & 63u;
     TraceCounters cnt{0, 0, 0};
     bool has = false, exhausted = false, any = false;
-    uint32_t slot = 0, e0 = kInvalid, e1 = kInvalid, sp = 0, cur = kBvhDone, best = kInvalid;
-    vec3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), inv = mk3(0, 0, 0), noi = mk3(0, 0, 0);
-    float tmax = 0.0f, best_t = 0.0f, best_u = 0.0f, best_v = 0.0f;
-#define AKR_PUSH(ref)                                  \
-    {                                                  \
-        if (sp < kBvhStackDepth) {                     \
-            stack[sp * 256u] = (ref);                  \
-            sp++;                                      \
-        } else {                                       \
-            cnt.overflow = 1;                          \
-        }                                              \
-    }
+    uint32_t slot = 0;
+    Trav s;
+    trav_begin(s, mk3(0, 0, 0), mk3(0, 0, 1), 0.0f, -1.0f, kInvalid, kInvalid);  // idle: tmax < tmin
     for (;;) {
         if (!exhausted) {  // refill idle lanes from the queue head
             const uint64_t idle = __builtin_amdgcn_ballot_w64(!has);
@@ -164,14 +155,7 @@ __global__ __launch_bounds__(256) void k_wf_trace(const PtParams p, const WfBuff
                     slot = any ? wf.queue_shadow[q_in][my - n_closest] : wf.queue_closest[q_in][my];
                     float4 a = any ? wf.sh_o[slot] : wf.ray_o[slot];
                     float4 b = any ? wf.sh_d[slot] : wf.ray_d[slot];
-                    o = xyz(a); d = xyz(b);
-                    e0 = f2u(a.w);
-                    e1 = any ? f2u(wf.sh_c[slot].w) : kInvalid;
-                    tmax = any ? b.w : 1e20f;
-                    inv = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
-                    noi = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
-                    best_t = tmax; best = kInvalid; best_u = 0.0f; best_v = 0.0f;
-                    sp = 0; cur = 0;
+                    trav_begin(s, xyz(a), xyz(b), 0.0f, any ? b.w : 1e20f, f2u(a.w), any ? f2u(wf.sh_c[slot].w) : kInvalid);
                     has = true;
                 }
                 if (base + n >= n_total) exhausted = true;
@@ -179,65 +163,13 @@ __global__ __launch_bounds__(256) void k_wf_trace(const PtParams p, const WfBuff
         }
         if (__builtin_amdgcn_ballot_w64(has) == 0) break;
         for (;;) {
-            while (has && !(cur & kBvhLeafBit)) {  // inner nodes
-                cnt.nodes++;
-                float tn[4];
-                uint32_t ch[4];
-                bvh4_node_test(sc, cur, inv, noi, 0.0f, best_t, tn, ch);
-#define AKR_CSWAP(a, b)                                            \
-    {                                                              \
-        bool sw = tn[b] < tn[a];                                   \
-        float tf = sw ? tn[b] : tn[a], tg = sw ? tn[a] : tn[b];    \
-        uint32_t cf = sw ? ch[b] : ch[a], cg = sw ? ch[a] : ch[b]; \
-        tn[a] = tf; tn[b] = tg; ch[a] = cf; ch[b] = cg;            \
-    }
-                AKR_CSWAP(0, 1) AKR_CSWAP(2, 3) AKR_CSWAP(0, 2) AKR_CSWAP(1, 3) AKR_CSWAP(1, 2)
-#undef AKR_CSWAP
-                if (tn[3] < __builtin_inff()) AKR_PUSH(ch[3])
-                if (tn[2] < __builtin_inff()) AKR_PUSH(ch[2])
-                if (tn[1] < __builtin_inff()) AKR_PUSH(ch[1])
-                if (tn[0] < __builtin_inff()) {
-                    cur = ch[0];
-                } else if (sp > 0) {
-                    sp--; cur = stack[sp * 256u];
-                } else {
-                    cur = kBvhDone;
-                }
-            }
-            if (has && cur != kBvhDone) {  // leaf
-                const uint32_t first = cur & 0x0fffffffu, count = (cur >> 28) & 7u;
-                bool stop = false;
-                for (uint32_t i = 0; i < count; i++) {
-                    const uint32_t k = first + i;
-                    float4 r0 = sc.woop[3 * (size_t)k + 0], r1 = sc.woop[3 * (size_t)k + 1], r2 = sc.woop[3 * (size_t)k + 2];
-                    cnt.tris++;
-                    float t, u, v;
-                    bool h = tri_test(o, d, r0, r1, r2, 0.0f, tmax, t, u, v);
-                    if (h) {
-                        uint32_t gid = sc.tri_gid[k];
-                        h = (gid != e0) & (gid != e1);
-                        if (h && sc.has_alpha) h = alpha_test<TEX>(sc, gid, u, v);
-                        if (h) {
-                            if (any) {
-                                best = gid;
-                                stop = true;
-                            } else {
-                                bool better = (best == kInvalid) | (t < best_t) | ((t == best_t) & (gid < best));
-                                if (better) { best_t = t; best_u = u; best_v = v; best = gid; }
-                            }
-                        }
-                    }
-                }
-                if (stop) cur = kBvhDone;
-                else if (sp > 0) { sp--; cur = stack[sp * 256u]; }
-                else cur = kBvhDone;
-            }
-            if (has && cur == kBvhDone) {  // ray finished: publish the result for k_wf_shade
+            if (has && s.active) trav_step<2, TEX>(sc, s, stack, cnt, any);
+            if (has && !s.active) {  // ray finished: publish the result for k_wf_shade
                 float* hp = (float*)&wf.hit[slot];
                 if (any) {
-                    hp[3] = u2f(best != kInvalid ? 1u : 0u);
+                    hp[3] = u2f(s.best != kInvalid ? 1u : 0u);
                 } else {
-                    hp[0] = u2f(best); hp[1] = best_u; hp[2] = best_v;
+                    hp[0] = u2f(s.best); hp[1] = s.best_u; hp[2] = s.best_v;
                 }
                 has = false;
             }
@@ -246,7 +178,6 @@ __global__ __launch_bounds__(256) void k_wf_trace(const PtParams p, const WfBuff
             if (!exhausted && n_idle >= AKR_WF_REFILL_IDLE) break;
         }
     }
-#undef AKR_PUSH
     // traversal counters
     if (p.counters != nullptr) {
         uint32_t nn = wave_sum_u32(cnt.nodes), nt = wave_sum_u32(cnt.tris), ov = wave_sum_u32(cnt.overflow);

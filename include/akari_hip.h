@@ -251,6 +251,10 @@ typedef struct {
     uint32_t n_bvh_nodes;     /* 0 when the scene uses the exhaustive small-scene intersector */
     uint32_t uses_bvh;
     uint64_t device_bytes;    /* HBM held by the scene */
+    uint32_t node_bytes;      /* bytes read per BVH node visit (80: 8-wide compressed node), 0 without a BVH */
+    uint32_t node_stride_bytes; /* distance between nodes in memory */
+    uint32_t tri_bytes;       /* bytes read per triangle test: 48 (exhaustive path) or 64 (BVH path: record + id) */
+    uint32_t bvh_depth;       /* levels of the 8-wide tree = most traversal-stack entries a ray can need */
 } akr_scene_info;
 AKR_API int32_t akr_scene_get_info(const akr_scene *scene, akr_scene_info *info);
 /* Light `light` of LightAggregate (light/mod.rs:87-98): owning instance, total power, selection pdf. */
@@ -270,12 +274,13 @@ AKR_API int32_t akr_scene_get_material_graph(const akr_scene *scene, uint32_t ma
 /* Read-only views of the compiled, device-ready arrays (owned by the scene): see akari_render_amd/csrc/device/dscene.h
  * for the record layouts. */
 typedef enum {
-    AKR_ARRAY_WOOP = 0,          /* f32[12 * n_tris]  ray-triangle records in traversal order */
+    AKR_ARRAY_WOOP = 0,          /* ray-triangle records in traversal order: f32[12 * n_tris] (exhaustive path) or, with a BVH,
+                                  * 16 words per triangle = the 12-float record | global triangle id (u32) | 3 unused */
     AKR_ARRAY_TRI_GID = 1,       /* u32[n_tris]       traversal order -> global triangle id (empty = identity) */
     AKR_ARRAY_SHADE = 2,         /* f32[32 * n_tris]  shading records by global triangle id */
     AKR_ARRAY_INSTANCES = 3,     /* f32[32 * n_instances] */
     AKR_ARRAY_MATERIALS = 4,     /* folded materials, 256 B each */
-    AKR_ARRAY_BVH_NODES = 5,     /* u32[16 * n_bvh_nodes]: 64-byte quantised BVH4 nodes (csrc/host/bvh.cpp) */
+    AKR_ARRAY_BVH_NODES = 5,     /* u32[(node_stride_bytes / 4) * n_bvh_nodes]: 80-byte 8-wide compressed nodes (csrc/host/bvh.cpp) */
     AKR_ARRAY_LIGHT_ENTRIES = 6, /* {u32 j, f32 t}[n_lights] */
     AKR_ARRAY_LIGHT_PDF = 7,     /* f32[n_lights] */
     AKR_ARRAY_AREA_ENTRIES = 8,  /* {u32 j, f32 t}[sum of light triangle counts] */

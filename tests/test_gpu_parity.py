@@ -266,3 +266,11 @@ def test_convergence_follows_one_over_sqrt_spp(ctx, cbox_path):
         ratio = errs[a] / errs[b]
         assert 1.6 < ratio < 2.5, (errs, ratio)  # x4 samples -> error / 2
     assert abs(render(1024, 3).mean() - ref.mean()) < 0.01 * ref.mean()
+
+
+def test_bvh_balanced_fallback_builder(ctx, monkeypatch):
+    """The median-split builder that replaces an SAH tree deeper than the traversal stack (host/scene_build.cpp): same image."""
+    monkeypatch.setenv("AKR_BVH_BALANCED", "1")
+    sd = grid_scene(n=24, width=96, height=64, with_normals=True)
+    g, o, gst, ost, _, _ = render_both(ctx, sd, make_config(spp=8, spp_per_pass=8, max_depth=6))
+    assert_parity(g, o, 96, 64, gst, ost)

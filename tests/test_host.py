@@ -109,66 +109,124 @@ def test_material_flags(hip_lib, cbox_path):
     assert fl("tallBox_001") & METAL and fl("tallBox_001") & BASE
 
 
+def _decode_bvh8(sc):
+    """The scene's 8-wide compressed BVH (csrc/host/bvh.cpp) as python objects: per node origin, scale, child_base, tri_base,
+    meta[8], q[6][8]."""
+    info = sc.info()
+    stride = info.node_stride_bytes // 4
+    raw = sc.array(capi.ARRAY_BVH_NODES, np.uint32).reshape(-1, stride)
+    assert raw.shape[0] == info.n_bvh_nodes and info.node_bytes == 80
+    return raw, info
+
+
+def _node(raw, ni):
+    nd = raw[ni]
+    origin = nd[0:3].view(np.float32).astype(np.float32)
+    e = [(int(nd[3]) >> (8 * a)) & 0xFF for a in range(3)]
+    scale = np.array([np.float32(2.0) ** np.float32(x - 127) for x in e], dtype=np.float32)
+    by = nd[6:20].view(np.uint8)
+    meta, q = by[0:8], by[8:56].reshape(6, 8)  # q rows: lo.x lo.y lo.z hi.x hi.y hi.z
+    return origin, scale, int(nd[4]), int(nd[5]), meta, q
+
+
 def test_bvh_structure(hip_lib):
-    """64-byte quantised BVH4 nodes (csrc/host/bvh.cpp): every triangle in exactly one leaf, decoded child boxes
-    contain their triangles and nest inside the parent's decoded box."""
+    """80-byte 8-wide compressed nodes (csrc/host/bvh.cpp): every triangle under exactly one leaf, decoded child boxes
+    contain their triangles and nest inside the parent's decoded box, inner children live at child_base + slot, leaf
+    triangles of a node are contiguous from tri_base, depth = what akr_scene_info reports and fits the traversal stack."""
     sd = grid_scene(n=20)
     sc = capi.Scene(None, sd)
-    nodes = sc.array(capi.ARRAY_BVH_NODES, np.uint32).reshape(-1, 16)
-    assert nodes.shape[0] == sc.info().n_bvh_nodes
+    raw, info = _decode_bvh8(sc)
     gid = sc.array(capi.ARRAY_TRI_GID, np.uint32)
-    woop = sc.array(capi.ARRAY_WOOP, np.float32).reshape(-1, 12)
-    n_tris = sc.info().n_triangles
+    rec = sc.array(capi.ARRAY_WOOP, np.float32).reshape(-1, 16)
+    n_tris = info.n_triangles
+    assert info.tri_bytes == 64 and rec.shape[0] >= n_tris
     assert sorted(gid.tolist()) == list(range(n_tris))
+    assert np.array_equal(rec[:n_tris, 12].view(np.uint32), gid)  # the record carries its global id
     shade = sc.array(capi.ARRAY_SHADE, np.float32).reshape(-1, 32)
     inst = sc.array(capi.ARRAY_INSTANCES, np.float32).reshape(-1, 32)
+
     def world(g):
         r = shade[g]; m = inst[int(r[26:27].view(np.uint32)[0])]
         M = np.stack([m[0:3], m[4:7], m[8:11]], axis=1); t = m[12:15]
         return np.stack([M @ r[0:3] + t, M @ r[4:7] + t, M @ r[8:11] + t])
-    def decode(nd):
-        origin = nd[0:3].view(np.float32).astype(np.float32)
-        e = np.array([(int(nd[3]) >> (8 * a)) & 0xFF for a in range(3)])
-        scale = np.array([np.float32(2.0) ** np.float32(int(x) - 127) for x in e], dtype=np.float32)
-        q = [[(int(nd[4 + k]) >> (8 * i)) & 0xFF for i in range(4)] for k in range(6)]  # lo.x lo.y lo.z hi.x hi.y hi.z
-        refs = [int(nd[10]), int(nd[11]), int(nd[12]), int(nd[13])]
-        boxes = []
-        for i in range(4):
-            lo = np.array([origin[a] + np.float32(q[a][i]) * scale[a] for a in range(3)], dtype=np.float32)
-            hi = np.array([origin[a] + np.float32(q[3 + a][i]) * scale[a] for a in range(3)], dtype=np.float32)
-            boxes.append((lo, hi))
-        return boxes, refs
+
     seen = np.zeros(n_tris, dtype=int)
-    stack = [(0, np.full(3, -np.inf), np.full(3, np.inf))]
-    n_visited = 0
+    visited = set()
+    stack = [(0, np.full(3, -np.inf), np.full(3, np.inf), 1)]
+    depth = 0
     while stack:
-        ni, plo, phi = stack.pop()
-        n_visited += 1
-        boxes, refs = decode(nodes[ni])
-        for (lo, hi), ref in zip(boxes, refs):
-            if ref == 0xFFFFFFFF:
-                assert np.all(lo > hi)  # empty slot: inverted box
+        ni, plo, phi, d = stack.pop()
+        assert ni not in visited
+        visited.add(ni)
+        depth = max(depth, d)
+        origin, scale, child_base, tri_base, meta, q = _node(raw, ni)
+        assert child_base < (1 << 24)
+        next_offset = 0
+        for s in range(8):
+            m = int(meta[s])
+            lo = origin + q[0:3, s].astype(np.float32) * scale
+            hi = origin + q[3:6, s].astype(np.float32) * scale
+            if m == 0:
+                assert np.all(q[0:3, s] == 255) and np.all(q[3:6, s] == 0)  # empty slot: inverted box
                 continue
-            # children are quantised in their own node's frame: they nest in the parent's decoded box up to one step
-            if np.all(np.isfinite(plo)):
+            if np.all(np.isfinite(plo)):  # children are quantised in their own node's frame: nested up to one step
                 tol = (phi - plo) / 100.0 + 1e-3
                 assert np.all(lo >= plo - tol) and np.all(hi <= phi + tol)
-            if ref & 0x80000000:
-                first, count = ref & 0x0FFFFFFF, (ref >> 28) & 7
-                assert 1 <= count <= 4
-                for k in range(first, first + count):
+            if (m & 0x18) == 0x18:  # inner: 0x20 | (24 + slot)
+                assert m == (0x20 | (24 + s))
+                stack.append((child_base + s, lo, hi, d + 1))
+            else:
+                unary, offset = m >> 5, m & 31
+                count = {1: 1, 3: 2, 7: 3}[unary]
+                assert offset == next_offset and offset + count <= 24   # leaves of a node are packed in slot order
+                next_offset += count
+                for k in range(tri_base + offset, tri_base + offset + count):
                     seen[k] += 1
                     w = world(int(gid[k]))
                     assert np.all(w >= lo - 1e-6) and np.all(w <= hi + 1e-6)  # conservative: decoded box contains the triangle
-            else:
-                stack.append((ref, lo, hi))
-    assert np.all(seen == 1) and n_visited == nodes.shape[0]
+    assert np.all(seen == 1)
+    assert depth == info.bvh_depth and depth <= 24
+    # slots the tree does not use are holes (all zero)
+    holes = [i for i in range(raw.shape[0]) if i not in visited]
+    assert all(not raw[i].any() for i in holes)
     # the 48-byte records map each triangle to the unit triangle
     for k in (0, 17, n_tris - 1):
         w = world(int(gid[k])).astype(np.float64)
-        R = woop[k].reshape(3, 4).astype(np.float64)
+        R = rec[k, :12].reshape(3, 4).astype(np.float64)
         loc = (R[:, :3] @ w.T + R[:, 3:4]).T
         assert np.allclose(loc, [[0, 0, 0], [1, 0, 0], [0, 1, 0]], atol=2e-4)
+
+
+def test_bvh_slot_order_is_front_to_back(hip_lib):
+    """Children sit in the slot whose bits say on which side of the node centre they lie, so visiting slots in the order
+    slot ^ octant is (approximately) near-to-far: for axis-aligned rays the first visited of two children that are separated
+    along that axis is the nearer one in at least 90 % of the node pairs."""
+    sd = grid_scene(n=20)
+    sc = capi.Scene(None, sd)
+    raw, info = _decode_bvh8(sc)
+    good = total = 0
+    for ni in range(raw.shape[0]):
+        if not raw[ni].any():
+            continue
+        origin, scale, _, _, meta, q = _node(raw, ni)
+        slots = [s for s in range(8) if meta[s]]
+        for a in range(3):
+            for s1 in slots:
+                for s2 in slots:
+                    if s1 >= s2:
+                        continue
+                    c1 = int(q[a, s1]) + int(q[3 + a, s1])
+                    c2 = int(q[a, s2]) + int(q[3 + a, s2])
+                    if q[3 + a, s1] <= q[a, s2] or q[3 + a, s2] <= q[a, s1]:  # separated along axis a
+                        # a ray towards +a visits the slot whose bit a is 0 first
+                        first = s1 if ((s1 >> a) & 1) < ((s2 >> a) & 1) else (s2 if ((s2 >> a) & 1) < ((s1 >> a) & 1) else None)
+                        if first is None:
+                            continue
+                        total += 1
+                        nearer = s1 if c1 < c2 else s2
+                        good += first == nearer
+    print(f"slot order agrees with the distance order for {good} of {total} separated child pairs")
+    assert total > 50 and good > 0.9 * total
 
 
 def test_coplanar_neighbours_share_their_plane_row(hip_lib, cbox_path):
@@ -187,3 +245,76 @@ def test_coplanar_neighbours_share_their_plane_row(hip_lib, cbox_path):
     # a cube of exact rectangles: all six faces; a grid of displaced vertices: (almost) none
     assert pyoracle.OracleScene(box_scene()).shared_plane_rows() == 6
     assert pyoracle.OracleScene(grid_scene(n=12)).shared_plane_rows() <= 2
+
+
+def _traverse_bvh8(raw, stride_unused, o, d, tmin, tmax):
+    """A scalar python mirror of device/disect.h trav_step (node part, no culling by hits): the set of traversal-order
+    triangle indices whose leaf box the ray enters, and the number of nodes visited."""
+    inv = np.where(np.abs(d) < 1e-20, np.copysign(1e-20, d), d)
+    inv = (1.0 / inv.astype(np.float64))
+    oi = int(inv[0] >= 0) | (int(inv[1] >= 0) << 1) | (int(inv[2] >= 0) << 2)
+    octinv4 = oi * 0x01010101
+    G = 1 << (24 + oi)
+    stack, tris, n_nodes = [], [], 0
+    while True:
+        if (G >> 24) == 0:
+            if not stack:
+                break
+            G = stack.pop()
+        j = G.bit_length() - 1
+        G &= ~(1 << j)
+        if (G >> 24) != 0:
+            stack.append(G)
+        slot = (j - 24) ^ (octinv4 & 7)
+        origin, scale, child_base, tri_base, meta, q = _node(raw, (G & 0xFFFFFF) + slot)
+        n_nodes += 1
+        hitmask = 0
+        for h in range(2):
+            meta4 = int.from_bytes(bytes(meta[4 * h:4 * h + 4]), "little")
+            is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010
+            inner_mask4 = (is_inner4 >> 4) * 0xFF
+            bit_index4 = (meta4 ^ (octinv4 & inner_mask4)) & 0x1F1F1F1F
+            child_bits4 = (meta4 >> 5) & 0x07070707
+            for i in range(4):
+                s = 4 * h + i
+                lo = origin.astype(np.float64) + q[0:3, s].astype(np.float64) * scale
+                hi = origin.astype(np.float64) + q[3:6, s].astype(np.float64) * scale
+                t0, t1 = (lo - o) * inv, (hi - o) * inv
+                tn = max(np.minimum(t0, t1).max(), tmin)
+                tf = min(np.maximum(t0, t1).min(), tmax)
+                if tn <= tf:
+                    hitmask |= ((child_bits4 >> (8 * i)) & 0xFF) << ((bit_index4 >> (8 * i)) & 0xFF)
+        G = (child_base & 0xFFFFFF) | (hitmask & 0xFF000000)
+        T = hitmask & 0xFFFFFF
+        while T:
+            b = (T & -T).bit_length() - 1
+            T &= T - 1
+            tris.append(tri_base + b)
+    return tris, n_nodes
+
+
+def test_bvh_traversal_reaches_every_hit(hip_lib):
+    """The traversal algorithm of device/disect.h, mirrored in python on the host-built tree: for 1500 rays (random and aimed
+    at edges) every triangle the oracle's exhaustive loop reports is among the triangles the traversal would test, and the
+    node-group bookkeeping (octant bit order, SWAR meta decode, one stack entry per level) never revisits a node."""
+    from tests.helpers import probe_rays
+
+    sd = grid_scene(n=20)
+    sc = capi.Scene(None, sd)
+    raw, info = _decode_bvh8(sc)
+    gid = sc.array(capi.ARRAY_TRI_GID, np.uint32)
+    osc = pyoracle.OracleScene(sd)
+    rays = probe_rays(osc.world_vertices(), 750, 750, seed=9)
+    out, _ = osc.intersect_many(rays)
+    off = osc.tri_offsets()
+    n_hit = 0
+    max_nodes = 0
+    for r, h in zip(rays, out):
+        tris, n_nodes = _traverse_bvh8(raw, None, r[0:3].astype(np.float64), r[3:6].astype(np.float32), 0.0, 1e20)
+        assert len(tris) == len(set(tris))          # no triangle (hence no node) reached twice
+        max_nodes = max(max_nodes, n_nodes)
+        if h[0]:
+            n_hit += 1
+            g = int(off[h[1]] + h[2])
+            assert g in set(int(gid[k]) for k in tris)
+    assert n_hit > 300 and max_nodes < info.n_bvh_nodes
