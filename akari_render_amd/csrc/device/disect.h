@@ -310,7 +310,11 @@ AKR_D void trav_step(const DScene& sc, Trav& s, uint32_t* __restrict__ stack, Tr
         p = sc.bvh_nodes + (size_t)((s.G & 0xffffffu) + slot) * (kBvhNodeWords / 4);
     }
     // the one fetch of the step; a triangle record is 64 bytes, so its lanes re-read word 0 instead of running into the next line
-    const uint4 w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3], w4 = p[do_tri ? 0 : 4];
+    uint4 w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3], w4 = p[do_tri ? 0 : 4];
+    // All five loads are in flight before anything waits. Without this fence the compiler sinks the words only the node test
+    // reads into the node branch -- a second dependent round trip to memory for every node step.
+    asm volatile("" : "+v"(w0.x), "+v"(w0.y), "+v"(w0.z), "+v"(w0.w), "+v"(w1.x), "+v"(w1.y), "+v"(w1.z), "+v"(w1.w), "+v"(w2.x), "+v"(w2.y),
+                      "+v"(w2.z), "+v"(w2.w), "+v"(w3.x), "+v"(w3.y), "+v"(w3.z), "+v"(w3.w), "+v"(w4.x), "+v"(w4.y), "+v"(w4.z), "+v"(w4.w));
     if (do_tri) {
         cnt.tris++;
         float t, u, v;

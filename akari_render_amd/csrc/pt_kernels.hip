@@ -24,6 +24,9 @@ namespace akr {
 #ifndef AKR_PT_MIN_WAVES_FD
 #define AKR_PT_MIN_WAVES_FD 4  // force_diffuse specialisation of the exhaustive kernel
 #endif
+#ifndef AKR_PT_MERGED_RAYS
+#define AKR_PT_MERGED_RAYS 1  // BVH path: a lane starts its shadow ray the moment its closest-hit ray is done (one loop)
+#endif
 template <bool BVH, bool FD, bool TEX, bool PMJ, bool STAGE>
 __global__ __launch_bounds__(256, BVH ? AKR_PT_MIN_WAVES_BVH : (FD ? AKR_PT_MIN_WAVES_FD : AKR_PT_MIN_WAVES)) void k_pt_pass(const PtParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: kBvhStackDepth x 256 words; else: staged tables
@@ -51,7 +54,31 @@ __global__ __launch_bounds__(256, BVH ? AKR_PT_MIN_WAVES_BVH : (FD ? AKR_PT_MIN_
             bool found = false, occluded = false;
             r.c_closest += r.has_ray ? 1u : 0u;
             r.c_shadow += r.has_shadow ? 1u : 0u;
-            if (BVH) {
+            if (BVH && AKR_PT_MERGED_RAYS) {
+                // Both rays of the iteration through ONE traversal loop: a lane whose closest-hit ray is done goes straight on
+                // to its shadow ray, so the wave pays for its longest PAIR of rays instead of its longest closest-hit ray plus
+                // its longest shadow ray (rays of a wave differ in length by an order of magnitude; the loop is the same code for
+                // both kinds: the visiting order comes from the node layout, not from sorting).
+                Trav s;
+                uint32_t phase = r.has_ray ? 0u : (r.has_shadow ? 1u : 2u);  // 0: closest-hit ray in flight, 1: shadow ray, 2: done
+                if (phase == 0) trav_begin(s, r.ro, r.rd, 0.0f, 1e20f, r.ray_ex0, kInvalid);
+                else trav_begin(s, r.s_o, r.s_d, 0.0f, phase == 1 ? r.s_tmax : -1.0f, r.s_ex0, r.s_ex1);
+                hit.t = 1e20f; hit.u = 0.0f; hit.v = 0.0f; hit.gid = kInvalid;
+                while (phase != 2u) {
+                    if (s.active) trav_step<2, TEX>(sc, s, tc.stack, tc.cnt, phase == 1u);
+                    if (!s.active) {
+                        if (phase == 0u) {
+                            found = s.best != kInvalid;
+                            hit.t = s.best_t; hit.u = s.best_u; hit.v = s.best_v; hit.gid = s.best;
+                            phase = r.has_shadow ? 1u : 2u;
+                            if (r.has_shadow) trav_begin(s, r.s_o, r.s_d, 0.0f, r.s_tmax, r.s_ex0, r.s_ex1);
+                        } else {
+                            occluded = s.best != kInvalid;
+                            phase = 2u;
+                        }
+                    }
+                }
+            } else if (BVH) {
                 if (r.has_ray) found = trace_bvh<false, TEX>(sc, r.ro, r.rd, 0.0f, 1e20f, r.ray_ex0, kInvalid, hit, tc.stack, tc.cnt);
                 if (r.has_shadow) {
                     Hit sh;
