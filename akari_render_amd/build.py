@@ -19,6 +19,7 @@ SOURCES = [
     "host/bvh.cpp",
     "host/image_io.cpp",
     "host/pmj_tables.cpp",
+    "host/comm.cpp",
 ]
 def _headers():
     """Every header the sources can include: all of csrc/ and the public header (a forgotten entry in a hand-kept list
@@ -102,7 +103,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if any(rc != 0 for _, rc, _ in results):
         raise RuntimeError("hipcc failed:\n" + log)
     open(tag, "w").write(flags_now)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [o for o, _, _ in results] + ["-o", LIB]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [o for o, _, _ in results] + ["-ldl", "-o", LIB]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc (link) failed:\n" + log + res.stdout)
@@ -134,7 +135,7 @@ def build_variant(name: str, extra_flags, verbose: bool = False) -> str:
         results = list(ex.map(compile_one, SOURCES))
     if any(rc != 0 for _, rc, _ in results):
         raise RuntimeError("hipcc failed:\n" + "".join(o for _, _, o in results))
-    res = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [o for o, _, _ in results] + ["-o", out],
+    res = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [o for o, _, _ in results] + ["-ldl", "-o", out],
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc (link) failed:\n" + res.stdout)

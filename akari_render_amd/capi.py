@@ -33,7 +33,8 @@ EXPORTS = [
     "akr_pt_config_default", "akr_pt_config_from_json", "akr_pt_render", "akr_pt_begin", "akr_pt_passes", "akr_pt_end",
     "akr_pt_get_stats", "akr_render_task", "akr_image_write", "akr_aov_config_default", "akr_aov_render",
     "akr_gpt_config_default", "akr_gpt_render", "akr_mcmc_config_default", "akr_mcmc_render", "akr_film_set_splat_scale", "akr_film_get_splat_scale",
-    "akr_pt_read_sampler_states",
+    "akr_pt_read_sampler_states", "akr_context_device_ordinal", "akr_device_count",
+    "akr_comm_unique_id", "akr_comm_create", "akr_comm_wrap", "akr_comm_destroy", "akr_film_reduce",
     "akr_host_stdrng_u64", "akr_host_chacha_block", "akr_host_pcg32_states", "akr_host_pcg_start", "akr_host_alias_table",
     "akr_probe_math", "akr_probe_bsdf", "akr_probe_intersect", "akr_probe_surface_interaction", "akr_probe_material_inputs",
     "akr_host_decode_png", "akr_host_decode_jpeg", "akr_host_decode_exr", "akr_host_pmj02bn_tables",
@@ -103,6 +104,13 @@ def lib() -> C.CDLL:
     proto("akr_film_write", vp, fp)
     proto("akr_film_resolve", vp, fp)
     proto("akr_film_device_ptr", vp, vpp, u64p)
+    proto("akr_context_device_ordinal", vp, C.POINTER(C.c_int32))
+    proto("akr_device_count", C.POINTER(C.c_int32))
+    proto("akr_comm_unique_id", C.POINTER(C.c_uint8))
+    proto("akr_comm_create", vp, C.POINTER(C.c_uint8), i32, i32, vpp)
+    proto("akr_comm_wrap", vp, vp, i32, i32, vpp)
+    proto("akr_comm_destroy", vp)
+    proto("akr_film_reduce", vp, vp, i32, i32)
     proto("akr_pt_config_default", C.POINTER(abi.PtConfig))
     proto("akr_aov_config_default", C.POINTER(abi.AovConfig))
     proto("akr_aov_render", vp, vp, C.POINTER(abi.AovConfig), vp, C.POINTER(abi.PtStats))
@@ -297,6 +305,45 @@ class Scene:
         check(lib().akr_scene_get_camera(self.h, C.byref(c)))
         cam = abi.CameraData(np.array(list(c.c2w), dtype=np.float32), float(c.fov), c.width, c.height)
         return abi.SceneData(meshes, instances, materials, cam, images=images)
+
+
+def device_count() -> int:
+    n = C.c_int32()
+    check(lib().akr_device_count(C.byref(n)))
+    return n.value
+
+
+def comm_unique_id() -> bytes:
+    """akr_comm_unique_id: the 128 bytes rank 0 hands to the other ranks (ncclGetUniqueId)."""
+    buf = (C.c_uint8 * 128)()
+    check(lib().akr_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    """akr_comm: an RCCL communicator of one process per GPU, for akr_film_reduce."""
+
+    def __init__(self, ctx: "Context", unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == 128
+        self.h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        check(lib().akr_comm_create(ctx.h, buf, rank, world, C.byref(self.h)))
+        self.rank, self.world = rank, world
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().akr_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reduce_film(self, film: "Film", root: int = 0, blocking: bool = True):
+        """Sum of the ranks' films in place, onto `root` (or onto every rank with root = -1)."""
+        check(lib().akr_film_reduce(film.h, self.h, root, 1 if blocking else 0))
 
 
 class Film:

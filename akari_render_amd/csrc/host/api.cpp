@@ -216,6 +216,19 @@ struct LaunchTimer {
 };
 }  // namespace
 
+namespace akr {
+// for host/comm.cpp (the RCCL film reduce): what it needs to know about a film, and the shared error slot
+int32_t film_device_view(akr_film* film, int* device, hipStream_t* stream, float** data, size_t* n_floats) {
+    if (!film || !film->ctx) return fail(AKR_ERR_INVALID_ARGUMENT, "film is NULL");
+    *device = film->ctx->device;
+    *stream = film->ctx->stream;
+    *data = film->data;
+    *n_floats = film->n_floats();
+    return AKR_OK;
+}
+int32_t api_fail(int32_t code, const std::string& msg) { return fail(code, msg); }
+}  // namespace akr
+
 static void ensure_ggx_table(akr_scene* s) {
     akr_context* ctx = s->ctx;
     if (!s->flat.ggx_table.empty()) {
@@ -506,6 +519,11 @@ AKR_API int32_t akr_context_synchronize(akr_context* ctx) {
         ctx->bind();
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
     });
+}
+AKR_API int32_t akr_context_device_ordinal(akr_context* ctx, int32_t* device) {
+    if (!ctx || !device) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_context_device_ordinal: NULL argument");
+    *device = ctx->device;
+    return AKR_OK;
 }
 AKR_API int32_t akr_context_device_info(akr_context* ctx, char* name, uint32_t name_len, uint32_t* compute_units, uint64_t* hbm_bytes) {
     if (!ctx) return fail(AKR_ERR_INVALID_ARGUMENT, "context is NULL");

@@ -146,7 +146,29 @@ def build_scene(ctx, key):
                    "generate_s": t1 - t0, "compile_upload_s": time.time() - t1}
 
 
-def run_config(ctx, key, steps, warmup, rank, world, scaling, film_t, torch, dist, backend, dev):
+def make_native_comm(ctx, rank, world, torch, dist, dev):
+    """The library's own RCCL communicator (akr_comm_create): rank 0's unique id travels over torch.distributed, which is
+    already up for the barrier and the timing reduction. Returns None on every rank if any rank could not create it."""
+    from akari_render_amd import capi
+
+    comm, ok = None, 1
+    try:
+        box = [capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = capi.Comm(ctx, box[0], rank, world)
+    except Exception as ex:  # noqa: BLE001
+        log(f"rank {rank}: native RCCL communicator unavailable ({ex}); falling back to torch.distributed.reduce")
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        if comm is not None:
+            comm.close()
+        return None
+    return comm
+
+
+def run_config(ctx, key, steps, warmup, rank, world, scaling, film_t, torch, dist, backend, dev, comm=None):
     """Times `steps` steps of configuration `key` on this rank. Returns (elapsed_s, per-rank counter deltas, extra info)."""
     from akari_render_amd import abi, capi, distributed
 
@@ -171,9 +193,15 @@ def run_config(ctx, key, steps, warmup, rank, world, scaling, film_t, torch, dis
         se.passes(warmup * PASSES_PER_STEP, blocking=True)
     if world > 1 and backend == "nccl":
         # warm the collective up too (RCCL builds its rings / proxy connections on the first reduce of a given size):
-        # same message size as the film, on a scratch tensor, outside the timed region
+        # same message size as the film, on a scratch buffer, outside the timed region
         scratch = torch.zeros_like(film_t)
-        distributed.reduce_film(scratch, dst=0)
+        torch.cuda.synchronize(dev)
+        if comm is not None:
+            sf = capi.Film(ctx, W, H, device_ptr=scratch.data_ptr())
+            comm.reduce_film(sf, root=0, blocking=True)
+            del sf
+        else:
+            distributed.reduce_film(scratch, dst=0)
         torch.cuda.synchronize(dev)
         del scratch
     s0 = se.stats()
@@ -192,6 +220,8 @@ def run_config(ctx, key, steps, warmup, rank, world, scaling, film_t, torch, dis
             host = film_t.cpu()
             distributed.reduce_film(host, dst=0)
             film_t.copy_(host)
+        elif comm is not None:
+            comm.reduce_film(film, root=0, blocking=True)  # akr_film_reduce: ncclReduce on the context's stream, after the render
         else:
             distributed.reduce_film(film_t, dst=0)
     sync()
@@ -204,6 +234,7 @@ def run_config(ctx, key, steps, warmup, rank, world, scaling, film_t, torch, dis
     d["node_bytes"] = int(getattr(info, "node_bytes", 64) or 64)
     d["tri_bytes"] = int(getattr(info, "tri_bytes", 48) or 48)
     sinfo["weak"] = weak
+    sinfo["film_reduce"] = "none (one GPU)" if world == 1 else ("akr_film_reduce (RCCL through the C ABI)" if comm is not None else f"torch.distributed.reduce ({backend})")
     sinfo["spp_done"] = (warmup + steps) * SPP_PER_STEP
     del film, scene
     return t1 - t0, d, sinfo
@@ -260,6 +291,9 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong (default) = the ONE frame's 32x32 pixel tiles round-robin over the GPUs, identical image for "
                          "every N; weak = every GPU renders the whole frame with its own sampler seed (N independent sample sets)")
+    ap.add_argument("--reduce", default="native", choices=["native", "torch"],
+                    help="N > 1: native = akr_film_reduce (the library's own RCCL call, csrc/host/comm.cpp; falls back to torch if the "
+                         "communicator cannot be created), torch = torch.distributed.reduce on the film tensor")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only for smoke-testing the "
                          "multi-rank path on a box with fewer GPUs than ranks: all ranks then share device 0)")
@@ -285,7 +319,8 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     film_t = torch.zeros(7 * W * H, dtype=torch.float32, device=dev)
     key = args.config
-    elapsed, d, sinfo = run_config(ctx, key, args.steps, args.warmup, rank, world, args.scaling, film_t, torch, dist, args.backend, dev)
+    comm = make_native_comm(ctx, rank, world, torch, dist, dev) if (world > 1 and args.backend == "nccl" and args.reduce == "native") else None
+    elapsed, d, sinfo = run_config(ctx, key, args.steps, args.warmup, rank, world, args.scaling, film_t, torch, dist, args.backend, dev, comm)
     weak = sinfo["weak"]
 
     if world > 1:
@@ -358,6 +393,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
 
 

@@ -225,6 +225,10 @@ AKR_API int32_t akr_context_create(int32_t device, akr_context **out);
 AKR_API int32_t akr_context_destroy(akr_context *ctx);
 /* Blocks until all work queued on the context's stream is done. */
 AKR_API int32_t akr_context_synchronize(akr_context *ctx);
+/* Number of HIP devices visible to the process (0 without a GPU; never fails for that reason). */
+AKR_API int32_t akr_device_count(int32_t *count);
+/* The HIP device ordinal the context was created on. */
+AKR_API int32_t akr_context_device_ordinal(akr_context *ctx, int32_t *device);
 /* Device name / compute units / HBM bytes of the context's GPU. `name` gets at most name_len-1 chars. */
 AKR_API int32_t akr_context_device_info(akr_context *ctx, char *name, uint32_t name_len, uint32_t *compute_units,
                                         uint64_t *hbm_bytes);
@@ -316,6 +320,23 @@ AKR_API int32_t akr_film_wrap(akr_context *ctx, uint32_t width, uint32_t height,
 /* Device pointer + byte size of the accumulator, for an RCCL reduce issued by the host application
  * (one process per GPU). The pointer stays valid until akr_film_destroy. */
 AKR_API int32_t akr_film_device_ptr(akr_film *film, void **ptr, uint64_t *bytes);
+
+/* ---- Multi-GPU: the one exchange step of the path (the reference has no counterpart) ----------------------
+ * One process per GPU renders its pixel tiles (akr_pt_config.shard_rank / shard_count) into a full-frame film that is zero
+ * elsewhere; akr_film_reduce sums the films over RCCL (xGMI) in place: onto rank `root`, or onto every rank with root = -1.
+ * Disjoint tiles make the sum exact. The collective is enqueued on the context's stream, after the render that filled the
+ * film; `blocking` != 0 waits for it. Bootstrap like NCCL: rank 0 calls akr_comm_unique_id and hands the 128 bytes to the
+ * other ranks by whatever channel the host has (MPI, a file, torch.distributed ...), then every rank calls akr_comm_create.
+ * A host that already has an ncclComm_t on the context's device passes it to akr_comm_wrap instead (not destroyed by
+ * akr_comm_destroy). librccl.so is loaded on first use (an RCCL the process already holds -- e.g. the copy PyTorch ships -- is
+ * reused: a host that also uses PyTorch imports it first); AKR_ERR_UNSUPPORTED if there is none. */
+#define AKR_COMM_ID_BYTES 128
+typedef struct akr_comm akr_comm;
+AKR_API int32_t akr_comm_unique_id(uint8_t id[AKR_COMM_ID_BYTES]);
+AKR_API int32_t akr_comm_create(akr_context *ctx, const uint8_t id[AKR_COMM_ID_BYTES], int32_t rank, int32_t world, akr_comm **out);
+AKR_API int32_t akr_comm_wrap(akr_context *ctx, void *nccl_comm, int32_t rank, int32_t world, akr_comm **out);
+AKR_API int32_t akr_comm_destroy(akr_comm *comm);
+AKR_API int32_t akr_film_reduce(akr_film *film, akr_comm *comm, int32_t root, int32_t blocking);
 
 /* Fills *cfg with pt::Config::default() (pt.rs:930-944), the default filter (film.rs:50-54) and sampler
  * (sampler/mod.rs:290-294). */

@@ -1,0 +1,80 @@
+"""The native exchange step (akr_comm_* / akr_film_reduce: RCCL through the C ABI, csrc/host/comm.cpp).
+
+On a one-GPU box RCCL runs with a world of one rank (communicator bootstrap, ncclReduce and ncclAllReduce really execute);
+with two or more GPUs visible, two processes render complementary tile shards of one frame and the reduced film must be the
+single-GPU film bit for bit (disjoint tiles: every element receives one non-zero addend)."""
+import multiprocessing as mp
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from akari_render_amd import capi, distributed
+from oracle import scene_json
+from tests.helpers import make_config, n_bit_diff
+
+pytestmark = pytest.mark.gpu
+
+
+def test_native_reduce_world_of_one(ctx, cbox_path):
+    sd = scene_json.load_scene(cbox_path, 96, 64)
+    scene = capi.Scene(ctx, sd)
+    film = capi.Film(ctx, 96, 64)
+    capi.pt_render(ctx, scene, make_config(spp=4, spp_per_pass=4), film)
+    before = film.read()
+    comm = capi.Comm(ctx, capi.comm_unique_id(), 0, 1)
+    comm.reduce_film(film, root=0)
+    assert n_bit_diff(film.read(), before) == 0
+    comm.reduce_film(film, root=-1, blocking=False)   # all-reduce, asynchronous on the context's stream
+    ctx.synchronize()
+    assert n_bit_diff(film.read(), before) == 0
+    comm.close()
+    with pytest.raises(capi.AkariError):
+        capi.Comm(ctx, capi.comm_unique_id(), 3, 2)   # rank >= world
+
+
+def _rank_main(rank, world, id_path, cbox_path, out_path):
+    import time
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    ctx = capi.Context(rank)
+    if rank == 0:
+        uid = capi.comm_unique_id()
+        with open(id_path + ".tmp", "wb") as f:
+            f.write(uid)
+        os.replace(id_path + ".tmp", id_path)
+    else:
+        for _ in range(600):
+            if os.path.exists(id_path):
+                break
+            time.sleep(0.05)
+        uid = open(id_path, "rb").read()
+    comm = capi.Comm(ctx, uid, rank, world)
+    sd = scene_json.load_scene(cbox_path, 200, 120)
+    scene = capi.Scene(ctx, sd)
+    film = capi.Film(ctx, 200, 120)
+    capi.pt_render(ctx, scene, distributed.shard_config(make_config(spp=8, spp_per_pass=4), rank, world, 32, 16), film)
+    comm.reduce_film(film, root=0)
+    if rank == 0:
+        np.save(out_path, film.read())
+    comm.close()
+
+
+def test_native_reduce_two_gpus(ctx, cbox_path):
+    if capi.device_count() < 2:
+        pytest.skip("needs two GPUs (the driver's multi-GPU run covers it; one-GPU boxes run the world-of-one test)")
+    sd = scene_json.load_scene(cbox_path, 200, 120)
+    scene = capi.Scene(ctx, sd)
+    full = capi.Film(ctx, 200, 120)
+    capi.pt_render(ctx, scene, make_config(spp=8, spp_per_pass=4), full)
+    with tempfile.TemporaryDirectory() as d:
+        id_path, out_path = os.path.join(d, "id"), os.path.join(d, "film.npy")
+        sp = mp.get_context("spawn")
+        procs = [sp.Process(target=_rank_main, args=(r, 2, id_path, cbox_path, out_path)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0
+        assert n_bit_diff(np.load(out_path), full.read()) == 0
