@@ -47,6 +47,9 @@ class InstanceDesc(C.Structure):
 
 
 MAT_PRINCIPLED, MAT_DIFFUSE, MAT_GLASS, MAT_EMISSION = 0, 1, 2, 3
+MAT_KIND_MASK = 0xFF
+MAT_CS_BASE_COLOR, MAT_CS_SPECULAR_TINT, MAT_CS_COAT_TINT, MAT_CS_EMISSION_COLOR = 0x100, 0x200, 0x400, 0x800  # input given in ACEScg
+COLOR_REPR_ACESCG, COLOR_RGB_ACESCG = 1, 2  # akr_pt_config.color bits (ColorPipeline, color.rs:663-676)
 
 
 class MaterialDesc(C.Structure):
@@ -139,7 +142,7 @@ class PtConfig(_Struct):
         ("filter_type", C.c_uint32),
         ("filter_radius", C.c_float),
         ("sampler_type", C.c_uint32),
-        ("_pad", C.c_uint32),
+        ("color", C.c_uint32),   # akr_color_pipeline_bits (COLOR_REPR_ACESCG | COLOR_RGB_ACESCG); 0 = sRGB / sRGB
         ("sampler_seed", C.c_uint64),
         ("shard_rank", C.c_uint32),
         ("shard_count", C.c_uint32),
@@ -333,10 +336,11 @@ class MaterialData:
     emission_strength: float = 0.0
     normal: tuple = (0.0, 0.0, 0.0)
     graph: Optional["GraphData"] = None
+    colorspaces: int = 0  # MAT_CS_* bits: which constant colour inputs are given in ACEScg
 
     def to_struct(self) -> MaterialDesc:
         m = MaterialDesc()
-        m.kind = self.kind
+        m.kind = self.kind | self.colorspaces
         for name in ("base_color", "specular_tint", "coat_tint", "emission_color", "normal"):
             v = np.asarray(getattr(self, name), dtype=np.float32)
             arr = getattr(m, name)

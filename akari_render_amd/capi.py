@@ -275,7 +275,8 @@ class Scene:
             d = abi.MaterialDesc()
             check(lib().akr_scene_get_material(self.h, i, C.byref(d)))
             md = abi.MaterialData()
-            md.kind = d.kind
+            md.kind = d.kind & abi.MAT_KIND_MASK
+            md.colorspaces = d.kind & 0xF00
             for name in ("base_color", "specular_tint", "coat_tint", "emission_color", "normal"):
                 setattr(md, name, tuple(float(x) for x in getattr(d, name)))
             for name in ("base_alpha", "metallic", "roughness", "ior", "specular_ior_level", "transmission_weight",

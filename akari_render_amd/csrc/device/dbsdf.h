@@ -67,6 +67,38 @@ struct BsdfEval {
     float pdf;
 };
 
+// ---- colour pipeline (color.rs:262-275,614-628; svm/texture/mod.rs:9-43) -------------------------------------------
+// PtParams.color / TexScene.color: ColorPipeline bits. Shading runs in the space of color_repr; constants enter through
+// rgb_to_target_colorspace (their Rgb node's space -> rgb_colorspace) and spectral_uplift (rgb_colorspace -> repr space);
+// the film converts every sample back to sRGB primaries. M * v = (c0 x + c1 y) + c2 z, the AKR-F32 matrix product.
+enum : uint32_t { COLOR_REPR_ACES = 1u, COLOR_RGB_ACES = 2u };
+enum : uint32_t { MAT_KIND_MASK = 0xffu, MAT_CS_BASE_COLOR = 0x100u, MAT_CS_SPECULAR_TINT = 0x200u, MAT_CS_COAT_TINT = 0x400u, MAT_CS_EMISSION_COLOR = 0x800u };
+AKR_HD vec3 cs_convert(vec3 v, bool from_aces, bool to_aces) {
+    if (from_aces == to_aces) return v;
+    if (to_aces)  // srgb_to_aces_with_cat_mat, color.rs:614-620
+        return mk3((0.612494199f * v.x + 0.338737252f * v.y) + 0.048855526f * v.z, (0.070594252f * v.x + 0.917671484f * v.y) + 0.011704306f * v.z,
+                   (0.020727335f * v.x + 0.106882232f * v.y) + 0.872338062f * v.z);
+    // aces_to_srgb_with_cat_mat, color.rs:622-628
+    return mk3((1.707062673f * v.x + -0.619959540f * v.y) + -0.087259850f * v.z, (-0.130976829f * v.x + 1.139032275f * v.y) + -0.007956297f * v.z,
+               (-0.024510601f * v.x + -0.124810932f * v.y) + 1.149395971f * v.z);
+}
+// an Rgb constant of colour space `tag_aces` through both conversions
+AKR_HD vec3 color_input(vec3 v, bool tag_aces, uint32_t color) {
+    v = cs_convert(v, tag_aces, (color & COLOR_RGB_ACES) != 0);
+    return cs_convert(v, (color & COLOR_RGB_ACES) != 0, (color & COLOR_REPR_ACES) != 0);
+}
+// The constant colour inputs of a surface node (those no graph node feeds: fed[k] == false) under the pipeline `color`.
+AKR_HD void convert_color_inputs(MatInputs& in, uint32_t cs_flags, uint32_t color, const bool fed[4]) {
+    if (color == 0 && (cs_flags & 0xf00u) == 0) return;
+    float* slot[4] = {in.base_color, in.specular_tint, in.coat_tint, in.emission_color};
+    const uint32_t bit[4] = {MAT_CS_BASE_COLOR, MAT_CS_SPECULAR_TINT, MAT_CS_COAT_TINT, MAT_CS_EMISSION_COLOR};
+    for (int k = 0; k < 4; k++) {
+        if (fed[k]) continue;
+        vec3 v = color_input(mk3(slot[k][0], slot[k][1], slot[k][2]), (cs_flags & bit[k]) != 0, color);
+        slot[k][0] = v.x; slot[k][1] = v.y; slot[k][2] = v.z;
+    }
+}
+
 // ---- Frame trig (geometry.rs:80-151); the reference's cos_phi uses w.y and sin_phi uses w.x ----
 AKR_HD float cos_theta(vec3 w) { return w.z; }
 AKR_HD float cos2_theta(vec3 w) { return w.z * w.z; }

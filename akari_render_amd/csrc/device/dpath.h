@@ -382,6 +382,7 @@ AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found,
         ind = mk3(clamp_f(ind.x, 0.0f, 1000.0f), clamp_f(ind.y, 0.0f, 1000.0f), clamp_f(ind.z, 0.0f, 1000.0f));
         vec3 L = r.base + ind;
         if (is_nan(L.x) || is_nan(L.y) || is_nan(L.z)) L = mk3(0, 0, 0);
+        if (p.color & COLOR_REPR_ACES) L = cs_convert(L, true, false);  // the film is sRGB: color.to_rgb(SRgb), film.rs:218, color.rs:262-275
         r.film_rgb = mk3(r.film_rgb.x + L.x * 1.0f, r.film_rgb.y + L.y * 1.0f, r.film_rgb.z + L.z * 1.0f);
         r.film_w = r.film_w + 1.0f;
         r.radiance = mk3(0, 0, 0);

@@ -118,7 +118,9 @@ struct TexScene {  // the texture part of DScene
     const DNode* __restrict__ nodes;
     const DImage* __restrict__ images;
     const uint32_t* __restrict__ texels;
-    const MatInputs* __restrict__ mat_inputs;  // raw (unfolded) inputs, one per material
+    const MatInputs* __restrict__ mat_inputs;  // raw (unfolded) inputs, one per material; constants already in the pipeline's space
+    uint32_t color;                            // ColorPipeline bits (dbsdf.h COLOR_*)
+    uint32_t _pad;
 };
 
 // eval_shader (eval.rs:363-380): every node of the (pruned) list in order; values are float4, narrower types
@@ -129,7 +131,11 @@ AKR_HD void eval_graph(const TexScene& ts, uint32_t first, uint32_t count, vec2 
         TexVal v = tv(0, 0, 0, 0);
         switch (nd.op) {
             case NODE_CONST: v = tv(nd.k[0], nd.k[1], nd.k[2], 0.0f); break;
-            case NODE_RGB: v = tv(nd.k[0], nd.k[1], nd.k[2], 1.0f); break;  // sRGB -> sRGB pipeline: identity (texture/mod.rs:9-30)
+            case NODE_RGB: {  // rgb_to_target_colorspace(rgb, node space, pipeline.rgb_colorspace), texture/mod.rs:9-30
+                vec3 c = cs_convert(mk3(nd.k[0], nd.k[1], nd.k[2]), nd.arg[0] == 1u, (ts.color & COLOR_RGB_ACES) != 0);
+                v = tv(c.x, c.y, c.z, 1.0f);
+                break;
+            }
             case NODE_TEXCOORDS: v = tv(uv.x, uv.y, 0.0f, 0.0f); break;
             case NODE_IMAGE: {
                 vec2 st = nd.arg[1] == kNodeNone ? uv : mk2(val[nd.arg[1]].x, val[nd.arg[1]].y);
@@ -150,7 +156,12 @@ AKR_HD void eval_graph(const TexScene& ts, uint32_t first, uint32_t count, vec2 
                 v = (((px + py) & 1) == 0) ? val[nd.arg[2]] : val[nd.arg[3]];
                 break;
             }
-            case NODE_SPECTRAL_UPLIFT: v = val[nd.arg[0]]; break;
+            case NODE_SPECTRAL_UPLIFT: {  // spectral_uplift: rgb_colorspace -> the space of color_repr, texture/mod.rs:31-43
+                TexVal a = val[nd.arg[0]];
+                vec3 c = cs_convert(mk3(a.x, a.y, a.z), (ts.color & COLOR_RGB_ACES) != 0, (ts.color & COLOR_REPR_ACES) != 0);
+                v = tv(c.x, c.y, c.z, a.w);
+                break;
+            }
             case NODE_SEPARATE_COLOR: v = val[nd.arg[0]]; break;
             case NODE_EXTRACT: {
                 TexVal a = val[nd.arg[0]];

@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cstring>
 #include <functional>
+#include <map>
 #include <memory>
 #include <new>
 #include <stdexcept>
@@ -134,6 +135,11 @@ struct akr_scene {
     DevBuf woop, tri_gid, shade, normals, inst, materials, ggx_table, light_entries, light_pdf, light_inst, light_tri_offset,
         light_n_tris, area_entries, area_pdf, inst_tri_offset, bvh_nodes, tex_nodes, tex_images, tex_texels, tex_mat_inputs;
     std::vector<float> ggx_host;
+    // materials / node lists / raw inputs re-compiled for a non-default colour pipeline (akr_pt_config.color), by pipeline
+    struct ColorSet {
+        DevBuf materials, tex_nodes, mat_inputs;
+    };
+    std::map<uint32_t, std::unique_ptr<ColorSet>> color_sets;
     DScene dscene;
     float r2c[16], c2w[16];
     uint32_t c2w_identity = 0;
@@ -370,6 +376,16 @@ static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pas
     p.states = se->states.as<Pcg32>();
     p.film = se->film->data;
     p.counters = se->counters.as<uint64_t>();
+    p.color = c.color;
+    p.sc.tex.color = c.color;
+    if (c.color != 0) {  // the material tables of this pipeline (created by akr_pt_begin)
+        const auto& set = *se->scene->color_sets.at(c.color);
+        p.sc.materials = set.materials.as<DMaterial>();
+        if (s->cs.has_textures) {
+            p.sc.tex.nodes = set.tex_nodes.as<DNode>();
+            p.sc.tex.mat_inputs = set.mat_inputs.as<MatInputs>();
+        }
+    }
     p.sampler = c.sampler_type;
     if (c.sampler_type == AKR_SAMPLER_PMJ02BN) {  // Pmj02BnSamplerCreator::new (sampler/mod.rs:376-395)
         p.smp_seed = (uint32_t)c.sampler_seed;
@@ -475,6 +491,7 @@ static void validate_config(const akr_pt_config& c) {
     if (c.spp_per_pass == 0) throw std::invalid_argument("akr_pt_config: spp_per_pass must be > 0");
     if (c.filter_type > AKR_FILTER_GAUSSIAN) throw std::invalid_argument("akr_pt_config: unknown filter_type");
     if (c.sampler_type > AKR_SAMPLER_PMJ02BN) throw std::invalid_argument("akr_pt_config: unknown sampler_type");
+    if (c.color > (AKR_COLOR_REPR_ACESCG | AKR_COLOR_RGB_ACESCG)) throw std::invalid_argument("akr_pt_config: unknown colour pipeline bits");
     if (c.sampler_type == AKR_SAMPLER_PMJ02BN && c.spp > 65536u)
         throw std::invalid_argument("Pmj02BnSampler supports up to 65536 spp (sampler/mod.rs:381-387)");
     uint32_t tw = c.tile_w ? c.tile_w : 32, th = c.tile_h ? c.tile_h : 32;
@@ -825,6 +842,21 @@ AKR_API int32_t akr_pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_co
         se->scene = scene;
         se->film = film;
         se->cfg = *cfg;
+        if (cfg->color != 0 && !scene->color_sets.count(cfg->color)) {
+            // ColorPipeline other than sRGB / sRGB: the scene's constants were folded for the default pipeline; fold them again
+            // for this one (svm/texture/mod.rs:9-43 at every Rgb / spectral_uplift node) and keep the tables with the scene
+            CompiledScene tmp;
+            tmp.images = scene->cs.images;
+            std::vector<akr_material_desc> descs;
+            compile_materials(scene->flat, cfg->color, tmp, descs);
+            auto set = std::make_unique<akr_scene::ColorSet>();
+            set->materials.upload(tmp.materials);
+            if (tmp.has_textures) {
+                set->tex_nodes.upload(tmp.tex_nodes);
+                set->mat_inputs.upload(tmp.mat_inputs);
+            }
+            scene->color_sets[cfg->color] = std::move(set);
+        }
         const uint64_t n = (uint64_t)film->width * film->height;
         // init_pcg32_buffer_with_seed (sampler/mod.rs:148-160): host StdRng(seed) u64 per pixel, device new_seq_offset
         if (cfg->sampler_type == AKR_SAMPLER_PMJ02BN) {
@@ -1535,7 +1567,7 @@ AKR_API int32_t akr_probe_material_inputs(akr_context* ctx, akr_scene* scene, ui
     return guarded([&] {
         const CompiledScene& cs = scene->cs;
         if (!ctx) {
-            const TexScene ts{cs.tex_nodes.data(), cs.images.data(), cs.texels.data(), cs.mat_inputs.data()};
+            const TexScene ts{cs.tex_nodes.data(), cs.images.data(), cs.texels.data(), cs.mat_inputs.data(), 0, 0};
             const DMaterial& m = cs.materials[material];
             for (uint32_t i = 0; i < n; i++) {
                 MatInputs in;

@@ -84,11 +84,14 @@ FlatScene FlatScene::from_desc(const akr_scene_desc& d) {
 static vec3 v3(const float* p) { return mk3(p[0], p[1], p[2]); }
 
 static_assert(sizeof(MatInputs) == sizeof(akr_material_desc), "MatInputs mirrors akr_material_desc");
-DMaterial fold_material(const akr_material_desc& m) {
+DMaterial fold_material(const akr_material_desc& m, uint32_t color) {
     DMaterial d;
     std::memset(&d, 0, sizeof d);
     MatInputs in;
     std::memcpy(&in, &m, sizeof in);
+    const bool fed[4] = {false, false, false, false};
+    convert_color_inputs(in, m.kind, color, fed);  // Rgb node space -> rgb_colorspace -> repr space (texture/mod.rs:9-43)
+    in.kind = m.kind & MAT_KIND_MASK;
     if (!fold_inputs(in, d)) throw std::invalid_argument("akr_material_desc: unknown kind");
     for (uint32_t i = 0; i < 14; i++) d.tex_input[i] = 0xffffffffu;
     return d;
@@ -145,7 +148,7 @@ static bool alpha_is_one(const HostGraph& g, const std::vector<HostImage>& image
         default: return false;  // float / float3 / texcoords / mapping / extract / normal_map values have w = 0
     }
 }
-static void compile_graph(const HostGraph& g, const std::vector<HostImage>& images, akr_material_desc& desc, DMaterial& dm, CompiledScene& out) {
+static void compile_graph(const HostGraph& g, const std::vector<HostImage>& images, uint32_t color, akr_material_desc& desc, DMaterial& dm, CompiledScene& out) {
     const uint32_t n_images = (uint32_t)images.size();
     const uint32_t n = (uint32_t)g.nodes.size();
     std::vector<uint8_t> varying(n, 0);
@@ -171,16 +174,14 @@ static void compile_graph(const HostGraph& g, const std::vector<HostImage>& imag
     }
     // constant inputs: evaluate the whole list once (the varying nodes see uv = 0 and are not read)
     std::vector<TexVal> val(n ? n : 1);
-    TexScene none{reinterpret_cast<const DNode*>(g.nodes.data()), nullptr, nullptr, nullptr};
     {
         // images are not available here; constant inputs never read an image node
         std::vector<akr_shader_node> tmp(g.nodes);
         for (auto& nd : tmp)
             if (nd.op == AKR_NODE_IMAGE) nd.op = AKR_NODE_CONST;
-        TexScene ts{reinterpret_cast<const DNode*>(tmp.data()), nullptr, nullptr, nullptr};
+        TexScene ts{reinterpret_cast<const DNode*>(tmp.data()), nullptr, nullptr, nullptr, color, 0};
         eval_graph(ts, 0, n, mk2(0, 0), val.data());
     }
-    (void)none;
     uint32_t map[AKR_IN_COUNT];
     bool any_varying = false;
     MatInputs in;
@@ -196,9 +197,14 @@ static void compile_graph(const HostGraph& g, const std::vector<HostImage>& imag
             any_varying = any_varying || v;
         }
         apply_inputs(cmap, val.data(), in);
+        // constants no node feeds go through the pipeline here; node-fed ones went through it inside the graph (Rgb / uplift nodes)
+        const bool fed[4] = {g.input[AKR_IN_BASE_COLOR] != AKR_NODE_NONE, g.input[AKR_IN_SPECULAR_TINT] != AKR_NODE_NONE,
+                             g.input[AKR_IN_COAT_TINT] != AKR_NODE_NONE, g.input[AKR_IN_EMISSION_COLOR] != AKR_NODE_NONE};
+        convert_color_inputs(in, desc.kind, color, fed);
+        in.kind = desc.kind & MAT_KIND_MASK;
         std::memcpy(&desc, &in, sizeof in);
     }
-    dm = fold_material(desc);
+    dm = fold_material(desc, 0);  // desc is in the pipeline's space now
     if (!any_varying) return;
     // prune: nodes reachable from the varying inputs, in index order
     std::vector<uint8_t> keep(n, 0);
@@ -385,6 +391,40 @@ static void share_plane_row(const float* wa, float* wb, const vec3 vb[3]) {
 void build_bvh8(const std::vector<float>& tri_bounds, uint32_t n_tris, float pad, uint32_t stride, bool balanced, std::vector<uint32_t>& order,
                 std::vector<uint32_t>& nodes, uint32_t& depth);
 
+// The material part of the scene under the colour pipeline `color` (ColorPipeline bits): folded records, pruned node lists of
+// the texture-fed materials, raw inputs. `out.images` must be filled already. The light tables always come from the default
+// pipeline (load.rs:316-319 fixes sRGB for the power kernel), i.e. from compile_scene's own call with color = 0.
+void compile_materials(const FlatScene& flat, uint32_t color, CompiledScene& out, std::vector<akr_material_desc>& descs) {
+    out.materials.clear();
+    out.tex_nodes.clear();
+    out.mat_inputs.clear();
+    out.has_textures = false;
+    descs = flat.materials;
+    for (size_t mi = 0; mi < flat.materials.size(); mi++) {
+        DMaterial d;
+        if (!flat.graphs.empty() && !flat.graphs[mi].nodes.empty()) {
+            compile_graph(flat.graphs[mi], flat.images, color, descs[mi], d, out);
+        } else {
+            d = fold_material(descs[mi], color);
+            MatInputs in;  // keep the converted constants: mat_inputs is what the device re-folds textured materials from
+            std::memcpy(&in, &descs[mi], sizeof in);
+            const bool fed[4] = {false, false, false, false};
+            convert_color_inputs(in, descs[mi].kind, color, fed);
+            in.kind = descs[mi].kind & MAT_KIND_MASK;
+            std::memcpy(&descs[mi], &in, sizeof in);
+        }
+        const bool tex = (d.flags & MF_TEXTURED) != 0;
+        if ((d.kind == MAT_PRINCIPLED || d.kind == MAT_DIFFUSE) && (d.base_alpha < 1.0f || (d.flags & MF_ALPHA_TEXTURED))) out.has_alpha = true;
+        // a textured material may switch the specular / coat layers on at any point
+        if (d.kind == MAT_PRINCIPLED && ((d.flags & (MF_SPEC | MF_COAT)) || tex)) out.needs_ggx_table = true;
+        out.materials.push_back(d);
+    }
+    if (out.has_textures) {
+        out.mat_inputs.resize(descs.size());
+        std::memcpy(out.mat_inputs.data(), descs.data(), descs.size() * sizeof(MatInputs));
+    }
+}
+
 void compile_scene(const FlatScene& flat, CompiledScene& out) {
     const size_t n_inst = flat.instances.size();
     out = CompiledScene();
@@ -401,24 +441,9 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
         out.images.push_back(d);
         out.texels.insert(out.texels.end(), im.words.begin(), im.words.end());
     }
-    std::vector<akr_material_desc> descs(flat.materials);  // constants after folding the constant graph inputs
-    for (size_t mi = 0; mi < flat.materials.size(); mi++) {
-        DMaterial d;
-        if (!flat.graphs.empty() && !flat.graphs[mi].nodes.empty())
-            compile_graph(flat.graphs[mi], flat.images, descs[mi], d, out);
-        else
-            d = fold_material(descs[mi]);
-        const bool tex = (d.flags & MF_TEXTURED) != 0;
-        if ((d.kind == MAT_PRINCIPLED || d.kind == MAT_DIFFUSE) && (d.base_alpha < 1.0f || (d.flags & MF_ALPHA_TEXTURED))) out.has_alpha = true;
-        // a textured material may switch the specular / coat layers on at any point
-        if (d.kind == MAT_PRINCIPLED && ((d.flags & (MF_SPEC | MF_COAT)) || tex)) out.needs_ggx_table = true;
-        out.materials.push_back(d);
-    }
-    if (out.has_textures) {
-        out.mat_inputs.resize(descs.size());
-        std::memcpy(out.mat_inputs.data(), descs.data(), descs.size() * sizeof(MatInputs));
-    }
-    const TexScene host_tex{out.tex_nodes.data(), out.images.data(), out.texels.data(), out.mat_inputs.data()};
+    std::vector<akr_material_desc> descs;  // constants after folding the constant graph inputs, in the (default) pipeline's space
+    compile_materials(flat, 0, out, descs);
+    const TexScene host_tex{out.tex_nodes.data(), out.images.data(), out.texels.data(), out.mat_inputs.data(), 0, 0};
     // instance table
     std::vector<Xform> xf(n_inst);
     out.inst.assign(32 * n_inst, 0.0f);

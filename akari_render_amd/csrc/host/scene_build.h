@@ -76,7 +76,10 @@ struct CompiledScene {
     float scene_lo[3], scene_hi[3];
 };
 
-DMaterial fold_material(const akr_material_desc& m);
+DMaterial fold_material(const akr_material_desc& m, uint32_t color = 0);
+// materials / node lists / raw inputs under the colour pipeline `color` (scene_build.cpp); fills out.materials, out.tex_nodes,
+// out.mat_inputs only
+void compile_materials(const FlatScene& flat, uint32_t color, CompiledScene& out, std::vector<akr_material_desc>& descs);
 void build_alias_table(const std::vector<float>& weights, std::vector<AliasEntry>& entries, std::vector<float>& pdf);
 void compile_scene(const FlatScene& flat, CompiledScene& out);
 // PerspectiveCameraData::new (camera/mod.rs:119-153)

@@ -176,12 +176,19 @@ struct BufferStore {
 struct ConstVal {
     float v[4];
     int n;
+    bool aces = false;  // an Rgb constant declared in ACEScg (akari_scenegraph ColorSpace "aces")
 };
+bool parse_rgb_colorspace(const JsonValue& n) {  // -> is ACEScg
+    const std::string cs = n.has("colorspace") ? n.at("colorspace").as_string() : std::string("srgb");
+    if (cs == "srgb") return false;
+    if (cs == "aces") return true;
+    throw std::runtime_error("unsupported: constant colour in colour space '" + cs + "' (RgbColorSpace is srgb | aces, color.rs:6-11)");
+}
 // constant evaluation of a shader node (svm/eval.rs:97-135): Float, Float3, Rgb (+alpha 1), SpectralUplift
 ConstVal fold_const(const JsonValue& nodes, const JsonValue& ref) {
     const JsonValue& n = nodes.at(ref.at("id").as_string());
     const std::string& ty = n.at("type").as_string();
-    ConstVal c{{0, 0, 0, 1}, 1};
+    ConstVal c{{0, 0, 0, 1}, 1, false};
     if (ty == "float") {
         c.v[0] = n.at("value").as_f32();
         c.n = 1;
@@ -189,8 +196,7 @@ ConstVal fold_const(const JsonValue& nodes, const JsonValue& ref) {
         for (int i = 0; i < 3; i++) c.v[i] = n.at("value").at(i).as_f32();
         c.n = 3;
     } else if (ty == "rgb") {
-        const std::string cs = n.has("colorspace") ? n.at("colorspace").as_string() : std::string("srgb");
-        if (cs != "srgb") throw std::runtime_error("unsupported: constant colour in colour space '" + cs + "'");
+        c.aces = parse_rgb_colorspace(n);
         for (int i = 0; i < 3; i++) c.v[i] = n.at("value").at(i).as_f32();
         c.v[3] = 1.0f;
         c.n = 4;
@@ -202,11 +208,12 @@ ConstVal fold_const(const JsonValue& nodes, const JsonValue& ref) {
     return c;
 }
 float fold_float(const JsonValue& nodes, const JsonValue& ref) { return fold_const(nodes, ref).v[0]; }  // eval_float_auto_convert
-void fold_color(const JsonValue& nodes, const JsonValue& ref, float* rgb, float* alpha) {
+bool fold_color(const JsonValue& nodes, const JsonValue& ref, float* rgb, float* alpha) {  // -> the constant is in ACEScg
     ConstVal c = fold_const(nodes, ref);
     if (c.n >= 3) { rgb[0] = c.v[0]; rgb[1] = c.v[1]; rgb[2] = c.v[2]; }
     else { rgb[0] = c.v[0]; rgb[1] = 0.0f; rgb[2] = 0.0f; }
     if (alpha) *alpha = c.n == 4 ? c.v[3] : 1.0f;
+    return c.aces;
 }
 
 // true when the node evaluates to the same value everywhere and fold_const can do it
@@ -305,10 +312,8 @@ struct GraphBuilder {
             r = push(AKR_NODE_CONST, AKR_NODE_NONE, AKR_NODE_NONE, AKR_NODE_NONE, AKR_NODE_NONE, n.at("value").at(0).as_f32(), n.at("value").at(1).as_f32(),
                      n.at("value").at(2).as_f32());
         } else if (ty == "rgb") {
-            const std::string cs = n.has("colorspace") ? n.at("colorspace").as_string() : std::string("srgb");
-            if (cs != "srgb") throw std::runtime_error("unsupported: constant colour in colour space '" + cs + "'");
-            r = push(AKR_NODE_RGB, AKR_NODE_NONE, AKR_NODE_NONE, AKR_NODE_NONE, AKR_NODE_NONE, n.at("value").at(0).as_f32(), n.at("value").at(1).as_f32(),
-                     n.at("value").at(2).as_f32());
+            r = push(AKR_NODE_RGB, parse_rgb_colorspace(n) ? 1u : 0u, AKR_NODE_NONE, AKR_NODE_NONE, AKR_NODE_NONE, n.at("value").at(0).as_f32(),
+                     n.at("value").at(1).as_f32(), n.at("value").at(2).as_f32());
         } else if (ty == "spectral_uplift") {
             r = push(AKR_NODE_SPECTRAL_UPLIFT, emit(n.at("rgb")));
         } else if (ty == "texcoords") {
@@ -362,9 +367,15 @@ void load_shader(const JsonValue& shader, BufferStore& bufs, FlatScene& flat, st
     m.specular_ior_level = 0.5f;
     GraphBuilder gb{nodes, bufs, flat, image_index, HostGraph(), {}};
     // constant inputs are folded here (svm/eval.rs:97-135), everything else becomes graph nodes
+    uint32_t cs_flags = 0;  // AKR_MAT_CS_*: which folded colour constants are ACEScg
     auto color = [&](const char* key, uint32_t input, float* rgb, float* alpha) {
-        if (is_const_tree(nodes, n.at(key))) fold_color(nodes, n.at(key), rgb, alpha);
-        else gb.graph.input[input] = gb.emit(n.at(key));
+        if (is_const_tree(nodes, n.at(key))) {
+            if (fold_color(nodes, n.at(key), rgb, alpha))
+                cs_flags |= input == AKR_IN_BASE_COLOR ? AKR_MAT_CS_BASE_COLOR : input == AKR_IN_SPECULAR_TINT ? AKR_MAT_CS_SPECULAR_TINT
+                          : input == AKR_IN_COAT_TINT ? AKR_MAT_CS_COAT_TINT : input == AKR_IN_EMISSION_COLOR ? AKR_MAT_CS_EMISSION_COLOR : 0u;
+        } else {
+            gb.graph.input[input] = gb.emit(n.at(key));
+        }
     };
     auto scalar = [&](const char* key, uint32_t input, float* v) {
         if (is_const_tree(nodes, n.at(key))) *v = fold_float(nodes, n.at(key));
@@ -401,6 +412,7 @@ void load_shader(const JsonValue& shader, BufferStore& bufs, FlatScene& flat, st
     } else {
         throw std::runtime_error("unsupported: surface shader '" + ty + "'");
     }
+    m.kind |= cs_flags;
     graph_out = std::move(gb.graph);
 }
 
@@ -561,12 +573,31 @@ static void parse_one_task(const JsonValue* j, akr_pt_config* cfg, std::string* 
         else throw std::runtime_error("unknown sampler '" + ty + "'");
         if (s.has("seed")) cfg->sampler_seed = (uint64_t)s.at("seed").as_number();
     }
-    if (j->has("color")) {  // ColorPipeline (color.rs:663-676): only the default RGB / sRGB pipeline is implemented
+    if (j->has("color")) {  // ColorPipeline (color.rs:663-676)
         const JsonValue& c = j->at("color");
-        if (c.has("rgb_colorspace") && c.at("rgb_colorspace").as_string() != "srgb")
-            throw std::runtime_error("unsupported: rgb_colorspace '" + c.at("rgb_colorspace").as_string() + "' (only \"srgb\")");
-        if (c.has("color_repr") && c.at("color_repr").has("type") && c.at("color_repr").at("type").as_string() != "rgb")
-            throw std::runtime_error("unsupported: color_repr '" + c.at("color_repr").at("type").as_string() + "' (spectral rendering is todo!() in the reference as well)");
+        auto space = [](const std::string& v) -> bool {  // -> is ACEScg
+            if (v == "srgb") return false;
+            if (v == "aces") return true;
+            throw std::runtime_error("unknown rgb colour space '" + v + "' (srgb | aces, color.rs:6-11)");
+        };
+        cfg->color = 0;
+        if (c.has("rgb_colorspace") && space(c.at("rgb_colorspace").as_string())) cfg->color |= AKR_COLOR_RGB_ACESCG;
+        if (c.has("color_repr")) {
+            // ColorRepr is an internally tagged enum around a bare RgbColorSpace (color.rs:78-86), a shape serde cannot read
+            // back; accepted here: {"type": "rgb", "colorspace": "aces"} and the ToString form "rgb_aces" (color.rs:87-93)
+            const JsonValue& r = c.at("color_repr");
+            std::string ty = (r.type == JsonValue::String) ? r.as_string() : r.at("type").as_string();
+            if (ty == "spectral") throw std::runtime_error("unsupported: color_repr 'spectral' (todo!() in the reference as well)");
+            bool aces = false;
+            if ((r.type == JsonValue::String)) {
+                if (ty.rfind("rgb_", 0) != 0) throw std::runtime_error("unknown color_repr '" + ty + "'");
+                aces = space(ty.substr(4));
+            } else {
+                if (ty != "rgb") throw std::runtime_error("unknown color_repr type '" + ty + "'");
+                if (r.has("colorspace")) aces = space(r.at("colorspace").as_string());
+            }
+            if (aces) cfg->color |= AKR_COLOR_REPR_ACESCG;
+        }
     }
     if (j->has("film")) {
         const JsonValue& f = j->at("film");
@@ -586,6 +617,8 @@ static void parse_one_task(const JsonValue* j, akr_pt_config* cfg, std::string* 
         if (film_out && f.has("out")) *film_out = f.at("out").as_string();
     }
     if (task) {  // sampler and film filter are per RenderConfig, whatever the method
+        if (cfg->color != 0 && (task->is_aov || task->is_gpt || task->is_mcmc))
+            throw std::runtime_error("unsupported: a colour pipeline other than srgb / srgb with the aov, gpt and mcmc_opt integrators (pt only)");
         task->aov.filter_type = cfg->filter_type;
         task->aov.filter_radius = cfg->filter_radius;
         task->aov.sampler_type = cfg->sampler_type;

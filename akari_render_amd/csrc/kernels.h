@@ -21,6 +21,7 @@ struct PtParams {
     int32_t pixel_offset[2];
     uint32_t filter_type;
     float filter_radius;
+    uint32_t color;          // ColorPipeline bits (device/dbsdf.h COLOR_*): the space the path shades in
     uint32_t pass_spp;       // samples per pixel per pass (spp_per_pass)
     uint32_t n_passes;       // passes fused into this launch (>= 1)
     uint32_t last_pass_spp;  // samples of the launch's last pass (<= pass_spp)

@@ -73,13 +73,18 @@ typedef struct {
 } akr_instance_desc;
 
 /* A surface shader graph whose inputs are constants (all of scenes/cbox), already folded:
- * svm/compiler.rs:116-337 + svm/eval.rs:97-269 applied on the host. Colours are linear RGB in the
- * pipeline's colour space (svm/texture/mod.rs:9-40). */
+ * svm/compiler.rs:116-337 + svm/eval.rs:97-269 applied on the host. Colours are linear RGB in the colour space their
+ * Rgb node declares (akari_scenegraph ColorSpace: srgb, or ACEScg when the AKR_MAT_CS_* bit of `kind` is set); the render's
+ * ColorPipeline converts them (svm/texture/mod.rs:9-43): Rgb node space -> rgb_colorspace, then spectral_uplift ->
+ * the space of color_repr. */
 typedef enum {
     AKR_MAT_PRINCIPLED = 0,  /* ShaderNode::PrincipledBsdf, svm/surface/principled.rs */
     AKR_MAT_DIFFUSE = 1,     /* ShaderNode::DiffuseBsdf,    svm/surface/diffuse.rs:83-104 */
     AKR_MAT_GLASS = 2,       /* ShaderNode::GlassBsdf,      svm/surface/glass.rs */
-    AKR_MAT_EMISSION = 3     /* ShaderNode::Emission,       svm/mod.rs:114-123 */
+    AKR_MAT_EMISSION = 3,    /* ShaderNode::Emission,       svm/mod.rs:114-123 */
+    AKR_MAT_KIND_MASK = 0xff,
+    /* OR-ed into akr_material_desc.kind: this constant colour input is given in ACEScg instead of sRGB primaries */
+    AKR_MAT_CS_BASE_COLOR = 0x100, AKR_MAT_CS_SPECULAR_TINT = 0x200, AKR_MAT_CS_COAT_TINT = 0x400, AKR_MAT_CS_EMISSION_COLOR = 0x800
 } akr_material_kind;
 
 typedef struct {
@@ -106,13 +111,14 @@ typedef struct {
 #define AKR_NODE_NONE 0xffffffffu
 typedef enum {
     AKR_NODE_CONST = 0,          /* Float / Float3: (k0,k1,k2,0)                           eval.rs:109-116 */
-    AKR_NODE_RGB = 1,            /* Rgb (colorspace srgb): (k0,k1,k2,1)                    eval.rs:123-133 */
+    AKR_NODE_RGB = 1,            /* Rgb: (k0,k1,k2,1) converted from its colour space (arg0: 0 / NONE = srgb,
+                                    1 = ACEScg) to the pipeline's rgb_colorspace           eval.rs:123-133 */
     AKR_NODE_TEXCOORDS = 2,      /* si.uv: (u,v,0,0)                                       eval.rs:219-226 */
     AKR_NODE_IMAGE = 3,          /* arg0 image, arg1 uv node | NONE, arg2 1 = sRGB decode  eval.rs:134-154 */
     AKR_NODE_MAPPING = 4,        /* arg0 vector, arg1 location, arg2 scale, arg3 akr_mapping_type (rotation is
                                     ignored by the reference)                              eval.rs:192-207 */
     AKR_NODE_CHECKERBOARD = 5,   /* arg0 vector | NONE, arg1 scale, arg2 color1, arg3 color2   eval.rs:227-240 */
-    AKR_NODE_SPECTRAL_UPLIFT = 6,/* arg0 rgb: identity in the RGB/sRGB pipeline            eval.rs:155-175 */
+    AKR_NODE_SPECTRAL_UPLIFT = 6,/* arg0 rgb: rgb_colorspace -> the space of color_repr    eval.rs:155-175 */
     AKR_NODE_SEPARATE_COLOR = 7, /* arg0 colour (carries the value for AKR_NODE_EXTRACT)   eval.rs:241-256 */
     AKR_NODE_EXTRACT = 8,        /* arg0 node, arg1 akr_extract_field                      eval.rs:208-218 */
     AKR_NODE_NORMAL_MAP = 9      /* arg0 normal, arg1 strength (tangent space)             eval.rs:176-191 */
@@ -181,6 +187,10 @@ typedef enum { AKR_FILTER_BOX = 0, AKR_FILTER_GAUSSIAN = 1 } akr_filter_type;   
 /* sampler/mod.rs:282-295. PMJ02BN runs on REGENERATED tables (the reference's copies of pbrt-v4's are not in its tree):
  * same algorithm, different point sets / blue-noise arrays, so its images are not bit-comparable with the reference's. */
 typedef enum { AKR_SAMPLER_INDEPENDENT = 0, AKR_SAMPLER_PMJ02BN = 1 } akr_sampler_type;
+/* ColorPipeline (color.rs:663-676) as bits of akr_pt_config.color; 0 = the default {color_repr: Rgb(SRgb), rgb_colorspace:
+ * SRgb}. Shading happens in the space of color_repr; the film is always sRGB-primaries linear (film.rs:176-229 converts
+ * every sample with color.to_rgb(SRgb), color.rs:262-275). Spectral rendering is todo!() in the reference. */
+typedef enum { AKR_COLOR_REPR_ACESCG = 1, AKR_COLOR_RGB_ACESCG = 2 } akr_color_pipeline_bits;
 
 typedef struct {
     uint32_t spp, max_depth, spp_per_pass, rr_depth;
@@ -190,7 +200,7 @@ typedef struct {
     uint32_t filter_type;
     float filter_radius;
     uint32_t sampler_type;
-    uint32_t _pad;
+    uint32_t color;           /* akr_color_pipeline_bits; 0 = sRGB / sRGB */
     uint64_t sampler_seed;
     /* Multi-GPU sharding (no reference counterpart): rank r of n renders the pixel tiles t with
      * t % n == r (tiles of tile_w x tile_h in row-major tile order; 0 = 32). shard_count <= 1 renders all.

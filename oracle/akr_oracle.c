@@ -77,6 +77,8 @@ typedef struct {
     float table[16 * 16 * 16];
     int has_table;
     struct or_bvh *bvh;          /* optional, checker-side only (or_accel.h); NULL = the exhaustive loop below */
+    uint32_t color;              /* ColorPipeline of the render in progress (OR_COLOR_*), set by the render entry points; 0 during
+                                  * scene creation: the light tables come from the sRGB pipeline (load.rs:316-319) */
 } or_scene;
 
 typedef struct { v3 o, d; float t_min, t_max; uint32_t ex0_inst, ex0_prim, ex1_inst, ex1_prim; } or_ray;
@@ -238,9 +240,10 @@ static inline int or_alpha_test(const or_scene *sc, uint32_t inst, uint32_t prim
     uint32_t slot = (g->material_slots && g->n_triangles > 1) ? g->material_slots[prim] : 0;
     uint32_t mid = in->materials[slot < in->n_materials ? slot : 0];
     const or_material_desc *m = &sc->materials[mid];
-    float alpha = (m->kind == OR_MAT_PRINCIPLED || m->kind == OR_MAT_DIFFUSE) ? m->base_alpha : 1.0f;
+    const uint32_t mkind = m->kind & OR_MAT_KIND_MASK;
+    float alpha = (mkind == OR_MAT_PRINCIPLED || mkind == OR_MAT_DIFFUSE) ? m->base_alpha : 1.0f;
     if (sc->graphs && sc->graphs[mid].n_nodes && sc->graphs[mid].input[OR_IN_BASE_COLOR] != OR_NODE_NONE &&
-        (m->kind == OR_MAT_PRINCIPLED || m->kind == OR_MAT_DIFFUSE)) {
+        (mkind == OR_MAT_PRINCIPLED || mkind == OR_MAT_DIFFUSE)) {
         /* SvmEvalMode::Alpha (principled.rs:15-21) at the candidate's uv (mesh.rs:426-485; this restatement uses the
          * uv defaults of surface_interaction for meshes without uvs) */
         uint32_t p3 = prim * 3;
@@ -249,7 +252,7 @@ static inline int or_alpha_test(const or_scene *sc, uint32_t inst, uint32_t prim
         else { uv0 = V2(0.0f, 0.0f); uv1 = V2(1.0f, 0.0f); uv2 = V2(1.0f, 0.1f); }
         v2 uv = interp2(V2(u, v), uv0, uv1, uv2);
         or_material_desc at;
-        or_material_at(m, &sc->graphs[mid], sc->images, uv.x, uv.y, &at);
+        or_material_at(m, &sc->graphs[mid], sc->images, sc->color, uv.x, uv.y, &at);
         alpha = at.base_alpha;
     }
     if (alpha >= 1.0f) return 1;
@@ -366,7 +369,7 @@ static or_surface *or_build_closure(or_closure_pool *p, const or_scene *sc, cons
         inner->color = V3(r, r, r);
     } else {
         or_material_desc at;
-        or_material_at(&sc->materials[si->material], sc->graphs ? &sc->graphs[si->material] : 0, sc->images, si->uv.x, si->uv.y, &at);
+        or_material_at(&sc->materials[si->material], sc->graphs ? &sc->graphs[si->material] : 0, sc->images, sc->color, si->uv.x, si->uv.y, &at);
         const or_material_desc *m = &at;
         switch (m->kind) {
         case OR_MAT_PRINCIPLED: inner = or_build_principled(p, sc, m, si); break;
@@ -569,12 +572,12 @@ OR_EXPORT or_scene *or_scene_create(const or_scene_desc *d) {
             uint32_t mid = in->materials[k];
             const or_material_desc *md = &sc->materials[mid];
             const or_material_graph *gr = sc->graphs ? &sc->graphs[mid] : 0;
-            if (gr && gr->n_nodes && (md->kind == OR_MAT_PRINCIPLED || md->kind == OR_MAT_EMISSION) &&
+            if (gr && gr->n_nodes && ((md->kind & OR_MAT_KIND_MASK) == OR_MAT_PRINCIPLED || (md->kind & OR_MAT_KIND_MASK) == OR_MAT_EMISSION) &&
                 (or_node_varies(gr, gr->input[OR_IN_EMISSION_COLOR]) || or_node_varies(gr, gr->input[OR_IN_EMISSION_STRENGTH]))) {
                 any |= 1; /* estimate_emission_tex_intensity_fast -> None (load.rs:76-92) */
             } else {
                 or_material_desc at; /* constant nodes feeding the emission inputs are folded first */
-                or_material_at(md, gr, sc->images, 0.0f, 0.0f, &at);
+                or_material_at(md, gr, sc->images, 0, 0.0f, 0.0f, &at);
                 any |= or_has_potential_emission(&at);
             }
         }
@@ -828,6 +831,11 @@ static void or_render_pixel(or_job *j, uint32_t x, uint32_t y) { /* kernel body,
         v3 L = or_radiance(sc, cfg, ray, &smp, &j->stats);
         /* film.add_sample(p, L, w = 1): film.rs:196-229, color.rs:337-351 */
         if (or_isnan(L.x) || or_isnan(L.y) || or_isnan(L.z)) L = V3(0, 0, 0);
+        if (cfg->color & OR_COLOR_REPR_ACES) { /* the film is sRGB: color.to_rgb(SRgb), film.rs:218, color.rs:262-275 */
+            float c[3] = {L.x, L.y, L.z};
+            or_cs_convert(c, 1, 0);
+            L = V3(c[0], c[1], c[2]);
+        }
         const float w = 1.0f;
         j->film[3 * (uint64_t)i + 0] += L.x * w;
         j->film[3 * (uint64_t)i + 1] += L.y * w;
@@ -870,6 +878,7 @@ static void or_init_sampler_states(uint32_t sampler_type, uint64_t n, uint32_t w
  * states: Pcg32[N] in/out (pass NULL to have them initialised from cfg->sampler_seed). Runs ceil(spp/spp_per_pass)
  * passes exactly like the host loop at pt.rs:1126-1149. */
 OR_EXPORT int or_pt_render(const or_scene *sc, const or_pt_config *cfg, float *film, uint64_t *states_io, uint32_t n_threads, or_stats *stats_out) {
+    ((or_scene *)sc)->color = cfg->color; /* the pipeline every material evaluation of this render sees */
     uint64_t N = (uint64_t)sc->width * sc->height;
     or_pcg32 *states = (or_pcg32 *)states_io;
     int own_states = 0;
@@ -962,6 +971,7 @@ static void *or_aov_worker(void *arg) {
     return 0;
 }
 OR_EXPORT int or_aov_render(const or_scene *sc, const or_aov_config *cfg, float *film, uint32_t n_threads, uint64_t *n_rays_out) {
+    ((or_scene *)sc)->color = 0; /* these integrators run in the default sRGB / sRGB pipeline here */
     uint64_t N = (uint64_t)sc->width * sc->height;
     or_pcg32 *states = (or_pcg32 *)malloc(sizeof(or_pcg32) * N);
     or_init_sampler_states(cfg->sampler_type, N, sc->width, cfg->sampler_seed, states);
@@ -1288,6 +1298,7 @@ static int or_gpt_sources(int32_t cp, int32_t o, uint32_t r, uint32_t out[3]) {
  * otherwise written with the reconstructed image, splat_scale = 1). aux (optional, reconstruction != none):
  * [primal 3N | Gx 3(W+1)(H+1) | Gy 3(W+1)(H+1)] = the accumulated sums of gpt.rs:441-455 (divide by spp for the mean). */
 OR_EXPORT int or_gpt_render(const or_scene *sc, const or_gpt_config *g, float *film, float *aux, uint32_t n_threads) {
+    ((or_scene *)sc)->color = 0; /* these integrators run in the default sRGB / sRGB pipeline here */
     const uint32_t W = sc->width, H = sc->height;
     const uint64_t N = (uint64_t)W * H, NG = (uint64_t)(W + 1) * (H + 1);
     if (g->stride < 1 || g->stride >= W || g->stride >= H) return -1;
@@ -1519,6 +1530,7 @@ static or_mcmc_eval or_mcmc_evaluate(const or_scene *sc, const or_mcmc_config *c
 /* out: film (7N floats; the direct pass fills rgb + weight, the chains the splat channels), result[4] = {b (normalisation),
  * acceptance rate, splat scale as f32 bits, contribution as f32 bits} (doubles / reinterpreted), chain_states (10 u32 each). */
 OR_EXPORT int or_mcmc_render(const or_scene *sc, const or_mcmc_config *c, float *film, double *result, uint32_t *chain_states, uint32_t n_threads) {
+    ((or_scene *)sc)->color = 0; /* these integrators run in the default sRGB / sRGB pipeline here */
     const uint32_t W = sc->width, H = sc->height;
     const uint64_t N = (uint64_t)W * H;
     if (c->n_chains == 0 || c->n_bootstrap == 0 || c->sampler_type > 1) return -1;
@@ -1713,11 +1725,13 @@ OR_EXPORT void or_kat_sincos(float x, float *s, float *c) { or_sincosf(x, s, c);
 OR_EXPORT float or_kat_log(float x) { return or_logf(x); }
 OR_EXPORT float or_kat_exp(float x) { return or_expf(x); }
 OR_EXPORT float or_kat_pow(float x, float y) { return or_powf(x, y); }
+/* the ColorPipeline (OR_COLOR_* bits) the probes below evaluate materials under; renders set it from their config */
+OR_EXPORT void or_scene_set_color(or_scene *sc, uint32_t color) { sc->color = color; }
 /* evaluated inputs (26 words each) of `material` at n uv points */
 OR_EXPORT void or_material_inputs(const or_scene *sc, uint32_t material, uint32_t n, const float *uv, float *out26) {
     for (uint32_t i = 0; i < n; i++) {
         or_material_desc at;
-        or_material_at(&sc->materials[material], sc->graphs ? &sc->graphs[material] : 0, sc->images, uv[2 * i], uv[2 * i + 1], &at);
+        or_material_at(&sc->materials[material], sc->graphs ? &sc->graphs[material] : 0, sc->images, sc->color, uv[2 * i], uv[2 * i + 1], &at);
         memcpy(out26 + 26 * (size_t)i, &at, sizeof at);
     }
 }

@@ -27,7 +27,11 @@ typedef struct {
     float transform[16];     /* column-major object->world (glam Mat4 / AffineTransform.m) */
 } or_instance_desc;
 
-enum { OR_MAT_PRINCIPLED = 0, OR_MAT_DIFFUSE = 1, OR_MAT_GLASS = 2, OR_MAT_EMISSION = 3 };
+enum { OR_MAT_PRINCIPLED = 0, OR_MAT_DIFFUSE = 1, OR_MAT_GLASS = 2, OR_MAT_EMISSION = 3, OR_MAT_KIND_MASK = 0xff,
+       /* OR-ed into kind: this constant colour input is given in ACEScg (akari_scenegraph ColorSpace "aces") instead of sRGB */
+       OR_MAT_CS_BASE_COLOR = 0x100, OR_MAT_CS_SPECULAR_TINT = 0x200, OR_MAT_CS_COAT_TINT = 0x400, OR_MAT_CS_EMISSION_COLOR = 0x800 };
+/* ColorPipeline (color.rs:663-676) as bits of or_pt_config.color: color_repr = Rgb(ACEScg), rgb_colorspace = ACEScg */
+enum { OR_COLOR_REPR_ACES = 1, OR_COLOR_RGB_ACES = 2 };
 typedef struct {
     uint32_t kind;
     float base_color[3];     /* principled base_color / diffuse color / glass color (linear, target RGB space) */
@@ -87,7 +91,7 @@ typedef struct {
     uint32_t filter_type;
     float filter_radius;
     uint32_t sampler_type;
-    uint32_t _pad;
+    uint32_t color;          /* OR_COLOR_* bits; 0 = the default sRGB / sRGB pipeline */
     uint64_t sampler_seed;
     /* pixel-tile sharding (rank r of n renders tiles t with t % n == r); n = 1 renders everything */
     uint32_t shard_rank, shard_count, tile_w, tile_h;

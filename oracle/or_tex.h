@@ -68,14 +68,33 @@ static inline or_val or_tex_sample(const or_image_desc *im, float u, float v) {
 }
 static inline float or_srgb_to_linear(float s) { return s <= 0.04045f ? s / 12.92f : or_powf((s + 0.055f) / 1.055f, 2.4f); }
 
-/* eval_shader (eval.rs:363-380): all nodes in order. Values are 4 floats, narrower types zero-extended. */
-static inline void or_eval_graph(const or_material_graph *g, const or_image_desc *images, float u, float v, or_val *val) {
+/* Color::to_rgb / rgb_to_target_colorspace (color.rs:262-275, svm/texture/mod.rs:9-30) with the CAT matrices of
+ * color.rs:614-628; M * v = (c0 x + c1 y) + c2 z. Identity when the two spaces agree. */
+static inline void or_cs_convert(float *v, int from_aces, int to_aces) {
+    if ((from_aces != 0) == (to_aces != 0)) return;
+    const float x = v[0], y = v[1], z = v[2];
+    if (to_aces) { /* srgb_to_aces_with_cat_mat */
+        v[0] = (0.612494199f * x + 0.338737252f * y) + 0.048855526f * z;
+        v[1] = (0.070594252f * x + 0.917671484f * y) + 0.011704306f * z;
+        v[2] = (0.020727335f * x + 0.106882232f * y) + 0.872338062f * z;
+    } else { /* aces_to_srgb_with_cat_mat */
+        v[0] = (1.707062673f * x + -0.619959540f * y) + -0.087259850f * z;
+        v[1] = (-0.130976829f * x + 1.139032275f * y) + -0.007956297f * z;
+        v[2] = (-0.024510601f * x + -0.124810932f * y) + 1.149395971f * z;
+    }
+}
+/* eval_shader (eval.rs:363-380): all nodes in order. Values are 4 floats, narrower types zero-extended. `color` = the render's
+ * ColorPipeline bits (OR_COLOR_*). */
+static inline void or_eval_graph(const or_material_graph *g, const or_image_desc *images, uint32_t color, float u, float v, or_val *val) {
     for (uint32_t i = 0; i < g->n_nodes; i++) {
         const or_shader_node *n = &g->nodes[i];
         or_val r = {{0, 0, 0, 0}};
         switch (n->op) {
         case OR_NODE_CONST: r.v[0] = n->k[0]; r.v[1] = n->k[1]; r.v[2] = n->k[2]; break;
-        case OR_NODE_RGB: r.v[0] = n->k[0]; r.v[1] = n->k[1]; r.v[2] = n->k[2]; r.v[3] = 1.0f; break;
+        case OR_NODE_RGB: /* eval.rs:125-135: node space (arg0: 1 = ACEScg) -> pipeline.rgb_colorspace */
+            r.v[0] = n->k[0]; r.v[1] = n->k[1]; r.v[2] = n->k[2]; r.v[3] = 1.0f;
+            or_cs_convert(r.v, n->arg[0] == 1u, (color & OR_COLOR_RGB_ACES) != 0);
+            break;
         case OR_NODE_TEXCOORDS: r.v[0] = u; r.v[1] = v; break;
         case OR_NODE_IMAGE: {
             float su = u, sv = v;
@@ -98,7 +117,10 @@ static inline void or_eval_graph(const or_material_graph *g, const or_image_desc
             r = (((px + py) % 2) == 0) ? val[n->arg[2]] : val[n->arg[3]];
             break;
         }
-        case OR_NODE_SPECTRAL_UPLIFT: r = val[n->arg[0]]; break;
+        case OR_NODE_SPECTRAL_UPLIFT: /* eval.rs:155-175 -> spectral_uplift: rgb_colorspace -> the space of color_repr */
+            r = val[n->arg[0]];
+            or_cs_convert(r.v, (color & OR_COLOR_RGB_ACES) != 0, (color & OR_COLOR_REPR_ACES) != 0);
+            break;
         case OR_NODE_SEPARATE_COLOR: r = val[n->arg[0]]; break;
         case OR_NODE_EXTRACT:
             if (n->arg[1] < 3) r.v[0] = val[n->arg[0]].v[n->arg[1]];
@@ -118,13 +140,24 @@ static inline void or_eval_graph(const or_material_graph *g, const or_image_desc
 
 /* The evaluated inputs of a material at uv: the constants of `m`, overridden by the nodes that feed inputs
  * (principled.rs:13-131 read rules: colours xyz (+ alpha for base_color), scalars x). */
-static inline void or_material_at(const or_material_desc *m, const or_material_graph *g, const or_image_desc *images, float u, float v,
-                                  or_material_desc *out) {
+static inline void or_material_at(const or_material_desc *m, const or_material_graph *g, const or_image_desc *images, uint32_t color, float u,
+                                  float v, or_material_desc *out) {
     *out = *m;
+    out->kind = m->kind & OR_MAT_KIND_MASK;
+    { /* constant colour inputs (an Rgb node behind a spectral_uplift, folded by the scene reader): both conversions */
+        float *slot[4] = {out->base_color, out->specular_tint, out->coat_tint, out->emission_color};
+        const uint32_t bit[4] = {OR_MAT_CS_BASE_COLOR, OR_MAT_CS_SPECULAR_TINT, OR_MAT_CS_COAT_TINT, OR_MAT_CS_EMISSION_COLOR};
+        const uint32_t key[4] = {OR_IN_BASE_COLOR, OR_IN_SPECULAR_TINT, OR_IN_COAT_TINT, OR_IN_EMISSION_COLOR};
+        for (int k = 0; k < 4; k++) {
+            if (g && g->n_nodes && g->input[key[k]] != OR_NODE_NONE) continue; /* fed by the graph: converted at its nodes */
+            or_cs_convert(slot[k], (m->kind & bit[k]) != 0, (color & OR_COLOR_RGB_ACES) != 0);
+            or_cs_convert(slot[k], (color & OR_COLOR_RGB_ACES) != 0, (color & OR_COLOR_REPR_ACES) != 0);
+        }
+    }
     if (!g || g->n_nodes == 0) return;
     or_val val[256];
     if (g->n_nodes > 256) return;
-    or_eval_graph(g, images, u, v, val);
+    or_eval_graph(g, images, color, u, v, val);
     const uint32_t *in = g->input;
 #define OR_IN3(K, F) if (in[K] != OR_NODE_NONE) { out->F[0] = val[in[K]].v[0]; out->F[1] = val[in[K]].v[1]; out->F[2] = val[in[K]].v[2]; }
 #define OR_IN1(K, F) if (in[K] != OR_NODE_NONE) out->F = val[in[K]].v[0];

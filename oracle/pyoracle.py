@@ -57,6 +57,7 @@ def lib() -> C.CDLL:
     L.or_scene_shared_plane_rows.restype = u32
     L.or_scene_shared_plane_rows.argtypes = [vp]
     L.or_set_share_plane_rows.argtypes = [i32]
+    L.or_scene_set_color.argtypes = [vp, u32]
     L.or_scene_build_bvh.restype = u32
     L.or_scene_build_bvh.argtypes = [vp]
     L.or_scene_free_bvh.argtypes = [vp]
@@ -220,7 +221,9 @@ class OracleScene:
         assert rc == 0, f"or_mcmc_render failed ({rc})"
         return film, {"normalization": res[0], "acceptance_rate": res[1], "splat_scale": np.float32(res[2]), "contribution": np.float32(res[3])}, chains
 
-    def material_inputs(self, material: int, uv) -> np.ndarray:
+    def material_inputs(self, material: int, uv, color: int = 0) -> np.ndarray:
+        """Evaluated inputs (akr_material_desc words) of `material` at uv points under the ColorPipeline bits `color`."""
+        lib().or_scene_set_color(self.h, color)
         u = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
         out = np.zeros((u.shape[0], 26), dtype=np.float32)
         lib().or_material_inputs(self.h, material, u.shape[0], _fp(u), _fp(out))

@@ -30,8 +30,9 @@ from akari_render_amd.abi import (
 
 f32 = np.float32
 
-# color.rs: srgb <-> ACEScg with CAT (only needed for non-sRGB constants; the default pipeline is sRGB)
-_ACES_TO_SRGB = None
+# which MaterialData.colorspaces bit an ACEScg constant of this input sets (abi.MAT_CS_*)
+_CS_BIT = {"base_color": abi.MAT_CS_BASE_COLOR, "specular_tint": abi.MAT_CS_SPECULAR_TINT, "coat_tint": abi.MAT_CS_COAT_TINT,
+           "emission_color": abi.MAT_CS_EMISSION_COLOR}
 
 
 def _axis_angle(axis, angle) -> np.ndarray:
@@ -377,9 +378,8 @@ class _Graph:
         elif ty == "float3":
             r = self.push(abi.NODE_CONST, (), tuple(n["value"]))
         elif ty == "rgb":
-            if n.get("colorspace", "srgb") != "srgb":
-                raise NotImplementedError("non-sRGB constant colours")
-            r = self.push(abi.NODE_RGB, (), tuple(n["value"]))
+            cs = {"srgb": 0, "aces": 1}[n.get("colorspace", "srgb")]  # RgbColorSpace, color.rs:6-11
+            r = self.push(abi.NODE_RGB, (cs,), tuple(n["value"]))
         elif ty == "spectral_uplift":
             r = self.push(abi.NODE_SPECTRAL_UPLIFT, (self.emit(n["rgb"]),))
         elif ty == "texcoords":
@@ -424,14 +424,15 @@ def _fold_material(shader: dict, bufs: "_Buffers" = None, images: list = None, i
         if ty == "float3":
             return list(n["value"]), 1.0
         if ty == "rgb":
-            if n.get("colorspace", "srgb") != "srgb":
-                raise NotImplementedError("non-sRGB constant colours")
+            if {"srgb": 0, "aces": 1}[n.get("colorspace", "srgb")] and current[0] in _CS_BIT:
+                cs_flags[0] |= _CS_BIT[current[0]]  # the constant stays in ACEScg; the render's ColorPipeline converts it
             return list(n["value"]), 1.0  # RgbTex: rgb.extend(1.0), svm/eval.rs:125-135
         if ty == "spectral_uplift":
             return const(n["rgb"])
         raise NotImplementedError(f"shader node '{ty}' (only constant inputs are supported)")
 
     current = [None]  # name of the input being read (abi.INPUT_NAMES)
+    cs_flags = [0]
 
     def f(ref, default=0.0):  # eval_float_auto_convert
         if not graph.is_const(ref):
@@ -496,6 +497,7 @@ def _fold_material(shader: dict, bufs: "_Buffers" = None, images: list = None, i
         raise NotImplementedError(f"surface shader '{ty}'")
     if graph.out:
         m.graph = abi.GraphData(graph.out, graph.inputs)
+    m.colorspaces = cs_flags[0]
     return m
 
 

@@ -58,7 +58,15 @@ def test_error_reporting(hip_lib, tmp_path):
     cfg = abi.PtConfig()
     assert hip_lib.akr_pt_config_from_json(b'{"method": {"type": "mcmc"}}', C.byref(cfg), None, 0) == capi.ERR_UNSUPPORTED
     assert hip_lib.akr_pt_config_from_json(b'{"sampler": {"type": "sobol", "seed": 0}}', C.byref(cfg), None, 0) == capi.ERR_PARSE
-    assert hip_lib.akr_pt_config_from_json(b'{"color": {"color_repr": {"type": "rgb"}, "rgb_colorspace": "aces"}}', C.byref(cfg), None, 0) == capi.ERR_UNSUPPORTED
+    # ColorPipeline (color.rs:663-676): srgb | aces for both members; spectral is todo!() in the reference too
+    assert hip_lib.akr_pt_config_from_json(b'{"color": {"color_repr": {"type": "rgb"}, "rgb_colorspace": "aces"}}', C.byref(cfg), None, 0) == 0
+    assert cfg.color == abi.COLOR_RGB_ACESCG
+    assert hip_lib.akr_pt_config_from_json(b'{"color": {"color_repr": {"type": "rgb", "colorspace": "aces"}, "rgb_colorspace": "aces"}}', C.byref(cfg), None, 0) == 0
+    assert cfg.color == abi.COLOR_RGB_ACESCG | abi.COLOR_REPR_ACESCG
+    assert hip_lib.akr_pt_config_from_json(b'{"color": {"color_repr": "rgb_aces"}}', C.byref(cfg), None, 0) == 0 and cfg.color == abi.COLOR_REPR_ACESCG
+    assert hip_lib.akr_pt_config_from_json(b'{"color": {"color_repr": {"type": "spectral"}}}', C.byref(cfg), None, 0) == capi.ERR_UNSUPPORTED
+    assert hip_lib.akr_pt_config_from_json(b'{"color": {"rgb_colorspace": "xyz"}}', C.byref(cfg), None, 0) == capi.ERR_PARSE
+    assert hip_lib.akr_pt_config_from_json(b'{"method": {"type": "aov"}, "color": {"rgb_colorspace": "aces"}}', C.byref(cfg), None, 0) == capi.ERR_UNSUPPORTED
     assert hip_lib.akr_pt_config_from_json(b'{"color": {"rgb_colorspace": "srgb"}, "film": {"color": "srgb"}}', C.byref(cfg), None, 0) == 0
     assert hip_lib.akr_pt_config_from_json(b'{"film": {"color": "xyz"}}', C.byref(cfg), None, 0) == capi.ERR_UNSUPPORTED
     assert len(hip_lib.akr_last_error()) > 0
