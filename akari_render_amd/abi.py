@@ -123,7 +123,7 @@ class SceneDesc(C.Structure):
 
 
 FILTER_BOX, FILTER_GAUSSIAN = 0, 1
-SAMPLER_INDEPENDENT, SAMPLER_PMJ02BN = 0, 1
+SAMPLER_INDEPENDENT, SAMPLER_PMJ02BN, SAMPLER_SOBOL = 0, 1, 2
 
 
 class PtConfig(_Struct):

@@ -91,6 +91,11 @@ AKR_D float next_1d(const PtParams& p, Sampler& s) {
     const uint32_t px = (uint32_t)s.pcg.inc, py = (uint32_t)(s.pcg.inc >> 32), sample_index = (uint32_t)s.pcg.state;
     uint32_t hash = xxhash32_4(px, py, s.dim, p.smp_seed);
     uint32_t index = permute_element(sample_index, p.smp_spp, p.smp_w, hash);
+    if (p.sampler == 2u) {  // sobol: the permuted index through the scrambled radical inverse (wave-uniform branch)
+        const uint32_t v = owen_scramble(reverse_bits32(index), xxhash32_4(py, px, s.dim, ~p.smp_seed));
+        s.dim += 1;
+        return min_f((float)v * 2.3283064365386963e-10f, kOneMinusEpsilon);
+    }
     float delta = pmj_bluenoise(p, s.dim, px, py);
     s.dim += 1;
     return min_f(((float)index + delta) / (float)p.smp_spp, kOneMinusEpsilon);
@@ -106,6 +111,14 @@ AKR_D vec2 next_2d(const PtParams& p, Sampler& s) {
     const uint32_t px = (uint32_t)s.pcg.inc, py = (uint32_t)(s.pcg.inc >> 32);
     uint32_t index = (uint32_t)s.pcg.state;
     const uint32_t dim = s.dim, pmj_instance = dim / 2;
+    if (p.sampler == 2u) {  // sobol: every dimension pair is the (0,2)-sequence under its own index permutation and scramble
+        const uint32_t hash = xxhash32_4(px, py, dim, p.smp_seed);
+        const uint32_t i = permute_element(index, p.smp_spp, p.smp_w, hash);
+        const uint32_t vx = owen_scramble(reverse_bits32(i), xxhash32_4(py, px, dim, ~p.smp_seed));
+        const uint32_t vy = owen_scramble(sobol_dim1(i), xxhash32_4(py, px, dim + 1u, ~p.smp_seed));
+        s.dim += 2;
+        return mk2(min_f((float)vx * 2.3283064365386963e-10f, kOneMinusEpsilon), min_f((float)vy * 2.3283064365386963e-10f, kOneMinusEpsilon));
+    }
     if (pmj_instance >= kPmjSets) index = permute_element(index, p.smp_spp, p.smp_w, xxhash32_4(px, py, dim, p.smp_seed));
     const uint32_t* smp = p.pmj_sets + 2 * ((size_t)kPmjSamples * (pmj_instance % kPmjSets) + (index % kPmjSamples));
     vec2 u = mk2((float)smp[0] * 2.3283064365386963e-10f, (float)smp[1] * 2.3283064365386963e-10f);

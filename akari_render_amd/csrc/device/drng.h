@@ -66,6 +66,36 @@ AKR_HD float pcg_next_1d(Pcg32& p) {  // sampler/mod.rs:194-198; can return exac
     return (float)n * 2.3283064365386963e-10f;  // f32(1.0 / u32::MAX as f64) == 2^-32
 }
 
+// ---- Owen-scrambled Sobol' (0,2)-sequence, for the "sobol" sampler (no reference counterpart: akari_data only stubs the
+// matrices). Dimension 0 = radical inverse base 2, dimension 1 = the Pascal-triangle generator matrix; nested uniform
+// scrambling by the Laine-Karras hash between two bit reversals (Laine & Karras 2011; Burley 2020, "Practical Hash-based
+// Owen Scrambling").
+AKR_HD uint32_t reverse_bits32(uint32_t x) {
+    x = (x >> 16) | (x << 16);
+    x = ((x & 0xff00ff00u) >> 8) | ((x & 0x00ff00ffu) << 8);
+    x = ((x & 0xf0f0f0f0u) >> 4) | ((x & 0x0f0f0f0fu) << 4);
+    x = ((x & 0xccccccccu) >> 2) | ((x & 0x33333333u) << 2);
+    x = ((x & 0xaaaaaaaau) >> 1) | ((x & 0x55555555u) << 1);
+    return x;
+}
+AKR_HD uint32_t laine_karras(uint32_t x, uint32_t seed) {
+    x += seed;
+    x ^= x * 0x6c50b47cu;
+    x ^= x * 0xb82f1e52u;
+    x ^= x * 0xc7afe638u;
+    x ^= x * 0x8d22f6e6u;
+    return x;
+}
+AKR_HD uint32_t owen_scramble(uint32_t x, uint32_t seed) { return reverse_bits32(laine_karras(reverse_bits32(x), seed)); }
+AKR_HD uint32_t sobol_dim1(uint32_t i) {
+    uint32_t v = 0x80000000u, r = 0;
+    for (; i; i >>= 1) {
+        if (i & 1u) r ^= v;
+        v ^= v >> 1;
+    }
+    return r;
+}
+
 AKR_HD uint32_t xxhash32_4(uint32_t px, uint32_t py, uint32_t pz, uint32_t pw) {
     const uint32_t PRIME32_2 = 2246822519u, PRIME32_3 = 3266489917u, PRIME32_4 = 668265263u, PRIME32_5 = 374761393u;
     uint32_t h32 = pw + PRIME32_5 + px * PRIME32_3;

@@ -387,14 +387,16 @@ static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pas
         }
     }
     p.sampler = c.sampler_type;
-    if (c.sampler_type == AKR_SAMPLER_PMJ02BN) {  // Pmj02BnSamplerCreator::new (sampler/mod.rs:376-395)
+    if (c.sampler_type == AKR_SAMPLER_PMJ02BN || c.sampler_type == AKR_SAMPLER_SOBOL) {  // Pmj02BnSamplerCreator::new (sampler/mod.rs:376-395)
         p.smp_seed = (uint32_t)c.sampler_seed;
         p.smp_spp = se->pmj_spp;
         uint32_t w = se->pmj_spp - 1;
         w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
         p.smp_w = w;
-        p.pmj_sets = se->ctx->pmj_sets.as<uint32_t>();
-        p.bluenoise = se->ctx->bluenoise.as<uint16_t>();
+        if (c.sampler_type == AKR_SAMPLER_PMJ02BN) {  // the sobol sampler computes its points, no tables
+            p.pmj_sets = se->ctx->pmj_sets.as<uint32_t>();
+            p.bluenoise = se->ctx->bluenoise.as<uint16_t>();
+        }
     }
     {  // LDS staging of the tables the shading phase gathers from (pt_kernels.hip: STAGE)
         const CompiledScene& cs = s->cs;
@@ -490,7 +492,7 @@ static void wf_run(akr_pt_session* se) {
 static void validate_config(const akr_pt_config& c) {
     if (c.spp_per_pass == 0) throw std::invalid_argument("akr_pt_config: spp_per_pass must be > 0");
     if (c.filter_type > AKR_FILTER_GAUSSIAN) throw std::invalid_argument("akr_pt_config: unknown filter_type");
-    if (c.sampler_type > AKR_SAMPLER_PMJ02BN) throw std::invalid_argument("akr_pt_config: unknown sampler_type");
+    if (c.sampler_type > AKR_SAMPLER_SOBOL) throw std::invalid_argument("akr_pt_config: unknown sampler_type");
     if (c.color > (AKR_COLOR_REPR_ACESCG | AKR_COLOR_RGB_ACESCG)) throw std::invalid_argument("akr_pt_config: unknown colour pipeline bits");
     if (c.sampler_type == AKR_SAMPLER_PMJ02BN && c.spp > 65536u)
         throw std::invalid_argument("Pmj02BnSampler supports up to 65536 spp (sampler/mod.rs:381-387)");
@@ -859,9 +861,9 @@ AKR_API int32_t akr_pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_co
         }
         const uint64_t n = (uint64_t)film->width * film->height;
         // init_pcg32_buffer_with_seed (sampler/mod.rs:148-160): host StdRng(seed) u64 per pixel, device new_seq_offset
-        if (cfg->sampler_type == AKR_SAMPLER_PMJ02BN) {
+        if (cfg->sampler_type == AKR_SAMPLER_PMJ02BN || cfg->sampler_type == AKR_SAMPLER_SOBOL) {
             // Pmj02BnState per pixel (sampler/mod.rs:451-466): sample_index = u32::MAX, pixel = (x, y), kept in a Pcg32 slot
-            ctx->ensure_pmj_tables();
+            if (cfg->sampler_type == AKR_SAMPLER_PMJ02BN) ctx->ensure_pmj_tables();
             se->pmj_spp = cfg->spp ? cfg->spp : 1;
             std::vector<Pcg32> init(n);
             for (uint64_t i = 0; i < n; i++) init[i] = Pcg32{0xffffffffull, (i % film->width) | ((i / film->width) << 32)};

@@ -570,6 +570,7 @@ static void parse_one_task(const JsonValue* j, akr_pt_config* cfg, std::string* 
         const std::string ty = s.has("type") ? s.at("type").as_string() : std::string("independent");
         if (ty == "independent" || (ty == "pmj02bn" && allow_sampler_override)) cfg->sampler_type = AKR_SAMPLER_INDEPENDENT;
         else if (ty == "pmj02bn") cfg->sampler_type = AKR_SAMPLER_PMJ02BN;  // on regenerated tables, see pmj_tables.cpp
+        else if (ty == "sobol") cfg->sampler_type = AKR_SAMPLER_SOBOL;      // Owen-scrambled Sobol' (0,2), device/drng.h
         else throw std::runtime_error("unknown sampler '" + ty + "'");
         if (s.has("seed")) cfg->sampler_seed = (uint64_t)s.at("seed").as_number();
     }

@@ -186,7 +186,10 @@ typedef struct {
 typedef enum { AKR_FILTER_BOX = 0, AKR_FILTER_GAUSSIAN = 1 } akr_filter_type;   /* film.rs:22-54 */
 /* sampler/mod.rs:282-295. PMJ02BN runs on REGENERATED tables (the reference's copies of pbrt-v4's are not in its tree):
  * same algorithm, different point sets / blue-noise arrays, so its images are not bit-comparable with the reference's. */
-typedef enum { AKR_SAMPLER_INDEPENDENT = 0, AKR_SAMPLER_PMJ02BN = 1 } akr_sampler_type;
+/* SOBOL: the reference ships only the data stub of a Sobol' sampler (akari_data/src/lib.rs:13,19: sobolmat, never used by a
+ * Sampler impl); this build's "sobol" is an Owen-scrambled, padded Sobol' (0,2)-sequence sampler with the same state and
+ * interface as Pmj02BnSampler (index-based, per-dimension Kensler permutation of the sample index) that needs no tables. */
+typedef enum { AKR_SAMPLER_INDEPENDENT = 0, AKR_SAMPLER_PMJ02BN = 1, AKR_SAMPLER_SOBOL = 2 } akr_sampler_type;
 /* ColorPipeline (color.rs:663-676) as bits of akr_pt_config.color; 0 = the default {color_repr: Rgb(SRgb), rgb_colorspace:
  * SRgb}. Shading happens in the space of color_repr; the film is always sRGB-primaries linear (film.rs:176-229 converts
  * every sample with color.to_rgb(SRgb), color.rs:262-275). Spectral rendering is todo!() in the reference. */

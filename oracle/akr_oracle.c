@@ -644,11 +644,36 @@ static float or_bluenoise(uint32_t tex, uint32_t px, uint32_t py) { /* uv = p.yx
     return (float)g_bluenoise[((size_t)(tex % 48u) * 128u + ty) * 128u + tx] / 65535.0f;
 }
 #define OR_ONE_MINUS_EPSILON 0.99999994f
+/* The "sobol" sampler (sampler_type 2; no reference counterpart beyond the sobolmat data stub, akari_data/src/lib.rs:13,19):
+ * Pmj02BnSampler's state and interface, points from an Owen-scrambled Sobol' (0,2)-sequence computed on the fly. */
+static uint32_t or_reverse_bits32(uint32_t x) {
+    x = (x >> 16) | (x << 16);
+    x = ((x & 0xff00ff00u) >> 8) | ((x & 0x00ff00ffu) << 8);
+    x = ((x & 0xf0f0f0f0u) >> 4) | ((x & 0x0f0f0f0fu) << 4);
+    x = ((x & 0xccccccccu) >> 2) | ((x & 0x33333333u) << 2);
+    x = ((x & 0xaaaaaaaau) >> 1) | ((x & 0x55555555u) << 1);
+    return x;
+}
+static uint32_t or_owen_scramble(uint32_t x, uint32_t seed) { /* Laine-Karras hash between two bit reversals */
+    x = or_reverse_bits32(x);
+    x += seed; x ^= x * 0x6c50b47cu; x ^= x * 0xb82f1e52u; x ^= x * 0xc7afe638u; x ^= x * 0x8d22f6e6u;
+    return or_reverse_bits32(x);
+}
+static uint32_t or_sobol_dim1(uint32_t i) {
+    uint32_t v = 0x80000000u, r = 0;
+    for (; i; i >>= 1) { if (i & 1u) r ^= v; v ^= v >> 1; }
+    return r;
+}
 static inline float smp_1d(or_sampler *s) {
     if (s->mc) return or_mcmc_next_1d(s);
     if (!s->pmj) { s->dim += 1; return pcg_next_1d(&s->pcg); }
     uint32_t hash = or_xxhash32_4(s->px, s->py, s->dim, s->seed);
     uint32_t index = or_permute_element(s->sample_index, s->spp, s->w, hash);
+    if (s->pmj == 2) {
+        uint32_t v = or_owen_scramble(or_reverse_bits32(index), or_xxhash32_4(s->py, s->px, s->dim, ~s->seed));
+        s->dim += 1;
+        return or_min((float)v * 2.3283064365386963e-10f, OR_ONE_MINUS_EPSILON);
+    }
     float delta = or_bluenoise(s->dim, s->px, s->py);
     s->dim += 1;
     return or_min(((float)index + delta) / (float)s->spp, OR_ONE_MINUS_EPSILON);
@@ -656,6 +681,13 @@ static inline float smp_1d(or_sampler *s) {
 static inline v2 smp_2d(or_sampler *s) {
     if (!s->pmj) { float a = smp_1d(s); float b = smp_1d(s); return V2(a, b); }
     uint32_t index = s->sample_index, dim = s->dim, inst = dim / 2;
+    if (s->pmj == 2) {
+        uint32_t i = or_permute_element(index, s->spp, s->w, or_xxhash32_4(s->px, s->py, dim, s->seed));
+        uint32_t vx = or_owen_scramble(or_reverse_bits32(i), or_xxhash32_4(s->py, s->px, dim, ~s->seed));
+        uint32_t vy = or_owen_scramble(or_sobol_dim1(i), or_xxhash32_4(s->py, s->px, dim + 1u, ~s->seed));
+        s->dim += 2;
+        return V2(or_min((float)vx * 2.3283064365386963e-10f, OR_ONE_MINUS_EPSILON), or_min((float)vy * 2.3283064365386963e-10f, OR_ONE_MINUS_EPSILON));
+    }
     if (inst >= 5u) index = or_permute_element(s->sample_index, s->spp, s->w, or_xxhash32_4(s->px, s->py, dim, s->seed));
     const uint32_t *p = g_pmj_sets + 2 * ((size_t)65536 * (inst % 5u) + (index % 65536u));
     float ux = (float)p[0] * 2.3283064365386963e-10f, uy = (float)p[1] * 2.3283064365386963e-10f;
@@ -677,8 +709,8 @@ static inline or_sampler smp_create(const or_pt_config *cfg, or_pcg32 st, uint32
     or_sampler s;
     memset(&s, 0, sizeof s);
     s.pcg = st;
-    if (cfg->sampler_type == 1) {
-        s.pmj = 1; s.seed = (uint32_t)cfg->sampler_seed; s.spp = spp_total ? spp_total : 1;
+    if (cfg->sampler_type == 1 || cfg->sampler_type == 2) {
+        s.pmj = (int)cfg->sampler_type; s.seed = (uint32_t)cfg->sampler_seed; s.spp = spp_total ? spp_total : 1;
         uint32_t w = s.spp - 1; w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
         s.w = w;
         s.sample_index = (uint32_t)st.state; s.px = (uint32_t)st.inc; s.py = (uint32_t)(st.inc >> 32);
@@ -868,7 +900,7 @@ OR_EXPORT void or_init_pcg32_buffer_with_seed(uint64_t count, uint64_t seed, uin
 
 /* SamplerConfig::creator (sampler/mod.rs:702-718): per-pixel states of either sampler */
 static void or_init_sampler_states(uint32_t sampler_type, uint64_t n, uint32_t width, uint64_t seed, or_pcg32 *states) {
-    if (sampler_type == 1) {
+    if (sampler_type == 1 || sampler_type == 2) {
         for (uint64_t i = 0; i < n; i++) { states[i].state = 0xffffffffull; states[i].inc = (i % width) | ((i / width) << 32); }
     } else {
         or_init_pcg32_buffer_with_seed(n, seed, (uint64_t *)states);
@@ -1727,6 +1759,16 @@ OR_EXPORT float or_kat_exp(float x) { return or_expf(x); }
 OR_EXPORT float or_kat_pow(float x, float y) { return or_powf(x, y); }
 /* the ColorPipeline (OR_COLOR_* bits) the probes below evaluate materials under; renders set it from their config */
 OR_EXPORT void or_scene_set_color(or_scene *sc, uint32_t color) { sc->color = color; }
+/* dimension pair (dim, dim + 1) of sample `index` of pixel (px, py) of the sobol sampler, as fixed-point-free floats */
+OR_EXPORT void or_kat_sobol_2d(uint32_t px, uint32_t py, uint32_t dim, uint32_t seed, uint32_t spp, uint32_t index, float *out2) {
+    or_sampler s;
+    memset(&s, 0, sizeof s);
+    s.pmj = 2; s.seed = seed; s.spp = spp; s.px = px; s.py = py; s.sample_index = index; s.dim = dim;
+    uint32_t w = spp - 1; w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
+    s.w = w;
+    v2 r = smp_2d(&s);
+    out2[0] = r.x; out2[1] = r.y;
+}
 /* evaluated inputs (26 words each) of `material` at n uv points */
 OR_EXPORT void or_material_inputs(const or_scene *sc, uint32_t material, uint32_t n, const float *uv, float *out26) {
     for (uint32_t i = 0; i < n; i++) {

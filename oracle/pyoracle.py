@@ -58,6 +58,7 @@ def lib() -> C.CDLL:
     L.or_scene_shared_plane_rows.argtypes = [vp]
     L.or_set_share_plane_rows.argtypes = [i32]
     L.or_scene_set_color.argtypes = [vp, u32]
+    L.or_kat_sobol_2d.argtypes = [u32, u32, u32, u32, u32, u32, fp]
     L.or_scene_build_bvh.restype = u32
     L.or_scene_build_bvh.argtypes = [vp]
     L.or_scene_free_bvh.argtypes = [vp]

@@ -57,7 +57,9 @@ def test_error_reporting(hip_lib, tmp_path):
     assert hip_lib.akr_scene_create(None, None, C.byref(h)) == capi.ERR_INVALID_ARGUMENT
     cfg = abi.PtConfig()
     assert hip_lib.akr_pt_config_from_json(b'{"method": {"type": "mcmc"}}', C.byref(cfg), None, 0) == capi.ERR_UNSUPPORTED
-    assert hip_lib.akr_pt_config_from_json(b'{"sampler": {"type": "sobol", "seed": 0}}', C.byref(cfg), None, 0) == capi.ERR_PARSE
+    assert hip_lib.akr_pt_config_from_json(b'{"sampler": {"type": "sobol", "seed": 7}}', C.byref(cfg), None, 0) == 0
+    assert cfg.sampler_type == abi.SAMPLER_SOBOL and cfg.sampler_seed == 7
+    assert hip_lib.akr_pt_config_from_json(b'{"sampler": {"type": "halton", "seed": 0}}', C.byref(cfg), None, 0) == capi.ERR_PARSE
     # ColorPipeline (color.rs:663-676): srgb | aces for both members; spectral is todo!() in the reference too
     assert hip_lib.akr_pt_config_from_json(b'{"color": {"color_repr": {"type": "rgb"}, "rgb_colorspace": "aces"}}', C.byref(cfg), None, 0) == 0
     assert cfg.color == abi.COLOR_RGB_ACESCG

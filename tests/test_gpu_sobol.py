@@ -1,0 +1,52 @@
+"""The sobol sampler on the GPU: the same bits as the oracle (films and per-pixel sampler states), every kernel family that
+draws random numbers through the index-based sampler path."""
+import numpy as np
+import pytest
+
+from akari_render_amd import abi, capi
+from oracle import pyoracle, scene_json
+from tests.helpers import grid_scene, make_config, n_bit_diff, textured_room
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", ["cbox_full", "cbox_ragged_passes", "bvh_grid", "textured"])
+def test_sobol_films_match_the_oracle(ctx, cbox_path, case):
+    if case == "bvh_grid":
+        sd = grid_scene(n=24, width=80, height=48, with_normals=True)
+    elif case == "textured":
+        sd = textured_room(64, 48)
+    else:
+        sd = scene_json.load_scene(cbox_path, 96, 72)
+    spp, per = (11, 4) if case == "cbox_ragged_passes" else (16, 8)
+    cfg = make_config(spp=spp, spp_per_pass=per, max_depth=8, sampler_type=abi.SAMPLER_SOBOL, sampler_seed=5)
+    w, h = sd.camera.width, sd.camera.height
+    scene = capi.Scene(ctx, sd)
+    film = capi.Film(ctx, w, h)
+    se = capi.PtSession(ctx, scene, cfg, film)
+    se.passes((spp + per - 1) // per, blocking=True)
+    gstates = se.sampler_states(w * h)
+    gst = se.end()
+    ostates = np.zeros(2 * w * h, dtype=np.uint64)
+    ostates[0::2] = 0xFFFFFFFF
+    ostates[1::2] = (np.arange(w * h, dtype=np.uint64) % np.uint64(w)) | ((np.arange(w * h, dtype=np.uint64) // np.uint64(w)) << np.uint64(32))
+    o, ost = pyoracle.OracleScene(sd).render(cfg, states=ostates)
+    assert n_bit_diff(film.read(), o) == 0
+    assert np.array_equal(gstates, ostates)
+    for k in ("n_samples", "n_closest", "n_shadow", "n_shaded"):
+        assert gst[k] == ost[k]
+
+
+def test_sobol_differs_from_the_other_samplers_and_is_deterministic(ctx, cbox_path):
+    sd = scene_json.load_scene(cbox_path, 64, 48)
+    scene = capi.Scene(ctx, sd)
+
+    def render(sampler, seed=0):
+        f = capi.Film(ctx, 64, 48)
+        capi.pt_render(ctx, scene, make_config(spp=8, spp_per_pass=8, sampler_type=sampler, sampler_seed=seed), f)
+        return f.read()
+
+    a, b = render(abi.SAMPLER_SOBOL), render(abi.SAMPLER_SOBOL)
+    assert n_bit_diff(a, b) == 0
+    assert n_bit_diff(a, render(abi.SAMPLER_INDEPENDENT)) > 0 and n_bit_diff(a, render(abi.SAMPLER_SOBOL, 1)) > 0
+    assert abs(a[: 3 * 64 * 48].mean() / render(abi.SAMPLER_INDEPENDENT)[: 3 * 64 * 48].mean() - 1.0) < 0.1
