@@ -34,7 +34,7 @@ EXPORTS = [
     "akr_pt_get_stats", "akr_render_task", "akr_image_write", "akr_aov_config_default", "akr_aov_render",
     "akr_gpt_config_default", "akr_gpt_render", "akr_mcmc_config_default", "akr_mcmc_render", "akr_film_set_splat_scale", "akr_film_get_splat_scale",
     "akr_pt_read_sampler_states", "akr_context_device_ordinal", "akr_device_count",
-    "akr_comm_unique_id", "akr_comm_create", "akr_comm_wrap", "akr_comm_destroy", "akr_film_reduce",
+    "akr_probe_material_inputs_host", "akr_comm_unique_id", "akr_comm_create", "akr_comm_wrap", "akr_comm_destroy", "akr_film_reduce",
     "akr_host_stdrng_u64", "akr_host_chacha_block", "akr_host_pcg32_states", "akr_host_pcg_start", "akr_host_alias_table",
     "akr_probe_math", "akr_probe_bsdf", "akr_probe_intersect", "akr_probe_surface_interaction", "akr_probe_material_inputs",
     "akr_host_decode_png", "akr_host_decode_jpeg", "akr_host_decode_exr", "akr_host_pmj02bn_tables",
@@ -139,6 +139,7 @@ def lib() -> C.CDLL:
     proto("akr_probe_intersect", vp, vp, u32, fp, up, fp)
     proto("akr_probe_surface_interaction", vp, vp, u32, up, fp, fp)
     proto("akr_probe_material_inputs", vp, vp, u32, u32, fp, fp)
+    proto("akr_probe_material_inputs_host", vp, u32, u32, u32, fp, fp)
     proto("akr_host_decode_png", C.c_char_p, u64, up, up, C.POINTER(C.c_uint8), u64)
     proto("akr_host_decode_jpeg", C.c_char_p, u64, up, up, C.POINTER(C.c_uint8), u64)
     proto("akr_host_decode_exr", C.c_char_p, u64, up, up, fp, u64)
@@ -547,6 +548,14 @@ def probe_material_inputs(ctx: Optional[Context], scene: Scene, material: int, u
     u = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
     out = np.zeros((u.shape[0], 26), dtype=np.float32)
     check(lib().akr_probe_material_inputs(ctx.h if ctx is not None else C.c_void_p(), scene.h, material, u.shape[0], _fp(u), _fp(out)))
+    return out
+
+
+def probe_material_inputs_host(scene: Scene, material: int, uv: np.ndarray, color: int = 0) -> np.ndarray:
+    """Evaluated inputs of `material` at uv points under the colour pipeline `color`, on the host (no GPU)."""
+    u = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
+    out = np.zeros((u.shape[0], 26), dtype=np.float32)
+    check(lib().akr_probe_material_inputs_host(scene.h, material, color, u.shape[0], _fp(u), _fp(out)))
     return out
 
 

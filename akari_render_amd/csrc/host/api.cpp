@@ -1563,6 +1563,31 @@ AKR_API int32_t akr_host_decode_exr(const uint8_t* data, uint64_t len, uint32_t*
 }
 // Evaluated inputs of a material at uv points: on the device (ctx != NULL; needs a scene with textures) or with the
 // same code on the host (ctx == NULL).
+// The same on the host for an arbitrary colour pipeline: the material tables are compiled for `color` (what akr_pt_begin does
+// for a session with akr_pt_config.color != 0) and evaluated with the code the kernels run.
+AKR_API int32_t akr_probe_material_inputs_host(akr_scene* scene, uint32_t material, uint32_t color, uint32_t n, const float* uv, float* out26) {
+    if (!scene || !uv || !out26) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_probe_material_inputs_host: NULL argument");
+    if (material >= scene->flat.materials.size()) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_probe_material_inputs_host: material out of range");
+    return guarded([&] {
+        CompiledScene tmp;
+        tmp.images = scene->cs.images;
+        std::vector<akr_material_desc> descs;
+        compile_materials(scene->flat, color, tmp, descs);
+        const TexScene ts{tmp.tex_nodes.data(), scene->cs.images.data(), scene->cs.texels.data(), tmp.mat_inputs.data(), color, 0};
+        const DMaterial& m = tmp.materials[material];
+        for (uint32_t i = 0; i < n; i++) {
+            MatInputs in;
+            std::memcpy(&in, &descs[material], sizeof in);
+            if (m.flags & MF_TEXTURED) {
+                TexVal val[kMaxGraphNodes];
+                eval_graph(ts, m.tex_first_node, m.tex_n_nodes, mk2(uv[2 * i], uv[2 * i + 1]), val);
+                apply_inputs(m.tex_input, val, in);
+            }
+            std::memcpy(out26 + 26ull * i, &in, sizeof in);
+        }
+    });
+}
+
 AKR_API int32_t akr_probe_material_inputs(akr_context* ctx, akr_scene* scene, uint32_t material, uint32_t n, const float* uv, float* out26) {
     if (!scene || !uv || !out26) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_probe_material_inputs: NULL argument");
     if (material >= scene->flat.materials.size()) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_probe_material_inputs: material out of range");

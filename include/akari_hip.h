@@ -535,6 +535,9 @@ AKR_API int32_t akr_host_decode_exr(const uint8_t *data, uint64_t len, uint32_t 
 /* Evaluated inputs of `material` (26 words each = akr_material_desc) at n uv points: shader-graph evaluation + texture
  * sampling on the device, or -- ctx == NULL -- the same code on the host. */
 AKR_API int32_t akr_probe_material_inputs(akr_context *ctx, akr_scene *scene, uint32_t material, uint32_t n, const float *uv, float *out26);
+/* The same on the host under the colour pipeline `color` (akr_color_pipeline_bits): the tables a session with that
+ * akr_pt_config.color uses, evaluated by the code the kernels run. */
+AKR_API int32_t akr_probe_material_inputs_host(akr_scene *scene, uint32_t material, uint32_t color, uint32_t n, const float *uv, float *out26);
 AKR_API int32_t akr_probe_surface_interaction(akr_context *ctx, akr_scene *scene, uint32_t n, const uint32_t *inst_prim,
                                               const float *bary, float *out);
 

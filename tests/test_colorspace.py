@@ -125,3 +125,24 @@ def test_scene_json_readers_keep_the_colour_space(hip_lib, tmp_path, root):
     fa = [m.colorspaces for m in a.materials]
     fb = [m.colorspaces for m in b.materials]
     assert fa == fb and sum(1 for f in fa if f) >= 1
+
+
+@pytest.mark.parametrize("color", [0, 1, 2, 3])
+def test_host_material_tables_match_the_oracle_in_every_pipeline(hip_lib, color):
+    """The tables a session compiles for its ColorPipeline (constants folded through the graph's Rgb / uplift nodes, pruned
+    node lists, raw inputs), evaluated on the host by the code the kernels run, against the oracle: every material, bit for bit."""
+    sd = textured_room(32, 24)
+    for m in sd.materials:
+        if m.graph is None:
+            continue
+        for k, nd in enumerate(m.graph.nodes):
+            if nd.op == abi.NODE_RGB and k % 2 == 0:
+                nd.args = (1,) + tuple(nd.args[1:])
+    sd.materials[3].colorspaces = abi.MAT_CS_BASE_COLOR
+    sc = capi.Scene(None, sd)
+    osc = pyoracle.OracleScene(sd)
+    uv = np.random.default_rng(1).random((64, 2), dtype=np.float32)
+    for mi in range(len(sd.materials)):
+        a = capi.probe_material_inputs_host(sc, mi, uv, color)
+        b = osc.material_inputs(mi, uv, color)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (color, mi)

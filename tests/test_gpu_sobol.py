@@ -11,13 +11,15 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("case", ["cbox_full", "cbox_ragged_passes", "bvh_grid", "textured"])
-def test_sobol_films_match_the_oracle(ctx, cbox_path, case):
+def test_sobol_films_match_the_oracle(ctx, cbox_path, root, case):
     if case == "bvh_grid":
         sd = grid_scene(n=24, width=80, height=48, with_normals=True)
     elif case == "textured":
         sd = textured_room(64, 48)
     else:
         sd = scene_json.load_scene(cbox_path, 96, 72)
+    import os
+    sd.ggx_table = np.fromfile(os.path.join(root, "tests", "golden", "ggx_dielectric_s.f32"), dtype=np.float32)  # both sides read the committed table
     spp, per = (11, 4) if case == "cbox_ragged_passes" else (16, 8)
     cfg = make_config(spp=spp, spp_per_pass=per, max_depth=8, sampler_type=abi.SAMPLER_SOBOL, sampler_seed=5)
     w, h = sd.camera.width, sd.camera.height
