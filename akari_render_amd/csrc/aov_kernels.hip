@@ -11,7 +11,7 @@ template <bool BVH, bool TEX, bool PMJ>
 __global__ __launch_bounds__(256) void k_aov(const PtParams p_in, uint32_t spp, uint32_t aov, uint32_t remap) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: traversal stacks; else: the staged scene tables
     PtParams staged = p_in;
-    if (!BVH) stage_scene_tables<false>(p_in, lds_stack, staged);
+    if (!BVH) stage_scene_tables<false, TEX>(p_in, lds_stack, staged);
     const PtParams& p = BVH ? p_in : staged;
     TraceCtx tc;
     tc.stack = lds_stack + threadIdx.x;

@@ -270,14 +270,14 @@ AKR_D float pdf_direct(const DScene& sc, const SurfacePoint& si, uint32_t gid, v
 // scene_build.cpp): shading records, normals, instance transforms, materials, light tables -- 11.5 KB for the cbox.
 // BVH path: instance transforms, materials and light tables, behind the traversal stacks, when the host found that they fit
 // (PtParams.stage_total != 0); the per-triangle records stay in HBM. Must be called by every thread of the workgroup.
-template <bool BVH>
+template <bool BVH, bool TEX = false>
 AKR_D void stage_scene_tables(const PtParams& p, uint32_t* lds, PtParams& staged) {
-    const void* src[9] = {p.sc.shade,      p.sc.normals, p.sc.inst,      p.sc.materials, p.sc.light_alias,
-                          p.sc.area_alias, p.sc.lights,  p.sc.light_pdf, p.sc.area_pdf};
-    uint32_t* dst[9];
+    const void* src[12] = {p.sc.shade,      p.sc.normals, p.sc.inst,      p.sc.materials, p.sc.light_alias, p.sc.area_alias,
+                           p.sc.lights,     p.sc.light_pdf, p.sc.area_pdf, p.sc.tex.nodes, p.sc.tex.images, p.sc.tex.mat_inputs};
+    uint32_t* dst[12];
     uint32_t off = BVH ? kBvhStackDepth * 256u : 0u;  // in words, behind the stacks
 #pragma unroll
-    for (int e = BVH ? 2 : 0; e < 9; e++) {
+    for (int e = BVH ? 2 : 0; e < (TEX ? 12 : 9); e++) {
         const uint32_t n = p.stage_bytes[e] >> 2;
         const uint32_t* g = (const uint32_t*)src[e];
         uint32_t* l = lds + off;
@@ -297,6 +297,15 @@ AKR_D void stage_scene_tables(const PtParams& p, uint32_t* lds, PtParams& staged
     staged.sc.lights = (const LightRec*)dst[6];
     staged.sc.light_pdf = (const float*)dst[7];
     staged.sc.area_pdf = (const float*)dst[8];
+    // Texture-fed materials: a textured hit walks its node list (32 B per node), reads image headers and the raw input record
+    // in dependent chains; from LDS each link is a ds_read instead of an L1 / L2 round trip. Texels stay in HBM.
+    // The host stages either all of it or nothing (api.cpp fill_params, scene_build.cpp), so a TEX kernel that stages at all
+    // reads the texture tables through LDS addresses unconditionally.
+    if (TEX) {
+        staged.sc.tex.nodes = (const DNode*)dst[9];
+        staged.sc.tex.images = (const DImage*)dst[10];
+        staged.sc.tex.mat_inputs = (const MatInputs*)dst[11];
+    }
 }
 
 // Per-thread intersection context: the LDS stack slot of this lane and the traversal counters.

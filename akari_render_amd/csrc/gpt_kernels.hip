@@ -29,7 +29,7 @@ template <bool BVH, bool TEX>
 __global__ __launch_bounds__(256, 2) void k_gpt_sample(const PtParams p_in, const GptParams g) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: traversal stacks; else: the staged scene tables
     PtParams staged = p_in;
-    if (!BVH) stage_scene_tables<false>(p_in, lds_stack, staged);
+    if (!BVH) stage_scene_tables<false, TEX>(p_in, lds_stack, staged);
     const PtParams& p = BVH ? p_in : staged;
     TraceCtx tc;
     tc.stack = lds_stack + threadIdx.x;

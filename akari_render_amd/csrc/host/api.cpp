@@ -403,14 +403,20 @@ static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pas
         const bool bvh = !cs.bvh_nodes.empty();
         // exhaustive path: everything, per-triangle records included (scene_build.cpp guarantees the fit);
         // BVH path: the per-scene tables only, if they fit beside the traversal stacks
-        const size_t bytes[9] = {bvh ? 0 : cs.shade.size() * 4, bvh ? 0 : cs.normals.size() * 4, cs.inst.size() * 4, cs.materials.size() * sizeof(DMaterial),
-                                 (size_t)cs.n_lights * sizeof(AliasPacked), cs.area_entries.size() * sizeof(AliasPacked), (size_t)cs.n_lights * sizeof(LightRec),
-                                 cs.light_pdf.size() * 4, cs.area_pdf.size() * 4};
+        size_t bytes[12] = {bvh ? 0 : cs.shade.size() * 4, bvh ? 0 : cs.normals.size() * 4, cs.inst.size() * 4, cs.materials.size() * sizeof(DMaterial),
+                            (size_t)cs.n_lights * sizeof(AliasPacked), cs.area_entries.size() * sizeof(AliasPacked), (size_t)cs.n_lights * sizeof(LightRec),
+                            cs.light_pdf.size() * 4, cs.area_pdf.size() * 4, 0, 0, 0};
+        if (cs.has_textures) {  // the node lists have the same size in every colour pipeline
+            bytes[9] = cs.tex_nodes.size() * sizeof(DNode);
+            bytes[10] = cs.images.size() * sizeof(DImage);
+            bytes[11] = cs.mat_inputs.size() * sizeof(MatInputs);
+        }
         size_t total = 0;
-        for (int i = 0; i < 9; i++) total += (bytes[i] + 15) & ~(size_t)15;
+        for (int i = 0; i < 12; i++) total += (bytes[i] + 15) & ~(size_t)15;
+        std::memset(p.stage_bytes, 0, sizeof p.stage_bytes);
         p.stage_total = 0;
-        if (total <= (bvh ? kStageMaxBytesBvh : kStageMaxBytes)) {
-            for (int i = 0; i < 9; i++) p.stage_bytes[i] = (uint32_t)bytes[i];
+        if (total <= (bvh ? kStageMaxBytesBvh : kStageMaxBytes)) {  // all of it or nothing (a TEX kernel reads its tables through LDS addresses)
+            for (int i = 0; i < 12; i++) p.stage_bytes[i] = (uint32_t)bytes[i];
             p.stage_total = (uint32_t)std::max<size_t>(total, 16);
         }
     }

@@ -635,7 +635,8 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
     // the exhaustive kernels stage the shading tables in LDS (pt_kernels.hip): a tiny mesh with a huge material list goes the BVH way
     size_t stage = 0;
     for (size_t b : {out.shade.size() * 4, out.normals.size() * 4, out.inst.size() * 4, out.materials.size() * sizeof(DMaterial),
-                     (size_t)out.n_lights * 32, out.area_entries.size() * 16, out.light_pdf.size() * 4, out.area_pdf.size() * 4})
+                     (size_t)out.n_lights * 32, out.area_entries.size() * 16, out.light_pdf.size() * 4, out.area_pdf.size() * 4,
+                     out.tex_nodes.size() * sizeof(DNode), out.images.size() * sizeof(DImage), out.mat_inputs.size() * sizeof(MatInputs)})
         stage += (b + 15) & ~(size_t)15;
     if (n_tris > kExhaustiveMax || stage > kStageMaxBytes) {
         float diag2 = 0.0f;

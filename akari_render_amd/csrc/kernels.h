@@ -38,7 +38,8 @@ struct PtParams {
     const uint16_t* bluenoise;              // [48][128][128] unorm16
     // Small scenes (exhaustive path): the tables the shading phase gathers from, staged in LDS by k_pt_pass. Bytes per table
     // in the order shade, normals, inst, materials, light_alias, area_alias, lights, light_pdf, area_pdf; 0 total = not staged.
-    uint32_t stage_bytes[9];
+    // ... then the texture tables of a TEX scene: pruned node lists, image headers, raw material inputs (12 entries in all).
+    uint32_t stage_bytes[12];
     uint32_t stage_total;
     // work distribution
     uint32_t n_items;

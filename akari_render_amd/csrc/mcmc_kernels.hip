@@ -137,7 +137,7 @@ template <bool BVH, bool TEX>
 __global__ __launch_bounds__(256, 2) void k_mcmc_bootstrap(const PtParams p_in, const McmcParams m) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: traversal stacks; else: the staged scene tables
     PtParams staged = p_in;
-    if (!BVH) stage_scene_tables<false>(p_in, lds_stack, staged);
+    if (!BVH) stage_scene_tables<false, TEX>(p_in, lds_stack, staged);
     const PtParams& p = BVH ? p_in : staged;
     TraceCtx tc;
     tc.stack = lds_stack + threadIdx.x;
@@ -156,7 +156,7 @@ template <bool BVH, bool TEX>
 __global__ __launch_bounds__(256, 2) void k_mcmc_init(const PtParams p_in, const McmcParams m) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: traversal stacks; else: the staged scene tables
     PtParams staged = p_in;
-    if (!BVH) stage_scene_tables<false>(p_in, lds_stack, staged);
+    if (!BVH) stage_scene_tables<false, TEX>(p_in, lds_stack, staged);
     const PtParams& p = BVH ? p_in : staged;
     TraceCtx tc;
     tc.stack = lds_stack + threadIdx.x;
@@ -178,7 +178,7 @@ template <bool BVH, bool TEX>
 __global__ __launch_bounds__(256, 2) void k_mcmc_advance(const PtParams p_in, const McmcParams m, uint32_t mutations_per_chain, float contribution) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: traversal stacks; else: the staged scene tables
     PtParams staged = p_in;
-    if (!BVH) stage_scene_tables<false>(p_in, lds_stack, staged);
+    if (!BVH) stage_scene_tables<false, TEX>(p_in, lds_stack, staged);
     const PtParams& p = BVH ? p_in : staged;
     TraceCtx tc;
     tc.stack = lds_stack + threadIdx.x;
