@@ -1,0 +1,57 @@
+#!/bin/bash
+# PMC passes over one bench.py configuration (one --pmc set per rocprofv3 run, kernel-trace only), summarised into the JSON
+# that bench.py's roofline block reads: profiles/r2_pmc_<config>.json.   usage: tools/pmc_bench.sh c2|c3|c4
+set -u
+CFG=${1:-c2}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/pmc_bench_$CFG
+rm -rf $OUT; mkdir -p $OUT
+ARGS="--config $CFG --steps 1 --warmup 0 --also none --no-cpu-baseline"
+i=0
+for SET in \
+  "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
+  "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA" \
+  "GRBM_GUI_ACTIVE" \
+  "FETCH_SIZE" \
+  "WRITE_SIZE" \
+  "TCC_HIT_sum TCC_MISS_sum" \
+  "TA_BUSY_avr TA_TA_BUSY_sum" ; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --kernel-trace --pmc $SET -f csv -d $OUT -o set$i -- python bench.py $ARGS > $OUT/set$i.out 2> $OUT/set$i.err
+  echo "set$i rc=$? : $SET"
+done
+python - <<PY
+import csv, glob, collections, json
+out, cfg = "$OUT", "$CFG"
+res = collections.defaultdict(float); disp = collections.defaultdict(set)
+kernel = None
+for f in sorted(glob.glob(out + "/**/*counter_collection.csv", recursive=True)):
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"].split("(")[0]
+        if "k_pt_pass" not in k: continue
+        kernel = k
+        res[row["Counter_Name"]] += float(row["Counter_Value"]); disp[row["Counter_Name"]].add(row["Dispatch_Id"])
+bench = json.loads(open(out + "/set1.out").read().strip().splitlines()[-1])
+n_launch = max(len(v) for v in disp.values())
+samples = bench["counters"]["n_samples"]
+c = dict(res)
+xcd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0   # summed over the 8 XCDs
+hbm = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0  # KiB units; gfx950 counts 128-byte reads as 64 (MI355X_MICROARCH.md, HBM)
+valu_busy = c["SQ_INSTS_VALU"] * 2.0 / (1024.0 * xcd_cycles)
+lane = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+wait = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
+ta = c.get("TA_BUSY_avr", 0.0) / xcd_cycles
+s = {"config": cfg, "kernel": kernel, "bench_args": "$ARGS", "launches": n_launch, "samples_per_launch": samples / n_launch,
+     "hbm_bytes_per_launch": hbm / n_launch, "hbm_bytes_per_sample": hbm / samples,
+     "valu_busy": valu_busy, "valu_lane_utilisation": lane, "wait_share": wait, "ta_busy": ta,
+     "l2_hit": c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"]),
+     "value_under_profiler_msamples_s": bench["value"],
+     "counters": c,
+     "source": "tools/pmc_bench.sh " + cfg + ": rocprofv3 --kernel-trace --pmc <one set per pass> -- python bench.py $ARGS; hbm = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (KiB units, gfx950 read correction); valu_busy = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)"}
+if cfg == "c4":
+    del s["hbm_bytes_per_launch"]  # traffic scales with the rays traced: bench.py multiplies bytes per sample by its own launch size
+s["binding_limiter"] = ("VALU issue (the 36-triangle walk and the shading run from SGPRs / LDS; HBM sees only sampler states + film)" if cfg != "c4"
+                        else "latency of dependent node / triangle fetches at 4 waves per SIMD, with fabric reads at about half of peak")
+json.dump(s, open(out + "/summary.json", "w"), indent=1)
+print(json.dumps({k: v for k, v in s.items() if k != "counters"}, indent=1))
+PY
