@@ -348,7 +348,9 @@ AKR_HD bool fold_inputs(const MatInputs& m, DMaterial& d) {
             d.transmission = m.transmission_weight;
             d.roughness = m.roughness;
             d.eta = m.ior;
-            d.transmission_color = mk3(__builtin_sqrtf(color.x), __builtin_sqrtf(color.y), __builtin_sqrtf(color.z));
+            // (the lobes a material's flags switch off never read their constants: skip the square roots and divisions of the
+            // dielectric's transmission colour and of the conductor's (n, k) -- this runs per hit for texture-fed materials)
+            if (m.transmission_weight > 1e-4f) d.transmission_color = mk3(__builtin_sqrtf(color.x), __builtin_sqrtf(color.y), __builtin_sqrtf(color.z));
             d.diffuse_refl = color * kInvPi;
             d.spec_tint = mk3(m.specular_tint[0], m.specular_tint[1], m.specular_tint[2]);
             float eta_s = m.ior, f0 = f0_from_ior(eta_s);
@@ -365,7 +367,7 @@ AKR_HD bool fold_inputs(const MatInputs& m, DMaterial& d) {
             d.coat_scale = lerp3(mk3(1, 1, 1), mk3(m.coat_tint[0], m.coat_tint[1], m.coat_tint[2]), m.coat_weight);
             d.alpha = mk2(max_f(m.roughness * m.roughness, 1e-4f), max_f(m.roughness * m.roughness, 1e-4f));
             d.coat_alpha = mk2(max_f(m.coat_roughness * m.coat_roughness, 1e-4f), max_f(m.coat_roughness * m.coat_roughness, 1e-4f));
-            artistic_to_conductor(color, d.spec_tint, d.metal_n, d.metal_k);
+            if (m.metallic > 1e-4f) artistic_to_conductor(color, d.spec_tint, d.metal_n, d.metal_k);
             uint32_t fl = 0;
             if (f0 != 0.0f) fl |= MF_SPEC;
             if (m.coat_weight != 0.0f) fl |= MF_COAT;
