@@ -88,11 +88,12 @@ hipError_t launch_aov(const PtParams& p, uint32_t spp, uint32_t aov, uint32_t re
     uint32_t blocks = (p.n_items + 255u) / 256u;
     if (blocks == 0) return hipSuccess;
     const bool bvh = p.sc.bvh_nodes != nullptr, tex = p.sc.tex.nodes != nullptr;
-    const size_t lds = bvh ? kBvhStackDepth * 256 * 4 : p.stage_total;
+    size_t lds;
+    const PtParams q = with_tex_slots(p, bvh ? kBvhStackDepth * 256 * 4 : p.stage_total, lds);
 #define AKR_AOV(B, T)                                                                                                  \
     {                                                                                                                \
-        if (p.sampler) hipLaunchKernelGGL((k_aov<B, T, true>), dim3(blocks), dim3(256), lds, stream, p, spp, aov, remap); \
-        else hipLaunchKernelGGL((k_aov<B, T, false>), dim3(blocks), dim3(256), lds, stream, p, spp, aov, remap);      \
+        if (p.sampler) hipLaunchKernelGGL((k_aov<B, T, true>), dim3(blocks), dim3(256), lds, stream, q, spp, aov, remap); \
+        else hipLaunchKernelGGL((k_aov<B, T, false>), dim3(blocks), dim3(256), lds, stream, q, spp, aov, remap);      \
     }
     if (bvh) { if (tex) AKR_AOV(true, true) else AKR_AOV(true, false) }
     else { if (tex) AKR_AOV(false, true) else AKR_AOV(false, false) }

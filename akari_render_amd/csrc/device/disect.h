@@ -53,9 +53,9 @@ AKR_D float textured_alpha(const DScene& sc, const float4* r, uint32_t material,
     float w = 1.0f - u - v;
     vec2 uv = mk2((r[0].w * w + r[2].w * u) + r[4].w * v, (r[1].w * w + r[3].w * u) + r[5].w * v);
     const DMaterial& m = sc.materials[material];
-    TexVal val[kMaxGraphNodes];
-    eval_graph(sc.tex, m.tex_first_node, m.tex_n_nodes, uv, val);
-    return val[m.tex_input[IN_BASE_COLOR]].w;
+    MatInputs in = sc.tex.mat_inputs[material];
+    eval_material_graph(sc.tex, m.tex_first_node, m.tex_n_nodes, uv, in);
+    return in.base_alpha;  // = w of the node feeding base_color
 }
 // scene.rs:49-86 for folded materials: alpha = alpha channel of the base-colour node
 template <bool TEX>

@@ -195,10 +195,8 @@ AKR_D vec3 material_emission_at(const DScene& sc, uint32_t material, vec2 uv) {
     if (TEX) {
         if ((m.flags & MF_TEXTURED) && (m.tex_input[IN_EMISSION_COLOR] != kNodeNone || m.tex_input[IN_EMISSION_STRENGTH] != kNodeNone)) {
             if (!(m.kind == MAT_PRINCIPLED || m.kind == MAT_EMISSION)) return mk3(0, 0, 0);
-            TexVal val[kMaxGraphNodes];
-            eval_graph(sc.tex, m.tex_first_node, m.tex_n_nodes, uv, val);
             MatInputs in = sc.tex.mat_inputs[material];
-            apply_inputs(m.tex_input, val, in);
+            eval_material_graph(sc.tex, m.tex_first_node, m.tex_n_nodes, uv, in);
             return mk3(in.emission_color[0], in.emission_color[1], in.emission_color[2]) * in.emission_strength;
         }
     }

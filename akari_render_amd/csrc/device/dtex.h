@@ -103,6 +103,14 @@ enum : uint32_t {
 };
 constexpr uint32_t kNodeNone = 0xffffffffu;
 constexpr uint32_t kMaxGraphNodes = 24;  // after pruning to the texture-fed inputs (host/scene_build.cpp)
+// A pruned node list is also register-allocated on the host: every node's value gets one of at most kTexMaxSlots value slots
+// (its slot is free again after its last consumer), the arguments of its consumers name slots, and the inputs of the surface
+// node it feeds are a bit mask. `op` of such a node: bits 0-7 the operation, bits 8-15 its slot (0xff: nobody reads the value
+// back), bits 16-29 the mask of akr_material_input it feeds. On the device the slots live in LDS, strided by the workgroup
+// size (kTexValStride lanes): the evaluation of a textured hit touches no scratch memory.
+constexpr uint32_t kTexMaxSlots = 8;
+constexpr uint32_t kTexValStride = 256;  // every kernel that evaluates graphs runs workgroups of (at most) 256 threads
+constexpr uint32_t kTexNoSlot = 0xffu;
 struct DNode {                           // = akr_shader_node, 32 B
     uint32_t op;
     uint32_t arg[4];
@@ -120,66 +128,74 @@ struct TexScene {  // the texture part of DScene
     const uint32_t* __restrict__ texels;
     const MatInputs* __restrict__ mat_inputs;  // raw (unfolded) inputs, one per material; constants already in the pipeline's space
     uint32_t color;                            // ColorPipeline bits (dbsdf.h COLOR_*)
-    uint32_t _pad;
+    uint32_t val_offset_words;                 // where this launch's value slots start in the workgroup's dynamic LDS (set by the launcher)
 };
 
-// eval_shader (eval.rs:363-380): every node of the (pruned) list in order; values are float4, narrower types
+// One node (svm/eval.rs:97-269). `get(a)` returns the value of argument node / slot `a`. Values are float4, narrower types
 // zero-extended, so the auto-convert rules of eval.rs:301-349 are component reads.
+template <typename Get>
+AKR_HD TexVal eval_node(const TexScene& ts, const DNode& nd, uint32_t op, vec2 uv, Get get) {
+    TexVal v = tv(0, 0, 0, 0);
+    switch (op) {
+        case NODE_CONST: v = tv(nd.k[0], nd.k[1], nd.k[2], 0.0f); break;
+        case NODE_RGB: {  // rgb_to_target_colorspace(rgb, node space, pipeline.rgb_colorspace), texture/mod.rs:9-30
+            vec3 c = cs_convert(mk3(nd.k[0], nd.k[1], nd.k[2]), nd.arg[0] == 1u, (ts.color & COLOR_RGB_ACES) != 0);
+            v = tv(c.x, c.y, c.z, 1.0f);
+            break;
+        }
+        case NODE_TEXCOORDS: v = tv(uv.x, uv.y, 0.0f, 0.0f); break;
+        case NODE_IMAGE: {
+            vec2 st = uv;
+            if (nd.arg[1] != kNodeNone) { TexVal a = get(nd.arg[1]); st = mk2(a.x, a.y); }
+            v = tex_sample(ts.texels, ts.images[nd.arg[0]], st);
+            if (nd.arg[2]) v = tv(srgb_to_linear1(v.x), srgb_to_linear1(v.y), srgb_to_linear1(v.z), v.w);
+            break;
+        }
+        case NODE_MAPPING: {
+            TexVal a = get(nd.arg[0]), loc = get(nd.arg[1]), sc = get(nd.arg[2]);
+            if (nd.arg[3] == 0) v = tv(a.x * sc.x + loc.x, a.y * sc.y + loc.y, a.z * sc.z + loc.z, 0.0f);
+            else v = tv((a.x - loc.x) / sc.x, (a.y - loc.y) / sc.y, (a.z - loc.z) / sc.z, 0.0f);
+            break;
+        }
+        case NODE_CHECKERBOARD: {
+            vec2 st = uv;
+            if (nd.arg[0] != kNodeNone) { TexVal a = get(nd.arg[0]); st = mk2(a.x, a.y); }
+            float scale = get(nd.arg[1]).x, fx, fy;
+            int px = tex_floor_to_int((st.x * scale) * 2.0f, fx), py = tex_floor_to_int((st.y * scale) * 2.0f, fy);
+            v = (((px + py) & 1) == 0) ? get(nd.arg[2]) : get(nd.arg[3]);
+            break;
+        }
+        case NODE_SPECTRAL_UPLIFT: {  // spectral_uplift: rgb_colorspace -> the space of color_repr, texture/mod.rs:31-43
+            TexVal a = get(nd.arg[0]);
+            vec3 c = cs_convert(mk3(a.x, a.y, a.z), (ts.color & COLOR_RGB_ACES) != 0, (ts.color & COLOR_REPR_ACES) != 0);
+            v = tv(c.x, c.y, c.z, a.w);
+            break;
+        }
+        case NODE_SEPARATE_COLOR: v = get(nd.arg[0]); break;
+        case NODE_EXTRACT: {
+            TexVal a = get(nd.arg[0]);
+            uint32_t f = nd.arg[1];
+            v = f == 0 ? tv(a.x, 0, 0, 0) : f == 1 ? tv(a.y, 0, 0, 0) : f == 2 ? tv(a.z, 0, 0, 0) : tv(a.x, a.y, 0, 0);
+            break;
+        }
+        case NODE_NORMAL_MAP: {
+            TexVal a = get(nd.arg[0]);
+            float s = get(nd.arg[1]).x;
+            float nx = 2.0f * a.x - 1.0f, ny = 2.0f * a.y - 1.0f, nz = 2.0f * a.z - 1.0f;
+            if (s != 1.0f) { nx = nx * s; ny = ny * s; nz = nz * 1.0f; }
+            v = tv(nx, ny, nz, 0.0f);
+            break;
+        }
+        default: break;
+    }
+    return v;
+}
+// eval_shader (eval.rs:363-380) over a node list whose arguments are NODE INDICES and whose values go to val[node]: the form
+// the scene description arrives in (host/scene_build.cpp folds the constant inputs with it).
 AKR_HD void eval_graph(const TexScene& ts, uint32_t first, uint32_t count, vec2 uv, TexVal* val) {
     for (uint32_t i = 0; i < count; i++) {
         const DNode nd = ts.nodes[first + i];
-        TexVal v = tv(0, 0, 0, 0);
-        switch (nd.op) {
-            case NODE_CONST: v = tv(nd.k[0], nd.k[1], nd.k[2], 0.0f); break;
-            case NODE_RGB: {  // rgb_to_target_colorspace(rgb, node space, pipeline.rgb_colorspace), texture/mod.rs:9-30
-                vec3 c = cs_convert(mk3(nd.k[0], nd.k[1], nd.k[2]), nd.arg[0] == 1u, (ts.color & COLOR_RGB_ACES) != 0);
-                v = tv(c.x, c.y, c.z, 1.0f);
-                break;
-            }
-            case NODE_TEXCOORDS: v = tv(uv.x, uv.y, 0.0f, 0.0f); break;
-            case NODE_IMAGE: {
-                vec2 st = nd.arg[1] == kNodeNone ? uv : mk2(val[nd.arg[1]].x, val[nd.arg[1]].y);
-                v = tex_sample(ts.texels, ts.images[nd.arg[0]], st);
-                if (nd.arg[2]) v = tv(srgb_to_linear1(v.x), srgb_to_linear1(v.y), srgb_to_linear1(v.z), v.w);
-                break;
-            }
-            case NODE_MAPPING: {
-                TexVal a = val[nd.arg[0]], loc = val[nd.arg[1]], sc = val[nd.arg[2]];
-                if (nd.arg[3] == 0) v = tv(a.x * sc.x + loc.x, a.y * sc.y + loc.y, a.z * sc.z + loc.z, 0.0f);
-                else v = tv((a.x - loc.x) / sc.x, (a.y - loc.y) / sc.y, (a.z - loc.z) / sc.z, 0.0f);
-                break;
-            }
-            case NODE_CHECKERBOARD: {
-                vec2 st = nd.arg[0] == kNodeNone ? uv : mk2(val[nd.arg[0]].x, val[nd.arg[0]].y);
-                float scale = val[nd.arg[1]].x, fx, fy;
-                int px = tex_floor_to_int((st.x * scale) * 2.0f, fx), py = tex_floor_to_int((st.y * scale) * 2.0f, fy);
-                v = (((px + py) & 1) == 0) ? val[nd.arg[2]] : val[nd.arg[3]];
-                break;
-            }
-            case NODE_SPECTRAL_UPLIFT: {  // spectral_uplift: rgb_colorspace -> the space of color_repr, texture/mod.rs:31-43
-                TexVal a = val[nd.arg[0]];
-                vec3 c = cs_convert(mk3(a.x, a.y, a.z), (ts.color & COLOR_RGB_ACES) != 0, (ts.color & COLOR_REPR_ACES) != 0);
-                v = tv(c.x, c.y, c.z, a.w);
-                break;
-            }
-            case NODE_SEPARATE_COLOR: v = val[nd.arg[0]]; break;
-            case NODE_EXTRACT: {
-                TexVal a = val[nd.arg[0]];
-                uint32_t f = nd.arg[1];
-                v = f == 0 ? tv(a.x, 0, 0, 0) : f == 1 ? tv(a.y, 0, 0, 0) : f == 2 ? tv(a.z, 0, 0, 0) : tv(a.x, a.y, 0, 0);
-                break;
-            }
-            case NODE_NORMAL_MAP: {
-                TexVal a = val[nd.arg[0]];
-                float s = val[nd.arg[1]].x;
-                float nx = 2.0f * a.x - 1.0f, ny = 2.0f * a.y - 1.0f, nz = 2.0f * a.z - 1.0f;
-                if (s != 1.0f) { nx = nx * s; ny = ny * s; nz = nz * 1.0f; }
-                v = tv(nx, ny, nz, 0.0f);
-                break;
-            }
-            default: break;
-        }
-        val[i] = v;
+        val[i] = eval_node(ts, nd, nd.op & 0xffu, uv, [&](uint32_t a) { return val[a]; });
     }
 }
 
@@ -203,17 +219,69 @@ AKR_HD void apply_inputs(const uint32_t* __restrict__ map, const TexVal* val, Ma
     if ((n = map[IN_NORMAL]) != kNodeNone) { in.normal[0] = val[n].x; in.normal[1] = val[n].y; in.normal[2] = val[n].z; }
 }
 
+// One input of the surface node from a node value (principled.rs:13-131 read rules, as apply_inputs above).
+AKR_HD void apply_fed(uint32_t feeds, TexVal v, MatInputs& in) {
+    if (feeds & (1u << IN_BASE_COLOR)) { in.base_color[0] = v.x; in.base_color[1] = v.y; in.base_color[2] = v.z; in.base_alpha = v.w; }
+    if (feeds & (1u << IN_METALLIC)) in.metallic = v.x;
+    if (feeds & (1u << IN_ROUGHNESS)) in.roughness = v.x;
+    if (feeds & (1u << IN_IOR)) in.ior = v.x;
+    if (feeds & (1u << IN_SPECULAR_IOR_LEVEL)) in.specular_ior_level = v.x;
+    if (feeds & (1u << IN_SPECULAR_TINT)) { in.specular_tint[0] = v.x; in.specular_tint[1] = v.y; in.specular_tint[2] = v.z; }
+    if (feeds & (1u << IN_TRANSMISSION_WEIGHT)) in.transmission_weight = v.x;
+    if (feeds & (1u << IN_COAT_WEIGHT)) in.coat_weight = v.x;
+    if (feeds & (1u << IN_COAT_ROUGHNESS)) in.coat_roughness = v.x;
+    if (feeds & (1u << IN_COAT_IOR)) in.coat_ior = v.x;
+    if (feeds & (1u << IN_COAT_TINT)) { in.coat_tint[0] = v.x; in.coat_tint[1] = v.y; in.coat_tint[2] = v.z; }
+    if (feeds & (1u << IN_EMISSION_COLOR)) { in.emission_color[0] = v.x; in.emission_color[1] = v.y; in.emission_color[2] = v.z; }
+    if (feeds & (1u << IN_EMISSION_STRENGTH)) in.emission_strength = v.x;
+    if (feeds & (1u << IN_NORMAL)) { in.normal[0] = v.x; in.normal[1] = v.y; in.normal[2] = v.z; }
+}
+
+// The value slots of one graph evaluation. Device: this lane's column of the workgroup's LDS block (TexScene.val_offset_words,
+// set by the launcher; ds_read / ds_write_b128, no bank conflicts: consecutive lanes hold consecutive 16-byte values).
+// Host (probes, tests): a local array.
+struct TexSlots {
+#if defined(__HIP_DEVICE_COMPILE__)
+    TexVal* base;
+    AKR_HD TexVal get(uint32_t s) const { return base[s * kTexValStride]; }
+    AKR_HD void set(uint32_t s, TexVal v) { base[s * kTexValStride] = v; }
+#else
+    TexVal v_[kTexMaxSlots];
+    TexVal get(uint32_t s) const { return v_[s]; }
+    void set(uint32_t s, TexVal v) { v_[s] = v; }
+#endif
+};
+AKR_HD TexSlots tex_slots(const TexScene& ts) {
+    TexSlots st;
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) uint32_t akr_dynamic_lds[];
+    st.base = reinterpret_cast<TexVal*>(akr_dynamic_lds + ts.val_offset_words) + threadIdx.x;
+#else
+    (void)ts;
+#endif
+    return st;
+}
+// The pruned, slot-allocated node list of a material at `uv`: every node's value into its slot, the inputs it feeds into `in`.
+AKR_HD void eval_material_graph(const TexScene& ts, uint32_t first, uint32_t count, vec2 uv, MatInputs& in) {
+    TexSlots st = tex_slots(ts);
+    for (uint32_t i = 0; i < count; i++) {
+        const DNode nd = ts.nodes[first + i];
+        const uint32_t slot = (nd.op >> 8) & 0xffu, feeds = nd.op >> 16;
+        const TexVal v = eval_node(ts, nd, nd.op & 0xffu, uv, [&](uint32_t a) { return st.get(a); });
+        if (slot != kTexNoSlot) st.set(slot, v);
+        if (feeds) apply_fed(feeds, v, in);
+    }
+}
+
 // The material at a shading point: the folded record as is, or -- for MF_TEXTURED materials -- its graph evaluated at
 // `uv` and folded. `m` must hold the material's folded record on entry.
 AKR_HD void material_at(const TexScene& ts, uint32_t material, vec2 uv, DMaterial& m) {
     if (!(m.flags & MF_TEXTURED)) return;
-    TexVal val[kMaxGraphNodes];
     const uint32_t first = m.tex_first_node, count = m.tex_n_nodes;
     uint32_t map[IN_COUNT];
     for (uint32_t i = 0; i < IN_COUNT; i++) map[i] = m.tex_input[i];
-    eval_graph(ts, first, count, uv, val);
     MatInputs in = ts.mat_inputs[material];
-    apply_inputs(map, val, in);
+    eval_material_graph(ts, first, count, uv, in);
     const uint32_t keep = m.flags & (MF_TEXTURED | MF_ALPHA_TEXTURED);
     fold_inputs(in, m);
     m.flags |= keep;

@@ -229,13 +229,14 @@ hipError_t launch_gpt_sample(const PtParams& p, const GptParams& g, hipStream_t 
     uint32_t blocks = (p.n_items + 255u) / 256u;
     if (blocks == 0) return hipSuccess;
     const bool bvh = p.sc.bvh_nodes != nullptr, tex = p.sc.tex.nodes != nullptr;
-    const size_t lds = bvh ? kBvhStackDepth * 256 * 4 : p.stage_total;
+    size_t lds;
+    const PtParams q = with_tex_slots(p, bvh ? kBvhStackDepth * 256 * 4 : p.stage_total, lds);
     if (bvh) {
-        if (tex) hipLaunchKernelGGL((k_gpt_sample<true, true>), dim3(blocks), dim3(256), lds, stream, p, g);
-        else hipLaunchKernelGGL((k_gpt_sample<true, false>), dim3(blocks), dim3(256), lds, stream, p, g);
+        if (tex) hipLaunchKernelGGL((k_gpt_sample<true, true>), dim3(blocks), dim3(256), lds, stream, q, g);
+        else hipLaunchKernelGGL((k_gpt_sample<true, false>), dim3(blocks), dim3(256), lds, stream, q, g);
     } else {
-        if (tex) hipLaunchKernelGGL((k_gpt_sample<false, true>), dim3(blocks), dim3(256), lds, stream, p, g);
-        else hipLaunchKernelGGL((k_gpt_sample<false, false>), dim3(blocks), dim3(256), lds, stream, p, g);
+        if (tex) hipLaunchKernelGGL((k_gpt_sample<false, true>), dim3(blocks), dim3(256), lds, stream, q, g);
+        else hipLaunchKernelGGL((k_gpt_sample<false, false>), dim3(blocks), dim3(256), lds, stream, q, g);
     }
     return hipGetLastError();
 }

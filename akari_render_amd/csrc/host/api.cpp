@@ -415,7 +415,10 @@ static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pas
         for (int i = 0; i < 12; i++) total += (bytes[i] + 15) & ~(size_t)15;
         std::memset(p.stage_bytes, 0, sizeof p.stage_bytes);
         p.stage_total = 0;
-        if (total <= (bvh ? kStageMaxBytesBvh : kStageMaxBytes)) {  // all of it or nothing (a TEX kernel reads its tables through LDS addresses)
+        p.tex_slots = cs.has_textures ? cs.tex_slots : 0;
+        // one workgroup's dynamic LDS stays within 64 KB: traversal stacks + staged tables + the graph evaluation's value slots
+        const size_t other = (bvh ? kBvhStackDepth * 256 * 4 : 0) + (size_t)p.tex_slots * kTexValStride * sizeof(TexVal);
+        if (total <= (bvh ? kStageMaxBytesBvh : kStageMaxBytes) && (!bvh || other + total <= 64 * 1024)) {  // all of it or nothing (a TEX kernel reads its tables through LDS addresses)
             for (int i = 0; i < 12; i++) p.stage_bytes[i] = (uint32_t)bytes[i];
             p.stage_total = (uint32_t)std::max<size_t>(total, 16);
         }
@@ -1478,6 +1481,7 @@ static PtParams probe_params(akr_scene* s) {
     PtParams p;
     std::memset(&p, 0, sizeof p);
     p.sc = s->dscene;
+    p.tex_slots = s->cs.has_textures ? s->cs.tex_slots : 0;
     return p;
 }
 AKR_API int32_t akr_probe_intersect(akr_context* ctx, akr_scene* scene, uint32_t n, const float* rays, uint32_t* hit_inst_prim, float* bary) {
@@ -1585,9 +1589,7 @@ AKR_API int32_t akr_probe_material_inputs_host(akr_scene* scene, uint32_t materi
             MatInputs in;
             std::memcpy(&in, &descs[material], sizeof in);
             if (m.flags & MF_TEXTURED) {
-                TexVal val[kMaxGraphNodes];
-                eval_graph(ts, m.tex_first_node, m.tex_n_nodes, mk2(uv[2 * i], uv[2 * i + 1]), val);
-                apply_inputs(m.tex_input, val, in);
+                eval_material_graph(ts, m.tex_first_node, m.tex_n_nodes, mk2(uv[2 * i], uv[2 * i + 1]), in);
             }
             std::memcpy(out26 + 26ull * i, &in, sizeof in);
         }
@@ -1607,9 +1609,7 @@ AKR_API int32_t akr_probe_material_inputs(akr_context* ctx, akr_scene* scene, ui
                 if (cs.has_textures) in = cs.mat_inputs[material];
                 else std::memcpy(&in, &scene->flat.materials[material], sizeof in);
                 if (m.flags & MF_TEXTURED) {
-                    TexVal val[kMaxGraphNodes];
-                    eval_graph(ts, m.tex_first_node, m.tex_n_nodes, mk2(uv[2 * i], uv[2 * i + 1]), val);
-                    apply_inputs(m.tex_input, val, in);
+                    eval_material_graph(ts, m.tex_first_node, m.tex_n_nodes, mk2(uv[2 * i], uv[2 * i + 1]), in);
                 }
                 std::memcpy(out26 + 26ull * i, &in, sizeof in);
             }

@@ -219,6 +219,7 @@ static void compile_graph(const HostGraph& g, const std::vector<HostImage>& imag
     std::vector<uint32_t> remap(n, AKR_NODE_NONE);
     const uint32_t first = (uint32_t)out.tex_nodes.size();
     uint32_t count = 0;
+    std::vector<akr_shader_node> pruned;
     for (uint32_t i = 0; i < n; i++) {
         if (!keep[i]) continue;
         remap[i] = count++;
@@ -228,12 +229,52 @@ static void compile_graph(const HostGraph& g, const std::vector<HostImage>& imag
             if (nd.op == AKR_NODE_IMAGE && a == 0) continue;
             if (nd.arg[a] != AKR_NODE_NONE) nd.arg[a] = remap[nd.arg[a]];
         }
-        DNode dn;
-        std::memcpy(&dn, &nd, sizeof dn);
-        out.tex_nodes.push_back(dn);
+        pruned.push_back(nd);
     }
     if (count > kMaxGraphNodes)
         throw std::invalid_argument("unsupported: shader graph needs more than " + std::to_string(kMaxGraphNodes) + " texture nodes");
+    // Register allocation of the node values (device/dtex.h: kTexMaxSlots value slots per lane, in LDS): a node's slot is free
+    // again after its last consumer; a node reads its arguments before it writes, so it may take over the slot of an argument
+    // whose last consumer it is. Inputs of the surface node are written the moment the node that feeds them has its value
+    // (`feeds` mask), so they pin nothing.
+    {
+        std::vector<uint32_t> last_use(count), feeds(count, 0), slot(count, kTexNoSlot);
+        for (uint32_t i = 0; i < count; i++) last_use[i] = i;
+        for (uint32_t i = 0; i < count; i++) {
+            uint32_t refs[4], nr;
+            node_refs(pruned[i], refs, nr);
+            for (uint32_t r = 0; r < nr; r++) last_use[refs[r]] = std::max(last_use[refs[r]], i);
+        }
+        for (uint32_t k = 0; k < AKR_IN_COUNT; k++)
+            if (map[k] != AKR_NODE_NONE) feeds[remap[map[k]]] |= 1u << k;
+        uint32_t owner[kTexMaxSlots], used = 0;
+        for (uint32_t& o : owner) o = AKR_NODE_NONE;
+        for (uint32_t i = 0; i < count; i++) {
+            for (uint32_t sl = 0; sl < kTexMaxSlots; sl++)
+                if (owner[sl] != AKR_NODE_NONE && last_use[owner[sl]] <= i) owner[sl] = AKR_NODE_NONE;  // read by node i at the latest
+            if (last_use[i] == i) continue;  // nobody reads this value back: no slot
+            uint32_t sl = 0;
+            while (sl < kTexMaxSlots && owner[sl] != AKR_NODE_NONE) sl++;
+            if (sl == kTexMaxSlots)
+                throw std::invalid_argument("unsupported: shader graph keeps more than " + std::to_string(kTexMaxSlots) + " values alive at once");
+            owner[sl] = i;
+            slot[i] = sl;
+            used = std::max(used, sl + 1);
+        }
+        out.tex_slots = std::max(out.tex_slots, std::max(used, 1u));
+        for (uint32_t i = 0; i < count; i++) {
+            akr_shader_node nd = pruned[i];
+            uint32_t na = node_n_args(nd.op);
+            for (uint32_t a = 0; a < na; a++) {
+                if (nd.op == AKR_NODE_IMAGE && a == 0) continue;
+                if (nd.arg[a] != AKR_NODE_NONE) nd.arg[a] = slot[nd.arg[a]];  // consumers name slots
+            }
+            nd.op = (nd.op & 0xffu) | (slot[i] << 8) | (feeds[i] << 16);
+            DNode dn;
+            std::memcpy(&dn, &nd, sizeof dn);
+            out.tex_nodes.push_back(dn);
+        }
+    }
     dm.flags |= MF_TEXTURED;
     if (map[AKR_IN_BASE_COLOR] != AKR_NODE_NONE && (dm.kind == MAT_PRINCIPLED || dm.kind == MAT_DIFFUSE) && !alpha_is_one(g, images, map[AKR_IN_BASE_COLOR]))
         dm.flags |= MF_ALPHA_TEXTURED;
@@ -399,6 +440,7 @@ void compile_materials(const FlatScene& flat, uint32_t color, CompiledScene& out
     out.tex_nodes.clear();
     out.mat_inputs.clear();
     out.has_textures = false;
+    out.tex_slots = 0;
     descs = flat.materials;
     for (size_t mi = 0; mi < flat.materials.size(); mi++) {
         DMaterial d;

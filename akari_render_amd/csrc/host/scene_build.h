@@ -70,6 +70,7 @@ struct CompiledScene {
     std::vector<DImage> images;
     std::vector<uint32_t> texels;
     std::vector<MatInputs> mat_inputs;   // one per material when any material is textured, else empty
+    uint32_t tex_slots = 0;              // value slots per lane the widest node list needs (device/dtex.h), 0 without textures
     bool has_textures = false;
     bool has_alpha = false;
     bool needs_ggx_table = false;

@@ -41,6 +41,7 @@ struct PtParams {
     // ... then the texture tables of a TEX scene: pruned node lists, image headers, raw material inputs (12 entries in all).
     uint32_t stage_bytes[12];
     uint32_t stage_total;
+    uint32_t tex_slots;      // TEX scenes: value slots per lane of the graph evaluation (LDS, after the launch's other blocks)
     // work distribution
     uint32_t n_items;
     uint32_t shard_rank, shard_count;
@@ -98,6 +99,15 @@ hipError_t launch_mcmc_bootstrap(const PtParams& p, const McmcParams& m, hipStre
 hipError_t launch_mcmc_init(const PtParams& p, const McmcParams& m, hipStream_t stream);
 hipError_t launch_mcmc_advance(const PtParams& p, const McmcParams& m, uint32_t mutations_per_chain, float contribution, hipStream_t stream);
 
+// Dynamic LDS of a launch that evaluates shader graphs = its own blocks (`base_bytes`: traversal stacks, staged tables), then
+// tex_slots x 256 lanes x 16 B of value slots. Returns the parameter block with the slots' offset filled in and the total size.
+inline PtParams with_tex_slots(const PtParams& p, size_t base_bytes, size_t& lds_bytes) {
+    PtParams q = p;
+    base_bytes = (base_bytes + 15) & ~(size_t)15;
+    q.sc.tex.val_offset_words = (uint32_t)(base_bytes / 4);
+    lds_bytes = base_bytes + (p.sc.tex.nodes != nullptr ? (size_t)p.tex_slots * kTexValStride * sizeof(TexVal) : 0);
+    return q;
+}
 hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream);
 hipError_t launch_gpt_sample(const PtParams& p, const GptParams& g, hipStream_t stream);
 hipError_t launch_gpt_update(const GptParams& g, uint32_t W, uint32_t H, float* film, hipStream_t stream);

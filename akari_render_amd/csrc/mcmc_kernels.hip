@@ -270,8 +270,9 @@ __global__ __launch_bounds__(256, 2) void k_mcmc_advance(const PtParams p_in, co
     {                                                                                                             \
         uint32_t blocks = ((COUNT) + 255u) / 256u;                                                                \
         if (blocks == 0) return hipSuccess;                                                                       \
-        const bool bvh = p.sc.bvh_nodes != nullptr, tex = p.sc.tex.nodes != nullptr;                              \
-        const size_t lds = bvh ? kBvhStackDepth * 256 * 4 : p.stage_total;                                        \
+        const bool bvh = p_in.sc.bvh_nodes != nullptr, tex = p_in.sc.tex.nodes != nullptr;                        \
+        size_t lds;                                                                                               \
+        const PtParams p = with_tex_slots(p_in, bvh ? kBvhStackDepth * 256 * 4 : p_in.stage_total, lds);           \
         if (bvh) {                                                                                                \
             if (tex) hipLaunchKernelGGL((KERNEL<true, true>), dim3(blocks), dim3(256), lds, stream, __VA_ARGS__);   \
             else hipLaunchKernelGGL((KERNEL<true, false>), dim3(blocks), dim3(256), lds, stream, __VA_ARGS__);      \
@@ -281,9 +282,9 @@ __global__ __launch_bounds__(256, 2) void k_mcmc_advance(const PtParams p_in, co
         }                                                                                                         \
         return hipGetLastError();                                                                                 \
     }
-hipError_t launch_mcmc_bootstrap(const PtParams& p, const McmcParams& m, hipStream_t stream) AKR_MCMC_LAUNCH(k_mcmc_bootstrap, m.n_bootstrap, p, m)
-hipError_t launch_mcmc_init(const PtParams& p, const McmcParams& m, hipStream_t stream) AKR_MCMC_LAUNCH(k_mcmc_init, m.n_chains, p, m)
-hipError_t launch_mcmc_advance(const PtParams& p, const McmcParams& m, uint32_t mutations_per_chain, float contribution, hipStream_t stream)
+hipError_t launch_mcmc_bootstrap(const PtParams& p_in, const McmcParams& m, hipStream_t stream) AKR_MCMC_LAUNCH(k_mcmc_bootstrap, m.n_bootstrap, p, m)
+hipError_t launch_mcmc_init(const PtParams& p_in, const McmcParams& m, hipStream_t stream) AKR_MCMC_LAUNCH(k_mcmc_init, m.n_chains, p, m)
+hipError_t launch_mcmc_advance(const PtParams& p_in, const McmcParams& m, uint32_t mutations_per_chain, float contribution, hipStream_t stream)
     AKR_MCMC_LAUNCH(k_mcmc_advance, m.n_chains, p, m, mutations_per_chain, contribution)
 #undef AKR_MCMC_LAUNCH
 

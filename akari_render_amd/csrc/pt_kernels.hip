@@ -228,9 +228,7 @@ __global__ void k_probe_material(PtParams p, uint32_t material, uint32_t n, cons
     const DMaterial& m = p.sc.materials[material];
     MatInputs in = p.sc.tex.mat_inputs[material];
     if (m.flags & MF_TEXTURED) {
-        TexVal val[kMaxGraphNodes];
-        eval_graph(p.sc.tex, m.tex_first_node, m.tex_n_nodes, mk2(uv[2 * i], uv[2 * i + 1]), val);
-        apply_inputs(m.tex_input, val, in);
+        eval_material_graph(p.sc.tex, m.tex_first_node, m.tex_n_nodes, mk2(uv[2 * i], uv[2 * i + 1]), in);
     }
     const uint32_t* w = reinterpret_cast<const uint32_t*>(&in);
     for (uint32_t k = 0; k < 26; k++) out[26 * (size_t)i + k] = w[k];
@@ -238,7 +236,9 @@ __global__ void k_probe_material(PtParams p, uint32_t material, uint32_t n, cons
 
 // ---------------------------------------------------------------------------------------------------- launchers
 hipError_t launch_probe_material(const PtParams& p, uint32_t material, uint32_t n, const float* uv, uint32_t* out, hipStream_t stream) {
-    hipLaunchKernelGGL(k_probe_material, dim3((n + 127) / 128), dim3(128), 0, stream, p, material, n, uv, out);
+    size_t lds;
+    const PtParams q = with_tex_slots(p, 0, lds);
+    hipLaunchKernelGGL(k_probe_material, dim3((n + 127) / 128), dim3(128), lds, stream, q, material, n, uv, out);
     return hipGetLastError();
 }
 hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream) {
@@ -246,12 +246,13 @@ hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream) {
     if (blocks == 0) return hipSuccess;
     const bool fd = p.force_diffuse != 0, tex = p.sc.tex.nodes != nullptr;
     const bool bvh = p.sc.bvh_nodes != nullptr;
-    const size_t lds = (bvh ? kBvhStackDepth * 256 * 4 : 0) + p.stage_total;
+    size_t lds;
+    const PtParams q = with_tex_slots(p, (bvh ? kBvhStackDepth * 256 * 4 : 0) + p.stage_total, lds);
     const bool stage = p.stage_total != 0;
 #define AKR_LAUNCH2(B, F, T, S)                                                                                        \
     {                                                                                                                  \
-        if (p.sampler) hipLaunchKernelGGL((k_pt_pass<B, F, T, true, S>), dim3(blocks), dim3(256), lds, stream, p);      \
-        else hipLaunchKernelGGL((k_pt_pass<B, F, T, false, S>), dim3(blocks), dim3(256), lds, stream, p);              \
+        if (p.sampler) hipLaunchKernelGGL((k_pt_pass<B, F, T, true, S>), dim3(blocks), dim3(256), lds, stream, q);      \
+        else hipLaunchKernelGGL((k_pt_pass<B, F, T, false, S>), dim3(blocks), dim3(256), lds, stream, q);              \
     }
 #define AKR_LAUNCH(B, F, T)                                                  \
     {                                                                        \

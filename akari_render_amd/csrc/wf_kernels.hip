@@ -202,8 +202,10 @@ hipError_t launch_wf_shade(const PtParams& p, const WfBuffers& wf, uint32_t q_ou
     if (blocks == 0) return hipSuccess;
     const bool tex = p.sc.tex.nodes != nullptr, pmj = p.sampler != 0;
     if (tex) {
-        if (pmj) hipLaunchKernelGGL((k_wf_shade<true, true>), dim3(blocks), dim3(256), 0, stream, p, wf, q_out);
-        else hipLaunchKernelGGL((k_wf_shade<true, false>), dim3(blocks), dim3(256), 0, stream, p, wf, q_out);
+        size_t lds;
+        const PtParams q = with_tex_slots(p, 0, lds);
+        if (pmj) hipLaunchKernelGGL((k_wf_shade<true, true>), dim3(blocks), dim3(256), lds, stream, q, wf, q_out);
+        else hipLaunchKernelGGL((k_wf_shade<true, false>), dim3(blocks), dim3(256), lds, stream, q, wf, q_out);
     } else {
         if (pmj) hipLaunchKernelGGL((k_wf_shade<false, true>), dim3(blocks), dim3(256), 0, stream, p, wf, q_out);
         else hipLaunchKernelGGL((k_wf_shade<false, false>), dim3(blocks), dim3(256), 0, stream, p, wf, q_out);
@@ -211,8 +213,11 @@ hipError_t launch_wf_shade(const PtParams& p, const WfBuffers& wf, uint32_t q_ou
     return hipGetLastError();
 }
 hipError_t launch_wf_trace(const PtParams& p, const WfBuffers& wf, uint32_t q_in, uint32_t n_blocks, hipStream_t stream) {
-    if (p.sc.tex.nodes != nullptr) hipLaunchKernelGGL(k_wf_trace<true>, dim3(n_blocks), dim3(256), kBvhStackDepth * 256 * 4, stream, p, wf, q_in);
-    else hipLaunchKernelGGL(k_wf_trace<false>, dim3(n_blocks), dim3(256), kBvhStackDepth * 256 * 4, stream, p, wf, q_in);
+    if (p.sc.tex.nodes != nullptr) {
+        size_t lds;
+        const PtParams q = with_tex_slots(p, kBvhStackDepth * 256 * 4, lds);
+        hipLaunchKernelGGL(k_wf_trace<true>, dim3(n_blocks), dim3(256), lds, stream, q, wf, q_in);
+    } else hipLaunchKernelGGL(k_wf_trace<false>, dim3(n_blocks), dim3(256), kBvhStackDepth * 256 * 4, stream, p, wf, q_in);
     return hipGetLastError();
 }
 

@@ -8,8 +8,9 @@ from akari_render_amd import abi, capi
 from tests.helpers import textured_room
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+n_floor = int(sys.argv[2]) if len(sys.argv) > 2 else 1   # > 1 tessellates the floor: the scene then takes the BVH path
 rng = np.random.default_rng(0)
-sd = textured_room(1920, 1080, n_floor=1)
+sd = textured_room(1920, 1080, n_floor=n_floor)
 big8 = rng.integers(0, 256, size=(4096, 4096, 4), dtype=np.uint8); big8[:, :, 3] = 255
 bigf = rng.random((2048, 2048, 4)).astype(np.float32); bigf[:, :, 2] = 0.5 + 0.5 * bigf[:, :, 2]; bigf[:, :, 3] = 1.0
 sd.images[0] = abi.ImageData(big8, abi.TEX_FILTER_LINEAR, abi.TEX_REPEAT)
@@ -19,7 +20,7 @@ ctx = capi.Context(0)
 out = {}
 for name, variant in (("textured", sd), ("same room, constant materials", None)):
     if variant is None:
-        variant = textured_room(1920, 1080, n_floor=1)
+        variant = textured_room(1920, 1080, n_floor=n_floor)
         for m in variant.materials:
             m.graph = None
         variant.materials[6].emission_color = (6.0, 6.0, 6.0)
