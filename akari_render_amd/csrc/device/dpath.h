@@ -343,6 +343,10 @@ struct PathRegs {
     vec3 film_rgb;
     float film_w;
     uint32_t c_samples, c_closest, c_shadow, c_shaded;
+    // a vertex whose shading was put off by one iteration (pt_kernels.hip: conductor hits are shaded on even iterations only)
+    bool deferred;
+    uint32_t d_gid;
+    float d_u, d_v;
 };
 
 template <bool PMJ = false>
@@ -355,6 +359,7 @@ AKR_D void path_regs_init(PathRegs& r, const PtParams& p, bool active, uint32_t 
     r.s_tmax = -1.0f; r.s_ex0 = kInvalid; r.s_ex1 = kInvalid;
     r.active = active; r.has_ray = active; r.has_shadow = false; r.s_add = false; r.s_depth1 = false;
     r.finalize = false; r.lane_done = false;
+    r.deferred = false; r.d_gid = kInvalid; r.d_u = 0.0f; r.d_v = 0.0f;
     r.samples_done = 0; r.pass_idx = 0; r.c_samples = 0;
     r.cur_spp = (p.n_passes == 1) ? p.last_pass_spp : p.pass_spp;
     r.c_closest = 0; r.c_shadow = 0; r.c_shaded = 0;

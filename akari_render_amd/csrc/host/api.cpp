@@ -423,6 +423,19 @@ static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pas
             p.stage_total = (uint32_t)std::max<size_t>(total, 16);
         }
     }
+    {   // conductor hits on even iterations only (pt_kernels.hip): pays when SOME materials have the lobe and most hits do not
+        const CompiledScene& cs = s->cs;
+        size_t n_metal = 0, n_surface = 0;
+        for (const DMaterial& m : cs.materials) {
+            if (m.kind == MAT_EMISSION) continue;
+            n_surface++;
+            if (m.kind == MAT_PRINCIPLED && (m.flags & MF_EVAL_METAL)) n_metal++;
+        }
+        bool want = n_metal > 0 && 2 * n_metal <= n_surface;
+        uint32_t mask = 1u;  // iterations with (iteration & mask) != 0 put conductor hits off
+        if (const char* e = std::getenv("AKR_PT_DEFER_METAL")) { mask = (uint32_t)std::atoi(e); want = mask != 0; }  // measurements / tests
+        p.defer_metal = (want && cs.bvh_nodes.empty() && !c.force_diffuse) ? mask : 0u;
+    }
     p.shard_rank = c.shard_count > 1 ? c.shard_rank : 0;
     p.shard_count = c.shard_count > 1 ? c.shard_count : 1;
     p.tile_w = c.tile_w ? c.tile_w : 32;

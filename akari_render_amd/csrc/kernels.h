@@ -41,6 +41,7 @@ struct PtParams {
     // ... then the texture tables of a TEX scene: pruned node lists, image headers, raw material inputs (12 entries in all).
     uint32_t stage_bytes[12];
     uint32_t stage_total;
+    uint32_t defer_metal;    // exhaustive path: shade hits on materials with a conductor lobe on even iterations only (pt_kernels.hip)
     uint32_t tex_slots;      // TEX scenes: value slots per lane of the graph evaluation (LDS, after the launch's other blocks)
     // work distribution
     uint32_t n_items;

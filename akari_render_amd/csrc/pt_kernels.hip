@@ -27,7 +27,7 @@ namespace akr {
 #ifndef AKR_PT_MERGED_RAYS
 #define AKR_PT_MERGED_RAYS 1  // BVH path: a lane starts its shadow ray the moment its closest-hit ray is done (one loop)
 #endif
-template <bool BVH, bool FD, bool TEX, bool PMJ, bool STAGE>
+template <bool BVH, bool FD, bool TEX, bool PMJ, bool STAGE, bool DEFER>
 __global__ __launch_bounds__(256, BVH ? AKR_PT_MIN_WAVES_BVH : (FD ? AKR_PT_MIN_WAVES_FD : AKR_PT_MIN_WAVES)) void k_pt_pass(const PtParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: kBvhStackDepth x 256 words; else: staged tables
     TraceCtx tc;
@@ -47,7 +47,9 @@ __global__ __launch_bounds__(256, BVH ? AKR_PT_MIN_WAVES_BVH : (FD ? AKR_PT_MIN_
     PathRegs r;
     path_regs_init<PMJ>(r, q, in_frame, pix, sx, sy);
 
+    uint32_t iteration = 0;
     while (__builtin_amdgcn_ballot_w64(r.active) != 0) {
+        iteration++;
         if (r.active) {
             // intersection phase: next closest-hit ray + pending shadow ray
             Hit hit;
@@ -87,6 +89,27 @@ __global__ __launch_bounds__(256, BVH ? AKR_PT_MIN_WAVES_BVH : (FD ? AKR_PT_MIN_
             } else {
                 trace_pair_exhaustive<TEX, FD>(sc, r.ro, r.rd, r.has_ray ? 1e20f : -1.0f, r.ray_ex0, r.s_o, r.s_d, r.has_shadow ? r.s_tmax : -1.0f,
                                       r.s_ex0, r.s_ex1, hit, found, occluded);
+                if (DEFER) {
+                    // A scene with one metal among diffuse surfaces: every wave carries a few lanes on the metal at every
+                    // iteration, so every iteration pays for the conductor lobe (GGX + complex Fresnel, the dearest code of the
+                    // material system) with a handful of lanes. Hits on a material with that lobe are therefore shaded on EVEN
+                    // iterations only: a lane that finds one on an odd iteration keeps the hit and sits the next intersection
+                    // phase out (the walk is wave-uniform: an idle lane costs nothing), and on odd iterations no lane enters
+                    // that code at all. Per lane nothing changes but the iteration a vertex is shaded in.
+                    if (r.deferred) {
+                        hit.gid = r.d_gid; hit.u = r.d_u; hit.v = r.d_v; hit.t = 0.0f;
+                        found = true;
+                        r.has_ray = true;
+                        r.deferred = false;
+                    } else if (r.has_ray && found && (iteration & q.defer_metal)) {
+                        const uint32_t mat = f2u(sc.shade[(size_t)hit.gid * SHADE_ROWS + 6].y);
+                        if (sc.materials[mat].flags & MF_EVAL_METAL) {
+                            r.d_gid = hit.gid; r.d_u = hit.u; r.d_v = hit.v;
+                            r.deferred = true;
+                            r.has_ray = false;  // path_step resolves the shadow ray and finishes the previous sample, no more
+                        }
+                    }
+                }
             }
             path_step<FD ? 1 : 0, TEX, PMJ>(q, r, hit, found, occluded, pix, sx, sy);
         }
@@ -249,14 +272,16 @@ hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream) {
     size_t lds;
     const PtParams q = with_tex_slots(p, (bvh ? kBvhStackDepth * 256 * 4 : 0) + p.stage_total, lds);
     const bool stage = p.stage_total != 0;
-#define AKR_LAUNCH2(B, F, T, S)                                                                                        \
+#define AKR_LAUNCH2(B, F, T, S, D)                                                                                       \
     {                                                                                                                  \
-        if (p.sampler) hipLaunchKernelGGL((k_pt_pass<B, F, T, true, S>), dim3(blocks), dim3(256), lds, stream, q);      \
-        else hipLaunchKernelGGL((k_pt_pass<B, F, T, false, S>), dim3(blocks), dim3(256), lds, stream, q);              \
+        if (p.sampler) hipLaunchKernelGGL((k_pt_pass<B, F, T, true, S, D>), dim3(blocks), dim3(256), lds, stream, q);   \
+        else hipLaunchKernelGGL((k_pt_pass<B, F, T, false, S, D>), dim3(blocks), dim3(256), lds, stream, q);           \
     }
 #define AKR_LAUNCH(B, F, T)                                                  \
     {                                                                        \
-        if (!B || stage) AKR_LAUNCH2(B, F, T, true) else AKR_LAUNCH2(B, F, T, !B) \
+        if (!B && !F && p.defer_metal) AKR_LAUNCH2(false, false, T, true, true)   \
+        else if (!B || stage) AKR_LAUNCH2(B, F, T, true, false)                  \
+        else AKR_LAUNCH2(B, F, T, !B, false)                                     \
     }
     if (bvh) {
         if (tex) { if (fd) AKR_LAUNCH(true, true, true) else AKR_LAUNCH(true, false, true) }

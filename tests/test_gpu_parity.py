@@ -274,3 +274,14 @@ def test_bvh_balanced_fallback_builder(ctx, monkeypatch):
     sd = grid_scene(n=24, width=96, height=64, with_normals=True)
     g, o, gst, ost, _, _ = render_both(ctx, sd, make_config(spp=8, spp_per_pass=8, max_depth=6))
     assert_parity(g, o, 96, 64, gst, ost)
+
+
+@pytest.mark.parametrize("mask", ["0", "1", "3"])
+def test_conductor_hits_shaded_on_even_iterations_only(ctx, cbox_path, monkeypatch, mask):
+    """pt_kernels.hip (DEFER): in a scene with one metal among diffuse surfaces a hit on the metal is kept for one iteration
+    when it arrives on an odd one. Per lane only the iteration changes, so the film and the sampler states stay bit-identical
+    to the oracle whatever the period (mask 0 = the plain kernel, 1 = the shipped period, 3 = three iterations in four)."""
+    monkeypatch.setenv("AKR_PT_DEFER_METAL", mask)
+    sd = scene_json.load_scene(cbox_path, 96, 96)
+    g, o, gst, ost, _, _ = render_both(ctx, sd, make_config(spp=8, spp_per_pass=4, max_depth=7))
+    assert_parity(g, o, 96, 96, gst, ost)
