@@ -507,13 +507,11 @@ AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found,
             };  // shade_vertex
             const DMaterial& folded = sc.materials[si.material];
             if (TEX) {
-                if (folded.flags & MF_TEXTURED) {
-                    DMaterial mat_here = folded;
-                    material_at(sc.tex, si.material, si.uv, mat_here);
-                    shade_vertex(mat_here);
-                } else {
-                    shade_vertex(folded);
-                }
+                // ONE pass over the shading code for the lanes on textured and on constant materials alike (two call sites
+                // would be two copies of it, run one after the other by every wave that holds both kinds of lane)
+                DMaterial mat_here = folded;
+                material_at(sc.tex, si.material, si.uv, mat_here);
+                shade_vertex(mat_here);
             } else {
                 shade_vertex(folded);
             }

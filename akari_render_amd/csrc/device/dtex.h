@@ -15,6 +15,10 @@
 
 namespace akr {
 
+#ifndef AKR_TEX_FAST_UNORM
+#define AKR_TEX_FAST_UNORM 1
+#endif
+
 // ---- images ------------------------------------------------------------------------------------------------------
 enum : uint32_t { IMG_RGBA8 = 0, IMG_RGBA32F = 1 };
 enum : uint32_t { TEXF_NEAREST = 0, TEXF_LINEAR = 1 };
@@ -53,14 +57,25 @@ AKR_HD bool tex_wrap(int& i, int n, uint32_t mode) {
     }
     return true;
 }
+// byte / 255 correctly rounded. Device: q = b y, r = b - 255 q (exact in an fma), q + r y with y = RN(1 / 255) -- the
+// division algorithm with a reciprocal known in advance, three operations instead of the eleven of an IEEE division and the
+// same bits for all 256 bytes (tests/test_textures.py checks the identity exhaustively; four taps x four channels per lookup).
+AKR_HD float unorm8(uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__) && AKR_TEX_FAST_UNORM
+    const float y = 0.003921568859368563f, fb = (float)b;
+    const float q = fb * y;
+    return __builtin_fmaf(__builtin_fmaf(-255.0f, q, fb), y, q);
+#else
+    return (float)b / 255.0f;
+#endif
+}
 AKR_HD TexVal tex_fetch(const uint32_t* __restrict__ texels, const DImage& im, int i, int j) {
     if (!tex_wrap(i, (int)im.width, im.address) || !tex_wrap(j, (int)im.height, im.address)) return tv(0, 0, 0, 0);
     const uint64_t base = ((uint64_t)im.offset_hi << 32) | im.offset_lo;
     const uint64_t t = (uint64_t)j * im.width + (uint64_t)i;
     if (im.format == IMG_RGBA8) {
         uint32_t p = texels[base + t];
-        return tv((float)(p & 0xffu) / 255.0f, (float)((p >> 8) & 0xffu) / 255.0f, (float)((p >> 16) & 0xffu) / 255.0f,
-                  (float)(p >> 24) / 255.0f);
+        return tv(unorm8(p & 0xffu), unorm8((p >> 8) & 0xffu), unorm8((p >> 16) & 0xffu), unorm8(p >> 24));
     }
     const uint32_t* q = texels + base + 4 * t;
     return tv(u2f(q[0]), u2f(q[1]), u2f(q[2]), u2f(q[3]));
@@ -262,6 +277,9 @@ AKR_HD TexSlots tex_slots(const TexScene& ts) {
     return st;
 }
 // The pruned, slot-allocated node list of a material at `uv`: every node's value into its slot, the inputs it feeds into `in`.
+// (Tried and dropped: letting the lanes of a wave vote so that those whose next node is an image lookup wait for each other
+// and sample together -- the lookup code then runs once per evaluation instead of once per loop position that holds one, but
+// the extra trips cost more: 698 against 750 Msamples/s on the textured room, +1 % on its BVH variant.)
 AKR_HD void eval_material_graph(const TexScene& ts, uint32_t first, uint32_t count, vec2 uv, MatInputs& in) {
     TexSlots st = tex_slots(ts);
     for (uint32_t i = 0; i < count; i++) {

@@ -24,11 +24,19 @@ namespace akr {
 #ifndef AKR_PT_MIN_WAVES_FD
 #define AKR_PT_MIN_WAVES_FD 4  // force_diffuse specialisation of the exhaustive kernel
 #endif
+#ifndef AKR_PT_MIN_WAVES_TEX
+#define AKR_PT_MIN_WAVES_TEX 3      // exhaustive full-graph kernel of a scene with texture-fed materials: 168 VGPRs hold the
+                                    // re-folded material of the hit (264 -> 96 bytes of scratch), 642 -> 750 Msamples/s
+#endif
+#ifndef AKR_PT_MIN_WAVES_BVH_TEX
+#define AKR_PT_MIN_WAVES_BVH_TEX 3  // BVH kernels of such a scene (399 -> 517)
+#endif
 #ifndef AKR_PT_MERGED_RAYS
 #define AKR_PT_MERGED_RAYS 1  // BVH path: a lane starts its shadow ray the moment its closest-hit ray is done (one loop)
 #endif
 template <bool BVH, bool FD, bool TEX, bool PMJ, bool STAGE, bool DEFER>
-__global__ __launch_bounds__(256, BVH ? AKR_PT_MIN_WAVES_BVH : (FD ? AKR_PT_MIN_WAVES_FD : AKR_PT_MIN_WAVES)) void k_pt_pass(const PtParams p) {
+__global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT_MIN_WAVES_BVH)
+                                   : (FD ? AKR_PT_MIN_WAVES_FD : (TEX ? AKR_PT_MIN_WAVES_TEX : AKR_PT_MIN_WAVES))) void k_pt_pass(const PtParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: kBvhStackDepth x 256 words; else: staged tables
     TraceCtx tc;
     tc.stack = lds_stack + threadIdx.x;

@@ -73,3 +73,22 @@ def test_textured_scene_through_the_json_loader(ctx, root, tmp_path):
     gst = capi.pt_render(ctx, scene, cfg, film)
     o, ost = pyoracle.OracleScene(sd).render(cfg)
     assert_parity(film.read(), o, 40, 30, gst, ost)
+
+
+def test_every_byte_value_decodes_like_a_division_by_255(ctx):
+    """dtex.h unorm8: the device decodes RGBA8 texels with q = b y, q + (b - 255 q) y (two fma) instead of an IEEE division;
+    a 256 x 1 nearest-filtered image holding every byte value, looked up at every texel centre, against the oracle's b / 255."""
+    sd = textured_room()
+    ramp = np.zeros((1, 256, 4), dtype=np.uint8)
+    ramp[0, :, 0] = np.arange(256)
+    ramp[0, :, 1] = np.arange(256)[::-1]
+    ramp[0, :, 2] = (np.arange(256) * 7 + 3) % 256
+    ramp[0, :, 3] = 255
+    sd.images[2] = abi.ImageData(ramp, abi.TEX_FILTER_NEAREST, abi.TEX_EXTEND)  # the emitter's image
+    scene = capi.Scene(ctx, sd)
+    osc = pyoracle.OracleScene(sd)
+    uv = np.stack([(np.arange(256, dtype=np.float32) + 0.5) / 256.0, np.full(256, 0.5, np.float32)], axis=1).astype(np.float32)
+    d = capi.probe_material_inputs(ctx, scene, 6, uv)
+    o = osc.material_inputs(6, uv)
+    assert n_bit_diff(d, o) == 0
+    assert np.array_equal(d[:, 19], np.arange(256, dtype=np.float32) / np.float32(255.0))  # emission colour, red

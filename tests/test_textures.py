@@ -498,3 +498,22 @@ def test_scene_loader_reads_exr_textures(tmp_path):
     b = [im.texels for im in pyl.images if im.texels.shape[:2] == (6, 5)][0]
     assert a.dtype == np.float32 and n_bit_diff(a, b) == 0
     assert np.array_equal(a[::-1, :, 0], planes["R"].astype(np.float32))  # flipped vertically
+
+
+def test_unorm8_reciprocal_form_is_a_correctly_rounded_division():
+    """dtex.h unorm8 (device): with y = RN(1 / 255), q = RN(b y), r = b - 255 q (exact), RN(q + r y) == RN(b / 255) for every
+    byte -- checked in exact rational arithmetic."""
+    from fractions import Fraction
+
+    def rn32(fr):
+        f = np.float32(float(fr))
+        cands = [f, np.nextafter(f, np.float32(np.inf)), np.nextafter(f, np.float32(-np.inf))]
+        return Fraction(float(min(cands, key=lambda c: (abs(Fraction(float(c)) - fr), int(np.float32(c).view(np.uint32)) & 1))))
+
+    y = rn32(Fraction(1, 255))
+    assert float(y) == float(np.float32(0.003921568859368563))
+    for b in range(256):
+        q = rn32(Fraction(b) * y)
+        r = Fraction(b) - 255 * q
+        assert rn32(r) == r
+        assert float(rn32(q + r * y)) == float(np.float32(b) / np.float32(255.0)), b

@@ -8,7 +8,7 @@ from akari_render_amd import abi, capi
 from tests.helpers import textured_room
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-n_floor = int(sys.argv[2]) if len(sys.argv) > 2 else 1   # > 1 tessellates the floor: the scene then takes the BVH path
+n_floor = int(sys.argv[2]) if len(sys.argv) > 2 else int(os.environ.get("TEXBENCH_NFLOOR", "1"))   # > 1 tessellates the floor: the scene then takes the BVH path
 rng = np.random.default_rng(0)
 sd = textured_room(1920, 1080, n_floor=n_floor)
 big8 = rng.integers(0, 256, size=(4096, 4096, 4), dtype=np.uint8); big8[:, :, 3] = 255
@@ -18,14 +18,27 @@ sd.images[1] = abi.ImageData(bigf, abi.TEX_FILTER_LINEAR, abi.TEX_MIRROR)
 sd.ggx_table = np.fromfile(os.path.join(ROOT, "tests/golden/ggx_dielectric_s.f32"), dtype=np.float32)
 ctx = capi.Context(0)
 out = {}
-for name, variant in (("textured", sd), ("same room, constant materials", None)):
-    if variant is None:
-        variant = textured_room(1920, 1080, n_floor=n_floor)
-        for m in variant.materials:
-            m.graph = None
-        variant.materials[6].emission_color = (6.0, 6.0, 6.0)
-        variant.images = []
-        variant.ggx_table = sd.ggx_table
+def constant_room(lobes_of_the_textured_room):
+    v = textured_room(1920, 1080, n_floor=n_floor)
+    for m in v.materials:
+        m.graph = None
+    if lobes_of_the_textured_room:  # what the graphs feed, as constants: the same lobes run, no graph is evaluated
+        v.materials[0].metallic, v.materials[0].roughness = 0.25, 0.5
+    v.materials[6].emission_color = (6.0, 6.0, 6.0)
+    v.images = []
+    v.ggx_table = sd.ggx_table
+    return v
+
+small = textured_room(1920, 1080, n_floor=n_floor)  # the 16x24 / 8x8 images of the tests: texel gathers hit in cache
+small.ggx_table = sd.ggx_table
+variants = [("textured", sd, None), ("textured, conductor deferral off", sd, "0"), ("textured, small images", small, None),
+            ("same room, constant materials with the lobes the graphs select", constant_room(True), None),
+            ("same room, constant materials", constant_room(False), None)]
+only = os.environ.get("TEXBENCH_ONLY")  # substring of the variant's name
+for name, variant, defer in variants:
+    if only and only != name: continue
+    if defer is None: os.environ.pop("AKR_PT_DEFER_METAL", None)
+    else: os.environ["AKR_PT_DEFER_METAL"] = defer
     scene = capi.Scene(ctx, variant)
     film = capi.Film(ctx, 1920, 1080)
     cfg = abi.PtConfig.default(); cfg.spp = 64 * (steps + 1); cfg.spp_per_pass = 64; cfg.max_depth = 12
