@@ -69,16 +69,55 @@ AKR_HD float unorm8(uint32_t b) {
     return (float)b / 255.0f;
 #endif
 }
-AKR_HD TexVal tex_fetch(const uint32_t* __restrict__ texels, const DImage& im, int i, int j) {
-    if (!tex_wrap(i, (int)im.width, im.address) || !tex_wrap(j, (int)im.height, im.address)) return tv(0, 0, 0, 0);
+// The taps of one lookup, together: the address modes are applied to the two columns and the two rows once, the texel format
+// is decided once, and the (up to four) loads are issued back to back before anything is decoded -- one memory round trip per
+// lookup. (Fetching tap by tap, each behind its own address-mode and format branches, made them four dependent round trips:
+// the bilinear filter cost 15 % of the textured room's run time.) A tap outside a clip-addressed image reads texel (0, 0) and is
+// zeroed afterwards.
+struct TexTaps {
+    TexVal a, b, c, d;  // (i, j), (i + 1, j), (i, j + 1), (i + 1, j + 1)
+};
+AKR_HD TexVal tex_decode8(uint32_t p) { return tv(unorm8(p & 0xffu), unorm8((p >> 8) & 0xffu), unorm8((p >> 16) & 0xffu), unorm8(p >> 24)); }
+AKR_HD TexVal tex_decode32f(const uint32_t* __restrict__ q) { return tv(u2f(q[0]), u2f(q[1]), u2f(q[2]), u2f(q[3])); }
+template <bool FOUR>
+AKR_HD TexTaps tex_fetch_taps(const uint32_t* __restrict__ texels, const DImage& im, int i, int j) {
+    int i0 = i, i1 = i + 1, j0 = j, j1 = j + 1;
+    const int w = (int)im.width, h = (int)im.height;
+    const bool vi0 = tex_wrap(i0, w, im.address), vj0 = tex_wrap(j0, h, im.address);
+    const bool vi1 = FOUR ? tex_wrap(i1, w, im.address) : false, vj1 = FOUR ? tex_wrap(j1, h, im.address) : false;
+    if (!vi0) i0 = 0;
+    if (!vi1) i1 = 0;
+    if (!vj0) j0 = 0;
+    if (!vj1) j1 = 0;
     const uint64_t base = ((uint64_t)im.offset_hi << 32) | im.offset_lo;
-    const uint64_t t = (uint64_t)j * im.width + (uint64_t)i;
+    const uint64_t r0 = (uint64_t)j0 * im.width, r1 = (uint64_t)j1 * im.width;
+    const TexVal zero = tv(0, 0, 0, 0);
+    TexTaps t;
+    t.b = t.c = t.d = zero;
     if (im.format == IMG_RGBA8) {
-        uint32_t p = texels[base + t];
-        return tv(unorm8(p & 0xffu), unorm8((p >> 8) & 0xffu), unorm8((p >> 16) & 0xffu), unorm8(p >> 24));
+        const uint32_t* q = texels + base;
+        const uint32_t pa = q[r0 + (uint64_t)i0];
+        uint32_t pb = 0, pc = 0, pd = 0;
+        if (FOUR) { pb = q[r0 + (uint64_t)i1]; pc = q[r1 + (uint64_t)i0]; pd = q[r1 + (uint64_t)i1]; }
+        t.a = tex_decode8(pa);
+        if (FOUR) { t.b = tex_decode8(pb); t.c = tex_decode8(pc); t.d = tex_decode8(pd); }
+    } else {
+        const uint32_t* q = texels + base;
+        const uint32_t* qa = q + 4 * (r0 + (uint64_t)i0);
+        t.a = tex_decode32f(qa);
+        if (FOUR) {
+            t.b = tex_decode32f(q + 4 * (r0 + (uint64_t)i1));
+            t.c = tex_decode32f(q + 4 * (r1 + (uint64_t)i0));
+            t.d = tex_decode32f(q + 4 * (r1 + (uint64_t)i1));
+        }
     }
-    const uint32_t* q = texels + base + 4 * t;
-    return tv(u2f(q[0]), u2f(q[1]), u2f(q[2]), u2f(q[3]));
+    if (!(vi0 && vj0)) t.a = zero;
+    if (FOUR) {
+        if (!(vi1 && vj0)) t.b = zero;
+        if (!(vi0 && vj1)) t.c = zero;
+        if (!(vi1 && vj1)) t.d = zero;
+    }
+    return t;
 }
 AKR_HD int tex_floor_to_int(float x, float& fl) {
     if (!(x > -1.0e9f)) x = -1.0e9f;  // also NaN
@@ -92,7 +131,7 @@ AKR_HD TexVal tex_sample(const uint32_t* __restrict__ texels, const DImage& im, 
     float fx, fy;
     if (im.filter == TEXF_NEAREST) {
         int i = tex_floor_to_int(x, fx), j = tex_floor_to_int(y, fy);
-        return tex_fetch(texels, im, i, j);
+        return tex_fetch_taps<false>(texels, im, i, j).a;
     }
     x = x - 0.5f;
     y = y - 0.5f;
@@ -102,8 +141,8 @@ AKR_HD TexVal tex_sample(const uint32_t* __restrict__ texels, const DImage& im, 
     if (!(ty >= 0.0f)) ty = 0.0f;
     if (tx > 1.0f) tx = 1.0f;
     if (ty > 1.0f) ty = 1.0f;
-    TexVal a = tex_fetch(texels, im, i, j), b = tex_fetch(texels, im, i + 1, j);
-    TexVal c = tex_fetch(texels, im, i, j + 1), d = tex_fetch(texels, im, i + 1, j + 1);
+    const TexTaps t = tex_fetch_taps<true>(texels, im, i, j);
+    const TexVal &a = t.a, &b = t.b, &c = t.c, &d = t.d;
     TexVal r0 = tv(tex_lerp(a.x, b.x, tx), tex_lerp(a.y, b.y, tx), tex_lerp(a.z, b.z, tx), tex_lerp(a.w, b.w, tx));
     TexVal r1 = tv(tex_lerp(c.x, d.x, tx), tex_lerp(c.y, d.y, tx), tex_lerp(c.z, d.z, tx), tex_lerp(c.w, d.w, tx));
     return tv(tex_lerp(r0.x, r1.x, ty), tex_lerp(r0.y, r1.y, ty), tex_lerp(r0.z, r1.z, ty), tex_lerp(r0.w, r1.w, ty));

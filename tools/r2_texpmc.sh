@@ -1,4 +1,6 @@
 #!/bin/bash
+# PMC passes over tools/textured_bench.py's room (textured, and the same room with constant materials that select the same
+# lobes): one --pmc set per rocprofv3 run, kernel-trace only; summary -> gpurun_out/texpmc/summary.json (-> profiles/r2_pmc_textured_room.json)
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/texpmc; rm -rf $OUT; mkdir -p $OUT
@@ -8,18 +10,33 @@ for V in "textured" "same room, constant materials with the lobes the graphs sel
   for SET in \
     "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
     "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA" \
-    "GRBM_GUI_ACTIVE" "SQ_INSTS_FLAT SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" ; do
+    "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" ; do
     i=$((i+1))
-    TEXBENCH_ONLY="$V" timeout 300 rocprofv3 --kernel-trace --pmc $SET -f csv -d $OUT -o ${tag}_set$i -- python tools/textured_bench.py 1 > $OUT/${tag}_set$i.out 2> $OUT/${tag}_set$i.err
+    TEXBENCH_ONLY="$V" timeout 300 rocprofv3 --kernel-trace --pmc $SET -f csv -d $OUT -o ${tag}_set$i -- python tools/textured_bench.py 3 > $OUT/${tag}_set$i.out 2> $OUT/${tag}_set$i.err
     echo "$tag set$i rc=$?"
   done
 done
 python - <<PY
 import csv, glob, collections, json
-for tag in ("text", "same"):
-    res = collections.defaultdict(float)
+out = {}
+for tag, name in (("text", "textured"), ("same", "same room, constant materials with the lobes the graphs select")):
+    res = collections.defaultdict(float); kernel = None
     for f in sorted(glob.glob("$OUT/**/%s_set*counter_collection.csv" % tag, recursive=True)):
         for row in csv.DictReader(open(f)):
-            if "k_pt_pass" in row["Kernel_Name"]: res[row["Counter_Name"]] += float(row["Counter_Value"])
-    print(tag, json.dumps(dict(res)))
+            if "k_pt_pass" in row["Kernel_Name"]:
+                res[row["Counter_Name"]] += float(row["Counter_Value"]); kernel = row["Kernel_Name"].split("(")[0]
+    b = json.loads(open("$OUT/%s_set1.out" % tag).read().strip().splitlines()[-1])[name]
+    c = dict(res)
+    samples = 4 * 64 * 1920 * 1080   # the warm-up pass + 3 timed passes of 64 spp, both launches counted
+    xcd = c["GRBM_GUI_ACTIVE"] / 8.0
+    hbm = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    out[name] = {"kernel": kernel, "msamples_per_s_under_profiler": b["msamples_per_s"], "shaded_per_sample": b["shaded_per_sample"],
+                 "wait_share": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], "valu_busy": c["SQ_INSTS_VALU"] * 2.0 / (1024.0 * xcd),
+                 "valu_lane_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]),
+                 "valu_insts_per_sample": c["SQ_INSTS_VALU"] * 64 / samples / 64, "vmem_insts_per_sample_x64": c["SQ_INSTS_VMEM"] * 64 / samples,
+                 "hbm_bytes_per_sample": hbm / samples, "l2_hit": c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"]),
+                 "counters": c}
+out["source"] = "tools/r2_texpmc.sh: rocprofv3 --kernel-trace --pmc <one set per pass> -- python tools/textured_bench.py 3 (TEXBENCH_ONLY=<variant>); 1920x1080, 4 passes of 64 spp; hbm = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; valu_busy = SQ_INSTS_VALU x 2 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)"
+json.dump(out, open("$OUT/summary.json", "w"), indent=1)
+print(json.dumps({k: ({kk: vv for kk, vv in v.items() if kk != "counters"} if isinstance(v, dict) else v) for k, v in out.items()}, indent=1))
 PY
