@@ -18,6 +18,7 @@ SOURCES = [
     "host/scene_json.cpp",
     "host/bvh.cpp",
     "host/image_io.cpp",
+    "host/image_formats.cpp",
     "host/pmj_tables.cpp",
     "host/comm.cpp",
 ]

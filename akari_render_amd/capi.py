@@ -37,7 +37,7 @@ EXPORTS = [
     "akr_probe_material_inputs_host", "akr_comm_unique_id", "akr_comm_create", "akr_comm_wrap", "akr_comm_destroy", "akr_film_reduce",
     "akr_host_stdrng_u64", "akr_host_chacha_block", "akr_host_pcg32_states", "akr_host_pcg_start", "akr_host_alias_table",
     "akr_probe_math", "akr_probe_bsdf", "akr_probe_intersect", "akr_probe_surface_interaction", "akr_probe_material_inputs",
-    "akr_host_decode_png", "akr_host_decode_jpeg", "akr_host_decode_exr", "akr_host_pmj02bn_tables",
+    "akr_host_decode_png", "akr_host_decode_jpeg", "akr_host_decode_exr", "akr_host_decode_tiff", "akr_host_decode_dds", "akr_host_pmj02bn_tables",
 ]
 
 
@@ -143,6 +143,8 @@ def lib() -> C.CDLL:
     proto("akr_host_decode_png", C.c_char_p, u64, up, up, C.POINTER(C.c_uint8), u64)
     proto("akr_host_decode_jpeg", C.c_char_p, u64, up, up, C.POINTER(C.c_uint8), u64)
     proto("akr_host_decode_exr", C.c_char_p, u64, up, up, fp, u64)
+    proto("akr_host_decode_tiff", C.c_char_p, u64, up, up, C.POINTER(C.c_uint8), u64)
+    proto("akr_host_decode_dds", C.c_char_p, u64, up, up, C.POINTER(C.c_uint8), u64)
     proto("akr_host_pmj02bn_tables", up, C.POINTER(C.c_uint16))
     _lib = L
     return L
@@ -575,6 +577,16 @@ def host_decode_png(data: bytes) -> np.ndarray:
 def host_decode_jpeg(data: bytes) -> np.ndarray:
     """JPEG -> (H, W, 4) uint8 in file order."""
     return _host_decode(lib().akr_host_decode_jpeg, data)
+
+
+def host_decode_tiff(data: bytes) -> np.ndarray:
+    """TIFF -> (H, W, 4) uint8 in file order."""
+    return _host_decode(lib().akr_host_decode_tiff, data)
+
+
+def host_decode_dds(data: bytes) -> np.ndarray:
+    """DDS (DXT1 / DXT3 / DXT5) -> (H, W, 4) uint8 in file order."""
+    return _host_decode(lib().akr_host_decode_dds, data)
 
 
 def aov_render(ctx: Context, scene: Scene, cfg: abi.AovConfig, film: Film) -> dict:

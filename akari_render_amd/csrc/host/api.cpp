@@ -1573,6 +1573,28 @@ AKR_API int32_t akr_host_decode_jpeg(const uint8_t* data, uint64_t len, uint32_t
         }
     });
 }
+AKR_API int32_t akr_host_decode_tiff(const uint8_t* data, uint64_t len, uint32_t* width, uint32_t* height, uint8_t* rgba, uint64_t capacity) {
+    if (!data || !width || !height) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_host_decode_tiff: NULL argument");
+    return guarded([&] {
+        std::vector<uint8_t> px;
+        decode_tiff(data, (size_t)len, *width, *height, px);
+        if (rgba) {
+            if (capacity < px.size()) throw std::invalid_argument("akr_host_decode_tiff: output buffer too small");
+            std::memcpy(rgba, px.data(), px.size());
+        }
+    });
+}
+AKR_API int32_t akr_host_decode_dds(const uint8_t* data, uint64_t len, uint32_t* width, uint32_t* height, uint8_t* rgba, uint64_t capacity) {
+    if (!data || !width || !height) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_host_decode_dds: NULL argument");
+    return guarded([&] {
+        std::vector<uint8_t> px;
+        decode_dds(data, (size_t)len, *width, *height, px);
+        if (rgba) {
+            if (capacity < px.size()) throw std::invalid_argument("akr_host_decode_dds: output buffer too small");
+            std::memcpy(rgba, px.data(), px.size());
+        }
+    });
+}
 AKR_API int32_t akr_host_decode_exr(const uint8_t* data, uint64_t len, uint32_t* width, uint32_t* height, float* rgba, uint64_t capacity_floats) {
     if (!data || !width || !height) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_host_decode_exr: NULL argument");
     return guarded([&] {

@@ -315,6 +315,8 @@ int paeth(int a, int b, int c) {
 }
 }  // namespace
 
+std::vector<uint8_t> inflate_zlib_stream(const uint8_t* data, size_t n) { return inflate_zlib(data, n); }  // for image_formats.cpp
+
 void decode_png(const uint8_t* data, size_t n, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba) {
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     if (n < 8 || std::memcmp(data, sig, 8) != 0) throw std::runtime_error("png: bad signature");

@@ -118,5 +118,10 @@ void decode_png(const uint8_t* data, size_t n, uint32_t& w, uint32_t& h, std::ve
 void decode_jpeg(const uint8_t* data, size_t n, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba);
 // OpenEXR (single-part scanline; none / RLE / ZIPS / ZIP; half / float / uint channels) -> RGBA f32 in file order
 void decode_exr(const uint8_t* data, size_t n, uint32_t& w, uint32_t& h, std::vector<float>& rgba);
+// TIFF (classic; strips / tiles; 8 / 16-bit and float samples; none / LZW / deflate / PackBits; predictor) and DDS (DXT1 / 3 / 5)
+// -> RGBA8 in file order (host/image_formats.cpp)
+void decode_tiff(const uint8_t* data, size_t n, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba);
+void decode_dds(const uint8_t* data, size_t n, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba);
+std::vector<uint8_t> inflate_zlib_stream(const uint8_t* data, size_t n);  // the PNG reader's inflate (zlib framing)
 
 }  // namespace akr

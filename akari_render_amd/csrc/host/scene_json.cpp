@@ -277,10 +277,12 @@ struct GraphBuilder {
             hi.words.resize((size_t)pw * ph);
             for (uint32_t y = 0; y < ph; y++)  // flipv (load.rs:596): row 0 of the texture is the bottom row of the file
                 std::memcpy(hi.words.data() + (size_t)y * pw, px.data() + 4ull * pw * (ph - 1 - y), 4ull * pw);
-        } else if (fmt == "jpeg") {
+        } else if (fmt == "jpeg" || fmt == "tiff" || fmt == "dds") {
             uint32_t pw = 0, ph = 0;
             std::vector<uint8_t> px;
-            decode_jpeg(bytes.data(), bytes.size(), pw, ph, px);
+            if (fmt == "jpeg") decode_jpeg(bytes.data(), bytes.size(), pw, ph, px);
+            else if (fmt == "tiff") decode_tiff(bytes.data(), bytes.size(), pw, ph, px);
+            else decode_dds(bytes.data(), bytes.size(), pw, ph, px);
             hi.width = pw; hi.height = ph; hi.format = AKR_IMAGE_RGBA8;
             hi.words.resize((size_t)pw * ph);
             for (uint32_t y = 0; y < ph; y++) std::memcpy(hi.words.data() + (size_t)y * pw, px.data() + 4ull * pw * (ph - 1 - y), 4ull * pw);
@@ -292,7 +294,7 @@ struct GraphBuilder {
             hi.words.resize(4ull * pw * ph);
             for (uint32_t y = 0; y < ph; y++) std::memcpy(hi.words.data() + 4ull * pw * y, px.data() + 4ull * pw * (ph - 1 - y), 16ull * pw);
         } else {
-            throw std::runtime_error("unsupported: image format '" + fmt + "' (decode it on the host and pass texels through akr_image_desc; float, png, jpeg and exr are read here)");
+            throw std::runtime_error("unsupported: image format '" + fmt + "' (float, png, jpeg, tiff, exr and dds are read here: load.rs:585-592)");
         }
         uint32_t idx = (uint32_t)flat.images.size();
         flat.images.push_back(std::move(hi));

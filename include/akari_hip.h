@@ -529,6 +529,11 @@ AKR_API int32_t akr_host_decode_png(const uint8_t *data, uint64_t len, uint32_t 
 /* The JPEG reader of akr_scene_load (baseline + progressive Huffman, 8 bit, grey / YCbCr / RGB, any integer sampling
  * ratios, restart intervals). Same calling convention as akr_host_decode_png. */
 AKR_API int32_t akr_host_decode_jpeg(const uint8_t *data, uint64_t len, uint32_t *width, uint32_t *height, uint8_t *rgba, uint64_t capacity);
+/* The TIFF reader of akr_scene_load (classic TIFF, first image; strips or tiles; chunky 8 / 16-bit or float samples; grey,
+ * grey + alpha, RGB, RGBA; none / LZW / deflate / PackBits; horizontal predictor) and the DDS reader (DXT1 / DXT3 / DXT5, top
+ * mip level) -- the remaining two encoded formats of load.rs:585-592. Same calling convention as akr_host_decode_png. */
+AKR_API int32_t akr_host_decode_tiff(const uint8_t *data, uint64_t len, uint32_t *width, uint32_t *height, uint8_t *rgba, uint64_t capacity);
+AKR_API int32_t akr_host_decode_dds(const uint8_t *data, uint64_t len, uint32_t *width, uint32_t *height, uint8_t *rgba, uint64_t capacity);
 /* The OpenEXR reader of akr_scene_load (single-part scanline; none / RLE / ZIPS / ZIP; half / float / uint channels R G B A
  * or Y), RGBA f32 out, rows in file order. rgba == NULL: only the size is returned. */
 AKR_API int32_t akr_host_decode_exr(const uint8_t *data, uint64_t len, uint32_t *width, uint32_t *height, float *rgba, uint64_t capacity_floats);

@@ -233,6 +233,90 @@ def decode_png(data: bytes) -> np.ndarray:
     return out
 
 
+def decode_tiff_pil(data: bytes) -> np.ndarray:
+    """TIFF -> (H, W, 4) uint8 through Pillow / libtiff (an independent decoder), with the image crate's `to_rgba8` rules applied
+    to what it returns: grey replicated, alpha 255 when absent, 16-bit samples (v + 128) // 257."""
+    import io
+
+    from PIL import Image
+
+    im = Image.open(io.BytesIO(data))
+    a = np.asarray(im)
+    if a.dtype == np.uint16:
+        a = ((a.astype(np.uint32) + 128) // 257).astype(np.uint8)
+    elif a.dtype != np.uint8:
+        raise NotImplementedError(f"tiff sample type {a.dtype}")
+    if a.ndim == 2:
+        a = a[:, :, None]
+    h, w, c = a.shape
+    out = np.full((h, w, 4), 255, dtype=np.uint8)
+    if c <= 2:
+        out[:, :, :3] = a[:, :, :1]
+        if c == 2:
+            out[:, :, 3] = a[:, :, 1]
+    else:
+        out[:, :, :c] = a
+    return out
+
+
+def decode_dds(data: bytes) -> np.ndarray:
+    """DDS with DXT1 / DXT3 / DXT5 blocks -> (H, W, 4) uint8, the integer rules of the image crate's decoder (image 0.24
+    src/codecs/dxt.rs: 565 channels c * 255 // 31 (63); (2a + b + 1) // 3; DXT1 3-colour mode (a + b + 1) // 2 and black, alpha
+    255; DXT5 alpha ((8 - i) a0 + (i - 1) a1) // 7 or ((6 - i) a0 + (i - 1) a1) // 5, 0, 255; DXT3 nibble * 17)."""
+    import struct
+
+    if data[:4] != b"DDS " or struct.unpack_from("<I", data, 4)[0] != 124:
+        raise ValueError("not a DDS file")
+    h, w = struct.unpack_from("<II", data, 12)
+    fourcc = data[84:88]
+    at = 128
+    if fourcc == b"DX10":
+        dxgi = struct.unpack_from("<I", data, 128)[0]
+        at = 148
+        kind = {70: 1, 71: 1, 72: 1, 73: 3, 74: 3, 75: 3, 76: 5, 77: 5, 78: 5}[dxgi]
+    else:
+        kind = {b"DXT1": 1, b"DXT3": 3, b"DXT5": 5}[fourcc]
+    bw, bh = (w + 3) // 4, (h + 3) // 4
+    out = np.full((bh * 4, bw * 4, 4), 255, dtype=np.uint8)
+    size = 8 if kind == 1 else 16
+
+    def colours(s, dxt1):
+        c0, c1, table = struct.unpack_from("<HHI", s, 0)
+        dec = lambda v: [((v >> 11) & 31) * 255 // 31, ((v >> 5) & 63) * 255 // 63, (v & 31) * 255 // 31]  # noqa: E731
+        col = [dec(c0), dec(c1), [0, 0, 0], [0, 0, 0]]
+        if c0 > c1 or not dxt1:
+            col[2] = [(2 * a + b + 1) // 3 for a, b in zip(col[0], col[1])]
+            col[3] = [(a + 2 * b + 1) // 3 for a, b in zip(col[0], col[1])]
+        else:
+            col[2] = [(a + b + 1) // 2 for a, b in zip(col[0], col[1])]
+        return [col[(table >> (2 * i)) & 3] for i in range(16)]
+
+    for by in range(bh):
+        for bx in range(bw):
+            s = data[at + (by * bw + bx) * size: at + (by * bw + bx + 1) * size]
+            alpha = [255] * 16
+            if kind == 1:
+                rgb = colours(s, True)
+            elif kind == 3:
+                alpha = [((s[i // 2] >> (4 * (i & 1))) & 15) * 17 for i in range(16)]
+                rgb = colours(s[8:], False)
+            else:
+                a0, a1 = s[0], s[1]
+                tab = [a0, a1, 0, 0, 0, 0, 0, 255]
+                if a0 > a1:
+                    for i in range(2, 8):
+                        tab[i] = ((8 - i) * a0 + (i - 1) * a1) // 7
+                else:
+                    for i in range(2, 6):
+                        tab[i] = ((6 - i) * a0 + (i - 1) * a1) // 5
+                bits = int.from_bytes(s[2:8], "little")
+                alpha = [tab[(bits >> (3 * i)) & 7] for i in range(16)]
+                rgb = colours(s[8:], False)
+            for i in range(16):
+                out[by * 4 + i // 4, bx * 4 + i % 4] = rgb[i] + [alpha[i]]
+    return out[:h, :w].copy()
+
+
 def decode_exr(data: bytes) -> np.ndarray:
     """OpenEXR (single-part scanline, none / RLE / ZIPS / ZIP, half / float / uint channels) -> (H, W, 4) float32 in file
     order; R, G, B (a lone Y is replicated), A = 1 when absent. Independent of the C++ reader (numpy + zlib)."""
@@ -360,6 +444,10 @@ class _Graph:
             from PIL import Image  # independent decoder (libjpeg); texels may differ from the library's by a few LSB
 
             tex = np.asarray(Image.open(io.BytesIO(raw)).convert("RGBA"), dtype=np.uint8)[::-1].copy()
+        elif im["format"] == "tiff":
+            tex = decode_tiff_pil(raw)[::-1].copy()
+        elif im["format"] == "dds":
+            tex = decode_dds(raw)[::-1].copy()
         else:
             raise NotImplementedError(f"image format '{im['format']}'")
         self.images.append(abi.ImageData(tex, filt, address))

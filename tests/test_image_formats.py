@@ -1,0 +1,286 @@
+"""The TIFF and DDS readers of the scene loader (csrc/host/image_formats.cpp; load.rs:585-603 decodes them with the image crate,
+`decode().flipv().to_rgba8()`): files written by libtiff (through Pillow) and by a byte-level writer here, decoded by the library
+and compared with the arrays that went in; DXT blocks against a restatement of the crate's integer rules and, loosely, Pillow."""
+import io
+import json
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from akari_render_amd import capi
+from oracle import scene_json
+
+PIL = pytest.importorskip("PIL")
+from PIL import Image  # noqa: E402
+
+
+def to_rgba8(a):
+    """image crate `to_rgba8` of an (H, W, C) array of u8 / u16 / f32 samples, C in 1..4"""
+    if a.dtype == np.uint16:
+        a = ((a.astype(np.uint32) + 128) // 257).astype(np.uint8)
+    elif a.dtype == np.float32:
+        a = np.round(np.clip(np.nan_to_num(a, nan=0.0), 0.0, 1.0) * np.float32(255.0)).astype(np.uint8)
+    h, w, c = a.shape
+    out = np.full((h, w, 4), 255, dtype=np.uint8)
+    if c <= 2:
+        out[:, :, :3] = a[:, :, :1]
+        if c == 2:
+            out[:, :, 3] = a[:, :, 1]
+    else:
+        out[:, :, :c] = a
+    return out
+
+
+def pil_tiff(a, compression, predictor=False):
+    mode = {1: "L", 2: "LA", 3: "RGB", 4: "RGBA"}[a.shape[2]]
+    im = Image.fromarray(a[:, :, 0] if a.shape[2] == 1 else a, mode=mode if a.dtype == np.uint8 else None)
+    b = io.BytesIO()
+    kw = {"tiffinfo": {317: 2}} if predictor else {}
+    im.save(b, format="TIFF", compression=compression, **kw)
+    return b.getvalue()
+
+
+@pytest.mark.parametrize("channels", [1, 2, 3, 4])
+@pytest.mark.parametrize("compression", ["raw", "tiff_lzw", "tiff_adobe_deflate", "packbits"])
+def test_tiff_written_by_libtiff(channels, compression):
+    rng = np.random.default_rng(channels * 7 + len(compression))
+    a = rng.integers(0, 256, size=(37, 53, channels), dtype=np.uint8)
+    a[5:20, 10:40] = a[5, 10]  # runs, so that PackBits and LZW have something to compress
+    got = capi.host_decode_tiff(pil_tiff(a, compression))
+    assert np.array_equal(got, to_rgba8(a))
+
+
+@pytest.mark.parametrize("compression", ["tiff_lzw", "tiff_adobe_deflate"])
+def test_tiff_horizontal_predictor_and_long_lzw_streams(compression):
+    """A smooth 300 x 200 RGB image with predictor 2, and noise (every LZW code width up to 12 bits, table resets)."""
+    y, x = np.mgrid[0:200, 0:300]
+    smooth = np.stack([(x + y) % 256, (2 * x) % 256, (x * y // 64) % 256], axis=2).astype(np.uint8)
+    data = pil_tiff(smooth, compression, predictor=True)
+    assert struct.unpack_from("<H", data, 0)[0] == 0x4949
+    assert np.array_equal(capi.host_decode_tiff(data), to_rgba8(smooth))
+    noise = np.random.default_rng(5).integers(0, 256, size=(200, 300, 3), dtype=np.uint8)
+    assert np.array_equal(capi.host_decode_tiff(pil_tiff(noise, compression)), to_rgba8(noise))
+
+
+def test_tiff_16_bit_grey_from_libtiff():
+    a = np.random.default_rng(3).integers(0, 65536, size=(19, 23), dtype=np.uint16)
+    b = io.BytesIO()
+    Image.fromarray(a).save(b, format="TIFF", compression="tiff_lzw")
+    assert np.array_equal(capi.host_decode_tiff(b.getvalue()), to_rgba8(a[:, :, None]))
+
+
+def write_tiff(a, big=False, photometric=None, compression=1, tile=None, rows_per_strip=None, predictor=1, extra_tags=()):
+    """Byte-level classic-TIFF writer: (H, W, C) u8 / u16 / f32, strips or tiles, none / deflate / PackBits-literal."""
+    e = ">" if big else "<"
+    h, w, c = a.shape
+    bps = a.dtype.itemsize
+    native = a.astype(a.dtype.newbyteorder(e))
+    if predictor == 2:
+        d = native.astype(a.dtype).astype(np.int64)
+        d[:, 1:] = d[:, 1:] - d[:, :-1]
+        native = (d % (1 << (8 * bps))).astype(a.dtype).astype(a.dtype.newbyteorder(e))
+    chunks = []
+    if tile:
+        tw, th = tile
+        for y0 in range(0, h, th):
+            for x0 in range(0, w, tw):
+                t = np.zeros((th, tw, c), dtype=native.dtype)
+                part = native[y0:y0 + th, x0:x0 + tw]
+                if predictor == 2:  # the predictor runs over the tile's own rows
+                    src = a[y0:y0 + th, x0:x0 + tw].astype(np.int64)
+                    src[:, 1:] = src[:, 1:] - src[:, :-1]
+                    part = (src % (1 << (8 * bps))).astype(a.dtype).astype(a.dtype.newbyteorder(e))
+                t[:part.shape[0], :part.shape[1]] = part
+                chunks.append(t.tobytes())
+    else:
+        rps = rows_per_strip or h
+        for y0 in range(0, h, rps):
+            chunks.append(native[y0:y0 + rps].tobytes())
+
+    def pack(raw):
+        if compression == 8:
+            return zlib.compress(raw)
+        if compression == 32773:  # literal runs of at most 128 bytes
+            return b"".join(bytes([len(raw[i:i + 128]) - 1]) + raw[i:i + 128] for i in range(0, len(raw), 128))
+        return raw
+
+    blobs = [pack(x) for x in chunks]
+    if photometric is None:
+        photometric = 2 if c >= 3 else 1
+    tags = [(256, 4, [w]), (257, 4, [h]), (258, 3, [8 * bps] * c), (259, 3, [compression]), (262, 3, [photometric]), (277, 3, [c]),
+            (284, 3, [1]), (317, 3, [predictor]), (339, 3, [3 if a.dtype == np.float32 else 1] * c)]
+    if c in (2, 4):
+        tags.append((338, 3, [2]))
+    tags += list(extra_tags)
+    n_tags = len(tags) + (4 if tile else 3)
+    ifd_at = 8
+    data_at = ifd_at + 2 + 12 * n_tags + 4
+    extra = b""
+
+    def field(tag, typ, vals):
+        nonlocal extra
+        size = {3: 2, 4: 4}[typ] * len(vals)
+        body = b"".join(struct.pack(e + ("H" if typ == 3 else "I"), v) for v in vals)
+        if size <= 4:
+            return struct.pack(e + "HHI", tag, typ, len(vals)) + body.ljust(4, b"\0")
+        off = data_at + len(extra)
+        extra += body + (b"\0" if len(body) % 2 else b"")
+        return struct.pack(e + "HHII", tag, typ, len(vals), off)
+
+    # offsets of the chunks are known only after the out-of-line field data: lay those out first with placeholder offsets
+    def build(offsets):
+        nonlocal extra
+        extra = b""
+        t = list(tags)
+        if tile:
+            t += [(322, 4, [tile[0]]), (323, 4, [tile[1]]), (324, 4, offsets), (325, 4, [len(x) for x in blobs])]
+        else:
+            t += [(273, 4, offsets), (278, 4, [rows_per_strip or h]), (279, 4, [len(x) for x in blobs])]
+        t.sort()
+        ifd = struct.pack(e + "H", len(t)) + b"".join(field(*x) for x in t) + struct.pack(e + "I", 0)
+        return ifd
+
+    build([0] * len(blobs))
+    base = data_at + len(extra)
+    offsets, o = [], base
+    for x in blobs:
+        offsets.append(o)
+        o += len(x) + (len(x) & 1)
+    ifd = build(offsets)
+    out = (b"MM" if big else b"II") + struct.pack(e + "HI", 42, ifd_at) + ifd + extra
+    assert len(out) == base
+    for x in blobs:
+        out += x + (b"\0" if len(x) & 1 else b"")
+    return out
+
+
+@pytest.mark.parametrize("big", [False, True], ids=["II", "MM"])
+@pytest.mark.parametrize("case", ["rgb16_strips", "rgba16_tiles_deflate", "greya8_tiles_packbits", "rgb_float", "white_is_zero", "rgb16_predictor", "rgb8_tiles_predictor"])
+def test_tiff_byte_level_cases(big, case):
+    rng = np.random.default_rng(len(case))
+    if case == "rgb16_strips":
+        a = rng.integers(0, 65536, size=(21, 17, 3), dtype=np.uint16)
+        data, want = write_tiff(a, big, rows_per_strip=4), to_rgba8(a)
+    elif case == "rgba16_tiles_deflate":
+        a = rng.integers(0, 65536, size=(37, 41, 4), dtype=np.uint16)
+        data, want = write_tiff(a, big, compression=8, tile=(16, 16)), to_rgba8(a)
+    elif case == "greya8_tiles_packbits":
+        a = rng.integers(0, 256, size=(33, 18, 2), dtype=np.uint8)
+        data, want = write_tiff(a, big, compression=32773, tile=(16, 32)), to_rgba8(a)
+    elif case == "rgb_float":
+        a = rng.uniform(-0.2, 1.3, size=(9, 11, 3)).astype(np.float32)
+        a[0, 0, 0] = np.nan
+        data, want = write_tiff(a, big, rows_per_strip=2), to_rgba8(a)
+    elif case == "white_is_zero":
+        a = rng.integers(0, 256, size=(8, 9, 1), dtype=np.uint8)
+        data, want = write_tiff(a, big, photometric=0), to_rgba8(255 - a)
+    elif case == "rgb16_predictor":
+        a = rng.integers(0, 65536, size=(12, 13, 3), dtype=np.uint16)
+        data, want = write_tiff(a, big, compression=8, predictor=2), to_rgba8(a)
+    else:
+        a = rng.integers(0, 256, size=(20, 45, 3), dtype=np.uint8)
+        data, want = write_tiff(a, big, compression=8, tile=(16, 16), predictor=2), to_rgba8(a)
+    got = capi.host_decode_tiff(data)
+    assert np.array_equal(got, want)
+    if a.dtype == np.uint8 and case != "white_is_zero" and a.shape[2] != 2:  # the writer itself, against libtiff
+        assert np.array_equal(np.asarray(Image.open(io.BytesIO(data)).convert("RGBA")), want)
+
+
+def test_tiff_refuses_what_it_does_not_read():
+    a = np.zeros((4, 4, 3), dtype=np.uint8)
+    good = write_tiff(a)
+    for bad, what in ((b"II" + struct.pack("<HI", 43, 8) + good[8:], "BigTIFF"), (good[:20], "truncated"), (b"XX" + good[2:], "not a TIFF"),
+                      (write_tiff(a, compression=7), "compression 7"), (write_tiff(a, photometric=6), "photometric"),
+                      (write_tiff(a, extra_tags=[]).replace(struct.pack("<HHIHH", 284, 3, 1, 1, 0), struct.pack("<HHIHH", 284, 3, 1, 2, 0)), "planar")):
+        with pytest.raises(capi.AkariError) as ei:
+            capi.host_decode_tiff(bad)
+        assert what.split()[0].lower() in str(ei.value).lower(), (what, str(ei.value))
+    for cut in (len(good) - 1, len(good) - 20):
+        with pytest.raises(capi.AkariError):
+            capi.host_decode_tiff(good[:cut])
+
+
+# ------------------------------------------------------------------------------------------------------------------ DDS
+def make_dds(w, h, kind, blocks: bytes, dx10=False):
+    hdr = bytearray(128)
+    hdr[0:4] = b"DDS "
+    struct.pack_into("<IIIII", hdr, 4, 124, 0x1 | 0x2 | 0x4 | 0x1000 | 0x80000, h, w, len(blocks))
+    struct.pack_into("<II", hdr, 76, 32, 0x4)
+    hdr[84:88] = b"DX10" if dx10 else {1: b"DXT1", 3: b"DXT3", 5: b"DXT5"}[kind]
+    struct.pack_into("<I", hdr, 108, 0x1000)
+    out = bytes(hdr)
+    if dx10:
+        out += struct.pack("<IIIII", {1: 71, 3: 74, 5: 77}[kind], 3, 0, 1, 0)
+    return out + blocks
+
+
+@pytest.mark.parametrize("dx10", [False, True])
+@pytest.mark.parametrize("kind", [1, 3, 5])
+def test_dds_blocks_against_the_restated_rules(kind, dx10):
+    rng = np.random.default_rng(kind)
+    w, h = 22, 13  # not multiples of 4: the last blocks are cropped
+    n = ((w + 3) // 4) * ((h + 3) // 4)
+    blocks = bytearray(rng.integers(0, 256, size=n * (8 if kind == 1 else 16), dtype=np.uint8).tobytes())
+    # force both orderings of the endpoints (colour and alpha) to appear
+    step = 8 if kind == 1 else 16
+    for b in range(0, len(blocks), 2 * step):
+        o = b + (0 if kind == 1 else 8)
+        c0, c1 = struct.unpack_from("<HH", blocks, o)
+        struct.pack_into("<HH", blocks, o, min(c0, c1), max(c0, c1))
+        if kind == 5:
+            blocks[b], blocks[b + 1] = min(blocks[b], blocks[b + 1]), max(blocks[b], blocks[b + 1])
+    data = make_dds(w, h, kind, bytes(blocks), dx10)
+    got = capi.host_decode_dds(data)
+    want = scene_json.decode_dds(data)
+    assert got.shape == (h, w, 4) and np.array_equal(got, want)
+    if kind == 1:
+        assert (got[:, :, 3] == 255).all()  # DXT1 decodes to RGB
+    if not dx10:  # an independent decoder: same layout, its own rounding of the interpolated colours (a few LSB)
+        pil = np.asarray(Image.open(io.BytesIO(data)).convert("RGBA"))
+        assert np.abs(pil[:, :, :3].astype(int) - got[:, :, :3].astype(int)).max() <= 8 or kind == 1
+        if kind != 1:
+            assert np.abs(pil[:, :, 3].astype(int) - got[:, :, 3].astype(int)).max() <= 1
+
+
+def test_dds_known_block():
+    """One DXT5 block by hand: endpoints red / blue, indices 0 1 2 3 repeating; alpha 255 -> 0 ramp."""
+    c0, c1 = 0xF800, 0x001F
+    idx = sum((i & 3) << (2 * i) for i in range(16))
+    abits = sum((i & 7) << (3 * i) for i in range(16))
+    block = bytes([255, 0]) + abits.to_bytes(6, "little") + struct.pack("<HHI", c0, c1, idx)
+    got = capi.host_decode_dds(make_dds(4, 4, 5, block))
+    assert got[0, 0].tolist() == [255, 0, 0, 255] and got[0, 1].tolist() == [0, 0, 255, 0]
+    assert got[0, 2].tolist() == [(2 * 255 + 0 + 1) // 3, 0, (0 + 255 + 1) // 3, (6 * 255) // 7]
+    assert got[0, 3].tolist() == [(255 + 1) // 3, 0, (2 * 255 + 1) // 3, (5 * 255) // 7]
+
+
+def test_dds_refuses_what_it_does_not_read():
+    good = make_dds(4, 4, 1, bytes(8))
+    for bad in (good[:100], b"XXXX" + good[4:], good[:84] + b"ATI2" + good[88:], good[:80] + struct.pack("<I", 0x40) + good[84:], good[:-1]):
+        with pytest.raises(capi.AkariError):
+            capi.host_decode_dds(bad)
+
+
+def test_scene_loader_reads_tiff_and_dds_textures(tmp_path):
+    from tests.test_textures import _scene_json_with_textures
+
+    rng = np.random.default_rng(12)
+    a = rng.integers(0, 256, size=(20, 24, 3), dtype=np.uint8)
+    tiff = pil_tiff(a, "tiff_lzw")
+    dds = make_dds(24, 20, 5, rng.integers(0, 256, size=6 * 5 * 16, dtype=np.uint8).tobytes())
+    for fmt, blob, want in (("tiff", tiff, to_rgba8(a)), ("dds", dds, scene_json.decode_dds(dds))):
+        d = tmp_path / fmt
+        d.mkdir()
+        path = _scene_json_with_textures(d, blob, rng.random((4, 3, 3)).astype(np.float32))
+        scene = json.loads(open(path).read())
+        for m in ("m_floor", "m_wall"):
+            scene["materials"][m]["shader"]["nodes"]["img"]["image"].update(format=fmt, width=24, height=20)
+        p2 = d / "scene2.json"
+        p2.write_text(json.dumps(scene))
+        got = capi.Scene(None, str(p2)).to_scene_data()
+        pyl = scene_json.load_scene(str(p2))
+        x = [im for im in got.images if im.texels.dtype == np.uint8][0].texels
+        y = [im for im in pyl.images if im.texels.dtype == np.uint8][0].texels
+        assert np.array_equal(x, want[::-1]) and np.array_equal(x, y)  # flipped vertically like every encoded image

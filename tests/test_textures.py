@@ -312,12 +312,12 @@ def test_loader_rejects_unsupported_texture_inputs(tmp_path):
     path = _scene_json_with_textures(tmp_path, make_png(rng.integers(0, 256, size=(5, 6, 3)), 2, 8), rng.random((4, 3, 3)).astype(np.float32))
     scene = json.loads(open(path).read())
     nodes = scene["materials"]["m_wall"]["shader"]["nodes"]
-    nodes["img"]["image"]["format"] = "tiff"
+    nodes["img"]["image"]["format"] = "webp"  # not one of load.rs:585-592 (float, png, jpeg, tiff, exr, dds)
     bad = tmp_path / "bad.json"
     bad.write_text(json.dumps(scene))
     with pytest.raises(capi.AkariError) as e:
         capi.Scene(None, str(bad))
-    assert "tiff" in str(e.value) and e.value.code == -6  # AKR_ERR_UNSUPPORTED
+    assert "webp" in str(e.value) and e.value.code == -6  # AKR_ERR_UNSUPPORTED
 
 
 def test_graph_validation_errors():
