@@ -38,9 +38,9 @@ struct alignas(16) DMaterial {
     vec3 spec_tint;           float coat_weight;
     vec3 coat_scale;          float coat_roughness; // lerp(1, coat_tint, coat_weight) (principled.rs:195-198)
     vec3 metal_n;             float coat_eta;
-    vec3 metal_k;             float _pad0;
+    vec3 metal_k;             float z_spec;         // sqrt(|(eta_s - 1) / (eta_s + 1)|): the table coordinate of the specular layer
     vec2 alpha;               vec2 coat_alpha;      // max(roughness^2, 1e-4)       (microfacet.rs:29-43)
-    vec3 nm_normal;           float _pad1;          // normalize((-nx, -ny, nz))
+    vec3 nm_normal;           float z_coat;         // normalize((-nx, -ny, nz)); the coat's table coordinate
     uint32_t tex_first_node, tex_n_nodes;           // MF_TEXTURED: pruned node list in DScene.tex.nodes
     uint32_t tex_input[14];                         // node feeding each input (dtex.h IN_*), kNodeNone = constant
 };
@@ -248,10 +248,13 @@ AKR_HD float table_read_3d(const float* __restrict__ buf, float x, float y, floa
     float d1 = table_read_2d(buf, x, y, xs * ys * nindex, xs, ys);
     return (1.0f - t) * d0 + t * d1;
 }
-AKR_HD float ggx_dielectric_albedo(const float* __restrict__ table, float roughness, float cos_i, float eta) {
-    float z = __builtin_sqrtf(abs_f((eta - 1.0f) / (eta + 1.0f)));
+AKR_HD float ggx_table_z(float eta) { return __builtin_sqrtf(abs_f((eta - 1.0f) / (eta + 1.0f))); }
+AKR_HD float ggx_dielectric_albedo_z(const float* __restrict__ table, float roughness, float cos_i, float z) {
     cos_i = abs_f(clamp_f(cos_i, -0.999f, 0.999f));
     return table_read_3d(table, roughness, abs_f(cos_i), z);
+}
+AKR_HD float ggx_dielectric_albedo(const float* __restrict__ table, float roughness, float cos_i, float eta) {
+    return ggx_dielectric_albedo_z(table, roughness, cos_i, ggx_table_z(eta));
 }
 
 // ---- lobes, in local shading space (z = normal) ----
@@ -335,7 +338,7 @@ AKR_HD bool fold_inputs(const MatInputs& m, DMaterial& d) {
     d.flags = 0;
     d.base_alpha = m.base_alpha;
     d.metallic = 0.0f; d.transmission = 0.0f; d.eta = 0.0f; d.f0 = 0.0f; d.eta_s = 0.0f; d.roughness = 0.0f;
-    d.coat_weight = 0.0f; d.coat_roughness = 0.0f; d.coat_eta = 0.0f; d._pad0 = 0.0f; d._pad1 = 0.0f;
+    d.coat_weight = 0.0f; d.coat_roughness = 0.0f; d.coat_eta = 0.0f; d.z_spec = 0.0f; d.z_coat = 0.0f;
     d.color = color;
     d.diffuse_refl = mk3(0, 0, 0); d.transmission_color = mk3(0, 0, 0); d.spec_color = mk3(0, 0, 0); d.spec_tint = mk3(0, 0, 0);
     d.coat_scale = mk3(0, 0, 0); d.metal_n = mk3(0, 0, 0); d.metal_k = mk3(0, 0, 0);
@@ -364,6 +367,9 @@ AKR_HD bool fold_inputs(const MatInputs& m, DMaterial& d) {
             d.coat_weight = m.coat_weight;
             d.coat_roughness = m.coat_roughness;
             d.coat_eta = m.coat_ior;
+            // the eta coordinate of the albedo table depends on the material only: once here, not at each of the five lookups of a vertex
+            if (f0 != 0.0f) d.z_spec = ggx_table_z(eta_s);
+            if (m.coat_weight != 0.0f) d.z_coat = ggx_table_z(m.coat_ior);
             d.coat_scale = lerp3(mk3(1, 1, 1), mk3(m.coat_tint[0], m.coat_tint[1], m.coat_tint[2]), m.coat_weight);
             d.alpha = mk2(max_f(m.roughness * m.roughness, 1e-4f), max_f(m.roughness * m.roughness, 1e-4f));
             d.coat_alpha = mk2(max_f(m.coat_roughness * m.coat_roughness, 1e-4f), max_f(m.coat_roughness * m.coat_roughness, 1e-4f));
@@ -403,18 +409,26 @@ AKR_HD bool fold_inputs(const MatInputs& m, DMaterial& d) {
     return true;
 }
 
-AKR_HD vec3 etop_spec(const DMaterial& m, const float* __restrict__ table, vec3 w) {
-    float albedo = ggx_dielectric_albedo(table, m.roughness, abs_cos_theta(w), m.eta_s);
-    return (m.spec_tint * albedo) * m.f0;
+AKR_HD float albedo_spec(const DMaterial& m, const float* __restrict__ table, vec3 w) {
+    return ggx_dielectric_albedo_z(table, m.roughness, abs_cos_theta(w), m.z_spec);
 }
-AKR_HD vec3 etop_coat(const DMaterial& m, const float* __restrict__ table, vec3 w) {
-    float albedo = ggx_dielectric_albedo(table, m.coat_roughness, abs_cos_theta(w), m.coat_eta);
-    return (mk3(1, 1, 1) * albedo) * m.coat_weight;
+AKR_HD float albedo_coat(const DMaterial& m, const float* __restrict__ table, vec3 w) {
+    return ggx_dielectric_albedo_z(table, m.coat_roughness, abs_cos_theta(w), m.z_coat);
 }
+AKR_HD vec3 etop_spec_of(const DMaterial& m, float albedo) { return (m.spec_tint * albedo) * m.f0; }
+AKR_HD vec3 etop_coat_of(const DMaterial& m, float albedo) { return (mk3(1, 1, 1) * albedo) * m.coat_weight; }
+AKR_HD vec3 etop_spec(const DMaterial& m, const float* __restrict__ table, vec3 w) { return etop_spec_of(m, albedo_spec(m, table, w)); }
+AKR_HD vec3 etop_coat(const DMaterial& m, const float* __restrict__ table, vec3 w) { return etop_coat_of(m, albedo_coat(m, table, w)); }
+// The table values of the OUTGOING direction of a vertex: the NEE evaluation, the lobe selection and the evaluation of the
+// sampled direction all ask for them (same material, same wo, same answer) -- looked up once per vertex by the path tracer
+// (shade_point_cache_wo); nullptr = look them up here.
+struct WoAlbedo {
+    float spec, coat;
+};
 AKR_HD float avg3(vec3 e) { return ((e.x + e.y) + e.z) / 3.0f; }
 
 // The Principled closure tree of principled.rs:133-202 (inside the wrapper), evaluated for (wo, wi).
-AKR_HD BsdfEval principled_eval(const DMaterial& m, const float* __restrict__ table, vec3 wo, vec3 wi) {
+AKR_HD BsdfEval principled_eval(const DMaterial& m, const float* __restrict__ table, vec3 wo, vec3 wi, const WoAlbedo* wc = nullptr) {
     const uint32_t fl = m.flags;
     BsdfEval b2{mk3(0, 0, 0), 0.0f};
     if (fl & MF_EVAL_BASE) {
@@ -426,7 +440,7 @@ AKR_HD BsdfEval principled_eval(const DMaterial& m, const float* __restrict__ ta
         // Coated{top: specular, bottom: b1}
         if (fl & MF_SPEC) {
             BsdfEval top = eval_reflection<FR_DIELECTRIC>(m.spec_color, m.eta_s, mk3(0, 0, 0), mk3(0, 0, 0), m.alpha, wo, wi);
-            vec3 eo = etop_spec(m, table, wo), ei = etop_spec(m, table, wi);
+            vec3 eo = wc ? etop_spec_of(m, wc->spec) : etop_spec(m, table, wo), ei = etop_spec(m, table, wi);
             float ps_top = avg3(eo);
             float ps_bottom = 1.0f - ps_top;
             b2.pdf = top.pdf * ps_top + b1.pdf * ps_bottom;
@@ -445,7 +459,7 @@ AKR_HD BsdfEval principled_eval(const DMaterial& m, const float* __restrict__ ta
     if (!(fl & MF_COAT)) return sc;
     // Coated{top: coat, bottom: scaled}
     BsdfEval top = eval_reflection<FR_DIELECTRIC>(splat3(1.0f) * m.coat_weight, m.coat_eta, mk3(0, 0, 0), mk3(0, 0, 0), m.coat_alpha, wo, wi);
-    vec3 eo = etop_coat(m, table, wo), ei = etop_coat(m, table, wi);
+    vec3 eo = wc ? etop_coat_of(m, wc->coat) : etop_coat(m, table, wo), ei = etop_coat(m, table, wi);
     float ps_top = avg3(eo);
     float ps_bottom = 1.0f - ps_top;
     BsdfEval r;
@@ -474,14 +488,15 @@ AKR_HD bool sample_lobe(LobeKind lobe, vec2 alpha, float eta, vec3 wo, vec2 u, v
     return refracted && !same_hemisphere(wo, wi);
 }
 // which lobe, which alpha, and -- for the roughness AOV -- whether it is the coat
-AKR_HD void principled_select_lobe(const DMaterial& m, const float* __restrict__ table, vec3 wo, float u, LobeKind& lobe, vec2& alpha, bool& coat) {
+AKR_HD void principled_select_lobe(const DMaterial& m, const float* __restrict__ table, vec3 wo, float u, LobeKind& lobe, vec2& alpha, bool& coat,
+                                   const WoAlbedo* wc = nullptr) {
     const uint32_t fl = m.flags;
     lobe = LOBE_DIFFUSE;
     alpha = m.alpha;
     coat = false;
     float r;
     // Coated{coat | Scaled{Emissive{...}}}: top iff u < avg(E_coat(wo))
-    float p_coat = (fl & MF_COAT) ? avg3(etop_coat(m, table, wo)) : 0.0f;
+    float p_coat = (fl & MF_COAT) ? avg3(wc ? etop_coat_of(m, wc->coat) : etop_coat(m, table, wo)) : 0.0f;
     if (weighted_choice2_and_remap(p_coat, u, r)) {
         lobe = LOBE_REFLECT;
         alpha = m.coat_alpha;
@@ -494,7 +509,7 @@ AKR_HD void principled_select_lobe(const DMaterial& m, const float* __restrict__
         } else {
             u = r;
             // Coated{specular | Mix(transmission)}: top iff u < avg(E_spec(wo))
-            float p_spec = (fl & MF_SPEC) ? avg3(etop_spec(m, table, wo)) : 0.0f;
+            float p_spec = (fl & MF_SPEC) ? avg3(wc ? etop_spec_of(m, wc->spec) : etop_spec(m, table, wo)) : 0.0f;
             if (weighted_choice2_and_remap(p_spec, u, r)) {
                 lobe = LOBE_REFLECT;
             } else {
@@ -512,11 +527,11 @@ AKR_HD void principled_select_lobe(const DMaterial& m, const float* __restrict__
         }
     }
 }
-AKR_HD bool principled_sample_wi(const DMaterial& m, const float* __restrict__ table, vec3 wo, float u, vec2 u2, vec3& wi) {
+AKR_HD bool principled_sample_wi(const DMaterial& m, const float* __restrict__ table, vec3 wo, float u, vec2 u2, vec3& wi, const WoAlbedo* wc = nullptr) {
     LobeKind lobe;
     vec2 alpha;
     bool coat;
-    principled_select_lobe(m, table, wo, u, lobe, alpha, coat);
+    principled_select_lobe(m, table, wo, u, lobe, alpha, coat, wc);
     return sample_lobe(lobe, alpha, m.eta, wo, u2, wi);
 }
 
@@ -536,6 +551,8 @@ struct ShadePoint {
     Frame nm_frame;     // inner (normal-map) frame in local space; identity when !MF_NORMAL_MAP
     vec3 ng_local;      // frame.to_local(ng)  (normal_map(): ng of the inner SurfaceClosure)
     bool force_diffuse;
+    bool wo_cached;     // wo_albedo holds the table values of the vertex's outgoing direction (shade_point_cache_wo)
+    WoAlbedo wo_albedo;
 };
 
 // normal_map(), svm/surface/mod.rs:1380-1417, for a constant `normal` input
@@ -543,6 +560,8 @@ AKR_HD void shade_point_init(ShadePoint& sp, const DMaterial& m, Frame frame, ve
     sp.frame = frame;
     sp.ng = ng;
     sp.force_diffuse = force_diffuse;
+    sp.wo_cached = false;
+    sp.wo_albedo = WoAlbedo{0.0f, 0.0f};
     sp.ng_local = to_local(frame, ng);
     sp.nm_frame = Frame{mk3(0, 0, 1), mk3(1, 0, 0), mk3(0, 1, 0)};
     if (!force_diffuse && m.kind == MAT_PRINCIPLED && (m.flags & MF_NORMAL_MAP)) {
@@ -552,6 +571,17 @@ AKR_HD void shade_point_init(ShadePoint& sp, const DMaterial& m, Frame frame, ve
         sp.nm_frame.s = to_local(frame, nf.s);
         sp.nm_frame.n = to_local(frame, nf.n);
     }
+}
+
+// After shade_point_init, for a vertex all of whose evaluate / sample calls use this `wo` (world space): the albedo-table values
+// of wo, once. The calls that follow must pass the same wo.
+AKR_HD void shade_point_cache_wo(ShadePoint& sp, const DMaterial& m, const float* __restrict__ table, vec3 wo) {
+    if (sp.force_diffuse || m.kind != MAT_PRINCIPLED) return;
+    vec3 lo = to_local(sp.frame, wo);
+    if (m.flags & MF_NORMAL_MAP) lo = to_local(sp.nm_frame, lo);
+    if (m.flags & MF_SPEC) sp.wo_albedo.spec = albedo_spec(m, table, lo);
+    if (m.flags & MF_COAT) sp.wo_albedo.coat = albedo_coat(m, table, lo);
+    sp.wo_cached = true;
 }
 
 // closure.evaluate(wo, wi) for world-space directions -> (f * |cos|, pdf); pt.rs:268-279 for force_diffuse
@@ -570,7 +600,7 @@ AKR_HD BsdfEval shade_evaluate(const ShadePoint& sp, const DMaterial& m, const f
                 lo = to_local(sp.nm_frame, lo);
                 li = to_local(sp.nm_frame, li);
             }
-            return principled_eval(m, table, lo, li);
+            return principled_eval(m, table, lo, li, sp.wo_cached ? &sp.wo_albedo : nullptr);
         }
         case MAT_DIFFUSE: return eval_diffuse(m.diffuse_refl, lo, li);
         case MAT_GLASS: return eval_dielectric(m.color, m.color, m.eta, m.alpha, lo, li);
@@ -598,7 +628,7 @@ AKR_HD BsdfSample shade_sample(const ShadePoint& sp, const DMaterial& m, const f
             case MAT_PRINCIPLED: {
                 vec3 lo2 = (m.flags & MF_NORMAL_MAP) ? to_local(sp.nm_frame, lo) : lo;
                 vec3 w2;
-                valid = principled_sample_wi(m, table, lo2, u_select, u_sample, w2);
+                valid = principled_sample_wi(m, table, lo2, u_select, u_sample, w2, sp.wo_cached ? &sp.wo_albedo : nullptr);
                 wl = (m.flags & MF_NORMAL_MAP) ? to_world(sp.nm_frame, w2) : w2;
                 valid = valid & check_wo_wi_valid(sp.nm_frame.n, sp.ng_local, lo, wl);
                 break;

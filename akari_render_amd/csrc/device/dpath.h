@@ -268,14 +268,16 @@ AKR_D float pdf_direct(const DScene& sc, const SurfacePoint& si, uint32_t gid, v
 // scene_build.cpp): shading records, normals, instance transforms, materials, light tables -- 11.5 KB for the cbox.
 // BVH path: instance transforms, materials and light tables, behind the traversal stacks, when the host found that they fit
 // (PtParams.stage_total != 0); the per-triangle records stay in HBM. Must be called by every thread of the workgroup.
-template <bool BVH, bool TEX = false>
+template <bool BVH, bool TEX = false, bool GGX = false>
 AKR_D void stage_scene_tables(const PtParams& p, uint32_t* lds, PtParams& staged) {
-    const void* src[12] = {p.sc.shade,      p.sc.normals, p.sc.inst,      p.sc.materials, p.sc.light_alias, p.sc.area_alias,
-                           p.sc.lights,     p.sc.light_pdf, p.sc.area_pdf, p.sc.tex.nodes, p.sc.tex.images, p.sc.tex.mat_inputs};
-    uint32_t* dst[12];
+    const void* src[13] = {p.sc.shade,      p.sc.normals, p.sc.inst,      p.sc.materials, p.sc.light_alias, p.sc.area_alias,
+                           p.sc.lights,     p.sc.light_pdf, p.sc.area_pdf, p.sc.tex.nodes, p.sc.tex.images, p.sc.tex.mat_inputs,
+                           p.sc.ggx_table};
+    uint32_t* dst[13];
     uint32_t off = BVH ? kBvhStackDepth * 256u : 0u;  // in words, behind the stacks
 #pragma unroll
-    for (int e = BVH ? 2 : 0; e < (TEX ? 12 : 9); e++) {
+    for (int e = BVH ? 2 : 0; e < 13; e++) {
+        if ((e >= 9 && e < 12 && !TEX) || (e == 12 && !GGX)) continue;
         const uint32_t n = p.stage_bytes[e] >> 2;
         const uint32_t* g = (const uint32_t*)src[e];
         uint32_t* l = lds + off;
@@ -299,6 +301,11 @@ AKR_D void stage_scene_tables(const PtParams& p, uint32_t* lds, PtParams& staged
     // in dependent chains; from LDS each link is a ds_read instead of an L1 / L2 round trip. Texels stay in HBM.
     // The host stages either all of it or nothing (api.cpp fill_params, scene_build.cpp), so a TEX kernel that stages at all
     // reads the texture tables through LDS addresses unconditionally.
+    // The 16 KB albedo table of the specular layer / coat (three to five trilinear lookups of 8 gathers each per shaded vertex),
+    // for the kernels of scenes with textures, whose L1 is busy with texels: textured room 822 -> 861 Msamples/s. The plain
+    // full-graph kernel is better off with the table in L1 (C3: 1887 with, 1851 without L1 -- LDS bank conflicts of the random
+    // gathers). The host leaves stage_bytes[12] at 0 when the workgroup's LDS budget is spent; the table then stays where it is.
+    if (GGX && p.stage_bytes[12] != 0) staged.sc.ggx_table = (const float*)dst[12];
     if (TEX) {
         staged.sc.tex.nodes = (const DNode*)dst[9];
         staged.sc.tex.images = (const DImage*)dst[10];
@@ -465,6 +472,7 @@ AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found,
                 // sample_surface_and_shade_direct, pt.rs:297-323
                 ShadePoint sp;
                 shade_point_init(sp, mat, si.frame, si.ng, force_diffuse);
+                if (FD != 1) shade_point_cache_wo(sp, mat, sc.ggx_table, wo);
                 if (dl.valid) {
                     BsdfEval e = shade_evaluate(sp, mat, sc.ggx_table, wo, dl.wi);
                     float w = mis_weight(dl.pdf, e.pdf);

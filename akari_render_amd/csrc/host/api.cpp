@@ -403,9 +403,9 @@ static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pas
         const bool bvh = !cs.bvh_nodes.empty();
         // exhaustive path: everything, per-triangle records included (scene_build.cpp guarantees the fit);
         // BVH path: the per-scene tables only, if they fit beside the traversal stacks
-        size_t bytes[12] = {bvh ? 0 : cs.shade.size() * 4, bvh ? 0 : cs.normals.size() * 4, cs.inst.size() * 4, cs.materials.size() * sizeof(DMaterial),
+        size_t bytes[13] = {bvh ? 0 : cs.shade.size() * 4, bvh ? 0 : cs.normals.size() * 4, cs.inst.size() * 4, cs.materials.size() * sizeof(DMaterial),
                             (size_t)cs.n_lights * sizeof(AliasPacked), cs.area_entries.size() * sizeof(AliasPacked), (size_t)cs.n_lights * sizeof(LightRec),
-                            cs.light_pdf.size() * 4, cs.area_pdf.size() * 4, 0, 0, 0};
+                            cs.light_pdf.size() * 4, cs.area_pdf.size() * 4, 0, 0, 0, 0};
         if (cs.has_textures) {  // the node lists have the same size in every colour pipeline
             bytes[9] = cs.tex_nodes.size() * sizeof(DNode);
             bytes[10] = cs.images.size() * sizeof(DImage);
@@ -419,7 +419,14 @@ static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pas
         // one workgroup's dynamic LDS stays within 64 KB: traversal stacks + staged tables + the graph evaluation's value slots
         const size_t other = (bvh ? kBvhStackDepth * 256 * 4 : 0) + (size_t)p.tex_slots * kTexValStride * sizeof(TexVal);
         if (total <= (bvh ? kStageMaxBytesBvh : kStageMaxBytes) && (!bvh || other + total <= 64 * 1024)) {  // all of it or nothing (a TEX kernel reads its tables through LDS addresses)
-            for (int i = 0; i < 12; i++) p.stage_bytes[i] = (uint32_t)bytes[i];
+            // the albedo table as well for the full-graph exhaustive kernel of a textured scene (stage_scene_tables: GGX), if three
+            // workgroups per CU still fit (AKR_PT_MIN_WAVES_TEX = 3: 160 KB / 3)
+            const size_t ggx_bytes = 4096 * sizeof(float);
+            if (!bvh && cs.has_textures && !c.force_diffuse && other + total + ggx_bytes <= 53 * 1024) {
+                bytes[12] = ggx_bytes;
+                total += ggx_bytes;
+            }
+            for (int i = 0; i < 13; i++) p.stage_bytes[i] = (uint32_t)bytes[i];
             p.stage_total = (uint32_t)std::max<size_t>(total, 16);
         }
     }

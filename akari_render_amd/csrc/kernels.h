@@ -39,7 +39,7 @@ struct PtParams {
     // Small scenes (exhaustive path): the tables the shading phase gathers from, staged in LDS by k_pt_pass. Bytes per table
     // in the order shade, normals, inst, materials, light_alias, area_alias, lights, light_pdf, area_pdf; 0 total = not staged.
     // ... then the texture tables of a TEX scene: pruned node lists, image headers, raw material inputs (12 entries in all).
-    uint32_t stage_bytes[12];
+    uint32_t stage_bytes[13];  // [12]: the GGX albedo table (full-graph exhaustive kernels)
     uint32_t stage_total;
     uint32_t defer_metal;    // exhaustive path: shade hits on materials with a conductor lobe on even iterations only (pt_kernels.hip)
     uint32_t tex_slots;      // TEX scenes: value slots per lane of the graph evaluation (LDS, after the launch's other blocks)

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT
     tc.cnt = TraceCounters{0, 0, 0};
     // STAGE: the kernel works on a parameter block whose table pointers aim at LDS copies (stage_scene_tables, dpath.h)
     PtParams staged = p;
-    if (STAGE) stage_scene_tables<BVH, TEX>(p, lds_stack, staged);
+    if (STAGE) stage_scene_tables<BVH, TEX, !BVH && !FD && TEX>(p, lds_stack, staged);
     const PtParams& q = STAGE ? staged : p;
     const DScene& sc = q.sc;
     const uint32_t item = blockIdx.x * 256u + threadIdx.x;
