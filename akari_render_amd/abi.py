@@ -189,6 +189,8 @@ class AovConfig(_Struct):
         ("shard_count", C.c_uint32),
         ("tile_w", C.c_uint32),
         ("tile_h", C.c_uint32),
+        ("color", C.c_uint32),
+        ("_pad", C.c_uint32),
     ]
 
     @staticmethod
@@ -217,6 +219,8 @@ class GptConfig(_Struct):
         ("sampler_type", C.c_uint32),
         ("sampler_seed", C.c_uint64),
         ("seed", C.c_uint64),
+        ("color", C.c_uint32),
+        ("_pad", C.c_uint32),
     ]
 
     @staticmethod
@@ -240,7 +244,7 @@ class McmcConfig(_Struct):
         ("small_sigma", C.c_float), ("large_step_prob", C.c_float), ("image_mutation_prob", C.c_float), ("image_mutation_size", C.c_float),
         ("adaptive", C.c_uint32), ("wis", C.c_uint32),
         ("seed", C.c_uint64),
-        ("filter_type", C.c_uint32), ("filter_radius", C.c_float), ("sampler_type", C.c_uint32), ("_pad", C.c_uint32),
+        ("filter_type", C.c_uint32), ("filter_radius", C.c_float), ("sampler_type", C.c_uint32), ("color", C.c_uint32),
         ("sampler_seed", C.c_uint64),
     ]
 

@@ -59,7 +59,9 @@ __global__ __launch_bounds__(256) void k_aov(const PtParams p_in, uint32_t spp, 
             }
             // film.add_sample(p, color, swl, ray_w = 1), film.rs:196-229
             if (is_nan(c.x) || is_nan(c.y) || is_nan(c.z)) c = mk3(0, 0, 0);
-            acc = mk3(acc.x + c.x * 1.0f, acc.y + c.y * 1.0f, acc.z + c.z * 1.0f);
+            c = c * 1.0f;
+            if (p.color & COLOR_REPR_ACES) c = cs_convert(c, true, false);  // Color::Rgb(v, the space of color_repr) -> the sRGB film (aov.rs:98-124, film.rs:218)
+            acc = mk3(acc.x + c.x, acc.y + c.y, acc.z + c.z);
             wsum = wsum + 1.0f;
         }
         sampler_end_pass<PMJ>(p, smp);  // Drop of the sampler

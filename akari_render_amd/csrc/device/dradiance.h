@@ -26,9 +26,12 @@ struct ShiftMapping {  // ReconnectionShiftMapping, pt.rs:1008-1017
     float jacobian;
 };
 
-AKR_D vec3 splat_value(vec3 c, float weight) {  // Film::add_splat: color.remove_nan() * weight, NaN components flushed
+// Film::add_splat (film.rs:167-194): color.remove_nan() * weight, converted to the film's sRGB primaries when the pipeline
+// shades in ACEScg (`aces`; color.to_rgb(SRgb), color.rs:262-275), NaN components flushed
+AKR_D vec3 splat_value(vec3 c, float weight, bool aces = false) {
     if (is_nan(c.x) || is_nan(c.y) || is_nan(c.z)) c = mk3(0, 0, 0);
     c = c * weight;
+    if (aces) c = cs_convert(c, true, false);
     return mk3(is_nan(c.x) ? 0.0f : c.x, is_nan(c.y) ? 0.0f : c.y, is_nan(c.z) ? 0.0f : c.z);
 }
 

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void k_gpt_sample(const PtParams p_in, cons
             if (k == 0) {
                 l0 = l;
                 rec0 = rec;
-                if (g.reconstruction != RECON_NONE) own = splat_value(l0 + rec0, 1.0f);
+                if (g.reconstruction != RECON_NONE) own = splat_value(l0 + rec0, 1.0f, (p.color & COLOR_REPR_ACES) != 0);
                 continue;
             }
             vec3 out;
@@ -89,8 +89,8 @@ __global__ __launch_bounds__(256, 2) void k_gpt_sample(const PtParams p_in, cons
                     a = l0 * wp;
                     b = (l * ws) * jac;
                 }
-                own = own + splat_value(a, 1.0f);
-                out = splat_value(b, 1.0f);
+                own = own + splat_value(a, 1.0f, (p.color & COLOR_REPR_ACES) != 0);
+                out = splat_value(b, 1.0f, (p.color & COLOR_REPR_ACES) != 0);
             } else {  // gpt.rs:308-346
                 vec3 grad;
                 if (sm.enabled) {
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void k_gpt_sample(const PtParams p_in, cons
                 } else {
                     grad = (l - l0) * 0.5f;
                 }
-                out = splat_value(grad, k <= 2 ? 1.0f : -1.0f);
+                out = splat_value(grad, k <= 2 ? 1.0f : -1.0f, (p.color & COLOR_REPR_ACES) != 0);
             }
             float* dst = g.shifted[k - 1] + 3 * (size_t)pix;
             dst[0] = out.x; dst[1] = out.y; dst[2] = out.z;

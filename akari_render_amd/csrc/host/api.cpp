@@ -1020,6 +1020,7 @@ AKR_API int32_t akr_aov_render(akr_context* ctx, akr_scene* scene, const akr_aov
     pc.filter_type = cfg->filter_type; pc.filter_radius = cfg->filter_radius;
     pc.sampler_type = cfg->sampler_type; pc.sampler_seed = cfg->sampler_seed;
     pc.shard_rank = cfg->shard_rank; pc.shard_count = cfg->shard_count; pc.tile_w = cfg->tile_w; pc.tile_h = cfg->tile_h;
+    pc.color = cfg->color;
     akr_pt_session* se = nullptr;
     int32_t rc = akr_pt_begin(ctx, scene, &pc, film, &se);
     if (rc != AKR_OK) return rc;
@@ -1067,6 +1068,7 @@ AKR_API int32_t akr_gpt_render(akr_context* ctx, akr_scene* scene, const akr_gpt
     pc.use_nee = cfg->use_nee; pc.indirect_only = cfg->indirect_only;
     pc.filter_type = cfg->filter_type; pc.filter_radius = cfg->filter_radius;
     pc.sampler_type = cfg->sampler_type; pc.sampler_seed = cfg->sampler_seed;
+    pc.color = cfg->color;
     akr_pt_session* se = nullptr;
     int32_t rc = akr_pt_begin(ctx, scene, &pc, film, &se);
     if (rc != AKR_OK) return rc;
@@ -1155,6 +1157,7 @@ static int32_t mcmc_render_impl(akr_context* ctx, akr_scene* scene, const akr_mc
         akr_pt_config_default(&d);
         d.max_depth = 1; d.rr_depth = 1; d.spp = (uint32_t)cfg->direct_spp; d.indirect_only = 0; d.spp_per_pass = cfg->spp_per_pass; d.use_nee = cfg->use_nee;
         d.filter_type = cfg->filter_type; d.filter_radius = cfg->filter_radius; d.sampler_type = cfg->sampler_type; d.sampler_seed = cfg->sampler_seed;
+        d.color = cfg->color;
         int32_t rc = akr_pt_render(ctx, scene, &d, film, nullptr);
         if (rc != AKR_OK) return rc;
     }
@@ -1163,6 +1166,7 @@ static int32_t mcmc_render_impl(akr_context* ctx, akr_scene* scene, const akr_mc
     pc.spp = 1; pc.spp_per_pass = 1; pc.max_depth = cfg->max_depth; pc.rr_depth = cfg->rr_depth; pc.use_nee = cfg->use_nee;
     pc.indirect_only = cfg->direct_spp >= 0 ? 1u : 0u;
     pc.filter_type = cfg->filter_type; pc.filter_radius = cfg->filter_radius;
+    pc.color = cfg->color;
     akr_pt_session* se = nullptr;
     int32_t rc = akr_pt_begin(ctx, scene, &pc, film, &se);
     if (rc != AKR_OK) return rc;

@@ -620,8 +620,7 @@ static void parse_one_task(const JsonValue* j, akr_pt_config* cfg, std::string* 
         if (film_out && f.has("out")) *film_out = f.at("out").as_string();
     }
     if (task) {  // sampler and film filter are per RenderConfig, whatever the method
-        if (cfg->color != 0 && (task->is_aov || task->is_gpt || task->is_mcmc))
-            throw std::runtime_error("unsupported: a colour pipeline other than srgb / srgb with the aov, gpt and mcmc_opt integrators (pt only)");
+        task->aov.color = task->gpt.color = task->mcmc.color = cfg->color;  // RenderConfig.color goes to whichever integrator runs (lib.rs:43,98)
         task->aov.filter_type = cfg->filter_type;
         task->aov.filter_radius = cfg->filter_radius;
         task->aov.sampler_type = cfg->sampler_type;

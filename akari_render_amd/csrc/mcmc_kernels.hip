@@ -222,10 +222,10 @@ __global__ __launch_bounds__(256, 2) void k_mcmc_advance(const PtParams p_in, co
             float accept = 0.0f;
             if (is_finite(proposal_f)) accept = (cur_f == 0.0f || !is_finite(cur_f)) ? 1.0f : clamp_f(proposal_f / cur_f, 0.0f, 1.0f);
             {  // the two expected-value splats, mcmc_opt.rs:463-474
-                const vec3 a = splat_value(div_s(e.l, proposal_f), accept * contribution);
+                const vec3 a = splat_value(div_s(e.l, proposal_f), accept * contribution, (p.color & COLOR_REPR_ACES) != 0);
                 float* d = splat + 3 * ((size_t)e.px + (size_t)e.py * p.width);
                 unsafeAtomicAdd(d + 0, a.x); unsafeAtomicAdd(d + 1, a.y); unsafeAtomicAdd(d + 2, a.z);
-                const vec3 b = splat_value(div_s(cur_color, cur_f), (1.0f - accept) * contribution);
+                const vec3 b = splat_value(div_s(cur_color, cur_f), (1.0f - accept) * contribution, (p.color & COLOR_REPR_ACES) != 0);
                 d = splat + 3 * ((size_t)st.cur_pixel[0] + (size_t)st.cur_pixel[1] * p.width);
                 unsafeAtomicAdd(d + 0, b.x); unsafeAtomicAdd(d + 1, b.y); unsafeAtomicAdd(d + 2, b.z);
             }

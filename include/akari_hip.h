@@ -418,6 +418,7 @@ typedef struct {
     uint32_t sampler_type;
     uint64_t sampler_seed;
     uint32_t shard_rank, shard_count, tile_w, tile_h;
+    uint32_t color, _pad;    /* ColorPipeline bits as in akr_pt_config.color (aov.rs:62: the values go through the film like colours) */
 } akr_aov_config;
 AKR_API int32_t akr_aov_config_default(akr_aov_config *cfg);
 /* Renders into `film` (accumulates: clear it first for a fresh image). stats: n_samples = n_closest = camera rays. */
@@ -442,6 +443,7 @@ typedef struct {
     uint32_t sampler_type;
     uint64_t sampler_seed;
     uint64_t seed;                                          /* gpt::Config.seed: carried, never read by the reference either */
+    uint32_t color, _pad;                                   /* ColorPipeline bits as in akr_pt_config.color (gpt.rs:96) */
 } akr_gpt_config;
 AKR_API int32_t akr_gpt_config_default(akr_gpt_config *cfg);
 /* Renders into `film` (clear it first; sets its splat scale). aux (host memory, optional, reconstruction != none):
@@ -470,7 +472,7 @@ typedef struct {
     uint64_t seed;                                          /* 0 */
     uint32_t filter_type;
     float filter_radius;
-    uint32_t sampler_type, _pad;                            /* sampler of the direct pass */
+    uint32_t sampler_type, color;                           /* sampler of the direct pass; ColorPipeline bits as in akr_pt_config.color */
     uint64_t sampler_seed;
 } akr_mcmc_config;
 typedef struct {

@@ -949,10 +949,13 @@ OR_EXPORT int or_pt_render(const or_scene *sc, const or_pt_config *cfg, float *f
     return 0;
 }
 
+static v3 or_cs_convert_v3(v3 c, int from_aces, int to_aces) { float a[3] = {c.x, c.y, c.z}; or_cs_convert(a, from_aces, to_aces); return V3(a[0], a[1], a[2]); }
+
 /* ---------------------------------- aov integrator, akari_integrator/src/aov.rs:57-173 -------------- */
 typedef struct {
     uint32_t spp, aov, remap, filter_type; float filter_radius; uint32_t sampler_type; uint64_t sampler_seed;
     uint32_t shard_rank, shard_count, tile_w, tile_h;
+    uint32_t color, _pad;
 } or_aov_config; /* = akr_aov_config */
 enum { OR_AOV_NS = 0, OR_AOV_NG, OR_AOV_TANGENT, OR_AOV_BITANGENT, OR_AOV_ALBEDO, OR_AOV_ROUGHNESS };
 typedef struct { const or_scene *sc; const or_aov_config *cfg; or_pt_config pc; float *film; or_pcg32 *states; volatile uint32_t *next_row; uint64_t n_rays; char pad[128]; } __attribute__((aligned(128))) or_aov_job;
@@ -984,9 +987,12 @@ static void or_aov_pixel(or_aov_job *j, uint32_t x, uint32_t y) { /* kernel body
         }
         if (or_isnan(c.x) || or_isnan(c.y) || or_isnan(c.z)) c = V3(0, 0, 0);
         const float w = 1.0f;
-        j->film[3 * (uint64_t)i + 0] += c.x * w;
-        j->film[3 * (uint64_t)i + 1] += c.y * w;
-        j->film[3 * (uint64_t)i + 2] += c.z * w;
+        c = v3scale(c, w);
+        /* Color::Rgb(v, the space of color_repr) -> the sRGB film: aov.rs:98-124, film.rs:196-229, color.rs:262-275 */
+        if (cfg->color & OR_COLOR_REPR_ACES) c = or_cs_convert_v3(c, 1, 0);
+        j->film[3 * (uint64_t)i + 0] += c.x;
+        j->film[3 * (uint64_t)i + 1] += c.y;
+        j->film[3 * (uint64_t)i + 2] += c.z;
         j->film[6 * N + i] += w;
     }
     j->states[i] = smp_drop(&smp);
@@ -1003,7 +1009,7 @@ static void *or_aov_worker(void *arg) {
     return 0;
 }
 OR_EXPORT int or_aov_render(const or_scene *sc, const or_aov_config *cfg, float *film, uint32_t n_threads, uint64_t *n_rays_out) {
-    ((or_scene *)sc)->color = 0; /* these integrators run in the default sRGB / sRGB pipeline here */
+    ((or_scene *)sc)->color = cfg->color; /* the pipeline every material evaluation of this render sees */
     uint64_t N = (uint64_t)sc->width * sc->height;
     or_pcg32 *states = (or_pcg32 *)malloc(sizeof(or_pcg32) * N);
     or_init_sampler_states(cfg->sampler_type, N, sc->width, cfg->sampler_seed, states);
@@ -1040,6 +1046,7 @@ typedef struct {
     uint32_t separate_weights, reconstruction, reconstruction_iter, filter_type;
     float filter_radius; uint32_t sampler_type;
     uint64_t sampler_seed, seed;
+    uint32_t color, _pad;
 } or_gpt_config; /* = akr_gpt_config */
 enum { OR_RECON_NONE = 0, OR_RECON_UNIFORM = 1, OR_RECON_WEIGHTED = 2 };
 enum { OR_VT_INVALID = 0, OR_VT_LAST_HIT_LIGHT = 1, OR_VT_LAST_NEE = 2, OR_VT_INTERIOR = 3 }; /* pt.rs:975-980 */
@@ -1233,8 +1240,9 @@ static void or_gpt_shifted(const or_gpt_config *g, uint32_t W, uint32_t H, uint3
 }
 static v3 or_remove_nan(v3 c) { return (or_isnan(c.x) || or_isnan(c.y) || or_isnan(c.z)) ? V3(0, 0, 0) : c; }
 /* what one add_splat adds: color.remove_nan() * weight, each component's NaN flushed again (film.rs:167-194) */
-static v3 or_splat_value(v3 c, float weight) {
+static v3 or_splat_value(v3 c, float weight, uint32_t color) {
     c = v3scale(or_remove_nan(c), weight);
+    if (color & OR_COLOR_REPR_ACES) c = or_cs_convert_v3(c, 1, 0); /* color.to_rgb(SRgb), film.rs:178 */
     return V3(or_isnan(c.x) ? 0.0f : c.x, or_isnan(c.y) ? 0.0f : c.y, or_isnan(c.z) ? 0.0f : c.z);
 }
 typedef struct {
@@ -1267,7 +1275,7 @@ static void or_gpt_pixel(or_gpt_job *j, uint32_t x, uint32_t y) {
         } else { l[k] = rad; jac[k] = 1.0f; ok[k] = 0; rec[k] = V3(0, 0, 0); }
     }
     v3 own = V3(0, 0, 0);
-    if (g->reconstruction != OR_RECON_NONE) own = or_splat_value(v3add(l[0], rec[0]), 1.0f);
+    if (g->reconstruction != OR_RECON_NONE) own = or_splat_value(v3add(l[0], rec[0]), 1.0f, g->color);
     for (uint32_t i = 0; i < 4; i++) {
         const uint32_t k = i + 1;
         v3 out;
@@ -1281,8 +1289,8 @@ static void or_gpt_pixel(or_gpt_job *j, uint32_t x, uint32_t y) {
                 a = v3scale(l[0], wp);
                 b = v3scale(v3scale(l[k], ws), jac[k]);
             }
-            own = v3add(own, or_splat_value(a, 1.0f));
-            out = or_splat_value(b, 1.0f);
+            own = v3add(own, or_splat_value(a, 1.0f, g->color));
+            out = or_splat_value(b, 1.0f, g->color);
         } else {
             v3 grad;
             if (sm) {
@@ -1293,7 +1301,7 @@ static void or_gpt_pixel(or_gpt_job *j, uint32_t x, uint32_t y) {
                     grad = ok[k] ? v3divs(v3sub(v3scale(l[k], jac[k]), l[0]), 1.0f + jac[k]) : v3sub(V3(0, 0, 0), l[0]);
                 }
             } else grad = v3scale(v3sub(l[k], l[0]), 0.5f);
-            out = or_splat_value(grad, i < 2 ? 1.0f : -1.0f);
+            out = or_splat_value(grad, i < 2 ? 1.0f : -1.0f, g->color);
         }
         j->shifted[i][3 * (uint64_t)pix + 0] = out.x; j->shifted[i][3 * (uint64_t)pix + 1] = out.y; j->shifted[i][3 * (uint64_t)pix + 2] = out.z;
     }
@@ -1330,7 +1338,7 @@ static int or_gpt_sources(int32_t cp, int32_t o, uint32_t r, uint32_t out[3]) {
  * otherwise written with the reconstructed image, splat_scale = 1). aux (optional, reconstruction != none):
  * [primal 3N | Gx 3(W+1)(H+1) | Gy 3(W+1)(H+1)] = the accumulated sums of gpt.rs:441-455 (divide by spp for the mean). */
 OR_EXPORT int or_gpt_render(const or_scene *sc, const or_gpt_config *g, float *film, float *aux, uint32_t n_threads) {
-    ((or_scene *)sc)->color = 0; /* these integrators run in the default sRGB / sRGB pipeline here */
+    ((or_scene *)sc)->color = g->color; /* the pipeline every material evaluation of this render sees */
     const uint32_t W = sc->width, H = sc->height;
     const uint64_t N = (uint64_t)W * H, NG = (uint64_t)(W + 1) * (H + 1);
     if (g->stride < 1 || g->stride >= W || g->stride >= H) return -1;
@@ -1446,7 +1454,7 @@ typedef struct {
     float small_sigma, large_step_prob, image_mutation_prob, image_mutation_size /* <= 0 = None */;
     uint32_t adaptive, wis;
     uint64_t seed;
-    uint32_t filter_type; float filter_radius; uint32_t sampler_type, _pad;
+    uint32_t filter_type; float filter_radius; uint32_t sampler_type, color;
     uint64_t sampler_seed;
 } or_mcmc_config; /* = akr_mcmc_config */
 typedef struct { float cur, backup; uint32_t last_modified, modified_backup; } or_pss; /* PssSample, mcmc_opt.rs:21-26 */
@@ -1562,7 +1570,7 @@ static or_mcmc_eval or_mcmc_evaluate(const or_scene *sc, const or_mcmc_config *c
 /* out: film (7N floats; the direct pass fills rgb + weight, the chains the splat channels), result[4] = {b (normalisation),
  * acceptance rate, splat scale as f32 bits, contribution as f32 bits} (doubles / reinterpreted), chain_states (10 u32 each). */
 OR_EXPORT int or_mcmc_render(const or_scene *sc, const or_mcmc_config *c, float *film, double *result, uint32_t *chain_states, uint32_t n_threads) {
-    ((or_scene *)sc)->color = 0; /* these integrators run in the default sRGB / sRGB pipeline here */
+    ((or_scene *)sc)->color = c->color; /* the pipeline every material evaluation of this render sees */
     const uint32_t W = sc->width, H = sc->height;
     const uint64_t N = (uint64_t)W * H;
     if (c->n_chains == 0 || c->n_bootstrap == 0 || c->sampler_type > 1) return -1;
@@ -1570,7 +1578,7 @@ OR_EXPORT int or_mcmc_render(const or_scene *sc, const or_mcmc_config *c, float 
         or_pt_config d; memset(&d, 0, sizeof d);
         d.spp = (uint32_t)c->direct_spp; d.max_depth = 1; d.rr_depth = 1; d.spp_per_pass = c->spp_per_pass; d.use_nee = c->use_nee;
         d.debug_depth = -1; d.filter_type = c->filter_type; d.filter_radius = c->filter_radius; d.sampler_type = c->sampler_type;
-        d.sampler_seed = c->sampler_seed; d.shard_count = 1;
+        d.sampler_seed = c->sampler_seed; d.shard_count = 1; d.color = c->color;
         if (or_pt_render(sc, &d, film, 0, n_threads, 0) != 0) return -1;
     }
     or_gpt_config pt; memset(&pt, 0, sizeof pt); /* the PathTracer inside McmcOpt::new, mcmc_opt.rs:233-252 */
@@ -1652,10 +1660,10 @@ OR_EXPORT int or_mcmc_render(const or_scene *sc, const or_mcmc_config *c, float 
                 float accept = 0.0f;
                 if (or_isfinite(proposal_f)) accept = (cur_f == 0.0f || !or_isfinite(cur_f)) ? 1.0f : or_clamp(proposal_f / cur_f, 0.0f, 1.0f);
                 {
-                    v3 a = or_splat_value(v3divs(e.l, proposal_f), accept * contribution);
+                    v3 a = or_splat_value(v3divs(e.l, proposal_f), accept * contribution, c->color);
                     float *d = film + 3 * N + 3 * ((uint64_t)e.px + (uint64_t)e.py * W);
                     d[0] += a.x; d[1] += a.y; d[2] += a.z;
-                    v3 b = or_splat_value(v3divs(cur_color, cur_f), (1.0f - accept) * contribution);
+                    v3 b = or_splat_value(v3divs(cur_color, cur_f), (1.0f - accept) * contribution, c->color);
                     d = film + 3 * N + 3 * ((uint64_t)st.cur_pixel[0] + (uint64_t)st.cur_pixel[1] * W);
                     d[0] += b.x; d[1] += b.y; d[2] += b.z;
                 }

@@ -95,4 +95,4 @@ def test_aov_method_json_and_config(hip_lib):
     assert bytes(c) == bytes(abi.AovConfig.default()) and (c.spp, c.aov, c.remap) == (256, abi.AOV_NS, 1)
     cfg = abi.PtConfig()
     assert hip_lib.akr_pt_config_from_json(b'{"method": {"type": "aov", "aov": "ng"}}', C.byref(cfg), None, 0) == capi.ERR_UNSUPPORTED
-    assert C.sizeof(abi.AovConfig) == 48
+    assert C.sizeof(abi.AovConfig) == 56

@@ -33,7 +33,7 @@ def test_gpt_config_default_and_method_json(hip_lib):
     """gpt::Config::default (gpt.rs:48-65); {"type": "gpt"} goes to akr_render_task, not to the pt-config entry point."""
     c = abi.GptConfig()
     assert hip_lib.akr_gpt_config_default(C.byref(c)) == 0
-    assert bytes(c) == bytes(abi.GptConfig.default()) and C.sizeof(abi.GptConfig) == 72 == pyoracle.lib().or_sizeof_gpt_config()
+    assert bytes(c) == bytes(abi.GptConfig.default()) and C.sizeof(abi.GptConfig) == 80 == pyoracle.lib().or_sizeof_gpt_config()
     assert (c.spp, c.max_depth, c.rr_depth, c.spp_per_pass, c.reconnect, c.stride, c.reconstruction, c.reconstruction_iter) == (256, 7, 5, 64, 1, 1, 0, 30)
     cfg = abi.PtConfig()
     assert hip_lib.akr_pt_config_from_json(b'{"method": {"type": "gpt"}}', C.byref(cfg), None, 0) == capi.ERR_UNSUPPORTED
@@ -198,3 +198,14 @@ def test_gpt_and_mcmc_at_1080p_agree_with_the_path_tracer(ctx, cbox_path, root):
     m = film.resolve().reshape(-1, 3).astype(np.float64).mean(0)
     assert res["n_mutations"] >= w * h * 8 - 262144 and 0.5 < res["acceptance_rate"] < 0.99
     assert np.all(np.abs(m - ref) < 0.04 * ref), (m, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("color", [abi.COLOR_REPR_ACESCG, abi.COLOR_RGB_ACESCG | abi.COLOR_REPR_ACESCG])
+@pytest.mark.parametrize("recon", [abi.GPT_RECON_NONE, abi.GPT_RECON_WEIGHTED], ids=["none", "weighted"])
+def test_gpt_in_a_non_default_colour_pipeline(ctx, cbox_path, root, recon, color):
+    """akr_gpt_config.color: materials folded for the pipeline, every splat converted to the film's sRGB primaries (film.rs:167-194)."""
+    sd = make_scene("textured" if recon == abi.GPT_RECON_NONE else "cbox", cbox_path, root, 40, 32)
+    g = both(ctx, sd, gpt_config(spp=4, max_depth=5, rr_depth=2, reconstruction=recon, reconstruction_iter=3, color=color))
+    g0 = both(ctx, sd, gpt_config(spp=4, max_depth=5, rr_depth=2, reconstruction=recon, reconstruction_iter=3))
+    assert n_bit_diff(g, g0) > 0

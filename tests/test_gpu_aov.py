@@ -68,3 +68,21 @@ def test_aov_sharded_and_through_render_task(ctx, cbox_path, tmp_path, monkeypat
     method = {"method": {"type": "aov", "spp": 4, "aov": "albedo", "remap": False}, "film": {"out": "albedo.exr", "filter": {"type": "gaussian", "radius": 1.5}}}
     capi.render_task(ctx, scene, json.dumps(method))
     assert os.path.getsize(tmp_path / "albedo.exr") > 64 * 64 * 12
+
+
+@pytest.mark.parametrize("color", [abi.COLOR_REPR_ACESCG, abi.COLOR_RGB_ACESCG, abi.COLOR_RGB_ACESCG | abi.COLOR_REPR_ACESCG])
+@pytest.mark.parametrize("aov", [abi.AOV_NS, abi.AOV_ALBEDO, abi.AOV_ROUGHNESS], ids=["ns", "albedo", "roughness"])
+def test_aov_in_a_non_default_colour_pipeline(ctx, cbox_path, root, aov, color):
+    """akr_aov_config.color: the materials are folded for the pipeline and every value -- normals included -- goes through the
+    film's conversion to sRGB primaries like a colour (aov.rs:98-124, film.rs:196-229)."""
+    sd = textured_room(40, 32) if aov == abi.AOV_ALBEDO else scene_json.load_scene(cbox_path, 40, 32)
+    sd.ggx_table = table(root)
+    cfg = abi.AovConfig.default()
+    cfg.spp, cfg.aov, cfg.remap, cfg.color = 4, aov, 1, color
+    g = both(ctx, sd, cfg)
+    cfg.color = 0
+    g0 = both(ctx, sd, cfg)
+    if aov != abi.AOV_ALBEDO and not (color & abi.COLOR_REPR_ACESCG):
+        assert n_bit_diff(g, g0) == 0      # no colour constant involved and the film conversion is the identity
+    else:
+        assert n_bit_diff(g, g0) > 0

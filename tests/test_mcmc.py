@@ -147,3 +147,15 @@ def test_mcmc_rejections_and_render_task(ctx, cbox_path, tmp_path, monkeypatch):
     last, final, half = read_exr_rgb(str(tmp_path / "run-8.exr")), read_exr_rgb(str(tmp_path / "mcmc.exr")), read_exr_rgb(str(tmp_path / "run-4.exr"))
     assert np.array_equal(last, final) and not np.array_equal(half, final) and abs(half.mean() - final.mean()) < 0.2 * final.mean()
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("color", [abi.COLOR_REPR_ACESCG, abi.COLOR_RGB_ACESCG | abi.COLOR_REPR_ACESCG])
+def test_mcmc_in_a_non_default_colour_pipeline(ctx, cbox_path, root, color):
+    """akr_mcmc_config.color: the direct pass, the chains' materials and the splats all run in the pipeline."""
+    from tests.test_gpt import make_scene
+
+    sd = make_scene("cbox", cbox_path, root, 36, 28)
+    a = both(ctx, sd, mcmc_config(color=color))
+    b = both(ctx, sd, mcmc_config())
+    assert a["normalization"] != b["normalization"]
