@@ -472,7 +472,9 @@ AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found,
                 // sample_surface_and_shade_direct, pt.rs:297-323
                 ShadePoint sp;
                 shade_point_init(sp, mat, si.frame, si.ng, force_diffuse);
+#ifndef AKR_NO_WO_CACHE  // (A/B switch of tools/r2_ab.sh)
                 if (FD != 1) shade_point_cache_wo(sp, mat, sc.ggx_table, wo);
+#endif
                 if (dl.valid) {
                     BsdfEval e = shade_evaluate(sp, mat, sc.ggx_table, wo, dl.wi);
                     float w = mis_weight(dl.pdf, e.pdf);
