@@ -284,3 +284,22 @@ def test_scene_loader_reads_tiff_and_dds_textures(tmp_path):
         x = [im for im in got.images if im.texels.dtype == np.uint8][0].texels
         y = [im for im in pyl.images if im.texels.dtype == np.uint8][0].texels
         assert np.array_equal(x, want[::-1]) and np.array_equal(x, y)  # flipped vertically like every encoded image
+
+
+def test_files_written_by_other_libraries_if_the_machine_has_them():
+    """CPython ships one small picture in several formats with its test-suite (test/imghdrdata): files written by libpng, libtiff,
+    libjpeg and the OpenEXR library -- the only EXR here that this repository's own writer did not produce. Skipped where absent."""
+    import glob
+    import sysconfig
+
+    roots = [sysconfig.get_paths()["stdlib"]] + glob.glob("/mnt/sandboxing/model_tools_env/*/python/install/lib/python3*") + glob.glob("/usr/lib/python3*")
+    base = next((r + "/test/imghdrdata/" for r in roots if glob.glob(r + "/test/imghdrdata/python.exr")), None)
+    if base is None:
+        pytest.skip("no CPython test data on this machine")
+    ref = np.asarray(Image.open(base + "python.png").convert("RGBA"))
+    assert np.array_equal(capi.host_decode_png(open(base + "python.png", "rb").read()), ref)
+    assert np.array_equal(capi.host_decode_tiff(open(base + "python.tiff", "rb").read()), ref)
+    jpg = capi.host_decode_jpeg(open(base + "python.jpg", "rb").read())
+    assert np.abs(jpg.astype(int) - np.asarray(Image.open(base + "python.jpg").convert("RGBA")).astype(int)).max() <= 3
+    exr = capi.host_decode_exr(open(base + "python.exr", "rb").read())  # uncompressed half RGBA, channels stored A B G R
+    assert exr.shape == ref.shape and np.abs(exr - ref.astype(np.float32) / 255.0).max() < 5e-4
