@@ -177,7 +177,7 @@ void decode_tiff(const uint8_t* data, size_t n, uint32_t& width, uint32_t& heigh
         }
     }
     if (width == 0 || height == 0) throw std::runtime_error("tiff: missing image size");
-    if ((uint64_t)width * height > (1ull << 30)) throw std::runtime_error("tiff: image too large");
+    if ((uint64_t)width * height > (1ull << 28)) throw std::runtime_error("tiff: image too large");
     if (spp < 1 || spp > 4) throw std::runtime_error("unsupported: tiff with " + std::to_string(spp) + " samples per pixel");
     uint32_t bits = 1;
     if (f_bits.count) {
@@ -325,7 +325,7 @@ void decode_dds(const uint8_t* data, size_t n, uint32_t& width, uint32_t& height
     } else {
         throw std::runtime_error("unsupported: dds FourCC");
     }
-    if (width == 0 || height == 0 || (uint64_t)width * height > (1ull << 30)) throw std::runtime_error("dds: bad image size");
+    if (width == 0 || height == 0 || (uint64_t)width * height > (1ull << 28)) throw std::runtime_error("dds: bad image size");
     const uint32_t bw = (width + 3) / 4, bh = (height + 3) / 4;
     const size_t block = kind == 1 ? 8 : 16;
     if (at > n || (size_t)bw * bh * block > n - at) throw std::runtime_error("dds: truncated block data");

@@ -347,6 +347,7 @@ void decode_png(const uint8_t* data, size_t n, uint32_t& w, uint32_t& h, std::ve
         pos += 12 + (size_t)len;
     }
     if (!have_hdr || w == 0 || h == 0) throw std::runtime_error("png: missing IHDR");
+    if ((uint64_t)w * h > (1ull << 28)) throw std::runtime_error("png: image too large");
     int channels;
     switch (ctype) {
         case 0: channels = 1; break;
@@ -548,11 +549,11 @@ struct JpegComp {
     std::vector<int16_t> coef;  // 64 per block
     std::vector<uint8_t> plane; // bw*8 x bh*8 after the IDCT
 };
-inline uint8_t clamp8(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+inline uint8_t clamp8(int64_t x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
 #define AKR_F2F(x) ((int)(((x) * 4096 + 0.5)))
 #define AKR_FSH(x) ((x) * 4096)
 #define AKR_IDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7)                         \
-    int t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                  \
+    int64_t t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3; /* 64 bit: a corrupt file's coefficients must not overflow */ \
     p2 = s2; p3 = s6;                                                        \
     p1 = (p2 + p3) * AKR_F2F(0.5411961f);                                    \
     t2 = p1 + p3 * AKR_F2F(-1.847759065f);                                   \
@@ -569,12 +570,12 @@ inline uint8_t clamp8(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x))
     p3 = p3 * AKR_F2F(-1.961570560f); p4 = p4 * AKR_F2F(-0.390180644f);      \
     t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
 void idct_block(uint8_t* out, int stride, const int16_t* coef, const uint16_t* q) {
-    int val[64], *v = val, d[64];
-    for (int i = 0; i < 64; i++) d[i] = coef[i] * (int)q[i];
-    const int* dd = d;
+    int64_t val[64], *v = val, d[64];
+    for (int i = 0; i < 64; i++) d[i] = (int64_t)coef[i] * (int64_t)q[i];
+    const int64_t* dd = d;
     for (int i = 0; i < 8; i++, dd++, v++) {
         if (dd[8] == 0 && dd[16] == 0 && dd[24] == 0 && dd[32] == 0 && dd[40] == 0 && dd[48] == 0 && dd[56] == 0) {
-            int dcterm = dd[0] * 4;
+            int64_t dcterm = dd[0] * 4;
             v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dcterm;
         } else {
             AKR_IDCT_1D(dd[0], dd[8], dd[16], dd[24], dd[32], dd[40], dd[48], dd[56])
@@ -686,6 +687,7 @@ void decode_jpeg(const uint8_t* data, size_t n, uint32_t& width, uint32_t& heigh
             width = (uint32_t)((seg[3] << 8) | seg[4]);
             int nc = seg[5];
             if (width == 0 || height == 0) throw std::runtime_error("jpeg: zero-sized image");
+            if ((uint64_t)width * height > (1ull << 28)) throw std::runtime_error("jpeg: image too large");
             if (nc != 1 && nc != 3) throw std::runtime_error("unsupported: JPEG with " + std::to_string(nc) + " components");
             if (sl < 6 + 3 * nc) throw std::runtime_error("jpeg: bad SOF");
             comps.resize((size_t)nc);
@@ -1050,8 +1052,8 @@ void decode_exr(const uint8_t* data, size_t n, uint32_t& width, uint32_t& height
     if (chans.empty() || dw[2] < dw[0] || dw[3] < dw[1]) throw std::runtime_error("exr: missing channels or data window");
     if (compression < 0 || compression > 3) throw std::runtime_error("unsupported: OpenEXR compression method " + std::to_string(compression) + " (none, RLE, ZIPS and ZIP are read)");
     (void)line_order;  // the offset table is indexed by scanline block in increasing y whatever the order on disk
-    const uint64_t W = (uint64_t)(dw[2] - dw[0]) + 1, H = (uint64_t)(dw[3] - dw[1]) + 1;
-    if (W > 65535 || H > 65535) throw std::runtime_error("exr: image too large");
+    const uint64_t W = (uint64_t)((int64_t)dw[2] - (int64_t)dw[0] + 1), H = (uint64_t)((int64_t)dw[3] - (int64_t)dw[1] + 1);
+    if (W > 65535 || H > 65535 || W * H > (1ull << 28)) throw std::runtime_error("exr: image too large");
     width = (uint32_t)W;
     height = (uint32_t)H;
     const uint32_t lines_per_block = compression == 3 ? 16u : 1u;

@@ -165,10 +165,13 @@ struct BufferStore {
     std::vector<T> view(const JsonValue& ref) {
         const JsonValue& v = scene.at("buffer_views").at(ref.at("id").as_string());
         const std::string& data = buffer(v.at("buffer").at("id").as_string());
-        size_t off = (size_t)v.at("offset").as_number(), len = (size_t)v.at("length").as_number();
-        if (off + len > data.size()) throw std::runtime_error("buffer view out of range");
+        const double off_d = v.at("offset").as_number(), len_d = v.at("length").as_number();
+        // validated as numbers first: a negative or huge value must not wrap around in size_t arithmetic
+        if (!(off_d >= 0.0 && len_d >= 0.0 && off_d <= (double)data.size() && len_d <= (double)data.size() - off_d))
+            throw std::runtime_error("buffer view out of range");
+        const size_t off = (size_t)off_d, len = (size_t)len_d;
         std::vector<T> out(len / sizeof(T));
-        std::memcpy(out.data(), data.data() + off, out.size() * sizeof(T));
+        if (!out.empty()) std::memcpy(out.data(), data.data() + off, out.size() * sizeof(T));
         return out;
     }
 };

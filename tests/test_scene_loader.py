@@ -66,3 +66,24 @@ def test_base64_and_relative_buffers(hip_lib, tmp_path, cbox_path):
     _same(capi.Scene(None, str(tmp_path / "a.json")).to_scene_data(), ref)
     _same(capi.Scene(None, str(tmp_path / "b.json")).to_scene_data(), ref)
     _same(scene_json.load_scene(str(tmp_path / "a.json")), scene_json.load_scene(cbox_path))
+
+
+def test_buffer_views_outside_their_buffer_are_refused(hip_lib, tmp_path, cbox_path):
+    """A negative or huge offset / length must not wrap around in the bounds check (found by tools/fuzz/scene_json.cpp)."""
+    import json
+    import shutil
+
+    import pytest
+
+    src = os.path.dirname(cbox_path)
+    dst = tmp_path / "cbox"
+    shutil.copytree(src, dst)
+    scene = json.load(open(dst / "scene.json"))
+    key = sorted(scene["buffer_views"])[0]
+    for field, value in (("offset", -1), ("offset", 99999999999), ("offset", 1e30), ("length", -4), ("length", 4294967296.0), ("offset", 18446744073709551615)):
+        bad = json.loads(json.dumps(scene))
+        bad["buffer_views"][key][field] = value
+        (dst / "bad.json").write_text(json.dumps(bad))
+        with pytest.raises(capi.AkariError) as e:
+            capi.Scene(None, str(dst / "bad.json"), 16, 16)
+        assert "buffer view" in str(e.value) or "json" in str(e.value).lower(), str(e.value)
