@@ -71,7 +71,16 @@ class JsonParser {
         if (peek() != c) fail(std::string("expected '") + c + "'");
         pos_++;
     }
+    // serde_json, which reads these files in the reference, refuses documents nested deeper than 128 levels; so does this reader
+    // (a recursive-descent parser must not let a file of brackets overflow the stack)
+    struct Depth {
+        int& d;
+        explicit Depth(int& dd) : d(dd) { d++; }
+        ~Depth() { d--; }
+    };
     JsonPtr value() {
+        Depth guard(depth_);
+        if (depth_ > 128) fail("recursion limit exceeded");
         skip_ws();
         auto v = std::make_shared<JsonValue>();
         char c = peek();
@@ -158,6 +167,7 @@ class JsonParser {
     }
     const std::string& s_;
     size_t pos_ = 0;
+    int depth_ = 0;
 };
 
 }  // namespace akr

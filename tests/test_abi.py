@@ -96,3 +96,11 @@ def test_aov_method_json_and_config(hip_lib):
     cfg = abi.PtConfig()
     assert hip_lib.akr_pt_config_from_json(b'{"method": {"type": "aov", "aov": "ng"}}', C.byref(cfg), None, 0) == capi.ERR_UNSUPPORTED
     assert C.sizeof(abi.AovConfig) == 56
+
+
+def test_json_nesting_limit(hip_lib):
+    """A file of two million brackets is refused (serde_json's 128-level recursion limit), not a stack overflow."""
+    cfg = abi.PtConfig()
+    for doc in (b"[" * 2_000_000, b'{"a":' * 2_000_000, b"[" * 129 + b"]" * 129):
+        assert hip_lib.akr_pt_config_from_json(doc, C.byref(cfg), None, 0) == capi.ERR_PARSE
+    assert hip_lib.akr_pt_config_from_json(b'{"x": ' + b"[" * 100 + b"]" * 100 + b"}", C.byref(cfg), None, 0) == 0
