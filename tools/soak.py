@@ -1,0 +1,129 @@
+"""Randomised parity soak: random small scenes (random triangle soups + a few quads, random materials drawn from edge values,
+random emitters, cameras, samplers, configs, colour pipelines), the HIP path tracer against the oracle, film accumulators and
+counters bit for bit. Prints the seeds that differ. python tools/soak.py [n_cases] [first_seed]   (needs a GPU; uses oracle/)"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from akari_render_amd import abi, capi
+from oracle import pyoracle
+
+EDGE = [0.0, 1e-5, 1e-4, 0.03, 0.25, 0.5, 0.75, 0.9999, 1.0]
+
+
+def rand_material(rng, emissive=False):
+    pick = lambda: float(rng.choice(EDGE)) if rng.random() < 0.5 else float(rng.random())  # noqa: E731
+    col = lambda s=1.0: tuple(float(x) * s for x in (rng.random(3) if rng.random() < 0.8 else rng.choice([0.0, 1.0], 3)))  # noqa: E731
+    kind = int(rng.choice([abi.MAT_PRINCIPLED] * 6 + [abi.MAT_DIFFUSE, abi.MAT_GLASS]))
+    m = abi.MaterialData(kind=kind, base_color=col(), metallic=pick() if rng.random() < 0.4 else 0.0, roughness=pick(),
+                         ior=float(rng.choice([1.0, 1.0001, 1.33, 1.45, 1.5, 2.4, 0.8])), specular_ior_level=float(rng.choice([0.0, 0.5, 0.5, 1.0, pick()])),
+                         specular_tint=col() if rng.random() < 0.3 else (1.0, 1.0, 1.0), transmission_weight=pick() if rng.random() < 0.25 else 0.0,
+                         coat_weight=pick() if rng.random() < 0.25 else 0.0, coat_roughness=pick(), coat_ior=float(rng.choice([1.0, 1.5, 1.8])),
+                         coat_tint=col() if rng.random() < 0.3 else (1.0, 1.0, 1.0),
+                         normal=tuple(float(x) for x in rng.normal(size=3)) if rng.random() < 0.15 else (0.0, 0.0, 0.0),
+                         base_alpha=float(rng.choice([1.0, 1.0, 1.0, 0.5, 0.0])))
+    if emissive:
+        m.emission_color, m.emission_strength = col(float(rng.choice([1.0, 5.0, 40.0]))), float(rng.choice([1.0, 0.5, 3.0]))
+        if kind != abi.MAT_PRINCIPLED and rng.random() < 0.5:
+            m.kind = abi.MAT_EMISSION
+    if rng.random() < 0.2:
+        m.colorspaces = int(rng.integers(0, 16)) << 8
+    return m
+
+
+def rand_scene(seed):
+    rng = np.random.default_rng(seed)
+    w, h = int(rng.integers(8, 40)), int(rng.integers(8, 40))
+    n_mats = int(rng.integers(1, 6))
+    mats = [rand_material(rng) for _ in range(n_mats)] + [rand_material(rng, True) for _ in range(int(rng.integers(0, 3)))]
+    meshes, insts = [], []
+    eye = np.eye(4, dtype=np.float32)
+    n_meshes = int(rng.integers(1, 5))
+    big = rng.random() < 0.35  # enough triangles for the BVH path
+    for mi in range(n_meshes):
+        nt = int(rng.integers(1, 60 if big else 12))
+        if rng.random() < 0.5:  # soup of random triangles in [-1, 1]^3, some degenerate / tiny / huge
+            c = rng.uniform(-1, 1, size=(nt, 1, 3))
+            e = rng.normal(size=(nt, 3, 3)) * rng.choice([1e-3, 0.1, 0.5, 2.0], size=(nt, 1, 1))
+            tri = (c + e).astype(np.float32)
+            if rng.random() < 0.3:
+                tri[0, 2] = tri[0, 1]  # a degenerate triangle
+            verts = tri.reshape(-1, 3)
+            idx = np.arange(3 * nt, dtype=np.uint32).reshape(nt, 3)
+        else:  # a grid patch with shared vertices (coplanar neighbours: the plane-sharing rule)
+            n = max(1, int(np.sqrt(nt / 2)))
+            xs = np.linspace(-1, 1, n + 1, dtype=np.float32)
+            y = np.float32(rng.uniform(-1, 1))
+            verts = np.array([[xs[i], y, xs[j]] for j in range(n + 1) for i in range(n + 1)], dtype=np.float32)
+            idx = []
+            for j in range(n):
+                for i in range(n):
+                    a, b, c2, d = j * (n + 1) + i, j * (n + 1) + i + 1, (j + 1) * (n + 1) + i + 1, (j + 1) * (n + 1) + i
+                    idx += [[a, c2, b], [a, d, c2]] if rng.random() < 0.5 else [[a, b, c2], [a, c2, d]]
+            idx = np.array(idx, dtype=np.uint32)
+        nt = idx.shape[0]
+        n_slots = int(rng.integers(1, 4))
+        slots = rng.integers(0, n_slots, size=nt).astype(np.uint32) if n_slots > 1 else None
+        normals = None
+        if rng.random() < 0.3:
+            nn = rng.normal(size=(nt, 3, 3)).astype(np.float32)
+            normals = (nn / np.linalg.norm(nn, axis=2, keepdims=True)).astype(np.float32)
+        uvs = rng.random((nt, 3, 2)).astype(np.float32) if rng.random() < 0.3 else None
+        meshes.append(abi.MeshData(vertices=np.ascontiguousarray(verts), indices=idx, material_slots=slots, normals=normals, uvs=uvs))
+        for _ in range(int(rng.integers(1, 3))):
+            t = eye.copy()
+            if rng.random() < 0.6:
+                a = np.float32(rng.uniform(0, 6.28))
+                t[:3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], dtype=np.float32) * np.float32(rng.choice([0.5, 1.0, 1.7, -1.0]))
+                t[:3, 3] = rng.uniform(-0.5, 0.5, size=3).astype(np.float32)
+            insts.append(abi.InstanceData(mi, [int(rng.integers(0, len(mats))) for _ in range(n_slots)], t.T.reshape(16).copy()))
+    c2w = eye.copy()
+    c2w[:3, 3] = rng.uniform(-0.5, 0.5, size=3).astype(np.float32) + np.array([0, 0, 2.5], dtype=np.float32) * np.float32(rng.random() < 0.7)
+    cam = abi.CameraData(c2w=c2w.T.reshape(16).copy(), fov=float(rng.uniform(0.3, 2.2)), width=w, height=h)
+    sd = abi.SceneData(meshes, insts, mats, cam)
+    cfg = abi.PtConfig.default()
+    cfg.spp = int(rng.integers(1, 7)); cfg.spp_per_pass = int(rng.integers(1, cfg.spp + 1))
+    cfg.max_depth = int(rng.integers(1, 9)); cfg.rr_depth = int(rng.integers(0, 6))
+    cfg.use_nee = int(rng.random() < 0.85); cfg.indirect_only = int(rng.random() < 0.1); cfg.force_diffuse = int(rng.random() < 0.25)
+    cfg.filter_type = int(rng.choice([abi.FILTER_BOX, abi.FILTER_GAUSSIAN])); cfg.filter_radius = float(rng.choice([0.5, 1.0, 1.5]))
+    cfg.sampler_type = int(rng.choice([abi.SAMPLER_INDEPENDENT] * 3 + [abi.SAMPLER_SOBOL, abi.SAMPLER_PMJ02BN]))
+    cfg.sampler_seed = int(rng.integers(0, 1 << 40))
+    cfg.color = int(rng.choice([0, 0, 0, 1, 2, 3]))
+    if rng.random() < 0.15:
+        cfg.debug_depth = int(rng.integers(0, 4))
+    return sd, cfg
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    table = np.fromfile(os.path.join(ROOT, "tests/golden/ggx_dielectric_s.f32"), dtype=np.float32)
+    ctx = capi.Context(0)
+    pyoracle.set_pmj_tables(*capi.host_pmj02bn_tables())
+    bad, refused, t0 = [], 0, time.time()
+    kinds = {"exhaustive": 0, "bvh": 0}
+    for seed in range(first, first + n):
+        sd, cfg = rand_scene(seed)
+        sd.ggx_table = table
+        try:
+            scene = capi.Scene(ctx, sd)
+        except capi.AkariError as e:
+            refused += 1
+            continue
+        kinds["bvh" if scene.info().uses_bvh else "exhaustive"] += 1
+        w, h = sd.camera.width, sd.camera.height
+        film = capi.Film(ctx, w, h)
+        st = capi.pt_render(ctx, scene, cfg, film)
+        g = film.read()
+        o, ost = pyoracle.OracleScene(sd).render(cfg)
+        nd = int(np.count_nonzero(g.view(np.uint32) != o.view(np.uint32)))
+        same_counts = all(int(st[k]) == int(ost[k]) for k in ("n_samples", "n_closest", "n_shadow", "n_shaded"))
+        if nd or not same_counts:
+            bad.append((seed, nd, {k: (int(st[k]), int(ost[k])) for k in ("n_samples", "n_closest", "n_shadow", "n_shaded")}))
+            print("MISMATCH seed", seed, "floats", nd, bad[-1][2], flush=True)
+    print(f"{n} cases from seed {first}: {len(bad)} mismatches, {refused} scenes refused, {kinds}, {time.time() - t0:.1f} s")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
