@@ -276,8 +276,13 @@ static void compile_graph(const HostGraph& g, const std::vector<HostImage>& imag
         }
     }
     dm.flags |= MF_TEXTURED;
-    if (map[AKR_IN_BASE_COLOR] != AKR_NODE_NONE && (dm.kind == MAT_PRINCIPLED || dm.kind == MAT_DIFFUSE) && !alpha_is_one(g, images, map[AKR_IN_BASE_COLOR]))
-        dm.flags |= MF_ALPHA_TEXTURED;
+    if (map[AKR_IN_BASE_COLOR] != AKR_NODE_NONE && (dm.kind == MAT_PRINCIPLED || dm.kind == MAT_DIFFUSE)) {
+        // the alpha of a node-fed base colour is the node's, never the constant of the description: either the graph is evaluated
+        // per candidate hit, or -- the node's alpha is 1 everywhere -- the folded record says so (found by tools/soak.py: a constant
+        // base_alpha below 1 next to an opaque texture-fed base colour made the alpha test read the constant)
+        if (!alpha_is_one(g, images, map[AKR_IN_BASE_COLOR])) dm.flags |= MF_ALPHA_TEXTURED;
+        else dm.base_alpha = 1.0f;
+    }
     dm.tex_first_node = first;
     dm.tex_n_nodes = count;
     for (uint32_t k = 0; k < AKR_IN_COUNT; k++) dm.tex_input[k] = map[k] == AKR_NODE_NONE ? AKR_NODE_NONE : remap[map[k]];

@@ -517,3 +517,21 @@ def test_unorm8_reciprocal_form_is_a_correctly_rounded_division():
         r = Fraction(b) - 255 * q
         assert rn32(r) == r
         assert float(rn32(q + r * y)) == float(np.float32(b) / np.float32(255.0)), b
+
+
+def test_constant_alpha_next_to_an_opaque_texture_fed_base_colour():
+    """The alpha of a node-fed base colour is the node's (principled.rs:15-21), never the description's constant: with an opaque
+    image feeding base_color the folded record carries alpha 1 (and no per-candidate graph evaluation), whatever base_alpha says.
+    Found by tools/soak.py -- every designed scene had left the constant at 1."""
+    sd = textured_room()
+    for m in sd.materials:
+        m.base_alpha = 0.25
+    mats = capi.Scene(None, sd).array(capi.ARRAY_MATERIALS, np.uint32).reshape(-1, 64)
+    flags = [(int(f) >> 8) & 3 for f in mats[:, 1]]
+    alpha = mats[:, 2].view(np.float32)
+    assert flags[1] == 1 and alpha[1] == 1.0          # back wall: opaque byte image -> base colour
+    assert flags[0] == 1 and alpha[0] == 1.0          # floor: checkerboard of two constants
+    assert flags[3] == 0 and alpha[3] == np.float32(0.25)  # constant material: the constant counts
+    osc = pyoracle.OracleScene(sd)
+    uv = np.random.default_rng(0).random((16, 2), dtype=np.float32)
+    assert np.all(osc.material_inputs(1, uv)[:, 4] == 1.0) and np.all(osc.material_inputs(3, uv)[:, 4] == np.float32(0.25))

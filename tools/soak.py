@@ -1,6 +1,7 @@
 """Randomised parity soak: random small scenes (random triangle soups + a few quads, random materials drawn from edge values,
-random emitters, cameras, samplers, configs, colour pipelines), the HIP path tracer against the oracle, film accumulators and
-counters bit for bit. Prints the seeds that differ. python tools/soak.py [n_cases] [first_seed]   (needs a GPU; uses oracle/)"""
+random emitters, cameras, samplers, configs, colour pipelines; a third of them with random images and random shader-graph DAGs
+feeding random inputs), the HIP path tracer against the oracle, film accumulators and
+counters bit for bit. Prints the seeds that differ. python tools/soak.py [n_cases] [first_seed] [tex]   (needs a GPU; uses oracle/)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -31,8 +32,58 @@ def rand_material(rng, emissive=False):
     return m
 
 
-def rand_scene(seed):
+def rand_images(rng):
+    out = []
+    for _ in range(int(rng.integers(1, 4))):
+        h, w = int(rng.integers(1, 10)), int(rng.integers(1, 10))
+        if rng.random() < 0.5:
+            t = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+            t[:, :, 3] = np.where(rng.random((h, w)) < (0.3 if rng.random() < 0.4 else 0.0), 0, 255)
+        else:
+            t = rng.random((h, w, 4)).astype(np.float32)
+            t[:, :, 3] = np.where(rng.random((h, w)) < (0.3 if rng.random() < 0.3 else 0.0), 0.25, 1.0)
+        out.append(abi.ImageData(t, int(rng.integers(0, 2)), int(rng.integers(0, 4))))
+    return out
+
+
+def rand_graph(rng, n_images):
+    """An arbitrary DAG of the ten node kinds (values are float4 whatever the node: every wiring is legal) feeding a random
+    subset of the surface node's inputs."""
+    N = abi.NodeData
+    nodes = []
+    k3 = lambda hi=1.5: tuple(float(x) for x in rng.uniform(0.0, hi, size=3))  # noqa: E731
+    for i in range(int(rng.integers(1, 11))):
+        prev = lambda none_ok=False: (abi.NODE_NONE if (none_ok and (i == 0 or rng.random() < 0.5)) else int(rng.integers(0, i)))  # noqa: E731
+        ops = [abi.NODE_CONST, abi.NODE_RGB, abi.NODE_TEXCOORDS, abi.NODE_IMAGE, abi.NODE_IMAGE]
+        if i > 0:
+            ops += [abi.NODE_MAPPING, abi.NODE_CHECKERBOARD, abi.NODE_SPECTRAL_UPLIFT, abi.NODE_SEPARATE_COLOR, abi.NODE_EXTRACT, abi.NODE_NORMAL_MAP, abi.NODE_IMAGE]
+        op = int(rng.choice(ops))
+        if op == abi.NODE_CONST:
+            nodes.append(N(op, (), k3(3.0)))
+        elif op == abi.NODE_RGB:
+            nodes.append(N(op, (int(rng.integers(0, 2)),), k3(1.0)))
+        elif op == abi.NODE_TEXCOORDS:
+            nodes.append(N(op))
+        elif op == abi.NODE_IMAGE:
+            nodes.append(N(op, (int(rng.integers(0, n_images)), prev(True), int(rng.integers(0, 2)))))
+        elif op == abi.NODE_MAPPING:
+            nodes.append(N(op, (prev(), prev(), prev(), int(rng.integers(0, 2)))))
+        elif op == abi.NODE_CHECKERBOARD:
+            nodes.append(N(op, (prev(True), prev(), prev(), prev())))
+        elif op in (abi.NODE_SPECTRAL_UPLIFT, abi.NODE_SEPARATE_COLOR):
+            nodes.append(N(op, (prev(),)))
+        elif op == abi.NODE_EXTRACT:
+            nodes.append(N(op, (prev(), int(rng.integers(0, 4)))))
+        else:
+            nodes.append(N(op, (prev(), prev())))
+    names = [n for n in abi.INPUT_NAMES if rng.random() < 0.25] or ["base_color"]
+    return abi.GraphData(nodes, {n: int(rng.integers(0, len(nodes))) for n in names})
+
+
+def rand_scene(seed, textures=None):
     rng = np.random.default_rng(seed)
+    textured = (rng.random() < 0.35) if textures is None else textures
+    images = rand_images(rng) if textured else []
     w, h = int(rng.integers(8, 40)), int(rng.integers(8, 40))
     n_mats = int(rng.integers(1, 6))
     mats = [rand_material(rng) for _ in range(n_mats)] + [rand_material(rng, True) for _ in range(int(rng.integers(0, 3)))]
@@ -68,7 +119,7 @@ def rand_scene(seed):
         if rng.random() < 0.3:
             nn = rng.normal(size=(nt, 3, 3)).astype(np.float32)
             normals = (nn / np.linalg.norm(nn, axis=2, keepdims=True)).astype(np.float32)
-        uvs = rng.random((nt, 3, 2)).astype(np.float32) if rng.random() < 0.3 else None
+        uvs = (rng.random((nt, 3, 2)) * rng.choice([1.0, 3.0, -2.0])).astype(np.float32) if rng.random() < (0.8 if textured else 0.3) else None
         meshes.append(abi.MeshData(vertices=np.ascontiguousarray(verts), indices=idx, material_slots=slots, normals=normals, uvs=uvs))
         for _ in range(int(rng.integers(1, 3))):
             t = eye.copy()
@@ -80,7 +131,11 @@ def rand_scene(seed):
     c2w = eye.copy()
     c2w[:3, 3] = rng.uniform(-0.5, 0.5, size=3).astype(np.float32) + np.array([0, 0, 2.5], dtype=np.float32) * np.float32(rng.random() < 0.7)
     cam = abi.CameraData(c2w=c2w.T.reshape(16).copy(), fov=float(rng.uniform(0.3, 2.2)), width=w, height=h)
-    sd = abi.SceneData(meshes, insts, mats, cam)
+    if textured:
+        for m in mats:
+            if rng.random() < 0.6:
+                m.graph = rand_graph(rng, len(images))
+    sd = abi.SceneData(meshes, insts, mats, cam, images=images)
     cfg = abi.PtConfig.default()
     cfg.spp = int(rng.integers(1, 7)); cfg.spp_per_pass = int(rng.integers(1, cfg.spp + 1))
     cfg.max_depth = int(rng.integers(1, 9)); cfg.rr_depth = int(rng.integers(0, 6))
@@ -97,20 +152,24 @@ def rand_scene(seed):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    textures = True if (len(sys.argv) > 3 and sys.argv[3] == "tex") else None  # "tex": every scene with images and shader graphs
     table = np.fromfile(os.path.join(ROOT, "tests/golden/ggx_dielectric_s.f32"), dtype=np.float32)
     ctx = capi.Context(0)
     pyoracle.set_pmj_tables(*capi.host_pmj02bn_tables())
     bad, refused, t0 = [], 0, time.time()
-    kinds = {"exhaustive": 0, "bvh": 0}
+    kinds = {"exhaustive": 0, "bvh": 0, "textured": 0}
     for seed in range(first, first + n):
-        sd, cfg = rand_scene(seed)
+        sd, cfg = rand_scene(seed, textures)
         sd.ggx_table = table
         try:
             scene = capi.Scene(ctx, sd)
         except capi.AkariError as e:
             refused += 1
+            if refused <= 3:
+                print("refused seed", seed, str(e)[:120], flush=True)
             continue
         kinds["bvh" if scene.info().uses_bvh else "exhaustive"] += 1
+        kinds["textured"] += int(bool(sd.images))
         w, h = sd.camera.width, sd.camera.height
         film = capi.Film(ctx, w, h)
         st = capi.pt_render(ctx, scene, cfg, film)
