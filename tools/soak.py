@@ -1,7 +1,7 @@
 """Randomised parity soak: random small scenes (random triangle soups + a few quads, random materials drawn from edge values,
 random emitters, cameras, samplers, configs, colour pipelines; a third of them with random images and random shader-graph DAGs
 feeding random inputs), the HIP path tracer against the oracle, film accumulators and
-counters bit for bit. Prints the seeds that differ. python tools/soak.py [n_cases] [first_seed] [tex]   (needs a GPU; uses oracle/)"""
+counters bit for bit. Prints the seeds that differ. python tools/soak.py [n_cases] [first_seed] [tex] [aov | gpt | wavefront]   (needs a GPU; uses oracle/)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -149,10 +149,54 @@ def rand_scene(seed, textures=None):
     return sd, cfg
 
 
+def run_pt(ctx, scene, sd, cfg, rng):
+    w, h = sd.camera.width, sd.camera.height
+    film = capi.Film(ctx, w, h)
+    st = capi.pt_render(ctx, scene, cfg, film)
+    g = film.read()
+    o, ost = pyoracle.OracleScene(sd).render(cfg)
+    nd = int(np.count_nonzero(g.view(np.uint32) != o.view(np.uint32)))
+    counts = {k: (int(st[k]), int(ost[k])) for k in ("n_samples", "n_closest", "n_shadow", "n_shaded")}
+    return nd, all(a == b for a, b in counts.values()), counts
+
+
+def run_aov(ctx, scene, sd, cfg, rng):
+    c = abi.AovConfig.default()
+    c.spp, c.aov, c.remap = int(rng.integers(1, 5)), int(rng.integers(0, 6)), int(rng.integers(0, 2))
+    c.filter_type, c.filter_radius, c.sampler_type, c.sampler_seed, c.color = cfg.filter_type, cfg.filter_radius, cfg.sampler_type, cfg.sampler_seed, cfg.color
+    film = capi.Film(ctx, sd.camera.width, sd.camera.height)
+    st = capi.aov_render(ctx, scene, c, film)
+    o, n_rays = pyoracle.OracleScene(sd).aov_render(c)
+    g = film.read()
+    return int(np.count_nonzero(g.view(np.uint32) != o.view(np.uint32))), int(st["n_samples"]) == int(n_rays), {"aov": c.aov}
+
+
+def run_gpt(ctx, scene, sd, cfg, rng):
+    c = abi.GptConfig.default()
+    c.spp, c.max_depth, c.rr_depth, c.spp_per_pass = int(rng.integers(1, 4)), min(cfg.max_depth, 5), cfg.rr_depth, 2
+    c.use_nee, c.indirect_only = cfg.use_nee, cfg.indirect_only
+    c.reconstruction, c.reconstruction_iter, c.separate_weights = int(rng.integers(0, 3)), int(rng.integers(1, 5)), int(rng.integers(0, 2))
+    c.stride = int(rng.integers(1, 3))
+    c.filter_type, c.filter_radius, c.sampler_seed, c.color = cfg.filter_type, cfg.filter_radius, cfg.sampler_seed, cfg.color
+    w, h = sd.camera.width, sd.camera.height
+    if c.stride >= min(w, h):
+        c.stride = 1
+    film = capi.Film(ctx, w, h)
+    capi.gpt_render(ctx, scene, c, film, want_aux=False)
+    o, _ = pyoracle.OracleScene(sd).gpt_render(c)
+    g = film.read()
+    return int(np.count_nonzero(g.view(np.uint32) != o.view(np.uint32))), True, {"recon": c.reconstruction}
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    textures = True if (len(sys.argv) > 3 and sys.argv[3] == "tex") else None  # "tex": every scene with images and shader graphs
+    opts = sys.argv[3:]
+    textures = True if "tex" in opts else None  # "tex": every scene with images and shader graphs
+    runner = run_aov if "aov" in opts else run_gpt if "gpt" in opts else run_pt   # which integrator (default: the path tracer)
+    if "wavefront" in opts:  # the path tracer's wavefront schedule instead of the megakernel
+        os.environ["AKR_PT_MODE"] = "wavefront"
+        os.environ["AKR_FORCE_BVH"] = "1"
     table = np.fromfile(os.path.join(ROOT, "tests/golden/ggx_dielectric_s.f32"), dtype=np.float32)
     ctx = capi.Context(0)
     pyoracle.set_pmj_tables(*capi.host_pmj02bn_tables())
@@ -160,6 +204,8 @@ def main():
     kinds = {"exhaustive": 0, "bvh": 0, "textured": 0}
     for seed in range(first, first + n):
         sd, cfg = rand_scene(seed, textures)
+        if runner is run_gpt:
+            cfg.sampler_type = abi.SAMPLER_INDEPENDENT  # gpt: independent sampler only
         sd.ggx_table = table
         try:
             scene = capi.Scene(ctx, sd)
@@ -170,17 +216,17 @@ def main():
             continue
         kinds["bvh" if scene.info().uses_bvh else "exhaustive"] += 1
         kinds["textured"] += int(bool(sd.images))
-        w, h = sd.camera.width, sd.camera.height
-        film = capi.Film(ctx, w, h)
-        st = capi.pt_render(ctx, scene, cfg, film)
-        g = film.read()
-        o, ost = pyoracle.OracleScene(sd).render(cfg)
-        nd = int(np.count_nonzero(g.view(np.uint32) != o.view(np.uint32)))
-        same_counts = all(int(st[k]) == int(ost[k]) for k in ("n_samples", "n_closest", "n_shadow", "n_shaded"))
+        try:
+            nd, same_counts, info = runner(ctx, scene, sd, cfg, np.random.default_rng(seed + 7))
+        except capi.AkariError as e:
+            refused += 1
+            if refused <= 3:
+                print("render refused seed", seed, str(e)[:120], flush=True)
+            continue
         if nd or not same_counts:
-            bad.append((seed, nd, {k: (int(st[k]), int(ost[k])) for k in ("n_samples", "n_closest", "n_shadow", "n_shaded")}))
-            print("MISMATCH seed", seed, "floats", nd, bad[-1][2], flush=True)
-    print(f"{n} cases from seed {first}: {len(bad)} mismatches, {refused} scenes refused, {kinds}, {time.time() - t0:.1f} s")
+            bad.append((seed, nd, info))
+            print("MISMATCH seed", seed, "floats", nd, info, flush=True)
+    print(f"{runner.__name__} {opts}: {n} cases from seed {first}: {len(bad)} mismatches, {refused} refused, {kinds}, {time.time() - t0:.1f} s")
     return 1 if bad else 0
 
 
