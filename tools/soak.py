@@ -1,7 +1,7 @@
 """Randomised parity soak: random small scenes (random triangle soups + a few quads, random materials drawn from edge values,
 random emitters, cameras, samplers, configs, colour pipelines; a third of them with random images and random shader-graph DAGs
 feeding random inputs), the HIP path tracer against the oracle, film accumulators and
-counters bit for bit. Prints the seeds that differ. python tools/soak.py [n_cases] [first_seed] [tex] [aov | gpt | wavefront]   (needs a GPU; uses oracle/)"""
+counters bit for bit. Prints the seeds that differ. python tools/soak.py [n_cases] [first_seed] [tex] [aov | gpt | mcmc | shard | wavefront]   (needs a GPU; uses oracle/)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -188,12 +188,58 @@ def run_gpt(ctx, scene, sd, cfg, rng):
     return int(np.count_nonzero(g.view(np.uint32) != o.view(np.uint32))), True, {"recon": c.reconstruction}
 
 
+def run_shard(ctx, scene, sd, cfg, rng):
+    """every rank of a random world renders its tiles; the films summed = the oracle's full frame"""
+    w, h = sd.camera.width, sd.camera.height
+    world = int(rng.integers(2, 5))
+    tw, th = int(rng.choice([8, 16, 32, 64])), int(rng.choice([8, 16, 32]))  # multiples of 8 (akr_pt_config)
+    total = np.zeros(7 * w * h, dtype=np.float32)
+    counts = {k: 0 for k in ("n_samples", "n_closest", "n_shadow", "n_shaded")}
+    for rank in range(world):
+        c = abi.PtConfig.from_buffer_copy(bytes(cfg))
+        c.shard_rank, c.shard_count, c.tile_w, c.tile_h = rank, world, tw, th
+        film = capi.Film(ctx, w, h)
+        st = capi.pt_render(ctx, scene, c, film)
+        g = film.read()
+        assert not np.any((total != 0) & (g != 0))  # disjoint pixels: the sum below is exact
+        total += g
+        for k in counts:
+            counts[k] += int(st[k])
+    o, ost = pyoracle.OracleScene(sd).render(cfg)
+    nd = int(np.count_nonzero(total.view(np.uint32) != o.view(np.uint32)))
+    # (-0.0 + 0.0 = +0.0: compare values where both are zero)
+    if nd:
+        nd = int(np.count_nonzero((total != o) & ~(np.isnan(total) & np.isnan(o))))
+    return nd, all(counts[k] == int(ost[k]) for k in counts), {"world": world, "tile": (tw, th)}
+
+
+def run_mcmc(ctx, scene, sd, cfg, rng):
+    c = abi.McmcConfig.default()
+    c.n_chains, c.n_bootstrap, c.spp, c.spp_per_pass, c.direct_spp = int(rng.integers(8, 64)), int(rng.integers(200, 800)), int(rng.integers(2, 8)), 4, int(rng.choice([-1, 0, 2]))
+    c.max_depth, c.rr_depth, c.use_nee = min(cfg.max_depth, 5), cfg.rr_depth, cfg.use_nee
+    c.filter_type, c.filter_radius, c.color, c.seed = cfg.filter_type, cfg.filter_radius, cfg.color, int(rng.integers(0, 1 << 30))
+    c.sampler_type = abi.SAMPLER_INDEPENDENT
+    film = capi.Film(ctx, sd.camera.width, sd.camera.height)
+    try:
+        o_film, o_res, o_chains = pyoracle.OracleScene(sd).mcmc_render(c)
+    except AssertionError:  # "Bootstrap failed": no path of the bootstrap carries light; the library must refuse as well
+        try:
+            capi.mcmc_render(ctx, scene, c, film)
+        except capi.AkariError:
+            return 0, True, {"both refused": True}
+        return 1, False, {"oracle refused, library rendered": True}
+    st, res, chains = capi.mcmc_render(ctx, scene, c, film)
+    nd = sum(int(np.count_nonzero(chains[name].view(np.uint32) != o_chains[name].view(np.uint32))) for name in chains.dtype.names)
+    same = res["normalization"] == o_res["normalization"] and res["acceptance_rate"] == o_res["acceptance_rate"]
+    return nd, bool(same), {"chains": c.n_chains}
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     opts = sys.argv[3:]
     textures = True if "tex" in opts else None  # "tex": every scene with images and shader graphs
-    runner = run_aov if "aov" in opts else run_gpt if "gpt" in opts else run_pt   # which integrator (default: the path tracer)
+    runner = run_aov if "aov" in opts else run_gpt if "gpt" in opts else run_mcmc if "mcmc" in opts else run_shard if "shard" in opts else run_pt
     if "wavefront" in opts:  # the path tracer's wavefront schedule instead of the megakernel
         os.environ["AKR_PT_MODE"] = "wavefront"
         os.environ["AKR_FORCE_BVH"] = "1"
@@ -204,7 +250,7 @@ def main():
     kinds = {"exhaustive": 0, "bvh": 0, "textured": 0}
     for seed in range(first, first + n):
         sd, cfg = rand_scene(seed, textures)
-        if runner is run_gpt:
+        if runner in (run_gpt, run_mcmc):
             cfg.sampler_type = abi.SAMPLER_INDEPENDENT  # gpt: independent sampler only
         sd.ggx_table = table
         try:
