@@ -368,14 +368,20 @@ AKR_HD bool fold_inputs(const MatInputs& m, DMaterial& d) {
             d.coat_roughness = m.coat_roughness;
             d.coat_eta = m.coat_ior;
             // the eta coordinate of the albedo table depends on the material only: once here, not at each of the five lookups of a vertex
-            if (f0 != 0.0f) d.z_spec = ggx_table_z(eta_s);
+            // The reference evaluates the specular layer and the coat whatever their weight (principled.rs:55-202). A layer of
+            // weight exactly 0 adds exactly 0 and may be skipped -- unless its colour is not finite (a shader graph can feed inf
+            // or NaN into specular_tint; 0 * inf is NaN and the reference's sample goes black): then it is evaluated like there.
+            // (found by tools/soak.py)
+            auto finite = [](float x) { return (x - x) == 0.0f; };
+            const bool spec_layer = f0 != 0.0f || !(finite(d.spec_tint.x) && finite(d.spec_tint.y) && finite(d.spec_tint.z));
+            if (spec_layer) d.z_spec = ggx_table_z(eta_s);
             if (m.coat_weight != 0.0f) d.z_coat = ggx_table_z(m.coat_ior);
             d.coat_scale = lerp3(mk3(1, 1, 1), mk3(m.coat_tint[0], m.coat_tint[1], m.coat_tint[2]), m.coat_weight);
             d.alpha = mk2(max_f(m.roughness * m.roughness, 1e-4f), max_f(m.roughness * m.roughness, 1e-4f));
             d.coat_alpha = mk2(max_f(m.coat_roughness * m.coat_roughness, 1e-4f), max_f(m.coat_roughness * m.coat_roughness, 1e-4f));
             if (m.metallic > 1e-4f) artistic_to_conductor(color, d.spec_tint, d.metal_n, d.metal_k);
             uint32_t fl = 0;
-            if (f0 != 0.0f) fl |= MF_SPEC;
+            if (spec_layer) fl |= MF_SPEC;
             if (m.coat_weight != 0.0f) fl |= MF_COAT;
             if (m.metallic < 1.0f - 1e-4f) fl |= MF_EVAL_BASE;
             if (m.metallic > 1e-4f) fl |= MF_EVAL_METAL;

@@ -163,8 +163,11 @@ def test_random_scene_soak(ctx):
     table = np.fromfile(os.path.join(root, "tests", "golden", "ggx_dielectric_s.f32"), dtype=np.float32)
     pyoracle.set_pmj_tables(*capi.host_pmj02bn_tables())
     n_bvh = 0
-    for seed in range(100000, 100150):
-        sd, cfg = soak.rand_scene(seed)
+    # the seeds that found something in round 2 first: 22901 / 22603 (forced graphs; constant alpha next to an opaque texture-fed base
+    # colour), 201578 / 201749 (a graph feeding inf / NaN into specular_tint of a layer of weight 0)
+    cases = [(22901, True), (22603, True), (201578, None), (201749, None)] + [(seed, None) for seed in range(100000, 100150)]
+    for seed, textures in cases:
+        sd, cfg = soak.rand_scene(seed, textures)
         sd.ggx_table = table
         scene = capi.Scene(ctx, sd)
         n_bvh += int(scene.info().uses_bvh != 0)
@@ -173,4 +176,4 @@ def test_random_scene_soak(ctx):
         o, ost = pyoracle.OracleScene(sd).render(cfg)
         assert n_bit_diff(film.read(), o) == 0, f"seed {seed}"
         assert all(int(st[k]) == int(ost[k]) for k in ("n_samples", "n_closest", "n_shadow", "n_shaded")), f"seed {seed}"
-    assert 10 < n_bvh < 140
+    assert 10 < n_bvh < 144

@@ -128,6 +128,8 @@ def rand_scene(seed, textures=None):
                 t[:3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], dtype=np.float32) * np.float32(rng.choice([0.5, 1.0, 1.7, -1.0]))
                 t[:3, 3] = rng.uniform(-0.5, 0.5, size=3).astype(np.float32)
             insts.append(abi.InstanceData(mi, [int(rng.integers(0, len(mats))) for _ in range(n_slots)], t.T.reshape(16).copy()))
+            if rng.random() < 0.15:  # an exact duplicate with other materials: every hit is a tie in t, the lower triangle id must win
+                insts.append(abi.InstanceData(mi, [int(rng.integers(0, len(mats))) for _ in range(n_slots)], t.T.reshape(16).copy()))
     c2w = eye.copy()
     c2w[:3, 3] = rng.uniform(-0.5, 0.5, size=3).astype(np.float32) + np.array([0, 0, 2.5], dtype=np.float32) * np.float32(rng.random() < 0.7)
     cam = abi.CameraData(c2w=c2w.T.reshape(16).copy(), fov=float(rng.uniform(0.3, 2.2)), width=w, height=h)
