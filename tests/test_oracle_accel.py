@@ -76,3 +76,37 @@ def test_triangle_test_agrees_with_f64_moeller_trumbore(cbox_path, name, n):
     # owns an edge point, or a hit / miss by the last bit at a silhouette edge)
     assert r["same_triangle"] + r["both_miss"] > 0.85 * n, r
     assert r["only_f32"] + r["only_f64"] < 0.03 * n, r
+
+
+def test_random_scenes_bvh_equals_the_exhaustive_loop_and_host_graphs_equal_the_oracle(hip_lib):
+    """tools/soak.py's generator on the CPU: (1) the oracle's own BVH (test infrastructure for the full-size cases) renders what its
+    exhaustive loop renders, bit for bit, on scenes with degenerate / tiny / duplicated geometry; (2) the library's host-side shader
+    graph evaluation and folding -- the code the kernels run -- equals the oracle's for random graph DAGs in every colour pipeline."""
+    import importlib.util
+    import os
+
+    from akari_render_amd import capi
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("soak", os.path.join(root, "tools", "soak.py"))
+    soak = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(soak)
+    pyoracle.set_pmj_tables(*capi.host_pmj02bn_tables())
+    for seed in range(700000, 700120):
+        sd, cfg = soak.rand_scene(seed)
+        a, sa = pyoracle.OracleScene(sd, bvh=False).render(cfg)
+        b, sb = pyoracle.OracleScene(sd, bvh=True).render(cfg)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), seed
+        assert all(sa[k] == sb[k] for k in ("n_samples", "n_closest", "n_shadow", "n_shaded")), seed
+    n = 0
+    for seed in range(710000, 710250):
+        sd, cfg = soak.rand_scene(seed, True)
+        sc = capi.Scene(None, sd)
+        osc = pyoracle.OracleScene(sd)
+        uv = np.random.default_rng(seed).uniform(-3, 4, size=(32, 2)).astype(np.float32)
+        for mi in range(len(sd.materials)):
+            x, y = capi.probe_material_inputs_host(sc, mi, uv, cfg.color), osc.material_inputs(mi, uv, cfg.color)
+            nx, ny = np.isnan(x), np.isnan(y)  # (NaN payloads are not part of the contract)
+            assert np.array_equal(nx, ny) and np.array_equal(x[~nx].view(np.uint32), y[~ny].view(np.uint32)), (seed, mi)
+            n += 1
+    assert n > 500
