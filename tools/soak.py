@@ -1,7 +1,7 @@
 """Randomised parity soak: random small scenes (random triangle soups + a few quads, random materials drawn from edge values,
 random emitters, cameras, samplers, configs, colour pipelines; a third of them with random images and random shader-graph DAGs
 feeding random inputs), the HIP path tracer against the oracle, film accumulators and
-counters bit for bit. Prints the seeds that differ. python tools/soak.py [n_cases] [first_seed] [tex] [aov | gpt | mcmc | shard | wavefront]   (needs a GPU; uses oracle/)"""
+counters bit for bit. Prints the seeds that differ. python tools/soak.py [n_cases] [first_seed] [tex] [big] [aov | gpt | mcmc | shard | wavefront]   (needs a GPU; uses oracle/)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -80,19 +80,20 @@ def rand_graph(rng, n_images):
     return abi.GraphData(nodes, {n: int(rng.integers(0, len(nodes))) for n in names})
 
 
-def rand_scene(seed, textures=None):
+def rand_scene(seed, textures=None, big=False):
+    """big: meshes of up to a few thousand triangles (deep BVHs), larger frames, longer paths"""
     rng = np.random.default_rng(seed)
     textured = (rng.random() < 0.35) if textures is None else textures
     images = rand_images(rng) if textured else []
-    w, h = int(rng.integers(8, 40)), int(rng.integers(8, 40))
+    w, h = (int(rng.integers(40, 90)), int(rng.integers(40, 90))) if big else (int(rng.integers(8, 40)), int(rng.integers(8, 40)))
     n_mats = int(rng.integers(1, 6))
     mats = [rand_material(rng) for _ in range(n_mats)] + [rand_material(rng, True) for _ in range(int(rng.integers(0, 3)))]
     meshes, insts = [], []
     eye = np.eye(4, dtype=np.float32)
     n_meshes = int(rng.integers(1, 5))
-    big = rng.random() < 0.35  # enough triangles for the BVH path
+    many = rng.random() < 0.35  # enough triangles for the BVH path
     for mi in range(n_meshes):
-        nt = int(rng.integers(1, 60 if big else 12))
+        nt = int(rng.integers(1, 60 if many else 12)) * (int(rng.integers(1, 80)) if big else 1)
         if rng.random() < 0.5:  # soup of random triangles in [-1, 1]^3, some degenerate / tiny / huge
             c = rng.uniform(-1, 1, size=(nt, 1, 3))
             e = rng.normal(size=(nt, 3, 3)) * rng.choice([1e-3, 0.1, 0.5, 2.0], size=(nt, 1, 1))
@@ -140,7 +141,7 @@ def rand_scene(seed, textures=None):
     sd = abi.SceneData(meshes, insts, mats, cam, images=images)
     cfg = abi.PtConfig.default()
     cfg.spp = int(rng.integers(1, 7)); cfg.spp_per_pass = int(rng.integers(1, cfg.spp + 1))
-    cfg.max_depth = int(rng.integers(1, 9)); cfg.rr_depth = int(rng.integers(0, 6))
+    cfg.max_depth = int(rng.integers(1, 16 if big else 9)); cfg.rr_depth = int(rng.integers(0, 6))
     cfg.use_nee = int(rng.random() < 0.85); cfg.indirect_only = int(rng.random() < 0.1); cfg.force_diffuse = int(rng.random() < 0.25)
     cfg.filter_type = int(rng.choice([abi.FILTER_BOX, abi.FILTER_GAUSSIAN])); cfg.filter_radius = float(rng.choice([0.5, 1.0, 1.5]))
     cfg.sampler_type = int(rng.choice([abi.SAMPLER_INDEPENDENT] * 3 + [abi.SAMPLER_SOBOL, abi.SAMPLER_PMJ02BN]))
@@ -251,7 +252,7 @@ def main():
     bad, refused, t0 = [], 0, time.time()
     kinds = {"exhaustive": 0, "bvh": 0, "textured": 0}
     for seed in range(first, first + n):
-        sd, cfg = rand_scene(seed, textures)
+        sd, cfg = rand_scene(seed, textures, "big" in opts)
         if runner in (run_gpt, run_mcmc):
             cfg.sampler_type = abi.SAMPLER_INDEPENDENT  # gpt: independent sampler only
         sd.ggx_table = table
