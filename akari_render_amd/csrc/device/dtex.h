@@ -156,7 +156,7 @@ enum : uint32_t {
     NODE_SPECTRAL_UPLIFT = 6, NODE_SEPARATE_COLOR = 7, NODE_EXTRACT = 8, NODE_NORMAL_MAP = 9
 };
 constexpr uint32_t kNodeNone = 0xffffffffu;
-constexpr uint32_t kMaxGraphNodes = 24;  // after pruning to the texture-fed inputs (host/scene_build.cpp)
+constexpr uint32_t kMaxGraphNodes = 256;  // after pruning to the texture-fed inputs (host/scene_build.cpp); the values live in at most kTexMaxSlots slots, so the length of a list costs LDS staging space only
 // A pruned node list is also register-allocated on the host: every node's value gets one of at most kTexMaxSlots value slots
 // (its slot is free again after its last consumer), the arguments of its consumers name slots, and the inputs of the surface
 // node it feeds are a bit mask. `op` of such a node: bits 0-7 the operation, bits 8-15 its slot (0xff: nobody reads the value

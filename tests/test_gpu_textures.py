@@ -92,3 +92,33 @@ def test_every_byte_value_decodes_like_a_division_by_255(ctx):
     o = osc.material_inputs(6, uv)
     assert n_bit_diff(d, o) == 0
     assert np.array_equal(d[:, 19], np.arange(256, dtype=np.float32) / np.float32(255.0))  # emission colour, red
+
+
+def test_long_shader_graph(ctx, root):
+    """A material whose five texture-fed inputs each bring their own mapping chain and image lookup (40 nodes after pruning: more
+    than the 24 the first implementation's private value array allowed; the values live in at most 8 LDS slots whatever the length)."""
+    sd = with_table(textured_room(40, 32), root)
+    N = abi.NodeData
+    nodes, inputs = [], {}
+    for k, name in enumerate(("base_color", "roughness", "metallic", "specular_tint", "coat_weight")):
+        b = len(nodes)
+        nodes += [N(abi.NODE_TEXCOORDS), N(abi.NODE_EXTRACT, (b, abi.FIELD_UV)), N(abi.NODE_CONST, (), (0.1 * k, 0.05 * k, 0.0)),
+                  N(abi.NODE_CONST, (), (1.0 + 0.5 * k, 2.0 - 0.2 * k, 1.0)), N(abi.NODE_MAPPING, (b + 1, b + 2, b + 3, k % 2)),
+                  N(abi.NODE_IMAGE, (k % 2, b + 4, 1 if k == 0 else 0))]
+        if name in ("base_color", "specular_tint"):
+            nodes += [N(abi.NODE_SPECTRAL_UPLIFT, (b + 5,)), N(abi.NODE_SEPARATE_COLOR, (b + 6,))]
+            inputs[name] = b + 7
+        else:
+            nodes += [N(abi.NODE_SEPARATE_COLOR, (b + 5,)), N(abi.NODE_EXTRACT, (b + 6, k % 3))]
+            inputs[name] = b + 7
+    assert len(nodes) == 40
+    sd.materials[0].graph = abi.GraphData(nodes, inputs)
+    scene = capi.Scene(ctx, sd)
+    osc = pyoracle.OracleScene(sd)
+    uv = np.random.default_rng(2).uniform(-1, 2, size=(4000, 2)).astype(np.float32)
+    assert n_bit_diff(capi.probe_material_inputs(ctx, scene, 0, uv), osc.material_inputs(0, uv)) == 0
+    film = capi.Film(ctx, 40, 32)
+    cfg = make_config(spp=4, spp_per_pass=4, max_depth=6)
+    capi.pt_render(ctx, scene, cfg, film)
+    o, _ = osc.render(cfg)
+    assert n_bit_diff(film.read(), o) == 0
