@@ -165,8 +165,8 @@ void write_image(const std::string& path, const float* rgb, uint32_t w, uint32_t
 
 // ------------------------------------------------------------------------------------------------ PNG reader
 // What `image::io::Reader::decode()` + `to_rgba8()` give the reference for a PNG texture (load.rs:583-604): expanded
-// palette / low bit depths / tRNS, 16-bit samples rounded to 8, grey replicated, alpha 255 when absent. Interlaced
-// files are rejected. Rows come out in file order (top first); the caller flips (load.rs:596).
+// palette / low bit depths / tRNS, 16-bit samples rounded to 8, grey replicated, alpha 255 when absent; Adam7
+// interlaced files included. Rows come out in file order (top first); the caller flips (load.rs:596).
 namespace {
 struct BitReader {
     const uint8_t* p;
@@ -322,7 +322,7 @@ void decode_png(const uint8_t* data, size_t n, uint32_t& w, uint32_t& h, std::ve
     if (n < 8 || std::memcmp(data, sig, 8) != 0) throw std::runtime_error("png: bad signature");
     size_t pos = 8;
     uint32_t depth = 0, ctype = 0;
-    bool have_hdr = false;
+    bool have_hdr = false, interlaced = false;
     std::vector<uint8_t> idat, plte, trns;
     while (pos + 12 <= n) {
         uint32_t len = be32(data + pos);
@@ -333,7 +333,8 @@ void decode_png(const uint8_t* data, size_t n, uint32_t& w, uint32_t& h, std::ve
             if (len != 13) throw std::runtime_error("png: bad IHDR");
             w = be32(body); h = be32(body + 4); depth = body[8]; ctype = body[9];
             if (body[10] != 0 || body[11] != 0) throw std::runtime_error("png: unknown compression / filter method");
-            if (body[12] != 0) throw std::runtime_error("unsupported: interlaced PNG");
+            if (body[12] > 1) throw std::runtime_error("png: unknown interlace method");
+            interlaced = body[12] == 1;
             have_hdr = true;
         } else if (!std::memcmp(type, "PLTE", 4)) {
             plte.assign(body, body + len);
@@ -362,29 +363,8 @@ void decode_png(const uint8_t* data, size_t n, uint32_t& w, uint32_t& h, std::ve
                     ((ctype == 2 || ctype == 4 || ctype == 6) && (depth == 8 || depth == 16));
     if (!depth_ok) throw std::runtime_error("png: bad bit depth");
     if (ctype == 3 && plte.size() < 3) throw std::runtime_error("png: palette image without PLTE");
-    const size_t bpp_bits = (size_t)channels * depth, stride = ((size_t)w * bpp_bits + 7) / 8, bpp = (bpp_bits + 7) / 8;
+    const size_t bpp_bits = (size_t)channels * depth, bpp = (bpp_bits + 7) / 8;
     std::vector<uint8_t> raw = inflate_zlib(idat.data(), idat.size());
-    if (raw.size() < (stride + 1) * (size_t)h) throw std::runtime_error("png: image data too short");
-    std::vector<uint8_t> img(stride * (size_t)h);
-    for (uint32_t y = 0; y < h; y++) {  // unfilter
-        const uint8_t* src = raw.data() + (stride + 1) * (size_t)y;
-        uint8_t ft = src[0];
-        src++;
-        uint8_t* cur = img.data() + stride * (size_t)y;
-        const uint8_t* up = y ? cur - stride : nullptr;
-        for (size_t x = 0; x < stride; x++) {
-            int a = x >= bpp ? cur[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= bpp) ? up[x - bpp] : 0, v = src[x];
-            switch (ft) {
-                case 0: break;
-                case 1: v += a; break;
-                case 2: v += b; break;
-                case 3: v += (a + b) >> 1; break;
-                case 4: v += paeth(a, b, c); break;
-                default: throw std::runtime_error("png: bad filter type");
-            }
-            cur[x] = (uint8_t)v;
-        }
-    }
     rgba.assign(4ull * w * h, 255);
     auto sample = [&](const uint8_t* row, size_t idx) -> uint32_t {  // idx-th sample of the row, raw value
         if (depth == 8) return row[idx];
@@ -397,31 +377,71 @@ void decode_png(const uint8_t* data, size_t n, uint32_t& w, uint32_t& h, std::ve
         if (depth == 16) return (uint8_t)((v + 128u) / 257u);
         return (uint8_t)(v * 255u / ((1u << depth) - 1u));  // 1/2/4-bit grey expanded to 8 bits
     };
-    for (uint32_t y = 0; y < h; y++) {
-        const uint8_t* row = img.data() + stride * (size_t)y;
-        uint8_t* o = rgba.data() + 4ull * w * y;
-        for (uint32_t x = 0; x < w; x++, o += 4) {
-            if (ctype == 3) {
-                uint32_t i = sample(row, x);
-                if (3 * (size_t)i + 2 >= plte.size()) throw std::runtime_error("png: palette index out of range");
-                o[0] = plte[3 * i]; o[1] = plte[3 * i + 1]; o[2] = plte[3 * i + 2];
-                o[3] = i < trns.size() ? trns[i] : 255;
-            } else if (ctype == 0) {
-                uint32_t v = sample(row, x);
-                o[0] = o[1] = o[2] = to8(v);
-                if (trns.size() >= 2 && v == (((uint32_t)trns[0] << 8) | trns[1])) o[3] = 0;
-            } else if (ctype == 4) {
-                o[0] = o[1] = o[2] = to8(sample(row, 2 * (size_t)x));
-                o[3] = to8(sample(row, 2 * (size_t)x + 1));
-            } else if (ctype == 2) {
-                uint32_t r = sample(row, 3 * (size_t)x), g = sample(row, 3 * (size_t)x + 1), b = sample(row, 3 * (size_t)x + 2);
-                o[0] = to8(r); o[1] = to8(g); o[2] = to8(b);
-                if (trns.size() >= 6 && r == (((uint32_t)trns[0] << 8) | trns[1]) && g == (((uint32_t)trns[2] << 8) | trns[3]) &&
-                    b == (((uint32_t)trns[4] << 8) | trns[5]))
-                    o[3] = 0;
-            } else {
-                for (int c = 0; c < 4; c++) o[c] = to8(sample(row, 4 * (size_t)x + c));
+    // One reduced image: pw x ph pixels whose scanlines start at `src`; pixel (px, py) of it is pixel (x0 + px dx, y0 + py dy) of
+    // the picture. The whole picture is one such image with steps 1; an Adam7 file holds seven (PNG specification, section 8.2),
+    // each filtered on its own (the "previous row" of a pass's first row is all zeros).
+    size_t consumed = 0;
+    std::vector<uint8_t> img;
+    auto reduced_image = [&](uint32_t pw, uint32_t ph, uint32_t x0, uint32_t y0, uint32_t dx, uint32_t dy) {
+        if (pw == 0 || ph == 0) return;
+        const size_t stride = ((size_t)pw * bpp_bits + 7) / 8;
+        if (raw.size() - consumed < (stride + 1) * (size_t)ph) throw std::runtime_error("png: image data too short");
+        img.assign(stride * (size_t)ph, 0);
+        for (uint32_t y = 0; y < ph; y++) {  // unfilter
+            const uint8_t* src = raw.data() + consumed + (stride + 1) * (size_t)y;
+            uint8_t ft = src[0];
+            src++;
+            uint8_t* cur = img.data() + stride * (size_t)y;
+            const uint8_t* up = y ? cur - stride : nullptr;
+            for (size_t x = 0; x < stride; x++) {
+                int a = x >= bpp ? cur[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= bpp) ? up[x - bpp] : 0, v = src[x];
+                switch (ft) {
+                    case 0: break;
+                    case 1: v += a; break;
+                    case 2: v += b; break;
+                    case 3: v += (a + b) >> 1; break;
+                    case 4: v += paeth(a, b, c); break;
+                    default: throw std::runtime_error("png: bad filter type");
+                }
+                cur[x] = (uint8_t)v;
             }
+        }
+        consumed += (stride + 1) * (size_t)ph;
+        for (uint32_t y = 0; y < ph; y++) {
+            const uint8_t* row = img.data() + stride * (size_t)y;
+            for (uint32_t x = 0; x < pw; x++) {
+                uint8_t* o = rgba.data() + 4ull * ((size_t)w * (y0 + (size_t)y * dy) + (x0 + (size_t)x * dx));
+                if (ctype == 3) {
+                    uint32_t i = sample(row, x);
+                    if (3 * (size_t)i + 2 >= plte.size()) throw std::runtime_error("png: palette index out of range");
+                    o[0] = plte[3 * i]; o[1] = plte[3 * i + 1]; o[2] = plte[3 * i + 2];
+                    o[3] = i < trns.size() ? trns[i] : 255;
+                } else if (ctype == 0) {
+                    uint32_t v = sample(row, x);
+                    o[0] = o[1] = o[2] = to8(v);
+                    if (trns.size() >= 2 && v == (((uint32_t)trns[0] << 8) | trns[1])) o[3] = 0;
+                } else if (ctype == 4) {
+                    o[0] = o[1] = o[2] = to8(sample(row, 2 * (size_t)x));
+                    o[3] = to8(sample(row, 2 * (size_t)x + 1));
+                } else if (ctype == 2) {
+                    uint32_t r = sample(row, 3 * (size_t)x), g = sample(row, 3 * (size_t)x + 1), b = sample(row, 3 * (size_t)x + 2);
+                    o[0] = to8(r); o[1] = to8(g); o[2] = to8(b);
+                    if (trns.size() >= 6 && r == (((uint32_t)trns[0] << 8) | trns[1]) && g == (((uint32_t)trns[2] << 8) | trns[3]) &&
+                        b == (((uint32_t)trns[4] << 8) | trns[5]))
+                        o[3] = 0;
+                } else {
+                    for (int c = 0; c < 4; c++) o[c] = to8(sample(row, 4 * (size_t)x + c));
+                }
+            }
+        }
+    };
+    if (!interlaced) {
+        reduced_image(w, h, 0, 0, 1, 1);
+    } else {
+        static const uint32_t X0[7] = {0, 4, 0, 2, 0, 1, 0}, Y0[7] = {0, 0, 4, 0, 2, 0, 1}, DX[7] = {8, 8, 4, 4, 2, 2, 1}, DY[7] = {8, 8, 8, 4, 4, 2, 2};
+        for (int k = 0; k < 7; k++) {
+            const uint32_t pw = w > X0[k] ? (w - X0[k] + DX[k] - 1) / DX[k] : 0, ph = h > Y0[k] ? (h - Y0[k] + DY[k] - 1) / DY[k] : 0;
+            reduced_image(pw, ph, X0[k], Y0[k], DX[k], DY[k]);
         }
     }
 }

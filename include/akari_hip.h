@@ -525,7 +525,7 @@ AKR_API int32_t akr_probe_intersect(akr_context *ctx, akr_scene *scene, uint32_t
 /* SurfaceInteraction of (inst, prim, u, v): out 19 floats / item = p, ng, n, t, s, uv, area, material. */
 /* The tables of the pmj02bn sampler as the library uses them: sets = u32[5 * 65536 * 2], bluenoise = u16[48 * 128 * 128]. */
 AKR_API int32_t akr_host_pmj02bn_tables(uint32_t *sets, uint16_t *bluenoise);
-/* The PNG reader of akr_scene_load (8/16-bit, all colour types, tRNS, no interlacing), image crate `to_rgba8` rules
+/* The PNG reader of akr_scene_load (8/16-bit, all colour types, tRNS, Adam7 interlacing), image crate `to_rgba8` rules
  * (load.rs:583-604). Rows in file order. rgba == NULL: only the size is returned. */
 AKR_API int32_t akr_host_decode_png(const uint8_t *data, uint64_t len, uint32_t *width, uint32_t *height, uint8_t *rgba, uint64_t capacity);
 /* The JPEG reader of akr_scene_load (baseline + progressive Huffman, 8 bit, grey / YCbCr / RGB, any integer sampling

@@ -153,8 +153,14 @@ def decode_png(data: bytes) -> np.ndarray:
             break
         pos += 12 + ln
     w, h, depth, ctype, _, _, interlace = hdr
-    if interlace:
-        raise NotImplementedError("interlaced PNG")
+    if interlace:  # Adam7: through Pillow (an independent decoder); its 8-bit RGBA conversion is the image crate's for depths <= 8
+        if depth > 8:
+            raise NotImplementedError("interlaced 16-bit PNG")
+        import io
+
+        from PIL import Image
+
+        return np.asarray(Image.open(io.BytesIO(data)).convert("RGBA"), dtype=np.uint8).copy()
     ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
     bits = ch * depth
     stride, bpp = (w * bits + 7) // 8, (bits + 7) // 8

@@ -124,9 +124,10 @@ def cbox_variant(sd: abi.SceneData, which: str) -> abi.SceneData:
 
 
 # ---------------------------------------------------------------------------------------------- textured scenes
-def make_png(pixels: np.ndarray, color_type: int, depth: int = 8, filters=None, palette=None, trns: bytes = None, level: int = 6) -> bytes:
+def make_png(pixels: np.ndarray, color_type: int, depth: int = 8, filters=None, palette=None, trns: bytes = None, level: int = 6, interlace: bool = False) -> bytes:
     """Encodes a PNG from raw samples: pixels (H, W, C) of integer samples (or (H, W) palette indices / grey).
-    `filters` = per-row filter types (default: cycling 0..4), encoded exactly as the PNG spec defines them."""
+    `filters` = per-row filter types (default: cycling 0..4), encoded exactly as the PNG spec defines them.
+    interlace: Adam7 (PNG specification 8.2): seven reduced images, each filtered on its own."""
     import struct
     import zlib
 
@@ -135,45 +136,59 @@ def make_png(pixels: np.ndarray, color_type: int, depth: int = 8, filters=None, 
         px = px[:, :, None]
     h, w, ch = px.shape
     bits = ch * depth
-    stride, bpp = (w * bits + 7) // 8, max(1, bits // 8)
-    rows = []
-    for y in range(h):
-        if depth == 8:
-            row = px[y].astype(np.uint8).reshape(-1)
-        elif depth == 16:
-            row = np.stack([(px[y] >> 8) & 255, px[y] & 255], axis=-1).astype(np.uint8).reshape(-1)
-        else:
-            b = ((px[y].reshape(-1)[:, None] >> np.arange(depth - 1, -1, -1)) & 1).astype(np.uint8).reshape(-1)
-            row = np.packbits(b)
-        assert row.size == stride
-        rows.append(row.astype(np.int32))
-    out = bytearray()
-    prev = np.zeros(stride, dtype=np.int32)
-    for y, row in enumerate(rows):
-        ft = (filters[y] if filters is not None else y % 5)
-        a = np.concatenate([np.zeros(bpp, dtype=np.int32), row[:-bpp]]) if stride > bpp else np.zeros(stride, dtype=np.int32)
-        c = np.concatenate([np.zeros(bpp, dtype=np.int32), prev[:-bpp]]) if stride > bpp else np.zeros(stride, dtype=np.int32)
-        if ft == 0:
-            f = row
-        elif ft == 1:
-            f = row - a
-        elif ft == 2:
-            f = row - prev
-        elif ft == 3:
-            f = row - ((a + prev) >> 1)
-        else:
-            p = a + prev - c
-            pa, pb, pc = np.abs(p - a), np.abs(p - prev), np.abs(p - c)
-            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
-            f = row - pred
-        out.append(ft)
-        out += bytes((f & 255).astype(np.uint8))
-        prev = row
+    bpp = max(1, bits // 8)
+
+    def scanlines(sub):  # filtered scanlines of one (reduced) image
+        sh, sw = sub.shape[:2]
+        stride = (sw * bits + 7) // 8
+        rows = []
+        for y in range(sh):
+            if depth == 8:
+                row = sub[y].astype(np.uint8).reshape(-1)
+            elif depth == 16:
+                row = np.stack([(sub[y] >> 8) & 255, sub[y] & 255], axis=-1).astype(np.uint8).reshape(-1)
+            else:
+                b = ((sub[y].reshape(-1)[:, None] >> np.arange(depth - 1, -1, -1)) & 1).astype(np.uint8).reshape(-1)
+                row = np.packbits(b)
+            assert row.size == stride
+            rows.append(row.astype(np.int32))
+        out = bytearray()
+        prev = np.zeros(stride, dtype=np.int32)
+        for y, row in enumerate(rows):
+            ft = (filters[y] if filters is not None else y % 5)
+            a = np.concatenate([np.zeros(bpp, dtype=np.int32), row[:-bpp]]) if stride > bpp else np.zeros(stride, dtype=np.int32)
+            c = np.concatenate([np.zeros(bpp, dtype=np.int32), prev[:-bpp]]) if stride > bpp else np.zeros(stride, dtype=np.int32)
+            if ft == 0:
+                f = row
+            elif ft == 1:
+                f = row - a
+            elif ft == 2:
+                f = row - prev
+            elif ft == 3:
+                f = row - ((a + prev) >> 1)
+            else:
+                p = a + prev - c
+                pa, pb, pc = np.abs(p - a), np.abs(p - prev), np.abs(p - c)
+                pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+                f = row - pred
+            out.append(ft)
+            out += bytes((f & 255).astype(np.uint8))
+            prev = row
+        return out
+
+    if interlace:
+        out = bytearray()
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = px[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                out += scanlines(sub)
+    else:
+        out = scanlines(px)
 
     def chunk(ty, body):
         return struct.pack(">I", len(body)) + ty + body + struct.pack(">I", zlib.crc32(ty + body) & 0xFFFFFFFF)
 
-    data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color_type, 0, 0, 0))
+    data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color_type, 0, 0, 1 if interlace else 0))
     if palette is not None:
         data += chunk(b"PLTE", bytes(np.asarray(palette, dtype=np.uint8).reshape(-1)))
     if trns is not None:

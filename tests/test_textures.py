@@ -87,6 +87,32 @@ def test_png_reader(name, ctype, depth, ch):
     assert np.array_equal(got.astype(np.int64), want)
 
 
+@pytest.mark.parametrize("size", [(1, 1), (2, 3), (5, 7), (8, 8), (9, 17), (33, 20), (3, 1), (1, 9)])
+def test_png_reader_adam7(size):
+    """Interlaced files (PNG specification 8.2): seven reduced images, each filtered on its own; every colour type and depth at sizes
+    that leave some passes empty. Against the non-interlaced encoding of the same pixels and, for 8-bit files, Pillow's decoder."""
+    import io
+
+    from PIL import Image
+
+    w, h = size
+    rng = np.random.default_rng(w * 100 + h)
+    for ct, depth, ch in ((2, 8, 3), (6, 8, 4), (0, 8, 1), (0, 1, 1), (0, 4, 1), (0, 16, 1), (4, 8, 2), (2, 16, 3), (6, 16, 4), (3, 2, 1), (3, 8, 1)):
+        kw = {}
+        if ct == 3:
+            kw["palette"] = rng.integers(0, 256, size=(1 << depth, 3))
+            px = rng.integers(0, 1 << depth, size=(h, w))
+        else:
+            px = rng.integers(0, 1 << depth, size=(h, w, ch))
+        inter, plain = make_png(px, ct, depth, interlace=True, **kw), make_png(px, ct, depth, **kw)
+        got = capi.host_decode_png(inter)
+        assert np.array_equal(got, capi.host_decode_png(plain)), (ct, depth)
+        if depth == 8 and ct != 3:
+            assert np.array_equal(got, np.asarray(Image.open(io.BytesIO(inter)).convert("RGBA"))), (ct, depth)
+    with pytest.raises(capi.AkariError):
+        capi.host_decode_png(inter[:-30])
+
+
 def test_png_reader_stored_and_fixed_blocks_and_errors():
     px = np.arange(5 * 7 * 3, dtype=np.int64).reshape(5, 7, 3) % 256
     for level in (0, 1, 9):  # stored blocks, fast (mostly fixed Huffman on tiny inputs), dynamic
