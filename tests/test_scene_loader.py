@@ -215,3 +215,44 @@ def test_random_typed_shader_graphs_read_alike_by_both_loaders(hip_lib, tmp_path
             assert np.float32(sc.light(i)[1]).view(np.uint32) == np.float32(osc.light_info(i)[1]).view(np.uint32), (case, i)
         compared += 1
     assert compared >= 150, compared
+
+
+def test_random_transforms_and_cameras_read_alike_by_both_loaders(hip_lib, tmp_path):
+    """TRS (both coordinate systems) and matrix transforms on instances and the camera, random values: the two readers agree on every
+    matrix transform bit for bit and on the TRS ones and the camera to the rounding of the trigonometric functions they use."""
+    import json
+
+    from tests.helpers import make_png
+    from tests.test_textures import _scene_json_with_textures
+
+    rng = np.random.default_rng(77)
+    path = _scene_json_with_textures(tmp_path, make_png(rng.integers(0, 256, size=(5, 6, 3)), 2, 8), rng.random((2, 2, 3)).astype(np.float32))
+    base = json.load(open(path))
+
+    def transform():
+        if rng.random() < 0.3:
+            m = rng.normal(size=(4, 4)).astype(np.float32)
+            m[3] = [0, 0, 0, 1]
+            return {"type": "matrix", "data": [[float(x) for x in row] for row in m]}
+        return {"type": "trs", "data": {"translation": [float(np.float32(x)) for x in rng.uniform(-3, 3, 3)], "rotation": [float(np.float32(x)) for x in rng.uniform(-3.2, 3.2, 3)],
+                                        "scale": [float(np.float32(x)) for x in rng.uniform(0.2, 3, 3)], "coordinate_system": str(rng.choice(["Akari", "Blender"]))}}
+
+    for case in range(150):
+        scene = json.loads(json.dumps(base))
+        for inst in scene["instances"].values():
+            inst["transform"] = transform()
+        scene["camera"]["data"]["transform"] = transform()
+        scene["camera"]["data"]["fov"] = float(np.float32(rng.uniform(10, 120)))
+        scene["camera"]["data"]["sensor_width"] = int(rng.integers(8, 64))
+        scene["camera"]["data"]["sensor_height"] = int(rng.integers(8, 64))
+        p = tmp_path / f"t{case}.json"
+        p.write_text(json.dumps(scene))
+        a = capi.Scene(None, str(p)).to_scene_data()
+        b = scene_json.load_scene(str(p))
+        for x, y in zip(a.instances, b.instances):  # (sin / cos come from two maths libraries: a few ulp; matrices are copied exactly)
+            tx, ty = np.float32(x.transform), np.float32(y.transform)
+            assert np.allclose(tx, ty, rtol=0, atol=4e-6 * max(1.0, float(np.abs(ty).max()))), (case, float(np.abs(tx - ty).max()))
+            if scene["instances"][sorted(scene["instances"])[a.instances.index(x)]]["transform"]["type"] == "matrix":
+                assert np.array_equal(tx.view(np.uint32), ty.view(np.uint32)), case
+        assert np.allclose(a.camera.c2w, b.camera.c2w, rtol=0, atol=2e-6 * max(1.0, float(np.abs(b.camera.c2w).max()))), case
+        assert abs(a.camera.fov - b.camera.fov) <= 1e-6 and (a.camera.width, a.camera.height) == (b.camera.width, b.camera.height), case
