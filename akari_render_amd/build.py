@@ -114,9 +114,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
-def build_variant(name: str, extra_flags, verbose: bool = False) -> str:
+def build_variant(name: str, extra_flags, verbose: bool = False, only=None) -> str:
     """An A/B build of the library with extra compiler flags (e.g. -DAKR_BVH_NODE_WORDS=32) next to the product:
-    akari_render_amd/variants/libakari_hip_<name>.so, selected at run time with AKR_HIP_LIB=<path> (measurement only)."""
+    akari_render_amd/variants/libakari_hip_<name>.so, selected at run time with AKR_HIP_LIB=<path> (measurement only).
+    only = the sources the flags concern (e.g. ["pt_kernels.hip"]): the others are linked from the product's objects."""
     from concurrent.futures import ThreadPoolExecutor
 
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -125,8 +126,12 @@ def build_variant(name: str, extra_flags, verbose: bool = False) -> str:
     os.makedirs(obj, exist_ok=True)
     os.makedirs(out_dir, exist_ok=True)
     out = os.path.join(out_dir, f"libakari_hip_{name}.so")
+    if only:
+        build(verbose=verbose)  # the product's objects must be current
 
     def compile_one(src: str):
+        if only and src not in only:
+            return os.path.join(OBJ, src.replace("/", "_") + ".o"), 0, ""
         o = os.path.join(obj, src.replace("/", "_") + ".o")
         res = subprocess.run([hipcc] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-I", CSRC, "-o", o],
                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -144,7 +149,11 @@ def build_variant(name: str, extra_flags, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] == "--variant":
-        print(build_variant(sys.argv[2], sys.argv[3:], verbose=True))
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":  # --variant NAME [--only a.hip,b.cpp] FLAGS...
+        rest = sys.argv[3:]
+        only = None
+        if rest and rest[0] == "--only":
+            only, rest = rest[1].split(","), rest[2:]
+        print(build_variant(sys.argv[2], rest, verbose=True, only=only))
     else:
         print(build(force="--force" in sys.argv, verbose=True))

@@ -22,7 +22,7 @@ ERR_INVALID_ARGUMENT, ERR_HIP, ERR_NO_DEVICE, ERR_IO, ERR_PARSE, ERR_UNSUPPORTED
 
 # every symbol include/akari_hip.h declares (checked by tests/test_abi.py against the header text)
 EXPORTS = [
-    "akr_last_error", "akr_version",
+    "akr_last_error", "akr_version", "akr_option_set", "akr_option_get",
     "akr_context_create", "akr_context_destroy", "akr_context_synchronize", "akr_context_device_info",
     "akr_scene_create", "akr_scene_load", "akr_scene_destroy", "akr_scene_set_resolution", "akr_scene_get_info",
     "akr_scene_get_light", "akr_scene_get_ggx_table", "akr_scene_get_desc_counts", "akr_scene_get_mesh",
@@ -106,6 +106,8 @@ def lib() -> C.CDLL:
     proto("akr_film_device_ptr", vp, vpp, u64p)
     proto("akr_context_device_ordinal", vp, C.POINTER(C.c_int32))
     proto("akr_device_count", C.POINTER(C.c_int32))
+    proto("akr_option_set", C.c_char_p, i32)
+    proto("akr_option_get", C.c_char_p, C.POINTER(C.c_int32))
     proto("akr_comm_unique_id", C.POINTER(C.c_uint8))
     proto("akr_comm_create", vp, C.POINTER(C.c_uint8), i32, i32, vpp)
     proto("akr_comm_wrap", vp, vp, i32, i32, vpp)
@@ -309,6 +311,40 @@ class Scene:
         check(lib().akr_scene_get_camera(self.h, C.byref(c)))
         cam = abi.CameraData(np.array(list(c.c2w), dtype=np.float32), float(c.fov), c.width, c.height)
         return abi.SceneData(meshes, instances, materials, cam, images=images)
+
+
+def set_option(name: str, value: int) -> None:
+    """akr_option_set: process-wide tuning switches / test hooks ("force_bvh", "bvh_balanced", "defer_metal", "wavefront")."""
+    check(lib().akr_option_set(name.encode(), int(value)))
+
+
+def get_option(name: str) -> int:
+    v = C.c_int32()
+    check(lib().akr_option_get(name.encode(), C.byref(v)))
+    return v.value
+
+
+class options:
+    """with capi.options(force_bvh=1, wavefront=1): ...   -- sets the options, restores the previous values on exit."""
+
+    def __init__(self, **kw):
+        self.kw, self.old = kw, {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.old[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
+
+
+def last_error() -> str:
+    """akr_last_error(): the calling thread's last failure message ("" if none)."""
+    return lib().akr_last_error().decode("utf-8", "replace")
 
 
 def device_count() -> int:

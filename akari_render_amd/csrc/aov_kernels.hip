@@ -91,7 +91,7 @@ hipError_t launch_aov(const PtParams& p, uint32_t spp, uint32_t aov, uint32_t re
     if (blocks == 0) return hipSuccess;
     const bool bvh = p.sc.bvh_nodes != nullptr, tex = p.sc.tex.nodes != nullptr;
     size_t lds;
-    const PtParams q = with_tex_slots(p, bvh ? kBvhStackDepth * 256 * 4 : p.stage_total, lds);
+    const PtParams q = with_tex_slots(p, bvh ? p.sc.bvh_stack_depth * 256 * 4 : p.stage_total, lds);
 #define AKR_AOV(B, T)                                                                                                  \
     {                                                                                                                \
         if (p.sampler) hipLaunchKernelGGL((k_aov<B, T, true>), dim3(blocks), dim3(256), lds, stream, q, spp, aov, remap); \

@@ -551,32 +551,61 @@ AKR_HD bool check_wo_wi_valid(vec3 ns, vec3 ng, vec3 wo, vec3 wi) {
 }
 
 // Everything the shading functions need at one path vertex.
+#ifndef AKR_LEAN_SP
+#define AKR_LEAN_SP 0  // 1: the normal-map frame and the local geometric normal are recomputed where they are read (12 fewer registers
+                       // live from the NEE evaluation to the end of the BSDF sample; the same operations on the same inputs, the same bits)
+#endif
 struct ShadePoint {
     Frame frame;        // si.frame
     vec3 ng;            // si.ng
-    Frame nm_frame;     // inner (normal-map) frame in local space; identity when !MF_NORMAL_MAP
-    vec3 ng_local;      // frame.to_local(ng)  (normal_map(): ng of the inner SurfaceClosure)
+#if !AKR_LEAN_SP
+    Frame nm_frame_;    // inner (normal-map) frame in local space; identity when !MF_NORMAL_MAP
+    vec3 ng_local_;     // frame.to_local(ng)  (normal_map(): ng of the inner SurfaceClosure)
+#endif
     bool force_diffuse;
     bool wo_cached;     // wo_albedo holds the table values of the vertex's outgoing direction (shade_point_cache_wo)
     WoAlbedo wo_albedo;
 };
+// normal_map(), svm/surface/mod.rs:1380-1417, for a constant `normal` input: the inner frame of a normal-mapped Principled material
+AKR_HD Frame nm_frame_compute(const Frame& frame, const DMaterial& m) {
+    vec3 n_world = to_world(frame, m.nm_normal);
+    Frame nf = frame_from_n_t(n_world, frame.t);
+    Frame r;
+    r.t = to_local(frame, nf.t);
+    r.s = to_local(frame, nf.s);
+    r.n = to_local(frame, nf.n);
+    return r;
+}
+AKR_HD Frame sp_nm_frame(const ShadePoint& sp, const DMaterial& m) {
+#if AKR_LEAN_SP
+    if (!sp.force_diffuse && m.kind == MAT_PRINCIPLED && (m.flags & MF_NORMAL_MAP)) return nm_frame_compute(sp.frame, m);
+    return Frame{mk3(0, 0, 1), mk3(1, 0, 0), mk3(0, 1, 0)};
+#else
+    (void)m;
+    return sp.nm_frame_;
+#endif
+}
+AKR_HD vec3 sp_ng_local(const ShadePoint& sp) {
+#if AKR_LEAN_SP
+    return to_local(sp.frame, sp.ng);
+#else
+    return sp.ng_local_;
+#endif
+}
 
-// normal_map(), svm/surface/mod.rs:1380-1417, for a constant `normal` input
 AKR_HD void shade_point_init(ShadePoint& sp, const DMaterial& m, Frame frame, vec3 ng, bool force_diffuse) {
     sp.frame = frame;
     sp.ng = ng;
     sp.force_diffuse = force_diffuse;
     sp.wo_cached = false;
     sp.wo_albedo = WoAlbedo{0.0f, 0.0f};
-    sp.ng_local = to_local(frame, ng);
-    sp.nm_frame = Frame{mk3(0, 0, 1), mk3(1, 0, 0), mk3(0, 1, 0)};
-    if (!force_diffuse && m.kind == MAT_PRINCIPLED && (m.flags & MF_NORMAL_MAP)) {
-        vec3 n_world = to_world(frame, m.nm_normal);
-        Frame nf = frame_from_n_t(n_world, frame.t);
-        sp.nm_frame.t = to_local(frame, nf.t);
-        sp.nm_frame.s = to_local(frame, nf.s);
-        sp.nm_frame.n = to_local(frame, nf.n);
-    }
+#if !AKR_LEAN_SP
+    sp.ng_local_ = to_local(frame, ng);
+    sp.nm_frame_ = Frame{mk3(0, 0, 1), mk3(1, 0, 0), mk3(0, 1, 0)};
+    if (!force_diffuse && m.kind == MAT_PRINCIPLED && (m.flags & MF_NORMAL_MAP)) sp.nm_frame_ = nm_frame_compute(frame, m);
+#else
+    (void)m;
+#endif
 }
 
 // After shade_point_init, for a vertex all of whose evaluate / sample calls use this `wo` (world space): the albedo-table values
@@ -584,7 +613,7 @@ AKR_HD void shade_point_init(ShadePoint& sp, const DMaterial& m, Frame frame, ve
 AKR_HD void shade_point_cache_wo(ShadePoint& sp, const DMaterial& m, const float* __restrict__ table, vec3 wo) {
     if (sp.force_diffuse || m.kind != MAT_PRINCIPLED) return;
     vec3 lo = to_local(sp.frame, wo);
-    if (m.flags & MF_NORMAL_MAP) lo = to_local(sp.nm_frame, lo);
+    if (m.flags & MF_NORMAL_MAP) lo = to_local(sp_nm_frame(sp, m), lo);
     if (m.flags & MF_SPEC) sp.wo_albedo.spec = albedo_spec(m, table, lo);
     if (m.flags & MF_COAT) sp.wo_albedo.coat = albedo_coat(m, table, lo);
     sp.wo_cached = true;
@@ -601,10 +630,13 @@ AKR_HD BsdfEval shade_evaluate(const ShadePoint& sp, const DMaterial& m, const f
     }
     switch (m.kind) {
         case MAT_PRINCIPLED: {
-            if (!check_wo_wi_valid(sp.nm_frame.n, sp.ng_local, lo, li)) return zero;
             if (m.flags & MF_NORMAL_MAP) {
-                lo = to_local(sp.nm_frame, lo);
-                li = to_local(sp.nm_frame, li);
+                const Frame nf = sp_nm_frame(sp, m);
+                if (!check_wo_wi_valid(nf.n, sp_ng_local(sp), lo, li)) return zero;
+                lo = to_local(nf, lo);
+                li = to_local(nf, li);
+            } else {
+                if (!check_wo_wi_valid(mk3(0, 0, 1), sp_ng_local(sp), lo, li)) return zero;
             }
             return principled_eval(m, table, lo, li, sp.wo_cached ? &sp.wo_albedo : nullptr);
         }
@@ -632,11 +664,13 @@ AKR_HD BsdfSample shade_sample(const ShadePoint& sp, const DMaterial& m, const f
     } else {
         switch (m.kind) {
             case MAT_PRINCIPLED: {
-                vec3 lo2 = (m.flags & MF_NORMAL_MAP) ? to_local(sp.nm_frame, lo) : lo;
+                const bool nm = (m.flags & MF_NORMAL_MAP) != 0;
+                const Frame nf = nm ? sp_nm_frame(sp, m) : Frame{mk3(0, 0, 1), mk3(1, 0, 0), mk3(0, 1, 0)};
+                vec3 lo2 = nm ? to_local(nf, lo) : lo;
                 vec3 w2;
                 valid = principled_sample_wi(m, table, lo2, u_select, u_sample, w2, sp.wo_cached ? &sp.wo_albedo : nullptr);
-                wl = (m.flags & MF_NORMAL_MAP) ? to_world(sp.nm_frame, w2) : w2;
-                valid = valid & check_wo_wi_valid(sp.nm_frame.n, sp.ng_local, lo, wl);
+                wl = nm ? to_world(nf, w2) : w2;
+                valid = valid & check_wo_wi_valid(nf.n, sp_ng_local(sp), lo, wl);
                 break;
             }
             case MAT_DIFFUSE: valid = sample_lobe(LOBE_DIFFUSE, mk2(0, 0), 1.0f, lo, u_sample, wl); break;
@@ -667,7 +701,7 @@ AKR_HD BsdfSample shade_sample(const ShadePoint& sp, const DMaterial& m, const f
 // (mod.rs:588-590).
 AKR_HD vec3 shade_ns(const ShadePoint& sp, const DMaterial& m) {
     vec3 ns = mk3(0, 0, 1);
-    if (m.kind == MAT_PRINCIPLED) ns = to_world(sp.nm_frame, mk3(0, 0, 1));
+    if (m.kind == MAT_PRINCIPLED) ns = to_world(sp_nm_frame(sp, m), mk3(0, 0, 1));
     else if (m.kind == MAT_GLASS) ns = normalize(mk3(0, 0, 1) + mk3(0, 0, 1));
     return to_world(sp.frame, ns);
 }
@@ -688,7 +722,7 @@ AKR_HD float shade_roughness(const ShadePoint& sp, const DMaterial& m, const flo
     vec3 lo = to_local(sp.frame, wo);
     switch (m.kind) {
         case MAT_PRINCIPLED: {
-            vec3 lo2 = (m.flags & MF_NORMAL_MAP) ? to_local(sp.nm_frame, lo) : lo;
+            vec3 lo2 = (m.flags & MF_NORMAL_MAP) ? to_local(sp_nm_frame(sp, m), lo) : lo;
             LobeKind lobe;
             vec2 alpha;
             bool coat;

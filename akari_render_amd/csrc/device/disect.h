@@ -149,9 +149,22 @@ AKR_D bool trace_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmin, float 
 // resident) records serves both: half the scalar loads and loop overhead of two separate walks, and two independent
 // dependency chains per record for the VALU to overlap. A ray that does not exist for a lane is passed with
 // tmax < tmin and can never hit.
-template <bool TEX = false, bool UNROLL = false>
+//
+// WALK selects where a record's coefficients sit when the VALU reads them (measured variants):
+//   0  SGPRs: s_load through the scalar cache, every fma of the affine rows names one SGPR operand. A SIMD accepts one
+//      scalar-operand VALU instruction per ~4.3 cycles against ~2.15 for a VGPR-only one (tools/micro/valu_rate.hip), and the
+//      rows come 16 such instructions in a row.
+//   1  VGPRs: the records are staged in LDS with the shading tables and every lane reads the same address (a broadcast
+//      ds_read_b128, 4 LDS cycles per wave and row); all of the test's arithmetic is then VGPR-only.
+//   2  SGPRs, but the two rays of the pair go through the rows as ONE packed instruction (v_pk_fma_f32 with the coefficient
+//      broadcast): half as many scalar-operand instructions; a packed f32 op holds the VALU for two slots either way.
+// The arithmetic (operation order, fma placement) is identical in all three: films do not change.
+typedef float v2f __attribute__((ext_vector_type(2)));
+AKR_D v2f pk_fma(float a, v2f b, v2f c) { return __builtin_elementwise_fma((v2f){a, a}, b, c); }
+AKR_D v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+template <bool TEX = false, bool UNROLL = false, int WALK = 0>
 AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, uint32_t ex0, vec3 so, vec3 sd, float stmax,
-                                 uint32_t sex0, uint32_t sex1, Hit& hit, bool& found, bool& occluded) {
+                                 uint32_t sex0, uint32_t sex1, Hit& hit, bool& found, bool& occluded, const float4* lds_recs = nullptr) {
     // best_t starts one ulp above tmax: "t < best_t" then admits a first hit at t == tmax and keeps, among equal t, the
     // lowest id afterwards (ascending k, strict '<') without a separate "no hit yet" test
     float best_t = next_up(tmax);
@@ -162,21 +175,43 @@ AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, u
     typedef const float __attribute__((address_space(4))) * ConstF;
     ConstF recs = (ConstF)(uintptr_t)sc.woop;
     auto load_rec = [&](uint32_t k, float4& a, float4& b, float4& c) {
+        if (WALK == 1) {  // the same LDS address in every lane: broadcast reads
+            const float4* r = lds_recs + 3 * (size_t)k;
+            a = r[0]; b = r[1]; c = r[2];
+            return;
+        }
         ConstF r = recs + 12 * (size_t)k;
         a = make_float4(r[0], r[1], r[2], r[3]);
         b = make_float4(r[4], r[5], r[6], r[7]);
         c = make_float4(r[8], r[9], r[10], r[11]);
     };
     PlaneHit ph{0.0f, 0.0f, 0.0f, 0.0f}, sph{0.0f, 0.0f, 0.0f, 0.0f};
+    const v2f ox2 = {o.x, so.x}, oy2 = {o.y, so.y}, oz2 = {o.z, so.z}, dx2 = {d.x, sd.x}, dy2 = {d.y, sd.y}, dz2 = {d.z, sd.z};
+    v2f hx2 = {0.0f, 0.0f}, hy2 = {0.0f, 0.0f}, hz2 = {0.0f, 0.0f};  // WALK 2: the two rays' hit points on the current plane
     auto record = [&](uint32_t k, const float4& r0, const float4& r1, const float4& r2) {
-        if (!((sc.plane_share_mask >> k) & 1ull)) {  // wave-uniform: one plane solve per ray per coplanar pair of records
-            ph = tri_plane(o, d, r2);
-            sph = tri_plane(so, sd, r2);
-        }
         float u, v, su, sv;
+        if (WALK == 2) {
+            // tri_plane / tri_uv for both rays at once, component 0 = closest-hit ray, 1 = shadow ray; the same fma chains
+            if (!((sc.plane_share_mask >> k) & 1ull)) {
+                const v2f den = pk_fma(r2.x, dx2, pk_fma(r2.y, dy2, (v2f){r2.z, r2.z} * dz2));
+                const v2f num = pk_fma(r2.x, ox2, pk_fma(r2.y, oy2, pk_fma(r2.z, oz2, (v2f){r2.w, r2.w})));
+                ph.t = -num.x / den.x;
+                sph.t = -num.y / den.y;
+                const v2f t2 = {ph.t, sph.t};
+                hx2 = pk_fma(t2, dx2, ox2); hy2 = pk_fma(t2, dy2, oy2); hz2 = pk_fma(t2, dz2, oz2);
+            }
+            const v2f u2 = pk_fma(r0.x, hx2, pk_fma(r0.y, hy2, pk_fma(r0.z, hz2, (v2f){r0.w, r0.w})));
+            const v2f v2 = pk_fma(r1.x, hx2, pk_fma(r1.y, hy2, pk_fma(r1.z, hz2, (v2f){r1.w, r1.w})));
+            u = u2.x; su = u2.y; v = v2.x; sv = v2.y;
+        } else {
+            if (!((sc.plane_share_mask >> k) & 1ull)) {  // wave-uniform: one plane solve per ray per coplanar pair of records
+                ph = tri_plane(o, d, r2);
+                sph = tri_plane(so, sd, r2);
+            }
+            tri_uv(ph, r0, r1, u, v);
+            tri_uv(sph, r0, r1, su, sv);
+        }
         const float t = ph.t, st = sph.t;
-        tri_uv(ph, r0, r1, u, v);
-        tri_uv(sph, r0, r1, su, sv);
         float m = hit_margin(t, u, v, tmax), sm = hit_margin(st, su, sv, stmax);
         m = (k == ex0) ? -1.0f : m;
         sm = (k == sex0) ? -1.0f : sm;
@@ -299,7 +334,7 @@ AKR_D void trav_step(const DScene& sc, Trav& s, uint32_t* __restrict__ stack, Tr
         const uint32_t j = 31u - (uint32_t)__builtin_clz(s.G);  // nearest pending sibling
         s.G &= ~(1u << j);
         if ((s.G >> 24) != 0) {  // the others wait as one entry
-            if (s.sp < kBvhStackDepth) {
+            if (s.sp < sc.bvh_stack_depth) {
                 stack[s.sp * 256u] = s.G;
                 s.sp++;
             } else {

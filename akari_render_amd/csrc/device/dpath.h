@@ -274,7 +274,7 @@ AKR_D void stage_scene_tables(const PtParams& p, uint32_t* lds, PtParams& staged
                            p.sc.lights,     p.sc.light_pdf, p.sc.area_pdf, p.sc.tex.nodes, p.sc.tex.images, p.sc.tex.mat_inputs,
                            p.sc.ggx_table};
     uint32_t* dst[13];
-    uint32_t off = BVH ? kBvhStackDepth * 256u : 0u;  // in words, behind the stacks
+    uint32_t off = BVH ? p.sc.bvh_stack_depth * 256u : 0u;  // in words, behind the stacks
 #pragma unroll
     for (int e = BVH ? 2 : 0; e < 13; e++) {
         if ((e >= 9 && e < 12 && !TEX) || (e == 12 && !GGX)) continue;
@@ -350,11 +350,27 @@ struct PathRegs {
     vec3 film_rgb;
     float film_w;
     uint32_t c_samples, c_closest, c_shadow, c_shaded;
+    bool carry;  // BVH kernels: the lane's rays of the last intersection phase are still being traced (pt_kernels.hip: AKR_PT_STRAGGLERS)
     // a vertex whose shading was put off by one iteration (pt_kernels.hip: conductor hits are shaded on even iterations only)
     bool deferred;
     uint32_t d_gid;
     float d_u, d_v;
 };
+
+// PARK: the part of a lane's state that the shading code never touches, kept out of the register file while a vertex is shaded.
+// The full-graph kernels need ~260 registers at their peak (the Principled closure tree) and run at 4 waves per SIMD, i.e. with
+// 128; what does not fit the compiler spills to scratch memory -- vector-memory round trips through L1 / L2, 300 B per sample of
+// fabric traffic on C3 and a quarter of the wave cycles waiting. Scratch is the only place the compiler knows; the workgroup's
+// LDS has room for a column of kParkSlots words per lane (slot s of lane i at word s * 256 + i: one bank per lane, no
+// conflicts). path_step<.., PARK> writes the cold fields there before it shades a vertex and reads them back after: two LDS
+// instructions per field and iteration instead of a scratch store and load, and the registers are free in between. The pixel
+// of the lane (pix, sx, sy: constant for the launch) lives there for the whole launch.
+constexpr uint32_t kParkSlots = 16, kParkSlotsNoDefer = 13;
+constexpr uint32_t kCarrySlots = 13;  // a traversal carried over to the next intersection phase (pt_kernels.hip: AKR_PT_STRAGGLERS)
+enum : uint32_t { PK_PIX = 0, PK_SX, PK_SY, PK_FILM, PK_FILM_W = PK_FILM + 3, PK_CNT, PK_SPP = PK_CNT + 3, PK_DEFER = PK_SPP + 3, PK_END = PK_DEFER + 3 };
+static_assert(PK_END <= kParkSlots, "park column too small");
+AKR_D void park_put(uint32_t* park, uint32_t slot, uint32_t v) { park[slot * 256u] = v; }
+AKR_D uint32_t park_get(const uint32_t* park, uint32_t slot) { return park[slot * 256u]; }
 
 template <bool PMJ = false>
 AKR_D void path_regs_init(PathRegs& r, const PtParams& p, bool active, uint32_t pix, uint32_t sx, uint32_t sy) {
@@ -367,6 +383,7 @@ AKR_D void path_regs_init(PathRegs& r, const PtParams& p, bool active, uint32_t 
     r.active = active; r.has_ray = active; r.has_shadow = false; r.s_add = false; r.s_depth1 = false;
     r.finalize = false; r.lane_done = false;
     r.deferred = false; r.d_gid = kInvalid; r.d_u = 0.0f; r.d_v = 0.0f;
+    r.carry = false;
     r.samples_done = 0; r.pass_idx = 0; r.c_samples = 0;
     r.cur_spp = (p.n_passes == 1) ? p.last_pass_spp : p.pass_spp;
     r.c_closest = 0; r.c_shadow = 0; r.c_shaded = 0;
@@ -396,9 +413,12 @@ AKR_D void shifted_pixel(const PtParams& p, uint32_t px, uint32_t py, uint32_t& 
 // FD: 1 / 0 = force_diffuse known at compile time (the reference's JIT also specialises the kernel on it: the branch
 // at pt.rs:268 is taken while tracing the kernel, so a force_diffuse kernel contains no Principled code); -1 = read
 // p.force_diffuse at run time.
-template <int FD = -1, bool TEX = false, bool PMJ = false>
-AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found, bool occluded, uint32_t pix, uint32_t sx, uint32_t sy) {
+template <int FD = -1, bool TEX = false, bool PMJ = false, int PARK = 0>  // PARK: 0 no, 1 yes, 2 yes without the DEFER fields
+AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found, bool occluded, uint32_t pix_in, uint32_t sx_in, uint32_t sy_in,
+                     uint32_t* park = nullptr) {
     const bool force_diffuse = FD < 0 ? (p.force_diffuse != 0) : (FD != 0);
+    // PARK: the lane's pixel comes from its LDS column where it is needed (the arguments are ignored)
+    auto pix_of = [&]() { return PARK ? park_get(park, PK_PIX) : pix_in; };
     const DScene& sc = p.sc;
     const size_t N = (size_t)p.width * p.height;
     // ---- resolve the shadow ray (pt.rs:504-513) ----
@@ -425,6 +445,7 @@ AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found,
         r.finalize = false;
         if (r.lane_done) {
             r.active = false;
+            const uint32_t pix = pix_of();
             p.states[pix] = r.smp.pcg;
             p.film[3 * (size_t)pix + 0] = r.film_rgb.x;
             p.film[3 * (size_t)pix + 1] = r.film_rgb.y;
@@ -435,6 +456,13 @@ AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found,
     // ---- shade the vertex the closest-hit ray found ----
     if (r.active && r.has_ray) {
         bool terminated = false;
+        if (PARK) {  // nothing below reads these before the sample-end bookkeeping
+            park_put(park, PK_FILM + 0, f2u(r.film_rgb.x)); park_put(park, PK_FILM + 1, f2u(r.film_rgb.y)); park_put(park, PK_FILM + 2, f2u(r.film_rgb.z));
+            park_put(park, PK_FILM_W, f2u(r.film_w));
+            park_put(park, PK_CNT + 0, r.c_samples); park_put(park, PK_CNT + 1, r.c_closest); park_put(park, PK_CNT + 2, r.c_shadow);
+            park_put(park, PK_SPP + 0, r.samples_done); park_put(park, PK_SPP + 1, r.pass_idx); park_put(park, PK_SPP + 2, r.cur_spp);
+            if (PARK == 1) { park_put(park, PK_DEFER + 0, r.d_gid); park_put(park, PK_DEFER + 1, f2u(r.d_u)); park_put(park, PK_DEFER + 2, f2u(r.d_v)); }
+        }
         if (!found) {
             terminated = true;  // pt.rs:381-396 (hit_envmap adds zero)
         } else {
@@ -526,6 +554,13 @@ AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found,
                 shade_vertex(folded);
             }
         }
+        if (PARK) {
+            r.film_rgb = mk3(u2f(park_get(park, PK_FILM + 0)), u2f(park_get(park, PK_FILM + 1)), u2f(park_get(park, PK_FILM + 2)));
+            r.film_w = u2f(park_get(park, PK_FILM_W));
+            r.c_samples = park_get(park, PK_CNT + 0); r.c_closest = park_get(park, PK_CNT + 1); r.c_shadow = park_get(park, PK_CNT + 2);
+            r.samples_done = park_get(park, PK_SPP + 0); r.pass_idx = park_get(park, PK_SPP + 1); r.cur_spp = park_get(park, PK_SPP + 2);
+            if (PARK == 1) { r.d_gid = park_get(park, PK_DEFER + 0); r.d_u = u2f(park_get(park, PK_DEFER + 1)); r.d_v = u2f(park_get(park, PK_DEFER + 2)); }
+        }
         if (terminated) {
             // this sample draws no more random numbers: account for it and start the next camera ray now; its
             // radiance is finished (above) after the shadow ray still pending has been resolved
@@ -544,6 +579,7 @@ AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found,
             }
             if (more) {
                 sampler_start<PMJ>(p, r.smp);
+                const uint32_t sx = PARK ? park_get(park, PK_SX) : sx_in, sy = PARK ? park_get(park, PK_SY) : sy_in;
                 generate_ray<PMJ>(p, sx, sy, r.smp, r.ro, r.rd);
                 r.ray_ex0 = kInvalid;
             } else {

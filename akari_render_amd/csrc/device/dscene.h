@@ -26,6 +26,8 @@ constexpr uint32_t kBvhNodeWords = AKR_BVH_NODE_WORDS;  // u32 words from one no
 constexpr uint32_t kBvhTriWords = 16;                   // BVH path: 12 words Woop record + global id + 3 unused
 // Traversal stack entries per lane. A pending group of sibling nodes is ONE entry and a traversal holds at most one group
 // per tree level, so a tree of depth <= kBvhStackDepth can never overflow; scene_build.cpp rejects deeper trees.
+// kBvhStackDepth is the deepest tree a scene may have; a launch sizes its stacks from the tree the scene actually got
+// (DScene.bvh_stack_depth: 10 levels for the 10 M-triangle hall -- 10 KB of LDS per workgroup instead of 24).
 constexpr uint32_t kBvhStackDepth = 24;
 
 // shade record rows (float4 each):
@@ -61,6 +63,7 @@ struct DScene {
     const LightRec* __restrict__ lights;            // light_tri_offset + light_n_tris + light_inst (+ inst_tri_offset), packed
     const uint4* __restrict__ bvh_nodes;            // nullptr on the exhaustive path
     uint32_t n_tris, n_lights, n_nodes, has_alpha;
+    uint32_t bvh_stack_depth;                       // BVH path: traversal stack entries per lane in LDS = depth of this scene's tree
     uint64_t plane_share_mask;                      // exhaustive path: bit k = record k carries the plane row of record k-1
     TexScene tex;                                   // textures + shader-graph node lists (all nullptr without textures)
 };

@@ -230,7 +230,7 @@ hipError_t launch_gpt_sample(const PtParams& p, const GptParams& g, hipStream_t 
     if (blocks == 0) return hipSuccess;
     const bool bvh = p.sc.bvh_nodes != nullptr, tex = p.sc.tex.nodes != nullptr;
     size_t lds;
-    const PtParams q = with_tex_slots(p, bvh ? kBvhStackDepth * 256 * 4 : p.stage_total, lds);
+    const PtParams q = with_tex_slots(p, bvh ? p.sc.bvh_stack_depth * 256 * 4 : p.stage_total, lds);
     if (bvh) {
         if (tex) hipLaunchKernelGGL((k_gpt_sample<true, true>), dim3(blocks), dim3(256), lds, stream, q, g);
         else hipLaunchKernelGGL((k_gpt_sample<true, false>), dim3(blocks), dim3(256), lds, stream, q, g);

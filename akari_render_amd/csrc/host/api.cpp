@@ -3,6 +3,7 @@
 // Every entry point catches C++ exceptions and HIP errors and turns them into an akr_status plus a thread-local
 // message; nothing throws or aborts across the boundary. There is no CPU path here: without a GPU
 // akr_context_create fails with AKR_ERR_NO_DEVICE.
+#include <mutex>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -140,6 +141,7 @@ struct akr_scene {
         DevBuf materials, tex_nodes, mat_inputs;
     };
     std::map<uint32_t, std::unique_ptr<ColorSet>> color_sets;
+    std::mutex color_sets_mutex;  // sessions of several host threads may begin on one scene; entries are never removed before the scene dies
     DScene dscene;
     float r2c[16], c2w[16];
     uint32_t c2w_identity = 0;
@@ -168,6 +170,8 @@ struct akr_pt_session {
     uint32_t wf_slots = 0, wf_trace_blocks = 0;
     uint32_t spp_done = 0, n_launches = 0;
     uint32_t pmj_spp = 1;  // the spp the pmj02bn sampler stratifies for (the method's total spp)
+    const akr_scene::ColorSet* color_set = nullptr;  // the scene's tables for cfg.color != 0 (looked up under the scene's lock by akr_pt_begin)
+    int defer_metal_option = -1;  // TuningOptions.defer_metal as it was when the session began
     // timed regions on the context's stream: pairs still in flight, and the elapsed time of the completed ones (folded in and
     // destroyed as they complete, so a long progressive session holds a bounded number of events)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -331,6 +335,7 @@ static void scene_finish(akr_scene* s) {
     d.n_lights = cs.n_lights;
     d.n_nodes = (uint32_t)(cs.bvh_nodes.size() / kBvhNodeWords);
     d.has_alpha = cs.has_alpha ? 1u : 0u;
+    d.bvh_stack_depth = std::max(1u, std::min(cs.bvh_depth, kBvhStackDepth));  // one pending group per tree level at most (disect.h)
     d.plane_share_mask = 0;
     if (cs.bvh_nodes.empty())  // exhaustive path (<= 64 triangles): which records repeat their predecessor's plane row
         for (uint32_t k = 1; k < d.n_tris && k < 64; k++)
@@ -379,7 +384,7 @@ static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pas
     p.color = c.color;
     p.sc.tex.color = c.color;
     if (c.color != 0) {  // the material tables of this pipeline (created by akr_pt_begin)
-        const auto& set = *se->scene->color_sets.at(c.color);
+        const auto& set = *se->color_set;
         p.sc.materials = set.materials.as<DMaterial>();
         if (s->cs.has_textures) {
             p.sc.tex.nodes = set.tex_nodes.as<DNode>();
@@ -417,7 +422,7 @@ static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pas
         p.stage_total = 0;
         p.tex_slots = cs.has_textures ? cs.tex_slots : 0;
         // one workgroup's dynamic LDS stays within 64 KB: traversal stacks + staged tables + the graph evaluation's value slots
-        const size_t other = (bvh ? kBvhStackDepth * 256 * 4 : 0) + (size_t)p.tex_slots * kTexValStride * sizeof(TexVal);
+        const size_t other = (bvh ? (size_t)p.sc.bvh_stack_depth * 256 * 4 : 0) + (size_t)p.tex_slots * kTexValStride * sizeof(TexVal);
         if (total <= (bvh ? kStageMaxBytesBvh : kStageMaxBytes) && (!bvh || other + total <= 64 * 1024)) {  // all of it or nothing (a TEX kernel reads its tables through LDS addresses)
             // the albedo table as well for the full-graph exhaustive kernel of a textured scene (stage_scene_tables: GGX), if three
             // workgroups per CU still fit (AKR_PT_MIN_WAVES_TEX = 3: 160 KB / 3)
@@ -440,7 +445,7 @@ static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pas
         }
         bool want = n_metal > 0 && 2 * n_metal <= n_surface;
         uint32_t mask = 1u;  // iterations with (iteration & mask) != 0 put conductor hits off
-        if (const char* e = std::getenv("AKR_PT_DEFER_METAL")) { mask = (uint32_t)std::atoi(e); want = mask != 0; }  // measurements / tests
+        if (se->defer_metal_option >= 0) { mask = (uint32_t)se->defer_metal_option; want = mask != 0; }  // akr_option_set("defer_metal"): measurements / tests
         p.defer_metal = (want && cs.bvh_nodes.empty() && !c.force_diffuse) ? mask : 0u;
     }
     p.shard_rank = c.shard_count > 1 ? c.shard_rank : 0;
@@ -460,15 +465,10 @@ static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pas
 // schedules trace ~2 G rays/s -- the traversal is bound by the L1/L2 request rate of the node fetches, not by occupancy --
 // and the wavefront schedule pays for streaming the path state and for its per-iteration tail on top).
 static bool choose_wavefront(const akr_scene* scene) {
-    const char* env = std::getenv("AKR_PT_MODE");
-    std::string mode = env ? env : "auto";
-    const bool has_bvh = !scene->cs.bvh_nodes.empty();
-    if (mode == "mega") return false;
-    if (mode == "wavefront") {
-        if (!has_bvh) throw std::invalid_argument("AKR_PT_MODE=wavefront needs a BVH scene (more than 64 triangles, or AKR_FORCE_BVH=1)");
-        return true;
-    }
-    return false;
+    if (!tuning().wavefront) return false;
+    if (scene->cs.bvh_nodes.empty())
+        throw std::invalid_argument("the wavefront schedule (option wavefront = 1 / AKR_PT_MODE=wavefront) needs a BVH scene (more than 64 triangles, or option force_bvh)");
+    return true;
 }
 
 static void wf_allocate(akr_pt_session* se, uint32_t n_slots) {
@@ -534,6 +534,16 @@ extern "C" {
 
 AKR_API const char* akr_last_error(void) { return g_last_error.c_str(); }
 AKR_API const char* akr_version(void) { return "akari_hip 0.1.0 gfx950"; }
+AKR_API int32_t akr_option_set(const char* name, int32_t value) {
+    if (!tuning_set(name, value)) return fail(AKR_ERR_INVALID_ARGUMENT, std::string("akr_option_set: unknown option '") + (name ? name : "(null)") + "'");
+    return AKR_OK;
+}
+AKR_API int32_t akr_option_get(const char* name, int32_t* value) {
+    int v = 0;
+    if (!value || !tuning_get(name, &v)) return fail(AKR_ERR_INVALID_ARGUMENT, std::string("akr_option_get: unknown option '") + (name ? name : "(null)") + "'");
+    *value = v;
+    return AKR_OK;
+}
 
 AKR_API int32_t akr_context_create(int32_t device, akr_context** out) {
     if (!out) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_context_create: out is NULL");
@@ -873,6 +883,7 @@ AKR_API int32_t akr_pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_co
         se->scene = scene;
         se->film = film;
         se->cfg = *cfg;
+        std::unique_lock<std::mutex> color_lock(scene->color_sets_mutex);
         if (cfg->color != 0 && !scene->color_sets.count(cfg->color)) {
             // ColorPipeline other than sRGB / sRGB: the scene's constants were folded for the default pipeline; fold them again
             // for this one (svm/texture/mod.rs:9-43 at every Rgb / spectral_uplift node) and keep the tables with the scene
@@ -888,6 +899,8 @@ AKR_API int32_t akr_pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_co
             }
             scene->color_sets[cfg->color] = std::move(set);
         }
+        if (cfg->color != 0) se->color_set = scene->color_sets.at(cfg->color).get();  // stable: the map owns it through a unique_ptr
+        color_lock.unlock();
         const uint64_t n = (uint64_t)film->width * film->height;
         // init_pcg32_buffer_with_seed (sampler/mod.rs:148-160): host StdRng(seed) u64 per pixel, device new_seq_offset
         if (cfg->sampler_type == AKR_SAMPLER_PMJ02BN || cfg->sampler_type == AKR_SAMPLER_SOBOL) {
@@ -910,6 +923,7 @@ AKR_API int32_t akr_pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_co
         se->counters.alloc(8 * sizeof(uint64_t));
         HIP_CHECK(hipMemsetAsync(se->counters.p, 0, 8 * sizeof(uint64_t), ctx->stream));
         se->wavefront = choose_wavefront(scene);
+        se->defer_metal_option = tuning().defer_metal;
         if (se->wavefront) {
             fill_params(se.get(), 1, cfg->spp_per_pass);  // for n_items
             wf_allocate(se.get(), se->params.n_items);

@@ -277,7 +277,9 @@ void build_bvh8(const std::vector<float>& tri_bounds, uint32_t n_tris, float pad
                     if (slot_of[c] >= 0) continue;
                     for (int sl = 0; sl < 8; sl++) {
                         if (child_in[sl] >= 0) continue;
-                        if (cost[c][sl] > bv) { bv = cost[c][sl]; bc = c; bs = sl; }
+                        // `!(cost <= bv)` also takes a NaN cost (boxes with non-finite corners are refused by compile_scene, but a
+                        // pairing must come out of this loop whatever the numbers are: bc / bs index the stack arrays below)
+                        if (bc < 0 || !(cost[c][sl] <= bv)) { bv = cost[c][sl]; bc = c; bs = sl; }
                     }
                 }
                 slot_of[bc] = bs;

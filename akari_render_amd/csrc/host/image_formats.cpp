@@ -14,6 +14,7 @@
 //     therefore pinned to the crate's arithmetic only as far as this restatement of it is right -- there is no copy of the crate
 //     here to check against ("parity unpinned" items).
 // Rows come out in file order (top first); the caller flips (load.rs:596).
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
@@ -66,7 +67,7 @@ void tiff_lzw(const uint8_t* src, size_t n, std::vector<uint8_t>& out, size_t ex
     size_t pos = 0;
     int old = -1;
     out.clear();
-    out.reserve(expect);
+    out.reserve(std::min<size_t>(expect, 1u << 24));  // `expect` comes from header fields: grow as the data really decodes
     for (;;) {
         while (have < (int)bits) {
             if (pos >= n) return;  // a stream without an end code: what was decoded stands (libtiff writes EOI; others may not)
@@ -106,7 +107,7 @@ void tiff_lzw(const uint8_t* src, size_t n, std::vector<uint8_t>& out, size_t ex
 }
 void tiff_packbits(const uint8_t* src, size_t n, std::vector<uint8_t>& out, size_t expect) {
     out.clear();
-    out.reserve(expect);
+    out.reserve(std::min<size_t>(expect, n * 128 + 16));  // PackBits expands at most 128 times
     size_t pos = 0;
     while (pos < n && out.size() < expect) {
         const int8_t c = (int8_t)src[pos++];
@@ -200,6 +201,9 @@ void decode_tiff(const uint8_t* data, size_t n, uint32_t& width, uint32_t& heigh
         throw std::runtime_error("unsupported: tiff compression " + std::to_string(compression));
     const bool tiled = f_tile_off.count != 0;
     if (tiled && (tile_w == 0 || tile_h == 0)) throw std::runtime_error("tiff: tile size missing");
+    // tile sizes are untrusted header fields: rows * tile_w * bytes_per_pixel below must not wrap around (a 2^31 x 2^31 tile made
+    // `expect` 0, the "enough samples" check pass and the pixel loop read past the chunk: round-2 advisor finding)
+    if (tiled && (tile_w > 65536u || tile_h > 65536u)) throw std::runtime_error("tiff: tile size out of range");
     if (!tiled && f_strip_off.count == 0) throw std::runtime_error("tiff: no strips and no tiles");
     const TiffField& f_off = tiled ? f_tile_off : f_strip_off;
     const TiffField& f_cnt = tiled ? f_tile_cnt : f_strip_cnt;
@@ -211,6 +215,12 @@ void decode_tiff(const uint8_t* data, size_t n, uint32_t& width, uint32_t& heigh
     const size_t bps = bits / 8, px_bytes = bps * spp;
     // samples of the whole image, native 16 / 32-bit values widened: decoded once, converted at the end
     std::vector<uint8_t> chunk;
+    // no allocation on the word of the header alone: the file must be able to hold the picture (stored: byte for byte; LZW /
+    // deflate / PackBits cannot expand more than ~1400 times), otherwise a 100-byte file costs a gigabyte before it is refused
+    {
+        const uint64_t need = (uint64_t)width * height * px_bytes;
+        if (compression == 1 ? need > n : need / 1400u > n) throw std::runtime_error("tiff: file too short for its image size");
+    }
     rgba.assign(4ull * width * height, 255);
     for (uint32_t cy = 0; cy < down; cy++) {
         for (uint32_t cx = 0; cx < across; cx++) {

@@ -365,6 +365,8 @@ void decode_png(const uint8_t* data, size_t n, uint32_t& w, uint32_t& h, std::ve
     if (ctype == 3 && plte.size() < 3) throw std::runtime_error("png: palette image without PLTE");
     const size_t bpp_bits = (size_t)channels * depth, bpp = (bpp_bits + 7) / 8;
     std::vector<uint8_t> raw = inflate_zlib(idat.data(), idat.size());
+    // the picture is allocated only once the data can hold it (every pixel's bits are in `raw`, interlaced or not)
+    if ((uint64_t)raw.size() * 8 < (uint64_t)w * h * bpp_bits) throw std::runtime_error("png: image data too short");
     rgba.assign(4ull * w * h, 255);
     auto sample = [&](const uint8_t* row, size_t idx) -> uint32_t {  // idx-th sample of the row, raw value
         if (depth == 8) return row[idx];

@@ -10,6 +10,7 @@
 // -ffp-contract=off too), so a quantity folded on the host has the bits the device would have computed.
 #include "scene_build.h"
 
+#include <mutex>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -603,6 +604,12 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
             float* bb = &bounds[6ull * gid];
             bb[0] = min_f(min_f(A.x, B.x), C.x); bb[1] = min_f(min_f(A.y, B.y), C.y); bb[2] = min_f(min_f(A.z, B.z), C.z);
             bb[3] = max_f(max_f(A.x, B.x), C.x); bb[4] = max_f(max_f(A.y, B.y), C.y); bb[5] = max_f(max_f(A.z, B.z), C.z);
+            // a non-finite corner (inf / NaN vertex, or a transform that produces one) has no place in a box hierarchy: the
+            // builder's costs become NaN and geometry would silently go missing. Refused here, for every scene size.
+            if (!(is_finite(A.x) && is_finite(A.y) && is_finite(A.z) && is_finite(B.x) && is_finite(B.y) && is_finite(B.z) && is_finite(C.x) &&
+                  is_finite(C.y) && is_finite(C.z)))
+                throw std::invalid_argument("instance " + std::to_string(i) + ", triangle " + std::to_string(prim) +
+                                            ": non-finite vertex position after the instance transform");
             for (int a = 0; a < 3; a++) {
                 out.scene_lo[a] = min_f(out.scene_lo[a], bb[a]);
                 out.scene_hi[a] = max_f(out.scene_hi[a], bb[3 + a]);
@@ -677,8 +684,8 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
 
     // acceleration structure: tiny scenes are intersected exhaustively from the scalar cache, others get a BVH4
     // (AKR_FORCE_BVH=1 builds the BVH for tiny scenes too: lets the tests run both intersectors on scenes/cbox)
-    const char* force = std::getenv("AKR_FORCE_BVH");
-    const uint32_t kExhaustiveMax = (force && force[0] == '1') ? 0u : 64u;
+    const TuningOptions tune = tuning();
+    const uint32_t kExhaustiveMax = tune.force_bvh ? 0u : 64u;
     // the exhaustive kernels stage the shading tables in LDS (pt_kernels.hip): a tiny mesh with a huge material list goes the BVH way
     size_t stage = 0;
     for (size_t b : {out.shade.size() * 4, out.normals.size() * 4, out.inst.size() * 4, out.materials.size() * sizeof(DMaterial),
@@ -690,8 +697,7 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
         for (int a = 0; a < 3; a++) diag2 += sqr(out.scene_hi[a] - out.scene_lo[a]);
         float pad = 4e-6f * __builtin_sqrtf(diag2);
         std::vector<uint32_t> order;
-        const char* bal = std::getenv("AKR_BVH_BALANCED");  // test hook: take the fallback builder
-        const bool force_balanced = bal && bal[0] == '1';
+        const bool force_balanced = tune.bvh_balanced != 0;  // test hook: take the fallback builder
         build_bvh8(bounds, n_tris, pad, kBvhNodeWords, force_balanced, order, out.bvh_nodes, out.bvh_depth);
         // A traversal keeps at most one stack entry per tree level (device/disect.h): a tree that fits the stack cannot
         // overflow it. An SAH tree deeper than that (pathological geometry) is replaced by a median-split tree of depth
@@ -711,6 +717,50 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
     }
     // two all-zero records of padding: the exhaustive intersectors prefetch up to record n + 1
     out.woop.resize(out.woop.size() + 32, 0.0f);
+}
+
+namespace {
+std::mutex g_tuning_mutex;
+bool g_tuning_init = false;
+TuningOptions g_tuning;
+void tuning_init_locked() {
+    if (g_tuning_init) return;
+    g_tuning_init = true;
+    auto flag = [](const char* name) { const char* e = std::getenv(name); return e && e[0] == '1' ? 1 : 0; };
+    g_tuning.force_bvh = flag("AKR_FORCE_BVH");
+    g_tuning.bvh_balanced = flag("AKR_BVH_BALANCED");
+    if (const char* e = std::getenv("AKR_PT_DEFER_METAL")) g_tuning.defer_metal = std::atoi(e);
+    if (const char* e = std::getenv("AKR_PT_MODE")) g_tuning.wavefront = std::string(e) == "wavefront" ? 1 : 0;
+}
+int* tuning_field(const char* name) {
+    const std::string n = name ? name : "";
+    if (n == "force_bvh") return &g_tuning.force_bvh;
+    if (n == "bvh_balanced") return &g_tuning.bvh_balanced;
+    if (n == "defer_metal") return &g_tuning.defer_metal;
+    if (n == "wavefront") return &g_tuning.wavefront;
+    return nullptr;
+}
+}  // namespace
+TuningOptions tuning() {
+    std::lock_guard<std::mutex> lock(g_tuning_mutex);
+    tuning_init_locked();
+    return g_tuning;
+}
+bool tuning_set(const char* name, int value) {
+    std::lock_guard<std::mutex> lock(g_tuning_mutex);
+    tuning_init_locked();
+    int* f = tuning_field(name);
+    if (!f) return false;
+    *f = value;
+    return true;
+}
+bool tuning_get(const char* name, int* value) {
+    std::lock_guard<std::mutex> lock(g_tuning_mutex);
+    tuning_init_locked();
+    int* f = tuning_field(name);
+    if (!f) return false;
+    *value = *f;
+    return true;
 }
 
 }  // namespace akr

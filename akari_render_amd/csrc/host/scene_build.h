@@ -82,6 +82,19 @@ DMaterial fold_material(const akr_material_desc& m, uint32_t color = 0);
 // out.mat_inputs only
 void compile_materials(const FlatScene& flat, uint32_t color, CompiledScene& out, std::vector<akr_material_desc>& descs);
 void build_alias_table(const std::vector<float>& weights, std::vector<AliasEntry>& entries, std::vector<float>& pdf);
+// Process-wide tuning switches and test hooks (akr_option_set / akr_option_get of the C ABI). Each starts from its environment
+// variable, read ONCE when the first of them is looked at; after that only akr_option_set changes it. No launch path calls getenv.
+//   force_bvh    AKR_FORCE_BVH=1          scenes of <= 64 triangles get a BVH too (both intersectors on one scene)
+//   bvh_balanced AKR_BVH_BALANCED=1       the median-split fallback builder instead of SAH
+//   defer_metal  AKR_PT_DEFER_METAL=<m>   -1 = the library decides (default); 0 = off; m > 0 = iterations with (i & m) != 0 put conductor hits off
+//   wavefront    AKR_PT_MODE=wavefront    1 = sessions on BVH scenes use the wavefront schedule (wf_kernels.hip) instead of the megakernel
+struct TuningOptions {
+    int force_bvh = 0, bvh_balanced = 0, defer_metal = -1, wavefront = 0;
+};
+TuningOptions tuning();                          // a snapshot (thread-safe)
+bool tuning_set(const char* name, int value);    // false: unknown name
+bool tuning_get(const char* name, int* value);
+
 void compile_scene(const FlatScene& flat, CompiledScene& out);
 // PerspectiveCameraData::new (camera/mod.rs:119-153)
 void camera_matrices(const akr_camera_desc& cam, float r2c[16], float c2w[16], uint32_t* c2w_identity);

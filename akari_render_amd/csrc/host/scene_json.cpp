@@ -86,7 +86,10 @@ M4 m4_translation(float x, float y, float z) {
     return r;
 }
 M4 m4_axis_angle(float ax, float ay, float az, float angle) {  // glam Mat4::from_axis_angle
-    float s = sinf(angle), c = cosf(angle);
+    // sin / cos of the f32 angle, correctly rounded to f32 (double-precision libm, rounded once): what glam's f32::sin_cos
+    // returns on every libm that rounds correctly, and bit for bit what the checker's reader (oracle/scene_json.py) computes --
+    // sinf / cosf of the host libm may be one ulp off that, which made this reader's camera matrix differ from the other's
+    const float s = (float)std::sin((double)angle), c = (float)std::cos((double)angle);
     float sx = ax * s, sy = ay * s, sz = az * s;
     float qx = ax * ax, qy = ay * ay, qz = az * az;
     float omc = 1.0f - c;

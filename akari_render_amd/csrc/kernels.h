@@ -43,6 +43,8 @@ struct PtParams {
     uint32_t stage_total;
     uint32_t defer_metal;    // exhaustive path: shade hits on materials with a conductor lobe on even iterations only (pt_kernels.hip)
     uint32_t tex_slots;      // TEX scenes: value slots per lane of the graph evaluation (LDS, after the launch's other blocks)
+    uint32_t park_offset;    // kernels that park cold path state in LDS while shading (dpath.h: PARK): word offset of the columns
+    uint32_t carry_offset;   // BVH kernels that let a wave's longest rays run on into the next iteration (pt_kernels.hip): their columns
     // work distribution
     uint32_t n_items;
     uint32_t shard_rank, shard_count;

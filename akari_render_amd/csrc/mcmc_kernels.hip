@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void k_mcmc_advance(const PtParams p_in, co
         if (blocks == 0) return hipSuccess;                                                                       \
         const bool bvh = p_in.sc.bvh_nodes != nullptr, tex = p_in.sc.tex.nodes != nullptr;                        \
         size_t lds;                                                                                               \
-        const PtParams p = with_tex_slots(p_in, bvh ? kBvhStackDepth * 256 * 4 : p_in.stage_total, lds);           \
+        const PtParams p = with_tex_slots(p_in, bvh ? p_in.sc.bvh_stack_depth * 256 * 4 : p_in.stage_total, lds);           \
         if (bvh) {                                                                                                \
             if (tex) hipLaunchKernelGGL((KERNEL<true, true>), dim3(blocks), dim3(256), lds, stream, __VA_ARGS__);   \
             else hipLaunchKernelGGL((KERNEL<true, false>), dim3(blocks), dim3(256), lds, stream, __VA_ARGS__);      \

@@ -31,6 +31,22 @@ namespace akr {
 #ifndef AKR_PT_MIN_WAVES_BVH_TEX
 #define AKR_PT_MIN_WAVES_BVH_TEX 3  // BVH kernels of such a scene (399 -> 517)
 #endif
+#ifndef AKR_WALK_FD
+#define AKR_WALK_FD 0    // exhaustive pair walk of the force_diffuse kernel: where the records' coefficients sit (disect.h: WALK)
+#endif
+#ifndef AKR_WALK_FULL
+#define AKR_WALK_FULL 0  // the same for the full-graph exhaustive kernels
+#endif
+#ifndef AKR_PT_PARK_FULL
+#define AKR_PT_PARK_FULL 0  // exhaustive full-graph kernels without textures: cold path state in LDS while a vertex is shaded (dpath.h: PARK)
+#endif
+#ifndef AKR_PT_PARK_BVH
+#define AKR_PT_PARK_BVH 0   // the same for the BVH full-graph kernels without textures
+#endif
+#ifndef AKR_PT_STRAGGLERS
+#define AKR_PT_STRAGGLERS 0  // BVH kernels: n > 0 = an intersection phase ends when at most 1/n of the lanes that entered it are still
+                             // tracing; those lanes keep their traversal and go on in the next phase (see k_pt_pass)
+#endif
 #ifndef AKR_PT_MERGED_RAYS
 #define AKR_PT_MERGED_RAYS 1  // BVH path: a lane starts its shadow ray the moment its closest-hit ray is done (one loop)
 #endif
@@ -46,6 +62,15 @@ __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT
     if (STAGE) stage_scene_tables<BVH, TEX, !BVH && !FD && TEX>(p, lds_stack, staged);
     const PtParams& q = STAGE ? staged : p;
     const DScene& sc = q.sc;
+    constexpr int WALK = FD ? AKR_WALK_FD : AKR_WALK_FULL;
+    const float4* lds_recs = nullptr;
+    if (!BVH && WALK == 1) {  // the triangle records behind the staged tables (launch_pt_pass sizes the block)
+        uint32_t* l = lds_stack + (p.stage_total >> 2);
+        const uint32_t* g = (const uint32_t*)p.sc.woop;
+        for (uint32_t i = threadIdx.x; i < (p.sc.n_tris + 2u) * 12u; i += 256u) l[i] = g[i];
+        __syncthreads();
+        lds_recs = (const float4*)l;
+    }
     const uint32_t item = blockIdx.x * 256u + threadIdx.x;
     uint32_t px = 0, py = 0;
     const bool in_frame = item < p.n_items && item_to_pixel(p, item, px, py);
@@ -54,6 +79,13 @@ __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT
     shifted_pixel(p, px, py, sx, sy);
     PathRegs r;
     path_regs_init<PMJ>(r, q, in_frame, pix, sx, sy);
+    constexpr bool PARK = !FD && !TEX && (BVH ? AKR_PT_PARK_BVH != 0 : AKR_PT_PARK_FULL != 0);
+    uint32_t* park = lds_stack + p.park_offset + threadIdx.x;
+    if (PARK) {
+        park_put(park, PK_PIX, pix);
+        park_put(park, PK_SX, sx);
+        park_put(park, PK_SY, sy);
+    }
 
     uint32_t iteration = 0;
     while (__builtin_amdgcn_ballot_w64(r.active) != 0) {
@@ -62,9 +94,65 @@ __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT
             // intersection phase: next closest-hit ray + pending shadow ray
             Hit hit;
             bool found = false, occluded = false;
-            r.c_closest += r.has_ray ? 1u : 0u;
-            r.c_shadow += r.has_shadow ? 1u : 0u;
-            if (BVH && AKR_PT_MERGED_RAYS) {
+            if (!(BVH && AKR_PT_STRAGGLERS > 0 && r.carry)) {
+                r.c_closest += r.has_ray ? 1u : 0u;
+                r.c_shadow += r.has_shadow ? 1u : 0u;
+            }
+            if (BVH && AKR_PT_MERGED_RAYS && AKR_PT_STRAGGLERS > 0) {
+                // The merged loop below ends when the wave's LONGEST pair of rays is done: on the 10 M-triangle hall 40 % of its
+                // lane-steps do work, the rest is lanes waiting for the tail of the ray-length distribution. Here the phase ends
+                // when at most 1/n of the lanes that entered it are still tracing. Those lanes keep their traversal -- position
+                // in the tree and best hit so far in a column of LDS, the stack where it is -- skip this iteration's shading and
+                // continue in the next phase, while the others shade and start their next rays. Per lane only the iteration in
+                // which a vertex is shaded changes (as with DEFER): films and sampler states are the same bit for bit.
+                uint32_t* cy = lds_stack + p.carry_offset + threadIdx.x;
+                Trav s;
+                uint32_t phase;
+                hit.t = 1e20f; hit.u = 0.0f; hit.v = 0.0f; hit.gid = kInvalid;
+                if (!r.carry) {
+                    phase = r.has_ray ? 0u : (r.has_shadow ? 1u : 2u);
+                    if (phase == 0) trav_begin(s, r.ro, r.rd, 0.0f, 1e20f, r.ray_ex0, kInvalid);
+                    else trav_begin(s, r.s_o, r.s_d, 0.0f, phase == 1 ? r.s_tmax : -1.0f, r.s_ex0, r.s_ex1);
+                } else {
+                    phase = cy[8 * 256];
+                    if (phase == 0) trav_begin(s, r.ro, r.rd, 0.0f, 1e20f, r.ray_ex0, kInvalid);
+                    else {
+                        trav_begin(s, r.s_o, r.s_d, 0.0f, r.s_tmax, r.s_ex0, r.s_ex1);
+                        hit.t = u2f(cy[9 * 256]); hit.u = u2f(cy[10 * 256]); hit.v = u2f(cy[11 * 256]); hit.gid = cy[12 * 256];
+                        found = hit.gid != kInvalid;
+                    }
+                    s.best_t = u2f(cy[0]); s.best_u = u2f(cy[1 * 256]); s.best_v = u2f(cy[2 * 256]); s.best = cy[3 * 256];
+                    s.G = cy[4 * 256]; s.T = cy[5 * 256]; s.tbase = cy[6 * 256]; s.sp = cy[7 * 256];
+                    s.active = true;
+                }
+                const uint32_t n_in = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(phase != 2u));
+                const uint32_t n_leave = n_in / (uint32_t)(AKR_PT_STRAGGLERS > 0 ? AKR_PT_STRAGGLERS : 1);
+                while (true) {
+                    const uint32_t n_now = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(phase != 2u));
+                    if (n_now <= n_leave) break;  // n_leave < n_in: at least one lane of the phase finishes
+                    if (phase != 2u) {
+                        if (s.active) trav_step<2, TEX>(sc, s, tc.stack, tc.cnt, phase == 1u);
+                        if (!s.active) {
+                            if (phase == 0u) {
+                                found = s.best != kInvalid;
+                                hit.t = s.best_t; hit.u = s.best_u; hit.v = s.best_v; hit.gid = s.best;
+                                phase = r.has_shadow ? 1u : 2u;
+                                if (r.has_shadow) trav_begin(s, r.s_o, r.s_d, 0.0f, r.s_tmax, r.s_ex0, r.s_ex1);
+                            } else {
+                                occluded = s.best != kInvalid;
+                                phase = 2u;
+                            }
+                        }
+                    }
+                }
+                r.carry = phase != 2u;
+                if (r.carry) {
+                    cy[0] = f2u(s.best_t); cy[1 * 256] = f2u(s.best_u); cy[2 * 256] = f2u(s.best_v); cy[3 * 256] = s.best;
+                    cy[4 * 256] = s.G; cy[5 * 256] = s.T; cy[6 * 256] = s.tbase; cy[7 * 256] = s.sp;
+                    cy[8 * 256] = phase;
+                    if (phase == 1u) { cy[9 * 256] = f2u(hit.t); cy[10 * 256] = f2u(hit.u); cy[11 * 256] = f2u(hit.v); cy[12 * 256] = hit.gid; }
+                }
+            } else if (BVH && AKR_PT_MERGED_RAYS) {
                 // Both rays of the iteration through ONE traversal loop: a lane whose closest-hit ray is done goes straight on
                 // to its shadow ray, so the wave pays for its longest PAIR of rays instead of its longest closest-hit ray plus
                 // its longest shadow ray (rays of a wave differ in length by an order of magnitude; the loop is the same code for
@@ -95,8 +183,8 @@ __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT
                     occluded = trace_bvh<true, TEX>(sc, r.s_o, r.s_d, 0.0f, r.s_tmax, r.s_ex0, r.s_ex1, sh, tc.stack, tc.cnt);
                 }
             } else {
-                trace_pair_exhaustive<TEX, FD>(sc, r.ro, r.rd, r.has_ray ? 1e20f : -1.0f, r.ray_ex0, r.s_o, r.s_d, r.has_shadow ? r.s_tmax : -1.0f,
-                                      r.s_ex0, r.s_ex1, hit, found, occluded);
+                trace_pair_exhaustive<TEX, FD, WALK>(sc, r.ro, r.rd, r.has_ray ? 1e20f : -1.0f, r.ray_ex0, r.s_o, r.s_d, r.has_shadow ? r.s_tmax : -1.0f,
+                                            r.s_ex0, r.s_ex1, hit, found, occluded, lds_recs);
                 if (DEFER) {
                     // A scene with one metal among diffuse surfaces: every wave carries a few lanes on the metal at every
                     // iteration, so every iteration pays for the conductor lobe (GGX + complex Fresnel, the dearest code of the
@@ -119,7 +207,10 @@ __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT
                     }
                 }
             }
-            path_step<FD ? 1 : 0, TEX, PMJ>(q, r, hit, found, occluded, pix, sx, sy);
+            if (BVH && AKR_PT_STRAGGLERS > 0 && r.carry) {
+                // still tracing: nothing to resolve or shade yet
+            } else if (PARK) path_step<FD ? 1 : 0, TEX, PMJ, DEFER ? 1 : 2>(q, r, hit, found, occluded, 0, 0, 0, park);
+            else path_step<FD ? 1 : 0, TEX, PMJ>(q, r, hit, found, occluded, pix, sx, sy);
         }
     }
     flush_counters(p, r, tc.cnt, BVH);
@@ -278,7 +369,17 @@ hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream) {
     const bool fd = p.force_diffuse != 0, tex = p.sc.tex.nodes != nullptr;
     const bool bvh = p.sc.bvh_nodes != nullptr;
     size_t lds;
-    const PtParams q = with_tex_slots(p, (bvh ? kBvhStackDepth * 256 * 4 : 0) + p.stage_total, lds);
+    // exhaustive kernels whose pair walk reads the records from LDS (WALK 1) keep them behind the staged tables
+    const bool recs_in_lds = !bvh && (fd ? AKR_WALK_FD : AKR_WALK_FULL) == 1;
+    const bool park = !fd && !tex && (bvh ? AKR_PT_PARK_BVH != 0 : AKR_PT_PARK_FULL != 0);
+    size_t base = (bvh ? p.sc.bvh_stack_depth * 256 * 4 : 0) + p.stage_total + (recs_in_lds ? (p.sc.n_tris + 2) * 48 : 0);
+    base = (base + 15) & ~(size_t)15;
+    PtParams pp = p;
+    pp.park_offset = (uint32_t)(base / 4);
+    if (park) base += (p.defer_metal ? kParkSlots : kParkSlotsNoDefer) * 256 * 4;
+    pp.carry_offset = (uint32_t)(base / 4);
+    if (bvh && AKR_PT_STRAGGLERS > 0) base += kCarrySlots * 256 * 4;
+    const PtParams q = with_tex_slots(pp, base, lds);
     const bool stage = p.stage_total != 0;
 #define AKR_LAUNCH2(B, F, T, S, D)                                                                                       \
     {                                                                                                                  \
@@ -329,7 +430,7 @@ hipError_t launch_probe_bsdf(const DMaterial* m, const float* table, int mode, c
 }
 hipError_t launch_probe_intersect(const PtParams& p, uint32_t n, const float* rays, uint32_t* out, float* bary, hipStream_t stream) {
     if (p.sc.bvh_nodes != nullptr)
-        hipLaunchKernelGGL(k_probe_intersect<true>, dim3((n + 255) / 256), dim3(256), kBvhStackDepth * 256 * 4, stream, p, n, rays, out, bary);
+        hipLaunchKernelGGL(k_probe_intersect<true>, dim3((n + 255) / 256), dim3(256), p.sc.bvh_stack_depth * 256 * 4, stream, p, n, rays, out, bary);
     else
         hipLaunchKernelGGL(k_probe_intersect<false>, dim3((n + 255) / 256), dim3(256), 0, stream, p, n, rays, out, bary);
     return hipGetLastError();

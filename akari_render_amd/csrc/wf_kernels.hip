@@ -215,9 +215,9 @@ hipError_t launch_wf_shade(const PtParams& p, const WfBuffers& wf, uint32_t q_ou
 hipError_t launch_wf_trace(const PtParams& p, const WfBuffers& wf, uint32_t q_in, uint32_t n_blocks, hipStream_t stream) {
     if (p.sc.tex.nodes != nullptr) {
         size_t lds;
-        const PtParams q = with_tex_slots(p, kBvhStackDepth * 256 * 4, lds);
+        const PtParams q = with_tex_slots(p, p.sc.bvh_stack_depth * 256 * 4, lds);
         hipLaunchKernelGGL(k_wf_trace<true>, dim3(n_blocks), dim3(256), lds, stream, q, wf, q_in);
-    } else hipLaunchKernelGGL(k_wf_trace<false>, dim3(n_blocks), dim3(256), kBvhStackDepth * 256 * 4, stream, p, wf, q_in);
+    } else hipLaunchKernelGGL(k_wf_trace<false>, dim3(n_blocks), dim3(256), p.sc.bvh_stack_depth * 256 * 4, stream, p, wf, q_in);
     return hipGetLastError();
 }
 

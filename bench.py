@@ -46,12 +46,34 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def algorithmic_bytes(d):
+NODE_BYTES_8D, TRI_BYTES_8D = 64, 48  # the byte model prices a node visit at 64 B and a triangle test at 48 B
+
+
+def algorithmic_bytes(d, fetched=False):
     """SURVEY.md 8(d) byte model: per-event record sizes x device counters. The BVH terms are zero
-    for cbox (36 triangles, cache-resident: no node visits are counted) and counted in full for BVH scenes, with the node
-    and triangle record sizes the scene actually uses (d["node_bytes"], d["tri_bytes"])."""
+    for cbox (36 triangles, cache-resident: no node visits are counted) and counted in full for BVH scenes -- at the MODEL's
+    record sizes (NODE = 64, TRI = 48), whatever this build's records weigh: fatter records must not raise the score.
+    fetched=True prices them at what a node / triangle step of this build actually fetches (80 / 64 bytes, akr_scene_info)."""
+    nb, tb = (d.get("node_bytes", NODE_BYTES_8D), d.get("tri_bytes", TRI_BYTES_8D)) if fetched else (NODE_BYTES_8D, TRI_BYTES_8D)
     return (56 * d["n_closest"] + 292 * d["n_shaded"] + 64 * d["n_shadow"] + 156 * d["n_samples"] +
-            d.get("node_bytes", 64) * d["n_node_visits"] + (d.get("tri_bytes", 48) * d["n_tri_tests"] if d["n_node_visits"] else 0))
+            nb * d["n_node_visits"] + (tb * d["n_tri_tests"] if d["n_node_visits"] else 0))
+
+
+def csrc_hash():
+    """sha256 over the kernel and host sources of the library (sorted relative paths + contents): what a PMC summary under
+    profiles/ must carry to be quoted next to a bench line -- the counters of a kernel that has since been edited describe
+    another kernel."""
+    import hashlib
+
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "akari_render_amd", "csrc")
+    for d_, _, files in sorted(os.walk(base)):
+        for f in sorted(files):
+            if f.endswith((".h", ".hip", ".cpp")):
+                path = os.path.join(d_, f)
+                h.update(os.path.relpath(path, base).encode())
+                h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def host_threads():
@@ -114,20 +136,23 @@ def cpu_baseline(key, n_threads, cores):
             "c1": {"value": c1v, "unit": "Msamples/s", "sample": f"C1: cbox 256x256 64 spp full graph ({c1n} camera paths, {c1dt:.1f} s)"}}
 
 
-def measured_counters(key, passes_per_launch, n_items_full):
+def measured_counters(key):
     """What rocprofv3's PMC passes measured for this launch shape (they cannot run inside this process): the committed
-    summary profiles/r2_pmc_<config>.json -- HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes, unit
-    and gfx950 corrections of MI355X_MICROARCH.md "HBM"), VALU busy share, lane utilisation -- or None. A launch of the cbox
-    kernels reads and writes the per-pixel sampler states and film once, whatever the number of fused passes; the hall's
-    traffic is per ray, so that file stores bytes per sample."""
-    for rnd in ("r2", "r1"):
-        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{key}.json")
-        if os.path.exists(path):
-            try:
-                return json.load(open(path))
-            except Exception:
-                return None
-    return None
+    summary profiles/r3_pmc_<config>.json (tools/pmc_bench.sh) -- HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate
+    --pmc passes, unit and gfx950 corrections of MI355X_MICROARCH.md "HBM"), VALU busy share, lane utilisation. The summary
+    carries the hash of the library sources it was measured on; if that is not the hash of the sources in this tree the
+    block is dropped and the line says so. Returns (summary or None, note or None)."""
+    path = os.path.join(ROOT, "profiles", f"r3_pmc_{key}.json")
+    if not os.path.exists(path):
+        return None, f"no PMC summary profiles/r3_pmc_{key}.json"
+    try:
+        m = json.load(open(path))
+    except Exception as ex:  # noqa: BLE001
+        return None, f"unreadable PMC summary: {ex}"
+    have, want = m.get("csrc_hash"), csrc_hash()
+    if have != want:
+        return None, f"PMC summary profiles/r3_pmc_{key}.json was measured on other kernel sources (csrc hash {have}, this tree {want}): not quoted"
+    return m, None
 
 
 def build_scene(ctx, key):
@@ -215,6 +240,7 @@ def run_config(ctx, key, steps, warmup, rank, world, scaling, film_t, torch, dis
     sync()
     t0 = time.perf_counter()
     se.passes(steps * PASSES_PER_STEP, blocking=True)
+    t_rendered = time.perf_counter()
     if world > 1:
         if backend == "gloo":
             host = film_t.cpu()
@@ -224,12 +250,19 @@ def run_config(ctx, key, steps, warmup, rank, world, scaling, film_t, torch, dis
             comm.reduce_film(film, root=0, blocking=True)  # akr_film_reduce: ncclReduce on the context's stream, after the render
         else:
             distributed.reduce_film(film_t, dst=0)
+        ctx.synchronize()
+        torch.cuda.synchronize(dev)
+    t_reduced = time.perf_counter()
     sync()
     t1 = time.perf_counter()
     s1 = se.end()
     d = {k: s1[k] - s0[k] for k in ("n_samples", "n_closest", "n_shadow", "n_shaded", "n_node_visits", "n_tri_tests")}
     d["kernel_ms"] = s1["kernel_ms"] - s0["kernel_ms"]
     d["n_launches"] = s1["n_launches"] - s0["n_launches"]
+    # this rank's share of the timed region: rendering (wall clock and kernel time) and its side of the film reduce (which
+    # includes waiting for slower ranks): a bad scaling curve can then be attributed without a second run
+    d["render_wall_ms"] = (t_rendered - t0) * 1e3
+    d["reduce_wall_ms"] = (t_reduced - t_rendered) * 1e3
     info = scene.info()
     d["node_bytes"] = int(getattr(info, "node_bytes", 64) or 64)
     d["tri_bytes"] = int(getattr(info, "tri_bytes", 48) or 48)
@@ -251,10 +284,12 @@ def roofline_block(key, d):
     out = {
         "bound": "hbm",
         "achieved": achieved,
-        "achieved_is": "ALGORITHMIC bytes of the SURVEY.md 8(d) byte model (device counters x record sizes) / launch time -- not measured traffic",
+        "achieved_is": "ALGORITHMIC bytes of the SURVEY.md 8(d) byte model (device counters x the model's record sizes: node 64 B, "
+                       "triangle 48 B) / launch time -- not measured traffic; frac_measured is the measured one",
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
+        "frac_measured": None,
         "traffic": None,
         "kernel": "k_pt_pass",
         "launches": d["n_launches"],
@@ -262,7 +297,12 @@ def roofline_block(key, d):
         "algorithmic_bytes_per_launch": bytes_per_launch,
         "algorithmic_bytes_per_sample": model_bytes / max(1, d["n_samples"]),
     }
-    m = measured_counters(key, PASSES_PER_STEP, W * H)
+    if d["n_node_visits"]:  # what this build's 80-byte nodes and 64-byte triangle records make of the same counters (not the score)
+        out["fetched_bytes_frac"] = algorithmic_bytes(d, fetched=True) / launches / avg_launch_s / 1e9 / HBM_PEAK_GBS
+        rays = max(1, d["n_closest"] + d["n_shadow"])
+        out["nodes_per_ray"] = d["n_node_visits"] / rays
+        out["tris_per_ray"] = d["n_tri_tests"] / rays
+    m, note = measured_counters(key)
     samples_per_launch = d["n_samples"] / launches
     if m:
         if m.get("hbm_bytes_per_launch") is not None and m.get("samples_per_launch") == samples_per_launch:
@@ -271,10 +311,12 @@ def roofline_block(key, d):
             out["traffic"] = m["hbm_bytes_per_sample"] * samples_per_launch
         if out["traffic"] is not None:
             out["hbm_measured_gbs"] = out["traffic"] / avg_launch_s / 1e9
-            out["hbm_measured_frac"] = out["hbm_measured_gbs"] / HBM_PEAK_GBS
-        for k in ("valu_busy", "valu_lane_utilisation", "wait_share", "binding_limiter", "source"):
+            out["frac_measured"] = out["hbm_measured_frac"] = out["hbm_measured_gbs"] / HBM_PEAK_GBS
+        for k in ("valu_busy", "valu_lane_utilisation", "wait_share", "l2_hit", "ta_busy", "binding_limiter", "source", "csrc_hash", "kernel"):
             if k in m:
-                out[k] = m[k]
+                out[k if k != "kernel" else "pmc_kernel"] = m[k]
+    else:
+        out["measured_counters"] = note
     return out
 
 
@@ -331,8 +373,13 @@ def main():
         c = torch.tensor([d["n_samples"], d["n_closest"], d["n_shadow"], d["n_shaded"]], dtype=torch.float64, device=cdev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         total_samples = int(c[0].item())
+        per = torch.tensor([d["kernel_ms"], d["render_wall_ms"], d["reduce_wall_ms"], float(d["n_samples"])], dtype=torch.float64, device=cdev)
+        allr = [torch.zeros_like(per) for _ in range(world)]
+        dist.all_gather(allr, per)
+        per_rank = [[float(x) for x in t.tolist()] for t in allr]
     else:
         total_samples = d["n_samples"]
+        per_rank = [[d["kernel_ms"], d["render_wall_ms"], d["reduce_wall_ms"], float(d["n_samples"])]]
     n_sets = world if weak else 1
     assert total_samples == n_sets * W * H * SPP_PER_STEP * args.steps, (total_samples, n_sets * W * H * SPP_PER_STEP * args.steps)
 
@@ -367,6 +414,11 @@ def main():
                                 f"{args.gpus} independent sample sets of {args.steps * SPP_PER_STEP} spp (sampler seed = rank), one per GPU, films sum-reduced (RCCL)" if weak else
                                 f"pixel tiles 32x32 round-robin over {args.gpus} GPUs, film sum-reduce (RCCL)"),
                 **{k: v for k, v in sinfo.items() if k not in ("weak", "spp_done")},
+                # per rank over the timed region: kernel time (HIP events), render wall clock, film-reduce wall clock (incl. waiting)
+                "per_rank_kernel_ms": {"max": max(r[0] for r in per_rank), "min": min(r[0] for r in per_rank), "all": [round(r[0], 2) for r in per_rank]},
+                "per_rank_render_wall_ms": {"max": max(r[1] for r in per_rank), "min": min(r[1] for r in per_rank)},
+                "film_reduce_wall_ms": {"max": max(r[2] for r in per_rank), "min": min(r[2] for r in per_rank), "rank0": per_rank[0][2]},
+                "per_rank_samples": [int(r[3]) for r in per_rank],
             },
             "roofline": roofline_block(key, d),
             "counters": {k: d[k] for k in ("n_samples", "n_closest", "n_shadow", "n_shaded", "n_node_visits", "n_tri_tests")},

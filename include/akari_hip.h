@@ -507,6 +507,15 @@ AKR_API int32_t akr_host_alias_table(const float *weights, uint32_t n, uint32_t 
 
 /* Library / build identification: "akari_hip <version> gfx950". */
 AKR_API const char *akr_version(void);
+/* Process-wide tuning switches and test hooks (no reference counterpart). Each starts from its environment variable, read once;
+ * afterwards only akr_option_set changes it, and it applies to scenes / sessions created after the call:
+ *   "force_bvh"    (AKR_FORCE_BVH=1)        scenes of <= 64 triangles get a BVH as well
+ *   "bvh_balanced" (AKR_BVH_BALANCED=1)     median-split fallback builder instead of binned SAH
+ *   "defer_metal"  (AKR_PT_DEFER_METAL=m)   -1 the library decides; 0 off; m > 0: conductor hits shaded when (iteration & m) == 0
+ *   "wavefront"    (AKR_PT_MODE=wavefront)  1 = pt sessions on BVH scenes run the wavefront schedule
+ * Unknown names fail with AKR_ERR_INVALID_ARGUMENT. */
+AKR_API int32_t akr_option_set(const char *name, int32_t value);
+AKR_API int32_t akr_option_get(const char *name, int32_t *value);
 
 /* ---------------------------------------------------------------------------------------------------
  * Device-function probes (used by the parity tests to compare single device functions with the oracle;

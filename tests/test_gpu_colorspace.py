@@ -109,6 +109,6 @@ def test_method_file_with_colour_pipeline(ctx, tmp_path, root):
     capi.pt_render(ctx, scene, cfg, film)
     sd = scene_json.load_scene(str(dst / "scene.json"), 80, 60)
     o, _ = pyoracle.OracleScene(sd).render(cfg)
-    # two independent readers of the same file: one ulp in the camera matrix at most (host libm), hence tolerance here
-    assert rel_rmse(resolve_np(film.read(), 80, 60), resolve_np(o, 80, 60)) < 1e-3
+    # two independent readers of the same file, both with correctly rounded sin / cos in their transforms: the same bits
+    assert n_bit_diff(film.read(), o) == 0
     assert os.path.exists(tmp_path / "out.exr")

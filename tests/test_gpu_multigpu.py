@@ -35,6 +35,21 @@ def test_native_reduce_world_of_one(ctx, cbox_path):
 
 
 def _rank_main(rank, world, id_path, cbox_path, out_path):
+    """One RCCL rank. Whatever goes wrong lands in <out_path>.rank<r>.err with the library's own message (akr_last_error, which
+    carries ncclGetErrorString / ncclGetLastError for RCCL failures), so that a run nobody is watching can be diagnosed."""
+    try:
+        _rank_body(rank, world, id_path, cbox_path, out_path)
+    except BaseException as ex:  # noqa: BLE001
+        import traceback
+
+        with open(f"{out_path}.rank{rank}.err", "w") as f:
+            f.write(f"rank {rank} of {world}: {type(ex).__name__}: {ex}\nakr_last_error: {capi.last_error()}\n"
+                    f"HIP devices visible: {capi.device_count()}, HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}, "
+                    f"NCCL_DEBUG={os.environ.get('NCCL_DEBUG')}\n{traceback.format_exc()}")
+        raise
+
+
+def _rank_body(rank, world, id_path, cbox_path, out_path):
     import time
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -76,7 +91,15 @@ def test_native_reduce_two_gpus(ctx, cbox_path):
             p.start()
         for p in procs:
             p.join(300)
-            assert p.exitcode == 0
+        errs = []
+        for r, p in enumerate(procs):
+            if p.exitcode is None:
+                p.kill()
+                errs.append(f"rank {r}: still running after 300 s (killed) -- a hung RCCL bootstrap or reduce")
+            elif p.exitcode != 0:
+                ef = f"{out_path}.rank{r}.err"
+                errs.append(open(ef).read() if os.path.exists(ef) else f"rank {r}: exit code {p.exitcode}, no error file (died in native code?)")
+        assert not errs, "akr_film_reduce over two GPUs failed:\n" + "\n".join(errs)
         assert n_bit_diff(np.load(out_path), full.read()) == 0
 
 

@@ -82,8 +82,22 @@ def test_scene_loaded_by_the_library(ctx, cbox_path):
     cfg = make_config(spp=8, spp_per_pass=8)
     capi.pt_render(ctx, scene, cfg, film)
     o, _ = pyoracle.OracleScene(scene_json.load_scene(cbox_path, 96, 64)).render(cfg)
-    # the two readers may differ by one ulp in the camera matrix (host libm sin/cos): tolerance, not bits
-    assert rel_rmse(resolve_np(film.read(), 96, 64), resolve_np(o, 96, 64)) < REL_RMSE_TOL
+    # two independent readers of the same file (C++ in the library, Python beside the oracle): both round sin / cos of a rotation
+    # correctly to f32, so the camera matrices -- and the films -- are the same bit for bit
+    assert n_bit_diff(film.read(), o) == 0
+
+
+def test_the_frame_bench_py_times_is_the_oracles(ctx, cbox_path):
+    """bench.py builds its scene with akr_scene_load at 1920x1080 (bench.py: build_scene). One tile shard of exactly that scene
+    and configuration (C2: force_diffuse, gaussian filter, depth 12) against the oracle on the Python reader's scene."""
+    from akari_render_amd import distributed
+    cfg = make_config(spp=16, spp_per_pass=8, max_depth=12, rr_depth=5, force_diffuse=1)
+    cfg = distributed.shard_config(cfg, 3, 64)
+    scene = capi.Scene(ctx, cbox_path, 1920, 1080)
+    film = capi.Film(ctx, 1920, 1080)
+    capi.pt_render(ctx, scene, cfg, film)
+    o, _ = pyoracle.OracleScene(scene_json.load_scene(cbox_path, 1920, 1080)).render(cfg)
+    assert n_bit_diff(film.read(), o) == 0
 
 
 CONFIG_CASES = {
@@ -207,9 +221,9 @@ def test_procedural_hall_small(ctx):
 
 # ---- the wavefront schedule (wf_kernels.hip): same arithmetic, different kernels -> same bits ----
 @pytest.fixture
-def wavefront_mode(monkeypatch):
-    monkeypatch.setenv("AKR_PT_MODE", "wavefront")
-    monkeypatch.setenv("AKR_FORCE_BVH", "1")
+def wavefront_mode():
+    with capi.options(wavefront=1, force_bvh=1):  # akr_option_set: the library reads its environment hooks only once
+        yield
 
 
 @pytest.mark.parametrize("case", ["cbox_full", "cbox_diffuse", "glass_coat", "kinds", "alpha", "grid_normals", "hall", "ragged_passes", "no_nee"])
@@ -268,20 +282,20 @@ def test_convergence_follows_one_over_sqrt_spp(ctx, cbox_path):
     assert abs(render(1024, 3).mean() - ref.mean()) < 0.01 * ref.mean()
 
 
-def test_bvh_balanced_fallback_builder(ctx, monkeypatch):
+def test_bvh_balanced_fallback_builder(ctx):
     """The median-split builder that replaces an SAH tree deeper than the traversal stack (host/scene_build.cpp): same image."""
-    monkeypatch.setenv("AKR_BVH_BALANCED", "1")
     sd = grid_scene(n=24, width=96, height=64, with_normals=True)
-    g, o, gst, ost, _, _ = render_both(ctx, sd, make_config(spp=8, spp_per_pass=8, max_depth=6))
+    with capi.options(bvh_balanced=1):
+        g, o, gst, ost, _, _ = render_both(ctx, sd, make_config(spp=8, spp_per_pass=8, max_depth=6))
     assert_parity(g, o, 96, 64, gst, ost)
 
 
-@pytest.mark.parametrize("mask", ["0", "1", "3"])
-def test_conductor_hits_shaded_on_even_iterations_only(ctx, cbox_path, monkeypatch, mask):
+@pytest.mark.parametrize("mask", [0, 1, 3])
+def test_conductor_hits_shaded_on_even_iterations_only(ctx, cbox_path, mask):
     """pt_kernels.hip (DEFER): in a scene with one metal among diffuse surfaces a hit on the metal is kept for one iteration
     when it arrives on an odd one. Per lane only the iteration changes, so the film and the sampler states stay bit-identical
     to the oracle whatever the period (mask 0 = the plain kernel, 1 = the shipped period, 3 = three iterations in four)."""
-    monkeypatch.setenv("AKR_PT_DEFER_METAL", mask)
     sd = scene_json.load_scene(cbox_path, 96, 96)
-    g, o, gst, ost, _, _ = render_both(ctx, sd, make_config(spp=8, spp_per_pass=4, max_depth=7))
+    with capi.options(defer_metal=mask):
+        g, o, gst, ost, _, _ = render_both(ctx, sd, make_config(spp=8, spp_per_pass=4, max_depth=7))
     assert_parity(g, o, 96, 96, gst, ost)

@@ -51,11 +51,11 @@ def test_textured_room_force_diffuse_keeps_textured_emission_and_alpha(ctx, root
     assert_parity(g, o, 40, 40, gst, ost)
 
 
-def test_textured_room_wavefront_schedule(ctx, root, monkeypatch):
+def test_textured_room_wavefront_schedule(ctx, root):
     sd = with_table(textured_room(40, 40, n_floor=8, alpha_cutout=True), root)
     cfg = make_config(spp=8, spp_per_pass=4, max_depth=8)
-    monkeypatch.setenv("AKR_PT_MODE", "wavefront")
-    g, o, gst, ost, _, _ = render_both(ctx, sd, cfg)
+    with capi.options(wavefront=1):
+        g, o, gst, ost, _, _ = render_both(ctx, sd, cfg)
     assert_parity(g, o, 40, 40, gst, ost)
 
 

@@ -318,3 +318,33 @@ def test_bvh_traversal_reaches_every_hit(hip_lib):
             g = int(off[h[1]] + h[2])
             assert g in set(int(gid[k]) for k in tris)
     assert n_hit > 300 and max_nodes < info.n_bvh_nodes
+
+
+def test_non_finite_vertices_are_refused(hip_lib):
+    """Round-2 advisor finding: one +-inf / NaN coordinate made the 8-wide builder's slot costs NaN, its greedy assignment write
+    out of bounds and the tree drop geometry. compile_scene refuses such scenes, whatever their size."""
+    from tests.helpers import grid_scene
+    for n, bad in ((2, np.inf), (12, -np.inf), (12, np.nan)):
+        sd = grid_scene(n=n, width=16, height=16)
+        v = sd.meshes[0].vertices.copy()
+        v[v.shape[0] // 2, 1] = bad
+        sd.meshes[0].vertices = v
+        with pytest.raises(capi.AkariError) as ei:
+            capi.Scene(None, sd)
+        assert ei.value.code == -1 and "non-finite" in str(ei.value)  # AKR_ERR_INVALID_ARGUMENT
+
+
+def test_options_are_a_table_not_the_environment(hip_lib, cbox_path, monkeypatch):
+    """akr_option_set / akr_option_get: the test hooks are read from the environment once; later changes of the environment
+    are not seen, akr_option_set is."""
+    assert capi.get_option("force_bvh") in (0, 1)
+    monkeypatch.setenv("AKR_FORCE_BVH", "1")  # after the first look: ignored
+    before = capi.get_option("force_bvh")
+    assert capi.Scene(None, cbox_path).info().uses_bvh == before
+    with capi.options(force_bvh=1):
+        assert capi.get_option("force_bvh") == 1
+        assert capi.Scene(None, cbox_path).info().uses_bvh == 1
+    assert capi.get_option("force_bvh") == before
+    assert capi.get_option("defer_metal") == -1 and capi.get_option("wavefront") == 0
+    with pytest.raises(capi.AkariError):
+        capi.set_option("no_such_option", 1)

@@ -202,6 +202,51 @@ def test_tiff_refuses_what_it_does_not_read():
             capi.host_decode_tiff(good[:cut])
 
 
+def test_tiff_header_fields_cannot_overflow_or_allocate(tmp_path):
+    """Round-2 advisor findings: (a) TileWidth = TileLength = 2^31 made rows x tile_w x bytes wrap to 0, the "enough samples"
+    check passed and the pixel loop read past the chunk (segfault with a 140-byte file); (b) a header alone claiming a huge
+    picture cost a 1 GiB allocation before the file was refused as truncated."""
+    a = np.arange(4 * 4 * 3, dtype=np.uint8).reshape(4, 4, 3)
+    good = write_tiff(a, tile=(16, 16))
+    assert np.array_equal(capi.host_decode_tiff(good)[..., :3], a)
+
+    def patch(data, tag, value):  # rewrite the inline value of a LONG / SHORT field of the (little-endian) IFD
+        n = struct.unpack_from("<H", data, 8)[0]
+        out = bytearray(data)
+        for i in range(n):
+            at = 10 + 12 * i
+            t, typ = struct.unpack_from("<HH", data, at)
+            if t == tag:
+                struct.pack_into("<HI", out, at + 2, 4, 1)  # type LONG, count 1
+                struct.pack_into("<I", out, at + 8, value)
+                return bytes(out)
+        raise KeyError(tag)
+
+    for tw, th in ((1 << 31, 1 << 31), (1 << 30, 4), (4, 1 << 31), (65537, 16)):
+        bad = patch(patch(good, 322, tw), 323, th)
+        with pytest.raises(capi.AkariError) as ei:
+            capi.host_decode_tiff(bad)
+        assert "tile size" in str(ei.value)
+    # 16384 x 16384 pixels claimed by a file of a few hundred bytes: refused before anything of that size is allocated
+    import resource, time
+    huge = patch(patch(write_tiff(a), 256, 16384), 257, 16384)
+    t0, r0 = time.time(), resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    with pytest.raises(capi.AkariError) as ei:
+        capi.host_decode_tiff(huge)
+    assert "too short" in str(ei.value) or "outside" in str(ei.value) or "few" in str(ei.value)
+    assert time.time() - t0 < 0.5 and resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - r0 < 200 * 1024  # KiB
+    # the same for a PNG header (IHDR says 16384 x 16384, IDAT holds a 4 x 4 picture)
+    png = io.BytesIO()
+    Image.fromarray(a).save(png, format="PNG")
+    raw = bytearray(png.getvalue())
+    struct.pack_into(">II", raw, 16, 16384, 16384)
+    struct.pack_into(">I", raw, 29, zlib.crc32(bytes(raw[12:29])))
+    r0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    with pytest.raises(capi.AkariError):
+        capi.host_decode_png(bytes(raw))
+    assert resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - r0 < 200 * 1024
+
+
 # ------------------------------------------------------------------------------------------------------------------ DDS
 def make_dds(w, h, kind, blocks: bytes, dx10=False):
     hdr = bytearray(128)

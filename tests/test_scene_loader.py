@@ -30,8 +30,8 @@ def _same(sd_a, sd_b, cam_tol=0.0):
 def test_cpp_loader_equals_python_loader(hip_lib, cbox_path):
     sc = capi.Scene(None, cbox_path)
     assert (sc.info().width, sc.info().height) == (1024, 1024)  # sensor_width/height of scenes/cbox
-    # transforms go through sin/cos of the host libm in both readers: allow 1 ulp on the camera matrix
-    _same(sc.to_scene_data(), scene_json.load_scene(cbox_path), cam_tol=2e-7)
+    # transforms go through correctly rounded f32 sin / cos in both readers: the camera matrix is the same bit for bit
+    _same(sc.to_scene_data(), scene_json.load_scene(cbox_path), cam_tol=0.0)
     sc2 = capi.Scene(None, cbox_path, 1920, 1080)
     assert (sc2.info().width, sc2.info().height) == (1920, 1080)
 

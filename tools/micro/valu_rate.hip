@@ -12,7 +12,12 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a, float b
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 p0 = {x0, x1}, p1 = {x1, x2}, p2 = {x2, x3}, p3 = {x3, x0}, pa = {a, a}, sa = {a, a};
     asm volatile("" : "+v"(pa));
+    // V >= 24: the same streams with only the low 32 lanes of the wave enabled -- does a SIMD-32 skip the empty half of a wave64?
+    if (V >= 24) asm volatile("s_mov_b64 exec, 0xffffffff");
     for (int i = 0; i < iters; i++) {
+        if (V == 24) asm volatile(REP16("v_mul_f32 %0, %4, %0\nv_mul_f32 %1, %4, %1\nv_mul_f32 %2, %4, %2\nv_mul_f32 %3, %4, %3\n") : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(va));
+        if (V == 25) asm volatile(REP16("v_fma_f32 %0, %0, %4, %5\nv_fma_f32 %1, %1, %4, %5\nv_fma_f32 %2, %2, %4, %5\nv_fma_f32 %3, %3, %4, %5\n") : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(va), "v"(vb));
+        if (V == 26) asm volatile(REP16("v_fma_f32 %0, %0, %4, %5\nv_fma_f32 %1, %1, %4, %5\nv_fma_f32 %2, %2, %4, %5\nv_fma_f32 %3, %3, %4, %5\n") : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "s"(a), "v"(vb));
         if (V == 0) asm volatile(REP16("v_mul_f32 %0, %1, %0\n") : "+v"(x0) : "v"(va));
         if (V == 1) asm volatile(REP16("v_mul_f32 %0, %1, %0\n") : "+v"(x0) : "s"(a));
         if (V == 2) asm volatile(REP16("v_mul_f32 %0, 0x3f800347, %0\n") : "+v"(x0));
@@ -45,8 +50,9 @@ static const char* names[] = {"mul  dep      vgpr", "mul  dep      sgpr", "mul  
                               "fma  dep      1 sgpr", "fma  4 chains vgpr", "fma  4 chains 1 sgpr", "mul sgpr + max vgpr, dep", "fma ring of 4, 1 sgpr",
                               "mul dep, alternating 2 sgprs", "mul dep sgpr + s_nop", "pk_mul dep vgpr", "pk_mul dep sgpr pair", "pk_mul 4 chains vgpr", "pk_mul 4 chains sgpr pair",
                               "[mul sgpr, mul vgpr] 2 chains", "[sgpr, vgpr, vgpr] 3 chains", "[sgpr, sgpr, vgpr] 3 chains", "[v_mov s->v, 4 mul vgpr]",
-                              "fma 4 chains sgpr in src2", "[mul sgpr, mul vgpr] ONE chain", "pk_fma 4 chains sgpr bcast"};
-static const int per_iter[] = {16, 16, 16, 64, 64, 16, 16, 64, 64, 32, 64, 32, 16, 16, 16, 64, 64, 32, 48, 48, 80, 64, 32, 64};
+                              "fma 4 chains sgpr in src2", "[mul sgpr, mul vgpr] ONE chain", "pk_fma 4 chains sgpr bcast",
+                              "mul 4 chains vgpr, 32 lanes", "fma 4 chains vgpr, 32 lanes", "fma 4 chains 1 sgpr, 32 lanes"};
+static const int per_iter[] = {16, 16, 16, 64, 64, 16, 16, 64, 64, 32, 64, 32, 16, 16, 16, 64, 64, 32, 48, 48, 80, 64, 32, 64, 64, 64, 64};
 template <int V>
 void run(float* d) {
     printf("%-32s", names[V]);
@@ -71,6 +77,6 @@ int main() {
     float* d;
     (void)hipMalloc(&d, 4);
     printf("cycles of one SIMD per wave64 VALU instruction (2.4 GHz), w = waves per SIMD\n");
-    run<0>(d); run<1>(d); run<2>(d); run<3>(d); run<4>(d); run<5>(d); run<6>(d); run<7>(d); run<8>(d); run<9>(d); run<10>(d); run<11>(d); run<12>(d); run<13>(d); run<14>(d); run<15>(d); run<16>(d); run<17>(d); run<18>(d); run<19>(d); run<20>(d); run<21>(d); run<22>(d); run<23>(d);
+    run<0>(d); run<1>(d); run<2>(d); run<3>(d); run<4>(d); run<5>(d); run<6>(d); run<7>(d); run<8>(d); run<9>(d); run<10>(d); run<11>(d); run<12>(d); run<13>(d); run<14>(d); run<15>(d); run<16>(d); run<17>(d); run<18>(d); run<19>(d); run<20>(d); run<21>(d); run<22>(d); run<23>(d); run<24>(d); run<25>(d); run<26>(d);
     return 0;
 }

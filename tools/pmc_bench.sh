@@ -1,6 +1,8 @@
 #!/bin/bash
 # PMC passes over one bench.py configuration (one --pmc set per rocprofv3 run, kernel-trace only), summarised into the JSON
-# that bench.py's roofline block reads: profiles/r2_pmc_<config>.json.   usage: tools/pmc_bench.sh c2|c3|c4
+# that bench.py's roofline block reads: profiles/r3_pmc_<config>.json (copy gpurun_out/pmc_bench_<cfg>/summary.json there). The summary
+# carries the hash of the library sources (bench.csrc_hash): bench.py quotes it only for the kernels it was measured on.
+# usage: tools/pmc_bench.sh c2|c3|c4
 set -u
 CFG=${1:-c2}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -21,7 +23,9 @@ for SET in \
   echo "set$i rc=$? : $SET"
 done
 python - <<PY
-import csv, glob, collections, json
+import csv, glob, collections, json, sys
+sys.path.insert(0, ".")
+import bench as _bench
 out, cfg = "$OUT", "$CFG"
 res = collections.defaultdict(float); disp = collections.defaultdict(set)
 kernel = None
@@ -41,7 +45,7 @@ valu_busy = c["SQ_INSTS_VALU"] * 2.0 / (1024.0 * xcd_cycles)
 lane = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
 wait = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
 ta = c.get("TA_BUSY_avr", 0.0) / xcd_cycles
-s = {"config": cfg, "kernel": kernel, "bench_args": "$ARGS", "launches": n_launch, "samples_per_launch": samples / n_launch,
+s = {"config": cfg, "kernel": kernel, "csrc_hash": _bench.csrc_hash(), "bench_args": "$ARGS", "launches": n_launch, "samples_per_launch": samples / n_launch,
      "hbm_bytes_per_launch": hbm / n_launch, "hbm_bytes_per_sample": hbm / samples,
      "valu_busy": valu_busy, "valu_lane_utilisation": lane, "wait_share": wait, "ta_busy": ta,
      "l2_hit": c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"]),

@@ -1,0 +1,36 @@
+#!/bin/bash
+# Round-3 same-box A/B of library variants (akari_render_amd/variants/libakari_hip_<name>.so, built with
+# `python akari_render_amd/build.py --variant <name> ...`; "product" = the shipped library).
+#   tools/r3_batch.sh bench <cfg> <variant>...      bench.py --config <cfg>, 2 steps, every variant, $REPS rounds (default 2)
+#   tools/r3_batch.sh shard <cfg-flag> <variant>... tools/shard_balance.py 8 (1080p) per variant; cfg-flag: fd | full
+#   tools/r3_batch.sh tests <variant>...            pytest -m gpu with the variant as the library under test
+# Different boxes differ by +-2 %: only numbers of one call compare.
+set -u
+cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/r3; mkdir -p $OUT
+MODE=$1; shift
+lib() { if [ "$1" = product ]; then unset AKR_HIP_LIB; else export AKR_HIP_LIB=$PWD/akari_render_amd/variants/libakari_hip_$1.so; fi; }
+case $MODE in
+bench)
+  CFG=$1; shift
+  for R in $(seq 1 ${REPS:-2}); do
+    for V in "$@"; do
+      lib $V
+      timeout 600 python bench.py --config $CFG --steps ${STEPS:-2} --warmup 1 --also none --no-cpu-baseline > $OUT/bench_${CFG}_$V.json 2> $OUT/bench_${CFG}_$V.err
+      echo "bench $CFG round $R $V $(python -c "import json;d=json.load(open('$OUT/bench_${CFG}_$V.json'));c=d['counters'];r=c['n_closest']+c['n_shadow'];print(round(d['value'],1),'Msamples/s  nodes/ray',round(c['n_node_visits']/r,2),'tris/ray',round(c['n_tri_tests']/r,2))" 2>&1 | tail -1)"
+    done
+  done ;;
+shard)
+  KIND=$1; shift
+  for V in "$@"; do
+    lib $V
+    timeout 900 python tools/shard_balance.py 8 ${STEPS:-8} --$KIND ${EXTRA:-} > $OUT/shard_${KIND}_$V.json 2> $OUT/shard_${KIND}_$V.err
+    echo "shard $KIND $V $(python -c "import json;d=json.load(open('$OUT/shard_${KIND}_$V.json'));print('T1',round(d['T1_ms'],1),'max rank',max(d['per_rank_ms']),'eff',round(d['kernel_scaling_efficiency'],3))" 2>&1 | tail -1)"
+  done ;;
+tests)
+  for V in "$@"; do
+    lib $V
+    timeout 1200 python -m pytest tests -x -q -m gpu ${PYTEST_ARGS:-} > $OUT/gputest_$V.log 2>&1
+    echo "tests $V rc=$? $(tail -1 $OUT/gputest_$V.log)"
+  done ;;
+esac

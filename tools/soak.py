@@ -244,8 +244,8 @@ def main():
     textures = True if "tex" in opts else None  # "tex": every scene with images and shader graphs
     runner = run_aov if "aov" in opts else run_gpt if "gpt" in opts else run_mcmc if "mcmc" in opts else run_shard if "shard" in opts else run_pt
     if "wavefront" in opts:  # the path tracer's wavefront schedule instead of the megakernel
-        os.environ["AKR_PT_MODE"] = "wavefront"
-        os.environ["AKR_FORCE_BVH"] = "1"
+        capi.set_option("wavefront", 1)
+        capi.set_option("force_bvh", 1)
     table = np.fromfile(os.path.join(ROOT, "tests/golden/ggx_dielectric_s.f32"), dtype=np.float32)
     ctx = capi.Context(0)
     pyoracle.set_pmj_tables(*capi.host_pmj02bn_tables())

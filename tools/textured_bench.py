@@ -37,8 +37,7 @@ variants = [("textured", sd, None), ("textured, conductor deferral off", sd, "0"
 only = os.environ.get("TEXBENCH_ONLY")  # substring of the variant's name
 for name, variant, defer in variants:
     if only and only != name: continue
-    if defer is None: os.environ.pop("AKR_PT_DEFER_METAL", None)
-    else: os.environ["AKR_PT_DEFER_METAL"] = defer
+    capi.set_option("defer_metal", -1 if defer is None else int(defer))
     scene = capi.Scene(ctx, variant)
     film = capi.Film(ctx, 1920, 1080)
     cfg = abi.PtConfig.default(); cfg.spp = 64 * (steps + 1); cfg.spp_per_pass = 64; cfg.max_depth = 12
