@@ -32,7 +32,8 @@ EXPORTS = [
     "akr_film_resolve", "akr_film_device_ptr",
     "akr_pt_config_default", "akr_pt_config_from_json", "akr_pt_render", "akr_pt_begin", "akr_pt_passes", "akr_pt_end",
     "akr_pt_get_stats", "akr_render_task", "akr_image_write", "akr_aov_config_default", "akr_aov_render",
-    "akr_gpt_config_default", "akr_gpt_render", "akr_mcmc_config_default", "akr_mcmc_render", "akr_film_set_splat_scale", "akr_film_get_splat_scale",
+    "akr_gpt_config_default", "akr_gpt_render", "akr_gpt_begin", "akr_gpt_sample", "akr_gpt_sums", "akr_gpt_sums_read", "akr_gpt_sums_write",
+    "akr_gpt_finish", "akr_gpt_reduce", "akr_mcmc_config_default", "akr_mcmc_render", "akr_film_set_splat_scale", "akr_film_get_splat_scale",
     "akr_pt_read_sampler_states", "akr_context_device_ordinal", "akr_device_count",
     "akr_probe_material_inputs_host", "akr_comm_unique_id", "akr_comm_create", "akr_comm_wrap", "akr_comm_destroy", "akr_film_reduce",
     "akr_host_stdrng_u64", "akr_host_chacha_block", "akr_host_pcg32_states", "akr_host_pcg_start", "akr_host_alias_table",
@@ -118,6 +119,13 @@ def lib() -> C.CDLL:
     proto("akr_aov_render", vp, vp, C.POINTER(abi.AovConfig), vp, C.POINTER(abi.PtStats))
     proto("akr_gpt_config_default", C.POINTER(abi.GptConfig))
     proto("akr_gpt_render", vp, vp, C.POINTER(abi.GptConfig), vp, fp, C.POINTER(abi.PtStats))
+    proto("akr_gpt_begin", vp, vp, C.POINTER(abi.GptConfig), vp, vp, vpp)
+    proto("akr_gpt_sample", vp, u32, i32)
+    proto("akr_gpt_sums", vp, C.POINTER(fp), u64p)
+    proto("akr_gpt_sums_read", vp, fp)
+    proto("akr_gpt_sums_write", vp, fp)
+    proto("akr_gpt_finish", vp, fp, C.POINTER(abi.PtStats))
+    proto("akr_gpt_reduce", vp, vp, i32, i32)
     proto("akr_mcmc_config_default", C.POINTER(abi.McmcConfig))
     proto("akr_mcmc_render", vp, vp, C.POINTER(abi.McmcConfig), vp, C.POINTER(abi.McmcResult), up, C.POINTER(abi.PtStats))
     proto("akr_film_set_splat_scale", vp, C.c_float)
@@ -643,6 +651,59 @@ def gpt_render(ctx: Context, scene: Scene, cfg: abi.GptConfig, film: Film, want_
     if not want_aux:
         return st.as_dict()
     return st.as_dict(), (aux[:3 * n].reshape(h, w, 3), aux[3 * n:3 * n + 3 * ng].reshape(h + 1, w + 1, 3), aux[3 * n + 3 * ng:].reshape(h + 1, w + 1, 3))
+
+
+class Shard(C.Structure):
+    """akr_shard"""
+
+    _fields_ = [("shard_rank", C.c_uint32), ("shard_count", C.c_uint32), ("tile_w", C.c_uint32), ("tile_h", C.c_uint32)]
+
+
+class GptSession:
+    """akr_gpt_begin / _sample / _reduce / _finish: a gpt render in steps (one rank's share of a sharded render, or the whole frame)."""
+
+    def __init__(self, ctx: Context, scene: Scene, cfg: abi.GptConfig, film: Film, rank: int = 0, world: int = 1, tile_w: int = 32, tile_h: int = 32):
+        self.ctx, self.scene, self.film, self.cfg = ctx, scene, film, cfg
+        self.h = C.c_void_p()
+        sh = Shard(rank, world, tile_w, tile_h)
+        check(lib().akr_gpt_begin(ctx.h, scene.h, C.byref(cfg), C.byref(sh) if world > 1 else None, film.h, C.byref(self.h)))
+
+    def sample(self, n: int = 0, blocking: bool = True):
+        check(lib().akr_gpt_sample(self.h, n, 1 if blocking else 0))
+
+    def n_sums(self) -> int:
+        p, n = C.POINTER(C.c_float)(), C.c_uint64()
+        check(lib().akr_gpt_sums(self.h, C.byref(p), C.byref(n)))
+        return n.value
+
+    def read_sums(self) -> np.ndarray:
+        out = np.zeros(self.n_sums(), dtype=np.float32)
+        if out.size:
+            check(lib().akr_gpt_sums_read(self.h, _fp(out)))
+        return out
+
+    def write_sums(self, a: np.ndarray):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        assert a.size == self.n_sums()
+        if a.size:
+            check(lib().akr_gpt_sums_write(self.h, _fp(a)))
+
+    def reduce(self, comm: "Comm", root: int = 0, blocking: bool = True):
+        check(lib().akr_gpt_reduce(self.h, comm.h, root, 1 if blocking else 0))
+
+    def finish(self, want_aux: bool = False):
+        st = abi.PtStats()
+        w, h = self.film.width, self.film.height
+        n, ng = w * h, (w + 1) * (h + 1)
+        aux = np.zeros(3 * n + 6 * ng, dtype=np.float32) if want_aux else None
+        hh, self.h = self.h, C.c_void_p()
+        check(lib().akr_gpt_finish(hh, _fp(aux) if want_aux else None, C.byref(st)))
+        return (st.as_dict(), aux) if want_aux else st.as_dict()
+
+    def __del__(self):
+        if getattr(self, "h", None) and self.h.value:
+            lib().akr_gpt_finish(self.h, None, None)
+            self.h = C.c_void_p()
 
 
 def mcmc_render(ctx: Context, scene: Scene, cfg: abi.McmcConfig, film: Film):

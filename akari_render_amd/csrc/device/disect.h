@@ -317,11 +317,16 @@ AKR_D void trav_begin(Trav& s, vec3 o, vec3 d, float tmin, float tmax, uint32_t 
 
 // One step of one lane: a triangle test if one is pending, else the next node. MODE 0: closest hit, 1: any hit, 2: `any_rt`
 // decides per lane (the wavefront schedule traces both kinds of ray in one loop).
-template <int MODE, bool TEX>
-AKR_D void trav_step(const DScene& sc, Trav& s, uint32_t* __restrict__ stack, TraceCounters& cnt, bool any_rt = false) {
+// TILE: the launch keeps the first sc.bvh_tile_nodes nodes (the top levels, breadth-first order: host/bvh.cpp) in LDS at `tile`;
+// a lane whose next node is one of them reads it with five ds_read_b128 instead of going through the texture addresser and L1 --
+// on the 10 M-triangle hall the traversal keeps that path 58 % busy, and every ray starts with three to five such nodes.
+template <int MODE, bool TEX, bool TILE = false>
+AKR_D void trav_step(const DScene& sc, Trav& s, uint32_t* __restrict__ stack, TraceCounters& cnt, bool any_rt = false, const uint4* tile = nullptr) {
     const bool any_hit = MODE == 2 ? any_rt : (MODE == 1);
     const bool do_tri = s.T != 0;
     const uint4* p;
+    bool in_tile = false;
+    uint32_t tile_idx = 0;
     if (do_tri) {
         const uint32_t b = (uint32_t)__builtin_ctz(s.T);
         s.T &= s.T - 1u;
@@ -342,10 +347,28 @@ AKR_D void trav_step(const DScene& sc, Trav& s, uint32_t* __restrict__ stack, Tr
             }
         }
         const uint32_t slot = (j - 24u) ^ (s.octinv4 & 7u);
-        p = sc.bvh_nodes + (size_t)((s.G & 0xffffffu) + slot) * (kBvhNodeWords / 4);
+        const uint32_t idx = (s.G & 0xffffffu) + slot;
+        p = sc.bvh_nodes + (size_t)idx * (kBvhNodeWords / 4);
+        if (TILE && idx < sc.bvh_tile_nodes) {
+            in_tile = true;
+            tile_idx = idx;
+        }
     }
     // the one fetch of the step; a triangle record is 64 bytes, so its lanes re-read word 0 instead of running into the next line
-    uint4 w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3], w4 = p[do_tri ? 0 : 4];
+    uint4 w0, w1, w2, w3, w4;
+    if (TILE && in_tile) {
+        // explicitly an LDS address: left generic, the compiler folds the two branches into ONE flat load of a selected pointer
+        // (and volatile: two plain loads in the arms of an if / else are sunk into one load of a selected -- generic -- pointer)
+        typedef const volatile uint32_t __attribute__((address_space(3))) * LdsW;
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef const volatile u32x4 __attribute__((address_space(3))) * LdsU4;
+        LdsU4 pt = (LdsU4)((LdsW)(const uint32_t*)tile + tile_idx * 20u);
+        const u32x4 t0 = pt[0], t1 = pt[1], t2 = pt[2], t3 = pt[3], t4 = pt[4];
+        w0 = make_uint4(t0.x, t0.y, t0.z, t0.w); w1 = make_uint4(t1.x, t1.y, t1.z, t1.w); w2 = make_uint4(t2.x, t2.y, t2.z, t2.w);
+        w3 = make_uint4(t3.x, t3.y, t3.z, t3.w); w4 = make_uint4(t4.x, t4.y, t4.z, t4.w);
+    } else {
+        w0 = p[0]; w1 = p[1]; w2 = p[2]; w3 = p[3]; w4 = p[do_tri ? 0 : 4];
+    }
     // All five loads are in flight before anything waits. Without this fence the compiler sinks the words only the node test
     // reads into the node branch -- a second dependent round trip to memory for every node step.
     asm volatile("" : "+v"(w0.x), "+v"(w0.y), "+v"(w0.z), "+v"(w0.w), "+v"(w1.x), "+v"(w1.y), "+v"(w1.z), "+v"(w1.w), "+v"(w2.x), "+v"(w2.y),

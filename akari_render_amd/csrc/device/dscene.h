@@ -64,6 +64,7 @@ struct DScene {
     const uint4* __restrict__ bvh_nodes;            // nullptr on the exhaustive path
     uint32_t n_tris, n_lights, n_nodes, has_alpha;
     uint32_t bvh_stack_depth;                       // BVH path: traversal stack entries per lane in LDS = depth of this scene's tree
+    uint32_t bvh_tile_nodes;                        // nodes 0 .. n-1 (the top of the tree, laid out breadth-first) a launch keeps in LDS; 0 = none
     uint64_t plane_share_mask;                      // exhaustive path: bit k = record k carries the plane row of record k-1
     TexScene tex;                                   // textures + shader-graph node lists (all nullptr without textures)
 };

@@ -36,7 +36,17 @@ __global__ __launch_bounds__(256, 2) void k_gpt_sample(const PtParams p_in, cons
     tc.cnt = TraceCounters{0, 0, 0};
     const uint32_t item = blockIdx.x * 256u + threadIdx.x;
     uint32_t px = 0, py = 0;
-    const bool in_frame = item < p.n_items && item_to_pixel(p, item, px, py);
+    bool in_frame;
+    if (g.item_pixels != nullptr) {  // sharded: the host's list of the pixels this rank has to sample (own tiles + halo)
+        in_frame = item < p.n_items;
+        if (in_frame) {
+            const uint32_t q = g.item_pixels[item];
+            py = q / p.width;
+            px = q - py * p.width;
+        }
+    } else {
+        in_frame = item < p.n_items && item_to_pixel(p, item, px, py);
+    }
     uint32_t n_rays = 0;
     if (in_frame) {
         const uint32_t pix = px + py * p.width;
@@ -149,9 +159,14 @@ AKR_D int gpt_sources(int32_t cp, int32_t o, uint32_t r, uint32_t out[3]) {
 
 // update_kernel, gpt.rs:424-461: fold one sample's splats into the film (reconstruction none: film.splat += v / 4) or into
 // the primal / gradient sums and sums of squares.
+AKR_D bool gpt_owned(const GptParams& g, uint32_t x, uint32_t y) {
+    if (g.shard_count <= 1) return true;
+    return ((y / g.tile_h) * g.tiles_x + x / g.tile_w) % g.shard_count == g.shard_rank;
+}
 __global__ __launch_bounds__(256) void k_gpt_update(const GptParams g, uint32_t W, uint32_t H, float* __restrict__ film) {
     const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
+    if (!gpt_owned(g, x, y)) return;  // another rank's pixel: its film / accumulator entries stay zero here
     const size_t N = (size_t)W * H, q = x + (size_t)y * W, gq = x + (size_t)y * (W + 1);
     for (int c = 0; c < 3; c++) {
         if (g.reconstruction == RECON_NONE) {

@@ -1067,8 +1067,39 @@ AKR_API int32_t akr_gpt_config_default(akr_gpt_config* c) {  // gpt::Config::def
     c->sampler_type = AKR_SAMPLER_INDEPENDENT; c->sampler_seed = 0; c->seed = 0;
     return AKR_OK;
 }
-AKR_API int32_t akr_gpt_render(akr_context* ctx, akr_scene* scene, const akr_gpt_config* cfg, akr_film* film, float* aux, akr_pt_stats* stats) {
-    if (!ctx || !scene || !cfg || !film) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_gpt_render: NULL argument");
+// One gpt render in steps, so that several GPUs can share it: begin (with the rank's akr_shard) -> sample -> reduce (the film's
+// splat channels with reconstruction none, the primal / gradient sums otherwise) -> finish (the reconstruction sweeps run on the
+// reduced sums). akr_gpt_render is begin + sample + finish on the whole frame.
+struct akr_gpt_session {
+    akr_context* ctx = nullptr;
+    akr_scene* scene = nullptr;
+    akr_film* film = nullptr;
+    akr_gpt_config cfg;
+    akr_pt_session* pt = nullptr;  // sampler states, counters, kernel parameters, timing
+    DevBuf scratch, sums, item_pixels;
+    GptParams g;
+    uint32_t W = 0, H = 0, spp_done = 0, n_items = 0;
+    bool recon = false;
+    size_t n_sums() const { return recon ? 6 * (size_t)W * H + 12 * (size_t)(W + 1) * (H + 1) : 0; }
+};
+extern "C++" {
+namespace akr {
+int32_t gpt_reduce_view(akr_gpt_session* se, akr_film** film, int* device, hipStream_t* stream, float** sums, size_t* n_sums) {
+    if (!se) return fail(AKR_ERR_INVALID_ARGUMENT, "gpt session is NULL");
+    *film = se->film;
+    *device = se->ctx->device;
+    *stream = se->ctx->stream;
+    *sums = se->sums.as<float>();
+    *n_sums = se->n_sums();
+    return AKR_OK;
+}
+}  // namespace akr
+}  // extern "C++"
+static uint32_t gpt_reflect_host(int64_t x, uint32_t r) { return x < 0 ? (uint32_t)(-x) : (x >= (int64_t)r ? r - (uint32_t)(x - r) - 1u : (uint32_t)x); }  // gpt.rs:131-139
+
+AKR_API int32_t akr_gpt_begin(akr_context* ctx, akr_scene* scene, const akr_gpt_config* cfg, const akr_shard* shard, akr_film* film, akr_gpt_session** out) {
+    if (!ctx || !scene || !cfg || !film || !out) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_gpt_begin: NULL argument");
+    *out = nullptr;
     const uint32_t W = scene->flat.camera.width, H = scene->flat.camera.height;
     if (cfg->reconstruction > AKR_GPT_RECON_WEIGHTED) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_gpt_render: unknown reconstruction");
     if (cfg->stride < 1 || cfg->stride >= W || cfg->stride >= H) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_gpt_render: stride must be in [1, min(width, height))");
@@ -1076,6 +1107,7 @@ AKR_API int32_t akr_gpt_render(akr_context* ctx, akr_scene* scene, const akr_gpt
         return fail(AKR_ERR_INVALID_ARGUMENT, "akr_gpt_render: reconstruction 'none' needs reconnect = true (the reference panics)");
     if (cfg->sampler_type != AKR_SAMPLER_INDEPENDENT)  // Pmj02BnSampler::clone_box is todo!(), sampler/mod.rs:677
         return fail(AKR_ERR_UNSUPPORTED, "akr_gpt_render: gpt needs the independent sampler (the reference's pmj02bn sampler cannot be cloned)");
+    if (shard && shard->shard_count > 1 && shard->shard_rank >= shard->shard_count) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_gpt_begin: shard_rank >= shard_count");
     akr_pt_config pc;
     akr_pt_config_default(&pc);
     pc.spp = cfg->spp; pc.spp_per_pass = 1; pc.max_depth = cfg->max_depth; pc.rr_depth = cfg->rr_depth;
@@ -1083,33 +1115,139 @@ AKR_API int32_t akr_gpt_render(akr_context* ctx, akr_scene* scene, const akr_gpt
     pc.filter_type = cfg->filter_type; pc.filter_radius = cfg->filter_radius;
     pc.sampler_type = cfg->sampler_type; pc.sampler_seed = cfg->sampler_seed;
     pc.color = cfg->color;
-    akr_pt_session* se = nullptr;
-    int32_t rc = akr_pt_begin(ctx, scene, &pc, film, &se);
+    akr_pt_session* pt = nullptr;
+    int32_t rc = akr_pt_begin(ctx, scene, &pc, film, &pt);
     if (rc != AKR_OK) return rc;
+    auto se = std::make_unique<akr_gpt_session>();
     rc = guarded([&] {
+        se->ctx = ctx; se->scene = scene; se->film = film; se->cfg = *cfg; se->pt = pt; se->W = W; se->H = H;
         const size_t N = (size_t)W * H, NG = (size_t)(W + 1) * (H + 1);
-        const bool recon = cfg->reconstruction != AKR_GPT_RECON_NONE;
-        DevBuf scratch, sums, old;
-        scratch.alloc(15 * N * sizeof(float));
-        GptParams g;
+        se->recon = cfg->reconstruction != AKR_GPT_RECON_NONE;
+        se->scratch.alloc(15 * N * sizeof(float));
+        // the slots are gathered from neighbours that a sharded render may never write (pixels outside the rank's halo): zero, not garbage
+        HIP_CHECK(hipMemsetAsync(se->scratch.p, 0, se->scratch.bytes, ctx->stream));
+        GptParams& g = se->g;
         std::memset(&g, 0, sizeof g);
-        g.own = scratch.as<float>();
-        for (int i = 0; i < 4; i++) g.shifted[i] = scratch.as<float>() + 3 * N * (size_t)(1 + i);
+        g.own = se->scratch.as<float>();
+        for (int i = 0; i < 4; i++) g.shifted[i] = se->scratch.as<float>() + 3 * N * (size_t)(1 + i);
         g.reconnect = cfg->reconnect ? 1u : 0u; g.stride = cfg->stride; g.separate_weights = cfg->separate_weights ? 1u : 0u;
         g.reconstruction = cfg->reconstruction;
-        if (recon) {
-            sums.alloc((6 * N + 12 * NG) * sizeof(float));
-            HIP_CHECK(hipMemsetAsync(sums.p, 0, sums.bytes, ctx->stream));
-            float* b = sums.as<float>();
+        if (se->recon) {
+            se->sums.alloc((6 * N + 12 * NG) * sizeof(float));
+            HIP_CHECK(hipMemsetAsync(se->sums.p, 0, se->sums.bytes, ctx->stream));
+            float* b = se->sums.as<float>();
             g.acc_p = b; g.sqr_p = b + 3 * N; g.acc_gx = b + 6 * N; g.acc_gy = g.acc_gx + 3 * NG; g.sqr_gx = g.acc_gy + 3 * NG; g.sqr_gy = g.sqr_gx + 3 * NG;
         }
-        fill_params(se, 1, 1);
-        LaunchTimer timer(se);
-        for (uint32_t s = 0; s < cfg->spp; s++) {  // gpt.rs:468-485: kernel + update_kernel per sample
-            HIP_CHECK(launch_gpt_sample(se->params, g, ctx->stream));
-            HIP_CHECK(launch_gpt_update(g, W, H, film->data, ctx->stream));
+        fill_params(pt, 1, 1);
+        se->n_items = pt->params.n_items;
+        g.shard_count = 1;
+        if (shard && shard->shard_count > 1) {
+            // The rank folds (k_gpt_update) the pixels of its own tiles; a pixel's value gathers what its neighbours' offset paths
+            // splat onto it, so the rank SAMPLES its own pixels plus the halo of pixels one of whose offset paths lands in an owned
+            // tile (reconstruction none: the four pixels `stride` away, mirrored at the borders, gpt.rs:118-142; otherwise the left
+            // and the upper neighbour, whose +x / +y gradients the update reads). Every rank keeps the whole frame's sampler states,
+            // and a halo pixel draws the same numbers on every rank that samples it. The list is built here, once: own pixels
+            // tile by tile in 8x8 blocks (the order of item_to_pixel), then the halo.
+            const uint32_t tw = shard->tile_w ? shard->tile_w : 32, th = shard->tile_h ? shard->tile_h : 32;
+            if (tw % 8 != 0 || th % 8 != 0) throw std::invalid_argument("akr_shard: tile sizes must be multiples of 8");
+            const uint32_t tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th;
+            g.shard_rank = shard->shard_rank; g.shard_count = shard->shard_count; g.tile_w = tw; g.tile_h = th; g.tiles_x = tiles_x;
+            auto owned = [&](uint32_t x, uint32_t y) { return ((y / th) * tiles_x + x / tw) % shard->shard_count == shard->shard_rank; };
+            std::vector<uint32_t> list;
+            for (uint32_t t = shard->shard_rank; t < tiles_x * tiles_y; t += shard->shard_count) {
+                const uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
+                for (uint32_t by = 0; by < th / 8; by++)
+                    for (uint32_t bx = 0; bx < tw / 8; bx++)
+                        for (uint32_t l = 0; l < 64; l++) {
+                            const uint32_t x = tx * tw + bx * 8 + (l & 7u), y = ty * th + by * 8 + (l >> 3);
+                            if (x < W && y < H) list.push_back(x + y * W);
+                        }
+            }
+            const int64_t st = cfg->stride;
+            for (uint32_t y = 0; y < H; y++)
+                for (uint32_t x = 0; x < W; x++) {
+                    if (owned(x, y)) continue;
+                    bool need;
+                    if (!se->recon) {
+                        need = owned(gpt_reflect_host((int64_t)x + st, W), y) || owned(gpt_reflect_host((int64_t)x - st, W), y) ||
+                               owned(x, gpt_reflect_host((int64_t)y + st, H)) || owned(x, gpt_reflect_host((int64_t)y - st, H));
+                    } else {
+                        need = (x + 1 < W && owned(x + 1, y)) || (y + 1 < H && owned(x, y + 1));
+                    }
+                    if (need) list.push_back(x + y * W);
+                }
+            se->item_pixels.upload(list);
+            g.item_pixels = se->item_pixels.as<uint32_t>();
+            se->n_items = (uint32_t)list.size();
         }
-        if (!recon) {
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+    if (rc != AKR_OK) {
+        std::string err = g_last_error;
+        akr_pt_end(pt, nullptr);
+        g_last_error = err;
+        return rc;
+    }
+    *out = se.release();
+    return AKR_OK;
+}
+AKR_API int32_t akr_gpt_sample(akr_gpt_session* se, uint32_t n_samples, int32_t blocking) {
+    if (!se) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_gpt_sample: session is NULL");
+    return guarded([&] {
+        se->ctx->bind();
+        const uint32_t left = se->cfg.spp - se->spp_done, n = n_samples == 0 ? left : std::min(n_samples, left);
+        akr_pt_session* pt = se->pt;
+        fill_params(pt, 1, 1);
+        pt->params.n_items = se->n_items;
+        LaunchTimer timer(pt);
+        for (uint32_t s = 0; s < n; s++) {  // gpt.rs:468-485: kernel + update_kernel per sample
+            HIP_CHECK(launch_gpt_sample(pt->params, se->g, se->ctx->stream));
+            HIP_CHECK(launch_gpt_update(se->g, se->W, se->H, se->film->data, se->ctx->stream));
+        }
+        timer.stop();
+        pt->n_launches += 2 * n;
+        se->spp_done += n;
+        pt->spp_done = se->spp_done;
+        if (blocking) HIP_CHECK(hipStreamSynchronize(se->ctx->stream));
+    });
+}
+// The primal / gradient sums and sums of squares of a reconstructing render ([6 N + 12 (W+1)(H+1)] floats on the device; n = 0
+// with reconstruction none, whose sums are the film's splat channels): for hosts that reduce with their own collective.
+AKR_API int32_t akr_gpt_sums(akr_gpt_session* se, float** device_ptr, uint64_t* n_floats) {
+    if (!se || !device_ptr || !n_floats) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_gpt_sums: NULL argument");
+    *device_ptr = se->sums.as<float>();
+    *n_floats = se->n_sums();
+    return AKR_OK;
+}
+AKR_API int32_t akr_gpt_sums_read(akr_gpt_session* se, float* dst) {
+    if (!se || !dst) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_gpt_sums_read: NULL argument");
+    return guarded([&] {
+        se->ctx->bind();
+        HIP_CHECK(hipStreamSynchronize(se->ctx->stream));
+        if (se->n_sums()) HIP_CHECK(hipMemcpy(dst, se->sums.p, se->n_sums() * sizeof(float), hipMemcpyDeviceToHost));
+    });
+}
+AKR_API int32_t akr_gpt_sums_write(akr_gpt_session* se, const float* src) {
+    if (!se || !src) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_gpt_sums_write: NULL argument");
+    return guarded([&] {
+        se->ctx->bind();
+        HIP_CHECK(hipStreamSynchronize(se->ctx->stream));
+        if (se->n_sums()) HIP_CHECK(hipMemcpy(se->sums.p, src, se->n_sums() * sizeof(float), hipMemcpyHostToDevice));
+    });
+}
+AKR_API int32_t akr_gpt_finish(akr_gpt_session* se, float* aux, akr_pt_stats* stats) {
+    if (!se) return AKR_OK;
+    akr_context* ctx = se->ctx;
+    akr_film* film = se->film;
+    const akr_gpt_config* cfg = &se->cfg;
+    const uint32_t W = se->W, H = se->H;
+    int32_t rc = guarded([&] {
+        ctx->bind();
+        const size_t N = (size_t)W * H, NG = (size_t)(W + 1) * (H + 1);
+        const GptParams& g = se->g;
+        DevBuf old;
+        LaunchTimer timer(se->pt);
+        if (!se->recon) {
             film->splat_scale = 1.0f / (float)cfg->spp;  // gpt.rs:463-466
         } else if (cfg->spp > 0) {  // gpt.rs:495-606
             const float spp = (float)cfg->spp;
@@ -1129,16 +1267,28 @@ AKR_API int32_t akr_gpt_render(akr_context* ctx, akr_scene* scene, const akr_gpt
             }
         }
         timer.stop();
-        se->n_launches += 2 * cfg->spp;
-        se->spp_done = cfg->spp;
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        if (aux && recon) {
+        if (aux && se->recon) {
             HIP_CHECK(hipMemcpy(aux, g.acc_p, 3 * N * sizeof(float), hipMemcpyDeviceToHost));
             HIP_CHECK(hipMemcpy(aux + 3 * N, g.acc_gx, 6 * NG * sizeof(float), hipMemcpyDeviceToHost));
         }
     });
     std::string err = g_last_error;
-    int32_t rc2 = akr_pt_end(se, stats);
+    int32_t rc2 = akr_pt_end(se->pt, stats);
+    delete se;
+    if (rc != AKR_OK) {
+        g_last_error = err;
+        return rc;
+    }
+    return rc2;
+}
+AKR_API int32_t akr_gpt_render(akr_context* ctx, akr_scene* scene, const akr_gpt_config* cfg, akr_film* film, float* aux, akr_pt_stats* stats) {
+    akr_gpt_session* se = nullptr;
+    int32_t rc = akr_gpt_begin(ctx, scene, cfg, nullptr, film, &se);
+    if (rc != AKR_OK) return rc;
+    rc = akr_gpt_sample(se, 0, 0);
+    std::string err = g_last_error;
+    int32_t rc2 = akr_gpt_finish(se, aux, stats);
     if (rc != AKR_OK) {
         g_last_error = err;
         return rc;

@@ -25,6 +25,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <deque>
 #include <limits>
 #include <numeric>
 #include <stdexcept>
@@ -66,6 +67,7 @@ struct BinNode {
 };
 
 constexpr int kBins = 16;
+constexpr size_t kBvhTopSlots = 1024;  // node slots laid out breadth-first (the first four levels of a full tree: 1 + 8 + 64 + 512)
 constexpr uint32_t kLeafMax = 3;
 
 struct Builder {
@@ -209,18 +211,21 @@ void build_bvh8(const std::vector<float>& tri_bounds, uint32_t n_tris, float pad
     b.build(0, n_tris);
     const auto& bn = b.nodes;
     struct Pending { int32_t bin; uint32_t out; uint32_t depth; };
-    std::vector<Pending> queue;
+    std::deque<Pending> queue;
     out_nodes.assign(stride, 0u);
     order_out.clear();
     order_out.reserve(n_tris);
     depth_out = 0;
     queue.push_back({0, 0, 1});
     auto fbits = [](float v) { uint32_t u; std::memcpy(&u, &v, 4); return u; };
-    // depth-first emission: a node's child block is allocated when the node is emitted and each subtree is laid out before
-    // its siblings' subtrees, so a ray that descends stays within a few DRAM pages / L2 lines
+    // Emission order = memory order. The top of the tree breadth-first -- level by level until kBvhTopSlots node slots exist --
+    // so that the nodes every ray visits first are the nodes 0 .. n of the array: the kernels keep a prefix of it in LDS
+    // (device/disect.h: node tile). Below that depth-first: a node's child block is allocated when the node is emitted and each
+    // subtree is laid out before its siblings' subtrees, so a ray that descends stays within a few DRAM pages / L2 lines.
     while (!queue.empty()) {
-        Pending pe = queue.back();
-        queue.pop_back();
+        Pending pe;
+        if (out_nodes.size() / stride < kBvhTopSlots) { pe = queue.front(); queue.pop_front(); }
+        else { pe = queue.back(); queue.pop_back(); }
         depth_out = std::max(depth_out, pe.depth);
         int32_t kids[8];
         int nk = 0;

@@ -18,6 +18,7 @@ namespace akr {
 // defined in api.cpp
 int32_t film_device_view(akr_film* film, int* device, hipStream_t* stream, float** data, size_t* n_floats);
 int32_t api_fail(int32_t code, const std::string& msg);
+int32_t gpt_reduce_view(akr_gpt_session* se, akr_film** film, int* device, hipStream_t* stream, float** sums, size_t* n_sums);
 }  // namespace akr
 using namespace akr;
 
@@ -159,6 +160,29 @@ AKR_API int32_t akr_film_reduce(akr_film* film, akr_comm* comm, int32_t root, in
     // in place, on the context's own stream: ordered after the render that filled the film, no extra synchronisation
     int rc = root < 0 ? r.AllReduce(data, data, n, /*ncclFloat32*/ 7, /*ncclSum*/ 0, comm->comm, stream)
                       : r.Reduce(data, data, n, 7, 0, root, comm->comm, stream);
+    if (rc != 0) return rccl_fail(root < 0 ? "ncclAllReduce" : "ncclReduce", rc);
+    if (blocking) {
+        hipError_t e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return api_fail(AKR_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    }
+    return AKR_OK;
+}
+
+// The exchange step of a sharded gpt render: with reconstruction none the ranks' films (splat channels of disjoint tiles) are
+// summed, otherwise the primal / gradient sums, onto `root` (or every rank, root = -1); akr_gpt_finish then reconstructs there.
+AKR_API int32_t akr_gpt_reduce(akr_gpt_session* se, akr_comm* comm, int32_t root, int32_t blocking) {
+    if (!se || !comm || root >= comm->world) return api_fail(AKR_ERR_INVALID_ARGUMENT, "akr_gpt_reduce: bad argument");
+    akr_film* film = nullptr;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    float* sums = nullptr;
+    size_t n = 0;
+    int32_t rc0 = gpt_reduce_view(se, &film, &device, &stream, &sums, &n);
+    if (rc0 != AKR_OK) return rc0;
+    if (n == 0) return akr_film_reduce(film, comm, root, blocking);
+    if (hipSetDevice(device) != hipSuccess) return api_fail(AKR_ERR_HIP, "hipSetDevice failed");
+    Rccl& r = rccl();
+    int rc = root < 0 ? r.AllReduce(sums, sums, n, /*ncclFloat32*/ 7, /*ncclSum*/ 0, comm->comm, stream) : r.Reduce(sums, sums, n, 7, 0, root, comm->comm, stream);
     if (rc != 0) return rccl_fail(root < 0 ? "ncclAllReduce" : "ncclReduce", rc);
     if (blocking) {
         hipError_t e = hipStreamSynchronize(stream);

@@ -43,6 +43,7 @@ struct PtParams {
     uint32_t stage_total;
     uint32_t defer_metal;    // exhaustive path: shade hits on materials with a conductor lobe on even iterations only (pt_kernels.hip)
     uint32_t tex_slots;      // TEX scenes: value slots per lane of the graph evaluation (LDS, after the launch's other blocks)
+    uint32_t tile_offset;    // BVH kernels with a node tile (disect.h: TILE): word offset of the tile; its size is sc.bvh_tile_nodes
     uint32_t park_offset;    // kernels that park cold path state in LDS while shading (dpath.h: PARK): word offset of the columns
     uint32_t carry_offset;   // BVH kernels that let a wave's longest rays run on into the next iteration (pt_kernels.hip): their columns
     // work distribution
@@ -73,6 +74,10 @@ struct GptParams {
     float* shifted[4];
     float *acc_p, *acc_gx, *acc_gy, *sqr_p, *sqr_gx, *sqr_gy;
     uint32_t reconnect, stride, separate_weights, reconstruction;
+    // Sharded render (akr_gpt_begin with an akr_shard): k_gpt_sample runs the pixels of `item_pixels` -- the rank's own tiles plus
+    // the halo whose offset paths land in them -- and k_gpt_update folds only the pixels of the rank's own tiles.
+    const uint32_t* item_pixels;  // pixel index per work item, or nullptr = PtParams' tile enumeration
+    uint32_t shard_rank, shard_count, tile_w, tile_h, tiles_x;
 };
 
 // mcmc_opt integrator (mcmc_kernels.hip)

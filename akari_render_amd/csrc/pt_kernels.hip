@@ -10,6 +10,7 @@
 // camera ray in the same iteration -- all 64 lanes of a wave stay on the same code (intersect / shade / shadow)
 // until the lane's pixel has all its samples. Sample values, RNG consumption order and film arithmetic are the
 // reference's; only the schedule differs.
+#include <algorithm>
 #include "device/dpath.h"
 
 namespace akr {
@@ -37,11 +38,17 @@ namespace akr {
 #ifndef AKR_WALK_FULL
 #define AKR_WALK_FULL 0  // the same for the full-graph exhaustive kernels
 #endif
+#ifndef AKR_WALK_FULL_UNROLL
+#define AKR_WALK_FULL_UNROLL 0  // full-graph exhaustive kernels: two records per trip of the pair walk, as the force_diffuse kernel does
+#endif
 #ifndef AKR_PT_PARK_FULL
 #define AKR_PT_PARK_FULL 0  // exhaustive full-graph kernels without textures: cold path state in LDS while a vertex is shaded (dpath.h: PARK)
 #endif
 #ifndef AKR_PT_PARK_BVH
 #define AKR_PT_PARK_BVH 0   // the same for the BVH full-graph kernels without textures
+#endif
+#ifndef AKR_BVH_TILE
+#define AKR_BVH_TILE 0  // BVH kernels: 1 = the top of the tree in LDS (disect.h: TILE), as many nodes as launch_pt_pass finds room for
 #endif
 #ifndef AKR_PT_STRAGGLERS
 #define AKR_PT_STRAGGLERS 0  // BVH kernels: n > 0 = an intersection phase ends when at most 1/n of the lanes that entered it are still
@@ -62,6 +69,14 @@ __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT
     if (STAGE) stage_scene_tables<BVH, TEX, !BVH && !FD && TEX>(p, lds_stack, staged);
     const PtParams& q = STAGE ? staged : p;
     const DScene& sc = q.sc;
+    constexpr bool TILE = BVH && AKR_BVH_TILE != 0;
+    const uint4* tile = (const uint4*)(lds_stack + p.tile_offset);
+    if (TILE) {  // nodes 0 .. bvh_tile_nodes - 1, 20 words each
+        uint32_t* l = lds_stack + p.tile_offset;
+        const uint32_t* g = (const uint32_t*)p.sc.bvh_nodes;
+        for (uint32_t i = threadIdx.x; i < p.sc.bvh_tile_nodes * 20u; i += 256u) l[i] = g[(i / 20u) * kBvhNodeWords + i % 20u];
+        __syncthreads();
+    }
     constexpr int WALK = FD ? AKR_WALK_FD : AKR_WALK_FULL;
     const float4* lds_recs = nullptr;
     if (!BVH && WALK == 1) {  // the triangle records behind the staged tables (launch_pt_pass sizes the block)
@@ -131,7 +146,7 @@ __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT
                     const uint32_t n_now = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(phase != 2u));
                     if (n_now <= n_leave) break;  // n_leave < n_in: at least one lane of the phase finishes
                     if (phase != 2u) {
-                        if (s.active) trav_step<2, TEX>(sc, s, tc.stack, tc.cnt, phase == 1u);
+                        if (s.active) trav_step<2, TEX, TILE>(sc, s, tc.stack, tc.cnt, phase == 1u, tile);
                         if (!s.active) {
                             if (phase == 0u) {
                                 found = s.best != kInvalid;
@@ -163,7 +178,7 @@ __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT
                 else trav_begin(s, r.s_o, r.s_d, 0.0f, phase == 1 ? r.s_tmax : -1.0f, r.s_ex0, r.s_ex1);
                 hit.t = 1e20f; hit.u = 0.0f; hit.v = 0.0f; hit.gid = kInvalid;
                 while (phase != 2u) {
-                    if (s.active) trav_step<2, TEX>(sc, s, tc.stack, tc.cnt, phase == 1u);
+                    if (s.active) trav_step<2, TEX, TILE>(sc, s, tc.stack, tc.cnt, phase == 1u, tile);
                     if (!s.active) {
                         if (phase == 0u) {
                             found = s.best != kInvalid;
@@ -183,7 +198,7 @@ __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT
                     occluded = trace_bvh<true, TEX>(sc, r.s_o, r.s_d, 0.0f, r.s_tmax, r.s_ex0, r.s_ex1, sh, tc.stack, tc.cnt);
                 }
             } else {
-                trace_pair_exhaustive<TEX, FD, WALK>(sc, r.ro, r.rd, r.has_ray ? 1e20f : -1.0f, r.ray_ex0, r.s_o, r.s_d, r.has_shadow ? r.s_tmax : -1.0f,
+                trace_pair_exhaustive<TEX, FD || AKR_WALK_FULL_UNROLL != 0, WALK>(sc, r.ro, r.rd, r.has_ray ? 1e20f : -1.0f, r.ray_ex0, r.s_o, r.s_d, r.has_shadow ? r.s_tmax : -1.0f,
                                             r.s_ex0, r.s_ex1, hit, found, occluded, lds_recs);
                 if (DEFER) {
                     // A scene with one metal among diffuse surfaces: every wave carries a few lanes on the metal at every
@@ -375,6 +390,17 @@ hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream) {
     size_t base = (bvh ? p.sc.bvh_stack_depth * 256 * 4 : 0) + p.stage_total + (recs_in_lds ? (p.sc.n_tris + 2) * 48 : 0);
     base = (base + 15) & ~(size_t)15;
     PtParams pp = p;
+    pp.tile_offset = (uint32_t)(base / 4);
+    pp.sc.bvh_tile_nodes = 0;
+    if (bvh && AKR_BVH_TILE) {
+        // what is left of a quarter of the CU's LDS (four workgroups per CU = four waves per SIMD) after the launch's other blocks
+        size_t other = base + (park ? (p.defer_metal ? kParkSlots : kParkSlotsNoDefer) * 256 * 4 : 0) + (AKR_PT_STRAGGLERS > 0 ? kCarrySlots * 256 * 4 : 0) +
+                       (tex ? (size_t)p.tex_slots * kTexValStride * sizeof(TexVal) : 0);
+        const size_t budget = (tex ? 53 : 40) * 1024 - 256;  // TEX kernels run three workgroups per CU (AKR_PT_MIN_WAVES_BVH_TEX)
+        if (other < budget) pp.sc.bvh_tile_nodes = (uint32_t)std::min<size_t>({(budget - other) / 80, (size_t)p.sc.n_nodes, (size_t)1024});
+        base += (size_t)pp.sc.bvh_tile_nodes * 80;
+        base = (base + 15) & ~(size_t)15;
+    }
     pp.park_offset = (uint32_t)(base / 4);
     if (park) base += (p.defer_metal ? kParkSlots : kParkSlotsNoDefer) * 256 * 4;
     pp.carry_offset = (uint32_t)(base / 4);

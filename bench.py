@@ -193,16 +193,27 @@ def make_native_comm(ctx, rank, world, torch, dist, dev):
     return comm
 
 
-def run_config(ctx, key, steps, warmup, rank, world, scaling, film_t, torch, dist, backend, dev, comm=None):
+_SCENES = {}  # (config key, forced BVH) -> (scene, info): the 10 M-triangle hall takes 20 s to generate and compile
+
+
+def run_config(ctx, key, steps, warmup, rank, world, scaling, film_t, torch, dist, backend, dev, comm=None, passes_per_step=PASSES_PER_STEP,
+               force_bvh=False, keep_scene=False):
     """Times `steps` steps of configuration `key` on this rank. Returns (elapsed_s, per-rank counter deltas, extra info)."""
     from akari_render_amd import abi, capi, distributed
 
-    scene, sinfo = build_scene(ctx, key)
+    if (key, force_bvh) in _SCENES:
+        scene, sinfo = _SCENES[(key, force_bvh)]
+        sinfo = dict(sinfo)
+    else:
+        with capi.options(force_bvh=1 if force_bvh else 0):
+            scene, sinfo = build_scene(ctx, key)
+        if keep_scene:
+            _SCENES[(key, force_bvh)] = (scene, dict(sinfo))
     film_t.zero_()
     torch.cuda.synchronize(dev)
     film = capi.Film(ctx, W, H, device_ptr=film_t.data_ptr())
     cfg = abi.PtConfig.default()
-    cfg.spp = (warmup + steps) * SPP_PER_STEP
+    cfg.spp = (warmup + steps) * SPP_PER_PASS * passes_per_step
     cfg.spp_per_pass, cfg.max_depth, cfg.rr_depth, cfg.use_nee = SPP_PER_PASS, 12, 5, 1
     cfg.force_diffuse = CONFIGS[key]["force_diffuse"]
     cfg.filter_type, cfg.filter_radius = abi.FILTER_GAUSSIAN, 1.5
@@ -215,7 +226,7 @@ def run_config(ctx, key, steps, warmup, rank, world, scaling, film_t, torch, dis
 
     se = capi.PtSession(ctx, scene, cfg, film)
     if warmup > 0:
-        se.passes(warmup * PASSES_PER_STEP, blocking=True)
+        se.passes(warmup * passes_per_step, blocking=True)
     if world > 1 and backend == "nccl":
         # warm the collective up too (RCCL builds its rings / proxy connections on the first reduce of a given size):
         # same message size as the film, on a scratch buffer, outside the timed region
@@ -239,7 +250,7 @@ def run_config(ctx, key, steps, warmup, rank, world, scaling, film_t, torch, dis
 
     sync()
     t0 = time.perf_counter()
-    se.passes(steps * PASSES_PER_STEP, blocking=True)
+    se.passes(steps * passes_per_step, blocking=True)
     t_rendered = time.perf_counter()
     if world > 1:
         if backend == "gloo":
@@ -268,7 +279,7 @@ def run_config(ctx, key, steps, warmup, rank, world, scaling, film_t, torch, dis
     d["tri_bytes"] = int(getattr(info, "tri_bytes", 48) or 48)
     sinfo["weak"] = weak
     sinfo["film_reduce"] = "none (one GPU)" if world == 1 else ("akr_film_reduce (RCCL through the C ABI)" if comm is not None else f"torch.distributed.reduce ({backend})")
-    sinfo["spp_done"] = (warmup + steps) * SPP_PER_STEP
+    sinfo["spp_done"] = (warmup + steps) * SPP_PER_PASS * passes_per_step
     del film, scene
     return t1 - t0, d, sinfo
 
@@ -429,7 +440,7 @@ def main():
         extra = {}
         for k2 in [k for k in also.split(",") if k and k != "none" and k != key]:
             try:
-                e2, d2, si2 = run_config(ctx, k2, 1, 0 if k2 == "c4" else 1, 0, 1, "strong", film_t, torch, dist, args.backend, dev)
+                e2, d2, si2 = run_config(ctx, k2, 1, 0 if k2 == "c4" else 1, 0, 1, "strong", film_t, torch, dist, args.backend, dev, keep_scene=(k2 == "c4"))
                 extra[k2] = {"metric": "Msamples/s, " + CONFIGS[k2]["name"], "value": d2["n_samples"] / e2 / 1e6, "unit": "Msamples/s",
                              "steps": 1, "ms_per_step": e2 * 1e3, "workload": CONFIGS[k2]["workload"],
                              "rays_per_s_G": (d2["n_closest"] + d2["n_shadow"]) / e2 / 1e9,
@@ -438,6 +449,24 @@ def main():
                              **{k: v for k, v in si2.items() if k not in ("weak", "spp_done")}}
             except Exception as ex:  # a secondary leg must not cost the headline line
                 extra[k2] = {"error": f"{type(ex).__name__}: {ex}"}
+        # The wavefront schedule (wf_kernels.hip: trace / shade kernels, path state in HBM, ballot + prefix-sum compaction) next to the
+        # megakernel on the same scenes, 4 passes (256 spp) each: the hall, and the cbox with a forced BVH (the wavefront schedule has
+        # no exhaustive intersector). Measured every run so that the comparison in DESIGN.md is never a stale number.
+        if also != "none" and args.gpus == 1 and key == "c2":
+            from akari_render_amd import capi as _capi
+            sched = {}
+            for name, k2, fbvh in (("c2_forced_bvh", "c2", True), ("c4", "c4", False)):
+                for mode in ("megakernel", "wavefront"):
+                    try:
+                        with _capi.options(wavefront=1 if mode == "wavefront" else 0):
+                            e2, d2, _ = run_config(ctx, k2, 1, 1 if k2 == "c2" else 0, 0, 1, "strong", film_t, torch, dist, args.backend, dev, passes_per_step=4,
+                                                   force_bvh=fbvh, keep_scene=True)
+                        sched[f"{name}_{mode}"] = {"value": d2["n_samples"] / e2 / 1e6, "unit": "Msamples/s", "spp": 4 * SPP_PER_PASS,
+                                                   "rays_per_s_G": (d2["n_closest"] + d2["n_shadow"]) / e2 / 1e9, "launches": d2["n_launches"]}
+                    except Exception as ex:  # noqa: BLE001
+                        sched[f"{name}_{mode}"] = {"error": f"{type(ex).__name__}: {ex}"}
+            _SCENES.clear()
+            extra["schedules"] = sched
         if extra:
             out["extra_configs"] = extra
         if args.gpus == 1 and not args.no_cpu_baseline:

@@ -350,6 +350,7 @@ AKR_API int32_t akr_comm_create(akr_context *ctx, const uint8_t id[AKR_COMM_ID_B
 AKR_API int32_t akr_comm_wrap(akr_context *ctx, void *nccl_comm, int32_t rank, int32_t world, akr_comm **out);
 AKR_API int32_t akr_comm_destroy(akr_comm *comm);
 AKR_API int32_t akr_film_reduce(akr_film *film, akr_comm *comm, int32_t root, int32_t blocking);
+AKR_API int32_t akr_gpt_reduce(struct akr_gpt_session *se, akr_comm *comm, int32_t root, int32_t blocking);   /* see akr_gpt_begin */
 
 /* Fills *cfg with pt::Config::default() (pt.rs:930-944), the default filter (film.rs:50-54) and sampler
  * (sampler/mod.rs:290-294). */
@@ -449,6 +450,26 @@ AKR_API int32_t akr_gpt_config_default(akr_gpt_config *cfg);
 /* Renders into `film` (clear it first; sets its splat scale). aux (host memory, optional, reconstruction != none):
  * [primal 3 N | Gx 3 (W+1)(H+1) | Gy 3 (W+1)(H+1)] floats, the sums the reference writes / spp to output/gpt_*.exr. */
 AKR_API int32_t akr_gpt_render(akr_context *ctx, akr_scene *scene, const akr_gpt_config *cfg, akr_film *film, float *aux, akr_pt_stats *stats);
+/* The same render in steps, so that the GPUs of a node can share it (no reference counterpart; gpt.rs:381-640 is one device):
+ *   akr_gpt_begin(.., shard, ..)   shard = NULL: the whole frame. Otherwise rank r of n folds the pixels of its tiles (the rule of
+ *                                  akr_pt_config.shard_*) and samples those pixels plus their halo: the pixels one of whose four
+ *                                  offset paths (`stride` away, mirrored at the border, gpt.rs:118-142) lands in an owned tile --
+ *                                  with a reconstruction, the left and upper neighbours whose gradients the update reads. Every
+ *                                  rank keeps the whole frame's sampler states; a halo pixel draws the same numbers everywhere.
+ *   akr_gpt_sample(se, n, block)   n more samples per pixel (0 = all that are left of cfg.spp)
+ *   akr_gpt_reduce(se, comm, root) the exchange: reconstruction none -> akr_film_reduce of the film (splat channels of disjoint
+ *                                  tiles); otherwise ncclReduce of the primal / gradient sums [6 N + 12 (W+1)(H+1) floats].
+ *                                  akr_gpt_sums / _read / _write expose the sums to hosts with their own collective.
+ *   akr_gpt_finish(se, aux, stats) splat scale or the reconstruction sweeps (gpt.rs:495-606) on the (reduced) sums; frees se.
+ * The summed result is the one-GPU result bit for bit: every film / sum entry has exactly one rank that writes it. */
+typedef struct { uint32_t shard_rank, shard_count, tile_w, tile_h; } akr_shard;   /* tile sizes: multiples of 8; 0 = 32 */
+typedef struct akr_gpt_session akr_gpt_session;
+AKR_API int32_t akr_gpt_begin(akr_context *ctx, akr_scene *scene, const akr_gpt_config *cfg, const akr_shard *shard, akr_film *film, akr_gpt_session **out);
+AKR_API int32_t akr_gpt_sample(akr_gpt_session *se, uint32_t n_samples, int32_t blocking);
+AKR_API int32_t akr_gpt_sums(akr_gpt_session *se, float **device_ptr, uint64_t *n_floats);
+AKR_API int32_t akr_gpt_sums_read(akr_gpt_session *se, float *dst);
+AKR_API int32_t akr_gpt_sums_write(akr_gpt_session *se, const float *src);
+AKR_API int32_t akr_gpt_finish(akr_gpt_session *se, float *aux, akr_pt_stats *stats);
 
 /* ---------------------------------------------------------------------------------------------------
  * `mcmc_opt` integrator (Method::McmcOpt, akari_integrator/src/mcmc_opt.rs + mcmc.rs:8-80; "type": "mcmc_opt"): primary-sample-

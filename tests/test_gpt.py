@@ -209,3 +209,57 @@ def test_gpt_in_a_non_default_colour_pipeline(ctx, cbox_path, root, recon, color
     g = both(ctx, sd, gpt_config(spp=4, max_depth=5, rr_depth=2, reconstruction=recon, reconstruction_iter=3, color=color))
     g0 = both(ctx, sd, gpt_config(spp=4, max_depth=5, rr_depth=2, reconstruction=recon, reconstruction_iter=3))
     assert n_bit_diff(g, g0) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("recon", range(3), ids=abi.GPT_RECON_NAMES)
+@pytest.mark.parametrize("case", ["cbox_s1", "kinds_s3", "grid_bvh_s2"])
+def test_gpt_sharded_across_ranks_is_the_single_gpu_render(ctx, cbox_path, root, recon, case):
+    """akr_gpt_begin(.., akr_shard, ..): three ranks (here: three sessions on one GPU) each sample their 16x8 tiles plus the halo
+    whose offset paths land in them and fold their own pixels; the sum of the three films (reconstruction none) or of the three
+    sets of primal / gradient sums followed by ONE reconstruction (uniform, weighted) is the unsharded render bit for bit: every
+    film / sum entry is written by exactly one rank, and a halo pixel draws the same numbers on every rank that samples it."""
+    name, stride = {"cbox_s1": ("cbox", 1), "kinds_s3": ("kinds", 3), "grid_bvh_s2": ("grid_bvh", 2)}[case]
+    w, h = 56, 40   # ragged: 3.5 x 5 tiles
+    sd = make_scene(name, cbox_path, root, w, h)
+    cfg = gpt_config(spp=4, max_depth=6, rr_depth=2, reconstruction=recon, reconstruction_iter=5, stride=stride)
+    scene = capi.Scene(ctx, sd)
+    full = capi.Film(ctx, w, h)
+    se = capi.GptSession(ctx, scene, cfg, full)
+    se.sample()
+    sums_full = se.read_sums()
+    se.finish()
+    ref = capi.Film(ctx, w, h)
+    capi.gpt_render(ctx, scene, cfg, ref)       # the one-call entry point is the same thing
+    assert n_bit_diff(full.read(), ref.read()) == 0 and full.splat_scale == ref.splat_scale
+    world = 3
+    films, sums, sessions = [], [], []
+    for r in range(world):
+        f = capi.Film(ctx, w, h)
+        s = capi.GptSession(ctx, scene, cfg, f, rank=r, world=world, tile_w=16, tile_h=8)
+        s.sample(2)
+        s.sample()       # in two steps: the session keeps its place
+        films.append(f)
+        sums.append(s.read_sums())
+        sessions.append(s)
+    if recon == abi.GPT_RECON_NONE:
+        for s in sessions:
+            s.finish()
+        total = np.zeros_like(films[0].read())
+        for f in films:
+            total = total + f.read()
+        assert n_bit_diff(total, full.read()) == 0
+        from akari_render_amd import distributed
+        for r, f in enumerate(films):   # and nothing outside a rank's own tiles
+            own = distributed.owned_pixel_mask(w, h, r, world, 16, 8)
+            splat = f.read()[3 * w * h:6 * w * h].reshape(h, w, 3)
+            assert not splat[~own].any() and splat[own].any()
+    else:
+        acc = np.zeros_like(sums[0])
+        for a in sums:
+            acc = acc + a
+        assert n_bit_diff(acc, sums_full) == 0
+        sessions[0].write_sums(acc)   # what akr_gpt_reduce leaves on the root
+        for s in sessions:
+            s.finish()
+        assert n_bit_diff(films[0].read(), full.read()) == 0

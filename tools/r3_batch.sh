@@ -9,6 +9,7 @@ set -u
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/r3; mkdir -p $OUT
 MODE=$1; shift
+export AKR_DATA_DIR=$PWD/akari_render_amd/data   # a variant library sits in another directory than the tables of the pmj02bn sampler
 lib() { if [ "$1" = product ]; then unset AKR_HIP_LIB; else export AKR_HIP_LIB=$PWD/akari_render_amd/variants/libakari_hip_$1.so; fi; }
 case $MODE in
 bench)
@@ -26,6 +27,14 @@ shard)
     lib $V
     timeout 900 python tools/shard_balance.py 8 ${STEPS:-8} --$KIND ${EXTRA:-} > $OUT/shard_${KIND}_$V.json 2> $OUT/shard_${KIND}_$V.err
     echo "shard $KIND $V $(python -c "import json;d=json.load(open('$OUT/shard_${KIND}_$V.json'));print('T1',round(d['T1_ms'],1),'max rank',max(d['per_rank_ms']),'eff',round(d['kernel_scaling_efficiency'],3))" 2>&1 | tail -1)"
+  done ;;
+tex)   # tools/textured_bench.py: the textured room (NFLOOR=1: exhaustive kernel; 8: BVH kernel), variant "textured" and its constant twin
+  for V in "$@"; do
+    lib $V
+    for ONLY in "textured" "same room, constant materials with the lobes the graphs select"; do
+      TEXBENCH_ONLY="$ONLY" timeout 600 python tools/textured_bench.py 4 ${NFLOOR:-8} > $OUT/tex_${NFLOOR:-8}_$V.json 2> $OUT/tex_${NFLOOR:-8}_$V.err
+      echo "tex nfloor=${NFLOOR:-8} $V [$ONLY] $(python -c "import json;d=json.load(open('$OUT/tex_${NFLOOR:-8}_$V.json'));print({k:round(v['msamples_per_s'],1) for k,v in d.items()})" 2>&1 | tail -1)"
+    done
   done ;;
 tests)
   for V in "$@"; do
