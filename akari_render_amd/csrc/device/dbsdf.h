@@ -551,17 +551,17 @@ AKR_HD bool check_wo_wi_valid(vec3 ns, vec3 ng, vec3 wo, vec3 wi) {
 }
 
 // Everything the shading functions need at one path vertex.
-#ifndef AKR_LEAN_SP
-#define AKR_LEAN_SP 0  // 1: the normal-map frame and the local geometric normal are recomputed where they are read (12 fewer registers
-                       // live from the NEE evaluation to the end of the BSDF sample; the same operations on the same inputs, the same bits)
-#endif
+// lean: the inner (normal-map) frame and the local geometric normal are not stored but recomputed where they are read -- the same
+// operations on the same inputs, the same bits, and 12 fewer registers live from the NEE evaluation to the end of the BSDF sample.
+// The path tracer's kernels for scenes without textures run lean (137 -> 51 spilled registers in the full-graph exhaustive
+// kernel at 128 VGPRs, +2 % on C3); the TEX kernels, which run at 168 VGPRs, lose 3-5 % to the recomputation and do not.
+// `lean` is a compile-time constant wherever a ShadePoint is used, so the branch and the unused members fold away.
 struct ShadePoint {
     Frame frame;        // si.frame
     vec3 ng;            // si.ng
-#if !AKR_LEAN_SP
-    Frame nm_frame_;    // inner (normal-map) frame in local space; identity when !MF_NORMAL_MAP
-    vec3 ng_local_;     // frame.to_local(ng)  (normal_map(): ng of the inner SurfaceClosure)
-#endif
+    Frame nm_frame_;    // inner (normal-map) frame in local space; identity when !MF_NORMAL_MAP   (not lean)
+    vec3 ng_local_;     // frame.to_local(ng)  (normal_map(): ng of the inner SurfaceClosure)       (not lean)
+    bool lean;
     bool force_diffuse;
     bool wo_cached;     // wo_albedo holds the table values of the vertex's outgoing direction (shade_point_cache_wo)
     WoAlbedo wo_albedo;
@@ -577,35 +577,25 @@ AKR_HD Frame nm_frame_compute(const Frame& frame, const DMaterial& m) {
     return r;
 }
 AKR_HD Frame sp_nm_frame(const ShadePoint& sp, const DMaterial& m) {
-#if AKR_LEAN_SP
+    if (!sp.lean) return sp.nm_frame_;
     if (!sp.force_diffuse && m.kind == MAT_PRINCIPLED && (m.flags & MF_NORMAL_MAP)) return nm_frame_compute(sp.frame, m);
     return Frame{mk3(0, 0, 1), mk3(1, 0, 0), mk3(0, 1, 0)};
-#else
-    (void)m;
-    return sp.nm_frame_;
-#endif
 }
-AKR_HD vec3 sp_ng_local(const ShadePoint& sp) {
-#if AKR_LEAN_SP
-    return to_local(sp.frame, sp.ng);
-#else
-    return sp.ng_local_;
-#endif
-}
+AKR_HD vec3 sp_ng_local(const ShadePoint& sp) { return sp.lean ? to_local(sp.frame, sp.ng) : sp.ng_local_; }
 
-AKR_HD void shade_point_init(ShadePoint& sp, const DMaterial& m, Frame frame, vec3 ng, bool force_diffuse) {
+AKR_HD void shade_point_init(ShadePoint& sp, const DMaterial& m, Frame frame, vec3 ng, bool force_diffuse, bool lean = false) {
     sp.frame = frame;
     sp.ng = ng;
+    sp.lean = lean;
     sp.force_diffuse = force_diffuse;
     sp.wo_cached = false;
     sp.wo_albedo = WoAlbedo{0.0f, 0.0f};
-#if !AKR_LEAN_SP
-    sp.ng_local_ = to_local(frame, ng);
     sp.nm_frame_ = Frame{mk3(0, 0, 1), mk3(1, 0, 0), mk3(0, 1, 0)};
-    if (!force_diffuse && m.kind == MAT_PRINCIPLED && (m.flags & MF_NORMAL_MAP)) sp.nm_frame_ = nm_frame_compute(frame, m);
-#else
-    (void)m;
-#endif
+    sp.ng_local_ = mk3(0, 0, 0);
+    if (!lean) {
+        sp.ng_local_ = to_local(frame, ng);
+        if (!force_diffuse && m.kind == MAT_PRINCIPLED && (m.flags & MF_NORMAL_MAP)) sp.nm_frame_ = nm_frame_compute(frame, m);
+    }
 }
 
 // After shade_point_init, for a vertex all of whose evaluate / sample calls use this `wo` (world space): the albedo-table values

@@ -365,8 +365,6 @@ struct PathRegs {
 // conflicts). path_step<.., PARK> writes the cold fields there before it shades a vertex and reads them back after: two LDS
 // instructions per field and iteration instead of a scratch store and load, and the registers are free in between. The pixel
 // of the lane (pix, sx, sy: constant for the launch) lives there for the whole launch.
-constexpr uint32_t kParkSlots = 16, kParkSlotsNoDefer = 13;
-constexpr uint32_t kCarrySlots = 13;  // a traversal carried over to the next intersection phase (pt_kernels.hip: AKR_PT_STRAGGLERS)
 enum : uint32_t { PK_PIX = 0, PK_SX, PK_SY, PK_FILM, PK_FILM_W = PK_FILM + 3, PK_CNT, PK_SPP = PK_CNT + 3, PK_DEFER = PK_SPP + 3, PK_END = PK_DEFER + 3 };
 static_assert(PK_END <= kParkSlots, "park column too small");
 AKR_D void park_put(uint32_t* park, uint32_t slot, uint32_t v) { park[slot * 256u] = v; }
@@ -499,7 +497,7 @@ AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found,
                 vec3 u_bsdf = next_3d<PMJ>(p, r.smp);
                 // sample_surface_and_shade_direct, pt.rs:297-323
                 ShadePoint sp;
-                shade_point_init(sp, mat, si.frame, si.ng, force_diffuse);
+                shade_point_init(sp, mat, si.frame, si.ng, force_diffuse, /*lean=*/!TEX);
 #ifndef AKR_NO_WO_CACHE  // (A/B switch of tools/r2_ab.sh)
                 if (FD != 1) shade_point_cache_wo(sp, mat, sc.ggx_table, wo);
 #endif

@@ -422,8 +422,11 @@ static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pas
         p.stage_total = 0;
         p.tex_slots = cs.has_textures ? cs.tex_slots : 0;
         // one workgroup's dynamic LDS stays within 64 KB: traversal stacks + staged tables + the graph evaluation's value slots
-        const size_t other = (bvh ? (size_t)p.sc.bvh_stack_depth * 256 * 4 : 0) + (size_t)p.tex_slots * kTexValStride * sizeof(TexVal);
-        if (total <= (bvh ? kStageMaxBytesBvh : kStageMaxBytes) && (!bvh || other + total <= 64 * 1024)) {  // all of it or nothing (a TEX kernel reads its tables through LDS addresses)
+        // (BVH kernels also keep kCarrySlots words per lane for traversals carried over an intersection phase: pt_kernels.hip)
+        const size_t other = (bvh ? (size_t)p.sc.bvh_stack_depth * 256 * 4 + (size_t)kCarrySlots * 256 * 4 : 0) + (size_t)p.tex_slots * kTexValStride * sizeof(TexVal);
+        // a quarter of the CU's 160 KB per workgroup (four waves per SIMD), a third for the kernels of textured scenes (three)
+        const size_t lds_budget = (cs.has_textures ? 53 : 40) * 1024;
+        if (total <= (bvh ? kStageMaxBytesBvh : kStageMaxBytes) && (!bvh || other + total <= lds_budget)) {  // all of it or nothing (a TEX kernel reads its tables through LDS addresses)
             // the albedo table as well for the full-graph exhaustive kernel of a textured scene (stage_scene_tables: GGX), if three
             // workgroups per CU still fit (AKR_PT_MIN_WAVES_TEX = 3: 160 KB / 3)
             const size_t ggx_bytes = 4096 * sizeof(float);
@@ -487,8 +490,8 @@ static void wf_allocate(akr_pt_session* se, uint32_t n_slots) {
     se->wf_ctrl.alloc(8 * sizeof(uint32_t));
     uint32_t* c = (uint32_t*)se->wf_ctrl.p;
     w.qcount = c; w.qhead = c + 4; w.n_active = c + 5;
-    // persistent trace kernel: enough workgroups to fill every CU at its occupancy (LDS stack: 32 KB per workgroup)
-    se->wf_trace_blocks = (uint32_t)se->ctx->props.multiProcessorCount * 5u;
+    // persistent trace kernel: as many workgroups as the CUs hold at once (occupancy API: registers + this tree's LDS stacks)
+    se->wf_trace_blocks = (uint32_t)se->ctx->props.multiProcessorCount * wf_trace_blocks_per_cu(se->params);
 }
 
 // One launch group of the wavefront schedule = `fused` passes for every slot: init, then trace/shade iterations until

@@ -7,6 +7,10 @@
 
 namespace akr {
 
+// LDS columns per lane (one word per slot, slot s of lane i at word s * 256 + i) of the path tracer's kernels: cold path state
+// parked while a vertex is shaded (dpath.h: PARK), and a traversal carried over to the next intersection phase (pt_kernels.hip).
+constexpr uint32_t kParkSlots = 16, kParkSlotsNoDefer = 13;
+constexpr uint32_t kCarrySlots = 13;
 // Everything one pass of the path tracer needs; passed by value as the kernel argument (lands in SGPRs).
 struct PtParams {
     DScene sc;
@@ -124,6 +128,7 @@ hipError_t launch_gpt_recon(const GptParams& g, uint32_t W, uint32_t H, const fl
 hipError_t launch_aov(const PtParams& p, uint32_t spp, uint32_t aov, uint32_t remap, hipStream_t stream);
 hipError_t launch_wf_init(const PtParams& p, const WfBuffers& wf, hipStream_t stream);
 hipError_t launch_wf_shade(const PtParams& p, const WfBuffers& wf, uint32_t q_out, hipStream_t stream);
+uint32_t wf_trace_blocks_per_cu(const PtParams& p);
 hipError_t launch_wf_trace(const PtParams& p, const WfBuffers& wf, uint32_t q_in, uint32_t n_blocks, hipStream_t stream);
 hipError_t launch_probe_material(const PtParams& p, uint32_t material, uint32_t n, const float* uv, uint32_t* out, hipStream_t stream);
 hipError_t launch_init_pcg32(const uint64_t* seeds, void* states, uint64_t n, hipStream_t stream);

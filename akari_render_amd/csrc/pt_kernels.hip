@@ -33,13 +33,13 @@ namespace akr {
 #define AKR_PT_MIN_WAVES_BVH_TEX 3  // BVH kernels of such a scene (399 -> 517)
 #endif
 #ifndef AKR_WALK_FD
-#define AKR_WALK_FD 0    // exhaustive pair walk of the force_diffuse kernel: where the records' coefficients sit (disect.h: WALK)
+#define AKR_WALK_FD 1    // exhaustive pair walk of the force_diffuse kernel: where the records' coefficients sit (disect.h: WALK)
 #endif
 #ifndef AKR_WALK_FULL
-#define AKR_WALK_FULL 0  // the same for the full-graph exhaustive kernels
+#define AKR_WALK_FULL 1  // the same for the full-graph exhaustive kernels of scenes without textures (TEX kernels keep the scalar walk)
 #endif
 #ifndef AKR_WALK_FULL_UNROLL
-#define AKR_WALK_FULL_UNROLL 0  // full-graph exhaustive kernels: two records per trip of the pair walk, as the force_diffuse kernel does
+#define AKR_WALK_FULL_UNROLL 1  // full-graph exhaustive kernels: two records per trip of the pair walk, as the force_diffuse kernel does
 #endif
 #ifndef AKR_PT_PARK_FULL
 #define AKR_PT_PARK_FULL 0  // exhaustive full-graph kernels without textures: cold path state in LDS while a vertex is shaded (dpath.h: PARK)
@@ -48,11 +48,17 @@ namespace akr {
 #define AKR_PT_PARK_BVH 0   // the same for the BVH full-graph kernels without textures
 #endif
 #ifndef AKR_BVH_TILE
-#define AKR_BVH_TILE 0  // BVH kernels: 1 = the top of the tree in LDS (disect.h: TILE), as many nodes as launch_pt_pass finds room for
+#define AKR_BVH_TILE 1  // BVH kernels: 1 = the top of the tree in LDS (disect.h: TILE), as many nodes as launch_pt_pass finds room for
 #endif
 #ifndef AKR_PT_STRAGGLERS
-#define AKR_PT_STRAGGLERS 0  // BVH kernels: n > 0 = an intersection phase ends when at most 1/n of the lanes that entered it are still
+#define AKR_PT_STRAGGLERS 8  // BVH kernels: n > 0 = an intersection phase ends when at most 1/n of the lanes that entered it are still
                              // tracing; those lanes keep their traversal and go on in the next phase (see k_pt_pass)
+#endif
+#ifndef AKR_PT_STRAGGLERS_TEX
+#define AKR_PT_STRAGGLERS_TEX 0  // the same for the BVH kernels of scenes with textures (measured separately)
+#endif
+#ifndef AKR_PT_PARK_TEX
+#define AKR_PT_PARK_TEX 0   // the same for the full-graph kernels of scenes with textures (exhaustive and BVH)
 #endif
 #ifndef AKR_PT_MERGED_RAYS
 #define AKR_PT_MERGED_RAYS 1  // BVH path: a lane starts its shadow ray the moment its closest-hit ray is done (one loop)
@@ -69,7 +75,8 @@ __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT
     if (STAGE) stage_scene_tables<BVH, TEX, !BVH && !FD && TEX>(p, lds_stack, staged);
     const PtParams& q = STAGE ? staged : p;
     const DScene& sc = q.sc;
-    constexpr bool TILE = BVH && AKR_BVH_TILE != 0;
+    constexpr bool TILE = BVH && !TEX && AKR_BVH_TILE != 0;
+    constexpr uint32_t STRAG = BVH ? (TEX ? AKR_PT_STRAGGLERS_TEX : AKR_PT_STRAGGLERS) : 0;
     const uint4* tile = (const uint4*)(lds_stack + p.tile_offset);
     if (TILE) {  // nodes 0 .. bvh_tile_nodes - 1, 20 words each
         uint32_t* l = lds_stack + p.tile_offset;
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT
         for (uint32_t i = threadIdx.x; i < p.sc.bvh_tile_nodes * 20u; i += 256u) l[i] = g[(i / 20u) * kBvhNodeWords + i % 20u];
         __syncthreads();
     }
-    constexpr int WALK = FD ? AKR_WALK_FD : AKR_WALK_FULL;
+    constexpr int WALK = FD ? AKR_WALK_FD : (TEX ? 0 : AKR_WALK_FULL);
     const float4* lds_recs = nullptr;
     if (!BVH && WALK == 1) {  // the triangle records behind the staged tables (launch_pt_pass sizes the block)
         uint32_t* l = lds_stack + (p.stage_total >> 2);
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT
     shifted_pixel(p, px, py, sx, sy);
     PathRegs r;
     path_regs_init<PMJ>(r, q, in_frame, pix, sx, sy);
-    constexpr bool PARK = !FD && !TEX && (BVH ? AKR_PT_PARK_BVH != 0 : AKR_PT_PARK_FULL != 0);
+    constexpr bool PARK = !FD && (TEX ? AKR_PT_PARK_TEX != 0 : (BVH ? AKR_PT_PARK_BVH != 0 : AKR_PT_PARK_FULL != 0));
     uint32_t* park = lds_stack + p.park_offset + threadIdx.x;
     if (PARK) {
         park_put(park, PK_PIX, pix);
@@ -109,11 +116,11 @@ __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT
             // intersection phase: next closest-hit ray + pending shadow ray
             Hit hit;
             bool found = false, occluded = false;
-            if (!(BVH && AKR_PT_STRAGGLERS > 0 && r.carry)) {
+            if (!(STRAG > 0 && r.carry)) {
                 r.c_closest += r.has_ray ? 1u : 0u;
                 r.c_shadow += r.has_shadow ? 1u : 0u;
             }
-            if (BVH && AKR_PT_MERGED_RAYS && AKR_PT_STRAGGLERS > 0) {
+            if (BVH && AKR_PT_MERGED_RAYS && STRAG > 0) {
                 // The merged loop below ends when the wave's LONGEST pair of rays is done: on the 10 M-triangle hall 40 % of its
                 // lane-steps do work, the rest is lanes waiting for the tail of the ray-length distribution. Here the phase ends
                 // when at most 1/n of the lanes that entered it are still tracing. Those lanes keep their traversal -- position
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT
                     s.active = true;
                 }
                 const uint32_t n_in = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(phase != 2u));
-                const uint32_t n_leave = n_in / (uint32_t)(AKR_PT_STRAGGLERS > 0 ? AKR_PT_STRAGGLERS : 1);
+                const uint32_t n_leave = n_in / (STRAG > 0 ? STRAG : 1u);
                 while (true) {
                     const uint32_t n_now = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(phase != 2u));
                     if (n_now <= n_leave) break;  // n_leave < n_in: at least one lane of the phase finishes
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT
                     occluded = trace_bvh<true, TEX>(sc, r.s_o, r.s_d, 0.0f, r.s_tmax, r.s_ex0, r.s_ex1, sh, tc.stack, tc.cnt);
                 }
             } else {
-                trace_pair_exhaustive<TEX, FD || AKR_WALK_FULL_UNROLL != 0, WALK>(sc, r.ro, r.rd, r.has_ray ? 1e20f : -1.0f, r.ray_ex0, r.s_o, r.s_d, r.has_shadow ? r.s_tmax : -1.0f,
+                trace_pair_exhaustive<TEX, FD || (!TEX && AKR_WALK_FULL_UNROLL != 0), WALK>(sc, r.ro, r.rd, r.has_ray ? 1e20f : -1.0f, r.ray_ex0, r.s_o, r.s_d, r.has_shadow ? r.s_tmax : -1.0f,
                                             r.s_ex0, r.s_ex1, hit, found, occluded, lds_recs);
                 if (DEFER) {
                     // A scene with one metal among diffuse surfaces: every wave carries a few lanes on the metal at every
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT
                     }
                 }
             }
-            if (BVH && AKR_PT_STRAGGLERS > 0 && r.carry) {
+            if (STRAG > 0 && r.carry) {
                 // still tracing: nothing to resolve or shade yet
             } else if (PARK) path_step<FD ? 1 : 0, TEX, PMJ, DEFER ? 1 : 2>(q, r, hit, found, occluded, 0, 0, 0, park);
             else path_step<FD ? 1 : 0, TEX, PMJ>(q, r, hit, found, occluded, pix, sx, sy);
@@ -385,16 +392,17 @@ hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream) {
     const bool bvh = p.sc.bvh_nodes != nullptr;
     size_t lds;
     // exhaustive kernels whose pair walk reads the records from LDS (WALK 1) keep them behind the staged tables
-    const bool recs_in_lds = !bvh && (fd ? AKR_WALK_FD : AKR_WALK_FULL) == 1;
-    const bool park = !fd && !tex && (bvh ? AKR_PT_PARK_BVH != 0 : AKR_PT_PARK_FULL != 0);
+    const bool recs_in_lds = !bvh && (fd ? AKR_WALK_FD : (tex ? 0 : AKR_WALK_FULL)) == 1;
+    const bool strag = bvh && (tex ? AKR_PT_STRAGGLERS_TEX : AKR_PT_STRAGGLERS) > 0;
+    const bool park = !fd && (tex ? AKR_PT_PARK_TEX != 0 : (bvh ? AKR_PT_PARK_BVH != 0 : AKR_PT_PARK_FULL != 0));
     size_t base = (bvh ? p.sc.bvh_stack_depth * 256 * 4 : 0) + p.stage_total + (recs_in_lds ? (p.sc.n_tris + 2) * 48 : 0);
     base = (base + 15) & ~(size_t)15;
     PtParams pp = p;
     pp.tile_offset = (uint32_t)(base / 4);
     pp.sc.bvh_tile_nodes = 0;
-    if (bvh && AKR_BVH_TILE) {
+    if (bvh && !tex && AKR_BVH_TILE) {
         // what is left of a quarter of the CU's LDS (four workgroups per CU = four waves per SIMD) after the launch's other blocks
-        size_t other = base + (park ? (p.defer_metal ? kParkSlots : kParkSlotsNoDefer) * 256 * 4 : 0) + (AKR_PT_STRAGGLERS > 0 ? kCarrySlots * 256 * 4 : 0) +
+        size_t other = base + (park ? (p.defer_metal ? kParkSlots : kParkSlotsNoDefer) * 256 * 4 : 0) + (strag ? kCarrySlots * 256 * 4 : 0) +
                        (tex ? (size_t)p.tex_slots * kTexValStride * sizeof(TexVal) : 0);
         const size_t budget = (tex ? 53 : 40) * 1024 - 256;  // TEX kernels run three workgroups per CU (AKR_PT_MIN_WAVES_BVH_TEX)
         if (other < budget) pp.sc.bvh_tile_nodes = (uint32_t)std::min<size_t>({(budget - other) / 80, (size_t)p.sc.n_nodes, (size_t)1024});
@@ -404,7 +412,7 @@ hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream) {
     pp.park_offset = (uint32_t)(base / 4);
     if (park) base += (p.defer_metal ? kParkSlots : kParkSlotsNoDefer) * 256 * 4;
     pp.carry_offset = (uint32_t)(base / 4);
-    if (bvh && AKR_PT_STRAGGLERS > 0) base += kCarrySlots * 256 * 4;
+    if (strag) base += kCarrySlots * 256 * 4;
     const PtParams q = with_tex_slots(pp, base, lds);
     const bool stage = p.stage_total != 0;
 #define AKR_LAUNCH2(B, F, T, S, D)                                                                                       \

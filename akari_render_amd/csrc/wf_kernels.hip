@@ -12,6 +12,7 @@
 //               then stream compaction of the rays it produced into the next queue (ballot/prefix-sum again).
 // The reference's author sketched the same decomposition in crates/akari_integrator/src/wfpt.rs:59-225,315-494
 // (PathState SoA, KernelWorkQueue, raygen / intersect / shade / test_shadow); that file never runs there.
+#include <algorithm>
 #include "device/dpath.h"
 
 namespace akr {
@@ -211,6 +212,17 @@ hipError_t launch_wf_shade(const PtParams& p, const WfBuffers& wf, uint32_t q_ou
         else hipLaunchKernelGGL((k_wf_shade<false, false>), dim3(blocks), dim3(256), 0, stream, p, wf, q_out);
     }
     return hipGetLastError();
+}
+// Workgroups of the persistent trace kernel one CU holds at once (registers and the LDS stacks of this scene's tree decide).
+uint32_t wf_trace_blocks_per_cu(const PtParams& p) {
+    int n = 0;
+    const bool tex = p.sc.tex.nodes != nullptr;
+    size_t lds = (size_t)p.sc.bvh_stack_depth * 256 * 4;
+    if (tex) (void)with_tex_slots(p, lds, lds);
+    hipError_t e = tex ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wf_trace<true>, 256, lds)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wf_trace<false>, 256, lds);
+    if (e != hipSuccess || n < 1) n = 4;
+    return (uint32_t)std::min(n, 8);
 }
 hipError_t launch_wf_trace(const PtParams& p, const WfBuffers& wf, uint32_t q_in, uint32_t n_blocks, hipStream_t stream) {
     if (p.sc.tex.nodes != nullptr) {
