@@ -58,7 +58,7 @@ namespace akr {
 #define AKR_PT_STRAGGLERS_TEX 0  // the same for the BVH kernels of scenes with textures (measured separately)
 #endif
 #ifndef AKR_PT_PARK_TEX
-#define AKR_PT_PARK_TEX 0   // the same for the full-graph kernels of scenes with textures (exhaustive and BVH)
+#define AKR_PT_PARK_TEX 1   // the same for the full-graph kernels of scenes with textures (exhaustive and BVH)
 #endif
 #ifndef AKR_PT_MERGED_RAYS
 #define AKR_PT_MERGED_RAYS 1  // BVH path: a lane starts its shadow ray the moment its closest-hit ray is done (one loop)

@@ -39,6 +39,8 @@ CONFIGS = {
     "c4": dict(name="C4", baseline_config=3, force_diffuse=0, scene="hall",
                workload="procedural Sponza-like hall, 10 M triangles (generator seed 1234), 1920x1080, 1024 spp per step"),
 }
+CONFIGS["c5"] = dict(name="C5", baseline_config=4, force_diffuse=0, scene="cbox", res=(3840, 2160),
+                     workload="scenes/cbox 3840x2160, full Cycles-subset shader graph, 1024 spp per step (configs[4] = 8 steps), tiles over the ranks")
 HALL_TRIS = 10_000_000
 
 
@@ -155,11 +157,16 @@ def measured_counters(key):
     return m, None
 
 
+def resolution(key):
+    return CONFIGS[key].get("res", (W, H))
+
+
 def build_scene(ctx, key):
     from akari_render_amd import capi
 
     if CONFIGS[key]["scene"] == "cbox":
-        return capi.Scene(ctx, os.path.join(ROOT, "scenes", "cbox", "scene.json"), W, H), {}  # akr_scene_load: C++ reader
+        w, h = resolution(key)
+        return capi.Scene(ctx, os.path.join(ROOT, "scenes", "cbox", "scene.json"), w, h), {}  # akr_scene_load: C++ reader
     from akari_render_amd import procedural
 
     t0 = time.time()
@@ -209,9 +216,12 @@ def run_config(ctx, key, steps, warmup, rank, world, scaling, film_t, torch, dis
             scene, sinfo = build_scene(ctx, key)
         if keep_scene:
             _SCENES[(key, force_bvh)] = (scene, dict(sinfo))
+    w, h = resolution(key)
+    if film_t.numel() != 7 * w * h:  # a configuration with its own frame size (C5: 3840x2160) renders into its own film
+        film_t = torch.zeros(7 * w * h, dtype=torch.float32, device=dev)
     film_t.zero_()
     torch.cuda.synchronize(dev)
-    film = capi.Film(ctx, W, H, device_ptr=film_t.data_ptr())
+    film = capi.Film(ctx, w, h, device_ptr=film_t.data_ptr())
     cfg = abi.PtConfig.default()
     cfg.spp = (warmup + steps) * SPP_PER_PASS * passes_per_step
     cfg.spp_per_pass, cfg.max_depth, cfg.rr_depth, cfg.use_nee = SPP_PER_PASS, 12, 5, 1
@@ -233,7 +243,7 @@ def run_config(ctx, key, steps, warmup, rank, world, scaling, film_t, torch, dis
         scratch = torch.zeros_like(film_t)
         torch.cuda.synchronize(dev)
         if comm is not None:
-            sf = capi.Film(ctx, W, H, device_ptr=scratch.data_ptr())
+            sf = capi.Film(ctx, w, h, device_ptr=scratch.data_ptr())
             comm.reduce_film(sf, root=0, blocking=True)
             del sf
         else:
@@ -336,7 +346,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c2", choices=list(CONFIGS), help="the timed workload (BASELINE.json configs[1..3])")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4"], help="the timed workload (BASELINE.json configs[1..3])")
     ap.add_argument("--also", default=None, help="comma list of further configs measured once each after the timed one, reported under "
                                                    "extra_configs (default at N = 1 with --config c2: c3,c4; 'none' to skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -394,6 +404,30 @@ def main():
     n_sets = world if weak else 1
     assert total_samples == n_sets * W * H * SPP_PER_STEP * args.steps, (total_samples, n_sets * W * H * SPP_PER_STEP * args.steps)
 
+    # Two more legs at EVERY N (all ranks take part; one step each, outside the timed region of the headline):
+    #  c5            BASELINE configs[4]: the 3840x2160 frame, full graph, its tiles over the N ranks -- the configuration the
+    #                reference's multi-GPU target is written for; 4x the pixels per rank of the 1080p frame (at N = 8 a rank of the
+    #                1080p frame holds 2.2 waves per SIMD of long-running pixels, of the 4K frame 8.8)
+    #  weak          N > 1: every rank renders the whole 1080p frame with its own sampler seed (N independent sample sets)
+    multi = {}
+    if args.also != "none" and key == "c2":
+        for name, k2, scal in (("c5_strong", "c5", "strong"),) + ((("c2_weak", "c2", "weak"),) if world > 1 else ()):
+            try:
+                # (its own film: the headline's film is checked below)
+                e2, d2, si2 = run_config(ctx, k2, 1, 1 if world > 1 else 0, rank, world, scal, torch.zeros(1, dtype=torch.float32, device=dev), torch, dist,
+                                         args.backend, dev, comm)
+                n2 = d2["n_samples"]
+                if world > 1:
+                    cdev2 = dev if args.backend == "nccl" else torch.device("cpu")
+                    t2 = torch.tensor([e2, float(n2)], dtype=torch.float64, device=cdev2)
+                    tmax = t2.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                    tsum = t2.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+                    e2, n2 = float(tmax[0].item()), int(tsum[1].item())
+                multi[name] = {"metric": "Msamples/s (whole node), " + CONFIGS[k2]["name"] + (" -- weak scaling: N independent sample sets" if scal == "weak" else ""),
+                               "value": n2 / e2 / 1e6, "unit": "Msamples/s", "n_gpus": args.gpus, "scaling": scal, "steps": 1, "ms_per_step": e2 * 1e3,
+                               "resolution": list(resolution(k2)), "workload": CONFIGS[k2]["workload"]}
+            except Exception as ex:  # noqa: BLE001 -- a secondary leg must not cost the headline line
+                multi[name] = {"error": f"{type(ex).__name__}: {ex}"}
     if rank == 0:
         # frame sanity inside the bench: every pixel got its samples (exact per-pixel comparison), film finite
         expect_w = float(n_sets * sinfo["spp_done"])
@@ -437,7 +471,7 @@ def main():
         also = args.also
         if also is None:
             also = "c3,c4" if (args.gpus == 1 and key == "c2") else "none"
-        extra = {}
+        extra = dict(multi)
         for k2 in [k for k in also.split(",") if k and k != "none" and k != key]:
             try:
                 e2, d2, si2 = run_config(ctx, k2, 1, 0 if k2 == "c4" else 1, 0, 1, "strong", film_t, torch, dist, args.backend, dev, keep_scene=(k2 == "c4"))
