@@ -591,17 +591,18 @@ AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found,
 // per-launch counters (akr_pt_stats): one atomic per wave
 AKR_D void flush_counters(const PtParams& p, const PathRegs& r, const TraceCounters& tc, bool bvh) {
     if (p.counters == nullptr) return;
+    uint64_t* const ctr = p.counters + 8u * (blockIdx.x % kStatStripes);
     uint32_t a = wave_sum_u32(r.c_samples), b = wave_sum_u32(r.c_closest), c = wave_sum_u32(r.c_shadow), e = wave_sum_u32(r.c_shaded);
     uint32_t nn = wave_sum_u32(tc.nodes), nt = wave_sum_u32(tc.tris), ov = wave_sum_u32(tc.overflow);
     if ((threadIdx.x & 63u) == 0) {
-        if (a) atomicAdd((unsigned long long*)&p.counters[0], (unsigned long long)a);
-        if (b) atomicAdd((unsigned long long*)&p.counters[1], (unsigned long long)b);
-        if (c) atomicAdd((unsigned long long*)&p.counters[2], (unsigned long long)c);
-        if (e) atomicAdd((unsigned long long*)&p.counters[3], (unsigned long long)e);
-        if (nn) atomicAdd((unsigned long long*)&p.counters[4], (unsigned long long)nn);
+        if (a) atomicAdd((unsigned long long*)&ctr[0], (unsigned long long)a);
+        if (b) atomicAdd((unsigned long long*)&ctr[1], (unsigned long long)b);
+        if (c) atomicAdd((unsigned long long*)&ctr[2], (unsigned long long)c);
+        if (e) atomicAdd((unsigned long long*)&ctr[3], (unsigned long long)e);
+        if (nn) atomicAdd((unsigned long long*)&ctr[4], (unsigned long long)nn);
         unsigned long long tt = bvh ? (unsigned long long)nt : (unsigned long long)(b + c) * p.sc.n_tris;
-        if (tt) atomicAdd((unsigned long long*)&p.counters[5], tt);
-        if (ov) atomicAdd((unsigned long long*)&p.counters[6], (unsigned long long)ov);
+        if (tt) atomicAdd((unsigned long long*)&ctr[5], tt);
+        if (ov) atomicAdd((unsigned long long*)&ctr[6], (unsigned long long)ov);
     }
 }
 

@@ -422,15 +422,16 @@ static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pas
         p.stage_total = 0;
         p.tex_slots = cs.has_textures ? cs.tex_slots : 0;
         // one workgroup's dynamic LDS stays within 64 KB: traversal stacks + staged tables + the graph evaluation's value slots
-        // (BVH kernels also keep kCarrySlots words per lane for traversals carried over an intersection phase: pt_kernels.hip)
-        const size_t other = (bvh ? (size_t)p.sc.bvh_stack_depth * 256 * 4 + (size_t)kCarrySlots * 256 * 4 : 0) + (size_t)p.tex_slots * kTexValStride * sizeof(TexVal);
-        // a quarter of the CU's 160 KB per workgroup (four waves per SIMD), a third for the kernels of textured scenes (three)
-        const size_t lds_budget = (cs.has_textures ? 53 : 40) * 1024;
+        // what the launch keeps in LDS besides the staged tables: traversal stacks, graph values, and the columns / records of pt_lds_plan
+        const PtLdsPlan plan = pt_lds_plan(bvh, c.force_diffuse != 0, cs.has_textures, /*defer: the larger park block*/ true, cs.n_tris);
+        const size_t other = (bvh ? (size_t)p.sc.bvh_stack_depth * 256 * 4 : 0) + (size_t)p.tex_slots * kTexValStride * sizeof(TexVal) + plan.recs_bytes +
+                             plan.park_bytes + plan.carry_bytes;
+        const size_t lds_budget = pt_lds_budget(cs.has_textures);
         if (total <= (bvh ? kStageMaxBytesBvh : kStageMaxBytes) && (!bvh || other + total <= lds_budget)) {  // all of it or nothing (a TEX kernel reads its tables through LDS addresses)
             // the albedo table as well for the full-graph exhaustive kernel of a textured scene (stage_scene_tables: GGX), if three
             // workgroups per CU still fit (AKR_PT_MIN_WAVES_TEX = 3: 160 KB / 3)
             const size_t ggx_bytes = 4096 * sizeof(float);
-            if (!bvh && cs.has_textures && !c.force_diffuse && other + total + ggx_bytes <= 53 * 1024) {
+            if (!bvh && cs.has_textures && !c.force_diffuse && other + total + ggx_bytes <= lds_budget) {
                 bytes[12] = ggx_bytes;
                 total += ggx_bytes;
             }
@@ -923,8 +924,8 @@ AKR_API int32_t akr_pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_co
             HIP_CHECK(launch_init_pcg32(dseeds.as<uint64_t>(), se->states.p, n, ctx->stream));
             HIP_CHECK(hipStreamSynchronize(ctx->stream));  // dseeds goes out of scope
         }
-        se->counters.alloc(8 * sizeof(uint64_t));
-        HIP_CHECK(hipMemsetAsync(se->counters.p, 0, 8 * sizeof(uint64_t), ctx->stream));
+        se->counters.alloc(8 * kStatStripes * sizeof(uint64_t));
+        HIP_CHECK(hipMemsetAsync(se->counters.p, 0, se->counters.bytes, ctx->stream));
         se->wavefront = choose_wavefront(scene);
         se->defer_metal_option = tuning().defer_metal;
         if (se->wavefront) {
@@ -974,8 +975,11 @@ AKR_API int32_t akr_pt_read_sampler_states(akr_pt_session* se, uint64_t* dst) {
 static void read_stats(akr_pt_session* se, akr_pt_stats* stats) {
     se->ctx->bind();
     HIP_CHECK(hipStreamSynchronize(se->ctx->stream));
-    uint64_t c[8];
-    HIP_CHECK(hipMemcpy(c, se->counters.p, sizeof c, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> stripes(8 * kStatStripes);
+    HIP_CHECK(hipMemcpy(stripes.data(), se->counters.p, stripes.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    uint64_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t k = 0; k < kStatStripes; k++)
+        for (int i = 0; i < 8; i++) c[i] += stripes[8 * k + i];
     se->fold_events(true);
     const double ms = se->kernel_ms;
     if (stats) {

@@ -7,10 +7,63 @@
 
 namespace akr {
 
-// LDS columns per lane (one word per slot, slot s of lane i at word s * 256 + i) of the path tracer's kernels: cold path state
-// parked while a vertex is shaded (dpath.h: PARK), and a traversal carried over to the next intersection phase (pt_kernels.hip).
-constexpr uint32_t kParkSlots = 16, kParkSlotsNoDefer = 13;
-constexpr uint32_t kCarrySlots = 13;
+// ---- build switches of k_pt_pass (pt_kernels.hip); each default is the winner of a same-box A/B run ----
+#ifndef AKR_WALK_FD
+#define AKR_WALK_FD 1    // exhaustive pair walk of the force_diffuse kernel: where the records' coefficients sit (disect.h: WALK)
+#endif
+#ifndef AKR_WALK_FULL
+#define AKR_WALK_FULL 1  // the same for the full-graph exhaustive kernels of scenes without textures (TEX kernels keep the scalar walk)
+#endif
+#ifndef AKR_WALK_FULL_UNROLL
+#define AKR_WALK_FULL_UNROLL 1  // full-graph exhaustive kernels: two records per trip of the pair walk, as the force_diffuse kernel does
+#endif
+#ifndef AKR_PT_PARK_FULL
+#define AKR_PT_PARK_FULL 0  // exhaustive full-graph kernels without textures: cold path state in LDS while a vertex is shaded (dpath.h: PARK)
+#endif
+#ifndef AKR_PT_PARK_BVH
+#define AKR_PT_PARK_BVH 0   // the same for the BVH full-graph kernels without textures
+#endif
+#ifndef AKR_BVH_TILE
+#define AKR_BVH_TILE 1  // BVH kernels: 1 = the top of the tree in LDS (disect.h: TILE), as many nodes as launch_pt_pass finds room for
+#endif
+#ifndef AKR_PT_STRAGGLERS
+#define AKR_PT_STRAGGLERS 8  // BVH kernels: n > 0 = an intersection phase ends when at most 1/n of the lanes that entered it are still
+                             // tracing; those lanes keep their traversal and go on in the next phase (see k_pt_pass)
+#endif
+#ifndef AKR_PT_STRAGGLERS_TEX
+#define AKR_PT_STRAGGLERS_TEX 0  // the same for the BVH kernels of scenes with textures (measured separately)
+#endif
+#ifndef AKR_PT_PARK_TEX
+#define AKR_PT_PARK_TEX 1   // the same for the full-graph kernels of scenes with textures (exhaustive and BVH)
+#endif
+// LDS columns per lane (one word per slot, slot s of lane i at word s * 256 + i): cold path state parked while a vertex is shaded
+// (dpath.h: PARK), and a traversal carried over to the next intersection phase (pt_kernels.hip).
+constexpr uint32_t kParkSlots = 16, kParkSlotsNoDefer = 13;  // dpath.h: PK_*
+constexpr uint32_t kCarrySlots = 13;                         // pt_kernels.hip: a carried traversal
+// What a k_pt_pass launch keeps in LDS beyond traversal stacks, staged tables and graph values, by kernel instantiation
+// (BVH / force_diffuse / textured scene / conductor deferral): used by the launcher and by the host's staging decision.
+struct PtLdsPlan {
+    size_t recs_bytes, park_bytes, carry_bytes;
+    bool tile;
+};
+inline PtLdsPlan pt_lds_plan(bool bvh, bool fd, bool tex, bool defer, uint32_t n_tris) {
+    PtLdsPlan pl;
+    const bool recs_in_lds = !bvh && (fd ? AKR_WALK_FD : (tex ? 0 : AKR_WALK_FULL)) == 1;
+    const bool park = !fd && (tex ? AKR_PT_PARK_TEX != 0 : (bvh ? AKR_PT_PARK_BVH != 0 : AKR_PT_PARK_FULL != 0));
+    const bool strag = bvh && (tex ? AKR_PT_STRAGGLERS_TEX : AKR_PT_STRAGGLERS) > 0;
+    pl.recs_bytes = recs_in_lds ? (size_t)(n_tris + 2) * 48 : 0;
+    pl.park_bytes = park ? (size_t)(defer ? kParkSlots : kParkSlotsNoDefer) * 256 * 4 : 0;
+    pl.carry_bytes = strag ? (size_t)kCarrySlots * 256 * 4 : 0;
+    pl.tile = bvh && !tex && AKR_BVH_TILE != 0;
+    return pl;
+}
+// a workgroup's share of the CU's 160 KB: a quarter (four waves per SIMD), a third for the kernels of textured scenes (three)
+inline size_t pt_lds_budget(bool tex) { return (tex ? 53 : 40) * 1024; }
+
+// Launch counters (akr_pt_stats) are kStatStripes copies of 8 u64, a workgroup adding to copy blockIdx % kStatStripes: the wavefront
+// schedule flushes them once per wave and ITERATION (32 k waves x 7 atomics on seven addresses per k_wf_shade launch serialise at the
+// L2 -- measured: a large part of that kernel's time); the host sums the copies when it reads them.
+constexpr uint32_t kStatStripes = 256;
 // Everything one pass of the path tracer needs; passed by value as the kernel argument (lands in SGPRs).
 struct PtParams {
     DScene sc;

@@ -32,34 +32,7 @@ namespace akr {
 #ifndef AKR_PT_MIN_WAVES_BVH_TEX
 #define AKR_PT_MIN_WAVES_BVH_TEX 3  // BVH kernels of such a scene (399 -> 517)
 #endif
-#ifndef AKR_WALK_FD
-#define AKR_WALK_FD 1    // exhaustive pair walk of the force_diffuse kernel: where the records' coefficients sit (disect.h: WALK)
-#endif
-#ifndef AKR_WALK_FULL
-#define AKR_WALK_FULL 1  // the same for the full-graph exhaustive kernels of scenes without textures (TEX kernels keep the scalar walk)
-#endif
-#ifndef AKR_WALK_FULL_UNROLL
-#define AKR_WALK_FULL_UNROLL 1  // full-graph exhaustive kernels: two records per trip of the pair walk, as the force_diffuse kernel does
-#endif
-#ifndef AKR_PT_PARK_FULL
-#define AKR_PT_PARK_FULL 0  // exhaustive full-graph kernels without textures: cold path state in LDS while a vertex is shaded (dpath.h: PARK)
-#endif
-#ifndef AKR_PT_PARK_BVH
-#define AKR_PT_PARK_BVH 0   // the same for the BVH full-graph kernels without textures
-#endif
-#ifndef AKR_BVH_TILE
-#define AKR_BVH_TILE 1  // BVH kernels: 1 = the top of the tree in LDS (disect.h: TILE), as many nodes as launch_pt_pass finds room for
-#endif
-#ifndef AKR_PT_STRAGGLERS
-#define AKR_PT_STRAGGLERS 8  // BVH kernels: n > 0 = an intersection phase ends when at most 1/n of the lanes that entered it are still
-                             // tracing; those lanes keep their traversal and go on in the next phase (see k_pt_pass)
-#endif
-#ifndef AKR_PT_STRAGGLERS_TEX
-#define AKR_PT_STRAGGLERS_TEX 0  // the same for the BVH kernels of scenes with textures (measured separately)
-#endif
-#ifndef AKR_PT_PARK_TEX
-#define AKR_PT_PARK_TEX 1   // the same for the full-graph kernels of scenes with textures (exhaustive and BVH)
-#endif
+// (AKR_WALK_*, AKR_PT_PARK_*, AKR_BVH_TILE, AKR_PT_STRAGGLERS*: kernels.h -- the host sizes the launch's LDS from them too)
 #ifndef AKR_PT_MERGED_RAYS
 #define AKR_PT_MERGED_RAYS 1  // BVH path: a lane starts its shadow ray the moment its closest-hit ray is done (one loop)
 #endif
@@ -391,28 +364,25 @@ hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream) {
     const bool fd = p.force_diffuse != 0, tex = p.sc.tex.nodes != nullptr;
     const bool bvh = p.sc.bvh_nodes != nullptr;
     size_t lds;
-    // exhaustive kernels whose pair walk reads the records from LDS (WALK 1) keep them behind the staged tables
-    const bool recs_in_lds = !bvh && (fd ? AKR_WALK_FD : (tex ? 0 : AKR_WALK_FULL)) == 1;
-    const bool strag = bvh && (tex ? AKR_PT_STRAGGLERS_TEX : AKR_PT_STRAGGLERS) > 0;
-    const bool park = !fd && (tex ? AKR_PT_PARK_TEX != 0 : (bvh ? AKR_PT_PARK_BVH != 0 : AKR_PT_PARK_FULL != 0));
-    size_t base = (bvh ? p.sc.bvh_stack_depth * 256 * 4 : 0) + p.stage_total + (recs_in_lds ? (p.sc.n_tris + 2) * 48 : 0);
+    // dynamic LDS of the launch: [traversal stacks][staged tables][triangle records (WALK 1)][node tile][park columns][carry columns][graph values]
+    const PtLdsPlan plan = pt_lds_plan(bvh, fd, tex, p.defer_metal != 0, p.sc.n_tris);
+    size_t base = (bvh ? p.sc.bvh_stack_depth * 256 * 4 : 0) + p.stage_total + plan.recs_bytes;
     base = (base + 15) & ~(size_t)15;
     PtParams pp = p;
     pp.tile_offset = (uint32_t)(base / 4);
     pp.sc.bvh_tile_nodes = 0;
-    if (bvh && !tex && AKR_BVH_TILE) {
-        // what is left of a quarter of the CU's LDS (four workgroups per CU = four waves per SIMD) after the launch's other blocks
-        size_t other = base + (park ? (p.defer_metal ? kParkSlots : kParkSlotsNoDefer) * 256 * 4 : 0) + (strag ? kCarrySlots * 256 * 4 : 0) +
-                       (tex ? (size_t)p.tex_slots * kTexValStride * sizeof(TexVal) : 0);
-        const size_t budget = (tex ? 53 : 40) * 1024 - 256;  // TEX kernels run three workgroups per CU (AKR_PT_MIN_WAVES_BVH_TEX)
+    if (plan.tile) {
+        // what is left of the workgroup's share of the CU's LDS after the launch's other blocks
+        const size_t other = base + plan.park_bytes + plan.carry_bytes + (tex ? (size_t)p.tex_slots * kTexValStride * sizeof(TexVal) : 0);
+        const size_t budget = pt_lds_budget(tex) - 256;
         if (other < budget) pp.sc.bvh_tile_nodes = (uint32_t)std::min<size_t>({(budget - other) / 80, (size_t)p.sc.n_nodes, (size_t)1024});
         base += (size_t)pp.sc.bvh_tile_nodes * 80;
         base = (base + 15) & ~(size_t)15;
     }
     pp.park_offset = (uint32_t)(base / 4);
-    if (park) base += (p.defer_metal ? kParkSlots : kParkSlotsNoDefer) * 256 * 4;
+    base += plan.park_bytes;
     pp.carry_offset = (uint32_t)(base / 4);
-    if (strag) base += kCarrySlots * 256 * 4;
+    base += plan.carry_bytes;
     const PtParams q = with_tex_slots(pp, base, lds);
     const bool stage = p.stage_total != 0;
 #define AKR_LAUNCH2(B, F, T, S, D)                                                                                       \

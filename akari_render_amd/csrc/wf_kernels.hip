@@ -61,26 +61,33 @@ AKR_D void wf_load(const WfBuffers& wf, uint32_t slot, PathRegs& r) {
     r.c_samples = r.c_closest = r.c_shadow = r.c_shaded = 0;
 }
 
-// wave64 stream compaction: every lane with `want` gets a distinct index into the queue; one atomicAdd per wave
-AKR_D uint32_t wave_enqueue_index(bool want, uint32_t* counter) {
-    const uint64_t mask = __builtin_amdgcn_ballot_w64(want);
-    if (mask == 0) return 0;
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t base = 0;
-    if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(mask));
-    base = __shfl(base, __builtin_ctzll(mask), 64);
-    return base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-}
-
+// Workgroup-wide stream compaction: every lane with a ray gets a distinct index into the queue of its kind; the four waves'
+// counts meet in LDS and ONE lane per counter adds the workgroup's total (three atomics per workgroup instead of three per wave:
+// queue heads and the active counter are single addresses, and their atomics serialise at the L2). Queue order = slot order
+// within the workgroup. Must be called by all 256 threads.
 AKR_D void wf_enqueue(const WfBuffers& wf, uint32_t q, uint32_t slot, PathRegs& r) {
     // closest-hit rays and shadow rays go to separate queues so that waves of the trace kernel are homogeneous
-    bool want_c = r.active && r.has_ray, want_s = r.active && r.has_shadow;
-    uint32_t ic = wave_enqueue_index(want_c, &wf.qcount[2 * q + 0]);
-    if (want_c) { wf.queue_closest[q][ic] = slot; r.c_closest++; }
-    uint32_t is = wave_enqueue_index(want_s, &wf.qcount[2 * q + 1]);
-    if (want_s) { wf.queue_shadow[q][is] = slot; r.c_shadow++; }
-    uint32_t na = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(r.active));
-    if ((threadIdx.x & 63u) == 0 && na) atomicAdd(wf.n_active, na);
+    __shared__ uint32_t sh_cnt[4][3], sh_base[3];
+    const bool want_c = r.active && r.has_ray, want_s = r.active && r.has_shadow;
+    const uint64_t mc = __builtin_amdgcn_ballot_w64(want_c), ms = __builtin_amdgcn_ballot_w64(want_s), ma = __builtin_amdgcn_ballot_w64(r.active);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        sh_cnt[wave][0] = (uint32_t)__builtin_popcountll(mc);
+        sh_cnt[wave][1] = (uint32_t)__builtin_popcountll(ms);
+        sh_cnt[wave][2] = (uint32_t)__builtin_popcountll(ma);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const uint32_t tot = sh_cnt[0][threadIdx.x] + sh_cnt[1][threadIdx.x] + sh_cnt[2][threadIdx.x] + sh_cnt[3][threadIdx.x];
+        uint32_t* counter = threadIdx.x == 2 ? wf.n_active : &wf.qcount[2 * q + threadIdx.x];
+        sh_base[threadIdx.x] = tot ? atomicAdd(counter, tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t bc = sh_base[0], bs = sh_base[1];
+    for (uint32_t k = 0; k < wave; k++) { bc += sh_cnt[k][0]; bs += sh_cnt[k][1]; }
+    const uint64_t below = (1ull << lane) - 1ull;
+    if (want_c) { wf.queue_closest[q][bc + (uint32_t)__builtin_popcountll(mc & below)] = slot; r.c_closest++; }
+    if (want_s) { wf.queue_shadow[q][bs + (uint32_t)__builtin_popcountll(ms & below)] = slot; r.c_shadow++; }
 }
 
 template <bool PMJ>
@@ -98,8 +105,11 @@ __global__ __launch_bounds__(256) void k_wf_init(const PtParams p, const WfBuffe
     flush_counters(p, r, TraceCounters{0, 0, 0}, true);
 }
 
+#ifndef AKR_WF_SHADE_WAVES
+#define AKR_WF_SHADE_WAVES 1  // waves per SIMD the shade kernel's register allocation must leave room for (1 = whatever it needs)
+#endif
 template <bool TEX, bool PMJ>
-__global__ __launch_bounds__(256) void k_wf_shade(const PtParams p, const WfBuffers wf, uint32_t q_out) {
+__global__ __launch_bounds__(256, TEX ? 1 : AKR_WF_SHADE_WAVES) void k_wf_shade(const PtParams p, const WfBuffers wf, uint32_t q_out) {
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     PathRegs r;
     r.active = false; r.has_ray = false; r.has_shadow = false;
@@ -140,27 +150,36 @@ __global__ __launch_bounds__(256) void k_wf_trace(const PtParams p, const WfBuff
     TraceCounters cnt{0, 0, 0};
     bool has = false, exhausted = false, any = false;
     uint32_t slot = 0;
+    constexpr uint32_t kWfChunk = 128;
+    uint32_t c_next = 0, c_end = 0;  // the wave's claimed range of ray ids
     Trav s;
     trav_begin(s, mk3(0, 0, 0), mk3(0, 0, 1), 0.0f, -1.0f, kInvalid, kInvalid);  // idle: tmax < tmin
     for (;;) {
-        if (!exhausted) {  // refill idle lanes from the queue head
+        // Refill idle lanes from the queue. A wave claims kWfChunk consecutive ray ids with ONE atomic and hands them to its idle
+        // lanes by ballot + prefix count until the chunk is used up (one atomic per refill -- 150 k of them on one address per
+        // launch -- kept the L2's atomic unit busier than the traversal kept the CUs).
+        for (int attempt = 0; attempt < 2 && !exhausted; attempt++) {
             const uint64_t idle = __builtin_amdgcn_ballot_w64(!has);
-            if (idle != 0) {
-                const uint32_t n = (uint32_t)__builtin_popcountll(idle);
+            if (idle == 0) break;
+            if (c_next >= c_end) {  // (wave-uniform)
                 uint32_t base = 0;
-                if (lane == (uint32_t)__builtin_ctzll(idle)) base = atomicAdd(wf.qhead, n);
-                base = __shfl(base, __builtin_ctzll(idle), 64);
-                const uint32_t my = base + (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
-                if (!has && my < n_total) {
-                    any = my >= n_closest;
-                    slot = any ? wf.queue_shadow[q_in][my - n_closest] : wf.queue_closest[q_in][my];
-                    float4 a = any ? wf.sh_o[slot] : wf.ray_o[slot];
-                    float4 b = any ? wf.sh_d[slot] : wf.ray_d[slot];
-                    trav_begin(s, xyz(a), xyz(b), 0.0f, any ? b.w : 1e20f, f2u(a.w), any ? f2u(wf.sh_c[slot].w) : kInvalid);
-                    has = true;
-                }
-                if (base + n >= n_total) exhausted = true;
+                if (lane == 0) base = atomicAdd(wf.qhead, kWfChunk);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                c_next = base;
+                c_end = base + kWfChunk < n_total ? base + kWfChunk : n_total;
+                if (base >= n_total) { exhausted = true; break; }
             }
+            const uint32_t my = c_next + (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
+            if (!has && my < c_end) {
+                any = my >= n_closest;
+                slot = any ? wf.queue_shadow[q_in][my - n_closest] : wf.queue_closest[q_in][my];
+                float4 a = any ? wf.sh_o[slot] : wf.ray_o[slot];
+                float4 b = any ? wf.sh_d[slot] : wf.ray_d[slot];
+                trav_begin(s, xyz(a), xyz(b), 0.0f, any ? b.w : 1e20f, f2u(a.w), any ? f2u(wf.sh_c[slot].w) : kInvalid);
+                has = true;
+            }
+            const uint32_t n = (uint32_t)__builtin_popcountll(idle);
+            c_next = c_next + n < c_end ? c_next + n : c_end;
         }
         if (__builtin_amdgcn_ballot_w64(has) == 0) break;
         for (;;) {
@@ -181,11 +200,12 @@ __global__ __launch_bounds__(256) void k_wf_trace(const PtParams p, const WfBuff
     }
     // traversal counters
     if (p.counters != nullptr) {
+        uint64_t* const ctr = p.counters + 8u * (blockIdx.x % kStatStripes);
         uint32_t nn = wave_sum_u32(cnt.nodes), nt = wave_sum_u32(cnt.tris), ov = wave_sum_u32(cnt.overflow);
         if (lane == 0) {
-            if (nn) atomicAdd((unsigned long long*)&p.counters[4], (unsigned long long)nn);
-            if (nt) atomicAdd((unsigned long long*)&p.counters[5], (unsigned long long)nt);
-            if (ov) atomicAdd((unsigned long long*)&p.counters[6], (unsigned long long)ov);
+            if (nn) atomicAdd((unsigned long long*)&ctr[4], (unsigned long long)nn);
+            if (nt) atomicAdd((unsigned long long*)&ctr[5], (unsigned long long)nt);
+            if (ov) atomicAdd((unsigned long long*)&ctr[6], (unsigned long long)ov);
         }
     }
 }
