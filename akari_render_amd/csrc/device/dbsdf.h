@@ -434,8 +434,11 @@ struct WoAlbedo {
 AKR_HD float avg3(vec3 e) { return ((e.x + e.y) + e.z) / 3.0f; }
 
 // The Principled closure tree of principled.rs:133-202 (inside the wrapper), evaluated for (wo, wi).
-AKR_HD BsdfEval principled_eval(const DMaterial& m, const float* __restrict__ table, vec3 wo, vec3 wi, const WoAlbedo* wc = nullptr) {
-    const uint32_t fl = m.flags;
+// simple (a compile-time constant where it matters): the scene has no coat, no transmission, no normal map and no glass material
+// (host: scene_is_simple), so those flags are known to be clear -- the same branches are skipped as at run time, but their code
+// is not in the kernel. The reference's kernel is traced from the scene's shader graphs and holds only the closures they use too.
+AKR_HD BsdfEval principled_eval(const DMaterial& m, const float* __restrict__ table, vec3 wo, vec3 wi, const WoAlbedo* wc = nullptr, bool simple = false) {
+    const uint32_t fl = simple ? (m.flags & ~(uint32_t)(MF_COAT | MF_EVAL_DIEL | MF_NORMAL_MAP)) : m.flags;
     BsdfEval b2{mk3(0, 0, 0), 0.0f};
     if (fl & MF_EVAL_BASE) {
         // Mix(transmission){diffuse, dielectric}
@@ -495,15 +498,16 @@ AKR_HD bool sample_lobe(LobeKind lobe, vec2 alpha, float eta, vec3 wo, vec2 u, v
 }
 // which lobe, which alpha, and -- for the roughness AOV -- whether it is the coat
 AKR_HD void principled_select_lobe(const DMaterial& m, const float* __restrict__ table, vec3 wo, float u, LobeKind& lobe, vec2& alpha, bool& coat,
-                                   const WoAlbedo* wc = nullptr) {
-    const uint32_t fl = m.flags;
+                                   const WoAlbedo* wc = nullptr, bool simple = false) {
+    const uint32_t fl = simple ? (m.flags & ~(uint32_t)(MF_COAT | MF_EVAL_DIEL | MF_NORMAL_MAP)) : m.flags;
     lobe = LOBE_DIFFUSE;
     alpha = m.alpha;
     coat = false;
-    float r;
+    float r = u;
     // Coated{coat | Scaled{Emissive{...}}}: top iff u < avg(E_coat(wo))
+    // (simple: the probability is 0 -- never taken, and the remapped number is (u - 0) / (1 - 0) = u exactly)
     float p_coat = (fl & MF_COAT) ? avg3(wc ? etop_coat_of(m, wc->coat) : etop_coat(m, table, wo)) : 0.0f;
-    if (weighted_choice2_and_remap(p_coat, u, r)) {
+    if (!simple && weighted_choice2_and_remap(p_coat, u, r)) {
         lobe = LOBE_REFLECT;
         alpha = m.coat_alpha;
         coat = true;
@@ -520,8 +524,8 @@ AKR_HD void principled_select_lobe(const DMaterial& m, const float* __restrict__
                 lobe = LOBE_REFLECT;
             } else {
                 u = r;
-                // Mix(transmission): b (dielectric) iff u < transmission
-                if (weighted_choice2_and_remap(m.transmission, u, r)) {
+                // Mix(transmission): b (dielectric) iff u < transmission  (simple: transmission is exactly 0)
+                if (!simple && weighted_choice2_and_remap(m.transmission, u, r)) {
                     u = r;
                     // Addictive{transmission, reflection}: b (reflection) iff u < fr_dielectric(cos wo, eta)
                     float frac = fr_dielectric(cos_theta(wo), m.eta);
@@ -533,11 +537,13 @@ AKR_HD void principled_select_lobe(const DMaterial& m, const float* __restrict__
         }
     }
 }
-AKR_HD bool principled_sample_wi(const DMaterial& m, const float* __restrict__ table, vec3 wo, float u, vec2 u2, vec3& wi, const WoAlbedo* wc = nullptr) {
+AKR_HD bool principled_sample_wi(const DMaterial& m, const float* __restrict__ table, vec3 wo, float u, vec2 u2, vec3& wi, const WoAlbedo* wc = nullptr,
+                                 bool simple = false) {
     LobeKind lobe;
     vec2 alpha;
     bool coat;
-    principled_select_lobe(m, table, wo, u, lobe, alpha, coat, wc);
+    principled_select_lobe(m, table, wo, u, lobe, alpha, coat, wc, simple);
+    if (simple && lobe == LOBE_TRANSMIT) lobe = LOBE_DIFFUSE;  // unreachable: tells the compiler to drop the refraction code
     return sample_lobe(lobe, alpha, m.eta, wo, u2, wi);
 }
 
@@ -562,6 +568,7 @@ struct ShadePoint {
     Frame nm_frame_;    // inner (normal-map) frame in local space; identity when !MF_NORMAL_MAP   (not lean)
     vec3 ng_local_;     // frame.to_local(ng)  (normal_map(): ng of the inner SurfaceClosure)       (not lean)
     bool lean;
+    bool simple;        // see principled_eval
     bool force_diffuse;
     bool wo_cached;     // wo_albedo holds the table values of the vertex's outgoing direction (shade_point_cache_wo)
     WoAlbedo wo_albedo;
@@ -578,15 +585,16 @@ AKR_HD Frame nm_frame_compute(const Frame& frame, const DMaterial& m) {
 }
 AKR_HD Frame sp_nm_frame(const ShadePoint& sp, const DMaterial& m) {
     if (!sp.lean) return sp.nm_frame_;
-    if (!sp.force_diffuse && m.kind == MAT_PRINCIPLED && (m.flags & MF_NORMAL_MAP)) return nm_frame_compute(sp.frame, m);
+    if (!sp.simple && !sp.force_diffuse && m.kind == MAT_PRINCIPLED && (m.flags & MF_NORMAL_MAP)) return nm_frame_compute(sp.frame, m);
     return Frame{mk3(0, 0, 1), mk3(1, 0, 0), mk3(0, 1, 0)};
 }
 AKR_HD vec3 sp_ng_local(const ShadePoint& sp) { return sp.lean ? to_local(sp.frame, sp.ng) : sp.ng_local_; }
 
-AKR_HD void shade_point_init(ShadePoint& sp, const DMaterial& m, Frame frame, vec3 ng, bool force_diffuse, bool lean = false) {
+AKR_HD void shade_point_init(ShadePoint& sp, const DMaterial& m, Frame frame, vec3 ng, bool force_diffuse, bool lean = false, bool simple = false) {
     sp.frame = frame;
     sp.ng = ng;
     sp.lean = lean;
+    sp.simple = simple;
     sp.force_diffuse = force_diffuse;
     sp.wo_cached = false;
     sp.wo_albedo = WoAlbedo{0.0f, 0.0f};
@@ -594,7 +602,7 @@ AKR_HD void shade_point_init(ShadePoint& sp, const DMaterial& m, Frame frame, ve
     sp.ng_local_ = mk3(0, 0, 0);
     if (!lean) {
         sp.ng_local_ = to_local(frame, ng);
-        if (!force_diffuse && m.kind == MAT_PRINCIPLED && (m.flags & MF_NORMAL_MAP)) sp.nm_frame_ = nm_frame_compute(frame, m);
+        if (!simple && !force_diffuse && m.kind == MAT_PRINCIPLED && (m.flags & MF_NORMAL_MAP)) sp.nm_frame_ = nm_frame_compute(frame, m);
     }
 }
 
@@ -603,9 +611,9 @@ AKR_HD void shade_point_init(ShadePoint& sp, const DMaterial& m, Frame frame, ve
 AKR_HD void shade_point_cache_wo(ShadePoint& sp, const DMaterial& m, const float* __restrict__ table, vec3 wo) {
     if (sp.force_diffuse || m.kind != MAT_PRINCIPLED) return;
     vec3 lo = to_local(sp.frame, wo);
-    if (m.flags & MF_NORMAL_MAP) lo = to_local(sp_nm_frame(sp, m), lo);
+    if (!sp.simple && (m.flags & MF_NORMAL_MAP)) lo = to_local(sp_nm_frame(sp, m), lo);
     if (m.flags & MF_SPEC) sp.wo_albedo.spec = albedo_spec(m, table, lo);
-    if (m.flags & MF_COAT) sp.wo_albedo.coat = albedo_coat(m, table, lo);
+    if (!sp.simple && (m.flags & MF_COAT)) sp.wo_albedo.coat = albedo_coat(m, table, lo);
     sp.wo_cached = true;
 }
 
@@ -620,7 +628,7 @@ AKR_HD BsdfEval shade_evaluate(const ShadePoint& sp, const DMaterial& m, const f
     }
     switch (m.kind) {
         case MAT_PRINCIPLED: {
-            if (m.flags & MF_NORMAL_MAP) {
+            if (!sp.simple && (m.flags & MF_NORMAL_MAP)) {
                 const Frame nf = sp_nm_frame(sp, m);
                 if (!check_wo_wi_valid(nf.n, sp_ng_local(sp), lo, li)) return zero;
                 lo = to_local(nf, lo);
@@ -628,10 +636,10 @@ AKR_HD BsdfEval shade_evaluate(const ShadePoint& sp, const DMaterial& m, const f
             } else {
                 if (!check_wo_wi_valid(mk3(0, 0, 1), sp_ng_local(sp), lo, li)) return zero;
             }
-            return principled_eval(m, table, lo, li, sp.wo_cached ? &sp.wo_albedo : nullptr);
+            return principled_eval(m, table, lo, li, sp.wo_cached ? &sp.wo_albedo : nullptr, sp.simple);
         }
         case MAT_DIFFUSE: return eval_diffuse(m.diffuse_refl, lo, li);
-        case MAT_GLASS: return eval_dielectric(m.color, m.color, m.eta, m.alpha, lo, li);
+        case MAT_GLASS: return sp.simple ? zero : eval_dielectric(m.color, m.color, m.eta, m.alpha, lo, li);
         default: return zero;  // Emission node: EmissiveSurface{inner: None}
     }
 }
@@ -654,17 +662,18 @@ AKR_HD BsdfSample shade_sample(const ShadePoint& sp, const DMaterial& m, const f
     } else {
         switch (m.kind) {
             case MAT_PRINCIPLED: {
-                const bool nm = (m.flags & MF_NORMAL_MAP) != 0;
+                const bool nm = !sp.simple && (m.flags & MF_NORMAL_MAP) != 0;
                 const Frame nf = nm ? sp_nm_frame(sp, m) : Frame{mk3(0, 0, 1), mk3(1, 0, 0), mk3(0, 1, 0)};
                 vec3 lo2 = nm ? to_local(nf, lo) : lo;
                 vec3 w2;
-                valid = principled_sample_wi(m, table, lo2, u_select, u_sample, w2, sp.wo_cached ? &sp.wo_albedo : nullptr);
+                valid = principled_sample_wi(m, table, lo2, u_select, u_sample, w2, sp.wo_cached ? &sp.wo_albedo : nullptr, sp.simple);
                 wl = nm ? to_world(nf, w2) : w2;
                 valid = valid & check_wo_wi_valid(nf.n, sp_ng_local(sp), lo, wl);
                 break;
             }
             case MAT_DIFFUSE: valid = sample_lobe(LOBE_DIFFUSE, mk2(0, 0), 1.0f, lo, u_sample, wl); break;
             case MAT_GLASS: {
+                if (sp.simple) { valid = false; break; }  // no glass material in a simple scene
                 float frac = fr_dielectric(cos_theta(lo), m.eta), r;
                 LobeKind lobe = weighted_choice2_and_remap(frac, u_select, r) ? LOBE_REFLECT : LOBE_TRANSMIT;
                 valid = sample_lobe(lobe, m.alpha, m.eta, lo, u_sample, wl);

@@ -439,6 +439,17 @@ static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pas
             p.stage_total = (uint32_t)std::max<size_t>(total, 16);
         }
     }
+    {   // SIMPLE instantiations (dbsdf.h principled_eval): the reference traces its kernel from the scene's shader graphs, so a scene
+        // without coat / transmission / normal map / glass runs a kernel without that code there too. The conditions are on the
+        // folded VALUES (coat_weight and transmission exactly 0), which is what makes dropping the branches exact.
+        const CompiledScene& cs = s->cs;
+        bool simple = !cs.has_textures;
+        for (const DMaterial& m : cs.materials) {
+            if (m.kind == MAT_GLASS) simple = false;
+            if (m.kind == MAT_PRINCIPLED && ((m.flags & (MF_COAT | MF_EVAL_DIEL | MF_NORMAL_MAP)) != 0 || m.transmission != 0.0f || m.coat_weight != 0.0f)) simple = false;
+        }
+        p.simple_scene = (simple && tuning().simple_kernels) ? 1u : 0u;
+    }
     {   // conductor hits on even iterations only (pt_kernels.hip): pays when SOME materials have the lobe and most hits do not
         const CompiledScene& cs = s->cs;
         size_t n_metal = 0, n_surface = 0;

@@ -731,6 +731,7 @@ void tuning_init_locked() {
     g_tuning.bvh_balanced = flag("AKR_BVH_BALANCED");
     if (const char* e = std::getenv("AKR_PT_DEFER_METAL")) g_tuning.defer_metal = std::atoi(e);
     if (const char* e = std::getenv("AKR_PT_MODE")) g_tuning.wavefront = std::string(e) == "wavefront" ? 1 : 0;
+    if (const char* e = std::getenv("AKR_PT_SIMPLE")) g_tuning.simple_kernels = std::atoi(e) != 0 ? 1 : 0;
 }
 int* tuning_field(const char* name) {
     const std::string n = name ? name : "";
@@ -738,6 +739,7 @@ int* tuning_field(const char* name) {
     if (n == "bvh_balanced") return &g_tuning.bvh_balanced;
     if (n == "defer_metal") return &g_tuning.defer_metal;
     if (n == "wavefront") return &g_tuning.wavefront;
+    if (n == "simple_kernels") return &g_tuning.simple_kernels;
     return nullptr;
 }
 }  // namespace

@@ -88,8 +88,9 @@ void build_alias_table(const std::vector<float>& weights, std::vector<AliasEntry
 //   bvh_balanced AKR_BVH_BALANCED=1       the median-split fallback builder instead of SAH
 //   defer_metal  AKR_PT_DEFER_METAL=<m>   -1 = the library decides (default); 0 = off; m > 0 = iterations with (i & m) != 0 put conductor hits off
 //   wavefront    AKR_PT_MODE=wavefront    1 = sessions on BVH scenes use the wavefront schedule (wf_kernels.hip) instead of the megakernel
+//   simple_kernels AKR_PT_SIMPLE=0        0 = never use the SIMPLE instantiations (scenes without coat / transmission / normal map / glass)
 struct TuningOptions {
-    int force_bvh = 0, bvh_balanced = 0, defer_metal = -1, wavefront = 0;
+    int force_bvh = 0, bvh_balanced = 0, defer_metal = -1, wavefront = 0, simple_kernels = 1;
 };
 TuningOptions tuning();                          // a snapshot (thread-safe)
 bool tuning_set(const char* name, int value);    // false: unknown name

@@ -98,6 +98,7 @@ struct PtParams {
     // ... then the texture tables of a TEX scene: pruned node lists, image headers, raw material inputs (12 entries in all).
     uint32_t stage_bytes[13];  // [12]: the GGX albedo table (full-graph exhaustive kernels)
     uint32_t stage_total;
+    uint32_t simple_scene;   // no coat, no transmission, no normal map, no glass material, no textures: the full-graph kernels without that code
     uint32_t defer_metal;    // exhaustive path: shade hits on materials with a conductor lobe on even iterations only (pt_kernels.hip)
     uint32_t tex_slots;      // TEX scenes: value slots per lane of the graph evaluation (LDS, after the launch's other blocks)
     uint32_t tile_offset;    // BVH kernels with a node tile (disect.h: TILE): word offset of the tile; its size is sc.bvh_tile_nodes

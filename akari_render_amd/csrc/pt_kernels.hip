@@ -36,7 +36,8 @@ namespace akr {
 #ifndef AKR_PT_MERGED_RAYS
 #define AKR_PT_MERGED_RAYS 1  // BVH path: a lane starts its shadow ray the moment its closest-hit ray is done (one loop)
 #endif
-template <bool BVH, bool FD, bool TEX, bool PMJ, bool STAGE, bool DEFER>
+// SIMPLE (full-graph kernels of scenes without textures): PtParams.simple_scene, see dbsdf.h principled_eval
+template <bool BVH, bool FD, bool TEX, bool PMJ, bool STAGE, bool DEFER, bool SIMPLE = false>
 __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT_MIN_WAVES_BVH)
                                    : (FD ? AKR_PT_MIN_WAVES_FD : (TEX ? AKR_PT_MIN_WAVES_TEX : AKR_PT_MIN_WAVES))) void k_pt_pass(const PtParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: kBvhStackDepth x 256 words; else: staged tables
@@ -204,8 +205,8 @@ __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT
             }
             if (STRAG > 0 && r.carry) {
                 // still tracing: nothing to resolve or shade yet
-            } else if (PARK) path_step<FD ? 1 : 0, TEX, PMJ, DEFER ? 1 : 2>(q, r, hit, found, occluded, 0, 0, 0, park);
-            else path_step<FD ? 1 : 0, TEX, PMJ>(q, r, hit, found, occluded, pix, sx, sy);
+            } else if (PARK) path_step<FD ? 1 : 0, TEX, PMJ, DEFER ? 1 : 2, SIMPLE>(q, r, hit, found, occluded, 0, 0, 0, park);
+            else path_step<FD ? 1 : 0, TEX, PMJ, 0, SIMPLE>(q, r, hit, found, occluded, pix, sx, sy);
         }
     }
     flush_counters(p, r, tc.cnt, BVH);
@@ -385,10 +386,16 @@ hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream) {
     base += plan.carry_bytes;
     const PtParams q = with_tex_slots(pp, base, lds);
     const bool stage = p.stage_total != 0;
-#define AKR_LAUNCH2(B, F, T, S, D)                                                                                       \
-    {                                                                                                                  \
-        if (p.sampler) hipLaunchKernelGGL((k_pt_pass<B, F, T, true, S, D>), dim3(blocks), dim3(256), lds, stream, q);   \
-        else hipLaunchKernelGGL((k_pt_pass<B, F, T, false, S, D>), dim3(blocks), dim3(256), lds, stream, q);           \
+#define AKR_LAUNCH3(B, F, T, S, D, X)                                                                                      \
+    {                                                                                                                     \
+        if (p.sampler) hipLaunchKernelGGL((k_pt_pass<B, F, T, true, S, D, X>), dim3(blocks), dim3(256), lds, stream, q);   \
+        else hipLaunchKernelGGL((k_pt_pass<B, F, T, false, S, D, X>), dim3(blocks), dim3(256), lds, stream, q);           \
+    }
+    // the SIMPLE instantiations exist for the full-graph kernels of scenes without textures only
+#define AKR_LAUNCH2(B, F, T, S, D)                                           \
+    {                                                                        \
+        if (!F && !T && p.simple_scene) AKR_LAUNCH3(B, F, T, S, D, (!F && !T)) \
+        else AKR_LAUNCH3(B, F, T, S, D, false)                               \
     }
 #define AKR_LAUNCH(B, F, T)                                                  \
     {                                                                        \
@@ -403,6 +410,7 @@ hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream) {
         if (tex) { if (fd) AKR_LAUNCH(false, true, true) else AKR_LAUNCH(false, false, true) }
         else { if (fd) AKR_LAUNCH(false, true, false) else AKR_LAUNCH(false, false, false) }
     }
+#undef AKR_LAUNCH3
 #undef AKR_LAUNCH2
 #undef AKR_LAUNCH
     return hipGetLastError();

@@ -534,6 +534,7 @@ AKR_API const char *akr_version(void);
  *   "bvh_balanced" (AKR_BVH_BALANCED=1)     median-split fallback builder instead of binned SAH
  *   "defer_metal"  (AKR_PT_DEFER_METAL=m)   -1 the library decides; 0 off; m > 0: conductor hits shaded when (iteration & m) == 0
  *   "wavefront"    (AKR_PT_MODE=wavefront)  1 = pt sessions on BVH scenes run the wavefront schedule
+ *   "simple_kernels" (AKR_PT_SIMPLE=0)      0 = never pick the kernels specialised for scenes without coat / transmission / normal map / glass
  * Unknown names fail with AKR_ERR_INVALID_ARGUMENT. */
 AKR_API int32_t akr_option_set(const char *name, int32_t value);
 AKR_API int32_t akr_option_get(const char *name, int32_t *value);
