@@ -1,4 +1,4 @@
-// disect.h -- ray/triangle test and the two scene intersectors (exhaustive for tiny scenes, BVH4 otherwise).
+// disect.h -- ray/triangle test and the two scene intersectors (exhaustive for tiny scenes, 8-wide compressed BVH otherwise).
 //
 // Replaces LuisaCompute's rtx::Accel ray queries (crates/akari_render/src/scene.rs:88-185). Semantics kept from
 // the reference: a candidate is rejected when its (inst, prim) equals one of the ray's two exclusion slots

@@ -484,7 +484,8 @@ typedef struct {
     uint32_t spp, max_depth, rr_depth, spp_per_pass;        /* mcmc::Config::default = pt defaults: 256, 7, 5, 64 (mcmc.rs:60-79) */
     uint32_t use_nee;                                       /* 1 */
     uint32_t mcmc_depth;                                    /* 0xffffffff = None = max_depth */
-    uint32_t n_chains, n_bootstrap;                         /* 512, 100000 */
+    uint32_t n_chains, n_bootstrap;                         /* 512, 100000 (the reference's defaults). One lane per chain: 512 chains are 8 waves
+                                                             * on a chip with 1024 SIMDs (2 M mutations/s); a GPU wants n_chains >= 1e5 (262144: 380 M/s) */
     int32_t direct_spp;                                     /* 64; 0 = no direct pass but indirect-only chains; < 0 = chains render everything */
     uint32_t exponential_mutation;                          /* Method::Kelemen (mcmc.rs:10-32): 1 */
     float small_sigma, large_step_prob, image_mutation_prob;/* 0.01, 0.1, 0 */

@@ -6,7 +6,7 @@
 set -u
 CFG=${1:-c2}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/pmc_bench_$CFG
+OUT=gpurun_out/r3_pmc_bench_$CFG
 rm -rf $OUT; mkdir -p $OUT
 ARGS="--config $CFG --steps 1 --warmup 0 --also none --no-cpu-baseline"
 i=0
@@ -54,8 +54,11 @@ s = {"config": cfg, "kernel": kernel, "csrc_hash": _bench.csrc_hash(), "bench_ar
      "source": "tools/pmc_bench.sh " + cfg + ": rocprofv3 --kernel-trace --pmc <one set per pass> -- python bench.py $ARGS; hbm = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (KiB units, gfx950 read correction); valu_busy = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)"}
 if cfg == "c4":
     del s["hbm_bytes_per_launch"]  # traffic scales with the rays traced: bench.py multiplies bytes per sample by its own launch size
-s["binding_limiter"] = ("VALU issue (the 36-triangle walk and the shading run from SGPRs / LDS; HBM sees only sampler states + film)" if cfg != "c4"
-                        else "latency of dependent node / triangle fetches at 4 waves per SIMD, with fabric reads at about half of peak")
+s["binding_limiter"] = ("VALU issue (the 36-triangle walk and the shading run from LDS / registers; HBM sees only sampler states + film)" if cfg != "c4"
+                        else "the memory system under dependent 80-byte node / 64-byte triangle gathers: the wavefront schedule's traversal-only kernel at 7 waves per SIMD "
+                             "reaches the same rays/s as this kernel (DESIGN.md section 4)")
+s["fabric_read_bytes_per_sample"] = 2.0 * c["FETCH_SIZE"] * 1024.0 / samples
+s["wave_cycle_shares"] = {"issuing": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], "waitcnt": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], "issue_stall": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]}
 json.dump(s, open(out + "/summary.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in s.items() if k != "counters"}, indent=1))
 PY

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Round-3 closing measurements on one box: tests, randomised soak, PMC summaries of the three bench configurations (stamped with the
+# hash of the library sources), the rocprofv3 kernel statistics of the driver's bench command, the bench line itself, shard balance,
+# textured-room numbers. Everything lands in gpurun_out/r3_final/; the summaries are then copied to profiles/.
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r3_final; rm -rf $O; mkdir -p $O
+timeout 1200 python -m pytest tests -x -q -m gpu > $O/gputest.log 2>&1; echo "tests rc=$? $(tail -1 $O/gputest.log)"
+for MODE in "800 100000" "300 200000 big" "400 300000 tex" "300 400000 wavefront" "300 500000 shard" "200 600000 gpt" "150 700000 aov"; do
+  timeout 400 python tools/soak.py $MODE 2>&1 | grep -E "MISMATCH|cases from seed|rror" | tail -3 | sed "s/^/soak [$MODE] /"
+done 2>&1 | tee $O/soak.txt
+for CFG in c2 c3 c4; do
+  bash tools/pmc_bench.sh $CFG > $O/pmc_$CFG.log 2>&1
+  cp gpurun_out/r3_pmc_bench_$CFG/summary.json profiles/r3_pmc_$CFG.json && cp profiles/r3_pmc_$CFG.json $O/
+  python -c "import json;d=json.load(open('profiles/r3_pmc_$CFG.json'));print('pmc $CFG', {k:d.get(k) for k in ('valu_busy','valu_lane_utilisation','wait_share','l2_hit','ta_busy','hbm_bytes_per_sample','fabric_read_bytes_per_sample','value_under_profiler_msamples_s','csrc_hash')})"
+done
+bash tools/profile_bench.sh r3 --gpus 1 --steps 20 --warmup 5 > $O/profile_bench.log 2>&1; cp gpurun_out/prof_r3/*kernel_stats.csv $O/r3_bench_kernel_stats.csv; cp gpurun_out/prof_r3/bench.json $O/r3_bench_under_rocprof.json; head -4 $O/r3_bench_kernel_stats.csv
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/r3_bench.json 2> $O/r3_bench.err; python -c "
+import json;d=json.load(open('$O/r3_bench.json'));r=d['roofline'];print('BENCH',round(d['value'],1),'ms/step',round(d['ms_per_step'],2),'frac',round(r['frac'],3),'frac_measured',r.get('frac_measured'),'cpu',d.get('cpu_baseline',{}).get('value'));e=d['extra_configs'];print({k:(round(v['value'],1), round(v.get('roofline',{}).get('frac',0),3), v.get('roofline',{}).get('frac_measured')) for k,v in e.items() if 'value' in v});print({k:round(v['value'],1) for k,v in e.get('schedules',{}).items() if 'value' in v})"
+for K in fd full; do for R in "" "--4k"; do
+  STEPS=$([ -z "$R" ] && echo 8 || echo 4)
+  timeout 900 python tools/shard_balance.py 8 $STEPS --$K $R > $O/shard_${K}${R}.json 2>> $O/shard.err
+  python -c "import json;d=json.load(open('$O/shard_${K}${R}.json'));print('shard $K $R eff',round(d['kernel_scaling_efficiency'],3),'T1',round(d['T1_ms'],1))"
+done; done
+for NF in 1 8; do timeout 900 python tools/textured_bench.py 4 $NF > $O/textured_nfloor$NF.json 2>> $O/tex.err; python -c "import json;d=json.load(open('$O/textured_nfloor$NF.json'));print('tex nfloor=$NF',{k[:28]:round(v['msamples_per_s'],1) for k,v in d.items()})"; done
