@@ -387,10 +387,17 @@ hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream) {
     base += plan.carry_bytes;
     const PtParams q = with_tex_slots(pp, base, lds);
     const bool stage = p.stage_total != 0;
-#define AKR_LAUNCH3(B, F, T, S, D, X)                                                                                      \
-    {                                                                                                                     \
-        if (p.sampler) hipLaunchKernelGGL((k_pt_pass<B, F, T, true, S, D, X>), dim3(blocks), dim3(256), lds, stream, q);   \
-        else hipLaunchKernelGGL((k_pt_pass<B, F, T, false, S, D, X>), dim3(blocks), dim3(256), lds, stream, q);           \
+    // a deep tree (up to 24 KB of stacks) + eight graph-value slots (32 KB) + the parked columns can pass the 64 KB a launch gets
+    // without asking: the kernel is then allowed what it needs (a workgroup may have all 160 KB of the CU; fewer workgroups fit)
+#define AKR_LAUNCH4(K)                                                                                                              \
+    {                                                                                                                               \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+        hipLaunchKernelGGL((K), dim3(blocks), dim3(256), lds, stream, q);                                                           \
+    }
+#define AKR_LAUNCH3(B, F, T, S, D, X)                                            \
+    {                                                                           \
+        if (p.sampler) AKR_LAUNCH4((k_pt_pass<B, F, T, true, S, D, X>))          \
+        else AKR_LAUNCH4((k_pt_pass<B, F, T, false, S, D, X>))                  \
     }
     // the SIMPLE instantiations exist for the full-graph kernels of scenes without textures only
 #define AKR_LAUNCH2(B, F, T, S, D)                                           \
@@ -411,6 +418,7 @@ hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream) {
         if (tex) { if (fd) AKR_LAUNCH(false, true, true) else AKR_LAUNCH(false, false, true) }
         else { if (fd) AKR_LAUNCH(false, true, false) else AKR_LAUNCH(false, false, false) }
     }
+#undef AKR_LAUNCH4
 #undef AKR_LAUNCH3
 #undef AKR_LAUNCH2
 #undef AKR_LAUNCH

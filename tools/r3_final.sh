@@ -22,3 +22,4 @@ for K in fd full; do for R in "" "--4k"; do
   python -c "import json;d=json.load(open('$O/shard_${K}${R}.json'));print('shard $K $R eff',round(d['kernel_scaling_efficiency'],3),'T1',round(d['T1_ms'],1))"
 done; done
 for NF in 1 8; do timeout 900 python tools/textured_bench.py 4 $NF > $O/textured_nfloor$NF.json 2>> $O/tex.err; python -c "import json;d=json.load(open('$O/textured_nfloor$NF.json'));print('tex nfloor=$NF',{k[:28]:round(v['msamples_per_s'],1) for k,v in d.items()})"; done
+for NF in 1 8; do bash tools/tex_pmc.sh $NF > $O/tex_pmc_$NF.log 2>&1; cp gpurun_out/texpmc_$NF/summary.json $O/r3_pmc_textured_room_nfloor$NF.json; python -c "import json;d=json.load(open('$O/r3_pmc_textured_room_nfloor$NF.json'));print('texpmc nfloor=$NF',{k[:10]:{kk:round(vv,3) for kk,vv in v.items() if kk in ('wait_share','valu_busy','valu_lane_utilisation','hbm_bytes_per_sample','msamples_per_s_under_profiler')} for k,v in d.items() if isinstance(v,dict)})"; done

@@ -1,9 +1,11 @@
 #!/bin/bash
 # PMC passes over tools/textured_bench.py's room (textured, and the same room with constant materials that select the same
-# lobes): one --pmc set per rocprofv3 run, kernel-trace only; summary -> gpurun_out/texpmc/summary.json (-> profiles/r2_pmc_textured_room.json)
+# lobes): one --pmc set per rocprofv3 run, kernel-trace only.  usage: tools/tex_pmc.sh [nfloor=1]   (1: exhaustive kernel, 8: tessellated
+# floor, BVH kernel); summary -> gpurun_out/texpmc_<nfloor>/summary.json (-> profiles/r3_pmc_textured_room_{exhaustive,bvh}.json)
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/texpmc; rm -rf $OUT; mkdir -p $OUT
+NF=${1:-1}
+OUT=gpurun_out/texpmc_$NF; rm -rf $OUT; mkdir -p $OUT
 for V in "textured" "same room, constant materials with the lobes the graphs select"; do
   tag=$(echo "$V" | cut -c1-4)
   i=0
@@ -12,7 +14,7 @@ for V in "textured" "same room, constant materials with the lobes the graphs sel
     "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA" \
     "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" ; do
     i=$((i+1))
-    TEXBENCH_ONLY="$V" timeout 300 rocprofv3 --kernel-trace --pmc $SET -f csv -d $OUT -o ${tag}_set$i -- python tools/textured_bench.py 3 > $OUT/${tag}_set$i.out 2> $OUT/${tag}_set$i.err
+    TEXBENCH_ONLY="$V" timeout 300 rocprofv3 --kernel-trace --pmc $SET -f csv -d $OUT -o ${tag}_set$i -- python tools/textured_bench.py 3 $NF > $OUT/${tag}_set$i.out 2> $OUT/${tag}_set$i.err
     echo "$tag set$i rc=$?"
   done
 done
@@ -36,7 +38,8 @@ for tag, name in (("text", "textured"), ("same", "same room, constant materials 
                  "valu_insts_per_sample": c["SQ_INSTS_VALU"] * 64 / samples / 64, "vmem_insts_per_sample_x64": c["SQ_INSTS_VMEM"] * 64 / samples,
                  "hbm_bytes_per_sample": hbm / samples, "l2_hit": c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"]),
                  "counters": c}
-out["source"] = "tools/r2_texpmc.sh: rocprofv3 --kernel-trace --pmc <one set per pass> -- python tools/textured_bench.py 3 (TEXBENCH_ONLY=<variant>); 1920x1080, 4 passes of 64 spp; hbm = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; valu_busy = SQ_INSTS_VALU x 2 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)"
+out["n_floor"] = $NF
+out["source"] = "tools/tex_pmc.sh $NF: rocprofv3 --kernel-trace --pmc <one set per pass> -- python tools/textured_bench.py 3 $NF (TEXBENCH_ONLY=<variant>); 1920x1080, 4 passes of 64 spp; hbm = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; valu_busy = SQ_INSTS_VALU x 2 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)"
 json.dump(out, open("$OUT/summary.json", "w"), indent=1)
 print(json.dumps({k: ({kk: vv for kk, vv in v.items() if kk != "counters"} if isinstance(v, dict) else v) for k, v in out.items()}, indent=1))
 PY
