@@ -211,29 +211,9 @@ struct LightSample {
     uint32_t ex1;
     bool valid;
 };
-// LightAggregate::sample_direct (light/mod.rs:115-132) + AreaLight::sample_direct (light/area.rs:51-107), in two halves:
-// light_pick = everything that depends on the random numbers only (which light, which triangle, the point on it, its emission):
-// three dependent table lookups and two record fetches; sample_direct_at = the geometry between that point and the shading point.
-struct LightPick {
-    SurfacePoint y;
-    vec3 emission;
-    float light_choice_pdf, pdf_prim;
-    uint32_t gid;
-};
+// LightAggregate::sample_direct (light/mod.rs:115-132) + AreaLight::sample_direct (light/area.rs:51-107)
 template <bool TEX>
-AKR_D LightPick light_pick(const DScene& sc, float u_select, vec2 u_sample) {
-    LightPick k;
-    float u_sel2, u_unused;
-    uint32_t light = alias_sample_and_remap(sc.light_alias, sc.n_lights, u_select, k.light_choice_pdf, u_sel2);
-    const LightRec L = sc.lights[light];
-    uint32_t prim = alias_sample_and_remap(sc.area_alias + L.tri_offset, L.n_tris, u_sel2, k.pdf_prim, u_unused);
-    k.gid = L.first_gid + prim;
-    vec2 bary = uniform_sample_triangle(u_sample);
-    k.y = surface_interaction(sc, k.gid, bary);
-    k.emission = material_emission_at<TEX>(sc, k.y.material, k.y.uv);
-    return k;
-}
-AKR_D LightSample sample_direct_at(const LightPick& k, vec3 pn_p, vec3 pn_n) {
+AKR_D LightSample sample_direct(const DScene& sc, vec3 pn_p, vec3 pn_n, float u_select, vec2 u_sample) {
     LightSample s;
     s.li = mk3(0, 0, 0);
     s.wi = mk3(0, 0, 0);
@@ -242,31 +222,30 @@ AKR_D LightSample sample_direct_at(const LightPick& k, vec3 pn_p, vec3 pn_n) {
     s.tmax = 0.0f;
     s.ex1 = kInvalid;
     s.valid = false;
-    const SurfacePoint& y = k.y;
+    if (sc.n_lights == 0) return s;
+    float light_choice_pdf, u_sel2, pdf_prim, u_unused;
+    uint32_t light = alias_sample_and_remap(sc.light_alias, sc.n_lights, u_select, light_choice_pdf, u_sel2);
+    const LightRec L = sc.lights[light];
+    uint32_t prim = alias_sample_and_remap(sc.area_alias + L.tri_offset, L.n_tris, u_sel2, pdf_prim, u_unused);
+    uint32_t gid = L.first_gid + prim;
+    vec2 bary = uniform_sample_triangle(u_sample);
+    SurfacePoint y = surface_interaction(sc, gid, bary);
     vec3 wi = y.p - pn_p;
     if (length2(wi) == 0.0f) return s;
     float dist2 = length2(wi);
     wi = div_s(wi, __builtin_sqrtf(dist2));
-    s.li = dot(wi, y.ng) < 0.0f ? k.emission : mk3(0, 0, 0);
+    vec3 emission = material_emission_at<TEX>(sc, y.material, y.uv);
+    s.li = dot(wi, y.ng) < 0.0f ? emission : mk3(0, 0, 0);
     float cos_theta_i = abs_f(dot(y.ng, wi));
-    float pdf = k.pdf_prim / y.prim_area * dist2 / cos_theta_i;
+    float pdf = pdf_prim / y.prim_area * dist2 / cos_theta_i;
     s.ro = offset_ray_origin(pn_p, face_forward(pn_n, wi));
     float dist = __builtin_sqrtf(dist2);
     s.tmax = dist * (1.0f - 1e-3f);
-    s.ex1 = k.gid;
+    s.ex1 = gid;
     s.wi = wi;
     s.valid = is_finite(pdf);
-    s.pdf = pdf * k.light_choice_pdf;
+    s.pdf = pdf * light_choice_pdf;
     return s;
-}
-template <bool TEX>
-AKR_D LightSample sample_direct(const DScene& sc, vec3 pn_p, vec3 pn_n, float u_select, vec2 u_sample) {
-    if (sc.n_lights == 0) {
-        LightSample s;
-        s.li = mk3(0, 0, 0); s.wi = mk3(0, 0, 0); s.pdf = 0.0f; s.ro = mk3(0, 0, 0); s.tmax = 0.0f; s.ex1 = kInvalid; s.valid = false;
-        return s;
-    }
-    return sample_direct_at(light_pick<TEX>(sc, u_select, u_sample), pn_p, pn_n);
 }
 // LightAggregate::pdf_direct (light/mod.rs:134-147) + AreaLight::pdf_direct (light/area.rs:109-130)
 AKR_D float pdf_direct(const DScene& sc, const SurfacePoint& si, uint32_t gid, vec3 pn_p) {
@@ -432,7 +411,7 @@ AKR_D void shifted_pixel(const PtParams& p, uint32_t px, uint32_t py, uint32_t& 
 // FD: 1 / 0 = force_diffuse known at compile time (the reference's JIT also specialises the kernel on it: the branch
 // at pt.rs:268 is taken while tracing the kernel, so a force_diffuse kernel contains no Principled code); -1 = read
 // p.force_diffuse at run time.
-template <int FD = -1, bool TEX = false, bool PMJ = false, int PARK = 0, bool SIMPLE = false, bool PREFETCH_LIGHT = false>  // PARK: 0 no, 1 yes, 2 yes without the DEFER fields
+template <int FD = -1, bool TEX = false, bool PMJ = false, int PARK = 0, bool SIMPLE = false>  // PARK: 0 no, 1 yes, 2 yes without the DEFER fields
 AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found, bool occluded, uint32_t pix_in, uint32_t sx_in, uint32_t sy_in,
                      uint32_t* park = nullptr) {
     const bool force_diffuse = FD < 0 ? (p.force_diffuse != 0) : (FD != 0);
@@ -485,19 +464,6 @@ AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found,
         if (!found) {
             terminated = true;  // pt.rs:381-396 (hit_envmap adds zero)
         } else {
-            // PREFETCH_LIGHT: the light sample of this vertex -- IF it takes one -- is a function of the next three numbers of the
-            // sampler alone. Picked here, from a copy of the sampler, its chain of dependent table reads (light, triangle, its
-            // records, its emission) runs beside the chain of the hit (records, instance, material) instead of after it; the
-            // numbers are drawn for real further down, unchanged, and a vertex that takes no light sample has lost a few
-            // instructions. Same values, same order of consumption.
-            LightPick pre;
-            bool pre_ok = false;
-            if (PREFETCH_LIGHT && sc.n_lights != 0 && p.use_nee) {
-                Sampler peek = r.smp;
-                const vec3 up = next_3d<PMJ>(p, peek);
-                pre = light_pick<TEX>(sc, up.x, mk2(up.y, up.z));
-                pre_ok = true;
-            }
             SurfacePoint si = surface_interaction(sc, hit.gid, mk2(hit.u, hit.v));
             vec3 wo = -r.rd;
             // Everything that reads the material, as a function of where the record lives: the folded record in HBM, or --
@@ -526,10 +492,8 @@ AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found,
                 vec3 u_direct = next_3d<PMJ>(p, r.smp);
                 LightSample dl;
                 dl.valid = false;
-                if (p.use_nee && (!p.indirect_only || r.depth > 1)) {
-                    if (PREFETCH_LIGHT && pre_ok) dl = sample_direct_at(pre, si.p, si.ng);  // picked above from the same three numbers
-                    else dl = sample_direct<TEX>(sc, si.p, si.ng, u_direct.x, mk2(u_direct.y, u_direct.z));
-                }
+                if (p.use_nee && (!p.indirect_only || r.depth > 1))
+                    dl = sample_direct<TEX>(sc, si.p, si.ng, u_direct.x, mk2(u_direct.y, u_direct.z));
                 vec3 u_bsdf = next_3d<PMJ>(p, r.smp);
                 // sample_surface_and_shade_direct, pt.rs:297-323
                 ShadePoint sp;

@@ -17,12 +17,6 @@ namespace akr {
 #ifndef AKR_WALK_FULL_UNROLL
 #define AKR_WALK_FULL_UNROLL 1  // full-graph exhaustive kernels: two records per trip of the pair walk, as the force_diffuse kernel does
 #endif
-#ifndef AKR_PT_PREFETCH_LIGHT_FD
-#define AKR_PT_PREFETCH_LIGHT_FD 0    // force_diffuse kernels: the vertex's light sample picked speculatively before the hit is reconstructed (dpath.h)
-#endif
-#ifndef AKR_PT_PREFETCH_LIGHT_FULL
-#define AKR_PT_PREFETCH_LIGHT_FULL 0  // the same for the full-graph kernels of scenes without textures
-#endif
 #ifndef AKR_PT_PARK_FULL
 #define AKR_PT_PARK_FULL 0  // exhaustive full-graph kernels without textures: cold path state in LDS while a vertex is shaded (dpath.h: PARK)
 #endif

@@ -49,7 +49,6 @@ __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT
     if (STAGE) stage_scene_tables<BVH, TEX, !BVH && !FD && TEX>(p, lds_stack, staged);
     const PtParams& q = STAGE ? staged : p;
     const DScene& sc = q.sc;
-    constexpr bool PFL = !TEX && (FD ? AKR_PT_PREFETCH_LIGHT_FD != 0 : AKR_PT_PREFETCH_LIGHT_FULL != 0);
     constexpr bool TILE = BVH && !TEX && AKR_BVH_TILE != 0;
     constexpr uint32_t STRAG = BVH ? (TEX ? AKR_PT_STRAGGLERS_TEX : AKR_PT_STRAGGLERS) : 0;
     const uint4* tile = (const uint4*)(lds_stack + p.tile_offset);
@@ -206,8 +205,8 @@ __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT
             }
             if (STRAG > 0 && r.carry) {
                 // still tracing: nothing to resolve or shade yet
-            } else if (PARK) path_step<FD ? 1 : 0, TEX, PMJ, DEFER ? 1 : 2, SIMPLE, PFL>(q, r, hit, found, occluded, 0, 0, 0, park);
-            else path_step<FD ? 1 : 0, TEX, PMJ, 0, SIMPLE, PFL>(q, r, hit, found, occluded, pix, sx, sy);
+            } else if (PARK) path_step<FD ? 1 : 0, TEX, PMJ, DEFER ? 1 : 2, SIMPLE>(q, r, hit, found, occluded, 0, 0, 0, park);
+            else path_step<FD ? 1 : 0, TEX, PMJ, 0, SIMPLE>(q, r, hit, found, occluded, pix, sx, sy);
         }
     }
     flush_counters(p, r, tc.cnt, BVH);
