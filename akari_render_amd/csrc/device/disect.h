@@ -1,4 +1,4 @@
-// disect.h -- ray/triangle test and the two scene intersectors (exhaustive for tiny scenes, 8-wide compressed BVH otherwise).
+// disect.h -- ray/triangle test and the two scene intersectors (exhaustive for tiny scenes, 6-wide compressed BVH of 64-byte nodes otherwise).
 //
 // Replaces LuisaCompute's rtx::Accel ray queries (crates/akari_render/src/scene.rs:88-185). Semantics kept from
 // the reference: a candidate is rejected when its (inst, prim) equals one of the ray's two exclusion slots
@@ -263,7 +263,8 @@ AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, u
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// 8-wide compressed BVH traversal (node layout and builder: host/bvh.cpp; after Ylitie, Karras & Laine, HPG 2017).
+// Compressed wide-BVH traversal: six children in eight octant positions, 64-byte nodes (layout and builder: host/bvh.cpp; after
+// Ylitie, Karras & Laine, HPG 2017).
 //
 // One ray per lane. A lane's state is a NODE GROUP G = child_base (24 bits) | hit bits of up to 8 sibling nodes, in
 // visiting order (bits 24..31), a TRIANGLE GROUP (tbase, T) = up to 24 pending triangles of the node visited last, and a
@@ -274,8 +275,8 @@ AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, u
 // (kBvhStackDepth levels, checked against the tree's depth when the scene is built) cannot overflow.
 //
 // Every step a lane does ONE thing -- test its next pending triangle, or fetch and test its next node -- and both kinds
-// of lane fetch through the SAME five 16-byte loads from a per-lane address (64-byte triangle record: Woop rows + global
-// id; 80-byte node). The wave waits once per step whatever mix of nodes and triangles its lanes are at: on the
+// of lane fetch through the SAME four 16-byte loads from a per-lane address (64-byte triangle record: Woop rows + global
+// id; 64-byte node: one memory sector each). The wave waits once per step whatever mix of nodes and triangles its lanes are at: on the
 // 10 M-triangle hall the previous while-while BVH4 loop ran at 26 % lane utilisation, all of it waiting on dependent
 // fetches.
 // The box test only culls and does not have to follow the AKR-F32 contract (the oracle has no BVH): it must be conservative,
@@ -318,7 +319,7 @@ AKR_D void trav_begin(Trav& s, vec3 o, vec3 d, float tmin, float tmax, uint32_t 
 // One step of one lane: a triangle test if one is pending, else the next node. MODE 0: closest hit, 1: any hit, 2: `any_rt`
 // decides per lane (the wavefront schedule traces both kinds of ray in one loop).
 // TILE: the launch keeps the first sc.bvh_tile_nodes nodes (the top levels, breadth-first order: host/bvh.cpp) in LDS at `tile`;
-// a lane whose next node is one of them reads it with five ds_read_b128 instead of going through the texture addresser and L1 --
+// a lane whose next node is one of them reads it with four ds_read_b128 instead of going through the texture addresser and L1 --
 // on the 10 M-triangle hall the traversal keeps that path 58 % busy, and every ray starts with three to five such nodes.
 template <int MODE, bool TEX, bool TILE = false>
 AKR_D void trav_step(const DScene& sc, Trav& s, uint32_t* __restrict__ stack, TraceCounters& cnt, bool any_rt = false, const uint4* tile = nullptr) {
@@ -354,25 +355,25 @@ AKR_D void trav_step(const DScene& sc, Trav& s, uint32_t* __restrict__ stack, Tr
             tile_idx = idx;
         }
     }
-    // the one fetch of the step; a triangle record is 64 bytes, so its lanes re-read word 0 instead of running into the next line
-    uint4 w0, w1, w2, w3, w4;
+    // the one fetch of the step: four 16-byte loads, a 64-byte triangle record or a 64-byte node -- one sector either way
+    uint4 w0, w1, w2, w3;
     if (TILE && in_tile) {
         // explicitly an LDS address: left generic, the compiler folds the two branches into ONE flat load of a selected pointer
         // (and volatile: two plain loads in the arms of an if / else are sunk into one load of a selected -- generic -- pointer)
         typedef const volatile uint32_t __attribute__((address_space(3))) * LdsW;
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         typedef const volatile u32x4 __attribute__((address_space(3))) * LdsU4;
-        LdsU4 pt = (LdsU4)((LdsW)(const uint32_t*)tile + tile_idx * 20u);
-        const u32x4 t0 = pt[0], t1 = pt[1], t2 = pt[2], t3 = pt[3], t4 = pt[4];
+        LdsU4 pt = (LdsU4)((LdsW)(const uint32_t*)tile + tile_idx * kBvhNodeWords);
+        const u32x4 t0 = pt[0], t1 = pt[1], t2 = pt[2], t3 = pt[3];
         w0 = make_uint4(t0.x, t0.y, t0.z, t0.w); w1 = make_uint4(t1.x, t1.y, t1.z, t1.w); w2 = make_uint4(t2.x, t2.y, t2.z, t2.w);
-        w3 = make_uint4(t3.x, t3.y, t3.z, t3.w); w4 = make_uint4(t4.x, t4.y, t4.z, t4.w);
+        w3 = make_uint4(t3.x, t3.y, t3.z, t3.w);
     } else {
-        w0 = p[0]; w1 = p[1]; w2 = p[2]; w3 = p[3]; w4 = p[do_tri ? 0 : 4];
+        w0 = p[0]; w1 = p[1]; w2 = p[2]; w3 = p[3];
     }
-    // All five loads are in flight before anything waits. Without this fence the compiler sinks the words only the node test
+    // All four loads are in flight before anything waits. Without this fence the compiler sinks the words only the node test
     // reads into the node branch -- a second dependent round trip to memory for every node step.
     asm volatile("" : "+v"(w0.x), "+v"(w0.y), "+v"(w0.z), "+v"(w0.w), "+v"(w1.x), "+v"(w1.y), "+v"(w1.z), "+v"(w1.w), "+v"(w2.x), "+v"(w2.y),
-                      "+v"(w2.z), "+v"(w2.w), "+v"(w3.x), "+v"(w3.y), "+v"(w3.z), "+v"(w3.w), "+v"(w4.x), "+v"(w4.y), "+v"(w4.z), "+v"(w4.w));
+                      "+v"(w2.z), "+v"(w2.w), "+v"(w3.x), "+v"(w3.y), "+v"(w3.z), "+v"(w3.w));
     if (do_tri) {
         cnt.tris++;
         float t, u, v;
@@ -397,33 +398,37 @@ AKR_D void trav_step(const DScene& sc, Trav& s, uint32_t* __restrict__ stack, Tr
         const float limit = s.best_t;  // closest hit: culls with the best distance so far (non-strict: equal-t lower ids stay reachable)
         const float bx = u2f((w0.w & 0xffu) << 23) * s.inv.x, by = u2f(((w0.w >> 8) & 0xffu) << 23) * s.inv.y, bz = u2f(((w0.w >> 16) & 0xffu) << 23) * s.inv.z;
         const float ax = __builtin_fmaf(u2f(w0.x), s.inv.x, s.noi.x), ay = __builtin_fmaf(u2f(w0.y), s.inv.y, s.noi.y), az = __builtin_fmaf(u2f(w0.z), s.inv.z, s.noi.z);
+        // Node words (host/bvh.cpp): w0 = origin | exponents + child_base[7:0]; w1 = child_base[23:8] + meta[4..5] | meta[0..3] | tri_base |
+        // lo.x of entries 0..3; w2 = lo.y, lo.z, hi.x, hi.y of entries 0..3; w3 = hi.z of entries 0..3 | x, y, z of entries 4, 5 (lo lo hi hi).
         // per axis: the byte planes the ray enters through (near) and leaves through (far)
         const bool nx = s.inv.x < 0.0f, ny = s.inv.y < 0.0f, nz = s.inv.z < 0.0f;
-        const uint32_t qnx[2] = {nx ? w3.z : w2.x, nx ? w3.w : w2.y}, qfx[2] = {nx ? w2.x : w3.z, nx ? w2.y : w3.w};
-        const uint32_t qny[2] = {ny ? w4.x : w2.z, ny ? w4.y : w2.w}, qfy[2] = {ny ? w2.z : w4.x, ny ? w2.w : w4.y};
-        const uint32_t qnz[2] = {nz ? w4.z : w3.x, nz ? w4.w : w3.y}, qfz[2] = {nz ? w3.x : w4.z, nz ? w3.y : w4.w};
+        const uint32_t xb = nx ? ((w3.y >> 16) | (w3.y << 16)) : w3.y, yb = ny ? ((w3.z >> 16) | (w3.z << 16)) : w3.z, zb = nz ? ((w3.w >> 16) | (w3.w << 16)) : w3.w;
+        // [0]: entries 0..3 (four bytes), [1]: entries 4, 5 (near in bytes 0, 1; far in bytes 2, 3 after the swap above)
+        const uint32_t qnx[2] = {nx ? w2.z : w1.w, xb}, qfx[2] = {nx ? w1.w : w2.z, xb >> 16};
+        const uint32_t qny[2] = {ny ? w2.w : w2.x, yb}, qfy[2] = {ny ? w2.x : w2.w, yb >> 16};
+        const uint32_t qnz[2] = {nz ? w3.x : w2.y, zb}, qfz[2] = {nz ? w2.y : w3.x, zb >> 16};
         uint32_t hitmask = 0;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const uint32_t meta4 = h ? w1.w : w1.z;
+            const uint32_t meta4 = h ? (w1.x >> 16) : w1.y;  // (h = 1: entries 4, 5; the two upper bytes are zero = empty)
             // inner children (index bits 3 and 4 set: 24..31) get their bit position xor-ed with the ray's octant
             const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
             const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xffu;
             const uint32_t bit_index4 = (meta4 ^ (s.octinv4 & inner_mask4)) & 0x1f1f1f1fu;
             const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < (h ? 2 : 4); i++) {
                 const float tnx = __builtin_fmaf((float)byte_of(qnx[h], i), bx, ax), tfx = __builtin_fmaf((float)byte_of(qfx[h], i), bx, ax);
                 const float tny = __builtin_fmaf((float)byte_of(qny[h], i), by, ay), tfy = __builtin_fmaf((float)byte_of(qfy[h], i), by, ay);
                 const float tnz = __builtin_fmaf((float)byte_of(qnz[h], i), bz, az), tfz = __builtin_fmaf((float)byte_of(qfz[h], i), bz, az);
                 const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, s.tmin));
                 const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, limit));
-                if (tn <= tf) hitmask |= byte_of(child_bits4, i) << byte_of(bit_index4, i);  // empty slots have no child bits
+                if (tn <= tf) hitmask |= byte_of(child_bits4, i) << byte_of(bit_index4, i);  // empty entries have no child bits
             }
         }
-        s.G = (w1.x & 0xffffffu) | (hitmask & 0xff000000u);
+        s.G = ((w0.w >> 24) | ((w1.x & 0xffffu) << 8)) | (hitmask & 0xff000000u);
         s.T = hitmask & 0x00ffffffu;
-        s.tbase = w1.y;
+        s.tbase = w1.z;
     }
     s.active = (s.T != 0) | ((s.G >> 24) != 0) | (s.sp != 0);
 }

@@ -4,7 +4,7 @@
 //   woop      exhaustive path: 3 x float4 per triangle (the ray-triangle test's 48 B record), global order;
 //             BVH path: 4 x float4 per triangle in traversal order = the 48 B record | global triangle id | 12 B unused
 //             (one 64-byte fetch per test; global id = inst_tri_offset[inst] + prim)
-//   bvh_nodes 8-wide compressed nodes, 80 B used of a kBvhNodeWords-word stride (host/bvh.cpp)
+//   bvh_nodes 6-wide compressed nodes of 64 B (host/bvh.cpp)
 //   shade     8 x float4 per triangle, indexed by global id    : everything surface_interaction needs (128 B)
 //   inst      8 x float4 per instance                          : object->world matrix and its cofactors (128 B)
 //   materials DMaterial[ ]                                     : folded shader graphs (256 B)
@@ -19,10 +19,7 @@ namespace akr {
 constexpr uint32_t kInvalid = 0xffffffffu;
 
 // BVH record geometry shared by the host builder (host/bvh.cpp, scene_build.cpp) and the traversal (disect.h)
-#ifndef AKR_BVH_NODE_WORDS
-#define AKR_BVH_NODE_WORDS 20  // 20 = packed 80-byte nodes; 32 = one node per 128-byte line
-#endif
-constexpr uint32_t kBvhNodeWords = AKR_BVH_NODE_WORDS;  // u32 words from one node to the next (20 used)
+constexpr uint32_t kBvhNodeWords = 16;                  // one node = 64 bytes = one sector, like a triangle record
 constexpr uint32_t kBvhTriWords = 16;                   // BVH path: 12 words Woop record + global id + 3 unused
 // Traversal stack entries per lane. A pending group of sibling nodes is ONE entry and a traversal holds at most one group
 // per tree level, so a tree of depth <= kBvhStackDepth can never overflow; scene_build.cpp rejects deeper trees.

@@ -659,7 +659,7 @@ AKR_API int32_t akr_scene_get_info(const akr_scene* s, akr_scene_info* info) {
     info->n_bvh_nodes = (uint32_t)(s->cs.bvh_nodes.size() / kBvhNodeWords);
     info->uses_bvh = s->cs.bvh_nodes.empty() ? 0u : 1u;
     info->device_bytes = s->device_bytes;
-    info->node_bytes = s->cs.bvh_nodes.empty() ? 0u : 80u;   // bytes a traversal reads per node visit
+    info->node_bytes = s->cs.bvh_nodes.empty() ? 0u : kBvhNodeWords * 4u;   // bytes a traversal reads per node visit
     info->node_stride_bytes = s->cs.bvh_nodes.empty() ? 0u : kBvhNodeWords * 4u;
     info->tri_bytes = s->cs.bvh_nodes.empty() ? 48u : kBvhTriWords * 4u;
     info->bvh_depth = s->cs.bvh_depth;

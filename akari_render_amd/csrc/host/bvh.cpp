@@ -1,23 +1,29 @@
-// bvh.cpp -- host builder of the 8-wide compressed BVH (replaces the BLAS/TLAS build the reference delegates to
+// bvh.cpp -- host builder of the compressed wide BVH (replaces the BLAS/TLAS build the reference delegates to
 // LuisaCompute, crates/akari_render/src/mesh.rs:288-294,331-333).
 //
 // Binned-SAH binary build over world-space triangle boxes (instances are flattened: every triangle is stored once per
 // instance, which is exact for the rigid/affine instance transforms of the scene graph), leaves of at most 3 triangles,
-// collapsed to an 8-wide tree in the compressed layout of Ylitie, Karras & Laine, "Efficient Incoherent Ray Traversal on
-// GPUs Through Compressed Wide BVHs" (HPG 2017), with one change: a node's inner children live at child_base + slot (unused
-// slots of the block are holes), so that a group of pending children is ONE 32-bit stack entry (24-bit base | 8 hit bits).
+// collapsed to a wide tree in a compressed layout after Ylitie, Karras & Laine, "Efficient Incoherent Ray Traversal on GPUs
+// Through Compressed Wide BVHs" (HPG 2017), with two changes: a node's inner children live at child_base + octant position
+// (unused positions of the block are holes), so that a group of pending children is ONE 32-bit stack entry (24-bit base | 8 hit
+// bits); and a node has SIX children in its eight octant positions, which makes it 64 bytes -- one memory sector, like a triangle
+// record. (Round 2's 8-wide node was 80 bytes: two sectors wherever it sat. The hall's rays visit 10 % more of the narrower
+// nodes and fetch 39 % fewer bytes: tools/bvh_sim.cpp; the traversal is bound by the memory system)
 //
-// Node = 80 bytes = 5 x 16-byte words, stored with a stride of kBvhNodeWords words (device/disect.h):
-//   word 0: p.xyz (f32, the node's own padded lower corner) | exponent bytes ex, ey, ez (scale_a = 2^(e_a - 127)), 0
-//   word 1: child_base (u32, < 2^24) | tri_base (u32) | meta[0..3] | meta[4..7]
-//   word 2: q_lo.x[0..7] | q_lo.y[0..7]          (one byte per child slot)
-//   word 3: q_lo.z[0..7] | q_hi.x[0..7]
-//   word 4: q_hi.y[0..7] | q_hi.z[0..7]
+// Node = 64 bytes = 16 words (device/disect.h trav_step reads it as four 16-byte loads):
+//   word 0-2 : p.xyz (f32, the node's own padded lower corner)
+//   word 3   : exponent bytes ex, ey, ez (scale_a = 2^(e_a - 127)) | child_base bits 0-7
+//   word 4   : child_base bits 8-23 | meta[4] | meta[5]
+//   word 5   : meta[0..3]
+//   word 6   : tri_base
+//   word 7-12: entries 0..3, one word per plane: q_lo.x, q_lo.y, q_lo.z, q_hi.x, q_hi.y, q_hi.z (one byte per entry)
+//   word 13-15: entries 4, 5, one word per axis: q_lo[4], q_lo[5], q_hi[4], q_hi[5]
 // child box = p + q * scale per axis, q_lo rounded down and q_hi rounded up (verified in double), so the decoded box always
-// contains the exact padded box. meta byte of slot s: 0 = empty; inner child: 0x20 | (24 + s) -- its node is child_base + s;
-// leaf: (unary triangle count 1 / 3 / 7) << 5 | offset -- its triangles are tri_base + offset .. (at most 24 triangles under
-// one node). Children are assigned to slots so that bit a of the slot number says on which side of the node's centre along
-// axis a the child lies: a ray then visits the slots in the order slot ^ octant, near to far, without sorting distances.
+// contains the exact padded box. Entries are stored in ascending octant position. meta byte of an entry: 0 = empty; inner child:
+// 0x20 | (24 + position) -- its node is child_base + position; leaf: (unary triangle count 1 / 3 / 7) << 5 | offset -- its
+// triangles are tri_base + offset .. (at most 18 triangles under one node). A child's position is the octant of the node it
+// lies in (bit a = the side of the node's centre along axis a): a ray then visits the positions in the order position ^ octant,
+// near to far, without sorting distances.
 // Triangles are re-ordered so that every node's leaf triangles are contiguous (`order`).
 // Boxes are padded by `pad` so that every triangle the exhaustive test would report is reached by traversal
 // (the triangle test itself has an absolute slop of a few ulp(t); see DESIGN.md "BVH conservativeness").
@@ -69,6 +75,7 @@ struct BinNode {
 constexpr int kBins = 16;
 constexpr size_t kBvhTopSlots = 1024;  // node slots laid out breadth-first (the first four levels of a full tree: 1 + 8 + 64 + 512)
 constexpr uint32_t kLeafMax = 3;
+constexpr int kWide = 6;  // children per node (in 8 octant positions)
 
 struct Builder {
     const float* bounds;
@@ -235,7 +242,7 @@ void build_bvh8(const std::vector<float>& tri_bounds, uint32_t n_tris, float pad
         } else {
             kids[nk++] = root.left;
             kids[nk++] = root.right;
-            while (nk < 8) {  // open the inner child with the largest surface area (balanced: with the most triangles)
+            while (nk < kWide) {  // open the inner child with the largest surface area (balanced: with the most triangles)
                 int pick = -1;
                 float best = -1.0f;
                 for (int i = 0; i < nk; i++) {
@@ -304,7 +311,7 @@ void build_bvh8(const std::vector<float>& tri_bounds, uint32_t n_tris, float pad
             ebits[a] = (uint32_t)(e + 127);
             scale[a] = std::ldexp(1.0, e);
         }
-        // children block: inner child in slot s lives at child_base + s
+        // children block: the inner child at octant position s lives at child_base + s
         int max_inner_slot = -1;
         for (int sl = 0; sl < 8; sl++)
             if (child_in[sl] >= 0 && bn[kids[child_in[sl]]].left >= 0) max_inner_slot = sl;
@@ -315,9 +322,13 @@ void build_bvh8(const std::vector<float>& tri_bounds, uint32_t n_tris, float pad
             if (out_nodes.size() / stride > (1u << 24)) throw std::runtime_error("unsupported: scene needs more than 2^24 BVH node slots");
         }
         const uint32_t tri_base = (uint32_t)order_out.size();
-        uint8_t meta[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[6][8];
-        for (int k = 0; k < 6; k++)
-            for (int sl = 0; sl < 8; sl++) q[k][sl] = k < 3 ? 255 : 0;  // empty slot: inverted box
+        // storage order = ascending octant position; entry e of the node holds the child at position pos_of[e]
+        uint8_t meta[kWide], q[6][kWide];
+        for (int e = 0; e < kWide; e++) {
+            meta[e] = 0;
+            for (int k = 0; k < 6; k++) q[k][e] = k < 3 ? 255 : 0;  // empty entry: inverted box
+        }
+        int e = 0;
         for (int sl = 0; sl < 8; sl++) {
             const int c = child_in[sl];
             if (c < 0) continue;
@@ -330,27 +341,30 @@ void build_bvh8(const std::vector<float>& tri_bounds, uint32_t n_tris, float pad
                 // the f32 decode origin + q * scale rounds to nearest: step outwards until it is conservative
                 while (l > 0.0 && (float)((double)origin[a] + l * scale[a]) > clo[c][a]) l -= 1.0;
                 while (h < 255.0 && (float)((double)origin[a] + h * scale[a]) < chi[c][a]) h += 1.0;
-                q[a][sl] = (uint8_t)l;
-                q[3 + a][sl] = (uint8_t)h;
+                q[a][e] = (uint8_t)l;
+                q[3 + a][e] = (uint8_t)h;
             }
             if (cn.left < 0) {  // leaf: its triangles follow the node's earlier leaves
                 const uint32_t offset = (uint32_t)order_out.size() - tri_base;
                 for (uint32_t t = 0; t < cn.count; t++) order_out.push_back(order[cn.first + t]);
                 const uint32_t unary = cn.count >= 3 ? 7u : (cn.count == 2 ? 3u : 1u);
-                meta[sl] = (uint8_t)((unary << 5) | offset);
+                meta[e] = (uint8_t)((unary << 5) | offset);
             } else {
-                meta[sl] = (uint8_t)(0x20u | (24u + (uint32_t)sl));
+                meta[e] = (uint8_t)(0x20u | (24u + (uint32_t)sl));
                 queue.push_back({kids[c], child_base + (uint32_t)sl, pe.depth + 1});
             }
+            e++;
         }
-        auto pack4 = [](const uint8_t* v) { return (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24); };
         uint32_t* n = &out_nodes[(size_t)stride * pe.out];
         n[0] = fbits(origin[0]); n[1] = fbits(origin[1]); n[2] = fbits(origin[2]);
-        n[3] = ebits[0] | (ebits[1] << 8) | (ebits[2] << 16);
-        n[4] = child_base; n[5] = tri_base; n[6] = pack4(meta); n[7] = pack4(meta + 4);
-        n[8] = pack4(q[0]); n[9] = pack4(q[0] + 4); n[10] = pack4(q[1]); n[11] = pack4(q[1] + 4);
-        n[12] = pack4(q[2]); n[13] = pack4(q[2] + 4); n[14] = pack4(q[3]); n[15] = pack4(q[3] + 4);
-        n[16] = pack4(q[4]); n[17] = pack4(q[4] + 4); n[18] = pack4(q[5]); n[19] = pack4(q[5] + 4);
+        n[3] = ebits[0] | (ebits[1] << 8) | (ebits[2] << 16) | ((child_base & 0xffu) << 24);
+        n[4] = ((child_base >> 8) & 0xffffu) | ((uint32_t)meta[4] << 16) | ((uint32_t)meta[5] << 24);
+        n[5] = (uint32_t)meta[0] | ((uint32_t)meta[1] << 8) | ((uint32_t)meta[2] << 16) | ((uint32_t)meta[3] << 24);
+        n[6] = tri_base;
+        for (int k = 0; k < 6; k++)  // entries 0..3: one word per plane
+            n[7 + k] = (uint32_t)q[k][0] | ((uint32_t)q[k][1] << 8) | ((uint32_t)q[k][2] << 16) | ((uint32_t)q[k][3] << 24);
+        for (int a = 0; a < 3; a++)  // entries 4, 5: one word per axis = lo[4] lo[5] hi[4] hi[5]
+            n[13 + a] = (uint32_t)q[a][4] | ((uint32_t)q[a][5] << 8) | ((uint32_t)q[3 + a][4] << 16) | ((uint32_t)q[3 + a][5] << 24);
     }
 }
 

@@ -682,7 +682,7 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
     out.n_lights = (uint32_t)out.light_inst.size();
     if (out.n_lights > 0) build_alias_table(light_weights, out.light_entries, out.light_pdf);
 
-    // acceleration structure: tiny scenes are intersected exhaustively (records from LDS or the scalar cache), others get the 8-wide compressed BVH of host/bvh.cpp
+    // acceleration structure: tiny scenes are intersected exhaustively (records from LDS or the scalar cache), others get the compressed wide BVH of host/bvh.cpp
     // (AKR_FORCE_BVH=1 builds the BVH for tiny scenes too: lets the tests run both intersectors on scenes/cbox)
     const TuningOptions tune = tuning();
     const uint32_t kExhaustiveMax = tune.force_bvh ? 0u : 64u;

@@ -62,7 +62,7 @@ struct CompiledScene {
     std::vector<uint32_t> light_inst, light_tri_offset, light_n_tris;
     std::vector<AliasEntry> area_entries;
     std::vector<float> area_pdf;
-    // 8-wide compressed BVH nodes (kBvhNodeWords words each, host/bvh.cpp) or empty for the exhaustive path
+    // 6-wide compressed BVH nodes (kBvhNodeWords = 16 words = 64 bytes each, host/bvh.cpp) or empty for the exhaustive path
     std::vector<uint32_t> bvh_nodes;
     uint32_t bvh_depth = 0;              // levels of the wide tree = the most stack entries a traversal can need
     // textures: pruned node lists of the materials with texture-fed inputs, image headers, texel words, raw inputs

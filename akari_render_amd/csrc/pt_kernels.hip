@@ -52,10 +52,10 @@ __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT
     constexpr bool TILE = BVH && !TEX && AKR_BVH_TILE != 0;
     constexpr uint32_t STRAG = BVH ? (TEX ? AKR_PT_STRAGGLERS_TEX : AKR_PT_STRAGGLERS) : 0;
     const uint4* tile = (const uint4*)(lds_stack + p.tile_offset);
-    if (TILE) {  // nodes 0 .. bvh_tile_nodes - 1, 20 words each
+    if (TILE) {  // nodes 0 .. bvh_tile_nodes - 1
         uint32_t* l = lds_stack + p.tile_offset;
         const uint32_t* g = (const uint32_t*)p.sc.bvh_nodes;
-        for (uint32_t i = threadIdx.x; i < p.sc.bvh_tile_nodes * 20u; i += 256u) l[i] = g[(i / 20u) * kBvhNodeWords + i % 20u];
+        for (uint32_t i = threadIdx.x; i < p.sc.bvh_tile_nodes * kBvhNodeWords; i += 256u) l[i] = g[i];
         __syncthreads();
     }
     constexpr int WALK = FD ? AKR_WALK_FD : (TEX ? 0 : AKR_WALK_FULL);
@@ -376,8 +376,8 @@ hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream) {
         // what is left of the workgroup's share of the CU's LDS after the launch's other blocks
         const size_t other = base + plan.park_bytes + plan.carry_bytes + (tex ? (size_t)p.tex_slots * kTexValStride * sizeof(TexVal) : 0);
         const size_t budget = pt_lds_budget(tex) - 256;
-        if (other < budget) pp.sc.bvh_tile_nodes = (uint32_t)std::min<size_t>({(budget - other) / 80, (size_t)p.sc.n_nodes, (size_t)1024});
-        base += (size_t)pp.sc.bvh_tile_nodes * 80;
+        if (other < budget) pp.sc.bvh_tile_nodes = (uint32_t)std::min<size_t>({(budget - other) / (kBvhNodeWords * 4), (size_t)p.sc.n_nodes, (size_t)1024});
+        base += (size_t)pp.sc.bvh_tile_nodes * kBvhNodeWords * 4;
         base = (base + 15) & ~(size_t)15;
     }
     pp.park_offset = (uint32_t)(base / 4);

@@ -268,7 +268,7 @@ typedef struct {
     uint32_t n_bvh_nodes;     /* 0 when the scene uses the exhaustive small-scene intersector */
     uint32_t uses_bvh;
     uint64_t device_bytes;    /* HBM held by the scene */
-    uint32_t node_bytes;      /* bytes read per BVH node visit (80: 8-wide compressed node), 0 without a BVH */
+    uint32_t node_bytes;      /* bytes read per BVH node visit (64: 6-wide compressed node = one sector), 0 without a BVH */
     uint32_t node_stride_bytes; /* distance between nodes in memory */
     uint32_t tri_bytes;       /* bytes read per triangle test: 48 (exhaustive path) or 64 (BVH path: record + id) */
     uint32_t bvh_depth;       /* levels of the 8-wide tree = most traversal-stack entries a ray can need */

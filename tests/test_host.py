@@ -110,28 +110,38 @@ def test_material_flags(hip_lib, cbox_path):
 
 
 def _decode_bvh8(sc):
-    """The scene's 8-wide compressed BVH (csrc/host/bvh.cpp) as python objects: per node origin, scale, child_base, tri_base,
-    meta[8], q[6][8]."""
+    """The scene's compressed wide BVH (csrc/host/bvh.cpp: 64-byte nodes, six entries in eight octant positions) as python
+    objects: per node origin, scale, child_base, tri_base, meta[8], q[6][8] (entries 6, 7 are always empty)."""
     info = sc.info()
     stride = info.node_stride_bytes // 4
     raw = sc.array(capi.ARRAY_BVH_NODES, np.uint32).reshape(-1, stride)
-    assert raw.shape[0] == info.n_bvh_nodes and info.node_bytes == 80
+    assert raw.shape[0] == info.n_bvh_nodes and info.node_bytes == 64 and stride == 16
     return raw, info
 
 
 def _node(raw, ni):
+    """Node words: origin xyz | exponents + child_base[7:0] | child_base[23:8] + meta[4..5] | meta[0..3] | tri_base | six words = the
+    planes lo.x lo.y lo.z hi.x hi.y hi.z of entries 0..3 | three words = x, y, z of entries 4, 5 as (lo4, lo5, hi4, hi5)."""
     nd = raw[ni]
     origin = nd[0:3].view(np.float32).astype(np.float32)
     e = [(int(nd[3]) >> (8 * a)) & 0xFF for a in range(3)]
     scale = np.array([np.float32(2.0) ** np.float32(x - 127) for x in e], dtype=np.float32)
-    by = nd[6:20].view(np.uint8)
-    meta, q = by[0:8], by[8:56].reshape(6, 8)  # q rows: lo.x lo.y lo.z hi.x hi.y hi.z
-    return origin, scale, int(nd[4]), int(nd[5]), meta, q
+    child_base = (int(nd[3]) >> 24) | ((int(nd[4]) & 0xFFFF) << 8)
+    meta = np.zeros(8, dtype=np.uint8)
+    meta[0:4] = nd[5:6].view(np.uint8)
+    meta[4:6] = nd[4:5].view(np.uint8)[2:4]
+    q = np.zeros((6, 8), dtype=np.uint8)
+    q[0:3, 6:8] = 255  # the two entries that do not exist: inverted boxes, like every empty entry
+    q[:, 0:4] = nd[7:13].view(np.uint8).reshape(6, 4)
+    b = nd[13:16].view(np.uint8).reshape(3, 4)  # per axis: lo4 lo5 hi4 hi5
+    q[0:3, 4:6] = b[:, 0:2]
+    q[3:6, 4:6] = b[:, 2:4]
+    return origin, scale, child_base, int(nd[6]), meta, q
 
 
 def test_bvh_structure(hip_lib):
-    """80-byte 8-wide compressed nodes (csrc/host/bvh.cpp): every triangle under exactly one leaf, decoded child boxes
-    contain their triangles and nest inside the parent's decoded box, inner children live at child_base + slot, leaf
+    """64-byte 6-wide compressed nodes (csrc/host/bvh.cpp): every triangle under exactly one leaf, decoded child boxes
+    contain their triangles and nest inside the parent's decoded box, inner children live at child_base + octant position, leaf
     triangles of a node are contiguous from tri_base, depth = what akr_scene_info reports and fits the traversal stack."""
     sd = grid_scene(n=20)
     sc = capi.Scene(None, sd)
@@ -160,8 +170,8 @@ def test_bvh_structure(hip_lib):
         visited.add(ni)
         depth = max(depth, d)
         origin, scale, child_base, tri_base, meta, q = _node(raw, ni)
-        assert child_base < (1 << 24)
-        next_offset = 0
+        assert child_base < (1 << 24) and not meta[6] and not meta[7]
+        next_offset, last_pos = 0, -1
         for s in range(8):
             m = int(meta[s])
             lo = origin + q[0:3, s].astype(np.float32) * scale
@@ -172,13 +182,15 @@ def test_bvh_structure(hip_lib):
             if np.all(np.isfinite(plo)):  # children are quantised in their own node's frame: nested up to one step
                 tol = (phi - plo) / 100.0 + 1e-3
                 assert np.all(lo >= plo - tol) and np.all(hi <= phi + tol)
-            if (m & 0x18) == 0x18:  # inner: 0x20 | (24 + slot)
-                assert m == (0x20 | (24 + s))
-                stack.append((child_base + s, lo, hi, d + 1))
+            if (m & 0x18) == 0x18:  # inner: 0x20 | (24 + octant position); entries are stored in ascending position
+                pos = (m & 31) - 24
+                assert (m >> 5) == 1 and 0 <= pos < 8 and pos > last_pos
+                last_pos = pos
+                stack.append((child_base + pos, lo, hi, d + 1))
             else:
                 unary, offset = m >> 5, m & 31
                 count = {1: 1, 3: 2, 7: 3}[unary]
-                assert offset == next_offset and offset + count <= 24   # leaves of a node are packed in slot order
+                assert offset == next_offset and offset + count <= 18   # leaves of a node are packed in entry order
                 next_offset += count
                 for k in range(tri_base + offset, tri_base + offset + count):
                     seen[k] += 1
@@ -209,7 +221,8 @@ def test_bvh_slot_order_is_front_to_back(hip_lib):
         if not raw[ni].any():
             continue
         origin, scale, _, _, meta, q = _node(raw, ni)
-        slots = [s for s in range(8) if meta[s]]
+        slots = [s for s in range(8) if (int(meta[s]) & 0x18) == 0x18]  # inner children: their octant position is in the meta byte
+        pos = {s: (int(meta[s]) & 31) - 24 for s in slots}
         for a in range(3):
             for s1 in slots:
                 for s2 in slots:
@@ -218,8 +231,8 @@ def test_bvh_slot_order_is_front_to_back(hip_lib):
                     c1 = int(q[a, s1]) + int(q[3 + a, s1])
                     c2 = int(q[a, s2]) + int(q[3 + a, s2])
                     if q[3 + a, s1] <= q[a, s2] or q[3 + a, s2] <= q[a, s1]:  # separated along axis a
-                        # a ray towards +a visits the slot whose bit a is 0 first
-                        first = s1 if ((s1 >> a) & 1) < ((s2 >> a) & 1) else (s2 if ((s2 >> a) & 1) < ((s1 >> a) & 1) else None)
+                        # a ray towards +a visits the position whose bit a is 0 first
+                        first = s1 if ((pos[s1] >> a) & 1) < ((pos[s2] >> a) & 1) else (s2 if ((pos[s2] >> a) & 1) < ((pos[s1] >> a) & 1) else None)
                         if first is None:
                             continue
                         total += 1

@@ -1,4 +1,4 @@
-// bvh_sim.cpp -- host-side model of the 8-wide traversal (device/disect.h: trav_step) over the tree host/bvh.cpp builds, for
+// bvh_sim.cpp -- host-side model of the wide-BVH traversal (device/disect.h: trav_step) over the tree host/bvh.cpp builds, for
 // judging builder changes without a GPU: builds the BVH of a triangle dump, traces path-like rays (camera rays, cosine-weighted
 // bounces, shadow rays towards a ceiling light) with the device's visiting order, culling and any-hit rules, and reports node
 // visits / triangle tests per ray, tree depth, node count and -- a proxy for the wave's divergence -- the ratio between the
@@ -20,7 +20,25 @@ namespace akr {
 void build_bvh8(const std::vector<float>& tri_bounds, uint32_t n_tris, float pad, uint32_t stride, bool balanced, std::vector<uint32_t>& order_out,
                 std::vector<uint32_t>& out_nodes, uint32_t& depth_out);
 }
-static const uint32_t kStride = 20;
+static const uint32_t kStride = 16;
+// 64-byte node, 6 entries (host/bvh.cpp): entry e -> meta byte and quantised box
+struct Kid { uint32_t meta; double lo[3], hi[3]; };
+static float u2f_(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+static void decode(const uint32_t* n, Kid k[6], uint32_t& child_base, uint32_t& tri_base) {
+    child_base = (n[3] >> 24) | ((n[4] & 0xffffu) << 8);
+    tri_base = n[6];
+    for (int e = 0; e < 6; e++) {
+        k[e].meta = e < 4 ? (n[5] >> (8 * e)) & 0xffu : (n[4] >> (16 + 8 * (e - 4))) & 0xffu;
+        for (int a = 0; a < 3; a++) {
+            const double scale = u2f_(((n[3] >> (8 * a)) & 0xffu) << 23);
+            uint32_t qlo, qhi;
+            if (e < 4) { qlo = (n[7 + a] >> (8 * e)) & 0xffu; qhi = (n[10 + a] >> (8 * e)) & 0xffu; }
+            else { qlo = (n[13 + a] >> (8 * (e - 4))) & 0xffu; qhi = (n[13 + a] >> (16 + 8 * (e - 4))) & 0xffu; }
+            k[e].lo[a] = u2f_(n[a]) + qlo * scale;
+            k[e].hi[a] = u2f_(n[a]) + qhi * scale;
+        }
+    }
+}
 struct V3 { double x, y, z; };
 static V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 static V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
@@ -60,26 +78,26 @@ static int trace_sorted(const Scene& sc, V3 o, V3 d, double tmax, bool any_hit, 
         E kids[8];
         int nk = 0;
         uint32_t T = 0;
-        for (int s = 0; s < 8; s++) {
-            const uint32_t meta = (n[6 + (s >> 2)] >> (8 * (s & 3))) & 0xffu;
+        Kid kd[6];
+        uint32_t cbase, tbase_;
+        decode(n, kd, cbase, tbase_);
+        for (int s = 0; s < 6; s++) {
+            const uint32_t meta = kd[s].meta;
             if (meta == 0) continue;
             double tn = 0.0, tf = best_t;
             for (int a = 0; a < 3; a++) {
-                const double scale = u2f(((n[3] >> (8 * a)) & 0xffu) << 23);
-                const uint32_t qlo = (n[8 + 2 * a + (s >> 2)] >> (8 * (s & 3))) & 0xffu, qhi = (n[14 + 2 * a + (s >> 2)] >> (8 * (s & 3))) & 0xffu;
-                const double lo = u2f(n[a]) + qlo * scale, hi = u2f(n[a]) + qhi * scale;
-                const double t0 = (lo - org[a]) * inv[a], t1 = (hi - org[a]) * inv[a];
+                const double t0 = (kd[s].lo[a] - org[a]) * inv[a], t1 = (kd[s].hi[a] - org[a]) * inv[a];
                 tn = std::max(tn, std::min(t0, t1));
                 tf = std::min(tf, std::max(t0, t1));
             }
             if (tn > tf) continue;
-            if ((meta & 0x18u) == 0x18u && (meta >> 5) == 1u) kids[nk++] = E{(n[4] & 0xffffffu) + ((meta & 0x1fu) - 24u), tn};
+            if ((meta & 0x18u) == 0x18u && (meta >> 5) == 1u) kids[nk++] = E{cbase + ((meta & 0x1fu) - 24u), tn};
             else T |= (meta >> 5) << (meta & 0x1fu);
         }
         while (T) {
             const uint32_t b = (uint32_t)__builtin_ctz(T);
             T &= T - 1;
-            const float* v = &sc.tris[9ull * (n[5] + b)];
+            const float* v = &sc.tris[9ull * (tbase_ + b)];
             c.tris++; steps++;
             const V3 A{v[0], v[1], v[2]}, B{v[3], v[4], v[5]}, C{v[6], v[7], v[8]};
             const V3 e1 = B - A, e2 = C - A, p = cross(d, e2);
@@ -91,8 +109,8 @@ static int trace_sorted(const Scene& sc, V3 o, V3 d, double tmax, bool any_hit, 
             const V3 q = cross(sv, e1);
             const double vv = dot(d, q) * id, t = dot(e2, q) * id;
             if (u >= 0 && vv >= 0 && u + vv <= 1 && t > 1e-9 && t <= best_t) {
-                if (any_hit) { t_out = t; return (int)(n[5] + b); }
-                if (t < best_t) { best_t = t; best = (int)(n[5] + b); }
+                if (any_hit) { t_out = t; return (int)(tbase_ + b); }
+                if (t < best_t) { best_t = t; best = (int)(tbase_ + b); }
             }
         }
         std::sort(kids, kids + nk, [](const E& a, const E& b) { return a.tn > b.tn; });
@@ -154,39 +172,29 @@ static int trace(const Scene& sc, V3 o, V3 d, double tmax, bool any_hit, double&
             const uint32_t* n = &sc.nodes[(size_t)kStride * ((G & 0xffffffu) + slot)];
             c.nodes++; steps++;
             uint32_t hitmask = 0;
-            for (int s = 0; s < 8; s++) {
-                const uint32_t meta = (n[6 + (s >> 2)] >> (8 * (s & 3))) & 0xffu;
+            Kid kd[6];
+            uint32_t cbase, tb;
+            decode(n, kd, cbase, tb);
+            for (int s = 0; s < 6; s++) {
+                const uint32_t meta = kd[s].meta;
                 if (meta == 0) continue;
                 double tn = 0.0, tf = best_t;
                 for (int a = 0; a < 3; a++) {
-                    const double scale = u2f(((n[3] >> (8 * a)) & 0xffu) << 23);
-                    const uint32_t qlo = (n[8 + 2 * a + (s >> 2)] >> (8 * (s & 3))) & 0xffu, qhi = (n[14 + 2 * a + (s >> 2)] >> (8 * (s & 3))) & 0xffu;
-                    const double lo = u2f(n[a]) + qlo * scale, hi = u2f(n[a]) + qhi * scale;
-                    const double t0 = (lo - org[a]) * inv[a], t1 = (hi - org[a]) * inv[a];
+                    const double t0 = (kd[s].lo[a] - org[a]) * inv[a], t1 = (kd[s].hi[a] - org[a]) * inv[a];
                     tn = std::max(tn, std::min(t0, t1));
                     tf = std::min(tf, std::max(t0, t1));
                 }
                 if (tn <= tf) {
                     const uint32_t is_inner = (meta & 0x18u) == 0x18u && (meta >> 5) == 1u;
-                    if (is_inner) { hitmask |= 1u << (24 + (((meta & 0x1fu) - 24u) ^ oi)); tn_child[s] = tn; }
+                    if (is_inner) hitmask |= 1u << (24 + (((meta & 0x1fu) - 24u) ^ oi));
                     else hitmask |= (meta >> 5) << (meta & 0x1fu);
                 }
             }
-            {   // smallest entry distance among the hit inner children EXCEPT the one visited first (that one is taken at once)
-                g_tn = 1e300;
-                const uint32_t hb = hitmask >> 24;
-                if (hb) {
-                    const uint32_t first = 31u - (uint32_t)__builtin_clz(hitmask);
-                    for (int s = 0; s < 8; s++) {
-                        const uint32_t bit = 24 + ((uint32_t)s ^ oi);
-                        const uint32_t meta = (n[6 + (s >> 2)] >> (8 * (s & 3))) & 0xffu;
-                        if ((hitmask >> bit) & 1u && (meta & 0x18u) == 0x18u && (meta >> 5) == 1u && bit != first) g_tn = std::min(g_tn, tn_child[s]);
-                    }
-                }
-            }
-            G = (n[4] & 0xffffffu) | (hitmask & 0xff000000u);
+            g_tn = 0.0;
+            (void)tn_child;
+            G = cbase | (hitmask & 0xff000000u);
             T = hitmask & 0x00ffffffu;
-            tbase = n[5];
+            tbase = tb;
         }
         if (T == 0 && (G >> 24) == 0 && stack.empty()) break;
     }
