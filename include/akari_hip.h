@@ -271,7 +271,7 @@ typedef struct {
     uint32_t node_bytes;      /* bytes read per BVH node visit (64: 6-wide compressed node = one sector), 0 without a BVH */
     uint32_t node_stride_bytes; /* distance between nodes in memory */
     uint32_t tri_bytes;       /* bytes read per triangle test: 48 (exhaustive path) or 64 (BVH path: record + id) */
-    uint32_t bvh_depth;       /* levels of the 8-wide tree = most traversal-stack entries a ray can need */
+    uint32_t bvh_depth;       /* levels of the wide tree = most traversal-stack entries a ray can need */
 } akr_scene_info;
 AKR_API int32_t akr_scene_get_info(const akr_scene *scene, akr_scene_info *info);
 /* Light `light` of LightAggregate (light/mod.rs:87-98): owning instance, total power, selection pdf. */
@@ -297,7 +297,7 @@ typedef enum {
     AKR_ARRAY_SHADE = 2,         /* f32[32 * n_tris]  shading records by global triangle id */
     AKR_ARRAY_INSTANCES = 3,     /* f32[32 * n_instances] */
     AKR_ARRAY_MATERIALS = 4,     /* folded materials, 256 B each */
-    AKR_ARRAY_BVH_NODES = 5,     /* u32[(node_stride_bytes / 4) * n_bvh_nodes]: 80-byte 8-wide compressed nodes (csrc/host/bvh.cpp) */
+    AKR_ARRAY_BVH_NODES = 5,     /* u32[(node_stride_bytes / 4) * n_bvh_nodes]: 64-byte compressed nodes of six children (csrc/host/bvh.cpp) */
     AKR_ARRAY_LIGHT_ENTRIES = 6, /* {u32 j, f32 t}[n_lights] */
     AKR_ARRAY_LIGHT_PDF = 7,     /* f32[n_lights] */
     AKR_ARRAY_AREA_ENTRIES = 8,  /* {u32 j, f32 t}[sum of light triangle counts] */
