@@ -148,6 +148,9 @@ class PtConfig(_Struct):
         ("shard_count", C.c_uint32),
         ("tile_w", C.c_uint32),
         ("tile_h", C.c_uint32),
+        # samples [sample_begin, sample_begin + sample_count) of the spp of the whole render; count 0 = all. Index-based samplers only.
+        ("sample_begin", C.c_uint32),
+        ("sample_count", C.c_uint32),
     ]
 
     @staticmethod

@@ -543,7 +543,16 @@ static void validate_config(const akr_pt_config& c) {
     uint32_t tw = c.tile_w ? c.tile_w : 32, th = c.tile_h ? c.tile_h : 32;
     if ((tw % 8) || (th % 8)) throw std::invalid_argument("akr_pt_config: tile_w and tile_h must be multiples of 8");
     if (c.shard_count > 1 && c.shard_rank >= c.shard_count) throw std::invalid_argument("akr_pt_config: shard_rank >= shard_count");
+    if (c.sample_begin != 0 || c.sample_count != 0) {  // sample-range split (akari_hip.h)
+        if (c.sampler_type != AKR_SAMPLER_PMJ02BN && c.sampler_type != AKR_SAMPLER_SOBOL)
+            throw Unsupported("akr_pt_config: a sample range needs an index-based sampler (pmj02bn, sobol): the independent sampler's start() advances the pixel's "
+                              "PCG stream from wherever the previous sample stopped (sampler/mod.rs:115-131,192-203), sample s cannot be drawn without samples 0 .. s-1");
+        if (c.sample_count == 0) throw std::invalid_argument("akr_pt_config: sample_begin without sample_count");
+        if ((uint64_t)c.sample_begin + c.sample_count > c.spp) throw std::invalid_argument("akr_pt_config: sample range exceeds spp");
+    }
 }
+// samples the session renders: the configured range, or all spp of the render
+static uint32_t session_samples(const akr_pt_config& c) { return c.sample_count ? c.sample_count : c.spp; }
 
 extern "C" {
 
@@ -923,7 +932,9 @@ AKR_API int32_t akr_pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_co
             if (cfg->sampler_type == AKR_SAMPLER_PMJ02BN) ctx->ensure_pmj_tables();
             se->pmj_spp = cfg->spp ? cfg->spp : 1;
             std::vector<Pcg32> init(n);
-            for (uint64_t i = 0; i < n; i++) init[i] = Pcg32{0xffffffffull, (i % film->width) | ((i / film->width) << 32)};
+            // a sample range [b, ..) starts with sample_index = b - 1: the next start() makes it b (sampler/mod.rs:650-663)
+            const uint64_t first = cfg->sample_begin ? (uint64_t)(cfg->sample_begin - 1u) : 0xffffffffull;
+            for (uint64_t i = 0; i < n; i++) init[i] = Pcg32{first, (i % film->width) | ((i / film->width) << 32)};
             se->states.upload(init);
         } else {
             std::vector<uint64_t> seeds(n);
@@ -955,10 +966,11 @@ AKR_API int32_t akr_pt_passes(akr_pt_session* se, uint32_t n_passes, int32_t blo
         // of at most kMaxFusedPasses passes
         const uint32_t kMaxFusedPasses = 16;
         uint32_t left = n_passes;
-        while (left > 0 && se->spp_done < se->cfg.spp) {
+        const uint32_t total = session_samples(se->cfg);
+        while (left > 0 && se->spp_done < total) {
             uint32_t fused = 0, last = 0, done = se->spp_done;
-            while (fused < kMaxFusedPasses && fused < left && done < se->cfg.spp) {
-                last = std::min(se->cfg.spp - done, se->cfg.spp_per_pass);
+            while (fused < kMaxFusedPasses && fused < left && done < total) {
+                last = std::min(total - done, se->cfg.spp_per_pass);
                 done += last;
                 fused++;
             }
@@ -1021,7 +1033,7 @@ AKR_API int32_t akr_pt_render(akr_context* ctx, akr_scene* scene, const akr_pt_c
     akr_pt_session* se = nullptr;
     int32_t rc = akr_pt_begin(ctx, scene, cfg, film, &se);
     if (rc != AKR_OK) return rc;
-    uint32_t n_passes = (cfg->spp + cfg->spp_per_pass - 1) / cfg->spp_per_pass;
+    uint32_t n_passes = (session_samples(*cfg) + cfg->spp_per_pass - 1) / cfg->spp_per_pass;
     rc = akr_pt_passes(se, n_passes, 1, nullptr);
     std::string err = g_last_error;
     int32_t rc2 = akr_pt_end(se, stats);

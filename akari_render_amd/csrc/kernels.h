@@ -26,6 +26,9 @@ namespace akr {
 #ifndef AKR_BVH_TILE
 #define AKR_BVH_TILE 1  // BVH kernels: 1 = the top of the tree in LDS (disect.h: TILE), as many nodes as launch_pt_pass finds room for
 #endif
+#ifndef AKR_PT_XCD_BANDS
+#define AKR_PT_XCD_BANDS 0  // BVH kernels: 1 = XCD x renders the x-th contiguous eighth of the launch's work items (pt_kernels.hip)
+#endif
 #ifndef AKR_PT_STRAGGLERS
 #define AKR_PT_STRAGGLERS 8  // BVH kernels: n > 0 = an intersection phase ends when at most 1/n of the lanes that entered it are still
                              // tracing; those lanes keep their traversal and go on in the next phase (see k_pt_pass)

@@ -67,7 +67,17 @@ __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT
         __syncthreads();
         lds_recs = (const float4*)l;
     }
-    const uint32_t item = blockIdx.x * 256u + threadIdx.x;
+    // Which 256 work items a workgroup takes. Workgroups are dealt to the chip's 8 XCDs round-robin (workgroup b runs on XCD b % 8)
+    // and every XCD has its own 4 MiB L2: with the identity mapping each XCD sees every eighth 32x8-pixel strip of the whole frame,
+    // so all eight L2s hold the same mix of the scene. BANDS gives XCD x the x-th contiguous eighth of the item space (items
+    // enumerate the rank's tiles in row-major order: a horizontal band of the image), so that an L2 only has to hold the part of
+    // the tree its band's rays walk. Only the assignment of pixels to workgroups changes: films are the same bit for bit.
+    uint32_t vblock = blockIdx.x;
+    if (BVH && AKR_PT_XCD_BANDS) {
+        const uint32_t nb = gridDim.x, xcd = blockIdx.x & 7u, local = blockIdx.x >> 3;
+        vblock = xcd * (nb >> 3) + (xcd < (nb & 7u) ? xcd : (nb & 7u)) + local;
+    }
+    const uint32_t item = vblock * 256u + threadIdx.x;
     uint32_t px = 0, py = 0;
     const bool in_frame = item < p.n_items && item_to_pixel(p, item, px, py);
     const uint32_t pix = px + py * p.width;

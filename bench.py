@@ -15,7 +15,10 @@ frame with the full Cycles-subset shader graph (configs[2]; its 4096 spp are 4 s
 Prints ONE JSON line on rank 0. N > 1: the path shards by pixel tiles (32x32, round-robin over the ranks; a pixel's sample
 stream does not depend on who renders it), the image is the same for every N ("scaling": "strong", the default), and the
 films are sum-reduced onto rank 0 over RCCL inside the timed region. --scaling weak instead gives every GPU the whole frame
-with its own sampler seed (N independent sample sets; the metric name says so).
+with its own sampler seed (N independent sample sets; the metric name says so). --split samples --sampler sobol shards the
+SAMPLES of every pixel instead of the pixels (akr_pt_config.sample_begin / sample_count: rank r renders samples
+[r S / N, (r + 1) S / N) of all pixels -- perfectly balanced at any resolution; exact only for the index-based samplers, so it
+is a secondary leg (extra_configs.c2_sobol_sample_split) next to the BASELINE configuration, which uses the independent sampler).
 """
 import argparse
 import json
@@ -55,7 +58,7 @@ def algorithmic_bytes(d, fetched=False):
     """SURVEY.md 8(d) byte model: per-event record sizes x device counters. The BVH terms are zero
     for cbox (36 triangles, cache-resident: no node visits are counted) and counted in full for BVH scenes -- at the MODEL's
     record sizes (NODE = 64, TRI = 48), whatever this build's records weigh: fatter records must not raise the score.
-    fetched=True prices them at what a node / triangle step of this build actually fetches (80 / 64 bytes, akr_scene_info)."""
+    fetched=True prices them at what a node / triangle step of this build actually fetches (64 / 64 bytes, akr_scene_info)."""
     nb, tb = (d.get("node_bytes", NODE_BYTES_8D), d.get("tri_bytes", TRI_BYTES_8D)) if fetched else (NODE_BYTES_8D, TRI_BYTES_8D)
     return (56 * d["n_closest"] + 292 * d["n_shaded"] + 64 * d["n_shadow"] + 156 * d["n_samples"] +
             nb * d["n_node_visits"] + (tb * d["n_tri_tests"] if d["n_node_visits"] else 0))
@@ -140,20 +143,21 @@ def cpu_baseline(key, n_threads, cores):
 
 def measured_counters(key):
     """What rocprofv3's PMC passes measured for this launch shape (they cannot run inside this process): the committed
-    summary profiles/r3_pmc_<config>.json (tools/pmc_bench.sh) -- HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate
-    --pmc passes, unit and gfx950 corrections of MI355X_MICROARCH.md "HBM"), VALU busy share, lane utilisation. The summary
+    summary profiles/r4_pmc_<config>.json (tools/pmc_bench.sh) -- HBM bytes per launch (FETCH_SIZE x its calibrated factor +
+    WRITE_SIZE, separate --pmc passes; the factor per access pattern is measured on a known byte count,
+    profiles/r4_fetch_size_calibration.json), VALU busy share, lane utilisation. The summary
     carries the hash of the library sources it was measured on; if that is not the hash of the sources in this tree the
     block is dropped and the line says so. Returns (summary or None, note or None)."""
-    path = os.path.join(ROOT, "profiles", f"r3_pmc_{key}.json")
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_pmc_{key}.json") for r in (4, 3)) if os.path.exists(q)), os.path.join(ROOT, "profiles", f"r4_pmc_{key}.json"))
     if not os.path.exists(path):
-        return None, f"no PMC summary profiles/r3_pmc_{key}.json"
+        return None, f"no PMC summary profiles/r4_pmc_{key}.json"
     try:
         m = json.load(open(path))
     except Exception as ex:  # noqa: BLE001
         return None, f"unreadable PMC summary: {ex}"
     have, want = m.get("csrc_hash"), csrc_hash()
     if have != want:
-        return None, f"PMC summary profiles/r3_pmc_{key}.json was measured on other kernel sources (csrc hash {have}, this tree {want}): not quoted"
+        return None, f"PMC summary {os.path.relpath(path, ROOT)} was measured on other kernel sources (csrc hash {have}, this tree {want}): not quoted"
     return m, None
 
 
@@ -178,68 +182,143 @@ def build_scene(ctx, key):
                    "generate_s": t1 - t0, "compile_upload_s": time.time() - t1}
 
 
-def make_native_comm(ctx, rank, world, torch, dist, dev):
-    """The library's own RCCL communicator (akr_comm_create): rank 0's unique id travels over torch.distributed, which is
-    already up for the barrier and the timing reduction. Returns None on every rank if any rank could not create it."""
+def _with_deadline(fn, seconds):
+    """Runs fn() in a daemon thread; returns (finished, result or exception). A call that does not come back in time is
+    abandoned (the thread may still be stuck inside RCCL): the caller must not touch what it was working on again."""
+    import threading
+
+    box = {}
+
+    def work():
+        try:
+            box["result"] = fn()
+        except BaseException as ex:  # noqa: BLE001
+            box["error"] = ex
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        return False, TimeoutError(f"no answer after {seconds:.0f} s")
+    if "error" in box:
+        return True, box["error"]
+    return True, box.get("result")
+
+
+def make_native_comm(ctx, rank, world, torch, dist, dev, local_rank, deadline_s):
+    """The library's own RCCL communicator (akr_comm_create) + ONE warm-up reduce of a full-size film through it, under a
+    wall-clock deadline: rank 0's unique id travels over torch.distributed, which is already up for the barrier and the timing
+    reduction. Returns (comm or None, ctx, note). akr_film_reduce with more than one rank has never run before the first
+    multi-GPU node appears, so nothing here may stall the run: if creation or the warm-up reduce fails or does not return
+    within the deadline on ANY rank, every rank drops the communicator AND the context whose stream the stuck call may still
+    occupy, makes a fresh context, and the films are reduced with torch.distributed instead (config.film_reduce says which)."""
     from akari_render_amd import capi
 
-    comm, ok = None, 1
-    try:
+    def create_and_warm():
         box = [capi.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         comm = capi.Comm(ctx, box[0], rank, world)
-    except Exception as ex:  # noqa: BLE001
-        log(f"rank {rank}: native RCCL communicator unavailable ({ex}); falling back to torch.distributed.reduce")
-        ok = 0
+        scratch = torch.zeros(7 * W * H, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize(dev)
+        sf = capi.Film(ctx, W, H, device_ptr=scratch.data_ptr())
+        comm.reduce_film(sf, root=0, blocking=True)  # RCCL builds its rings / proxy connections on the first reduce of a size
+        del sf
+        return comm
+
+    finished, res = _with_deadline(create_and_warm, deadline_s)
+    ok = 1 if (finished and not isinstance(res, BaseException)) else 0
+    note = None
+    if not ok:
+        note = f"rank {rank}: akr_comm_create / first akr_film_reduce: {type(res).__name__}: {res}"
+        log(note + " -- falling back to torch.distributed.reduce")
     flag = torch.tensor([ok], dtype=torch.int32, device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if int(flag.item()) == 0:
-        if comm is not None:
-            comm.close()
-        return None
-    return comm
+    if int(flag.item()) == 1:
+        return res, ctx, None
+    if ok:
+        try:
+            res.close()
+        except Exception:  # noqa: BLE001
+            pass
+    # a reduce that never returned still sits on the old context's stream: render on a new one
+    return None, capi.Context(local_rank), (note or "another rank could not create the native communicator")
+
+
+class LegSkipped(RuntimeError):
+    pass
+
+
+def agree(ok, world, torch, dist, cdev):
+    """True iff every rank says ok. Called before a leg enters its collectives: a rank that failed to set the leg up (e.g. out of
+    memory on the 4K film) must not leave the others waiting in a reduce."""
+    if world <= 1:
+        return bool(ok)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=cdev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return int(flag.item()) == 1
 
 
 _SCENES = {}  # (config key, forced BVH) -> (scene, info): the 10 M-triangle hall takes 20 s to generate and compile
 
 
 def run_config(ctx, key, steps, warmup, rank, world, scaling, film_t, torch, dist, backend, dev, comm=None, passes_per_step=PASSES_PER_STEP,
-               force_bvh=False, keep_scene=False):
-    """Times `steps` steps of configuration `key` on this rank. Returns (elapsed_s, per-rank counter deltas, extra info)."""
+               force_bvh=False, keep_scene=False, split="tiles", sampler="independent"):
+    """Times `steps` steps of configuration `key` on this rank. Returns (elapsed_s, per-rank counter deltas, extra info).
+    split = "tiles": rank r renders the pixel tiles t % world == r. split = "samples" (index-based samplers only): rank r renders
+    samples [r S / world, (r + 1) S / world) of EVERY pixel, S = the run's total spp (akr_pt_config.sample_begin / sample_count)."""
     from akari_render_amd import abi, capi, distributed
 
-    if (key, force_bvh) in _SCENES:
-        scene, sinfo = _SCENES[(key, force_bvh)]
-        sinfo = dict(sinfo)
-    else:
-        with capi.options(force_bvh=1 if force_bvh else 0):
-            scene, sinfo = build_scene(ctx, key)
-        if keep_scene:
-            _SCENES[(key, force_bvh)] = (scene, dict(sinfo))
-    w, h = resolution(key)
-    if film_t.numel() != 7 * w * h:  # a configuration with its own frame size (C5: 3840x2160) renders into its own film
-        film_t = torch.zeros(7 * w * h, dtype=torch.float32, device=dev)
-    film_t.zero_()
-    torch.cuda.synchronize(dev)
-    film = capi.Film(ctx, w, h, device_ptr=film_t.data_ptr())
-    cfg = abi.PtConfig.default()
-    cfg.spp = (warmup + steps) * SPP_PER_PASS * passes_per_step
-    cfg.spp_per_pass, cfg.max_depth, cfg.rr_depth, cfg.use_nee = SPP_PER_PASS, 12, 5, 1
-    cfg.force_diffuse = CONFIGS[key]["force_diffuse"]
-    cfg.filter_type, cfg.filter_radius = abi.FILTER_GAUSSIAN, 1.5
+    cdev = dev if backend == "nccl" else torch.device("cpu")
     weak = world > 1 and scaling == "weak"
-    if weak:
-        cfg.sampler_seed = rank  # independent sample set per GPU (sampler/mod.rs:148-160 seeds the per-pixel streams from it)
-    else:
-        cfg.sampler_seed = 0
-        cfg = distributed.shard_config(cfg, rank, world)
-
-    se = capi.PtSession(ctx, scene, cfg, film)
-    if warmup > 0:
-        se.passes(warmup * passes_per_step, blocking=True)
-    if world > 1 and backend == "nccl":
-        # warm the collective up too (RCCL builds its rings / proxy connections on the first reduce of a given size):
-        # same message size as the film, on a scratch buffer, outside the timed region
+    by_samples = world > 1 and split == "samples" and not weak
+    setup_error = None
+    try:
+        if (key, force_bvh) in _SCENES:
+            scene, sinfo = _SCENES[(key, force_bvh)]
+            sinfo = dict(sinfo)
+        else:
+            with capi.options(force_bvh=1 if force_bvh else 0):
+                scene, sinfo = build_scene(ctx, key)
+            if keep_scene:
+                _SCENES[(key, force_bvh)] = (scene, dict(sinfo))
+        w, h = resolution(key)
+        if film_t.numel() != 7 * w * h:  # a configuration with its own frame size (C5: 3840x2160) renders into its own film
+            film_t = torch.zeros(7 * w * h, dtype=torch.float32, device=dev)
+        film_t.zero_()
+        torch.cuda.synchronize(dev)
+        film = capi.Film(ctx, w, h, device_ptr=film_t.data_ptr())
+        cfg = abi.PtConfig.default()
+        cfg.spp = (warmup + steps) * SPP_PER_PASS * passes_per_step
+        cfg.spp_per_pass, cfg.max_depth, cfg.rr_depth, cfg.use_nee = SPP_PER_PASS, 12, 5, 1
+        cfg.force_diffuse = CONFIGS[key]["force_diffuse"]
+        cfg.filter_type, cfg.filter_radius = abi.FILTER_GAUSSIAN, 1.5
+        cfg.sampler_type = {"independent": abi.SAMPLER_INDEPENDENT, "sobol": abi.SAMPLER_SOBOL, "pmj02bn": abi.SAMPLER_PMJ02BN}[sampler]
+        my_passes = passes_per_step
+        if weak:
+            cfg.sampler_seed = rank  # independent sample set per GPU (sampler/mod.rs:148-160 seeds the per-pixel streams from it)
+        elif by_samples:
+            if passes_per_step % world:
+                raise ValueError(f"--split samples: {passes_per_step} passes per step do not divide over {world} ranks")
+            my_passes = passes_per_step // world
+            cfg.sampler_seed = 0
+            cfg.sample_count = (warmup + steps) * SPP_PER_PASS * my_passes
+            cfg.sample_begin = rank * cfg.sample_count
+        else:
+            cfg.sampler_seed = 0
+            cfg = distributed.shard_config(cfg, rank, world)
+        se = capi.PtSession(ctx, scene, cfg, film)
+        if warmup > 0:
+            se.passes(warmup * my_passes, blocking=True)
+    except Exception as ex:  # noqa: BLE001
+        setup_error = ex
+    if not agree(setup_error is None, world, torch, dist, cdev):
+        if setup_error is not None:
+            raise setup_error
+        raise LegSkipped("another rank could not set this leg up")
+    if world > 1 and backend == "nccl" and (comm is None or (w, h) != (W, H)):
+        # warm the collective up too (RCCL builds its rings / proxy connections on the first reduce of a given size): same
+        # message size as the film, on a scratch buffer, outside the timed region (the native communicator's 1080p warm-up
+        # happened under a deadline when it was created, make_native_comm)
         scratch = torch.zeros_like(film_t)
         torch.cuda.synchronize(dev)
         if comm is not None:
@@ -260,7 +339,7 @@ def run_config(ctx, key, steps, warmup, rank, world, scaling, film_t, torch, dis
 
     sync()
     t0 = time.perf_counter()
-    se.passes(steps * passes_per_step, blocking=True)
+    se.passes(steps * my_passes, blocking=True)
     t_rendered = time.perf_counter()
     if world > 1:
         if backend == "gloo":
@@ -288,8 +367,11 @@ def run_config(ctx, key, steps, warmup, rank, world, scaling, film_t, torch, dis
     d["node_bytes"] = int(getattr(info, "node_bytes", 64) or 64)
     d["tri_bytes"] = int(getattr(info, "tri_bytes", 48) or 48)
     sinfo["weak"] = weak
-    sinfo["film_reduce"] = "none (one GPU)" if world == 1 else ("akr_film_reduce (RCCL through the C ABI)" if comm is not None else f"torch.distributed.reduce ({backend})")
+    sinfo["film_reduce"] = ("none (one GPU)" if world == 1 else
+                            "akr_film_reduce (ncclReduce over RCCL through the C ABI)" if (comm is not None and backend == "nccl") else
+                            f"torch.distributed.reduce ({'RCCL' if backend == 'nccl' else 'gloo, through host memory'})")
     sinfo["spp_done"] = (warmup + steps) * SPP_PER_PASS * passes_per_step
+    sinfo["film_tensor"] = film_t
     del film, scene
     return t1 - t0, d, sinfo
 
@@ -318,7 +400,7 @@ def roofline_block(key, d):
         "algorithmic_bytes_per_launch": bytes_per_launch,
         "algorithmic_bytes_per_sample": model_bytes / max(1, d["n_samples"]),
     }
-    if d["n_node_visits"]:  # what this build's 80-byte nodes and 64-byte triangle records make of the same counters (not the score)
+    if d["n_node_visits"]:  # what this build's 64-byte nodes and 64-byte triangle records make of the same counters (not the score)
         out["fetched_bytes_frac"] = algorithmic_bytes(d, fetched=True) / launches / avg_launch_s / 1e9 / HBM_PEAK_GBS
         rays = max(1, d["n_closest"] + d["n_shadow"])
         out["nodes_per_ray"] = d["n_node_visits"] / rays
@@ -341,6 +423,9 @@ def roofline_block(key, d):
     return out
 
 
+_NOT_REPORTED = ("weak", "spp_done", "film_tensor")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -354,15 +439,25 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong (default) = the ONE frame's 32x32 pixel tiles round-robin over the GPUs, identical image for "
                          "every N; weak = every GPU renders the whole frame with its own sampler seed (N independent sample sets)")
+    ap.add_argument("--split", default="tiles", choices=["tiles", "samples"],
+                    help="N > 1, strong scaling: what is sharded. tiles (default) = pixels; samples = rank r renders samples "
+                         "[r S / N, (r + 1) S / N) of every pixel (needs --sampler sobol | pmj02bn: akr_pt_config.sample_begin / _count)")
+    ap.add_argument("--sampler", default="independent", choices=["independent", "sobol", "pmj02bn"],
+                    help="independent = BASELINE's configuration (default)")
     ap.add_argument("--reduce", default="native", choices=["native", "torch"],
                     help="N > 1: native = akr_film_reduce (the library's own RCCL call, csrc/host/comm.cpp; falls back to torch if the "
-                         "communicator cannot be created), torch = torch.distributed.reduce on the film tensor")
+                         "communicator cannot be created or its first reduce does not return), torch = torch.distributed.reduce on the film tensor")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only for smoke-testing the "
                          "multi-rank path on a box with fewer GPUs than ranks: all ranks then share device 0)")
+    ap.add_argument("--comm-deadline", type=float, default=120.0, help="seconds akr_comm_create + the first akr_film_reduce may take before the run falls back to --reduce torch")
+    ap.add_argument("--legs-deadline", type=float, default=900.0, help="seconds the secondary legs (extra_configs, CPU baseline) may take after the "
+                                                                        "headline is measured; past it rank 0 prints the headline line without them")
     args = ap.parse_args()
     if args.full_graph:
         args.config = "c3"
+    if args.split == "samples" and args.sampler == "independent":
+        ap.error("--split samples needs an index-based sampler (--sampler sobol | pmj02bn): the independent sampler's per-pixel PCG stream is sequential")
 
     import torch
 
@@ -378,16 +473,20 @@ def main():
         distributed.init_process_group(args.backend)
     import torch.distributed as dist
 
-    ctx = capi.Context(local_rank if world > 1 else 0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev_index = local_rank if world > 1 else 0
+    ctx = capi.Context(dev_index)
+    dev = torch.device("cuda", dev_index)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")
     film_t = torch.zeros(7 * W * H, dtype=torch.float32, device=dev)
     key = args.config
-    comm = make_native_comm(ctx, rank, world, torch, dist, dev) if (world > 1 and args.backend == "nccl" and args.reduce == "native") else None
-    elapsed, d, sinfo = run_config(ctx, key, args.steps, args.warmup, rank, world, args.scaling, film_t, torch, dist, args.backend, dev, comm)
+    comm, comm_note = None, None
+    if world > 1 and args.backend == "nccl" and args.reduce == "native":
+        comm, ctx, comm_note = make_native_comm(ctx, rank, world, torch, dist, dev, dev_index, args.comm_deadline)
+    elapsed, d, sinfo = run_config(ctx, key, args.steps, args.warmup, rank, world, args.scaling, film_t, torch, dist, args.backend, dev, comm,
+                                   split=args.split, sampler=args.sampler)
     weak = sinfo["weak"]
 
     if world > 1:
-        cdev = dev if args.backend == "nccl" else torch.device("cpu")
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -404,30 +503,8 @@ def main():
     n_sets = world if weak else 1
     assert total_samples == n_sets * W * H * SPP_PER_STEP * args.steps, (total_samples, n_sets * W * H * SPP_PER_STEP * args.steps)
 
-    # Two more legs at EVERY N (all ranks take part; one step each, outside the timed region of the headline):
-    #  c5            BASELINE configs[4]: the 3840x2160 frame, full graph, its tiles over the N ranks -- the configuration the
-    #                reference's multi-GPU target is written for; 4x the pixels per rank of the 1080p frame (at N = 8 a rank of the
-    #                1080p frame holds 2.2 waves per SIMD of long-running pixels, of the 4K frame 8.8)
-    #  weak          N > 1: every rank renders the whole 1080p frame with its own sampler seed (N independent sample sets)
-    multi = {}
-    if args.also != "none" and key == "c2":
-        for name, k2, scal in (("c5_strong", "c5", "strong"),) + ((("c2_weak", "c2", "weak"),) if world > 1 else ()):
-            try:
-                # (its own film: the headline's film is checked below)
-                e2, d2, si2 = run_config(ctx, k2, 1, 1 if world > 1 else 0, rank, world, scal, torch.zeros(1, dtype=torch.float32, device=dev), torch, dist,
-                                         args.backend, dev, comm)
-                n2 = d2["n_samples"]
-                if world > 1:
-                    cdev2 = dev if args.backend == "nccl" else torch.device("cpu")
-                    t2 = torch.tensor([e2, float(n2)], dtype=torch.float64, device=cdev2)
-                    tmax = t2.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-                    tsum = t2.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-                    e2, n2 = float(tmax[0].item()), int(tsum[1].item())
-                multi[name] = {"metric": "Msamples/s (whole node), " + CONFIGS[k2]["name"] + (" -- weak scaling: N independent sample sets" if scal == "weak" else ""),
-                               "value": n2 / e2 / 1e6, "unit": "Msamples/s", "n_gpus": args.gpus, "scaling": scal, "steps": 1, "ms_per_step": e2 * 1e3,
-                               "resolution": list(resolution(k2)), "workload": CONFIGS[k2]["workload"]}
-            except Exception as ex:  # noqa: BLE001 -- a secondary leg must not cost the headline line
-                multi[name] = {"error": f"{type(ex).__name__}: {ex}"}
+    # ---- the headline line is complete HERE, before any secondary leg runs: whatever happens below, rank 0 can print it ----
+    out = None
     if rank == 0:
         # frame sanity inside the bench: every pixel got its samples (exact per-pixel comparison), film finite
         expect_w = float(n_sets * sinfo["spp_done"])
@@ -436,6 +513,7 @@ def main():
         assert bool(torch.isfinite(film_t).all().item())
         cfgd = CONFIGS[key]
         scal = "weak" if weak else "strong"
+        by_samples = world > 1 and args.split == "samples" and not weak
         out = {
             "metric": "Msamples/s (whole node), 1080p path tracer, " + cfgd["name"] + (" -- weak scaling: N independent sample sets" if weak else ""),
             "value": total_samples / elapsed / 1e6,
@@ -449,16 +527,18 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic: " + ("scenes/cbox (36 triangles, reference scene data)" if cfgd["scene"] == "cbox" else "procedural hall, generator seed 1234")
-                    + f" at {W}x{H}, independent sampler, seed " + ("= rank" if weak else "0"),
+                    + f" at {W}x{H}, {args.sampler} sampler, seed " + ("= rank" if weak else "0"),
             "config": {
                 "workload": cfgd["workload"] + ", max_depth 12, rr_depth 5, NEE, gaussian filter r=1.5",
                 "baseline_config": f"BASELINE.json configs[{cfgd['baseline_config']}]",
                 "spp_per_step": SPP_PER_STEP,
                 "spp_total": args.steps * SPP_PER_STEP * n_sets,
                 "parallelism": ("single GPU" if args.gpus == 1 else
-                                f"{args.gpus} independent sample sets of {args.steps * SPP_PER_STEP} spp (sampler seed = rank), one per GPU, films sum-reduced (RCCL)" if weak else
-                                f"pixel tiles 32x32 round-robin over {args.gpus} GPUs, film sum-reduce (RCCL)"),
-                **{k: v for k, v in sinfo.items() if k not in ("weak", "spp_done")},
+                                f"{args.gpus} independent sample sets of {args.steps * SPP_PER_STEP} spp (sampler seed = rank), one per GPU, films sum-reduced" if weak else
+                                f"sample ranges: GPU r of {args.gpus} renders samples [r S / N, (r + 1) S / N) of every pixel, film sum-reduce" if by_samples else
+                                f"pixel tiles 32x32 round-robin over {args.gpus} GPUs, film sum-reduce"),
+                **{k: v for k, v in sinfo.items() if k not in _NOT_REPORTED},
+                **({"film_reduce_fallback": comm_note} if comm_note else {}),
                 # per rank over the timed region: kernel time (HIP events), render wall clock, film-reduce wall clock (incl. waiting)
                 "per_rank_kernel_ms": {"max": max(r[0] for r in per_rank), "min": min(r[0] for r in per_rank), "all": [round(r[0], 2) for r in per_rank]},
                 "per_rank_render_wall_ms": {"max": max(r[1] for r in per_rank), "min": min(r[1] for r in per_rank)},
@@ -468,10 +548,67 @@ def main():
             "roofline": roofline_block(key, d),
             "counters": {k: d[k] for k in ("n_samples", "n_closest", "n_shadow", "n_shaded", "n_node_visits", "n_tri_tests")},
         }
+    extra = {}
+    printed = []
+
+    def emit(note=None):
+        if rank == 0 and not printed:
+            printed.append(1)
+            if note:
+                extra["incomplete"] = note
+            if extra:
+                out["extra_configs"] = extra
+            print(json.dumps(out), flush=True)
+
+    # A secondary leg that never comes back (a rank lost inside a collective) must not cost the headline: past the deadline rank 0
+    # prints what it has and every rank leaves.
+    import threading
+
+    def give_up():
+        log(f"rank {rank}: secondary legs did not finish within {args.legs_deadline:.0f} s; printing the headline line without them")
+        emit(f"secondary legs did not finish within {args.legs_deadline:.0f} s")
+        os._exit(0)
+
+    dog = threading.Timer(args.legs_deadline, give_up)
+    dog.daemon = True
+    dog.start()
+
+    # Legs at EVERY N (all ranks take part; one step each, outside the timed region of the headline):
+    #  c5_strong              BASELINE configs[4]: the 3840x2160 frame, full graph, its tiles over the N ranks -- the configuration the
+    #                         reference's multi-GPU target is written for; 4x the pixels per rank of the 1080p frame (at N = 8 a rank of
+    #                         the 1080p frame holds 2.2 waves per SIMD of long-running pixels, of the 4K frame 8.8)
+    #  c2_weak                N > 1: every rank renders the whole 1080p frame with its own sampler seed (N independent sample sets)
+    #  c2_sobol_sample_split  the 1080p frame with the sobol sampler, the SAMPLES of every pixel over the ranks (at N = 1: the same
+    #                         frame on one GPU, the number the split's speed-up is measured against)
+    if args.also != "none" and key == "c2" and args.split == "tiles" and args.sampler == "independent":
+        legs = (("c5_strong", "c5", "strong", "tiles", "independent"),) + ((("c2_weak", "c2", "weak", "tiles", "independent"),) if world > 1 else ())
+        legs += (("c2_sobol_sample_split", "c2", "strong", "samples", "sobol"),)
+        for name, k2, scal2, split2, smp2 in legs:
+            try:
+                e2, d2, si2 = run_config(ctx, k2, 1, 1 if world > 1 else 0, rank, world, scal2, torch.zeros(1, dtype=torch.float32, device=dev), torch, dist,
+                                         args.backend, dev, comm, split=split2, sampler=smp2)
+                n2 = d2["n_samples"]
+                if world > 1:
+                    t2 = torch.tensor([e2, float(n2)], dtype=torch.float64, device=cdev)
+                    tmax = t2.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                    tsum = t2.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+                    e2, n2 = float(tmax[0].item()), int(tsum[1].item())
+                leg = {"metric": "Msamples/s (whole node), " + CONFIGS[k2]["name"] + (" -- weak scaling: N independent sample sets" if scal2 == "weak" else "")
+                                 + (", sobol sampler, sample ranges over the ranks" if split2 == "samples" else ""),
+                       "value": n2 / e2 / 1e6, "unit": "Msamples/s", "n_gpus": args.gpus, "scaling": scal2, "split": split2, "sampler": smp2, "steps": 1,
+                       "ms_per_step": e2 * 1e3, "resolution": list(resolution(k2)), "workload": CONFIGS[k2]["workload"], "film_reduce": si2["film_reduce"]}
+                if rank == 0 and split2 == "samples":  # every pixel holds all S samples after the reduce
+                    w2, h2 = resolution(k2)
+                    wp = si2["film_tensor"][6 * w2 * h2:]
+                    leg["weight_plane_ok"] = bool((wp == float(si2["spp_done"])).all().item())
+                extra[name] = leg
+                del si2
+            except Exception as ex:  # noqa: BLE001 -- a secondary leg must not cost the headline line
+                extra[name] = {"error": f"{type(ex).__name__}: {ex}"}
+    if rank == 0:
         also = args.also
         if also is None:
             also = "c3,c4" if (args.gpus == 1 and key == "c2") else "none"
-        extra = dict(multi)
         for k2 in [k for k in also.split(",") if k and k != "none" and k != key]:
             try:
                 e2, d2, si2 = run_config(ctx, k2, 1, 0 if k2 == "c4" else 1, 0, 1, "strong", film_t, torch, dist, args.backend, dev, keep_scene=(k2 == "c4"))
@@ -480,7 +617,7 @@ def main():
                              "rays_per_s_G": (d2["n_closest"] + d2["n_shadow"]) / e2 / 1e9,
                              "roofline": roofline_block(k2, d2),
                              "counters": {k: d2[k] for k in ("n_samples", "n_closest", "n_shadow", "n_shaded", "n_node_visits", "n_tri_tests")},
-                             **{k: v for k, v in si2.items() if k not in ("weak", "spp_done")}}
+                             **{k: v for k, v in si2.items() if k not in _NOT_REPORTED}}
             except Exception as ex:  # a secondary leg must not cost the headline line
                 extra[k2] = {"error": f"{type(ex).__name__}: {ex}"}
         # The wavefront schedule (wf_kernels.hip: trace / shade kernels, path state in HBM, ballot + prefix-sum compaction) next to the
@@ -501,11 +638,13 @@ def main():
                         sched[f"{name}_{mode}"] = {"error": f"{type(ex).__name__}: {ex}"}
             _SCENES.clear()
             extra["schedules"] = sched
-        if extra:
-            out["extra_configs"] = extra
         if args.gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(key, *host_threads())
-        print(json.dumps(out), flush=True)
+            try:
+                out["cpu_baseline"] = cpu_baseline(key, *host_threads())
+            except Exception as ex:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": f"{type(ex).__name__}: {ex}"}
+    dog.cancel()
+    emit()
     if world > 1:
         dist.barrier()
         if comm is not None:

@@ -209,6 +209,15 @@ typedef struct {
      * t % n == r (tiles of tile_w x tile_h in row-major tile order; 0 = 32). shard_count <= 1 renders all.
      * Pixels a rank does not own are left untouched in its film, so a sum-reduce assembles the frame. */
     uint32_t shard_rank, shard_count, tile_w, tile_h;
+    /* Sample-range split (SURVEY.md 8b "sample range", 8e "sample-range split"; no reference counterpart): the session renders
+     * samples [sample_begin, sample_begin + sample_count) of every pixel it owns, out of the `spp` samples of the whole render;
+     * sample_count = 0 means "all of them" (sample_begin must then be 0). GPU g of n takes [g * spp / n, (g + 1) * spp / n) of
+     * EVERY pixel -- perfectly balanced at any resolution -- and the films' sum-reduce (akr_film_reduce) gives the frame.
+     * Only for the index-based samplers (PMJ02BN, SOBOL), whose sample s of a pixel is a pure function of (pixel, s, seed,
+     * spp): Pmj02BnState.sample_index simply starts at sample_begin - 1 (sampler/mod.rs:451-466, 650-663). With the
+     * INDEPENDENT sampler a range is refused with AKR_ERR_UNSUPPORTED: start() advances the pixel's PCG stream from wherever
+     * the previous sample stopped (sampler/mod.rs:115-131, 192-203), so sample s cannot be drawn without drawing 0 .. s-1. */
+    uint32_t sample_begin, sample_count;
 } akr_pt_config;
 
 /* Device counters of one render call (the n_* of the algorithmic-bytes model). */

@@ -914,9 +914,20 @@ OR_EXPORT int or_pt_render(const or_scene *sc, const or_pt_config *cfg, float *f
     uint64_t N = (uint64_t)sc->width * sc->height;
     or_pcg32 *states = (or_pcg32 *)states_io;
     int own_states = 0;
+    /* Sample-range split (akr_pt_config.sample_begin / sample_count; no reference counterpart): samples [begin, begin + count)
+     * of the cfg->spp samples of the whole render. Exact only for the index-based samplers, whose per-pixel state is the index of
+     * the sample drawn last (Pmj02BnState.sample_index, sampler/mod.rs:451-466): it starts at begin - 1 instead of u32::MAX.
+     * The independent sampler's start() continues the pixel's PCG stream (sampler/mod.rs:192-203): a range is refused. */
+    const uint32_t n_samples = cfg->sample_count ? cfg->sample_count : cfg->spp;
+    if (cfg->sample_count || cfg->sample_begin) {
+        if (cfg->sampler_type != 1 && cfg->sampler_type != 2) return -4;
+        if (cfg->sample_count == 0 || (uint64_t)cfg->sample_begin + cfg->sample_count > cfg->spp) return -4;
+    }
     if (!states) {
         states = (or_pcg32 *)malloc(sizeof(or_pcg32) * N);
         or_init_sampler_states(cfg->sampler_type, N, sc->width, cfg->sampler_seed, states);
+        if (cfg->sample_begin)
+            for (uint64_t i = 0; i < N; i++) states[i].state = (uint64_t)(cfg->sample_begin - 1u);
         own_states = 1;
     }
     if (n_threads < 1) n_threads = 1;
@@ -924,8 +935,8 @@ OR_EXPORT int or_pt_render(const or_scene *sc, const or_pt_config *cfg, float *f
     or_stats total;
     memset(&total, 0, sizeof total);
     uint32_t cnt = 0;
-    while (cnt < cfg->spp) {
-        uint32_t cur = cfg->spp - cnt < cfg->spp_per_pass ? cfg->spp - cnt : cfg->spp_per_pass;
+    while (cnt < n_samples) {
+        uint32_t cur = n_samples - cnt < cfg->spp_per_pass ? n_samples - cnt : cfg->spp_per_pass;
         volatile uint32_t next_row = 0;
         or_job jobs[256];
         pthread_t th[256];

@@ -95,6 +95,8 @@ typedef struct {
     uint64_t sampler_seed;
     /* pixel-tile sharding (rank r of n renders tiles t with t % n == r); n = 1 renders everything */
     uint32_t shard_rank, shard_count, tile_w, tile_h;
+    /* samples [sample_begin, sample_begin + sample_count) of the spp of the whole render; 0 count = all (index-based samplers only) */
+    uint32_t sample_begin, sample_count;
 } or_pt_config;
 
 typedef struct {

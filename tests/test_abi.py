@@ -34,7 +34,7 @@ def test_struct_sizes_match_header(hip_lib):
     assert all(b == 0xAB for b in g.guard)
     d = abi.PtConfig.default()
     assert bytes(g.cfg) == bytes(d)
-    assert C.sizeof(abi.MaterialDesc) == 4 * 26 and C.sizeof(abi.PtConfig) == 80
+    assert C.sizeof(abi.MaterialDesc) == 4 * 26 and C.sizeof(abi.PtConfig) == 88
 
 
 def test_no_cpu_fallback(hip_lib):

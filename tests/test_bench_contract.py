@@ -26,9 +26,9 @@ def test_pmc_summary_is_quoted_only_for_the_sources_it_was_measured_on(tmp_path,
     os.makedirs(tmp_path / "akari_render_amd" / "csrc" / "device")
     src = tmp_path / "akari_render_amd" / "csrc" / "device" / "k.h"
     src.write_text("// kernel v1\n")
-    assert bench.measured_counters("c2") == (None, "no PMC summary profiles/r3_pmc_c2.json")
+    assert bench.measured_counters("c2") == (None, "no PMC summary profiles/r4_pmc_c2.json")
     h1 = bench.csrc_hash()
-    json.dump({"csrc_hash": h1, "hbm_bytes_per_sample": 10.0, "valu_busy": 0.5}, open(tmp_path / "profiles" / "r3_pmc_c2.json", "w"))
+    json.dump({"csrc_hash": h1, "hbm_bytes_per_sample": 10.0, "valu_busy": 0.5}, open(tmp_path / "profiles" / "r4_pmc_c2.json", "w"))
     m, note = bench.measured_counters("c2")
     assert note is None and m["valu_busy"] == 0.5
     src.write_text("// kernel v2\n")                      # the kernel is edited: the summary describes another kernel now
@@ -44,7 +44,7 @@ def test_pmc_summary_is_quoted_only_for_the_sources_it_was_measured_on(tmp_path,
 
 def test_committed_pmc_summaries_carry_a_hash(root):
     for key in ("c2", "c3", "c4"):
-        path = os.path.join(root, "profiles", f"r3_pmc_{key}.json")
+        path = os.path.join(root, "profiles", f"r4_pmc_{key}.json")
         if os.path.exists(path):
             m = json.load(open(path))
             assert len(m.get("csrc_hash", "")) == 16 and "k_pt_pass" in m["kernel"]

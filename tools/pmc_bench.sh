@@ -1,12 +1,12 @@
 #!/bin/bash
 # PMC passes over one bench.py configuration (one --pmc set per rocprofv3 run, kernel-trace only), summarised into the JSON
-# that bench.py's roofline block reads: profiles/r3_pmc_<config>.json (copy gpurun_out/pmc_bench_<cfg>/summary.json there). The summary
+# that bench.py's roofline block reads: profiles/r4_pmc_<config>.json (copy gpurun_out/r4_pmc_bench_<cfg>/summary.json there). The summary
 # carries the hash of the library sources (bench.csrc_hash): bench.py quotes it only for the kernels it was measured on.
 # usage: tools/pmc_bench.sh c2|c3|c4
 set -u
 CFG=${1:-c2}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/r3_pmc_bench_$CFG
+OUT=gpurun_out/r4_pmc_bench_$CFG
 rm -rf $OUT; mkdir -p $OUT
 ARGS="--config $CFG --steps 1 --warmup 0 --also none --no-cpu-baseline"
 i=0
@@ -40,7 +40,12 @@ n_launch = max(len(v) for v in disp.values())
 samples = bench["counters"]["n_samples"]
 c = dict(res)
 xcd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0   # summed over the 8 XCDs
-hbm = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0  # KiB units; gfx950 counts 128-byte reads as 64 (MI355X_MICROARCH.md, HBM)
+# FETCH_SIZE (KiB) tallies every L2 miss at 64 B. Calibrated on known byte counts (profiles/r4_fetch_size_calibration.json,
+# tools/gather_calib.sh): a coalesced stream reads 2.000 x FETCH_SIZE (the guide's gfx950 correction) -- the cbox launches' traffic is
+# sampler states and film, streamed; a random 64-byte record read with four 16-byte loads (the BVH traversal's node / triangle
+# fetch, what C4's traffic is made of) reads 1.0008 x FETCH_SIZE.
+fetch_factor = 1.0 if cfg == "c4" else 2.0
+hbm = (fetch_factor * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
 valu_busy = c["SQ_INSTS_VALU"] * 2.0 / (1024.0 * xcd_cycles)
 lane = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
 wait = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
@@ -51,13 +56,15 @@ s = {"config": cfg, "kernel": kernel, "csrc_hash": _bench.csrc_hash(), "bench_ar
      "l2_hit": c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"]),
      "value_under_profiler_msamples_s": bench["value"],
      "counters": c,
-     "source": "tools/pmc_bench.sh " + cfg + ": rocprofv3 --kernel-trace --pmc <one set per pass> -- python bench.py $ARGS; hbm = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (KiB units, gfx950 read correction); valu_busy = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)"}
+     "fetch_size_factor": fetch_factor,
+     "source": "tools/pmc_bench.sh " + cfg + ": rocprofv3 --kernel-trace --pmc <one set per pass> -- python bench.py $ARGS; hbm = (factor x FETCH_SIZE + WRITE_SIZE) x 1024, factor = bytes read / FETCH_SIZE calibrated per access pattern on a known byte count (profiles/r4_fetch_size_calibration.json: 2.000 coalesced stream, 1.0008 random 64-byte records); valu_busy = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)"}
 if cfg == "c4":
     del s["hbm_bytes_per_launch"]  # traffic scales with the rays traced: bench.py multiplies bytes per sample by its own launch size
 s["binding_limiter"] = ("VALU issue (the 36-triangle walk and the shading run from LDS / registers; HBM sees only sampler states + film)" if cfg != "c4"
-                        else "the memory system under dependent 80-byte node / 64-byte triangle gathers: the wavefront schedule's traversal-only kernel at 7 waves per SIMD "
-                             "reaches the same rays/s as this kernel (DESIGN.md section 4)")
-s["fabric_read_bytes_per_sample"] = 2.0 * c["FETCH_SIZE"] * 1024.0 / samples
+                        else "the memory system's rate for random 64-byte records (tools/micro/gather_bw.hip: 25.8 G records/s from HBM, 56 G/s from the Infinity Cache, whatever "
+                             "the occupancy or the loads in flight per lane): this kernel misses the L2 " + str(round(c["TCC_MISS_sum"] / samples, 1)) + " times per sample")
+s["fabric_read_bytes_per_sample"] = fetch_factor * c["FETCH_SIZE"] * 1024.0 / samples
+s["l2_misses_per_sample"] = c["TCC_MISS_sum"] / samples
 s["wave_cycle_shares"] = {"issuing": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], "waitcnt": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], "issue_stall": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]}
 json.dump(s, open(out + "/summary.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in s.items() if k != "counters"}, indent=1))
