@@ -33,7 +33,7 @@ EXPORTS = [
     "akr_pt_config_default", "akr_pt_config_from_json", "akr_pt_render", "akr_pt_begin", "akr_pt_passes", "akr_pt_end",
     "akr_pt_get_stats", "akr_render_task", "akr_image_write", "akr_aov_config_default", "akr_aov_render",
     "akr_gpt_config_default", "akr_gpt_render", "akr_gpt_begin", "akr_gpt_sample", "akr_gpt_sums", "akr_gpt_sums_read", "akr_gpt_sums_write",
-    "akr_gpt_finish", "akr_gpt_reduce", "akr_mcmc_config_default", "akr_mcmc_render", "akr_film_set_splat_scale", "akr_film_get_splat_scale",
+    "akr_gpt_finish", "akr_gpt_abort", "akr_gpt_reduce", "akr_mcmc_config_default", "akr_mcmc_render", "akr_film_set_splat_scale", "akr_film_get_splat_scale",
     "akr_pt_read_sampler_states", "akr_context_device_ordinal", "akr_device_count",
     "akr_probe_material_inputs_host", "akr_comm_unique_id", "akr_comm_create", "akr_comm_wrap", "akr_comm_destroy", "akr_film_reduce",
     "akr_host_stdrng_u64", "akr_host_chacha_block", "akr_host_pcg32_states", "akr_host_pcg_start", "akr_host_alias_table",
@@ -125,6 +125,7 @@ def lib() -> C.CDLL:
     proto("akr_gpt_sums_read", vp, fp)
     proto("akr_gpt_sums_write", vp, fp)
     proto("akr_gpt_finish", vp, fp, C.POINTER(abi.PtStats))
+    proto("akr_gpt_abort", vp, C.POINTER(abi.PtStats))
     proto("akr_gpt_reduce", vp, vp, i32, i32)
     proto("akr_mcmc_config_default", C.POINTER(abi.McmcConfig))
     proto("akr_mcmc_render", vp, vp, C.POINTER(abi.McmcConfig), vp, C.POINTER(abi.McmcResult), up, C.POINTER(abi.PtStats))
@@ -700,9 +701,16 @@ class GptSession:
         check(lib().akr_gpt_finish(hh, _fp(aux) if want_aux else None, C.byref(st)))
         return (st.as_dict(), aux) if want_aux else st.as_dict()
 
+    def abort(self) -> dict:
+        """akr_gpt_abort: frees the session without reconstructing (non-root ranks of a reduced render; abandoned renders)."""
+        st = abi.PtStats()
+        hh, self.h = self.h, C.c_void_p()
+        check(lib().akr_gpt_abort(hh, C.byref(st)))
+        return st.as_dict()
+
     def __del__(self):
         if getattr(self, "h", None) and self.h.value:
-            lib().akr_gpt_finish(self.h, None, None)
+            lib().akr_gpt_abort(self.h, None)  # never reconstruct implicitly: a forgotten session must not write the film
             self.h = C.c_void_p()
 
 

@@ -5,6 +5,7 @@
 // (scene.rs:98-100) or fails the stochastic alpha test (scene.rs:49-86); closest hit = smallest t.
 // Added so that results do not depend on traversal order: ties in t go to the lowest global triangle id.
 #pragma once
+#include <type_traits>
 #include "drng.h"
 #include "dscene.h"
 
@@ -174,10 +175,57 @@ AKR_D bool trace_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmin, float 
 //      ds_read_b128, 4 LDS cycles per wave and row); all of the test's arithmetic is then VGPR-only.
 //   2  SGPRs, but the two rays of the pair go through the rows as ONE packed instruction (v_pk_fma_f32 with the coefficient
 //      broadcast): half as many scalar-operand instructions; a packed f32 op holds the VALU for two slots either way.
-// The arithmetic (operation order, fma placement) is identical in all three: films do not change.
+//   3  records in LDS, every fma of plane solve and inside test packed over the two rays, the coefficient broadcast from one half
+//      of a register pair by op_sel (no copies, no register-bank conflicts: 417 instead of 535 modelled issue cycles per two records,
+//      tools/valu_cost_report.py) -- and 3 % SLOWER than 1 on C2 and C3: half as many independent instructions per wave.
+//   4  records in LDS, scalar fmas as in 1, with the cheaper bookkeeping of 3: the alpha test unswitched out of the loop (inside
+//      it the wave-uniform flag cost every record a v_cndmask + v_cmp), min / max without the compiler's canonicalising v_max x, x,
+//      the shadow ray's margin folded with one v_max, and only (t, id) of the best hit selected per record -- its (u, v) are
+//      recomputed once after the walk. +4.2 % on C2, +3.3 % on C3 over 1 (same box, profiles/r4_ab_walk.txt). The default.
+// The arithmetic (operation order, fma placement) is identical in all of them: films do not change.
 typedef float v2f __attribute__((ext_vector_type(2)));
 AKR_D v2f pk_fma(float a, v2f b, v2f c) { return __builtin_elementwise_fma((v2f){a, a}, b, c); }
 AKR_D v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+// WALK 3: v_pk_fma_f32 / v_pk_mul_f32 with ONE half of a 64-bit register pair feeding both lanes (op_sel / op_sel_hi): the
+// coefficient of a record row, read from LDS as part of a 128-bit quad, multiplies the closest-hit ray's value in the low lane and
+// the shadow ray's in the high lane without ever being copied. Each lane is the IEEE fma / mul the scalar instruction computes.
+//   SA / SC = which half (0 = low, 1 = high) of `a` / `c` is broadcast.
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <int SA>
+AKR_D v2f pk_fma_b(v2f a, v2f b, v2f c) {  // {a[SA], a[SA]} * b + c
+    v2f r;
+    if (SA == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+template <int SA, int SC>
+AKR_D v2f pk_fma_bb(v2f a, v2f b, v2f c) {  // {a[SA], a[SA]} * b + {c[SC], c[SC]}
+    v2f r;
+    if (SA == 0 && SC == 1) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else if (SA == 0 && SC == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else if (SA == 1 && SC == 1) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+template <int SA>
+AKR_D v2f pk_mul_b(v2f a, v2f b) {  // {a[SA], a[SA]} * b
+    v2f r;
+    if (SA == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// IEEE minNum / maxNum as the instruction computes them, without the v_max x, x the compiler puts in front of fminf / fmaxf to quiet
+// a possible signalling NaN (4.4 cycles of the SIMD each, tools/micro/vgpr_bank.hip; arithmetic never produces one)
+AKR_D float min_raw(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+AKR_D float max_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 template <bool TEX = false, bool UNROLL = false, int WALK = 0>
 AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, uint32_t ex0, vec3 so, vec3 sd, float stmax,
                                  uint32_t sex0, uint32_t sex1, Hit& hit, bool& found, bool& occluded, const float4* lds_recs = nullptr) {
@@ -247,7 +295,100 @@ AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, u
         best = better ? k : best;
         occ_margin = sm > occ_margin ? sm : occ_margin;  // (not fmaxf: that costs two canonicalising v_max per record)
     };
-    if (UNROLL) {
+    if (WALK == 3 || WALK == 4) {  // 4: the same loop with scalar fmas instead of packed ones
+        // Both rays of the pair through every fma of the plane solve and of the inside test as ONE packed instruction. A scalar
+        // v_fma_f32 costs its SIMD 2.2 cycles unless its three source registers all have the same parity (the register file's two
+        // banks): then 4.4 -- and which registers a value lands in is the allocator's choice, 13 of the 76 three-source instructions
+        // of the two-record trip were hit (tools/valu_cost_report.py). A v_pk_fma_f32 costs 4.4 for its two results whatever its
+        // registers are. The records' rows are read from LDS as 128-bit quads; a row's coefficient is one half of a 64-bit register
+        // pair and is broadcast to both lanes by op_sel, the rays' components are pairs {closest-hit ray, shadow ray} throughout.
+        // The comparisons of a record are cut down too: a v_cmp costs 4.4 cycles and a v_cndmask on its result 3.7.
+        const v4f* lrec = (const v4f*)lds_recs;
+        const bool has_alpha = __builtin_amdgcn_readfirstlane((int)sc.has_alpha) != 0;  // (a scalar branch per record, nothing per lane)
+        const v2f tmax2 = {tmax, stmax};
+        v2f T2 = {0.0f, 0.0f};
+        auto record3 = [&](auto alpha_tag, uint32_t k, const v4f& q0, const v4f& q1, const v4f& q2) {
+            constexpr bool ALPHA = decltype(alpha_tag)::value;
+            const v2f r0xy = __builtin_shufflevector(q0, q0, 0, 1), r0zw = __builtin_shufflevector(q0, q0, 2, 3);
+            const v2f r1xy = __builtin_shufflevector(q1, q1, 0, 1), r1zw = __builtin_shufflevector(q1, q1, 2, 3);
+            v2f u2, v2;
+            if (WALK == 4) {
+                if (!((sc.plane_share_mask >> k) & 1ull)) {
+                    const PlaneHit a = tri_plane(o, d, make_float4(q2.x, q2.y, q2.z, q2.w)), b = tri_plane(so, sd, make_float4(q2.x, q2.y, q2.z, q2.w));
+                    T2 = (v2f){a.t, b.t};
+                    hx2 = (v2f){a.px, b.px}; hy2 = (v2f){a.py, b.py}; hz2 = (v2f){a.pz, b.pz};
+                }
+                float u, v, su, sv;
+                tri_uv(PlaneHit{T2.x, hx2.x, hy2.x, hz2.x}, make_float4(q0.x, q0.y, q0.z, q0.w), make_float4(q1.x, q1.y, q1.z, q1.w), u, v);
+                tri_uv(PlaneHit{T2.y, hx2.y, hy2.y, hz2.y}, make_float4(q0.x, q0.y, q0.z, q0.w), make_float4(q1.x, q1.y, q1.z, q1.w), su, sv);
+                u2 = (v2f){u, su}; v2 = (v2f){v, sv};
+            } else {
+            if (!((sc.plane_share_mask >> k) & 1ull)) {
+                const v2f r2xy = __builtin_shufflevector(q2, q2, 0, 1), r2zw = __builtin_shufflevector(q2, q2, 2, 3);
+                // tri_plane for both rays: den = fma(x, d.x, fma(y, d.y, z * d.z)), num = fma(x, o.x, fma(y, o.y, fma(z, o.z, w)))
+                const v2f den = pk_fma_b<0>(r2xy, dx2, pk_fma_b<1>(r2xy, dy2, pk_mul_b<0>(r2zw, dz2)));
+                const v2f num = pk_fma_b<0>(r2xy, ox2, pk_fma_b<1>(r2xy, oy2, pk_fma_bb<0, 1>(r2zw, oz2, r2zw)));
+                T2 = (v2f){-num.x / den.x, -num.y / den.y};
+                hx2 = pk_fma(T2, dx2, ox2); hy2 = pk_fma(T2, dy2, oy2); hz2 = pk_fma(T2, dz2, oz2);
+            }
+            // tri_uv: u = fma(r0.x, p.x, fma(r0.y, p.y, fma(r0.z, p.z, r0.w))), v likewise from r1
+            u2 = pk_fma_b<0>(r0xy, hx2, pk_fma_b<1>(r0xy, hy2, pk_fma_bb<0, 1>(r0zw, hz2, r0zw)));
+            v2 = pk_fma_b<0>(r1xy, hx2, pk_fma_b<1>(r1xy, hy2, pk_fma_bb<0, 1>(r1zw, hz2, r1zw)));
+            }
+            // hit_margin: min(min(min(u, v), 1 - (u + v)), min(t, tmax - t)) per ray
+            v2f s2, w2;
+            if (WALK == 4) {
+                s2 = (v2f){1.0f - (u2.x + v2.x), 1.0f - (u2.y + v2.y)};
+                w2 = (v2f){tmax - T2.x, stmax - T2.y};
+            } else {
+                s2 = (v2f){1.0f, 1.0f} - (u2 + v2);
+                w2 = tmax2 - T2;
+            }
+            float m = min_raw(min_raw(min_raw(u2.x, v2.x), s2.x), min_raw(T2.x, w2.x));
+            float sm = min_raw(min_raw(min_raw(u2.y, v2.y), s2.y), min_raw(T2.y, w2.y));
+            m = (k == ex0) ? -1.0f : m;
+            sm = (k == sex0) ? -1.0f : sm;
+            sm = (k == sex1) ? -1.0f : sm;
+            if (ALPHA) {
+                const uint32_t ka = __builtin_amdgcn_readfirstlane(k);
+                if (m >= 0.0f && !alpha_test<TEX>(sc, ka, u2.x, v2.x)) m = -1.0f;
+                if (sm >= 0.0f && !alpha_test<TEX>(sc, ka, u2.y, v2.y)) sm = -1.0f;
+            }
+            // only the distance and the id of the best hit are tracked here; its (u, v) are recomputed after the walk (below)
+            const float tc = (m >= 0.0f) ? T2.x : __builtin_inff();
+            const bool better = tc < best_t;
+            best_t = better ? tc : best_t;
+            best = better ? k : best;
+            // max over the records of the shadow ray's margin (a NaN margin leaves it as it is, like the comparison it replaces; only
+            // the sign of the result is read)
+            occ_margin = max_raw(occ_margin, sm);
+        };
+        // The loop exists twice, with and without the alpha test of a candidate: left as a run-time branch inside ONE loop, the
+        // (wave-uniform) flag is turned into a lane mask and back by every record of every scene -- a v_cndmask and a v_cmp, 8.8
+        // cycles of 240 -- to merge the two values of the margins behind the branch.
+        auto walk3 = [&](auto alpha_tag) {
+            v4f a0 = lrec[0], a1 = lrec[1], a2 = lrec[2], b0, b1, b2;
+            uint32_t k = 0;
+            for (; k + 1 < n; k += 2) {
+                b0 = lrec[3 * (k + 1)]; b1 = lrec[3 * (k + 1) + 1]; b2 = lrec[3 * (k + 1) + 2];
+                record3(alpha_tag, k, a0, a1, a2);
+                a0 = lrec[3 * (k + 2)]; a1 = lrec[3 * (k + 2) + 1]; a2 = lrec[3 * (k + 2) + 2];
+                record3(alpha_tag, k + 1, b0, b1, b2);
+            }
+            if (k < n) record3(alpha_tag, k, a0, a1, a2);
+        };
+        if (has_alpha) walk3(std::true_type{});
+        else walk3(std::false_type{});
+        // (u, v) of the closest hit, once per walk instead of two selects per record: the record's rows from LDS again (a per-lane
+        // address now) and the hit point o + t d with the t the walk kept -- the very operations on the very operands of the walk
+        // (hx2.x = fma(T2.x, d.x, o.x), u2.x = the fma chain over row 0), so the bits are the walk's.
+        if (best != kInvalid) {
+            const v4f q0 = lrec[3 * best], q1 = lrec[3 * best + 1];
+            const float px = __builtin_fmaf(best_t, d.x, o.x), py = __builtin_fmaf(best_t, d.y, o.y), pz = __builtin_fmaf(best_t, d.z, o.z);
+            best_u = __builtin_fmaf(q0.x, px, __builtin_fmaf(q0.y, py, __builtin_fmaf(q0.z, pz, q0.w)));
+            best_v = __builtin_fmaf(q1.x, px, __builtin_fmaf(q1.y, py, __builtin_fmaf(q1.z, pz, q1.w)));
+        }
+    } else if (UNROLL) {
         // two records per trip on alternating register sets: the one-record software prefetch without the scalar moves that
         // rotating a single pair of sets costs per record (buffer padded by two records). +5 % in the small force_diffuse
         // kernel, -3 % in the full-graph kernel, whose 111 KB of code already overflow the instruction cache.
@@ -282,8 +423,9 @@ AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, u
 // Compressed wide-BVH traversal: six children in eight octant positions, 64-byte nodes (layout and builder: host/bvh.cpp; after
 // Ylitie, Karras & Laine, HPG 2017).
 //
-// One ray per lane. A lane's state is a NODE GROUP G = child_base (24 bits) | hit bits of up to 8 sibling nodes, in
-// visiting order (bits 24..31), a TRIANGLE GROUP (tbase, T) = up to 24 pending triangles of the node visited last, and a
+// One ray per lane. A lane's state is a NODE GROUP G = child_base (24 bits) | hit bits of the (at most 6) sibling nodes in their 8 octant
+// positions, in visiting order (bits 24..31), a TRIANGLE GROUP (tbase, T) = the pending triangles of the node visited last (at most 18:
+// six leaves of three; 24 bits), and a
 // stack of node groups in LDS (strided by the workgroup size: lane i of every wave touches bank i). A node's children are
 // tested together; those the ray enters become the new G, ordered by octant: slot s sits at bit 24 + (s ^ octinv), the
 // highest bit is the nearest child, so "pop the nearest" is one count-leading-zeros and nothing is sorted. The siblings
@@ -293,7 +435,7 @@ AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, u
 // Every step a lane does ONE thing -- test its next pending triangle, or fetch and test its next node -- and both kinds
 // of lane fetch through the SAME four 16-byte loads from a per-lane address (64-byte triangle record: Woop rows + global
 // id; 64-byte node: one memory sector each). The wave waits once per step whatever mix of nodes and triangles its lanes are at: on the
-// 10 M-triangle hall the previous while-while BVH4 loop ran at 26 % lane utilisation, all of it waiting on dependent
+// 10 M-triangle hall round 1's while-while loop over a 4-wide BVH ran at 26 % lane utilisation, all of it waiting on dependent
 // fetches.
 // The box test only culls and does not have to follow the AKR-F32 contract (the oracle has no BVH): it must be conservative,
 // which the padding of the boxes (host/bvh.cpp) guarantees; so it may use v_rcp_f32, fma and min3 / max3.

@@ -171,7 +171,10 @@ struct akr_pt_session {
     uint32_t spp_done = 0, n_launches = 0;
     uint32_t pmj_spp = 1;  // the spp the pmj02bn sampler stratifies for (the method's total spp)
     const akr_scene::ColorSet* color_set = nullptr;  // the scene's tables for cfg.color != 0 (looked up under the scene's lock by akr_pt_begin)
-    int defer_metal_option = -1;  // TuningOptions.defer_metal as it was when the session began
+    // the process-wide tuning options as they were when the session began (akr_pt_begin): an akr_option_set from another thread
+    // cannot change the kernel of a running session
+    int defer_metal_option = -1;
+    int simple_kernels_option = 1;
     // timed regions on the context's stream: pairs still in flight, and the elapsed time of the completed ones (folded in and
     // destroyed as they complete, so a long progressive session holds a bounded number of events)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -448,7 +451,7 @@ static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pas
             if (m.kind == MAT_GLASS) simple = false;
             if (m.kind == MAT_PRINCIPLED && ((m.flags & (MF_COAT | MF_EVAL_DIEL | MF_NORMAL_MAP)) != 0 || m.transmission != 0.0f || m.coat_weight != 0.0f)) simple = false;
         }
-        p.simple_scene = (simple && tuning().simple_kernels) ? 1u : 0u;
+        p.simple_scene = (simple && se->simple_kernels_option) ? 1u : 0u;
     }
     {   // conductor hits on even iterations only (pt_kernels.hip): pays when SOME materials have the lobe and most hits do not
         const CompiledScene& cs = s->cs;
@@ -477,13 +480,13 @@ static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pas
 // Which schedule renders this session: "mega" = persistent-lane megakernel (pt_kernels.hip), "wavefront" = trace /
 // shade kernels with the path state in HBM (wf_kernels.hip; needs a BVH scene). AKR_PT_MODE selects; the default is the
 // megakernel, which measured faster on every configuration so far (on the 10 M-triangle hall both
-// schedules trace ~2 G rays/s -- the traversal is bound by the L1/L2 request rate of the node fetches, not by occupancy --
-// and the wavefront schedule pays for streaming the path state and for its per-iteration tail on top).
+// schedules trace 3.3 - 3.7 G rays/s -- the traversal is bound by the memory system's rate for random 64-byte records, not by
+// occupancy -- and the wavefront schedule pays for streaming the path state and for its per-iteration tail on top).
+// The option is process-wide and aov / gpt / mcmc_opt sessions come through here too: a scene without a BVH (64 triangles or
+// fewer, no force_bvh) has no wavefront kernels and renders with the megakernel whatever the option says.
 static bool choose_wavefront(const akr_scene* scene) {
     if (!tuning().wavefront) return false;
-    if (scene->cs.bvh_nodes.empty())
-        throw std::invalid_argument("the wavefront schedule (option wavefront = 1 / AKR_PT_MODE=wavefront) needs a BVH scene (more than 64 triangles, or option force_bvh)");
-    return true;
+    return !scene->cs.bvh_nodes.empty();
 }
 
 static void wf_allocate(akr_pt_session* se, uint32_t n_slots) {
@@ -949,7 +952,11 @@ AKR_API int32_t akr_pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_co
         se->counters.alloc(8 * kStatStripes * sizeof(uint64_t));
         HIP_CHECK(hipMemsetAsync(se->counters.p, 0, se->counters.bytes, ctx->stream));
         se->wavefront = choose_wavefront(scene);
-        se->defer_metal_option = tuning().defer_metal;
+        {
+            const TuningOptions t = tuning();
+            se->defer_metal_option = t.defer_metal;
+            se->simple_kernels_option = t.simple_kernels;
+        }
         if (se->wavefront) {
             fill_params(se.get(), 1, cfg->spp_per_pass);  // for n_items
             wf_allocate(se.get(), se->params.n_items);
@@ -1131,12 +1138,12 @@ AKR_API int32_t akr_gpt_begin(akr_context* ctx, akr_scene* scene, const akr_gpt_
     if (!ctx || !scene || !cfg || !film || !out) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_gpt_begin: NULL argument");
     *out = nullptr;
     const uint32_t W = scene->flat.camera.width, H = scene->flat.camera.height;
-    if (cfg->reconstruction > AKR_GPT_RECON_WEIGHTED) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_gpt_render: unknown reconstruction");
-    if (cfg->stride < 1 || cfg->stride >= W || cfg->stride >= H) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_gpt_render: stride must be in [1, min(width, height))");
+    if (cfg->reconstruction > AKR_GPT_RECON_WEIGHTED) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_gpt_begin: unknown reconstruction");
+    if (cfg->stride < 1 || cfg->stride >= W || cfg->stride >= H) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_gpt_begin: stride must be in [1, min(width, height))");
     if (cfg->reconstruction == AKR_GPT_RECON_NONE && !cfg->reconnect)  // shift_mapping.as_ref().unwrap(), gpt.rs:276
-        return fail(AKR_ERR_INVALID_ARGUMENT, "akr_gpt_render: reconstruction 'none' needs reconnect = true (the reference panics)");
+        return fail(AKR_ERR_INVALID_ARGUMENT, "akr_gpt_begin: reconstruction 'none' needs reconnect = true (the reference panics)");
     if (cfg->sampler_type != AKR_SAMPLER_INDEPENDENT)  // Pmj02BnSampler::clone_box is todo!(), sampler/mod.rs:677
-        return fail(AKR_ERR_UNSUPPORTED, "akr_gpt_render: gpt needs the independent sampler (the reference's pmj02bn sampler cannot be cloned)");
+        return fail(AKR_ERR_UNSUPPORTED, "akr_gpt_begin: gpt needs the independent sampler (the reference's pmj02bn sampler cannot be cloned)");
     if (shard && shard->shard_count > 1 && shard->shard_rank >= shard->shard_count) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_gpt_begin: shard_rank >= shard_count");
     akr_pt_config pc;
     akr_pt_config_default(&pc);
@@ -1148,8 +1155,9 @@ AKR_API int32_t akr_gpt_begin(akr_context* ctx, akr_scene* scene, const akr_gpt_
     akr_pt_session* pt = nullptr;
     int32_t rc = akr_pt_begin(ctx, scene, &pc, film, &pt);
     if (rc != AKR_OK) return rc;
-    auto se = std::make_unique<akr_gpt_session>();
+    std::unique_ptr<akr_gpt_session> se;
     rc = guarded([&] {
+        se = std::make_unique<akr_gpt_session>();  // (inside guarded: a bad_alloc must not cross the C ABI)
         se->ctx = ctx; se->scene = scene; se->film = film; se->cfg = *cfg; se->pt = pt; se->W = W; se->H = H;
         const size_t N = (size_t)W * H, NG = (size_t)(W + 1) * (H + 1);
         se->recon = cfg->reconstruction != AKR_GPT_RECON_NONE;
@@ -1311,6 +1319,15 @@ AKR_API int32_t akr_gpt_finish(akr_gpt_session* se, float* aux, akr_pt_stats* st
         return rc;
     }
     return rc2;
+}
+// Ends a session WITHOUT the splat scale / reconstruction sweeps of akr_gpt_finish: the film keeps whatever the samples (and a
+// reduce) left in it. For a rank that is not the root of akr_gpt_reduce (its partial sums would reconstruct into garbage) and for
+// abandoning a render.
+AKR_API int32_t akr_gpt_abort(akr_gpt_session* se, akr_pt_stats* stats) {
+    if (!se) return AKR_OK;
+    int32_t rc = akr_pt_end(se->pt, stats);
+    delete se;
+    return rc;
 }
 AKR_API int32_t akr_gpt_render(akr_context* ctx, akr_scene* scene, const akr_gpt_config* cfg, akr_film* film, float* aux, akr_pt_stats* stats) {
     akr_gpt_session* se = nullptr;

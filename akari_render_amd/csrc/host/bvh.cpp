@@ -28,14 +28,21 @@
 // Boxes are padded by `pad` so that every triangle the exhaustive test would report is reached by traversal
 // (the triangle test itself has an absolute slop of a few ulp(t); see DESIGN.md "BVH conservativeness").
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <deque>
 #include <limits>
 #include <numeric>
 #include <stdexcept>
+#include <thread>
 #include <vector>
+
+#include "host_parallel.h"
 
 namespace akr {
 
@@ -83,124 +90,258 @@ struct Builder {
     std::vector<uint32_t>& order;
     std::vector<float> centroid;  // 3 / tri
     std::vector<BinNode> nodes;
+    unsigned threads = 1;
+    // A node of more than kWideMin triangles is split with its passes over the triangles (bounds, SAH bins) divided over the
+    // threads; the subtrees below kTaskMax triangles are built one per thread. Every quantity a split depends on is a minimum, a
+    // maximum or an integer count, and the partition of `order` is the sequential std::partition in both cases: the tree and the
+    // triangle order are the same for every thread count (tests/test_host.py compares builds).
+    static constexpr uint32_t kWideMin = 1u << 17, kTaskMax = 1u << 16;
 
     Builder(const float* b, uint32_t n, std::vector<uint32_t>& ord) : bounds(b), order(ord) {
         order.resize(n);
         std::iota(order.begin(), order.end(), 0u);
         centroid.resize(3ull * n);
-        for (uint32_t i = 0; i < n; i++)
-            for (int a = 0; a < 3; a++) centroid[3ull * i + a] = 0.5f * (b[6ull * i + a] + b[6ull * i + 3 + a]);
+        threads = host_threads();
+        const unsigned chunks = n > kWideMin ? threads * 4 : 1;
+        parallel_chunks(chunks, threads, [&](unsigned c) {
+            const uint64_t lo = (uint64_t)n * c / chunks, hi = (uint64_t)n * (c + 1) / chunks;
+            for (uint64_t i = lo; i < hi; i++)
+                for (int a = 0; a < 3; a++) centroid[3ull * i + a] = 0.5f * (b[6ull * i + a] + b[6ull * i + 3 + a]);
+        });
         nodes.reserve(2ull * n / 2 + 16);
     }
 
-    int32_t build(uint32_t first, uint32_t count) {
-        // iterative to survive degenerate inputs; explicit stack of (node, first, count)
-        struct Item { int32_t node; uint32_t first, count; };
-        std::vector<Item> stack;
-        nodes.emplace_back();
-        stack.push_back({0, first, count});
+    struct Item { int32_t node; uint32_t first, count; };
+    struct Bins {
+        Box box[3][kBins];
+        uint32_t cnt[3][kBins];
+    };
+
+    // Bounds, the split decision and the partition of one node's triangles. Returns false for a leaf, else `mid`.
+    bool split(const Item& it, Box& box_out, uint32_t& mid, unsigned th) {
+        const unsigned chunks = (th > 1 && it.count > kWideMin) ? th * 2 : 1;
+        auto range = [&](unsigned c, uint32_t& lo, uint32_t& hi) {
+            lo = it.first + (uint32_t)((uint64_t)it.count * c / chunks);
+            hi = it.first + (uint32_t)((uint64_t)it.count * (c + 1) / chunks);
+        };
+        Box box, cbox;
+        box.reset();
+        cbox.reset();
+        {
+            Box pb1, pc1;
+            std::vector<Box> pbv, pcv;
+            if (chunks > 1) { pbv.resize(chunks); pcv.resize(chunks); }
+            Box* pb = chunks > 1 ? pbv.data() : &pb1;
+            Box* pc = chunks > 1 ? pcv.data() : &pc1;
+            parallel_chunks(chunks, th, [&](unsigned c) {
+                uint32_t lo, hi;
+                range(c, lo, hi);
+                Box b1, c1;
+                b1.reset();
+                c1.reset();
+                for (uint32_t i = lo; i < hi; i++) {
+                    b1.grow(bounds + 6ull * order[i]);
+                    const float* cc = &centroid[3ull * order[i]];
+                    for (int a = 0; a < 3; a++) {
+                        c1.lo[a] = std::min(c1.lo[a], cc[a]);
+                        c1.hi[a] = std::max(c1.hi[a], cc[a]);
+                    }
+                }
+                pb[c] = b1;
+                pc[c] = c1;
+            });
+            for (unsigned c = 0; c < chunks; c++) {
+                box.grow(pb[c]);
+                cbox.grow(pc[c]);
+            }
+        }
+        box_out = box;
+        if (it.count <= kLeafMax) return false;
+        if (balanced) {  // median of the centroids along their widest axis
+            int axis = 0;
+            for (int a = 1; a < 3; a++)
+                if (cbox.hi[a] - cbox.lo[a] > cbox.hi[axis] - cbox.lo[axis]) axis = a;
+            auto* beg = order.data() + it.first;
+            std::nth_element(beg, beg + it.count / 2, beg + it.count,
+                             [&](uint32_t x, uint32_t y) { return centroid[3ull * x + axis] < centroid[3ull * y + axis]; });
+            mid = it.first + it.count / 2;
+            return true;
+        }
+        // binned SAH over the three axes
+        Bins part1;
+        std::vector<Bins> partv;
+        if (chunks > 1) partv.resize(chunks);
+        Bins* part = chunks > 1 ? partv.data() : &part1;
+        parallel_chunks(chunks, th, [&](unsigned c) {
+            uint32_t lo, hi;
+            range(c, lo, hi);
+            Bins& bn = part[c];
+            for (int axis = 0; axis < 3; axis++)
+                for (int k = 0; k < kBins; k++) {
+                    bn.box[axis][k].reset();
+                    bn.cnt[axis][k] = 0;
+                }
+            for (int axis = 0; axis < 3; axis++) {
+                const float clo = cbox.lo[axis], ext = cbox.hi[axis] - cbox.lo[axis];
+                if (!(ext > 0.0f)) continue;
+                const float scale = (float)kBins / ext;
+                for (uint32_t i = lo; i < hi; i++) {
+                    int k = (int)((centroid[3ull * order[i] + axis] - clo) * scale);
+                    k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                    bn.cnt[axis][k]++;
+                    bn.box[axis][k].grow(bounds + 6ull * order[i]);
+                }
+            }
+        });
+        float best_cost = std::numeric_limits<float>::infinity();
+        int best_axis = -1, best_split = -1;
+        for (int axis = 0; axis < 3; axis++) {
+            const float ext = cbox.hi[axis] - cbox.lo[axis];
+            if (!(ext > 0.0f)) continue;
+            Box bin_box[kBins];
+            uint32_t bin_cnt[kBins];
+            for (int k = 0; k < kBins; k++) {
+                bin_box[k].reset();
+                bin_cnt[k] = 0;
+                for (unsigned c = 0; c < chunks; c++) {
+                    if (part[c].cnt[axis][k] == 0) continue;
+                    bin_box[k].grow(part[c].box[axis][k]);
+                    bin_cnt[k] += part[c].cnt[axis][k];
+                }
+            }
+            float right_area[kBins];
+            uint32_t right_cnt[kBins];
+            Box acc;
+            acc.reset();
+            uint32_t cnt = 0;
+            for (int k = kBins - 1; k > 0; k--) {
+                acc.grow(bin_box[k]);
+                cnt += bin_cnt[k];
+                right_area[k] = acc.half_area();
+                right_cnt[k] = cnt;
+            }
+            acc.reset();
+            cnt = 0;
+            for (int k = 0; k < kBins - 1; k++) {
+                acc.grow(bin_box[k]);
+                cnt += bin_cnt[k];
+                if (cnt == 0 || right_cnt[k + 1] == 0) continue;
+                float cost = acc.half_area() * (float)cnt + right_area[k + 1] * (float)right_cnt[k + 1];
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = axis;
+                    best_split = k;
+                }
+            }
+        }
+        if (best_axis < 0) {
+            mid = it.first + it.count / 2;  // all centroids coincide: split by index
+        } else {
+            float lo = cbox.lo[best_axis], ext = cbox.hi[best_axis] - cbox.lo[best_axis];
+            float scale = (float)kBins / ext;
+            auto* beg = order.data() + it.first;
+            auto* end = beg + it.count;
+            auto* m = std::partition(beg, end, [&](uint32_t t) {
+                int k = (int)((centroid[3ull * t + best_axis] - lo) * scale);
+                k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                return k <= best_split;
+            });
+            mid = it.first + (uint32_t)(m - beg);
+            if (mid == it.first || mid == it.first + it.count) mid = it.first + it.count / 2;
+        }
+        return true;
+    }
+
+    // the subtree of `root` into `out` (out[0] = its root; children are indices into `out`), one thread
+    void build_subtree(const Item& root, std::vector<BinNode>& out) {
+        std::vector<Item> stack;  // iterative to survive degenerate inputs
+        out.emplace_back();
+        stack.push_back({0, root.first, root.count});
         while (!stack.empty()) {
             Item it = stack.back();
             stack.pop_back();
-            Box box, cbox;
-            box.reset();
-            cbox.reset();
-            for (uint32_t i = it.first; i < it.first + it.count; i++) {
-                box.grow(bounds + 6ull * order[i]);
-                const float* c = &centroid[3ull * order[i]];
-                for (int a = 0; a < 3; a++) {
-                    cbox.lo[a] = std::min(cbox.lo[a], c[a]);
-                    cbox.hi[a] = std::max(cbox.hi[a], c[a]);
-                }
+            Box box;
+            uint32_t mid = 0;
+            const bool inner = split(it, box, mid, 1);
+            out[it.node].box = box;
+            out[it.node].first = it.first;
+            out[it.node].count = it.count;
+            if (!inner) continue;
+            const int32_t l = (int32_t)out.size();
+            out.emplace_back();
+            const int32_t r = (int32_t)out.size();
+            out.emplace_back();
+            out[it.node].left = l;
+            out[it.node].right = r;
+            stack.push_back({l, it.first, mid - it.first});
+            stack.push_back({r, mid, it.first + it.count - mid});
+        }
+    }
+
+    int32_t build(uint32_t first, uint32_t count) {
+        nodes.emplace_back();
+        std::vector<Item> stack, tasks;
+        stack.push_back({0, first, count});
+        // the top of the tree, node by node with every thread on the node's triangles, down to subtrees small enough to hand out whole
+        while (!stack.empty()) {
+            Item it = stack.back();
+            stack.pop_back();
+            if (threads > 1 && it.count <= kTaskMax) {
+                tasks.push_back(it);
+                continue;
             }
+            if (threads <= 1) {  // one thread: the whole tree is one "subtree"
+                tasks.push_back(it);
+                continue;
+            }
+            Box box;
+            uint32_t mid = 0;
+            const bool inner = split(it, box, mid, threads);
             nodes[it.node].box = box;
             nodes[it.node].first = it.first;
             nodes[it.node].count = it.count;
-            if (it.count <= kLeafMax) continue;
-            if (balanced) {  // median of the centroids along their widest axis
-                int axis = 0;
-                for (int a = 1; a < 3; a++)
-                    if (cbox.hi[a] - cbox.lo[a] > cbox.hi[axis] - cbox.lo[axis]) axis = a;
-                auto* beg = order.data() + it.first;
-                std::nth_element(beg, beg + it.count / 2, beg + it.count,
-                                 [&](uint32_t x, uint32_t y) { return centroid[3ull * x + axis] < centroid[3ull * y + axis]; });
-                const uint32_t mid = it.first + it.count / 2;
-                int32_t l = (int32_t)nodes.size();
-                nodes.emplace_back();
-                int32_t r = (int32_t)nodes.size();
-                nodes.emplace_back();
-                nodes[it.node].left = l;
-                nodes[it.node].right = r;
-                stack.push_back({l, it.first, mid - it.first});
-                stack.push_back({r, mid, it.first + it.count - mid});
-                continue;
-            }
-            // binned SAH over the three axes
-            float best_cost = std::numeric_limits<float>::infinity();
-            int best_axis = -1, best_split = -1;
-            for (int axis = 0; axis < 3; axis++) {
-                float lo = cbox.lo[axis], ext = cbox.hi[axis] - cbox.lo[axis];
-                if (!(ext > 0.0f)) continue;
-                Box bin_box[kBins];
-                uint32_t bin_cnt[kBins] = {0};
-                for (auto& b : bin_box) b.reset();
-                float scale = (float)kBins / ext;
-                for (uint32_t i = it.first; i < it.first + it.count; i++) {
-                    int b = (int)((centroid[3ull * order[i] + axis] - lo) * scale);
-                    b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
-                    bin_cnt[b]++;
-                    bin_box[b].grow(bounds + 6ull * order[i]);
-                }
-                float right_area[kBins];
-                uint32_t right_cnt[kBins];
-                Box acc;
-                acc.reset();
-                uint32_t cnt = 0;
-                for (int b = kBins - 1; b > 0; b--) {
-                    acc.grow(bin_box[b]);
-                    cnt += bin_cnt[b];
-                    right_area[b] = acc.half_area();
-                    right_cnt[b] = cnt;
-                }
-                acc.reset();
-                cnt = 0;
-                for (int b = 0; b < kBins - 1; b++) {
-                    acc.grow(bin_box[b]);
-                    cnt += bin_cnt[b];
-                    if (cnt == 0 || right_cnt[b + 1] == 0) continue;
-                    float cost = acc.half_area() * (float)cnt + right_area[b + 1] * (float)right_cnt[b + 1];
-                    if (cost < best_cost) {
-                        best_cost = cost;
-                        best_axis = axis;
-                        best_split = b;
-                    }
-                }
-            }
-            uint32_t mid;
-            if (best_axis < 0) {
-                mid = it.first + it.count / 2;  // all centroids coincide: split by index
-            } else {
-                float lo = cbox.lo[best_axis], ext = cbox.hi[best_axis] - cbox.lo[best_axis];
-                float scale = (float)kBins / ext;
-                auto* beg = order.data() + it.first;
-                auto* end = beg + it.count;
-                auto* m = std::partition(beg, end, [&](uint32_t t) {
-                    int b = (int)((centroid[3ull * t + best_axis] - lo) * scale);
-                    b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
-                    return b <= best_split;
-                });
-                mid = it.first + (uint32_t)(m - beg);
-                if (mid == it.first || mid == it.first + it.count) mid = it.first + it.count / 2;
-            }
-            int32_t l = (int32_t)nodes.size();
+            if (!inner) continue;
+            const int32_t l = (int32_t)nodes.size();
             nodes.emplace_back();
-            int32_t r = (int32_t)nodes.size();
+            const int32_t r = (int32_t)nodes.size();
             nodes.emplace_back();
             nodes[it.node].left = l;
             nodes[it.node].right = r;
             stack.push_back({l, it.first, mid - it.first});
             stack.push_back({r, mid, it.first + it.count - mid});
         }
+        const bool timing = std::getenv("AKR_TIMING") != nullptr;
+        auto t0 = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) {
+            if (!timing) return;
+            auto n = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[akari_hip] bvh build (%u threads): %-22s %.3f s\n", threads, what, std::chrono::duration<double>(n - t0).count());
+            t0 = n;
+        };
+        std::vector<std::vector<BinNode>> sub(tasks.size());
+        // the largest subtrees first: the tail of the parallel region is then made of small ones
+        std::vector<unsigned> by_size(tasks.size());
+        std::iota(by_size.begin(), by_size.end(), 0u);
+        std::sort(by_size.begin(), by_size.end(), [&](unsigned x, unsigned y) { return tasks[x].count > tasks[y].count; });
+        parallel_chunks((unsigned)tasks.size(), threads, [&](unsigned t) { build_subtree(tasks[by_size[t]], sub[by_size[t]]); });
+        lap("subtrees");
+        for (size_t t = 0; t < tasks.size(); t++) {  // splice: local index i > 0 becomes base + i - 1, local 0 is the task's node
+            const int32_t base = (int32_t)nodes.size();
+            auto fix = [&](int32_t c) { return c < 0 ? c : base + c - 1; };
+            const std::vector<BinNode>& sn = sub[t];
+            BinNode root = sn[0];
+            root.left = fix(root.left);
+            root.right = fix(root.right);
+            nodes[tasks[t].node] = root;
+            for (size_t i = 1; i < sn.size(); i++) {
+                BinNode n = sn[i];
+                n.left = fix(n.left);
+                n.right = fix(n.right);
+                nodes.push_back(n);
+            }
+            std::vector<BinNode>().swap(sub[t]);
+        }
+        lap("splice");
         return 0;
     }
 };
@@ -215,7 +356,10 @@ void build_bvh8(const std::vector<float>& tri_bounds, uint32_t n_tris, float pad
     std::vector<uint32_t> order;
     Builder b(tri_bounds.data(), n_tris, order);
     b.balanced = balanced;
+    const bool timing = std::getenv("AKR_TIMING") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
     b.build(0, n_tris);
+    if (timing) std::fprintf(stderr, "[akari_hip] build_bvh8: binary SAH build %.3f s (%zu nodes)\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), b.nodes.size());
     const auto& bn = b.nodes;
     struct Pending { int32_t bin; uint32_t out; uint32_t depth; };
     std::deque<Pending> queue;

@@ -9,7 +9,10 @@
 // All f32 arithmetic here uses the same akr:: helpers as the kernels (this file is compiled with
 // -ffp-contract=off too), so a quantity folded on the host has the bits the device would have computed.
 #include "scene_build.h"
+#include "host_parallel.h"
 
+#include <chrono>
+#include <cstdio>
 #include <mutex>
 #include <cmath>
 #include <cstdlib>
@@ -473,7 +476,21 @@ void compile_materials(const FlatScene& flat, uint32_t color, CompiledScene& out
     }
 }
 
+namespace {
+// AKR_TIMING=1: wall clock of the phases of a scene compile on stderr (host-side diagnostics; no effect on results)
+struct PhaseTimer {
+    bool on = std::getenv("AKR_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[akari_hip] compile_scene: %-28s %.3f s\n", what, std::chrono::duration<double>(n - t).count());
+        t = n;
+    }
+};
+}  // namespace
 void compile_scene(const FlatScene& flat, CompiledScene& out) {
+    PhaseTimer phase;
     const size_t n_inst = flat.instances.size();
     out = CompiledScene();
     out.materials.reserve(flat.materials.size());
@@ -523,15 +540,34 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
     std::vector<float> tri_power(n_tris, 0.0f);
     for (int a = 0; a < 3; a++) { out.scene_lo[a] = INFINITY; out.scene_hi[a] = -INFINITY; }
 
-    for (size_t i = 0; i < n_inst; i++) {
+    // Per-triangle records, chunk by chunk on the host's threads (a 10 M-triangle mesh: 0.9 s on one). A chunk starts at an even
+    // triangle: share_plane_row looks at the pair (prim - 1, prim). What the triangles share -- the scene box and the first error --
+    // is kept per chunk and merged in chunk order afterwards, so results and error messages do not depend on the thread count.
+    struct TriChunk { size_t inst; uint32_t first, last; float lo[3], hi[3]; std::string error; bool bad_slot = false; };
+    std::vector<TriChunk> chunks;
+    {
+        const uint32_t kChunk = 1u << 16;
+        for (size_t i = 0; i < n_inst; i++) {
+            const uint32_t nt = flat.meshes[flat.instances[i].mesh].n_triangles();
+            for (uint32_t f = 0; f < nt; f += kChunk) {
+                TriChunk c;
+                c.inst = i; c.first = f; c.last = std::min(nt, f + kChunk);
+                for (int a = 0; a < 3; a++) { c.lo[a] = INFINITY; c.hi[a] = -INFINITY; }
+                chunks.push_back(c);
+            }
+        }
+    }
+    parallel_chunks((unsigned)chunks.size(), n_tris > (1u << 17) ? host_threads() : 1u, [&](unsigned ci) {
+        TriChunk& chunk = chunks[ci];
+        const size_t i = chunk.inst;
         const HostInstance& in = flat.instances[i];
         const HostMesh& g = flat.meshes[in.mesh];
         const Xform& x = xf[i];
-        for (uint32_t prim = 0; prim < g.n_triangles(); prim++) {
+        for (uint32_t prim = chunk.first; prim < chunk.last; prim++) {
             const uint32_t gid = out.inst_tri_offset[i] + prim;
             // material: mats[slots[prim]] when the slot buffer has more than one entry, else mats[0] (mesh.rs:508-521)
             uint32_t slot = (g.slots.size() > 1) ? g.slots[prim] : 0;
-            if (slot >= in.materials.size()) throw std::invalid_argument("material slot out of range for instance");
+            if (slot >= in.materials.size()) { chunk.bad_slot = true; return; }
             uint32_t material = in.materials[slot];
             vec3 v0 = ld3(g.vertices, g.indices[3 * prim]), v1 = ld3(g.vertices, g.indices[3 * prim + 1]), v2 = ld3(g.vertices, g.indices[3 * prim + 2]);
             // mesh.rs:527-535
@@ -608,11 +644,13 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
             // builder's costs become NaN and geometry would silently go missing. Refused here, for every scene size.
             if (!(is_finite(A.x) && is_finite(A.y) && is_finite(A.z) && is_finite(B.x) && is_finite(B.y) && is_finite(B.z) && is_finite(C.x) &&
                   is_finite(C.y) && is_finite(C.z)))
-                throw std::invalid_argument("instance " + std::to_string(i) + ", triangle " + std::to_string(prim) +
-                                            ": non-finite vertex position after the instance transform");
+            {
+                chunk.error = "instance " + std::to_string(i) + ", triangle " + std::to_string(prim) + ": non-finite vertex position after the instance transform";
+                return;
+            }
             for (int a = 0; a < 3; a++) {
-                out.scene_lo[a] = min_f(out.scene_lo[a], bb[a]);
-                out.scene_hi[a] = max_f(out.scene_hi[a], bb[3 + a]);
+                chunk.lo[a] = min_f(chunk.lo[a], bb[a]);
+                chunk.hi[a] = max_f(chunk.hi[a], bb[3 + a]);
             }
             // emission power estimate, load.rs:312-343: 16 x (max(emission) * prim_area) / 16. For the folded
             // (constant) emitters supported here the emission does not depend on the sampled point or direction,
@@ -642,7 +680,16 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
             }
             tri_power[gid] = acc / 16.0f;
         }
+    });
+    for (const TriChunk& c : chunks) {  // in chunk order = in triangle order: the first error is the one the serial loop would raise
+        if (c.bad_slot) throw std::invalid_argument("material slot out of range for instance");
+        if (!c.error.empty()) throw std::invalid_argument(c.error);
+        for (int a = 0; a < 3; a++) {
+            out.scene_lo[a] = min_f(out.scene_lo[a], c.lo[a]);
+            out.scene_hi[a] = max_f(out.scene_hi[a], c.hi[a]);
+        }
     }
+    phase.lap("triangle records");
     // lights, load.rs:345-444
     std::vector<float> light_weights;
     for (size_t i = 0; i < n_inst; i++) {
@@ -682,6 +729,7 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
     out.n_lights = (uint32_t)out.light_inst.size();
     if (out.n_lights > 0) build_alias_table(light_weights, out.light_entries, out.light_pdf);
 
+    phase.lap("light tables");
     // acceleration structure: tiny scenes are intersected exhaustively (records from LDS or the scalar cache), others get the compressed wide BVH of host/bvh.cpp
     // (AKR_FORCE_BVH=1 builds the BVH for tiny scenes too: lets the tests run both intersectors on scenes/cbox)
     const TuningOptions tune = tuning();
@@ -706,14 +754,22 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
         if (out.bvh_depth > kBvhStackDepth)
             throw std::runtime_error("unsupported: BVH depth " + std::to_string(out.bvh_depth) + " exceeds the traversal stack (" +
                                      std::to_string(kBvhStackDepth) + " levels)");
+        phase.lap("BVH build");
         // triangle records in traversal order: the 48-byte test record, then the global id (one 64-byte fetch per test)
         std::vector<float> rec((size_t)kBvhTriWords * n_tris, 0.0f);
-        for (uint32_t k = 0; k < n_tris; k++) {
-            std::memcpy(&rec[(size_t)kBvhTriWords * k], &out.woop[12ull * order[k]], 48);
-            rec[(size_t)kBvhTriWords * k + 12] = u2f(order[k]);
+        {
+            const unsigned nc = n_tris > (1u << 17) ? host_threads() * 4 : 1;
+            parallel_chunks(nc, host_threads(), [&](unsigned c) {
+                const uint32_t lo = (uint32_t)((uint64_t)n_tris * c / nc), hi = (uint32_t)((uint64_t)n_tris * (c + 1) / nc);
+                for (uint32_t k = lo; k < hi; k++) {
+                    std::memcpy(&rec[(size_t)kBvhTriWords * k], &out.woop[12ull * order[k]], 48);
+                    rec[(size_t)kBvhTriWords * k + 12] = u2f(order[k]);
+                }
+            });
         }
         out.woop.swap(rec);
         out.tri_gid = order;
+        phase.lap("records in traversal order");
     }
     // two all-zero records of padding: the exhaustive intersectors prefetch up to record n + 1
     out.woop.resize(out.woop.size() + 32, 0.0f);

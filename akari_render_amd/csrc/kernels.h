@@ -9,10 +9,13 @@ namespace akr {
 
 // ---- build switches of k_pt_pass (pt_kernels.hip); each default is the winner of a same-box A/B run ----
 #ifndef AKR_WALK_FD
-#define AKR_WALK_FD 1    // exhaustive pair walk of the force_diffuse kernel: where the records' coefficients sit (disect.h: WALK)
+#define AKR_WALK_FD 4    // exhaustive pair walk of the force_diffuse kernel: which form of the walk (disect.h: WALK; 4 measured best in round 4)
 #endif
 #ifndef AKR_WALK_FULL
-#define AKR_WALK_FULL 1  // the same for the full-graph exhaustive kernels of scenes without textures (TEX kernels keep the scalar walk)
+#define AKR_WALK_FULL 4  // the same for the full-graph exhaustive kernels of scenes without textures
+#endif
+#ifndef AKR_WALK_TEX
+#define AKR_WALK_TEX 4   // the same for the exhaustive kernels of scenes with textures (round 3: 0, the scalar-cache walk)
 #endif
 #ifndef AKR_WALK_FULL_UNROLL
 #define AKR_WALK_FULL_UNROLL 1  // full-graph exhaustive kernels: two records per trip of the pair walk, as the force_diffuse kernel does
@@ -51,7 +54,8 @@ struct PtLdsPlan {
 };
 inline PtLdsPlan pt_lds_plan(bool bvh, bool fd, bool tex, bool defer, uint32_t n_tris) {
     PtLdsPlan pl;
-    const bool recs_in_lds = !bvh && (fd ? AKR_WALK_FD : (tex ? 0 : AKR_WALK_FULL)) == 1;
+    const int walk = fd ? AKR_WALK_FD : (tex ? AKR_WALK_TEX : AKR_WALK_FULL);
+    const bool recs_in_lds = !bvh && (walk == 1 || walk == 3 || walk == 4);
     const bool park = !fd && (tex ? AKR_PT_PARK_TEX != 0 : (bvh ? AKR_PT_PARK_BVH != 0 : AKR_PT_PARK_FULL != 0));
     const bool strag = bvh && (tex ? AKR_PT_STRAGGLERS_TEX : AKR_PT_STRAGGLERS) > 0;
     pl.recs_bytes = recs_in_lds ? (size_t)(n_tris + 2) * 48 : 0;

@@ -58,9 +58,9 @@ __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT
         for (uint32_t i = threadIdx.x; i < p.sc.bvh_tile_nodes * kBvhNodeWords; i += 256u) l[i] = g[i];
         __syncthreads();
     }
-    constexpr int WALK = FD ? AKR_WALK_FD : (TEX ? 0 : AKR_WALK_FULL);
+    constexpr int WALK = FD ? AKR_WALK_FD : (TEX ? AKR_WALK_TEX : AKR_WALK_FULL);
     const float4* lds_recs = nullptr;
-    if (!BVH && WALK == 1) {  // the triangle records behind the staged tables (launch_pt_pass sizes the block)
+    if (!BVH && (WALK == 1 || WALK == 3 || WALK == 4)) {  // the triangle records behind the staged tables (launch_pt_pass sizes the block)
         uint32_t* l = lds_stack + (p.stage_total >> 2);
         const uint32_t* g = (const uint32_t*)p.sc.woop;
         for (uint32_t i = threadIdx.x; i < (p.sc.n_tris + 2u) * 12u; i += 256u) l[i] = g[i];

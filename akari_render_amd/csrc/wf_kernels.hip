@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void k_wf_trace(const PtParams p, const WfBuff
     TraceCounters cnt{0, 0, 0};
     bool has = false, exhausted = false, any = false;
     uint32_t slot = 0;
-    constexpr uint32_t kWfChunk = 128;
+    constexpr uint32_t kWfChunk = 64;  // one wave-fill: near the end of a queue no wave sits on ray ids that idle waves could have traced
     uint32_t c_next = 0, c_end = 0;  // the wave's claimed range of ray ids
     Trav s;
     trav_begin(s, mk3(0, 0, 0), mk3(0, 0, 1), 0.0f, -1.0f, kInvalid, kInvalid);  // idle: tmax < tmin

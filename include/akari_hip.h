@@ -442,7 +442,8 @@ AKR_API int32_t akr_aov_render(akr_context *ctx, akr_scene *scene, const akr_aov
  * MIS-combined into the film's splat channels (resolve scale 1 / spp); uniform / weighted: primal + gradient images are
  * accumulated and `reconstruction_iter` Jacobi sweeps of the screened Poisson problem write the film (gpt.rs:495-606).
  * The reference lets float atomics order a pixel's splats; here the order is fixed (own terms, then neighbours 0..3).
- * Independent sampler only (the reference's Pmj02BnSampler::clone_box is todo!()). Not sharded: one GPU per frame.
+ * Independent sampler only (the reference's Pmj02BnSampler::clone_box is todo!()). akr_gpt_render = one GPU per frame; the session
+ * calls below (akr_gpt_begin with an akr_shard, akr_gpt_reduce) shard a frame over several.
  * ------------------------------------------------------------------------------------------------- */
 typedef enum { AKR_GPT_RECON_NONE = 0, AKR_GPT_RECON_UNIFORM = 1, AKR_GPT_RECON_WEIGHTED = 2 } akr_gpt_reconstruction;
 typedef struct {
@@ -479,6 +480,9 @@ AKR_API int32_t akr_gpt_sums(akr_gpt_session *se, float **device_ptr, uint64_t *
 AKR_API int32_t akr_gpt_sums_read(akr_gpt_session *se, float *dst);
 AKR_API int32_t akr_gpt_sums_write(akr_gpt_session *se, const float *src);
 AKR_API int32_t akr_gpt_finish(akr_gpt_session *se, float *aux, akr_pt_stats *stats);
+/* Frees the session without akr_gpt_finish's reconstruction: for the ranks that are not the root of akr_gpt_reduce (only the root
+ * holds the whole frame's sums) and for abandoning a render. The film keeps what the samples / the reduce left in it. */
+AKR_API int32_t akr_gpt_abort(akr_gpt_session *se, akr_pt_stats *stats);
 
 /* ---------------------------------------------------------------------------------------------------
  * `mcmc_opt` integrator (Method::McmcOpt, akari_integrator/src/mcmc_opt.rs + mcmc.rs:8-80; "type": "mcmc_opt"): primary-sample-

@@ -142,3 +142,32 @@ def test_sharded_hip_render_under_torch_distributed(ctx, cbox_path):
             p.join(300)
             assert p.exitcode == 0
         assert n_bit_diff(np.load(out_path), full.read()) == 0
+
+
+def test_bench_control_flow_with_eight_ranks_on_one_gpu(root):
+    """`bench.py --gpus 8` exactly as the driver launches it (torch.distributed.run, one process per rank) but over gloo with all
+    eight ranks on the one GPU of this box: the 8-rank control flow -- tile shards, per-rank all-gather, the C5 / weak-scaling /
+    sample-range legs, the film reduces, the headline-first bookkeeping -- runs BEFORE the first real 8-GPU node does. (RCCL
+    refuses two ranks on one device, so the wire itself cannot be exercised here.)"""
+    import json
+    import subprocess
+    import sys
+
+    port = 29900 + (os.getpid() % 90)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "8", "--backend", "gloo", "--steps", "1", "--warmup", "0"]
+    res = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]   # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["value"] > 0
+    cfg = out["config"]
+    assert len(cfg["per_rank_samples"]) == 8 and sum(cfg["per_rank_samples"]) == 1920 * 1080 * 1024
+    assert "gloo" in cfg["film_reduce"]            # the line names the reduce path that ran
+    ex = out["extra_configs"]
+    for leg in ("c5_strong", "c2_weak", "c2_sobol_sample_split"):
+        assert "error" not in ex[leg], ex[leg]
+        assert ex[leg]["n_gpus"] == 8 and ex[leg]["value"] > 0
+    assert ex["c2_sobol_sample_split"]["weight_plane_ok"] is True

@@ -137,7 +137,7 @@ def test_material_variants(ctx, cbox_path, root, which):
 
 @pytest.mark.parametrize("normals", [False, True])
 def test_bvh_scene(ctx, normals):
-    """> 64 triangles: BVH4 traversal on the GPU against the oracle's exhaustive loop; instance transform with
+    """> 64 triangles: traversal of the compressed 6-wide BVH on the GPU against the oracle's exhaustive loop; instance transform with
     rotation + scale, per-triangle material slots, optional shading normals."""
     sd = grid_scene(n=24, width=96, height=64, with_normals=normals)
     scene = capi.Scene(ctx, sd)

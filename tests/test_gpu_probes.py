@@ -127,7 +127,7 @@ def test_ggx_dielectric_table(ctx, root, oracle_lib):
 @pytest.mark.parametrize("which", ["exhaustive_cbox", "bvh4_grid", "bvh4_cbox_forced"])
 def test_both_intersectors_against_f64_moeller_trumbore(ctx, cbox_path, which):
     """10^6 rays (half random, half aimed at triangle edges and vertices) through the GPU's exhaustive walk and through its
-    BVH4 traversal: (a) identical to the oracle's exhaustive loop -- hit, triangle, bits of (u, v) -- and (b) in agreement
+    BVH traversal (6-wide compressed nodes): (a) identical to the oracle's exhaustive loop -- hit, triangle, bits of (u, v) -- and (b) in agreement
     with an independent f64 Moeller-Trumbore intersector built from the vertices (oracle/or_accel.h), the stand-in for the
     reference's absent Embree/LuisaCompute intersector (crates/akari_render/src/scene.rs:88-110): same triangle and (t, u, v)
     within a few ulp x conditioning, disagreements only on razor's edges."""

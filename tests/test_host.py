@@ -361,3 +361,25 @@ def test_options_are_a_table_not_the_environment(hip_lib, cbox_path, monkeypatch
     assert capi.get_option("defer_metal") == -1 and capi.get_option("wavefront") == 0
     with pytest.raises(capi.AkariError):
         capi.set_option("no_such_option", 1)
+
+
+def test_scene_compile_does_not_depend_on_the_thread_count(hip_lib, monkeypatch):
+    """host/bvh.cpp and the per-triangle records run on the host's threads above 2^17 triangles: the tree, the triangle order and
+    the records are the same bytes for 1, 3 and 8 threads (every quantity a split depends on is a min, a max or an integer count;
+    the partition is the sequential one)."""
+    import hashlib
+
+    from akari_render_amd import procedural
+
+    sd = procedural.sponza_like(300_000, seed=7, width=32, height=32)
+
+    def digest(threads):
+        monkeypatch.setenv("AKR_HOST_THREADS", str(threads))
+        sc = capi.Scene(None, sd)
+        h = hashlib.sha256()
+        for arr in (capi.ARRAY_BVH_NODES, capi.ARRAY_TRI_GID, capi.ARRAY_WOOP, capi.ARRAY_SHADE):
+            h.update(sc.array(arr, np.uint32).tobytes())
+        return h.hexdigest(), sc.info().n_bvh_nodes, sc.info().bvh_depth
+
+    one = digest(1)
+    assert digest(3) == one and digest(8) == one
