@@ -295,7 +295,7 @@ AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, u
         best = better ? k : best;
         occ_margin = sm > occ_margin ? sm : occ_margin;  // (not fmaxf: that costs two canonicalising v_max per record)
     };
-    if (WALK == 3 || WALK == 4) {  // 4: the same loop with scalar fmas instead of packed ones
+    if (WALK == 3 || WALK == 4 || WALK == 5) {  // 4: the same loop with scalar fmas instead of packed ones; 5: 4 + lockstep pairs
         // Both rays of the pair through every fma of the plane solve and of the inside test as ONE packed instruction. A scalar
         // v_fma_f32 costs its SIMD 2.2 cycles unless its three source registers all have the same parity (the register file's two
         // banks): then 4.4 -- and which registers a value lands in is the allocator's choice, 13 of the 76 three-source instructions
@@ -307,13 +307,14 @@ AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, u
         const bool has_alpha = __builtin_amdgcn_readfirstlane((int)sc.has_alpha) != 0;  // (a scalar branch per record, nothing per lane)
         const v2f tmax2 = {tmax, stmax};
         v2f T2 = {0.0f, 0.0f};
-        auto record3 = [&](auto alpha_tag, uint32_t k, const v4f& q0, const v4f& q1, const v4f& q2) {
+        auto record3 = [&](auto alpha_tag, auto shared_tag, uint32_t k, const v4f& q0, const v4f& q1, const v4f& q2) {
             constexpr bool ALPHA = decltype(alpha_tag)::value;
+            constexpr bool SHARED = decltype(shared_tag)::value;  // the caller knows that this record shares the plane solved last
             const v2f r0xy = __builtin_shufflevector(q0, q0, 0, 1), r0zw = __builtin_shufflevector(q0, q0, 2, 3);
             const v2f r1xy = __builtin_shufflevector(q1, q1, 0, 1), r1zw = __builtin_shufflevector(q1, q1, 2, 3);
             v2f u2, v2;
-            if (WALK == 4) {
-                if (!((sc.plane_share_mask >> k) & 1ull)) {
+            if (WALK == 4 || WALK == 5) {
+                if (!SHARED && !((sc.plane_share_mask >> k) & 1ull)) {
                     const PlaneHit a = tri_plane(o, d, make_float4(q2.x, q2.y, q2.z, q2.w)), b = tri_plane(so, sd, make_float4(q2.x, q2.y, q2.z, q2.w));
                     T2 = (v2f){a.t, b.t};
                     hx2 = (v2f){a.px, b.px}; hy2 = (v2f){a.py, b.py}; hz2 = (v2f){a.pz, b.pz};
@@ -323,7 +324,7 @@ AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, u
                 tri_uv(PlaneHit{T2.y, hx2.y, hy2.y, hz2.y}, make_float4(q0.x, q0.y, q0.z, q0.w), make_float4(q1.x, q1.y, q1.z, q1.w), su, sv);
                 u2 = (v2f){u, su}; v2 = (v2f){v, sv};
             } else {
-            if (!((sc.plane_share_mask >> k) & 1ull)) {
+            if (!SHARED && !((sc.plane_share_mask >> k) & 1ull)) {
                 const v2f r2xy = __builtin_shufflevector(q2, q2, 0, 1), r2zw = __builtin_shufflevector(q2, q2, 2, 3);
                 // tri_plane for both rays: den = fma(x, d.x, fma(y, d.y, z * d.z)), num = fma(x, o.x, fma(y, o.y, fma(z, o.z, w)))
                 const v2f den = pk_fma_b<0>(r2xy, dx2, pk_fma_b<1>(r2xy, dy2, pk_mul_b<0>(r2zw, dz2)));
@@ -337,7 +338,7 @@ AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, u
             }
             // hit_margin: min(min(min(u, v), 1 - (u + v)), min(t, tmax - t)) per ray
             v2f s2, w2;
-            if (WALK == 4) {
+            if (WALK == 4 || WALK == 5) {
                 s2 = (v2f){1.0f - (u2.x + v2.x), 1.0f - (u2.y + v2.y)};
                 w2 = (v2f){tmax - T2.x, stmax - T2.y};
             } else {
@@ -371,11 +372,19 @@ AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, u
             uint32_t k = 0;
             for (; k + 1 < n; k += 2) {
                 b0 = lrec[3 * (k + 1)]; b1 = lrec[3 * (k + 1) + 1]; b2 = lrec[3 * (k + 1) + 2];
-                record3(alpha_tag, k, a0, a1, a2);
-                a0 = lrec[3 * (k + 2)]; a1 = lrec[3 * (k + 2) + 1]; a2 = lrec[3 * (k + 2) + 2];
-                record3(alpha_tag, k + 1, b0, b1, b2);
+                if (WALK == 5 && ((sc.plane_share_mask >> (k + 1)) & 1ull)) {
+                    // the two triangles of a quad: one plane solve, then both inside tests in ONE basic block (no branch between
+                    // them), so that the scheduler can interleave the two records' chains
+                    record3(alpha_tag, std::false_type{}, k, a0, a1, a2);
+                    a0 = lrec[3 * (k + 2)]; a1 = lrec[3 * (k + 2) + 1]; a2 = lrec[3 * (k + 2) + 2];
+                    record3(alpha_tag, std::true_type{}, k + 1, b0, b1, b2);
+                } else {
+                    record3(alpha_tag, std::false_type{}, k, a0, a1, a2);
+                    a0 = lrec[3 * (k + 2)]; a1 = lrec[3 * (k + 2) + 1]; a2 = lrec[3 * (k + 2) + 2];
+                    record3(alpha_tag, std::false_type{}, k + 1, b0, b1, b2);
+                }
             }
-            if (k < n) record3(alpha_tag, k, a0, a1, a2);
+            if (k < n) record3(alpha_tag, std::false_type{}, k, a0, a1, a2);
         };
         if (has_alpha) walk3(std::true_type{});
         else walk3(std::false_type{});

@@ -175,6 +175,7 @@ struct akr_pt_session {
     // cannot change the kernel of a running session
     int defer_metal_option = -1;
     int simple_kernels_option = 1;
+    int defer_on_option = 0;
     // timed regions on the context's stream: pairs still in flight, and the elapsed time of the completed ones (folded in and
     // destroyed as they complete, so a long progressive session holds a bounded number of events)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -453,18 +454,25 @@ static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pas
         }
         p.simple_scene = (simple && se->simple_kernels_option) ? 1u : 0u;
     }
-    {   // conductor hits on even iterations only (pt_kernels.hip): pays when SOME materials have the lobe and most hits do not
+    {   // hits on "expensive" materials on even iterations only (pt_kernels.hip: DEFER): pays when SOME materials are expensive and
+        // most hits are not. Expensive = the conductor lobe; in the BVH kernels of scenes with textures (option defer_on) also /
+        // instead a shader graph to evaluate at the hit.
         const CompiledScene& cs = s->cs;
-        size_t n_metal = 0, n_surface = 0;
+        const bool bvh = !cs.bvh_nodes.empty();
+        uint32_t flags = MF_EVAL_METAL;
+        // (measured on the textured room, BVH kernel: conductor hits deferred 591 Msamples/s, textured hits 573, both 573, none 544)
+        if (bvh && cs.has_textures) flags = se->defer_on_option == 2 ? MF_TEXTURED : (se->defer_on_option == 3 ? (MF_EVAL_METAL | MF_TEXTURED) : MF_EVAL_METAL);
+        size_t n_dear = 0, n_surface = 0;
         for (const DMaterial& m : cs.materials) {
             if (m.kind == MAT_EMISSION) continue;
             n_surface++;
-            if (m.kind == MAT_PRINCIPLED && (m.flags & MF_EVAL_METAL)) n_metal++;
+            if (m.kind == MAT_PRINCIPLED && (m.flags & flags)) n_dear++;
         }
-        bool want = n_metal > 0 && 2 * n_metal <= n_surface;
-        uint32_t mask = 1u;  // iterations with (iteration & mask) != 0 put conductor hits off
+        bool want = n_dear > 0 && 2 * n_dear <= n_surface;
+        uint32_t mask = 1u;  // iterations with (iteration & mask) != 0 put those hits off
         if (se->defer_metal_option >= 0) { mask = (uint32_t)se->defer_metal_option; want = mask != 0; }  // akr_option_set("defer_metal"): measurements / tests
-        p.defer_metal = (want && cs.bvh_nodes.empty() && !c.force_diffuse) ? mask : 0u;
+        p.defer_metal = (want && (!bvh || cs.has_textures) && !c.force_diffuse) ? mask : 0u;
+        p.defer_flags = flags;
     }
     p.shard_rank = c.shard_count > 1 ? c.shard_rank : 0;
     p.shard_count = c.shard_count > 1 ? c.shard_count : 1;
@@ -956,6 +964,7 @@ AKR_API int32_t akr_pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_co
             const TuningOptions t = tuning();
             se->defer_metal_option = t.defer_metal;
             se->simple_kernels_option = t.simple_kernels;
+            se->defer_on_option = t.defer_on;
         }
         if (se->wavefront) {
             fill_params(se.get(), 1, cfg->spp_per_pass);  // for n_items

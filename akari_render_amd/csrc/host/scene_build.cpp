@@ -796,6 +796,7 @@ int* tuning_field(const char* name) {
     if (n == "defer_metal") return &g_tuning.defer_metal;
     if (n == "wavefront") return &g_tuning.wavefront;
     if (n == "simple_kernels") return &g_tuning.simple_kernels;
+    if (n == "defer_on") return &g_tuning.defer_on;
     return nullptr;
 }
 }  // namespace

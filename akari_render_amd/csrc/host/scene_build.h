@@ -91,6 +91,7 @@ void build_alias_table(const std::vector<float>& weights, std::vector<AliasEntry
 //   simple_kernels AKR_PT_SIMPLE=0        0 = never use the SIMPLE instantiations (scenes without coat / transmission / normal map / glass)
 struct TuningOptions {
     int force_bvh = 0, bvh_balanced = 0, defer_metal = -1, wavefront = 0, simple_kernels = 1;
+    int defer_on = 0;  // BVH kernels of textured scenes: which hits the deferral puts off -- 0 / 1 = the conductor lobe (default), 2 = texture-fed materials, 3 = both
 };
 TuningOptions tuning();                          // a snapshot (thread-safe)
 bool tuning_set(const char* name, int value);    // false: unknown name

@@ -55,7 +55,7 @@ struct PtLdsPlan {
 inline PtLdsPlan pt_lds_plan(bool bvh, bool fd, bool tex, bool defer, uint32_t n_tris) {
     PtLdsPlan pl;
     const int walk = fd ? AKR_WALK_FD : (tex ? AKR_WALK_TEX : AKR_WALK_FULL);
-    const bool recs_in_lds = !bvh && (walk == 1 || walk == 3 || walk == 4);
+    const bool recs_in_lds = !bvh && (walk == 1 || walk >= 3);
     const bool park = !fd && (tex ? AKR_PT_PARK_TEX != 0 : (bvh ? AKR_PT_PARK_BVH != 0 : AKR_PT_PARK_FULL != 0));
     const bool strag = bvh && (tex ? AKR_PT_STRAGGLERS_TEX : AKR_PT_STRAGGLERS) > 0;
     pl.recs_bytes = recs_in_lds ? (size_t)(n_tris + 2) * 48 : 0;
@@ -106,7 +106,8 @@ struct PtParams {
     uint32_t stage_bytes[13];  // [12]: the GGX albedo table (full-graph exhaustive kernels)
     uint32_t stage_total;
     uint32_t simple_scene;   // no coat, no transmission, no normal map, no glass material, no textures: the full-graph kernels without that code
-    uint32_t defer_metal;    // exhaustive path: shade hits on materials with a conductor lobe on even iterations only (pt_kernels.hip)
+    uint32_t defer_metal;    // iterations with (iteration & defer_metal) != 0 put hits on "expensive" materials off by one iteration (pt_kernels.hip: DEFER)
+    uint32_t defer_flags;    // ... expensive = (DMaterial.flags & defer_flags) != 0: MF_EVAL_METAL (the conductor lobe), MF_TEXTURED (a graph to evaluate)
     uint32_t tex_slots;      // TEX scenes: value slots per lane of the graph evaluation (LDS, after the launch's other blocks)
     uint32_t tile_offset;    // BVH kernels with a node tile (disect.h: TILE): word offset of the tile; its size is sc.bvh_tile_nodes
     uint32_t park_offset;    // kernels that park cold path state in LDS while shading (dpath.h: PARK): word offset of the columns

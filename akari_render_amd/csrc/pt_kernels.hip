@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT
     }
     constexpr int WALK = FD ? AKR_WALK_FD : (TEX ? AKR_WALK_TEX : AKR_WALK_FULL);
     const float4* lds_recs = nullptr;
-    if (!BVH && (WALK == 1 || WALK == 3 || WALK == 4)) {  // the triangle records behind the staged tables (launch_pt_pass sizes the block)
+    if (!BVH && (WALK == 1 || WALK >= 3)) {  // the triangle records behind the staged tables (launch_pt_pass sizes the block)
         uint32_t* l = lds_stack + (p.stage_total >> 2);
         const uint32_t* g = (const uint32_t*)p.sc.woop;
         for (uint32_t i = threadIdx.x; i < (p.sc.n_tris + 2u) * 12u; i += 256u) l[i] = g[i];
@@ -191,25 +191,27 @@ __global__ __launch_bounds__(256, BVH ? (TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT
             } else {
                 trace_pair_exhaustive<TEX, FD || (!TEX && AKR_WALK_FULL_UNROLL != 0), WALK>(sc, r.ro, r.rd, r.has_ray ? 1e20f : -1.0f, r.ray_ex0, r.s_o, r.s_d, r.has_shadow ? r.s_tmax : -1.0f,
                                             r.s_ex0, r.s_ex1, hit, found, occluded, lds_recs);
-                if (DEFER) {
-                    // A scene with one metal among diffuse surfaces: every wave carries a few lanes on the metal at every
-                    // iteration, so every iteration pays for the conductor lobe (GGX + complex Fresnel, the dearest code of the
-                    // material system) with a handful of lanes. Hits on a material with that lobe are therefore shaded on EVEN
-                    // iterations only: a lane that finds one on an odd iteration keeps the hit and sits the next intersection
-                    // phase out (the walk is wave-uniform: an idle lane costs nothing), and on odd iterations no lane enters
-                    // that code at all. Per lane nothing changes but the iteration a vertex is shaded in.
-                    if (r.deferred) {
-                        hit.gid = r.d_gid; hit.u = r.d_u; hit.v = r.d_v; hit.t = 0.0f;
-                        found = true;
-                        r.has_ray = true;
-                        r.deferred = false;
-                    } else if (r.has_ray && found && (iteration & q.defer_metal)) {
-                        const uint32_t mat = f2u(sc.shade[(size_t)hit.gid * SHADE_ROWS + 6].y);
-                        if (sc.materials[mat].flags & MF_EVAL_METAL) {
-                            r.d_gid = hit.gid; r.d_u = hit.u; r.d_v = hit.v;
-                            r.deferred = true;
-                            r.has_ray = false;  // path_step resolves the shadow ray and finishes the previous sample, no more
-                        }
+            }
+            if (DEFER) {
+                // A scene with one metal among diffuse surfaces: every wave carries a few lanes on the metal at every
+                // iteration, so every iteration pays for the conductor lobe (GGX + complex Fresnel, the dearest code of the
+                // material system) with a handful of lanes. Hits on a material with that lobe are therefore shaded on EVEN
+                // iterations only: a lane that finds one on an odd iteration keeps the hit and sits the next intersection
+                // phase out (the walk is wave-uniform: an idle lane costs nothing), and on odd iterations no lane enters
+                // that code at all. Per lane nothing changes but the iteration a vertex is shaded in.
+                // The BVH kernels of scenes with textures do the same (round 4), for the conductor lobe and for materials whose
+                // shader graph has to be evaluated at the hit: a lane that waits has no ray in the next traversal phase either.
+                if (r.deferred) {
+                    hit.gid = r.d_gid; hit.u = r.d_u; hit.v = r.d_v; hit.t = 0.0f;
+                    found = true;
+                    r.has_ray = true;
+                    r.deferred = false;
+                } else if (r.has_ray && found && (iteration & q.defer_metal)) {
+                    const uint32_t mat = f2u(sc.shade[(size_t)hit.gid * SHADE_ROWS + 6].y);
+                    if (sc.materials[mat].flags & q.defer_flags) {  // MF_EVAL_METAL and / or MF_TEXTURED, the host's choice (api.cpp fill_params)
+                        r.d_gid = hit.gid; r.d_u = hit.u; r.d_v = hit.v;
+                        r.deferred = true;
+                        r.has_ray = false;  // path_step resolves the shadow ray and finishes the previous sample, no more
                     }
                 }
             }
@@ -417,6 +419,10 @@ hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream) {
 #define AKR_LAUNCH(B, F, T)                                                  \
     {                                                                        \
         if (!B && !F && p.defer_metal) AKR_LAUNCH2(false, false, T, true, true)   \
+        else if (B && T && !F && p.defer_metal) {                                 \
+            if (stage) AKR_LAUNCH2(B, false, T, true, true)                       \
+            else AKR_LAUNCH2(B, false, T, false, true)                            \
+        }                                                                         \
         else if (!B || stage) AKR_LAUNCH2(B, F, T, true, false)                  \
         else AKR_LAUNCH2(B, F, T, !B, false)                                     \
     }

@@ -45,6 +45,18 @@ def test_textured_room_parity(ctx, root, variant):
     assert img[40:, :, :].std() > 0.01
 
 
+@pytest.mark.parametrize("defer_on,mask", [(1, 1), (2, 1), (3, 1), (3, 3), (0, 0)])
+def test_deferred_shading_in_the_textured_bvh_kernel_changes_no_bit(ctx, root, defer_on, mask):
+    """The BVH kernels of scenes with textures put hits on conductor / texture-fed materials off to even iterations (pt_kernels.hip:
+    DEFER, option defer_on): per lane only the iteration a vertex is shaded in changes -- film, sampler states and counters are
+    the oracle's for every choice of what is deferred and every period."""
+    sd = with_table(textured_room(48, 40, n_floor=8, alpha_cutout=True), root)
+    with capi.options(defer_on=defer_on, defer_metal=mask):
+        g, o, gst, ost, gs, os_ = render_both(ctx, sd, make_config(spp=12, spp_per_pass=4, max_depth=8), want_states=True)
+    assert_parity(g, o, 48, 40, gst, ost)
+    assert np.array_equal(gs, os_)
+
+
 def test_textured_room_force_diffuse_keeps_textured_emission_and_alpha(ctx, root):
     sd = with_table(textured_room(40, 40, alpha_cutout=True), root)
     g, o, gst, ost, _, _ = render_both(ctx, sd, make_config(spp=8, spp_per_pass=8, max_depth=6, force_diffuse=1))

@@ -146,6 +146,9 @@ def rand_scene(seed, textures=None, big=False):
     cfg.filter_type = int(rng.choice([abi.FILTER_BOX, abi.FILTER_GAUSSIAN])); cfg.filter_radius = float(rng.choice([0.5, 1.0, 1.5]))
     cfg.sampler_type = int(rng.choice([abi.SAMPLER_INDEPENDENT] * 3 + [abi.SAMPLER_SOBOL, abi.SAMPLER_PMJ02BN]))
     cfg.sampler_seed = int(rng.integers(0, 1 << 40))
+    if cfg.sampler_type != abi.SAMPLER_INDEPENDENT and cfg.spp > 1 and rng.random() < 0.4:  # a sample range of the render (index-based samplers)
+        cfg.sample_begin = int(rng.integers(0, cfg.spp))
+        cfg.sample_count = int(rng.integers(1, cfg.spp - cfg.sample_begin + 1))
     cfg.color = int(rng.choice([0, 0, 0, 1, 2, 3]))
     if rng.random() < 0.15:
         cfg.debug_depth = int(rng.integers(0, 4))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes over tools/textured_bench.py's room (textured, and the same room with constant materials that select the same
 # lobes): one --pmc set per rocprofv3 run, kernel-trace only.  usage: tools/tex_pmc.sh [nfloor=1]   (1: exhaustive kernel, 8: tessellated
-# floor, BVH kernel); summary -> gpurun_out/texpmc_<nfloor>/summary.json (-> profiles/r3_pmc_textured_room_{exhaustive,bvh}.json)
+# floor, BVH kernel); summary -> gpurun_out/texpmc_<nfloor>/summary.json (-> profiles/r4_pmc_textured_room_{exhaustive,bvh}.json)
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 NF=${1:-1}
@@ -31,7 +31,9 @@ for tag, name in (("text", "textured"), ("same", "same room, constant materials 
     c = dict(res)
     samples = 4 * 64 * 1920 * 1080   # the warm-up pass + 3 timed passes of 64 spp, both launches counted
     xcd = c["GRBM_GUI_ACTIVE"] / 8.0
-    hbm = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    # FETCH_SIZE tallies every L2 miss at 64 B (profiles/r4_fetch_size_calibration.json); the textured room's traffic is texel gathers
+    # (4 - 16 bytes asked of a line): taken as it is (L2 misses x 64 B), not doubled as for a coalesced stream
+    hbm = (1.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
     out[name] = {"kernel": kernel, "msamples_per_s_under_profiler": b["msamples_per_s"], "shaded_per_sample": b["shaded_per_sample"],
                  "wait_share": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], "valu_busy": c["SQ_INSTS_VALU"] * 2.0 / (1024.0 * xcd),
                  "valu_lane_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]),

@@ -38,6 +38,9 @@ only = os.environ.get("TEXBENCH_ONLY")  # substring of the variant's name
 for name, variant, defer in variants:
     if only and only != name: continue
     capi.set_option("defer_metal", -1 if defer is None else int(defer))
+    if os.environ.get("TEXBENCH_DEFER_ON"):  # which hits the BVH kernels' deferral puts off (1 conductor, 2 textured, 3 both); forces the deferral on
+        capi.set_option("defer_on", int(os.environ["TEXBENCH_DEFER_ON"]))
+        if defer is None: capi.set_option("defer_metal", int(os.environ.get("TEXBENCH_DEFER_MASK", "1")))
     scene = capi.Scene(ctx, variant)
     film = capi.Film(ctx, 1920, 1080)
     cfg = abi.PtConfig.default(); cfg.spp = 64 * (steps + 1); cfg.spp_per_pass = 64; cfg.max_depth = 12
