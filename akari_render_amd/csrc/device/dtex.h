@@ -334,11 +334,16 @@ AKR_HD void eval_material_graph(const TexScene& ts, uint32_t first, uint32_t cou
 // `uv` and folded. `m` must hold the material's folded record on entry.
 AKR_HD void material_at(const TexScene& ts, uint32_t material, vec2 uv, DMaterial& m) {
     if (!(m.flags & MF_TEXTURED)) return;
+#if defined(AKR_DIAG_NO_GRAPH) && defined(__HIP_DEVICE_COMPILE__)  // diagnostic builds only (wrong images): what graph evaluation + re-folding cost
+    return;
+#endif
     const uint32_t first = m.tex_first_node, count = m.tex_n_nodes;
     uint32_t map[IN_COUNT];
     for (uint32_t i = 0; i < IN_COUNT; i++) map[i] = m.tex_input[i];
     MatInputs in = ts.mat_inputs[material];
+#if !(defined(AKR_DIAG_NO_EVAL) && defined(__HIP_DEVICE_COMPILE__))  // diagnostic: re-fold the raw inputs without evaluating the graph
     eval_material_graph(ts, first, count, uv, in);
+#endif
     const uint32_t keep = m.flags & (MF_TEXTURED | MF_ALPHA_TEXTURED);
     fold_inputs(in, m);
     m.flags |= keep;

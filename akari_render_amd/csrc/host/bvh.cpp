@@ -81,7 +81,10 @@ struct BinNode {
 
 constexpr int kBins = 16;
 constexpr size_t kBvhTopSlots = 1024;  // node slots laid out breadth-first (the first four levels of a full tree: 1 + 8 + 64 + 512)
-constexpr uint32_t kLeafMax = 3;
+#ifndef AKR_BVH_LEAF_MAX
+#define AKR_BVH_LEAF_MAX 3  // triangles per leaf (at most 3: the unary count of a node entry)
+#endif
+constexpr uint32_t kLeafMax = AKR_BVH_LEAF_MAX;
 constexpr int kWide = 6;  // children per node (in 8 octant positions)
 
 struct Builder {

@@ -48,3 +48,25 @@ def test_committed_pmc_summaries_carry_a_hash(root):
         if os.path.exists(path):
             m = json.load(open(path))
             assert len(m.get("csrc_hash", "")) == 16 and "k_pt_pass" in m["kernel"]
+
+
+def test_deadline_helper_reports_a_call_that_does_not_come_back():
+    """bench.py puts akr_comm_create + the first akr_film_reduce (never run with more than one rank before a multi-GPU node exists)
+    under a wall-clock deadline: a call that hangs is abandoned and reported, one that raises is reported, one that returns is used."""
+    import time
+
+    done, res = bench._with_deadline(lambda: 41 + 1, 5.0)
+    assert done and res == 42
+    done, res = bench._with_deadline(lambda: (_ for _ in ()).throw(RuntimeError("no communicator")), 5.0)
+    assert done and isinstance(res, RuntimeError)
+    t0 = time.time()
+    done, res = bench._with_deadline(lambda: time.sleep(30), 0.3)
+    assert not done and isinstance(res, TimeoutError) and time.time() - t0 < 5.0
+
+
+def test_sample_split_needs_an_index_based_sampler():
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(bench.ROOT, "bench.py"), "--split", "samples"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode != 0 and "index-based sampler" in r.stderr
