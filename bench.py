@@ -214,12 +214,24 @@ def make_native_comm(ctx, rank, world, torch, dist, dev, local_rank, deadline_s)
     occupy, makes a fresh context, and the films are reduced with torch.distributed instead (config.film_reduce says which)."""
     from akari_render_amd import capi
 
+    # torch.distributed's own collective stays on the main thread (the current CUDA device is thread-local in PyTorch: a helper
+    # thread would start on device 0); only the library's calls -- which bind their context's device themselves -- go under the deadline
+    uid, why = None, None
+    if rank == 0:
+        try:
+            uid = capi.comm_unique_id()
+        except Exception as ex:  # noqa: BLE001 -- e.g. no librccl to dlopen: every rank must still get past the broadcast
+            why = f"akr_comm_unique_id: {type(ex).__name__}: {ex}"
+            log("rank 0: " + why + " -- falling back to torch.distributed.reduce")
+    box = [uid, why]
+    dist.broadcast_object_list(box, src=0)
+    if box[0] is None:
+        return None, ctx, box[1]
+    scratch = torch.zeros(7 * W * H, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize(dev)
+
     def create_and_warm():
-        box = [capi.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
         comm = capi.Comm(ctx, box[0], rank, world)
-        scratch = torch.zeros(7 * W * H, dtype=torch.float32, device=dev)
-        torch.cuda.synchronize(dev)
         sf = capi.Film(ctx, W, H, device_ptr=scratch.data_ptr())
         comm.reduce_film(sf, root=0, blocking=True)  # RCCL builds its rings / proxy connections on the first reduce of a size
         del sf

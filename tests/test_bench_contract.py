@@ -70,3 +70,65 @@ def test_sample_split_needs_an_index_based_sampler():
 
     r = subprocess.run([sys.executable, os.path.join(bench.ROOT, "bench.py"), "--split", "samples"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode != 0 and "index-based sampler" in r.stderr
+
+
+def test_native_communicator_fallbacks(monkeypatch):
+    """make_native_comm with the library and torch.distributed faked: a communicator that works is used on the context it was made
+    on; one whose creation raises, whose first reduce never returns, or whose unique id cannot be made gives (None, a FRESH context,
+    the reason) on every rank -- the run goes on with torch.distributed.reduce instead of waiting on a stuck stream."""
+    import time
+    import types
+
+    import torch as real_torch
+
+    from akari_render_amd import capi
+
+    made = []
+
+    class FakeCtx:
+        def __init__(self, dev):
+            made.append(dev)
+
+    class FakeFilm:
+        def __init__(self, *a, **k):
+            pass
+
+    behaviour = {"mode": "ok"}
+
+    class FakeComm:
+        def __init__(self, ctx, uid, rank, world):
+            if behaviour["mode"] == "raise":
+                raise capi.AkariError(-6, "ncclCommInitRank: unhandled system error")
+            self.closed = False
+
+        def reduce_film(self, film, root=0, blocking=True):
+            if behaviour["mode"] == "hang":
+                time.sleep(60)
+
+        def close(self):
+            self.closed = True
+
+    def uid():
+        if behaviour["mode"] == "no_rccl":
+            raise capi.AkariError(-6, "librccl.so not found")
+        return b"\\0" * 128
+
+    monkeypatch.setattr(capi, "Context", FakeCtx)
+    monkeypatch.setattr(capi, "Film", FakeFilm)
+    monkeypatch.setattr(capi, "Comm", FakeComm)
+    monkeypatch.setattr(capi, "comm_unique_id", uid)
+    fake_torch = types.SimpleNamespace(zeros=lambda *a, **k: types.SimpleNamespace(data_ptr=lambda: 0), float32=real_torch.float32, int32=real_torch.int32,
+                                       tensor=lambda v, dtype=None, device=None: real_torch.tensor(v, dtype=dtype), cuda=types.SimpleNamespace(synchronize=lambda d: None))
+    fake_dist = types.SimpleNamespace(broadcast_object_list=lambda box, src=0: None, all_reduce=lambda t, op=None: None, ReduceOp=types.SimpleNamespace(MIN=0))
+    ctx0 = object()
+    comm, ctx, note = bench.make_native_comm(ctx0, 0, 2, fake_torch, fake_dist, "cpu", 3, 5.0)
+    assert isinstance(comm, FakeComm) and ctx is ctx0 and note is None and made == []
+    for mode, expect in (("raise", "ncclCommInitRank"), ("hang", "no answer after"), ("no_rccl", "librccl.so not found")):
+        behaviour["mode"] = mode
+        before = len(made)
+        comm, ctx, note = bench.make_native_comm(ctx0, 0, 2, fake_torch, fake_dist, "cpu", 3, 0.3)
+        assert comm is None and expect in note, (mode, note)
+        if mode != "no_rccl":  # a possibly stuck stream is abandoned with its context
+            assert isinstance(ctx, FakeCtx) and made[before:] == [3]
+        else:
+            assert ctx is ctx0
