@@ -323,7 +323,7 @@ class Scene:
 
 
 def set_option(name: str, value: int) -> None:
-    """akr_option_set: process-wide tuning switches / test hooks ("force_bvh", "bvh_balanced", "defer_metal", "wavefront")."""
+    """akr_option_set: process-wide tuning switches / test hooks ("force_bvh", "bvh_balanced", "defer_metal", "defer_on", "wavefront", "simple_kernels")."""
     check(lib().akr_option_set(name.encode(), int(value)))
 
 

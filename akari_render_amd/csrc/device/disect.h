@@ -85,24 +85,9 @@ AKR_D float next_up(float x) {  // the next float above a finite x
     uint32_t b = f2u(x);
     return x > 0.0f ? u2f(b + 1u) : (x < 0.0f ? u2f(b - 1u) : u2f(1u));
 }
-#ifndef AKR_MARGIN_ASM
-#define AKR_MARGIN_ASM 0
-#endif
 AKR_D float hit_margin(float t, float u, float v, float tmax) {
-#if AKR_MARGIN_ASM
-    // The same minimum through v_min_f32 / v_min3_f32 named directly: fminf() makes the compiler quiet a possible signalling NaN
-    // in `t` first (a v_max_f32 t, t per ray and record -- t is loop-carried across the records that share a plane, so the
-    // canonicalisation is not hoisted); arithmetic never produces a signalling NaN and v_min returns what fminf returns for
-    // every other input, quiet NaNs included.
-    float a, b, r;
-    const float s = 1.0f - (u + v), w = tmax - t;
-    asm("v_min_f32 %0, %1, %2" : "=v"(a) : "v"(u), "v"(v));
-    asm("v_min_f32 %0, %1, %2" : "=v"(b) : "v"(t), "v"(w));
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(s), "v"(b));
-    return r;
-#else
+    // (v_min3_f32 instead of two v_min_f32 was measured in round 4: a min3 costs two issue slots, -1.3 %; profiles/r4_ab_walk.txt)
     return __builtin_fminf(__builtin_fminf(__builtin_fminf(u, v), 1.0f - (u + v)), __builtin_fminf(t, tmax - t));
-#endif
 }
 
 // Exhaustive intersector: every lane of the wave walks the same triangle list, so the 48-byte records are

@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -37,19 +39,32 @@ void parallel_chunks(unsigned n_chunks, unsigned threads, F&& fn) {
         return;
     }
     std::atomic<unsigned> next{0};
+    std::atomic<bool> failed{false};
+    std::exception_ptr first_error;  // an exception in a worker (std::bad_alloc in a subtree build ...) is re-thrown by the caller:
+    std::mutex error_mutex;          // it must reach the C ABI's guard as a status code, not std::terminate the host process
     auto work = [&] {
         for (;;) {
             unsigned c = next.fetch_add(1);
-            if (c >= n_chunks) break;
-            fn(c);
+            if (c >= n_chunks || failed.load()) break;
+            try {
+                fn(c);
+            } catch (...) {
+                std::lock_guard<std::mutex> lock(error_mutex);
+                if (!first_error) first_error = std::current_exception();
+                failed.store(true);
+            }
         }
     };
     std::vector<std::thread> pool;
     const unsigned extra = std::min(threads, n_chunks) - 1;
     pool.reserve(extra);
-    for (unsigned t = 0; t < extra; t++) pool.emplace_back(work);
+    try {
+        for (unsigned t = 0; t < extra; t++) pool.emplace_back(work);
+    } catch (...) {  // the system refused another thread: the ones that started (and this one) do the work
+    }
     work();
     for (auto& t : pool) t.join();
+    if (first_error) std::rethrow_exception(first_error);
 }
 
 

@@ -89,6 +89,7 @@ void build_alias_table(const std::vector<float>& weights, std::vector<AliasEntry
 //   defer_metal  AKR_PT_DEFER_METAL=<m>   -1 = the library decides (default); 0 = off; m > 0 = iterations with (i & m) != 0 put conductor hits off
 //   wavefront    AKR_PT_MODE=wavefront    1 = sessions on BVH scenes use the wavefront schedule (wf_kernels.hip) instead of the megakernel
 //   simple_kernels AKR_PT_SIMPLE=0        0 = never use the SIMPLE instantiations (scenes without coat / transmission / normal map / glass)
+//   defer_on     (no environment hook)   BVH kernels of textured scenes: which hits the deferral puts off (0 / 1 conductor lobe, 2 texture-fed, 3 both)
 struct TuningOptions {
     int force_bvh = 0, bvh_balanced = 0, defer_metal = -1, wavefront = 0, simple_kernels = 1;
     int defer_on = 0;  // BVH kernels of textured scenes: which hits the deferral puts off -- 0 / 1 = the conductor lobe (default), 2 = texture-fed materials, 3 = both
