@@ -171,3 +171,23 @@ def test_bench_control_flow_with_eight_ranks_on_one_gpu(root):
         assert "error" not in ex[leg], ex[leg]
         assert ex[leg]["n_gpus"] == 8 and ex[leg]["value"] > 0
     assert ex["c2_sobol_sample_split"]["weight_plane_ok"] is True
+
+
+def test_bench_sample_split_headline_with_two_ranks_on_one_gpu(root):
+    """`bench.py --gpus 2 --split samples --sampler sobol`: the headline itself sharded by sample ranges (two ranks over gloo on the
+    one GPU): every rank renders all pixels and half of the samples, the reduced film holds every pixel's full weight (bench.py
+    checks the weight plane itself before it prints), the ranks' sample counts are equal."""
+    import json
+    import subprocess
+    import sys
+
+    port = 29800 + (os.getpid() % 90)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "1", "--split", "samples", "--sampler", "sobol",
+           "--also", "none"]
+    res = subprocess.run(cmd, cwd=root, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    cfg = out["config"]
+    assert out["n_gpus"] == 2 and "sample ranges" in cfg["parallelism"] and "sobol" in out["data"]
+    assert cfg["per_rank_samples"] == [1920 * 1080 * 512] * 2

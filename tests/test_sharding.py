@@ -71,3 +71,49 @@ def test_gloo_world2_film_reduce(oracle_lib, cbox_path, tmp_path):
     sd = scene_json.load_scene(cbox_path, 48, 48)
     full, _ = pyoracle.OracleScene(sd).render(make_config(spp=4, spp_per_pass=2, max_depth=4))
     assert np.array_equal(np.load(out), full)
+
+
+def sample_range_config(cfg: abi.PtConfig, rank: int, world: int) -> abi.PtConfig:
+    """Rank r of `world` renders samples [r spp / world, (r + 1) spp / world) of every pixel (akr_pt_config.sample_begin / _count)."""
+    c = cfg.copy()
+    per = cfg.spp // world
+    c.sample_begin, c.sample_count = rank * per, (cfg.spp - rank * per) if rank == world - 1 else per
+    return c
+
+
+def _range_worker(rank, world, port, cbox_path, out_path):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+
+    torch.set_num_threads(1)
+    distributed.init_process_group("gloo")
+    sd = scene_json.load_scene(cbox_path, 40, 32)
+    sc = pyoracle.OracleScene(sd)
+    cfg = sample_range_config(make_config(spp=10, spp_per_pass=4, max_depth=4, sampler_type=abi.SAMPLER_SOBOL, sampler_seed=2), rank, world)
+    film, _ = sc.render(cfg, n_threads=2)
+    t = torch.from_numpy(film)
+    distributed.reduce_film(t, dst=0)
+    if rank == 0:
+        np.save(out_path, t.numpy())
+    import torch.distributed as dist
+
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_sample_ranges_reduce_to_the_one_shot_render(oracle_lib, cbox_path, tmp_path):
+    """The other way to shard (SURVEY 8e "sample-range split"): two ranks, each ALL pixels and half of the samples of an index-based
+    sampler, films summed over gloo: the weight plane is the one-shot render's exactly, the radiance within the re-association of
+    its f32 additions."""
+    import torch.multiprocessing as mp
+
+    from tests.helpers import rel_rmse, resolve_np
+
+    out = str(tmp_path / "film.npy")
+    mp.spawn(_range_worker, args=(2, _free_port(), cbox_path, out), nprocs=2, join=True)
+    sd = scene_json.load_scene(cbox_path, 40, 32)
+    full, _ = pyoracle.OracleScene(sd).render(make_config(spp=10, spp_per_pass=4, max_depth=4, sampler_type=abi.SAMPLER_SOBOL, sampler_seed=2))
+    got = np.load(out)
+    n = 40 * 32
+    assert np.array_equal(got[6 * n:], full[6 * n:]) and np.all(got[6 * n:] == 10)
+    assert rel_rmse(resolve_np(got, 40, 32), resolve_np(full, 40, 32)) < 1e-6
