@@ -263,3 +263,31 @@ def test_gpt_sharded_across_ranks_is_the_single_gpu_render(ctx, cbox_path, root,
         for s in sessions:
             s.finish()
         assert n_bit_diff(films[0].read(), full.read()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("recon", range(3), ids=abi.GPT_RECON_NAMES)
+def test_gpt_reduce_through_rccl_with_a_world_of_one(ctx, cbox_path, root, recon):
+    """akr_gpt_reduce really runs its ncclReduce (film for `none`, the primal / gradient sums otherwise) -- with the one rank a
+    one-GPU box allows: the reduced session finishes into the film of a session that was never reduced, and a session ended with
+    akr_gpt_abort leaves its film as the samples left it (no splat scale, no reconstruction)."""
+    w, h = 48, 32
+    sd = make_scene("cbox", cbox_path, root, w, h)
+    cfg = gpt_config(spp=3, max_depth=5, rr_depth=2, reconstruction=recon, reconstruction_iter=4)
+    scene = capi.Scene(ctx, sd)
+    plain = capi.Film(ctx, w, h)
+    capi.gpt_render(ctx, scene, cfg, plain)
+    comm = capi.Comm(ctx, capi.comm_unique_id(), 0, 1)
+    film = capi.Film(ctx, w, h)
+    se = capi.GptSession(ctx, scene, cfg, film)
+    se.sample()
+    se.reduce(comm, root=0)
+    se.finish()
+    assert n_bit_diff(film.read(), plain.read()) == 0 and film.splat_scale == plain.splat_scale
+    raw = capi.Film(ctx, w, h)
+    se = capi.GptSession(ctx, scene, cfg, raw)
+    se.sample()
+    before = raw.read()
+    st = se.abort()
+    assert st["n_samples"] > 0 and n_bit_diff(raw.read(), before) == 0 and raw.splat_scale == 1.0
+    comm.close()
