@@ -549,7 +549,10 @@ AKR_API const char *akr_version(void);
  *   "defer_metal"  (AKR_PT_DEFER_METAL=m)   -1 the library decides; 0 off; m > 0: conductor hits shaded when (iteration & m) == 0
  *   "wavefront"    (AKR_PT_MODE=wavefront)  1 = pt sessions on BVH scenes run the wavefront schedule
  *   "simple_kernels" (AKR_PT_SIMPLE=0)      0 = never pick the kernels specialised for scenes without coat / transmission / normal map / glass
- * Unknown names fail with AKR_ERR_INVALID_ARGUMENT. */
+ *   "defer_on"     (no environment hook)    BVH kernels of scenes with textures: which hits "defer_metal" puts off -- 0 / 1 the conductor
+ *                                           lobe (default), 2 texture-fed materials, 3 both
+ * A session reads the options once, when it begins (akr_pt_begin / akr_gpt_begin / ...): a later akr_option_set does not change it.
+ * "wavefront" = 1 on a scene without a BVH renders with the megakernel. Unknown names fail with AKR_ERR_INVALID_ARGUMENT. */
 AKR_API int32_t akr_option_set(const char *name, int32_t value);
 AKR_API int32_t akr_option_get(const char *name, int32_t *value);
 
