@@ -169,6 +169,7 @@ struct akr_pt_session {
     WfBuffers wf;
     uint32_t wf_slots = 0, wf_trace_blocks = 0;
     uint32_t spp_done = 0, n_launches = 0;
+    uint64_t passes_launched = 0;  // passes of all akr_pt_passes launches so far (kernel_ms / passes_launched = what a pass costs)
     uint32_t pmj_spp = 1;  // the spp the pmj02bn sampler stratifies for (the method's total spp)
     const akr_scene::ColorSet* color_set = nullptr;  // the scene's tables for cfg.color != 0 (looked up under the scene's lock by akr_pt_begin)
     // the process-wide tuning options as they were when the session began (akr_pt_begin): an akr_option_set from another thread
@@ -979,8 +980,17 @@ AKR_API int32_t akr_pt_passes(akr_pt_session* se, uint32_t n_passes, int32_t blo
     return guarded([&] {
         se->ctx->bind();
         // the passes requested (each min(spp - cnt, spp_per_pass) samples, pt.rs:1127) are fused into launches
-        // of at most kMaxFusedPasses passes
-        const uint32_t kMaxFusedPasses = 16;
+        // of at most kMaxFusedPasses passes: 16, or -- once the session knows what a pass costs, i.e. when every earlier launch has
+        // completed (a progressive render, a warm-up) -- as many as fit in about three seconds of kernel time, up to 64. The waves of
+        // a launch do not finish together; fewer, longer launches spend less of a render in those tails (C2: +1.2 % at 64 passes,
+        // profiles/r4_ab_walk.txt). The bound keeps a launch on a heavy scene from running for minutes.
+        uint32_t kMaxFusedPasses = 16;
+        se->fold_events(false);
+        if (se->pending.empty() && se->passes_launched > 0 && se->kernel_ms > 0.0) {
+            const double per_pass_ms = se->kernel_ms / (double)se->passes_launched;
+            const double fit = 3000.0 / per_pass_ms;
+            kMaxFusedPasses = fit >= 64.0 ? 64u : (fit <= 16.0 ? 16u : (uint32_t)fit);
+        }
         uint32_t left = n_passes;
         const uint32_t total = session_samples(se->cfg);
         while (left > 0 && se->spp_done < total) {
@@ -997,6 +1007,7 @@ AKR_API int32_t akr_pt_passes(akr_pt_session* se, uint32_t n_passes, int32_t blo
             timer.stop();
             se->spp_done = done;
             se->n_launches++;
+            se->passes_launched += fused;
             left -= fused;
         }
         if (blocking) HIP_CHECK(hipStreamSynchronize(se->ctx->stream));

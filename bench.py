@@ -420,7 +420,8 @@ def roofline_block(key, d):
     m, note = measured_counters(key)
     samples_per_launch = d["n_samples"] / launches
     if m:
-        if m.get("hbm_bytes_per_launch") is not None and m.get("samples_per_launch") == samples_per_launch:
+        if m.get("hbm_bytes_per_launch") is not None and (m.get("samples_per_launch") == samples_per_launch or not d["n_node_visits"]):
+            # (a cbox launch reads and writes the sampler states and the film once, however many passes it fuses)
             out["traffic"] = m["hbm_bytes_per_launch"]
         elif m.get("hbm_bytes_per_sample") is not None:
             out["traffic"] = m["hbm_bytes_per_sample"] * samples_per_launch

@@ -380,7 +380,8 @@ AKR_API int32_t akr_pt_render(akr_context *ctx, akr_scene *scene, const akr_pt_c
  *   begin  -> sampler state buffer created and seeded;
  *   passes -> runs up to n_passes further passes (fewer if spp is reached), asynchronously on the context
  *             stream unless `blocking` is non-zero; *spp_done receives the cumulative sample count. Passes of
- *             one call may share a kernel launch (up to 16): results are those of separate launches;
+ *             one call may share a kernel launch (up to 16; up to 64 once earlier launches of the session have completed and been timed):
+ *             results are those of separate launches;
  *   end    -> waits, returns accumulated counters, frees the session. */
 AKR_API int32_t akr_pt_begin(akr_context *ctx, akr_scene *scene, const akr_pt_config *cfg, akr_film *film,
                              akr_pt_session **out);

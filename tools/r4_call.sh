@@ -1,7 +1,6 @@
 #!/bin/bash
 # Round-4 gpurun payload (rewritten per call; the reusable pieces are tools/pc_sample.sh, gather_calib.sh, r3_batch.sh).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-NFLOOR=1 bash tools/r3_batch.sh tex product texu 2>&1 | grep "\[textured\]"
-NFLOOR=8 bash tools/r3_batch.sh tex product texu 2>&1 | grep "\[textured\]"
-export AKR_DATA_DIR=$PWD/akari_render_amd/data AKR_HIP_LIB=$PWD/akari_render_amd/variants/libakari_hip_texu.so
-timeout 600 python -m pytest tests/test_gpu_textures.py -x -q -m gpu 2>&1 | tail -3
+STEPS=8 REPS=2 bash tools/r3_batch.sh bench c2 product fuse32 fuse64
+STEPS=8 bash tools/r3_batch.sh bench c3 product fuse32 fuse64
+STEPS=4 bash tools/r3_batch.sh bench c4 product fuse64
