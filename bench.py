@@ -561,6 +561,10 @@ def main():
             "roofline": roofline_block(key, d),
             "counters": {k: d[k] for k in ("n_samples", "n_closest", "n_shadow", "n_shaded", "n_node_visits", "n_tri_tests")},
         }
+        # the library fuses the timed region's passes into launches of up to 64 once the warm-up has told the session what a pass costs
+        # (akr_pt_passes): a launch is then several steps, and rocprofv3's per-kernel average mixes it with the 16-pass warm-up launches
+        out["roofline"]["passes_per_launch"] = args.steps * PASSES_PER_STEP / max(1, d["n_launches"])
+        out["roofline"]["steps_per_launch"] = args.steps / max(1, d["n_launches"])
     extra = {}
     printed = []
 
