@@ -288,6 +288,29 @@ class PtStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("_")}
 
 
+class KernelInfo(C.Structure):
+    """akr_kernel_info (include/akari_hip.h): which kernel a pt session launches -- per-scene (hiprtc) or the interpreter."""
+
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("specialised", C.c_uint32),
+        ("cache_hit", C.c_uint32),
+        ("n_shader_kinds", C.c_uint32),
+        ("absent_mask", C.c_uint32),
+        ("min_waves", C.c_uint32),
+        ("vgprs", C.c_uint32),
+        ("scratch_bytes", C.c_uint32),
+        ("compile_ms", C.c_double),
+        ("load_ms", C.c_double),
+        ("status", C.c_char * 256),
+    ]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("struct_size", "status")}
+        d["status"] = self.status.decode(errors="replace")
+        return d
+
+
 class SceneInfo(C.Structure):
     _fields_ = [
         ("width", C.c_uint32),

@@ -18,7 +18,8 @@ AKR_OK = 0
 ERR_INVALID_ARGUMENT, ERR_HIP, ERR_NO_DEVICE, ERR_IO, ERR_PARSE, ERR_UNSUPPORTED, ERR_OOM, ERR_RENDER = -1, -2, -3, -4, -5, -6, -7, -8
 
 (ARRAY_WOOP, ARRAY_TRI_GID, ARRAY_SHADE, ARRAY_INSTANCES, ARRAY_MATERIALS, ARRAY_BVH_NODES, ARRAY_LIGHT_ENTRIES,
- ARRAY_LIGHT_PDF, ARRAY_AREA_ENTRIES, ARRAY_AREA_PDF, ARRAY_INST_TRI_OFFSET, ARRAY_R2C, ARRAY_C2W) = range(13)
+ ARRAY_LIGHT_PDF, ARRAY_AREA_ENTRIES, ARRAY_AREA_PDF, ARRAY_INST_TRI_OFFSET, ARRAY_R2C, ARRAY_C2W,
+ ARRAY_TEX_NODES, ARRAY_TEX_IMAGES, ARRAY_TEX_TEXELS, ARRAY_MAT_INPUTS) = range(17)
 
 # every symbol include/akari_hip.h declares (checked by tests/test_abi.py against the header text)
 EXPORTS = [
@@ -39,6 +40,7 @@ EXPORTS = [
     "akr_host_stdrng_u64", "akr_host_chacha_block", "akr_host_pcg32_states", "akr_host_pcg_start", "akr_host_alias_table",
     "akr_probe_math", "akr_probe_bsdf", "akr_probe_intersect", "akr_probe_surface_interaction", "akr_probe_material_inputs",
     "akr_host_decode_png", "akr_host_decode_jpeg", "akr_host_decode_exr", "akr_host_decode_tiff", "akr_host_decode_dds", "akr_host_pmj02bn_tables",
+    "akr_pt_kernel_info", "akr_scene_spec_source", "akr_host_spec_compile", "akr_probe_material_folded_host",
 ]
 
 
@@ -105,6 +107,10 @@ def lib() -> C.CDLL:
     proto("akr_film_write", vp, fp)
     proto("akr_film_resolve", vp, fp)
     proto("akr_film_device_ptr", vp, vpp, u64p)
+    proto("akr_pt_kernel_info", vp, C.POINTER(abi.KernelInfo))
+    proto("akr_scene_spec_source", vp, C.c_char_p, u64, u64p)
+    proto("akr_host_spec_compile", vp, u32, u32, C.c_char_p, u64p, C.c_char_p, u32)
+    proto("akr_probe_material_folded_host", vp, u32, u32, fp, up, fp, fp)
     proto("akr_context_device_ordinal", vp, C.POINTER(C.c_int32))
     proto("akr_device_count", C.POINTER(C.c_int32))
     proto("akr_option_set", C.c_char_p, i32)
@@ -233,6 +239,30 @@ class Scene:
         i = abi.SceneInfo()
         check(lib().akr_scene_get_info(self.h, C.byref(i)))
         return i
+
+    def spec_source(self) -> str:
+        """akr_scene_spec_source: the kernel text generated for the scene's shader kinds ("" without texture-fed materials)."""
+        n = C.c_uint64()
+        check(lib().akr_scene_spec_source(self.h, None, 0, C.byref(n)))
+        buf = C.create_string_buffer(n.value + 1)
+        check(lib().akr_scene_spec_source(self.h, buf, n.value + 1, C.byref(n)))
+        return buf.value.decode()
+
+    def spec_compile(self, bvh: bool = False, pmj: bool = False, stage: bool = True, defer: bool = False, min_waves: int = 3, arch: str = "gfx950") -> int:
+        """akr_host_spec_compile: hiprtc-compiles the scene's per-scene kernel (no device needed); returns the code object's size."""
+        nbytes = C.c_uint64()
+        log = C.create_string_buffer(4096)
+        flags = (1 if bvh else 0) | (2 if pmj else 0) | (4 if stage else 0) | (8 if defer else 0)
+        check(lib().akr_host_spec_compile(self.h, flags, min_waves, arch.encode(), C.byref(nbytes), log, 4096))
+        return nbytes.value
+
+    def material_folded_host(self, material: int, uv: np.ndarray):
+        """akr_probe_material_folded_host: (folded records u32[n, 64], alpha f32[n], emission f32[n, 3]) of the interpreter, on the host."""
+        uv = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
+        n = uv.shape[0]
+        out, alpha, em = np.zeros((n, 64), np.uint32), np.zeros(n, np.float32), np.zeros((n, 3), np.float32)
+        check(lib().akr_probe_material_folded_host(self.h, material, n, _fp(uv), out.ctypes.data_as(C.POINTER(C.c_uint32)), _fp(alpha), _fp(em)))
+        return out, alpha, em
 
     def set_resolution(self, w: int, h: int):
         check(lib().akr_scene_set_resolution(self.h, w, h))
@@ -474,6 +504,13 @@ class PtSession:
         st = abi.PtStats()
         check(lib().akr_pt_get_stats(self.h, C.byref(st)))
         return st.as_dict()
+
+    def kernel_info(self) -> dict:
+        """akr_pt_kernel_info: per-scene kernel (hiprtc) or interpreter, compile / load times, why."""
+        ki = abi.KernelInfo()
+        ki.struct_size = C.sizeof(abi.KernelInfo)
+        check(lib().akr_pt_kernel_info(self.h, C.byref(ki)))
+        return ki.as_dict()
 
     def end(self) -> dict:
         st = abi.PtStats()

@@ -26,6 +26,19 @@ enum : uint32_t {
 
 enum : uint32_t { MAT_PRINCIPLED = 0, MAT_DIFFUSE = 1, MAT_GLASS = 2, MAT_EMISSION = 3 };
 
+// What a scene's shader graphs can never produce, as a compile-time mask of the kernels (`absent`): the reference traces its kernel
+// from the scene's graphs (svm/compiler.rs:16-76, svm/eval.rs:428-467), so a closure no graph builds is not in its kernel either.
+// A bit may be set only when the VALUE that switches the lobe on is exactly zero for every material and no texture expression
+// feeds it (coat_weight, transmission_weight, metallic: a selection probability of exactly 0 is never taken and remaps u to
+// (u - 0) / (1 - 0) = u; the normal socket; no Glass node) -- the same branches are skipped as at run time, but their code is gone.
+// AB_SIMPLE: the four bits of the precompiled SIMPLE instantiations (scenes without textures); per-scene kernels
+// (host/specialise.cpp) get the scene's own mask.
+enum : uint32_t { AB_COAT = 1u, AB_TRANSMISSION = 2u, AB_NORMAL_MAP = 4u, AB_GLASS = 8u, AB_METAL = 16u, AB_SIMPLE = 15u };
+AKR_HD constexpr uint32_t absent_flags(uint32_t absent) {
+    return ((absent & AB_COAT) ? (uint32_t)MF_COAT : 0u) | ((absent & AB_TRANSMISSION) ? (uint32_t)MF_EVAL_DIEL : 0u) |
+           ((absent & AB_NORMAL_MAP) ? (uint32_t)MF_NORMAL_MAP : 0u) | ((absent & AB_METAL) ? (uint32_t)MF_EVAL_METAL : 0u);
+}
+
 // One folded material. 64 x 4 B = 256 B, 16-byte aligned rows.
 struct alignas(16) DMaterial {
     uint32_t kind, flags;
@@ -415,6 +428,105 @@ AKR_HD bool fold_inputs(const MatInputs& m, DMaterial& d) {
     return true;
 }
 
+// fold_inputs for a record that is already folded: `d` holds fold_inputs of the material's CONSTANT inputs, `m` the inputs at a
+// shading point (constants + the inputs a texture expression feeds, evaluated), `fed` which inputs those are (bit k = input k of
+// dtex.h IN_*), `kind` the material's kind. Recomputes exactly the fields (and flag bits) that read a fed input, with the
+// expressions of fold_inputs above -- the result is fold_inputs(m, d) bit for bit (tests/test_specialise.py checks all masks on
+// the host), but an input nobody feeds costs nothing. `kind` and `fed` are literals in the per-scene code that calls this
+// (host/specialise.cpp), so the conditions fold away at compile time.
+AKR_HD void fold_inputs_fed(uint32_t kind, uint32_t fed, const MatInputs& m, DMaterial& d) {
+    const bool f_color = fed & (1u << 0), f_metallic = fed & (1u << 1), f_rough = fed & (1u << 2), f_ior = fed & (1u << 3), f_level = fed & (1u << 4),
+               f_tint = fed & (1u << 5), f_trans = fed & (1u << 6), f_cw = fed & (1u << 7), f_cr = fed & (1u << 8), f_ci = fed & (1u << 9),
+               f_ct = fed & (1u << 10), f_ecol = fed & (1u << 11), f_estr = fed & (1u << 12), f_normal = fed & (1u << 13);
+    const vec3 color = mk3(m.base_color[0], m.base_color[1], m.base_color[2]);
+    uint32_t fl = d.flags;
+    auto set_flag = [&](uint32_t bit, bool on) { fl = on ? (fl | bit) : (fl & ~bit); };
+    if (kind == MAT_PRINCIPLED) {
+        if (f_color) {
+            d.color = color;
+            d.base_alpha = m.base_alpha;
+            d.diffuse_refl = color * kInvPi;
+        }
+        if (f_metallic) d.metallic = m.metallic;
+        if (f_trans) d.transmission = m.transmission_weight;
+        if (f_rough) {
+            d.roughness = m.roughness;
+            d.alpha = mk2(max_f(m.roughness * m.roughness, 1e-4f), max_f(m.roughness * m.roughness, 1e-4f));
+        }
+        if (f_ior) d.eta = m.ior;
+        if (f_color || f_trans)
+            d.transmission_color = m.transmission_weight > 1e-4f ? mk3(__builtin_sqrtf(color.x), __builtin_sqrtf(color.y), __builtin_sqrtf(color.z)) : mk3(0, 0, 0);
+        const vec3 tint = mk3(m.specular_tint[0], m.specular_tint[1], m.specular_tint[2]);
+        if (f_tint) d.spec_tint = tint;
+        if (f_ior || f_level) {
+            float eta_s = m.ior, f0 = f0_from_ior(eta_s);
+            if (m.specular_ior_level != 0.5f) {
+                f0 *= 2.0f * m.specular_ior_level;
+                eta_s = ior_from_f0(f0);
+            }
+            d.f0 = f0;
+            d.eta_s = eta_s;
+        }
+        if (f_ior || f_level || f_tint) {
+            d.spec_color = tint * d.f0;
+            auto finite = [](float x) { return (x - x) == 0.0f; };
+            const bool spec_layer = d.f0 != 0.0f || !(finite(tint.x) && finite(tint.y) && finite(tint.z));
+            d.z_spec = spec_layer ? ggx_table_z(d.eta_s) : 0.0f;
+            set_flag(MF_SPEC, spec_layer);
+        }
+        if (f_cw) {
+            d.coat_weight = m.coat_weight;
+            set_flag(MF_COAT, m.coat_weight != 0.0f);
+        }
+        if (f_cr) {
+            d.coat_roughness = m.coat_roughness;
+            d.coat_alpha = mk2(max_f(m.coat_roughness * m.coat_roughness, 1e-4f), max_f(m.coat_roughness * m.coat_roughness, 1e-4f));
+        }
+        if (f_ci) d.coat_eta = m.coat_ior;
+        if (f_cw || f_ci) d.z_coat = m.coat_weight != 0.0f ? ggx_table_z(m.coat_ior) : 0.0f;
+        if (f_cw || f_ct) d.coat_scale = lerp3(mk3(1, 1, 1), mk3(m.coat_tint[0], m.coat_tint[1], m.coat_tint[2]), m.coat_weight);
+        if (f_color || f_tint || f_metallic) {
+            d.metal_n = mk3(0, 0, 0);
+            d.metal_k = mk3(0, 0, 0);
+            if (m.metallic > 1e-4f) artistic_to_conductor(color, tint, d.metal_n, d.metal_k);
+        }
+        if (f_metallic) {
+            set_flag(MF_EVAL_BASE, m.metallic < 1.0f - 1e-4f);
+            set_flag(MF_EVAL_METAL, m.metallic > 1e-4f);
+        }
+        if (f_trans) {
+            set_flag(MF_EVAL_DIFF, m.transmission_weight < 1.0f - 1e-4f);
+            set_flag(MF_EVAL_DIEL, m.transmission_weight > 1e-4f);
+        }
+        if (f_normal) {
+            vec3 normal = mk3(-m.normal[0], -m.normal[1], m.normal[2]);
+            const bool nm = !(normal.x == 0.0f && normal.y == 0.0f && normal.z == 0.0f);
+            d.nm_normal = nm ? normalize(normal) : mk3(0, 0, 1);
+            set_flag(MF_NORMAL_MAP, nm);
+        }
+        if (f_ecol || f_estr) d.emission = mk3(m.emission_color[0], m.emission_color[1], m.emission_color[2]) * m.emission_strength;
+    } else if (kind == MAT_DIFFUSE) {
+        if (f_color) {
+            d.color = color;
+            d.base_alpha = m.base_alpha;
+            d.diffuse_refl = color * kInvPi;
+        }
+    } else if (kind == MAT_GLASS) {
+        if (f_color) d.color = color;
+        if (f_ior) d.eta = m.ior;
+        if (f_rough) {
+            d.roughness = m.roughness;
+            d.alpha = mk2(max_f(m.roughness * m.roughness, 1e-4f), max_f(m.roughness * m.roughness, 1e-4f));
+        }
+    } else {  // MAT_EMISSION
+        if (f_color) d.color = color;
+        if (f_ecol || f_estr) d.emission = mk3(m.emission_color[0], m.emission_color[1], m.emission_color[2]) * m.emission_strength;
+    }
+    if ((f_ecol || f_estr) && (kind == MAT_PRINCIPLED || kind == MAT_EMISSION))
+        set_flag(MF_EMISSIVE, d.emission.x != 0.0f || d.emission.y != 0.0f || d.emission.z != 0.0f);
+    d.flags = fl;
+}
+
 AKR_HD float albedo_spec(const DMaterial& m, const float* __restrict__ table, vec3 w) {
     return ggx_dielectric_albedo_z(table, m.roughness, abs_cos_theta(w), m.z_spec);
 }
@@ -434,11 +546,10 @@ struct WoAlbedo {
 AKR_HD float avg3(vec3 e) { return ((e.x + e.y) + e.z) / 3.0f; }
 
 // The Principled closure tree of principled.rs:133-202 (inside the wrapper), evaluated for (wo, wi).
-// simple (a compile-time constant where it matters): the scene has no coat, no transmission, no normal map and no glass material
-// (host: scene_is_simple), so those flags are known to be clear -- the same branches are skipped as at run time, but their code
-// is not in the kernel. The reference's kernel is traced from the scene's shader graphs and holds only the closures they use too.
-AKR_HD BsdfEval principled_eval(const DMaterial& m, const float* __restrict__ table, vec3 wo, vec3 wi, const WoAlbedo* wc = nullptr, bool simple = false) {
-    const uint32_t fl = simple ? (m.flags & ~(uint32_t)(MF_COAT | MF_EVAL_DIEL | MF_NORMAL_MAP)) : m.flags;
+// absent (a compile-time constant where it matters; AB_* above): lobes the scene cannot have, so their flags are known to be clear
+// -- the same branches are skipped as at run time, but their code is not in the kernel.
+AKR_HD BsdfEval principled_eval(const DMaterial& m, const float* __restrict__ table, vec3 wo, vec3 wi, const WoAlbedo* wc = nullptr, uint32_t absent = 0) {
+    const uint32_t fl = m.flags & ~absent_flags(absent);
     BsdfEval b2{mk3(0, 0, 0), 0.0f};
     if (fl & MF_EVAL_BASE) {
         // Mix(transmission){diffuse, dielectric}
@@ -498,23 +609,24 @@ AKR_HD bool sample_lobe(LobeKind lobe, vec2 alpha, float eta, vec3 wo, vec2 u, v
 }
 // which lobe, which alpha, and -- for the roughness AOV -- whether it is the coat
 AKR_HD void principled_select_lobe(const DMaterial& m, const float* __restrict__ table, vec3 wo, float u, LobeKind& lobe, vec2& alpha, bool& coat,
-                                   const WoAlbedo* wc = nullptr, bool simple = false) {
-    const uint32_t fl = simple ? (m.flags & ~(uint32_t)(MF_COAT | MF_EVAL_DIEL | MF_NORMAL_MAP)) : m.flags;
+                                   const WoAlbedo* wc = nullptr, uint32_t absent = 0) {
+    const uint32_t fl = m.flags & ~absent_flags(absent);
     lobe = LOBE_DIFFUSE;
     alpha = m.alpha;
     coat = false;
     float r = u;
     // Coated{coat | Scaled{Emissive{...}}}: top iff u < avg(E_coat(wo))
-    // (simple: the probability is 0 -- never taken, and the remapped number is (u - 0) / (1 - 0) = u exactly)
+    // (absent: the probability is 0 -- never taken, and the remapped number is (u - 0) / (1 - 0) = u exactly; r == u holds here and
+    // after every "u = r" below, so skipping a choice leaves both as they are)
     float p_coat = (fl & MF_COAT) ? avg3(wc ? etop_coat_of(m, wc->coat) : etop_coat(m, table, wo)) : 0.0f;
-    if (!simple && weighted_choice2_and_remap(p_coat, u, r)) {
+    if (!(absent & AB_COAT) && weighted_choice2_and_remap(p_coat, u, r)) {
         lobe = LOBE_REFLECT;
         alpha = m.coat_alpha;
         coat = true;
     } else {
         u = r;
-        // Mix(metallic): b (metal) iff u < metallic
-        if (weighted_choice2_and_remap(m.metallic, u, r)) {
+        // Mix(metallic): b (metal) iff u < metallic  (AB_METAL: metallic is exactly 0)
+        if (!(absent & AB_METAL) && weighted_choice2_and_remap(m.metallic, u, r)) {
             lobe = LOBE_REFLECT;
         } else {
             u = r;
@@ -524,8 +636,8 @@ AKR_HD void principled_select_lobe(const DMaterial& m, const float* __restrict__
                 lobe = LOBE_REFLECT;
             } else {
                 u = r;
-                // Mix(transmission): b (dielectric) iff u < transmission  (simple: transmission is exactly 0)
-                if (!simple && weighted_choice2_and_remap(m.transmission, u, r)) {
+                // Mix(transmission): b (dielectric) iff u < transmission  (AB_TRANSMISSION: transmission is exactly 0)
+                if (!(absent & AB_TRANSMISSION) && weighted_choice2_and_remap(m.transmission, u, r)) {
                     u = r;
                     // Addictive{transmission, reflection}: b (reflection) iff u < fr_dielectric(cos wo, eta)
                     float frac = fr_dielectric(cos_theta(wo), m.eta);
@@ -538,12 +650,12 @@ AKR_HD void principled_select_lobe(const DMaterial& m, const float* __restrict__
     }
 }
 AKR_HD bool principled_sample_wi(const DMaterial& m, const float* __restrict__ table, vec3 wo, float u, vec2 u2, vec3& wi, const WoAlbedo* wc = nullptr,
-                                 bool simple = false) {
+                                 uint32_t absent = 0) {
     LobeKind lobe;
     vec2 alpha;
     bool coat;
-    principled_select_lobe(m, table, wo, u, lobe, alpha, coat, wc, simple);
-    if (simple && lobe == LOBE_TRANSMIT) lobe = LOBE_DIFFUSE;  // unreachable: tells the compiler to drop the refraction code
+    principled_select_lobe(m, table, wo, u, lobe, alpha, coat, wc, absent);
+    if ((absent & AB_TRANSMISSION) && lobe == LOBE_TRANSMIT) lobe = LOBE_DIFFUSE;  // unreachable: tells the compiler to drop the refraction code
     return sample_lobe(lobe, alpha, m.eta, wo, u2, wi);
 }
 
@@ -568,7 +680,7 @@ struct ShadePoint {
     Frame nm_frame_;    // inner (normal-map) frame in local space; identity when !MF_NORMAL_MAP   (not lean)
     vec3 ng_local_;     // frame.to_local(ng)  (normal_map(): ng of the inner SurfaceClosure)       (not lean)
     bool lean;
-    bool simple;        // see principled_eval
+    uint32_t absent;    // AB_* mask, see principled_eval
     bool force_diffuse;
     bool wo_cached;     // wo_albedo holds the table values of the vertex's outgoing direction (shade_point_cache_wo)
     WoAlbedo wo_albedo;
@@ -585,16 +697,16 @@ AKR_HD Frame nm_frame_compute(const Frame& frame, const DMaterial& m) {
 }
 AKR_HD Frame sp_nm_frame(const ShadePoint& sp, const DMaterial& m) {
     if (!sp.lean) return sp.nm_frame_;
-    if (!sp.simple && !sp.force_diffuse && m.kind == MAT_PRINCIPLED && (m.flags & MF_NORMAL_MAP)) return nm_frame_compute(sp.frame, m);
+    if (!(sp.absent & AB_NORMAL_MAP) && !sp.force_diffuse && m.kind == MAT_PRINCIPLED && (m.flags & MF_NORMAL_MAP)) return nm_frame_compute(sp.frame, m);
     return Frame{mk3(0, 0, 1), mk3(1, 0, 0), mk3(0, 1, 0)};
 }
 AKR_HD vec3 sp_ng_local(const ShadePoint& sp) { return sp.lean ? to_local(sp.frame, sp.ng) : sp.ng_local_; }
 
-AKR_HD void shade_point_init(ShadePoint& sp, const DMaterial& m, Frame frame, vec3 ng, bool force_diffuse, bool lean = false, bool simple = false) {
+AKR_HD void shade_point_init(ShadePoint& sp, const DMaterial& m, Frame frame, vec3 ng, bool force_diffuse, bool lean = false, uint32_t absent = 0) {
     sp.frame = frame;
     sp.ng = ng;
     sp.lean = lean;
-    sp.simple = simple;
+    sp.absent = absent;
     sp.force_diffuse = force_diffuse;
     sp.wo_cached = false;
     sp.wo_albedo = WoAlbedo{0.0f, 0.0f};
@@ -602,7 +714,7 @@ AKR_HD void shade_point_init(ShadePoint& sp, const DMaterial& m, Frame frame, ve
     sp.ng_local_ = mk3(0, 0, 0);
     if (!lean) {
         sp.ng_local_ = to_local(frame, ng);
-        if (!simple && !force_diffuse && m.kind == MAT_PRINCIPLED && (m.flags & MF_NORMAL_MAP)) sp.nm_frame_ = nm_frame_compute(frame, m);
+        if (!(absent & AB_NORMAL_MAP) && !force_diffuse && m.kind == MAT_PRINCIPLED && (m.flags & MF_NORMAL_MAP)) sp.nm_frame_ = nm_frame_compute(frame, m);
     }
 }
 
@@ -611,9 +723,9 @@ AKR_HD void shade_point_init(ShadePoint& sp, const DMaterial& m, Frame frame, ve
 AKR_HD void shade_point_cache_wo(ShadePoint& sp, const DMaterial& m, const float* __restrict__ table, vec3 wo) {
     if (sp.force_diffuse || m.kind != MAT_PRINCIPLED) return;
     vec3 lo = to_local(sp.frame, wo);
-    if (!sp.simple && (m.flags & MF_NORMAL_MAP)) lo = to_local(sp_nm_frame(sp, m), lo);
+    if (!(sp.absent & AB_NORMAL_MAP) && (m.flags & MF_NORMAL_MAP)) lo = to_local(sp_nm_frame(sp, m), lo);
     if (m.flags & MF_SPEC) sp.wo_albedo.spec = albedo_spec(m, table, lo);
-    if (!sp.simple && (m.flags & MF_COAT)) sp.wo_albedo.coat = albedo_coat(m, table, lo);
+    if (!(sp.absent & AB_COAT) && (m.flags & MF_COAT)) sp.wo_albedo.coat = albedo_coat(m, table, lo);
     sp.wo_cached = true;
 }
 
@@ -628,7 +740,7 @@ AKR_HD BsdfEval shade_evaluate(const ShadePoint& sp, const DMaterial& m, const f
     }
     switch (m.kind) {
         case MAT_PRINCIPLED: {
-            if (!sp.simple && (m.flags & MF_NORMAL_MAP)) {
+            if (!(sp.absent & AB_NORMAL_MAP) && (m.flags & MF_NORMAL_MAP)) {
                 const Frame nf = sp_nm_frame(sp, m);
                 if (!check_wo_wi_valid(nf.n, sp_ng_local(sp), lo, li)) return zero;
                 lo = to_local(nf, lo);
@@ -636,10 +748,10 @@ AKR_HD BsdfEval shade_evaluate(const ShadePoint& sp, const DMaterial& m, const f
             } else {
                 if (!check_wo_wi_valid(mk3(0, 0, 1), sp_ng_local(sp), lo, li)) return zero;
             }
-            return principled_eval(m, table, lo, li, sp.wo_cached ? &sp.wo_albedo : nullptr, sp.simple);
+            return principled_eval(m, table, lo, li, sp.wo_cached ? &sp.wo_albedo : nullptr, sp.absent);
         }
         case MAT_DIFFUSE: return eval_diffuse(m.diffuse_refl, lo, li);
-        case MAT_GLASS: return sp.simple ? zero : eval_dielectric(m.color, m.color, m.eta, m.alpha, lo, li);
+        case MAT_GLASS: return (sp.absent & AB_GLASS) ? zero : eval_dielectric(m.color, m.color, m.eta, m.alpha, lo, li);
         default: return zero;  // Emission node: EmissiveSurface{inner: None}
     }
 }
@@ -662,18 +774,18 @@ AKR_HD BsdfSample shade_sample(const ShadePoint& sp, const DMaterial& m, const f
     } else {
         switch (m.kind) {
             case MAT_PRINCIPLED: {
-                const bool nm = !sp.simple && (m.flags & MF_NORMAL_MAP) != 0;
+                const bool nm = !(sp.absent & AB_NORMAL_MAP) && (m.flags & MF_NORMAL_MAP) != 0;
                 const Frame nf = nm ? sp_nm_frame(sp, m) : Frame{mk3(0, 0, 1), mk3(1, 0, 0), mk3(0, 1, 0)};
                 vec3 lo2 = nm ? to_local(nf, lo) : lo;
                 vec3 w2;
-                valid = principled_sample_wi(m, table, lo2, u_select, u_sample, w2, sp.wo_cached ? &sp.wo_albedo : nullptr, sp.simple);
+                valid = principled_sample_wi(m, table, lo2, u_select, u_sample, w2, sp.wo_cached ? &sp.wo_albedo : nullptr, sp.absent);
                 wl = nm ? to_world(nf, w2) : w2;
                 valid = valid & check_wo_wi_valid(nf.n, sp_ng_local(sp), lo, wl);
                 break;
             }
             case MAT_DIFFUSE: valid = sample_lobe(LOBE_DIFFUSE, mk2(0, 0), 1.0f, lo, u_sample, wl); break;
             case MAT_GLASS: {
-                if (sp.simple) { valid = false; break; }  // no glass material in a simple scene
+                if (sp.absent & AB_GLASS) { valid = false; break; }  // no glass material in the scene
                 float frac = fr_dielectric(cos_theta(lo), m.eta), r;
                 LobeKind lobe = weighted_choice2_and_remap(frac, u_select, r) ? LOBE_REFLECT : LOBE_TRANSMIT;
                 valid = sample_lobe(lobe, m.alpha, m.eta, lo, u_sample, wl);

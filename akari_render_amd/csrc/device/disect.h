@@ -5,11 +5,16 @@
 // (scene.rs:98-100) or fails the stochastic alpha test (scene.rs:49-86); closest hit = smallest t.
 // Added so that results do not depend on traversal order: ties in t go to the lowest global triangle id.
 #pragma once
-#include <type_traits>
 #include "drng.h"
 #include "dscene.h"
 
 namespace akr {
+
+// compile-time flags passed to generic lambdas (the headers keep clear of <type_traits>: they are also compiled by hiprtc, which has no host headers)
+template <bool V>
+struct BoolTag {
+    static constexpr bool value = V;
+};
 
 struct Hit {
     float t, u, v;
@@ -53,10 +58,7 @@ AKR_HD bool tri_test(vec3 o, vec3 d, float4 r0, float4 r1, float4 r2, float tmin
 AKR_D float textured_alpha(const DScene& sc, const float4* r, uint32_t material, float u, float v) {
     float w = 1.0f - u - v;
     vec2 uv = mk2((r[0].w * w + r[2].w * u) + r[4].w * v, (r[1].w * w + r[3].w * u) + r[5].w * v);
-    const DMaterial& m = sc.materials[material];
-    MatInputs in = sc.tex.mat_inputs[material];
-    eval_material_graph(sc.tex, m.tex_first_node, m.tex_n_nodes, uv, in);
-    return in.base_alpha;  // = w of the node feeding base_color
+    return material_alpha_at(sc.tex, sc.materials[material], material, uv);  // = w of the node feeding base_color
 }
 // scene.rs:49-86 for folded materials: alpha = alpha channel of the base-colour node
 template <bool TEX>
@@ -360,19 +362,19 @@ AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, u
                 if (WALK == 5 && ((sc.plane_share_mask >> (k + 1)) & 1ull)) {
                     // the two triangles of a quad: one plane solve, then both inside tests in ONE basic block (no branch between
                     // them), so that the scheduler can interleave the two records' chains
-                    record3(alpha_tag, std::false_type{}, k, a0, a1, a2);
+                    record3(alpha_tag, BoolTag<false>{}, k, a0, a1, a2);
                     a0 = lrec[3 * (k + 2)]; a1 = lrec[3 * (k + 2) + 1]; a2 = lrec[3 * (k + 2) + 2];
-                    record3(alpha_tag, std::true_type{}, k + 1, b0, b1, b2);
+                    record3(alpha_tag, BoolTag<true>{}, k + 1, b0, b1, b2);
                 } else {
-                    record3(alpha_tag, std::false_type{}, k, a0, a1, a2);
+                    record3(alpha_tag, BoolTag<false>{}, k, a0, a1, a2);
                     a0 = lrec[3 * (k + 2)]; a1 = lrec[3 * (k + 2) + 1]; a2 = lrec[3 * (k + 2) + 2];
-                    record3(alpha_tag, std::false_type{}, k + 1, b0, b1, b2);
+                    record3(alpha_tag, BoolTag<false>{}, k + 1, b0, b1, b2);
                 }
             }
-            if (k < n) record3(alpha_tag, std::false_type{}, k, a0, a1, a2);
+            if (k < n) record3(alpha_tag, BoolTag<false>{}, k, a0, a1, a2);
         };
-        if (has_alpha) walk3(std::true_type{});
-        else walk3(std::false_type{});
+        if (has_alpha) walk3(BoolTag<true>{});
+        else walk3(BoolTag<false>{});
         // (u, v) of the closest hit, once per walk instead of two selects per record: the record's rows from LDS again (a per-lane
         // address now) and the hit point o + t d with the t the walk kept -- the very operations on the very operands of the walk
         // (hx2.x = fma(T2.x, d.x, o.x), u2.x = the fma chain over row 0), so the bits are the walk's.

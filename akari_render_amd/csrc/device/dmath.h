@@ -6,8 +6,19 @@
 // the polynomial kernels below instead of the device math library -- so a film rendered here is a pure
 // function of (scene, config, seed), reproducible bit-for-bit on any IEEE machine that follows the same text.
 #pragma once
+#if !defined(__HIPCC_RTC__)  // hiprtc (per-scene kernels, host/specialise.cpp) brings the HIP runtime declarations and the fixed-width integers itself
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else
+typedef unsigned char uint8_t;
+typedef unsigned short uint16_t;
+typedef int int32_t;
+typedef unsigned int uint32_t;
+typedef long int64_t;
+typedef unsigned long uint64_t;
+typedef unsigned long uintptr_t;
+typedef unsigned long size_t;
+#endif
 
 #define AKR_HD __host__ __device__ __forceinline__
 #define AKR_D __device__ __forceinline__

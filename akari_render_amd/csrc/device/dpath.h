@@ -195,9 +195,7 @@ AKR_D vec3 material_emission_at(const DScene& sc, uint32_t material, vec2 uv) {
     if (TEX) {
         if ((m.flags & MF_TEXTURED) && (m.tex_input[IN_EMISSION_COLOR] != kNodeNone || m.tex_input[IN_EMISSION_STRENGTH] != kNodeNone)) {
             if (!(m.kind == MAT_PRINCIPLED || m.kind == MAT_EMISSION)) return mk3(0, 0, 0);
-            MatInputs in = sc.tex.mat_inputs[material];
-            eval_material_graph(sc.tex, m.tex_first_node, m.tex_n_nodes, uv, in);
-            return mk3(in.emission_color[0], in.emission_color[1], in.emission_color[2]) * in.emission_strength;
+            return material_emission_inputs_at(sc.tex, m, material, uv);
         }
     }
     return material_emission(m);
@@ -411,7 +409,7 @@ AKR_D void shifted_pixel(const PtParams& p, uint32_t px, uint32_t py, uint32_t& 
 // FD: 1 / 0 = force_diffuse known at compile time (the reference's JIT also specialises the kernel on it: the branch
 // at pt.rs:268 is taken while tracing the kernel, so a force_diffuse kernel contains no Principled code); -1 = read
 // p.force_diffuse at run time.
-template <int FD = -1, bool TEX = false, bool PMJ = false, int PARK = 0, bool SIMPLE = false>  // PARK: 0 no, 1 yes, 2 yes without the DEFER fields
+template <int FD = -1, bool TEX = false, bool PMJ = false, int PARK = 0, uint32_t ABSENT = 0>  // PARK: 0 no, 1 yes, 2 yes without the DEFER fields; ABSENT: dbsdf.h AB_*
 AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found, bool occluded, uint32_t pix_in, uint32_t sx_in, uint32_t sy_in,
                      uint32_t* park = nullptr) {
     const bool force_diffuse = FD < 0 ? (p.force_diffuse != 0) : (FD != 0);
@@ -497,7 +495,7 @@ AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found,
                 vec3 u_bsdf = next_3d<PMJ>(p, r.smp);
                 // sample_surface_and_shade_direct, pt.rs:297-323
                 ShadePoint sp;
-                shade_point_init(sp, mat, si.frame, si.ng, force_diffuse, /*lean=*/!TEX, /*simple=*/SIMPLE);
+                shade_point_init(sp, mat, si.frame, si.ng, force_diffuse, /*lean=*/!TEX, /*absent=*/ABSENT);
 #ifndef AKR_NO_WO_CACHE  // (A/B switch of tools/r2_ab.sh)
                 if (FD != 1) shade_point_cache_wo(sp, mat, sc.ggx_table, wo);
 #endif

@@ -165,6 +165,10 @@ constexpr uint32_t kMaxGraphNodes = 256;  // after pruning to the texture-fed in
 constexpr uint32_t kTexMaxSlots = 8;
 constexpr uint32_t kTexValStride = 256;  // every kernel that evaluates graphs runs workgroups of (at most) 256 threads
 constexpr uint32_t kTexNoSlot = 0xffu;
+// DMaterial.tex_n_nodes: bits 0-15 the length of the pruned list, bits 16-31 the material's shader kind -- materials whose lists
+// have the same shape (operations, argument topology, fed inputs, image formats) share one, the reference's `shader_kind`
+// (svm/compiler.rs:16-76); a per-scene kernel switches on it (host/specialise.cpp), the interpreter ignores it.
+constexpr uint32_t kTexCountMask = 0xffffu, kTexKindShift = 16;
 struct DNode {                           // = akr_shader_node, 32 B
     uint32_t op;
     uint32_t arg[4];
@@ -185,59 +189,70 @@ struct TexScene {  // the texture part of DScene
     uint32_t val_offset_words;                 // where this launch's value slots start in the workgroup's dynamic LDS (set by the launcher)
 };
 
-// One node (svm/eval.rs:97-269). `get(a)` returns the value of argument node / slot `a`. Values are float4, narrower types
-// zero-extended, so the auto-convert rules of eval.rs:301-349 are component reads.
+// The nodes (svm/eval.rs:97-269), one function each: the interpreter below (eval_node) and the straight-line code generated per
+// scene (host/specialise.cpp) call the same definitions. Values are float4, narrower types zero-extended, so the auto-convert
+// rules of eval.rs:301-349 are component reads.
+AKR_HD TexVal node_const(float k0, float k1, float k2) { return tv(k0, k1, k2, 0.0f); }
+AKR_HD TexVal node_rgb(uint32_t color, float k0, float k1, float k2, bool tag_aces) {  // rgb_to_target_colorspace(rgb, node space, pipeline.rgb_colorspace), texture/mod.rs:9-30
+    vec3 c = cs_convert(mk3(k0, k1, k2), tag_aces, (color & COLOR_RGB_ACES) != 0);
+    return tv(c.x, c.y, c.z, 1.0f);
+}
+AKR_HD TexVal node_texcoords(vec2 uv) { return tv(uv.x, uv.y, 0.0f, 0.0f); }
+AKR_HD TexVal node_image(const uint32_t* __restrict__ texels, const DImage& im, vec2 st, bool srgb) {
+    TexVal v = tex_sample(texels, im, st);
+    if (srgb) v = tv(srgb_to_linear1(v.x), srgb_to_linear1(v.y), srgb_to_linear1(v.z), v.w);
+    return v;
+}
+AKR_HD TexVal node_mapping(TexVal a, TexVal loc, TexVal sc, uint32_t type) {
+    if (type == 0) return tv(a.x * sc.x + loc.x, a.y * sc.y + loc.y, a.z * sc.z + loc.z, 0.0f);
+    return tv((a.x - loc.x) / sc.x, (a.y - loc.y) / sc.y, (a.z - loc.z) / sc.z, 0.0f);
+}
+AKR_HD bool node_checker_first(vec2 st, float scale) {  // which of the two colours
+    float fx, fy;
+    int px = tex_floor_to_int((st.x * scale) * 2.0f, fx), py = tex_floor_to_int((st.y * scale) * 2.0f, fy);
+    return ((px + py) & 1) == 0;
+}
+AKR_HD TexVal node_uplift(uint32_t color, TexVal a) {  // spectral_uplift: rgb_colorspace -> the space of color_repr, texture/mod.rs:31-43
+    vec3 c = cs_convert(mk3(a.x, a.y, a.z), (color & COLOR_RGB_ACES) != 0, (color & COLOR_REPR_ACES) != 0);
+    return tv(c.x, c.y, c.z, a.w);
+}
+AKR_HD TexVal node_extract(TexVal a, uint32_t f) { return f == 0 ? tv(a.x, 0, 0, 0) : f == 1 ? tv(a.y, 0, 0, 0) : f == 2 ? tv(a.z, 0, 0, 0) : tv(a.x, a.y, 0, 0); }
+AKR_HD TexVal node_normal_map(TexVal a, float s) {
+    float nx = 2.0f * a.x - 1.0f, ny = 2.0f * a.y - 1.0f, nz = 2.0f * a.z - 1.0f;
+    if (s != 1.0f) { nx = nx * s; ny = ny * s; nz = nz * 1.0f; }
+    return tv(nx, ny, nz, 0.0f);
+}
+// One node of a list. `get(a)` returns the value of argument node / slot `a`.
 template <typename Get>
 AKR_HD TexVal eval_node(const TexScene& ts, const DNode& nd, uint32_t op, vec2 uv, Get get) {
     TexVal v = tv(0, 0, 0, 0);
     switch (op) {
-        case NODE_CONST: v = tv(nd.k[0], nd.k[1], nd.k[2], 0.0f); break;
-        case NODE_RGB: {  // rgb_to_target_colorspace(rgb, node space, pipeline.rgb_colorspace), texture/mod.rs:9-30
-            vec3 c = cs_convert(mk3(nd.k[0], nd.k[1], nd.k[2]), nd.arg[0] == 1u, (ts.color & COLOR_RGB_ACES) != 0);
-            v = tv(c.x, c.y, c.z, 1.0f);
-            break;
-        }
-        case NODE_TEXCOORDS: v = tv(uv.x, uv.y, 0.0f, 0.0f); break;
+        case NODE_CONST: v = node_const(nd.k[0], nd.k[1], nd.k[2]); break;
+        case NODE_RGB: v = node_rgb(ts.color, nd.k[0], nd.k[1], nd.k[2], nd.arg[0] == 1u); break;
+        case NODE_TEXCOORDS: v = node_texcoords(uv); break;
         case NODE_IMAGE: {
             vec2 st = uv;
             if (nd.arg[1] != kNodeNone) { TexVal a = get(nd.arg[1]); st = mk2(a.x, a.y); }
-            v = tex_sample(ts.texels, ts.images[nd.arg[0]], st);
-            if (nd.arg[2]) v = tv(srgb_to_linear1(v.x), srgb_to_linear1(v.y), srgb_to_linear1(v.z), v.w);
+            v = node_image(ts.texels, ts.images[nd.arg[0]], st, nd.arg[2] != 0);
             break;
         }
         case NODE_MAPPING: {
             TexVal a = get(nd.arg[0]), loc = get(nd.arg[1]), sc = get(nd.arg[2]);
-            if (nd.arg[3] == 0) v = tv(a.x * sc.x + loc.x, a.y * sc.y + loc.y, a.z * sc.z + loc.z, 0.0f);
-            else v = tv((a.x - loc.x) / sc.x, (a.y - loc.y) / sc.y, (a.z - loc.z) / sc.z, 0.0f);
+            v = node_mapping(a, loc, sc, nd.arg[3]);
             break;
         }
         case NODE_CHECKERBOARD: {
             vec2 st = uv;
             if (nd.arg[0] != kNodeNone) { TexVal a = get(nd.arg[0]); st = mk2(a.x, a.y); }
-            float scale = get(nd.arg[1]).x, fx, fy;
-            int px = tex_floor_to_int((st.x * scale) * 2.0f, fx), py = tex_floor_to_int((st.y * scale) * 2.0f, fy);
-            v = (((px + py) & 1) == 0) ? get(nd.arg[2]) : get(nd.arg[3]);
+            v = node_checker_first(st, get(nd.arg[1]).x) ? get(nd.arg[2]) : get(nd.arg[3]);
             break;
         }
-        case NODE_SPECTRAL_UPLIFT: {  // spectral_uplift: rgb_colorspace -> the space of color_repr, texture/mod.rs:31-43
-            TexVal a = get(nd.arg[0]);
-            vec3 c = cs_convert(mk3(a.x, a.y, a.z), (ts.color & COLOR_RGB_ACES) != 0, (ts.color & COLOR_REPR_ACES) != 0);
-            v = tv(c.x, c.y, c.z, a.w);
-            break;
-        }
+        case NODE_SPECTRAL_UPLIFT: v = node_uplift(ts.color, get(nd.arg[0])); break;
         case NODE_SEPARATE_COLOR: v = get(nd.arg[0]); break;
-        case NODE_EXTRACT: {
-            TexVal a = get(nd.arg[0]);
-            uint32_t f = nd.arg[1];
-            v = f == 0 ? tv(a.x, 0, 0, 0) : f == 1 ? tv(a.y, 0, 0, 0) : f == 2 ? tv(a.z, 0, 0, 0) : tv(a.x, a.y, 0, 0);
-            break;
-        }
+        case NODE_EXTRACT: v = node_extract(get(nd.arg[0]), nd.arg[1]); break;
         case NODE_NORMAL_MAP: {
             TexVal a = get(nd.arg[0]);
-            float s = get(nd.arg[1]).x;
-            float nx = 2.0f * a.x - 1.0f, ny = 2.0f * a.y - 1.0f, nz = 2.0f * a.z - 1.0f;
-            if (s != 1.0f) { nx = nx * s; ny = ny * s; nz = nz * 1.0f; }
-            v = tv(nx, ny, nz, 0.0f);
+            v = node_normal_map(a, get(nd.arg[1]).x);
             break;
         }
         default: break;
@@ -330,6 +345,15 @@ AKR_HD void eval_material_graph(const TexScene& ts, uint32_t first, uint32_t cou
     }
 }
 
+#if defined(AKR_SPEC_GRAPHS)
+// Per-scene kernels (hiprtc, host/specialise.cpp): the scene's node lists as straight-line code, one case per shader kind
+// (svm/eval.rs:428-467 emits the same switch). The generated text defines
+//   spec_material_at(ts, material, uv, m)   the whole of material_at below for an MF_TEXTURED material
+//   spec_alpha(ts, m, material, uv)         w of the node feeding base_color (the alpha test, disect.h)
+//   spec_emission(ts, m, material, uv)      emission_color * emission_strength with the fed ones evaluated (light samples, dpath.h)
+#include "akr_scene_spec.h"
+#endif
+
 // The material at a shading point: the folded record as is, or -- for MF_TEXTURED materials -- its graph evaluated at
 // `uv` and folded. `m` must hold the material's folded record on entry.
 AKR_HD void material_at(const TexScene& ts, uint32_t material, vec2 uv, DMaterial& m) {
@@ -337,12 +361,15 @@ AKR_HD void material_at(const TexScene& ts, uint32_t material, vec2 uv, DMateria
 #if defined(AKR_DIAG_NO_GRAPH) && defined(__HIP_DEVICE_COMPILE__)  // diagnostic builds only (wrong images): what graph evaluation + re-folding cost
     return;
 #endif
+#if defined(AKR_SPEC_GRAPHS)
+    spec_material_at(ts, material, uv, m);
+#else
     const uint32_t first = m.tex_first_node, count = m.tex_n_nodes;
     uint32_t map[IN_COUNT];
     for (uint32_t i = 0; i < IN_COUNT; i++) map[i] = m.tex_input[i];
     MatInputs in = ts.mat_inputs[material];
 #if !(defined(AKR_DIAG_NO_EVAL) && defined(__HIP_DEVICE_COMPILE__))  // diagnostic: re-fold the raw inputs without evaluating the graph
-    eval_material_graph(ts, first, count, uv, in);
+    eval_material_graph(ts, first, count & kTexCountMask, uv, in);
 #endif
     const uint32_t keep = m.flags & (MF_TEXTURED | MF_ALPHA_TEXTURED);
     fold_inputs(in, m);
@@ -350,6 +377,27 @@ AKR_HD void material_at(const TexScene& ts, uint32_t material, vec2 uv, DMateria
     m.tex_first_node = first;
     m.tex_n_nodes = count;
     for (uint32_t i = 0; i < IN_COUNT; i++) m.tex_input[i] = map[i];
+#endif
+}
+// w of the node feeding a texture-fed base colour at `uv` (the stochastic alpha test, scene.rs:49-86 / principled.rs:15-21)
+AKR_HD float material_alpha_at(const TexScene& ts, const DMaterial& m, uint32_t material, vec2 uv) {
+#if defined(AKR_SPEC_GRAPHS)
+    return spec_alpha(ts, m, material, uv);
+#else
+    MatInputs in = ts.mat_inputs[material];
+    eval_material_graph(ts, m.tex_first_node, m.tex_n_nodes & kTexCountMask, uv, in);
+    return in.base_alpha;
+#endif
+}
+// emission_color * emission_strength of a material whose emission inputs are texture-fed, at `uv` (AreaLight::sample_direct)
+AKR_HD vec3 material_emission_inputs_at(const TexScene& ts, const DMaterial& m, uint32_t material, vec2 uv) {
+#if defined(AKR_SPEC_GRAPHS)
+    return spec_emission(ts, m, material, uv);
+#else
+    MatInputs in = ts.mat_inputs[material];
+    eval_material_graph(ts, m.tex_first_node, m.tex_n_nodes & kTexCountMask, uv, in);
+    return mk3(in.emission_color[0], in.emission_color[1], in.emission_color[2]) * in.emission_strength;
+#endif
 }
 
 }  // namespace akr

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "scene_build.h"
+#include "specialise.h"
 #include "stdrng.h"
 
 using namespace akr;
@@ -115,6 +116,7 @@ struct akr_context {
     hipStream_t stream = nullptr;
     hipDeviceProp_t props;
     void bind() const { HIP_CHECK(hipSetDevice(device)); }
+    SpecCache spec_cache;  // per-scene kernels loaded on this device (host/specialise.cpp)
     // tables of the pmj02bn sampler, uploaded when the first session asks for it
     DevBuf pmj_sets, bluenoise;
     void ensure_pmj_tables() {
@@ -142,6 +144,10 @@ struct akr_scene {
     };
     std::map<uint32_t, std::unique_ptr<ColorSet>> color_sets;
     std::mutex color_sets_mutex;  // sessions of several host threads may begin on one scene; entries are never removed before the scene dies
+    // the scene's shader kinds as kernel text (host/specialise.cpp), made when the first session asks for a per-scene kernel
+    std::string spec_header;
+    bool spec_header_made = false;
+    std::mutex spec_mutex;
     DScene dscene;
     float r2c[16], c2w[16];
     uint32_t c2w_identity = 0;
@@ -177,6 +183,13 @@ struct akr_pt_session {
     int defer_metal_option = -1;
     int simple_kernels_option = 1;
     int defer_on_option = 0;
+    int max_fused_option = 0;
+    // per-scene kernel (host/specialise.cpp): set by akr_pt_begin when the options ask for one and the compile succeeded; the
+    // precompiled interpreter kernel otherwise. spec_active also shapes fill_params (no value slots in LDS, the kernel's own LDS budget).
+    bool spec_active = false;
+    int spec_waves = 3;
+    std::shared_ptr<SpecKernel> spec;
+    std::string spec_status = "not requested";
     // timed regions on the context's stream: pairs still in flight, and the elapsed time of the completed ones (folded in and
     // destroyed as they complete, so a long progressive session holds a bounded number of events)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -425,13 +438,13 @@ static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pas
         for (int i = 0; i < 12; i++) total += (bytes[i] + 15) & ~(size_t)15;
         std::memset(p.stage_bytes, 0, sizeof p.stage_bytes);
         p.stage_total = 0;
-        p.tex_slots = cs.has_textures ? cs.tex_slots : 0;
+        p.tex_slots = (cs.has_textures && !se->spec_active) ? cs.tex_slots : 0;  // a per-scene kernel keeps node values in registers
         // one workgroup's dynamic LDS stays within 64 KB: traversal stacks + staged tables + the graph evaluation's value slots
         // what the launch keeps in LDS besides the staged tables: traversal stacks, graph values, and the columns / records of pt_lds_plan
         const PtLdsPlan plan = pt_lds_plan(bvh, c.force_diffuse != 0, cs.has_textures, /*defer: the larger park block*/ true, cs.n_tris);
         const size_t other = (bvh ? (size_t)p.sc.bvh_stack_depth * 256 * 4 : 0) + (size_t)p.tex_slots * kTexValStride * sizeof(TexVal) + plan.recs_bytes +
                              plan.park_bytes + plan.carry_bytes;
-        const size_t lds_budget = pt_lds_budget(cs.has_textures);
+        const size_t lds_budget = (se->spec_active && se->spec_waves >= 4) ? pt_lds_budget(false) : pt_lds_budget(cs.has_textures);
         if (total <= (bvh ? kStageMaxBytesBvh : kStageMaxBytes) && (!bvh || other + total <= lds_budget)) {  // all of it or nothing (a TEX kernel reads its tables through LDS addresses)
             // the albedo table as well for the full-graph exhaustive kernel of a textured scene (stage_scene_tables: GGX), if three
             // workgroups per CU still fit (AKR_PT_MIN_WAVES_TEX = 3: 160 KB / 3)
@@ -467,7 +480,7 @@ static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pas
         for (const DMaterial& m : cs.materials) {
             if (m.kind == MAT_EMISSION) continue;
             n_surface++;
-            if (m.kind == MAT_PRINCIPLED && (m.flags & flags)) n_dear++;
+            if (m.flags & flags) n_dear++;  // the kernel's own test (pt_pass.h: DEFER), whatever the material's kind
         }
         bool want = n_dear > 0 && 2 * n_dear <= n_surface;
         uint32_t mask = 1u;  // iterations with (iteration & mask) != 0 put those hits off
@@ -569,9 +582,9 @@ static uint32_t session_samples(const akr_pt_config& c) { return c.sample_count 
 extern "C" {
 
 AKR_API const char* akr_last_error(void) { return g_last_error.c_str(); }
-AKR_API const char* akr_version(void) { return "akari_hip 0.1.0 gfx950"; }
+AKR_API const char* akr_version(void) { return "akari_hip 0.2.0 gfx950"; }  // 0.2.0: akr_pt_config gained sample_begin / sample_count (88 bytes); akr_kernel_info carries its own size
 AKR_API int32_t akr_option_set(const char* name, int32_t value) {
-    if (!tuning_set(name, value)) return fail(AKR_ERR_INVALID_ARGUMENT, std::string("akr_option_set: unknown option '") + (name ? name : "(null)") + "'");
+    if (!tuning_set(name, value)) return fail(AKR_ERR_INVALID_ARGUMENT, std::string("akr_option_set: unknown option '") + (name ? name : "(null)") + "' or value out of range");
     return AKR_OK;
 }
 AKR_API int32_t akr_option_get(const char* name, int32_t* value) {
@@ -780,6 +793,10 @@ AKR_API int32_t akr_scene_get_array(const akr_scene* s, int32_t which, const voi
         case AKR_ARRAY_INST_TRI_OFFSET: set(cs.inst_tri_offset.data(), cs.inst_tri_offset.size() * 4); break;
         case AKR_ARRAY_R2C: set(s->r2c, 64); break;
         case AKR_ARRAY_C2W: set(s->c2w, 64); break;
+        case AKR_ARRAY_TEX_NODES: set(cs.tex_nodes.data(), cs.tex_nodes.size() * sizeof(DNode)); break;
+        case AKR_ARRAY_TEX_IMAGES: set(cs.images.data(), cs.images.size() * sizeof(DImage)); break;
+        case AKR_ARRAY_TEX_TEXELS: set(cs.texels.data(), cs.texels.size() * 4); break;
+        case AKR_ARRAY_MAT_INPUTS: set(cs.mat_inputs.data(), cs.mat_inputs.size() * sizeof(MatInputs)); break;
         default: return fail(AKR_ERR_INVALID_ARGUMENT, "akr_scene_get_array: unknown array id");
     }
     return AKR_OK;
@@ -966,6 +983,36 @@ AKR_API int32_t akr_pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_co
             se->defer_metal_option = t.defer_metal;
             se->simple_kernels_option = t.simple_kernels;
             se->defer_on_option = t.defer_on;
+            se->max_fused_option = t.max_fused_passes;
+            // A per-scene kernel (host/specialise.cpp) for the megakernel of a scene with texture-fed materials: always / never by
+            // option, else when the render is long enough for a first-use compile to pay.
+            const uint64_t samples = n * (uint64_t)session_samples(*cfg);
+            const bool want = t.specialise == 1 || (t.specialise < 0 && samples >= kSpecAutoSamples);
+            if (!scene->cs.has_textures) se->spec_status = "the scene has no texture-fed material";
+            else if (!want) se->spec_status = t.specialise == 0 ? "option specialise = 0" : "render below the automatic threshold (option specialise = -1)";
+            else if (cfg->force_diffuse) se->spec_status = "force_diffuse kernels evaluate no surface graphs";
+            else if (se->wavefront) se->spec_status = "wavefront schedule";
+            else {
+                {
+                    std::lock_guard<std::mutex> lock(scene->spec_mutex);
+                    if (!scene->spec_header_made) {
+                        scene->spec_header = generate_scene_spec(scene->cs);
+                        scene->spec_header_made = true;
+                    }
+                }
+                se->spec_waves = t.specialise_waves ? t.specialise_waves : 3;
+                se->spec_active = true;
+                fill_params(se.get(), 1, cfg->spp_per_pass);  // which instantiation the session's launches use
+                SpecRequest rq;
+                rq.bvh = !scene->cs.bvh_nodes.empty();
+                rq.pmj = se->params.sampler != 0;
+                rq.stage = se->params.stage_total != 0;
+                rq.defer = se->params.defer_metal != 0;
+                rq.min_waves = se->spec_waves;
+                se->spec = ctx->spec_cache.get(scene->spec_header, rq, ctx->props.gcnArchName);
+                se->spec_status = se->spec->status;
+                if (!se->spec->fn) se->spec_active = false;  // the interpreter kernel renders the same film
+            }
         }
         if (se->wavefront) {
             fill_params(se.get(), 1, cfg->spp_per_pass);  // for n_items
@@ -986,7 +1033,10 @@ AKR_API int32_t akr_pt_passes(akr_pt_session* se, uint32_t n_passes, int32_t blo
         // profiles/r4_ab_walk.txt). The bound keeps a launch on a heavy scene from running for minutes.
         uint32_t kMaxFusedPasses = 16;
         se->fold_events(false);
-        if (se->pending.empty() && se->passes_launched > 0 && se->kernel_ms > 0.0) {
+        if (se->max_fused_option > 0) {
+            kMaxFusedPasses = (uint32_t)se->max_fused_option;  // option max_fused_passes: a fixed bound (deterministic launch counts)
+        } else if (blocking && se->pending.empty() && se->passes_launched > 0 && se->kernel_ms > 0.0) {
+            // (blocking calls only: a progressive caller that polls between non-blocking calls is not put behind multi-second launches)
             const double per_pass_ms = se->kernel_ms / (double)se->passes_launched;
             const double fit = 3000.0 / per_pass_ms;
             kMaxFusedPasses = fit >= 64.0 ? 64u : (fit <= 16.0 ? 16u : (uint32_t)fit);
@@ -1003,7 +1053,7 @@ AKR_API int32_t akr_pt_passes(akr_pt_session* se, uint32_t n_passes, int32_t blo
             fill_params(se, fused, last);
             LaunchTimer timer(se);
             if (se->wavefront) wf_run(se);
-            else HIP_CHECK(launch_pt_pass(se->params, se->ctx->stream));
+            else HIP_CHECK(launch_pt_pass(se->params, se->ctx->stream, se->spec_active ? se->spec->fn : nullptr));
             timer.stop();
             se->spp_done = done;
             se->n_launches++;
@@ -1048,6 +1098,67 @@ static void read_stats(akr_pt_session* se, akr_pt_stats* stats) {
 AKR_API int32_t akr_pt_get_stats(akr_pt_session* se, akr_pt_stats* stats) {
     if (!se || !stats) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_pt_get_stats: NULL argument");
     return guarded([&] { read_stats(se, stats); });
+}
+AKR_API int32_t akr_pt_kernel_info(akr_pt_session* se, akr_kernel_info* info) {
+    if (!se || !info) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_pt_kernel_info: NULL argument");
+    if (info->struct_size < sizeof(akr_kernel_info)) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_pt_kernel_info: struct_size is smaller than this library's akr_kernel_info (set it to sizeof)");
+    return guarded([&] {
+        const uint32_t size = info->struct_size;
+        std::memset(info, 0, sizeof *info);
+        info->struct_size = size;
+        info->specialised = se->spec_active ? 1u : 0u;
+        info->n_shader_kinds = (uint32_t)se->scene->cs.shader_kinds.size();
+        info->absent_mask = se->scene->cs.absent;
+        if (se->spec) {
+            info->cache_hit = se->spec->cache_hit ? 1u : 0u;
+            info->min_waves = (uint32_t)se->spec_waves;
+            info->vgprs = (uint32_t)se->spec->vgprs;
+            info->scratch_bytes = (uint32_t)se->spec->scratch_bytes;
+            info->compile_ms = se->spec->compile_ms;
+            info->load_ms = se->spec->load_ms;
+        }
+        std::snprintf(info->status, sizeof info->status, "%s", se->spec_status.c_str());
+    });
+}
+AKR_API int32_t akr_scene_spec_source(akr_scene* scene, char* dst, uint64_t capacity, uint64_t* length) {
+    if (!scene || !length) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_scene_spec_source: NULL argument");
+    return guarded([&] {
+        std::lock_guard<std::mutex> lock(scene->spec_mutex);
+        if (!scene->spec_header_made) {
+            scene->spec_header = generate_scene_spec(scene->cs);
+            scene->spec_header_made = true;
+        }
+        *length = scene->spec_header.size();
+        if (dst && capacity) {
+            const size_t n = std::min<size_t>(capacity - 1, scene->spec_header.size());
+            std::memcpy(dst, scene->spec_header.data(), n);
+            dst[n] = 0;
+        }
+    });
+}
+AKR_API int32_t akr_host_spec_compile(akr_scene* scene, uint32_t flags, uint32_t min_waves, const char* arch, uint64_t* code_bytes, char* log, uint32_t log_len) {
+    if (!scene || !code_bytes) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_host_spec_compile: NULL argument");
+    return guarded([&] {
+        std::string header;
+        {
+            std::lock_guard<std::mutex> lock(scene->spec_mutex);
+            if (!scene->spec_header_made) {
+                scene->spec_header = generate_scene_spec(scene->cs);
+                scene->spec_header_made = true;
+            }
+            header = scene->spec_header;
+        }
+        if (header.empty()) throw Unsupported("unsupported: the scene has no per-scene code (no texture-fed material, or too many shader kinds)");
+        SpecRequest rq;
+        rq.bvh = flags & 1u; rq.pmj = flags & 2u; rq.stage = flags & 4u; rq.defer = flags & 8u;
+        rq.min_waves = (int)min_waves;
+        std::vector<char> code;
+        std::string text;
+        const bool ok = spec_compile(header, rq, arch && *arch ? arch : "gfx950", code, text);
+        if (log && log_len) std::snprintf(log, log_len, "%s", text.c_str());
+        if (!ok) throw RenderError("per-scene kernel did not compile: " + text.substr(0, 1500));
+        *code_bytes = code.size();
+    });
 }
 AKR_API int32_t akr_pt_end(akr_pt_session* se, akr_pt_stats* stats) {
     if (!se) return AKR_OK;
@@ -1866,9 +1977,34 @@ AKR_API int32_t akr_probe_material_inputs_host(akr_scene* scene, uint32_t materi
             MatInputs in;
             std::memcpy(&in, &descs[material], sizeof in);
             if (m.flags & MF_TEXTURED) {
-                eval_material_graph(ts, m.tex_first_node, m.tex_n_nodes, mk2(uv[2 * i], uv[2 * i + 1]), in);
+                eval_material_graph(ts, m.tex_first_node, m.tex_n_nodes & kTexCountMask, mk2(uv[2 * i], uv[2 * i + 1]), in);
             }
             std::memcpy(out26 + 26ull * i, &in, sizeof in);
+        }
+    });
+}
+
+// The interpreter's view of a material at n uv points, on the host, default colour pipeline: material_at (the folded record, 64
+// words), material_alpha_at and material_emission_inputs_at (device/dtex.h). What a per-scene kernel's generated code must
+// reproduce bit for bit (tests/test_specialise.py compiles that text for the host and compares).
+AKR_API int32_t akr_probe_material_folded_host(akr_scene* scene, uint32_t material, uint32_t n, const float* uv, uint32_t* out64, float* alpha, float* emission3) {
+    if (!scene || !uv || !out64) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_probe_material_folded_host: NULL argument");
+    if (material >= scene->cs.materials.size()) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_probe_material_folded_host: material out of range");
+    return guarded([&] {
+        const CompiledScene& cs = scene->cs;
+        const TexScene ts{cs.tex_nodes.data(), cs.images.data(), cs.texels.data(), cs.mat_inputs.data(), 0, 0};
+        const DMaterial& folded = cs.materials[material];
+        for (uint32_t i = 0; i < n; i++) {
+            const vec2 p = mk2(uv[2 * i], uv[2 * i + 1]);
+            DMaterial m = folded;
+            material_at(ts, material, p, m);
+            std::memcpy(out64 + 64ull * i, &m, sizeof m);
+            const bool tex = (folded.flags & MF_TEXTURED) != 0;
+            if (alpha) alpha[i] = tex ? material_alpha_at(ts, folded, material, p) : folded.base_alpha;
+            if (emission3) {
+                const vec3 e = tex ? material_emission_inputs_at(ts, folded, material, p) : folded.emission;
+                emission3[3 * i] = e.x; emission3[3 * i + 1] = e.y; emission3[3 * i + 2] = e.z;
+            }
         }
     });
 }
@@ -1886,7 +2022,7 @@ AKR_API int32_t akr_probe_material_inputs(akr_context* ctx, akr_scene* scene, ui
                 if (cs.has_textures) in = cs.mat_inputs[material];
                 else std::memcpy(&in, &scene->flat.materials[material], sizeof in);
                 if (m.flags & MF_TEXTURED) {
-                    eval_material_graph(ts, m.tex_first_node, m.tex_n_nodes, mk2(uv[2 * i], uv[2 * i + 1]), in);
+                    eval_material_graph(ts, m.tex_first_node, m.tex_n_nodes & kTexCountMask, mk2(uv[2 * i], uv[2 * i + 1]), in);
                 }
                 std::memcpy(out26 + 26ull * i, &in, sizeof in);
             }

@@ -152,8 +152,10 @@ static bool alpha_is_one(const HostGraph& g, const std::vector<HostImage>& image
         default: return false;  // float / float3 / texcoords / mapping / extract / normal_map values have w = 0
     }
 }
-static void compile_graph(const HostGraph& g, const std::vector<HostImage>& images, uint32_t color, akr_material_desc& desc, DMaterial& dm, CompiledScene& out) {
+static void compile_graph(const HostGraph& g, const std::vector<HostImage>& images, uint32_t color, uint32_t material_index, akr_material_desc& desc, DMaterial& dm,
+                          CompiledScene& out) {
     const uint32_t n_images = (uint32_t)images.size();
+    uint32_t shader_kind = 0;
     const uint32_t n = (uint32_t)g.nodes.size();
     std::vector<uint8_t> varying(n, 0);
     for (uint32_t i = 0; i < n; i++) {
@@ -266,6 +268,41 @@ static void compile_graph(const HostGraph& g, const std::vector<HostImage>& imag
             used = std::max(used, sl + 1);
         }
         out.tex_slots = std::max(out.tex_slots, std::max(used, 1u));
+        {   // the list as the per-scene code generator wants it, and its shape
+            std::string sig = "k" + std::to_string(dm.kind) + ";";
+            for (uint32_t i = 0; i < count; i++) {
+                const akr_shader_node& nd = pruned[i];
+                out.tex_nodes_ssa.push_back(nd);
+                sig += std::to_string(nd.op) + "(";
+                const uint32_t na = node_n_args(nd.op);
+                for (uint32_t a = 0; a < na; a++) {
+                    if (nd.op == AKR_NODE_IMAGE && a == 0) {
+                        const HostImage& im = images[nd.arg[0]];
+                        sig += "i" + std::to_string(im.format) + "." + std::to_string(im.filter) + "." + std::to_string(im.address) + ",";
+                    } else {
+                        sig += (nd.arg[a] == AKR_NODE_NONE ? std::string("-") : std::to_string(nd.arg[a])) + ",";
+                    }
+                }
+                // immediates that select code: the Rgb node's colour space, the sRGB decode of an image, mapping type, extract field
+                if (nd.op == AKR_NODE_RGB) sig += "t" + std::to_string(nd.arg[0] == 1u ? 1 : 0);
+                if (nd.op == AKR_NODE_IMAGE) sig += "s" + std::to_string(nd.arg[2] != 0 ? 1 : 0);
+                if (nd.op == AKR_NODE_MAPPING) sig += "m" + std::to_string(nd.arg[3]);
+                if (nd.op == AKR_NODE_EXTRACT) sig += "f" + std::to_string(nd.arg[1]);
+                sig += ")" + std::to_string(feeds[i]) + ";";
+            }
+            uint32_t kind = 0;
+            while (kind < out.shader_kinds.size() && out.shader_kinds[kind].signature != sig) kind++;
+            if (kind == out.shader_kinds.size()) {
+                CompiledScene::ShaderKind sk;
+                sk.signature = sig;
+                sk.mat_kind = dm.kind;
+                sk.n_nodes = count;
+                out.shader_kinds.push_back(sk);
+            }
+            if (kind > 0xffffu) throw std::invalid_argument("unsupported: more than 65536 distinct shader graph shapes");
+            out.shader_kinds[kind].materials.push_back(material_index);
+            shader_kind = kind;
+        }
         for (uint32_t i = 0; i < count; i++) {
             akr_shader_node nd = pruned[i];
             uint32_t na = node_n_args(nd.op);
@@ -288,7 +325,7 @@ static void compile_graph(const HostGraph& g, const std::vector<HostImage>& imag
         else dm.base_alpha = 1.0f;
     }
     dm.tex_first_node = first;
-    dm.tex_n_nodes = count;
+    dm.tex_n_nodes = count | (shader_kind << kTexKindShift);
     for (uint32_t k = 0; k < AKR_IN_COUNT; k++) dm.tex_input[k] = map[k] == AKR_NODE_NONE ? AKR_NODE_NONE : remap[map[k]];
     out.has_textures = true;
 }
@@ -447,6 +484,8 @@ void build_bvh8(const std::vector<float>& tri_bounds, uint32_t n_tris, float pad
 void compile_materials(const FlatScene& flat, uint32_t color, CompiledScene& out, std::vector<akr_material_desc>& descs) {
     out.materials.clear();
     out.tex_nodes.clear();
+    out.tex_nodes_ssa.clear();
+    out.shader_kinds.clear();
     out.mat_inputs.clear();
     out.has_textures = false;
     out.tex_slots = 0;
@@ -454,7 +493,7 @@ void compile_materials(const FlatScene& flat, uint32_t color, CompiledScene& out
     for (size_t mi = 0; mi < flat.materials.size(); mi++) {
         DMaterial d;
         if (!flat.graphs.empty() && !flat.graphs[mi].nodes.empty()) {
-            compile_graph(flat.graphs[mi], flat.images, color, descs[mi], d, out);
+            compile_graph(flat.graphs[mi], flat.images, color, (uint32_t)mi, descs[mi], d, out);
         } else {
             d = fold_material(descs[mi], color);
             MatInputs in;  // keep the converted constants: mat_inputs is what the device re-folds textured materials from
@@ -474,6 +513,18 @@ void compile_materials(const FlatScene& flat, uint32_t color, CompiledScene& out
         out.mat_inputs.resize(descs.size());
         std::memcpy(out.mat_inputs.data(), descs.data(), descs.size() * sizeof(MatInputs));
     }
+    // Lobes no material can have (device/dbsdf.h AB_*): the switching VALUE is exactly zero everywhere and nothing feeds it.
+    uint32_t absent = AB_COAT | AB_TRANSMISSION | AB_NORMAL_MAP | AB_GLASS | AB_METAL;
+    for (const DMaterial& m : out.materials) {
+        auto fed = [&](uint32_t k) { return (m.flags & MF_TEXTURED) && m.tex_input[k] != kNodeNone; };
+        if (m.kind == MAT_GLASS) absent &= ~(uint32_t)AB_GLASS;
+        if (m.kind != MAT_PRINCIPLED) continue;
+        if (m.coat_weight != 0.0f || (m.flags & MF_COAT) || fed(IN_COAT_WEIGHT)) absent &= ~(uint32_t)AB_COAT;
+        if (m.transmission != 0.0f || (m.flags & MF_EVAL_DIEL) || fed(IN_TRANSMISSION_WEIGHT)) absent &= ~(uint32_t)AB_TRANSMISSION;
+        if ((m.flags & MF_NORMAL_MAP) || fed(IN_NORMAL)) absent &= ~(uint32_t)AB_NORMAL_MAP;
+        if (m.metallic != 0.0f || (m.flags & MF_EVAL_METAL) || fed(IN_METALLIC)) absent &= ~(uint32_t)AB_METAL;
+    }
+    out.absent = absent;
 }
 
 namespace {
@@ -788,6 +839,8 @@ void tuning_init_locked() {
     if (const char* e = std::getenv("AKR_PT_DEFER_METAL")) g_tuning.defer_metal = std::atoi(e);
     if (const char* e = std::getenv("AKR_PT_MODE")) g_tuning.wavefront = std::string(e) == "wavefront" ? 1 : 0;
     if (const char* e = std::getenv("AKR_PT_SIMPLE")) g_tuning.simple_kernels = std::atoi(e) != 0 ? 1 : 0;
+    if (const char* e = std::getenv("AKR_SPECIALISE")) g_tuning.specialise = std::atoi(e);
+    if (const char* e = std::getenv("AKR_SPECIALISE_WAVES")) g_tuning.specialise_waves = std::atoi(e);
 }
 int* tuning_field(const char* name) {
     const std::string n = name ? name : "";
@@ -797,6 +850,9 @@ int* tuning_field(const char* name) {
     if (n == "wavefront") return &g_tuning.wavefront;
     if (n == "simple_kernels") return &g_tuning.simple_kernels;
     if (n == "defer_on") return &g_tuning.defer_on;
+    if (n == "specialise") return &g_tuning.specialise;
+    if (n == "specialise_waves") return &g_tuning.specialise_waves;
+    if (n == "max_fused_passes") return &g_tuning.max_fused_passes;
     return nullptr;
 }
 }  // namespace
@@ -810,6 +866,10 @@ bool tuning_set(const char* name, int value) {
     tuning_init_locked();
     int* f = tuning_field(name);
     if (!f) return false;
+    if (f == &g_tuning.defer_on && (value < 0 || value > 3)) return false;
+    if (f == &g_tuning.specialise && (value < -1 || value > 1)) return false;
+    if (f == &g_tuning.specialise_waves && value != 0 && (value < 2 || value > 4)) return false;
+    if (f == &g_tuning.max_fused_passes && (value < 0 || value > 64)) return false;
     *f = value;
     return true;
 }

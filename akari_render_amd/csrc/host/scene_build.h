@@ -71,6 +71,17 @@ struct CompiledScene {
     std::vector<uint32_t> texels;
     std::vector<MatInputs> mat_inputs;   // one per material when any material is textured, else empty
     uint32_t tex_slots = 0;              // value slots per lane the widest node list needs (device/dtex.h), 0 without textures
+    // The same node lists before slot allocation (arguments name nodes of the material's own list), element for element with
+    // tex_nodes, and the scene's shader kinds: materials whose lists have the same shape share a kind (svm/compiler.rs:16-76); the
+    // kind of a material is also in DMaterial.tex_n_nodes >> 16. What host/specialise.cpp turns into per-scene kernel code.
+    std::vector<akr_shader_node> tex_nodes_ssa;
+    struct ShaderKind {
+        std::string signature;            // everything that shapes the code: surface kind, operations, argument topology, modes, image formats, fed inputs
+        uint32_t mat_kind = 0, n_nodes = 0;
+        std::vector<uint32_t> materials;  // the materials of this kind, ascending
+    };
+    std::vector<ShaderKind> shader_kinds;
+    uint32_t absent = 0;                  // lobes no material of the scene can have (device/dbsdf.h AB_*)
     bool has_textures = false;
     bool has_alpha = false;
     bool needs_ggx_table = false;
@@ -90,10 +101,17 @@ void build_alias_table(const std::vector<float>& weights, std::vector<AliasEntry
 //   wavefront    AKR_PT_MODE=wavefront    1 = sessions on BVH scenes use the wavefront schedule (wf_kernels.hip) instead of the megakernel
 //   simple_kernels AKR_PT_SIMPLE=0        0 = never use the SIMPLE instantiations (scenes without coat / transmission / normal map / glass)
 //   defer_on     (no environment hook)   BVH kernels of textured scenes: which hits the deferral puts off (0 / 1 conductor lobe, 2 texture-fed, 3 both)
+//   specialise   AKR_SPECIALISE=<v>       per-scene kernels for scenes with texture-fed materials (host/specialise.cpp): -1 = the library decides
+//                                         (renders of at least kSpecAutoSamples samples), 0 = never (the interpreter), 1 = always
+//   specialise_waves AKR_SPECIALISE_WAVES=<n>  waves per SIMD a per-scene kernel is compiled for: 0 = the library's choice, else 2..4
+//   max_fused_passes (no environment hook)     most passes akr_pt_passes fuses into one launch: 0 = adaptive (16, up to 64 once a pass has been timed), else 1..64
 struct TuningOptions {
     int force_bvh = 0, bvh_balanced = 0, defer_metal = -1, wavefront = 0, simple_kernels = 1;
     int defer_on = 0;  // BVH kernels of textured scenes: which hits the deferral puts off -- 0 / 1 = the conductor lobe (default), 2 = texture-fed materials, 3 = both
+    int specialise = -1, specialise_waves = 0;
+    int max_fused_passes = 0;
 };
+constexpr uint64_t kSpecAutoSamples = 1ull << 27;  // option specialise = -1: a first-use compile (seconds) has to be worth it
 TuningOptions tuning();                          // a snapshot (thread-safe)
 bool tuning_set(const char* name, int value);    // false: unknown name
 bool tuning_get(const char* name, int* value);

@@ -1,6 +1,8 @@
 // kernels.h -- kernel parameter block and host-callable launchers (implemented in pt_kernels.hip).
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <hip/hip_runtime.h>
+#endif
 
 #include "device/drng.h"
 #include "device/dscene.h"
@@ -169,9 +171,11 @@ struct McmcParams {
     uint32_t exponential_mutation;
     float small_sigma, large_step_prob, image_mutation_prob, image_mutation_size;
 };
+#if !defined(__HIPCC_RTC__)  // host-callable launchers: not part of a per-scene kernel module
 hipError_t launch_mcmc_bootstrap(const PtParams& p, const McmcParams& m, hipStream_t stream);
 hipError_t launch_mcmc_init(const PtParams& p, const McmcParams& m, hipStream_t stream);
 hipError_t launch_mcmc_advance(const PtParams& p, const McmcParams& m, uint32_t mutations_per_chain, float contribution, hipStream_t stream);
+#endif
 
 // Dynamic LDS of a launch that evaluates shader graphs = its own blocks (`base_bytes`: traversal stacks, staged tables), then
 // tex_slots x 256 lanes x 16 B of value slots. Returns the parameter block with the slots' offset filled in and the total size.
@@ -182,7 +186,9 @@ inline PtParams with_tex_slots(const PtParams& p, size_t base_bytes, size_t& lds
     lds_bytes = base_bytes + (p.sc.tex.nodes != nullptr ? (size_t)p.tex_slots * kTexValStride * sizeof(TexVal) : 0);
     return q;
 }
-hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream);
+#if !defined(__HIPCC_RTC__)
+// spec_fn: the per-scene kernel of the session (host/specialise.cpp) instead of the precompiled instantiation, or nullptr
+hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream, hipFunction_t spec_fn = nullptr);
 hipError_t launch_gpt_sample(const PtParams& p, const GptParams& g, hipStream_t stream);
 hipError_t launch_gpt_update(const GptParams& g, uint32_t W, uint32_t H, float* film, hipStream_t stream);
 hipError_t launch_gpt_recon_init(const GptParams& g, uint32_t W, uint32_t H, float* old, float spp, hipStream_t stream);
@@ -201,5 +207,6 @@ hipError_t launch_probe_bsdf(const DMaterial* m, const float* table, int mode, c
                              hipStream_t stream);
 hipError_t launch_probe_intersect(const PtParams& p, uint32_t n, const float* rays, uint32_t* out, float* bary, hipStream_t stream);
 hipError_t launch_probe_si(const PtParams& p, uint32_t n, const uint32_t* inst_prim, const float* bary, float* out, hipStream_t stream);
+#endif
 
 }  // namespace akr

@@ -313,7 +313,12 @@ typedef enum {
     AKR_ARRAY_AREA_PDF = 9,      /* f32[sum of light triangle counts] */
     AKR_ARRAY_INST_TRI_OFFSET = 10, /* u32[n_instances + 1] */
     AKR_ARRAY_R2C = 11,          /* f32[16] raster->camera, column-major (camera/mod.rs:119-153) */
-    AKR_ARRAY_C2W = 12           /* f32[16] */
+    AKR_ARRAY_C2W = 12,          /* f32[16] */
+    /* texture-fed materials (default colour pipeline; empty without them): csrc/device/dtex.h, dbsdf.h for the layouts */
+    AKR_ARRAY_TEX_NODES = 13,    /* pruned, slot-allocated node lists, 32 B each */
+    AKR_ARRAY_TEX_IMAGES = 14,   /* image headers, 32 B each */
+    AKR_ARRAY_TEX_TEXELS = 15,   /* u32[] texel words of all images */
+    AKR_ARRAY_MAT_INPUTS = 16    /* raw inputs per material = akr_material_desc, 104 B each */
 } akr_array_id;
 AKR_API int32_t akr_scene_get_array(const akr_scene *scene, int32_t which, const void **ptr, uint64_t *bytes);
 
@@ -389,6 +394,36 @@ AKR_API int32_t akr_pt_passes(akr_pt_session *session, uint32_t n_passes, int32_
 AKR_API int32_t akr_pt_end(akr_pt_session *session, akr_pt_stats *stats);
 /* Waits for the queued passes and returns the counters accumulated so far (the session stays open). */
 AKR_API int32_t akr_pt_get_stats(akr_pt_session *session, akr_pt_stats *stats);
+
+/* Per-scene kernels. The reference JIT-compiles every scene's shader graphs into its kernel: graphs of the same shape share a
+ * `shader_kind` (crates/akari_render/src/svm/compiler.rs:16-76) and the kernel switches over the kind into straight-line node code
+ * (svm/eval.rs:428-467). This library's precompiled kernels interpret a pruned node list per textured hit; with option
+ * "specialise" a pt session on a scene with texture-fed materials instead gets a kernel compiled for the scene at akr_pt_begin
+ * (hiprtc; code objects cached in $AKR_KERNEL_CACHE, default ~/.cache/akari_hip, keyed by library sources + generated code +
+ * kernel flags + compiler options). Films are bit-identical either way; when hiprtc is missing or the compile fails the session
+ * silently uses the interpreter and `status` says why. struct_size = sizeof(akr_kernel_info), set by the caller. */
+typedef struct {
+    uint32_t struct_size;     /* in: the caller's sizeof(akr_kernel_info) */
+    uint32_t specialised;     /* 1 = the session launches a per-scene kernel */
+    uint32_t cache_hit;       /* 1 = no compile: the code object came from the disk cache or an earlier session of this process */
+    uint32_t n_shader_kinds;  /* distinct graph shapes of the scene */
+    uint32_t absent_mask;     /* lobes no material of the scene can have: 1 coat, 2 transmission, 4 normal map, 8 glass, 16 conductor */
+    uint32_t min_waves;       /* waves per SIMD the kernel was compiled for */
+    uint32_t vgprs, scratch_bytes;
+    double compile_ms;        /* hiprtc compile at akr_pt_begin (0 on a cache hit) */
+    double load_ms;           /* cache lookup + module load */
+    char status[256];         /* "ok", or why the session uses the interpreter */
+} akr_kernel_info;
+AKR_API int32_t akr_pt_kernel_info(akr_pt_session *session, akr_kernel_info *info);
+/* The kernel text generated for the scene's shader kinds (what device/dtex.h includes in a per-scene kernel): length without the
+ * terminator in *length; dst may be NULL to ask for the length only. Empty = no texture-fed material. Works on host-only scenes. */
+AKR_API int32_t akr_scene_spec_source(akr_scene *scene, char *dst, uint64_t capacity, uint64_t *length);
+/* Compiles the scene's per-scene kernel for `arch` ("gfx950" when NULL) without a device (hiprtc cross-compiles): flags bit 0 BVH,
+ * 1 index-based sampler, 2 staged tables, 3 deferral. For tests and tools; sessions compile through the cache. */
+AKR_API int32_t akr_host_spec_compile(akr_scene *scene, uint32_t flags, uint32_t min_waves, const char *arch, uint64_t *code_bytes, char *log, uint32_t log_len);
+/* The interpreter's result for `material` at n uv points on the host (default colour pipeline): the folded record (64 words each),
+ * optionally the alpha of the base-colour node and emission_color * emission_strength -- the values per-scene code must reproduce. */
+AKR_API int32_t akr_probe_material_folded_host(akr_scene *scene, uint32_t material, uint32_t n, const float *uv, uint32_t *out64, float *alpha, float *emission3);
 /* Copies the session's Pcg32 state buffer (2 x u64 per pixel: state, inc) to the host. */
 AKR_API int32_t akr_pt_read_sampler_states(akr_pt_session *session, uint64_t *dst);
 
@@ -552,6 +587,11 @@ AKR_API const char *akr_version(void);
  *   "simple_kernels" (AKR_PT_SIMPLE=0)      0 = never pick the kernels specialised for scenes without coat / transmission / normal map / glass
  *   "defer_on"     (no environment hook)    BVH kernels of scenes with textures: which hits "defer_metal" puts off -- 0 / 1 the conductor
  *                                           lobe (default), 2 texture-fed materials, 3 both
+ *   "specialise"   (AKR_SPECIALISE=v)       per-scene kernels for pt sessions on scenes with texture-fed materials (below): -1 the library
+ *                                           decides (renders of >= 2^27 samples), 0 never, 1 always
+ *   "specialise_waves" (AKR_SPECIALISE_WAVES=n)  waves per SIMD a per-scene kernel is compiled for: 0 the library's choice, else 2..4
+ *   "max_fused_passes" (no environment hook)     most passes one launch of akr_pt_passes fuses: 0 adaptive, else 1..64
+ * Values out of an option's range fail with AKR_ERR_INVALID_ARGUMENT.
  * A session reads the options once, when it begins (akr_pt_begin / akr_gpt_begin / ...): a later akr_option_set does not change it.
  * "wavefront" = 1 on a scene without a BVH renders with the megakernel. Unknown names fail with AKR_ERR_INVALID_ARGUMENT. */
 AKR_API int32_t akr_option_set(const char *name, int32_t value);
