@@ -31,7 +31,8 @@ def constant_room(lobes_of_the_textured_room):
 
 small = textured_room(1920, 1080, n_floor=n_floor)  # the 16x24 / 8x8 images of the tests: texel gathers hit in cache
 small.ggx_table = sd.ggx_table
-variants = [("textured", sd, None), ("textured, conductor deferral off", sd, "0"), ("textured, small images", small, None),
+variants = [("textured", sd, None), ("textured, per-scene kernel", sd, None), ("textured, per-scene kernel, 4 waves", sd, None),
+            ("textured, conductor deferral off", sd, "0"), ("textured, small images", small, None),
             ("same room, constant materials with the lobes the graphs select", constant_room(True), None),
             ("same room, constant materials", constant_room(False), None)]
 only = os.environ.get("TEXBENCH_ONLY")  # substring of the variant's name
@@ -41,13 +42,17 @@ for name, variant, defer in variants:
     if os.environ.get("TEXBENCH_DEFER_ON"):  # which hits the BVH kernels' deferral puts off (1 conductor, 2 textured, 3 both); forces the deferral on
         capi.set_option("defer_on", int(os.environ["TEXBENCH_DEFER_ON"]))
         if defer is None: capi.set_option("defer_metal", int(os.environ.get("TEXBENCH_DEFER_MASK", "1")))
+    capi.set_option("specialise", 1 if "per-scene" in name else 0)
+    capi.set_option("specialise_waves", 4 if "4 waves" in name else 0)
     scene = capi.Scene(ctx, variant)
     film = capi.Film(ctx, 1920, 1080)
     cfg = abi.PtConfig.default(); cfg.spp = 64 * (steps + 1); cfg.spp_per_pass = 64; cfg.max_depth = 12
     se = capi.PtSession(ctx, scene, cfg, film)
     se.passes(1, blocking=True); s0 = se.stats()
     t0 = time.perf_counter(); se.passes(steps, blocking=True); t1 = time.perf_counter()
+    ki = se.kernel_info()
     s1 = se.end()
     out[name] = {"msamples_per_s": (s1["n_samples"] - s0["n_samples"]) / (t1 - t0) / 1e6, "device_MB": scene.info().device_bytes / 1e6,
+                 "kernel": {k: ki[k] for k in ("specialised", "cache_hit", "min_waves", "vgprs", "scratch_bytes", "compile_ms", "load_ms", "status")},
                  "shaded_per_sample": (s1["n_shaded"] - s0["n_shaded"]) / (s1["n_samples"] - s0["n_samples"])}
 print(json.dumps(out))
