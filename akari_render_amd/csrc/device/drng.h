@@ -70,14 +70,7 @@ AKR_HD float pcg_next_1d(Pcg32& p) {  // sampler/mod.rs:194-198; can return exac
 // matrices). Dimension 0 = radical inverse base 2, dimension 1 = the Pascal-triangle generator matrix; nested uniform
 // scrambling by the Laine-Karras hash between two bit reversals (Laine & Karras 2011; Burley 2020, "Practical Hash-based
 // Owen Scrambling").
-AKR_HD uint32_t reverse_bits32(uint32_t x) {
-    x = (x >> 16) | (x << 16);
-    x = ((x & 0xff00ff00u) >> 8) | ((x & 0x00ff00ffu) << 8);
-    x = ((x & 0xf0f0f0f0u) >> 4) | ((x & 0x0f0f0f0fu) << 4);
-    x = ((x & 0xccccccccu) >> 2) | ((x & 0x33333333u) << 2);
-    x = ((x & 0xaaaaaaaau) >> 1) | ((x & 0x55555555u) << 1);
-    return x;
-}
+AKR_HD uint32_t reverse_bits32(uint32_t x) { return __builtin_bitreverse32(x); }  // v_bfrev_b32
 AKR_HD uint32_t laine_karras(uint32_t x, uint32_t seed) {
     x += seed;
     x ^= x * 0x6c50b47cu;
@@ -87,6 +80,8 @@ AKR_HD uint32_t laine_karras(uint32_t x, uint32_t seed) {
     return x;
 }
 AKR_HD uint32_t owen_scramble(uint32_t x, uint32_t seed) { return reverse_bits32(laine_karras(reverse_bits32(x), seed)); }
+// owen_scramble of a value that is known bit-reversed: owen_scramble(reverse_bits32(r), seed) without the two reversals that cancel
+AKR_HD uint32_t owen_scramble_of_reversed(uint32_t r, uint32_t seed) { return reverse_bits32(laine_karras(r, seed)); }
 AKR_HD uint32_t sobol_dim1(uint32_t i) {
     uint32_t v = 0x80000000u, r = 0;
     for (; i; i >>= 1) {
@@ -95,18 +90,37 @@ AKR_HD uint32_t sobol_dim1(uint32_t i) {
     }
     return r;
 }
+// reverse_bits32(sobol_dim1(i)) without the loop. Column k of the generator matrix, reversed, is (1 + x)^k over GF(2): bit j of it
+// is set iff j is a submask of k (Lucas). So bit j of the result is the parity of the set bits k of i with k a superset of j --
+// the superset sum over the 5-bit lattice of bit POSITIONS, five butterfly steps on the word. (tests/test_sobol.py: equal to the
+// loop for every index below 2^20 and random 32-bit ones.)
+AKR_HD uint32_t sobol_dim1_reversed(uint32_t i) {
+    i ^= (i >> 1) & 0x55555555u;
+    i ^= (i >> 2) & 0x33333333u;
+    i ^= (i >> 4) & 0x0f0f0f0fu;
+    i ^= (i >> 8) & 0x00ff00ffu;
+    i ^= (i >> 16) & 0x0000ffffu;
+    return i;
+}
 
-AKR_HD uint32_t xxhash32_4(uint32_t px, uint32_t py, uint32_t pz, uint32_t pw) {
-    const uint32_t PRIME32_2 = 2246822519u, PRIME32_3 = 3266489917u, PRIME32_4 = 668265263u, PRIME32_5 = 374761393u;
+// xxhash32_4(px, py, pz, pw) (util/hash.rs:44-60) in two halves: what does not depend on pz, and the rest. The index-based samplers
+// hash (pixel, dimension, seed) for every dimension of a path: the pixel's half is computed once per sample (dpath.h).
+AKR_HD uint32_t xxhash32_4_begin(uint32_t px, uint32_t py, uint32_t pw) {
+    const uint32_t PRIME32_3 = 3266489917u, PRIME32_4 = 668265263u, PRIME32_5 = 374761393u;
     uint32_t h32 = pw + PRIME32_5 + px * PRIME32_3;
     h32 = PRIME32_4 * ((h32 << 17) | (h32 >> (32 - 17)));
     h32 = h32 + py * PRIME32_3;
     h32 = PRIME32_4 * ((h32 << 17) | (h32 >> (32 - 17)));
+    return h32;
+}
+AKR_HD uint32_t xxhash32_4_end(uint32_t h32, uint32_t pz) {
+    const uint32_t PRIME32_2 = 2246822519u, PRIME32_3 = 3266489917u, PRIME32_4 = 668265263u;
     h32 = h32 + pz * PRIME32_3;
     h32 = PRIME32_4 * ((h32 << 17) | (h32 >> (32 - 17)));
     h32 = PRIME32_2 * (h32 ^ (h32 >> 15));
     h32 = PRIME32_3 * (h32 ^ (h32 >> 13));
     return h32 ^ (h32 >> 16);
 }
+AKR_HD uint32_t xxhash32_4(uint32_t px, uint32_t py, uint32_t pz, uint32_t pw) { return xxhash32_4_end(xxhash32_4_begin(px, py, pw), pz); }
 
 }  // namespace akr

@@ -987,9 +987,11 @@ AKR_API int32_t akr_pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_co
             // A per-scene kernel (host/specialise.cpp) for the megakernel of a scene with texture-fed materials: always / never by
             // option, else when the render is long enough for a first-use compile to pay.
             const uint64_t samples = n * (uint64_t)session_samples(*cfg);
-            const bool want = t.specialise == 1 || (t.specialise < 0 && samples >= kSpecAutoSamples);
+            // (automatic: a kernel that is already cached is used whatever the render's size; a compile -- about a second -- only
+            // when the render is long enough to win it back)
+            const bool may_compile = t.specialise == 1 || samples >= kSpecAutoSamples;
             if (!scene->cs.has_textures) se->spec_status = "the scene has no texture-fed material";
-            else if (!want) se->spec_status = t.specialise == 0 ? "option specialise = 0" : "render below the automatic threshold (option specialise = -1)";
+            else if (t.specialise == 0) se->spec_status = "option specialise = 0";
             else if (cfg->force_diffuse) se->spec_status = "force_diffuse kernels evaluate no surface graphs";
             else if (se->wavefront) se->spec_status = "wavefront schedule";
             else {
@@ -1009,7 +1011,7 @@ AKR_API int32_t akr_pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_co
                 rq.stage = se->params.stage_total != 0;
                 rq.defer = se->params.defer_metal != 0;
                 rq.min_waves = se->spec_waves;
-                se->spec = ctx->spec_cache.get(scene->spec_header, rq, ctx->props.gcnArchName);
+                se->spec = ctx->spec_cache.get(scene->spec_header, rq, ctx->props.gcnArchName, may_compile);
                 se->spec_status = se->spec->status;
                 if (!se->spec->fn) se->spec_active = false;  // the interpreter kernel renders the same film
             }
@@ -1793,6 +1795,15 @@ AKR_API int32_t akr_host_pcg_start(uint64_t* state, uint64_t inc) {
     Pcg32 p{*state, inc};
     pcg_start(p, pcg_start_constants());
     *state = p.state;
+    return AKR_OK;
+}
+// device/drng.h on the host: reverse_bits32(sobol_dim1(i)) by the defining loop and by the five-step butterfly the kernels use
+AKR_API int32_t akr_host_sobol_dim1(uint32_t n, const uint32_t* index, uint32_t* by_loop, uint32_t* by_butterfly) {
+    if (!index || !by_loop || !by_butterfly) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_host_sobol_dim1: NULL argument");
+    for (uint32_t k = 0; k < n; k++) {
+        by_loop[k] = reverse_bits32(sobol_dim1(index[k]));
+        by_butterfly[k] = sobol_dim1_reversed(index[k]);
+    }
     return AKR_OK;
 }
 AKR_API int32_t akr_host_alias_table(const float* weights, uint32_t n, uint32_t* j, float* t, float* pdf) {

@@ -101,8 +101,8 @@ void build_alias_table(const std::vector<float>& weights, std::vector<AliasEntry
 //   wavefront    AKR_PT_MODE=wavefront    1 = sessions on BVH scenes use the wavefront schedule (wf_kernels.hip) instead of the megakernel
 //   simple_kernels AKR_PT_SIMPLE=0        0 = never use the SIMPLE instantiations (scenes without coat / transmission / normal map / glass)
 //   defer_on     (no environment hook)   BVH kernels of textured scenes: which hits the deferral puts off (0 / 1 conductor lobe, 2 texture-fed, 3 both)
-//   specialise   AKR_SPECIALISE=<v>       per-scene kernels for scenes with texture-fed materials (host/specialise.cpp): -1 = the library decides
-//                                         (renders of at least kSpecAutoSamples samples), 0 = never (the interpreter), 1 = always
+//   specialise   AKR_SPECIALISE=<v>       per-scene kernels for scenes with texture-fed materials (host/specialise.cpp): -1 = the library decides (a cached
+//                                         kernel always; a compile for renders of at least kSpecAutoSamples samples), 0 = never (the interpreter), 1 = always
 //   specialise_waves AKR_SPECIALISE_WAVES=<n>  waves per SIMD a per-scene kernel is compiled for: 0 = the library's choice, else 2..4
 //   max_fused_passes (no environment hook)     most passes akr_pt_passes fuses into one launch: 0 = adaptive (16, up to 64 once a pass has been timed), else 1..64
 struct TuningOptions {
@@ -111,7 +111,7 @@ struct TuningOptions {
     int specialise = -1, specialise_waves = 0;
     int max_fused_passes = 0;
 };
-constexpr uint64_t kSpecAutoSamples = 1ull << 27;  // option specialise = -1: a first-use compile (seconds) has to be worth it
+constexpr uint64_t kSpecAutoSamples = 1ull << 31;  // option specialise = -1: a first-use compile (about a second; 20-30 % of the render to win) has to be worth it
 TuningOptions tuning();                          // a snapshot (thread-safe)
 bool tuning_set(const char* name, int value);    // false: unknown name
 bool tuning_get(const char* name, int* value);

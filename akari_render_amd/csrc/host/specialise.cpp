@@ -271,6 +271,13 @@ std::vector<std::string> compile_options(const std::string& arch) {
     size_t n;
     const char* const* f = embedded_compile_flags(&n);
     for (size_t i = 0; i < n; i++) o.push_back(f[i]);
+    // AKR_SPEC_EXTRA_FLAGS: A/B switches of the device code for measurements (-DAKR_...=...), part of the cache key. Only switches
+    // that leave the launch's LDS layout alone are safe here: the host plans the layout from the library's own build (kernels.h).
+    if (const char* e = std::getenv("AKR_SPEC_EXTRA_FLAGS")) {
+        std::istringstream ss(e);
+        std::string w;
+        while (ss >> w) o.push_back(w);
+    }
     return o;
 }
 uint64_t fnv1a(uint64_t h, const void* p, size_t n) {
@@ -361,7 +368,7 @@ SpecKernel::~SpecKernel() {
     if (module) (void)hipModuleUnload(module);
 }
 
-std::shared_ptr<SpecKernel> SpecCache::get(const std::string& spec_header, const SpecRequest& rq, const std::string& arch) {
+std::shared_ptr<SpecKernel> SpecCache::get(const std::string& spec_header, const SpecRequest& rq, const std::string& arch, bool may_compile) {
     std::lock_guard<std::mutex> lock(mutex_);
     const std::string key = spec_cache_key(spec_header, rq, arch);
     auto it = loaded_.find(key);
@@ -390,6 +397,10 @@ std::shared_ptr<SpecKernel> SpecCache::get(const std::string& spec_header, const
             code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
             k->cache_hit = !code.empty();
         }
+    }
+    if (code.empty() && !may_compile) {
+        k->status = "no cached kernel, and the render is below the automatic threshold (option specialise = -1)";
+        return k;
     }
     if (code.empty()) {
         std::string log;

@@ -575,6 +575,8 @@ AKR_API int32_t akr_host_chacha_block(const uint32_t *key8, uint64_t counter, ui
 AKR_API int32_t akr_host_pcg32_states(uint64_t seed, uint64_t n, uint64_t *out2n);
 AKR_API int32_t akr_host_pcg_start(uint64_t *state, uint64_t inc);
 AKR_API int32_t akr_host_alias_table(const float *weights, uint32_t n, uint32_t *j, float *t, float *pdf);
+/* The sobol sampler's second dimension, bit-reversed: by the defining loop and by the butterfly the kernels use (csrc/device/drng.h). */
+AKR_API int32_t akr_host_sobol_dim1(uint32_t n, const uint32_t *index, uint32_t *by_loop, uint32_t *by_butterfly);
 
 /* Library / build identification: "akari_hip <version> gfx950". */
 AKR_API const char *akr_version(void);
@@ -588,7 +590,7 @@ AKR_API const char *akr_version(void);
  *   "defer_on"     (no environment hook)    BVH kernels of scenes with textures: which hits "defer_metal" puts off -- 0 / 1 the conductor
  *                                           lobe (default), 2 texture-fed materials, 3 both
  *   "specialise"   (AKR_SPECIALISE=v)       per-scene kernels for pt sessions on scenes with texture-fed materials (below): -1 the library
- *                                           decides (renders of >= 2^27 samples), 0 never, 1 always
+ *                                           decides (a cached kernel always, a compile for renders of >= 2^31 samples), 0 never, 1 always
  *   "specialise_waves" (AKR_SPECIALISE_WAVES=n)  waves per SIMD a per-scene kernel is compiled for: 0 the library's choice, else 2..4
  *   "max_fused_passes" (no environment hook)     most passes one launch of akr_pt_passes fuses: 0 adaptive, else 1..64
  * Values out of an option's range fail with AKR_ERR_INVALID_ARGUMENT.

@@ -74,7 +74,7 @@ def test_interpreter_and_per_scene_kernel_agree_and_the_cache_is_used(ctx, root,
     path.write_bytes(b"not a code object")
     ctx3 = capi.Context(0)
     g4, _, _, i4 = render_specialised(ctx3, sd, cfg)
-    assert n_bit_diff(g4, ref) == 0 and i4["cache_hit"] == 0 and i4["compile_ms"] > 100.0
+    assert n_bit_diff(g4, ref) == 0 and i4["cache_hit"] == 0 and i4["compile_ms"] > 0.0  # (hiprtc keeps its own in-process cache: the second compile is quick)
 
 
 @pytest.mark.parametrize("sampler", [abi.SAMPLER_PMJ02BN, abi.SAMPLER_SOBOL])
@@ -136,11 +136,18 @@ def test_fall_backs(ctx, root, tmp_path, monkeypatch):
     g, gst, _, info = render_specialised(ctx2, sd, cfg)
     o, ost = pyoracle.OracleScene(sd).render(cfg)
     assert_parity(g, o, 32, 32, gst, ost)
-    # automatic mode: a render this small is not worth a compile
+    # automatic mode: a render this small is not worth a compile -- but a kernel that is already cached is used
+    monkeypatch.setenv("AKR_KERNEL_CACHE", str(tmp_path / "auto"))
+    ctx3 = capi.Context(0)
     with capi.options(specialise=-1):
-        scene = capi.Scene(ctx, sd)
-        se = capi.PtSession(ctx, scene, cfg, capi.Film(ctx, 32, 32))
+        scene = capi.Scene(ctx3, sd)
+        se = capi.PtSession(ctx3, scene, cfg, capi.Film(ctx3, 32, 32))
         assert se.kernel_info()["specialised"] == 0 and "threshold" in se.kernel_info()["status"]
+        se.end()
+    render_specialised(ctx3, sd, cfg)
+    with capi.options(specialise=-1):
+        se = capi.PtSession(ctx3, scene, cfg, capi.Film(ctx3, 32, 32))
+        assert se.kernel_info()["specialised"] == 1 and se.kernel_info()["cache_hit"] == 1
         se.end()
     with pytest.raises(capi.AkariError):
         capi.set_option("specialise_waves", 7)

@@ -62,3 +62,20 @@ def test_converges_faster_than_independent(cbox_path):
         assert e_sob < 0.85 * e_ind
     # unbiased: the 1024-spp sobol image agrees with the reference to within its (smaller) noise
     assert abs(render(1024, abi.SAMPLER_SOBOL, 5).mean() - ref.mean()) < 0.01 * ref.mean()
+
+
+def test_second_dimension_without_the_loop():
+    """drng.h sobol_dim1_reversed (five butterfly steps) = reverse_bits32(sobol_dim1(i)) (the defining loop): every index below
+    2^20, random 32-bit indices, and the single-bit ones."""
+    from akari_render_amd import capi
+
+    idx = np.concatenate([np.arange(1 << 20, dtype=np.uint32), np.random.default_rng(0).integers(0, 1 << 32, size=200000, dtype=np.uint64).astype(np.uint32),
+                          (np.uint32(1) << np.arange(32, dtype=np.uint32)), np.array([0xffffffff, 0x80000001], dtype=np.uint32)])
+    a, b = np.zeros_like(idx), np.zeros_like(idx)
+    up = lambda x: x.ctypes.data_as(C.POINTER(C.c_uint32))  # noqa: E731
+    capi.check(capi.lib().akr_host_sobol_dim1(idx.size, up(idx), up(a), up(b)))
+    assert np.array_equal(a, b)
+    # and the loop is the Pascal matrix: index 2^k gives column k = (1 + x)^k, bit j set iff j is a submask of k
+    for k in range(32):
+        col = int(a[(1 << 20) + 200000 + k])
+        assert col == sum(1 << j for j in range(32) if (j & ~k) == 0)

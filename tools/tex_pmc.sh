@@ -1,13 +1,14 @@
 #!/bin/bash
 # PMC passes over tools/textured_bench.py's room (textured, and the same room with constant materials that select the same
 # lobes): one --pmc set per rocprofv3 run, kernel-trace only.  usage: tools/tex_pmc.sh [nfloor=1]   (1: exhaustive kernel, 8: tessellated
-# floor, BVH kernel); summary -> gpurun_out/texpmc_<nfloor>/summary.json (-> profiles/r4_pmc_textured_room_{exhaustive,bvh}.json)
+# floor, BVH kernel); summary -> gpurun_out/texpmc_<nfloor>/summary.json (-> profiles/r5_pmc_textured_room_{exhaustive,bvh}.json)
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 NF=${1:-1}
 OUT=gpurun_out/texpmc_$NF; rm -rf $OUT; mkdir -p $OUT
-for V in "textured" "same room, constant materials with the lobes the graphs select"; do
-  tag=$(echo "$V" | cut -c1-4)
+export AKR_KERNEL_CACHE=${AKR_KERNEL_CACHE:-/tmp/akr_cache_pmc}
+for V in "textured" "textured, per-scene kernel" "same room, constant materials with the lobes the graphs select"; do
+  tag=$(echo "$V" | cut -c1-4); [ "$V" = "textured, per-scene kernel" ] && tag=spec
   i=0
   for SET in \
     "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
@@ -21,11 +22,11 @@ done
 python - <<PY
 import csv, glob, collections, json
 out = {}
-for tag, name in (("text", "textured"), ("same", "same room, constant materials with the lobes the graphs select")):
+for tag, name in (("text", "textured"), ("spec", "textured, per-scene kernel"), ("same", "same room, constant materials with the lobes the graphs select")):
     res = collections.defaultdict(float); kernel = None
     for f in sorted(glob.glob("$OUT/**/%s_set*counter_collection.csv" % tag, recursive=True)):
         for row in csv.DictReader(open(f)):
-            if "k_pt_pass" in row["Kernel_Name"]:
+            if "k_pt_pass" in row["Kernel_Name"] or "akr_pt_pass_spec" in row["Kernel_Name"]:
                 res[row["Counter_Name"]] += float(row["Counter_Value"]); kernel = row["Kernel_Name"].split("(")[0]
     b = json.loads(open("$OUT/%s_set1.out" % tag).read().strip().splitlines()[-1])[name]
     c = dict(res)
