@@ -56,8 +56,10 @@ struct Sampler {
     uint32_t hash_perm, hash_scramble;
 };
 constexpr uint32_t kPmjSets = 5, kPmjSamples = 65536, kBlueNoiseTextures = 48, kBlueNoiseRes = 128;
-// permute_element (sampler/mod.rs:473-507; Kensler's hashed permutation of [0, l))
-AKR_D uint32_t permute_element(uint32_t i, uint32_t l, uint32_t w, uint32_t p) {
+// permute_element (sampler/mod.rs:473-507; Kensler's hashed permutation of [0, l)). The last line is (i + p) % l: with l a power
+// of two (w = l - 1) that is a mask; otherwise the remainder by the launch's precomputed constant (drng.h fastmod_u32, magic =
+// fastmod_magic(l) from PtParams) -- the same number either way.
+AKR_D uint32_t permute_element(uint32_t i, uint32_t l, uint32_t w, uint32_t p, uint64_t magic) {
     do {
         i ^= p;
         i *= 0xe170893du;
@@ -78,13 +80,44 @@ AKR_D uint32_t permute_element(uint32_t i, uint32_t l, uint32_t w, uint32_t p) {
         i &= w;
         i ^= i >> 5;
     } while (i >= l);
-    return (i + p) % l;
+    if (l == w + 1u) return (i + p) & w;  // wave-uniform
+    return fastmod_u32(i + p, magic, l);
+}
+// unorm16 -> float: v / 65535 correctly rounded, by the reciprocal known in advance (q = v y, q + (v - 65535 q) y with y = RN(1 / 65535):
+// two fma instead of an IEEE division; identical for all 65536 values, tests/test_pmj02bn.py)
+AKR_HD float unorm16(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float y = 1.5259021893143654e-05f, fv = (float)v;
+    const float q = fv * y;
+    return __builtin_fmaf(__builtin_fmaf(-65535.0f, q, fv), y, q);
+#else
+    return (float)v / 65535.0f;
+#endif
 }
 // bluenoise(tex_index, p): uv = p.yx() % 128 of texture tex_index % 48 (sampler/mod.rs:545-553), unorm16 -> float
+// k_pt_pass keeps a lane's pixel for the whole launch, and a pixel reads ONE texel of each of the 48 arrays: when the launch has
+// room (PtParams.bn_offset != 0, launch_pt_pass) the lane's 48 values sit in a column of LDS (pmj_bluenoise_stage below) and a
+// lookup is a ds_read_u16 instead of a gather from a 1.5 MB table.
 AKR_D float pmj_bluenoise(const PtParams& p, uint32_t tex, uint32_t px, uint32_t py) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (p.bn_offset != 0) {  // wave-uniform
+        extern __shared__ __attribute__((aligned(16))) uint32_t akr_dynamic_lds[];
+        const uint16_t* bn = reinterpret_cast<const uint16_t*>(akr_dynamic_lds + p.bn_offset);
+        return unorm16(bn[(tex % kBlueNoiseTextures) * 256u + threadIdx.x]);
+    }
+#endif
     uint32_t tx = py % kBlueNoiseRes, ty = px % kBlueNoiseRes;  // uv = (p.y, p.x)
     uint16_t v = p.bluenoise[((size_t)(tex % kBlueNoiseTextures) * kBlueNoiseRes + ty) * kBlueNoiseRes + tx];
-    return (float)v / 65535.0f;
+    return unorm16(v);
+}
+// the lane's column of blue-noise values (see pmj_bluenoise): every lane writes and later reads only its own entries -- no barrier
+AKR_D void pmj_bluenoise_stage(const PtParams& p, uint32_t px, uint32_t py) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) uint32_t akr_dynamic_lds[];
+    uint16_t* bn = reinterpret_cast<uint16_t*>(akr_dynamic_lds + p.bn_offset);
+    const uint32_t tx = py % kBlueNoiseRes, ty = px % kBlueNoiseRes;
+    for (uint32_t t = 0; t < kBlueNoiseTextures; t++) bn[t * 256u + threadIdx.x] = p.bluenoise[((size_t)t * kBlueNoiseRes + ty) * kBlueNoiseRes + tx];
+#endif
 }
 constexpr float kOneMinusEpsilon = 0.99999994f;
 template <bool PMJ>
@@ -96,7 +129,7 @@ AKR_D float next_1d(const PtParams& p, Sampler& s) {
     // Pmj02BnSampler::next_1d (sampler/mod.rs:555-580)
     const uint32_t px = (uint32_t)s.pcg.inc, py = (uint32_t)(s.pcg.inc >> 32), sample_index = (uint32_t)s.pcg.state;
     uint32_t hash = xxhash32_4_end(s.hash_perm, s.dim);  // = xxhash32_4(px, py, s.dim, p.smp_seed)
-    uint32_t index = permute_element(sample_index, p.smp_spp, p.smp_w, hash);
+    uint32_t index = permute_element(sample_index, p.smp_spp, p.smp_w, hash, p.smp_mod_magic);
     if (p.sampler == 2u) {  // sobol: the permuted index through the scrambled radical inverse (wave-uniform branch)
         // owen_scramble(reverse_bits32(index), seed): the reversal of the argument and the scramble's first one cancel
         const uint32_t v = owen_scramble_of_reversed(index, xxhash32_4_end(s.hash_scramble, s.dim));
@@ -120,14 +153,14 @@ AKR_D vec2 next_2d(const PtParams& p, Sampler& s) {
     const uint32_t dim = s.dim, pmj_instance = dim / 2;
     if (p.sampler == 2u) {  // sobol: every dimension pair is the (0,2)-sequence under its own index permutation and scramble
         const uint32_t hash = xxhash32_4_end(s.hash_perm, dim);
-        const uint32_t i = permute_element(index, p.smp_spp, p.smp_w, hash);
+        const uint32_t i = permute_element(index, p.smp_spp, p.smp_w, hash, p.smp_mod_magic);
         // owen_scramble(reverse_bits32(i), .) and owen_scramble(sobol_dim1(i), .) with the cancelling reversals left out
         const uint32_t vx = owen_scramble_of_reversed(i, xxhash32_4_end(s.hash_scramble, dim));
         const uint32_t vy = owen_scramble_of_reversed(sobol_dim1_reversed(i), xxhash32_4_end(s.hash_scramble, dim + 1u));
         s.dim += 2;
         return mk2(min_f((float)vx * 2.3283064365386963e-10f, kOneMinusEpsilon), min_f((float)vy * 2.3283064365386963e-10f, kOneMinusEpsilon));
     }
-    if (pmj_instance >= kPmjSets) index = permute_element(index, p.smp_spp, p.smp_w, xxhash32_4_end(s.hash_perm, dim));
+    if (pmj_instance >= kPmjSets) index = permute_element(index, p.smp_spp, p.smp_w, xxhash32_4_end(s.hash_perm, dim), p.smp_mod_magic);
     const uint32_t* smp = p.pmj_sets + 2 * ((size_t)kPmjSamples * (pmj_instance % kPmjSets) + (index % kPmjSamples));
     vec2 u = mk2((float)smp[0] * 2.3283064365386963e-10f, (float)smp[1] * 2.3283064365386963e-10f);
     float dx = pmj_bluenoise(p, dim, px, py), dy = pmj_bluenoise(p, dim + 1, px, py);

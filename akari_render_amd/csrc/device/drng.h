@@ -121,6 +121,17 @@ AKR_HD uint32_t xxhash32_4_end(uint32_t h32, uint32_t pz) {
     h32 = PRIME32_3 * (h32 ^ (h32 >> 13));
     return h32 ^ (h32 >> 16);
 }
+// a % d for a divisor known in advance (Lemire, Kaser & Kurz 2019, "Faster remainder by direct computation"): with
+// M = floor((2^64 - 1) / d) + 1, a % d = floor(((M * a mod 2^64) * d) / 2^64) for every 32-bit a and d > 0. Four multiplies instead
+// of the thirty-odd instructions of a division by a run-time value. (tests/test_host.py checks it against % .)
+AKR_HD uint64_t fastmod_magic(uint32_t d) { return 0xffffffffffffffffull / d + 1ull; }
+AKR_HD uint32_t fastmod_u32(uint32_t a, uint64_t M, uint32_t d) {
+    const uint64_t low = M * (uint64_t)a;
+    const uint64_t t = (uint64_t)(uint32_t)low * d;                   // low 32 bits of `low` times d
+    const uint64_t u = (uint64_t)(uint32_t)(low >> 32) * d + (t >> 32);  // + high 32 bits times d: bits 32 .. 95 of low * d
+    return (uint32_t)(u >> 32);
+}
+
 AKR_HD uint32_t xxhash32_4(uint32_t px, uint32_t py, uint32_t pz, uint32_t pw) { return xxhash32_4_end(xxhash32_4_begin(px, py, pw), pz); }
 
 }  // namespace akr

@@ -84,6 +84,7 @@ AKR_D void pt_pass_body(const PtParams& p) {
     const uint32_t pix = px + py * p.width;
     uint32_t sx, sy;
     shifted_pixel(p, px, py, sx, sy);
+    if (PMJ && p.bn_offset != 0) pmj_bluenoise_stage(p, px, py);  // before the first draw (path_regs_init generates the first camera ray)
     PathRegs r;
     path_regs_init<PMJ>(r, q, in_frame, pix, sx, sy);
     constexpr bool PARK = !FD && (TEX ? AKR_PT_PARK_TEX != 0 : (BVH ? AKR_PT_PARK_BVH != 0 : AKR_PT_PARK_FULL != 0));

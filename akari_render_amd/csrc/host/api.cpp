@@ -416,6 +416,7 @@ static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pas
         uint32_t w = se->pmj_spp - 1;
         w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
         p.smp_w = w;
+        p.smp_mod_magic = fastmod_magic(se->pmj_spp);
         if (c.sampler_type == AKR_SAMPLER_PMJ02BN) {  // the sobol sampler computes its points, no tables
             p.pmj_sets = se->ctx->pmj_sets.as<uint32_t>();
             p.bluenoise = se->ctx->bluenoise.as<uint16_t>();
@@ -1803,6 +1804,15 @@ AKR_API int32_t akr_host_sobol_dim1(uint32_t n, const uint32_t* index, uint32_t*
     for (uint32_t k = 0; k < n; k++) {
         by_loop[k] = reverse_bits32(sobol_dim1(index[k]));
         by_butterfly[k] = sobol_dim1_reversed(index[k]);
+    }
+    return AKR_OK;
+}
+// device/drng.h fastmod_u32 on the host: a[k] % d[k] through the precomputed constant
+AKR_API int32_t akr_host_fastmod(uint32_t n, const uint32_t* a, const uint32_t* d, uint32_t* out) {
+    if (!a || !d || !out) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_host_fastmod: NULL argument");
+    for (uint32_t k = 0; k < n; k++) {
+        if (d[k] == 0) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_host_fastmod: divisor 0");
+        out[k] = fastmod_u32(a[k], fastmod_magic(d[k]), d[k]);
     }
     return AKR_OK;
 }

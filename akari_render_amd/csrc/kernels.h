@@ -48,6 +48,7 @@ namespace akr {
 // (dpath.h: PARK), and a traversal carried over to the next intersection phase (pt_kernels.hip).
 constexpr uint32_t kParkSlots = 16, kParkSlotsNoDefer = 13;  // dpath.h: PK_*
 constexpr uint32_t kCarrySlots = 13;                         // pt_kernels.hip: a carried traversal
+constexpr size_t kBlueNoiseColumnBytes = 48 * 256 * 2;          // dpath.h pmj_bluenoise_stage: one u16 per array and lane
 // What a k_pt_pass launch keeps in LDS beyond traversal stacks, staged tables and graph values, by kernel instantiation
 // (BVH / force_diffuse / textured scene / conductor deferral): used by the launcher and by the host's staging decision.
 struct PtLdsPlan {
@@ -100,6 +101,7 @@ struct PtParams {
     // blue-noise offsets; states[pix].state holds the pixel's sample index, .inc its coordinates)
     uint32_t sampler;
     uint32_t smp_seed, smp_spp, smp_w;      // Pmj02BnState.{seed, spp, w}
+    uint64_t smp_mod_magic;                 // fastmod_magic(smp_spp): x % spp without a division (drng.h)
     const uint32_t* pmj_sets;               // [5][65536][2] u32 fixed point
     const uint16_t* bluenoise;              // [48][128][128] unorm16
     // Small scenes (exhaustive path): the tables the shading phase gathers from, staged in LDS by k_pt_pass. Bytes per table
@@ -114,6 +116,7 @@ struct PtParams {
     uint32_t tile_offset;    // BVH kernels with a node tile (disect.h: TILE): word offset of the tile; its size is sc.bvh_tile_nodes
     uint32_t park_offset;    // kernels that park cold path state in LDS while shading (dpath.h: PARK): word offset of the columns
     uint32_t carry_offset;   // BVH kernels that let a wave's longest rays run on into the next iteration (pt_kernels.hip): their columns
+    uint32_t bn_offset;      // pmj02bn sampler, k_pt_pass: word offset of the lanes' blue-noise columns (48 x 256 x 2 B, dpath.h), 0 = the table in HBM
     // work distribution
     uint32_t n_items;
     uint32_t shard_rank, shard_count;

@@ -162,7 +162,7 @@ hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream, hipFunction_t s
     const bool fd = p.force_diffuse != 0, tex = p.sc.tex.nodes != nullptr;
     const bool bvh = p.sc.bvh_nodes != nullptr;
     size_t lds;
-    // dynamic LDS of the launch: [traversal stacks][staged tables][triangle records (WALK 1)][node tile][park columns][carry columns][graph values]
+    // dynamic LDS of the launch: [traversal stacks][staged tables][triangle records (WALK 1)][node tile][park columns][carry columns][blue-noise columns (pmj02bn)][graph values]
     const PtLdsPlan plan = pt_lds_plan(bvh, fd, tex, p.defer_metal != 0, p.sc.n_tris);
     size_t base = (bvh ? p.sc.bvh_stack_depth * 256 * 4 : 0) + p.stage_total + plan.recs_bytes;
     base = (base + 15) & ~(size_t)15;
@@ -181,6 +181,16 @@ hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream, hipFunction_t s
     base += plan.park_bytes;
     pp.carry_offset = (uint32_t)(base / 4);
     base += plan.carry_bytes;
+    pp.bn_offset = 0;
+    {   // pmj02bn: the lanes' blue-noise columns, if the workgroup's share of the CU's LDS has room for them (exhaustive kernels of
+        // small scenes: 24 KB next to ~13 KB of staged tables; the BVH kernels' traversal stacks leave none)
+        const size_t slots = tex ? (size_t)p.tex_slots * kTexValStride * sizeof(TexVal) : 0;
+        if (p.sampler == 1u && !bvh && p.bluenoise != nullptr && base + slots + kBlueNoiseColumnBytes <= pt_lds_budget(tex)) {
+            base = (base + 15) & ~(size_t)15;
+            pp.bn_offset = (uint32_t)(base / 4);
+            base += kBlueNoiseColumnBytes;
+        }
+    }
     const PtParams q = with_tex_slots(pp, base, lds);
     const bool stage = p.stage_total != 0;
     if (spec_fn) {  // the scene's own kernel (host/specialise.cpp): same parameter block, same LDS layout (p.tex_slots is 0: no value slots)

@@ -576,6 +576,8 @@ AKR_API int32_t akr_host_pcg32_states(uint64_t seed, uint64_t n, uint64_t *out2n
 AKR_API int32_t akr_host_pcg_start(uint64_t *state, uint64_t inc);
 AKR_API int32_t akr_host_alias_table(const float *weights, uint32_t n, uint32_t *j, float *t, float *pdf);
 /* The sobol sampler's second dimension, bit-reversed: by the defining loop and by the butterfly the kernels use (csrc/device/drng.h). */
+/* a[k] % d[k] the way the index-based samplers compute it (csrc/device/drng.h fastmod_u32: precomputed constant, no division). */
+AKR_API int32_t akr_host_fastmod(uint32_t n, const uint32_t *a, const uint32_t *d, uint32_t *out);
 AKR_API int32_t akr_host_sobol_dim1(uint32_t n, const uint32_t *index, uint32_t *by_loop, uint32_t *by_butterfly);
 
 /* Library / build identification: "akari_hip <version> gfx950". */

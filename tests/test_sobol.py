@@ -79,3 +79,33 @@ def test_second_dimension_without_the_loop():
     for k in range(32):
         col = int(a[(1 << 20) + 200000 + k])
         assert col == sum(1 << j for j in range(32) if (j & ~k) == 0)
+
+
+def test_remainder_without_a_division():
+    """drng.h fastmod_u32 (the last line of permute_element for a sample count that is not a power of two) = a % d."""
+    from akari_render_amd import capi
+
+    rng = np.random.default_rng(3)
+    d = np.concatenate([rng.integers(1, 1 << 32, size=300000, dtype=np.uint64), rng.integers(1, 70000, size=300000, dtype=np.uint64),
+                        np.array([1, 2, 3, 25600, 65535, 65536, 0xffffffff, 0x80000000, 0x7fffffff], dtype=np.uint64)]).astype(np.uint32)
+    a = rng.integers(0, 1 << 32, size=d.size, dtype=np.uint64).astype(np.uint32)
+    a[:9] = [0, 1, 0xffffffff, 0xfffffffe, 25599, 25600, 25601, 0x80000000, 65535]
+    a[-9:] = 0xffffffff
+    out = np.zeros_like(a)
+    up = lambda x: x.ctypes.data_as(C.POINTER(C.c_uint32))  # noqa: E731
+    capi.check(capi.lib().akr_host_fastmod(a.size, up(a), up(d), up(out)))
+    assert np.array_equal(out, a % d)
+
+
+def test_unorm16_by_reciprocal_is_the_division():
+    """dpath.h unorm16 on the device: q = v y, q + (v - 65535 q) y with y = RN(1 / 65535) (two fma) -- the correctly rounded
+    v / 65535 for all 65536 values (the fma is emulated exactly in float64: every product and sum here fits its 53 bits)."""
+    v = np.arange(65536, dtype=np.float64)
+    want = (v.astype(np.float32) / np.float32(65535.0)).astype(np.float32)
+    y = np.float32(1.5259021893143654e-05)
+    assert y == np.float32(1.0) / np.float32(65535.0)
+    fv = v.astype(np.float32)
+    q = (fv * y).astype(np.float32)
+    r = (np.float64(-65535.0) * q.astype(np.float64) + fv.astype(np.float64)).astype(np.float32)
+    got = (r.astype(np.float64) * np.float64(y) + q.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
