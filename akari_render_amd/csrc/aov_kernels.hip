@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void k_aov(const PtParams p_in, uint32_t spp, 
         const size_t N = (size_t)p.width * p.height;
         Sampler smp;
         smp.pcg = p.states[pix];
-        smp.dim = 0; smp.hash_perm = 0; smp.hash_scramble = 0;
+        smp.dim = 0;
         vec3 acc = mk3(p.film[3 * (size_t)pix + 0], p.film[3 * (size_t)pix + 1], p.film[3 * (size_t)pix + 2]);
         float wsum = p.film[6 * N + pix];
         for (uint32_t s = 0; s < spp; s++) {

@@ -51,9 +51,6 @@ AKR_D vec2 filter_sample(const PtParams& p, vec2 u) {
 struct Sampler {
     Pcg32 pcg;
     uint32_t dim;
-    // index-based samplers: the pixel's half of the two hashes every dimension draws -- xxhash32_4(x, y, dim, seed) (index
-    // permutation) and xxhash32_4(y, x, dim, ~seed) (the sobol sampler's scramble) -- set by sampler_start / sampler_prepare
-    uint32_t hash_perm, hash_scramble;
 };
 constexpr uint32_t kPmjSets = 5, kPmjSamples = 65536, kBlueNoiseTextures = 48, kBlueNoiseRes = 128;
 // permute_element (sampler/mod.rs:473-507; Kensler's hashed permutation of [0, l)). The last line is (i + p) % l: with l a power
@@ -128,11 +125,11 @@ AKR_D float next_1d(const PtParams& p, Sampler& s) {
     }
     // Pmj02BnSampler::next_1d (sampler/mod.rs:555-580)
     const uint32_t px = (uint32_t)s.pcg.inc, py = (uint32_t)(s.pcg.inc >> 32), sample_index = (uint32_t)s.pcg.state;
-    uint32_t hash = xxhash32_4_end(s.hash_perm, s.dim);  // = xxhash32_4(px, py, s.dim, p.smp_seed)
+    uint32_t hash = xxhash32_4(px, py, s.dim, p.smp_seed);
     uint32_t index = permute_element(sample_index, p.smp_spp, p.smp_w, hash, p.smp_mod_magic);
     if (p.sampler == 2u) {  // sobol: the permuted index through the scrambled radical inverse (wave-uniform branch)
         // owen_scramble(reverse_bits32(index), seed): the reversal of the argument and the scramble's first one cancel
-        const uint32_t v = owen_scramble_of_reversed(index, xxhash32_4_end(s.hash_scramble, s.dim));
+        const uint32_t v = owen_scramble_of_reversed(index, xxhash32_4(py, px, s.dim, ~p.smp_seed));
         s.dim += 1;
         return min_f((float)v * 2.3283064365386963e-10f, kOneMinusEpsilon);
     }
@@ -152,15 +149,15 @@ AKR_D vec2 next_2d(const PtParams& p, Sampler& s) {
     uint32_t index = (uint32_t)s.pcg.state;
     const uint32_t dim = s.dim, pmj_instance = dim / 2;
     if (p.sampler == 2u) {  // sobol: every dimension pair is the (0,2)-sequence under its own index permutation and scramble
-        const uint32_t hash = xxhash32_4_end(s.hash_perm, dim);
+        const uint32_t hash = xxhash32_4(px, py, dim, p.smp_seed);
         const uint32_t i = permute_element(index, p.smp_spp, p.smp_w, hash, p.smp_mod_magic);
         // owen_scramble(reverse_bits32(i), .) and owen_scramble(sobol_dim1(i), .) with the cancelling reversals left out
-        const uint32_t vx = owen_scramble_of_reversed(i, xxhash32_4_end(s.hash_scramble, dim));
-        const uint32_t vy = owen_scramble_of_reversed(sobol_dim1_reversed(i), xxhash32_4_end(s.hash_scramble, dim + 1u));
+        const uint32_t vx = owen_scramble_of_reversed(i, xxhash32_4(py, px, dim, ~p.smp_seed));
+        const uint32_t vy = owen_scramble_of_reversed(sobol_dim1_reversed(i), xxhash32_4(py, px, dim + 1u, ~p.smp_seed));
         s.dim += 2;
         return mk2(min_f((float)vx * 2.3283064365386963e-10f, kOneMinusEpsilon), min_f((float)vy * 2.3283064365386963e-10f, kOneMinusEpsilon));
     }
-    if (pmj_instance >= kPmjSets) index = permute_element(index, p.smp_spp, p.smp_w, xxhash32_4_end(s.hash_perm, dim), p.smp_mod_magic);
+    if (pmj_instance >= kPmjSets) index = permute_element(index, p.smp_spp, p.smp_w, xxhash32_4(px, py, dim, p.smp_seed), p.smp_mod_magic);
     const uint32_t* smp = p.pmj_sets + 2 * ((size_t)kPmjSamples * (pmj_instance % kPmjSets) + (index % kPmjSamples));
     vec2 u = mk2((float)smp[0] * 2.3283064365386963e-10f, (float)smp[1] * 2.3283064365386963e-10f);
     float dx = pmj_bluenoise(p, dim, px, py), dy = pmj_bluenoise(p, dim + 1, px, py);
@@ -175,23 +172,12 @@ AKR_D vec3 next_3d(const PtParams& p, Sampler& s) {  // trait default: (next_1d,
     vec2 b = next_2d<PMJ>(p, s);
     return mk3(a, b.x, b.y);
 }
-// the pixel's halves of the sampler's hashes (Sampler.hash_*), for a sampler whose pixel is set. sampler_start does it; a kernel that
-// re-creates a Sampler in the middle of a sample from stored state (wf_kernels.hip) calls it itself.
-template <bool PMJ>
-AKR_D void sampler_prepare(const PtParams& p, Sampler& s) {
-    if (PMJ) {
-        const uint32_t px = (uint32_t)s.pcg.inc, py = (uint32_t)(s.pcg.inc >> 32);
-        s.hash_perm = xxhash32_4_begin(px, py, p.smp_seed);
-        s.hash_scramble = xxhash32_4_begin(py, px, ~p.smp_seed);
-    }
-}
 // sampler.start() (sampler/mod.rs:199-203 / 650-663)
 template <bool PMJ>
 AKR_D void sampler_start(const PtParams& p, Sampler& s) {
     if (!PMJ) {
         pcg_start(s.pcg, p.start);
     } else {
-        sampler_prepare<PMJ>(p, s);
         s.dim = 4;
         uint32_t idx = (uint32_t)s.pcg.state;
         s.pcg.state = idx == 0xffffffffu ? 0u : idx + 1u;
@@ -435,7 +421,7 @@ AKR_D void path_regs_init(PathRegs& r, const PtParams& p, bool active, uint32_t 
     r.samples_done = 0; r.pass_idx = 0; r.c_samples = 0;
     r.cur_spp = (p.n_passes == 1) ? p.last_pass_spp : p.pass_spp;
     r.c_closest = 0; r.c_shadow = 0; r.c_shaded = 0;
-    r.smp.pcg = Pcg32{0, 1}; r.smp.dim = 0; r.smp.hash_perm = 0; r.smp.hash_scramble = 0;
+    r.smp.pcg = Pcg32{0, 1}; r.smp.dim = 0;
     r.film_rgb = mk3(0, 0, 0); r.film_w = 0.0f;
     if (active) {
         r.smp.pcg = p.states[pix];  // SamplerCreator::create, sampler/mod.rs:317-327

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256, 2) void k_gpt_sample(const PtParams p_in, cons
             if (k > 0) gpt_shifted(g, p.width, p.height, px, py, k - 1, qx, qy);
             Sampler smp;
             smp.pcg = backup;  // sampler_backup.clone_box()
-            smp.dim = 0; smp.hash_perm = 0; smp.hash_scramble = 0;
+            smp.dim = 0;
             sampler_start<false>(p, smp);
             vec3 ro, rd;
             generate_ray<false>(p, qx, qy, smp, ro, rd);
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void k_gpt_sample(const PtParams p_in, cons
         g.own[3 * (size_t)pix + 2] = own.z;
         Sampler b;  // sampler_backup.start(); its Drop stores the state with dim = 0
         b.pcg = backup;
-        b.dim = 0; b.hash_perm = 0; b.hash_scramble = 0;
+        b.dim = 0;
         sampler_start<false>(p, b);
         p.states[pix] = b.pcg;
     }

@@ -421,6 +421,7 @@ std::shared_ptr<SpecKernel> SpecCache::get(const std::string& spec_header, const
         }
     }
     hipError_t e = hipModuleLoadData(&k->module, code.data());
+    if (e != hipSuccess) (void)hipGetLastError();  // (the runtime remembers the failure: the next launch's hipGetLastError would report it)
     if (e != hipSuccess && k->cache_hit) {  // a stale or damaged file: compile again
         (void)std::remove(path.c_str());
         k->cache_hit = false;
@@ -433,6 +434,7 @@ std::shared_ptr<SpecKernel> SpecCache::get(const std::string& spec_header, const
         }
         k->compile_ms = now_ms() - c0;
         e = hipModuleLoadData(&k->module, code.data());
+        if (e != hipSuccess) (void)hipGetLastError();
     }
     if (e != hipSuccess) {
         k->module = nullptr;
@@ -441,6 +443,7 @@ std::shared_ptr<SpecKernel> SpecCache::get(const std::string& spec_header, const
     }
     e = hipModuleGetFunction(&k->fn, k->module, "akr_pt_pass_spec");
     if (e != hipSuccess) {
+        (void)hipGetLastError();
         k->fn = nullptr;
         k->status = std::string("hipModuleGetFunction: ") + hipGetErrorString(e);
         return k;

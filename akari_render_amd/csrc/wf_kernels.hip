@@ -123,7 +123,6 @@ __global__ __launch_bounds__(256, TEX ? 1 : AKR_WF_SHADE_WAVES) void k_wf_shade(
         uint32_t sx, sy;
         shifted_pixel(p, px, py, sx, sy);
         wf_load(wf, slot, r);
-        sampler_prepare<PMJ>(p, r.smp);  // the pixel's hash halves are not part of the stored state
         float4 hv = wf.hit[slot];
         Hit hit;
         hit.gid = f2u(hv.x); hit.u = hv.y; hit.v = hv.z; hit.t = 0.0f;

@@ -61,7 +61,7 @@ def test_interpreter_and_per_scene_kernel_agree_and_the_cache_is_used(ctx, root,
     ctx1 = capi.Context(0)  # (the session-wide context may hold this kernel already: modules are cached per context)
     g1, _, _, i1 = render_specialised(ctx1, sd, cfg)
     assert n_bit_diff(g1, ref) == 0
-    assert i1["cache_hit"] == 0 and i1["compile_ms"] > 100.0 and i1["vgprs"] > 0
+    assert i1["cache_hit"] == 0 and i1["compile_ms"] > 0.0 and i1["vgprs"] > 0  # (hiprtc has an in-process cache of its own: not necessarily a second)
     files = os.listdir(tmp_path / "cache")
     assert len(files) == 1 and files[0].startswith("akr_") and files[0].endswith(".co")
     g2, _, _, i2 = render_specialised(ctx1, sd, cfg)  # the same context: the loaded module
