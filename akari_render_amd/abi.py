@@ -267,6 +267,13 @@ class McmcResult(C.Structure):
                 ("n_mutations", C.c_uint64), ("sample_dimension", C.c_uint32), ("_pad", C.c_uint32)]
 
 
+class McmcPartial(C.Structure):
+    """akr_mcmc_partial: one rank's share of the mcmc_opt normalisation (akr_mcmc_render_shard -> akr_mcmc_combine)."""
+
+    _fields_ = [("bootstrap_sum", C.c_double), ("b_sum", C.c_double), ("n_bootstrap", C.c_uint64), ("b_cnt", C.c_uint64), ("n_accepted", C.c_uint64),
+                ("n_mutations", C.c_uint64), ("n_executed", C.c_uint64), ("spp", C.c_uint32), ("contribution", C.c_float)]
+
+
 MARKOV_STATE_DTYPE = [("cur_pixel", "<u4", (2,)), ("chain_id", "<u4"), ("cur_f", "<f4"), ("b", "<f4"), ("b_cnt", "<u4"), ("n_accepted", "<u4"),
                       ("n_mutations", "<u4"), ("cur_iter", "<u4"), ("last_large_iter", "<u4")]
 

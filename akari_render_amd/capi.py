@@ -15,6 +15,7 @@ from . import abi
 from .build import LIB, build
 
 AKR_OK = 0
+FILM_PLANE_RGB, FILM_PLANE_SPLAT, FILM_PLANE_WEIGHT, FILM_PLANES_PT, FILM_PLANES_ALL = 1, 2, 4, 5, 7
 ERR_INVALID_ARGUMENT, ERR_HIP, ERR_NO_DEVICE, ERR_IO, ERR_PARSE, ERR_UNSUPPORTED, ERR_OOM, ERR_RENDER = -1, -2, -3, -4, -5, -6, -7, -8
 
 (ARRAY_WOOP, ARRAY_TRI_GID, ARRAY_SHADE, ARRAY_INSTANCES, ARRAY_MATERIALS, ARRAY_BVH_NODES, ARRAY_LIGHT_ENTRIES,
@@ -40,7 +41,7 @@ EXPORTS = [
     "akr_host_stdrng_u64", "akr_host_chacha_block", "akr_host_pcg32_states", "akr_host_pcg_start", "akr_host_alias_table",
     "akr_probe_math", "akr_probe_bsdf", "akr_probe_intersect", "akr_probe_surface_interaction", "akr_probe_material_inputs",
     "akr_host_decode_png", "akr_host_decode_jpeg", "akr_host_decode_exr", "akr_host_decode_tiff", "akr_host_decode_dds", "akr_host_pmj02bn_tables",
-    "akr_pt_kernel_info", "akr_scene_spec_source", "akr_host_spec_compile", "akr_probe_material_folded_host", "akr_host_sobol_dim1", "akr_host_fastmod",
+    "akr_pt_kernel_info", "akr_scene_spec_source", "akr_host_spec_compile", "akr_probe_material_folded_host", "akr_host_sobol_dim1", "akr_host_fastmod", "akr_film_reduce_planes", "akr_mcmc_render_shard", "akr_mcmc_combine_host", "akr_mcmc_combine",
 ]
 
 
@@ -122,6 +123,10 @@ def lib() -> C.CDLL:
     proto("akr_comm_wrap", vp, vp, i32, i32, vpp)
     proto("akr_comm_destroy", vp)
     proto("akr_film_reduce", vp, vp, i32, i32)
+    proto("akr_film_reduce_planes", vp, vp, i32, i32, u32)
+    proto("akr_mcmc_render_shard", vp, vp, C.POINTER(abi.McmcConfig), u32, u32, vp, C.POINTER(abi.McmcPartial), up, C.POINTER(abi.PtStats))
+    proto("akr_mcmc_combine_host", vp, C.POINTER(abi.McmcPartial), u32, C.POINTER(abi.McmcResult))
+    proto("akr_mcmc_combine", vp, vp, i32, C.POINTER(abi.McmcPartial), C.POINTER(abi.McmcResult))
     proto("akr_pt_config_default", C.POINTER(abi.PtConfig))
     proto("akr_aov_config_default", C.POINTER(abi.AovConfig))
     proto("akr_aov_render", vp, vp, C.POINTER(abi.AovConfig), vp, C.POINTER(abi.PtStats))
@@ -422,9 +427,16 @@ class Comm:
         except Exception:
             pass
 
-    def reduce_film(self, film: "Film", root: int = 0, blocking: bool = True):
-        """Sum of the ranks' films in place, onto `root` (or onto every rank with root = -1)."""
-        check(lib().akr_film_reduce(film.h, self.h, root, 1 if blocking else 0))
+    def mcmc_combine(self, film: "Film", partial, root: int = 0) -> dict:
+        """akr_mcmc_combine: film reduce (all planes) + all-reduce of the normalisation sums over RCCL."""
+        res = abi.McmcResult()
+        check(lib().akr_mcmc_combine(film.h, self.h, root, C.byref(partial), C.byref(res)))
+        return {k: getattr(res, k) for k, _ in abi.McmcResult._fields_ if k != "_pad"}
+
+    def reduce_film(self, film: "Film", root: int = 0, blocking: bool = True, planes: int = 7):
+        """Sum of the ranks' films in place, onto `root` (or onto every rank with root = -1). planes: FILM_PLANES_PT (rgb + weight:
+        what a pt / aov film holds, 4 N floats) or FILM_PLANES_ALL (7 N; gpt / mcmc_opt splats)."""
+        check(lib().akr_film_reduce_planes(film.h, self.h, root, 1 if blocking else 0, planes))
 
 
 class Film:
@@ -759,6 +771,23 @@ def mcmc_render(ctx: Context, scene: Scene, cfg: abi.McmcConfig, film: Film):
     chains = np.zeros(cfg.n_chains, dtype=abi.MARKOV_STATE_DTYPE)
     check(lib().akr_mcmc_render(ctx.h, scene.h, C.byref(cfg), film.h, C.byref(res), chains.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(st)))
     return st.as_dict(), {k: getattr(res, k) for k, _ in abi.McmcResult._fields_ if k != "_pad"}, chains
+
+
+def mcmc_render_shard(ctx: Context, scene: Scene, cfg: abi.McmcConfig, film: Film, rank: int, world: int):
+    """akr_mcmc_render_shard: rank `rank` of `world` -- its chains, its tiles of the direct pass. Returns (counters, partial sums, chain
+    states: n_chains records, this rank's filled)."""
+    st, part = abi.PtStats(), abi.McmcPartial()
+    chains = np.zeros(cfg.n_chains, dtype=abi.MARKOV_STATE_DTYPE)
+    check(lib().akr_mcmc_render_shard(ctx.h, scene.h, C.byref(cfg), rank, world, film.h, C.byref(part), chains.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(st)))
+    return st.as_dict(), part, chains
+
+
+def mcmc_combine_host(film: Optional[Film], partials) -> dict:
+    """akr_mcmc_combine_host: the normalisation from the ranks' partial sums (sets the film's splat scale when a film is given)."""
+    arr = (abi.McmcPartial * len(partials))(*partials)
+    res = abi.McmcResult()
+    check(lib().akr_mcmc_combine_host(film.h if film is not None else None, arr, len(partials), C.byref(res)))
+    return {k: getattr(res, k) for k, _ in abi.McmcResult._fields_ if k != "_pad"}
 
 
 def host_decode_exr(data: bytes) -> np.ndarray:

@@ -1491,8 +1491,12 @@ AKR_API int32_t akr_mcmc_config_default(akr_mcmc_config* c) {  // mcmc::Config::
 }
 // on_pass(spp so far, seconds of rendering so far): called after every pass with the film's splat scale already set for that
 // many samples (reconstruct(film, cnt), mcmc_opt.rs:644-662); used by akr_render_task for --save-intermediate
+// shard_count > 1: this rank's share of the render (akr_mcmc_render_shard) -- chains [rank n / count, (rank + 1) n / count) of the
+// n_chains, the direct-lighting pass on the rank's pixel tiles; `partial` receives what the normalisation needs from this rank.
 static int32_t mcmc_render_impl(akr_context* ctx, akr_scene* scene, const akr_mcmc_config* cfg, akr_film* film, akr_mcmc_result* result,
-                                uint32_t* chain_states, akr_pt_stats* stats, const std::function<void(uint32_t, double)>& on_pass) {
+                                uint32_t* chain_states, akr_pt_stats* stats, const std::function<void(uint32_t, double)>& on_pass,
+                                uint32_t shard_rank = 0, uint32_t shard_count = 1, akr_mcmc_partial* partial = nullptr) {
+    if (shard_count == 0 || shard_rank >= shard_count) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_mcmc_render_shard: shard_rank >= shard_count");
     if (!ctx || !scene || !cfg || !film) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_mcmc_render: NULL argument");
     if (cfg->n_chains == 0 || cfg->n_bootstrap == 0) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_mcmc_render: n_chains and n_bootstrap must be positive");
     if (cfg->spp_per_pass == 0) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_mcmc_render: spp_per_pass must be positive");
@@ -1503,6 +1507,7 @@ static int32_t mcmc_render_impl(akr_context* ctx, akr_scene* scene, const akr_mc
         d.max_depth = 1; d.rr_depth = 1; d.spp = (uint32_t)cfg->direct_spp; d.indirect_only = 0; d.spp_per_pass = cfg->spp_per_pass; d.use_nee = cfg->use_nee;
         d.filter_type = cfg->filter_type; d.filter_radius = cfg->filter_radius; d.sampler_type = cfg->sampler_type; d.sampler_seed = cfg->sampler_seed;
         d.color = cfg->color;
+        d.shard_rank = shard_rank; d.shard_count = shard_count;  // the direct pass is a pt render: its tiles over the ranks
         int32_t rc = akr_pt_render(ctx, scene, &d, film, nullptr);
         if (rc != AKR_OK) return rc;
     }
@@ -1534,12 +1539,18 @@ static int32_t mcmc_render_impl(akr_context* ctx, akr_scene* scene, const akr_mc
         d_states.alloc(n_chains * sizeof(MarkovState));
         d_colors.alloc(n_chains * sizeof(float4));
         d_rngs.alloc(n_chains * sizeof(Pcg32));
+        HIP_CHECK(hipMemsetAsync(d_states.p, 0, d_states.bytes, ctx->stream));  // (a shard leaves the other ranks' records untouched: zeros)
         HIP_CHECK(hipMemcpyAsync(d_rngs.p, seeds.data(), n_chains * sizeof(Pcg32), hipMemcpyHostToDevice, ctx->stream));
         McmcParams m;
         std::memset(&m, 0, sizeof m);
         m.pss = d_pss.as<PssSample>(); m.states = d_states.as<MarkovState>(); m.cur_colors = d_colors.as<float4>(); m.rngs = d_rngs.as<Pcg32>();
         m.seeds = d_seeds.as<Pcg32>(); m.fs = d_fs.as<float>(); m.film = film->data;
         m.n_chains = n_chains; m.n_bootstrap = n_boot; m.dim = dim; m.width = W; m.height = H;
+        // this rank's chains; everything that defines a chain (its bootstrap path, its sampler, the mutations per chain, the weight of a
+        // mutation) comes from the GLOBAL chain index and count, so the union of the ranks' chain sets is the one-GPU chain set
+        const uint32_t chain_begin = (uint32_t)((uint64_t)shard_rank * n_chains / shard_count);
+        const uint32_t chain_end = (uint32_t)((uint64_t)(shard_rank + 1) * n_chains / shard_count);
+        m.chain_begin = chain_begin; m.chain_count = chain_end - chain_begin;
         m.exponential_mutation = cfg->exponential_mutation ? 1u : 0u;
         m.small_sigma = cfg->small_sigma; m.large_step_prob = cfg->large_step_prob; m.image_mutation_prob = cfg->image_mutation_prob;
         m.image_mutation_size = cfg->image_mutation_size;
@@ -1591,22 +1602,34 @@ static int32_t mcmc_render_impl(akr_context* ctx, akr_scene* scene, const akr_mc
             b = sum;
             uint64_t b_cnt = n_boot;
             accepted = 0; mutations = 0;
-            for (const MarkovState& st : states) {
-                b += (double)st.b; b_cnt += st.b_cnt; accepted += st.n_accepted; mutations += st.n_mutations;
+            double own_b = 0.0;
+            uint64_t own_cnt = 0;
+            for (uint32_t k = chain_begin; k < chain_end; k++) {
+                const MarkovState& st = states[k];
+                if (shard_count == 1) b += (double)st.b;  // (one GPU: the reference's summation order)
+                own_b += (double)st.b; own_cnt += st.b_cnt; accepted += st.n_accepted; mutations += st.n_mutations;
             }
-            b = b / (double)b_cnt;
-            film->splat_scale = (float)b / (float)spp_done;
+            b_cnt += own_cnt;
+            if (partial) {
+                partial->bootstrap_sum = sum; partial->b_sum = own_b; partial->n_bootstrap = n_boot; partial->b_cnt = own_cnt;
+                partial->n_accepted = accepted; partial->n_mutations = mutations;
+                partial->spp = spp_done;
+            }
+            if (shard_count == 1) {
+                b = b / (double)b_cnt;
+                film->splat_scale = (float)b / (float)spp_done;
+            }  // a shard's film gets its scale from akr_mcmc_combine, which knows every rank's sums
         };
         uint32_t cnt = 0;
         uint64_t total_mutations = 0;
         double acc_s = 0.0;
         while (cnt < cfg->spp) {
             const uint32_t cur_pass = std::min(cfg->spp - cnt, cfg->spp_per_pass);
-            const uint64_t per = std::max<uint64_t>(npixels * (uint64_t)cur_pass / n_chains, 1);
+            const uint64_t per = std::max<uint64_t>(npixels * (uint64_t)cur_pass / n_chains, 1);  // (global chain count)
             if (per > 0xffffffffull) throw std::invalid_argument("Number of mutations per chain exceeds u32::MAX, please reduce spp per pass or increase number of chains");
             const auto tic = std::chrono::steady_clock::now();
             HIP_CHECK(launch_mcmc_advance(se->params, m, (uint32_t)per, contribution, ctx->stream));
-            total_mutations += per * n_chains;
+            total_mutations += per * (chain_end - chain_begin);
             cnt += cur_pass;
             if (on_pass) {
                 reconstruct(cnt);
@@ -1617,6 +1640,7 @@ static int32_t mcmc_render_impl(akr_context* ctx, akr_scene* scene, const akr_mc
         timer.stop();
         se->n_launches += 2 + (cfg->spp + cfg->spp_per_pass - 1) / cfg->spp_per_pass;
         reconstruct(cfg->spp);
+        if (partial) { partial->contribution = contribution; partial->n_executed = total_mutations; }
         if (result) {
             result->normalization = b; result->acceptance_rate = (double)accepted / (double)mutations; result->splat_scale = film->splat_scale;
             result->contribution = contribution; result->n_mutations = total_mutations; result->sample_dimension = dim; result->_pad = 0;
@@ -1635,6 +1659,33 @@ static int32_t mcmc_render_impl(akr_context* ctx, akr_scene* scene, const akr_mc
 AKR_API int32_t akr_mcmc_render(akr_context* ctx, akr_scene* scene, const akr_mcmc_config* cfg, akr_film* film, akr_mcmc_result* result,
                                 uint32_t* chain_states, akr_pt_stats* stats) {
     return mcmc_render_impl(ctx, scene, cfg, film, result, chain_states, stats, nullptr);
+}
+AKR_API int32_t akr_mcmc_render_shard(akr_context* ctx, akr_scene* scene, const akr_mcmc_config* cfg, uint32_t shard_rank, uint32_t shard_count, akr_film* film,
+                                      akr_mcmc_partial* partial, uint32_t* chain_states, akr_pt_stats* stats) {
+    if (!partial) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_mcmc_render_shard: NULL argument");
+    std::memset(partial, 0, sizeof *partial);
+    return mcmc_render_impl(ctx, scene, cfg, film, nullptr, chain_states, stats, nullptr, shard_rank, shard_count, partial);
+}
+// reconstruct (mcmc_opt.rs:587-611) from the ranks' sums: b = (bootstrap sum + sum of the chains' large-step contributions) / (their count)
+AKR_API int32_t akr_mcmc_combine_host(akr_film* film, const akr_mcmc_partial* partials, uint32_t n, akr_mcmc_result* result) {
+    if (!partials || n == 0) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_mcmc_combine_host: no partial sums");
+    double b = partials[0].bootstrap_sum;
+    uint64_t cnt = partials[0].n_bootstrap, accepted = 0, mutations = 0, executed = 0;
+    for (uint32_t r = 0; r < n; r++) {
+        if (partials[r].bootstrap_sum != partials[0].bootstrap_sum || partials[r].n_bootstrap != partials[0].n_bootstrap || partials[r].spp != partials[0].spp)
+            return fail(AKR_ERR_INVALID_ARGUMENT, "akr_mcmc_combine_host: the partial sums are not of one render (bootstrap or spp differ between ranks)");
+        b += partials[r].b_sum; cnt += partials[r].b_cnt; accepted += partials[r].n_accepted; mutations += partials[r].n_mutations;
+        executed += partials[r].n_executed;
+    }
+    b /= (double)cnt;
+    const float scale = (float)b / (float)partials[0].spp;
+    if (film) film->splat_scale = scale;
+    if (result) {
+        std::memset(result, 0, sizeof *result);
+        result->normalization = b; result->acceptance_rate = mutations ? (double)accepted / (double)mutations : 0.0; result->splat_scale = scale;
+        result->contribution = partials[0].contribution; result->n_mutations = executed;
+    }
+    return AKR_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ render driver

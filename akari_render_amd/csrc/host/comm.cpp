@@ -33,6 +33,8 @@ struct Rccl {
     int (*CommDestroy)(Comm) = nullptr;
     int (*Reduce)(const void*, void*, size_t, int, int, int, Comm, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     std::string error;
 };
@@ -64,6 +66,8 @@ Rccl& rccl() {
         r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
         r.Reduce = (decltype(r.Reduce))sym("ncclReduce");
         r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
         r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
     });
     return r;
@@ -147,8 +151,13 @@ AKR_API int32_t akr_comm_destroy(akr_comm* comm) {
     return AKR_OK;
 }
 
-AKR_API int32_t akr_film_reduce(akr_film* film, akr_comm* comm, int32_t root, int32_t blocking) {
+// planes: which parts of the accumulator [rgb 3N | splat 3N | weight N] carry anything to sum. A `pt` / `aov` film never touches
+// its splat plane (film.rs:196-229 add_sample: rgb + weight), so its exchange is the 4 N floats SURVEY.md 8(e) names -- rgb and
+// weight as two collectives of one RCCL group -- instead of all 7 N; gpt / mcmc_opt films (splats) need all of it. Every rank of
+// the communicator must pass the same mask.
+AKR_API int32_t akr_film_reduce_planes(akr_film* film, akr_comm* comm, int32_t root, int32_t blocking, uint32_t planes) {
     if (!film || !comm || root >= comm->world) return api_fail(AKR_ERR_INVALID_ARGUMENT, "akr_film_reduce: bad argument");
+    if (planes == 0 || (planes & ~(uint32_t)AKR_FILM_PLANES_ALL)) return api_fail(AKR_ERR_INVALID_ARGUMENT, "akr_film_reduce_planes: planes must be a non-empty subset of AKR_FILM_PLANES_ALL");
     int device = 0;
     hipStream_t stream = nullptr;
     float* data = nullptr;
@@ -157,15 +166,66 @@ AKR_API int32_t akr_film_reduce(akr_film* film, akr_comm* comm, int32_t root, in
     if (rc0 != AKR_OK) return rc0;
     if (hipSetDevice(device) != hipSuccess) return api_fail(AKR_ERR_HIP, "hipSetDevice failed");
     Rccl& r = rccl();
+    const size_t N = n / 7;
+    // contiguous runs of the selected planes: [0, 3N) rgb, [3N, 6N) splat, [6N, 7N) weight
+    size_t first[3], count[3];
+    int runs = 0;
+    const size_t lo[3] = {0, 3 * N, 6 * N}, len[3] = {3 * N, 3 * N, N};
+    for (int k = 0; k < 3; k++) {
+        if (!(planes & (1u << k))) continue;
+        if (runs > 0 && first[runs - 1] + count[runs - 1] == lo[k]) count[runs - 1] += len[k];
+        else { first[runs] = lo[k]; count[runs] = len[k]; runs++; }
+    }
     // in place, on the context's own stream: ordered after the render that filled the film, no extra synchronisation
-    int rc = root < 0 ? r.AllReduce(data, data, n, /*ncclFloat32*/ 7, /*ncclSum*/ 0, comm->comm, stream)
-                      : r.Reduce(data, data, n, 7, 0, root, comm->comm, stream);
+    auto one = [&](size_t off, size_t cnt) {
+        return root < 0 ? r.AllReduce(data + off, data + off, cnt, /*ncclFloat32*/ 7, /*ncclSum*/ 0, comm->comm, stream)
+                        : r.Reduce(data + off, data + off, cnt, 7, 0, root, comm->comm, stream);
+    };
+    int rc = 0;
+    if (runs == 1) {
+        rc = one(first[0], count[0]);
+    } else {
+        rc = r.GroupStart();
+        for (int k = 0; k < runs && rc == 0; k++) rc = one(first[k], count[k]);
+        const int rc_end = r.GroupEnd();
+        if (rc == 0) rc = rc_end;
+    }
     if (rc != 0) return rccl_fail(root < 0 ? "ncclAllReduce" : "ncclReduce", rc);
     if (blocking) {
         hipError_t e = hipStreamSynchronize(stream);
         if (e != hipSuccess) return api_fail(AKR_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
     }
     return AKR_OK;
+}
+AKR_API int32_t akr_film_reduce(akr_film* film, akr_comm* comm, int32_t root, int32_t blocking) {
+    return akr_film_reduce_planes(film, comm, root, blocking, AKR_FILM_PLANES_ALL);
+}
+
+// The exchange step of a sharded mcmc_opt render: the films (direct lighting of disjoint tiles + every rank's splats) are summed, the
+// normalisation sums of all ranks meet in one small all-reduce, and akr_mcmc_combine_host's arithmetic sets the film's splat scale.
+AKR_API int32_t akr_mcmc_combine(akr_film* film, akr_comm* comm, int32_t root, const akr_mcmc_partial* mine, akr_mcmc_result* result) {
+    if (!film || !comm || !mine || root >= comm->world) return api_fail(AKR_ERR_INVALID_ARGUMENT, "akr_mcmc_combine: bad argument");
+    int32_t rc0 = akr_film_reduce_planes(film, comm, root, 0, AKR_FILM_PLANES_ALL);
+    if (rc0 != AKR_OK) return rc0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    float* data = nullptr;
+    size_t n = 0;
+    rc0 = film_device_view(film, &device, &stream, &data, &n);
+    if (rc0 != AKR_OK) return rc0;
+    double h[5] = {mine->b_sum, (double)mine->b_cnt, (double)mine->n_accepted, (double)mine->n_mutations, (double)mine->n_executed};  // counts < 2^53: exact
+    double* d = nullptr;
+    if (hipMalloc((void**)&d, sizeof h) != hipSuccess) return api_fail(AKR_ERR_HIP, "akr_mcmc_combine: hipMalloc failed");
+    hipError_t e = hipMemcpyAsync(d, h, sizeof h, hipMemcpyHostToDevice, stream);
+    int rc = e == hipSuccess ? rccl().AllReduce(d, d, 5, /*ncclFloat64*/ 8, /*ncclSum*/ 0, comm->comm, stream) : 0;
+    if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess && rc == 0) e = hipStreamSynchronize(stream);
+    (void)hipFree(d);
+    if (rc != 0) return rccl_fail("ncclAllReduce", rc);
+    if (e != hipSuccess) return api_fail(AKR_ERR_HIP, std::string("akr_mcmc_combine: ") + hipGetErrorString(e));
+    akr_mcmc_partial all = *mine;  // one pseudo-rank that carries everybody's sums
+    all.b_sum = h[0]; all.b_cnt = (uint64_t)h[1]; all.n_accepted = (uint64_t)h[2]; all.n_mutations = (uint64_t)h[3]; all.n_executed = (uint64_t)h[4];
+    return akr_mcmc_combine_host(film, &all, 1, result);
 }
 
 // The exchange step of a sharded gpt render: with reconstruction none the ranks' films (splat channels of disjoint tiles) are

@@ -171,6 +171,7 @@ struct McmcParams {
     const uint32_t* resampled;  // [n_chains] bootstrap path each chain starts from
     float* film;             // the film (7 N floats); the chains splat into its splat channels
     uint32_t n_chains, n_bootstrap, dim, width, height;
+    uint32_t chain_begin, chain_count;  // the chains this launch runs: [chain_begin, chain_begin + chain_count) of the n_chains (a rank's share, akr_mcmc_render_shard)
     uint32_t exponential_mutation;
     float small_sigma, large_step_prob, image_mutation_prob, image_mutation_size;
 };

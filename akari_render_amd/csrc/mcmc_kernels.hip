@@ -161,8 +161,9 @@ __global__ __launch_bounds__(256, 2) void k_mcmc_init(const PtParams p_in, const
     TraceCtx tc;
     tc.stack = lds_stack + threadIdx.x;
     tc.cnt = TraceCounters{0, 0, 0};
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= m.n_chains) return;
+    const uint32_t local = blockIdx.x * 256u + threadIdx.x;
+    if (local >= m.chain_count) return;
+    const uint32_t i = m.chain_begin + local;  // arrays are indexed by the chain's global id: a shard touches its own range only
     McmcSampler s;
     s.rng = m.seeds[m.resampled[i]];
     s.samples = m.pss + i; s.stride = m.n_chains; s.mcmc_dim = m.dim; s.mutate = false; s.is_large_step = false; s.is_image_mutation = false;
@@ -183,9 +184,9 @@ __global__ __launch_bounds__(256, 2) void k_mcmc_advance(const PtParams p_in, co
     TraceCtx tc;
     tc.stack = lds_stack + threadIdx.x;
     tc.cnt = TraceCounters{0, 0, 0};
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t local = blockIdx.x * 256u + threadIdx.x, i = m.chain_begin + local;
     uint32_t n_rays = 0, n_paths = 0;
-    if (i < m.n_chains) {
+    if (local < m.chain_count) {
         const size_t N = (size_t)p.width * p.height;
         float* splat = m.film + 3 * N;
         McmcSampler s;
@@ -283,9 +284,9 @@ __global__ __launch_bounds__(256, 2) void k_mcmc_advance(const PtParams p_in, co
         return hipGetLastError();                                                                                 \
     }
 hipError_t launch_mcmc_bootstrap(const PtParams& p_in, const McmcParams& m, hipStream_t stream) AKR_MCMC_LAUNCH(k_mcmc_bootstrap, m.n_bootstrap, p, m)
-hipError_t launch_mcmc_init(const PtParams& p_in, const McmcParams& m, hipStream_t stream) AKR_MCMC_LAUNCH(k_mcmc_init, m.n_chains, p, m)
+hipError_t launch_mcmc_init(const PtParams& p_in, const McmcParams& m, hipStream_t stream) AKR_MCMC_LAUNCH(k_mcmc_init, m.chain_count, p, m)
 hipError_t launch_mcmc_advance(const PtParams& p_in, const McmcParams& m, uint32_t mutations_per_chain, float contribution, hipStream_t stream)
-    AKR_MCMC_LAUNCH(k_mcmc_advance, m.n_chains, p, m, mutations_per_chain, contribution)
+    AKR_MCMC_LAUNCH(k_mcmc_advance, m.chain_count, p, m, mutations_per_chain, contribution)
 #undef AKR_MCMC_LAUNCH
 
 }  // namespace akr

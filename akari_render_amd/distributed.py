@@ -50,11 +50,17 @@ def owned_pixel_count(width: int, height: int, rank: int, world: int, tile_w: in
     return int(owned_pixel_mask(width, height, rank, world, tile_w, tile_h).sum())
 
 
-def reduce_film(film_tensor, dst: int = 0):
+def reduce_film(film_tensor, dst: int = 0, planes: int = 7):
     """Sum-reduces the per-rank films (f32[7*W*H], reference layout) onto rank `dst`. Disjoint tiles make the sum
     exact: every element receives one non-zero contribution plus zeros."""
     import torch.distributed as dist
 
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(film_tensor, dst=dst, op=dist.ReduceOp.SUM)
+        if planes == 7:
+            dist.reduce(film_tensor, dst=dst, op=dist.ReduceOp.SUM)
+        else:  # the planes a pt / aov film holds: rgb [0, 3N) and weight [6N, 7N) (akr_film_reduce_planes does the same over RCCL)
+            n = film_tensor.numel() // 7
+            runs = [(0, 3 * n)] * bool(planes & 1) + [(3 * n, 6 * n)] * bool(planes & 2) + [(6 * n, 7 * n)] * bool(planes & 4)
+            for a, b in runs:
+                dist.reduce(film_tensor[a:b], dst=dst, op=dist.ReduceOp.SUM)
     return film_tensor

@@ -34,6 +34,7 @@ import numpy as np  # noqa: E402
 W, H, SPP_PER_PASS, PASSES_PER_STEP = 1920, 1080, 64, 16
 SPP_PER_STEP = SPP_PER_PASS * PASSES_PER_STEP
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+PT_PLANES = 5  # akr_film_reduce_planes: rgb + weight, the planes a pt film holds (4 N floats)
 CONFIGS = {
     "c2": dict(name="C2", baseline_config=1, force_diffuse=1, scene="cbox",
                workload="scenes/cbox 1920x1080, diffuse-only BSDF (force_diffuse), 1024 spp per step"),
@@ -148,7 +149,7 @@ def measured_counters(key):
     profiles/r4_fetch_size_calibration.json), VALU busy share, lane utilisation. The summary
     carries the hash of the library sources it was measured on; if that is not the hash of the sources in this tree the
     block is dropped and the line says so. Returns (summary or None, note or None)."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_pmc_{key}.json") for r in (4, 3)) if os.path.exists(q)), os.path.join(ROOT, "profiles", f"r4_pmc_{key}.json"))
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_pmc_{key}.json") for r in (5, 4, 3)) if os.path.exists(q)), os.path.join(ROOT, "profiles", f"r4_pmc_{key}.json"))
     if not os.path.exists(path):
         return None, f"no PMC summary profiles/r4_pmc_{key}.json"
     try:
@@ -233,7 +234,7 @@ def make_native_comm(ctx, rank, world, torch, dist, dev, local_rank, deadline_s)
     def create_and_warm():
         comm = capi.Comm(ctx, box[0], rank, world)
         sf = capi.Film(ctx, W, H, device_ptr=scratch.data_ptr())
-        comm.reduce_film(sf, root=0, blocking=True)  # RCCL builds its rings / proxy connections on the first reduce of a size
+        comm.reduce_film(sf, root=0, blocking=True, planes=PT_PLANES)  # RCCL builds its rings / proxy connections on the first reduce of a size
         del sf
         return comm
 
@@ -335,10 +336,10 @@ def run_config(ctx, key, steps, warmup, rank, world, scaling, film_t, torch, dis
         torch.cuda.synchronize(dev)
         if comm is not None:
             sf = capi.Film(ctx, w, h, device_ptr=scratch.data_ptr())
-            comm.reduce_film(sf, root=0, blocking=True)
+            comm.reduce_film(sf, root=0, blocking=True, planes=PT_PLANES)
             del sf
         else:
-            distributed.reduce_film(scratch, dst=0)
+            distributed.reduce_film(scratch, dst=0, planes=PT_PLANES)
         torch.cuda.synchronize(dev)
         del scratch
     s0 = se.stats()
@@ -356,12 +357,12 @@ def run_config(ctx, key, steps, warmup, rank, world, scaling, film_t, torch, dis
     if world > 1:
         if backend == "gloo":
             host = film_t.cpu()
-            distributed.reduce_film(host, dst=0)
+            distributed.reduce_film(host, dst=0, planes=PT_PLANES)
             film_t.copy_(host)
         elif comm is not None:
-            comm.reduce_film(film, root=0, blocking=True)  # akr_film_reduce: ncclReduce on the context's stream, after the render
+            comm.reduce_film(film, root=0, blocking=True, planes=PT_PLANES)  # akr_film_reduce_planes: ncclReduce of rgb + weight (one group) on the context's stream, after the render
         else:
-            distributed.reduce_film(film_t, dst=0)
+            distributed.reduce_film(film_t, dst=0, planes=PT_PLANES)
         ctx.synchronize()
         torch.cuda.synchronize(dev)
     t_reduced = time.perf_counter()
@@ -380,8 +381,12 @@ def run_config(ctx, key, steps, warmup, rank, world, scaling, film_t, torch, dis
     d["tri_bytes"] = int(getattr(info, "tri_bytes", 48) or 48)
     sinfo["weak"] = weak
     sinfo["film_reduce"] = ("none (one GPU)" if world == 1 else
-                            "akr_film_reduce (ncclReduce over RCCL through the C ABI)" if (comm is not None and backend == "nccl") else
-                            f"torch.distributed.reduce ({'RCCL' if backend == 'nccl' else 'gloo, through host memory'})")
+                            "akr_film_reduce_planes (ncclReduce of rgb + weight over RCCL through the C ABI)" if (comm is not None and backend == "nccl") else
+                            f"torch.distributed.reduce of rgb + weight ({'RCCL' if backend == 'nccl' else 'gloo, through host memory'})")
+    sinfo["film_reduce_bytes"] = 0 if world == 1 else 4 * w * h * 4  # 4 N floats: SURVEY.md 8(e)'s count
+    # what the warm-up launches (16 passes = ONE step = 1024 spp each: the session fuses more only once it has timed a pass) cost
+    if warmup > 0 and s0["n_launches"] and warmup * my_passes == 16 * s0["n_launches"]:
+        sinfo["warmup_launch_ms"] = s0["kernel_ms"] / s0["n_launches"]
     sinfo["spp_done"] = (warmup + steps) * SPP_PER_PASS * passes_per_step
     sinfo["film_tensor"] = film_t
     del film, scene
@@ -433,6 +438,75 @@ def roofline_block(key, d):
                 out[k if k != "kernel" else "pmc_kernel"] = m[k]
     else:
         out["measured_counters"] = note
+    return out
+
+
+def reference_default_leg(ctx):
+    """scenes/cbox/pt.json as it is, through akr_render_task (lib.rs:111-207): 1024 x 1024 (scene.json's own resolution), 4096 spp in
+    passes of 64, pmj02bn sampler (the reference's shipped default), gaussian filter, film written to output/pt.exr."""
+    import tempfile
+
+    from akari_render_amd import capi
+
+    scene = capi.Scene(ctx, os.path.join(ROOT, "scenes", "cbox", "scene.json"))
+    info = scene.info()
+    method = open(os.path.join(ROOT, "scenes", "cbox", "pt.json")).read()
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as d:
+        os.chdir(d)
+        try:
+            t0 = time.perf_counter()
+            st = capi.render_task(ctx, scene, method)
+            wall = time.perf_counter() - t0
+            wrote = os.path.exists(os.path.join(d, "output", "pt.exr"))
+        finally:
+            os.chdir(cwd)
+    dd = {k: st[k] for k in ("n_samples", "n_closest", "n_shadow", "n_shaded", "n_node_visits", "n_tri_tests", "kernel_ms", "n_launches")}
+    dd["node_bytes"], dd["tri_bytes"] = 64, 48
+    return {"metric": "Msamples/s, scenes/cbox/pt.json unchanged (akr_render_task)", "value": st["n_samples"] / wall / 1e6, "unit": "Msamples/s",
+            "value_kernels_only": st["n_samples"] / (st["kernel_ms"] * 1e-3) / 1e6, "wall_s": wall, "kernel_ms": st["kernel_ms"], "launches": st["n_launches"],
+            "resolution": [int(info.width), int(info.height)], "spp": int(st["n_samples"] // (int(info.width) * int(info.height))), "sampler": "pmj02bn",
+            "film_written": bool(wrote), "workload": "scenes/cbox/scene.json + scenes/cbox/pt.json (reference files, unchanged), output stage included",
+            "roofline": roofline_block("reference_default", dd)}
+
+
+def textured_room_leg(ctx):
+    """The textured room of tests/helpers.py at 1080p with 2 x 64 MB images (tools/textured_bench.py's workload): the interpreter
+    kernels against the per-scene kernel (hiprtc, option specialise), exhaustive (n_floor 1) and BVH (n_floor 8) intersectors;
+    4 x 64 spp timed after a 64-spp warm-up. Films of the two settings are compared bit for bit."""
+    from akari_render_amd import abi, capi
+    from tests.helpers import textured_room
+
+    out = {}
+    rng = np.random.default_rng(0)
+    big8 = rng.integers(0, 256, size=(4096, 4096, 4), dtype=np.uint8); big8[:, :, 3] = 255
+    bigf = rng.random((2048, 2048, 4)).astype(np.float32); bigf[:, :, 2] = 0.5 + 0.5 * bigf[:, :, 2]; bigf[:, :, 3] = 1.0
+    table = np.fromfile(os.path.join(ROOT, "tests", "golden", "ggx_dielectric_s.f32"), dtype=np.float32)
+    for nf, label in ((1, "exhaustive"), (8, "bvh")):
+        sd = textured_room(W, H, n_floor=nf)
+        sd.images[0] = abi.ImageData(big8, abi.TEX_FILTER_LINEAR, abi.TEX_REPEAT)
+        sd.images[1] = abi.ImageData(bigf, abi.TEX_FILTER_LINEAR, abi.TEX_MIRROR)
+        sd.ggx_table = table
+        films = {}
+        for mode, opt in (("interpreter", 0), ("per_scene", 1)):
+            with capi.options(specialise=opt):
+                scene = capi.Scene(ctx, sd)
+                film = capi.Film(ctx, W, H)
+                cfg = abi.PtConfig.default()
+                cfg.spp, cfg.spp_per_pass, cfg.max_depth = 64 * 5, 64, 12
+                se = capi.PtSession(ctx, scene, cfg, film)
+            ki = se.kernel_info()
+            se.passes(1, blocking=True)
+            s0 = se.stats()
+            t0 = time.perf_counter()
+            se.passes(4, blocking=True)
+            dt = time.perf_counter() - t0
+            s1 = se.end()
+            films[mode] = film.read()
+            out[f"{label}_{mode}"] = {"value": (s1["n_samples"] - s0["n_samples"]) / dt / 1e6, "unit": "Msamples/s",
+                                      "kernel": {k: ki[k] for k in ("specialised", "cache_hit", "min_waves", "vgprs", "scratch_bytes", "compile_ms", "load_ms", "status")}}
+            del se, film, scene
+        out[f"{label}_films_identical"] = bool(np.array_equal(films["interpreter"].view(np.uint32), films["per_scene"].view(np.uint32)))
     return out
 
 
@@ -565,26 +639,43 @@ def main():
         # (akr_pt_passes): a launch is then several steps, and rocprofv3's per-kernel average mixes it with the 16-pass warm-up launches
         out["roofline"]["passes_per_launch"] = args.steps * PASSES_PER_STEP / max(1, d["n_launches"])
         out["roofline"]["steps_per_launch"] = args.steps / max(1, d["n_launches"])
+        # ... so the line says what its value is the throughput OF: launches of `spp_per_launch` samples per pixel; and next to it what the
+        # configuration's literal 1024-spp render (one 16-pass launch) gives, from the warm-up launches' HIP-event times on this rank
+        out["config"]["passes_per_launch"] = out["roofline"]["passes_per_launch"]
+        out["config"]["spp_per_launch"] = out["roofline"]["passes_per_launch"] * SPP_PER_PASS
+        if world == 1 and sinfo.get("warmup_launch_ms"):
+            out["value_1024spp_launch"] = W * H * SPP_PER_STEP / (sinfo["warmup_launch_ms"] * 1e-3) / 1e6
+            out["config"]["value_1024spp_launch_is"] = "Msamples/s of a 16-pass (1024 spp) launch: mean HIP-event time of the warm-up launches"
     extra = {}
     printed = []
+    import threading
+
+    line_lock = threading.Lock()  # the watchdog thread serialises the line while the main thread may still be adding legs to it
 
     def emit(note=None):
-        if rank == 0 and not printed:
-            printed.append(1)
-            if note:
-                extra["incomplete"] = note
-            if extra:
-                out["extra_configs"] = extra
-            print(json.dumps(out), flush=True)
+        with line_lock:
+            if rank == 0 and not printed:
+                printed.append(1)
+                line = dict(out)
+                legs = dict(extra)
+                if note:
+                    legs["incomplete"] = note
+                if legs:
+                    line["extra_configs"] = legs
+                print(json.dumps(line), flush=True)
+
+    def add_leg(name, leg):
+        with line_lock:
+            extra[name] = leg
 
     # A secondary leg that never comes back (a rank lost inside a collective) must not cost the headline: past the deadline rank 0
     # prints what it has and every rank leaves.
-    import threading
-
     def give_up():
-        log(f"rank {rank}: secondary legs did not finish within {args.legs_deadline:.0f} s; printing the headline line without them")
-        emit(f"secondary legs did not finish within {args.legs_deadline:.0f} s")
-        os._exit(0)
+        try:
+            log(f"rank {rank}: secondary legs did not finish within {args.legs_deadline:.0f} s; printing the headline line without them")
+            emit(f"secondary legs did not finish within {args.legs_deadline:.0f} s")
+        finally:
+            os._exit(0)
 
     dog = threading.Timer(args.legs_deadline, give_up)
     dog.daemon = True
@@ -618,10 +709,10 @@ def main():
                     w2, h2 = resolution(k2)
                     wp = si2["film_tensor"][6 * w2 * h2:]
                     leg["weight_plane_ok"] = bool((wp == float(si2["spp_done"])).all().item())
-                extra[name] = leg
+                add_leg(name, leg)
                 del si2
             except Exception as ex:  # noqa: BLE001 -- a secondary leg must not cost the headline line
-                extra[name] = {"error": f"{type(ex).__name__}: {ex}"}
+                add_leg(name, {"error": f"{type(ex).__name__}: {ex}"})
     if rank == 0:
         also = args.also
         if also is None:
@@ -629,14 +720,26 @@ def main():
         for k2 in [k for k in also.split(",") if k and k != "none" and k != key]:
             try:
                 e2, d2, si2 = run_config(ctx, k2, 1, 0 if k2 == "c4" else 1, 0, 1, "strong", film_t, torch, dist, args.backend, dev, keep_scene=(k2 == "c4"))
-                extra[k2] = {"metric": "Msamples/s, " + CONFIGS[k2]["name"], "value": d2["n_samples"] / e2 / 1e6, "unit": "Msamples/s",
+                add_leg(k2, {"metric": "Msamples/s, " + CONFIGS[k2]["name"], "value": d2["n_samples"] / e2 / 1e6, "unit": "Msamples/s",
                              "steps": 1, "ms_per_step": e2 * 1e3, "workload": CONFIGS[k2]["workload"],
                              "rays_per_s_G": (d2["n_closest"] + d2["n_shadow"]) / e2 / 1e9,
                              "roofline": roofline_block(k2, d2),
                              "counters": {k: d2[k] for k in ("n_samples", "n_closest", "n_shadow", "n_shaded", "n_node_visits", "n_tri_tests")},
-                             **{k: v for k, v in si2.items() if k not in _NOT_REPORTED}}
+                             **{k: v for k, v in si2.items() if k not in _NOT_REPORTED}})
             except Exception as ex:  # a secondary leg must not cost the headline line
-                extra[k2] = {"error": f"{type(ex).__name__}: {ex}"}
+                add_leg(k2, {"error": f"{type(ex).__name__}: {ex}"})
+        # The reference's own shipped workload, unchanged: scenes/cbox/scene.json at the resolution the file names with scenes/cbox/pt.json
+        # (4096 spp, pmj02bn, gaussian 1.5, full graph) through akr_render_task -- what `akari-cli -s scene.json -m pt.json` runs,
+        # output stage included (the film written as OpenEXR into a scratch directory).
+        if also != "none" and args.gpus == 1 and key == "c2":
+            try:
+                add_leg("reference_default", reference_default_leg(ctx))
+            except Exception as ex:  # noqa: BLE001
+                add_leg("reference_default", {"error": f"{type(ex).__name__}: {ex}"})
+            try:
+                add_leg("textured_room", textured_room_leg(ctx))
+            except Exception as ex:  # noqa: BLE001
+                add_leg("textured_room", {"error": f"{type(ex).__name__}: {ex}"})
         # The wavefront schedule (wf_kernels.hip: trace / shade kernels, path state in HBM, ballot + prefix-sum compaction) next to the
         # megakernel on the same scenes, 4 passes (256 spp) each: the hall, and the cbox with a forced BVH (the wavefront schedule has
         # no exhaustive intersector). Measured every run so that the comparison in DESIGN.md is never a stale number.
@@ -654,12 +757,14 @@ def main():
                     except Exception as ex:  # noqa: BLE001
                         sched[f"{name}_{mode}"] = {"error": f"{type(ex).__name__}: {ex}"}
             _SCENES.clear()
-            extra["schedules"] = sched
+            add_leg("schedules", sched)
         if args.gpus == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(key, *host_threads())
+                base = cpu_baseline(key, *host_threads())
             except Exception as ex:  # noqa: BLE001
-                out["cpu_baseline"] = {"error": f"{type(ex).__name__}: {ex}"}
+                base = {"error": f"{type(ex).__name__}: {ex}"}
+            with line_lock:
+                out["cpu_baseline"] = base
     dog.cancel()
     emit()
     if world > 1:

@@ -364,6 +364,11 @@ AKR_API int32_t akr_comm_create(akr_context *ctx, const uint8_t id[AKR_COMM_ID_B
 AKR_API int32_t akr_comm_wrap(akr_context *ctx, void *nccl_comm, int32_t rank, int32_t world, akr_comm **out);
 AKR_API int32_t akr_comm_destroy(akr_comm *comm);
 AKR_API int32_t akr_film_reduce(akr_film *film, akr_comm *comm, int32_t root, int32_t blocking);
+/* The same for a subset of the accumulator's planes [rgb 3N | splat 3N | weight N]: a pt / aov film is rgb + weight only (its
+ * splat plane stays zero), i.e. 4 N floats -- SURVEY.md 8(e)'s count -- as two collectives of one RCCL group; gpt / mcmc_opt films
+ * need AKR_FILM_PLANES_ALL, which is what akr_film_reduce passes. Every rank must pass the same mask. */
+enum { AKR_FILM_PLANE_RGB = 1, AKR_FILM_PLANE_SPLAT = 2, AKR_FILM_PLANE_WEIGHT = 4, AKR_FILM_PLANES_PT = 5, AKR_FILM_PLANES_ALL = 7 };
+AKR_API int32_t akr_film_reduce_planes(akr_film *film, akr_comm *comm, int32_t root, int32_t blocking, uint32_t planes);
 AKR_API int32_t akr_gpt_reduce(struct akr_gpt_session *se, akr_comm *comm, int32_t root, int32_t blocking);   /* see akr_gpt_begin */
 
 /* Fills *cfg with pt::Config::default() (pt.rs:930-944), the default filter (film.rs:50-54) and sampler
@@ -554,11 +559,34 @@ typedef struct {
     uint64_t n_mutations;      /* mutations executed, all chains */
     uint32_t sample_dimension, _pad;
 } akr_mcmc_result;
+/* What the normalisation (reconstruct, mcmc_opt.rs:587-611) needs from one rank of a sharded render. */
+typedef struct {
+    double bootstrap_sum;      /* sum of the n_bootstrap bootstrap contributions: the same on every rank */
+    double b_sum;              /* this rank's chains: sum of their large-step contributions (MarkovState.b) */
+    uint64_t n_bootstrap;
+    uint64_t b_cnt;            /* ... and their count */
+    uint64_t n_accepted, n_mutations;   /* small steps accepted / proposed by this rank's chains */
+    uint64_t n_executed;       /* mutations this rank executed (small and large) */
+    uint32_t spp;              /* samples per pixel of the render (cfg.spp) */
+    float contribution;        /* weight of one mutation (from the global chain count) */
+} akr_mcmc_partial;
 AKR_API int32_t akr_mcmc_config_default(akr_mcmc_config *cfg);
 /* Renders into `film` (clear it first; sets its splat scale). chain_states (host memory, optional): n_chains records of 10
  * u32 = MarkovState {cur_pixel[2], chain_id, cur_f, b, b_cnt, n_accepted, n_mutations, cur_iter, last_large_iter}. */
 AKR_API int32_t akr_mcmc_render(akr_context *ctx, akr_scene *scene, const akr_mcmc_config *cfg, akr_film *film, akr_mcmc_result *result,
                                 uint32_t *chain_states, akr_pt_stats *stats);
+/* mcmc_opt over several GPUs (no reference counterpart): the chains are independent, so rank r of n runs chains
+ * [r c / n, (r + 1) c / n) of the c = cfg.n_chains. Everything that defines a chain -- the bootstrap path it starts from (every rank runs
+ * the same bootstrap and resampling), its sampler stream, the mutations per chain and the weight of a mutation -- comes from the chain's
+ * GLOBAL index and the global count: the union of the ranks' chain sets is the one-GPU chain set, chain for chain (chain_states:
+ * n_chains records, only this rank's are filled, the others zero). The direct-lighting pass (direct_spp > 0) renders the rank's pixel
+ * tiles. Afterwards the films are summed (all planes) and the normalisation is made from every rank's sums:
+ *   akr_mcmc_combine(film, comm, root, &mine, &result)   akr_film_reduce + an all-reduce of the sums over RCCL; sets the film's splat scale
+ *   akr_mcmc_combine_host(film, partials, n, &result)    the same arithmetic from partial sums the caller gathered itself */
+AKR_API int32_t akr_mcmc_render_shard(akr_context *ctx, akr_scene *scene, const akr_mcmc_config *cfg, uint32_t shard_rank, uint32_t shard_count,
+                                      akr_film *film, akr_mcmc_partial *partial, uint32_t *chain_states, akr_pt_stats *stats);
+AKR_API int32_t akr_mcmc_combine_host(akr_film *film, const akr_mcmc_partial *partials, uint32_t n, akr_mcmc_result *result);
+AKR_API int32_t akr_mcmc_combine(akr_film *film, akr_comm *comm, int32_t root, const akr_mcmc_partial *mine, akr_mcmc_result *result);
 
 /* util::write_image (akari_render/src/util/mod.rs:57-127): ".exr" -> linear RGB f32 OpenEXR (uncompressed scanlines),
  * ".png" -> 8-bit sRGB. rgb = 3 * W * H floats, row-major, top row first. Creates parent directories. */

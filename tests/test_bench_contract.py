@@ -101,7 +101,7 @@ def test_native_communicator_fallbacks(monkeypatch):
                 raise capi.AkariError(-6, "ncclCommInitRank: unhandled system error")
             self.closed = False
 
-        def reduce_film(self, film, root=0, blocking=True):
+        def reduce_film(self, film, root=0, blocking=True, planes=7):
             if behaviour["mode"] == "hang":
                 time.sleep(60)
 

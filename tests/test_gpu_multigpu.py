@@ -29,6 +29,14 @@ def test_native_reduce_world_of_one(ctx, cbox_path):
     comm.reduce_film(film, root=-1, blocking=False)   # all-reduce, asynchronous on the context's stream
     ctx.synchronize()
     assert n_bit_diff(film.read(), before) == 0
+    # the planes a pt film holds (rgb + weight = 4 N floats, two collectives in one RCCL group), and every other subset
+    assert not before[3 * 96 * 64: 6 * 96 * 64].any()
+    for planes in (capi.FILM_PLANES_PT, 1, 2, 3, 4, 6, capi.FILM_PLANES_ALL):
+        comm.reduce_film(film, root=0, planes=planes)
+        assert n_bit_diff(film.read(), before) == 0
+    for bad in (0, 8):
+        with pytest.raises(capi.AkariError):
+            comm.reduce_film(film, root=0, planes=bad)
     comm.close()
     with pytest.raises(capi.AkariError):
         capi.Comm(ctx, capi.comm_unique_id(), 3, 2)   # rank >= world

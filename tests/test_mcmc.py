@@ -159,3 +159,117 @@ def test_mcmc_in_a_non_default_colour_pipeline(ctx, cbox_path, root, color):
     a = both(ctx, sd, mcmc_config(color=color))
     b = both(ctx, sd, mcmc_config())
     assert a["normalization"] != b["normalization"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [3, 2])
+def test_mcmc_sharded_chain_sets_are_the_one_gpu_chain_set(ctx, cbox_path, root, world):
+    """akr_mcmc_render_shard: rank r of `world` runs chains [r c / world, (r + 1) c / world) and its tiles of the direct pass. Rendered one
+    after the other on this GPU: every chain's final state is the oracle's (= the one-GPU run's) bit for bit, the direct pass's planes sum
+    to the oracle's exactly (disjoint tiles), the normalisation from the ranks' sums is the oracle's up to the order of a double sum, and
+    the splats agree up to the order of the float atomics (as on one GPU)."""
+    from tests.test_gpt import make_scene
+
+    sd = make_scene("cbox", cbox_path, root, 40, 32)
+    cfg = mcmc_config(n_chains=100, spp=10, spp_per_pass=4)  # 100 chains over 3 ranks: uneven shares
+    w, h = 40, 32
+    n = w * h
+    scene = capi.Scene(ctx, sd)
+    o_film, o_res, o_chains = pyoracle.OracleScene(sd).mcmc_render(cfg)
+    total = np.zeros(7 * n, dtype=np.float32)
+    chains = np.zeros(cfg.n_chains, dtype=abi.MARKOV_STATE_DTYPE)
+    partials, executed = [], 0
+    for rank in range(world):
+        film = capi.Film(ctx, w, h)
+        st, part, ch = capi.mcmc_render_shard(ctx, scene, cfg, film, rank, world)
+        lo, hi = rank * cfg.n_chains // world, (rank + 1) * cfg.n_chains // world
+        assert not ch[:lo].view(np.uint8).any() and not ch[hi:].view(np.uint8).any()  # the other ranks' records stay zero
+        chains[lo:hi] = ch[lo:hi]
+        g = film.read()
+        assert not np.any((total[: 3 * n] != 0) & (g[: 3 * n] != 0))  # direct pass: disjoint tiles
+        total += g
+        partials.append(part)
+        executed += part.n_executed
+        assert part.bootstrap_sum == partials[0].bootstrap_sum and part.spp == cfg.spp
+    for name in chains.dtype.names:
+        assert np.array_equal(chains[name].view(np.uint32), o_chains[name].view(np.uint32)), f"MarkovState.{name} differs"
+    res = capi.mcmc_combine_host(None, partials)
+    assert abs(res["normalization"] - o_res["normalization"]) <= 1e-12 * o_res["normalization"]
+    assert res["acceptance_rate"] == o_res["acceptance_rate"] and np.float32(res["contribution"]) == o_res["contribution"]
+    assert abs(np.float32(res["splat_scale"]) - o_res["splat_scale"]) <= np.spacing(np.float32(o_res["splat_scale"]))
+    assert res["n_mutations"] == executed == max(n * 4 // cfg.n_chains, 1) * cfg.n_chains * 2 + max(n * 2 // cfg.n_chains, 1) * cfg.n_chains
+    assert np.array_equal(total[: 3 * n], o_film[: 3 * n]) and np.array_equal(total[6 * n:], o_film[6 * n:])
+    gs, os_ = total[3 * n: 6 * n], o_film[3 * n: 6 * n]
+    assert np.allclose(gs, os_, rtol=2e-4, atol=2e-5 * float(np.abs(os_).max()))
+    with pytest.raises(capi.AkariError):
+        capi.mcmc_render_shard(ctx, scene, cfg, capi.Film(ctx, w, h), 3, 3)
+
+
+@pytest.mark.gpu
+def test_mcmc_combine_over_rccl_world_of_one(ctx, cbox_path, root):
+    """akr_mcmc_combine (film reduce + all-reduce of the normalisation sums over RCCL) on a world of one = akr_mcmc_render."""
+    from tests.test_gpt import make_scene
+
+    sd = make_scene("cbox", cbox_path, root, 36, 36)
+    cfg = mcmc_config(spp=6)
+    scene = capi.Scene(ctx, sd)
+    f1, f2 = capi.Film(ctx, 36, 36), capi.Film(ctx, 36, 36)
+    _, res, chains = capi.mcmc_render(ctx, scene, cfg, f1)
+    _, part, ch = capi.mcmc_render_shard(ctx, scene, cfg, f2, 0, 1)
+    comm = capi.Comm(ctx, capi.comm_unique_id(), 0, 1)
+    got = comm.mcmc_combine(f2, part, root=0)
+    comm.close()
+    assert np.array_equal(ch.view(np.uint8), chains.view(np.uint8))
+    assert got["normalization"] == res["normalization"] and got["acceptance_rate"] == res["acceptance_rate"] and got["n_mutations"] == res["n_mutations"]
+    assert f2.splat_scale == f1.splat_scale == np.float32(res["splat_scale"])
+    n = 36 * 36
+    a, b = f1.read(), f2.read()
+    assert np.array_equal(a[: 3 * n], b[: 3 * n]) and np.allclose(a[3 * n: 6 * n], b[3 * n: 6 * n], rtol=2e-4, atol=2e-5 * float(np.abs(a).max()))
+
+
+def _combine_worker(rank, world, port, out_path):
+    import torch
+    import torch.distributed as dist
+
+    from akari_render_amd import distributed
+
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    distributed.init_process_group("gloo")
+    # a rank's partial sums (synthetic: the arithmetic of the exchange is what runs here; the chains themselves need a GPU)
+    part = abi.McmcPartial(bootstrap_sum=12.5, b_sum=1.25 * (rank + 1), n_bootstrap=1000, b_cnt=10 + rank, n_accepted=700 + rank, n_mutations=900 + 2 * rank,
+                           n_executed=1000 + rank, spp=16, contribution=1.5)
+    t = torch.tensor([part.b_sum, float(part.b_cnt), float(part.n_accepted), float(part.n_mutations), float(part.n_executed)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)  # what akr_mcmc_combine does over RCCL
+    everyone = abi.McmcPartial(bootstrap_sum=part.bootstrap_sum, b_sum=float(t[0]), n_bootstrap=part.n_bootstrap, b_cnt=int(t[1]), n_accepted=int(t[2]),
+                               n_mutations=int(t[3]), n_executed=int(t[4]), spp=part.spp, contribution=part.contribution)
+    res = capi.mcmc_combine_host(None, [everyone])
+    if rank == 0:
+        with open(out_path, "w") as f:
+            json.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_mcmc_normalisation_from_two_ranks_over_gloo(tmp_path):
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "res.json")
+    mp.spawn(_combine_worker, args=(2, port, out), nprocs=2, join=True)
+    res = json.load(open(out))
+    b = (12.5 + 1.25 + 2.5) / (1000 + 10 + 11)
+    assert res["normalization"] == b and res["acceptance_rate"] == (700 + 701) / (900 + 902) and res["n_mutations"] == 2001
+    assert np.float32(res["splat_scale"]) == np.float32(b) / np.float32(16) and res["contribution"] == 1.5
+    # gathered partials give the same numbers; partials of different renders are refused
+    parts = [abi.McmcPartial(bootstrap_sum=12.5, b_sum=1.25 * (r + 1), n_bootstrap=1000, b_cnt=10 + r, n_accepted=700 + r, n_mutations=900 + 2 * r, n_executed=1000 + r,
+                             spp=16, contribution=1.5) for r in range(2)]
+    assert capi.mcmc_combine_host(None, parts) == res
+    parts[1].spp = 8
+    with pytest.raises(capi.AkariError):
+        capi.mcmc_combine_host(None, parts)

@@ -53,8 +53,9 @@ def _worker(rank, world, port, cbox_path, out_path):
     sc = pyoracle.OracleScene(sd)
     cfg = distributed.shard_config(make_config(spp=4, spp_per_pass=2, max_depth=4), rank, world, 16, 16)
     film, _ = sc.render(cfg, n_threads=2)
+    assert not film[3 * 48 * 48: 6 * 48 * 48].any()  # a pt film never touches its splat plane
     t = torch.from_numpy(film)
-    distributed.reduce_film(t, dst=0)
+    distributed.reduce_film(t, dst=0, planes=5)  # rgb + weight: the 4 N floats of SURVEY.md 8(e) (akr_film_reduce_planes over RCCL)
     if rank == 0:
         np.save(out_path, t.numpy())
     import torch.distributed as dist
