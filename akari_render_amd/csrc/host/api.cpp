@@ -172,6 +172,10 @@ struct akr_pt_session {
     // wavefront schedule (wf_kernels.hip): path state SoA + ray queues
     bool wavefront = false;
     DevBuf wf_state, wf_queues, wf_ctrl;
+    // option wf_sort: keys of the queue entries, the sorted copies the trace kernel reads, rocPRIM's scratch
+    bool wf_sort = false;
+    DevBuf wf_keys, wf_sorted, wf_sort_tmp;
+    uint32_t *wf_sorted_closest = nullptr, *wf_sorted_shadow = nullptr, *wf_sorted_keys = nullptr;
     WfBuffers wf;
     uint32_t wf_slots = 0, wf_trace_blocks = 0;
     uint32_t spp_done = 0, n_launches = 0;
@@ -489,6 +493,12 @@ static void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pas
         p.defer_metal = (want && (!bvh || cs.has_textures) && !c.force_diffuse) ? mask : 0u;
         p.defer_flags = flags;
     }
+    p.wf_sort = se->wf_sort ? 1u : 0u;
+    for (int a = 0; a < 3; a++) {  // the sort key's grid: 128 cells per axis over the scene's box
+        const float lo = s->cs.scene_lo[a], ext = s->cs.scene_hi[a] - s->cs.scene_lo[a];
+        p.sort_lo[a] = lo;
+        p.sort_scale[a] = ext > 0.0f ? 128.0f / ext : 0.0f;
+    }
     p.shard_rank = c.shard_count > 1 ? c.shard_rank : 0;
     p.shard_count = c.shard_count > 1 ? c.shard_count : 1;
     p.tile_w = c.tile_w ? c.tile_w : 32;
@@ -525,6 +535,17 @@ static void wf_allocate(akr_pt_session* se, uint32_t n_slots) {
     se->wf_queues.alloc(4 * n * sizeof(uint32_t));
     uint32_t* q = (uint32_t*)se->wf_queues.p;
     w.queue_closest[0] = q; w.queue_closest[1] = q + n; w.queue_shadow[0] = q + 2 * n; w.queue_shadow[1] = q + 3 * n;
+    w.key_closest[0] = w.key_closest[1] = w.key_shadow[0] = w.key_shadow[1] = nullptr;
+    if (se->wf_sort) {
+        se->wf_keys.alloc(4 * n * sizeof(uint32_t));
+        uint32_t* k = (uint32_t*)se->wf_keys.p;
+        w.key_closest[0] = k; w.key_closest[1] = k + n; w.key_shadow[0] = k + 2 * n; w.key_shadow[1] = k + 3 * n;
+        se->wf_sorted.alloc(3 * n * sizeof(uint32_t));
+        se->wf_sorted_closest = (uint32_t*)se->wf_sorted.p;
+        se->wf_sorted_shadow = se->wf_sorted_closest + n;
+        se->wf_sorted_keys = se->wf_sorted_closest + 2 * n;
+        se->wf_sort_tmp.alloc(wf_sort_temp_bytes((uint32_t)n));
+    }
     se->wf_ctrl.alloc(8 * sizeof(uint32_t));
     uint32_t* c = (uint32_t*)se->wf_ctrl.p;
     w.qcount = c; w.qhead = c + 4; w.n_active = c + 5;
@@ -543,13 +564,34 @@ static void wf_run(akr_pt_session* se) {
     const int kCheckEvery = 16;
     uint32_t q = 0;
     for (uint64_t iter = 0;; iter++) {
+        // option wf_sort: the sizes of the queue this iteration traces (rocPRIM wants the element count on the host): one small read-back
+        // per iteration, before the counters are reset -- it also ends the loop the moment the last path has finished
+        uint32_t nc = 0, ns = 0;
+        const bool sort_now = se->wf_sort && iter > 0;  // (the first iteration's camera rays are in pixel order: coherent as they are)
+        if (sort_now) {
+            uint32_t counts[6];
+            HIP_CHECK(hipMemcpyAsync(counts, ctrl, sizeof counts, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            if (counts[5] == 0) break;  // n_active after the last shade
+            nc = counts[2 * q];
+            ns = counts[2 * q + 1];
+        }
         // queue q holds the rays to trace; reset the head, the other queue's counts and the active counter
         HIP_CHECK(hipMemsetAsync(ctrl + 2 * (1 - q), 0, 2 * sizeof(uint32_t), st));
         HIP_CHECK(hipMemsetAsync(ctrl + 4, 0, 2 * sizeof(uint32_t), st));
-        HIP_CHECK(launch_wf_trace(p, se->wf, q, se->wf_trace_blocks, st));
+        if (sort_now) {
+            WfBuffers sorted = se->wf;
+            HIP_CHECK(wf_sort_pairs(se->wf_sort_tmp.p, se->wf_sort_tmp.bytes, se->wf.key_closest[q], se->wf_sorted_keys, se->wf.queue_closest[q], se->wf_sorted_closest, nc, st));
+            HIP_CHECK(wf_sort_pairs(se->wf_sort_tmp.p, se->wf_sort_tmp.bytes, se->wf.key_shadow[q], se->wf_sorted_keys, se->wf.queue_shadow[q], se->wf_sorted_shadow, ns, st));
+            sorted.queue_closest[q] = se->wf_sorted_closest;
+            sorted.queue_shadow[q] = se->wf_sorted_shadow;
+            HIP_CHECK(launch_wf_trace(p, sorted, q, se->wf_trace_blocks, st));
+        } else {
+            HIP_CHECK(launch_wf_trace(p, se->wf, q, se->wf_trace_blocks, st));
+        }
         HIP_CHECK(launch_wf_shade(p, se->wf, 1 - q, st));
         q = 1 - q;
-        if ((iter + 1) % kCheckEvery == 0) {
+        if (!se->wf_sort && (iter + 1) % kCheckEvery == 0) {
             uint32_t n_active = 0;
             HIP_CHECK(hipMemcpyAsync(&n_active, ctrl + 5, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
@@ -979,6 +1021,7 @@ AKR_API int32_t akr_pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_co
         se->counters.alloc(8 * kStatStripes * sizeof(uint64_t));
         HIP_CHECK(hipMemsetAsync(se->counters.p, 0, se->counters.bytes, ctx->stream));
         se->wavefront = choose_wavefront(scene);
+        se->wf_sort = se->wavefront && tuning().wf_sort != 0;
         {
             const TuningOptions t = tuning();
             se->defer_metal_option = t.defer_metal;

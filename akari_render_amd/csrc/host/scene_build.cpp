@@ -841,6 +841,7 @@ void tuning_init_locked() {
     if (const char* e = std::getenv("AKR_PT_SIMPLE")) g_tuning.simple_kernels = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("AKR_SPECIALISE")) g_tuning.specialise = std::atoi(e);
     if (const char* e = std::getenv("AKR_SPECIALISE_WAVES")) g_tuning.specialise_waves = std::atoi(e);
+    if (const char* e = std::getenv("AKR_WF_SORT")) g_tuning.wf_sort = std::atoi(e) != 0 ? 1 : 0;
 }
 int* tuning_field(const char* name) {
     const std::string n = name ? name : "";
@@ -853,6 +854,7 @@ int* tuning_field(const char* name) {
     if (n == "specialise") return &g_tuning.specialise;
     if (n == "specialise_waves") return &g_tuning.specialise_waves;
     if (n == "max_fused_passes") return &g_tuning.max_fused_passes;
+    if (n == "wf_sort") return &g_tuning.wf_sort;
     return nullptr;
 }
 }  // namespace
@@ -870,6 +872,7 @@ bool tuning_set(const char* name, int value) {
     if (f == &g_tuning.specialise && (value < -1 || value > 1)) return false;
     if (f == &g_tuning.specialise_waves && value != 0 && (value < 2 || value > 4)) return false;
     if (f == &g_tuning.max_fused_passes && (value < 0 || value > 64)) return false;
+    if (f == &g_tuning.wf_sort && (value < 0 || value > 1)) return false;
     *f = value;
     return true;
 }

@@ -104,12 +104,14 @@ void build_alias_table(const std::vector<float>& weights, std::vector<AliasEntry
 //   specialise   AKR_SPECIALISE=<v>       per-scene kernels for scenes with texture-fed materials (host/specialise.cpp): -1 = the library decides (a cached
 //                                         kernel always; a compile for renders of at least kSpecAutoSamples samples), 0 = never (the interpreter), 1 = always
 //   specialise_waves AKR_SPECIALISE_WAVES=<n>  waves per SIMD a per-scene kernel is compiled for: 0 = the library's choice, else 2..4
+//   wf_sort      AKR_WF_SORT=1            wavefront schedule: ray queues sorted by origin cell + direction octant before each trace launch
 //   max_fused_passes (no environment hook)     most passes akr_pt_passes fuses into one launch: 0 = adaptive (16, up to 64 once a pass has been timed), else 1..64
 struct TuningOptions {
     int force_bvh = 0, bvh_balanced = 0, defer_metal = -1, wavefront = 0, simple_kernels = 1;
     int defer_on = 0;  // BVH kernels of textured scenes: which hits the deferral puts off -- 0 / 1 = the conductor lobe (default), 2 = texture-fed materials, 3 = both
     int specialise = -1, specialise_waves = 0;
     int max_fused_passes = 0;
+    int wf_sort = 0;  // wavefront schedule: 1 = the ray queues are sorted by (Morton code of the origin, octant) before every trace launch (wf_sort.hip)
 };
 constexpr uint64_t kSpecAutoSamples = 1ull << 31;  // option specialise = -1: a first-use compile (about a second; 20-30 % of the render to win) has to be worth it
 TuningOptions tuning();                          // a snapshot (thread-safe)

@@ -117,6 +117,9 @@ struct PtParams {
     uint32_t park_offset;    // kernels that park cold path state in LDS while shading (dpath.h: PARK): word offset of the columns
     uint32_t carry_offset;   // BVH kernels that let a wave's longest rays run on into the next iteration (pt_kernels.hip): their columns
     uint32_t bn_offset;      // pmj02bn sampler, k_pt_pass: word offset of the lanes' blue-noise columns (48 x 256 x 2 B, dpath.h), 0 = the table in HBM
+    // wavefront schedule, option wf_sort: the ray queues are sorted by (Morton code of the origin in the scene's box, octant of the direction)
+    uint32_t wf_sort;
+    float sort_lo[3], sort_scale[3];  // cell = (o - lo) * scale, 128 cells per axis
     // work distribution
     uint32_t n_items;
     uint32_t shard_rank, shard_count;
@@ -133,6 +136,8 @@ struct WfBuffers {
     uint4 *rng, *misc;              // pcg state, dim, samples_done ; pass_idx, cur_spp, pcg inc
     uint32_t* queue_closest[2];     // ray queues (slot ids), double-buffered
     uint32_t* queue_shadow[2];
+    uint32_t* key_closest[2];       // option wf_sort: sort key of every queue entry (wf_kernels.hip wf_ray_key), same indexing as the queues
+    uint32_t* key_shadow[2];
     uint32_t* qcount;               // [4]: closest/shadow counts of queue 0, of queue 1
     uint32_t* qhead;                // next unclaimed ray id of the queue being traced
     uint32_t* n_active;             // slots still active after the last shade
@@ -202,6 +207,9 @@ hipError_t launch_wf_init(const PtParams& p, const WfBuffers& wf, hipStream_t st
 hipError_t launch_wf_shade(const PtParams& p, const WfBuffers& wf, uint32_t q_out, hipStream_t stream);
 uint32_t wf_trace_blocks_per_cu(const PtParams& p);
 hipError_t launch_wf_trace(const PtParams& p, const WfBuffers& wf, uint32_t q_in, uint32_t n_blocks, hipStream_t stream);
+// wf_sort.hip: key-value radix sort of a ray queue (24-bit keys)
+size_t wf_sort_temp_bytes(uint32_t n);
+hipError_t wf_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, uint32_t n, hipStream_t stream);
 hipError_t launch_probe_material(const PtParams& p, uint32_t material, uint32_t n, const float* uv, uint32_t* out, hipStream_t stream);
 hipError_t launch_init_pcg32(const uint64_t* seeds, void* states, uint64_t n, hipStream_t stream);
 hipError_t launch_film_resolve(const float* film, uint64_t n, float splat_scale, float* rgb, hipStream_t stream);

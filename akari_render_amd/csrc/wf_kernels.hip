@@ -65,7 +65,22 @@ AKR_D void wf_load(const WfBuffers& wf, uint32_t slot, PathRegs& r) {
 // counts meet in LDS and ONE lane per counter adds the workgroup's total (three atomics per workgroup instead of three per wave:
 // queue heads and the active counter are single addresses, and their atomics serialise at the L2). Queue order = slot order
 // within the workgroup. Must be called by all 256 threads.
-AKR_D void wf_enqueue(const WfBuffers& wf, uint32_t q, uint32_t slot, PathRegs& r) {
+// Sort key of a ray (option wf_sort): 21-bit Morton code of the origin's cell in the scene's box (128 cells per axis), then the
+// three sign bits of the direction -- rays that start close together and head the same way end up in the same trace wave.
+AKR_D uint32_t wf_spread7(uint32_t x) {  // bit i of the low 7 bits -> bit 3 i
+    x &= 0x7fu;
+    x = (x | (x << 8)) & 0x0000700fu;
+    x = (x | (x << 4)) & 0x000430c3u;
+    x = (x | (x << 2)) & 0x00049249u;
+    return x;
+}
+AKR_D uint32_t wf_ray_key(const PtParams& p, vec3 o, vec3 d) {
+    auto cell = [](float t) { return (uint32_t)(int)min_f(max_f(t, 0.0f), 127.0f); };  // (NaN -> 0)
+    const uint32_t cx = cell((o.x - p.sort_lo[0]) * p.sort_scale[0]), cy = cell((o.y - p.sort_lo[1]) * p.sort_scale[1]), cz = cell((o.z - p.sort_lo[2]) * p.sort_scale[2]);
+    const uint32_t oct = (d.x >= 0.0f ? 1u : 0u) | (d.y >= 0.0f ? 2u : 0u) | (d.z >= 0.0f ? 4u : 0u);
+    return ((wf_spread7(cx) | (wf_spread7(cy) << 1) | (wf_spread7(cz) << 2)) << 3) | oct;
+}
+AKR_D void wf_enqueue(const PtParams& p, const WfBuffers& wf, uint32_t q, uint32_t slot, PathRegs& r) {
     // closest-hit rays and shadow rays go to separate queues so that waves of the trace kernel are homogeneous
     __shared__ uint32_t sh_cnt[4][3], sh_base[3];
     const bool want_c = r.active && r.has_ray, want_s = r.active && r.has_shadow;
@@ -86,8 +101,18 @@ AKR_D void wf_enqueue(const WfBuffers& wf, uint32_t q, uint32_t slot, PathRegs& 
     uint32_t bc = sh_base[0], bs = sh_base[1];
     for (uint32_t k = 0; k < wave; k++) { bc += sh_cnt[k][0]; bs += sh_cnt[k][1]; }
     const uint64_t below = (1ull << lane) - 1ull;
-    if (want_c) { wf.queue_closest[q][bc + (uint32_t)__builtin_popcountll(mc & below)] = slot; r.c_closest++; }
-    if (want_s) { wf.queue_shadow[q][bs + (uint32_t)__builtin_popcountll(ms & below)] = slot; r.c_shadow++; }
+    if (want_c) {
+        const uint32_t at = bc + (uint32_t)__builtin_popcountll(mc & below);
+        wf.queue_closest[q][at] = slot;
+        if (p.wf_sort) wf.key_closest[q][at] = wf_ray_key(p, r.ro, r.rd);
+        r.c_closest++;
+    }
+    if (want_s) {
+        const uint32_t at = bs + (uint32_t)__builtin_popcountll(ms & below);
+        wf.queue_shadow[q][at] = slot;
+        if (p.wf_sort) wf.key_shadow[q][at] = wf_ray_key(p, r.s_o, r.s_d);
+        r.c_shadow++;
+    }
 }
 
 template <bool PMJ>
@@ -101,7 +126,7 @@ __global__ __launch_bounds__(256) void k_wf_init(const PtParams p, const WfBuffe
     PathRegs r;
     path_regs_init<PMJ>(r, p, in_frame, pix, sx, sy);
     if (slot < p.n_items) wf_store(wf, slot, r);
-    wf_enqueue(wf, 0, slot, r);
+    wf_enqueue(p, wf, 0, slot, r);
     flush_counters(p, r, TraceCounters{0, 0, 0}, true);
 }
 
@@ -130,7 +155,7 @@ __global__ __launch_bounds__(256, TEX ? 1 : AKR_WF_SHADE_WAVES) void k_wf_shade(
         path_step<-1, TEX, PMJ>(p, r, hit, found, occluded, pix, sx, sy);
         wf_store(wf, slot, r);
     }
-    wf_enqueue(wf, q_out, slot, r);
+    wf_enqueue(p, wf, q_out, slot, r);
     flush_counters(p, r, TraceCounters{0, 0, 0}, true);
 }
 

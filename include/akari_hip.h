@@ -623,6 +623,8 @@ AKR_API const char *akr_version(void);
  *                                           decides (a cached kernel always, a compile for renders of >= 2^31 samples), 0 never, 1 always
  *   "specialise_waves" (AKR_SPECIALISE_WAVES=n)  waves per SIMD a per-scene kernel is compiled for: 0 the library's choice, else 2..4
  *   "max_fused_passes" (no environment hook)     most passes one launch of akr_pt_passes fuses: 0 adaptive, else 1..64
+ *   "wf_sort"      (AKR_WF_SORT=1)          wavefront schedule: the ray queues are sorted by (Morton code of the origin, octant of the
+ *                                           direction) before every trace launch (films unchanged; measurement in DESIGN.md)
  * Values out of an option's range fail with AKR_ERR_INVALID_ARGUMENT.
  * A session reads the options once, when it begins (akr_pt_begin / akr_gpt_begin / ...): a later akr_option_set does not change it.
  * "wavefront" = 1 on a scene without a BVH renders with the megakernel. Unknown names fail with AKR_ERR_INVALID_ARGUMENT. */
