@@ -307,13 +307,15 @@ class KernelInfo(C.Structure):
         ("min_waves", C.c_uint32),
         ("vgprs", C.c_uint32),
         ("scratch_bytes", C.c_uint32),
+        ("kernel_flags", C.c_uint32),
+        ("_pad", C.c_uint32),
         ("compile_ms", C.c_double),
         ("load_ms", C.c_double),
         ("status", C.c_char * 256),
     ]
 
     def as_dict(self):
-        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("struct_size", "status")}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("struct_size", "status", "_pad")}
         d["status"] = self.status.decode(errors="replace")
         return d
 

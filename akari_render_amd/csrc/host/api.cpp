@@ -1154,6 +1154,8 @@ AKR_API int32_t akr_pt_kernel_info(akr_pt_session* se, akr_kernel_info* info) {
         info->struct_size = size;
         info->specialised = se->spec_active ? 1u : 0u;
         info->n_shader_kinds = (uint32_t)se->scene->cs.shader_kinds.size();
+        info->kernel_flags = (se->scene->cs.bvh_nodes.empty() ? 0u : 1u) | (se->params.sampler != 0 ? 2u : 0u) | (se->params.stage_total != 0 ? 4u : 0u) |
+                             (se->params.defer_metal != 0 ? 8u : 0u);
         info->absent_mask = se->scene->cs.absent;
         if (se->spec) {
             info->cache_hit = se->spec->cache_hit ? 1u : 0u;
