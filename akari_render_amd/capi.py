@@ -41,7 +41,7 @@ EXPORTS = [
     "akr_host_stdrng_u64", "akr_host_chacha_block", "akr_host_pcg32_states", "akr_host_pcg_start", "akr_host_alias_table",
     "akr_probe_math", "akr_probe_bsdf", "akr_probe_intersect", "akr_probe_surface_interaction", "akr_probe_material_inputs",
     "akr_host_decode_png", "akr_host_decode_jpeg", "akr_host_decode_exr", "akr_host_decode_tiff", "akr_host_decode_dds", "akr_host_pmj02bn_tables",
-    "akr_pt_kernel_info", "akr_scene_spec_source", "akr_host_spec_compile", "akr_probe_material_folded_host", "akr_host_sobol_dim1", "akr_host_fastmod", "akr_film_reduce_planes", "akr_mcmc_render_shard", "akr_mcmc_combine_host", "akr_mcmc_combine",
+    "akr_pt_kernel_info", "akr_scene_spec_source", "akr_host_spec_compile", "akr_probe_material_folded_host", "akr_host_sobol_dim1", "akr_host_fastmod", "akr_host_spec_compile_text", "akr_film_reduce_planes", "akr_mcmc_render_shard", "akr_mcmc_combine_host", "akr_mcmc_combine",
 ]
 
 
@@ -114,6 +114,7 @@ def lib() -> C.CDLL:
     proto("akr_probe_material_folded_host", vp, u32, u32, fp, up, fp, fp)
     proto("akr_host_sobol_dim1", u32, up, up, up)
     proto("akr_host_fastmod", u32, up, up, up)
+    proto("akr_host_spec_compile_text", C.c_char_p, u32, u32, C.c_char_p, C.c_char_p)
     proto("akr_context_device_ordinal", vp, C.POINTER(C.c_int32))
     proto("akr_device_count", C.POINTER(C.c_int32))
     proto("akr_option_set", C.c_char_p, i32)

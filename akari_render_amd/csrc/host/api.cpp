@@ -1208,6 +1208,23 @@ AKR_API int32_t akr_host_spec_compile(akr_scene* scene, uint32_t flags, uint32_t
         *code_bytes = code.size();
     });
 }
+// the helper process's entry (akari-cli --spec-compile): generated text in, code object file out; always this process's hiprtc
+AKR_API int32_t akr_host_spec_compile_text(const char* spec_header, uint32_t flags, uint32_t min_waves, const char* arch, const char* out_path) {
+    if (!spec_header || !arch || !out_path) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_host_spec_compile_text: NULL argument");
+    return guarded([&] {
+        SpecRequest rq;
+        rq.bvh = flags & 1u; rq.pmj = flags & 2u; rq.stage = flags & 4u; rq.defer = flags & 8u;
+        rq.min_waves = (int)min_waves;
+        std::vector<char> code;
+        std::string log;
+        if (!spec_compile(spec_header, rq, arch, code, log, /*in_process=*/true)) throw RenderError("per-scene kernel did not compile: " + log.substr(0, 3000));
+        FILE* f = std::fopen(out_path, "wb");
+        if (!f) throw IoError(std::string("cannot open ") + out_path);
+        const size_t n = std::fwrite(code.data(), 1, code.size(), f);
+        std::fclose(f);
+        if (n != code.size()) throw IoError(std::string("short write to ") + out_path);
+    });
+}
 AKR_API int32_t akr_pt_end(akr_pt_session* se, akr_pt_stats* stats) {
     if (!se) return AKR_OK;
     int32_t rc = guarded([&] { read_stats(se, stats); });

@@ -24,7 +24,24 @@ static void usage() {
               "      --save-stats <NAME>  write NAME.json (RenderStats) and use NAME for intermediate files");
 }
 
+// akari-cli --spec-compile <header file> <out.co> <arch> <flags> <min waves>: the library's helper process for per-scene kernels
+// (host/specialise.cpp). The kernel is compiled HERE, in a process that holds nothing but this library and the ROCm installation's
+// hiprtc, so that the host application's own copies of the ROCm compiler libraries (PyTorch ships its own) cannot change the code.
+static int spec_compile_main(int argc, char** argv) {
+    if (argc != 7) { std::fputs("usage: akari-cli --spec-compile <header> <out.co> <arch> <flags> <min_waves>\n", stderr); return 2; }
+    std::ifstream hf(argv[2]);
+    if (!hf) { std::fprintf(stderr, "akari-cli: cannot open %s\n", argv[2]); return 2; }
+    std::stringstream ss;
+    ss << hf.rdbuf();
+    if (akr_host_spec_compile_text(ss.str().c_str(), (uint32_t)std::atoi(argv[5]), (uint32_t)std::atoi(argv[6]), argv[4], argv[3]) != AKR_OK) {
+        std::fprintf(stderr, "%s\n", akr_last_error());
+        return 1;
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "--spec-compile") return spec_compile_main(argc, argv);
     std::string scene, method, name;
     int device = 0, verbose = 0, save_intermediate = 0, save_stats = 0, indep = 0;
     unsigned w = 0, h = 0;

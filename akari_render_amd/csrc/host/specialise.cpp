@@ -2,8 +2,13 @@
 #include "specialise.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <spawn.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
+
+extern char** environ;
 
 #include <chrono>
 #include <cstdarg>
@@ -318,7 +323,65 @@ std::string spec_cache_dir() {
     return fmt("/tmp/akari_hip-%u", (unsigned)getuid());
 }
 
-bool spec_compile(const std::string& spec_header, const SpecRequest& rq, const std::string& arch, std::vector<char>& code, std::string& log) {
+namespace {
+// <directory of this library>/akari-cli, or "" (dladdr on a symbol of the library)
+std::string helper_path() {
+    Dl_info info;
+    if (!dladdr((const void*)&helper_path, &info) || !info.dli_fname) return std::string();
+    std::string p = info.dli_fname;
+    const size_t slash = p.rfind('/');
+    p = (slash == std::string::npos ? std::string(".") : p.substr(0, slash)) + "/akari-cli";
+    return access(p.c_str(), X_OK) == 0 ? p : std::string();
+}
+bool compile_in_helper(const std::string& helper, const std::string& spec_header, const SpecRequest& rq, const std::string& arch, std::vector<char>& code, std::string& log) {
+    char dir[] = "/tmp/akr_spec_XXXXXX";
+    if (!mkdtemp(dir)) return false;
+    const std::string hdr = std::string(dir) + "/akr_scene_spec.h", out = std::string(dir) + "/k.co", err = std::string(dir) + "/err.txt";
+    bool ok = false;
+    {
+        std::ofstream f(hdr, std::ios::binary);
+        f.write(spec_header.data(), (std::streamsize)spec_header.size());
+    }
+    const std::string flags = std::to_string((rq.bvh ? 1 : 0) | (rq.pmj ? 2 : 0) | (rq.stage ? 4 : 0) | (rq.defer ? 8 : 0)), waves = std::to_string(rq.min_waves);
+    // posix_spawn, not fork + setup code: the host process has threads (HIP runtime, the application's own)
+    std::vector<std::string> env_store;
+    for (char** e = environ; e && *e; e++)
+        if (std::strncmp(*e, "AKR_SPEC_INPROCESS=", 19) != 0) env_store.emplace_back(*e);
+    env_store.emplace_back("AKR_SPEC_INPROCESS=1");  // the helper compiles in its own process, it does not spawn another
+    std::vector<char*> envp;
+    for (std::string& e : env_store) envp.push_back(&e[0]);
+    envp.push_back(nullptr);
+    const char* argv[] = {helper.c_str(), "--spec-compile", hdr.c_str(), out.c_str(), arch.c_str(), flags.c_str(), waves.c_str(), nullptr};
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    posix_spawn_file_actions_addopen(&fa, 2, err.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
+    pid_t pid = -1;
+    if (posix_spawn(&pid, helper.c_str(), &fa, nullptr, const_cast<char* const*>(argv), envp.data()) != 0) pid = -1;
+    posix_spawn_file_actions_destroy(&fa);
+    if (pid > 0) {
+        int status = 0;
+        if (waitpid(pid, &status, 0) == pid && WIFEXITED(status) && WEXITSTATUS(status) == 0) {
+            std::ifstream f(out, std::ios::binary);
+            code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+            ok = !code.empty();
+        } else {
+            std::ifstream f(err);
+            std::stringstream ss;
+            ss << f.rdbuf();
+            log = "akari-cli --spec-compile failed: " + ss.str().substr(0, 1500);
+        }
+    }
+    (void)std::remove(hdr.c_str()); (void)std::remove(out.c_str()); (void)std::remove(err.c_str()); (void)rmdir(dir);
+    return ok;
+}
+}  // namespace
+
+bool spec_compile(const std::string& spec_header, const SpecRequest& rq, const std::string& arch, std::vector<char>& code, std::string& log, bool in_process) {
+    if (!in_process && !std::getenv("AKR_SPEC_INPROCESS")) {
+        const std::string helper = helper_path();
+        if (!helper.empty() && compile_in_helper(helper, spec_header, rq, arch, code, log)) return true;
+        code.clear();  // no helper, or it failed: this process's hiprtc
+    }
     Rtc& r = rtc();
     if (!r.ok) {
         log = r.why;

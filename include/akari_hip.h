@@ -428,6 +428,9 @@ AKR_API int32_t akr_scene_spec_source(akr_scene *scene, char *dst, uint64_t capa
 /* Compiles the scene's per-scene kernel for `arch` ("gfx950" when NULL) without a device (hiprtc cross-compiles): flags bit 0 BVH,
  * 1 index-based sampler, 2 staged tables, 3 deferral. For tests and tools; sessions compile through the cache. */
 AKR_API int32_t akr_host_spec_compile(akr_scene *scene, uint32_t flags, uint32_t min_waves, const char *arch, uint64_t *code_bytes, char *log, uint32_t log_len);
+/* The same from the generated text, written to a file: what the library's helper process runs (akari-cli --spec-compile; sessions
+ * compile their kernel there so that a host application's own copies of the ROCm compiler libraries cannot change the code). */
+AKR_API int32_t akr_host_spec_compile_text(const char *spec_header, uint32_t flags, uint32_t min_waves, const char *arch, const char *out_path);
 /* The interpreter's result for `material` at n uv points on the host (default colour pipeline): the folded record (64 words each),
  * optionally the alpha of the base-colour node and emission_color * emission_strength -- the values per-scene code must reproduce. */
 AKR_API int32_t akr_probe_material_folded_host(akr_scene *scene, uint32_t material, uint32_t n, const float *uv, uint32_t *out64, float *alpha, float *emission3);

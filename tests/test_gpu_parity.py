@@ -252,6 +252,22 @@ def test_wavefront_schedule_matches_oracle(ctx, cbox_path, root, wavefront_mode,
     assert np.array_equal(gs, os_)
 
 
+@pytest.mark.parametrize("case", ["cbox_full", "hall"])
+def test_wavefront_with_sorted_ray_queues_changes_no_bit(ctx, cbox_path, wavefront_mode, case):
+    """option wf_sort (wf_sort.hip): the trace kernel reads its ray queues sorted by origin cell + direction octant. A ray's result is
+    written to its own slot whatever the order it was traced in: film, sampler states and counters are the oracle's."""
+    if case == "cbox_full":
+        sd, cfg = scene_json.load_scene(cbox_path, 96, 72), make_config(spp=11, spp_per_pass=4, max_depth=8)
+    else:
+        from akari_render_amd import procedural
+        sd, cfg = procedural.sponza_like(20_000, seed=1234, width=96, height=54), make_config(spp=4, spp_per_pass=4, max_depth=5)
+    with capi.options(wf_sort=1):
+        g, o, gst, ost, gs, os_ = render_both(ctx, sd, cfg, want_states=True)
+    assert gst["n_node_visits"] > 0
+    assert_parity(g, o, sd.camera.width, sd.camera.height, gst, ost)
+    assert np.array_equal(gs, os_)
+
+
 def test_wavefront_equals_megakernel_sharded(ctx, cbox_path, wavefront_mode):
     sd = scene_json.load_scene(cbox_path, 120, 80)
     scene = capi.Scene(ctx, sd)
