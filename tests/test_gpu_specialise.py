@@ -195,3 +195,19 @@ def test_random_textured_scenes(ctx, root, first):
         if done >= 12:
             break
     assert done >= 8
+
+
+def test_other_integrators_keep_the_interpreter(ctx, root):
+    """aov, gpt and mcmc_opt sessions share akr_pt_begin's plumbing but launch their own kernels, which interpret shader graphs: with
+    per-scene kernels forced on (and one for this very scene cached by the pt render below) they must still get the interpreter's
+    parameter block -- value slots in LDS and all. (A cached kernel once reached a later mcmc_opt render of the same scene.)"""
+    from tests import test_gpu_aov, test_mcmc
+
+    sd = with_table(textured_room(40, 32, alpha_cutout=True), root)
+    render_specialised(ctx, sd, make_config(spp=4, spp_per_pass=4, max_depth=5))
+    with capi.options(specialise=1):
+        cfg = abi.AovConfig.default()
+        cfg.spp, cfg.aov = 3, abi.AOV_ROUGHNESS
+        test_gpu_aov.both(ctx, sd, cfg)
+        test_mcmc.both(ctx, sd, test_mcmc.mcmc_config(n_chains=64, spp=6))
+    test_mcmc.both(ctx, sd, test_mcmc.mcmc_config(n_chains=64, spp=6))  # automatic mode: the cached kernel is not for them either
