@@ -20,7 +20,8 @@ ERR_INVALID_ARGUMENT, ERR_HIP, ERR_NO_DEVICE, ERR_IO, ERR_PARSE, ERR_UNSUPPORTED
 
 (ARRAY_WOOP, ARRAY_TRI_GID, ARRAY_SHADE, ARRAY_INSTANCES, ARRAY_MATERIALS, ARRAY_BVH_NODES, ARRAY_LIGHT_ENTRIES,
  ARRAY_LIGHT_PDF, ARRAY_AREA_ENTRIES, ARRAY_AREA_PDF, ARRAY_INST_TRI_OFFSET, ARRAY_R2C, ARRAY_C2W,
- ARRAY_TEX_NODES, ARRAY_TEX_IMAGES, ARRAY_TEX_TEXELS, ARRAY_MAT_INPUTS) = range(17)
+ ARRAY_TEX_NODES, ARRAY_TEX_IMAGES, ARRAY_TEX_TEXELS, ARRAY_MAT_INPUTS,
+ ARRAY_INST_LEAVES, ARRAY_MESH_TRIS, ARRAY_MESH_POS, ARRAY_MESH_META, ARRAY_MESH_NORMALS) = range(22)
 
 # every symbol include/akari_hip.h declares (checked by tests/test_abi.py against the header text)
 EXPORTS = [

@@ -1,0 +1,235 @@
+// dinst_trav.h -- two-level traversal and hit reconstruction for a scene kept as meshes + instances (host/scene_inst.cpp).
+//
+// The reference's accel is two-level (crates/akari_render/src/mesh.rs:259-348: one BLAS per mesh, instances pushed with their
+// transform) and its hit reconstruction works from object-space buffers + the instance transform (mesh.rs:487-654). Here the two
+// box levels only cull; a triangle is accepted, and a hit shaded, by the FLATTENED arithmetic computed on the fly (dinst.h): the
+// candidate's object-space vertices through the instance transform in f32, Woop rows in f64, the coplanar-neighbour rule, then
+// the same tri_test on the WORLD ray. Films are bit-identical to the flattened scene's (and the oracle's).
+//
+// State machine = disect.h's trav_step with an instance level: a lane is in the TLAS (inst == kInvalid: world-space ray, "triangles"
+// of a leaf are instances) or inside one instance's BLAS (the ray taken through the instance's inverse, unnormalised so that t is the
+// world parameter). Entering an instance pushes the TLAS position (pending group, triangle base, pending leaf bits as a sentinel
+// whose top byte is 0 -- a BLAS never pushes such a word); popping the sentinel leaves the instance.
+#pragma once
+#include "dinst.h"
+#include "disect.h"
+
+namespace akr {
+
+struct TravI : Trav {
+    vec3 wo, wd;                 // the world-space ray (s.o / s.d are the current level's)
+    uint32_t inst, node_off, tri_off, gid_base;  // current instance (kInvalid: TLAS), its BLAS's node offset, mesh triangle base, first gid
+};
+AKR_D void trav_set_ray(Trav& s, vec3 o, vec3 d) {
+    s.o = o; s.d = d;
+    s.inv = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+    s.noi = mk3(-o.x * s.inv.x, -o.y * s.inv.y, -o.z * s.inv.z);
+    const uint32_t oi = (s.inv.x >= 0.0f ? 1u : 0u) | (s.inv.y >= 0.0f ? 2u : 0u) | (s.inv.z >= 0.0f ? 4u : 0u);
+    s.octinv4 = oi * 0x01010101u;
+}
+AKR_D void trav_begin_inst(TravI& s, vec3 o, vec3 d, float tmin, float tmax, uint32_t ex0, uint32_t ex1) {
+    trav_begin(s, o, d, tmin, tmax, ex0, ex1);
+    s.wo = o; s.wd = d;
+    s.inst = kInvalid; s.node_off = 0; s.tri_off = 0; s.gid_base = 0;
+}
+
+// material of (instance record m, mesh triangle): mats[slots[prim]] (mesh.rs:508-521)
+AKR_D uint32_t inst_material(const DScene& sc, const float4* m, uint32_t meta) { return sc.in2.inst_mats[f2u(m[2].w) + (meta & 0x3fffffffu)]; }
+
+// scene.rs:49-86 for a candidate of an instanced scene: alpha of the base colour (folded, or the graph at the candidate's uv)
+template <bool TEX>
+AKR_D bool alpha_test_inst(const DScene& sc, const float4* m, uint32_t inst, uint32_t prim, uint32_t mesh_base, float4 q0, float4 q1, float4 q2, float4 q3, float u, float v) {
+    const uint32_t material = inst_material(sc, m, sc.in2.mesh_meta[mesh_base + prim]);
+    const DMaterial& mt = sc.materials[material];
+    float alpha = (mt.kind == MAT_PRINCIPLED || mt.kind == MAT_DIFFUSE) ? mt.base_alpha : 1.0f;
+    if (TEX) {
+        if (mt.flags & MF_ALPHA_TEXTURED) {
+            const float w = 1.0f - u - v;
+            // uv0 = (q0.w, q1.w), uv1 = (q2.w, q3.x), uv2 = (q3.y, q3.z): the interpolation of textured_alpha (disect.h)
+            const vec2 uv = mk2((q0.w * w + q2.w * u) + q3.y * v, (q1.w * w + q3.x * u) + q3.z * v);
+            alpha = material_alpha_at(sc.tex, mt, material, uv);
+        }
+    }
+    if (alpha >= 1.0f) return true;
+    float h = (float)xxhash32_4(inst, prim, f2u(u), f2u(v)) * 2.3283064365386963e-10f;
+    return alpha > h;
+}
+
+template <int MODE, bool TEX>
+AKR_D void trav_step_inst(const DScene& sc, TravI& s, uint32_t* __restrict__ stack, TraceCounters& cnt, bool any_rt = false) {
+    const bool any_hit = MODE == 2 ? any_rt : (MODE == 1);
+    const bool in_blas = s.inst != kInvalid;
+    const bool do_leaf = s.T != 0;
+    const uint4* p;
+    if (do_leaf) {
+        const uint32_t b = (uint32_t)__builtin_ctz(s.T);
+        s.T &= s.T - 1u;
+        p = in_blas ? (const uint4*)sc.in2.mesh_tris + (size_t)(s.tri_off + s.tbase + b) * 4 : sc.in2.tlas_leaves + (size_t)(s.tbase + b) * 4;
+    } else {
+        if ((s.G >> 24) == 0) {  // the caller guarantees sp > 0 here
+            s.sp--;
+            const uint32_t e = stack[s.sp * 256u];
+            if (in_blas && (e >> 24) == 0) {
+                // the sentinel: this instance is done. Back to the TLAS where it stood: pending leaf bits, their base, the pending group.
+                s.T = e;
+                s.sp--;
+                s.tbase = stack[s.sp * 256u];
+                s.sp--;
+                s.G = stack[s.sp * 256u];
+                s.inst = kInvalid; s.node_off = 0; s.tri_off = 0;
+                trav_set_ray(s, s.wo, s.wd);
+                s.active = (s.T != 0) | ((s.G >> 24) != 0) | (s.sp != 0);
+                return;
+            }
+            s.G = e;
+        }
+        const uint32_t j = 31u - (uint32_t)__builtin_clz(s.G);  // nearest pending sibling
+        s.G &= ~(1u << j);
+        if ((s.G >> 24) != 0) {  // the others wait as one entry
+            if (s.sp < sc.bvh_stack_depth) {
+                stack[s.sp * 256u] = s.G;
+                s.sp++;
+            } else {
+                cnt.overflow = 1;
+            }
+        }
+        const uint32_t slot = (j - 24u) ^ (s.octinv4 & 7u);
+        const uint32_t idx = s.node_off + (s.G & 0xffffffu) + slot;
+        p = sc.bvh_nodes + (size_t)idx * (kBvhNodeWords / 4);
+    }
+    uint4 w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3];
+    asm volatile("" : "+v"(w0.x), "+v"(w0.y), "+v"(w0.z), "+v"(w0.w), "+v"(w1.x), "+v"(w1.y), "+v"(w1.z), "+v"(w1.w), "+v"(w2.x), "+v"(w2.y),
+                      "+v"(w2.z), "+v"(w2.w), "+v"(w3.x), "+v"(w3.y), "+v"(w3.z), "+v"(w3.w));
+    if (do_leaf && !in_blas) {
+        // ---- a TLAS leaf entry = an instance: remember where the TLAS traversal stands, take the ray into object space, start at the BLAS root
+        cnt.nodes++;
+        if (s.sp + 3 <= sc.bvh_stack_depth) {
+            stack[s.sp * 256u] = s.G; s.sp++;
+            stack[s.sp * 256u] = s.tbase; s.sp++;
+            stack[s.sp * 256u] = s.T & 0x00ffffffu; s.sp++;
+        } else {
+            cnt.overflow = 1;
+        }
+        s.inst = w3.z; s.node_off = w3.x; s.tri_off = w3.y; s.gid_base = w3.w;
+        const vec3 r0 = mk3(u2f(w0.x), u2f(w0.y), u2f(w0.z)), r1 = mk3(u2f(w1.x), u2f(w1.y), u2f(w1.z)), r2 = mk3(u2f(w2.x), u2f(w2.y), u2f(w2.z));
+        const vec3 oo = mk3(dot(r0, s.wo) + u2f(w0.w), dot(r1, s.wo) + u2f(w1.w), dot(r2, s.wo) + u2f(w2.w));
+        const vec3 od = mk3(dot(r0, s.wd), dot(r1, s.wd), dot(r2, s.wd));
+        trav_set_ray(s, oo, od);
+        s.G = 1u << (24u + (s.octinv4 & 7u));  // the group {BLAS root}: base 0 (relative), slot 0
+        s.T = 0; s.tbase = 0;
+    } else if (do_leaf) {
+        // ---- a candidate triangle of the current instance: its flattened record, computed here (dinst.h), then the flattened test
+        cnt.tris++;
+        const float4 q0 = make_float4(u2f(w0.x), u2f(w0.y), u2f(w0.z), u2f(w0.w)), q1 = make_float4(u2f(w1.x), u2f(w1.y), u2f(w1.z), u2f(w1.w));
+        const float4 q2 = make_float4(u2f(w2.x), u2f(w2.y), u2f(w2.z), u2f(w2.w)), q3 = make_float4(u2f(w3.x), u2f(w3.y), u2f(w3.z), u2f(w3.w));
+        const uint32_t prim = w3.w, gid = s.gid_base + prim;
+        if ((gid != s.ex0) & (gid != s.ex1)) {
+            const float4* m = sc.inst + (size_t)s.inst * INST_ROWS;
+            const vec3 c0 = xyz(m[0]), c1 = xyz(m[1]), c2 = xyz(m[2]), tr = xyz(m[3]);
+            const vec3 A = xf_point(c0, c1, c2, tr, xyz(q0)), B = xf_point(c0, c1, c2, tr, xyz(q1)), C = xf_point(c0, c1, c2, tr, xyz(q2));
+            float wr[12];
+            woop_precompute(A, B, C, wr);
+            if (prim & 1u) {  // the coplanar-neighbour rule: the even triangle's plane row, if this one lies in it
+                const float4* nb = sc.in2.mesh_tris + (size_t)(s.tri_off + sc.in2.mesh_pos[s.tri_off + prim - 1u]) * 4;
+                const vec3 na = xf_point(c0, c1, c2, tr, xyz(nb[0])), nbv = xf_point(c0, c1, c2, tr, xyz(nb[1])), nc = xf_point(c0, c1, c2, tr, xyz(nb[2]));
+                float ra[4];
+                woop_plane_row(na, nbv, nc, ra);
+                const vec3 vb[3] = {A, B, C};
+                share_plane_row(ra, wr + 8, vb);
+            }
+            float t, u, v;
+            bool h = tri_test(s.wo, s.wd, make_float4(wr[0], wr[1], wr[2], wr[3]), make_float4(wr[4], wr[5], wr[6], wr[7]), make_float4(wr[8], wr[9], wr[10], wr[11]), s.tmin,
+                              s.tmax, t, u, v);
+            if (h && sc.has_alpha) h = alpha_test_inst<TEX>(sc, m, s.inst, prim, s.tri_off, q0, q1, q2, q3, u, v);
+            if (h) {
+                if (any_hit) {
+                    s.best = gid;
+                    s.T = 0; s.G = 0; s.sp = 0;  // any hit: done
+                } else {
+                    const bool better = (s.best == kInvalid) | (t < s.best_t) | ((t == s.best_t) & (gid < s.best));
+                    if (better) { s.best_t = t; s.best_u = u; s.best_v = v; s.best = gid; }
+                }
+            }
+        }
+    } else {
+        // ---- a node of either level: disect.h trav_step's box test on the current level's ray
+        cnt.nodes++;
+        const float limit = s.best_t;
+        const float bx = u2f((w0.w & 0xffu) << 23) * s.inv.x, by = u2f(((w0.w >> 8) & 0xffu) << 23) * s.inv.y, bz = u2f(((w0.w >> 16) & 0xffu) << 23) * s.inv.z;
+        const float ax = __builtin_fmaf(u2f(w0.x), s.inv.x, s.noi.x), ay = __builtin_fmaf(u2f(w0.y), s.inv.y, s.noi.y), az = __builtin_fmaf(u2f(w0.z), s.inv.z, s.noi.z);
+        const bool nx = s.inv.x < 0.0f, ny = s.inv.y < 0.0f, nz = s.inv.z < 0.0f;
+        const uint32_t xb = nx ? ((w3.y >> 16) | (w3.y << 16)) : w3.y, yb = ny ? ((w3.z >> 16) | (w3.z << 16)) : w3.z, zb = nz ? ((w3.w >> 16) | (w3.w << 16)) : w3.w;
+        const uint32_t qnx[2] = {nx ? w2.z : w1.w, xb}, qfx[2] = {nx ? w1.w : w2.z, xb >> 16};
+        const uint32_t qny[2] = {ny ? w2.w : w2.x, yb}, qfy[2] = {ny ? w2.x : w2.w, yb >> 16};
+        const uint32_t qnz[2] = {nz ? w3.x : w2.y, zb}, qfz[2] = {nz ? w2.y : w3.x, zb >> 16};
+        uint32_t hitmask = 0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t meta4 = h ? (w1.x >> 16) : w1.y;
+            const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+            const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xffu;
+            const uint32_t bit_index4 = (meta4 ^ (s.octinv4 & inner_mask4)) & 0x1f1f1f1fu;
+            const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
+#pragma unroll
+            for (int i = 0; i < (h ? 2 : 4); i++) {
+                const float tnx = __builtin_fmaf((float)byte_of(qnx[h], i), bx, ax), tfx = __builtin_fmaf((float)byte_of(qfx[h], i), bx, ax);
+                const float tny = __builtin_fmaf((float)byte_of(qny[h], i), by, ay), tfy = __builtin_fmaf((float)byte_of(qfy[h], i), by, ay);
+                const float tnz = __builtin_fmaf((float)byte_of(qnz[h], i), bz, az), tfz = __builtin_fmaf((float)byte_of(qfz[h], i), bz, az);
+                const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, s.tmin));
+                const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, limit));
+                if (tn <= tf) hitmask |= byte_of(child_bits4, i) << byte_of(bit_index4, i);
+            }
+        }
+        s.G = ((w0.w >> 24) | ((w1.x & 0xffffu) << 8)) | (hitmask & 0xff000000u);
+        s.T = hitmask & 0x00ffffffu;
+        s.tbase = w1.z;
+    }
+    s.active = (s.T != 0) | ((s.G >> 24) != 0) | (s.sp != 0);
+}
+
+template <bool ANY_HIT, bool TEX = false>
+AKR_D bool trace_inst(const DScene& sc, vec3 o, vec3 d, float tmin, float tmax, uint32_t ex0, uint32_t ex1, Hit& hit, uint32_t* __restrict__ stack, TraceCounters& cnt) {
+    TravI s;
+    trav_begin_inst(s, o, d, tmin, tmax, ex0, ex1);
+    while (s.active) trav_step_inst<ANY_HIT ? 1 : 0, TEX>(sc, s, stack, cnt);
+    hit.t = s.best_t; hit.u = s.best_u; hit.v = s.best_v; hit.gid = s.best;
+    return s.best != kInvalid;
+}
+
+// the instance a global triangle id belongs to: the last i with inst_tri_offset[i] <= gid
+AKR_D uint32_t inst_of_gid(const DScene& sc, uint32_t gid) {
+    uint32_t lo = 0, hi = sc.in2.n_instances;  // inst_tri_offset has n + 1 entries
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (sc.inst_tri_offset[mid] <= gid) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// MeshAggregate::surface_interaction (mesh.rs:487-654) for a scene kept as meshes + instances: the shade record the flattening
+// compiler would have stored for this instance-triangle, rebuilt from the mesh triangle and the instance transform (dinst.h).
+AKR_D SurfacePoint surface_interaction_inst(const DScene& sc, uint32_t gid, vec2 bary) {
+    const uint32_t inst = inst_of_gid(sc, gid);
+    const float4* m = sc.inst + (size_t)inst * INST_ROWS;
+    const uint32_t mesh_base = f2u(m[1].w), prim = gid - f2u(m[5].w);
+    const float4* r = sc.in2.mesh_tris + (size_t)(mesh_base + sc.in2.mesh_pos[mesh_base + prim]) * 4;
+    const float4 a = r[0], b = r[1], c = r[2], d = r[3];
+    const uint32_t meta = sc.in2.mesh_meta[mesh_base + prim];
+    const vec2 uv0 = mk2(a.w, b.w), uv1 = mk2(c.w, d.x), uv2 = mk2(d.y, d.z);
+    const TriWorld tw = tri_world(inst_xf_from_rows(m), xyz(a), xyz(b), xyz(c), uv0, uv1, uv2);
+    // the eight rows of the flattened shade record (dscene.h)
+    const float4 q0 = make_float4(a.x, a.y, a.z, uv0.x), q1 = make_float4(b.x, b.y, b.z, uv0.y), q2 = make_float4(c.x, c.y, c.z, uv1.x);
+    const float4 q3 = make_float4(tw.ng.x, tw.ng.y, tw.ng.z, uv1.y), q4 = make_float4(tw.frame.t.x, tw.frame.t.y, tw.frame.t.z, uv2.x);
+    const float4 q5 = make_float4(tw.frame.s.x, tw.frame.s.y, tw.frame.s.z, uv2.y);
+    const float4 q6 = make_float4(tw.area, u2f(inst_material(sc, m, meta)), u2f(inst), m[3].w);
+    const float4 q7 = make_float4(tw.tt.x, tw.tt.y, tw.tt.z, u2f(meta >> 30));
+    const bool has_normals = sc.in2.mesh_normals != nullptr;
+    return surface_interaction_rows(m, q0, q1, q2, q3, q4, q5, q6, q7, has_normals, has_normals ? sc.in2.mesh_normals + (size_t)(mesh_base + prim) * 6 : nullptr, bary);
+}
+template <bool INST>
+AKR_D SurfacePoint surface_interaction_any(const DScene& sc, uint32_t gid, vec2 bary) {
+    if (INST) return surface_interaction_inst(sc, gid, bary);
+    return surface_interaction(sc, gid, bary);
+}
+
+}  // namespace akr

@@ -3,7 +3,7 @@
 // Everything here follows crates/akari_integrator/src/pt.rs:95-323,329-900 (shift_mapping = None), camera/mod.rs,
 // film.rs, sampler/mod.rs, light/{mod,area}.rs of the reference; file:line cited per function.
 #pragma once
-#include "disect.h"
+#include "dinst_trav.h"
 #include "drng.h"
 #include "../kernels.h"
 
@@ -248,7 +248,7 @@ struct LightSample {
     bool valid;
 };
 // LightAggregate::sample_direct (light/mod.rs:115-132) + AreaLight::sample_direct (light/area.rs:51-107)
-template <bool TEX>
+template <bool TEX, bool INST = false>
 AKR_D LightSample sample_direct(const DScene& sc, vec3 pn_p, vec3 pn_n, float u_select, vec2 u_sample) {
     LightSample s;
     s.li = mk3(0, 0, 0);
@@ -265,7 +265,7 @@ AKR_D LightSample sample_direct(const DScene& sc, vec3 pn_p, vec3 pn_n, float u_
     uint32_t prim = alias_sample_and_remap(sc.area_alias + L.tri_offset, L.n_tris, u_sel2, pdf_prim, u_unused);
     uint32_t gid = L.first_gid + prim;
     vec2 bary = uniform_sample_triangle(u_sample);
-    SurfacePoint y = surface_interaction(sc, gid, bary);
+    SurfacePoint y = surface_interaction_any<INST>(sc, gid, bary);
     vec3 wi = y.p - pn_p;
     if (length2(wi) == 0.0f) return s;
     float dist2 = length2(wi);
@@ -447,7 +447,7 @@ AKR_D void shifted_pixel(const PtParams& p, uint32_t px, uint32_t py, uint32_t& 
 // FD: 1 / 0 = force_diffuse known at compile time (the reference's JIT also specialises the kernel on it: the branch
 // at pt.rs:268 is taken while tracing the kernel, so a force_diffuse kernel contains no Principled code); -1 = read
 // p.force_diffuse at run time.
-template <int FD = -1, bool TEX = false, bool PMJ = false, int PARK = 0, uint32_t ABSENT = 0>  // PARK: 0 no, 1 yes, 2 yes without the DEFER fields; ABSENT: dbsdf.h AB_*
+template <int FD = -1, bool TEX = false, bool PMJ = false, int PARK = 0, uint32_t ABSENT = 0, bool INST = false>  // PARK: 0 no, 1 yes, 2 yes without the DEFER fields; ABSENT: dbsdf.h AB_*; INST: meshes + instances (dinst_trav.h)
 AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found, bool occluded, uint32_t pix_in, uint32_t sx_in, uint32_t sy_in,
                      uint32_t* park = nullptr) {
     const bool force_diffuse = FD < 0 ? (p.force_diffuse != 0) : (FD != 0);
@@ -500,7 +500,7 @@ AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found,
         if (!found) {
             terminated = true;  // pt.rs:381-396 (hit_envmap adds zero)
         } else {
-            SurfacePoint si = surface_interaction(sc, hit.gid, mk2(hit.u, hit.v));
+            SurfacePoint si = surface_interaction_any<INST>(sc, hit.gid, mk2(hit.u, hit.v));
             vec3 wo = -r.rd;
             // Everything that reads the material, as a function of where the record lives: the folded record in HBM, or --
             // TEX kernels, texture-fed inputs -- a per-hit record (graph evaluated at si.uv, folded here). Two instantiations
@@ -529,7 +529,7 @@ AKR_D void path_step(const PtParams& p, PathRegs& r, const Hit& hit, bool found,
                 LightSample dl;
                 dl.valid = false;
                 if (p.use_nee && (!p.indirect_only || r.depth > 1))
-                    dl = sample_direct<TEX>(sc, si.p, si.ng, u_direct.x, mk2(u_direct.y, u_direct.z));
+                    dl = sample_direct<TEX, INST>(sc, si.p, si.ng, u_direct.x, mk2(u_direct.y, u_direct.z));
                 vec3 u_bsdf = next_3d<PMJ>(p, r.smp);
                 // sample_surface_and_shade_direct, pt.rs:297-323
                 ShadePoint sp;

@@ -39,6 +39,18 @@ struct LightRec {  // one light = one emissive instance: where its triangles sit
     uint32_t tri_offset, n_tris, first_gid, inst;
 };
 
+// A scene kept as meshes + instances (host/scene_inst.cpp; two-level traversal: disect.h trav_step_inst). When `on`, the per
+// instance-triangle arrays of DScene (woop, shade, normals, tri_gid) are null and bvh_nodes holds the TLAS followed by the BLASes.
+struct DInst {
+    const uint4* __restrict__ tlas_leaves;     // 64 B per instance in TLAS order: world->object rows | BLAS node offset, mesh triangle base, instance, first gid
+    const float4* __restrict__ mesh_tris;      // 64 B per mesh triangle in BLAS order: v0 | uv0.x, v1 | uv0.y, v2 | uv1.x, uv1.y uv2.x uv2.y | prim
+    const uint32_t* __restrict__ mesh_pos;     // mesh order -> position in mesh_tris (relative to the mesh's base)
+    const uint32_t* __restrict__ mesh_meta;    // mesh order: material slot | TRI_HAS_* << 30
+    const float4* __restrict__ mesh_normals;   // 6 x float4 per mesh triangle, mesh order, or nullptr
+    const uint32_t* __restrict__ inst_mats;    // the instances' material lists
+    uint32_t on, n_instances;
+};
+
 struct DScene {
     const float4* __restrict__ woop;        // 3 float4 per triangle (exhaustive path) or 4 (BVH path: + global id)
     const uint32_t* __restrict__ tri_gid;   // traversal order -> global id (host-side tests; the BVH path reads the id from the record)
@@ -64,6 +76,7 @@ struct DScene {
     uint32_t bvh_tile_nodes;                        // nodes 0 .. n-1 (the top of the tree, laid out breadth-first) a launch keeps in LDS; 0 = none
     uint64_t plane_share_mask;                      // exhaustive path: bit k = record k carries the plane row of record k-1
     TexScene tex;                                   // textures + shader-graph node lists (all nullptr without textures)
+    DInst in2;                                      // meshes + instances kept as they are (in2.on; else all zero)
 };
 
 struct SurfacePoint {  // interaction.rs:15-48, minus what this path never reads
@@ -85,16 +98,15 @@ AKR_HD vec3 interp3(vec2 b, vec3 a0, vec3 a1, vec3 a2) {
 AKR_HD vec3 xf_point(vec3 c0, vec3 c1, vec3 c2, vec3 t, vec3 p) { return ((c0 * p.x + c1 * p.y) + c2 * p.z) + t; }
 AKR_HD vec3 xf_vector(vec3 c0, vec3 c1, vec3 c2, vec3 v) { return (c0 * v.x + c1 * v.y) + c2 * v.z; }
 
-// MeshAggregate::surface_interaction (mesh.rs:487-654) from the folded records.
-AKR_D SurfacePoint surface_interaction(const DScene& sc, uint32_t gid, vec2 bary) {
-    const float4* r = sc.shade + (size_t)gid * SHADE_ROWS;
-    float4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3], q4 = r[4], q5 = r[5], q6 = r[6];
+// MeshAggregate::surface_interaction (mesh.rs:487-654) from the eight rows of a shade record (q7: dpdu | flags), the instance's
+// record `m` and the triangle's corner normals / tangents `nr` (read only when the flags say so).
+AKR_D SurfacePoint surface_interaction_rows(const float4* m, float4 q0, float4 q1, float4 q2, float4 q3, float4 q4, float4 q5, float4 q6, float4 q7, bool has_normals,
+                                            const float4* nr, vec2 bary) {
     SurfacePoint s;
     s.prim_area = q6.x;
     s.material = f2u(q6.y);
     s.inst = f2u(q6.z);
     s.light = (int32_t)f2u(q6.w);
-    const float4* m = sc.inst + (size_t)s.inst * INST_ROWS;
     float4 c0 = m[0], c1 = m[1], c2 = m[2], t = m[3];
     vec3 p_local = interp3(bary, xyz(q0), xyz(q1), xyz(q2));
     s.p = xf_point(xyz(c0), xyz(c1), xyz(c2), xyz(t), p_local);
@@ -104,11 +116,9 @@ AKR_D SurfacePoint surface_interaction(const DScene& sc, uint32_t gid, vec2 bary
         float w = 1.0f - bary.x - bary.y;
         s.uv = mk2((q0.w * w + q2.w * bary.x) + q4.w * bary.y, (q1.w * w + q3.w * bary.x) + q5.w * bary.y);
     }
-    if (sc.normals != nullptr) {
-        float4 q7 = r[7];
+    if (has_normals) {
         const uint32_t tf = f2u(q7.w);
         if (tf & (TRI_HAS_NORMALS | TRI_HAS_TANGENTS)) {  // mesh.rs:557-571, 591-602, 619-640
-            const float4* nr = sc.normals + (size_t)gid * 6;
             vec3 ns = s.ng;
             if (tf & TRI_HAS_NORMALS) {
                 vec3 ns_local = interp3(bary, xyz(nr[0]), xyz(nr[1]), xyz(nr[2]));
@@ -125,6 +135,16 @@ AKR_D SurfacePoint surface_interaction(const DScene& sc, uint32_t gid, vec2 bary
         }
     }
     return s;
+}
+// ... from the folded records of a flattened scene
+AKR_D SurfacePoint surface_interaction(const DScene& sc, uint32_t gid, vec2 bary) {
+    const float4* r = sc.shade + (size_t)gid * SHADE_ROWS;
+    float4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3], q4 = r[4], q5 = r[5], q6 = r[6];
+    const float4* m = sc.inst + (size_t)f2u(q6.z) * INST_ROWS;
+    const bool has_normals = sc.normals != nullptr;
+    float4 q7 = make_float4(0, 0, 0, 0);
+    if (has_normals) q7 = r[7];
+    return surface_interaction_rows(m, q0, q1, q2, q3, q4, q5, q6, q7, has_normals, has_normals ? sc.normals + (size_t)gid * 6 : nullptr, bary);
 }
 
 }  // namespace akr

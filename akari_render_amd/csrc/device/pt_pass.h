@@ -39,7 +39,8 @@ namespace akr {
 #endif
 // ABSENT: lobes the scene cannot have (dbsdf.h AB_*). The precompiled kernels know 0 and AB_SIMPLE (PtParams.simple_scene: scenes without
 // textures); a per-scene kernel gets the mask of its scene.
-template <bool BVH, bool FD, bool TEX, bool PMJ, bool STAGE, bool DEFER, uint32_t ABSENT = 0>
+// INST: the scene is kept as meshes + instances (two-level traversal, dinst_trav.h); BVH kernels without STAGE / DEFER only.
+template <bool BVH, bool FD, bool TEX, bool PMJ, bool STAGE, bool DEFER, uint32_t ABSENT = 0, bool INST = false>
 AKR_D void pt_pass_body(const PtParams& p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: kBvhStackDepth x 256 words; else: staged tables
     TraceCtx tc;
@@ -50,8 +51,8 @@ AKR_D void pt_pass_body(const PtParams& p) {
     if (STAGE) stage_scene_tables<BVH, TEX, !BVH && !FD && TEX>(p, lds_stack, staged);
     const PtParams& q = STAGE ? staged : p;
     const DScene& sc = q.sc;
-    constexpr bool TILE = BVH && !TEX && AKR_BVH_TILE != 0;
-    constexpr uint32_t STRAG = BVH ? (TEX ? AKR_PT_STRAGGLERS_TEX : AKR_PT_STRAGGLERS) : 0;
+    constexpr bool TILE = BVH && !TEX && !INST && AKR_BVH_TILE != 0;
+    constexpr uint32_t STRAG = (BVH && !INST) ? (TEX ? AKR_PT_STRAGGLERS_TEX : AKR_PT_STRAGGLERS) : 0;
     const uint4* tile = (const uint4*)(lds_stack + p.tile_offset);
     if (TILE) {  // nodes 0 .. bvh_tile_nodes - 1
         uint32_t* l = lds_stack + p.tile_offset;
@@ -106,7 +107,14 @@ AKR_D void pt_pass_body(const PtParams& p) {
                 r.c_closest += r.has_ray ? 1u : 0u;
                 r.c_shadow += r.has_shadow ? 1u : 0u;
             }
-            if (BVH && AKR_PT_MERGED_RAYS && STRAG > 0) {
+            if (BVH && INST) {
+                // meshes + instances: the two-level traversal, one ray after the other
+                if (r.has_ray) found = trace_inst<false, TEX>(sc, r.ro, r.rd, 0.0f, 1e20f, r.ray_ex0, kInvalid, hit, tc.stack, tc.cnt);
+                if (r.has_shadow) {
+                    Hit sh;
+                    occluded = trace_inst<true, TEX>(sc, r.s_o, r.s_d, 0.0f, r.s_tmax, r.s_ex0, r.s_ex1, sh, tc.stack, tc.cnt);
+                }
+            } else if (BVH && AKR_PT_MERGED_RAYS && STRAG > 0) {
                 // The merged loop below ends when the wave's LONGEST pair of rays is done: on the 10 M-triangle hall 40 % of its
                 // lane-steps do work, the rest is lanes waiting for the tail of the ray-length distribution. Here the phase ends
                 // when at most 1/n of the lanes that entered it are still tracing. Those lanes keep their traversal -- position
@@ -219,8 +227,8 @@ AKR_D void pt_pass_body(const PtParams& p) {
             }
             if (STRAG > 0 && r.carry) {
                 // still tracing: nothing to resolve or shade yet
-            } else if (PARK) path_step<FD ? 1 : 0, TEX, PMJ, DEFER ? 1 : 2, ABSENT>(q, r, hit, found, occluded, 0, 0, 0, park);
-            else path_step<FD ? 1 : 0, TEX, PMJ, 0, ABSENT>(q, r, hit, found, occluded, pix, sx, sy);
+            } else if (PARK) path_step<FD ? 1 : 0, TEX, PMJ, DEFER ? 1 : 2, ABSENT, INST>(q, r, hit, found, occluded, 0, 0, 0, park);
+            else path_step<FD ? 1 : 0, TEX, PMJ, 0, ABSENT, INST>(q, r, hit, found, occluded, pix, sx, sy);
         }
     }
     flush_counters(p, r, tc.cnt, BVH);

@@ -54,7 +54,7 @@ void akr_api::fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_p
     }
     {  // LDS staging of the tables the shading phase gathers from (pt_kernels.hip: STAGE)
         const CompiledScene& cs = s->cs;
-        const bool bvh = !cs.bvh_nodes.empty();
+        const bool bvh = !cs.bvh_nodes.empty() || cs.instanced.on;
         // exhaustive path: everything, per-triangle records included (scene_build.cpp guarantees the fit);
         // BVH path: the per-scene tables only, if they fit beside the traversal stacks
         size_t bytes[13] = {bvh ? 0 : cs.shade.size() * 4, bvh ? 0 : cs.normals.size() * 4, cs.inst.size() * 4, cs.materials.size() * sizeof(DMaterial),
@@ -76,7 +76,7 @@ void akr_api::fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_p
         const size_t other = (bvh ? (size_t)p.sc.bvh_stack_depth * 256 * 4 : 0) + (size_t)p.tex_slots * kTexValStride * sizeof(TexVal) + plan.recs_bytes +
                              plan.park_bytes + plan.carry_bytes;
         const size_t lds_budget = (se->spec_active && se->spec_waves >= 4) ? pt_lds_budget(false) : pt_lds_budget(cs.has_textures);
-        if (total <= (bvh ? kStageMaxBytesBvh : kStageMaxBytes) && (!bvh || other + total <= lds_budget)) {  // all of it or nothing (a TEX kernel reads its tables through LDS addresses)
+        if (!cs.instanced.on && total <= (bvh ? kStageMaxBytesBvh : kStageMaxBytes) && (!bvh || other + total <= lds_budget)) {  // (the instanced-scene kernels do not stage)  // all of it or nothing (a TEX kernel reads its tables through LDS addresses)
             // the albedo table as well for the full-graph exhaustive kernel of a textured scene (stage_scene_tables: GGX), if three
             // workgroups per CU still fit (AKR_PT_MIN_WAVES_TEX = 3: 160 KB / 3)
             const size_t ggx_bytes = 4096 * sizeof(float);
@@ -103,7 +103,7 @@ void akr_api::fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_p
         // most hits are not. Expensive = the conductor lobe; in the BVH kernels of scenes with textures (option defer_on) also /
         // instead a shader graph to evaluate at the hit.
         const CompiledScene& cs = s->cs;
-        const bool bvh = !cs.bvh_nodes.empty();
+        const bool bvh = !cs.bvh_nodes.empty() || cs.instanced.on;
         uint32_t flags = MF_EVAL_METAL;
         // (measured on the textured room, BVH kernel: conductor hits deferred 591 Msamples/s, textured hits 573, both 573, none 544)
         if (bvh && cs.has_textures) flags = se->defer_on_option == 2 ? MF_TEXTURED : (se->defer_on_option == 3 ? (MF_EVAL_METAL | MF_TEXTURED) : MF_EVAL_METAL);
@@ -116,7 +116,7 @@ void akr_api::fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_p
         bool want = n_dear > 0 && 2 * n_dear <= n_surface;
         uint32_t mask = 1u;  // iterations with (iteration & mask) != 0 put those hits off
         if (se->defer_metal_option >= 0) { mask = (uint32_t)se->defer_metal_option; want = mask != 0; }  // akr_option_set("defer_metal"): measurements / tests
-        p.defer_metal = (want && (!bvh || cs.has_textures) && !c.force_diffuse) ? mask : 0u;
+        p.defer_metal = (want && (!bvh || cs.has_textures) && !c.force_diffuse && !cs.instanced.on) ? mask : 0u;
         p.defer_flags = flags;
     }
     p.wf_sort = se->wf_sort ? 1u : 0u;
@@ -145,7 +145,7 @@ void akr_api::fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_p
 // fewer, no force_bvh) has no wavefront kernels and renders with the megakernel whatever the option says.
 static bool choose_wavefront(const akr_scene* scene) {
     if (!tuning().wavefront) return false;
-    return !scene->cs.bvh_nodes.empty();
+    return !scene->cs.bvh_nodes.empty();  // (a scene kept as meshes + instances has no flattened tree: megakernel)
 }
 
 static void wf_allocate(akr_pt_session* se, uint32_t n_slots) {
@@ -344,7 +344,10 @@ int32_t akr_api::pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_confi
             // (automatic: a kernel that is already cached is used whatever the render's size; a compile -- about a second -- only
             // when the render is long enough to win it back)
             const bool may_compile = t.specialise == 1 || samples >= kSpecAutoSamples;
+            if (scene->cs.instanced.on && !for_pt_kernel)
+                throw Unsupported("unsupported: a scene kept as meshes + instances (option instancing) renders with the pt integrator only");
             if (!for_pt_kernel) se->spec_status = "not a pt session";
+            else if (scene->cs.instanced.on) se->spec_status = "scene kept as meshes + instances";
             else if (!scene->cs.has_textures) se->spec_status = "the scene has no texture-fed material";
             else if (t.specialise == 0) se->spec_status = "option specialise = 0";
             else if (cfg->force_diffuse) se->spec_status = "force_diffuse kernels evaluate no surface graphs";

@@ -64,7 +64,15 @@ void akr_api::scene_finish(akr_scene* s) {
         s->area_alias.upload(aa);
         s->lights.upload(lr);
     }
-    s->bvh_nodes.upload(cs.bvh_nodes);
+    s->bvh_nodes.upload(cs.instanced.on ? cs.instanced.nodes : cs.bvh_nodes);
+    if (cs.instanced.on) {
+        s->in2_tlas_leaves.upload(cs.instanced.tlas_leaves);
+        s->in2_mesh_tris.upload(cs.instanced.mesh_tris);
+        s->in2_mesh_pos.upload(cs.instanced.mesh_pos);
+        s->in2_mesh_meta.upload(cs.instanced.mesh_meta);
+        s->in2_mesh_normals.upload(cs.instanced.mesh_normals);
+        s->in2_inst_mats.upload(cs.instanced.inst_mats);
+    }
     if (cs.has_textures) {
         s->tex_nodes.upload(cs.tex_nodes);
         s->tex_images.upload(cs.images);
@@ -95,11 +103,22 @@ void akr_api::scene_finish(akr_scene* s) {
     d.bvh_nodes = s->bvh_nodes.as<uint4>();
     d.n_tris = cs.n_tris;
     d.n_lights = cs.n_lights;
-    d.n_nodes = (uint32_t)(cs.bvh_nodes.size() / kBvhNodeWords);
+    d.n_nodes = (uint32_t)((cs.instanced.on ? cs.instanced.nodes.size() : cs.bvh_nodes.size()) / kBvhNodeWords);
     d.has_alpha = cs.has_alpha ? 1u : 0u;
     d.bvh_stack_depth = std::max(1u, std::min(cs.bvh_depth, kBvhStackDepth));  // one pending group per tree level at most (disect.h)
+    if (cs.instanced.on) {  // two levels + the three words that remember the TLAS position (dinst_trav.h); scene_inst.cpp checked the bound
+        d.bvh_stack_depth = cs.bvh_depth;
+        d.in2.tlas_leaves = s->in2_tlas_leaves.as<uint4>();
+        d.in2.mesh_tris = s->in2_mesh_tris.as<float4>();
+        d.in2.mesh_pos = s->in2_mesh_pos.as<uint32_t>();
+        d.in2.mesh_meta = s->in2_mesh_meta.as<uint32_t>();
+        d.in2.mesh_normals = s->in2_mesh_normals.as<float4>();
+        d.in2.inst_mats = s->in2_inst_mats.as<uint32_t>();
+        d.in2.on = 1u;
+        d.in2.n_instances = (uint32_t)s->flat.instances.size();
+    }
     d.plane_share_mask = 0;
-    if (cs.bvh_nodes.empty())  // exhaustive path (<= 64 triangles): which records repeat their predecessor's plane row
+    if (cs.bvh_nodes.empty() && !cs.instanced.on)  // exhaustive path (<= 64 triangles): which records repeat their predecessor's plane row
         for (uint32_t k = 1; k < d.n_tris && k < 64; k++)
             if (std::memcmp(&cs.woop[12ull * k + 8], &cs.woop[12ull * (k - 1) + 8], 16) == 0) d.plane_share_mask |= 1ull << k;
     if (cs.has_textures) {
@@ -111,8 +130,20 @@ void akr_api::scene_finish(akr_scene* s) {
     s->device_bytes = 0;
     for (const DevBuf* b : {&s->woop, &s->tri_gid, &s->shade, &s->normals, &s->inst, &s->materials, &s->ggx_table, &s->light_entries,
                             &s->light_pdf, &s->light_inst, &s->light_tri_offset, &s->light_n_tris, &s->area_entries, &s->area_pdf,
-                            &s->inst_tri_offset, &s->light_alias, &s->area_alias, &s->lights, &s->bvh_nodes, &s->tex_nodes, &s->tex_images, &s->tex_texels, &s->tex_mat_inputs})
+                            &s->inst_tri_offset, &s->light_alias, &s->area_alias, &s->lights, &s->bvh_nodes, &s->tex_nodes, &s->tex_images, &s->tex_texels, &s->tex_mat_inputs,
+                            &s->in2_tlas_leaves, &s->in2_mesh_tris, &s->in2_mesh_pos, &s->in2_mesh_meta, &s->in2_mesh_normals, &s->in2_inst_mats})
         s->device_bytes += b->bytes;
+}
+
+// the arrays scene_finish uploads, in bytes (the packed light tables repeat the alias tables: 16 B per entry)
+static uint64_t compiled_scene_bytes(const CompiledScene& cs) {
+    auto b = [](const auto& v) { return (uint64_t)v.size() * sizeof(v[0]); };
+    uint64_t n = b(cs.woop) + b(cs.tri_gid) + b(cs.shade) + b(cs.normals) + b(cs.inst) + b(cs.materials) + b(cs.light_entries) + b(cs.light_pdf) +
+                 b(cs.light_inst) + b(cs.light_tri_offset) + b(cs.light_n_tris) + b(cs.area_entries) + b(cs.area_pdf) + b(cs.inst_tri_offset) +
+                 16ull * (cs.light_entries.size() + cs.area_entries.size() + cs.n_lights) + b(cs.bvh_nodes) + b(cs.tex_nodes) + b(cs.images) + b(cs.texels) +
+                 b(cs.mat_inputs);
+    const CompiledScene::Instanced& is = cs.instanced;
+    return n + b(is.nodes) + b(is.tlas_leaves) + b(is.mesh_tris) + b(is.mesh_pos) + b(is.mesh_meta) + b(is.mesh_normals) + b(is.inst_mats);
 }
 
 extern "C" {
@@ -165,12 +196,12 @@ AKR_API int32_t akr_scene_get_info(const akr_scene* s, akr_scene_info* info) {
     info->n_triangles = s->cs.n_tris;
     info->n_materials = (uint32_t)s->flat.materials.size();
     info->n_lights = s->cs.n_lights;
-    info->n_bvh_nodes = (uint32_t)(s->cs.bvh_nodes.size() / kBvhNodeWords);
-    info->uses_bvh = s->cs.bvh_nodes.empty() ? 0u : 1u;
-    info->device_bytes = s->device_bytes;
-    info->node_bytes = s->cs.bvh_nodes.empty() ? 0u : kBvhNodeWords * 4u;   // bytes a traversal reads per node visit
-    info->node_stride_bytes = s->cs.bvh_nodes.empty() ? 0u : kBvhNodeWords * 4u;
-    info->tri_bytes = s->cs.bvh_nodes.empty() ? 48u : kBvhTriWords * 4u;
+    info->n_bvh_nodes = (uint32_t)((s->cs.instanced.on ? s->cs.instanced.nodes.size() : s->cs.bvh_nodes.size()) / kBvhNodeWords);
+    info->uses_bvh = (s->cs.bvh_nodes.empty() && !s->cs.instanced.on) ? 0u : (s->cs.instanced.on ? 2u : 1u);  // 2 = two-level (meshes + instances)
+    info->device_bytes = s->device_bytes ? s->device_bytes : compiled_scene_bytes(s->cs);  // (a host-only scene: what an upload would take)
+    info->node_bytes = (s->cs.bvh_nodes.empty() && !s->cs.instanced.on) ? 0u : kBvhNodeWords * 4u;   // bytes a traversal reads per node visit
+    info->node_stride_bytes = (s->cs.bvh_nodes.empty() && !s->cs.instanced.on) ? 0u : kBvhNodeWords * 4u;
+    info->tri_bytes = (s->cs.bvh_nodes.empty() && !s->cs.instanced.on) ? 48u : kBvhTriWords * 4u;
     info->bvh_depth = s->cs.bvh_depth;
     return AKR_OK;
 }
@@ -260,7 +291,10 @@ AKR_API int32_t akr_scene_get_array(const akr_scene* s, int32_t which, const voi
         case AKR_ARRAY_SHADE: set(cs.shade.data(), cs.shade.size() * 4); break;
         case AKR_ARRAY_INSTANCES: set(cs.inst.data(), cs.inst.size() * 4); break;
         case AKR_ARRAY_MATERIALS: set(cs.materials.data(), cs.materials.size() * sizeof(DMaterial)); break;
-        case AKR_ARRAY_BVH_NODES: set(cs.bvh_nodes.data(), cs.bvh_nodes.size() * 4); break;
+        case AKR_ARRAY_BVH_NODES:
+            if (cs.instanced.on) set(cs.instanced.nodes.data(), cs.instanced.nodes.size() * 4);
+            else set(cs.bvh_nodes.data(), cs.bvh_nodes.size() * 4);
+            break;
         case AKR_ARRAY_LIGHT_ENTRIES: set(cs.light_entries.data(), cs.light_entries.size() * sizeof(AliasEntry)); break;
         case AKR_ARRAY_LIGHT_PDF: set(cs.light_pdf.data(), cs.light_pdf.size() * 4); break;
         case AKR_ARRAY_AREA_ENTRIES: set(cs.area_entries.data(), cs.area_entries.size() * sizeof(AliasEntry)); break;
@@ -272,6 +306,11 @@ AKR_API int32_t akr_scene_get_array(const akr_scene* s, int32_t which, const voi
         case AKR_ARRAY_TEX_IMAGES: set(cs.images.data(), cs.images.size() * sizeof(DImage)); break;
         case AKR_ARRAY_TEX_TEXELS: set(cs.texels.data(), cs.texels.size() * 4); break;
         case AKR_ARRAY_MAT_INPUTS: set(cs.mat_inputs.data(), cs.mat_inputs.size() * sizeof(MatInputs)); break;
+        case AKR_ARRAY_INST_LEAVES: set(cs.instanced.tlas_leaves.data(), cs.instanced.tlas_leaves.size() * 4); break;
+        case AKR_ARRAY_MESH_TRIS: set(cs.instanced.mesh_tris.data(), cs.instanced.mesh_tris.size() * 4); break;
+        case AKR_ARRAY_MESH_POS: set(cs.instanced.mesh_pos.data(), cs.instanced.mesh_pos.size() * 4); break;
+        case AKR_ARRAY_MESH_META: set(cs.instanced.mesh_meta.data(), cs.instanced.mesh_meta.size() * 4); break;
+        case AKR_ARRAY_MESH_NORMALS: set(cs.instanced.mesh_normals.data(), cs.instanced.mesh_normals.size() * 4); break;
         default: return fail(AKR_ERR_INVALID_ARGUMENT, "akr_scene_get_array: unknown array id");
     }
     return AKR_OK;

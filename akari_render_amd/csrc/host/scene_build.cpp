@@ -9,6 +9,7 @@
 // All f32 arithmetic here uses the same akr:: helpers as the kernels (this file is compiled with
 // -ffp-contract=off too), so a quantity folded on the host has the bits the device would have computed.
 #include "scene_build.h"
+#include "../device/dinst.h"
 #include "host_parallel.h"
 
 #include <chrono>
@@ -415,12 +416,8 @@ PcgStartConsts pcg_start_constants() {
 }
 
 // ------------------------------------------------------------------------------------------------ geometry
-struct Xform {
-    vec3 c0, c1, c2, t, k0, k1, k2;
-    float det, inv_det;
-};
-static Xform make_xform(const float* m) {
-    Xform x;
+static InstXf make_xform(const float* m) {
+    InstXf x;
     x.c0 = mk3(m[0], m[1], m[2]);
     x.c1 = mk3(m[4], m[5], m[6]);
     x.c2 = mk3(m[8], m[9], m[10]);
@@ -432,49 +429,9 @@ static Xform make_xform(const float* m) {
     x.inv_det = 1.0f / x.det;
     return x;
 }
-static vec3 xf_normal(const Xform& x, vec3 n) {  // (M^T)^-1 n
-    vec3 r = (x.k0 * n.x + x.k1 * n.y) + x.k2 * n.z;
-    return r * x.inv_det;
-}
 static vec3 ld3(const std::vector<float>& v, size_t i) { return mk3(v[3 * i], v[3 * i + 1], v[3 * i + 2]); }
 
-// Woop's precomputed transform, in double, from the f32 world-space vertices.
-static void woop_precompute(vec3 A, vec3 B, vec3 C, float* w) {
-    double ax = A.x, ay = A.y, az = A.z;
-    double e1x = (double)B.x - ax, e1y = (double)B.y - ay, e1z = (double)B.z - az;
-    double e2x = (double)C.x - ax, e2y = (double)C.y - ay, e2z = (double)C.z - az;
-    double nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
-    double det = nx * nx + ny * ny + nz * nz;
-    if (!(det > 0.0)) {
-        for (int i = 0; i < 12; i++) w[i] = 0.0f;
-        return;
-    }
-    double r0x = (e2y * nz - e2z * ny) / det, r0y = (e2z * nx - e2x * nz) / det, r0z = (e2x * ny - e2y * nx) / det;
-    double r1x = (ny * e1z - nz * e1y) / det, r1y = (nz * e1x - nx * e1z) / det, r1z = (nx * e1y - ny * e1x) / det;
-    double r2x = nx / det, r2y = ny / det, r2z = nz / det;
-    w[0] = (float)r0x; w[1] = (float)r0y; w[2] = (float)r0z; w[3] = (float)(-(r0x * ax + r0y * ay + r0z * az));
-    w[4] = (float)r1x; w[5] = (float)r1y; w[6] = (float)r1z; w[7] = (float)(-(r1x * ax + r1y * ay + r1z * az));
-    w[8] = (float)r2x; w[9] = (float)r2y; w[10] = (float)r2z; w[11] = (float)(-(r2x * ax + r2y * ay + r2z * az));
-}
-
-// Coplanar neighbours share a plane row: triangles 2j and 2j+1 of an instance -- the two halves of a quad in every mesh an
-// exporter triangulated -- get the SAME third row (plane equation) when the second one's vertices lie in the first one's
-// plane to within 1e-6 of the triangle's size: the second record's row is overwritten with the first's. Every intersector
-// then computes bit-identical t and hit point for the two (same ray, same row), which the exhaustive pair walk uses to
-// solve the plane once per quad (disect.h). A data-level definition: the oracle applies the same rule when it builds its
-// scene (oracle/akr_oracle.c: or_share_plane_row); nothing in either tracer depends on it.
-static void share_plane_row(const float* wa, float* wb, const vec3 vb[3]) {
-    const double rx = wa[8], ry = wa[9], rz = wa[10], c = wa[11];
-    const double len = std::sqrt(rx * rx + ry * ry + rz * rz);  // = 1 / |n| = 1 / (2 area)
-    if (!(len > 0.0) || (wb[8] == 0.0f && wb[9] == 0.0f && wb[10] == 0.0f)) return;  // a degenerate triangle on either side
-    const double tol = 1e-6 * std::sqrt(len);  // height / sqrt(|n|) <= 1e-6
-    for (int i = 0; i < 3; i++) {
-        const double s = ((rx * (double)vb[i].x + ry * (double)vb[i].y) + rz * (double)vb[i].z) + c;
-        if (!(std::fabs(s) <= tol)) return;
-    }
-    wb[8] = wa[8]; wb[9] = wa[9]; wb[10] = wa[10]; wb[11] = wa[11];
-}
-
+// (woop_precompute, share_plane_row, tri_world: device/dinst.h -- shared with the two-level traversal, which computes them at the hit)
 void build_bvh8(const std::vector<float>& tri_bounds, uint32_t n_tris, float pad, uint32_t stride, bool balanced, std::vector<uint32_t>& order,
                 std::vector<uint32_t>& nodes, uint32_t& depth);
 
@@ -527,6 +484,51 @@ void compile_materials(const FlatScene& flat, uint32_t color, CompiledScene& out
     out.absent = absent;
 }
 
+// Emission power estimate of one triangle, load.rs:312-343: 16 x (max(emission) * prim_area) / 16. For the folded (constant)
+// emitters the emission does not depend on the sampled point or direction, so the RNG of the reference kernel does not
+// influence the value; the f32 accumulation is kept. Texture-fed emission: the kernel of load.rs:312-343 as is --
+// Pcg32::new_seq(prim), per sample next_2d -> barycentrics, next_2d -> wo (drawn, unused by the emission of these closures).
+float triangle_emission_power(const CompiledScene& out, const TexScene& host_tex, uint32_t material, uint32_t prim, vec2 uv0, vec2 uv1, vec2 uv2, float area) {
+    const DMaterial& dm = out.materials[material];
+    vec3 e = (dm.kind == MAT_PRINCIPLED || dm.kind == MAT_EMISSION) ? dm.emission : mk3(0, 0, 0);
+    float acc = 0.0f;
+    const bool tex_emission = (dm.flags & MF_TEXTURED) && (dm.kind == MAT_PRINCIPLED || dm.kind == MAT_EMISSION) &&
+                              (dm.tex_input[IN_EMISSION_COLOR] != kNodeNone || dm.tex_input[IN_EMISSION_STRENGTH] != kNodeNone);
+    if (tex_emission) {
+        Pcg32 rng = pcg_new_seq((uint64_t)prim);
+        for (int k = 0; k < 16; k++) {
+            float u0 = pcg_next_1d(rng), u1 = pcg_next_1d(rng);
+            vec2 bary = uniform_sample_triangle(mk2(u0, u1));
+            (void)pcg_next_1d(rng);
+            (void)pcg_next_1d(rng);
+            float w = 1.0f - bary.x - bary.y;
+            vec2 uv = mk2((uv0.x * w + uv1.x * bary.x) + uv2.x * bary.y, (uv0.y * w + uv1.y * bary.x) + uv2.y * bary.y);
+            DMaterial at = dm;
+            material_at(host_tex, material, uv, at);
+            acc += max3(at.emission) * area;
+        }
+    } else {
+        for (int k = 0; k < 16; k++) acc += max3(e) * area;
+    }
+    return acc / 16.0f;
+}
+// has_potential_surface_emission, load.rs:94-127, over an instance's material list
+bool instance_may_emit(const CompiledScene& out, const std::vector<akr_material_desc>& descs, const HostInstance& in) {
+    bool any = false;
+    for (uint32_t mi : in.materials) {
+        const akr_material_desc& m = descs[mi];
+        if (m.kind != AKR_MAT_PRINCIPLED && m.kind != AKR_MAT_EMISSION) { any = true; continue; }
+        const DMaterial& dm = out.materials[mi];
+        if ((dm.flags & MF_TEXTURED) && (dm.tex_input[IN_EMISSION_COLOR] != kNodeNone || dm.tex_input[IN_EMISSION_STRENGTH] != kNodeNone)) {
+            any = true;  // estimate_emission_tex_intensity_fast gives None for texture nodes (load.rs:76-92)
+            continue;
+        }
+        float power = max_f(max_f(m.emission_color[0], m.emission_color[1]), m.emission_color[2]);
+        if (!(power * m.emission_strength == 0.0f)) any = true;
+    }
+    return any;
+}
+
 namespace {
 // AKR_TIMING=1: wall clock of the phases of a scene compile on stderr (host-side diagnostics; no effect on results)
 struct PhaseTimer {
@@ -561,7 +563,7 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
     compile_materials(flat, 0, out, descs);
     const TexScene host_tex{out.tex_nodes.data(), out.images.data(), out.texels.data(), out.mat_inputs.data(), 0, 0};
     // instance table
-    std::vector<Xform> xf(n_inst);
+    std::vector<InstXf> xf(n_inst);
     out.inst.assign(32 * n_inst, 0.0f);
     out.inst_tri_offset.resize(n_inst + 1);
     uint32_t n_tris = 0;
@@ -569,7 +571,7 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
     for (size_t i = 0; i < n_inst; i++) {
         const HostInstance& in = flat.instances[i];
         xf[i] = make_xform(in.transform);
-        const Xform& x = xf[i];
+        const InstXf& x = xf[i];
         float* r = &out.inst[32 * i];
         r[0] = x.c0.x; r[1] = x.c0.y; r[2] = x.c0.z; r[3] = x.det;
         r[4] = x.c1.x; r[5] = x.c1.y; r[6] = x.c1.z;
@@ -584,6 +586,11 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
     }
     out.inst_tri_offset[n_inst] = n_tris;
     out.n_tris = n_tris;
+    if (want_instancing(flat)) {  // meshes + instances as they are: nothing per instance-triangle (scene_inst.cpp)
+        compile_instanced_geometry(flat, xf, descs, out);
+        phase.lap("instanced geometry");
+        return;
+    }
     out.woop.assign(12ull * n_tris, 0.0f);
     out.shade.assign(32ull * n_tris, 0.0f);
     if (any_normals) out.normals.assign(24ull * n_tris, 0.0f);  // 3 float4 normals + 3 float4 tangents per triangle
@@ -613,7 +620,7 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
         const size_t i = chunk.inst;
         const HostInstance& in = flat.instances[i];
         const HostMesh& g = flat.meshes[in.mesh];
-        const Xform& x = xf[i];
+        const InstXf& x = xf[i];
         for (uint32_t prim = chunk.first; prim < chunk.last; prim++) {
             const uint32_t gid = out.inst_tri_offset[i] + prim;
             // material: mats[slots[prim]] when the slot buffer has more than one entry, else mats[0] (mesh.rs:508-521)
@@ -621,44 +628,23 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
             if (slot >= in.materials.size()) { chunk.bad_slot = true; return; }
             uint32_t material = in.materials[slot];
             vec3 v0 = ld3(g.vertices, g.indices[3 * prim]), v1 = ld3(g.vertices, g.indices[3 * prim + 1]), v2 = ld3(g.vertices, g.indices[3 * prim + 2]);
-            // mesh.rs:527-535
-            vec3 ngc = cross(v1 - v0, v2 - v0);
-            float len = length(ngc);
-            float area_local = len * 0.5f;
-            vec3 ng_local = div_s(ngc, len);
-            vec2 uv0 = mk2(0.0f, 0.0f), uv1 = mk2(1.0f, 0.0f), uv2 = mk2(1.0f, 0.1f);  // mesh.rs:541-546
+            vec2 uv0, uv1, uv2;
+            tri_default_uvs(uv0, uv1, uv2);  // mesh.rs:541-546
             if (!g.uvs.empty()) {
                 uv0 = mk2(g.uvs[6 * prim + 0], g.uvs[6 * prim + 1]);
                 uv1 = mk2(g.uvs[6 * prim + 2], g.uvs[6 * prim + 3]);
                 uv2 = mk2(g.uvs[6 * prim + 4], g.uvs[6 * prim + 5]);
             }
-            // default tangent = dpdu (mesh.rs:572-589)
-            vec3 tt_local = mk3(0, 0, 0);
-            {
-                vec2 duv02 = mk2(uv0.x - uv2.x, uv0.y - uv2.y), duv12 = mk2(uv1.x - uv2.x, uv1.y - uv2.y);
-                vec3 dp02 = v0 - v2, dp12 = v1 - v2;
-                float determinant = difference_of_products(duv02.x, duv12.y, duv02.y, duv12.x);
-                bool degenerate_uv = abs_f(determinant) < 1e-8f;
-                if (!degenerate_uv) {
-                    float inv_det = 1.0f / determinant;
-                    tt_local.x = difference_of_products(duv12.y, dp02.x, duv02.y, dp12.x) * inv_det;
-                    tt_local.y = difference_of_products(duv12.y, dp02.y, duv02.y, dp12.y) * inv_det;
-                    tt_local.z = difference_of_products(duv12.y, dp02.z, duv02.y, dp12.z) * inv_det;
-                }
-                if (degenerate_uv || length2(tt_local) == 0.0f) tt_local = frame_from_n(ng_local).t;
-            }
+            const TriWorld tw = tri_world(x, v0, v1, v2, uv0, uv1, uv2);  // device/dinst.h: mesh.rs:527-535, 572-589, 608-635
+            const vec3 ng_local = tw.ng_local, tt = tw.tt, ng = tw.ng;
+            const float area = tw.area;
+            const Frame fr = tw.frame;
             uint32_t tri_flags = 0;
             bool tangents_ok = false;
             if (!g.tangents.empty()) {  // mesh.rs:557-571: per-corner tangents are used only if all nine are finite
                 tangents_ok = true;
                 for (int k = 0; k < 9; k++) tangents_ok = tangents_ok && is_finite(g.tangents[9 * prim + k]);
             }
-            // world space (mesh.rs:608-635)
-            vec3 tt = xf_vector(x.c0, x.c1, x.c2, tt_local);
-            vec3 c = xf_vector(x.c0, x.c1, x.c2, ng_local);
-            vec3 ng = normalize(xf_normal(x, ng_local));
-            float area = (area_local == 0.0f || x.det == 0.0f) ? 0.0f : abs_f(area_local * x.det / dot(ng, c));
-            Frame fr = (tt.x != 0.0f || tt.y != 0.0f || tt.z != 0.0f) ? frame_from_n_t(ng, tt) : frame_from_n(ng);
             if (!g.normals.empty()) tri_flags |= TRI_HAS_NORMALS;
             if (tangents_ok) tri_flags |= 2u;  // TRI_HAS_TANGENTS
             float* r = &out.shade[32ull * gid];
@@ -686,7 +672,7 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
             woop_precompute(A, B, C, &out.woop[12ull * gid]);
             if (prim & 1u) {
                 const vec3 vb[3] = {A, B, C};
-                share_plane_row(&out.woop[12ull * (gid - 1)], &out.woop[12ull * gid], vb);
+                share_plane_row(&out.woop[12ull * (gid - 1) + 8], &out.woop[12ull * gid + 8], vb);
             }
             float* bb = &bounds[6ull * gid];
             bb[0] = min_f(min_f(A.x, B.x), C.x); bb[1] = min_f(min_f(A.y, B.y), C.y); bb[2] = min_f(min_f(A.z, B.z), C.z);
@@ -703,33 +689,7 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
                 chunk.lo[a] = min_f(chunk.lo[a], bb[a]);
                 chunk.hi[a] = max_f(chunk.hi[a], bb[3 + a]);
             }
-            // emission power estimate, load.rs:312-343: 16 x (max(emission) * prim_area) / 16. For the folded
-            // (constant) emitters supported here the emission does not depend on the sampled point or direction,
-            // so the RNG of the reference kernel does not influence the value; the f32 accumulation is kept.
-            const DMaterial& dm = out.materials[material];
-            vec3 e = (dm.kind == MAT_PRINCIPLED || dm.kind == MAT_EMISSION) ? dm.emission : mk3(0, 0, 0);
-            float acc = 0.0f;
-            const bool tex_emission = (dm.flags & MF_TEXTURED) && (dm.kind == MAT_PRINCIPLED || dm.kind == MAT_EMISSION) &&
-                                      (dm.tex_input[IN_EMISSION_COLOR] != kNodeNone || dm.tex_input[IN_EMISSION_STRENGTH] != kNodeNone);
-            if (tex_emission) {
-                // the kernel of load.rs:312-343 as is: Pcg32::new_seq(prim), per sample next_2d -> barycentrics,
-                // next_2d -> wo (drawn, unused by the emission of these closures)
-                Pcg32 rng = pcg_new_seq((uint64_t)prim);
-                for (int k = 0; k < 16; k++) {
-                    float u0 = pcg_next_1d(rng), u1 = pcg_next_1d(rng);
-                    vec2 bary = uniform_sample_triangle(mk2(u0, u1));
-                    (void)pcg_next_1d(rng);
-                    (void)pcg_next_1d(rng);
-                    float w = 1.0f - bary.x - bary.y;
-                    vec2 uv = mk2((uv0.x * w + uv1.x * bary.x) + uv2.x * bary.y, (uv0.y * w + uv1.y * bary.x) + uv2.y * bary.y);
-                    DMaterial at = dm;
-                    material_at(host_tex, material, uv, at);
-                    acc += max3(at.emission) * area;
-                }
-            } else {
-                for (int k = 0; k < 16; k++) acc += max3(e) * area;
-            }
-            tri_power[gid] = acc / 16.0f;
+            tri_power[gid] = triangle_emission_power(out, host_tex, material, prim, uv0, uv1, uv2, area);
         }
     });
     for (const TriChunk& c : chunks) {  // in chunk order = in triangle order: the first error is the one the serial loop would raise
@@ -745,18 +705,7 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
     std::vector<float> light_weights;
     for (size_t i = 0; i < n_inst; i++) {
         const HostInstance& in = flat.instances[i];
-        bool any = false;  // has_potential_surface_emission, load.rs:94-127
-        for (uint32_t mi : in.materials) {
-            const akr_material_desc& m = descs[mi];
-            if (m.kind != AKR_MAT_PRINCIPLED && m.kind != AKR_MAT_EMISSION) { any = true; continue; }
-            const DMaterial& dm = out.materials[mi];
-            if ((dm.flags & MF_TEXTURED) && (dm.tex_input[IN_EMISSION_COLOR] != kNodeNone || dm.tex_input[IN_EMISSION_STRENGTH] != kNodeNone)) {
-                any = true;  // estimate_emission_tex_intensity_fast gives None for texture nodes (load.rs:76-92)
-                continue;
-            }
-            float power = max_f(max_f(m.emission_color[0], m.emission_color[1]), m.emission_color[2]);
-            if (!(power * m.emission_strength == 0.0f)) any = true;
-        }
+        const bool any = instance_may_emit(out, descs, in);
         if (!any) continue;
         uint32_t first = out.inst_tri_offset[i], count = out.inst_tri_offset[i + 1] - first;
         std::vector<float> powers(tri_power.begin() + first, tri_power.begin() + first + count);
@@ -842,6 +791,7 @@ void tuning_init_locked() {
     if (const char* e = std::getenv("AKR_SPECIALISE")) g_tuning.specialise = std::atoi(e);
     if (const char* e = std::getenv("AKR_SPECIALISE_WAVES")) g_tuning.specialise_waves = std::atoi(e);
     if (const char* e = std::getenv("AKR_WF_SORT")) g_tuning.wf_sort = std::atoi(e) != 0 ? 1 : 0;
+    if (const char* e = std::getenv("AKR_INSTANCING")) g_tuning.instancing = std::atoi(e);
 }
 int* tuning_field(const char* name) {
     const std::string n = name ? name : "";
@@ -855,6 +805,7 @@ int* tuning_field(const char* name) {
     if (n == "specialise_waves") return &g_tuning.specialise_waves;
     if (n == "max_fused_passes") return &g_tuning.max_fused_passes;
     if (n == "wf_sort") return &g_tuning.wf_sort;
+    if (n == "instancing") return &g_tuning.instancing;
     return nullptr;
 }
 }  // namespace
@@ -873,6 +824,7 @@ bool tuning_set(const char* name, int value) {
     if (f == &g_tuning.specialise_waves && value != 0 && (value < 2 || value > 4)) return false;
     if (f == &g_tuning.max_fused_passes && (value < 0 || value > 64)) return false;
     if (f == &g_tuning.wf_sort && (value < 0 || value > 1)) return false;
+    if (f == &g_tuning.instancing && (value < -1 || value > 1)) return false;
     *f = value;
     return true;
 }

@@ -82,6 +82,23 @@ struct CompiledScene {
     };
     std::vector<ShaderKind> shader_kinds;
     uint32_t absent = 0;                  // lobes no material of the scene can have (device/dbsdf.h AB_*)
+    // Two-level mode (scene_inst.cpp; option `instancing`): the scene is kept as meshes + instances. woop / shade / normals / tri_gid /
+    // bvh_nodes above stay EMPTY; nothing is stored per instance-triangle. What the device computes at a hit from these arrays is
+    // the flattened record bit for bit (device/dinst.h).
+    struct Instanced {
+        bool on = false;
+        std::vector<uint32_t> nodes;        // TLAS nodes (root = slot 0) followed by every mesh's BLAS nodes; child_base / tri_base are
+                                            // relative to the start of their own tree
+        std::vector<float> tlas_leaves;     // 16 words per instance in TLAS order: world->object rows (3 x float4) | BLAS node offset, mesh triangle
+                                            // base, instance id, global id of the instance's first triangle
+        std::vector<float> mesh_tris;       // 16 words per mesh triangle in BLAS order: v0 | uv0.x, v1 | uv0.y, v2 | uv1.x, uv1.y uv2.x uv2.y | prim
+        std::vector<uint32_t> mesh_pos;     // per mesh triangle in MESH order: its position in mesh_tris (relative to the mesh's base)
+        std::vector<uint32_t> mesh_meta;    // per mesh triangle in mesh order: material slot | TRI_HAS_* flags << 30
+        std::vector<float> mesh_normals;    // 24 words per mesh triangle in mesh order (corner normals, corner tangents) or empty
+        std::vector<uint32_t> inst_mats;    // the instances' material lists, concatenated
+        std::vector<uint32_t> inst_light;   // light id per instance or 0xffffffff
+        uint32_t tlas_nodes = 0, tlas_depth = 0, blas_depth = 0, n_mesh_tris = 0;
+    } instanced;
     bool has_textures = false;
     bool has_alpha = false;
     bool needs_ggx_table = false;
@@ -104,6 +121,7 @@ void build_alias_table(const std::vector<float>& weights, std::vector<AliasEntry
 //   specialise   AKR_SPECIALISE=<v>       per-scene kernels for scenes with texture-fed materials (host/specialise.cpp): -1 = the library decides (a cached
 //                                         kernel always; a compile for renders of at least kSpecAutoSamples samples), 0 = never (the interpreter), 1 = always
 //   specialise_waves AKR_SPECIALISE_WAVES=<n>  waves per SIMD a per-scene kernel is compiled for: 0 = the library's choice, else 2..4
+//   instancing   AKR_INSTANCING=<v>       meshes + instances kept as they are (BLAS per mesh, TLAS over instances; scene_inst.cpp): -1 auto, 0 never, 1 always
 //   wf_sort      AKR_WF_SORT=1            wavefront schedule: ray queues sorted by origin cell + direction octant before each trace launch
 //   max_fused_passes (no environment hook)     most passes akr_pt_passes fuses into one launch: 0 = adaptive (16, up to 64 once a pass has been timed), else 1..64
 struct TuningOptions {
@@ -111,6 +129,8 @@ struct TuningOptions {
     int defer_on = 0;  // BVH kernels of textured scenes: which hits the deferral puts off -- 0 / 1 = the conductor lobe (default), 2 = texture-fed materials, 3 = both
     int specialise = -1, specialise_waves = 0;
     int max_fused_passes = 0;
+    int instancing = -1;  // two-level acceleration structure for scenes whose meshes are instanced: -1 the library decides (flattening is the
+                          // default while its records fit a budget), 0 never, 1 whenever a mesh has more than one instance
     int wf_sort = 0;  // wavefront schedule: 1 = the ray queues are sorted by (Morton code of the origin, octant) before every trace launch (wf_sort.hip)
 };
 constexpr uint64_t kSpecAutoSamples = 1ull << 31;  // option specialise = -1: a first-use compile (about a second; 20-30 % of the render to win) has to be worth it
@@ -119,6 +139,13 @@ bool tuning_set(const char* name, int value);    // false: unknown name
 bool tuning_get(const char* name, int* value);
 
 void compile_scene(const FlatScene& flat, CompiledScene& out);
+float triangle_emission_power(const CompiledScene& out, const TexScene& host_tex, uint32_t material, uint32_t prim, vec2 uv0, vec2 uv1, vec2 uv2, float area);
+bool instance_may_emit(const CompiledScene& out, const std::vector<akr_material_desc>& descs, const HostInstance& in);
+// scene_inst.cpp: does this scene take the two-level route, and its geometry + light tables if so (materials and the instance table
+// of `out` must be filled: compile_scene calls it)
+bool want_instancing(const FlatScene& flat);
+struct InstXf;
+void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>& xf, const std::vector<akr_material_desc>& descs, CompiledScene& out);
 // PerspectiveCameraData::new (camera/mod.rs:119-153)
 void camera_matrices(const akr_camera_desc& cam, float r2c[16], float c2w[16], uint32_t* c2w_identity);
 PcgStartConsts pcg_start_constants();

@@ -1,0 +1,321 @@
+// scene_inst.cpp -- a scene kept as meshes + instances: one BLAS per mesh in object space, a TLAS over the instances' world boxes.
+//
+// The reference builds exactly that (crates/akari_render/src/mesh.rs:259-348: `push_mesh(mesh, transform, ..)` per instance into a
+// LuisaCompute accel) and evaluates everything per hit from object-space buffers and the instance transform (mesh.rs:487-654). The
+// flattening compiler (scene_build.cpp) stores 192 bytes per instance-triangle instead -- fine for the Cornell box and a 10 M-triangle
+// hall, impossible for a thousand instances of a 100 k-triangle plant. Here nothing is stored per instance-triangle:
+//   * the two box levels only CULL (they must be conservative, nothing more): the TLAS in world space over boxes of the exactly
+//     transformed vertices, a BLAS in object space, entered with the ray taken through the instance's inverse -- its boxes padded for
+//     the round-off of that;
+//   * every accept / reject of a triangle and every shaded value is the flattened arithmetic, computed at the candidate from the
+//     object-space triangle and the instance transform by the code the flattening compiler runs (device/dinst.h): f32-transformed
+//     vertices, Woop rows in f64, the coplanar-neighbour rule, the per-triangle frame and area. Films are the oracle's bit for bit
+//     (the oracle flattens).
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+
+#include "../device/dinst.h"
+#include "host_parallel.h"
+#include "scene_build.h"
+
+namespace akr {
+
+void build_bvh8(const std::vector<float>& tri_bounds, uint32_t n_tris, float pad, uint32_t stride, bool balanced, std::vector<uint32_t>& order,
+                std::vector<uint32_t>& nodes, uint32_t& depth);
+
+namespace {
+vec3 ld3(const std::vector<float>& v, size_t i) { return mk3(v[3 * i], v[3 * i + 1], v[3 * i + 2]); }
+// flattened records of a scene: 64 B traversal + 128 B shade per instance-triangle (+ 96 B with corner normals), ~0.3 nodes of 64 B
+constexpr uint64_t kFlatBytesPerTriangle = 64 + 128 + 20;
+constexpr uint64_t kFlatBudgetBytes = 8ull << 30;   // automatic mode: flatten while the records stay below this
+constexpr uint64_t kFlatMaxTriangles = 48u << 20;   // ... and the flattened tree below its 2^24 node slots (~0.29 slots per triangle)
+}  // namespace
+
+bool want_instancing(const FlatScene& flat) {
+    const TuningOptions t = tuning();
+    if (t.instancing == 0) return false;
+    std::vector<uint32_t> uses(flat.meshes.size(), 0);
+    uint64_t flat_tris = 0;
+    bool shared = false;
+    for (const HostInstance& in : flat.instances) {
+        if (in.mesh >= flat.meshes.size()) return false;  // (compile_scene reports it)
+        shared = shared || ++uses[in.mesh] > 1;
+        flat_tris += flat.meshes[in.mesh].n_triangles();
+        // a singular transform has no inverse to take the ray through: such a scene is flattened (its triangles are degenerate there)
+        const float* m = in.transform;
+        const double det = (double)m[0] * ((double)m[5] * m[10] - (double)m[9] * m[6]) - (double)m[4] * ((double)m[1] * m[10] - (double)m[9] * m[2]) +
+                           (double)m[8] * ((double)m[1] * m[6] - (double)m[5] * m[2]);
+        if (!(std::fabs(det) > 1e-30) || !std::isfinite(det)) return false;
+    }
+    if (!shared) return false;
+    if (t.instancing == 1) return true;
+    return flat_tris * kFlatBytesPerTriangle > kFlatBudgetBytes || flat_tris > kFlatMaxTriangles;
+}
+
+void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>& xf, const std::vector<akr_material_desc>& descs, CompiledScene& out) {
+    CompiledScene::Instanced& is = out.instanced;
+    is = CompiledScene::Instanced();
+    is.on = true;
+    const size_t n_inst = flat.instances.size(), n_mesh = flat.meshes.size();
+    const TexScene host_tex{out.tex_nodes.data(), out.images.data(), out.texels.data(), out.mat_inputs.data(), 0, 0};
+    // ---- which meshes are used, their triangle bases
+    std::vector<uint8_t> used(n_mesh, 0);
+    for (const HostInstance& in : flat.instances) used[in.mesh] = 1;
+    std::vector<uint32_t> mesh_base(n_mesh, 0);
+    uint32_t n_mesh_tris = 0;
+    bool any_normals = false;
+    for (size_t m = 0; m < n_mesh; m++) {
+        mesh_base[m] = n_mesh_tris;
+        if (!used[m]) continue;
+        n_mesh_tris += flat.meshes[m].n_triangles();
+        if (!flat.meshes[m].normals.empty() || !flat.meshes[m].tangents.empty()) any_normals = true;
+    }
+    is.n_mesh_tris = n_mesh_tris;
+    // ---- instance world boxes from the exactly transformed vertices (what the flattened triangles' boxes would span), scene box
+    std::vector<float> inst_bounds(6 * n_inst);
+    std::vector<std::string> errors(n_inst);
+    parallel_chunks((unsigned)n_inst, n_inst > 16 ? host_threads() : 1u, [&](unsigned i) {
+        const HostMesh& g = flat.meshes[flat.instances[i].mesh];
+        const InstXf& x = xf[i];
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        bool finite = true;
+        for (size_t k = 0; k < g.indices.size(); k++) {  // (every corner that some triangle uses)
+            const vec3 p = xf_point(x.c0, x.c1, x.c2, x.t, ld3(g.vertices, g.indices[k]));
+            finite = finite && is_finite(p.x) && is_finite(p.y) && is_finite(p.z);
+            lo[0] = min_f(lo[0], p.x); lo[1] = min_f(lo[1], p.y); lo[2] = min_f(lo[2], p.z);
+            hi[0] = max_f(hi[0], p.x); hi[1] = max_f(hi[1], p.y); hi[2] = max_f(hi[2], p.z);
+        }
+        if (!finite) errors[i] = "instance " + std::to_string(i) + ": non-finite vertex position after the instance transform";
+        for (int a = 0; a < 3; a++) { inst_bounds[6 * i + a] = lo[a]; inst_bounds[6 * i + 3 + a] = hi[a]; }
+    });
+    for (int a = 0; a < 3; a++) { out.scene_lo[a] = INFINITY; out.scene_hi[a] = -INFINITY; }
+    for (size_t i = 0; i < n_inst; i++) {
+        if (!errors[i].empty()) throw std::invalid_argument(errors[i]);
+        if (flat.meshes[flat.instances[i].mesh].n_triangles() == 0) continue;
+        for (int a = 0; a < 3; a++) {
+            out.scene_lo[a] = min_f(out.scene_lo[a], inst_bounds[6 * i + a]);
+            out.scene_hi[a] = max_f(out.scene_hi[a], inst_bounds[6 * i + 3 + a]);
+        }
+    }
+    float diag2 = 0.0f, reach = 0.0f;  // reach: how far from the origin a ray can start (scene box, camera)
+    for (int a = 0; a < 3; a++) {
+        diag2 += sqr(out.scene_hi[a] - out.scene_lo[a]);
+        reach += max_f(max_f(abs_f(out.scene_lo[a]), abs_f(out.scene_hi[a])), abs_f(flat.camera.c2w[12 + a]));
+    }
+    const float pad_world = 4e-6f * __builtin_sqrtf(diag2);  // the flattened tree's padding: covers the triangle test's own slop
+    // ---- per instance: the inverse transform (double -> f32; used for culling only) and its norm
+    std::vector<double> inv(12 * n_inst);
+    std::vector<float> inv_norm(n_inst, 0.0f), mesh_inv_norm(n_mesh, 0.0f);
+    for (size_t i = 0; i < n_inst; i++) {
+        const float* m = flat.instances[i].transform;
+        const double a[3][3] = {{m[0], m[4], m[8]}, {m[1], m[5], m[9]}, {m[2], m[6], m[10]}};  // row-major 3x3 of the column-major 4x4
+        const double t[3] = {m[12], m[13], m[14]};
+        const double det = a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+                           a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
+        double r[3][3];
+        r[0][0] = (a[1][1] * a[2][2] - a[1][2] * a[2][1]) / det; r[0][1] = (a[0][2] * a[2][1] - a[0][1] * a[2][2]) / det; r[0][2] = (a[0][1] * a[1][2] - a[0][2] * a[1][1]) / det;
+        r[1][0] = (a[1][2] * a[2][0] - a[1][0] * a[2][2]) / det; r[1][1] = (a[0][0] * a[2][2] - a[0][2] * a[2][0]) / det; r[1][2] = (a[0][2] * a[1][0] - a[0][0] * a[1][2]) / det;
+        r[2][0] = (a[1][0] * a[2][1] - a[1][1] * a[2][0]) / det; r[2][1] = (a[0][1] * a[2][0] - a[0][0] * a[2][1]) / det; r[2][2] = (a[0][0] * a[1][1] - a[0][1] * a[1][0]) / det;
+        float norm = 0.0f;
+        for (int row = 0; row < 3; row++) {
+            double* o = &inv[12 * i + 4 * row];
+            o[0] = r[row][0]; o[1] = r[row][1]; o[2] = r[row][2];
+            o[3] = -(r[row][0] * t[0] + r[row][1] * t[1] + r[row][2] * t[2]);
+            norm = max_f(norm, (float)(std::fabs(o[0]) + std::fabs(o[1]) + std::fabs(o[2])));
+        }
+        inv_norm[i] = norm;
+        mesh_inv_norm[flat.instances[i].mesh] = max_f(mesh_inv_norm[flat.instances[i].mesh], norm);
+    }
+    // ---- per mesh: BLAS over object-space boxes, triangles in BLAS order, lookup by prim
+    is.mesh_tris.assign(16ull * n_mesh_tris, 0.0f);
+    is.mesh_pos.assign(n_mesh_tris, 0u);
+    is.mesh_meta.assign(n_mesh_tris, 0u);
+    if (any_normals) is.mesh_normals.assign(24ull * n_mesh_tris, 0.0f);
+    std::vector<uint32_t> blas_node_off(n_mesh, 0);
+    std::vector<std::vector<uint32_t>> blas_nodes(n_mesh);
+    std::vector<uint32_t> blas_depth(n_mesh, 0);
+    const TuningOptions tune = tuning();
+    for (size_t m = 0; m < n_mesh; m++) {
+        if (!used[m]) continue;
+        const HostMesh& g = flat.meshes[m];
+        const uint32_t nt = g.n_triangles();
+        if (nt == 0) continue;
+        std::vector<float> bounds(6ull * nt);
+        float olo[3] = {INFINITY, INFINITY, INFINITY}, ohi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t prim = 0; prim < nt; prim++) {
+            const vec3 v0 = ld3(g.vertices, g.indices[3 * prim]), v1 = ld3(g.vertices, g.indices[3 * prim + 1]), v2 = ld3(g.vertices, g.indices[3 * prim + 2]);
+            float* bb = &bounds[6ull * prim];
+            bb[0] = min_f(min_f(v0.x, v1.x), v2.x); bb[1] = min_f(min_f(v0.y, v1.y), v2.y); bb[2] = min_f(min_f(v0.z, v1.z), v2.z);
+            bb[3] = max_f(max_f(v0.x, v1.x), v2.x); bb[4] = max_f(max_f(v0.y, v1.y), v2.y); bb[5] = max_f(max_f(v0.z, v1.z), v2.z);
+            for (int a = 0; a < 3; a++) { olo[a] = min_f(olo[a], bb[a]); ohi[a] = max_f(ohi[a], bb[3 + a]); }
+        }
+        // Padding of the object-space boxes. A triangle the flattened test would accept lies within pad_world of its world box; in object
+        // space that is pad_world x |M^-1|. The ray is taken through M^-1 in f32: its origin is off by a few ulp of |M^-1| x (how far from
+        // the origin a ray can start), its direction by a few ulp -- i.e. by that much of the object-space scene extent at the far end.
+        // Both with a generous constant; the largest |M^-1| over the mesh's instances (the BLAS is shared).
+        float odiag = 0.0f;
+        for (int a = 0; a < 3; a++) odiag += ohi[a] - olo[a];
+        const float pad_obj = mesh_inv_norm[m] * (pad_world + 4e-6f * (reach + __builtin_sqrtf(diag2))) + 4e-6f * odiag;
+        std::vector<uint32_t> order;
+        build_bvh8(bounds, nt, pad_obj, kBvhNodeWords, tune.bvh_balanced != 0, order, blas_nodes[m], blas_depth[m]);
+        if (blas_depth[m] > kBvhStackDepth) build_bvh8(bounds, nt, pad_obj, kBvhNodeWords, true, order, blas_nodes[m], blas_depth[m]);
+        is.blas_depth = std::max(is.blas_depth, blas_depth[m]);
+        const uint32_t base = mesh_base[m];
+        for (uint32_t k = 0; k < nt; k++) {
+            const uint32_t prim = order[k];
+            is.mesh_pos[base + prim] = k;
+            const vec3 v0 = ld3(g.vertices, g.indices[3 * prim]), v1 = ld3(g.vertices, g.indices[3 * prim + 1]), v2 = ld3(g.vertices, g.indices[3 * prim + 2]);
+            vec2 uv0, uv1, uv2;
+            tri_default_uvs(uv0, uv1, uv2);
+            if (!g.uvs.empty()) {
+                uv0 = mk2(g.uvs[6 * prim + 0], g.uvs[6 * prim + 1]);
+                uv1 = mk2(g.uvs[6 * prim + 2], g.uvs[6 * prim + 3]);
+                uv2 = mk2(g.uvs[6 * prim + 4], g.uvs[6 * prim + 5]);
+            }
+            float* r = &is.mesh_tris[16ull * (base + k)];
+            r[0] = v0.x; r[1] = v0.y; r[2] = v0.z; r[3] = uv0.x;
+            r[4] = v1.x; r[5] = v1.y; r[6] = v1.z; r[7] = uv0.y;
+            r[8] = v2.x; r[9] = v2.y; r[10] = v2.z; r[11] = uv1.x;
+            r[12] = uv1.y; r[13] = uv2.x; r[14] = uv2.y; r[15] = u2f(prim);
+        }
+        for (uint32_t prim = 0; prim < nt; prim++) {
+            uint32_t tri_flags = 0;
+            bool tangents_ok = false;
+            if (!g.tangents.empty()) {  // mesh.rs:557-571: per-corner tangents are used only if all nine are finite
+                tangents_ok = true;
+                for (int k = 0; k < 9; k++) tangents_ok = tangents_ok && is_finite(g.tangents[9 * prim + k]);
+            }
+            if (!g.normals.empty()) tri_flags |= TRI_HAS_NORMALS;
+            if (tangents_ok) tri_flags |= TRI_HAS_TANGENTS;
+            const uint32_t slot = (g.slots.size() > 1) ? g.slots[prim] : 0;
+            if (slot >= (1u << 30)) throw std::invalid_argument("material slot out of range for instance");
+            is.mesh_meta[base + prim] = slot | (tri_flags << 30);
+            if (any_normals) {
+                float* nr = &is.mesh_normals[24ull * (base + prim)];
+                const vec3 v0 = ld3(g.vertices, g.indices[3 * prim]), v1 = ld3(g.vertices, g.indices[3 * prim + 1]), v2 = ld3(g.vertices, g.indices[3 * prim + 2]);
+                const vec3 ngc = cross(v1 - v0, v2 - v0);
+                const vec3 ng_local = div_s(ngc, length(ngc));  // = TriWorld.ng_local
+                for (int k = 0; k < 3; k++) {
+                    vec3 nk = g.normals.empty() ? ng_local : mk3(g.normals[9 * prim + 3 * k], g.normals[9 * prim + 3 * k + 1], g.normals[9 * prim + 3 * k + 2]);
+                    nr[4 * k] = nk.x; nr[4 * k + 1] = nk.y; nr[4 * k + 2] = nk.z;
+                    if (tangents_ok) {
+                        nr[12 + 4 * k] = g.tangents[9 * prim + 3 * k]; nr[12 + 4 * k + 1] = g.tangents[9 * prim + 3 * k + 1];
+                        nr[12 + 4 * k + 2] = g.tangents[9 * prim + 3 * k + 2];
+                    }
+                }
+            }
+        }
+    }
+    // ---- TLAS over the world boxes of the instances that have triangles
+    std::vector<uint32_t> tlas_ids, tlas_order;
+    {
+        std::vector<float> tb;
+        for (size_t i = 0; i < n_inst; i++) {
+            if (flat.meshes[flat.instances[i].mesh].n_triangles() == 0) continue;
+            tlas_ids.push_back((uint32_t)i);
+            tb.insert(tb.end(), &inst_bounds[6 * i], &inst_bounds[6 * i] + 6);
+        }
+        if (tlas_ids.empty()) throw std::invalid_argument("instanced scene without triangles");
+        build_bvh8(tb, (uint32_t)tlas_ids.size(), pad_world, kBvhNodeWords, tune.bvh_balanced != 0, tlas_order, is.nodes, is.tlas_depth);
+        if (is.tlas_depth > kBvhStackDepth) build_bvh8(tb, (uint32_t)tlas_ids.size(), pad_world, kBvhNodeWords, true, tlas_order, is.nodes, is.tlas_depth);
+        is.tlas_nodes = (uint32_t)(is.nodes.size() / kBvhNodeWords);
+    }
+    for (size_t m = 0; m < n_mesh; m++) {
+        if (blas_nodes[m].empty()) continue;
+        blas_node_off[m] = (uint32_t)(is.nodes.size() / kBvhNodeWords);
+        is.nodes.insert(is.nodes.end(), blas_nodes[m].begin(), blas_nodes[m].end());
+        std::vector<uint32_t>().swap(blas_nodes[m]);
+    }
+    // one stack entry per level of either tree + the three words that remember where the TLAS traversal stood (disect.h)
+    out.bvh_depth = is.tlas_depth + is.blas_depth + 3;
+    if (out.bvh_depth > 40)
+        throw std::runtime_error("unsupported: two-level BVH depth " + std::to_string(out.bvh_depth) + " exceeds the traversal stack (40 levels)");
+    // ---- TLAS leaf records, instance material lists
+    is.tlas_leaves.assign(16ull * tlas_ids.size(), 0.0f);
+    std::vector<uint32_t> mat_base(n_inst, 0);
+    for (size_t i = 0; i < n_inst; i++) {
+        mat_base[i] = (uint32_t)is.inst_mats.size();
+        for (uint32_t mi : flat.instances[i].materials) is.inst_mats.push_back(mi);
+    }
+    for (size_t k = 0; k < tlas_ids.size(); k++) {
+        const uint32_t i = tlas_ids[tlas_order[k]];
+        const HostInstance& in = flat.instances[i];
+        float* r = &is.tlas_leaves[16ull * k];
+        for (int row = 0; row < 3; row++)
+            for (int c = 0; c < 4; c++) r[4 * row + c] = (float)inv[12 * i + 4 * row + c];
+        r[12] = u2f(blas_node_off[in.mesh]);
+        r[13] = u2f(mesh_base[in.mesh]);
+        r[14] = u2f(i);
+        r[15] = u2f(out.inst_tri_offset[i]);
+    }
+    // ---- lights (load.rs:345-444), per emissive instance only
+    is.inst_light.assign(n_inst, 0xffffffffu);
+    std::vector<float> light_weights;
+    for (size_t i = 0; i < n_inst; i++) {
+        const HostInstance& in = flat.instances[i];
+        if (!instance_may_emit(out, descs, in)) continue;
+        const HostMesh& g = flat.meshes[in.mesh];
+        const uint32_t count = g.n_triangles();
+        std::vector<float> powers(count, 0.0f);
+        std::atomic<bool> bad_slot{false};
+        parallel_chunks(std::max(1u, count >> 14), count > (1u << 15) ? host_threads() : 1u, [&](unsigned c) {
+            const unsigned nc = std::max(1u, count >> 14);
+            const uint32_t lo = (uint32_t)((uint64_t)count * c / nc), hi = (uint32_t)((uint64_t)count * (c + 1) / nc);
+            for (uint32_t prim = lo; prim < hi; prim++) {
+                const uint32_t slot = (g.slots.size() > 1) ? g.slots[prim] : 0;
+                if (slot >= in.materials.size()) { bad_slot = true; return; }
+                const vec3 v0 = ld3(g.vertices, g.indices[3 * prim]), v1 = ld3(g.vertices, g.indices[3 * prim + 1]), v2 = ld3(g.vertices, g.indices[3 * prim + 2]);
+                vec2 uv0, uv1, uv2;
+                tri_default_uvs(uv0, uv1, uv2);
+                if (!g.uvs.empty()) {
+                    uv0 = mk2(g.uvs[6 * prim + 0], g.uvs[6 * prim + 1]);
+                    uv1 = mk2(g.uvs[6 * prim + 2], g.uvs[6 * prim + 3]);
+                    uv2 = mk2(g.uvs[6 * prim + 4], g.uvs[6 * prim + 5]);
+                }
+                const TriWorld tw = tri_world(xf[i], v0, v1, v2, uv0, uv1, uv2);
+                powers[prim] = triangle_emission_power(out, host_tex, in.materials[slot], prim, uv0, uv1, uv2, tw.area);
+            }
+        });
+        if (bad_slot) throw std::invalid_argument("material slot out of range for instance");
+        float total = 0.0f;
+        for (float pw : powers) total += pw;
+        if (total > 1e-4f) {
+            const uint32_t light_id = (uint32_t)out.light_inst.size();
+            out.light_inst.push_back((uint32_t)i);
+            out.light_power.push_back(total);
+            light_weights.push_back(total);
+            std::vector<AliasEntry> ent;
+            std::vector<float> pdf;
+            build_alias_table(powers, ent, pdf);
+            out.light_tri_offset.push_back((uint32_t)out.area_entries.size());
+            out.light_n_tris.push_back(count);
+            out.area_entries.insert(out.area_entries.end(), ent.begin(), ent.end());
+            out.area_pdf.insert(out.area_pdf.end(), pdf.begin(), pdf.end());
+            is.inst_light[i] = light_id;
+        }
+    }
+    out.n_lights = (uint32_t)out.light_inst.size();
+    if (out.n_lights > 0) build_alias_table(light_weights, out.light_entries, out.light_pdf);
+    // every instance's material slots must be in range even when it does not emit (the flattening compiler checks per triangle)
+    for (size_t i = 0; i < n_inst; i++) {
+        const HostMesh& g = flat.meshes[flat.instances[i].mesh];
+        uint32_t max_slot = 0;
+        if (g.slots.size() > 1)
+            for (uint32_t sl : g.slots) max_slot = std::max(max_slot, sl);
+        if (g.n_triangles() && max_slot >= flat.instances[i].materials.size()) throw std::invalid_argument("material slot out of range for instance");
+    }
+    // the instance records' spare words: where the device finds an instance's mesh, materials, light and global ids (dinst.h)
+    for (size_t i = 0; i < n_inst; i++) {
+        float* r = &out.inst[32 * i];
+        r[7] = u2f(mesh_base[flat.instances[i].mesh]);
+        r[11] = u2f(mat_base[i]);
+        r[15] = u2f(is.inst_light[i]);
+        r[23] = u2f(out.inst_tri_offset[i]);
+        r[27] = u2f((uint32_t)flat.instances[i].materials.size());
+    }
+}
+
+}  // namespace akr

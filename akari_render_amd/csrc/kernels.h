@@ -196,6 +196,9 @@ inline PtParams with_tex_slots(const PtParams& p, size_t base_bytes, size_t& lds
     return q;
 }
 #if !defined(__HIPCC_RTC__)
+// LDS layout of a k_pt_pass launch (pt_kernels.hip): the parameter block with the offsets filled in, the dynamic LDS size, the grid
+PtParams pt_pass_layout(const PtParams& p, size_t& lds_bytes, uint32_t& blocks);
+hipError_t launch_pt_pass_inst(const PtParams& p, hipStream_t stream);  // pt_inst_kernels.hip: scenes kept as meshes + instances
 // spec_fn: the per-scene kernel of the session (host/specialise.cpp) instead of the precompiled instantiation, or nullptr
 hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream, hipFunction_t spec_fn = nullptr);
 hipError_t launch_gpt_sample(const PtParams& p, const GptParams& g, hipStream_t stream);

@@ -156,20 +156,20 @@ hipError_t launch_probe_material(const PtParams& p, uint32_t material, uint32_t 
     hipLaunchKernelGGL(k_probe_material, dim3((n + 127) / 128), dim3(128), lds, stream, q, material, n, uv, out);
     return hipGetLastError();
 }
-hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream, hipFunction_t spec_fn) {
-    uint32_t blocks = (p.n_items + 255u) / 256u;
-    if (blocks == 0) return hipSuccess;
+// Dynamic LDS of a k_pt_pass launch and where its blocks start: [traversal stacks][staged tables][triangle records (WALK 1)][node
+// tile][park columns][carry columns][blue-noise columns (pmj02bn)][graph values]. Shared by the precompiled kernels, the per-scene
+// kernels and the instanced-scene kernels (pt_inst_kernels.hip).
+PtParams pt_pass_layout(const PtParams& p, size_t& lds, uint32_t& blocks) {
+    blocks = (p.n_items + 255u) / 256u;
     const bool fd = p.force_diffuse != 0, tex = p.sc.tex.nodes != nullptr;
-    const bool bvh = p.sc.bvh_nodes != nullptr;
-    size_t lds;
-    // dynamic LDS of the launch: [traversal stacks][staged tables][triangle records (WALK 1)][node tile][park columns][carry columns][blue-noise columns (pmj02bn)][graph values]
+    const bool bvh = p.sc.bvh_nodes != nullptr, inst = p.sc.in2.on != 0;
     const PtLdsPlan plan = pt_lds_plan(bvh, fd, tex, p.defer_metal != 0, p.sc.n_tris);
     size_t base = (bvh ? p.sc.bvh_stack_depth * 256 * 4 : 0) + p.stage_total + plan.recs_bytes;
     base = (base + 15) & ~(size_t)15;
     PtParams pp = p;
     pp.tile_offset = (uint32_t)(base / 4);
     pp.sc.bvh_tile_nodes = 0;
-    if (plan.tile) {
+    if (plan.tile && !inst) {
         // what is left of the workgroup's share of the CU's LDS after the launch's other blocks
         const size_t other = base + plan.park_bytes + plan.carry_bytes + (tex ? (size_t)p.tex_slots * kTexValStride * sizeof(TexVal) : 0);
         const size_t budget = pt_lds_budget(tex) - 256;
@@ -180,7 +180,7 @@ hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream, hipFunction_t s
     pp.park_offset = (uint32_t)(base / 4);
     base += plan.park_bytes;
     pp.carry_offset = (uint32_t)(base / 4);
-    base += plan.carry_bytes;
+    base += inst ? 0 : plan.carry_bytes;
     pp.bn_offset = 0;
     {   // pmj02bn: the lanes' blue-noise columns, if the workgroup's share of the CU's LDS has room for them (exhaustive kernels of
         // small scenes: 24 KB next to ~13 KB of staged tables; the BVH kernels' traversal stacks leave none)
@@ -191,7 +191,16 @@ hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream, hipFunction_t s
             base += kBlueNoiseColumnBytes;
         }
     }
-    const PtParams q = with_tex_slots(pp, base, lds);
+    return with_tex_slots(pp, base, lds);
+}
+hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream, hipFunction_t spec_fn) {
+    if (p.sc.in2.on) return launch_pt_pass_inst(p, stream);  // meshes + instances: pt_inst_kernels.hip
+    size_t lds;
+    uint32_t blocks;
+    const PtParams q = pt_pass_layout(p, lds, blocks);
+    if (blocks == 0) return hipSuccess;
+    const bool fd = p.force_diffuse != 0, tex = p.sc.tex.nodes != nullptr;
+    const bool bvh = p.sc.bvh_nodes != nullptr;
     const bool stage = p.stage_total != 0;
     if (spec_fn) {  // the scene's own kernel (host/specialise.cpp): same parameter block, same LDS layout (p.tex_slots is 0: no value slots)
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)spec_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

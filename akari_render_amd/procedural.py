@@ -112,3 +112,76 @@ def sponza_like(target_tris: int = 10_000_000, seed: int = 1234, width: int = 19
     cam = abi.CameraData(c2w=c2w.T.reshape(16).astype(np.float32).copy(), fov=np.deg2rad(70.0), width=width, height=height)
     insts = [abi.InstanceData(0, list(range(6)), eye), abi.InstanceData(1, [6], eye)]
     return abi.SceneData([hall, light], insts, mats, cam)
+
+
+def instanced_forest(n_instances: int = 1000, tris_per_mesh: int = 100_000, seed: int = 77, width: int = 1920, height: int = 1080,
+                     n_meshes: int = 2, n_lanterns: int = 4) -> abi.SceneData:
+    """A field of `n_instances` copies of `n_meshes` "plants" (closed, lumpy, fluted blobs of ~`tris_per_mesh` triangles each, with
+    smooth corner normals, uvs and two material slots) on a displaced ground, under a sky-light quad. Transforms: a rotation about
+    a tilted axis, non-uniform scale, every fifth copy mirrored; the first `n_lanterns` copies carry an emissive material in slot 1.
+    The kind of scene the reference's accel is built for (mesh.rs:259-348: one `push_mesh` per instance) and a flattening scene
+    compiler cannot hold: 1000 x 100 k = 100 M instance-triangles. A pure function of its arguments."""
+    rng = np.random.default_rng(seed)
+    meshes = []
+    for mi in range(n_meshes):
+        segs = max(4, int(round(np.sqrt(tris_per_mesh))))
+        rings = max(3, int(round(tris_per_mesh / (2.0 * segs))) + 1)
+        th = np.linspace(0.0, np.pi, rings + 1)[:, None]
+        ph = (np.linspace(0.0, 2.0 * np.pi, segs + 1)[:-1])[None, :]
+        k = rng.random(8) * 2 * np.pi
+        r = 1.0 + 0.18 * np.sin(5 * ph + k[0]) * np.sin(3 * th + k[1]) + 0.08 * np.sin(17 * ph + 9 * th + k[2]) + 0.03 * np.sin(61 * ph + k[3]) * np.sin(47 * th + k[4])
+        r = r * (0.55 + 0.45 * np.sin(th) ** (0.5 + mi))  # plant 0 is round, the next ones more spindle-shaped
+        x, y, z = r * np.sin(th) * np.cos(ph), (1.0 + 0.6 * mi) * np.cos(th) * np.ones_like(ph), r * np.sin(th) * np.sin(ph)
+        verts = np.stack([x, y, z], -1).reshape(-1, 3).astype(np.float32)
+        vuv = np.stack([np.broadcast_to(ph / (2 * np.pi), x.shape), np.broadcast_to(th / np.pi, x.shape)], -1).reshape(-1, 2).astype(np.float32)
+        j, i = np.meshgrid(np.arange(rings), np.arange(segs), indexing="ij")
+        a, b = j * segs + i, j * segs + (i + 1) % segs
+        c, d = (j + 1) * segs + (i + 1) % segs, (j + 1) * segs + i
+        t1 = np.stack([a, b, c], -1)[1:].reshape(-1, 3)      # (the first ring's upper triangles are degenerate at the pole: left out)
+        t2 = np.stack([a, c, d], -1)[:-1].reshape(-1, 3)     # (and the last ring's lower ones)
+        idx = np.concatenate([t1, t2]).astype(np.uint32)
+        idx = idx[np.argsort(_hash_u32(np.arange(idx.shape[0]) + 977 * mi), kind="stable")]  # exporter order is not spatial order
+        fn = np.cross(verts[idx[:, 1]] - verts[idx[:, 0]], verts[idx[:, 2]] - verts[idx[:, 0]]).astype(np.float64)
+        vn = np.zeros((verts.shape[0], 3))
+        for kk in range(3):
+            np.add.at(vn, idx[:, kk], fn)
+        vn /= np.maximum(np.linalg.norm(vn, axis=1, keepdims=True), 1e-30)
+        slots = (_hash_u32(np.arange(idx.shape[0]) // 64 + 31 * mi) % 5 == 0).astype(np.uint32)  # patches of 64 triangles in slot 1
+        meshes.append(abi.MeshData(vertices=verts, indices=idx, material_slots=slots, normals=vn[idx].astype(np.float32), uvs=vuv[idx].astype(np.float32)))
+    side = int(np.ceil(np.sqrt(n_instances)))
+    extent = 2.6 * side
+    gp, gi = _grid(64, 64, lambda u, v: np.stack([extent * (u - 0.5) * 1.3, 0.15 * np.sin(9 * u) * np.cos(7 * v), extent * (v - 0.5) * 1.3], 1), flip=True)
+    ground = abi.MeshData(vertices=gp, indices=gi)
+    lq = np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], dtype=np.float32) * np.float32(0.35 * extent) + np.array([0, 0.55 * extent, 0], dtype=np.float32)
+    sky = abi.MeshData(vertices=lq, indices=np.array([[0, 1, 2], [0, 2, 3]], dtype=np.uint32))
+    meshes += [ground, sky]
+    mats = [
+        abi.MaterialData(base_color=(0.45, 0.4, 0.3), roughness=0.9, ior=1.45, specular_ior_level=0.5),     # 0 ground
+        abi.MaterialData(base_color=(0.8, 0.8, 0.8), ior=1.0, specular_ior_level=0.0, emission_color=(6.0, 6.5, 8.0), emission_strength=1.0),  # 1 sky
+        abi.MaterialData(base_color=(0.15, 0.5, 0.2), roughness=0.6, ior=1.45, specular_ior_level=0.5),     # 2 leaf
+        abi.MaterialData(base_color=(0.45, 0.3, 0.15), roughness=0.8, ior=1.45, specular_ior_level=0.3),    # 3 bark
+        abi.MaterialData(base_color=(0.7, 0.75, 0.3), roughness=0.35, ior=1.5, specular_ior_level=0.5, coat_weight=0.5, coat_roughness=0.1, coat_ior=1.5),  # 4 waxy
+        abi.MaterialData(base_color=(0.9, 0.8, 0.5), roughness=0.25, metallic=1.0, ior=1.5),                # 5 brass ornament
+        abi.MaterialData(base_color=(0.5, 0.5, 0.5), ior=1.0, specular_ior_level=0.0, emission_color=(9.0, 5.0, 2.0), emission_strength=1.0),  # 6 lantern
+    ]
+    eye = np.eye(4, dtype=np.float32)
+    insts = [abi.InstanceData(n_meshes, [0], eye.T.reshape(16).copy()), abi.InstanceData(n_meshes + 1, [1], eye.T.reshape(16).copy())]
+    for kk in range(n_instances):
+        gx, gz = kk % side, kk // side
+        ax = np.array([0.25 * (rng.random() - 0.5), 1.0, 0.25 * (rng.random() - 0.5)])
+        ax /= np.linalg.norm(ax)
+        ang = rng.random() * 2 * np.pi
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+        S = np.diag(0.6 + 0.7 * rng.random(3))
+        if kk % 5 == 4:
+            S[2, 2] = -S[2, 2]
+        M = np.eye(4)
+        M[:3, :3] = R @ S
+        M[:3, 3] = [(gx + 0.5 + 0.6 * (rng.random() - 0.5)) * 2.6 - 0.5 * extent, 1.2 * S[1, 1] + 0.2, (gz + 0.5 + 0.6 * (rng.random() - 0.5)) * 2.6 - 0.5 * extent]
+        slot1 = 6 if kk < n_lanterns else (3, 4, 5)[kk % 3]
+        insts.append(abi.InstanceData(kk % n_meshes, [2, slot1], M.astype(np.float32).T.reshape(16).copy()))
+    ca = -0.45
+    c2w = np.array([[1, 0, 0, 0], [0, np.cos(ca), -np.sin(ca), 0.32 * extent], [0, np.sin(ca), np.cos(ca), 0.62 * extent], [0, 0, 0, 1]], dtype=np.float32)
+    cam = abi.CameraData(c2w=c2w.T.reshape(16).copy(), fov=0.9, width=width, height=height)
+    return abi.SceneData(meshes, insts, mats, cam)

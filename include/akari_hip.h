@@ -275,8 +275,9 @@ typedef struct {
     uint32_t width, height;
     uint32_t n_instances, n_triangles, n_materials, n_lights;
     uint32_t n_bvh_nodes;     /* 0 when the scene uses the exhaustive small-scene intersector */
-    uint32_t uses_bvh;
-    uint64_t device_bytes;    /* HBM held by the scene */
+    uint32_t uses_bvh;        /* 0 exhaustive small-scene intersector, 1 one tree over the flattened triangles, 2 meshes + instances
+                               * (a tree over the instances, one per mesh; option "instancing") */
+    uint64_t device_bytes;    /* HBM held by the scene (a host-only scene: what its upload would take) */
     uint32_t node_bytes;      /* bytes read per BVH node visit (64: 6-wide compressed node = one sector), 0 without a BVH */
     uint32_t node_stride_bytes; /* distance between nodes in memory */
     uint32_t tri_bytes;       /* bytes read per triangle test: 48 (exhaustive path) or 64 (BVH path: record + id) */
@@ -318,7 +319,14 @@ typedef enum {
     AKR_ARRAY_TEX_NODES = 13,    /* pruned, slot-allocated node lists, 32 B each */
     AKR_ARRAY_TEX_IMAGES = 14,   /* image headers, 32 B each */
     AKR_ARRAY_TEX_TEXELS = 15,   /* u32[] texel words of all images */
-    AKR_ARRAY_MAT_INPUTS = 16    /* raw inputs per material = akr_material_desc, 104 B each */
+    AKR_ARRAY_MAT_INPUTS = 16,   /* raw inputs per material = akr_material_desc, 104 B each */
+    /* a scene kept as meshes + instances (akr_scene_info.uses_bvh == 2; csrc/host/scene_inst.cpp, empty otherwise). AKR_ARRAY_BVH_NODES
+     * then holds the top-level tree over the instances followed by every mesh's own tree; WOOP / TRI_GID / SHADE are empty */
+    AKR_ARRAY_INST_LEAVES = 17,  /* f32[16 * instances with triangles] in top-level order: world->object rows | tree, mesh, instance, first id */
+    AKR_ARRAY_MESH_TRIS = 18,    /* f32[16 * mesh triangles] object-space vertices and uvs in each mesh's traversal order */
+    AKR_ARRAY_MESH_POS = 19,     /* u32[mesh triangles] mesh order -> position in MESH_TRIS */
+    AKR_ARRAY_MESH_META = 20,    /* u32[mesh triangles] material slot | flags << 30 */
+    AKR_ARRAY_MESH_NORMALS = 21  /* f32[24 * mesh triangles] corner normals / tangents (empty if no mesh has any) */
 } akr_array_id;
 AKR_API int32_t akr_scene_get_array(const akr_scene *scene, int32_t which, const void **ptr, uint64_t *bytes);
 
@@ -630,6 +638,12 @@ AKR_API const char *akr_version(void);
  *   "max_fused_passes" (no environment hook)     most passes one launch of akr_pt_passes fuses: 0 adaptive, else 1..64
  *   "wf_sort"      (AKR_WF_SORT=1)          wavefront schedule: the ray queues are sorted by (Morton code of the origin, octant of the
  *                                           direction) before every trace launch (films unchanged; measurement in DESIGN.md)
+ *   "instancing"   (AKR_INSTANCING=v)       scenes in which a mesh has several instances: -1 the library decides (kept as meshes +
+ *                                           instances -- a tree over the instances and one per mesh in object space, nothing stored per
+ *                                           instance-triangle -- when the flattened records would pass 8 GB or 48 M triangles), 0 always
+ *                                           flattened, 1 kept as meshes + instances whenever a mesh is shared. Films are the same bit for
+ *                                           bit either way. Such a scene renders with akr_pt_* only: aov / gpt / mcmc_opt sessions and the
+ *                                           probes need the flattened records and fail with AKR_ERR_UNSUPPORTED; "wavefront" is ignored. A singular instance transform means flattening whatever the option says.
  * Values out of an option's range fail with AKR_ERR_INVALID_ARGUMENT.
  * A session reads the options once, when it begins (akr_pt_begin / akr_gpt_begin / ...): a later akr_option_set does not change it.
  * "wavefront" = 1 on a scene without a BVH renders with the megakernel. Unknown names fail with AKR_ERR_INVALID_ARGUMENT. */

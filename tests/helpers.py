@@ -437,3 +437,98 @@ def check_against_mt_f64(world_vertices, rays, hit, gid, tuv, mt_gid, mt, mt_own
         bad += int((~(near | edge)).sum())
     out["only_f32"], out["only_f64"], out["other_triangle"], out["unexplained"] = int(only_f32.sum()), int(only_f64.sum()), int(other.sum()), bad
     return out
+
+
+# ---------------------------------------------------------------------------------------------- instanced scenes
+def instanced_scene(n_inst=12, n=6, width=48, height=48, seed=5, with_normals=True, with_uvs=True, mirror=True, emissive_instances=1,
+                    alpha=False, textured=False) -> abi.SceneData:
+    """`n_inst` copies of one bumpy blob (a closed latitude/longitude mesh of 2 n (2n - 1)... triangles, two material slots, corner
+    normals, uvs) with rotated, non-uniformly scaled and (every third) mirrored transforms, over a floor quad, under a light quad.
+    `emissive_instances` of the copies carry an emissive material in slot 1 (lights on an instanced mesh)."""
+    rng = np.random.default_rng(seed)
+    # the blob: rings x segments grid on a sphere with a radial bump
+    rings, segs = n, 2 * n
+    th = np.linspace(0.0, np.pi, rings + 1, dtype=np.float32)
+    ph = np.linspace(0.0, 2.0 * np.pi, segs + 1, dtype=np.float32)[:-1]
+    bump = (1.0 + 0.25 * rng.random((rings + 1, segs))).astype(np.float32)
+    bump[0, :] = bump[0, 0]
+    bump[-1, :] = bump[-1, 0]
+    verts = np.array([[bump[j, i] * np.sin(th[j]) * np.cos(ph[i]), bump[j, i] * np.cos(th[j]), bump[j, i] * np.sin(th[j]) * np.sin(ph[i])]
+                      for j in range(rings + 1) for i in range(segs)], dtype=np.float32)
+    vuv = np.array([[i / segs, j / rings] for j in range(rings + 1) for i in range(segs)], dtype=np.float32)
+    idx = []
+    for j in range(rings):
+        for i in range(segs):
+            a, b = j * segs + i, j * segs + (i + 1) % segs
+            c, d = (j + 1) * segs + (i + 1) % segs, (j + 1) * segs + i
+            if j > 0:
+                idx.append([a, b, c])
+            if j < rings - 1:
+                idx.append([a, c, d])
+    idx = np.array(idx, dtype=np.uint32)
+    slots = (rng.random(idx.shape[0]) < 0.35).astype(np.uint32)
+    normals = None
+    if with_normals:
+        vn = np.zeros_like(verts)
+        for t in idx:
+            fn = np.cross(verts[t[1]] - verts[t[0]], verts[t[2]] - verts[t[0]])
+            for k in t:
+                vn[k] += fn
+        vn /= np.maximum(np.linalg.norm(vn, axis=1, keepdims=True), 1e-20)
+        normals = vn[idx].astype(np.float32)
+    uvs = vuv[idx].astype(np.float32) if with_uvs else None
+    blob = abi.MeshData(vertices=verts, indices=idx, material_slots=slots, normals=normals, uvs=uvs)
+    quad = np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], dtype=np.float32)
+    floor = abi.MeshData(vertices=quad * np.float32(6.0), indices=np.array([[0, 2, 1], [0, 3, 2]], dtype=np.uint32))
+    light = abi.MeshData(vertices=quad * np.float32(1.5) + np.array([0, 6.0, 0], dtype=np.float32), indices=np.array([[0, 1, 2], [0, 2, 3]], dtype=np.uint32))
+    mats = [
+        abi.MaterialData(base_color=(0.7, 0.65, 0.6), roughness=0.7, ior=1.45, specular_ior_level=0.5),                       # 0 floor
+        abi.MaterialData(base_color=(0.8, 0.8, 0.8), ior=1.0, specular_ior_level=0.0, emission_color=(9.0, 8.0, 7.0), emission_strength=1.0),  # 1 light
+        abi.MaterialData(base_color=(0.2, 0.6, 0.3), roughness=0.5, ior=1.45, specular_ior_level=0.5),                        # 2 blob a
+        abi.MaterialData(base_color=(0.9, 0.85, 0.6), roughness=0.2, metallic=1.0, ior=1.5),                                  # 3 blob b
+        abi.MaterialData(base_color=(0.6, 0.3, 0.2), roughness=0.4, ior=1.45, coat_weight=0.6, coat_roughness=0.1, coat_ior=1.5),  # 4 blob c
+        abi.MaterialData(base_color=(0.5, 0.5, 0.5), ior=1.0, specular_ior_level=0.0, emission_color=(2.0, 3.0, 4.0), emission_strength=1.0),  # 5 glow
+    ]
+    if alpha:
+        mats[2].base_alpha = 0.5
+    images = []
+    if textured:  # slot 0: byte image with holes (alpha cut-out) through a mapping; coat material: normal map; glow: textured emission
+        N = abi.NodeData
+        img8 = rng.integers(0, 256, size=(16, 24, 4), dtype=np.uint8)
+        img8[:, :, 3] = np.where(rng.random((16, 24)) < 0.3, 0, 255).astype(np.uint8)
+        imgf = rng.random((8, 8, 4)).astype(np.float32)
+        imgf[:, :, 2] = 0.5 + 0.5 * imgf[:, :, 2]
+        imgf[:, :, 3] = 1.0
+        img_e = (rng.random((4, 4, 4)) * 5.0).astype(np.float32)
+        img_e[:, :, 3] = 1.0
+        images = [abi.ImageData(img8, abi.TEX_FILTER_LINEAR, abi.TEX_REPEAT), abi.ImageData(imgf, abi.TEX_FILTER_LINEAR, abi.TEX_MIRROR),
+                  abi.ImageData(img_e, abi.TEX_FILTER_NEAREST, abi.TEX_REPEAT)]
+        mats[2].graph = abi.GraphData([
+            N(abi.NODE_TEXCOORDS), N(abi.NODE_EXTRACT, (0, abi.FIELD_UV)), N(abi.NODE_CONST, (), (0.125, -0.25, 0.0)), N(abi.NODE_CONST, (), (3.0, 2.0, 1.0)),
+            N(abi.NODE_MAPPING, (1, 2, 3, abi.MAPPING_POINT)), N(abi.NODE_IMAGE, (0, 4, 1)), N(abi.NODE_SPECTRAL_UPLIFT, (5,))], {"base_color": 6})
+        mats[4].graph = abi.GraphData([
+            N(abi.NODE_IMAGE, (1, abi.NODE_NONE, 0)), N(abi.NODE_CONST, (), (0.8, 0.0, 0.0)), N(abi.NODE_NORMAL_MAP, (0, 1)),
+            N(abi.NODE_RGB, (), (0.9, 0.5, 0.2)), N(abi.NODE_SPECTRAL_UPLIFT, (3,)), N(abi.NODE_RGB, (), (0.1, 0.2, 0.5)), N(abi.NODE_SPECTRAL_UPLIFT, (5,)),
+            N(abi.NODE_CONST, (), (6.0, 0.0, 0.0)), N(abi.NODE_CHECKERBOARD, (abi.NODE_NONE, 7, 4, 6))], {"normal": 2, "base_color": 8})
+        mats[5].graph = abi.GraphData([N(abi.NODE_IMAGE, (2, abi.NODE_NONE, 0)), N(abi.NODE_SPECTRAL_UPLIFT, (0,))], {"emission_color": 1})
+        mats[5].emission_strength = 1.5
+    eye = np.eye(4, dtype=np.float32)
+    insts = [abi.InstanceData(1, [0], eye.T.reshape(16).copy()), abi.InstanceData(2, [1], eye.T.reshape(16).copy())]
+    for k in range(n_inst):
+        ax = rng.normal(size=3)
+        ax /= np.linalg.norm(ax)
+        ang = rng.random() * 2 * np.pi
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+        S = np.diag(0.35 + 0.5 * rng.random(3))
+        if mirror and k % 3 == 2:
+            S[0, 0] = -S[0, 0]
+        M = np.eye(4)
+        M[:3, :3] = R @ S
+        M[:3, 3] = [(rng.random() - 0.5) * 7.0, 0.6 + rng.random() * 2.5, (rng.random() - 0.5) * 7.0]
+        slot1 = 5 if k < emissive_instances else (3 if k % 2 else 4)
+        insts.append(abi.InstanceData(0, [2, slot1], M.astype(np.float32).T.reshape(16).copy()))
+    ca = np.float32(-0.35)
+    c2w = np.array([[1, 0, 0, 0], [0, np.cos(ca), -np.sin(ca), 4.0], [0, np.sin(ca), np.cos(ca), 9.0], [0, 0, 0, 1]], dtype=np.float32)
+    cam = abi.CameraData(c2w=c2w.T.reshape(16).copy(), fov=0.8, width=width, height=height)
+    return abi.SceneData([blob, floor, light], insts, mats, cam, images=images)

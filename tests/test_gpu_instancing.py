@@ -1,0 +1,159 @@
+"""The two-level acceleration structure (csrc/host/scene_inst.cpp, csrc/device/dinst_trav.h) against the oracle, bit for bit.
+
+The reference keeps meshes and instances apart (mesh.rs:259-348) and evaluates a hit from object-space buffers and the instance's
+transform (mesh.rs:487-654). The oracle restates that per-hit arithmetic over a FLATTENED scene; a scene kept as meshes + instances
+computes the same records at the candidate. Both must give the same film floats -- and the flattening compiler's as well."""
+import os
+
+import numpy as np
+import pytest
+
+from akari_render_amd import abi, capi, distributed, procedural
+from oracle import pyoracle
+from tests.helpers import instanced_scene, make_config, n_bit_diff
+
+pytestmark = pytest.mark.gpu
+
+
+def _table(root):
+    return np.fromfile(os.path.join(root, "tests", "golden", "ggx_dielectric_s.f32"), dtype=np.float32)
+
+
+def _index_states(w, h):
+    st = np.zeros(2 * w * h, dtype=np.uint64)
+    st[0::2] = 0xFFFFFFFF
+    st[1::2] = (np.arange(w * h, dtype=np.uint64) % np.uint64(w)) | ((np.arange(w * h, dtype=np.uint64) // np.uint64(w)) << np.uint64(32))
+    return st
+
+
+def _render(ctx, sd, cfg, mode):
+    with capi.options(instancing=mode):
+        scene = capi.Scene(ctx, sd)
+        assert scene.info().uses_bvh == (2 if mode == 1 else 1)
+        film = capi.Film(ctx, sd.camera.width, sd.camera.height)
+        st = capi.pt_render(ctx, scene, cfg, film)
+    return film.read(), st, scene
+
+
+def _oracle(sd, cfg, bvh=False):
+    pyoracle.set_pmj_tables(*capi.host_pmj02bn_tables())
+    w, h = sd.camera.width, sd.camera.height
+    return pyoracle.OracleScene(sd, bvh=bvh).render(cfg, states=_index_states(w, h) if cfg.sampler_type != 0 else None)
+
+
+CASES = {
+    "plain": (dict(n_inst=6, n=4, with_normals=False, with_uvs=False, mirror=False, emissive_instances=0), dict()),
+    "mirrored": (dict(n_inst=9, n=4, with_normals=False, with_uvs=False, emissive_instances=0), dict()),
+    "normals_uvs": (dict(n_inst=9, n=5, emissive_instances=0), dict()),
+    "lights_on_instances": (dict(n_inst=12, n=6, emissive_instances=3), dict()),
+    "force_diffuse": (dict(n_inst=12, n=6, emissive_instances=1), dict(force_diffuse=1)),
+    "alpha": (dict(n_inst=12, n=6, emissive_instances=1, alpha=True), dict()),
+    "textured": (dict(n_inst=12, n=6, emissive_instances=2, textured=True), dict()),
+    "textured_fd": (dict(n_inst=12, n=6, emissive_instances=2, textured=True), dict(force_diffuse=1)),
+    "pmj02bn": (dict(n_inst=12, n=6, emissive_instances=1), dict(sampler_type=abi.SAMPLER_PMJ02BN, sampler_seed=3)),
+    "sobol_textured": (dict(n_inst=12, n=6, emissive_instances=1, textured=True), dict(sampler_type=abi.SAMPLER_SOBOL, sampler_seed=11)),
+    "ragged_passes": (dict(n_inst=12, n=6, emissive_instances=1), dict(spp=11, spp_per_pass=4)),
+    "deep": (dict(n_inst=40, n=12, emissive_instances=2), dict(max_depth=16, rr_depth=8)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_kept_scene_matches_oracle_and_flattened_scene(ctx, root, case):
+    skw, ckw = CASES[case]
+    sd = instanced_scene(width=40, height=32, **skw)
+    sd.ggx_table = _table(root)
+    cfg = make_config(**{**dict(spp=8, spp_per_pass=8, max_depth=8), **ckw})
+    kept, kst, _ = _render(ctx, sd, cfg, 1)
+    flat, fst, _ = _render(ctx, sd, cfg, 0)
+    o, ost = _oracle(sd, cfg)
+    assert np.all(np.isfinite(kept))
+    assert n_bit_diff(kept, o) == 0, f"{n_bit_diff(kept, o)} of {o.size} film floats differ from the oracle's"
+    assert n_bit_diff(kept, flat) == 0
+    for k in ("n_samples", "n_closest", "n_shadow", "n_shaded"):
+        assert kst[k] == ost[k] == fst[k], k
+
+
+def test_tile_shards_of_a_kept_scene_add_up(ctx, root):
+    """Tile shards (what each GPU of a multi-GPU render gets) of a kept scene: their sum is the whole frame's film, bit for bit."""
+    sd = instanced_scene(width=64, height=48, n_inst=20, n=8, emissive_instances=2)
+    sd.ggx_table = _table(root)
+    base = make_config(spp=4, spp_per_pass=4, max_depth=8)
+    whole, _, scene = _render(ctx, sd, base, 1)
+    acc = np.zeros_like(whole)
+    for r in range(3):
+        film = capi.Film(ctx, 64, 48)
+        capi.pt_render(ctx, scene, distributed.shard_config(make_config(spp=4, spp_per_pass=4, max_depth=8), r, 3, 8, 8), film)
+        part = film.read()
+        assert not np.any((acc != 0) & (part != 0))
+        acc += part
+    assert n_bit_diff(acc, whole) == 0
+
+
+def test_other_integrators_and_probes_refuse_a_kept_scene(ctx, root):
+    sd = instanced_scene(width=16, height=16, n_inst=4)
+    with capi.options(instancing=1):
+        scene = capi.Scene(ctx, sd)
+    film = capi.Film(ctx, 16, 16)
+    rays = np.zeros((4, 8), dtype=np.float32)
+    rays[:, 5] = -1.0
+    rays[:, 7] = 1e30
+    gcfg = abi.GptConfig.default() if hasattr(abi.GptConfig, "default") else None
+    calls = [lambda: capi.aov_render(ctx, scene, abi.AovConfig.default(), film), lambda: capi.probe_intersect(ctx, scene, rays)]
+    if gcfg is not None:
+        calls.append(lambda: capi.gpt_render(ctx, scene, gcfg, film))
+    for call in calls:
+        with pytest.raises(capi.AkariError) as ei:
+            call()
+        assert ei.value.code == capi.ERR_UNSUPPORTED, str(ei.value)
+    with capi.options(wavefront=1):  # ignored: the megakernel renders
+        f2 = capi.Film(ctx, 16, 16)
+        st = capi.pt_render(ctx, scene, make_config(spp=2, spp_per_pass=2), f2)
+        assert st["n_samples"] == 16 * 16 * 2
+
+
+def test_forest_of_ten_million_instance_triangles_on_a_tile_shard(ctx, root):
+    """1000 instances x 10 k triangles, oracle with its checker-side tree (pinned to the exhaustive loop in test_oracle_accel.py and
+    test_gpu_fullsize.py), one tile shard of a 512x288 frame."""
+    sd = procedural.instanced_forest(1000, 10_000, width=512, height=288)
+    sd.ggx_table = _table(root)
+    cfg = distributed.shard_config(make_config(spp=8, spp_per_pass=8, max_depth=8), 5, 64, 8, 8)
+    scene = capi.Scene(ctx, sd)  # the automatic mode: 10 M triangles would still be flattened
+    assert scene.info().uses_bvh == 1
+    kept, kst, ks = _render(ctx, sd, cfg, 1)
+    assert ks.info().device_bytes < 32 << 20
+    film = capi.Film(ctx, 512, 288)
+    capi.pt_render(ctx, scene, cfg, film)
+    assert n_bit_diff(kept, film.read()) == 0
+    o, ost = _oracle(sd, cfg, bvh=True)
+    assert n_bit_diff(kept, o) == 0
+    for k in ("n_samples", "n_closest", "n_shadow", "n_shaded"):
+        assert kst[k] == ost[k], k
+
+
+@pytest.mark.parametrize("name", ["independent", "fd_sobol"])
+def test_forest_of_a_hundred_million_instance_triangles(ctx, root, name):
+    """1000 instances x 100 k triangles load in under 1 GB and a tile shard is the oracle's bit for bit. The oracle's
+    film of this shard is a committed fixture (tools/make_forest_golden.py: the oracle flattens the scene -- 12 GB and minutes of
+    tree building on the CPU, once)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_forest_golden", os.path.join(root, "tools", "make_forest_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    gold = np.load(os.path.join(root, "tests", "golden", "forest_1000x100k_shard.npz"))
+    sd = procedural.instanced_forest(1000, 100_000, **mk.FOREST)
+    assert sd.n_triangles() == int(gold["n_triangles"][0])
+    sd.ggx_table = _table(root)
+    scene = capi.Scene(ctx, sd)
+    info = scene.info()
+    assert info.uses_bvh == 2 and info.device_bytes < 1 << 30
+    w, h = mk.FOREST["width"], mk.FOREST["height"]
+    cfg = distributed.shard_config(make_config(**mk.CONFIGS[name]), *mk.SHARD)
+    film = capi.Film(ctx, w, h)
+    st = capi.pt_render(ctx, scene, cfg, film)
+    g = film.read().view(np.uint32)
+    want = np.zeros(7 * w * h, dtype=np.uint32)
+    want[gold[name + "_idx"]] = gold[name + "_bits"]
+    nd = int(np.count_nonzero(g != want))
+    assert nd == 0, f"{nd} film floats differ from the oracle's"
+    assert [st[k] for k in ("n_samples", "n_closest", "n_shadow", "n_shaded")] == [int(x) for x in gold[name + "_stats"]]

@@ -1,0 +1,108 @@
+"""Scenes kept as meshes + instances (csrc/host/scene_inst.cpp): host side. The reference keeps every scene that way
+(mesh.rs:259-348: one `push_mesh(mesh, transform)` per instance into the accel); the flattening compiler is this build's choice for
+scenes that fit, and must stay the default for them."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from akari_render_amd import capi, procedural
+from tests.helpers import grid_scene, instanced_scene
+
+INST_ARRAYS = (capi.ARRAY_BVH_NODES, capi.ARRAY_INST_LEAVES, capi.ARRAY_MESH_TRIS, capi.ARRAY_MESH_POS, capi.ARRAY_MESH_META, capi.ARRAY_MESH_NORMALS,
+               capi.ARRAY_INSTANCES, capi.ARRAY_AREA_ENTRIES, capi.ARRAY_AREA_PDF, capi.ARRAY_LIGHT_ENTRIES, capi.ARRAY_LIGHT_PDF)
+
+
+def test_small_and_unshared_scenes_stay_flattened(hip_lib, cbox_path):
+    """The automatic mode flattens whatever fits: scenes/cbox, a scene whose meshes are used once, a small scene with a shared mesh."""
+    assert capi.get_option("instancing") == -1
+    assert capi.Scene(None, cbox_path).info().uses_bvh == 0
+    assert capi.Scene(None, grid_scene(n=12)).info().uses_bvh == 1
+    assert capi.Scene(None, instanced_scene()).info().uses_bvh == 1
+    with capi.options(instancing=1):
+        assert capi.Scene(None, cbox_path).info().uses_bvh == 0          # no mesh is shared: nothing to keep
+        assert capi.Scene(None, grid_scene(n=12)).info().uses_bvh == 1
+        assert capi.Scene(None, instanced_scene()).info().uses_bvh == 2
+    with pytest.raises(capi.AkariError):
+        capi.set_option("instancing", 2)
+    with pytest.raises(capi.AkariError):
+        capi.set_option("instancing", -2)
+
+
+def test_kept_scene_has_the_flattened_scene_s_lights_and_counts(hip_lib):
+    sd = instanced_scene(n_inst=12, emissive_instances=2)
+    flat = capi.Scene(None, sd)
+    with capi.options(instancing=1):
+        kept = capi.Scene(None, sd)
+    a, b = flat.info(), kept.info()
+    assert (a.n_triangles, a.n_instances, a.n_lights, a.n_materials) == (b.n_triangles, b.n_instances, b.n_lights, b.n_materials)
+    assert b.uses_bvh == 2 and b.node_bytes == 64 and b.tri_bytes == 64
+    for arr, dt in ((capi.ARRAY_LIGHT_ENTRIES, np.uint32), (capi.ARRAY_LIGHT_PDF, np.float32), (capi.ARRAY_AREA_ENTRIES, np.uint32),
+                    (capi.ARRAY_AREA_PDF, np.float32), (capi.ARRAY_INST_TRI_OFFSET, np.uint32), (capi.ARRAY_MATERIALS, np.uint32)):
+        assert np.array_equal(flat.array(arr, dt), kept.array(arr, dt)), arr
+    for l in range(a.n_lights):
+        assert flat.light(l) == kept.light(l)
+    # the instance records agree in everything the flattened scene defines (the kept scene uses five spare words: dinst_trav.h)
+    fi, ki = flat.array(capi.ARRAY_INSTANCES, np.uint32).reshape(-1, 32), kept.array(capi.ARRAY_INSTANCES, np.uint32).reshape(-1, 32)
+    spare = [7, 11, 15, 23, 27]
+    keep = [k for k in range(32) if k not in spare]
+    assert np.array_equal(fi[:, keep], ki[:, keep])
+    # nothing per instance-triangle
+    assert kept.array(capi.ARRAY_WOOP, np.uint32).size == 0 and kept.array(capi.ARRAY_SHADE, np.uint32).size == 0
+    n_mesh_tris = sum(m.indices.shape[0] for m in sd.meshes)
+    assert kept.array(capi.ARRAY_MESH_TRIS, np.float32).size == 16 * n_mesh_tris
+    pos = kept.array(capi.ARRAY_MESH_POS, np.uint32)
+    assert pos.size == n_mesh_tris
+    # MESH_POS is a permutation inside each mesh, and MESH_TRIS holds the object-space vertices it points at
+    tris = kept.array(capi.ARRAY_MESH_TRIS, np.float32).reshape(-1, 16)
+    base = 0
+    for m in sd.meshes:
+        nt = m.indices.shape[0]
+        p = pos[base:base + nt]
+        assert np.array_equal(np.sort(p), np.arange(nt))
+        rec = tris[base + p]
+        v = np.asarray(m.vertices, dtype=np.float32)[np.asarray(m.indices)]
+        assert np.array_equal(rec[:, 0:3], v[:, 0]) and np.array_equal(rec[:, 4:7], v[:, 1]) and np.array_equal(rec[:, 8:11], v[:, 2])
+        assert np.array_equal(rec[:, 15].view(np.uint32), np.arange(nt, dtype=np.uint32))
+        base += nt
+
+
+def test_a_singular_transform_means_flattening(hip_lib):
+    sd = instanced_scene(n_inst=4)
+    t = np.asarray(sd.instances[3].transform, dtype=np.float32).reshape(4, 4).copy()
+    t[1, :3] = 0.0  # second column of the matrix (stored transposed): the copy is squashed into a plane
+    sd.instances[3].transform = t.reshape(16)
+    with capi.options(instancing=1):
+        assert capi.Scene(None, sd).info().uses_bvh == 1
+
+
+def test_bad_slots_are_reported_either_way(hip_lib):
+    sd = instanced_scene(n_inst=4)
+    sd.instances[-1].materials = [2]  # the blob uses slots 0 and 1
+    for mode in (0, 1):
+        with capi.options(instancing=mode):
+            with pytest.raises(capi.AkariError) as ei:
+                capi.Scene(None, sd)
+            assert "slot" in str(ei.value)
+
+
+def test_a_hundred_million_instance_triangles_take_megabytes(hip_lib, monkeypatch):
+    """1000 instances of two 100 k-triangle meshes: flattened, 21 GB of records; kept, under 1 GB -- in fact tens of MB,
+    compiled in seconds. The arrays do not depend on the host's thread count."""
+    sd = procedural.instanced_forest(1000, 100_000, width=64, height=36)
+    assert sd.n_triangles() > 99_000_000
+
+    def digest(threads):
+        monkeypatch.setenv("AKR_HOST_THREADS", str(threads))
+        sc = capi.Scene(None, sd)
+        i = sc.info()
+        assert i.uses_bvh == 2 and i.n_triangles == sd.n_triangles()
+        h = hashlib.sha256()
+        for arr in INST_ARRAYS:
+            h.update(sc.array(arr, np.uint32).tobytes())
+        return h.hexdigest(), i.device_bytes, i.bvh_depth, i.n_lights
+
+    one = digest(1)
+    assert one[1] < 64 << 20, one
+    assert one[2] <= 40 and one[3] == 5
+    assert digest(3) == one and digest(8) == one
