@@ -125,4 +125,34 @@ AKR_HD void share_plane_row(const float* ra, float* rb, const vec3 vb[3]) {
     rb[0] = ra[0]; rb[1] = ra[1]; rb[2] = ra[2]; rb[3] = ra[3];
 }
 
+
+// A cheap, CONSERVATIVE reject ahead of the exact test of a candidate (dinst_trav.h): Moeller-Trumbore in f32 on the world-space
+// vertices the exact test uses, with a bound on how far its t, u, v can be from the ones tri_test computes from the f64 Woop rows.
+// Returns false only when tri_test cannot accept; true = "undecided", the exact test decides. With eps = 2^-24 and 2-norms bounded
+// by 1-norms (M = |o| + |A| + |t||d| the magnitudes that cancel, L = the longer of the edges e1, e2, D = |d . n| = |det|):
+//   * tri_test: the rows are exact to eps per component (the f64 arithmetic is far below that), each 4-term fma chain loses
+//     <= 4 eps of its absolute sum; t = -(r2.o + c2) / (r2.d) is off by <= 5 eps M |n| / D, the hit point by 6 eps M |n||d| / D, and
+//     u = r0.P + c0 with |r0| = |e2| / |n| by <= 14 eps |e2| M |d| / D;
+//   * this function: edges and o - A are exact to eps per component, a cross product and a dot product on top lose <= 11 eps of
+//     |a||b||c|: u is off by <= 11 eps |e2||d| (|o - A| + |u||e1|) / D, the determinant by the fraction rho = 11 eps |e1||e2||d| / D;
+//   * a shared plane row (share_plane_row: odd triangles) moves the plane by <= `plane_shift` along its normal.
+// The sum, doubled: E below. Slivers and grazing rays make rho large: undecided. Every comparison is false on a NaN: undecided.
+AKR_HD bool tri_may_hit(vec3 o, vec3 d, vec3 A, vec3 B, vec3 C, float tmin, float tlimit, float plane_shift) {
+    const float eps = 5.9604645e-8f;
+    const vec3 e1 = B - A, e2 = C - A, tv = o - A;
+    const vec3 pv = cross(d, e2), qv = cross(tv, e1);
+    const float det = dot(e1, pv);
+    const float inv = 1.0f / det;
+    const float u = dot(tv, pv) * inv, v = dot(d, qv) * inv, t = dot(e2, qv) * inv;
+    const float l1 = (abs_f(e1.x) + abs_f(e1.y)) + abs_f(e1.z), l2 = (abs_f(e2.x) + abs_f(e2.y)) + abs_f(e2.z);
+    const float L = max_f(l1, l2), dn = (abs_f(d.x) + abs_f(d.y)) + abs_f(d.z);
+    const float M = ((abs_f(o.x) + abs_f(o.y)) + abs_f(o.z)) + ((abs_f(A.x) + abs_f(A.y)) + abs_f(A.z)) + abs_f(t) * dn;
+    const float k = 1.0f / abs_f(det);
+    const float rho = 11.0f * eps * L * L * dn * k;
+    const float E = 2.0f * L * dn * k * (eps * (25.0f * M + 11.0f * ((abs_f(u) + abs_f(v)) + 1.0f) * L) + plane_shift);
+    const float Et = 2.0f * L * L * k * (16.0f * eps * M + plane_shift) + 4.0f * (eps + rho) * abs_f(t);
+    const bool reject = (u < -E) | (v < -E) | (u + v > 1.0f + 2.0f * E) | (t + Et < tmin) | (t - Et > tlimit);
+    return !(reject & (rho < 0.25f));
+}
+
 }  // namespace akr

@@ -19,6 +19,12 @@ namespace akr {
 struct TravI : Trav {
     vec3 wo, wd;                 // the world-space ray (s.o / s.d are the current level's)
     uint32_t inst, node_off, tri_off, gid_base;  // current instance (kInvalid: TLAS), its BLAS's node offset, mesh triangle base, first gid
+    uint32_t leaf;                               // ... and its TLAS leaf record (what a carried traversal re-enters the instance from)
+#if defined(AKR_INST_PRETEST_CHECK)
+    float check_t;                               // >= 0: tri_may_hit rejected the pending candidate against this limit
+#endif
+    uint32_t pend_rec, pend_inst;                // a candidate that passed tri_may_hit and waits for the exact test: its record in mesh_tris
+                                                 // (kInvalid: none) and its instance
 };
 AKR_D void trav_set_ray(Trav& s, vec3 o, vec3 d) {
     s.o = o; s.d = d;
@@ -30,7 +36,20 @@ AKR_D void trav_set_ray(Trav& s, vec3 o, vec3 d) {
 AKR_D void trav_begin_inst(TravI& s, vec3 o, vec3 d, float tmin, float tmax, uint32_t ex0, uint32_t ex1) {
     trav_begin(s, o, d, tmin, tmax, ex0, ex1);
     s.wo = o; s.wd = d;
-    s.inst = kInvalid; s.node_off = 0; s.tri_off = 0; s.gid_base = 0;
+    s.inst = kInvalid; s.node_off = 0; s.tri_off = 0; s.gid_base = 0; s.leaf = kInvalid;
+    s.pend_rec = kInvalid; s.pend_inst = 0;
+#if defined(AKR_INST_PRETEST_CHECK)
+    s.check_t = -1.0f;
+#endif
+}
+
+// the ray into the object space of the instance of a TLAS leaf record (rows of the inverse transform | ids)
+AKR_D void trav_into_instance(TravI& s, uint4 w0, uint4 w1, uint4 w2, uint4 w3) {
+    s.inst = w3.z; s.node_off = w3.x; s.tri_off = w3.y; s.gid_base = w3.w;
+    const vec3 r0 = mk3(u2f(w0.x), u2f(w0.y), u2f(w0.z)), r1 = mk3(u2f(w1.x), u2f(w1.y), u2f(w1.z)), r2 = mk3(u2f(w2.x), u2f(w2.y), u2f(w2.z));
+    const vec3 oo = mk3(dot(r0, s.wo) + u2f(w0.w), dot(r1, s.wo) + u2f(w1.w), dot(r2, s.wo) + u2f(w2.w));
+    const vec3 od = mk3(dot(r0, s.wd), dot(r1, s.wd), dot(r2, s.wd));
+    trav_set_ray(s, oo, od);
 }
 
 // material of (instance record m, mesh triangle): mats[slots[prim]] (mesh.rs:508-521)
@@ -55,14 +74,58 @@ AKR_D bool alpha_test_inst(const DScene& sc, const float4* m, uint32_t inst, uin
     return alpha > h;
 }
 
-template <int MODE, bool TEX>
-AKR_D void trav_step_inst(const DScene& sc, TravI& s, uint32_t* __restrict__ stack, TraceCounters& cnt, bool any_rt = false) {
-    const bool any_hit = MODE == 2 ? any_rt : (MODE == 1);
+// The exact test of the pending candidate: its flattened record, computed here (dinst.h), then the flattened test on the world ray.
+template <bool TEX>
+AKR_D void resolve_pending(const DScene& sc, TravI& s, bool any_hit) {
+    const uint32_t inst = s.pend_inst;
+    const float4* m = sc.inst + (size_t)inst * INST_ROWS;
+    const float4* rec = sc.in2.mesh_tris + (size_t)s.pend_rec * 4;
+    s.pend_rec = kInvalid;
+    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+    const uint32_t tri_off = f2u(m[1].w), prim = f2u(q3.w), gid = f2u(m[5].w) + prim;
+    const vec3 c0 = xyz(m[0]), c1 = xyz(m[1]), c2 = xyz(m[2]), tr = xyz(m[3]);
+    const vec3 A = xf_point(c0, c1, c2, tr, xyz(q0)), B = xf_point(c0, c1, c2, tr, xyz(q1)), C = xf_point(c0, c1, c2, tr, xyz(q2));
+    float wr[12];
+    woop_precompute(A, B, C, wr);
+    if (prim & 1u) {  // the coplanar-neighbour rule: the even triangle's plane row, if this one lies in it
+        const float4* nb = sc.in2.mesh_tris + (size_t)(tri_off + sc.in2.mesh_pos[tri_off + prim - 1u]) * 4;
+        const vec3 na = xf_point(c0, c1, c2, tr, xyz(nb[0])), nbv = xf_point(c0, c1, c2, tr, xyz(nb[1])), nc = xf_point(c0, c1, c2, tr, xyz(nb[2]));
+        float ra[4];
+        woop_plane_row(na, nbv, nc, ra);
+        const vec3 vb[3] = {A, B, C};
+        share_plane_row(ra, wr + 8, vb);
+    }
+    float t, u, v;
+    bool h = tri_test(s.wo, s.wd, make_float4(wr[0], wr[1], wr[2], wr[3]), make_float4(wr[4], wr[5], wr[6], wr[7]), make_float4(wr[8], wr[9], wr[10], wr[11]), s.tmin, s.tmax,
+                      t, u, v);
+#if defined(AKR_INST_PRETEST_CHECK)
+    if (h && s.check_t >= 0.0f && t <= s.check_t) s.check_t = -2.0f;  // (trace_inst turns this into the overflow flag: the render fails)
+#endif
+    if (h && sc.has_alpha) h = alpha_test_inst<TEX>(sc, m, inst, prim, tri_off, q0, q1, q2, q3, u, v);
+    if (h) {
+        if (any_hit) {
+            s.best = gid;
+            s.T = 0; s.G = 0; s.sp = 0;  // any hit: done
+            s.active = false;
+        } else {
+            const bool better = (s.best == kInvalid) | (t < s.best_t) | ((t == s.best_t) & (gid < s.best));
+            if (better) { s.best_t = t; s.best_u = u; s.best_v = v; s.best = gid; }
+        }
+    }
+}
+
+// One step of one lane. Returns true when the lane found a second candidate for the exact test while one is pending: the candidate
+// is put back (its leaf bit set again) and the lane waits for trace_inst to resolve the pending one.
+template <bool TEX>
+AKR_D bool trav_step_inst(const DScene& sc, TravI& s, uint32_t* __restrict__ stack, TraceCounters& cnt) {
     const bool in_blas = s.inst != kInvalid;
     const bool do_leaf = s.T != 0;
+    bool blocked = false;
+    uint32_t leaf_bit = 0;
     const uint4* p;
     if (do_leaf) {
         const uint32_t b = (uint32_t)__builtin_ctz(s.T);
+        leaf_bit = b;
         s.T &= s.T - 1u;
         p = in_blas ? (const uint4*)sc.in2.mesh_tris + (size_t)(s.tri_off + s.tbase + b) * 4 : sc.in2.tlas_leaves + (size_t)(s.tbase + b) * 4;
     } else {
@@ -76,10 +139,10 @@ AKR_D void trav_step_inst(const DScene& sc, TravI& s, uint32_t* __restrict__ sta
                 s.tbase = stack[s.sp * 256u];
                 s.sp--;
                 s.G = stack[s.sp * 256u];
-                s.inst = kInvalid; s.node_off = 0; s.tri_off = 0;
+                s.inst = kInvalid; s.node_off = 0; s.tri_off = 0; s.leaf = kInvalid;
                 trav_set_ray(s, s.wo, s.wd);
                 s.active = (s.T != 0) | ((s.G >> 24) != 0) | (s.sp != 0);
-                return;
+                return false;
             }
             s.G = e;
         }
@@ -102,7 +165,9 @@ AKR_D void trav_step_inst(const DScene& sc, TravI& s, uint32_t* __restrict__ sta
                       "+v"(w2.z), "+v"(w2.w), "+v"(w3.x), "+v"(w3.y), "+v"(w3.z), "+v"(w3.w));
     if (do_leaf && !in_blas) {
         // ---- a TLAS leaf entry = an instance: remember where the TLAS traversal stands, take the ray into object space, start at the BLAS root
+#if !defined(AKR_INST_COUNT)
         cnt.nodes++;
+#endif
         if (s.sp + 3 <= sc.bvh_stack_depth) {
             stack[s.sp * 256u] = s.G; s.sp++;
             stack[s.sp * 256u] = s.tbase; s.sp++;
@@ -110,50 +175,45 @@ AKR_D void trav_step_inst(const DScene& sc, TravI& s, uint32_t* __restrict__ sta
         } else {
             cnt.overflow = 1;
         }
-        s.inst = w3.z; s.node_off = w3.x; s.tri_off = w3.y; s.gid_base = w3.w;
-        const vec3 r0 = mk3(u2f(w0.x), u2f(w0.y), u2f(w0.z)), r1 = mk3(u2f(w1.x), u2f(w1.y), u2f(w1.z)), r2 = mk3(u2f(w2.x), u2f(w2.y), u2f(w2.z));
-        const vec3 oo = mk3(dot(r0, s.wo) + u2f(w0.w), dot(r1, s.wo) + u2f(w1.w), dot(r2, s.wo) + u2f(w2.w));
-        const vec3 od = mk3(dot(r0, s.wd), dot(r1, s.wd), dot(r2, s.wd));
-        trav_set_ray(s, oo, od);
+        s.leaf = s.tbase + leaf_bit;
+        trav_into_instance(s, w0, w1, w2, w3);
         s.G = 1u << (24u + (s.octinv4 & 7u));  // the group {BLAS root}: base 0 (relative), slot 0
         s.T = 0; s.tbase = 0;
     } else if (do_leaf) {
-        // ---- a candidate triangle of the current instance: its flattened record, computed here (dinst.h), then the flattened test
+        // ---- a candidate triangle of the current instance: the conservative reject (dinst.h tri_may_hit) here; what it cannot decide
+        // waits in the lane's pending slot for the exact test, which trace_inst runs for many lanes at once
         cnt.tris++;
-        const float4 q0 = make_float4(u2f(w0.x), u2f(w0.y), u2f(w0.z), u2f(w0.w)), q1 = make_float4(u2f(w1.x), u2f(w1.y), u2f(w1.z), u2f(w1.w));
-        const float4 q2 = make_float4(u2f(w2.x), u2f(w2.y), u2f(w2.z), u2f(w2.w)), q3 = make_float4(u2f(w3.x), u2f(w3.y), u2f(w3.z), u2f(w3.w));
         const uint32_t prim = w3.w, gid = s.gid_base + prim;
         if ((gid != s.ex0) & (gid != s.ex1)) {
             const float4* m = sc.inst + (size_t)s.inst * INST_ROWS;
             const vec3 c0 = xyz(m[0]), c1 = xyz(m[1]), c2 = xyz(m[2]), tr = xyz(m[3]);
-            const vec3 A = xf_point(c0, c1, c2, tr, xyz(q0)), B = xf_point(c0, c1, c2, tr, xyz(q1)), C = xf_point(c0, c1, c2, tr, xyz(q2));
-            float wr[12];
-            woop_precompute(A, B, C, wr);
-            if (prim & 1u) {  // the coplanar-neighbour rule: the even triangle's plane row, if this one lies in it
-                const float4* nb = sc.in2.mesh_tris + (size_t)(s.tri_off + sc.in2.mesh_pos[s.tri_off + prim - 1u]) * 4;
-                const vec3 na = xf_point(c0, c1, c2, tr, xyz(nb[0])), nbv = xf_point(c0, c1, c2, tr, xyz(nb[1])), nc = xf_point(c0, c1, c2, tr, xyz(nb[2]));
-                float ra[4];
-                woop_plane_row(na, nbv, nc, ra);
-                const vec3 vb[3] = {A, B, C};
-                share_plane_row(ra, wr + 8, vb);
-            }
-            float t, u, v;
-            bool h = tri_test(s.wo, s.wd, make_float4(wr[0], wr[1], wr[2], wr[3]), make_float4(wr[4], wr[5], wr[6], wr[7]), make_float4(wr[8], wr[9], wr[10], wr[11]), s.tmin,
-                              s.tmax, t, u, v);
-            if (h && sc.has_alpha) h = alpha_test_inst<TEX>(sc, m, s.inst, prim, s.tri_off, q0, q1, q2, q3, u, v);
-            if (h) {
-                if (any_hit) {
-                    s.best = gid;
-                    s.T = 0; s.G = 0; s.sp = 0;  // any hit: done
+            const vec3 A = xf_point(c0, c1, c2, tr, mk3(u2f(w0.x), u2f(w0.y), u2f(w0.z))), B = xf_point(c0, c1, c2, tr, mk3(u2f(w1.x), u2f(w1.y), u2f(w1.z)));
+            const vec3 C = xf_point(c0, c1, c2, tr, mk3(u2f(w2.x), u2f(w2.y), u2f(w2.z)));
+            // (an odd triangle may carry its even neighbour's plane row: that plane is within 1e-6 sqrt(|n_even|) of its vertices;
+            // m[7].x bounds sqrt(|n|) over the instance's triangles -- scene_inst.cpp)
+            const float shift = (prim & 1u) ? 2e-6f * m[7].x : 0.0f;
+#if defined(AKR_INST_PRETEST_CHECK)  // measurement / test builds: every candidate takes the exact test, which reports a wrong reject
+            const bool may = tri_may_hit(s.wo, s.wd, A, B, C, s.tmin, s.best_t, shift);
+            if (s.pend_rec == kInvalid && s.check_t != -2.0f) s.check_t = may ? -1.0f : s.best_t;
+            if (true) {
+#else
+            if (tri_may_hit(s.wo, s.wd, A, B, C, s.tmin, s.best_t, shift)) {
+#endif
+                if (s.pend_rec == kInvalid) {
+                    s.pend_rec = s.tri_off + s.tbase + leaf_bit;
+                    s.pend_inst = s.inst;
                 } else {
-                    const bool better = (s.best == kInvalid) | (t < s.best_t) | ((t == s.best_t) & (gid < s.best));
-                    if (better) { s.best_t = t; s.best_u = u; s.best_v = v; s.best = gid; }
+                    s.T |= 1u << leaf_bit;
+                    cnt.tris--;
+                    blocked = true;
                 }
             }
         }
     } else {
         // ---- a node of either level: disect.h trav_step's box test on the current level's ray
+#if !defined(AKR_INST_COUNT)
         cnt.nodes++;
+#endif
         const float limit = s.best_t;
         const float bx = u2f((w0.w & 0xffu) << 23) * s.inv.x, by = u2f(((w0.w >> 8) & 0xffu) << 23) * s.inv.y, bz = u2f(((w0.w >> 16) & 0xffu) << 23) * s.inv.z;
         const float ax = __builtin_fmaf(u2f(w0.x), s.inv.x, s.noi.x), ay = __builtin_fmaf(u2f(w0.y), s.inv.y, s.noi.y), az = __builtin_fmaf(u2f(w0.z), s.inv.z, s.noi.z);
@@ -185,15 +245,128 @@ AKR_D void trav_step_inst(const DScene& sc, TravI& s, uint32_t* __restrict__ sta
         s.tbase = w1.z;
     }
     s.active = (s.T != 0) | ((s.G >> 24) != 0) | (s.sp != 0);
+    return blocked;
 }
 
+// The exact test is ~20 times a node visit (nine f64 divisions) and few candidates need it: the lanes of a wave collect theirs and
+// take the test together -- when AKR_INST_QUORUM lanes have one, when a lane that cannot go on without its verdict (a second
+// candidate, or the end of its traversal) has waited AKR_INST_PATIENCE steps, or when no lane can go on. The order in which a ray's
+// candidates are tested changes neither the closest hit (smallest t, then smallest id) nor whether there is any.
+#ifndef AKR_INST_QUORUM
+#define AKR_INST_QUORUM 16
+#endif
+#ifndef AKR_INST_PATIENCE
+#define AKR_INST_PATIENCE 4
+#endif
 template <bool ANY_HIT, bool TEX = false>
 AKR_D bool trace_inst(const DScene& sc, vec3 o, vec3 d, float tmin, float tmax, uint32_t ex0, uint32_t ex1, Hit& hit, uint32_t* __restrict__ stack, TraceCounters& cnt) {
     TravI s;
     trav_begin_inst(s, o, d, tmin, tmax, ex0, ex1);
-    while (s.active) trav_step_inst<ANY_HIT ? 1 : 0, TEX>(sc, s, stack, cnt);
+    uint32_t waited = 0;
+    bool blocked = false;
+    while (s.active | (s.pend_rec != kInvalid)) {
+#if defined(AKR_INST_COUNT) && AKR_INST_COUNT == 3
+        if ((uint32_t)__builtin_ctzll(__ballot(true)) == (threadIdx.x & 63u)) cnt.nodes++;
+#endif
+        if (s.pend_rec == kInvalid) blocked = false;
+        if (s.active & !blocked) blocked = trav_step_inst<TEX>(sc, s, stack, cnt);
+        const bool pending = s.pend_rec != kInvalid;
+        const bool wait = pending & (blocked | !s.active);  // cannot go on without the verdict
+        const uint64_t waiting = __ballot(wait);
+        if (waiting == 0) continue;
+        waited++;
+        if (waited >= AKR_INST_PATIENCE || __ballot(s.active & !wait) == 0 || __popcll(__ballot(pending)) >= AKR_INST_QUORUM) {
+            waited = 0;
+#if defined(AKR_INST_COUNT) && AKR_INST_COUNT == 1   // measurement builds: n_node_visits counts exact tests (lanes) instead
+            if (pending) cnt.nodes++;
+#elif defined(AKR_INST_COUNT) && AKR_INST_COUNT == 2  // ... or the times a wave ran the exact test
+            if (pending && (uint32_t)__builtin_ctzll(__ballot(pending)) == (threadIdx.x & 63u)) cnt.nodes++;
+#elif defined(AKR_INST_COUNT) && AKR_INST_COUNT == 3  // ... or the loop iterations of the waves
+            if (false) cnt.nodes++;
+#endif
+            if (pending) resolve_pending<TEX>(sc, s, ANY_HIT);
+#if defined(AKR_INST_PRETEST_CHECK)
+            if (s.check_t == -2.0f) cnt.overflow = 1;
+#endif
+        }
+    }
     hit.t = s.best_t; hit.u = s.best_u; hit.v = s.best_v; hit.gid = s.best;
     return s.best != kInvalid;
+}
+
+// Both rays of a path vertex through ONE loop (a lane whose closest-hit ray is done goes straight on to its shadow ray), which ends
+// when at most 1/STRAG of the lanes that entered it are still tracing: those keep their traversal -- in 16 words of LDS per lane, the
+// stack where it is -- and go on in the next intersection phase while the others shade (pt_pass.h: the flattened scenes' kernels do
+// the same, AKR_PT_STRAGGLERS). cy = the lane's LDS column (slot k at cy[k * 256]).
+constexpr uint32_t kCarrySlotsInst = 16;
+template <bool TEX, uint32_t STRAG>
+AKR_D void trace_pair_inst(const DScene& sc, bool has_ray, vec3 ro, vec3 rd, uint32_t ray_ex0, bool has_shadow, vec3 s_o, vec3 s_d, float s_tmax, uint32_t s_ex0,
+                           uint32_t s_ex1, bool& carry, Hit& hit, bool& found, bool& occluded, uint32_t* __restrict__ stack, uint32_t* __restrict__ cy, TraceCounters& cnt) {
+    TravI s;
+    uint32_t phase;  // 0: closest-hit ray in flight, 1: shadow ray, 2: done
+    hit.t = 1e20f; hit.u = 0.0f; hit.v = 0.0f; hit.gid = kInvalid;
+    if (!(STRAG > 0 && carry)) {
+        phase = has_ray ? 0u : (has_shadow ? 1u : 2u);
+        if (phase == 0) trav_begin_inst(s, ro, rd, 0.0f, 1e20f, ray_ex0, kInvalid);
+        else trav_begin_inst(s, s_o, s_d, 0.0f, phase == 1 ? s_tmax : -1.0f, s_ex0, s_ex1);
+    } else {
+        phase = cy[8 * 256];
+        if (phase == 0) trav_begin_inst(s, ro, rd, 0.0f, 1e20f, ray_ex0, kInvalid);
+        else {
+            trav_begin_inst(s, s_o, s_d, 0.0f, s_tmax, s_ex0, s_ex1);
+            hit.t = u2f(cy[9 * 256]); hit.u = u2f(cy[10 * 256]); hit.v = u2f(cy[11 * 256]); hit.gid = cy[12 * 256];
+            found = hit.gid != kInvalid;
+        }
+        s.best_t = u2f(cy[0]); s.best_u = u2f(cy[1 * 256]); s.best_v = u2f(cy[2 * 256]); s.best = cy[3 * 256];
+        s.G = cy[4 * 256]; s.T = cy[5 * 256]; s.tbase = cy[6 * 256]; s.sp = cy[7 * 256];
+        s.leaf = cy[13 * 256]; s.pend_rec = cy[14 * 256]; s.pend_inst = cy[15 * 256];
+        if (s.leaf != kInvalid) {
+            const uint4* lf = sc.in2.tlas_leaves + (size_t)s.leaf * 4;
+            trav_into_instance(s, lf[0], lf[1], lf[2], lf[3]);
+        }
+        s.active = (s.T != 0) | ((s.G >> 24) != 0) | (s.sp != 0);
+    }
+    const uint32_t n_in = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(phase != 2u));
+    const uint32_t n_leave = STRAG > 0 ? n_in / STRAG : 0u;
+    uint32_t waited = 0;
+    bool blocked = false;
+    while (true) {
+        const uint32_t n_now = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(phase != 2u));
+        if (n_now <= n_leave) break;  // (n_leave < n_in: at least one lane of the phase finishes)
+        if (phase != 2u) {
+            if (s.pend_rec == kInvalid) blocked = false;
+            if (s.active & !blocked) blocked = trav_step_inst<TEX>(sc, s, stack, cnt);
+            const bool pending = s.pend_rec != kInvalid;
+            const bool wait = pending & (blocked | !s.active);  // cannot go on without the verdict
+            if (__ballot(wait) != 0) {
+                waited++;
+                if (waited >= AKR_INST_PATIENCE || __ballot(s.active & !wait) == 0 || __popcll(__ballot(pending)) >= AKR_INST_QUORUM) {
+                    waited = 0;
+                    if (pending) resolve_pending<TEX>(sc, s, phase == 1u);
+                }
+            }
+            if (!s.active & (s.pend_rec == kInvalid)) {
+                blocked = false;
+                if (phase == 0u) {
+                    found = s.best != kInvalid;
+                    hit.t = s.best_t; hit.u = s.best_u; hit.v = s.best_v; hit.gid = s.best;
+                    phase = has_shadow ? 1u : 2u;
+                    if (has_shadow) trav_begin_inst(s, s_o, s_d, 0.0f, s_tmax, s_ex0, s_ex1);
+                } else {
+                    occluded = s.best != kInvalid;
+                    phase = 2u;
+                }
+            }
+        }
+    }
+    carry = STRAG > 0 && phase != 2u;
+    if (STRAG > 0 && carry) {
+        cy[0] = f2u(s.best_t); cy[1 * 256] = f2u(s.best_u); cy[2 * 256] = f2u(s.best_v); cy[3 * 256] = s.best;
+        cy[4 * 256] = s.G; cy[5 * 256] = s.T; cy[6 * 256] = s.tbase; cy[7 * 256] = s.sp;
+        cy[8 * 256] = phase;
+        if (phase == 1u) { cy[9 * 256] = f2u(hit.t); cy[10 * 256] = f2u(hit.u); cy[11 * 256] = f2u(hit.v); cy[12 * 256] = hit.gid; }
+        cy[13 * 256] = s.leaf; cy[14 * 256] = s.pend_rec; cy[15 * 256] = s.pend_inst;
+    }
 }
 
 // the instance a global triangle id belongs to: the last i with inst_tri_offset[i] <= gid

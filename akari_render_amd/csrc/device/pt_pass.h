@@ -52,7 +52,7 @@ AKR_D void pt_pass_body(const PtParams& p) {
     const PtParams& q = STAGE ? staged : p;
     const DScene& sc = q.sc;
     constexpr bool TILE = BVH && !TEX && !INST && AKR_BVH_TILE != 0;
-    constexpr uint32_t STRAG = (BVH && !INST) ? (TEX ? AKR_PT_STRAGGLERS_TEX : AKR_PT_STRAGGLERS) : 0;
+    constexpr uint32_t STRAG = BVH ? (INST ? AKR_PT_STRAGGLERS_INST : (TEX ? AKR_PT_STRAGGLERS_TEX : AKR_PT_STRAGGLERS)) : 0;
     const uint4* tile = (const uint4*)(lds_stack + p.tile_offset);
     if (TILE) {  // nodes 0 .. bvh_tile_nodes - 1
         uint32_t* l = lds_stack + p.tile_offset;
@@ -108,12 +108,10 @@ AKR_D void pt_pass_body(const PtParams& p) {
                 r.c_shadow += r.has_shadow ? 1u : 0u;
             }
             if (BVH && INST) {
-                // meshes + instances: the two-level traversal, one ray after the other
-                if (r.has_ray) found = trace_inst<false, TEX>(sc, r.ro, r.rd, 0.0f, 1e20f, r.ray_ex0, kInvalid, hit, tc.stack, tc.cnt);
-                if (r.has_shadow) {
-                    Hit sh;
-                    occluded = trace_inst<true, TEX>(sc, r.s_o, r.s_d, 0.0f, r.s_tmax, r.s_ex0, r.s_ex1, sh, tc.stack, tc.cnt);
-                }
+                // meshes + instances: the two-level traversal (dinst_trav.h), both rays in one loop, stragglers carried over
+                static_assert(kCarrySlotsInstanced == kCarrySlotsInst, "LDS plan and traversal disagree");
+                trace_pair_inst<TEX, STRAG>(sc, r.has_ray, r.ro, r.rd, r.ray_ex0, r.has_shadow, r.s_o, r.s_d, r.s_tmax, r.s_ex0, r.s_ex1, r.carry, hit, found, occluded, tc.stack,
+                                            lds_stack + p.carry_offset + threadIdx.x, tc.cnt);
             } else if (BVH && AKR_PT_MERGED_RAYS && STRAG > 0) {
                 // The merged loop below ends when the wave's LONGEST pair of rays is done: on the 10 M-triangle hall 40 % of its
                 // lane-steps do work, the rest is lanes waiting for the tail of the ray-length distribution. Here the phase ends

@@ -137,6 +137,7 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
     std::vector<uint32_t> blas_node_off(n_mesh, 0);
     std::vector<std::vector<uint32_t>> blas_nodes(n_mesh);
     std::vector<uint32_t> blas_depth(n_mesh, 0);
+    std::vector<float> mesh_size(n_mesh, 0.0f);
     const TuningOptions tune = tuning();
     for (size_t m = 0; m < n_mesh; m++) {
         if (!used[m]) continue;
@@ -145,13 +146,20 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
         if (nt == 0) continue;
         std::vector<float> bounds(6ull * nt);
         float olo[3] = {INFINITY, INFINITY, INFINITY}, ohi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        double max_n2 = 0.0;
         for (uint32_t prim = 0; prim < nt; prim++) {
             const vec3 v0 = ld3(g.vertices, g.indices[3 * prim]), v1 = ld3(g.vertices, g.indices[3 * prim + 1]), v2 = ld3(g.vertices, g.indices[3 * prim + 2]);
+            {
+                const double ax = (double)v1.x - v0.x, ay = (double)v1.y - v0.y, az = (double)v1.z - v0.z, bx = (double)v2.x - v0.x, by = (double)v2.y - v0.y, bz = (double)v2.z - v0.z;
+                const double nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+                max_n2 = std::max(max_n2, nx * nx + ny * ny + nz * nz);
+            }
             float* bb = &bounds[6ull * prim];
             bb[0] = min_f(min_f(v0.x, v1.x), v2.x); bb[1] = min_f(min_f(v0.y, v1.y), v2.y); bb[2] = min_f(min_f(v0.z, v1.z), v2.z);
             bb[3] = max_f(max_f(v0.x, v1.x), v2.x); bb[4] = max_f(max_f(v0.y, v1.y), v2.y); bb[5] = max_f(max_f(v0.z, v1.z), v2.z);
             for (int a = 0; a < 3; a++) { olo[a] = min_f(olo[a], bb[a]); ohi[a] = max_f(ohi[a], bb[3 + a]); }
         }
+        mesh_size[m] = (float)(std::sqrt(std::sqrt(max_n2)) * 1.0001);  // sqrt(|n|) of the mesh's largest triangle
         // Padding of the object-space boxes. A triangle the flattened test would accept lies within pad_world of its world box; in object
         // space that is pad_world x |M^-1|. The ray is taken through M^-1 in f32: its origin is off by a few ulp of |M^-1| x (how far from
         // the origin a ray can start), its direction by a few ulp -- i.e. by that much of the object-space scene extent at the far end.
@@ -315,6 +323,13 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
         r[15] = u2f(is.inst_light[i]);
         r[23] = u2f(out.inst_tri_offset[i]);
         r[27] = u2f((uint32_t)flat.instances[i].materials.size());
+        // sqrt(|n|) of a world-space triangle of this instance is at most |M|_F x the mesh's (cof(M) has singular values <= |M|_F^2):
+        // what tri_may_hit (dinst.h) allows for a plane row shared with the even neighbour
+        const float* tm = flat.instances[i].transform;
+        double f2 = 0.0;
+        for (int c = 0; c < 3; c++)
+            for (int rr = 0; rr < 3; rr++) f2 += (double)tm[4 * c + rr] * tm[4 * c + rr];
+        r[28] = (float)(std::sqrt(f2) * 1.0001) * mesh_size[flat.instances[i].mesh];
     }
 }
 

@@ -41,6 +41,9 @@ namespace akr {
 #ifndef AKR_PT_STRAGGLERS_TEX
 #define AKR_PT_STRAGGLERS_TEX 0  // the same for the BVH kernels of scenes with textures (measured separately)
 #endif
+#ifndef AKR_PT_STRAGGLERS_INST
+#define AKR_PT_STRAGGLERS_INST 8  // the same for the kernels of scenes kept as meshes + instances (dinst_trav.h trace_pair_inst)
+#endif
 #ifndef AKR_PT_PARK_TEX
 #define AKR_PT_PARK_TEX 1   // the same for the full-graph kernels of scenes with textures (exhaustive and BVH)
 #endif
@@ -48,6 +51,7 @@ namespace akr {
 // (dpath.h: PARK), and a traversal carried over to the next intersection phase (pt_kernels.hip).
 constexpr uint32_t kParkSlots = 16, kParkSlotsNoDefer = 13;  // dpath.h: PK_*
 constexpr uint32_t kCarrySlots = 13;                         // pt_kernels.hip: a carried traversal
+constexpr uint32_t kCarrySlotsInstanced = 16;                // ... of a scene kept as meshes + instances (dinst_trav.h)
 constexpr size_t kBlueNoiseColumnBytes = 48 * 256 * 2;          // dpath.h pmj_bluenoise_stage: one u16 per array and lane
 // What a k_pt_pass launch keeps in LDS beyond traversal stacks, staged tables and graph values, by kernel instantiation
 // (BVH / force_diffuse / textured scene / conductor deferral): used by the launcher and by the host's staging decision.

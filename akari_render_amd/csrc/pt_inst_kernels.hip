@@ -3,10 +3,17 @@
 // force_diffuse x textures x sampler family.
 #include "device/pt_pass.h"
 
+#ifndef AKR_PT_MIN_WAVES_INST
+#define AKR_PT_MIN_WAVES_INST AKR_PT_MIN_WAVES_BVH
+#endif
+#ifndef AKR_PT_MIN_WAVES_INST_TEX
+#define AKR_PT_MIN_WAVES_INST_TEX AKR_PT_MIN_WAVES_BVH_TEX
+#endif
+
 namespace akr {
 
 template <bool FD, bool TEX, bool PMJ>
-__global__ __launch_bounds__(256, TEX ? AKR_PT_MIN_WAVES_BVH_TEX : AKR_PT_MIN_WAVES_BVH) void k_pt_pass_inst(const PtParams p) {
+__global__ __launch_bounds__(256, TEX ? AKR_PT_MIN_WAVES_INST_TEX : AKR_PT_MIN_WAVES_INST) void k_pt_pass_inst(const PtParams p) {
     pt_pass_body<true, FD, TEX, PMJ, false, false, 0u, true>(p);
 }
 

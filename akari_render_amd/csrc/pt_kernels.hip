@@ -180,7 +180,7 @@ PtParams pt_pass_layout(const PtParams& p, size_t& lds, uint32_t& blocks) {
     pp.park_offset = (uint32_t)(base / 4);
     base += plan.park_bytes;
     pp.carry_offset = (uint32_t)(base / 4);
-    base += inst ? 0 : plan.carry_bytes;
+    base += inst ? (AKR_PT_STRAGGLERS_INST > 0 ? (size_t)kCarrySlotsInstanced * 256 * 4 : 0) : plan.carry_bytes;
     pp.bn_offset = 0;
     {   // pmj02bn: the lanes' blue-noise columns, if the workgroup's share of the CU's LDS has room for them (exhaustive kernels of
         // small scenes: 24 KB next to ~13 KB of staged tables; the BVH kernels' traversal stacks leave none)
