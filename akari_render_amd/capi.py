@@ -42,7 +42,7 @@ EXPORTS = [
     "akr_host_stdrng_u64", "akr_host_chacha_block", "akr_host_pcg32_states", "akr_host_pcg_start", "akr_host_alias_table",
     "akr_probe_math", "akr_probe_bsdf", "akr_probe_intersect", "akr_probe_surface_interaction", "akr_probe_material_inputs",
     "akr_host_decode_png", "akr_host_decode_jpeg", "akr_host_decode_exr", "akr_host_decode_tiff", "akr_host_decode_dds", "akr_host_pmj02bn_tables",
-    "akr_pt_kernel_info", "akr_scene_spec_source", "akr_host_spec_compile", "akr_probe_material_folded_host", "akr_host_sobol_dim1", "akr_host_fastmod", "akr_host_spec_compile_text", "akr_film_reduce_planes", "akr_mcmc_render_shard", "akr_mcmc_combine_host", "akr_mcmc_combine",
+    "akr_pt_kernel_info", "akr_scene_spec_source", "akr_host_spec_compile", "akr_probe_material_folded_host", "akr_host_sobol_dim1", "akr_host_fastmod", "akr_host_tri_pretest", "akr_host_spec_compile_text", "akr_film_reduce_planes", "akr_mcmc_render_shard", "akr_mcmc_combine_host", "akr_mcmc_combine",
 ]
 
 
@@ -115,6 +115,7 @@ def lib() -> C.CDLL:
     proto("akr_probe_material_folded_host", vp, u32, u32, fp, up, fp, fp)
     proto("akr_host_sobol_dim1", u32, up, up, up)
     proto("akr_host_fastmod", u32, up, up, up)
+    proto("akr_host_tri_pretest", u32, fp, fp, f32, up, up, fp)
     proto("akr_host_spec_compile_text", C.c_char_p, u32, u32, C.c_char_p, C.c_char_p)
     proto("akr_context_device_ordinal", vp, C.POINTER(C.c_int32))
     proto("akr_device_count", C.POINTER(C.c_int32))
@@ -597,6 +598,16 @@ def host_pcg_start(state: int, inc: int) -> int:
     s = C.c_uint64(state)
     check(lib().akr_host_pcg_start(C.byref(s), inc))
     return s.value
+
+
+def host_tri_pretest(rays8: np.ndarray, tris9: np.ndarray, plane_shift: float = 0.0):
+    """(may_hit, exact_accept, exact_t) per (ray, triangle) pair: dinst.h tri_may_hit and the exact Woop test on the host."""
+    rays8 = np.ascontiguousarray(rays8, dtype=np.float32).reshape(-1, 8)
+    tris9 = np.ascontiguousarray(tris9, dtype=np.float32).reshape(-1, 9)
+    n = rays8.shape[0]
+    may, exact, t = np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.float32)
+    check(lib().akr_host_tri_pretest(n, _fp(rays8), _fp(tris9), C.c_float(plane_shift), _up(may), _up(exact), _fp(t)))
+    return may.astype(bool), exact.astype(bool), t
 
 
 def host_alias_table(weights):

@@ -1,5 +1,7 @@
 // api_probe.cpp -- host-side known-answer hooks and device probes for the tests (C ABI of libakari_hip.so, include/akari_hip.h; shared internals: api_internal.h)
 #include "api_internal.h"
+#include "../device/dinst.h"
+#include "../device/disect.h"
 
 extern "C" {
 
@@ -47,6 +49,22 @@ AKR_API int32_t akr_host_fastmod(uint32_t n, const uint32_t* a, const uint32_t* 
     for (uint32_t k = 0; k < n; k++) {
         if (d[k] == 0) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_host_fastmod: divisor 0");
         out[k] = fastmod_u32(a[k], fastmod_magic(d[k]), d[k]);
+    }
+    return AKR_OK;
+}
+// device/dinst.h on the host: the conservative reject of a candidate (tri_may_hit) next to the exact test it stands in front of
+// (woop_precompute + tri_test), per item: ray = o.xyz d.xyz tmin tlimit, tri = A B C (world space, f32). exact: bit 0 accept, t in out_t.
+AKR_API int32_t akr_host_tri_pretest(uint32_t n, const float* rays8, const float* tris9, float plane_shift, uint32_t* may, uint32_t* exact, float* out_t) {
+    if (!rays8 || !tris9 || !may || !exact) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_host_tri_pretest: NULL argument");
+    for (uint32_t k = 0; k < n; k++) {
+        const float* r = rays8 + 8ull * k;
+        const float* t = tris9 + 9ull * k;
+        const vec3 o = mk3(r[0], r[1], r[2]), d = mk3(r[3], r[4], r[5]), A = mk3(t[0], t[1], t[2]), B = mk3(t[3], t[4], t[5]), C = mk3(t[6], t[7], t[8]);
+        may[k] = tri_may_hit(o, d, A, B, C, r[6], r[7], plane_shift) ? 1u : 0u;
+        float w[12], tt, u, v;
+        woop_precompute(A, B, C, w);
+        exact[k] = tri_test(o, d, make_float4(w[0], w[1], w[2], w[3]), make_float4(w[4], w[5], w[6], w[7]), make_float4(w[8], w[9], w[10], w[11]), r[6], r[7], tt, u, v) ? 1u : 0u;
+        if (out_t) out_t[k] = tt;
     }
     return AKR_OK;
 }

@@ -621,6 +621,11 @@ AKR_API int32_t akr_host_alias_table(const float *weights, uint32_t n, uint32_t 
 AKR_API int32_t akr_host_fastmod(uint32_t n, const uint32_t *a, const uint32_t *d, uint32_t *out);
 AKR_API int32_t akr_host_sobol_dim1(uint32_t n, const uint32_t *index, uint32_t *by_loop, uint32_t *by_butterfly);
 
+/* Scenes kept as meshes + instances: the conservative reject of a candidate triangle (csrc/device/dinst.h tri_may_hit) next to the exact
+ * test it stands in front of, on the host. rays8 = o.xyz d.xyz tmin tlimit, tris9 = world-space A B C; may / exact = 0 or 1 per item. */
+AKR_API int32_t akr_host_tri_pretest(uint32_t n, const float *rays8, const float *tris9, float plane_shift, uint32_t *may, uint32_t *exact,
+                                     float *out_t /* or NULL */);
+
 /* Library / build identification: "akari_hip <version> gfx950". */
 AKR_API const char *akr_version(void);
 /* Process-wide tuning switches and test hooks (no reference counterpart). Each starts from its environment variable, read once;

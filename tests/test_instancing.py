@@ -106,3 +106,77 @@ def test_a_hundred_million_instance_triangles_take_megabytes(hip_lib, monkeypatc
     assert one[1] < 64 << 20, one
     assert one[2] <= 40 and one[3] == 5
     assert digest(3) == one and digest(8) == one
+
+
+def _pretest_cases(rng, n, offset, size, aspect, aim):
+    """n (ray, triangle) pairs: triangles of edge ~`size` around `offset`, squashed by `aspect` along one edge (slivers), rays from a
+    few sizes away aimed at a point of the triangle's plane spread `aim` x the triangle around its centre (aim 1: half hit, near
+    misses at every edge and vertex)."""
+    A = (offset + size * rng.normal(size=(n, 3))).astype(np.float32)
+    e1 = size * rng.normal(size=(n, 3))
+    e2 = size * rng.normal(size=(n, 3))
+    e2 = e1 * rng.normal(size=(n, 1)) + aspect * e2
+    B, C = (A + e1).astype(np.float32), (A + e2).astype(np.float32)
+    bu, bv = aim * (rng.random(n) * 2.0 - 0.5), aim * (rng.random(n) * 2.0 - 0.5)
+    k = rng.integers(0, 4, n)  # a quarter each: anywhere, on edge u = 0, on edge v = 0, on the hypotenuse
+    bu = np.where(k == 1, 0.0, bu)
+    bv = np.where(k == 2, 0.0, bv)
+    bv = np.where(k == 3, 1.0 - bu, bv)
+    target = A.astype(np.float64) + bu[:, None] * (B.astype(np.float64) - A) + bv[:, None] * (C.astype(np.float64) - A)
+    dirs = rng.normal(size=(n, 3))
+    nrm = np.cross(B.astype(np.float64) - A, C.astype(np.float64) - A)
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-300)
+    graze = rng.random(n) < 0.25  # a quarter of the rays nearly in the triangle's plane
+    dirs = np.where(graze[:, None], dirs - (1.0 - 1e-3) * np.sum(dirs * nrm, axis=1, keepdims=True) * nrm, dirs)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    dist = size * (0.5 + 20.0 * rng.random(n))
+    o = (target - dirs * dist[:, None]).astype(np.float32)
+    d = dirs.astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    rays = np.concatenate([o, d, np.zeros((n, 1), np.float32), np.full((n, 1), 1e20, np.float32)], axis=1).astype(np.float32)
+    return rays, np.concatenate([A, B, C], axis=1)
+
+
+def test_the_conservative_reject_never_drops_what_the_exact_test_accepts(hip_lib):
+    """dinst.h tri_may_hit stands in front of the exact (f64 Woop rows) test of a candidate of a kept scene: it may only reject what
+    that test rejects. Edges, vertices, slivers, grazing rays, triangles far from the origin, tiny and huge ones; and the t limits."""
+    rng = np.random.default_rng(2024)
+    total = hits = rejected = misses = 0
+    for offset in (0.0, 10.0, 1e3, 1e5):
+        for size in (1e-4, 1e-2, 1.0, 1e3):
+            for aspect in (1.0, 1e-2, 1e-4, 1e-6):
+                for aim in (1.0, 4.0):
+                    rays, tris = _pretest_cases(rng, 4000, offset, size, aspect, aim)
+                    may, exact, t = capi.host_tri_pretest(rays, tris)
+                    assert not np.any(exact & ~may), (offset, size, aspect, aim, int(np.sum(exact & ~may)))
+                    # the t limits: a limit just below / a tmin just above the exact t must not be rejected either way round
+                    h = np.flatnonzero(exact)
+                    if h.size:
+                        r2 = rays[h].copy()
+                        r2[:, 7] = t[h]                      # tlimit = t exactly: tri_test accepts (t <= tmax)
+                        m2, e2, _ = capi.host_tri_pretest(r2, tris[h])
+                        assert np.all(e2) and np.all(m2)
+                        r2[:, 7] = 1e20
+                        r2[:, 6] = t[h]                      # tmin = t exactly
+                        m2, e2, _ = capi.host_tri_pretest(r2, tris[h])
+                        assert np.all(e2) and np.all(m2)
+                    total += rays.shape[0]
+                    hits += int(exact.sum())
+                    if offset <= 10.0 and aspect >= 1e-2:
+                        misses += int((~exact).sum())
+                        rejected += int((~exact & ~may).sum())
+    assert hits > 0.05 * total
+    # ... and it is worth having: on well-conditioned triangles it rejects half of these misses, three quarters of which sit exactly on
+    # an edge or come from a grazing ray (in a render: 86 % of the candidates of the 10 M-triangle forest, profiles/r5_forest_*.json)
+    assert rejected > 0.4 * misses, (rejected, misses)
+    # a shared plane row (odd triangles): the plane may be off by plane_shift -- hits of the shifted plane must survive
+    rays, tris = _pretest_cases(rng, 20000, 5.0, 0.5, 1.0, 1.0)
+    shifted = tris.copy()
+    n = np.cross(tris[:, 3:6] - tris[:, 0:3], tris[:, 6:9] - tris[:, 0:3])
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    shift = 1e-4
+    for k in range(3):
+        shifted[:, 3 * k:3 * k + 3] += (shift * n).astype(np.float32)
+    _, exact_shifted, _ = capi.host_tri_pretest(rays, shifted)
+    may, _, _ = capi.host_tri_pretest(rays, tris, plane_shift=shift)
+    assert not np.any(exact_shifted & ~may)
