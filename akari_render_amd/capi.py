@@ -25,7 +25,7 @@ ERR_INVALID_ARGUMENT, ERR_HIP, ERR_NO_DEVICE, ERR_IO, ERR_PARSE, ERR_UNSUPPORTED
 
 # every symbol include/akari_hip.h declares (checked by tests/test_abi.py against the header text)
 EXPORTS = [
-    "akr_last_error", "akr_version", "akr_option_set", "akr_option_get",
+    "akr_last_error", "akr_version", "akr_struct_size", "akr_option_set", "akr_option_get",
     "akr_context_create", "akr_context_destroy", "akr_context_synchronize", "akr_context_device_info",
     "akr_scene_create", "akr_scene_load", "akr_scene_destroy", "akr_scene_set_resolution", "akr_scene_get_info",
     "akr_scene_get_light", "akr_scene_get_ggx_table", "akr_scene_get_desc_counts", "akr_scene_get_mesh",
@@ -75,6 +75,13 @@ def lib() -> C.CDLL:
     fp, up, u64p, vpp = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p)
     L.akr_last_error.restype = C.c_char_p
     L.akr_version.restype = C.c_char_p
+    # the library's structs against these bindings' (a stale libakari_hip.so or a stale abi.py fails here, not inside a render)
+    L.akr_struct_size.restype = C.c_uint32
+    L.akr_struct_size.argtypes = [C.c_int32]
+    for sid, cls in enumerate((abi.MeshDesc, abi.InstanceDesc, abi.MaterialDesc, abi.CameraDesc, abi.SceneDesc, abi.PtConfig, abi.PtStats, abi.SceneInfo,
+                               abi.KernelInfo, abi.AovConfig, abi.GptConfig, abi.McmcConfig, abi.McmcResult, abi.McmcPartial), start=1):
+        if L.akr_struct_size(sid) != C.sizeof(cls):
+            raise ImportError("libakari_hip.so and akari_render_amd/abi.py disagree on sizeof(%s): %d vs %d" % (cls.__name__, L.akr_struct_size(sid), C.sizeof(cls)))
 
     def proto(name, *args):
         fn = getattr(L, name)

@@ -19,7 +19,26 @@ int32_t api_fail(int32_t code, const std::string& msg) { return fail(code, msg);
 extern "C" {
 
 AKR_API const char* akr_last_error(void) { return g_last_error.c_str(); }
-AKR_API const char* akr_version(void) { return "akari_hip 0.2.0 gfx950"; }  // 0.2.0: akr_pt_config gained sample_begin / sample_count (88 bytes); akr_kernel_info carries its own size
+AKR_API uint32_t akr_struct_size(int32_t which) {
+    switch (which) {
+        case AKR_STRUCT_MESH_DESC: return sizeof(akr_mesh_desc);
+        case AKR_STRUCT_INSTANCE_DESC: return sizeof(akr_instance_desc);
+        case AKR_STRUCT_MATERIAL_DESC: return sizeof(akr_material_desc);
+        case AKR_STRUCT_CAMERA_DESC: return sizeof(akr_camera_desc);
+        case AKR_STRUCT_SCENE_DESC: return sizeof(akr_scene_desc);
+        case AKR_STRUCT_PT_CONFIG: return sizeof(akr_pt_config);
+        case AKR_STRUCT_PT_STATS: return sizeof(akr_pt_stats);
+        case AKR_STRUCT_SCENE_INFO: return sizeof(akr_scene_info);
+        case AKR_STRUCT_KERNEL_INFO: return sizeof(akr_kernel_info);
+        case AKR_STRUCT_AOV_CONFIG: return sizeof(akr_aov_config);
+        case AKR_STRUCT_GPT_CONFIG: return sizeof(akr_gpt_config);
+        case AKR_STRUCT_MCMC_CONFIG: return sizeof(akr_mcmc_config);
+        case AKR_STRUCT_MCMC_RESULT: return sizeof(akr_mcmc_result);
+        case AKR_STRUCT_MCMC_PARTIAL: return sizeof(akr_mcmc_partial);
+        default: return 0;
+    }
+}
+AKR_API const char* akr_version(void) { return "akari_hip 0.3.0 gfx950"; }  // 0.3.0: akr_struct_size, scenes kept as meshes + instances; 0.2.0: akr_pt_config gained sample_begin / sample_count (88 bytes); akr_kernel_info carries its own size
 AKR_API int32_t akr_option_set(const char* name, int32_t value) {
     if (!tuning_set(name, value)) return fail(AKR_ERR_INVALID_ARGUMENT, std::string("akr_option_set: unknown option '") + (name ? name : "(null)") + "' or value out of range");
     return AKR_OK;

@@ -628,6 +628,14 @@ AKR_API int32_t akr_host_tri_pretest(uint32_t n, const float *rays8, const float
 
 /* Library / build identification: "akari_hip <version> gfx950". */
 AKR_API const char *akr_version(void);
+/* sizeof() of the structs of this header as the LIBRARY was built, so that a caller (or a binding generated from another version of the
+ * header) can check its own before passing one: 0 = unknown id. The bindings in akari_render_amd/capi.py check every one at load. */
+typedef enum {
+    AKR_STRUCT_MESH_DESC = 1, AKR_STRUCT_INSTANCE_DESC, AKR_STRUCT_MATERIAL_DESC, AKR_STRUCT_CAMERA_DESC, AKR_STRUCT_SCENE_DESC,
+    AKR_STRUCT_PT_CONFIG, AKR_STRUCT_PT_STATS, AKR_STRUCT_SCENE_INFO, AKR_STRUCT_KERNEL_INFO, AKR_STRUCT_AOV_CONFIG, AKR_STRUCT_GPT_CONFIG,
+    AKR_STRUCT_MCMC_CONFIG, AKR_STRUCT_MCMC_RESULT, AKR_STRUCT_MCMC_PARTIAL
+} akr_struct_id;
+AKR_API uint32_t akr_struct_size(int32_t which);
 /* Process-wide tuning switches and test hooks (no reference counterpart). Each starts from its environment variable, read once;
  * afterwards only akr_option_set changes it, and it applies to scenes / sessions created after the call:
  *   "force_bvh"    (AKR_FORCE_BVH=1)        scenes of <= 64 triangles get a BVH as well

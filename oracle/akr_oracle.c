@@ -923,6 +923,12 @@ OR_EXPORT int or_pt_render(const or_scene *sc, const or_pt_config *cfg, float *f
         if (cfg->sampler_type != 1 && cfg->sampler_type != 2) return -4;
         if (cfg->sample_count == 0 || (uint64_t)cfg->sample_begin + cfg->sample_count > cfg->spp) return -4;
     }
+    if (states && cfg->sample_begin) {
+        /* caller-supplied states of a range that does not start at 0: they must already stand at sample begin - 1 (what the previous
+         * range left behind); anything else would silently render other samples than the ones asked for */
+        for (uint64_t i = 0; i < N; i++)
+            if ((uint32_t)states[i].state != cfg->sample_begin - 1u) return -4;
+    }
     if (!states) {
         states = (or_pcg32 *)malloc(sizeof(or_pcg32) * N);
         or_init_sampler_states(cfg->sampler_type, N, sc->width, cfg->sampler_seed, states);

@@ -35,6 +35,11 @@ def test_struct_sizes_match_header(hip_lib):
     d = abi.PtConfig.default()
     assert bytes(g.cfg) == bytes(d)
     assert C.sizeof(abi.MaterialDesc) == 4 * 26 and C.sizeof(abi.PtConfig) == 88
+    # akr_struct_size: what the library was built with, per struct (capi.lib() compares every one with abi.py when it loads)
+    hip_lib.akr_struct_size.restype = C.c_uint32
+    assert hip_lib.akr_struct_size(6) == 88 and hip_lib.akr_struct_size(3) == 104 and hip_lib.akr_struct_size(0) == 0 and hip_lib.akr_struct_size(99) == 0
+    assert hip_lib.akr_struct_size(8) == C.sizeof(abi.SceneInfo) and hip_lib.akr_struct_size(9) == C.sizeof(abi.KernelInfo)
+    assert hip_lib.akr_version().startswith(b"akari_hip 0.3.")
 
 
 def test_no_cpu_fallback(hip_lib):

@@ -69,3 +69,25 @@ def test_the_independent_sampler_refuses_a_range(cbox_path):
     assert rc == -4
     bad = make_config(spp=16, spp_per_pass=8, sampler_type=abi.SAMPLER_SOBOL, sample_begin=10, sample_count=8)  # runs past spp
     assert pyoracle.lib().or_pt_render(osc.h, C.byref(bad), film.ctypes.data_as(C.POINTER(C.c_float)), C.POINTER(C.c_uint64)(), 1, None) == -4
+
+
+def test_caller_states_must_stand_where_the_range_begins(cbox_path):
+    """or_pt_render with caller-supplied sampler states and sample_begin != 0: the states must hold sample index begin - 1 (what the
+    previous range left); anything else is refused instead of silently rendering other samples."""
+    import ctypes as C
+    w, h = 16, 12
+    sd = scene_json.load_scene(cbox_path, w, h)
+    osc = pyoracle.OracleScene(sd)
+    n = w * h
+    states = np.zeros(2 * n, dtype=np.uint64)
+    states[0::2] = 0xFFFFFFFF
+    states[1::2] = (np.arange(n, dtype=np.uint64) % np.uint64(w)) | ((np.arange(n, dtype=np.uint64) // np.uint64(w)) << np.uint64(32))
+    cfg = make_config(spp=16, spp_per_pass=8, max_depth=4, sampler_type=abi.SAMPLER_SOBOL, sampler_seed=1, sample_begin=8, sample_count=8)
+    film = np.zeros(7 * n, dtype=np.float32)
+    sp = states.ctypes.data_as(C.POINTER(C.c_uint64))
+    assert pyoracle.lib().or_pt_render(osc.h, C.byref(cfg), film.ctypes.data_as(C.POINTER(C.c_float)), sp, 2, None) == -4  # fresh states: index -1
+    assert not film.any()
+    states[0::2] = 7
+    assert pyoracle.lib().or_pt_render(osc.h, C.byref(cfg), film.ctypes.data_as(C.POINTER(C.c_float)), sp, 2, None) == 0
+    ref, _ = osc.render(cfg, n_threads=2)
+    assert np.array_equal(film.view(np.uint32), ref.view(np.uint32)) and np.all(states[0::2] == 15)
