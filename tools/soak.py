@@ -1,7 +1,7 @@
 """Randomised parity soak: random small scenes (random triangle soups + a few quads, random materials drawn from edge values,
 random emitters, cameras, samplers, configs, colour pipelines; a third of them with random images and random shader-graph DAGs
 feeding random inputs), the HIP path tracer against the oracle, film accumulators and
-counters bit for bit. Prints the seeds that differ. python tools/soak.py [n_cases] [first_seed] [tex] [big] [aov | gpt | mcmc | shard | wavefront]   (needs a GPU; uses oracle/)"""
+counters bit for bit. Prints the seeds that differ. python tools/soak.py [n_cases] [first_seed] [tex] [big] [aov | gpt | mcmc | shard | wavefront | inst]   (needs a GPU; uses oracle/)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -80,7 +80,7 @@ def rand_graph(rng, n_images):
     return abi.GraphData(nodes, {n: int(rng.integers(0, len(nodes))) for n in names})
 
 
-def rand_scene(seed, textures=None, big=False):
+def rand_scene(seed, textures=None, big=False, inst=False):
     """big: meshes of up to a few thousand triangles (deep BVHs), larger frames, longer paths"""
     rng = np.random.default_rng(seed)
     textured = (rng.random() < 0.35) if textures is None else textures
@@ -122,9 +122,20 @@ def rand_scene(seed, textures=None, big=False):
             normals = (nn / np.linalg.norm(nn, axis=2, keepdims=True)).astype(np.float32)
         uvs = (rng.random((nt, 3, 2)) * rng.choice([1.0, 3.0, -2.0])).astype(np.float32) if rng.random() < (0.8 if textured else 0.3) else None
         meshes.append(abi.MeshData(vertices=np.ascontiguousarray(verts), indices=idx, material_slots=slots, normals=normals, uvs=uvs))
-        for _ in range(int(rng.integers(1, 3))):
+        for _ in range(int(rng.integers(1, 7 if inst else 3))):
             t = eye.copy()
-            if rng.random() < 0.6:
+            if inst and rng.random() < 0.7:  # "inst": any non-singular affine map -- rotation about a random axis, non-uniform scale, mirror, shear
+                ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+                a = rng.uniform(0, 6.28)
+                K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+                R = np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * (K @ K)
+                S = np.diag(rng.choice([0.05, 0.3, 1.0, 1.0, 2.5, -1.0, -0.4], size=3).astype(np.float64))
+                M = R @ S
+                if rng.random() < 0.3:
+                    M[0] += rng.uniform(-1, 1) * M[1]
+                t[:3, :3] = M.astype(np.float32)
+                t[:3, 3] = (rng.uniform(-0.8, 0.8, size=3) * rng.choice([1.0, 1.0, 30.0])).astype(np.float32)
+            elif rng.random() < 0.6:
                 a = np.float32(rng.uniform(0, 6.28))
                 t[:3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], dtype=np.float32) * np.float32(rng.choice([0.5, 1.0, 1.7, -1.0]))
                 t[:3, 3] = rng.uniform(-0.5, 0.5, size=3).astype(np.float32)
@@ -246,6 +257,8 @@ def main():
     opts = sys.argv[3:]
     textures = True if "tex" in opts else None  # "tex": every scene with images and shader graphs
     runner = run_aov if "aov" in opts else run_gpt if "gpt" in opts else run_mcmc if "mcmc" in opts else run_shard if "shard" in opts else run_pt
+    if "inst" in opts:  # scenes with a shared mesh are kept as meshes + instances (two-level traversal) instead of flattened
+        capi.set_option("instancing", 1)
     if "wavefront" in opts:  # the path tracer's wavefront schedule instead of the megakernel
         capi.set_option("wavefront", 1)
         capi.set_option("force_bvh", 1)
@@ -253,9 +266,9 @@ def main():
     ctx = capi.Context(0)
     pyoracle.set_pmj_tables(*capi.host_pmj02bn_tables())
     bad, refused, t0 = [], 0, time.time()
-    kinds = {"exhaustive": 0, "bvh": 0, "textured": 0}
+    kinds = {"exhaustive": 0, "bvh": 0, "kept": 0, "textured": 0}
     for seed in range(first, first + n):
-        sd, cfg = rand_scene(seed, textures, "big" in opts)
+        sd, cfg = rand_scene(seed, textures, "big" in opts, "inst" in opts)
         if runner in (run_gpt, run_mcmc):
             cfg.sampler_type = abi.SAMPLER_INDEPENDENT  # gpt: independent sampler only
         sd.ggx_table = table
@@ -266,7 +279,7 @@ def main():
             if refused <= 3:
                 print("refused seed", seed, str(e)[:120], flush=True)
             continue
-        kinds["bvh" if scene.info().uses_bvh else "exhaustive"] += 1
+        kinds[("exhaustive", "bvh", "kept")[scene.info().uses_bvh]] += 1
         kinds["textured"] += int(bool(sd.images))
         try:
             nd, same_counts, info = runner(ctx, scene, sd, cfg, np.random.default_rng(seed + 7))
