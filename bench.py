@@ -510,6 +510,44 @@ def textured_room_leg(ctx):
     return out
 
 
+def instanced_forest_leg(ctx):
+    """procedural.instanced_forest(1000, 100_000) at 1080p -- 99.86 M instance-triangles, kept as meshes + instances (two-level
+    acceleration structure; flattened it would take 21 GB): 2 x 8 spp, the second launch timed; the same forest at
+    10 k triangles per mesh both ways, films compared bit for bit."""
+    from akari_render_amd import abi, capi, procedural
+
+    out = {}
+    for tris, modes in ((100_000, ("kept",)), (10_000, ("kept", "flattened"))):
+        sd = procedural.instanced_forest(1000, tris, width=W, height=H)
+        films = {}
+        for mode in modes:
+            with capi.options(instancing=1 if mode == "kept" else 0):
+                t0 = time.perf_counter()
+                scene = capi.Scene(ctx, sd)
+                t_load = time.perf_counter() - t0
+                info = scene.info()
+                film = capi.Film(ctx, W, H)
+                cfg = abi.PtConfig.default()
+                cfg.spp, cfg.spp_per_pass, cfg.max_depth, cfg.rr_depth = 16, 8, 12, 5
+                se = capi.PtSession(ctx, scene, cfg, film)
+            se.passes(1, blocking=True)
+            s0 = se.stats()
+            t0 = time.perf_counter()
+            se.passes(1, blocking=True)
+            dt = time.perf_counter() - t0
+            s1 = se.end()
+            d = {k: s1[k] - s0[k] for k in ("n_samples", "n_closest", "n_shadow", "n_node_visits", "n_tri_tests")}
+            rays = d["n_closest"] + d["n_shadow"]
+            films[mode] = film.read()
+            out[f"{tris // 1000}k_{mode}"] = {"value": d["n_samples"] / dt / 1e6, "unit": "Msamples/s", "n_triangles": int(info.n_triangles), "uses_bvh": int(info.uses_bvh),
+                                             "device_MB": info.device_bytes / 1e6, "compile_upload_s": t_load, "rays_per_s_G": rays / dt / 1e9,
+                                             "node_visits_per_ray": d["n_node_visits"] / rays, "candidates_per_ray": d["n_tri_tests"] / rays}
+            del se, film, scene
+        if len(films) == 2:
+            out[f"{tris // 1000}k_films_identical"] = bool(np.array_equal(films["kept"].view(np.uint32), films["flattened"].view(np.uint32)))
+    return out
+
+
 _NOT_REPORTED = ("weak", "spp_done", "film_tensor")
 
 
@@ -740,6 +778,10 @@ def main():
                 add_leg("textured_room", textured_room_leg(ctx))
             except Exception as ex:  # noqa: BLE001
                 add_leg("textured_room", {"error": f"{type(ex).__name__}: {ex}"})
+            try:
+                add_leg("instanced_forest", instanced_forest_leg(ctx))
+            except Exception as ex:  # noqa: BLE001
+                add_leg("instanced_forest", {"error": f"{type(ex).__name__}: {ex}"})
         # The wavefront schedule (wf_kernels.hip: trace / shade kernels, path state in HBM, ballot + prefix-sum compaction) next to the
         # megakernel on the same scenes, 4 passes (256 spp) each: the hall, and the cbox with a forced BVH (the wavefront schedule has
         # no exhaustive intersector). Measured every run so that the comparison in DESIGN.md is never a stale number.
