@@ -114,38 +114,56 @@ AKR_D void resolve_pending(const DScene& sc, TravI& s, bool any_hit) {
     }
 }
 
-// One step of one lane. Returns true when the lane found a second candidate for the exact test while one is pending: the candidate
-// is put back (its leaf bit set again) and the lane waits for trace_inst to resolve the pending one.
+// One step of one lane, in up to four stages -- whatever the lane's state allows, in this order: pop a stack entry (possibly the
+// sentinel that ends an instance), enter the instance of a pending top-level leaf, visit a node, test a candidate. (A wave pays for
+// every stage some lane is in; a lane that is through with one goes on to the next in the same iteration instead of waiting for the
+// wave's next one: a third fewer iterations per ray than one stage per step.) The order of a ray's node visits and candidates is the
+// one-stage-per-step order. Returns true when the lane found a second candidate for the exact test while one is pending: the
+// candidate is put back (its leaf bit set again) and the lane waits for trace_pair_inst / trace_inst to resolve the pending one.
 template <bool TEX>
 AKR_D bool trav_step_inst(const DScene& sc, TravI& s, uint32_t* __restrict__ stack, TraceCounters& cnt) {
-    const bool in_blas = s.inst != kInvalid;
-    const bool do_leaf = s.T != 0;
     bool blocked = false;
-    uint32_t leaf_bit = 0;
-    const uint4* p;
-    if (do_leaf) {
-        const uint32_t b = (uint32_t)__builtin_ctz(s.T);
-        leaf_bit = b;
-        s.T &= s.T - 1u;
-        p = in_blas ? (const uint4*)sc.in2.mesh_tris + (size_t)(s.tri_off + s.tbase + b) * 4 : sc.in2.tlas_leaves + (size_t)(s.tbase + b) * 4;
-    } else {
-        if ((s.G >> 24) == 0) {  // the caller guarantees sp > 0 here
+    // ---- stage 0: nothing pending at this level -> the next stack entry (the caller guarantees sp > 0 then)
+    if ((s.T == 0) & ((s.G >> 24) == 0)) {
+        s.sp--;
+        const uint32_t e = stack[s.sp * 256u];
+        if ((s.inst != kInvalid) & ((e >> 24) == 0)) {
+            // the sentinel: this instance is done. Back to the TLAS where it stood: pending leaf bits, their base, the pending group.
+            s.T = e;
             s.sp--;
-            const uint32_t e = stack[s.sp * 256u];
-            if (in_blas && (e >> 24) == 0) {
-                // the sentinel: this instance is done. Back to the TLAS where it stood: pending leaf bits, their base, the pending group.
-                s.T = e;
-                s.sp--;
-                s.tbase = stack[s.sp * 256u];
-                s.sp--;
-                s.G = stack[s.sp * 256u];
-                s.inst = kInvalid; s.node_off = 0; s.tri_off = 0; s.leaf = kInvalid;
-                trav_set_ray(s, s.wo, s.wd);
-                s.active = (s.T != 0) | ((s.G >> 24) != 0) | (s.sp != 0);
-                return false;
-            }
+            s.tbase = stack[s.sp * 256u];
+            s.sp--;
+            s.G = stack[s.sp * 256u];
+            s.inst = kInvalid; s.node_off = 0; s.tri_off = 0; s.leaf = kInvalid;
+            trav_set_ray(s, s.wo, s.wd);
+        } else {
             s.G = e;
         }
+    }
+    // ---- stage 1: a pending TLAS leaf entry = an instance: remember where the TLAS traversal stands, take the ray into object space,
+    // start at the BLAS root
+    if ((s.T != 0) & (s.inst == kInvalid)) {
+        const uint32_t b = (uint32_t)__builtin_ctz(s.T);
+        s.T &= s.T - 1u;
+        const uint4* lf = sc.in2.tlas_leaves + (size_t)(s.tbase + b) * 4;
+        const uint4 w0 = lf[0], w1 = lf[1], w2 = lf[2], w3 = lf[3];
+#if !defined(AKR_INST_COUNT)
+        cnt.nodes++;
+#endif
+        if (s.sp + 3 <= sc.bvh_stack_depth) {
+            stack[s.sp * 256u] = s.G; s.sp++;
+            stack[s.sp * 256u] = s.tbase; s.sp++;
+            stack[s.sp * 256u] = s.T & 0x00ffffffu; s.sp++;
+        } else {
+            cnt.overflow = 1;
+        }
+        s.leaf = s.tbase + b;
+        trav_into_instance(s, w0, w1, w2, w3);
+        s.G = 1u << (24u + (s.octinv4 & 7u));  // the group {BLAS root}: base 0 (relative), slot 0
+        s.T = 0; s.tbase = 0;
+    }
+    // ---- stage 2: a node of either level: disect.h trav_step's box test on the current level's ray
+    if ((s.T == 0) & ((s.G >> 24) != 0)) {
         const uint32_t j = 31u - (uint32_t)__builtin_clz(s.G);  // nearest pending sibling
         s.G &= ~(1u << j);
         if ((s.G >> 24) != 0) {  // the others wait as one entry
@@ -158,59 +176,8 @@ AKR_D bool trav_step_inst(const DScene& sc, TravI& s, uint32_t* __restrict__ sta
         }
         const uint32_t slot = (j - 24u) ^ (s.octinv4 & 7u);
         const uint32_t idx = s.node_off + (s.G & 0xffffffu) + slot;
-        p = sc.bvh_nodes + (size_t)idx * (kBvhNodeWords / 4);
-    }
-    uint4 w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3];
-    asm volatile("" : "+v"(w0.x), "+v"(w0.y), "+v"(w0.z), "+v"(w0.w), "+v"(w1.x), "+v"(w1.y), "+v"(w1.z), "+v"(w1.w), "+v"(w2.x), "+v"(w2.y),
-                      "+v"(w2.z), "+v"(w2.w), "+v"(w3.x), "+v"(w3.y), "+v"(w3.z), "+v"(w3.w));
-    if (do_leaf && !in_blas) {
-        // ---- a TLAS leaf entry = an instance: remember where the TLAS traversal stands, take the ray into object space, start at the BLAS root
-#if !defined(AKR_INST_COUNT)
-        cnt.nodes++;
-#endif
-        if (s.sp + 3 <= sc.bvh_stack_depth) {
-            stack[s.sp * 256u] = s.G; s.sp++;
-            stack[s.sp * 256u] = s.tbase; s.sp++;
-            stack[s.sp * 256u] = s.T & 0x00ffffffu; s.sp++;
-        } else {
-            cnt.overflow = 1;
-        }
-        s.leaf = s.tbase + leaf_bit;
-        trav_into_instance(s, w0, w1, w2, w3);
-        s.G = 1u << (24u + (s.octinv4 & 7u));  // the group {BLAS root}: base 0 (relative), slot 0
-        s.T = 0; s.tbase = 0;
-    } else if (do_leaf) {
-        // ---- a candidate triangle of the current instance: the conservative reject (dinst.h tri_may_hit) here; what it cannot decide
-        // waits in the lane's pending slot for the exact test, which trace_inst runs for many lanes at once
-        cnt.tris++;
-        const uint32_t prim = w3.w, gid = s.gid_base + prim;
-        if ((gid != s.ex0) & (gid != s.ex1)) {
-            const float4* m = sc.inst + (size_t)s.inst * INST_ROWS;
-            const vec3 c0 = xyz(m[0]), c1 = xyz(m[1]), c2 = xyz(m[2]), tr = xyz(m[3]);
-            const vec3 A = xf_point(c0, c1, c2, tr, mk3(u2f(w0.x), u2f(w0.y), u2f(w0.z))), B = xf_point(c0, c1, c2, tr, mk3(u2f(w1.x), u2f(w1.y), u2f(w1.z)));
-            const vec3 C = xf_point(c0, c1, c2, tr, mk3(u2f(w2.x), u2f(w2.y), u2f(w2.z)));
-            // (an odd triangle may carry its even neighbour's plane row: that plane is within 1e-6 sqrt(|n_even|) of its vertices;
-            // m[7].x bounds sqrt(|n|) over the instance's triangles -- scene_inst.cpp)
-            const float shift = (prim & 1u) ? 2e-6f * m[7].x : 0.0f;
-#if defined(AKR_INST_PRETEST_CHECK)  // measurement / test builds: every candidate takes the exact test, which reports a wrong reject
-            const bool may = tri_may_hit(s.wo, s.wd, A, B, C, s.tmin, s.best_t, shift);
-            if (s.pend_rec == kInvalid && s.check_t != -2.0f) s.check_t = may ? -1.0f : s.best_t;
-            if (true) {
-#else
-            if (tri_may_hit(s.wo, s.wd, A, B, C, s.tmin, s.best_t, shift)) {
-#endif
-                if (s.pend_rec == kInvalid) {
-                    s.pend_rec = s.tri_off + s.tbase + leaf_bit;
-                    s.pend_inst = s.inst;
-                } else {
-                    s.T |= 1u << leaf_bit;
-                    cnt.tris--;
-                    blocked = true;
-                }
-            }
-        }
-    } else {
-        // ---- a node of either level: disect.h trav_step's box test on the current level's ray
+        const uint4* p = sc.bvh_nodes + (size_t)idx * (kBvhNodeWords / 4);
+        const uint4 w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3];
 #if !defined(AKR_INST_COUNT)
         cnt.nodes++;
 #endif
@@ -243,6 +210,42 @@ AKR_D bool trav_step_inst(const DScene& sc, TravI& s, uint32_t* __restrict__ sta
         s.G = ((w0.w >> 24) | ((w1.x & 0xffffu) << 8)) | (hitmask & 0xff000000u);
         s.T = hitmask & 0x00ffffffu;
         s.tbase = w1.z;
+    }
+    // ---- stage 3: a candidate triangle of the current instance: the conservative reject (dinst.h tri_may_hit) here; what it cannot
+    // decide waits in the lane's pending slot for the exact test, which the caller runs for many lanes at once
+    // (two or three candidates, or two or three nodes, per step were measured too: 135 / 125 and 156 / 148 against 159 Msamples/s)
+    if ((s.T != 0) & (s.inst != kInvalid)) {
+        const uint32_t leaf_bit = (uint32_t)__builtin_ctz(s.T);
+        s.T &= s.T - 1u;
+        const uint4* p = (const uint4*)sc.in2.mesh_tris + (size_t)(s.tri_off + s.tbase + leaf_bit) * 4;
+        const uint4 w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3];
+        cnt.tris++;
+        const uint32_t prim = w3.w, gid = s.gid_base + prim;
+        if ((gid != s.ex0) & (gid != s.ex1)) {
+            const float4* m = sc.inst + (size_t)s.inst * INST_ROWS;
+            const vec3 c0 = xyz(m[0]), c1 = xyz(m[1]), c2 = xyz(m[2]), tr = xyz(m[3]);
+            const vec3 A = xf_point(c0, c1, c2, tr, mk3(u2f(w0.x), u2f(w0.y), u2f(w0.z))), B = xf_point(c0, c1, c2, tr, mk3(u2f(w1.x), u2f(w1.y), u2f(w1.z)));
+            const vec3 C = xf_point(c0, c1, c2, tr, mk3(u2f(w2.x), u2f(w2.y), u2f(w2.z)));
+            // (an odd triangle may carry its even neighbour's plane row: that plane is within 1e-6 sqrt(|n_even|) of its vertices;
+            // m[7].x bounds sqrt(|n|) over the instance's triangles -- scene_inst.cpp)
+            const float shift = (prim & 1u) ? 2e-6f * m[7].x : 0.0f;
+#if defined(AKR_INST_PRETEST_CHECK)  // measurement / test builds: every candidate takes the exact test, which reports a wrong reject
+            const bool may = tri_may_hit(s.wo, s.wd, A, B, C, s.tmin, s.best_t, shift);
+            if (s.pend_rec == kInvalid && s.check_t != -2.0f) s.check_t = may ? -1.0f : s.best_t;
+            if (true) {
+#else
+            if (tri_may_hit(s.wo, s.wd, A, B, C, s.tmin, s.best_t, shift)) {
+#endif
+                if (s.pend_rec == kInvalid) {
+                    s.pend_rec = s.tri_off + s.tbase + leaf_bit;
+                    s.pend_inst = s.inst;
+                } else {
+                    s.T |= 1u << leaf_bit;
+                    cnt.tris--;
+                    blocked = true;
+                }
+            }
+        }
     }
     s.active = (s.T != 0) | ((s.G >> 24) != 0) | (s.sp != 0);
     return blocked;
@@ -327,7 +330,7 @@ AKR_D void trace_pair_inst(const DScene& sc, bool has_ray, vec3 ro, vec3 rd, uin
         s.active = (s.T != 0) | ((s.G >> 24) != 0) | (s.sp != 0);
     }
     const uint32_t n_in = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(phase != 2u));
-    const uint32_t n_leave = STRAG > 0 ? n_in / STRAG : 0u;
+    const uint32_t n_leave = STRAG > 0 ? n_in / (STRAG > 0 ? STRAG : 1u) : 0u;
     uint32_t waited = 0;
     bool blocked = false;
     while (true) {
