@@ -536,12 +536,16 @@ def instanced_forest_leg(ctx):
             se.passes(1, blocking=True)
             dt = time.perf_counter() - t0
             s1 = se.end()
-            d = {k: s1[k] - s0[k] for k in ("n_samples", "n_closest", "n_shadow", "n_node_visits", "n_tri_tests")}
+            d = {k: s1[k] - s0[k] for k in ("n_samples", "n_closest", "n_shadow", "n_shaded", "n_node_visits", "n_tri_tests", "n_launches", "kernel_ms")}
             rays = d["n_closest"] + d["n_shadow"]
             films[mode] = film.read()
+            rl = roofline_block("forest", d)  # the same byte model (8d) over the same counters: 64 B per node visit, 48 B per candidate
+            rl["kernel"] = "k_pt_pass_inst" if mode == "kept" else "k_pt_pass"
             out[f"{tris // 1000}k_{mode}"] = {"value": d["n_samples"] / dt / 1e6, "unit": "Msamples/s", "n_triangles": int(info.n_triangles), "uses_bvh": int(info.uses_bvh),
                                              "device_MB": info.device_bytes / 1e6, "compile_upload_s": t_load, "rays_per_s_G": rays / dt / 1e9,
-                                             "node_visits_per_ray": d["n_node_visits"] / rays, "candidates_per_ray": d["n_tri_tests"] / rays}
+                                             "node_visits_per_ray": d["n_node_visits"] / rays, "candidates_per_ray": d["n_tri_tests"] / rays,
+                                             "roofline": {k: rl[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_measured", "traffic", "kernel", "avg_launch_ms",
+                                                                             "algorithmic_bytes_per_sample")}}
             del se, film, scene
         if len(films) == 2:
             out[f"{tris // 1000}k_films_identical"] = bool(np.array_equal(films["kept"].view(np.uint32), films["flattened"].view(np.uint32)))
