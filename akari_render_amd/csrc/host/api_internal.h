@@ -120,6 +120,10 @@ struct akr_context {
     hipDeviceProp_t props;
     void bind() const { HIP_CHECK(hipSetDevice(device)); }
     SpecCache spec_cache;  // per-scene kernels loaded on this device (host/specialise.cpp)
+    // PreComputedTables (svm/surface/precompute.rs:133-145) as this context's first scene that needed it computed it: the table is
+    // a constant of the algorithm (fixed seed stream, 2^20 samples per entry: 1.8 s on an MI355X), not of the scene
+    std::mutex ggx_mutex;
+    std::vector<float> ggx_cache;
     // tables of the pmj02bn sampler, uploaded when the first session asks for it
     DevBuf pmj_sets, bluenoise;
     void ensure_pmj_tables() {

@@ -6,6 +6,12 @@ static void ensure_ggx_table(akr_scene* s) {
     if (!s->flat.ggx_table.empty()) {
         s->ggx_host = s->flat.ggx_table;
     } else if (s->cs.needs_ggx_table) {
+        std::lock_guard<std::mutex> lock(ctx->ggx_mutex);
+        if (!ctx->ggx_cache.empty()) {  // computed for an earlier scene of this context
+            s->ggx_host = ctx->ggx_cache;
+            s->ggx_table.upload(s->ggx_host);
+            return;
+        }
         // PreComputedTables::init (svm/surface/precompute.rs:133-145): seeds = StdRng(0) stream, one per entry
         std::vector<uint64_t> seeds(4096);
         StdRng rng(0);
@@ -17,6 +23,7 @@ static void ensure_ggx_table(akr_scene* s) {
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         s->ggx_host.resize(4096);
         HIP_CHECK(hipMemcpy(s->ggx_host.data(), s->ggx_table.p, 4096 * sizeof(float), hipMemcpyDeviceToHost));
+        ctx->ggx_cache = s->ggx_host;
         return;
     } else {
         s->ggx_host.assign(4096, 0.0f);  // never read with a non-zero weight

@@ -124,6 +124,25 @@ def test_ggx_dielectric_table(ctx, root, oracle_lib):
         assert np.array_equal(np.fromfile(path, dtype=np.float32).view(np.uint32), tab.view(np.uint32))
 
 
+def test_ggx_table_is_computed_once_per_context(root):
+    """The table is a constant of the algorithm, not of the scene: a context's first scene that needs it computes it (1.8 s), later
+    scenes of the context get the same bits without the kernel."""
+    import time
+
+    from tests.helpers import box_scene
+    c2 = capi.Context(0)
+    sd = box_scene()
+    sd.materials = [abi.MaterialData(base_color=(0.5, 0.5, 0.5), roughness=0.4, ior=1.5, specular_ior_level=0.5)]
+    t0 = time.perf_counter()
+    a = capi.Scene(c2, sd)
+    t1 = time.perf_counter()
+    b = capi.Scene(c2, sd)
+    t2 = time.perf_counter()
+    assert np.array_equal(a.ggx_table().view(np.uint32), b.ggx_table().view(np.uint32))
+    assert np.array_equal(np.fromfile(os.path.join(root, "tests", "golden", "ggx_dielectric_s.f32"), dtype=np.float32).view(np.uint32), b.ggx_table().view(np.uint32))
+    assert (t2 - t1) < 0.25 * (t1 - t0), (t1 - t0, t2 - t1)
+
+
 @pytest.mark.parametrize("which", ["exhaustive_cbox", "bvh4_grid", "bvh4_cbox_forced"])
 def test_both_intersectors_against_f64_moeller_trumbore(ctx, cbox_path, which):
     """10^6 rays (half random, half aimed at triangle edges and vertices) through the GPU's exhaustive walk and through its

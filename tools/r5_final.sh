@@ -6,7 +6,17 @@
 #      sampler bench, forest (kept vs flattened), the conservative-reject check build
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r5_final; mkdir -p $O
-if [ "${1:-a}" = "a" ]; then
+if [ "${1:-a}" = "c" ]; then  # after a late change: tests, the PMC stamps of the three configurations, the bench line
+  timeout 1500 python -m pytest tests -x -q -m gpu > $O/gputest.log 2>&1; echo "tests rc=$? $(grep -E "passed|failed" $O/gputest.log | tail -1)"
+  for CFG in c2 c3 c4; do
+    bash tools/pmc_bench.sh $CFG > $O/pmc_$CFG.log 2>&1
+    cp gpurun_out/r4_pmc_bench_$CFG/summary.json $O/r5_pmc_$CFG.json; rm -rf gpurun_out/r4_pmc_bench_$CFG
+    python -c "import json;d=json.load(open('$O/r5_pmc_$CFG.json'));print('pmc $CFG', {k:d.get(k) for k in ('valu_lane_utilisation','hbm_bytes_per_sample','value_under_profiler_msamples_s','csrc_hash')})"
+  done
+  for f in c2 c3 c4; do cp $O/r5_pmc_$f.json profiles/r5_pmc_$f.json; done   # (bench.py reads them from profiles/)
+  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/r5_bench.json 2> $O/r5_bench.err; python -c "
+import json;d=json.load(open('$O/r5_bench.json'));r=d['roofline'];print('BENCH',round(d['value'],1),'frac',round(r['frac'],3),'frac_measured',r.get('frac_measured'));e=d['extra_configs'];print({k:(round(v['value'],1), v.get('roofline',{}).get('frac_measured')) for k,v in e.items() if isinstance(v,dict) and 'value' in v})"
+elif [ "${1:-a}" = "a" ]; then
   timeout 1500 python -m pytest tests -x -q -m gpu > $O/gputest.log 2>&1; echo "tests rc=$? $(grep -E "passed|failed" $O/gputest.log | tail -1)"
   python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
   for MODE in "400 1100000" "120 1200000 big" "200 1300000 tex" "120 1400000 wavefront" "120 1500000 shard" "80 1600000 gpt" "80 1700000 aov" "60 1750000 mcmc" "400 1800000 inst" "120 1810000 inst big" "200 1820000 inst tex" "100 1830000 inst shard"; do
