@@ -441,7 +441,7 @@ def check_against_mt_f64(world_vertices, rays, hit, gid, tuv, mt_gid, mt, mt_own
 
 # ---------------------------------------------------------------------------------------------- instanced scenes
 def instanced_scene(n_inst=12, n=6, width=48, height=48, seed=5, with_normals=True, with_uvs=True, mirror=True, emissive_instances=1,
-                    alpha=False, textured=False) -> abi.SceneData:
+                    alpha=False, textured=False, tangents=False) -> abi.SceneData:
     """`n_inst` copies of one bumpy blob (a closed latitude/longitude mesh of 2 n (2n - 1)... triangles, two material slots, corner
     normals, uvs) with rotated, non-uniformly scaled and (every third) mirrored transforms, over a floor quad, under a light quad.
     `emissive_instances` of the copies carry an emissive material in slot 1 (lights on an instanced mesh)."""
@@ -477,7 +477,12 @@ def instanced_scene(n_inst=12, n=6, width=48, height=48, seed=5, with_normals=Tr
         vn /= np.maximum(np.linalg.norm(vn, axis=1, keepdims=True), 1e-20)
         normals = vn[idx].astype(np.float32)
     uvs = vuv[idx].astype(np.float32) if with_uvs else None
-    blob = abi.MeshData(vertices=verts, indices=idx, material_slots=slots, normals=normals, uvs=uvs)
+    tang = None
+    if tangents:  # per-corner tangents (mesh.rs:557-571: used only when all nine floats of a triangle are finite)
+        tang = rng.normal(size=(idx.shape[0], 3, 3)).astype(np.float32)
+        tang /= np.linalg.norm(tang, axis=2, keepdims=True)
+        tang[::7, 1, 2] = np.nan
+    blob = abi.MeshData(vertices=verts, indices=idx, material_slots=slots, normals=normals, uvs=uvs, tangents=tang)
     quad = np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], dtype=np.float32)
     floor = abi.MeshData(vertices=quad * np.float32(6.0), indices=np.array([[0, 2, 1], [0, 3, 2]], dtype=np.uint32))
     light = abi.MeshData(vertices=quad * np.float32(1.5) + np.array([0, 6.0, 0], dtype=np.float32), indices=np.array([[0, 1, 2], [0, 2, 3]], dtype=np.uint32))

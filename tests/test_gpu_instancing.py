@@ -54,6 +54,8 @@ CASES = {
     "sobol_textured": (dict(n_inst=12, n=6, emissive_instances=1, textured=True), dict(sampler_type=abi.SAMPLER_SOBOL, sampler_seed=11)),
     "ragged_passes": (dict(n_inst=12, n=6, emissive_instances=1), dict(spp=11, spp_per_pass=4)),
     "deep": (dict(n_inst=40, n=12, emissive_instances=2), dict(max_depth=16, rr_depth=8)),
+    "tangents": (dict(n_inst=12, n=6, emissive_instances=1, tangents=True), dict()),
+    "tangents_no_normals": (dict(n_inst=12, n=6, emissive_instances=1, tangents=True, with_normals=False, textured=True), dict()),
 }
 
 
