@@ -741,9 +741,7 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
                      out.tex_nodes.size() * sizeof(DNode), out.images.size() * sizeof(DImage), out.mat_inputs.size() * sizeof(MatInputs)})
         stage += (b + 15) & ~(size_t)15;
     if (n_tris > kExhaustiveMax || stage > kStageMaxBytes) {
-        float diag2 = 0.0f;
-        for (int a = 0; a < 3; a++) diag2 += sqr(out.scene_hi[a] - out.scene_lo[a]);
-        float pad = 4e-6f * __builtin_sqrtf(diag2);
+        const float pad = bvh_box_padding(out.scene_lo, out.scene_hi, flat.camera.c2w);
         std::vector<uint32_t> order;
         const bool force_balanced = tune.bvh_balanced != 0;  // test hook: take the fallback builder
         build_bvh8(bounds, n_tris, pad, kBvhNodeWords, force_balanced, order, out.bvh_nodes, out.bvh_depth);

@@ -105,7 +105,7 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
         diag2 += sqr(out.scene_hi[a] - out.scene_lo[a]);
         reach += max_f(max_f(abs_f(out.scene_lo[a]), abs_f(out.scene_hi[a])), abs_f(flat.camera.c2w[12 + a]));
     }
-    const float pad_world = 4e-6f * __builtin_sqrtf(diag2);  // the flattened tree's padding: covers the triangle test's own slop
+    const float pad_world = bvh_box_padding(out.scene_lo, out.scene_hi, flat.camera.c2w);  // the flattened tree's padding
     // ---- per instance: the inverse transform (double -> f32; used for culling only) and its norm
     std::vector<double> inv(12 * n_inst);
     std::vector<float> inv_norm(n_inst, 0.0f), mesh_inv_norm(n_mesh, 0.0f);

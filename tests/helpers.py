@@ -537,3 +537,16 @@ def instanced_scene(n_inst=12, n=6, width=48, height=48, seed=5, with_normals=Tr
     c2w = np.array([[1, 0, 0, 0], [0, np.cos(ca), -np.sin(ca), 4.0], [0, np.sin(ca), np.cos(ca), 9.0], [0, 0, 0, 1]], dtype=np.float32)
     cam = abi.CameraData(c2w=c2w.T.reshape(16).copy(), fov=0.8, width=width, height=height)
     return abi.SceneData([blob, floor, light], insts, mats, cam, images=images)
+
+
+def shift_scene(sd: abi.SceneData, offset) -> abi.SceneData:
+    """The whole scene, camera included, moved by `offset` (a scene modelled far from the origin)."""
+    off = np.asarray(offset, dtype=np.float32)
+    for inst in sd.instances:
+        t = np.asarray(inst.transform, dtype=np.float32).reshape(4, 4).copy()  # stored transposed: row 3 is the translation
+        t[3, :3] += off
+        inst.transform = t.reshape(16)
+    c = np.asarray(sd.camera.c2w, dtype=np.float32).reshape(4, 4).copy()
+    c[3, :3] += off
+    sd.camera.c2w = c.reshape(16)
+    return sd

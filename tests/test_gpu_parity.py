@@ -11,7 +11,7 @@ import pytest
 
 from akari_render_amd import abi, capi, distributed
 from oracle import pyoracle, scene_json
-from tests.helpers import box_scene, cbox_variant, grid_scene, make_config, n_bit_diff, rel_rmse, resolve_np
+from tests.helpers import box_scene, cbox_variant, grid_scene, instanced_scene, make_config, n_bit_diff, rel_rmse, resolve_np, shift_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -315,3 +315,24 @@ def test_conductor_hits_shaded_on_even_iterations_only(ctx, cbox_path, mask):
     with capi.options(defer_metal=mask):
         g, o, gst, ost, _, _ = render_both(ctx, sd, make_config(spp=8, spp_per_pass=4, max_depth=7))
     assert_parity(g, o, 96, 96, gst, ost)
+
+
+@pytest.mark.parametrize("offset", [1000.0, 10000.0])
+def test_bvh_scenes_far_from_the_origin(ctx, cbox_path, root, offset):
+    """A scene modelled far from the origin: the round-off of the slab test and of the triangle test grows with the coordinates, and
+    the padding of the tree's boxes has to grow with it (host/scene_build.h bvh_box_padding). Before round 5 it looked at the
+    scene's diagonal only and the forced-BVH Cornell box at offset 1000 lost hits (12 film floats off the oracle, 3 621 at 10 000)."""
+    table = np.fromfile(os.path.join(root, "tests", "golden", "ggx_dielectric_s.f32"), dtype=np.float32)
+    cfg = make_config(spp=8, spp_per_pass=8, max_depth=8)
+    for name, sd, opts in (("cbox", scene_json.load_scene(cbox_path, 64, 64), dict(force_bvh=1)), ("grid", grid_scene(n=16, width=48, height=48), dict()),
+                           ("instanced flattened", instanced_scene(width=48, height=40), dict(instancing=0)),
+                           ("instanced kept", instanced_scene(width=48, height=40), dict(instancing=1))):
+        sd = shift_scene(sd, (offset, 2 * offset, -0.5 * offset))
+        sd.ggx_table = table
+        with capi.options(**opts):
+            scene = capi.Scene(ctx, sd)
+            assert scene.info().uses_bvh >= 1
+            film = capi.Film(ctx, sd.camera.width, sd.camera.height)
+            capi.pt_render(ctx, scene, cfg, film)
+        o, _ = pyoracle.OracleScene(sd).render(cfg)  # the exhaustive loop: the definition of a hit
+        assert n_bit_diff(film.read(), o) == 0, name
