@@ -568,6 +568,14 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
     out.inst_tri_offset.resize(n_inst + 1);
     uint32_t n_tris = 0;
     bool any_normals = false;
+    {   // global triangle ids are 32 bits (0xffffffff = none): a scene kept as meshes + instances costs nothing per instance-triangle,
+        // so nothing else would stop one that has more of them than that
+        uint64_t total = 0;
+        for (const HostInstance& in : flat.instances)
+            if (in.mesh < flat.meshes.size()) total += flat.meshes[in.mesh].n_triangles();
+        if (total >= 0xffffffffull)
+            throw std::runtime_error("unsupported: " + std::to_string(total) + " instance-triangles; global triangle ids are 32 bits");
+    }
     for (size_t i = 0; i < n_inst; i++) {
         const HostInstance& in = flat.instances[i];
         xf[i] = make_xform(in.transform);

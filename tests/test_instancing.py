@@ -180,3 +180,13 @@ def test_the_conservative_reject_never_drops_what_the_exact_test_accepts(hip_lib
     _, exact_shifted, _ = capi.host_tri_pretest(rays, shifted)
     may, _, _ = capi.host_tri_pretest(rays, tris, plane_shift=shift)
     assert not np.any(exact_shifted & ~may)
+
+
+def test_more_instance_triangles_than_ids_are_refused(hip_lib):
+    """Global triangle ids are 32 bits. A kept scene costs nothing per instance-triangle, so the count has to be checked: 43 100
+    instances of a 100 k-triangle mesh (4.3 G instance-triangles) are refused, not rendered with wrapped ids."""
+    sd = procedural.instanced_forest(43_100, 100_000, width=32, height=18, n_meshes=1, n_lanterns=0)
+    assert sd.n_triangles() > 0xFFFFFFFF
+    with pytest.raises(capi.AkariError) as ei:
+        capi.Scene(None, sd)
+    assert ei.value.code == capi.ERR_UNSUPPORTED and "32 bits" in str(ei.value)
