@@ -604,6 +604,7 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
     if (any_normals) out.normals.assign(24ull * n_tris, 0.0f);  // 3 float4 normals + 3 float4 tangents per triangle
     std::vector<float> bounds(6ull * n_tris);
     std::vector<float> tri_power(n_tris, 0.0f);
+    std::vector<float> tri_cond(3ull * n_tris, 0.0f);  // conditioning of each triangle's (u, v) parametrisation per axis (scene_build.h)
     for (int a = 0; a < 3; a++) { out.scene_lo[a] = INFINITY; out.scene_hi[a] = -INFINITY; }
 
     // Per-triangle records, chunk by chunk on the host's threads (a 10 M-triangle mesh: 0.9 s on one). A chunk starts at an even
@@ -685,6 +686,10 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
             float* bb = &bounds[6ull * gid];
             bb[0] = min_f(min_f(A.x, B.x), C.x); bb[1] = min_f(min_f(A.y, B.y), C.y); bb[2] = min_f(min_f(A.z, B.z), C.z);
             bb[3] = max_f(max_f(A.x, B.x), C.x); bb[4] = max_f(max_f(A.y, B.y), C.y); bb[5] = max_f(max_f(A.z, B.z), C.z);
+            {
+                const double Ad[3] = {A.x, A.y, A.z}, Bd[3] = {B.x, B.y, B.z}, Cd[3] = {C.x, C.y, C.z};
+                tri_conditioning(Ad, Bd, Cd, &tri_cond[3ull * gid]);
+            }
             // a non-finite corner (inf / NaN vertex, or a transform that produces one) has no place in a box hierarchy: the
             // builder's costs become NaN and geometry would silently go missing. Refused here, for every scene size.
             if (!(is_finite(A.x) && is_finite(A.y) && is_finite(A.z) && is_finite(B.x) && is_finite(B.y) && is_finite(B.z) && is_finite(C.x) &&
@@ -750,6 +755,22 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
         stage += (b + 15) & ~(size_t)15;
     if (n_tris > kExhaustiveMax || stage > kStageMaxBytes) {
         const float pad = bvh_box_padding(out.scene_lo, out.scene_hi, flat.camera.c2w);
+        {   // needles: what their ill-conditioned inside test reaches beyond the flat padding, per triangle and axis (scene_build.h)
+            const float reach = scene_reach(out.scene_lo, out.scene_hi, flat.camera.c2w);
+            const unsigned nc = n_tris > (1u << 17) ? host_threads() * 4 : 1;
+            parallel_chunks(nc, host_threads(), [&](unsigned c) {
+                const uint32_t lo = (uint32_t)((uint64_t)n_tris * c / nc), hi = (uint32_t)((uint64_t)n_tris * (c + 1) / nc);
+                for (uint32_t g = lo; g < hi; g++)
+                    for (int a = 0; a < 3; a++) {
+                        const float extra = tri_cond_extra(tri_cond[3ull * g + a], reach);
+                        if (extra > 0.0f) {
+                            bounds[6ull * g + a] -= extra;
+                            bounds[6ull * g + 3 + a] += extra;
+                        }
+                    }
+            });
+        }
+        std::vector<float>().swap(tri_cond);
         std::vector<uint32_t> order;
         const bool force_balanced = tune.bvh_balanced != 0;  // test hook: take the fallback builder
         build_bvh8(bounds, n_tris, pad, kBvhNodeWords, force_balanced, order, out.bvh_nodes, out.bvh_depth);

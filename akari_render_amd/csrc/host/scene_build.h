@@ -122,6 +122,38 @@ inline float bvh_box_padding(const float lo[3], const float hi[3], const float* 
     return 4e-6f * (diag > reach ? diag : reach);
 }
 
+// Conditioning of a triangle's (u, v) parametrisation. The inside test computes u = r0 . p + c0 with |r0| = |e2| / |n| (v likewise with
+// |r1| = |e1| / |n|) and is off by up to ~11 x 2^-24 x |r0| x (magnitude of the coordinates): the triangle the test "sees" is displaced by
+// du e1 + dv e2. For a well-shaped triangle that is a few ulp of the coordinates -- what bvh_box_padding allows for -- but |r0||e1| = 1 / sin(angle
+// at the first vertex): a needle whose first vertex holds its small angle is displaced along its long axis by 1 / sin times as much, and
+// the exhaustive loop accepts hits that far outside it (round 6: tests/bvh_model.py found such pairs in 9 of 150 extreme scenes, among
+// them the one film pixel of HISTORY R5.7). k[a] = |r0||e1_a| + |r1||e2_a| per axis; a box must reach kTriCondEps x magnitude x k[a] beyond the
+// triangle. The flat padding covers k <= kTriCondFree (2 for a right angle at the first vertex, 2.31 for 60 degrees); what exceeds it is added to
+// the triangle's own box.
+constexpr float kTriCondEps = 16.0f * 5.9604645e-8f;
+constexpr float kTriCondFree = 2.7f;
+inline void tri_conditioning(const double A[3], const double B[3], const double C[3], float k[3]) {
+    const double e1[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, e2[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
+    const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const double nl = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    const double l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]), l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+    for (int a = 0; a < 3; a++) {
+        const double v = nl > 0.0 ? (l2 * std::fabs(e1[a]) + l1 * std::fabs(e2[a])) / nl : 0.0;  // (a degenerate triangle has an all-zero record: never accepted)
+        k[a] = v < 1e30 ? (float)(v * 1.0001) : 1e30f;
+    }
+}
+// what a box of a triangle with conditioning k[a] needs beyond the flat padding, along axis a; magnitude = the `reach` of bvh_box_padding
+inline float tri_cond_extra(float k, float magnitude) { return k > kTriCondFree ? kTriCondEps * magnitude * (k - kTriCondFree) : 0.0f; }
+inline float scene_reach(const float lo[3], const float hi[3], const float* c2w) {
+    float reach = 0.0f;
+    for (int a = 0; a < 3; a++) {
+        const float m = std::fabs(lo[a]) > std::fabs(hi[a]) ? std::fabs(lo[a]) : std::fabs(hi[a]);
+        const float c = std::fabs(c2w[12 + a]);
+        reach += m > c ? m : c;
+    }
+    return reach;
+}
+
 DMaterial fold_material(const akr_material_desc& m, uint32_t color = 0);
 // materials / node lists / raw inputs under the colour pipeline `color` (scene_build.cpp); fills out.materials, out.tex_nodes,
 // out.mat_inputs only

@@ -32,6 +32,41 @@ vec3 ld3(const std::vector<float>& v, size_t i) { return mk3(v[3 * i], v[3 * i +
 constexpr uint64_t kFlatBytesPerTriangle = 64 + 128 + 20;
 constexpr uint64_t kFlatBudgetBytes = 8ull << 30;   // automatic mode: flatten while the records stay below this
 constexpr uint64_t kFlatMaxTriangles = 48u << 20;   // ... and the flattened tree below its 2^24 node slots (~0.29 slots per triangle)
+
+// largest and smallest singular value of the linear part of an instance transform (column-major 4x4): square roots of the extreme
+// eigenvalues of L^T L, by the trigonometric solution of the symmetric 3x3 characteristic polynomial
+void singular_range(const float* m, double& smax, double& smin) {
+    double a[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            a[i][j] = 0.0;
+            for (int k = 0; k < 3; k++) a[i][j] += (double)m[4 * i + k] * (double)m[4 * j + k];  // (columns i, j of L)
+        }
+    const double p1 = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+    const double q = (a[0][0] + a[1][1] + a[2][2]) / 3.0;
+    const double p2 = (a[0][0] - q) * (a[0][0] - q) + (a[1][1] - q) * (a[1][1] - q) + (a[2][2] - q) * (a[2][2] - q) + 2.0 * p1;
+    double e0, e2;
+    if (!(p2 > 0.0)) {
+        e0 = e2 = q;
+    } else {
+        const double p = std::sqrt(p2 / 6.0);
+        double b[3][3];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) b[i][j] = (a[i][j] - (i == j ? q : 0.0)) / p;
+        double r = 0.5 * (b[0][0] * (b[1][1] * b[2][2] - b[1][2] * b[2][1]) - b[0][1] * (b[1][0] * b[2][2] - b[1][2] * b[2][0]) +
+                          b[0][2] * (b[1][0] * b[2][1] - b[1][1] * b[2][0]));
+        r = std::max(-1.0, std::min(1.0, r));
+        const double phi = std::acos(r) / 3.0;
+        e0 = q + 2.0 * p * std::cos(phi);                             // largest
+        e2 = q + 2.0 * p * std::cos(phi + 2.0 * 3.14159265358979323846 / 3.0);  // smallest
+    }
+    smax = std::sqrt(std::max(e0, 0.0));
+    // the smallest eigenvalue comes out of a cancellation: never report it larger than |det| / smax^2 allows, nor smaller than what is representable
+    smin = std::sqrt(std::max(e2, 0.0));
+    const double det = (double)m[0] * ((double)m[5] * m[10] - (double)m[9] * m[6]) - (double)m[4] * ((double)m[1] * m[10] - (double)m[9] * m[2]) +
+                       (double)m[8] * ((double)m[1] * m[6] - (double)m[5] * m[2]);
+    if (smax > 0.0) smin = std::min(smin > 0.0 ? smin : 1e300, std::fabs(det) / (smax * smax));  // s0 s1 s2 = |det|, s1 <= s0  =>  s2 >= |det| / s0^2
+}
 }  // namespace
 
 bool want_instancing(const FlatScene& flat) {
@@ -109,6 +144,17 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
     // ---- per instance: the inverse transform (double -> f32; used for culling only) and its norm
     std::vector<double> inv(12 * n_inst);
     std::vector<float> inv_norm(n_inst, 0.0f), mesh_inv_norm(n_mesh, 0.0f);
+    std::vector<float> inst_cond(n_inst, 1.0f);         // condition number of the instance's linear part (2-norm)
+    std::vector<float> mesh_back_reach(n_mesh, 0.0f);   // max over a mesh's instances of |M^-1| x (|M| x the mesh's own coordinates + |translation|)
+    std::vector<float> mesh_obj_reach(n_mesh, 0.0f);    // sum over the axes of the largest |object-space coordinate| of a mesh
+    for (size_t m = 0; m < n_mesh; m++) {
+        if (!used[m]) continue;
+        const HostMesh& g = flat.meshes[m];
+        float mx[3] = {0.0f, 0.0f, 0.0f};
+        for (size_t k = 0; k < g.indices.size(); k++)
+            for (int a = 0; a < 3; a++) mx[a] = max_f(mx[a], abs_f(g.vertices[3ull * g.indices[k] + a]));
+        mesh_obj_reach[m] = (mx[0] + mx[1]) + mx[2];
+    }
     for (size_t i = 0; i < n_inst; i++) {
         const float* m = flat.instances[i].transform;
         const double a[3][3] = {{m[0], m[4], m[8]}, {m[1], m[5], m[9]}, {m[2], m[6], m[10]}};  // row-major 3x3 of the column-major 4x4
@@ -126,8 +172,23 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
             o[3] = -(r[row][0] * t[0] + r[row][1] * t[1] + r[row][2] * t[2]);
             norm = max_f(norm, (float)(std::fabs(o[0]) + std::fabs(o[1]) + std::fabs(o[2])));
         }
+        {   // 2-norms: |M^-1|_2 = 1 / (smallest singular value); the padding formulas below take whichever norm is larger
+            double smax, smin;
+            singular_range(m, smax, smin);
+            if (smin > 0.0) {
+                norm = max_f(norm, (float)std::min(1.0001 / smin, 3e38));
+                inst_cond[i] = (float)std::min(1.0001 * smax / smin, 3e38);
+            }
+        }
         inv_norm[i] = norm;
-        mesh_inv_norm[flat.instances[i].mesh] = max_f(mesh_inv_norm[flat.instances[i].mesh], norm);
+        const uint32_t mesh = flat.instances[i].mesh;
+        mesh_inv_norm[mesh] = max_f(mesh_inv_norm[mesh], norm);
+        // how large the numbers are that cancel when a ray goes through M^-1 and a vertex through M: a mesh modelled far from its own
+        // origin and moved back by the instance's translation has world coordinates ~ 1 and both of these ~ 1e4
+        float fwd = 0.0f;  // largest absolute row sum of the linear part
+        for (int row = 0; row < 3; row++) fwd = max_f(fwd, (float)(std::fabs(a[row][0]) + std::fabs(a[row][1]) + std::fabs(a[row][2])));
+        const float tl = (float)(std::fabs(t[0]) + std::fabs(t[1]) + std::fabs(t[2]));
+        mesh_back_reach[mesh] = max_f(mesh_back_reach[mesh], norm * (fwd * mesh_obj_reach[mesh] + tl));
     }
     // ---- per mesh: BLAS over object-space boxes, triangles in BLAS order, lookup by prim
     is.mesh_tris.assign(16ull * n_mesh_tris, 0.0f);
@@ -138,6 +199,7 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
     std::vector<std::vector<uint32_t>> blas_nodes(n_mesh);
     std::vector<uint32_t> blas_depth(n_mesh, 0);
     std::vector<float> mesh_size(n_mesh, 0.0f);
+    std::vector<float> mesh_k2max(n_mesh, 0.0f);  // worst conditioning (isotropic: 2 |e1||e2| / |n|) of a mesh's triangles, scene_build.h
     const TuningOptions tune = tuning();
     for (size_t m = 0; m < n_mesh; m++) {
         if (!used[m]) continue;
@@ -158,6 +220,19 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
             bb[0] = min_f(min_f(v0.x, v1.x), v2.x); bb[1] = min_f(min_f(v0.y, v1.y), v2.y); bb[2] = min_f(min_f(v0.z, v1.z), v2.z);
             bb[3] = max_f(max_f(v0.x, v1.x), v2.x); bb[4] = max_f(max_f(v0.y, v1.y), v2.y); bb[5] = max_f(max_f(v0.z, v1.z), v2.z);
             for (int a = 0; a < 3; a++) { olo[a] = min_f(olo[a], bb[a]); ohi[a] = max_f(ohi[a], bb[3 + a]); }
+            // A needle's ill-conditioned inside test (scene_build.h tri_conditioning). The world-space triangle the test sees is displaced
+            // by du e1_w + dv e2_w with |du| <= eps x reach x |r0_w|, |r0_w| <= |M^-1|_2 |r0|; taken back through M^-1 that is
+            // du e1 + dv e2 of the OBJECT-space edges: per axis eps x reach x |M^-1| x k[a], whatever the instance does to the shape.
+            float k[3];
+            {
+                const double Ad[3] = {v0.x, v0.y, v0.z}, Bd[3] = {v1.x, v1.y, v1.z}, Cd[3] = {v2.x, v2.y, v2.z};
+                tri_conditioning(Ad, Bd, Cd, k);
+            }
+            mesh_k2max[m] = max_f(mesh_k2max[m], (k[0] + k[1]) + k[2]);  // (>= the 2-norm of the per-axis values)
+            for (int a = 0; a < 3; a++) {
+                const float extra = tri_cond_extra(k[a], reach * mesh_inv_norm[m]);
+                if (extra > 0.0f) { bb[a] -= extra; bb[3 + a] += extra; }
+            }
         }
         mesh_size[m] = (float)(std::sqrt(std::sqrt(max_n2)) * 1.0001);  // sqrt(|n|) of the mesh's largest triangle
         // Padding of the object-space boxes. A triangle the flattened test would accept lies within pad_world of its world box; in object
@@ -166,7 +241,9 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
         // Both with a generous constant; the largest |M^-1| over the mesh's instances (the BLAS is shared).
         float odiag = 0.0f;
         for (int a = 0; a < 3; a++) odiag += ohi[a] - olo[a];
-        const float pad_obj = mesh_inv_norm[m] * (pad_world + 4e-6f * (reach + __builtin_sqrtf(diag2))) + 4e-6f * odiag;
+        // Round 6: + the magnitude of what cancels (vertices at 1e4, size 1, translation -1e4 -- the object-space ray is
+        // then off by ulp(1e4) while the terms above see a scene of size 1 at the origin).
+        const float pad_obj = mesh_inv_norm[m] * (pad_world + 4e-6f * (reach + __builtin_sqrtf(diag2))) + 4e-6f * (odiag + mesh_obj_reach[m] + mesh_back_reach[m]);
         std::vector<uint32_t> order;
         build_bvh8(bounds, nt, pad_obj, kBvhNodeWords, tune.bvh_balanced != 0, order, blas_nodes[m], blas_depth[m]);
         if (blas_depth[m] > kBvhStackDepth) build_bvh8(bounds, nt, pad_obj, kBvhNodeWords, true, order, blas_nodes[m], blas_depth[m]);
@@ -225,6 +302,9 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
             if (flat.meshes[flat.instances[i].mesh].n_triangles() == 0) continue;
             tlas_ids.push_back((uint32_t)i);
             tb.insert(tb.end(), &inst_bounds[6 * i], &inst_bounds[6 * i] + 6);
+            // the instance's needles in world space: conditioning at most cond(M) x the mesh's worst
+            const float extra = tri_cond_extra(inst_cond[i] * mesh_k2max[flat.instances[i].mesh], reach);
+            for (int a = 0; a < 3; a++) { tb[tb.size() - 6 + a] -= extra; tb[tb.size() - 3 + a] += extra; }
         }
         if (tlas_ids.empty()) throw std::invalid_argument("instanced scene without triangles");
         build_bvh8(tb, (uint32_t)tlas_ids.size(), pad_world, kBvhNodeWords, tune.bvh_balanced != 0, tlas_order, is.nodes, is.tlas_depth);

@@ -550,3 +550,52 @@ def shift_scene(sd: abi.SceneData, offset) -> abi.SceneData:
     c[3, :3] += off
     sd.camera.c2w = c.reshape(16)
     return sd
+
+
+def extreme_instanced_scene(seed: int, width: int = 40, height: int = 32):
+    """An instanced scene under transforms far outside the soak's range: log-uniform scales 1e-4 .. 1e4 (non-uniform, mirrored,
+    sheared), offsets up to 1e4 x the scene's unit, meshes squashed into slivers. What stresses the CULLING of a tree (the padding
+    of its boxes): tools/inst_extreme_check.py, tests/test_bvh_conservative.py, tests/test_gpu_parity.py. Returns (scene, config)."""
+    rng = np.random.default_rng(seed)
+    sd = instanced_scene(n_inst=int(rng.integers(3, 20)), n=int(rng.integers(3, 10)), width=width, height=height, seed=seed,
+                         emissive_instances=int(rng.integers(0, 3)), with_normals=bool(rng.random() < 0.5), alpha=bool(rng.random() < 0.3),
+                         textured=bool(rng.random() < 0.3))
+    if rng.random() < 0.3:  # slivers
+        v = sd.meshes[0].vertices.copy()
+        v[:, int(rng.integers(0, 3))] *= np.float32(10.0 ** rng.uniform(-5, -1))
+        sd.meshes[0].vertices = v
+        sd.meshes[0].normals = None
+    world = 10.0 ** rng.uniform(-3, 3)      # the whole scene's unit
+    offset = rng.uniform(-1, 1, size=3) * 10.0 ** rng.uniform(0, 4) * world * float(rng.random() < 0.6)
+    for k, inst in enumerate(sd.instances):
+        t = np.asarray(inst.transform, dtype=np.float64).reshape(4, 4).copy()  # transposed: rows are columns
+        if k >= 2 and rng.random() < 0.5:     # a blob: its own extreme, non-uniform scale (the camera still looks at the cluster)
+            s3 = 10.0 ** rng.uniform(-2, 2, size=3) * rng.choice([1.0, 1.0, -1.0], size=3)
+            t[:3, :3] = t[:3, :3] * s3[:, None]
+            if rng.random() < 0.3:
+                t[0, :3] += rng.uniform(-2, 2) * t[1, :3]
+        t[:3, :3] *= world
+        t[3, :3] = t[3, :3] * world + offset
+        inst.transform = t.astype(np.float32).reshape(16)
+    c = np.asarray(sd.camera.c2w, dtype=np.float64).reshape(4, 4).copy()
+    c[3, :3] = c[3, :3] * world + offset
+    sd.camera.c2w = c.astype(np.float32).reshape(16)
+    cfg = make_config(spp=4, spp_per_pass=4, max_depth=int(rng.integers(2, 10)), force_diffuse=int(rng.random() < 0.3), sampler_type=int(rng.integers(0, 3)))
+    return sd, cfg
+
+
+def far_modelled_mesh_scene(offset: float, **kw) -> abi.SceneData:
+    """instanced_scene with its shared mesh modelled `offset` away from its own origin and every instance's translation taking it
+    back: world coordinates as before, object-space coordinates and translations ~ offset -- what cancels when a ray is taken
+    through an instance's inverse (the padding of the per-mesh trees has to follow THAT magnitude)."""
+    sd = instanced_scene(**kw)
+    off = np.array([offset, -0.5 * offset, 0.25 * offset], dtype=np.float64)
+    v = np.asarray(sd.meshes[0].vertices, dtype=np.float64) + off[None, :]
+    sd.meshes[0].vertices = v.astype(np.float32)
+    for inst in sd.instances:
+        if inst.mesh != 0:
+            continue
+        t = np.asarray(inst.transform, dtype=np.float64).reshape(4, 4).copy()  # stored transposed: rows 0..2 are the matrix columns
+        t[3, :3] -= off @ t[:3, :3]
+        inst.transform = t.astype(np.float32).reshape(16)
+    return sd

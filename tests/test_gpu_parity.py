@@ -11,7 +11,8 @@ import pytest
 
 from akari_render_amd import abi, capi, distributed
 from oracle import pyoracle, scene_json
-from tests.helpers import box_scene, cbox_variant, grid_scene, instanced_scene, make_config, n_bit_diff, rel_rmse, resolve_np, shift_scene
+from tests.helpers import (box_scene, cbox_variant, extreme_instanced_scene, far_modelled_mesh_scene, grid_scene, instanced_scene, make_config, n_bit_diff,
+                           rel_rmse, resolve_np, shift_scene)
 
 pytestmark = pytest.mark.gpu
 
@@ -336,3 +337,52 @@ def test_bvh_scenes_far_from_the_origin(ctx, cbox_path, root, offset):
             capi.pt_render(ctx, scene, cfg, film)
         o, _ = pyoracle.OracleScene(sd).render(cfg)  # the exhaustive loop: the definition of a hit
         assert n_bit_diff(film.read(), o) == 0, name
+
+
+def _oracle_film(sd, cfg):
+    w, h = sd.camera.width, sd.camera.height
+    st = None
+    if cfg.sampler_type != 0:  # index-based samplers: state = (sample index - 1, pixel coordinates)
+        pyoracle.set_pmj_tables(*capi.host_pmj02bn_tables())
+        st = np.zeros(2 * w * h, dtype=np.uint64)
+        st[0::2] = 0xFFFFFFFF
+        st[1::2] = (np.arange(w * h, dtype=np.uint64) % np.uint64(w)) | ((np.arange(w * h, dtype=np.uint64) // np.uint64(w)) << np.uint64(32))
+    o, _ = pyoracle.OracleScene(sd).render(cfg, states=st)
+    return o
+
+
+# 93 = the scene of HISTORY R5.7 (flattened: one film pixel off the oracle in round 5); the others: scenes in which tests/bvh_model.py
+# found a round-5 tree culling a pair the triangle test accepts (tests/test_bvh_conservative.py)
+@pytest.mark.parametrize("seed", [93, 50, 52, 63, 88, 107])
+def test_needles_under_extreme_transforms(ctx, root, seed):
+    """Instances under scales of 1e-4 .. 1e4, shears, offsets of 1e4 x the scene's unit, meshes squashed into slivers -- flattened and
+    kept as meshes + instances, both against the oracle's exhaustive loop, bit for bit (the documented exception
+    to "bit-exact" is gone; boxes follow each triangle's conditioning, scene_build.h tri_conditioning)."""
+    sd, cfg = extreme_instanced_scene(seed)
+    sd.ggx_table = np.fromfile(os.path.join(root, "tests", "golden", "ggx_dielectric_s.f32"), dtype=np.float32)
+    o = _oracle_film(sd, cfg)
+    for mode, kind in ((0, 1), (1, 2)):
+        with capi.options(instancing=mode, force_bvh=1):
+            scene = capi.Scene(ctx, sd)
+            assert scene.info().uses_bvh == kind
+            film = capi.Film(ctx, sd.camera.width, sd.camera.height)
+            capi.pt_render(ctx, scene, cfg, film)
+        g = film.read()
+        assert np.isfinite(g).all()
+        assert n_bit_diff(g, o) == 0, ("kept" if mode else "flattened")
+
+
+@pytest.mark.parametrize("offset", [1e3, 1e4])
+def test_mesh_modelled_far_from_its_own_origin(ctx, root, offset):
+    """a shared mesh whose vertices sit ~offset from its own origin, moved back by the instances' translations. The ray
+    taken through an instance's inverse is then uncertain by ulp(offset); the per-mesh trees' padding has to follow (scene_inst.cpp)."""
+    sd = far_modelled_mesh_scene(offset, width=48, height=40)
+    sd.ggx_table = np.fromfile(os.path.join(root, "tests", "golden", "ggx_dielectric_s.f32"), dtype=np.float32)
+    cfg = make_config(spp=8, spp_per_pass=8, max_depth=8)
+    o = _oracle_film(sd, cfg)
+    for mode in (0, 1):
+        with capi.options(instancing=mode):
+            scene = capi.Scene(ctx, sd)
+            film = capi.Film(ctx, 48, 40)
+            capi.pt_render(ctx, scene, cfg, film)
+        assert n_bit_diff(film.read(), o) == 0, ("kept" if mode else "flattened")
