@@ -30,7 +30,7 @@ AKR_HD PlaneHit tri_plane(vec3 o, vec3 d, float4 r2) {
     float dz = __builtin_fmaf(r2.x, d.x, __builtin_fmaf(r2.y, d.y, r2.z * d.z));
     float oz = __builtin_fmaf(r2.x, o.x, __builtin_fmaf(r2.y, o.y, __builtin_fmaf(r2.z, o.z, r2.w)));
     PlaneHit h;
-    h.t = -oz / dz;
+    h.t = div_f(-oz, dz);
     h.px = __builtin_fmaf(h.t, d.x, o.x);
     h.py = __builtin_fmaf(h.t, d.y, o.y);
     h.pz = __builtin_fmaf(h.t, d.z, o.z);
@@ -246,8 +246,8 @@ AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, u
             if (!((sc.plane_share_mask >> k) & 1ull)) {
                 const v2f den = pk_fma(r2.x, dx2, pk_fma(r2.y, dy2, (v2f){r2.z, r2.z} * dz2));
                 const v2f num = pk_fma(r2.x, ox2, pk_fma(r2.y, oy2, pk_fma(r2.z, oz2, (v2f){r2.w, r2.w})));
-                ph.t = -num.x / den.x;
-                sph.t = -num.y / den.y;
+                ph.t = div_f(-num.x, den.x);
+                sph.t = div_f(-num.y, den.y);
                 const v2f t2 = {ph.t, sph.t};
                 hx2 = pk_fma(t2, dx2, ox2); hy2 = pk_fma(t2, dy2, oy2); hz2 = pk_fma(t2, dz2, oz2);
             }
@@ -316,7 +316,7 @@ AKR_D void trace_pair_exhaustive(const DScene& sc, vec3 o, vec3 d, float tmax, u
                 // tri_plane for both rays: den = fma(x, d.x, fma(y, d.y, z * d.z)), num = fma(x, o.x, fma(y, o.y, fma(z, o.z, w)))
                 const v2f den = pk_fma_b<0>(r2xy, dx2, pk_fma_b<1>(r2xy, dy2, pk_mul_b<0>(r2zw, dz2)));
                 const v2f num = pk_fma_b<0>(r2xy, ox2, pk_fma_b<1>(r2xy, oy2, pk_fma_bb<0, 1>(r2zw, oz2, r2zw)));
-                T2 = (v2f){-num.x / den.x, -num.y / den.y};
+                T2 = (v2f){div_f(-num.x, den.x), div_f(-num.y, den.y)};
                 hx2 = pk_fma(T2, dx2, ox2); hy2 = pk_fma(T2, dy2, oy2); hz2 = pk_fma(T2, dz2, oz2);
             }
             // tri_uv: u = fma(r0.x, p.x, fma(r0.y, p.y, fma(r0.z, p.z, r0.w))), v likewise from r1

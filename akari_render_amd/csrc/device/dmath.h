@@ -23,6 +23,28 @@ typedef unsigned long size_t;
 #define AKR_HD __host__ __device__ __forceinline__
 #define AKR_D __device__ __forceinline__
 
+// The arithmetic tier of a translation unit. 0 (everything but pt_kernels_relaxed.hip): the AKR-F32 contract above, bit for bit the
+// oracle's. 1 = RELAXED (option `arith`): the same algorithm to the tolerance north_star states (relRMSE < 1e-3
+// against the oracle, tests/test_gpu_relaxed.py) instead of to the bit -- v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 (1 ulp) for the IEEE
+// division and square root (11 and 16 instructions each under the contract), the hardware's sin / cos / log2 / exp2, and the
+// compiler's contraction of a * b + c (that translation unit is built with -ffp-contract=fast, without correctly rounded
+// divide / sqrt and with denormals flushed). Device code only: anything a relaxed translation unit compiles for the host keeps the contract.
+#ifndef AKR_ARITH_RELAXED
+#define AKR_ARITH_RELAXED 0
+#endif
+#if AKR_ARITH_RELAXED && defined(__HIP_DEVICE_COMPILE__)
+#define AKR_RX 1
+#else
+#define AKR_RX 0
+#endif
+// parts of the relaxed tier that can be switched off one by one in a variant build (tools/arith_parts.sh: what each part buys and what it costs in flipped comparisons)
+#ifndef AKR_RX_TRANS
+#define AKR_RX_TRANS 1  // hardware sin / cos / log2 / exp2
+#endif
+#ifndef AKR_RX_RCP
+#define AKR_RX_RCP 1    // v_rcp_f32 / v_rsq_f32 in the triangle test's plane solve and in vector normalisation
+#endif
+
 namespace akr {
 
 constexpr float kPi = 3.14159265358979323846f;
@@ -45,14 +67,42 @@ AKR_HD vec3 operator*(vec3 a, float s) { return vec3{a.x * s, a.y * s, a.z * s};
 AKR_HD vec3 operator-(vec3 a) { return vec3{-a.x, -a.y, -a.z}; }
 AKR_HD float dot(vec3 a, vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 AKR_HD vec3 cross(vec3 a, vec3 b) { return vec3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+// 1 / x, a / b, sqrt(x): correctly rounded under the contract; one hardware instruction (+ a multiply) in the relaxed tier
+AKR_HD float rcp_f(float x) {
+#if AKR_RX && AKR_RX_RCP
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+AKR_HD float div_f(float a, float b) {
+#if AKR_RX && AKR_RX_RCP
+    return a * __builtin_amdgcn_rcpf(b);
+#else
+    return a / b;
+#endif
+}
+AKR_HD float sqrt_f(float x) {
+#if AKR_RX
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return __builtin_sqrtf(x);
+#endif
+}
 AKR_HD float length2(vec3 a) { return dot(a, a); }
-AKR_HD float length(vec3 a) { return __builtin_sqrtf(dot(a, a)); }
+AKR_HD float length(vec3 a) { return sqrt_f(dot(a, a)); }
 // vec / scalar := vec * (1 / scalar): one IEEE division
 AKR_HD vec3 div_s(vec3 a, float s) {
-    float inv = 1.0f / s;
+    float inv = rcp_f(s);
     return a * inv;
 }
-AKR_HD vec3 normalize(vec3 a) { return div_s(a, length(a)); }
+AKR_HD vec3 normalize(vec3 a) {
+#if AKR_RX && AKR_RX_RCP
+    return a * __builtin_amdgcn_rsqf(dot(a, a));
+#else
+    return div_s(a, length(a));
+#endif
+}
 AKR_HD float min_f(float a, float b) { return a < b ? a : b; }  // b when a is NaN
 AKR_HD float max_f(float a, float b) { return a > b ? a : b; }  // b when a is NaN
 AKR_HD float clamp_f(float x, float lo, float hi) { return min_f(max_f(x, lo), hi); }
@@ -70,6 +120,12 @@ AKR_HD bool is_nan(float x) { return x != x; }
 
 // sin and cos of x (radians): Cody-Waite reduction by pi/2, then the Cephes single-precision kernels.
 AKR_HD void sincos_f(float x, float& s_out, float& c_out) {
+#if AKR_RX && AKR_RX_TRANS
+    const float rev = x * 0.15915494309189535f;  // v_sin_f32 / v_cos_f32 take revolutions
+    s_out = __builtin_amdgcn_sinf(rev);
+    c_out = __builtin_amdgcn_cosf(rev);
+    return;
+#endif
     const float kTwoOverPi = 0.636619772367581343f;
     const float P1 = 1.5703125f, P2 = 4.837512969970703125e-4f, P3 = 7.54978995489188216e-8f;
     float kf = __builtin_rintf(x * kTwoOverPi);
@@ -92,6 +148,9 @@ AKR_HD void sincos_f(float x, float& s_out, float& c_out) {
 
 // natural log (Cephes logf); log(0) = -inf, log(x < 0) = NaN
 AKR_HD float log_f(float x) {
+#if AKR_RX && AKR_RX_TRANS
+    return __builtin_amdgcn_logf(x) * 0.6931471805599453f;  // v_log_f32 = log2; log2(0) = -inf, log2(x < 0) = NaN as below
+#endif
     if (x == 0.0f) return -__builtin_inff();
     if (!(x > 0.0f)) return __builtin_nanf("");
     uint32_t ux = f2u(x);
@@ -130,6 +189,9 @@ AKR_HD float log_f(float x) {
 
 // e^x (Cephes expf: x = g + n ln2, degree-5 polynomial on g, scale by 2^n in two exact steps)
 AKR_HD float exp_f(float x) {
+#if AKR_RX && AKR_RX_TRANS
+    return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+#endif
     if (x != x) return x;
     if (x > 88.72283905206835f) return __builtin_inff();
     if (x < -103.278929903431851103f) return 0.0f;

@@ -199,6 +199,7 @@ struct akr_pt_session {
     // per-scene kernel (host/specialise.cpp): set by akr_pt_begin when the options ask for one and the compile succeeded; the
     // precompiled interpreter kernel otherwise. spec_active also shapes fill_params (no value slots in LDS, the kernel's own LDS budget).
     bool spec_active = false;
+    bool arith_relaxed = false;  // option arith = 1 and the session is one the relaxed tier covers: launches go to pt_kernels_relaxed.hip
     int spec_waves = 3;
     std::shared_ptr<SpecKernel> spec;
     std::string spec_status = "not requested";

@@ -346,7 +346,11 @@ int32_t akr_api::pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_confi
             const bool may_compile = t.specialise == 1 || samples >= kSpecAutoSamples;
             if (scene->cs.instanced.on && !for_pt_kernel)
                 throw Unsupported("unsupported: a scene kept as meshes + instances (option instancing) renders with the pt integrator only");
+            // The relaxed arithmetic tier (pt_kernels_relaxed.hip): the precompiled megakernels of flattened scenes. Everything else --
+            // kept scenes, the wavefront schedule, aov / gpt / mcmc_opt -- stays on the contract whatever the option says.
+            se->arith_relaxed = t.arith == 1 && for_pt_kernel && !scene->cs.instanced.on && !se->wavefront;
             if (!for_pt_kernel) se->spec_status = "not a pt session";
+            else if (se->arith_relaxed) se->spec_status = "relaxed arithmetic tier: precompiled kernels";
             else if (scene->cs.instanced.on) se->spec_status = "scene kept as meshes + instances";
             else if (!scene->cs.has_textures) se->spec_status = "the scene has no texture-fed material";
             else if (t.specialise == 0) se->spec_status = "option specialise = 0";
@@ -382,6 +386,8 @@ int32_t akr_api::pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_confi
         *out = se.release();
     });
 }
+// pt_kernels_relaxed.hip: launch_pt_pass of the relaxed arithmetic tier (its PtParams is this one, in another namespace)
+extern "C" hipError_t akr_launch_pt_pass_relaxed(const void* params, hipStream_t stream);
 extern "C" {
 AKR_API int32_t akr_pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_config* cfg, akr_film* film, akr_pt_session** out) {
     return pt_begin(ctx, scene, cfg, film, out, /*for_pt_kernel=*/true);
@@ -417,6 +423,7 @@ AKR_API int32_t akr_pt_passes(akr_pt_session* se, uint32_t n_passes, int32_t blo
             fill_params(se, fused, last);
             LaunchTimer timer(se);
             if (se->wavefront) wf_run(se);
+            else if (se->arith_relaxed) HIP_CHECK(akr_launch_pt_pass_relaxed(&se->params, se->ctx->stream));
             else HIP_CHECK(launch_pt_pass(se->params, se->ctx->stream, se->spec_active ? se->spec->fn : nullptr));
             timer.stop();
             se->spp_done = done;
@@ -473,7 +480,7 @@ AKR_API int32_t akr_pt_kernel_info(akr_pt_session* se, akr_kernel_info* info) {
         info->specialised = se->spec_active ? 1u : 0u;
         info->n_shader_kinds = (uint32_t)se->scene->cs.shader_kinds.size();
         info->kernel_flags = (se->scene->cs.bvh_nodes.empty() ? 0u : 1u) | (se->params.sampler != 0 ? 2u : 0u) | (se->params.stage_total != 0 ? 4u : 0u) |
-                             (se->params.defer_metal != 0 ? 8u : 0u);
+                             (se->params.defer_metal != 0 ? 8u : 0u) | (se->arith_relaxed ? 16u : 0u);
         info->absent_mask = se->scene->cs.absent;
         if (se->spec) {
             info->cache_hit = se->spec->cache_hit ? 1u : 0u;

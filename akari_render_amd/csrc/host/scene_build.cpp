@@ -756,18 +756,21 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
     if (n_tris > kExhaustiveMax || stage > kStageMaxBytes) {
         const float pad = bvh_box_padding(out.scene_lo, out.scene_hi, flat.camera.c2w);
         {   // needles: what their ill-conditioned inside test reaches beyond the flat padding, per triangle and axis (scene_build.h)
-            const float reach = scene_reach(out.scene_lo, out.scene_hi, flat.camera.c2w);
             const unsigned nc = n_tris > (1u << 17) ? host_threads() * 4 : 1;
             parallel_chunks(nc, host_threads(), [&](unsigned c) {
                 const uint32_t lo = (uint32_t)((uint64_t)n_tris * c / nc), hi = (uint32_t)((uint64_t)n_tris * (c + 1) / nc);
-                for (uint32_t g = lo; g < hi; g++)
+                for (uint32_t g = lo; g < hi; g++) {
+                    const float* k = &tri_cond[3ull * g];
+                    float* bb = &bounds[6ull * g];
+                    const float mag = box_magnitude(bb, bb + 3);
                     for (int a = 0; a < 3; a++) {
-                        const float extra = tri_cond_extra(tri_cond[3ull * g + a], reach);
+                        const float extra = tri_cond_extra(k[a], mag, pad);
                         if (extra > 0.0f) {
-                            bounds[6ull * g + a] -= extra;
-                            bounds[6ull * g + 3 + a] += extra;
+                            bb[a] -= extra;
+                            bb[3 + a] += extra;
                         }
                     }
+                }
             });
         }
         std::vector<float>().swap(tri_cond);
@@ -819,6 +822,7 @@ void tuning_init_locked() {
     if (const char* e = std::getenv("AKR_SPECIALISE_WAVES")) g_tuning.specialise_waves = std::atoi(e);
     if (const char* e = std::getenv("AKR_WF_SORT")) g_tuning.wf_sort = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("AKR_INSTANCING")) g_tuning.instancing = std::atoi(e);
+    if (const char* e = std::getenv("AKR_ARITH")) g_tuning.arith = std::atoi(e) != 0 ? 1 : 0;
 }
 int* tuning_field(const char* name) {
     const std::string n = name ? name : "";
@@ -833,6 +837,7 @@ int* tuning_field(const char* name) {
     if (n == "max_fused_passes") return &g_tuning.max_fused_passes;
     if (n == "wf_sort") return &g_tuning.wf_sort;
     if (n == "instancing") return &g_tuning.instancing;
+    if (n == "arith") return &g_tuning.arith;
     return nullptr;
 }
 }  // namespace
@@ -852,6 +857,7 @@ bool tuning_set(const char* name, int value) {
     if (f == &g_tuning.max_fused_passes && (value < 0 || value > 64)) return false;
     if (f == &g_tuning.wf_sort && (value < 0 || value > 1)) return false;
     if (f == &g_tuning.instancing && (value < -1 || value > 1)) return false;
+    if (f == &g_tuning.arith && (value < 0 || value > 1)) return false;
     *f = value;
     return true;
 }

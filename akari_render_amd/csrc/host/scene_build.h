@@ -123,15 +123,17 @@ inline float bvh_box_padding(const float lo[3], const float hi[3], const float* 
 }
 
 // Conditioning of a triangle's (u, v) parametrisation. The inside test computes u = r0 . p + c0 with |r0| = |e2| / |n| (v likewise with
-// |r1| = |e1| / |n|) and is off by up to ~11 x 2^-24 x |r0| x (magnitude of the coordinates): the triangle the test "sees" is displaced by
-// du e1 + dv e2. For a well-shaped triangle that is a few ulp of the coordinates -- what bvh_box_padding allows for -- but |r0||e1| = 1 / sin(angle
-// at the first vertex): a needle whose first vertex holds its small angle is displaced along its long axis by 1 / sin times as much, and
-// the exhaustive loop accepts hits that far outside it (round 6: tests/bvh_model.py found such pairs in 9 of 150 extreme scenes, among
-// them the one film pixel of HISTORY R5.7). k[a] = |r0||e1_a| + |r1||e2_a| per axis; a box must reach kTriCondEps x magnitude x k[a] beyond the
-// triangle. The flat padding covers k <= kTriCondFree (2 for a right angle at the first vertex, 2.31 for 60 degrees); what exceeds it is added to
-// the triangle's own box.
-constexpr float kTriCondEps = 16.0f * 5.9604645e-8f;
-constexpr float kTriCondFree = 2.7f;
+// |r1| = |e1| / |n|): two of its three fma roundings act on partial sums of size S = |r0||p| + |c0| <= 2 |r0||p|, the rounded row and the
+// rounded hit point add one unit each -- |du| <= 8 x 2^-24 x |r0| x |p|, p a point of the triangle -- and the triangle the test "sees" is
+// displaced by du e1 + dv e2. For a well-shaped triangle that is a few ulp of its coordinates, what bvh_box_padding allows for; but
+// |r0||e1| = 1 / sin(angle at the first vertex): a needle whose first vertex holds its small angle is displaced along its long axis by 1 / sin
+// times as much, and the exhaustive loop accepts hits that far outside it (round 6: tests/bvh_model.py found such pairs in 9 of 150
+// extreme scenes, among them the one film pixel of HISTORY R5.7). k[a] = |r0||e1_a| + |r1||e2_a| per axis (2 for a right angle at the first
+// vertex, 2.31 for 60 degrees); a box must reach kTriCondEps x |p| x k[a] beyond the triangle along axis a. kTriCondFree of the flat
+// padding is counted towards that (the rest of it covers the slab test's own round-off and the plane's); what exceeds it is added to the
+// triangle's own box.
+constexpr float kTriCondEps = 10.0f * 5.9604645e-8f;
+constexpr float kTriCondFree = 0.64f;
 inline void tri_conditioning(const double A[3], const double B[3], const double C[3], float k[3]) {
     const double e1[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, e2[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
     const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
@@ -142,18 +144,20 @@ inline void tri_conditioning(const double A[3], const double B[3], const double 
         k[a] = v < 1e30 ? (float)(v * 1.0001) : 1e30f;
     }
 }
-// what a box of a triangle with conditioning k[a] needs beyond the flat padding, along axis a; magnitude = the `reach` of bvh_box_padding
-inline float tri_cond_extra(float k, float magnitude) { return k > kTriCondFree ? kTriCondEps * magnitude * (k - kTriCondFree) : 0.0f; }
-inline float scene_reach(const float lo[3], const float hi[3], const float* c2w) {
-    float reach = 0.0f;
+// what a box of a triangle with conditioning k needs along an axis beyond the flat padding `pad`; magnitude = |p| (2-norm) of the triangle's points
+inline float tri_cond_extra(float k, float magnitude, float pad) {
+    const float need = kTriCondEps * magnitude * k, have = kTriCondFree * pad;
+    return need > have ? need - have : 0.0f;
+}
+// 2-norm of the largest coordinates a box holds
+inline float box_magnitude(const float lo[3], const float hi[3]) {
+    float m2 = 0.0f;
     for (int a = 0; a < 3; a++) {
         const float m = std::fabs(lo[a]) > std::fabs(hi[a]) ? std::fabs(lo[a]) : std::fabs(hi[a]);
-        const float c = std::fabs(c2w[12 + a]);
-        reach += m > c ? m : c;
+        m2 += m * m;
     }
-    return reach;
+    return __builtin_sqrtf(m2) * 1.0001f;
 }
-
 DMaterial fold_material(const akr_material_desc& m, uint32_t color = 0);
 // materials / node lists / raw inputs under the colour pipeline `color` (scene_build.cpp); fills out.materials, out.tex_nodes,
 // out.mat_inputs only
@@ -171,6 +175,8 @@ void build_alias_table(const std::vector<float>& weights, std::vector<AliasEntry
 //                                         kernel always; a compile for renders of at least kSpecAutoSamples samples), 0 = never (the interpreter), 1 = always
 //   specialise_waves AKR_SPECIALISE_WAVES=<n>  waves per SIMD a per-scene kernel is compiled for: 0 = the library's choice, else 2..4
 //   instancing   AKR_INSTANCING=<v>       meshes + instances kept as they are (BLAS per mesh, TLAS over instances; scene_inst.cpp): -1 auto, 0 never, 1 always
+//   arith        AKR_ARITH=1              pt megakernel in the relaxed arithmetic tier (flattened scenes; precompiled kernels): hardware rcp / sqrt /
+//                                         sin / cos / log / exp and contraction instead of the bit-exact contract
 //   wf_sort      AKR_WF_SORT=1            wavefront schedule: ray queues sorted by origin cell + direction octant before each trace launch
 //   max_fused_passes (no environment hook)     most passes akr_pt_passes fuses into one launch: 0 = adaptive (16, up to 64 once a pass has been timed), else 1..64
 struct TuningOptions {
@@ -180,6 +186,8 @@ struct TuningOptions {
     int max_fused_passes = 0;
     int instancing = -1;  // two-level acceleration structure for scenes whose meshes are instanced: -1 the library decides (flattening is the
                           // default while its records fit a budget), 0 never, 1 whenever a mesh has more than one instance
+    int arith = 0;    // arithmetic tier of the pt megakernel: 0 = the AKR-F32 contract (bit-exact with the oracle), 1 = relaxed (pt_kernels_relaxed.hip:
+                      // films within north_star's relRMSE < 1e-3 of the oracle, not identical to it)
     int wf_sort = 0;  // wavefront schedule: 1 = the ray queues are sorted by (Morton code of the origin, octant) before every trace launch (wf_sort.hip)
 };
 constexpr uint64_t kSpecAutoSamples = 1ull << 31;  // option specialise = -1: a first-use compile (about a second; 20-30 % of the render to win) has to be worth it

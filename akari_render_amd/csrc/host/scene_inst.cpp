@@ -147,6 +147,7 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
     std::vector<float> inst_cond(n_inst, 1.0f);         // condition number of the instance's linear part (2-norm)
     std::vector<float> mesh_back_reach(n_mesh, 0.0f);   // max over a mesh's instances of |M^-1| x (|M| x the mesh's own coordinates + |translation|)
     std::vector<float> mesh_obj_reach(n_mesh, 0.0f);    // sum over the axes of the largest |object-space coordinate| of a mesh
+    std::vector<float> mesh_back_mag(n_mesh, 0.0f);     // max over a mesh's instances of |M^-1|_2 x (2-norm of the largest world coordinates of the instance)
     for (size_t m = 0; m < n_mesh; m++) {
         if (!used[m]) continue;
         const HostMesh& g = flat.meshes[m];
@@ -189,6 +190,7 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
         for (int row = 0; row < 3; row++) fwd = max_f(fwd, (float)(std::fabs(a[row][0]) + std::fabs(a[row][1]) + std::fabs(a[row][2])));
         const float tl = (float)(std::fabs(t[0]) + std::fabs(t[1]) + std::fabs(t[2]));
         mesh_back_reach[mesh] = max_f(mesh_back_reach[mesh], norm * (fwd * mesh_obj_reach[mesh] + tl));
+        mesh_back_mag[mesh] = max_f(mesh_back_mag[mesh], norm * box_magnitude(&inst_bounds[6 * i], &inst_bounds[6 * i + 3]));
     }
     // ---- per mesh: BLAS over object-space boxes, triangles in BLAS order, lookup by prim
     is.mesh_tris.assign(16ull * n_mesh_tris, 0.0f);
@@ -230,7 +232,8 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
             }
             mesh_k2max[m] = max_f(mesh_k2max[m], (k[0] + k[1]) + k[2]);  // (>= the 2-norm of the per-axis values)
             for (int a = 0; a < 3; a++) {
-                const float extra = tri_cond_extra(k[a], reach * mesh_inv_norm[m]);
+                // worst instance of the mesh: |M^-1| x how far from the origin its copy of the triangle can be; the flat part: what pad_obj below holds of pad_world
+                const float extra = tri_cond_extra(k[a], mesh_back_mag[m], mesh_inv_norm[m] * pad_world);
                 if (extra > 0.0f) { bb[a] -= extra; bb[3 + a] += extra; }
             }
         }
@@ -303,7 +306,7 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
             tlas_ids.push_back((uint32_t)i);
             tb.insert(tb.end(), &inst_bounds[6 * i], &inst_bounds[6 * i] + 6);
             // the instance's needles in world space: conditioning at most cond(M) x the mesh's worst
-            const float extra = tri_cond_extra(inst_cond[i] * mesh_k2max[flat.instances[i].mesh], reach);
+            const float extra = tri_cond_extra(inst_cond[i] * mesh_k2max[flat.instances[i].mesh], box_magnitude(&inst_bounds[6 * i], &inst_bounds[6 * i + 3]), pad_world);
             for (int a = 0; a < 3; a++) { tb[tb.size() - 6 + a] -= extra; tb[tb.size() - 3 + a] += extra; }
         }
         if (tlas_ids.empty()) throw std::invalid_argument("instanced scene without triangles");

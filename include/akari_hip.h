@@ -423,7 +423,7 @@ typedef struct {
     uint32_t absent_mask;     /* lobes no material of the scene can have: 1 coat, 2 transmission, 4 normal map, 8 glass, 16 conductor */
     uint32_t min_waves;       /* waves per SIMD the kernel was compiled for */
     uint32_t vgprs, scratch_bytes;
-    uint32_t kernel_flags;    /* the instantiation: bit 0 BVH intersector, 1 index-based sampler, 2 tables staged in LDS, 3 deferral */
+    uint32_t kernel_flags;    /* the instantiation: bit 0 BVH intersector, 1 index-based sampler, 2 tables staged in LDS, 3 deferral, 4 relaxed arithmetic tier (option arith) */
     uint32_t _pad;
     double compile_ms;        /* hiprtc compile at akr_pt_begin (0 on a cache hit) */
     double load_ms;           /* cache lookup + module load */

@@ -1,0 +1,165 @@
+"""The relaxed arithmetic tier of the pt megakernel (option `arith` = 1; csrc/pt_kernels_relaxed.hip, device/dmath.h AKR_ARITH_RELAXED)
+against the oracle at fixed seed: what it guarantees, and why it is NOT the default.
+
+The default tier is bit-exact with the oracle (tests/test_gpu_parity.py, test_gpu_fullsize.py) and stays the verifier. This tier trades the
+bits for hardware reciprocal / square root / sin / cos / log / exp and the compiler's contraction: +19 % on C2, +33 % on C3, +3 % on C4
+(bench.py arithmetic_tiers). Measured in round 6 (tools/rx_diag.py, profiles/r6_relaxed_tier.txt):
+
+  * the median pixel is off by 3e-7 of its value, the 99th percentile by 3e-5, and relRMSE over all but the outliers is 1e-5 .. 4e-5;
+  * but 2e-5 of the samples of the full shader graph (5e-6 with force_diffuse) take a different decision somewhere -- a triangle's edge,
+    a lobe choice, Russian roulette -- whichever single relaxation is taken back (tools/arith_parts.sh): any arithmetic that is not
+    the oracle's to the bit flips them. With the reference's `independent` sampler a flip that changes a path's length moves the
+    stream of every later sample of the pixel's pass (sampler/mod.rs:199-203: start() advances from wherever the last sample left
+    the state), so one flip re-rolls up to 63 samples;
+  * relRMSE at fixed seed is therefore set by those pixels: 7.8e-4 on C2's 1024-spp shard (inside north_star's 1e-3), 2e-3 .. 9e-3 on
+    C1 and on C3's shard (outside it), 5e-5 / 3e-4 on the C2 / C3 shards with the index-based sobol sampler, whose samples do not depend
+    on each other.
+
+So the assertions: the tier is off unless asked for; every film is finite, complete and unbiased to 1e-4; the error outside the flipped
+pixels is < 1e-4; flipped pixels are few; relRMSE < 3e-2 everywhere (an order of magnitude under the noise at these sample counts) and
+< 1e-3 where the measurements above put it there. pytest -s prints the numbers."""
+import numpy as np
+import pytest
+
+from akari_render_amd import abi, capi, distributed
+from oracle import pyoracle, scene_json
+from tests.helpers import cbox_variant, grid_scene, make_config, n_bit_diff, resolve_np
+
+pytestmark = pytest.mark.gpu
+
+REL_RMSE_TOL = 1e-3  # BASELINE.json north_star: "L2 error vs CPU reference < 1e-3"
+
+
+LOOSE_TOL = 3e-2     # what the tier guarantees with the independent sampler (see above)
+FLIPPED = 1e-3       # a pixel counts as flipped when it is off by more than this fraction of its value
+
+
+def relaxed_against_oracle(ctx, sd, cfg, osc=None, scene=None, label="", tol=LOOSE_TOL, max_flipped=0.01):
+    w, h = sd.camera.width, sd.camera.height
+    with capi.options(arith=1, max_fused_passes=16):
+        scene = scene or capi.Scene(ctx, sd)
+        film = capi.Film(ctx, w, h)
+        se = capi.PtSession(ctx, scene, cfg, film)
+        se.passes((cfg.spp + cfg.spp_per_pass - 1) // cfg.spp_per_pass, blocking=True)
+        info = se.kernel_info()
+        gst = se.end()
+    assert info["kernel_flags"] & 16, info  # the session did run the relaxed kernels
+    g = film.read()
+    n = w * h
+    ostates = None
+    if cfg.sampler_type != abi.SAMPLER_INDEPENDENT:  # index-based samplers: a pixel's state = (sample index - 1, its coordinates)
+        ostates = np.zeros(2 * n, dtype=np.uint64)
+        ostates[0::2] = 0xFFFFFFFF
+        ostates[1::2] = (np.arange(n, dtype=np.uint64) % np.uint64(w)) | ((np.arange(n, dtype=np.uint64) // np.uint64(w)) << np.uint64(32))
+    o, ost = (osc or pyoracle.OracleScene(sd)).render(cfg, states=ostates)
+    owned = distributed.owned_pixel_mask(w, h, cfg.shard_rank, cfg.shard_count, cfg.tile_w, cfg.tile_h).ravel() if cfg.shard_count > 1 else np.ones(n, bool)
+    assert np.isfinite(g).all()
+    assert np.array_equal(g[6 * n:] == cfg.spp, owned)  # every owned pixel got all its samples, nobody else any
+    assert gst["n_samples"] == ost["n_samples"]
+    a = resolve_np(g, w, h).reshape(-1, 3)[owned].astype(np.float64)
+    b = resolve_np(o, w, h).reshape(-1, 3)[owned].astype(np.float64)
+    lum = b @ np.array([0.2126, 0.7152, 0.0722])
+    d = np.sqrt(((a - b) ** 2).sum(axis=1))
+    per_pixel = d / np.maximum(lum, 1e-3 * lum.mean())
+    flipped = per_pixel > FLIPPED
+    err = float(np.sqrt((d ** 2).mean()) / lum.mean())                       # BASELINE.md's relRMSE over the owned pixels
+    err_rest = float(np.sqrt((d[~flipped] ** 2).mean()) / lum.mean())
+    bias = float(a.mean() / b.mean() - 1.0)
+    drift = max(abs(gst[k] - ost[k]) / max(ost[k], 1) for k in ("n_closest", "n_shadow", "n_shaded"))
+    print(f"\n[relaxed] {label}: relRMSE {err:.2e} ({err_rest:.2e} outside the {int(flipped.sum())} flipped pixels of {int(owned.sum())}), median pixel {np.median(per_pixel):.1e}, "
+          f"mean off by {bias:.1e}, ray counts off by {drift:.1e}")
+    assert err < tol
+    assert err_rest < 1e-4
+    assert flipped.mean() < max_flipped
+    assert np.median(per_pixel) < 1e-5
+    assert abs(bias) < 1e-4
+    assert drift < 1e-3
+    return err
+
+
+def test_the_tier_is_off_unless_asked_for(ctx, cbox_path):
+    assert capi.get_option("arith") == 0
+    sd = scene_json.load_scene(cbox_path, 32, 32)
+    scene = capi.Scene(ctx, sd)
+    film = capi.Film(ctx, 32, 32)
+    cfg = make_config(spp=4, spp_per_pass=4)
+    se = capi.PtSession(ctx, scene, cfg, film)
+    se.passes(1, blocking=True)
+    assert se.kernel_info()["kernel_flags"] & 16 == 0
+    se.end()
+    o, _ = pyoracle.OracleScene(sd).render(cfg)
+    assert n_bit_diff(film.read(), o) == 0
+    with pytest.raises(capi.AkariError):
+        capi.set_option("arith", 2)
+
+
+def test_c1_cbox_256_64spp_full_graph(ctx, cbox_path):
+    """configs[0]: the reference's own CPU-runnable case."""
+    sd = scene_json.load_scene(cbox_path, 256, 256)
+    relaxed_against_oracle(ctx, sd, make_config(spp=64, spp_per_pass=64, max_depth=12, rr_depth=5), label="C1 full graph")  # measured 8.8e-3: 100 flipped pixels
+    relaxed_against_oracle(ctx, sd, make_config(spp=64, spp_per_pass=64, max_depth=12, rr_depth=5, sampler_type=abi.SAMPLER_SOBOL), label="C1 full graph, sobol")
+
+
+def test_c1_force_diffuse_and_bvh(ctx, cbox_path):
+    sd = scene_json.load_scene(cbox_path, 256, 256)
+    cfg = make_config(spp=64, spp_per_pass=64, max_depth=12, rr_depth=5, force_diffuse=1)
+    relaxed_against_oracle(ctx, sd, cfg, label="C1 force_diffuse")  # measured 2.3e-3: 25 flipped pixels
+    with capi.options(force_bvh=1):
+        relaxed_against_oracle(ctx, sd, cfg, label="C1 force_diffuse, BVH intersector")
+    cfg.sampler_type = abi.SAMPLER_SOBOL  # samples that do not depend on each other: a flip costs one sample, not the rest of the pass
+    relaxed_against_oracle(ctx, sd, cfg, label="C1 force_diffuse, sobol", tol=REL_RMSE_TOL)
+
+
+@pytest.mark.parametrize("which", ["glass_coat", "kinds"])
+def test_material_variants(ctx, cbox_path, which):
+    sd = cbox_variant(scene_json.load_scene(cbox_path, 96, 96), which)
+    relaxed_against_oracle(ctx, sd, make_config(spp=64, spp_per_pass=32, max_depth=10), label=f"cbox {which}", max_flipped=0.03)
+
+
+def test_c2_1080p_force_diffuse_1024spp_shard(ctx, cbox_path):
+    sd = scene_json.load_scene(cbox_path, 1920, 1080)
+    cfg = distributed.shard_config(make_config(spp=1024, spp_per_pass=64, max_depth=12, rr_depth=5, force_diffuse=1), 7, 255, 32, 32)
+    relaxed_against_oracle(ctx, sd, cfg, label="C2 shard", tol=REL_RMSE_TOL)  # the headline configuration: inside north_star's bar (7.8e-4)
+    cfg.sampler_type = abi.SAMPLER_SOBOL
+    relaxed_against_oracle(ctx, sd, cfg, label="C2 shard, sobol", tol=REL_RMSE_TOL)
+
+
+def test_c3_1080p_full_graph_4096spp_shard(ctx, cbox_path):
+    sd = scene_json.load_scene(cbox_path, 1920, 1080)
+    cfg = distributed.shard_config(make_config(spp=4096, spp_per_pass=64, max_depth=12, rr_depth=5), 100, 510, 32, 32)
+    # 4096 samples per pixel x 2e-5 flips per sample: a tenth of the pixels hold a flip, each worth ~0.5 % of the pixel
+    relaxed_against_oracle(ctx, sd, cfg, label="C3 shard", max_flipped=0.1)
+    cfg.sampler_type = abi.SAMPLER_SOBOL
+    relaxed_against_oracle(ctx, sd, cfg, label="C3 shard, sobol", tol=REL_RMSE_TOL)
+
+
+def test_c4_hall_1m_shard(ctx):
+    from akari_render_amd import procedural
+    sd = procedural.sponza_like(1_000_000, seed=1234, width=1920, height=1080)
+    cfg = distributed.shard_config(make_config(spp=1024, spp_per_pass=64, max_depth=12, rr_depth=5), 4321, 8100, 8, 8)
+    relaxed_against_oracle(ctx, sd, cfg, osc=pyoracle.OracleScene(sd, bvh=True), label="C4 (1 M triangles) shard", max_flipped=0.1)
+
+
+def test_grid_scene_with_normals(ctx):
+    sd = grid_scene(n=24, width=96, height=64, with_normals=True)
+    relaxed_against_oracle(ctx, sd, make_config(spp=32, spp_per_pass=16, max_depth=8), label="grid", max_flipped=0.03)
+
+
+def test_convergence_towards_the_exact_tier(ctx, cbox_path):
+    """Against a 16384-spp image of the EXACT tier the error of relaxed N-spp images falls like 1/sqrt(N), and the two tiers' means agree."""
+    w = h = 64
+    scene = capi.Scene(ctx, cbox_path, w, h)
+
+    def render(spp, seed, arith):
+        film = capi.Film(ctx, w, h)
+        with capi.options(arith=arith):
+            capi.pt_render(ctx, scene, make_config(spp=spp, spp_per_pass=min(spp, 256), max_depth=12, sampler_seed=seed), film)
+        return film.resolve().astype(np.float64)
+
+    ref = render(16384, 1, 0)
+    errs = {n: np.sqrt(np.mean((render(n, 2, 1) - ref) ** 2)) for n in (16, 64, 256, 1024)}
+    for a, b in ((16, 64), (64, 256), (256, 1024)):
+        assert 1.6 < errs[a] / errs[b] < 2.5, errs
+    same_seed = render(16384, 1, 1)
+    assert abs(same_seed.mean() - ref.mean()) < 1e-4 * ref.mean()
+    assert np.sqrt(np.mean((same_seed - ref) ** 2)) / ref.mean() < LOOSE_TOL
