@@ -754,7 +754,8 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
                      out.tex_nodes.size() * sizeof(DNode), out.images.size() * sizeof(DImage), out.mat_inputs.size() * sizeof(MatInputs)})
         stage += (b + 15) & ~(size_t)15;
     if (n_tris > kExhaustiveMax || stage > kStageMaxBytes) {
-        const float pad = bvh_box_padding(out.scene_lo, out.scene_hi, flat.camera.c2w);
+        const float pad_scale = 0.01f * (float)tune.pad_percent;  // (test hook: 100)
+        const float pad = pad_scale * bvh_box_padding(out.scene_lo, out.scene_hi, flat.camera.c2w);
         {   // needles: what their ill-conditioned inside test reaches beyond the flat padding, per triangle and axis (scene_build.h)
             const unsigned nc = n_tris > (1u << 17) ? host_threads() * 4 : 1;
             parallel_chunks(nc, host_threads(), [&](unsigned c) {
@@ -764,7 +765,7 @@ void compile_scene(const FlatScene& flat, CompiledScene& out) {
                     float* bb = &bounds[6ull * g];
                     const float mag = box_magnitude(bb, bb + 3);
                     for (int a = 0; a < 3; a++) {
-                        const float extra = tri_cond_extra(k[a], mag, pad);
+                        const float extra = pad_scale * tri_cond_extra(k[a], mag, pad / pad_scale);
                         if (extra > 0.0f) {
                             bb[a] -= extra;
                             bb[3 + a] += extra;
@@ -838,6 +839,7 @@ int* tuning_field(const char* name) {
     if (n == "wf_sort") return &g_tuning.wf_sort;
     if (n == "instancing") return &g_tuning.instancing;
     if (n == "arith") return &g_tuning.arith;
+    if (n == "pad_percent") return &g_tuning.pad_percent;
     return nullptr;
 }
 }  // namespace
@@ -858,6 +860,7 @@ bool tuning_set(const char* name, int value) {
     if (f == &g_tuning.wf_sort && (value < 0 || value > 1)) return false;
     if (f == &g_tuning.instancing && (value < -1 || value > 1)) return false;
     if (f == &g_tuning.arith && (value < 0 || value > 1)) return false;
+    if (f == &g_tuning.pad_percent && (value < 1 || value > 10000)) return false;
     *f = value;
     return true;
 }

@@ -177,6 +177,7 @@ void build_alias_table(const std::vector<float>& weights, std::vector<AliasEntry
 //   instancing   AKR_INSTANCING=<v>       meshes + instances kept as they are (BLAS per mesh, TLAS over instances; scene_inst.cpp): -1 auto, 0 never, 1 always
 //   arith        AKR_ARITH=1              pt megakernel in the relaxed arithmetic tier (flattened scenes; precompiled kernels): hardware rcp / sqrt /
 //                                         sin / cos / log / exp and contraction instead of the bit-exact contract
+//   pad_percent  (no environment hook)    test hook: box padding in percent of the derived value (100)
 //   wf_sort      AKR_WF_SORT=1            wavefront schedule: ray queues sorted by origin cell + direction octant before each trace launch
 //   max_fused_passes (no environment hook)     most passes akr_pt_passes fuses into one launch: 0 = adaptive (16, up to 64 once a pass has been timed), else 1..64
 struct TuningOptions {
@@ -188,6 +189,8 @@ struct TuningOptions {
                           // default while its records fit a budget), 0 never, 1 whenever a mesh has more than one instance
     int arith = 0;    // arithmetic tier of the pt megakernel: 0 = the AKR-F32 contract (bit-exact with the oracle), 1 = relaxed (pt_kernels_relaxed.hip:
                       // films within north_star's relRMSE < 1e-3 of the oracle, not identical to it)
+    int pad_percent = 100;  // test hook: the padding of the acceleration structures' boxes (flat part and needle part) in percent of what the compiler derives --
+                            // tests/test_bvh_conservative.py shows with it how far the derived padding is from the first lost hit
     int wf_sort = 0;  // wavefront schedule: 1 = the ray queues are sorted by (Morton code of the origin, octant) before every trace launch (wf_sort.hip)
 };
 constexpr uint64_t kSpecAutoSamples = 1ull << 31;  // option specialise = -1: a first-use compile (about a second; 20-30 % of the render to win) has to be worth it

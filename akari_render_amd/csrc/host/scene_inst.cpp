@@ -135,12 +135,14 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
             out.scene_hi[a] = max_f(out.scene_hi[a], inst_bounds[6 * i + 3 + a]);
         }
     }
-    float diag2 = 0.0f, reach = 0.0f;  // reach: how far from the origin a ray can start (scene box, camera)
-    for (int a = 0; a < 3; a++) {
-        diag2 += sqr(out.scene_hi[a] - out.scene_lo[a]);
-        reach += max_f(max_f(abs_f(out.scene_lo[a]), abs_f(out.scene_hi[a])), abs_f(flat.camera.c2w[12 + a]));
+    const float pad_scale = 0.01f * (float)tuning().pad_percent;  // (test hook: 100)
+    const float pad_world = pad_scale * bvh_box_padding(out.scene_lo, out.scene_hi, flat.camera.c2w);  // the flattened tree's padding
+    float scene_mag;  // 2-norm of the largest coordinates a ray origin or a hit point can have
+    {
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; a++) { lo[a] = min_f(out.scene_lo[a], flat.camera.c2w[12 + a]); hi[a] = max_f(out.scene_hi[a], flat.camera.c2w[12 + a]); }
+        scene_mag = box_magnitude(lo, hi);
     }
-    const float pad_world = bvh_box_padding(out.scene_lo, out.scene_hi, flat.camera.c2w);  // the flattened tree's padding
     // ---- per instance: the inverse transform (double -> f32; used for culling only) and its norm
     std::vector<double> inv(12 * n_inst);
     std::vector<float> inv_norm(n_inst, 0.0f), mesh_inv_norm(n_mesh, 0.0f);
@@ -232,21 +234,24 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
             }
             mesh_k2max[m] = max_f(mesh_k2max[m], (k[0] + k[1]) + k[2]);  // (>= the 2-norm of the per-axis values)
             for (int a = 0; a < 3; a++) {
-                // worst instance of the mesh: |M^-1| x how far from the origin its copy of the triangle can be; the flat part: what pad_obj below holds of pad_world
-                const float extra = tri_cond_extra(k[a], mesh_back_mag[m], mesh_inv_norm[m] * pad_world);
-                if (extra > 0.0f) { bb[a] -= extra; bb[3 + a] += extra; }
+                // worst instance of the mesh: |M^-1| x how far from the origin its copy of the triangle can be
+                const float extra = pad_scale * kTriCondEps * mesh_back_mag[m] * k[a];  // (in full: the flat padding below holds no allowance for it)
+                bb[a] -= extra; bb[3 + a] += extra;
             }
         }
         mesh_size[m] = (float)(std::sqrt(std::sqrt(max_n2)) * 1.0001);  // sqrt(|n|) of the mesh's largest triangle
-        // Padding of the object-space boxes. A triangle the flattened test would accept lies within pad_world of its world box; in object
-        // space that is pad_world x |M^-1|. The ray is taken through M^-1 in f32: its origin is off by a few ulp of |M^-1| x (how far from
-        // the origin a ray can start), its direction by a few ulp -- i.e. by that much of the object-space scene extent at the far end.
-        // Both with a generous constant; the largest |M^-1| over the mesh's instances (the BLAS is shared).
-        float odiag = 0.0f;
-        for (int a = 0; a < 3; a++) odiag += ohi[a] - olo[a];
-        // Round 6: + the magnitude of what cancels (vertices at 1e4, size 1, translation -1e4 -- the object-space ray is
-        // then off by ulp(1e4) while the terms above see a scene of size 1 at the origin).
-        const float pad_obj = mesh_inv_norm[m] * (pad_world + 4e-6f * (reach + __builtin_sqrtf(diag2))) + 4e-6f * (odiag + mesh_obj_reach[m] + mesh_back_reach[m]);
+        // Flat padding of the object-space boxes (round 6: derived term by term instead of stacked 4e-6's -- the forest's per-mesh trees carried
+        // a padding of a quarter of their triangles' size). u = 2^-24; |R| = the instance's inverse (the larger of its infinity- and 2-norm),
+        // Ms = magnitude of the scene's coordinates (2-norm of the largest per axis, camera included), back = |R| (|M| V + |t|), V = the mesh's own
+        // coordinates. A pair the world-space test accepts has its hit point p on the world ray, within 16 u Ms of the triangle's plane-and-edges
+        // (plane solve: 4 roundings on sums of size 2 |r2| max(|o|, |A|), the rows' own rounding, the division; p = fma(t, d, o): 1 more) plus
+        // the needle term that is added per triangle above. Into object space: x |R|. The object-space ray: origin off by 4 u (|R| Ms + |c|), |c| <=
+        // back (rounded rows, three products and three sums), direction by 4 u |R||d|, i.e. 8 u |R| Ms at the far end; v_rcp_f32's ulp scales
+        // every slab distance: 2 u |R| Ms. The vertices themselves: fl(M v + t) is off by 3 u (|M| V + |t|), back through R: 3 u back. The slab
+        // test's own fma roundings: 6 u (V + |R| Ms + |c|). Sum: u (36 |R| Ms + 13 back + 6 V), doubled.
+        const float kU = 5.9604645e-8f;
+        float pad_obj = 2.0f * kU * (36.0f * mesh_inv_norm[m] * scene_mag + 13.0f * mesh_back_reach[m] + 6.0f * mesh_obj_reach[m]);
+        pad_obj *= pad_scale;
         std::vector<uint32_t> order;
         build_bvh8(bounds, nt, pad_obj, kBvhNodeWords, tune.bvh_balanced != 0, order, blas_nodes[m], blas_depth[m]);
         if (blas_depth[m] > kBvhStackDepth) build_bvh8(bounds, nt, pad_obj, kBvhNodeWords, true, order, blas_nodes[m], blas_depth[m]);
@@ -306,7 +311,7 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
             tlas_ids.push_back((uint32_t)i);
             tb.insert(tb.end(), &inst_bounds[6 * i], &inst_bounds[6 * i] + 6);
             // the instance's needles in world space: conditioning at most cond(M) x the mesh's worst
-            const float extra = tri_cond_extra(inst_cond[i] * mesh_k2max[flat.instances[i].mesh], box_magnitude(&inst_bounds[6 * i], &inst_bounds[6 * i + 3]), pad_world);
+            const float extra = pad_scale * tri_cond_extra(inst_cond[i] * mesh_k2max[flat.instances[i].mesh], box_magnitude(&inst_bounds[6 * i], &inst_bounds[6 * i + 3]), pad_world / pad_scale);
             for (int a = 0; a < 3; a++) { tb[tb.size() - 6 + a] -= extra; tb[tb.size() - 3 + a] += extra; }
         }
         if (tlas_ids.empty()) throw std::invalid_argument("instanced scene without triangles");

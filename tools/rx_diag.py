@@ -27,6 +27,11 @@ def run(label, sd, cfg, osc=None):
     out = dict(label=label, relRMSE=float(np.sqrt((d**2).mean())/lum.mean()), median_pix=float(np.median(pr)), p99=float(np.percentile(pr,99)), frac_gt_1e3=float((pr>1e-3).mean()), n_gt_1e3=int((pr>1e-3).sum()), n_pix=int(owned.sum()),
                relRMSE_without_outliers=float(np.sqrt((d[pr<=1e-3]**2).mean())/lum.mean()), mean_ratio=float(r.mean()/e.mean()-1))
     print(json.dumps(out), flush=True)
+from tests.helpers import cbox_variant
+if 'variants' in sys.argv:
+    for which in ("glass_coat", "kinds"):
+        run(f"cbox {which}", cbox_variant(scene_json.load_scene(cbox, 96, 96), which), make_config(spp=64, spp_per_pass=32, max_depth=10))
+    sys.exit(0)
 sd = scene_json.load_scene(cbox, 256, 256)
 for smp in (0, 2, 1):
     run(f"C1 full sampler {smp}", sd, make_config(spp=64, spp_per_pass=64, max_depth=12, rr_depth=5, sampler_type=smp))
