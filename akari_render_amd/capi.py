@@ -25,24 +25,28 @@ ERR_INVALID_ARGUMENT, ERR_HIP, ERR_NO_DEVICE, ERR_IO, ERR_PARSE, ERR_UNSUPPORTED
 
 # every symbol include/akari_hip.h declares (checked by tests/test_abi.py against the header text)
 EXPORTS = [
-    "akr_last_error", "akr_version", "akr_struct_size", "akr_option_set", "akr_option_get",
-    "akr_context_create", "akr_context_destroy", "akr_context_synchronize", "akr_context_device_info",
-    "akr_scene_create", "akr_scene_load", "akr_scene_destroy", "akr_scene_set_resolution", "akr_scene_get_info",
-    "akr_scene_get_light", "akr_scene_get_ggx_table", "akr_scene_get_desc_counts", "akr_scene_get_mesh",
-    "akr_scene_get_instance", "akr_scene_get_material", "akr_scene_get_camera", "akr_scene_get_array",
-    "akr_scene_get_image_count", "akr_scene_get_image", "akr_scene_get_material_graph",
-    "akr_film_create", "akr_film_wrap", "akr_film_destroy", "akr_film_clear", "akr_film_read", "akr_film_write",
-    "akr_film_resolve", "akr_film_device_ptr",
-    "akr_pt_config_default", "akr_pt_config_from_json", "akr_pt_render", "akr_pt_begin", "akr_pt_passes", "akr_pt_end",
-    "akr_pt_get_stats", "akr_render_task", "akr_image_write", "akr_aov_config_default", "akr_aov_render",
-    "akr_gpt_config_default", "akr_gpt_render", "akr_gpt_begin", "akr_gpt_sample", "akr_gpt_sums", "akr_gpt_sums_read", "akr_gpt_sums_write",
-    "akr_gpt_finish", "akr_gpt_abort", "akr_gpt_reduce", "akr_mcmc_config_default", "akr_mcmc_render", "akr_film_set_splat_scale", "akr_film_get_splat_scale",
-    "akr_pt_read_sampler_states", "akr_context_device_ordinal", "akr_device_count",
-    "akr_probe_material_inputs_host", "akr_comm_unique_id", "akr_comm_create", "akr_comm_wrap", "akr_comm_destroy", "akr_film_reduce",
-    "akr_host_stdrng_u64", "akr_host_chacha_block", "akr_host_pcg32_states", "akr_host_pcg_start", "akr_host_alias_table",
-    "akr_probe_math", "akr_probe_bsdf", "akr_probe_intersect", "akr_probe_surface_interaction", "akr_probe_material_inputs",
-    "akr_host_decode_png", "akr_host_decode_jpeg", "akr_host_decode_exr", "akr_host_decode_tiff", "akr_host_decode_dds", "akr_host_pmj02bn_tables",
-    "akr_pt_kernel_info", "akr_scene_spec_source", "akr_host_spec_compile", "akr_probe_material_folded_host", "akr_host_sobol_dim1", "akr_host_fastmod", "akr_host_tri_pretest", "akr_host_spec_compile_text", "akr_film_reduce_planes", "akr_mcmc_render_shard", "akr_mcmc_combine_host", "akr_mcmc_combine",
+    "akr_last_error", "akr_version", "akr_struct_size", "akr_option_set", "akr_option_get", "akr_context_create",
+    "akr_context_destroy", "akr_context_synchronize", "akr_context_device_info", "akr_scene_create", "akr_scene_load",
+    "akr_scene_destroy", "akr_scene_set_resolution", "akr_scene_get_info", "akr_scene_get_light", "akr_scene_get_ggx_table",
+    "akr_scene_get_desc_counts", "akr_scene_get_mesh", "akr_scene_get_instance", "akr_scene_get_material", "akr_scene_get_camera",
+    "akr_scene_get_array", "akr_scene_get_image_count", "akr_scene_get_image", "akr_scene_get_material_graph", "akr_film_create",
+    "akr_film_wrap", "akr_film_destroy", "akr_film_clear", "akr_film_read", "akr_film_write", "akr_film_resolve",
+    "akr_film_device_ptr", "akr_pt_config_default", "akr_pt_config_from_json", "akr_pt_render", "akr_pt_begin", "akr_pt_passes",
+    "akr_pt_end", "akr_pt_get_stats", "akr_render_task", "akr_image_write", "akr_aov_config_default", "akr_aov_render",
+    "akr_gpt_config_default", "akr_gpt_render", "akr_gpt_begin", "akr_gpt_sample", "akr_gpt_sums", "akr_gpt_sums_read",
+    "akr_gpt_sums_write", "akr_gpt_finish", "akr_gpt_abort", "akr_gpt_reduce", "akr_mcmc_config_default", "akr_mcmc_render",
+    "akr_film_set_splat_scale", "akr_film_get_splat_scale", "akr_pt_read_sampler_states", "akr_context_device_ordinal",
+    "akr_device_count", "akr_comm_unique_id", "akr_comm_create", "akr_comm_wrap", "akr_comm_destroy", "akr_film_reduce",
+    "akr_pt_kernel_info", "akr_scene_spec_source", "akr_host_spec_compile", "akr_host_spec_compile_text",
+    "akr_film_reduce_planes", "akr_mcmc_render_shard", "akr_mcmc_combine_host", "akr_mcmc_combine",
+]
+# include/akari_hip_test.h: the test hooks (compiled into the in-tree test build, absent from a build with AKR_SHIP=1)
+TEST_EXPORTS = [
+    "akr_probe_material_inputs_host", "akr_host_stdrng_u64", "akr_host_chacha_block", "akr_host_pcg32_states",
+    "akr_host_pcg_start", "akr_host_alias_table", "akr_probe_math", "akr_probe_bsdf", "akr_probe_intersect",
+    "akr_probe_surface_interaction", "akr_probe_material_inputs", "akr_host_decode_png", "akr_host_decode_jpeg",
+    "akr_host_decode_exr", "akr_host_decode_tiff", "akr_host_decode_dds", "akr_host_pmj02bn_tables",
+    "akr_probe_material_folded_host", "akr_host_sobol_dim1", "akr_host_fastmod", "akr_host_tri_pretest",
 ]
 
 
@@ -84,6 +88,8 @@ def lib() -> C.CDLL:
             raise ImportError("libakari_hip.so and akari_render_amd/abi.py disagree on sizeof(%s): %d vs %d" % (cls.__name__, L.akr_struct_size(sid), C.sizeof(cls)))
 
     def proto(name, *args):
+        if name in TEST_EXPORTS and not hasattr(L, name):
+            return  # a library built without the test hooks (AKR_SHIP=1)
         fn = getattr(L, name)
         fn.restype = i32
         fn.argtypes = list(args)

@@ -1,23 +1,26 @@
-// api_probe.cpp -- host-side known-answer hooks and device probes for the tests (C ABI of libakari_hip.so, include/akari_hip.h; shared internals: api_internal.h)
+// api_probe.cpp -- host-side known-answer hooks and device probes for the tests: the TEST HOOKS of libakari_hip.so, declared in
+// include/akari_hip_test.h and compiled in only with -DAKR_TEST_HOOKS=1 (the in-tree test build; build.py). Shared internals: api_internal.h
+#if defined(AKR_TEST_HOOKS) && AKR_TEST_HOOKS
 #include "api_internal.h"
+#include "../../../include/akari_hip_test.h"
 #include "../device/dinst.h"
 #include "../device/disect.h"
 
 extern "C" {
 
 // ------------------------------------------------------------------------------------------------ host KAT hooks
-AKR_API int32_t akr_host_stdrng_u64(uint64_t seed, uint32_t n, uint64_t* out) {
+AKR_TEST_API int32_t akr_host_stdrng_u64(uint64_t seed, uint32_t n, uint64_t* out) {
     if (!out) return fail(AKR_ERR_INVALID_ARGUMENT, "out is NULL");
     StdRng rng(seed);
     for (uint32_t i = 0; i < n; i++) out[i] = rng.next_u64();
     return AKR_OK;
 }
-AKR_API int32_t akr_host_chacha_block(const uint32_t* key8, uint64_t counter, uint64_t stream, int32_t rounds, uint32_t* out16) {
+AKR_TEST_API int32_t akr_host_chacha_block(const uint32_t* key8, uint64_t counter, uint64_t stream, int32_t rounds, uint32_t* out16) {
     if (!key8 || !out16) return fail(AKR_ERR_INVALID_ARGUMENT, "NULL argument");
     StdRng::chacha_block(key8, counter, stream, rounds, out16);
     return AKR_OK;
 }
-AKR_API int32_t akr_host_pcg32_states(uint64_t seed, uint64_t n, uint64_t* out2n) {
+AKR_TEST_API int32_t akr_host_pcg32_states(uint64_t seed, uint64_t n, uint64_t* out2n) {
     if (!out2n) return fail(AKR_ERR_INVALID_ARGUMENT, "out is NULL");
     StdRng rng(seed);
     for (uint64_t i = 0; i < n; i++) {
@@ -27,7 +30,7 @@ AKR_API int32_t akr_host_pcg32_states(uint64_t seed, uint64_t n, uint64_t* out2n
     }
     return AKR_OK;
 }
-AKR_API int32_t akr_host_pcg_start(uint64_t* state, uint64_t inc) {
+AKR_TEST_API int32_t akr_host_pcg_start(uint64_t* state, uint64_t inc) {
     if (!state) return fail(AKR_ERR_INVALID_ARGUMENT, "state is NULL");
     Pcg32 p{*state, inc};
     pcg_start(p, pcg_start_constants());
@@ -35,7 +38,7 @@ AKR_API int32_t akr_host_pcg_start(uint64_t* state, uint64_t inc) {
     return AKR_OK;
 }
 // device/drng.h on the host: reverse_bits32(sobol_dim1(i)) by the defining loop and by the five-step butterfly the kernels use
-AKR_API int32_t akr_host_sobol_dim1(uint32_t n, const uint32_t* index, uint32_t* by_loop, uint32_t* by_butterfly) {
+AKR_TEST_API int32_t akr_host_sobol_dim1(uint32_t n, const uint32_t* index, uint32_t* by_loop, uint32_t* by_butterfly) {
     if (!index || !by_loop || !by_butterfly) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_host_sobol_dim1: NULL argument");
     for (uint32_t k = 0; k < n; k++) {
         by_loop[k] = reverse_bits32(sobol_dim1(index[k]));
@@ -44,7 +47,7 @@ AKR_API int32_t akr_host_sobol_dim1(uint32_t n, const uint32_t* index, uint32_t*
     return AKR_OK;
 }
 // device/drng.h fastmod_u32 on the host: a[k] % d[k] through the precomputed constant
-AKR_API int32_t akr_host_fastmod(uint32_t n, const uint32_t* a, const uint32_t* d, uint32_t* out) {
+AKR_TEST_API int32_t akr_host_fastmod(uint32_t n, const uint32_t* a, const uint32_t* d, uint32_t* out) {
     if (!a || !d || !out) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_host_fastmod: NULL argument");
     for (uint32_t k = 0; k < n; k++) {
         if (d[k] == 0) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_host_fastmod: divisor 0");
@@ -54,7 +57,7 @@ AKR_API int32_t akr_host_fastmod(uint32_t n, const uint32_t* a, const uint32_t* 
 }
 // device/dinst.h on the host: the conservative reject of a candidate (tri_may_hit) next to the exact test it stands in front of
 // (woop_precompute + tri_test), per item: ray = o.xyz d.xyz tmin tlimit, tri = A B C (world space, f32). exact: bit 0 accept, t in out_t.
-AKR_API int32_t akr_host_tri_pretest(uint32_t n, const float* rays8, const float* tris9, float plane_shift, uint32_t* may, uint32_t* exact, float* out_t) {
+AKR_TEST_API int32_t akr_host_tri_pretest(uint32_t n, const float* rays8, const float* tris9, float plane_shift, uint32_t* may, uint32_t* exact, float* out_t) {
     if (!rays8 || !tris9 || !may || !exact) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_host_tri_pretest: NULL argument");
     for (uint32_t k = 0; k < n; k++) {
         const float* r = rays8 + 8ull * k;
@@ -68,7 +71,7 @@ AKR_API int32_t akr_host_tri_pretest(uint32_t n, const float* rays8, const float
     }
     return AKR_OK;
 }
-AKR_API int32_t akr_host_alias_table(const float* weights, uint32_t n, uint32_t* j, float* t, float* pdf) {
+AKR_TEST_API int32_t akr_host_alias_table(const float* weights, uint32_t n, uint32_t* j, float* t, float* pdf) {
     if (!weights || !j || !t || !pdf || n == 0) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_host_alias_table: bad argument");
     return guarded([&] {
         std::vector<float> w(weights, weights + n), p;
@@ -79,7 +82,7 @@ AKR_API int32_t akr_host_alias_table(const float* weights, uint32_t n, uint32_t*
 }
 
 // ------------------------------------------------------------------------------------------------ probes
-AKR_API int32_t akr_probe_math(akr_context* ctx, uint32_t n, const float* x, float* s, float* c, float* l) {
+AKR_TEST_API int32_t akr_probe_math(akr_context* ctx, uint32_t n, const float* x, float* s, float* c, float* l) {
     if (!ctx || !x || !s || !c || !l) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_probe_math: NULL argument");
     return guarded([&] {
         ctx->bind();
@@ -96,7 +99,7 @@ AKR_API int32_t akr_probe_math(akr_context* ctx, uint32_t n, const float* x, flo
         }
     });
 }
-AKR_API int32_t akr_probe_bsdf(akr_context* ctx, const akr_material_desc* m, const float* table, int32_t mode, const float* wo, uint32_t n,
+AKR_TEST_API int32_t akr_probe_bsdf(akr_context* ctx, const akr_material_desc* m, const float* table, int32_t mode, const float* wo, uint32_t n,
                                const float* in, float* out) {
     if (!ctx || !m || !wo || !in || !out) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_probe_bsdf: NULL argument");
     return guarded([&] {
@@ -124,7 +127,7 @@ static PtParams probe_params(akr_scene* s) {
     p.tex_slots = s->cs.has_textures ? s->cs.tex_slots : 0;
     return p;
 }
-AKR_API int32_t akr_probe_intersect(akr_context* ctx, akr_scene* scene, uint32_t n, const float* rays, uint32_t* hit_inst_prim, float* bary) {
+AKR_TEST_API int32_t akr_probe_intersect(akr_context* ctx, akr_scene* scene, uint32_t n, const float* rays, uint32_t* hit_inst_prim, float* bary) {
     if (!ctx || !scene || !rays || !hit_inst_prim || !bary) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_probe_intersect: NULL argument");
     return guarded([&] {
         ctx->bind();
@@ -141,7 +144,7 @@ AKR_API int32_t akr_probe_intersect(akr_context* ctx, akr_scene* scene, uint32_t
         }
     });
 }
-AKR_API int32_t akr_probe_surface_interaction(akr_context* ctx, akr_scene* scene, uint32_t n, const uint32_t* inst_prim, const float* bary,
+AKR_TEST_API int32_t akr_probe_surface_interaction(akr_context* ctx, akr_scene* scene, uint32_t n, const uint32_t* inst_prim, const float* bary,
                                               float* out) {
     if (!ctx || !scene || !inst_prim || !bary || !out) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_probe_surface_interaction: NULL argument");
     return guarded([&] {
@@ -163,7 +166,7 @@ AKR_API int32_t akr_probe_surface_interaction(akr_context* ctx, akr_scene* scene
     });
 }
 
-AKR_API int32_t akr_host_pmj02bn_tables(uint32_t* sets, uint16_t* bluenoise) {
+AKR_TEST_API int32_t akr_host_pmj02bn_tables(uint32_t* sets, uint16_t* bluenoise) {
     return guarded([&] {
         if (sets) {
             std::vector<uint32_t> v;
@@ -178,7 +181,7 @@ AKR_API int32_t akr_host_pmj02bn_tables(uint32_t* sets, uint16_t* bluenoise) {
     });
 }
 // PNG reader of the scene loader, exposed for tests: rgba == NULL returns the size only.
-AKR_API int32_t akr_host_decode_png(const uint8_t* data, uint64_t len, uint32_t* width, uint32_t* height, uint8_t* rgba, uint64_t capacity) {
+AKR_TEST_API int32_t akr_host_decode_png(const uint8_t* data, uint64_t len, uint32_t* width, uint32_t* height, uint8_t* rgba, uint64_t capacity) {
     if (!data || !width || !height) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_host_decode_png: NULL argument");
     return guarded([&] {
         std::vector<uint8_t> px;
@@ -189,7 +192,7 @@ AKR_API int32_t akr_host_decode_png(const uint8_t* data, uint64_t len, uint32_t*
         }
     });
 }
-AKR_API int32_t akr_host_decode_jpeg(const uint8_t* data, uint64_t len, uint32_t* width, uint32_t* height, uint8_t* rgba, uint64_t capacity) {
+AKR_TEST_API int32_t akr_host_decode_jpeg(const uint8_t* data, uint64_t len, uint32_t* width, uint32_t* height, uint8_t* rgba, uint64_t capacity) {
     if (!data || !width || !height) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_host_decode_jpeg: NULL argument");
     return guarded([&] {
         std::vector<uint8_t> px;
@@ -200,7 +203,7 @@ AKR_API int32_t akr_host_decode_jpeg(const uint8_t* data, uint64_t len, uint32_t
         }
     });
 }
-AKR_API int32_t akr_host_decode_tiff(const uint8_t* data, uint64_t len, uint32_t* width, uint32_t* height, uint8_t* rgba, uint64_t capacity) {
+AKR_TEST_API int32_t akr_host_decode_tiff(const uint8_t* data, uint64_t len, uint32_t* width, uint32_t* height, uint8_t* rgba, uint64_t capacity) {
     if (!data || !width || !height) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_host_decode_tiff: NULL argument");
     return guarded([&] {
         std::vector<uint8_t> px;
@@ -211,7 +214,7 @@ AKR_API int32_t akr_host_decode_tiff(const uint8_t* data, uint64_t len, uint32_t
         }
     });
 }
-AKR_API int32_t akr_host_decode_dds(const uint8_t* data, uint64_t len, uint32_t* width, uint32_t* height, uint8_t* rgba, uint64_t capacity) {
+AKR_TEST_API int32_t akr_host_decode_dds(const uint8_t* data, uint64_t len, uint32_t* width, uint32_t* height, uint8_t* rgba, uint64_t capacity) {
     if (!data || !width || !height) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_host_decode_dds: NULL argument");
     return guarded([&] {
         std::vector<uint8_t> px;
@@ -222,7 +225,7 @@ AKR_API int32_t akr_host_decode_dds(const uint8_t* data, uint64_t len, uint32_t*
         }
     });
 }
-AKR_API int32_t akr_host_decode_exr(const uint8_t* data, uint64_t len, uint32_t* width, uint32_t* height, float* rgba, uint64_t capacity_floats) {
+AKR_TEST_API int32_t akr_host_decode_exr(const uint8_t* data, uint64_t len, uint32_t* width, uint32_t* height, float* rgba, uint64_t capacity_floats) {
     if (!data || !width || !height) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_host_decode_exr: NULL argument");
     return guarded([&] {
         std::vector<float> px;
@@ -237,7 +240,7 @@ AKR_API int32_t akr_host_decode_exr(const uint8_t* data, uint64_t len, uint32_t*
 // same code on the host (ctx == NULL).
 // The same on the host for an arbitrary colour pipeline: the material tables are compiled for `color` (what akr_pt_begin does
 // for a session with akr_pt_config.color != 0) and evaluated with the code the kernels run.
-AKR_API int32_t akr_probe_material_inputs_host(akr_scene* scene, uint32_t material, uint32_t color, uint32_t n, const float* uv, float* out26) {
+AKR_TEST_API int32_t akr_probe_material_inputs_host(akr_scene* scene, uint32_t material, uint32_t color, uint32_t n, const float* uv, float* out26) {
     if (!scene || !uv || !out26) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_probe_material_inputs_host: NULL argument");
     if (material >= scene->flat.materials.size()) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_probe_material_inputs_host: material out of range");
     return guarded([&] {
@@ -261,7 +264,7 @@ AKR_API int32_t akr_probe_material_inputs_host(akr_scene* scene, uint32_t materi
 // The interpreter's view of a material at n uv points, on the host, default colour pipeline: material_at (the folded record, 64
 // words), material_alpha_at and material_emission_inputs_at (device/dtex.h). What a per-scene kernel's generated code must
 // reproduce bit for bit (tests/test_specialise.py compiles that text for the host and compares).
-AKR_API int32_t akr_probe_material_folded_host(akr_scene* scene, uint32_t material, uint32_t n, const float* uv, uint32_t* out64, float* alpha, float* emission3) {
+AKR_TEST_API int32_t akr_probe_material_folded_host(akr_scene* scene, uint32_t material, uint32_t n, const float* uv, uint32_t* out64, float* alpha, float* emission3) {
     if (!scene || !uv || !out64) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_probe_material_folded_host: NULL argument");
     if (material >= scene->cs.materials.size()) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_probe_material_folded_host: material out of range");
     return guarded([&] {
@@ -283,7 +286,7 @@ AKR_API int32_t akr_probe_material_folded_host(akr_scene* scene, uint32_t materi
     });
 }
 
-AKR_API int32_t akr_probe_material_inputs(akr_context* ctx, akr_scene* scene, uint32_t material, uint32_t n, const float* uv, float* out26) {
+AKR_TEST_API int32_t akr_probe_material_inputs(akr_context* ctx, akr_scene* scene, uint32_t material, uint32_t n, const float* uv, float* out26) {
     if (!scene || !uv || !out26) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_probe_material_inputs: NULL argument");
     if (material >= scene->flat.materials.size()) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_probe_material_inputs: material out of range");
     return guarded([&] {
@@ -316,3 +319,4 @@ AKR_API int32_t akr_probe_material_inputs(akr_context* ctx, akr_scene* scene, ui
 }
 
 }  // extern "C"
+#endif  // AKR_TEST_HOOKS

@@ -1,4 +1,5 @@
-"""The C-ABI library loads without a GPU and exports every symbol include/akari_hip.h declares."""
+"""The C-ABI library loads without a GPU and exports every symbol include/akari_hip.h declares (and, in the test build, every
+test hook of include/akari_hip_test.h)."""
 import ctypes as C
 import os
 import re
@@ -9,18 +10,38 @@ import pytest
 from akari_render_amd import abi, capi
 
 
-def _declared(root):
-    text = open(os.path.join(root, "include", "akari_hip.h")).read()
-    return sorted(set(re.findall(r"AKR_API\s+[\w\s\*]+?\b(akr_\w+)\s*\(", text)))
+def _declared(root, header="akari_hip.h", macro="AKR_API"):
+    text = open(os.path.join(root, "include", header)).read()
+    return sorted(set(re.findall(macro + r"\s+[\w\s\*]+?\b(akr_\w+)\s*\(", text)))
 
 
 def test_every_declared_symbol_is_exported(hip_lib, root):
+    """Two symbol sets: the drop-in boundary (include/akari_hip.h, what INTEGRATION.md binds) and the test hooks
+    (include/akari_hip_test.h, only in a library built with -DAKR_TEST_HOOKS=1 -- the in-tree test build)."""
     names = _declared(root)
     assert len(names) >= 40
     for n in names:
         assert hasattr(hip_lib, n), f"libakari_hip.so does not export {n}"
     # and the binding lists exactly the header's symbols
     assert sorted(capi.EXPORTS) == names
+    hooks = _declared(root, "akari_hip_test.h", "AKR_TEST_API")
+    assert sorted(capi.TEST_EXPORTS) == hooks and len(hooks) >= 20
+    assert not set(hooks) & set(names)
+    # nothing that looks like a hook is left in the public header (the spec compile entry points are the JIT's, used by akari-cli)
+    assert [n for n in names if n.startswith("akr_probe_") or (n.startswith("akr_host_") and "spec_compile" not in n)] == []
+    have = [hasattr(hip_lib, n) for n in hooks]
+    assert all(have) or not any(have), "the library exports some test hooks and not others"
+    from akari_render_amd import build
+    assert all(have) == build.TEST_HOOKS
+
+
+def test_a_shipping_build_leaves_the_hooks_out(root):
+    """api_probe.cpp compiles to nothing without AKR_TEST_HOOKS (what AKR_SHIP=1 builds): checked on the preprocessed source."""
+    import subprocess
+    src = os.path.join(root, "akari_render_amd", "csrc", "host", "api_probe.cpp")
+    out = subprocess.run(["g++", "-E", "-P", "-x", "c++", src], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert out.returncode == 0, out.stderr[-500:]
+    assert "akr_" not in out.stdout
 
 
 def test_struct_sizes_match_header(hip_lib):
