@@ -7,7 +7,7 @@ namespace akr {
 
 enum : uint32_t { AOV_NS = 0, AOV_NG = 1, AOV_TANGENT = 2, AOV_BITANGENT = 3, AOV_ALBEDO = 4, AOV_ROUGHNESS = 5 };
 
-template <bool BVH, bool TEX, bool PMJ>
+template <bool BVH, bool TEX, bool PMJ, bool INST = false>
 __global__ __launch_bounds__(256) void k_aov(const PtParams p_in, uint32_t spp, uint32_t aov, uint32_t remap) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: traversal stacks; else: the staged scene tables
     PtParams staged = p_in;
@@ -35,11 +35,12 @@ __global__ __launch_bounds__(256) void k_aov(const PtParams p_in, uint32_t spp, 
             generate_ray<PMJ>(p, px, py, smp, o, d);
             Hit hit;
             n_closest++;
-            bool found = BVH ? trace_bvh<false, TEX>(sc, o, d, 0.0f, 1e20f, kInvalid, kInvalid, hit, tc.stack, tc.cnt)
-                             : trace_exhaustive<false, TEX>(sc, o, d, 0.0f, 1e20f, kInvalid, kInvalid, hit);
+            bool found = INST ? trace_inst<false, TEX>(sc, o, d, 0.0f, 1e20f, kInvalid, kInvalid, hit, tc.stack, tc.cnt)
+                              : (BVH ? trace_bvh<false, TEX>(sc, o, d, 0.0f, 1e20f, kInvalid, kInvalid, hit, tc.stack, tc.cnt)
+                                     : trace_exhaustive<false, TEX>(sc, o, d, 0.0f, 1e20f, kInvalid, kInvalid, hit));
             vec3 c = mk3(0, 0, 0);
             if (found) {
-                SurfacePoint si = surface_interaction(sc, hit.gid, mk2(hit.u, hit.v));
+                SurfacePoint si = surface_interaction_any<INST>(sc, hit.gid, mk2(hit.u, hit.v));
                 auto remapped = [&](vec3 v) { return remap ? v * 0.5f + mk3(0.5f, 0.5f, 0.5f) : v; };
                 if (aov == AOV_NG) {
                     c = remapped(si.ng);
@@ -97,9 +98,16 @@ hipError_t launch_aov(const PtParams& p, uint32_t spp, uint32_t aov, uint32_t re
         if (p.sampler) hipLaunchKernelGGL((k_aov<B, T, true>), dim3(blocks), dim3(256), lds, stream, q, spp, aov, remap); \
         else hipLaunchKernelGGL((k_aov<B, T, false>), dim3(blocks), dim3(256), lds, stream, q, spp, aov, remap);      \
     }
-    if (bvh) { if (tex) AKR_AOV(true, true) else AKR_AOV(true, false) }
+#define AKR_AOV_INST(T)                                                                                                          \
+    {                                                                                                                            \
+        if (p.sampler) hipLaunchKernelGGL((k_aov<true, T, true, true>), dim3(blocks), dim3(256), lds, stream, q, spp, aov, remap); \
+        else hipLaunchKernelGGL((k_aov<true, T, false, true>), dim3(blocks), dim3(256), lds, stream, q, spp, aov, remap);      \
+    }
+    if (p.sc.in2.on) { if (tex) AKR_AOV_INST(true) else AKR_AOV_INST(false) }  // meshes + instances (aov.rs:57-173 over the reference's two-level accel)
+    else if (bvh) { if (tex) AKR_AOV(true, true) else AKR_AOV(true, false) }
     else { if (tex) AKR_AOV(false, true) else AKR_AOV(false, false) }
 #undef AKR_AOV
+#undef AKR_AOV_INST
     return hipGetLastError();
 }
 

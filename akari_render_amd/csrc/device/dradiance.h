@@ -52,18 +52,21 @@ AKR_D vec3 draw_3d(const PtParams& p, S& s) {
 
 // run_pt_hybrid_shift_mapping with min_reconnect_depth = 1, no denoising features, no cached first hit.
 // SM = false compiles the shift mapping out (PathTracer::radiance = run_megakernel); S = the sampler type, read through draw_1d / draw_3d.
-template <bool BVH, bool TEX, bool SM, class S>
+// INST: the scene is kept as meshes + instances (two-level traversal + on-the-fly records, dinst_trav.h); BVH is true then.
+template <bool BVH, bool TEX, bool SM, bool INST, class S>
 AKR_D vec3 radiance_sm(const PtParams& p, TraceCtx& tc, vec3 ro, vec3 rd, S& smp, ShiftMapping& sm, ReconVertex& vx, vec3& base_out,
                        uint32_t& n_rays) {
     const DScene& sc = p.sc;
     auto closest = [&](vec3 o, vec3 d, uint32_t ex0, Hit& h) {
         n_rays++;
+        if (INST) return trace_inst<false, TEX>(sc, o, d, 0.0f, 1e20f, ex0, kInvalid, h, tc.stack, tc.cnt);
         return BVH ? trace_bvh<false, TEX>(sc, o, d, 0.0f, 1e20f, ex0, kInvalid, h, tc.stack, tc.cnt)
                    : trace_exhaustive<false, TEX>(sc, o, d, 0.0f, 1e20f, ex0, kInvalid, h);
     };
     auto occluded_ray = [&](vec3 o, vec3 d, float tmax, uint32_t ex0, uint32_t ex1) {
         Hit h;
         n_rays++;
+        if (INST) return trace_inst<true, TEX>(sc, o, d, 0.0f, tmax, ex0, ex1, h, tc.stack, tc.cnt);
         return BVH ? trace_bvh<true, TEX>(sc, o, d, 0.0f, tmax, ex0, ex1, h, tc.stack, tc.cnt)
                    : trace_exhaustive<true, TEX>(sc, o, d, 0.0f, tmax, ex0, ex1, h);
     };
@@ -92,7 +95,7 @@ AKR_D vec3 radiance_sm(const PtParams& p, TraceCtx& tc, vec3 ro, vec3 rd, S& smp
     for (;;) {
         Hit hit;
         if (!closest(ro, rd, ray_ex0, hit)) break;
-        SurfacePoint si = surface_interaction(sc, hit.gid, mk2(hit.u, hit.v));
+        SurfacePoint si = surface_interaction_any<INST>(sc, hit.gid, mk2(hit.u, hit.v));
         DMaterial mat;
         material_of(si, mat);
         const vec3 wo = -rd;
@@ -128,7 +131,7 @@ AKR_D vec3 radiance_sm(const PtParams& p, TraceCtx& tc, vec3 ro, vec3 rd, S& smp
         const vec3 u_direct = draw_3d(p, smp);
         LightSample dl;
         dl.valid = false;
-        if (p.use_nee && (!p.indirect_only || depth > 1)) dl = sample_direct<TEX>(sc, si.p, si.ng, u_direct.x, mk2(u_direct.y, u_direct.z));
+        if (p.use_nee && (!p.indirect_only || depth > 1)) dl = sample_direct<TEX, INST>(sc, si.p, si.ng, u_direct.x, mk2(u_direct.y, u_direct.z));
         if (!dl.valid) {  // DirectLighting::invalid, pt.rs:67-77
             dl.li = mk3(0, 0, 0); dl.wi = mk3(0, 0, 0); dl.pdf = 0.0f;
         }
@@ -157,7 +160,7 @@ AKR_D vec3 radiance_sm(const PtParams& p, TraceCtx& tc, vec3 ro, vec3 rd, S& smp
                 break;
             }
             if (vx.depth == depth) {
-                const SurfacePoint rsi = surface_interaction(sc, vx.gid, vx.bary);
+                const SurfacePoint rsi = surface_interaction_any<INST>(sc, vx.gid, vx.bary);
                 const vec3 dvec = rsi.p - si.p;
                 const float dist = length(dvec);
                 const vec3 wi = normalize(dvec);

@@ -25,7 +25,7 @@ AKR_D void gpt_shifted(const GptParams& g, uint32_t W, uint32_t H, uint32_t x, u
 // Register allocation aims at 2 waves per SIMD (230 VGPRs, no spills). Measured on the 1080p cbox, Mpaths/s: 1 wave 425,
 // 2 waves 810, 4 waves (128 VGPRs, 330 spilled) 630. Running a lane's five paths through one flattened loop (a finished
 // path starts the next one while the neighbours still bounce) was slower than the nested loops: 716 at 2 waves.
-template <bool BVH, bool TEX>
+template <bool BVH, bool TEX, bool INST = false>
 __global__ __launch_bounds__(256, 2) void k_gpt_sample(const PtParams p_in, const GptParams g) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: traversal stacks; else: the staged scene tables
     PtParams staged = p_in;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void k_gpt_sample(const PtParams p_in, cons
                 sm.jacobian = 0.0f;
             }
             vec3 base;
-            const vec3 rad = radiance_sm<BVH, TEX, true>(p, tc, ro, rd, smp, sm, vx, base, n_rays);
+            const vec3 rad = radiance_sm<BVH, TEX, true, INST>(p, tc, ro, rd, smp, sm, vx, base, n_rays);
             vec3 l = rad, rec = mk3(0, 0, 0);
             float jac = 1.0f;
             bool ok = false;
@@ -246,7 +246,10 @@ hipError_t launch_gpt_sample(const PtParams& p, const GptParams& g, hipStream_t 
     const bool bvh = p.sc.bvh_nodes != nullptr, tex = p.sc.tex.nodes != nullptr;
     size_t lds;
     const PtParams q = with_tex_slots(p, bvh ? p.sc.bvh_stack_depth * 256 * 4 : p.stage_total, lds);
-    if (bvh) {
+    if (p.sc.in2.on) {  // meshes + instances (gpt.rs:381-640 traces through the same two-level accel the path tracer does)
+        if (tex) hipLaunchKernelGGL((k_gpt_sample<true, true, true>), dim3(blocks), dim3(256), lds, stream, q, g);
+        else hipLaunchKernelGGL((k_gpt_sample<true, false, true>), dim3(blocks), dim3(256), lds, stream, q, g);
+    } else if (bvh) {
         if (tex) hipLaunchKernelGGL((k_gpt_sample<true, true>), dim3(blocks), dim3(256), lds, stream, q, g);
         else hipLaunchKernelGGL((k_gpt_sample<true, false>), dim3(blocks), dim3(256), lds, stream, q, g);
     } else {

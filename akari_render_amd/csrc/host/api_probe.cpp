@@ -120,7 +120,6 @@ AKR_TEST_API int32_t akr_probe_bsdf(akr_context* ctx, const akr_material_desc* m
     });
 }
 static PtParams probe_params(akr_scene* s) {
-    if (s->cs.instanced.on) throw Unsupported("unsupported: the probes read the flattened records; this scene is kept as meshes + instances");
     PtParams p;
     std::memset(&p, 0, sizeof p);
     p.sc = s->dscene;

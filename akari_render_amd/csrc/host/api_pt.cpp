@@ -344,8 +344,6 @@ int32_t akr_api::pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_confi
             // (automatic: a kernel that is already cached is used whatever the render's size; a compile -- about a second -- only
             // when the render is long enough to win it back)
             const bool may_compile = t.specialise == 1 || samples >= kSpecAutoSamples;
-            if (scene->cs.instanced.on && !for_pt_kernel)
-                throw Unsupported("unsupported: a scene kept as meshes + instances (option instancing) renders with the pt integrator only");
             // The relaxed arithmetic tier (pt_kernels_relaxed.hip): the precompiled megakernels of flattened scenes. Everything else --
             // kept scenes, the wavefront schedule, aov / gpt / mcmc_opt -- stays on the contract whatever the option says.
             se->arith_relaxed = t.arith == 1 && for_pt_kernel && !scene->cs.instanced.on && !se->wavefront;

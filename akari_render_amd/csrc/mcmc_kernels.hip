@@ -109,7 +109,7 @@ struct McmcEval {
     float f;
 };
 // McmcOpt::evaluate, mcmc_opt.rs:253-305
-template <bool BVH, bool TEX>
+template <bool BVH, bool TEX, bool INST>
 AKR_D McmcEval mcmc_evaluate(const PtParams& p, TraceCtx& tc, McmcSampler& s, uint32_t& n_rays) {
     s.cur_dim = 0;  // sampler.start()
     const vec2 u = draw_2d(p, s);
@@ -122,7 +122,7 @@ AKR_D McmcEval mcmc_evaluate(const PtParams& p, TraceCtx& tc, McmcSampler& s, ui
     ReconVertex vx;
     vx.type = VT_INVALID;
     vec3 base;
-    vec3 l = radiance_sm<BVH, TEX, false>(p, tc, o, d, s, sm, vx, base, n_rays);
+    vec3 l = radiance_sm<BVH, TEX, false, INST>(p, tc, o, d, s, sm, vx, base, n_rays);
     l = l * 1.0f;  // * ray_w
     McmcEval e;
     e.px = (uint32_t)ix;
@@ -133,7 +133,7 @@ AKR_D McmcEval mcmc_evaluate(const PtParams& p, TraceCtx& tc, McmcSampler& s, ui
 }
 
 // bootstrap (mcmc_opt.rs:331-349): the contribution of n_bootstrap independent paths
-template <bool BVH, bool TEX>
+template <bool BVH, bool TEX, bool INST = false>
 __global__ __launch_bounds__(256, 2) void k_mcmc_bootstrap(const PtParams p_in, const McmcParams m) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: traversal stacks; else: the staged scene tables
     PtParams staged = p_in;
@@ -149,10 +149,10 @@ __global__ __launch_bounds__(256, 2) void k_mcmc_bootstrap(const PtParams p_in, 
     s.samples = nullptr; s.stride = 0; s.mcmc_dim = 0; s.mutate = false; s.is_large_step = false; s.is_image_mutation = false;
     s.last_large_iter = 0; s.cur_iter = 0; s.mp = &m;
     uint32_t n_rays = 0;
-    m.fs[i] = mcmc_evaluate<BVH, TEX>(p, tc, s, n_rays).f;
+    m.fs[i] = mcmc_evaluate<BVH, TEX, INST>(p, tc, s, n_rays).f;
 }
 // the chains' initial states (mcmc_opt.rs:356-386): chain i starts from bootstrap path resampled[i]
-template <bool BVH, bool TEX>
+template <bool BVH, bool TEX, bool INST = false>
 __global__ __launch_bounds__(256, 2) void k_mcmc_init(const PtParams p_in, const McmcParams m) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: traversal stacks; else: the staged scene tables
     PtParams staged = p_in;
@@ -170,12 +170,12 @@ __global__ __launch_bounds__(256, 2) void k_mcmc_init(const PtParams p_in, const
     s.last_large_iter = 0; s.cur_iter = 0; s.mp = &m;
     for (uint32_t j = 0; j < m.dim; j++) s.samples[(size_t)j * s.stride] = PssSample{pcg_next_1d(s.rng), 0.0f, 0u, 0u};
     uint32_t n_rays = 0;
-    McmcEval e = mcmc_evaluate<BVH, TEX>(p, tc, s, n_rays);
+    McmcEval e = mcmc_evaluate<BVH, TEX, INST>(p, tc, s, n_rays);
     m.cur_colors[i] = make_float4(e.l.x, e.l.y, e.l.z, 0.0f);
     m.states[i] = MarkovState{{e.px, e.py}, i, e.f, 0.0f, 0u, 0u, 0u, 0u, 0u};
 }
 // advance_chain + mutate_chain (mcmc_opt.rs:409-552)
-template <bool BVH, bool TEX>
+template <bool BVH, bool TEX, bool INST = false>
 __global__ __launch_bounds__(256, 2) void k_mcmc_advance(const PtParams p_in, const McmcParams m, uint32_t mutations_per_chain, float contribution) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // BVH: traversal stacks; else: the staged scene tables
     PtParams staged = p_in;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void k_mcmc_advance(const PtParams p_in, co
             s.is_image_mutation = pcg_next_1d(s.rng) < m.image_mutation_prob;
             s.last_large_iter = st.last_large_iter;
             s.cur_iter = st.cur_iter;
-            const McmcEval e = mcmc_evaluate<BVH, TEX>(p, tc, s, n_rays);
+            const McmcEval e = mcmc_evaluate<BVH, TEX, INST>(p, tc, s, n_rays);
             n_paths++;
             const float proposal_f = e.f;
             if (s.is_large_step && st.b_cnt < 1024u * 1024u) {
@@ -274,7 +274,10 @@ __global__ __launch_bounds__(256, 2) void k_mcmc_advance(const PtParams p_in, co
         const bool bvh = p_in.sc.bvh_nodes != nullptr, tex = p_in.sc.tex.nodes != nullptr;                        \
         size_t lds;                                                                                               \
         const PtParams p = with_tex_slots(p_in, bvh ? p_in.sc.bvh_stack_depth * 256 * 4 : p_in.stage_total, lds);           \
-        if (bvh) {                                                                                                \
+        if (p_in.sc.in2.on) { /* meshes + instances (mcmc_opt.rs:686-746 over the reference's two-level accel) */   \
+            if (tex) hipLaunchKernelGGL((KERNEL<true, true, true>), dim3(blocks), dim3(256), lds, stream, __VA_ARGS__);  \
+            else hipLaunchKernelGGL((KERNEL<true, false, true>), dim3(blocks), dim3(256), lds, stream, __VA_ARGS__);     \
+        } else if (bvh) {                                                                                         \
             if (tex) hipLaunchKernelGGL((KERNEL<true, true>), dim3(blocks), dim3(256), lds, stream, __VA_ARGS__);   \
             else hipLaunchKernelGGL((KERNEL<true, false>), dim3(blocks), dim3(256), lds, stream, __VA_ARGS__);      \
         } else {                                                                                                  \

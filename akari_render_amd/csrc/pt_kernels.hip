@@ -89,7 +89,7 @@ __global__ void k_probe_bsdf(const DMaterial* __restrict__ m, const float* __res
         o[7] = s.valid ? 1.0f : 0.0f;
     }
 }
-template <bool BVH>
+template <bool BVH, bool INST = false>
 __global__ __launch_bounds__(256) void k_probe_intersect(PtParams p, uint32_t n, const float* __restrict__ rays, uint32_t* __restrict__ out, float* __restrict__ bary) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     TraceCtx tc;
@@ -99,11 +99,12 @@ __global__ __launch_bounds__(256) void k_probe_intersect(PtParams p, uint32_t n,
     bool act = i < n;
     const float* r = rays + 8 * (size_t)(act ? i : 0);
     Hit h;
-    bool found = trace<BVH, false>(p, tc, mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]), r[6], r[7], kInvalid, kInvalid, h);
+    bool found = INST ? trace_inst<false, false>(p.sc, mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]), r[6], r[7], kInvalid, kInvalid, h, tc.stack, tc.cnt)
+                      : trace<BVH, false>(p, tc, mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]), r[6], r[7], kInvalid, kInvalid, h);
     if (!act) return;
     uint32_t inst = 0, prim = 0;
     if (found) {
-        inst = f2u(p.sc.shade[(size_t)h.gid * SHADE_ROWS + 6].z);
+        inst = INST ? inst_of_gid(p.sc, h.gid) : f2u(p.sc.shade[(size_t)h.gid * SHADE_ROWS + 6].z);
         prim = h.gid - p.sc.inst_tri_offset[inst];
     }
     out[3 * i + 0] = found ? 1u : 0u;
@@ -112,22 +113,20 @@ __global__ __launch_bounds__(256) void k_probe_intersect(PtParams p, uint32_t n,
     bary[2 * i + 0] = found ? h.u : 0.0f;
     bary[2 * i + 1] = found ? h.v : 0.0f;
 }
+template <bool INST>
 __global__ void k_probe_si(PtParams p, uint32_t n, const uint32_t* __restrict__ inst_prim, const float* __restrict__ bary, float* __restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t gid = p.sc.inst_tri_offset[inst_prim[2 * i]] + inst_prim[2 * i + 1];
-    SurfacePoint s = surface_interaction(p.sc, gid, mk2(bary[2 * i], bary[2 * i + 1]));
+    SurfacePoint s = surface_interaction_any<INST>(p.sc, gid, mk2(bary[2 * i], bary[2 * i + 1]));
     float* o = out + 19 * (size_t)i;
     o[0] = s.p.x; o[1] = s.p.y; o[2] = s.p.z;
     o[3] = s.ng.x; o[4] = s.ng.y; o[5] = s.ng.z;
     o[6] = s.frame.n.x; o[7] = s.frame.n.y; o[8] = s.frame.n.z;
     o[9] = s.frame.t.x; o[10] = s.frame.t.y; o[11] = s.frame.t.z;
     o[12] = s.frame.s.x; o[13] = s.frame.s.y; o[14] = s.frame.s.z;
-    const float4* r = p.sc.shade + (size_t)gid * SHADE_ROWS;
-    vec2 b = mk2(bary[2 * i], bary[2 * i + 1]);
-    float w = 1.0f - b.x - b.y;
-    o[15] = (r[0].w * w + r[2].w * b.x) + r[4].w * b.y;  // uv = interp(uv0, uv1, uv2)
-    o[16] = (r[1].w * w + r[3].w * b.x) + r[5].w * b.y;
+    o[15] = s.uv.x;  // uv = interp(uv0, uv1, uv2)
+    o[16] = s.uv.y;
     o[17] = s.prim_area;
     o[18] = (float)s.material;
 }
@@ -178,14 +177,17 @@ hipError_t launch_probe_bsdf(const DMaterial* m, const float* table, int mode, c
     return hipGetLastError();
 }
 hipError_t launch_probe_intersect(const PtParams& p, uint32_t n, const float* rays, uint32_t* out, float* bary, hipStream_t stream) {
-    if (p.sc.bvh_nodes != nullptr)
+    if (p.sc.in2.on)
+        hipLaunchKernelGGL((k_probe_intersect<true, true>), dim3((n + 255) / 256), dim3(256), p.sc.bvh_stack_depth * 256 * 4, stream, p, n, rays, out, bary);
+    else if (p.sc.bvh_nodes != nullptr)
         hipLaunchKernelGGL(k_probe_intersect<true>, dim3((n + 255) / 256), dim3(256), p.sc.bvh_stack_depth * 256 * 4, stream, p, n, rays, out, bary);
     else
         hipLaunchKernelGGL(k_probe_intersect<false>, dim3((n + 255) / 256), dim3(256), 0, stream, p, n, rays, out, bary);
     return hipGetLastError();
 }
 hipError_t launch_probe_si(const PtParams& p, uint32_t n, const uint32_t* inst_prim, const float* bary, float* out, hipStream_t stream) {
-    hipLaunchKernelGGL(k_probe_si, dim3((n + 255) / 256), dim3(256), 0, stream, p, n, inst_prim, bary, out);
+    if (p.sc.in2.on) hipLaunchKernelGGL(k_probe_si<true>, dim3((n + 255) / 256), dim3(256), 0, stream, p, n, inst_prim, bary, out);
+    else hipLaunchKernelGGL(k_probe_si<false>, dim3((n + 255) / 256), dim3(256), 0, stream, p, n, inst_prim, bary, out);
     return hipGetLastError();
 }
 

@@ -91,22 +91,82 @@ def test_tile_shards_of_a_kept_scene_add_up(ctx, root):
     assert n_bit_diff(acc, whole) == 0
 
 
-def test_other_integrators_and_probes_refuse_a_kept_scene(ctx, root):
+def _kept_scene_data(root, textured, w=40, h=32):
+    sd = instanced_scene(width=w, height=h, n_inst=9, n=6, emissive_instances=2, textured=textured, alpha=textured)
+    sd.ggx_table = _table(root)
+    return sd
+
+
+@pytest.mark.parametrize("textured", [False, True], ids=["constant", "textured"])
+def test_aov_on_a_kept_scene(ctx, root, textured):
+    """aov.rs:57-173 traces the reference's two-level accel like every integrator; round 5 refused kept scenes here."""
+    from tests.test_gpu_aov import both
+    sd = _kept_scene_data(root, textured)
+    with capi.options(instancing=1):
+        assert capi.Scene(ctx, sd).info().uses_bvh == 2
+        for aov in range(6):
+            cfg = abi.AovConfig.default()
+            cfg.spp, cfg.aov, cfg.remap = 3, aov, aov % 2
+            both(ctx, sd, cfg)  # kept scene against the oracle, bit for bit
+
+
+@pytest.mark.parametrize("recon", range(3), ids=abi.GPT_RECON_NAMES)
+def test_gpt_on_a_kept_scene(ctx, root, recon):
+    """gpt.rs:381-640 (base path + four shifted paths, reconnection vertices) over meshes + instances."""
+    from tests.test_gpt import both, gpt_config
+    sd = _kept_scene_data(root, textured=(recon == 1))
+    with capi.options(instancing=1):
+        assert capi.Scene(ctx, sd).info().uses_bvh == 2
+        kept = both(ctx, sd, gpt_config(spp=4, max_depth=6, rr_depth=2, reconstruction=recon, reconstruction_iter=5))
+    with capi.options(instancing=0):
+        flat = both(ctx, sd, gpt_config(spp=4, max_depth=6, rr_depth=2, reconstruction=recon, reconstruction_iter=5))
+    assert n_bit_diff(kept, flat) == 0
+
+
+@pytest.mark.parametrize("textured", [False, True], ids=["constant", "textured"])
+def test_mcmc_opt_on_a_kept_scene(ctx, root, textured):
+    """mcmc_opt.rs:686-746 over meshes + instances: chain states, normalisation and the direct pass identical to the oracle's."""
+    from tests.test_mcmc import both, mcmc_config
+    sd = _kept_scene_data(root, textured, 36, 28)
+    with capi.options(instancing=1):
+        assert capi.Scene(ctx, sd).info().uses_bvh == 2
+        both(ctx, sd, mcmc_config())
+
+
+def test_probes_on_a_kept_scene(ctx, root):
+    """Closest hits and surface interactions of random rays: kept scene against the oracle's exhaustive loop."""
+    rng = np.random.default_rng(4)
+    sd = _kept_scene_data(root, False)
+    with capi.options(instancing=1):
+        scene = capi.Scene(ctx, sd)
+    assert scene.info().uses_bvh == 2
+    osc = pyoracle.OracleScene(sd)
+    n = 3000
+    o = rng.uniform([-6, 0.1, -6], [6, 6, 6], size=(n, 3))
+    t = rng.uniform([-5, 0, -5], [5, 3, 5], size=(n, 3))
+    rays = np.zeros((n, 8), dtype=np.float32)
+    rays[:, :3], rays[:, 3:6], rays[:, 7] = o, t - o, 1e30
+    hit, bary = capi.probe_intersect(ctx, scene, rays)
+    ip, bb = [], []
+    for i in range(n):
+        h, inst, prim, b = osc.intersect(rays[i, :3], rays[i, 3:6], float(rays[i, 6]), float(rays[i, 7]))
+        assert bool(hit[i, 0]) == h, i
+        if h:
+            assert (int(hit[i, 1]), int(hit[i, 2])) == (inst, prim), i
+            assert np.array_equal(bary[i].view(np.uint32), b.view(np.uint32)), i
+            ip.append((inst, prim)); bb.append(b)
+    assert len(ip) > 500
+    ip, bb = np.array(ip, dtype=np.uint32), np.array(bb, dtype=np.float32)
+    si = capi.probe_surface_interaction(ctx, scene, ip, bb)
+    for k in range(0, len(ip), 5):
+        ref = osc.surface_interaction(int(ip[k, 0]), int(ip[k, 1]), float(bb[k, 0]), float(bb[k, 1]))
+        assert np.array_equal(si[k].view(np.uint32), ref.view(np.uint32)), (k, si[k], ref)
+
+
+def test_the_wavefront_option_is_ignored_on_a_kept_scene(ctx, root):
     sd = instanced_scene(width=16, height=16, n_inst=4)
     with capi.options(instancing=1):
         scene = capi.Scene(ctx, sd)
-    film = capi.Film(ctx, 16, 16)
-    rays = np.zeros((4, 8), dtype=np.float32)
-    rays[:, 5] = -1.0
-    rays[:, 7] = 1e30
-    gcfg = abi.GptConfig.default() if hasattr(abi.GptConfig, "default") else None
-    calls = [lambda: capi.aov_render(ctx, scene, abi.AovConfig.default(), film), lambda: capi.probe_intersect(ctx, scene, rays)]
-    if gcfg is not None:
-        calls.append(lambda: capi.gpt_render(ctx, scene, gcfg, film))
-    for call in calls:
-        with pytest.raises(capi.AkariError) as ei:
-            call()
-        assert ei.value.code == capi.ERR_UNSUPPORTED, str(ei.value)
     with capi.options(wavefront=1):  # ignored: the megakernel renders
         f2 = capi.Film(ctx, 16, 16)
         st = capi.pt_render(ctx, scene, make_config(spp=2, spp_per_pass=2), f2)
