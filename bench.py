@@ -149,9 +149,9 @@ def measured_counters(key):
     profiles/r4_fetch_size_calibration.json), VALU busy share, lane utilisation. The summary
     carries the hash of the library sources it was measured on; if that is not the hash of the sources in this tree the
     block is dropped and the line says so. Returns (summary or None, note or None)."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_pmc_{key}.json") for r in (5, 4, 3)) if os.path.exists(q)), os.path.join(ROOT, "profiles", f"r4_pmc_{key}.json"))
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_pmc_{key}.json") for r in (6, 5, 4, 3)) if os.path.exists(q)), os.path.join(ROOT, "profiles", f"r6_pmc_{key}.json"))
     if not os.path.exists(path):
-        return None, f"no PMC summary profiles/r4_pmc_{key}.json"
+        return None, f"no PMC summary profiles/r6_pmc_{key}.json (tools/pmc_bench.sh {key})"
     try:
         m = json.load(open(path))
     except Exception as ex:  # noqa: BLE001
@@ -469,10 +469,10 @@ def reference_default_leg(ctx):
             "value_kernels_only": st["n_samples"] / (st["kernel_ms"] * 1e-3) / 1e6, "wall_s": wall, "kernel_ms": st["kernel_ms"], "launches": st["n_launches"],
             "resolution": [int(info.width), int(info.height)], "spp": int(st["n_samples"] // (int(info.width) * int(info.height))), "sampler": "pmj02bn",
             "film_written": bool(wrote), "workload": "scenes/cbox/scene.json + scenes/cbox/pt.json (reference files, unchanged), output stage included",
-            "roofline": roofline_block("reference_default", dd)}
+            "roofline": roofline_block("reference_default", dd), "total_samples": st["n_samples"]}
 
 
-def textured_room_leg(ctx):
+def textured_room_leg(ctx, only=None):
     """The textured room of tests/helpers.py at 1080p with 2 x 64 MB images (tools/textured_bench.py's workload): the interpreter
     kernels against the per-scene kernel (hiprtc, option specialise), exhaustive (n_floor 1) and BVH (n_floor 8) intersectors;
     4 x 64 spp timed after a 64-spp warm-up. Films of the two settings are compared bit for bit."""
@@ -485,12 +485,16 @@ def textured_room_leg(ctx):
     bigf = rng.random((2048, 2048, 4)).astype(np.float32); bigf[:, :, 2] = 0.5 + 0.5 * bigf[:, :, 2]; bigf[:, :, 3] = 1.0
     table = np.fromfile(os.path.join(ROOT, "tests", "golden", "ggx_dielectric_s.f32"), dtype=np.float32)
     for nf, label in ((1, "exhaustive"), (8, "bvh")):
+        if only and not only.startswith(label):
+            continue
         sd = textured_room(W, H, n_floor=nf)
         sd.images[0] = abi.ImageData(big8, abi.TEX_FILTER_LINEAR, abi.TEX_REPEAT)
         sd.images[1] = abi.ImageData(bigf, abi.TEX_FILTER_LINEAR, abi.TEX_MIRROR)
         sd.ggx_table = table
         films = {}
         for mode, opt in (("interpreter", 0), ("per_scene", 1)):
+            if only and only != f"{label}_{mode}":
+                continue
             with capi.options(specialise=opt):
                 scene = capi.Scene(ctx, sd)
                 film = capi.Film(ctx, W, H)
@@ -505,14 +509,18 @@ def textured_room_leg(ctx):
             dt = time.perf_counter() - t0
             s1 = se.end()
             films[mode] = film.read()
+            d = {k: s1[k] - s0[k] for k in ("n_samples", "n_closest", "n_shadow", "n_shaded", "n_node_visits", "n_tri_tests", "n_launches", "kernel_ms")}
+            rl = roofline_block(f"textured_{label}_{mode}", d)
             out[f"{label}_{mode}"] = {"value": (s1["n_samples"] - s0["n_samples"]) / dt / 1e6, "unit": "Msamples/s",
-                                      "kernel": {k: ki[k] for k in ("specialised", "cache_hit", "min_waves", "vgprs", "scratch_bytes", "compile_ms", "load_ms", "status")}}
+                                      "kernel": {k: ki[k] for k in ("specialised", "cache_hit", "min_waves", "vgprs", "scratch_bytes", "compile_ms", "load_ms", "status")},
+                                      "roofline": {k: rl.get(k) for k in _LEG_ROOFLINE_KEYS if k in rl}, "total_samples": s1["n_samples"]}
             del se, film, scene
-        out[f"{label}_films_identical"] = bool(np.array_equal(films["interpreter"].view(np.uint32), films["per_scene"].view(np.uint32)))
+        if len(films) == 2:
+            out[f"{label}_films_identical"] = bool(np.array_equal(films["interpreter"].view(np.uint32), films["per_scene"].view(np.uint32)))
     return out
 
 
-def instanced_forest_leg(ctx):
+def instanced_forest_leg(ctx, only=None):
     """procedural.instanced_forest(1000, 100_000) at 1080p -- 99.86 M instance-triangles, kept as meshes + instances (two-level
     acceleration structure; flattened it would take 21 GB): 2 x 8 spp, the second launch timed; the same forest at
     10 k triangles per mesh both ways, films compared bit for bit."""
@@ -520,9 +528,13 @@ def instanced_forest_leg(ctx):
 
     out = {}
     for tris, modes in ((100_000, ("kept",)), (10_000, ("kept", "flattened"))):
+        if only and not only.startswith(f"{tris // 1000}k_"):
+            continue
         sd = procedural.instanced_forest(1000, tris, width=W, height=H)
         films = {}
         for mode in modes:
+            if only and only != f"{tris // 1000}k_{mode}":
+                continue
             with capi.options(instancing=1 if mode == "kept" else 0):
                 t0 = time.perf_counter()
                 scene = capi.Scene(ctx, sd)
@@ -541,19 +553,21 @@ def instanced_forest_leg(ctx):
             d = {k: s1[k] - s0[k] for k in ("n_samples", "n_closest", "n_shadow", "n_shaded", "n_node_visits", "n_tri_tests", "n_launches", "kernel_ms")}
             rays = d["n_closest"] + d["n_shadow"]
             films[mode] = film.read()
-            rl = roofline_block("forest", d)  # the same byte model (8d) over the same counters: 64 B per node visit, 48 B per candidate
+            rl = roofline_block(f"forest_{tris // 1000}k_{mode}", d)  # the same byte model (8d) over the same counters: 64 B per node visit, 48 B per candidate
             rl["kernel"] = "k_pt_pass_inst" if mode == "kept" else "k_pt_pass"
             out[f"{tris // 1000}k_{mode}"] = {"value": d["n_samples"] / dt / 1e6, "unit": "Msamples/s", "n_triangles": int(info.n_triangles), "uses_bvh": int(info.uses_bvh),
                                              "device_MB": info.device_bytes / 1e6, "compile_upload_s": t_load, "rays_per_s_G": rays / dt / 1e9,
                                              "node_visits_per_ray": d["n_node_visits"] / rays, "candidates_per_ray": d["n_tri_tests"] / rays,
-                                             "roofline": {k: rl[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_measured", "traffic", "kernel", "avg_launch_ms",
-                                                                             "algorithmic_bytes_per_sample")}}
+                                             "roofline": {k: rl.get(k) for k in _LEG_ROOFLINE_KEYS if k in rl}, "total_samples": s1["n_samples"]}
             del se, film, scene
         if len(films) == 2:
             out[f"{tris // 1000}k_films_identical"] = bool(np.array_equal(films["kept"].view(np.uint32), films["flattened"].view(np.uint32)))
     return out
 
 
+# what a secondary leg's roofline block carries: the model fraction, the measured one (PMC summary of the same sources: tools/pmc_bench.sh <leg>), and what bounds the kernel
+_LEG_ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "frac_measured", "traffic", "kernel", "avg_launch_ms", "algorithmic_bytes_per_sample", "hbm_measured_gbs",
+                      "valu_busy", "valu_lane_utilisation", "wait_share", "l2_hit", "nodes_per_ray", "tris_per_ray", "csrc_hash", "measured_counters")
 _NOT_REPORTED = ("weak", "spp_done", "film_tensor", "arith_relaxed")
 
 
@@ -566,6 +580,9 @@ def main():
     ap.add_argument("--also", default=None, help="comma list of further configs measured once each after the timed one, reported under "
                                                    "extra_configs (default at N = 1 with --config c2: c3,c4; 'none' to skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--leg", default=None, help="run ONE secondary leg alone and print its JSON (what tools/pmc_bench.sh profiles): reference_default, "
+                                                "forest_100k_kept, forest_10k_kept, forest_10k_flattened, textured_exhaustive_interpreter, textured_exhaustive_per_scene, "
+                                                "textured_bvh_interpreter, textured_bvh_per_scene")
     ap.add_argument("--full-graph", action="store_true", help="same as --config c3")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong (default) = the ONE frame's 32x32 pixel tiles round-robin over the GPUs, identical image for "
@@ -593,6 +610,20 @@ def main():
     import torch
 
     from akari_render_amd import capi, distributed
+
+    if args.leg:  # one secondary leg alone (for the profiler): no headline, no other legs
+        ctx = capi.Context(0)
+        name = args.leg
+        if name == "reference_default":
+            leg = reference_default_leg(ctx)
+        elif name.startswith("forest_"):
+            leg = instanced_forest_leg(ctx, only=name[len("forest_"):])[name[len("forest_"):]]
+        elif name.startswith("textured_"):
+            leg = textured_room_leg(ctx, only=name[len("textured_"):])[name[len("textured_"):]]
+        else:
+            ap.error("unknown --leg " + name)
+        print(json.dumps({"leg": name, **leg}), flush=True)
+        return
 
     rank, world, local_rank = distributed.env_rank_world()
     if args.gpus > 1 or world > 1:

@@ -26,7 +26,7 @@ def test_pmc_summary_is_quoted_only_for_the_sources_it_was_measured_on(tmp_path,
     os.makedirs(tmp_path / "akari_render_amd" / "csrc" / "device")
     src = tmp_path / "akari_render_amd" / "csrc" / "device" / "k.h"
     src.write_text("// kernel v1\n")
-    assert bench.measured_counters("c2") == (None, "no PMC summary profiles/r4_pmc_c2.json")
+    assert bench.measured_counters("c2") == (None, "no PMC summary profiles/r6_pmc_c2.json (tools/pmc_bench.sh c2)")
     h1 = bench.csrc_hash()
     json.dump({"csrc_hash": h1, "hbm_bytes_per_sample": 10.0, "valu_busy": 0.5}, open(tmp_path / "profiles" / "r4_pmc_c2.json", "w"))
     m, note = bench.measured_counters("c2")

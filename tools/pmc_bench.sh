@@ -1,14 +1,17 @@
 #!/bin/bash
-# PMC passes over one bench.py configuration (one --pmc set per rocprofv3 run, kernel-trace only), summarised into the JSON
-# that bench.py's roofline block reads: profiles/r4_pmc_<config>.json (copy gpurun_out/r4_pmc_bench_<cfg>/summary.json there). The summary
+# PMC passes over one bench.py configuration or secondary leg (one --pmc set per rocprofv3 run, kernel-trace only), summarised into the
+# JSON that bench.py's roofline blocks read: profiles/r6_pmc_<name>.json (copy gpurun_out/pmc_bench_<name>/summary.json there). The summary
 # carries the hash of the library sources (bench.csrc_hash): bench.py quotes it only for the kernels it was measured on.
-# usage: tools/pmc_bench.sh c2|c3|c4
+# usage: tools/pmc_bench.sh c2|c3|c4|reference_default|forest_100k_kept|forest_10k_kept|forest_10k_flattened|textured_{exhaustive,bvh}_{interpreter,per_scene}
 set -u
 CFG=${1:-c2}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/r4_pmc_bench_$CFG
+OUT=gpurun_out/pmc_bench_$CFG
 rm -rf $OUT; mkdir -p $OUT
-ARGS="--config $CFG --steps 1 --warmup 0 --also none --no-cpu-baseline"
+case $CFG in
+  c2|c3|c4) ARGS="--config $CFG --steps 1 --warmup 0 --also none --no-cpu-baseline" ;;
+  *) ARGS="--leg $CFG" ;;
+esac
 i=0
 for SET in \
   "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
@@ -32,19 +35,20 @@ kernel = None
 for f in sorted(glob.glob(out + "/**/*counter_collection.csv", recursive=True)):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0]
-        if "k_pt_pass" not in k: continue
+        if "k_pt_pass" not in k and "akr_pt_pass_spec" not in k: continue  # (k_pt_pass, k_pt_pass_inst, and a per-scene kernel's wrapper)
         kernel = k
         res[row["Counter_Name"]] += float(row["Counter_Value"]); disp[row["Counter_Name"]].add(row["Dispatch_Id"])
 bench = json.loads(open(out + "/set1.out").read().strip().splitlines()[-1])
 n_launch = max(len(v) for v in disp.values())
-samples = bench["counters"]["n_samples"]
+samples = bench["counters"]["n_samples"] if "counters" in bench else bench["total_samples"]  # (a leg: every launch of its session, warm-up included -- the counters sum over them all)
 c = dict(res)
 xcd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0   # summed over the 8 XCDs
 # FETCH_SIZE (KiB) tallies every L2 miss at 64 B. Calibrated on known byte counts (profiles/r4_fetch_size_calibration.json,
 # tools/gather_calib.sh): a coalesced stream reads 2.000 x FETCH_SIZE (the guide's gfx950 correction) -- the cbox launches' traffic is
 # sampler states and film, streamed; a random 64-byte record read with four 16-byte loads (the BVH traversal's node / triangle
 # fetch, what C4's traffic is made of) reads 1.0008 x FETCH_SIZE.
-fetch_factor = 1.0 if cfg == "c4" else 2.0
+gathers = cfg == "c4" or cfg.startswith("forest") or cfg.startswith("textured")  # traffic made of random 64-byte records / texel gathers
+fetch_factor = 1.0 if gathers else 2.0
 hbm = (fetch_factor * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
 valu_busy = c["SQ_INSTS_VALU"] * 2.0 / (1024.0 * xcd_cycles)
 lane = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
@@ -58,10 +62,10 @@ s = {"config": cfg, "kernel": kernel, "csrc_hash": _bench.csrc_hash(), "bench_ar
      "counters": c,
      "fetch_size_factor": fetch_factor,
      "source": "tools/pmc_bench.sh " + cfg + ": rocprofv3 --kernel-trace --pmc <one set per pass> -- python bench.py $ARGS; hbm = (factor x FETCH_SIZE + WRITE_SIZE) x 1024, factor = bytes read / FETCH_SIZE calibrated per access pattern on a known byte count (profiles/r4_fetch_size_calibration.json: 2.000 coalesced stream, 1.0008 random 64-byte records); valu_busy = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)"}
-if cfg == "c4":
+if gathers:
     del s["hbm_bytes_per_launch"]  # traffic scales with the rays traced: bench.py multiplies bytes per sample by its own launch size
-s["binding_limiter"] = ("VALU issue (the 36-triangle walk and the shading run from LDS / registers; HBM sees only sampler states + film)" if cfg != "c4"
-                        else "the memory system's rate for random 64-byte records (tools/micro/gather_bw.hip: 25.8 G records/s from HBM, 56 G/s from the Infinity Cache, whatever "
+s["binding_limiter"] = ("VALU issue (the 36-triangle walk and the shading run from LDS / registers; HBM sees only sampler states + film)" if not gathers
+                        else ("lane utilisation of the two-level traversal (divergent stages, on-the-fly records)" if cfg.startswith("forest") and "kept" in cfg else "texel / record gathers and the divergent graph code") if cfg != "c4" else "the memory system's rate for random 64-byte records (tools/micro/gather_bw.hip: 25.8 G records/s from HBM, 56 G/s from the Infinity Cache, whatever "
                              "the occupancy or the loads in flight per lane): this kernel misses the L2 " + str(round(c["TCC_MISS_sum"] / samples, 1)) + " times per sample")
 s["fabric_read_bytes_per_sample"] = fetch_factor * c["FETCH_SIZE"] * 1024.0 / samples
 s["l2_misses_per_sample"] = c["TCC_MISS_sum"] / samples
