@@ -271,11 +271,11 @@ class Scene:
         check(lib().akr_scene_spec_source(self.h, buf, n.value + 1, C.byref(n)))
         return buf.value.decode()
 
-    def spec_compile(self, bvh: bool = False, pmj: bool = False, stage: bool = True, defer: bool = False, min_waves: int = 3, arch: str = "gfx950") -> int:
+    def spec_compile(self, bvh: bool = False, pmj: bool = False, stage: bool = True, defer: bool = False, min_waves: int = 3, arch: str = "gfx950", inst: bool = False) -> int:
         """akr_host_spec_compile: hiprtc-compiles the scene's per-scene kernel (no device needed); returns the code object's size."""
         nbytes = C.c_uint64()
         log = C.create_string_buffer(4096)
-        flags = (1 if bvh else 0) | (2 if pmj else 0) | (4 if stage else 0) | (8 if defer else 0)
+        flags = (1 if bvh else 0) | (2 if pmj else 0) | (4 if stage else 0) | (8 if defer else 0) | (16 if inst else 0)
         check(lib().akr_host_spec_compile(self.h, flags, min_waves, arch.encode(), C.byref(nbytes), log, 4096))
         return nbytes.value
 

@@ -349,7 +349,6 @@ int32_t akr_api::pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_confi
             se->arith_relaxed = t.arith == 1 && for_pt_kernel && !scene->cs.instanced.on && !se->wavefront;
             if (!for_pt_kernel) se->spec_status = "not a pt session";
             else if (se->arith_relaxed) se->spec_status = "relaxed arithmetic tier: precompiled kernels";
-            else if (scene->cs.instanced.on) se->spec_status = "scene kept as meshes + instances";
             else if (!scene->cs.has_textures) se->spec_status = "the scene has no texture-fed material";
             else if (t.specialise == 0) se->spec_status = "option specialise = 0";
             else if (cfg->force_diffuse) se->spec_status = "force_diffuse kernels evaluate no surface graphs";
@@ -366,7 +365,8 @@ int32_t akr_api::pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_confi
                 se->spec_active = true;
                 fill_params(se.get(), 1, cfg->spp_per_pass);  // which instantiation the session's launches use
                 SpecRequest rq;
-                rq.bvh = !scene->cs.bvh_nodes.empty();
+                rq.bvh = !scene->cs.bvh_nodes.empty() || scene->cs.instanced.on;
+                rq.inst = scene->cs.instanced.on;
                 rq.pmj = se->params.sampler != 0;
                 rq.stage = se->params.stage_total != 0;
                 rq.defer = se->params.defer_metal != 0;

@@ -353,7 +353,7 @@ AKR_API int32_t akr_host_spec_compile(akr_scene* scene, uint32_t flags, uint32_t
         }
         if (header.empty()) throw Unsupported("unsupported: the scene has no per-scene code (no texture-fed material, or too many shader kinds)");
         SpecRequest rq;
-        rq.bvh = flags & 1u; rq.pmj = flags & 2u; rq.stage = flags & 4u; rq.defer = flags & 8u;
+        rq.bvh = flags & 1u; rq.pmj = flags & 2u; rq.stage = flags & 4u; rq.defer = flags & 8u; rq.inst = flags & 16u;
         rq.min_waves = (int)min_waves;
         std::vector<char> code;
         std::string text;
@@ -368,7 +368,7 @@ AKR_API int32_t akr_host_spec_compile_text(const char* spec_header, uint32_t fla
     if (!spec_header || !arch || !out_path) return fail(AKR_ERR_INVALID_ARGUMENT, "akr_host_spec_compile_text: NULL argument");
     return guarded([&] {
         SpecRequest rq;
-        rq.bvh = flags & 1u; rq.pmj = flags & 2u; rq.stage = flags & 4u; rq.defer = flags & 8u;
+        rq.bvh = flags & 1u; rq.pmj = flags & 2u; rq.stage = flags & 4u; rq.defer = flags & 8u; rq.inst = flags & 16u;
         rq.min_waves = (int)min_waves;
         std::vector<char> code;
         std::string log;

@@ -267,8 +267,9 @@ Rtc& rtc() {
 std::string wrapper_source(const SpecRequest& rq) {
     return fmt("// per-scene instantiation of k_pt_pass (host/specialise.cpp)\n#define AKR_SPEC_GRAPHS 1\n#include \"device/pt_pass.h\"\n"
                "extern \"C\" __global__ __launch_bounds__(256, %d) void akr_pt_pass_spec(const akr::PtParams p) {\n"
-               "    akr::pt_pass_body<%s, false, true, %s, %s, %s, akr::kSpecAbsent>(p);\n}\n",
-               rq.min_waves, rq.bvh ? "true" : "false", rq.pmj ? "true" : "false", rq.stage ? "true" : "false", rq.defer ? "true" : "false");
+               "    akr::pt_pass_body<%s, false, true, %s, %s, %s, akr::kSpecAbsent, %s>(p);\n}\n",
+               rq.min_waves, (rq.bvh || rq.inst) ? "true" : "false", rq.pmj ? "true" : "false", (rq.stage && !rq.inst) ? "true" : "false",
+               (rq.defer && !rq.inst) ? "true" : "false", rq.inst ? "true" : "false");
 }
 std::vector<std::string> compile_options(const std::string& arch) {
     std::vector<std::string> o;
@@ -324,6 +325,20 @@ std::string spec_cache_dir() {
 }
 
 namespace {
+// The disk cache is trusted code: a code object found there is loaded and run. So the directory must be ours alone -- created (with its
+// parents) mode 0700, and used only if it is a real directory (not a link) owned by this user that nobody else can write to. Otherwise
+// the disk cache is skipped (kernels are compiled per process). Matters where the fall-back /tmp/akari_hip-<uid> is in play: another local
+// user could have made that directory first and planted a file under a key that is computable from public inputs.
+bool cache_dir_usable(const std::string& dir, bool create) {
+    if (dir.empty()) return false;
+    if (create) {
+        for (size_t i = 1; i <= dir.size(); i++)
+            if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0700);  // (existing components: EEXIST)
+    }
+    struct stat st;
+    if (lstat(dir.c_str(), &st) != 0) return false;
+    return S_ISDIR(st.st_mode) && st.st_uid == getuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+}
 // <directory of this library>/akari-cli, or "" (dladdr on a symbol of the library)
 std::string helper_path() {
     Dl_info info;
@@ -342,7 +357,7 @@ bool compile_in_helper(const std::string& helper, const std::string& spec_header
         std::ofstream f(hdr, std::ios::binary);
         f.write(spec_header.data(), (std::streamsize)spec_header.size());
     }
-    const std::string flags = std::to_string((rq.bvh ? 1 : 0) | (rq.pmj ? 2 : 0) | (rq.stage ? 4 : 0) | (rq.defer ? 8 : 0)), waves = std::to_string(rq.min_waves);
+    const std::string flags = std::to_string((rq.bvh ? 1 : 0) | (rq.pmj ? 2 : 0) | (rq.stage ? 4 : 0) | (rq.defer ? 8 : 0) | (rq.inst ? 16 : 0)), waves = std::to_string(rq.min_waves);
     // posix_spawn, not fork + setup code: the host process has threads (HIP runtime, the application's own)
     std::vector<std::string> env_store;
     for (char** e = environ; e && *e; e++)
@@ -454,7 +469,7 @@ std::shared_ptr<SpecKernel> SpecCache::get(const std::string& spec_header, const
     const double t0 = now_ms();
     std::vector<char> code;
     const std::string dir = spec_cache_dir(), path = dir + "/akr_" + key + ".co";
-    {
+    if (cache_dir_usable(dir, false)) {
         std::ifstream f(path, std::ios::binary);
         if (f) {
             code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
@@ -474,10 +489,10 @@ std::shared_ptr<SpecKernel> SpecCache::get(const std::string& spec_header, const
         }
         k->compile_ms = now_ms() - c0;
         // keep it for the next process: temporary file + rename, so that a reader never sees half a code object
-        (void)mkdir(dir.c_str(), 0755);
         const std::string tmp = path + fmt(".%d.tmp", (int)getpid());
-        std::ofstream f(tmp, std::ios::binary);
-        if (f) {
+        std::ofstream f;
+        if (cache_dir_usable(dir, true)) f.open(tmp, std::ios::binary);
+        if (f.is_open()) {
             f.write(code.data(), (std::streamsize)code.size());
             f.close();
             if (!f || std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());

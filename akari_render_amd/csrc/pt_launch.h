@@ -51,7 +51,7 @@ PtParams pt_pass_layout(const PtParams& p, size_t& lds, uint32_t& blocks) {
 }
 hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream, hipFunction_t spec_fn) {
 #if !AKR_ARITH_RELAXED
-    if (p.sc.in2.on) return launch_pt_pass_inst(p, stream);  // meshes + instances: pt_inst_kernels.hip
+    if (p.sc.in2.on && !spec_fn) return launch_pt_pass_inst(p, stream);  // meshes + instances: pt_inst_kernels.hip (a per-scene kernel wraps the same body: below)
 #else
     if (p.sc.in2.on) return hipErrorInvalidValue;  // (the host never sends a kept scene to the relaxed tier: api_pt.cpp)
 #endif

@@ -163,6 +163,27 @@ def test_probes_on_a_kept_scene(ctx, root):
         assert np.array_equal(si[k].view(np.uint32), ref.view(np.uint32)), (k, si[k], ref)
 
 
+@pytest.mark.parametrize("sampler", [abi.SAMPLER_INDEPENDENT, abi.SAMPLER_SOBOL], ids=["independent", "sobol"])
+def test_per_scene_kernel_of_a_kept_scene(ctx, root, sampler):
+    """option specialise on a textured scene kept as meshes + instances: the hiprtc kernel renders the interpreter's film and the oracle's."""
+    sd = _kept_scene_data(root, True, 48, 40)
+    cfg = make_config(spp=8, spp_per_pass=4, max_depth=8, sampler_type=sampler, sampler_seed=3)
+    films = {}
+    for spec in (0, 1):
+        with capi.options(instancing=1, specialise=spec):
+            scene = capi.Scene(ctx, sd)
+            film = capi.Film(ctx, 48, 40)
+            se = capi.PtSession(ctx, scene, cfg, film)
+            se.passes(2, blocking=True)
+            ki = se.kernel_info()
+            se.end()
+        assert ki["specialised"] == spec, ki
+        films[spec] = film.read()
+    assert n_bit_diff(films[0], films[1]) == 0
+    o, _ = _oracle(sd, cfg)
+    assert n_bit_diff(films[1], o) == 0
+
+
 def test_the_wavefront_option_is_ignored_on_a_kept_scene(ctx, root):
     sd = instanced_scene(width=16, height=16, n_inst=4)
     with capi.options(instancing=1):

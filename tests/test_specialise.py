@@ -179,6 +179,15 @@ def test_kernel_compiles_for_gfx950_without_a_device():
     assert sc.spec_compile(bvh=True, pmj=True, stage=False, defer=False) > 20000
 
 
+def test_kernel_of_a_kept_scene_compiles():
+    """Round 6: scenes kept as meshes + instances get per-scene kernels too (pt_pass_body<.., INST> wrapped by the same generated text)."""
+    from tests.helpers import instanced_scene
+    with capi.options(instancing=1):
+        sc = capi.Scene(None, instanced_scene(textured=True, alpha=True))
+    assert sc.info().uses_bvh == 2 and sc.spec_source() != ""
+    assert sc.spec_compile(bvh=True, pmj=False, stage=False, defer=False, inst=True) > 20000
+
+
 def test_no_per_scene_code_without_textures(cbox_path):
     sc = capi.Scene(None, cbox_path, 32, 32)
     assert sc.spec_source() == ""

@@ -226,14 +226,80 @@ int main(int argc, char** argv) {
             lo[a] = std::min(lo[a], bounds[6ull * i + a]);
             hi[a] = std::max(hi[a], bounds[6ull * i + 3 + a]);
         }
+    // SIM_SPLIT=<f> (round 6): SPATIAL SPLITS as early split clipping (Ernst & Greiner 2007): the reference whose box has
+    // the largest surface area is cut at the middle of its box's longest axis -- the triangle's polygon clipped against the plane, a tight box
+    // per half -- until there are f x n references. A triangle then sits in several leaves (every copy is the same full test: the min-t /
+    // lowest-id rule gives the same hit; the copies cost fetches). The tree is built over the references' boxes.
+    std::vector<uint32_t> ref_tri(n);
+    for (uint32_t i = 0; i < n; i++) ref_tri[i] = i;
+    const double split_f = std::getenv("SIM_SPLIT") ? std::atof(std::getenv("SIM_SPLIT")) : 1.0;
+    if (split_f > 1.0) {
+        struct Ref { uint32_t tri; int nv; float v[9][3]; float lo[3], hi[3]; float area; };
+        auto finish = [](Ref& r) {
+            for (int a = 0; a < 3; a++) { r.lo[a] = 1e30f; r.hi[a] = -1e30f; }
+            for (int k = 0; k < r.nv; k++)
+                for (int a = 0; a < 3; a++) { r.lo[a] = std::min(r.lo[a], r.v[k][a]); r.hi[a] = std::max(r.hi[a], r.v[k][a]); }
+            const float dx = r.hi[0] - r.lo[0], dy = r.hi[1] - r.lo[1], dz = r.hi[2] - r.lo[2];
+            r.area = dx * dy + dy * dz + dz * dx;
+        };
+        std::vector<Ref> refs(n);
+        for (uint32_t i = 0; i < n; i++) {
+            refs[i].tri = i; refs[i].nv = 3;
+            for (int k = 0; k < 3; k++) for (int a = 0; a < 3; a++) refs[i].v[k][a] = src[9ull * i + 3 * k + a];
+            finish(refs[i]);
+        }
+        auto cmp = [&](uint32_t x, uint32_t y) { return refs[x].area < refs[y].area; };
+        std::vector<uint32_t> heap(n);
+        for (uint32_t i = 0; i < n; i++) heap[i] = i;
+        std::make_heap(heap.begin(), heap.end(), cmp);
+        const size_t target = (size_t)(split_f * n);
+        refs.reserve(target + 8);
+        while (refs.size() < target && !heap.empty()) {
+            std::pop_heap(heap.begin(), heap.end(), cmp);
+            const uint32_t ri = heap.back(); heap.pop_back();
+            Ref r = refs[ri];
+            int ax = 0;
+            for (int a = 1; a < 3; a++) if (r.hi[a] - r.lo[a] > r.hi[ax] - r.lo[ax]) ax = a;
+            const float mid = 0.5f * (r.lo[ax] + r.hi[ax]);
+            if (!(mid > r.lo[ax] && mid < r.hi[ax])) continue;
+            Ref L = r, R = r; L.nv = R.nv = 0;
+            for (int k = 0; k < r.nv; k++) {  // Sutherland-Hodgman against the plane, both sides at once
+                const float* p = r.v[k]; const float* q = r.v[(k + 1) % r.nv];
+                const bool pin = p[ax] <= mid, qin = q[ax] <= mid;
+                if (pin) { std::memcpy(L.v[L.nv++], p, 12); }
+                if (!pin || p[ax] == mid) { std::memcpy(R.v[R.nv++], p, 12); }
+                if (pin != qin) {
+                    const float t = (mid - p[ax]) / (q[ax] - p[ax]);
+                    float x[3];
+                    for (int a = 0; a < 3; a++) x[a] = p[a] + t * (q[a] - p[a]);
+                    x[ax] = mid;
+                    std::memcpy(L.v[L.nv++], x, 12); std::memcpy(R.v[R.nv++], x, 12);
+                }
+            }
+            if (L.nv < 3 || R.nv < 3 || L.nv > 8 || R.nv > 8) continue;
+            finish(L); finish(R);
+            refs[ri] = L;
+            refs.push_back(R);
+            heap.push_back(ri); std::push_heap(heap.begin(), heap.end(), cmp);
+            heap.push_back((uint32_t)refs.size() - 1); std::push_heap(heap.begin(), heap.end(), cmp);
+        }
+        bounds.resize(6ull * refs.size());
+        ref_tri.resize(refs.size());
+        for (size_t i = 0; i < refs.size(); i++) {
+            ref_tri[i] = refs[i].tri;
+            for (int a = 0; a < 3; a++) { bounds[6 * i + a] = refs[i].lo[a]; bounds[6 * i + 3 + a] = refs[i].hi[a]; }
+        }
+        std::fprintf(stderr, "spatial splits: %zu references for %u triangles (x%.3f)\n", refs.size(), n, (double)refs.size() / n);
+    }
+    const uint32_t n_refs = (uint32_t)ref_tri.size();
     const float diag = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
     Scene sc;
     std::vector<uint32_t> order;
     auto t0 = std::chrono::steady_clock::now();
-    akr::build_bvh8(bounds, n, 4e-6f * diag, kStride, false, order, sc.nodes, sc.depth);
+    akr::build_bvh8(bounds, n_refs, 4e-6f * diag, kStride, false, order, sc.nodes, sc.depth);
     const double build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    sc.tris.resize(9ull * n);
-    for (uint32_t k = 0; k < n; k++) std::memcpy(&sc.tris[9ull * k], &src[9ull * order[k]], 36);
+    sc.tris.resize(9ull * n_refs);
+    for (uint32_t k = 0; k < n_refs; k++) std::memcpy(&sc.tris[9ull * k], &src[9ull * ref_tri[order[k]]], 36);
     // camera and light of akari_render_amd/procedural.py (hall 30 x 12 x 15)
     const double L = 30, H = 12;
     const V3 eye{-L / 2 + 1.0, 1.7, 0.3}, fwd = norm(V3{1.0, 0.08, 0.05}), right = norm(cross(fwd, V3{0, 1, 0})), up = cross(right, fwd);
@@ -286,9 +352,9 @@ int main(int argc, char** argv) {
         for (int i = 0; i < 64; i++) { sum += pair_steps[g * 64 + i]; mx = std::max(mx, pair_steps[g * 64 + i]); }
         summax += mx;
     }
-    std::printf("{\"n_tris\": %u, \"node_slots\": %zu, \"depth\": %u, \"build_s\": %.2f, \"rays\": %llu, \"nodes_per_ray\": %.3f, \"tris_per_ray\": %.3f, "
+    std::printf("{\"references\": %u, \"n_tris\": %u, \"node_slots\": %zu, \"depth\": %u, \"build_s\": %.2f, \"rays\": %llu, \"nodes_per_ray\": %.3f, \"tris_per_ray\": %.3f, "
                 "\"closest\": {\"nodes\": %.3f, \"tris\": %.3f}, \"shadow\": {\"nodes\": %.3f, \"tris\": %.3f}, \"lane_utilisation_proxy\": %.3f}\n",
-                n, sc.nodes.size() / kStride, sc.depth, build_s, (unsigned long long)c.rays, (double)c.nodes / c.rays, (double)c.tris / c.rays,
+                n_refs, n, sc.nodes.size() / kStride, sc.depth, build_s, (unsigned long long)c.rays, (double)c.nodes / c.rays, (double)c.tris / c.rays,
                 (double)cc.nodes / cc.rays, (double)cc.tris / cc.rays, (double)cs.nodes / cs.rays, (double)cs.tris / cs.rays, sum / (64.0 * summax));
     return 0;
 }

@@ -14,6 +14,9 @@
 //   gather16   random 64-B-aligned record, ONE 16-B load (how much of a line does a 16-B miss fetch?)
 //   gather64x2 as gather64 with TWO independent records in flight per lane
 //   gather32   random 64-B-aligned record, TWO 16-B loads (the first 32 B)
+//   chain4_1k / chain4_2k / chain4_4k / chain4_64k   round 6: a random window of 1 / 2 / 4 / 64 KiB, then FOUR dependent
+//              64-byte records at random places inside it -- what a traversal would fetch if a subtree's nodes were laid out as a treelet
+//              aligned to such a window (does the rate of random records rise when consecutive dependent fetches share a DRAM page?)
 // Prints one JSON line: known bytes, time, GB/s, loads. Run it under `rocprofv3 --kernel-trace --pmc <set>` (tools/gather_calib.sh).
 // build: hipcc --offload-arch=gfx950 -O3 gather_bw.hip -o gather_bw
 #include <hip/hip_runtime.h>
@@ -63,6 +66,26 @@ __global__ __launch_bounds__(256) void k_gather_x2(const uint4* __restrict__ buf
     }
     if (acc == 0x12345678u) out[0] = acc;
 }
+// four dependent records inside one random window of WIN_RECORDS 64-byte records (aligned to the window's size)
+template <uint32_t WIN_RECORDS>
+__global__ __launch_bounds__(256) void k_chain4(const uint4* __restrict__ buf, uint64_t n_windows, uint32_t per_lane, uint32_t seed, uint32_t* out) {
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    uint32_t acc = 0, h = mix(gid * 0x9e3779b9u + seed);
+    for (uint32_t i = 0; i < per_lane; i += 4) {
+        h = mix(h + i);
+        const uint64_t win = ((uint64_t)h * n_windows) >> 32;
+        const uint4* base = buf + win * (uint64_t)WIN_RECORDS * 4;
+#pragma unroll 1
+        for (uint32_t k = 0; k < 4; k++) {
+            h = mix(h + k);
+            const uint4* p = base + (h % WIN_RECORDS) * 4;
+            const uint4 w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3];
+            acc ^= w0.x ^ w0.y ^ w0.z ^ w0.w ^ w1.x ^ w1.y ^ w1.z ^ w1.w ^ w2.x ^ w2.y ^ w2.z ^ w2.w ^ w3.x ^ w3.y ^ w3.z ^ w3.w;
+            h ^= acc & 1u;  // the next record's place depends on this one's data
+        }
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
 __global__ __launch_bounds__(256) void k_stream(const uint4* __restrict__ buf, uint64_t n16, uint32_t per_lane, uint32_t* out) {
     const uint64_t total = (uint64_t)gridDim.x * 256u;
     uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
@@ -96,11 +119,16 @@ int main(int argc, char** argv) {
     if (!strcmp(pat, "gather16")) loads = 1;
     if (!strcmp(pat, "gather32")) loads = 2;
     const bool stream = !strcmp(pat, "stream"), x2 = !strcmp(pat, "gather64x2");
+    const uint32_t chain_win = !strcmp(pat, "chain4_1k") ? 16u : !strcmp(pat, "chain4_2k") ? 32u : !strcmp(pat, "chain4_4k") ? 64u : !strcmp(pat, "chain4_64k") ? 1024u : 0u;
     if (stream) loads = 1;
     const uint64_t n_slots = n16 / stride16;
     if (stream && (uint64_t)blocks * 256u * per_lane > n16) { fprintf(stderr, "stream: buffer too small\n"); return 1; }
     auto launch = [&](uint32_t seed) {
-        if (stream) hipLaunchKernelGGL(k_stream, dim3(blocks), dim3(256), lds, 0, buf, n16, per_lane, out);
+        if (chain_win == 16u) hipLaunchKernelGGL((k_chain4<16>), dim3(blocks), dim3(256), lds, 0, buf, n16 / (4 * 16), per_lane, seed, out);
+        else if (chain_win == 32u) hipLaunchKernelGGL((k_chain4<32>), dim3(blocks), dim3(256), lds, 0, buf, n16 / (4 * 32), per_lane, seed, out);
+        else if (chain_win == 64u) hipLaunchKernelGGL((k_chain4<64>), dim3(blocks), dim3(256), lds, 0, buf, n16 / (4 * 64), per_lane, seed, out);
+        else if (chain_win == 1024u) hipLaunchKernelGGL((k_chain4<1024>), dim3(blocks), dim3(256), lds, 0, buf, n16 / (4 * 1024), per_lane, seed, out);
+        else if (stream) hipLaunchKernelGGL(k_stream, dim3(blocks), dim3(256), lds, 0, buf, n16, per_lane, out);
         else if (x2) hipLaunchKernelGGL(k_gather_x2, dim3(blocks), dim3(256), lds, 0, buf, n_slots, per_lane, seed, out);
         else if (loads == 8) hipLaunchKernelGGL((k_gather<8, 8>), dim3(blocks), dim3(256), lds, 0, buf, n_slots, per_lane, seed, out);
         else if (loads == 4) hipLaunchKernelGGL((k_gather<4, 4>), dim3(blocks), dim3(256), lds, 0, buf, n_slots, per_lane, seed, out);
@@ -119,7 +147,9 @@ int main(int argc, char** argv) {
     (void)hipEventElapsedTime(&ms, e0, e1);
     const double lanes = (double)blocks * 256.0;
     const double requested = lanes * per_lane * loads * 16.0;  // bytes the lanes asked for, per launch
-    printf("{\"pattern\": \"%s\", \"buffer_mib\": %llu, \"records_per_lane\": %u, \"lanes\": %.0f, \"loads_per_record\": %d, \"record_align\": %d, "
+    const double records = lanes * per_lane;
+    printf("{\"records_per_s_G\": %.2f, ", stream ? 0.0 : records / (ms * 1e-3) / 1e9);
+    printf("\"pattern\": \"%s\", \"buffer_mib\": %llu, \"records_per_lane\": %u, \"lanes\": %.0f, \"loads_per_record\": %d, \"record_align\": %d, "
            "\"requested_bytes_per_launch\": %.0f, \"launches\": 2, \"lds_bytes\": %zu, \"ms\": %.4f, \"requested_gbs\": %.1f}\n",
            pat, (unsigned long long)mib, per_lane, lanes, loads, stream ? 16 : stride16 * 16, requested, lds, ms, requested / (ms * 1e-3) / 1e9);
     return 0;
