@@ -44,15 +44,23 @@ struct TiffReader {
 };
 struct TiffField {
     uint16_t type = 0;
-    uint32_t count = 0;
+    uint64_t count = 0;
     size_t value_at = 0;  // where the values start (inside the entry or at the offset it holds)
 };
-size_t tiff_type_size(uint16_t t) { return t == 1 || t == 2 || t == 6 || t == 7 ? 1 : t == 3 || t == 8 ? 2 : t == 4 || t == 9 || t == 11 ? 4 : t == 5 || t == 10 || t == 12 ? 8 : 0; }
-uint32_t tiff_value(const TiffReader& r, const TiffField& f, uint32_t i) {
+size_t tiff_type_size(uint16_t t) {
+    return t == 1 || t == 2 || t == 6 || t == 7 ? 1 : t == 3 || t == 8 ? 2 : t == 4 || t == 9 || t == 11 || t == 13 ? 4 : t == 5 || t == 10 || t == 12 || (t >= 16 && t <= 18) ? 8 : 0;
+}
+uint64_t tiff_u64(const TiffReader& r, size_t o) {
+    const uint64_t a = r.u32(o), b = r.u32(o + 4);
+    return r.big ? (a << 32) | b : (b << 32) | a;
+}
+// BYTE / SHORT / LONG and BigTIFF's LONG8 / IFD8 (offsets and byte counts of files past 4 GiB; values that do not fit 64-bit size_t do not occur)
+uint64_t tiff_value(const TiffReader& r, const TiffField& f, uint64_t i) {
     if (i >= f.count) throw std::runtime_error("tiff: field index out of range");
     if (f.type == 1 || f.type == 7) { if (f.value_at + i >= r.n) throw std::runtime_error("tiff: truncated file"); return r.d[f.value_at + i]; }
     if (f.type == 3) return r.u16(f.value_at + 2 * (size_t)i);
-    if (f.type == 4) return r.u32(f.value_at + 4 * (size_t)i);
+    if (f.type == 4 || f.type == 13) return r.u32(f.value_at + 4 * (size_t)i);
+    if (f.type == 16 || f.type == 18) return tiff_u64(r, f.value_at + 8 * (size_t)i);
     throw std::runtime_error("tiff: unexpected field type " + std::to_string(f.type));
 }
 
@@ -139,23 +147,33 @@ void decode_tiff(const uint8_t* data, size_t n, uint32_t& width, uint32_t& heigh
     else if (data[0] == 'M' && data[1] == 'M') r.big = true;
     else throw std::runtime_error("tiff: not a TIFF file");
     const uint16_t magic = r.u16(2);
-    if (magic == 43) throw std::runtime_error("unsupported: BigTIFF");
-    if (magic != 42) throw std::runtime_error("tiff: not a TIFF file");
-    const size_t ifd = r.u32(4);
-    const uint16_t n_entries = r.u16(ifd);
+    // BigTIFF (magic 43; the `tiff` crate 0.9 behind load.rs:586-600 reads it): 8-byte offsets, 20-byte directory entries with 64-bit counts, values of
+    // up to 8 bytes inline. Everything after the directory is the same file format.
+    const bool bigtiff = magic == 43;
+    if (!bigtiff && magic != 42) throw std::runtime_error("tiff: not a TIFF file");
+    if (bigtiff && (n < 16 || r.u16(4) != 8 || r.u16(6) != 0)) throw std::runtime_error("tiff: bad BigTIFF header");
+    const uint64_t ifd64 = bigtiff ? tiff_u64(r, 8) : r.u32(4);
+    if (ifd64 > n) throw std::runtime_error("tiff: directory outside the file");
+    const size_t ifd = (size_t)ifd64;
+    const uint64_t n_entries = bigtiff ? tiff_u64(r, ifd) : r.u16(ifd);
+    if (n_entries > 65535) throw std::runtime_error("tiff: directory too large");
+    const size_t entry_size = bigtiff ? 20 : 12, entries_at = ifd + (bigtiff ? 8 : 2), inline_bytes = bigtiff ? 8 : 4;
     TiffField f_bits, f_strip_off, f_strip_cnt, f_tile_off, f_tile_cnt, f_extra, f_format;
     uint32_t compression = 1, photometric = 0xffffffffu, spp = 1, rows_per_strip = 0xffffffffu, planar = 1, predictor = 1, tile_w = 0, tile_h = 0;
     width = height = 0;
-    for (uint16_t e = 0; e < n_entries; e++) {
-        const size_t at = ifd + 2 + 12 * (size_t)e;
+    for (uint64_t e = 0; e < n_entries; e++) {
+        const size_t at = entries_at + entry_size * (size_t)e;
         const uint16_t tag = r.u16(at);
         TiffField f;
         f.type = r.u16(at + 2);
-        f.count = r.u32(at + 4);
+        f.count = bigtiff ? tiff_u64(r, at + 4) : r.u32(at + 4);
+        if (f.count > n) throw std::runtime_error("tiff: field count larger than the file");
         const size_t bytes = tiff_type_size(f.type) * (size_t)f.count;
-        f.value_at = bytes <= 4 ? at + 8 : (size_t)r.u32(at + 8);
-        if (bytes > 4 && f.value_at + bytes > n) throw std::runtime_error("tiff: field data outside the file");
-        auto first = [&] { return tiff_value(r, f, 0); };
+        const size_t val = at + (bigtiff ? 12 : 8);
+        const uint64_t where = bytes <= inline_bytes ? val : (bigtiff ? tiff_u64(r, val) : r.u32(val));
+        if (where > n || (bytes > inline_bytes && bytes > n - where)) throw std::runtime_error("tiff: field data outside the file");
+        f.value_at = (size_t)where;
+        auto first = [&] { return (uint32_t)tiff_value(r, f, 0); };
         switch (tag) {
             case 256: width = first(); break;
             case 257: height = first(); break;
@@ -182,16 +200,19 @@ void decode_tiff(const uint8_t* data, size_t n, uint32_t& width, uint32_t& heigh
     if (spp < 1 || spp > 4) throw std::runtime_error("unsupported: tiff with " + std::to_string(spp) + " samples per pixel");
     uint32_t bits = 1;
     if (f_bits.count) {
-        bits = tiff_value(r, f_bits, 0);
+        bits = (uint32_t)tiff_value(r, f_bits, 0);
         for (uint32_t i = 1; i < f_bits.count && i < spp; i++)
             if (tiff_value(r, f_bits, i) != bits) throw std::runtime_error("unsupported: tiff with different bit depths per sample");
     }
     uint32_t format = 1;
-    if (f_format.count) format = tiff_value(r, f_format, 0);
+    if (f_format.count) format = (uint32_t)tiff_value(r, f_format, 0);
     const bool is_float = format == 3;
     if (!((bits == 8 || bits == 16) && format == 1) && !(bits == 32 && is_float))
         throw std::runtime_error("unsupported: tiff sample format (" + std::to_string(bits) + " bits, format " + std::to_string(format) + ")");
-    if (planar != 1 && spp > 1) throw std::runtime_error("unsupported: tiff with planar sample layout");
+    // PlanarConfiguration 2 (TIFF 6.0 section "PlanarConfiguration"): every sample has its own strips / tiles -- all chunks of sample 0, then all of
+    // sample 1, ... -- each holding one sample per pixel. Read as `spp` one-sample images written into their component.
+    if (planar != 1 && planar != 2) throw std::runtime_error("tiff: bad planar configuration");
+    const bool separate = planar == 2 && spp > 1;
     if (photometric == 0xffffffffu) throw std::runtime_error("tiff: missing photometric interpretation");
     if (photometric > 2) throw std::runtime_error("unsupported: tiff photometric interpretation " + std::to_string(photometric));
     if (photometric == 2 ? (spp != 3 && spp != 4) : (spp != 1 && spp != 2)) throw std::runtime_error("unsupported: tiff sample count for its photometric interpretation");
@@ -211,25 +232,30 @@ void decode_tiff(const uint8_t* data, size_t n, uint32_t& width, uint32_t& heigh
     const uint32_t ch = tiled ? tile_h : (rows_per_strip > height ? height : rows_per_strip);
     if (ch == 0) throw std::runtime_error("tiff: zero rows per strip");
     const uint32_t across = (width + cw - 1) / cw, down = (height + ch - 1) / ch;
-    if ((uint64_t)across * down > f_off.count) throw std::runtime_error("tiff: too few strip / tile offsets");
-    const size_t bps = bits / 8, px_bytes = bps * spp;
+    const uint32_t n_planes = separate ? spp : 1u, chunk_spp = separate ? 1u : spp;
+    if ((uint64_t)across * down * n_planes > f_off.count) throw std::runtime_error("tiff: too few strip / tile offsets");
+    const size_t bps = bits / 8, px_bytes = bps * chunk_spp;
     // samples of the whole image, native 16 / 32-bit values widened: decoded once, converted at the end
     std::vector<uint8_t> chunk;
     // no allocation on the word of the header alone: the file must be able to hold the picture (stored: byte for byte; LZW /
     // deflate / PackBits cannot expand more than ~1400 times), otherwise a 100-byte file costs a gigabyte before it is refused
     {
-        const uint64_t need = (uint64_t)width * height * px_bytes;
+        const uint64_t need = (uint64_t)width * height * px_bytes * n_planes;
         if (compression == 1 ? need > n : need / 1400u > n) throw std::runtime_error("tiff: file too short for its image size");
     }
     rgba.assign(4ull * width * height, 255);
+    for (uint32_t plane = 0; plane < n_planes; plane++)
     for (uint32_t cy = 0; cy < down; cy++) {
         for (uint32_t cx = 0; cx < across; cx++) {
-            const uint32_t idx = cy * across + cx;
-            const size_t off = tiff_value(r, f_off, idx);
+            const uint64_t idx = ((uint64_t)plane * down + cy) * across + cx;
+            const uint64_t off64 = tiff_value(r, f_off, idx);
+            if (off64 > n) throw std::runtime_error("tiff: strip / tile data outside the file");
+            const size_t off = (size_t)off64;
             const uint32_t rows = tiled ? ch : (cy + 1 == down ? height - cy * ch : ch);  // the last strip may be short; tiles are padded
             const size_t expect = (size_t)rows * cw * px_bytes;
-            size_t len = f_cnt.count > idx ? tiff_value(r, f_cnt, idx) : (compression == 1 ? expect : n - off);
-            if (off > n || len > n - off) throw std::runtime_error("tiff: strip / tile data outside the file");
+            const uint64_t len64 = f_cnt.count > idx ? tiff_value(r, f_cnt, idx) : (compression == 1 ? expect : n - off);
+            if (len64 > n - off) throw std::runtime_error("tiff: strip / tile data outside the file");
+            const size_t len = (size_t)len64;
             if (compression == 1) chunk.assign(data + off, data + off + len);
             else if (compression == 5) tiff_lzw(data + off, len, chunk, expect);
             else if (compression == 32773) tiff_packbits(data + off, len, chunk, expect);
@@ -244,8 +270,8 @@ void decode_tiff(const uint8_t* data, size_t n, uint32_t& width, uint32_t& heigh
                 for (uint32_t x = 0; x < cw; x++) {
                     const uint32_t ix = cx * cw + x;
                     uint32_t v[4];
-                    for (uint32_t s = 0; s < spp; s++) {
-                        const uint8_t* p = row + ((size_t)x * spp + s) * bps;
+                    for (uint32_t s = 0; s < chunk_spp; s++) {
+                        const uint8_t* p = row + ((size_t)x * chunk_spp + s) * bps;
                         uint32_t q = bps == 1 ? p[0] : bps == 2 ? (r.big ? (uint32_t)((p[0] << 8) | p[1]) : (uint32_t)(p[0] | (p[1] << 8)))
                                                                 : (r.big ? ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]
                                                                          : ((uint32_t)p[3] << 24) | ((uint32_t)p[2] << 16) | ((uint32_t)p[1] << 8) | p[0]);
@@ -254,12 +280,19 @@ void decode_tiff(const uint8_t* data, size_t n, uint32_t& width, uint32_t& heigh
                     }
                     if (ix >= width) continue;
                     uint8_t b[4];
-                    for (uint32_t s = 0; s < spp; s++) {
+                    for (uint32_t s = 0; s < chunk_spp; s++) {
                         if (is_float) { float fv; std::memcpy(&fv, &v[s], 4); b[s] = f32_to_u8(fv); }
                         else b[s] = bps == 1 ? (uint8_t)v[s] : (uint8_t)((v[s] + 128u) / 257u);
                     }
                     uint8_t* o = rgba.data() + 4 * ((size_t)iy * width + ix);
-                    if (photometric == 2) {
+                    if (separate) {  // this chunk holds sample `plane` of its pixels
+                        if (photometric == 2) {
+                            o[plane] = b[0];  // R, G, B, A in that order
+                        } else {
+                            const uint8_t l = photometric == 0 ? (uint8_t)(255 - b[0]) : b[0];
+                            if (plane == 0) o[0] = o[1] = o[2] = l; else o[3] = b[0];
+                        }
+                    } else if (photometric == 2) {
                         o[0] = b[0]; o[1] = b[1]; o[2] = b[2];
                         o[3] = spp == 4 ? b[3] : 255;
                     } else {

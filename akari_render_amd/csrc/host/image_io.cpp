@@ -1028,13 +1028,14 @@ void decode_exr(const uint8_t* data, size_t n, uint32_t& width, uint32_t& height
     if (n < 8 || rd32(0) != 20000630u) throw std::runtime_error("exr: bad magic number");
     uint32_t version = rd32(4);
     if ((version & 0xffu) != 2u) throw std::runtime_error("exr: unknown version");
-    if (version & 0x200u) throw std::runtime_error("unsupported: tiled OpenEXR file");
+    const bool tiled = (version & 0x200u) != 0;  // single-part tiled file (round 6; the exr crate behind load.rs:586-600 reads them)
     if (version & 0x1800u) throw std::runtime_error("unsupported: deep / multi-part OpenEXR file");
     size_t pos = 8;
     struct Chan { std::string name; uint32_t type; };
     std::vector<Chan> chans;
     int compression = -1, line_order = 0;
     int32_t dw[4] = {0, 0, -1, -1};
+    uint32_t tile_w = 0, tile_h = 0, tile_mode = 0;
     for (;;) {  // attributes
         need(pos, 1);
         if (data[pos] == 0) { pos++; break; }
@@ -1068,20 +1069,31 @@ void decode_exr(const uint8_t* data, size_t n, uint32_t& width, uint32_t& height
             std::memcpy(dw, v, 16);
         } else if (name == "lineOrder") {
             line_order = size ? v[0] : 0;
+        } else if (name == "tiles") {  // tiledesc: xSize, ySize, mode (level mode in the low nibble, rounding mode in the high one)
+            if (size != 9) throw std::runtime_error("exr: bad tile description");
+            std::memcpy(&tile_w, v, 4);
+            std::memcpy(&tile_h, v + 4, 4);
+            tile_mode = v[8];
         }
         pos += size;
     }
     if (chans.empty() || dw[2] < dw[0] || dw[3] < dw[1]) throw std::runtime_error("exr: missing channels or data window");
-    if (compression < 0 || compression > 3) throw std::runtime_error("unsupported: OpenEXR compression method " + std::to_string(compression) + " (none, RLE, ZIPS and ZIP are read)");
+    if (compression < 0 || (compression > 3 && compression != 5))
+        throw std::runtime_error("unsupported: OpenEXR compression method " + std::to_string(compression) + " (none, RLE, ZIPS, ZIP and PXR24 are read; PIZ, B44 and DWA are not)");
+    if (tiled && (tile_w == 0 || tile_h == 0 || tile_w > 65535 || tile_h > 65535)) throw std::runtime_error("exr: tiled file without a valid tile size");
+    if (tiled && (tile_mode & 0xfu) > 2u) throw std::runtime_error("exr: bad tile level mode");
     (void)line_order;  // the offset table is indexed by scanline block in increasing y whatever the order on disk
     const uint64_t W = (uint64_t)((int64_t)dw[2] - (int64_t)dw[0] + 1), H = (uint64_t)((int64_t)dw[3] - (int64_t)dw[1] + 1);
     if (W > 65535 || H > 65535 || W * H > (1ull << 28)) throw std::runtime_error("exr: image too large");
     width = (uint32_t)W;
     height = (uint32_t)H;
-    const uint32_t lines_per_block = compression == 3 ? 16u : 1u;
-    const uint64_t n_blocks = (H + lines_per_block - 1) / lines_per_block;
-    size_t bytes_per_pixel_row = 0;
-    for (const Chan& c : chans) bytes_per_pixel_row += (size_t)W * (c.type == 1 ? 2 : 4);
+    const uint32_t lines_per_block = (compression == 3 || compression == 5) ? 16u : 1u;
+    // chunks: blocks of scanlines, or -- tiled -- the tiles of the full-resolution level (level (0, 0); mip / rip levels follow it in the
+    // offset table and are not read), row-major
+    const uint64_t tiles_x = tiled ? (W + tile_w - 1) / tile_w : 1, tiles_y = tiled ? (H + tile_h - 1) / tile_h : 0;
+    const uint64_t n_blocks = tiled ? tiles_x * tiles_y : (H + lines_per_block - 1) / lines_per_block;
+    size_t bytes_per_pixel = 0;
+    for (const Chan& c : chans) bytes_per_pixel += (c.type == 1 ? 2 : 4);
     // which file channel feeds which of R, G, B, A
     int src[4] = {-1, -1, -1, -1}, y_chan = -1;
     for (size_t i = 0; i < chans.size(); i++) {
@@ -1097,21 +1109,61 @@ void decode_exr(const uint8_t* data, size_t n, uint32_t& width, uint32_t& height
     need(table, 8 * n_blocks);
     for (uint64_t blk = 0; blk < n_blocks; blk++) {
         uint64_t off = rd64(table + 8 * blk);
-        need(off, 8);
+        if (off > n) throw std::runtime_error("exr: chunk outside the file");
         int32_t y0;
-        std::memcpy(&y0, data + off, 4);
-        uint32_t csize = rd32(off + 4);
-        need(off + 8, csize);
-        if (y0 < dw[1] || y0 > dw[3]) throw std::runtime_error("exr: scanline outside the data window");
-        const uint64_t rows = std::min<uint64_t>(lines_per_block, (uint64_t)(dw[3] - y0) + 1);
-        const size_t raw_size = bytes_per_pixel_row * rows;
+        uint64_t x0 = 0, cols = W, rows;
+        uint32_t csize;
+        size_t head;
+        if (tiled) {  // tile coordinates, level, size
+            need(off, 20);
+            int32_t tc[4];
+            std::memcpy(tc, data + off, 16);
+            csize = rd32(off + 16);
+            head = 20;
+            if (tc[2] != 0 || tc[3] != 0) throw std::runtime_error("exr: the offset table's first tiles are not those of level 0");
+            if (tc[0] < 0 || tc[1] < 0 || (uint64_t)tc[0] >= tiles_x || (uint64_t)tc[1] >= tiles_y) throw std::runtime_error("exr: tile outside the data window");
+            x0 = (uint64_t)tc[0] * tile_w;
+            y0 = dw[1] + (int32_t)((uint64_t)tc[1] * tile_h);
+            cols = std::min<uint64_t>(tile_w, W - x0);
+            rows = std::min<uint64_t>(tile_h, H - (uint64_t)tc[1] * tile_h);
+        } else {
+            need(off, 8);
+            std::memcpy(&y0, data + off, 4);
+            csize = rd32(off + 4);
+            head = 8;
+            if (y0 < dw[1] || y0 > dw[3]) throw std::runtime_error("exr: scanline outside the data window");
+            rows = std::min<uint64_t>(lines_per_block, (uint64_t)(dw[3] - y0) + 1);
+        }
+        need(off + head, csize);
+        const size_t raw_size = bytes_per_pixel * cols * rows;
         std::vector<uint8_t> raw;
-        const uint8_t* src_bytes = data + off + 8;
+        const uint8_t* src_bytes = data + off + head;
         if (csize == raw_size || compression == 0) {  // stored uncompressed (also when compression did not help)
             if (csize != raw_size) throw std::runtime_error("exr: bad block size");
             raw.assign(src_bytes, src_bytes + csize);
         } else if (compression == 1) {
             raw = exr_unpredict(exr_rle_decode(src_bytes, csize, raw_size));
+        } else if (compression == 5) {
+            // PXR24 (lossy for FLOAT channels: 24 bits kept): zlib over, per scanline and channel, the byte PLANES (most significant first) of the
+            // running differences of the pixel values -- 4 planes for UINT, 2 for HALF, 3 for FLOAT (the low byte is dropped)
+            const std::vector<uint8_t> planes = inflate_zlib(src_bytes, csize);
+            raw.resize(raw_size);
+            size_t q = 0, w = 0;
+            for (uint64_t r = 0; r < rows; r++)
+                for (const Chan& c : chans) {
+                    const size_t np = c.type == 0 ? 4 : (c.type == 1 ? 2 : 3);
+                    if (q + np * cols > planes.size()) throw std::runtime_error("exr: PXR24 block too short");
+                    uint32_t pixel = 0;
+                    for (uint64_t x = 0; x < cols; x++) {
+                        uint32_t diff = 0;
+                        for (size_t k = 0; k < np; k++) diff = (diff << 8) | planes[q + k * cols + x];
+                        if (c.type == 2) diff <<= 8;
+                        pixel += diff;
+                        if (c.type == 1) { const uint16_t hv = (uint16_t)pixel; std::memcpy(&raw[w], &hv, 2); w += 2; }
+                        else { std::memcpy(&raw[w], &pixel, 4); w += 4; }
+                    }
+                    q += np * cols;
+                }
         } else {
             raw = exr_unpredict(inflate_zlib(src_bytes, csize));
         }
@@ -1121,7 +1173,8 @@ void decode_exr(const uint8_t* data, size_t n, uint32_t& width, uint32_t& height
             const uint64_t y = (uint64_t)(y0 - dw[1]) + r;
             for (size_t ci = 0; ci < chans.size(); ci++) {  // channels are stored one after the other within a scanline
                 const uint32_t ty = chans[ci].type;
-                for (uint64_t x = 0; x < W; x++) {
+                for (uint64_t xx = 0; xx < cols; xx++) {
+                    const uint64_t x = x0 + xx;
                     float f;
                     if (ty == 1) { uint16_t hbits; std::memcpy(&hbits, &raw[p], 2); p += 2; f = half_to_float(hbits); }
                     else if (ty == 2) { std::memcpy(&f, &raw[p], 4); p += 4; }

@@ -287,10 +287,20 @@ def textured_room(width=48, height=48, n_floor=1, seed=11, alpha_cutout=False, t
     return abi.SceneData(meshes, insts, mats, cam, images=images)
 
 
-def make_exr(planes: dict, compression: int = 3, line_order: int = 0) -> bytes:
-    """Single-part scanline OpenEXR from {channel name: (H, W) array of float16 / float32 / uint32}; compression 0 none,
+def pxr24_round(a: np.ndarray) -> np.ndarray:
+    """What a FLOAT channel holds after PXR24: the value rounded to 24 bits (ImfPxr24Compressor floatToFloat24 for finite values whose
+    rounding does not overflow the mantissa into infinity)."""
+    b = a.astype(np.float32).view(np.uint32).astype(np.uint64)
+    return (((b + 0x80) >> 8) << 8).astype(np.uint32).view(np.float32)
+
+
+def make_exr(planes: dict, compression: int = 3, line_order: int = 0, tiles=None, mipmap: bool = False) -> bytes:
+    """Single-part OpenEXR from {channel name: (H, W) array of float16 / float32 / uint32}; compression 0 none,
     1 RLE, 2 ZIPS, 3 ZIP (the file-format definitions: per block, channel rows one after the other, byte de-interleave,
-    delta predictor, then RLE / deflate; a block that does not shrink is stored raw)."""
+    delta predictor, then RLE / deflate; a block that does not shrink is stored raw), 5 PXR24 (per row and channel the byte planes,
+    most significant first, of the running differences of the values -- FLOAT cut to 24 bits -- deflated). tiles = (w, h): a TILED
+    file (version flag 0x200, `tiles` attribute, one chunk per tile in row-major order: tile x, tile y, level x, level y, size);
+    mipmap: the level mode says MIPMAP and a half-resolution level's tiles follow level 0's (readers of the full resolution skip them)."""
     import struct
     import zlib
 
@@ -302,18 +312,50 @@ def make_exr(planes: dict, compression: int = 3, line_order: int = 0) -> bytes:
         return name.encode() + b"\0" + ty.encode() + b"\0" + struct.pack("<I", len(v)) + v
 
     chl = b"".join(n.encode() + b"\0" + struct.pack("<IIII", tcode[planes[n].dtype], 0, 1, 1) for n in names) + b"\0"
-    head = struct.pack("<II", 20000630, 2)
+    head = struct.pack("<II", 20000630, 2 | (0x200 if tiles else 0))
     head += attr("channels", "chlist", chl) + attr("compression", "compression", bytes([compression]))
+    if tiles:
+        head += attr("tiles", "tiledesc", struct.pack("<IIB", tiles[0], tiles[1], 1 if mipmap else 0))
     box = struct.pack("<iiii", 0, 0, w - 1, h - 1)
     head += attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", bytes([line_order]))
     head += attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0))
     head += attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
-    lpb = 16 if compression == 3 else 1
+    lpb = 16 if compression in (3, 5) else 1
+
+    def pxr24(rows_of_planes):  # [(channel array row), ...] in file order
+        out = bytearray()
+        for row in rows_of_planes:
+            if row.dtype == np.float32:
+                v = ((row.view(np.uint32).astype(np.uint64) + 0x80) >> 8).astype(np.uint64)  # 24-bit values
+                nb, mod = 3, 1 << 24
+            elif row.dtype == np.float16:
+                v, nb, mod = row.view(np.uint16).astype(np.uint64), 2, 1 << 16
+            else:
+                v, nb, mod = row.astype(np.uint64), 4, 1 << 32
+            d = v.copy()
+            d[1:] = (v[1:] - v[:-1]) % mod
+            for k in range(nb):
+                out += ((d >> (8 * (nb - 1 - k))) & 255).astype(np.uint8).tobytes()
+        return zlib.compress(bytes(out), 6)
+
+    regions = []  # (header bytes before the size, x0, x1, y0, y1)
+    if tiles:
+        tw, th = tiles
+        for ty in range((h + th - 1) // th):
+            for tx in range((w + tw - 1) // tw):
+                regions.append((struct.pack("<iiii", tx, ty, 0, 0), tx * tw, min(w, tx * tw + tw), ty * th, min(h, ty * th + th)))
+    else:
+        for y0 in range(0, h, lpb):
+            regions.append((struct.pack("<i", y0), 0, w, y0, min(h, y0 + lpb)))
     blocks = []
-    for y0 in range(0, h, lpb):
-        raw = b"".join(planes[n][y].tobytes() for y in range(y0, min(h, y0 + lpb)) for n in names)
+    for hdr, x0, x1, y0, y1 in regions:
+        rows = [np.ascontiguousarray(planes[n][y, x0:x1]) for y in range(y0, y1) for n in names]
+        raw = b"".join(r.tobytes() for r in rows)
         blob = raw
-        if compression:
+        if compression == 5:
+            comp = pxr24(rows)
+            blob = comp if len(comp) < len(raw) else raw
+        elif compression:
             t = np.frombuffer(raw, dtype=np.uint8)
             t = np.concatenate([t[0::2], t[1::2]]).astype(np.int64)
             d = t.copy()
@@ -336,7 +378,12 @@ def make_exr(planes: dict, compression: int = 3, line_order: int = 0) -> bytes:
             else:
                 comp = zlib.compress(pre, 6)
             blob = comp if len(comp) < len(raw) else raw
-        blocks.append(struct.pack("<iI", y0, len(blob)) + blob)
+        blocks.append(hdr + struct.pack("<I", len(blob)) + blob)
+    if tiles and mipmap:  # one more level: what it holds does not matter to a reader of level 0
+        lw, lh = max(1, w // 2), max(1, h // 2)
+        for ty in range((lh + tiles[1] - 1) // tiles[1]):
+            for tx in range((lw + tiles[0] - 1) // tiles[0]):
+                blocks.append(struct.pack("<iiiiI", tx, ty, 1, 1, 4) + b"\xde\xad\xbe\xef")
     order = range(len(blocks)) if line_order == 0 else reversed(range(len(blocks)))
     table_pos = len(head)
     offsets = [0] * len(blocks)

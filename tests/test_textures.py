@@ -488,6 +488,29 @@ def test_exr_reader(compression, layout):
     assert n_bit_diff(got, want) == 0
 
 
+@pytest.mark.parametrize("compression", [0, 1, 3, 5], ids=["none", "rle", "zip", "pxr24"])
+@pytest.mark.parametrize("tiles", [None, (16, 16), (32, 8), (64, 64)], ids=["scanlines", "tiles16", "tiles32x8", "one_tile"])
+def test_exr_reader_tiled_and_pxr24(compression, tiles):
+    """Round 6: tiled single-part files and PXR24, which the exr crate behind load.rs:586-600 reads. The fixture
+    writer (tests/helpers.py make_exr) is written from the file-format description, independently of the reader."""
+    from tests.helpers import make_exr, pxr24_round
+
+    if tiles is None and compression != 5:
+        pytest.skip("covered by test_exr_reader")
+    rng = np.random.default_rng(compression + (tiles[0] if tiles else 0))
+    h, w = 45, 52
+    smooth = lambda: (np.linspace(0, 4, w)[None, :] * np.linspace(0.5, 2, h)[:, None] + rng.random((h, w)) * 0.01)  # noqa: E731
+    planes = {"R": smooth().astype(np.float32), "G": smooth().astype(np.float16), "B": smooth().astype(np.float32), "A": (smooth() * 50).astype(np.uint32)}
+    for mip in ((False, True) if tiles else (False,)):
+        data = make_exr(planes, compression, tiles=tiles, mipmap=mip)
+        got = capi.host_decode_exr(data)
+        want = np.zeros((h, w, 4), dtype=np.float32)
+        for k, c in enumerate("RGBA"):
+            v = planes[c]
+            want[:, :, k] = pxr24_round(v) if (compression == 5 and v.dtype == np.float32) else v.astype(np.float32)
+        assert got.shape == (h, w, 4) and n_bit_diff(got, want) == 0
+
+
 def test_exr_reader_reads_the_writer_and_rejects_what_it_cannot_read(tmp_path):
     rgb = np.random.default_rng(0).random((9, 14, 3)).astype(np.float32)
     path = str(tmp_path / "out.exr")
