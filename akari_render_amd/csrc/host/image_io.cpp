@@ -1001,6 +1001,207 @@ std::vector<uint8_t> exr_unpredict(const std::vector<uint8_t>& in) {  // delta p
     for (size_t i = 0; i < t.size(); i++) out[i] = (i & 1) ? t[b++] : t[a++];
     return out;
 }
+// ---- PIZ (OpenEXR's wavelet + Huffman compression; round 6). A block's 16-bit words -- per channel a plane of rows x cols x (1 word for
+// HALF, 2 for FLOAT / UINT) -- are mapped through a table of the values that occur (a 65536-bit bitmap in the stream), Haar-wavelet
+// transformed in place per word plane (14-bit or 16-bit modular variant, by the largest mapped value), and Huffman coded with canonical
+// codes of up to 58 bits, a packed table of code lengths with zero runs, and one extra symbol meaning "repeat the last word n times".
+struct PizBits {  // MSB-first bit reader
+    const uint8_t* p;
+    size_t n, pos = 0;
+    uint64_t acc = 0;
+    int have = 0;
+    uint64_t get(int bits) {
+        while (have < bits) {
+            acc = (acc << 8) | (pos < n ? p[pos] : 0u);  // (reading past the end yields zeros; the caller checks the counts)
+            pos++;
+            have += 8;
+        }
+        have -= bits;
+        return (acc >> have) & ((bits == 64) ? ~0ull : ((1ull << bits) - 1ull));
+    }
+};
+void piz_huf_decode(const uint8_t* src, size_t n, std::vector<uint16_t>& out, size_t n_out) {
+    if (n < 20) throw std::runtime_error("exr: PIZ block too short");
+    auto u32 = [&](size_t o) { uint32_t v; std::memcpy(&v, src + o, 4); return v; };
+    const uint32_t im = u32(0), iM = u32(4), n_bits = u32(12);
+    constexpr uint32_t kEncSize = 65537;
+    if (im >= kEncSize || iM >= kEncSize || im > iM) throw std::runtime_error("exr: bad PIZ Huffman header");
+    std::vector<uint8_t> len(kEncSize, 0);
+    PizBits tb{src + 20, n - 20};
+    for (uint32_t i = im; i <= iM;) {  // packed code lengths: 6 bits each; 63 = a zero run of 6 + (8 more bits), 59..62 = a zero run of 2..5
+        const uint32_t l = (uint32_t)tb.get(6);
+        if (l == 63) {
+            const uint32_t run = (uint32_t)tb.get(8) + 6;
+            if (i + run > iM + 1) throw std::runtime_error("exr: bad PIZ code table");
+            i += run;
+        } else if (l >= 59) {
+            const uint32_t run = l - 59 + 2;
+            if (i + run > iM + 1) throw std::runtime_error("exr: bad PIZ code table");
+            i += run;
+        } else {
+            len[i++] = (uint8_t)l;
+        }
+    }
+    if (tb.pos > n - 20 + 8) throw std::runtime_error("exr: PIZ code table outside the block");
+    const size_t table_bytes = (size_t)(tb.pos - (size_t)(tb.have / 8));  // whole bytes consumed (the data starts at the next byte)
+    // canonical codes: within a length in symbol order, the LONGEST codes start at 0 (hufCanonicalCodeTable)
+    uint64_t count[59] = {0}, base[59] = {0};
+    for (uint32_t i = im; i <= iM; i++) count[len[i]]++;
+    {
+        uint64_t c = 0;
+        for (int l = 58; l >= 1; l--) {
+            const uint64_t nc = (c + count[l]) >> 1;
+            base[l] = c;
+            c = nc;
+        }
+    }
+    std::vector<uint32_t> first(60, 0), syms;  // symbols sorted by (length, symbol)
+    syms.reserve(iM - im + 1);
+    for (int l = 1; l <= 58; l++) {
+        first[l] = (uint32_t)syms.size();
+        for (uint32_t i = im; i <= iM; i++)
+            if (len[i] == l) syms.push_back(i);
+    }
+    first[59] = (uint32_t)syms.size();
+    const uint32_t rlc = iM;
+    const size_t data_at = 20 + table_bytes;
+    if (data_at > n || ((uint64_t)n_bits + 7) / 8 > n - data_at) throw std::runtime_error("exr: PIZ data outside the block");
+    PizBits db{src + data_at, n - data_at};
+    out.clear();
+    out.reserve(n_out);
+    uint64_t used = 0;
+    while (used < n_bits) {
+        uint64_t code = 0;
+        int l = 0;
+        uint32_t sym = 0xffffffffu;
+        while (l < 58 && used < n_bits) {
+            code = (code << 1) | db.get(1);
+            l++;
+            used++;
+            if (count[l] && code >= base[l] && code - base[l] < count[l]) { sym = syms[first[l] + (uint32_t)(code - base[l])]; break; }
+        }
+        if (sym == 0xffffffffu) {
+            if (used >= n_bits) break;  // trailing bits of the last byte
+            throw std::runtime_error("exr: bad PIZ Huffman code");
+        }
+        if (sym == rlc) {
+            if (used + 8 > n_bits || out.empty()) throw std::runtime_error("exr: bad PIZ run");
+            const uint32_t run = (uint32_t)db.get(8);
+            used += 8;
+            if (out.size() + run > n_out) throw std::runtime_error("exr: PIZ block decodes to too many words");
+            out.insert(out.end(), run, out.back());
+        } else {
+            if (out.size() >= n_out) throw std::runtime_error("exr: PIZ block decodes to too many words");
+            out.push_back((uint16_t)sym);
+        }
+    }
+    if (out.size() != n_out) throw std::runtime_error("exr: PIZ block decodes to the wrong number of words");
+}
+inline void piz_wdec14(uint16_t l, uint16_t h, uint16_t& a, uint16_t& b) {
+    const int ls = (int16_t)l, hs = (int16_t)h;
+    const int ai = ls + (hs & 1) + (hs >> 1);
+    a = (uint16_t)(int16_t)ai;
+    b = (uint16_t)(int16_t)(ai - hs);
+}
+inline void piz_wdec16(uint16_t l, uint16_t h, uint16_t& a, uint16_t& b) {
+    const int m = l, d = h;
+    const int bb = (m - (d >> 1)) & 0xffff;
+    const int aa = (d + bb - 0x8000) & 0xffff;
+    b = (uint16_t)bb;
+    a = (uint16_t)aa;
+}
+void piz_wav2_decode(uint16_t* in, int nx, int ox, int ny, int oy, uint16_t mx) {
+    const bool w14 = mx < (1 << 14);
+    const int n = nx > ny ? ny : nx;
+    int p = 1;
+    while (p <= n) p <<= 1;
+    p >>= 1;
+    int p2 = p;
+    p >>= 1;
+    auto dec = [&](uint16_t l, uint16_t h, uint16_t& a, uint16_t& b) { if (w14) piz_wdec14(l, h, a, b); else piz_wdec16(l, h, a, b); };
+    while (p >= 1) {
+        uint16_t* py = in;
+        uint16_t* ey = in + (ptrdiff_t)oy * (ny - p2);
+        const ptrdiff_t oy1 = (ptrdiff_t)oy * p, oy2 = (ptrdiff_t)oy * p2, ox1 = (ptrdiff_t)ox * p, ox2 = (ptrdiff_t)ox * p2;
+        uint16_t i00, i01, i10, i11;
+        for (; py <= ey; py += oy2) {
+            uint16_t* px = py;
+            uint16_t* ex = py + (ptrdiff_t)ox * (nx - p2);
+            for (; px <= ex; px += ox2) {
+                uint16_t *p01 = px + ox1, *p10 = px + oy1, *p11 = p10 + ox1;
+                dec(*px, *p10, i00, i10);
+                dec(*p01, *p11, i01, i11);
+                dec(i00, i01, *px, *p01);
+                dec(i10, i11, *p10, *p11);
+            }
+            if (nx & p) {
+                uint16_t* p10 = px + oy1;
+                dec(*px, *p10, i00, *p10);
+                *px = i00;
+            }
+        }
+        if (ny & p) {
+            uint16_t* px = py;
+            uint16_t* ex = py + (ptrdiff_t)ox * (nx - p2);
+            for (; px <= ex; px += ox2) {
+                uint16_t* p01 = px + ox1;
+                dec(*px, *p01, i00, *p01);
+                *px = i00;
+            }
+        }
+        p2 = p;
+        p >>= 1;
+    }
+}
+// one PIZ block -> the block's raw bytes (rows of channel rows, the layout every other method decodes to); types[c] = 0 UINT, 1 HALF, 2 FLOAT
+std::vector<uint8_t> piz_decode(const uint8_t* src, size_t n, const std::vector<uint32_t>& types, size_t cols, size_t rows) {
+    if (n < 4) throw std::runtime_error("exr: PIZ block too short");
+    uint16_t min_nz, max_nz;
+    std::memcpy(&min_nz, src, 2);
+    std::memcpy(&max_nz, src + 2, 2);
+    std::vector<uint8_t> bitmap(8192, 0);
+    size_t pos = 4;
+    if (min_nz <= max_nz) {
+        if (max_nz >= 8192 || pos + (size_t)(max_nz - min_nz + 1) > n) throw std::runtime_error("exr: bad PIZ bitmap");
+        std::memcpy(&bitmap[min_nz], src + pos, (size_t)(max_nz - min_nz + 1));
+        pos += (size_t)(max_nz - min_nz + 1);
+    }
+    std::vector<uint16_t> lut(65536, 0);
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < 65536; i++)
+        if (i == 0 || (bitmap[i >> 3] & (1u << (i & 7)))) lut[k++] = (uint16_t)i;
+    const uint16_t max_value = (uint16_t)(k - 1);
+    if (pos + 4 > n) throw std::runtime_error("exr: PIZ block too short");
+    int32_t hlen;
+    std::memcpy(&hlen, src + pos, 4);
+    pos += 4;
+    if (hlen < 0 || (size_t)hlen > n - pos) throw std::runtime_error("exr: PIZ Huffman data outside the block");
+    size_t n_words = 0;
+    for (uint32_t t : types) n_words += cols * rows * (t == 1 ? 1 : 2);
+    std::vector<uint16_t> tmp;
+    piz_huf_decode(src + pos, (size_t)hlen, tmp, n_words);
+    size_t at = 0;
+    std::vector<size_t> start(types.size());
+    for (size_t c = 0; c < types.size(); c++) {
+        const int size = types[c] == 1 ? 1 : 2;
+        start[c] = at;
+        for (int j = 0; j < size; j++) piz_wav2_decode(&tmp[at + j], (int)cols, size, (int)rows, (int)cols * size, max_value);
+        at += cols * rows * size;
+    }
+    for (uint16_t& w : tmp) w = lut[w];
+    std::vector<uint8_t> raw(2 * n_words);
+    size_t w = 0;
+    std::vector<size_t> cur = start;
+    for (size_t r = 0; r < rows; r++)
+        for (size_t c = 0; c < types.size(); c++) {
+            const size_t words = cols * (types[c] == 1 ? 1 : 2);
+            std::memcpy(&raw[w], &tmp[cur[c]], 2 * words);
+            w += 2 * words;
+            cur[c] += words;
+        }
+    return raw;
+}
+
 std::vector<uint8_t> exr_rle_decode(const uint8_t* p, size_t n, size_t expect) {
     std::vector<uint8_t> out;
     size_t i = 0;
@@ -1078,8 +1279,8 @@ void decode_exr(const uint8_t* data, size_t n, uint32_t& width, uint32_t& height
         pos += size;
     }
     if (chans.empty() || dw[2] < dw[0] || dw[3] < dw[1]) throw std::runtime_error("exr: missing channels or data window");
-    if (compression < 0 || (compression > 3 && compression != 5))
-        throw std::runtime_error("unsupported: OpenEXR compression method " + std::to_string(compression) + " (none, RLE, ZIPS, ZIP and PXR24 are read; PIZ, B44 and DWA are not)");
+    if (compression < 0 || compression > 5)
+        throw std::runtime_error("unsupported: OpenEXR compression method " + std::to_string(compression) + " (none, RLE, ZIPS, ZIP, PIZ and PXR24 are read; B44 and DWA are not)");
     if (tiled && (tile_w == 0 || tile_h == 0 || tile_w > 65535 || tile_h > 65535)) throw std::runtime_error("exr: tiled file without a valid tile size");
     if (tiled && (tile_mode & 0xfu) > 2u) throw std::runtime_error("exr: bad tile level mode");
     (void)line_order;  // the offset table is indexed by scanline block in increasing y whatever the order on disk
@@ -1087,7 +1288,7 @@ void decode_exr(const uint8_t* data, size_t n, uint32_t& width, uint32_t& height
     if (W > 65535 || H > 65535 || W * H > (1ull << 28)) throw std::runtime_error("exr: image too large");
     width = (uint32_t)W;
     height = (uint32_t)H;
-    const uint32_t lines_per_block = (compression == 3 || compression == 5) ? 16u : 1u;
+    const uint32_t lines_per_block = compression == 4 ? 32u : ((compression == 3 || compression == 5) ? 16u : 1u);
     // chunks: blocks of scanlines, or -- tiled -- the tiles of the full-resolution level (level (0, 0); mip / rip levels follow it in the
     // offset table and are not read), row-major
     const uint64_t tiles_x = tiled ? (W + tile_w - 1) / tile_w : 1, tiles_y = tiled ? (H + tile_h - 1) / tile_h : 0;
@@ -1143,6 +1344,10 @@ void decode_exr(const uint8_t* data, size_t n, uint32_t& width, uint32_t& height
             raw.assign(src_bytes, src_bytes + csize);
         } else if (compression == 1) {
             raw = exr_unpredict(exr_rle_decode(src_bytes, csize, raw_size));
+        } else if (compression == 4) {
+            std::vector<uint32_t> types;
+            for (const Chan& c : chans) types.push_back(c.type);
+            raw = piz_decode(src_bytes, csize, types, (size_t)cols, (size_t)rows);
         } else if (compression == 5) {
             // PXR24 (lossy for FLOAT channels: 24 bits kept): zlib over, per scanline and channel, the byte PLANES (most significant first) of the
             // running differences of the pixel values -- 4 planes for UINT, 2 for HALF, 3 for FLOAT (the low byte is dropped)

@@ -294,6 +294,165 @@ def pxr24_round(a: np.ndarray) -> np.ndarray:
     return (((b + 0x80) >> 8) << 8).astype(np.uint32).view(np.float32)
 
 
+def piz_compress(rows_of_planes, n_rows: int, names_per_row: int, use_runs: bool = True) -> bytes:
+    """One PIZ block from the block's channel rows in file order (n_rows x names_per_row arrays). Written from the description of the
+    format (OpenEXR's ImfPizCompressor / ImfHuf / ImfWav): value bitmap + forward table, in-place 2-D Haar wavelet per 16-bit word plane
+    (14-bit variant when the largest table index is below 2^14, else the modular 16-bit one), canonical Huffman codes with the packed
+    length table (zero runs) and the run-length symbol. An ENCODER: independent of the library's decoder by construction."""
+    import heapq
+    import struct
+
+    # per channel: a (rows, cols, size) array of 16-bit words (FLOAT / UINT: low word first)
+    chans = []
+    for c in range(names_per_row):
+        rows = [rows_of_planes[r * names_per_row + c] for r in range(n_rows)]
+        a = np.stack(rows)
+        size = 1 if a.dtype == np.float16 else 2
+        chans.append(np.ascontiguousarray(a).view(np.uint16).reshape(n_rows, a.shape[1], size).astype(np.int64))
+    allw = np.concatenate([c.ravel() for c in chans])
+    present = np.zeros(65536, bool)
+    present[allw] = True
+    bitmap = np.packbits(present, bitorder="little")
+    bitmap[0] &= 0xFE  # zero is never stored explicitly
+    nz = np.nonzero(bitmap)[0]
+    present[0] = True
+    lut = np.cumsum(present) - 1
+    max_value = int(present.sum()) - 1
+    w14 = max_value < (1 << 14)
+
+    def s16(x):
+        return ((x + 32768) & 0xFFFF) - 32768
+
+    def wenc(a, b):
+        if w14:
+            a_, b_ = s16(a), s16(b)
+            return ((a_ + b_) >> 1) & 0xFFFF, (a_ - b_) & 0xFFFF
+        ao = (a + 0x8000) & 0xFFFF
+        m = (ao + b) >> 1
+        d = ao - b
+        if d < 0:
+            m = (m + 0x8000) & 0xFFFF
+        return m, d & 0xFFFF
+
+    def wav2_encode(pl):  # pl: (ny, nx) python lists of ints, in place
+        ny, nx = len(pl), len(pl[0])
+        n = min(nx, ny)
+        p, p2 = 1, 2
+        while p2 <= n:
+            y = 0
+            while y <= ny - p2:
+                x = 0
+                while x <= nx - p2:
+                    i00, i01 = wenc(pl[y][x], pl[y][x + p])
+                    i10, i11 = wenc(pl[y + p][x], pl[y + p][x + p])
+                    pl[y][x], pl[y + p][x] = wenc(i00, i10)
+                    pl[y][x + p], pl[y + p][x + p] = wenc(i01, i11)
+                    x += p2
+                if nx & p:
+                    pl[y][x], pl[y + p][x] = wenc(pl[y][x], pl[y + p][x])
+                y += p2
+            if ny & p:
+                x = 0
+                while x <= nx - p2:
+                    pl[y][x], pl[y][x + p] = wenc(pl[y][x], pl[y][x + p])
+                    x += p2
+            p, p2 = p2, p2 << 1
+
+    words = []
+    for c in chans:
+        m = lut[c]
+        for j in range(c.shape[2]):
+            pl = [[int(v) for v in row] for row in m[:, :, j]]
+            wav2_encode(pl)
+            m[:, :, j] = np.array(pl)
+        words += [int(v) for v in m.ravel()]
+    # Huffman: code lengths from the word frequencies + the run-length symbol
+    freq = {}
+    for v in words:
+        freq[v] = freq.get(v, 0) + 1
+    im, iM = min(freq), max(freq) + 1
+    freq[iM] = 1
+    heap = [(f, i, (sym,)) for i, (sym, f) in enumerate(sorted(freq.items()))]
+    heapq.heapify(heap)
+    length = {sym: 0 for sym in freq}
+    tick = len(heap)
+    if len(heap) == 1:
+        length[heap[0][2][0]] = 1
+    while len(heap) > 1:
+        f1, _, s1 = heapq.heappop(heap)
+        f2, _, s2 = heapq.heappop(heap)
+        for sym in s1 + s2:
+            length[sym] += 1
+        heapq.heappush(heap, (f1 + f2, tick, s1 + s2))
+        tick += 1
+    assert max(length.values()) <= 58
+    count = [0] * 59
+    for l in length.values():
+        count[l] += 1
+    base, c = [0] * 59, 0
+    for l in range(58, 0, -1):
+        base[l] = c
+        c = (c + count[l]) >> 1
+    code, nxt = {}, list(base)
+    for sym in sorted(length):
+        l = length[sym]
+        code[sym] = (nxt[l], l)
+        nxt[l] += 1
+    bits = []
+
+    def put(v, n):
+        bits.append((v, n))
+
+    i = im
+    while i <= iM:  # the packed table of code lengths
+        l = length.get(i, 0)
+        if l == 0:
+            run = 1
+            while i + run <= iM and length.get(i + run, 0) == 0 and run < 255 + 6:
+                run += 1
+            if run >= 6:
+                put(63, 6); put(run - 6, 8); i += run; continue
+            if run >= 2:
+                put(59 + run - 2, 6); i += run; continue
+        put(l, 6)
+        i += 1
+
+    def flush(bl):
+        acc = n = 0
+        out = bytearray()
+        for v, k in bl:
+            acc = (acc << k) | v
+            n += k
+            while n >= 8:
+                out.append((acc >> (n - 8)) & 255)
+                n -= 8
+            acc &= (1 << n) - 1
+        if n:
+            out.append((acc << (8 - n)) & 255)
+        return bytes(out), sum(k for _, k in bl)
+
+    table, _ = flush(bits)
+    bits = []
+    k = 0
+    while k < len(words):
+        sym, run = words[k], 0
+        while k + run + 1 < len(words) and words[k + run + 1] == sym and run < 255:
+            run += 1
+        cl, rl = code[sym][1], code[iM][1]
+        if use_runs and cl + rl + 8 < cl * run:
+            put(*code[sym]); put(*code[iM]); put(run, 8)
+        else:
+            for _ in range(run + 1):
+                put(*code[sym])
+        k += run + 1
+    data, n_bits = flush(bits)
+    huf = struct.pack("<IIIII", im, iM, len(table), n_bits, 0) + table + data
+    head = struct.pack("<HH", int(nz[0]) if len(nz) else 8191, int(nz[-1]) if len(nz) else 0)
+    if len(nz):
+        head += bitmap[nz[0]:nz[-1] + 1].tobytes()
+    return head + struct.pack("<i", len(huf)) + huf
+
+
 def make_exr(planes: dict, compression: int = 3, line_order: int = 0, tiles=None, mipmap: bool = False) -> bytes:
     """Single-part OpenEXR from {channel name: (H, W) array of float16 / float32 / uint32}; compression 0 none,
     1 RLE, 2 ZIPS, 3 ZIP (the file-format definitions: per block, channel rows one after the other, byte de-interleave,
@@ -320,7 +479,7 @@ def make_exr(planes: dict, compression: int = 3, line_order: int = 0, tiles=None
     head += attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", bytes([line_order]))
     head += attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0))
     head += attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
-    lpb = 16 if compression in (3, 5) else 1
+    lpb = 32 if compression == 4 else (16 if compression in (3, 5) else 1)
 
     def pxr24(rows_of_planes):  # [(channel array row), ...] in file order
         out = bytearray()
@@ -354,6 +513,9 @@ def make_exr(planes: dict, compression: int = 3, line_order: int = 0, tiles=None
         blob = raw
         if compression == 5:
             comp = pxr24(rows)
+            blob = comp if len(comp) < len(raw) else raw
+        elif compression == 4:
+            comp = piz_compress(rows, y1 - y0, len(names))
             blob = comp if len(comp) < len(raw) else raw
         elif compression:
             t = np.frombuffer(raw, dtype=np.uint8)
