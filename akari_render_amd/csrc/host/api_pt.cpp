@@ -145,7 +145,7 @@ void akr_api::fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_p
 // fewer, no force_bvh) has no wavefront kernels and renders with the megakernel whatever the option says.
 static bool choose_wavefront(const akr_scene* scene) {
     if (!tuning().wavefront) return false;
-    return !scene->cs.bvh_nodes.empty();  // (a scene kept as meshes + instances has no flattened tree: megakernel)
+    return !scene->cs.bvh_nodes.empty() || scene->cs.instanced.on;  // (round 6: kept scenes too -- k_wf_trace<.., INST> over the two-level traversal)
 }
 
 static void wf_allocate(akr_pt_session* se, uint32_t n_slots) {

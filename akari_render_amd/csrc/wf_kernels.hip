@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_wf_init(const PtParams p, const WfBuffe
 #ifndef AKR_WF_SHADE_WAVES
 #define AKR_WF_SHADE_WAVES 1  // waves per SIMD the shade kernel's register allocation must leave room for (1 = whatever it needs)
 #endif
-template <bool TEX, bool PMJ>
+template <bool TEX, bool PMJ, bool INST = false>
 __global__ __launch_bounds__(256, TEX ? 1 : AKR_WF_SHADE_WAVES) void k_wf_shade(const PtParams p, const WfBuffers wf, uint32_t q_out) {
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     PathRegs r;
@@ -152,20 +152,29 @@ __global__ __launch_bounds__(256, TEX ? 1 : AKR_WF_SHADE_WAVES) void k_wf_shade(
         Hit hit;
         hit.gid = f2u(hv.x); hit.u = hv.y; hit.v = hv.z; hit.t = 0.0f;
         bool found = hit.gid != kInvalid, occluded = f2u(hv.w) != 0;
-        path_step<-1, TEX, PMJ>(p, r, hit, found, occluded, pix, sx, sy);
+        path_step<-1, TEX, PMJ, 0, 0u, INST>(p, r, hit, found, occluded, pix, sx, sy);
         wf_store(wf, slot, r);
     }
     wf_enqueue(p, wf, q_out, slot, r);
     flush_counters(p, r, TraceCounters{0, 0, 0}, true);
 }
 
+template <bool INST> struct TravOf { typedef Trav type; };
+template <> struct TravOf<true> { typedef TravI type; };
+template <bool INST, class T>
+AKR_D void wf_trav_begin(T& s, vec3 o, vec3 d, float tmin, float tmax, uint32_t ex0, uint32_t ex1) {
+    if constexpr (INST) trav_begin_inst(s, o, d, tmin, tmax, ex0, ex1);
+    else trav_begin(s, o, d, tmin, tmax, ex0, ex1);
+}
 // Persistent traversal kernel. Ray id = slot; ids [0, n_closest) come from the closest-hit queue, the rest from the
 // shadow queue. A lane that finishes its ray writes the result and becomes idle; when enough lanes of the wave are
 // idle (or all), the wave refills them from the queue head.
 #ifndef AKR_WF_REFILL_IDLE
 #define AKR_WF_REFILL_IDLE 20  // refill when at least this many of the 64 lanes are idle
 #endif
-template <bool TEX>
+// INST (round 6): the scene is kept as meshes + instances -- the two-level traversal of dinst_trav.h: a lane's candidates wait in its
+// pending slot and the wave takes the exact test in batches, as trace_inst does.
+template <bool TEX, bool INST = false>
 __global__ __launch_bounds__(256) void k_wf_trace(const PtParams p, const WfBuffers wf, uint32_t q_in) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     uint32_t* stack = lds_stack + threadIdx.x;
@@ -180,8 +189,10 @@ __global__ __launch_bounds__(256) void k_wf_trace(const PtParams p, const WfBuff
     // cbox with a forced BVH 398 against 576 Msamples/s, 10 M-triangle hall 211 against 219.)
     constexpr uint32_t kWfChunk = 128;
     uint32_t c_next = 0, c_end = 0;  // the wave's claimed range of ray ids
-    Trav s;
-    trav_begin(s, mk3(0, 0, 0), mk3(0, 0, 1), 0.0f, -1.0f, kInvalid, kInvalid);  // idle: tmax < tmin
+    typename TravOf<INST>::type s;
+    wf_trav_begin<INST>(s, mk3(0, 0, 0), mk3(0, 0, 1), 0.0f, -1.0f, kInvalid, kInvalid);  // idle: tmax < tmin
+    uint32_t waited = 0;
+    bool blocked = false;
     for (;;) {
         // Refill idle lanes from the queue. A wave claims kWfChunk consecutive ray ids with ONE atomic and hands them to its idle
         // lanes by ballot + prefix count until the chunk is used up (one atomic per refill -- 150 k of them on one address per
@@ -203,16 +214,38 @@ __global__ __launch_bounds__(256) void k_wf_trace(const PtParams p, const WfBuff
                 slot = any ? wf.queue_shadow[q_in][my - n_closest] : wf.queue_closest[q_in][my];
                 float4 a = any ? wf.sh_o[slot] : wf.ray_o[slot];
                 float4 b = any ? wf.sh_d[slot] : wf.ray_d[slot];
-                trav_begin(s, xyz(a), xyz(b), 0.0f, any ? b.w : 1e20f, f2u(a.w), any ? f2u(wf.sh_c[slot].w) : kInvalid);
+                wf_trav_begin<INST>(s, xyz(a), xyz(b), 0.0f, any ? b.w : 1e20f, f2u(a.w), any ? f2u(wf.sh_c[slot].w) : kInvalid);
                 has = true;
+                blocked = false;
             }
             const uint32_t n = (uint32_t)__builtin_popcountll(idle);
             c_next = c_next + n < c_end ? c_next + n : c_end;
         }
         if (__builtin_amdgcn_ballot_w64(has) == 0) break;
         for (;;) {
-            if (has && s.active) trav_step<2, TEX>(sc, s, stack, cnt, any);
-            if (has && !s.active) {  // ray finished: publish the result for k_wf_shade
+            bool finished;
+            if constexpr (INST) {
+                bool pending = false, wait = false;
+                if (has) {
+                    if (s.pend_rec == kInvalid) blocked = false;
+                    if (s.active & !blocked) blocked = trav_step_inst<TEX>(sc, s, stack, cnt);
+                    pending = s.pend_rec != kInvalid;
+                    wait = pending & (blocked | !s.active);  // cannot go on without the verdict
+                }
+                if (__builtin_amdgcn_ballot_w64(wait) != 0) {
+                    waited++;
+                    if (waited >= AKR_INST_PATIENCE || __builtin_amdgcn_ballot_w64(has & s.active & !wait) == 0 ||
+                        __builtin_popcountll(__builtin_amdgcn_ballot_w64(pending)) >= AKR_INST_QUORUM) {
+                        waited = 0;
+                        if (pending) resolve_pending<TEX>(sc, s, any);
+                    }
+                }
+                finished = has && !s.active && s.pend_rec == kInvalid;
+            } else {
+                if (has && s.active) trav_step<2, TEX>(sc, s, stack, cnt, any);
+                finished = has && !s.active;
+            }
+            if (finished) {  // ray finished: publish the result for k_wf_shade
                 float* hp = (float*)&wf.hit[slot];
                 if (any) {
                     hp[3] = u2f(s.best != kInvalid ? 1u : 0u);
@@ -250,15 +283,20 @@ hipError_t launch_wf_shade(const PtParams& p, const WfBuffers& wf, uint32_t q_ou
     uint32_t blocks = (p.n_items + 255u) / 256u;
     if (blocks == 0) return hipSuccess;
     const bool tex = p.sc.tex.nodes != nullptr, pmj = p.sampler != 0;
+    const bool inst = p.sc.in2.on != 0;
+#define AKR_WF_SHADE(T, S, Q, L)                                                                                              \
+    {                                                                                                                       \
+        if (inst) hipLaunchKernelGGL((k_wf_shade<T, S, true>), dim3(blocks), dim3(256), L, stream, Q, wf, q_out);              \
+        else hipLaunchKernelGGL((k_wf_shade<T, S, false>), dim3(blocks), dim3(256), L, stream, Q, wf, q_out);                  \
+    }
     if (tex) {
         size_t lds;
         const PtParams q = with_tex_slots(p, 0, lds);
-        if (pmj) hipLaunchKernelGGL((k_wf_shade<true, true>), dim3(blocks), dim3(256), lds, stream, q, wf, q_out);
-        else hipLaunchKernelGGL((k_wf_shade<true, false>), dim3(blocks), dim3(256), lds, stream, q, wf, q_out);
+        if (pmj) AKR_WF_SHADE(true, true, q, lds) else AKR_WF_SHADE(true, false, q, lds)
     } else {
-        if (pmj) hipLaunchKernelGGL((k_wf_shade<false, true>), dim3(blocks), dim3(256), 0, stream, p, wf, q_out);
-        else hipLaunchKernelGGL((k_wf_shade<false, false>), dim3(blocks), dim3(256), 0, stream, p, wf, q_out);
+        if (pmj) AKR_WF_SHADE(false, true, p, 0) else AKR_WF_SHADE(false, false, p, 0)
     }
+#undef AKR_WF_SHADE
     return hipGetLastError();
 }
 // Workgroups of the persistent trace kernel one CU holds at once (registers and the LDS stacks of this scene's tree decide).
@@ -267,17 +305,23 @@ uint32_t wf_trace_blocks_per_cu(const PtParams& p) {
     const bool tex = p.sc.tex.nodes != nullptr;
     size_t lds = (size_t)p.sc.bvh_stack_depth * 256 * 4;
     if (tex) (void)with_tex_slots(p, lds, lds);
-    hipError_t e = tex ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wf_trace<true>, 256, lds)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wf_trace<false>, 256, lds);
+    const bool inst = p.sc.in2.on != 0;
+    hipError_t e = inst ? (tex ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wf_trace<true, true>, 256, lds)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wf_trace<false, true>, 256, lds))
+                        : (tex ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wf_trace<true, false>, 256, lds)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wf_trace<false, false>, 256, lds));
     if (e != hipSuccess || n < 1) n = 4;
     return (uint32_t)std::min(n, 8);
 }
 hipError_t launch_wf_trace(const PtParams& p, const WfBuffers& wf, uint32_t q_in, uint32_t n_blocks, hipStream_t stream) {
+    const bool inst = p.sc.in2.on != 0;
     if (p.sc.tex.nodes != nullptr) {
         size_t lds;
         const PtParams q = with_tex_slots(p, p.sc.bvh_stack_depth * 256 * 4, lds);
-        hipLaunchKernelGGL(k_wf_trace<true>, dim3(n_blocks), dim3(256), lds, stream, q, wf, q_in);
-    } else hipLaunchKernelGGL(k_wf_trace<false>, dim3(n_blocks), dim3(256), p.sc.bvh_stack_depth * 256 * 4, stream, p, wf, q_in);
+        if (inst) hipLaunchKernelGGL((k_wf_trace<true, true>), dim3(n_blocks), dim3(256), lds, stream, q, wf, q_in);
+        else hipLaunchKernelGGL((k_wf_trace<true, false>), dim3(n_blocks), dim3(256), lds, stream, q, wf, q_in);
+    } else if (inst) hipLaunchKernelGGL((k_wf_trace<false, true>), dim3(n_blocks), dim3(256), p.sc.bvh_stack_depth * 256 * 4, stream, p, wf, q_in);
+    else hipLaunchKernelGGL((k_wf_trace<false, false>), dim3(n_blocks), dim3(256), p.sc.bvh_stack_depth * 256 * 4, stream, p, wf, q_in);
     return hipGetLastError();
 }
 

@@ -184,14 +184,27 @@ def test_per_scene_kernel_of_a_kept_scene(ctx, root, sampler):
     assert n_bit_diff(films[1], o) == 0
 
 
-def test_the_wavefront_option_is_ignored_on_a_kept_scene(ctx, root):
-    sd = instanced_scene(width=16, height=16, n_inst=4)
-    with capi.options(instancing=1):
+@pytest.mark.parametrize("case", ["constant", "textured_alpha", "sobol_fd", "sorted"])
+def test_wavefront_schedule_on_a_kept_scene(ctx, root, case):
+    """Round 6: the persistent trace kernel walks the two-level structure too (k_wf_trace<.., INST>: candidates wait in the lane's pending
+    slot, the wave takes the exact test in batches); the shade kernel rebuilds the hit from mesh triangle + instance. Same film as the
+    megakernel's and the oracle's."""
+    sd = _kept_scene_data(root, case == "textured_alpha", 48, 40)
+    cfg = make_config(spp=8, spp_per_pass=4, max_depth=8, **({"sampler_type": abi.SAMPLER_SOBOL, "sampler_seed": 5, "force_diffuse": 1} if case == "sobol_fd" else {}))
+    with capi.options(instancing=1, wavefront=1, wf_sort=1 if case == "sorted" else 0):
         scene = capi.Scene(ctx, sd)
-    with capi.options(wavefront=1):  # ignored: the megakernel renders
-        f2 = capi.Film(ctx, 16, 16)
-        st = capi.pt_render(ctx, scene, make_config(spp=2, spp_per_pass=2), f2)
-        assert st["n_samples"] == 16 * 16 * 2
+        assert scene.info().uses_bvh == 2
+        film = capi.Film(ctx, 48, 40)
+        se = capi.PtSession(ctx, scene, cfg, film)
+        se.passes(2, blocking=True)
+        status = se.kernel_info()["status"]
+        st = se.end()
+    if case == "textured_alpha":
+        assert "wavefront" in status, status  # (the reason a textured session has no per-scene kernel: the wavefront schedule runs it)
+    o, ost = _oracle(sd, cfg)
+    assert n_bit_diff(film.read(), o) == 0
+    for k in ("n_samples", "n_closest", "n_shadow", "n_shaded"):
+        assert st[k] == ost[k], k
 
 
 def test_forest_of_ten_million_instance_triangles_on_a_tile_shard(ctx, root):
