@@ -44,8 +44,9 @@ AKR_D void trav_begin_inst(TravI& s, vec3 o, vec3 d, float tmin, float tmax, uin
 }
 
 // the ray into the object space of the instance of a TLAS leaf record (rows of the inverse transform | ids)
-AKR_D void trav_into_instance(TravI& s, uint4 w0, uint4 w1, uint4 w2, uint4 w3) {
-    s.inst = w3.z; s.node_off = w3.x; s.tri_off = w3.y; s.gid_base = w3.w;
+AKR_D void trav_into_instance(const DScene& sc, TravI& s, uint4 w0, uint4 w1, uint4 w2, uint4 w3) {
+    s.inst = w3.z; s.node_off = w3.x; s.tri_off = w3.y;
+    s.gid_base = f2u(sc.inst[(size_t)w3.z * INST_ROWS + 5].w);  // (w3.w = the node of the mesh's tree this leaf record starts at)
     const vec3 r0 = mk3(u2f(w0.x), u2f(w0.y), u2f(w0.z)), r1 = mk3(u2f(w1.x), u2f(w1.y), u2f(w1.z)), r2 = mk3(u2f(w2.x), u2f(w2.y), u2f(w2.z));
     const vec3 oo = mk3(dot(r0, s.wo) + u2f(w0.w), dot(r1, s.wo) + u2f(w1.w), dot(r2, s.wo) + u2f(w2.w));
     const vec3 od = mk3(dot(r0, s.wd), dot(r1, s.wd), dot(r2, s.wd));
@@ -158,8 +159,8 @@ AKR_D bool trav_step_inst(const DScene& sc, TravI& s, uint32_t* __restrict__ sta
             cnt.overflow = 1;
         }
         s.leaf = s.tbase + b;
-        trav_into_instance(s, w0, w1, w2, w3);
-        s.G = 1u << (24u + (s.octinv4 & 7u));  // the group {BLAS root}: base 0 (relative), slot 0
+        trav_into_instance(sc, s, w0, w1, w2, w3);
+        s.G = (1u << (24u + (s.octinv4 & 7u))) | w3.w;  // the group {entry node}: base = the node (relative; 0 = the root), slot 0
         s.T = 0; s.tbase = 0;
     }
     // ---- stage 2: a node of either level: disect.h trav_step's box test on the current level's ray
@@ -325,7 +326,7 @@ AKR_D void trace_pair_inst(const DScene& sc, bool has_ray, vec3 ro, vec3 rd, uin
         s.leaf = cy[13 * 256]; s.pend_rec = cy[14 * 256]; s.pend_inst = cy[15 * 256];
         if (s.leaf != kInvalid) {
             const uint4* lf = sc.in2.tlas_leaves + (size_t)s.leaf * 4;
-            trav_into_instance(s, lf[0], lf[1], lf[2], lf[3]);
+            trav_into_instance(sc, s, lf[0], lf[1], lf[2], lf[3]);
         }
         s.active = (s.T != 0) | ((s.G >> 24) != 0) | (s.sp != 0);
     }

@@ -42,7 +42,7 @@ struct LightRec {  // one light = one emissive instance: where its triangles sit
 // A scene kept as meshes + instances (host/scene_inst.cpp; two-level traversal: disect.h trav_step_inst). When `on`, the per
 // instance-triangle arrays of DScene (woop, shade, normals, tri_gid) are null and bvh_nodes holds the TLAS followed by the BLASes.
 struct DInst {
-    const uint4* __restrict__ tlas_leaves;     // 64 B per instance in TLAS order: world->object rows | BLAS node offset, mesh triangle base, instance, first gid
+    const uint4* __restrict__ tlas_leaves;     // 64 B per top-level leaf entry (one or more per instance, TLAS order): world->object rows | BLAS node offset, mesh triangle base, instance, entry node
     const float4* __restrict__ mesh_tris;      // 64 B per mesh triangle in BLAS order: v0 | uv0.x, v1 | uv0.y, v2 | uv1.x, uv1.y uv2.x uv2.y | prim
     const uint32_t* __restrict__ mesh_pos;     // mesh order -> position in mesh_tris (relative to the mesh's base)
     const uint32_t* __restrict__ mesh_meta;    // mesh order: material slot | TRI_HAS_* << 30

@@ -186,6 +186,11 @@ struct akr_pt_session {
     uint32_t *wf_sorted_closest = nullptr, *wf_sorted_shadow = nullptr, *wf_sorted_keys = nullptr;
     WfBuffers wf;
     uint32_t wf_slots = 0, wf_trace_blocks = 0;
+    // slot groups (option wf_groups; api_pt.cpp wf_run): each with its own queues, counters and stream
+    std::vector<WfBuffers> wf_group;
+    std::vector<hipStream_t> wf_streams;
+    std::vector<hipEvent_t> wf_join;
+    hipEvent_t wf_fork = nullptr;
     uint32_t spp_done = 0, n_launches = 0;
     uint64_t passes_launched = 0;  // passes of all akr_pt_passes launches so far (kernel_ms / passes_launched = what a pass costs)
     uint32_t pmj_spp = 1;  // the spp the pmj02bn sampler stratifies for (the method's total spp)
@@ -224,6 +229,9 @@ struct akr_pt_session {
         pending.resize(keep);
     }
     ~akr_pt_session() {
+        for (hipStream_t st : wf_streams) (void)hipStreamDestroy(st);
+        for (hipEvent_t ev : wf_join) (void)hipEventDestroy(ev);
+        if (wf_fork) (void)hipEventDestroy(wf_fork);
         for (auto& ev : pending) {
             (void)hipEventDestroy(ev.first);
             (void)hipEventDestroy(ev.second);

@@ -136,16 +136,33 @@ void akr_api::fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_p
     p.n_items = owned * p.tile_w * p.tile_h;
 }
 
-// Which schedule renders this session: "mega" = persistent-lane megakernel (pt_kernels.hip), "wavefront" = trace /
-// shade kernels with the path state in HBM (wf_kernels.hip; needs a BVH scene). AKR_PT_MODE selects; the default is the
-// megakernel, which measured faster on every configuration so far (on the 10 M-triangle hall both
-// schedules trace 3.3 - 3.7 G rays/s -- the traversal is bound by the memory system's rate for random 64-byte records, not by
-// occupancy -- and the wavefront schedule pays for streaming the path state and for its per-iteration tail on top).
-// The option is process-wide and aov / gpt / mcmc_opt sessions come through here too: a scene without a BVH (64 triangles or
-// fewer, no force_bvh) has no wavefront kernels and renders with the megakernel whatever the option says.
-static bool choose_wavefront(const akr_scene* scene) {
-    if (!tuning().wavefront) return false;
-    return !scene->cs.bvh_nodes.empty() || scene->cs.instanced.on;  // (round 6: kept scenes too -- k_wf_trace<.., INST> over the two-level traversal)
+// Which schedule renders this session: the persistent-lane megakernel (pt_kernels.hip, pt_inst_kernels.hip) or the wavefront schedule --
+// trace / shade kernels with the path state in HBM (wf_kernels.hip; needs a scene with a tree). Option wavefront: 1 = wherever it can run,
+// 0 = never, -1 (default) = the library decides:
+//   * flattened scenes: the megakernel, which measured faster on every one (on the 10 M-triangle hall both schedules
+//     are bound by the memory system's rate for random 64-byte records, and the wavefront schedule pays for streaming the path state on top);
+//   * scenes kept as meshes + instances: the WAVEFRONT schedule for pt sessions of at least kWfAutoItems pixels (round 6). The two-level
+//     traversal with its exact test spills 172 registers inside the megakernel (one lane = one whole path) and none in k_wf_trace, and the
+//     trace kernel refills a wave's idle lanes where the megakernel's wait: 1080p forest 1000 x 10 k triangles 163 -> 228 Msamples/s, 4K
+//     177 -> 282 (x 100 k: 113 -> 136 with two slot groups, 4K 125 -> 179). Below that size the persistent trace kernel's 262 k lanes
+//     are not filled and the megakernel wins (1024 x 1024, x 100 k: 124 against 85) -- profiles/r6_kept_schedules.txt. Kept scenes with
+//     texture-fed materials stay on the megakernel (its per-scene kernels evaluate the shader graphs; k_wf_shade interprets them).
+// The option is process-wide and aov / gpt / mcmc_opt sessions come through here too: they render with their own kernels; a scene without a
+// tree (64 triangles or fewer, no force_bvh) has no wavefront kernels and renders with the megakernel whatever the option says.
+constexpr uint32_t kWfAutoItems = 2000000;
+static uint32_t session_items(const akr_pt_config& c, uint32_t width, uint32_t height) {  // = fill_params' n_items
+    const uint32_t tw = c.tile_w ? c.tile_w : 32, th = c.tile_h ? c.tile_h : 32;
+    const uint32_t n_tiles = ((width + tw - 1) / tw) * ((height + th - 1) / th);
+    const uint32_t rank = c.shard_count > 1 ? c.shard_rank : 0, count = c.shard_count > 1 ? c.shard_count : 1;
+    return (rank < n_tiles ? (n_tiles - rank + count - 1) / count : 0) * tw * th;
+}
+static bool choose_wavefront(const akr_scene* scene, const akr_pt_config& cfg, bool for_pt_kernel) {
+    const int opt = tuning().wavefront;
+    const bool can = !scene->cs.bvh_nodes.empty() || scene->cs.instanced.on;
+    if (opt == 0 || !can) return false;
+    if (opt > 0) return true;
+    return for_pt_kernel && scene->cs.instanced.on && !scene->cs.has_textures &&
+           session_items(cfg, scene->flat.camera.width, scene->flat.camera.height) >= kWfAutoItems;
 }
 
 static void wf_allocate(akr_pt_session* se, uint32_t n_slots) {
@@ -172,9 +189,49 @@ static void wf_allocate(akr_pt_session* se, uint32_t n_slots) {
         se->wf_sorted_keys = se->wf_sorted_closest + 2 * n;
         se->wf_sort_tmp.alloc(wf_sort_temp_bytes((uint32_t)n));
     }
-    se->wf_ctrl.alloc(8 * sizeof(uint32_t));
-    uint32_t* c = (uint32_t*)se->wf_ctrl.p;
-    w.qcount = c; w.qhead = c + 4; w.n_active = c + 5;
+    // ---- slot groups. A trace launch ends with its slowest rays, a hundred dependent fetches deep, while the rest of the chip idles, and a
+    // launch group is a hundred such launches (the slots with the longest paths decide): measured on the kept 1080p forest that tail is
+    // 19 ms of 73 ms (1000 x 10 k triangles) and 69 ms of 144 ms (x 100 k) per 8 spp -- tools/kept_schedules.py at four frame sizes,
+    // HISTORY R6.6. The slots are therefore divided into groups that run the same init / trace / shade chain on streams of their own:
+    // one group's kernels fill the CUs another's tail leaves idle. Nothing a slot computes depends on which group it is in.
+    // Measured (profiles/r6_kept_schedules.txt, 1080p): two groups 113 -> 136 Msamples/s on the kept forest of 100 k-triangle meshes (its trace
+    // launches wait on memory -- the meshes do not fit the L2s -- and the other group's shade launch streams meanwhile), 228 -> 221 on the
+    // 10 k-triangle one, 208 -> 213 on the flattened hall; four groups and more lose everywhere (each group's launches are shorter and their
+    // ends no better filled). Option wf_groups: 0 = the library decides (two for a kept scene whose meshes exceed the L2s, else one).
+    const akr_scene* sc = se->scene;
+    const size_t mesh_bytes = sc->cs.instanced.on ? (sc->cs.instanced.nodes.size() + sc->cs.instanced.mesh_tris.size()) * 4 : 0;
+    const int opt_groups = tuning().wf_groups;
+    uint32_t groups = se->wf_sort ? 1u : (opt_groups > 0 ? (uint32_t)opt_groups : (mesh_bytes > (16u << 20) ? 2u : 1u));
+    groups = std::min(groups, std::max(1u, n_slots / 65536u));  // (small frames: a group should still be a few waves per CU)
+    se->wf_ctrl.alloc((size_t)groups * 8 * sizeof(uint32_t));  // per group: qcount[4], qhead, n_active
+    se->wf_group.clear();
+    for (uint32_t g = 0; g < groups; g++) {
+        WfBuffers wg = w;
+        // boundaries on whole 1024-slot tiles
+        auto bound = [&](uint32_t k) { return k >= groups ? n_slots : (uint32_t)(((uint64_t)n_slots * k / groups) & ~1023ull); };
+        wg.slot_base = bound(g);
+        wg.slot_end = bound(g + 1);
+        for (int k = 0; k < 2; k++) {  // a group's queues: its share of the session's
+            wg.queue_closest[k] = w.queue_closest[k] + wg.slot_base;
+            wg.queue_shadow[k] = w.queue_shadow[k] + wg.slot_base;
+        }
+        uint32_t* c = (uint32_t*)se->wf_ctrl.p + 8 * g;
+        wg.qcount = c; wg.qhead = c + 4; wg.n_active = c + 5;
+        se->wf_group.push_back(wg);
+    }
+    for (hipStream_t st : se->wf_streams) (void)hipStreamDestroy(st);
+    se->wf_streams.clear();
+    if (groups > 1) {
+        for (uint32_t g = 0; g < groups; g++) {
+            hipStream_t st = nullptr;
+            HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            se->wf_streams.push_back(st);
+            hipEvent_t ev = nullptr;
+            HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            se->wf_join.push_back(ev);
+        }
+        if (!se->wf_fork) HIP_CHECK(hipEventCreateWithFlags(&se->wf_fork, hipEventDisableTiming));
+    }
     // persistent trace kernel: as many workgroups as the CUs hold at once (occupancy API: registers + this tree's LDS stacks)
     se->wf_trace_blocks = (uint32_t)se->ctx->props.multiProcessorCount * wf_trace_blocks_per_cu(se->params);
 }
@@ -182,46 +239,77 @@ static void wf_allocate(akr_pt_session* se, uint32_t n_slots) {
 // One launch group of the wavefront schedule = `fused` passes for every slot: init, then trace/shade iterations until
 // no slot is active. The host only looks at the device every kCheckEvery iterations.
 static void wf_run(akr_pt_session* se) {
-    hipStream_t st = se->ctx->stream;
+    hipStream_t main_st = se->ctx->stream;
     const PtParams& p = se->params;
-    uint32_t* ctrl = (uint32_t*)se->wf_ctrl.p;
-    HIP_CHECK(hipMemsetAsync(ctrl, 0, 8 * sizeof(uint32_t), st));
-    HIP_CHECK(launch_wf_init(p, se->wf, st));
+    const uint32_t groups = (uint32_t)se->wf_group.size();
+    HIP_CHECK(hipMemsetAsync(se->wf_ctrl.p, 0, se->wf_ctrl.bytes, main_st));
+    std::vector<hipStream_t> streams(groups, main_st);
+    if (groups > 1) {  // the groups' streams start after everything the session's stream holds so far ...
+        HIP_CHECK(hipEventRecord(se->wf_fork, main_st));
+        for (uint32_t g = 0; g < groups; g++) {
+            streams[g] = se->wf_streams[g];
+            HIP_CHECK(hipStreamWaitEvent(streams[g], se->wf_fork, 0));
+        }
+    }
+    struct Join {  // ... and the session's stream goes on after all of them, also when this function is left by an exception
+        akr_pt_session* se; std::vector<hipStream_t>& st; hipStream_t main_st;
+        ~Join() {
+            if (st.size() < 2) return;
+            for (size_t g = 0; g < st.size(); g++) {
+                (void)hipEventRecord(se->wf_join[g], st[g]);
+                (void)hipStreamWaitEvent(main_st, se->wf_join[g], 0);
+            }
+        }
+    } join{se, streams, main_st};
+    for (uint32_t g = 0; g < groups; g++) HIP_CHECK(launch_wf_init(p, se->wf_group[g], streams[g]));
     const int kCheckEvery = 16;
     uint32_t q = 0;
+    std::vector<uint8_t> done(groups, 0);
     for (uint64_t iter = 0;; iter++) {
-        // option wf_sort: the sizes of the queue this iteration traces (rocPRIM wants the element count on the host): one small read-back
-        // per iteration, before the counters are reset -- it also ends the loop the moment the last path has finished
+        // option wf_sort (one group): the sizes of the queue this iteration traces (rocPRIM wants the element count on the host): one small
+        // read-back per iteration, before the counters are reset -- it also ends the loop the moment the last path has finished
         uint32_t nc = 0, ns = 0;
         const bool sort_now = se->wf_sort && iter > 0;  // (the first iteration's camera rays are in pixel order: coherent as they are)
         if (sort_now) {
             uint32_t counts[6];
-            HIP_CHECK(hipMemcpyAsync(counts, ctrl, sizeof counts, hipMemcpyDeviceToHost, st));
-            HIP_CHECK(hipStreamSynchronize(st));
+            HIP_CHECK(hipMemcpyAsync(counts, se->wf_ctrl.p, sizeof counts, hipMemcpyDeviceToHost, main_st));
+            HIP_CHECK(hipStreamSynchronize(main_st));
             if (counts[5] == 0) break;  // n_active after the last shade
             nc = counts[2 * q];
             ns = counts[2 * q + 1];
         }
-        // queue q holds the rays to trace; reset the head, the other queue's counts and the active counter
-        HIP_CHECK(hipMemsetAsync(ctrl + 2 * (1 - q), 0, 2 * sizeof(uint32_t), st));
-        HIP_CHECK(hipMemsetAsync(ctrl + 4, 0, 2 * sizeof(uint32_t), st));
-        if (sort_now) {
-            WfBuffers sorted = se->wf;
-            HIP_CHECK(wf_sort_pairs(se->wf_sort_tmp.p, se->wf_sort_tmp.bytes, se->wf.key_closest[q], se->wf_sorted_keys, se->wf.queue_closest[q], se->wf_sorted_closest, nc, st));
-            HIP_CHECK(wf_sort_pairs(se->wf_sort_tmp.p, se->wf_sort_tmp.bytes, se->wf.key_shadow[q], se->wf_sorted_keys, se->wf.queue_shadow[q], se->wf_sorted_shadow, ns, st));
-            sorted.queue_closest[q] = se->wf_sorted_closest;
-            sorted.queue_shadow[q] = se->wf_sorted_shadow;
-            HIP_CHECK(launch_wf_trace(p, sorted, q, se->wf_trace_blocks, st));
-        } else {
-            HIP_CHECK(launch_wf_trace(p, se->wf, q, se->wf_trace_blocks, st));
+        for (uint32_t g = 0; g < groups; g++) {
+            if (done[g]) continue;
+            const WfBuffers& wg = se->wf_group[g];
+            hipStream_t st = streams[g];
+            uint32_t* ctrl = wg.qcount;
+            // queue q holds the rays to trace; reset the head, the other queue's counts and the active counter
+            HIP_CHECK(hipMemsetAsync(ctrl + 2 * (1 - q), 0, 2 * sizeof(uint32_t), st));
+            HIP_CHECK(hipMemsetAsync(ctrl + 4, 0, 2 * sizeof(uint32_t), st));
+            if (sort_now) {
+                WfBuffers sorted = wg;
+                HIP_CHECK(wf_sort_pairs(se->wf_sort_tmp.p, se->wf_sort_tmp.bytes, wg.key_closest[q], se->wf_sorted_keys, wg.queue_closest[q], se->wf_sorted_closest, nc, st));
+                HIP_CHECK(wf_sort_pairs(se->wf_sort_tmp.p, se->wf_sort_tmp.bytes, wg.key_shadow[q], se->wf_sorted_keys, wg.queue_shadow[q], se->wf_sorted_shadow, ns, st));
+                sorted.queue_closest[q] = se->wf_sorted_closest;
+                sorted.queue_shadow[q] = se->wf_sorted_shadow;
+                HIP_CHECK(launch_wf_trace(p, sorted, q, se->wf_trace_blocks, st));
+            } else {
+                HIP_CHECK(launch_wf_trace(p, wg, q, se->wf_trace_blocks, st));
+            }
+            HIP_CHECK(launch_wf_shade(p, wg, 1 - q, st));
         }
-        HIP_CHECK(launch_wf_shade(p, se->wf, 1 - q, st));
         q = 1 - q;
         if (!se->wf_sort && (iter + 1) % kCheckEvery == 0) {
-            uint32_t n_active = 0;
-            HIP_CHECK(hipMemcpyAsync(&n_active, ctrl + 5, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            HIP_CHECK(hipStreamSynchronize(st));
-            if (n_active == 0) break;
+            std::vector<uint32_t> n_active(groups, 0);
+            for (uint32_t g = 0; g < groups; g++)
+                if (!done[g]) HIP_CHECK(hipMemcpyAsync(&n_active[g], se->wf_group[g].n_active, sizeof(uint32_t), hipMemcpyDeviceToHost, streams[g]));
+            bool all = true;
+            for (uint32_t g = 0; g < groups; g++) {
+                if (done[g]) continue;
+                HIP_CHECK(hipStreamSynchronize(streams[g]));
+                if (n_active[g] == 0) done[g] = 1; else all = false;
+            }
+            if (all) break;
         }
         if (iter > (1ull << 26)) throw RenderError("wavefront schedule did not terminate");
     }
@@ -330,7 +418,7 @@ int32_t akr_api::pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_confi
         }
         se->counters.alloc(8 * kStatStripes * sizeof(uint64_t));
         HIP_CHECK(hipMemsetAsync(se->counters.p, 0, se->counters.bytes, ctx->stream));
-        se->wavefront = choose_wavefront(scene);
+        se->wavefront = choose_wavefront(scene, *cfg, for_pt_kernel);
         se->wf_sort = se->wavefront && tuning().wf_sort != 0;
         {
             const TuningOptions t = tuning();
@@ -349,10 +437,10 @@ int32_t akr_api::pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_confi
             se->arith_relaxed = t.arith == 1 && for_pt_kernel && !scene->cs.instanced.on && !se->wavefront;
             if (!for_pt_kernel) se->spec_status = "not a pt session";
             else if (se->arith_relaxed) se->spec_status = "relaxed arithmetic tier: precompiled kernels";
+            else if (se->wavefront) se->spec_status = "wavefront schedule";
             else if (!scene->cs.has_textures) se->spec_status = "the scene has no texture-fed material";
             else if (t.specialise == 0) se->spec_status = "option specialise = 0";
             else if (cfg->force_diffuse) se->spec_status = "force_diffuse kernels evaluate no surface graphs";
-            else if (se->wavefront) se->spec_status = "wavefront schedule";
             else {
                 {
                     std::lock_guard<std::mutex> lock(scene->spec_mutex);

@@ -817,12 +817,14 @@ void tuning_init_locked() {
     g_tuning.force_bvh = flag("AKR_FORCE_BVH");
     g_tuning.bvh_balanced = flag("AKR_BVH_BALANCED");
     if (const char* e = std::getenv("AKR_PT_DEFER_METAL")) g_tuning.defer_metal = std::atoi(e);
-    if (const char* e = std::getenv("AKR_PT_MODE")) g_tuning.wavefront = std::string(e) == "wavefront" ? 1 : 0;
+    if (const char* e = std::getenv("AKR_PT_MODE")) g_tuning.wavefront = std::string(e) == "wavefront" ? 1 : (std::string(e) == "auto" ? -1 : 0);
     if (const char* e = std::getenv("AKR_PT_SIMPLE")) g_tuning.simple_kernels = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("AKR_SPECIALISE")) g_tuning.specialise = std::atoi(e);
     if (const char* e = std::getenv("AKR_SPECIALISE_WAVES")) g_tuning.specialise_waves = std::atoi(e);
     if (const char* e = std::getenv("AKR_WF_SORT")) g_tuning.wf_sort = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("AKR_INSTANCING")) g_tuning.instancing = std::atoi(e);
+    if (const char* e = std::getenv("AKR_WF_GROUPS")) g_tuning.wf_groups = std::max(0, std::min(32, std::atoi(e)));
+    if (const char* e = std::getenv("AKR_REBRAID")) g_tuning.rebraid = std::max(1, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("AKR_ARITH")) g_tuning.arith = std::atoi(e) != 0 ? 1 : 0;
 }
 int* tuning_field(const char* name) {
@@ -839,6 +841,8 @@ int* tuning_field(const char* name) {
     if (n == "wf_sort") return &g_tuning.wf_sort;
     if (n == "instancing") return &g_tuning.instancing;
     if (n == "arith") return &g_tuning.arith;
+    if (n == "rebraid") return &g_tuning.rebraid;
+    if (n == "wf_groups") return &g_tuning.wf_groups;
     if (n == "pad_percent") return &g_tuning.pad_percent;
     return nullptr;
 }
@@ -860,6 +864,9 @@ bool tuning_set(const char* name, int value) {
     if (f == &g_tuning.wf_sort && (value < 0 || value > 1)) return false;
     if (f == &g_tuning.instancing && (value < -1 || value > 1)) return false;
     if (f == &g_tuning.arith && (value < 0 || value > 1)) return false;
+    if (f == &g_tuning.rebraid && (value < 1 || value > 64)) return false;
+    if (f == &g_tuning.wf_groups && (value < 0 || value > 32)) return false;
+    if (f == &g_tuning.wavefront && (value < -1 || value > 1)) return false;
     if (f == &g_tuning.pad_percent && (value < 1 || value > 10000)) return false;
     *f = value;
     return true;

@@ -90,8 +90,8 @@ struct CompiledScene {
         bool on = false;
         std::vector<uint32_t> nodes;        // TLAS nodes (root = slot 0) followed by every mesh's BLAS nodes; child_base / tri_base are
                                             // relative to the start of their own tree
-        std::vector<float> tlas_leaves;     // 16 words per instance in TLAS order: world->object rows (3 x float4) | BLAS node offset, mesh triangle
-                                            // base, instance id, global id of the instance's first triangle
+        std::vector<float> tlas_leaves;     // 16 words per top-level leaf entry (one per instance; more with option rebraid) in TLAS order: world->object
+                                            // rows (3 x float4) | BLAS node offset, mesh triangle base, instance id, the node of the mesh's tree to start at
         std::vector<float> mesh_tris;       // 16 words per mesh triangle in BLAS order: v0 | uv0.x, v1 | uv0.y, v2 | uv1.x, uv1.y uv2.x uv2.y | prim
         std::vector<uint32_t> mesh_pos;     // per mesh triangle in MESH order: its position in mesh_tris (relative to the mesh's base)
         std::vector<uint32_t> mesh_meta;    // per mesh triangle in mesh order: material slot | TRI_HAS_* flags << 30
@@ -168,29 +168,35 @@ void build_alias_table(const std::vector<float>& weights, std::vector<AliasEntry
 //   force_bvh    AKR_FORCE_BVH=1          scenes of <= 64 triangles get a BVH too (both intersectors on one scene)
 //   bvh_balanced AKR_BVH_BALANCED=1       the median-split fallback builder instead of SAH
 //   defer_metal  AKR_PT_DEFER_METAL=<m>   -1 = the library decides (default); 0 = off; m > 0 = iterations with (i & m) != 0 put conductor hits off
-//   wavefront    AKR_PT_MODE=wavefront    1 = sessions on BVH scenes use the wavefront schedule (wf_kernels.hip) instead of the megakernel
+//   wavefront    AKR_PT_MODE=wavefront|megakernel   the wavefront schedule (wf_kernels.hip) instead of the megakernel: 1 = wherever it can run, 0 = never,
+//                                         -1 = the library decides (default: pt sessions of >= 2 M pixels on untextured scenes kept as meshes + instances)
 //   simple_kernels AKR_PT_SIMPLE=0        0 = never use the SIMPLE instantiations (scenes without coat / transmission / normal map / glass)
 //   defer_on     (no environment hook)   BVH kernels of textured scenes: which hits the deferral puts off (0 / 1 conductor lobe, 2 texture-fed, 3 both)
 //   specialise   AKR_SPECIALISE=<v>       per-scene kernels for scenes with texture-fed materials (host/specialise.cpp): -1 = the library decides (a cached
 //                                         kernel always; a compile for renders of at least kSpecAutoSamples samples), 0 = never (the interpreter), 1 = always
 //   specialise_waves AKR_SPECIALISE_WAVES=<n>  waves per SIMD a per-scene kernel is compiled for: 0 = the library's choice, else 2..4
 //   instancing   AKR_INSTANCING=<v>       meshes + instances kept as they are (BLAS per mesh, TLAS over instances; scene_inst.cpp): -1 auto, 0 never, 1 always
+//   rebraid      AKR_REBRAID=<k>          scenes kept as meshes + instances: the top-level tree is built over k x as many (instance, subtree) pairs as
+//                                         there are instances, the largest instance boxes opened first (scene_inst.cpp); 1 = one pair per instance
 //   arith        AKR_ARITH=1              pt megakernel in the relaxed arithmetic tier (flattened scenes; precompiled kernels): hardware rcp / sqrt /
 //                                         sin / cos / log / exp and contraction instead of the bit-exact contract
 //   pad_percent  (no environment hook)    test hook: box padding in percent of the derived value (100)
 //   wf_sort      AKR_WF_SORT=1            wavefront schedule: ray queues sorted by origin cell + direction octant before each trace launch
+//   wf_groups    AKR_WF_GROUPS=<g>        wavefront schedule: the slots run as g groups with queues and streams of their own (api_pt.cpp wf_run); 0 = the library decides
 //   max_fused_passes (no environment hook)     most passes akr_pt_passes fuses into one launch: 0 = adaptive (16, up to 64 once a pass has been timed), else 1..64
 struct TuningOptions {
-    int force_bvh = 0, bvh_balanced = 0, defer_metal = -1, wavefront = 0, simple_kernels = 1;
+    int force_bvh = 0, bvh_balanced = 0, defer_metal = -1, wavefront = -1, simple_kernels = 1;
     int defer_on = 0;  // BVH kernels of textured scenes: which hits the deferral puts off -- 0 / 1 = the conductor lobe (default), 2 = texture-fed materials, 3 = both
     int specialise = -1, specialise_waves = 0;
     int max_fused_passes = 0;
     int instancing = -1;  // two-level acceleration structure for scenes whose meshes are instanced: -1 the library decides (flattening is the
                           // default while its records fit a budget), 0 never, 1 whenever a mesh has more than one instance
+    int rebraid = 1;  // kept scenes: (instance, subtree) pairs of the top-level tree per instance, on average (partial re-braiding); 1 = off
     int arith = 0;    // arithmetic tier of the pt megakernel: 0 = the AKR-F32 contract (bit-exact with the oracle), 1 = relaxed (pt_kernels_relaxed.hip:
                       // films within north_star's relRMSE < 1e-3 of the oracle, not identical to it)
     int pad_percent = 100;  // test hook: the padding of the acceleration structures' boxes (flat part and needle part) in percent of what the compiler derives --
                             // tests/test_bvh_conservative.py shows with it how far the derived padding is from the first lost hit
+    int wf_groups = 0;  // wavefront schedule: slot groups whose init / trace / shade chains run side by side on streams of their own (1 = one chain, 0 = the library decides)
     int wf_sort = 0;  // wavefront schedule: 1 = the ray queues are sorted by (Morton code of the origin, octant) before every trace launch (wf_sort.hip)
 };
 constexpr uint64_t kSpecAutoSamples = 1ull << 31;  // option specialise = -1: a first-use compile (about a second; 20-30 % of the render to win) has to be worth it

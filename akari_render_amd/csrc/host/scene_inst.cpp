@@ -67,6 +67,71 @@ void singular_range(const float* m, double& smax, double& smin) {
                        (double)m[8] * ((double)m[1] * m[6] - (double)m[5] * m[2]);
     if (smax > 0.0) smin = std::min(smin > 0.0 ? smin : 1e300, std::fabs(det) / (smax * smax));  // s0 s1 s2 = |det|, s1 <= s0  =>  s2 >= |det| / s0^2
 }
+
+// ---- a per-mesh tree as build_bvh8 wrote it, decoded for the host (bvh.cpp: node layout)
+struct TreeNode {
+    float lo[3], hi[3];        // object-space box of everything below (from the padded triangle boxes the tree was built over)
+    uint32_t inner[6];         // inner children: node indices relative to the tree
+    uint32_t tri_first[6];     // leaf children: first triangle (tree order), count
+    uint8_t tri_count[6];
+    uint8_t n_inner = 0, n_leaf = 0;
+};
+void decode_tree_nodes(const std::vector<uint32_t>& words, const std::vector<uint32_t>& order, const std::vector<float>& bounds, std::vector<TreeNode>& out) {
+    const size_t n_nodes = words.size() / kBvhNodeWords;
+    out.assign(n_nodes, TreeNode());
+    std::vector<uint8_t> reached(n_nodes, 0);
+    // children first: walk from the root, remember the visiting order, fold the boxes in reverse
+    std::vector<uint32_t> visit;
+    visit.reserve(n_nodes);
+    visit.push_back(0);
+    reached[0] = 1;
+    for (size_t v = 0; v < visit.size(); v++) {
+        const uint32_t idx = visit[v];
+        const uint32_t* n = &words[(size_t)kBvhNodeWords * idx];
+        TreeNode& t = out[idx];
+        const uint32_t child_base = (n[3] >> 24) | ((n[4] & 0xffffu) << 8), tri_base = n[6];
+        for (int e = 0; e < 6; e++) {
+            const uint32_t meta = e < 4 ? (n[5] >> (8 * e)) & 0xffu : (n[4] >> (16 + 8 * (e - 4))) & 0xffu;
+            if (meta == 0) continue;
+            if ((meta >> 5) == 1u && (meta & 0x1fu) >= 24u) {
+                const uint32_t c = child_base + (meta & 0x1fu) - 24u;
+                if (c >= n_nodes || reached[c]) throw std::runtime_error("internal: malformed per-mesh tree");
+                reached[c] = 1;
+                t.inner[t.n_inner++] = c;
+                visit.push_back(c);
+            } else {
+                t.tri_first[t.n_leaf] = tri_base + (meta & 0x1fu);
+                t.tri_count[t.n_leaf] = (uint8_t)((meta >> 5) == 7u ? 3 : ((meta >> 5) == 3u ? 2 : 1));
+                t.n_leaf++;
+            }
+        }
+    }
+    for (size_t v = visit.size(); v-- > 0;) {
+        TreeNode& t = out[visit[v]];
+        for (int a = 0; a < 3; a++) { t.lo[a] = INFINITY; t.hi[a] = -INFINITY; }
+        for (int l = 0; l < t.n_leaf; l++)
+            for (uint32_t k = 0; k < t.tri_count[l]; k++) {
+                const float* bb = &bounds[6ull * order[t.tri_first[l] + k]];
+                for (int a = 0; a < 3; a++) { t.lo[a] = min_f(t.lo[a], bb[a]); t.hi[a] = max_f(t.hi[a], bb[3 + a]); }
+            }
+        for (int c = 0; c < t.n_inner; c++) {
+            const TreeNode& ch = out[t.inner[c]];
+            for (int a = 0; a < 3; a++) { t.lo[a] = min_f(t.lo[a], ch.lo[a]); t.hi[a] = max_f(t.hi[a], ch.hi[a]); }
+        }
+    }
+}
+// half the surface area of the world box of an object-space box under an instance transform (a heuristic only: which subtree to open)
+float world_half_area(const InstXf& x, const float* lo, const float* hi) {
+    float wl[3] = {INFINITY, INFINITY, INFINITY}, wh[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int c = 0; c < 8; c++) {
+        const vec3 p = xf_point(x.c0, x.c1, x.c2, x.t, mk3((c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]));
+        wl[0] = min_f(wl[0], p.x); wl[1] = min_f(wl[1], p.y); wl[2] = min_f(wl[2], p.z);
+        wh[0] = max_f(wh[0], p.x); wh[1] = max_f(wh[1], p.y); wh[2] = max_f(wh[2], p.z);
+    }
+    const float dx = wh[0] - wl[0], dy = wh[1] - wl[1], dz = wh[2] - wl[2];
+    if (!(dx >= 0.0f) || !is_finite(dx) || !is_finite(dy) || !is_finite(dz)) return 0.0f;
+    return dx * dy + dy * dz + dz * dx;
+}
 }  // namespace
 
 bool want_instancing(const FlatScene& flat) {
@@ -205,6 +270,9 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
     std::vector<float> mesh_size(n_mesh, 0.0f);
     std::vector<float> mesh_k2max(n_mesh, 0.0f);  // worst conditioning (isotropic: 2 |e1||e2| / |n|) of a mesh's triangles, scene_build.h
     const TuningOptions tune = tuning();
+    const bool rebraid = tune.rebraid > 1;
+    std::vector<std::vector<uint32_t>> mesh_order(n_mesh);   // (re-braiding only) tree order -> prim, and the decoded tree
+    std::vector<std::vector<TreeNode>> mesh_tree(n_mesh);
     for (size_t m = 0; m < n_mesh; m++) {
         if (!used[m]) continue;
         const HostMesh& g = flat.meshes[m];
@@ -256,6 +324,10 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
         build_bvh8(bounds, nt, pad_obj, kBvhNodeWords, tune.bvh_balanced != 0, order, blas_nodes[m], blas_depth[m]);
         if (blas_depth[m] > kBvhStackDepth) build_bvh8(bounds, nt, pad_obj, kBvhNodeWords, true, order, blas_nodes[m], blas_depth[m]);
         is.blas_depth = std::max(is.blas_depth, blas_depth[m]);
+        if (rebraid) {
+            decode_tree_nodes(blas_nodes[m], order, bounds, mesh_tree[m]);
+            mesh_order[m] = order;
+        }
         const uint32_t base = mesh_base[m];
         for (uint32_t k = 0; k < nt; k++) {
             const uint32_t prim = order[k];
@@ -302,21 +374,98 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
             }
         }
     }
-    // ---- TLAS over the world boxes of the instances that have triangles
-    std::vector<uint32_t> tlas_ids, tlas_order;
-    {
-        std::vector<float> tb;
-        for (size_t i = 0; i < n_inst; i++) {
-            if (flat.meshes[flat.instances[i].mesh].n_triangles() == 0) continue;
-            tlas_ids.push_back((uint32_t)i);
-            tb.insert(tb.end(), &inst_bounds[6 * i], &inst_bounds[6 * i] + 6);
-            // the instance's needles in world space: conditioning at most cond(M) x the mesh's worst
-            const float extra = pad_scale * tri_cond_extra(inst_cond[i] * mesh_k2max[flat.instances[i].mesh], box_magnitude(&inst_bounds[6 * i], &inst_bounds[6 * i + 3]), pad_world / pad_scale);
-            for (int a = 0; a < 3; a++) { tb[tb.size() - 6 + a] -= extra; tb[tb.size() - 3 + a] += extra; }
+    // ---- what the TLAS is built over: (instance, entry node of its mesh's tree) pairs. One pair per instance -- the root -- unless
+    // option rebraid > 1: then the pairs with the largest world boxes are OPENED (replaced by the children of their node) until there are
+    // rebraid x as many as instances (after Benthin, Woop, Wald, Afra, "Improved Two-Level BVHs using Partial Re-Braiding", HPG 2017:
+    // instances whose boxes overlap -- trees of a forest -- make every ray that crosses the overlap descend all of them; the top levels
+    // of their trees, taken into the world-space tree, separate what the instance boxes cannot). A node is opened only if all its
+    // children are nodes (triangles are reached through some node of the mesh's tree: a leaf record names a node to start at).
+    struct Prim { uint32_t inst, node; };
+    std::vector<Prim> prims;
+    for (size_t i = 0; i < n_inst; i++)
+        if (flat.meshes[flat.instances[i].mesh].n_triangles() != 0) prims.push_back({(uint32_t)i, 0u});
+    if (prims.empty()) throw std::invalid_argument("instanced scene without triangles");
+    if (rebraid) {
+        struct Cand { float sa; uint32_t inst, node; };
+        auto lower = [](const Cand& a, const Cand& b) {  // (a strict order: the choice does not depend on how the heap breaks ties)
+            if (a.sa != b.sa) return a.sa < b.sa;
+            if (a.inst != b.inst) return a.inst > b.inst;
+            return a.node > b.node;
+        };
+        std::vector<Cand> heap;
+        for (const Prim& pr : prims) {
+            const TreeNode& t = mesh_tree[flat.instances[pr.inst].mesh][0];
+            heap.push_back({world_half_area(xf[pr.inst], t.lo, t.hi), pr.inst, 0u});
         }
-        if (tlas_ids.empty()) throw std::invalid_argument("instanced scene without triangles");
-        build_bvh8(tb, (uint32_t)tlas_ids.size(), pad_world, kBvhNodeWords, tune.bvh_balanced != 0, tlas_order, is.nodes, is.tlas_depth);
-        if (is.tlas_depth > kBvhStackDepth) build_bvh8(tb, (uint32_t)tlas_ids.size(), pad_world, kBvhNodeWords, true, tlas_order, is.nodes, is.tlas_depth);
+        std::make_heap(heap.begin(), heap.end(), lower);
+        const uint64_t budget = std::min<uint64_t>((uint64_t)prims.size() * (uint64_t)tune.rebraid, 1ull << 22);
+        uint64_t count = prims.size();
+        prims.clear();
+        while (!heap.empty()) {
+            std::pop_heap(heap.begin(), heap.end(), lower);
+            const Cand c = heap.back();
+            heap.pop_back();
+            const std::vector<TreeNode>& tree = mesh_tree[flat.instances[c.inst].mesh];
+            const TreeNode& t = tree[c.node];
+            if (t.n_leaf == 0 && t.n_inner > 0 && count + t.n_inner - 1u <= budget) {
+                count += t.n_inner - 1u;
+                for (int k = 0; k < t.n_inner; k++) {
+                    const TreeNode& ch = tree[t.inner[k]];
+                    heap.push_back({world_half_area(xf[c.inst], ch.lo, ch.hi), c.inst, t.inner[k]});
+                    std::push_heap(heap.begin(), heap.end(), lower);
+                }
+            } else {
+                prims.push_back({c.inst, c.node});
+            }
+        }
+        std::sort(prims.begin(), prims.end(), [](const Prim& a, const Prim& b) { return a.inst != b.inst ? a.inst < b.inst : a.node < b.node; });
+    }
+    // ---- TLAS over the world boxes of the pairs: boxes of the exactly transformed vertices of the triangles below the entry node
+    std::vector<uint32_t> tlas_order;
+    {
+        std::vector<float> tb(6 * prims.size());
+        std::vector<uint32_t> first_of(n_inst + 1, 0);  // prims of instance i: [first_of[i], first_of[i + 1])
+        for (const Prim& pr : prims) first_of[pr.inst + 1]++;
+        for (size_t i = 0; i < n_inst; i++) first_of[i + 1] += first_of[i];
+        parallel_chunks((unsigned)n_inst, n_inst > 16 ? host_threads() : 1u, [&](unsigned i) {
+            const uint32_t p0 = first_of[i], p1 = first_of[i + 1];
+            if (p0 == p1) return;
+            const uint32_t mesh = flat.instances[i].mesh;
+            if (p1 - p0 == 1 && prims[p0].node == 0) {
+                for (int a = 0; a < 6; a++) tb[6ull * p0 + a] = inst_bounds[6 * i + a];
+            } else {
+                const HostMesh& g = flat.meshes[mesh];
+                const InstXf& x = xf[i];
+                const std::vector<TreeNode>& tree = mesh_tree[mesh];
+                const std::vector<uint32_t>& ord = mesh_order[mesh];
+                std::vector<uint32_t> stack;
+                for (uint32_t p = p0; p < p1; p++) {
+                    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                    stack.assign(1, prims[p].node);
+                    while (!stack.empty()) {
+                        const TreeNode& t = tree[stack.back()];
+                        stack.pop_back();
+                        for (int c = 0; c < t.n_inner; c++) stack.push_back(t.inner[c]);
+                        for (int l = 0; l < t.n_leaf; l++)
+                            for (uint32_t k = 0; k < t.tri_count[l]; k++) {
+                                const uint32_t prim = ord[t.tri_first[l] + k];
+                                for (int c = 0; c < 3; c++) {
+                                    const vec3 q = xf_point(x.c0, x.c1, x.c2, x.t, ld3(g.vertices, g.indices[3 * prim + c]));
+                                    lo[0] = min_f(lo[0], q.x); lo[1] = min_f(lo[1], q.y); lo[2] = min_f(lo[2], q.z);
+                                    hi[0] = max_f(hi[0], q.x); hi[1] = max_f(hi[1], q.y); hi[2] = max_f(hi[2], q.z);
+                                }
+                            }
+                    }
+                    for (int a = 0; a < 3; a++) { tb[6ull * p + a] = lo[a]; tb[6ull * p + 3 + a] = hi[a]; }
+                }
+            }
+            // the instance's needles in world space: conditioning at most cond(M) x the mesh's worst (the instance's own value for each of its pairs)
+            const float extra = pad_scale * tri_cond_extra(inst_cond[i] * mesh_k2max[mesh], box_magnitude(&inst_bounds[6 * i], &inst_bounds[6 * i + 3]), pad_world / pad_scale);
+            for (uint32_t p = p0; p < p1; p++)
+                for (int a = 0; a < 3; a++) { tb[6ull * p + a] -= extra; tb[6ull * p + 3 + a] += extra; }
+        });
+        build_bvh8(tb, (uint32_t)prims.size(), pad_world, kBvhNodeWords, tune.bvh_balanced != 0, tlas_order, is.nodes, is.tlas_depth);
+        if (is.tlas_depth > kBvhStackDepth) build_bvh8(tb, (uint32_t)prims.size(), pad_world, kBvhNodeWords, true, tlas_order, is.nodes, is.tlas_depth);
         is.tlas_nodes = (uint32_t)(is.nodes.size() / kBvhNodeWords);
     }
     for (size_t m = 0; m < n_mesh; m++) {
@@ -330,14 +479,14 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
     if (out.bvh_depth > 40)
         throw std::runtime_error("unsupported: two-level BVH depth " + std::to_string(out.bvh_depth) + " exceeds the traversal stack (40 levels)");
     // ---- TLAS leaf records, instance material lists
-    is.tlas_leaves.assign(16ull * tlas_ids.size(), 0.0f);
+    is.tlas_leaves.assign(16ull * prims.size(), 0.0f);
     std::vector<uint32_t> mat_base(n_inst, 0);
     for (size_t i = 0; i < n_inst; i++) {
         mat_base[i] = (uint32_t)is.inst_mats.size();
         for (uint32_t mi : flat.instances[i].materials) is.inst_mats.push_back(mi);
     }
-    for (size_t k = 0; k < tlas_ids.size(); k++) {
-        const uint32_t i = tlas_ids[tlas_order[k]];
+    for (size_t k = 0; k < prims.size(); k++) {
+        const uint32_t i = prims[tlas_order[k]].inst;
         const HostInstance& in = flat.instances[i];
         float* r = &is.tlas_leaves[16ull * k];
         for (int row = 0; row < 3; row++)
@@ -345,7 +494,7 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
         r[12] = u2f(blas_node_off[in.mesh]);
         r[13] = u2f(mesh_base[in.mesh]);
         r[14] = u2f(i);
-        r[15] = u2f(out.inst_tri_offset[i]);
+        r[15] = u2f(prims[tlas_order[k]].node);  // where in the mesh's tree this record starts (0 = the root)
     }
     // ---- lights (load.rs:345-444), per emissive instance only
     is.inst_light.assign(n_inst, 0xffffffffu);

@@ -145,6 +145,10 @@ struct WfBuffers {
     uint32_t* qcount;               // [4]: closest/shadow counts of queue 0, of queue 1
     uint32_t* qhead;                // next unclaimed ray id of the queue being traced
     uint32_t* n_active;             // slots still active after the last shade
+    // The slots [slot_base, slot_end) this set of queues and counters serves: a session's slots are divided into GROUPS, each with its own
+    // queues, counters and stream, so that one group's kernels fill the chip while another's trace launch waits for its last rays
+    // (host/api_pt.cpp wf_run). The state arrays above are the session's, indexed by slot.
+    uint32_t slot_base, slot_end;
 };
 
 // Scratch and accumulators of the gpt integrator (gpt_kernels.hip), all f32 RGB: per-pixel splat slots of one sample (own,

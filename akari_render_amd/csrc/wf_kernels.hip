@@ -117,15 +117,15 @@ AKR_D void wf_enqueue(const PtParams& p, const WfBuffers& wf, uint32_t q, uint32
 
 template <bool PMJ>
 __global__ __launch_bounds__(256) void k_wf_init(const PtParams p, const WfBuffers wf) {
-    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t slot = wf.slot_base + blockIdx.x * 256u + threadIdx.x;
     uint32_t px = 0, py = 0;
-    const bool in_frame = slot < p.n_items && item_to_pixel(p, slot, px, py);
+    const bool in_frame = slot < wf.slot_end && item_to_pixel(p, slot, px, py);
     const uint32_t pix = px + py * p.width;
     uint32_t sx, sy;
     shifted_pixel(p, px, py, sx, sy);
     PathRegs r;
     path_regs_init<PMJ>(r, p, in_frame, pix, sx, sy);
-    if (slot < p.n_items) wf_store(wf, slot, r);
+    if (slot < wf.slot_end) wf_store(wf, slot, r);
     wf_enqueue(p, wf, 0, slot, r);
     flush_counters(p, r, TraceCounters{0, 0, 0}, true);
 }
@@ -135,12 +135,12 @@ __global__ __launch_bounds__(256) void k_wf_init(const PtParams p, const WfBuffe
 #endif
 template <bool TEX, bool PMJ, bool INST = false>
 __global__ __launch_bounds__(256, TEX ? 1 : AKR_WF_SHADE_WAVES) void k_wf_shade(const PtParams p, const WfBuffers wf, uint32_t q_out) {
-    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t slot = wf.slot_base + blockIdx.x * 256u + threadIdx.x;
     PathRegs r;
     r.active = false; r.has_ray = false; r.has_shadow = false;
     r.c_samples = r.c_closest = r.c_shadow = r.c_shaded = 0;
     bool live = false;
-    if (slot < p.n_items) live = (f2u(wf.base[slot].w) & WF_ACTIVE) != 0;
+    if (slot < wf.slot_end) live = (f2u(wf.base[slot].w) & WF_ACTIVE) != 0;
     if (live) {
         uint32_t px = 0, py = 0;
         item_to_pixel(p, slot, px, py);
@@ -174,8 +174,11 @@ AKR_D void wf_trav_begin(T& s, vec3 o, vec3 d, float tmin, float tmax, uint32_t 
 #endif
 // INST (round 6): the scene is kept as meshes + instances -- the two-level traversal of dinst_trav.h: a lane's candidates wait in its
 // pending slot and the wave takes the exact test in batches, as trace_inst does.
+#ifndef AKR_WF_TRACE_INST_WAVES
+#define AKR_WF_TRACE_INST_WAVES 1  // waves per SIMD the kept-scene trace kernel's register allocation must leave room for (1 = whatever it needs: 128 VGPRs, 4 waves)
+#endif
 template <bool TEX, bool INST = false>
-__global__ __launch_bounds__(256) void k_wf_trace(const PtParams p, const WfBuffers wf, uint32_t q_in) {
+__global__ __launch_bounds__(256, INST ? AKR_WF_TRACE_INST_WAVES : 1) void k_wf_trace(const PtParams p, const WfBuffers wf, uint32_t q_in) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     uint32_t* stack = lds_stack + threadIdx.x;
     const DScene& sc = p.sc;
@@ -273,14 +276,14 @@ __global__ __launch_bounds__(256) void k_wf_trace(const PtParams p, const WfBuff
 
 // ---------------------------------------------------------------------------------------------------- launchers
 hipError_t launch_wf_init(const PtParams& p, const WfBuffers& wf, hipStream_t stream) {
-    uint32_t blocks = (p.n_items + 255u) / 256u;
+    uint32_t blocks = (wf.slot_end - wf.slot_base + 255u) / 256u;
     if (blocks == 0) return hipSuccess;
     if (p.sampler) hipLaunchKernelGGL(k_wf_init<true>, dim3(blocks), dim3(256), 0, stream, p, wf);
     else hipLaunchKernelGGL(k_wf_init<false>, dim3(blocks), dim3(256), 0, stream, p, wf);
     return hipGetLastError();
 }
 hipError_t launch_wf_shade(const PtParams& p, const WfBuffers& wf, uint32_t q_out, hipStream_t stream) {
-    uint32_t blocks = (p.n_items + 255u) / 256u;
+    uint32_t blocks = (wf.slot_end - wf.slot_base + 255u) / 256u;
     if (blocks == 0) return hipSuccess;
     const bool tex = p.sc.tex.nodes != nullptr, pmj = p.sampler != 0;
     const bool inst = p.sc.in2.on != 0;

@@ -540,26 +540,36 @@ def instanced_forest_leg(ctx, only=None):
                 scene = capi.Scene(ctx, sd)
                 t_load = time.perf_counter() - t0
                 info = scene.info()
+
+            def run(**opts):
                 film = capi.Film(ctx, W, H)
                 cfg = abi.PtConfig.default()
                 cfg.spp, cfg.spp_per_pass, cfg.max_depth, cfg.rr_depth = 16, 8, 12, 5
-                se = capi.PtSession(ctx, scene, cfg, film)
-            se.passes(1, blocking=True)
-            s0 = se.stats()
-            t0 = time.perf_counter()
-            se.passes(1, blocking=True)
-            dt = time.perf_counter() - t0
-            s1 = se.end()
-            d = {k: s1[k] - s0[k] for k in ("n_samples", "n_closest", "n_shadow", "n_shaded", "n_node_visits", "n_tri_tests", "n_launches", "kernel_ms")}
+                with capi.options(**opts):
+                    se = capi.PtSession(ctx, scene, cfg, film)
+                status = se.kernel_info()["status"]
+                se.passes(1, blocking=True)
+                s0 = se.stats()
+                t0 = time.perf_counter()
+                se.passes(1, blocking=True)
+                dt = time.perf_counter() - t0
+                s1 = se.end()
+                d = {k: s1[k] - s0[k] for k in ("n_samples", "n_closest", "n_shadow", "n_shaded", "n_node_visits", "n_tri_tests", "n_launches", "kernel_ms")}
+                return d, dt, s1, film.read(), "wavefront" if "wavefront" in status else "megakernel"
+
+            d, dt, s1, films[mode], schedule = run()  # the schedule the library chooses (kept scenes of this size: wavefront, api_pt.cpp choose_wavefront)
             rays = d["n_closest"] + d["n_shadow"]
-            films[mode] = film.read()
             rl = roofline_block(f"forest_{tris // 1000}k_{mode}", d)  # the same byte model (8d) over the same counters: 64 B per node visit, 48 B per candidate
-            rl["kernel"] = "k_pt_pass_inst" if mode == "kept" else "k_pt_pass"
-            out[f"{tris // 1000}k_{mode}"] = {"value": d["n_samples"] / dt / 1e6, "unit": "Msamples/s", "n_triangles": int(info.n_triangles), "uses_bvh": int(info.uses_bvh),
+            rl["kernel"] = ("k_wf_trace<.., INST> + k_wf_shade" if schedule == "wavefront" else "k_pt_pass_inst") if mode == "kept" else "k_pt_pass"
+            out[f"{tris // 1000}k_{mode}"] = {"value": d["n_samples"] / dt / 1e6, "unit": "Msamples/s", "schedule": schedule, "n_triangles": int(info.n_triangles), "uses_bvh": int(info.uses_bvh),
                                              "device_MB": info.device_bytes / 1e6, "compile_upload_s": t_load, "rays_per_s_G": rays / dt / 1e9,
                                              "node_visits_per_ray": d["n_node_visits"] / rays, "candidates_per_ray": d["n_tri_tests"] / rays,
                                              "roofline": {k: rl.get(k) for k in _LEG_ROOFLINE_KEYS if k in rl}, "total_samples": s1["n_samples"]}
-            del se, film, scene
+            if mode == "kept" and not only:  # the other schedule on the same scene (not under a profiler: --leg runs the chosen one alone)
+                d2, dt2, _, film2, _ = run(wavefront=0 if schedule == "wavefront" else 1)
+                out[f"{tris // 1000}k_{mode}"]["other_schedule"] = {"schedule": "megakernel" if schedule == "wavefront" else "wavefront", "value": d2["n_samples"] / dt2 / 1e6,
+                                                                  "film_identical": bool(np.array_equal(film2.view(np.uint32), films[mode].view(np.uint32)))}
+            del scene
         if len(films) == 2:
             out[f"{tris // 1000}k_films_identical"] = bool(np.array_equal(films["kept"].view(np.uint32), films["flattened"].view(np.uint32)))
     return out

@@ -322,7 +322,7 @@ typedef enum {
     AKR_ARRAY_MAT_INPUTS = 16,   /* raw inputs per material = akr_material_desc, 104 B each */
     /* a scene kept as meshes + instances (akr_scene_info.uses_bvh == 2; csrc/host/scene_inst.cpp, empty otherwise). AKR_ARRAY_BVH_NODES
      * then holds the top-level tree over the instances followed by every mesh's own tree; WOOP / TRI_GID / SHADE are empty */
-    AKR_ARRAY_INST_LEAVES = 17,  /* f32[16 * instances with triangles] in top-level order: world->object rows | tree, mesh, instance, first id */
+    AKR_ARRAY_INST_LEAVES = 17,  /* f32[16 * top-level leaf entries] (one or more per instance with triangles): world->object rows | tree, mesh, instance, entry node */
     AKR_ARRAY_MESH_TRIS = 18,    /* f32[16 * mesh triangles] object-space vertices and uvs in each mesh's traversal order */
     AKR_ARRAY_MESH_POS = 19,     /* u32[mesh triangles] mesh order -> position in MESH_TRIS */
     AKR_ARRAY_MESH_META = 20,    /* u32[mesh triangles] material slot | flags << 30 */

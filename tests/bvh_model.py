@@ -19,12 +19,14 @@ def fma(a, b, c):
     return (np.asarray(a, dtype=np.float64) * np.asarray(b, dtype=np.float64) + np.asarray(c, dtype=np.float64)).astype(F)
 
 
-def decode_tree(nodes: np.ndarray, node_off: int = 0):
+def decode_tree(nodes: np.ndarray, node_off: int = 0, start: int = 0):
     """Per leaf triangle (index relative to the tree's triangle base): the list of (node index, entry) from the root down to the entry
-    that holds it. nodes = u32 array of the whole node buffer; the tree starts at node `node_off` (child_base is relative to it)."""
+    that holds it. nodes = u32 array of the whole node buffer; the tree starts at node `node_off` (child_base is relative to it).
+    start: the node of the tree to start at instead of its root (a top-level leaf record of a re-braided scene names one): the
+    triangles below that node, and their paths from it."""
     nodes = nodes.reshape(-1, NODE_WORDS)
     paths = {}
-    stack = [(0, [])]
+    stack = [(start, [])]
     while stack:
         idx, path = stack.pop()
         n = nodes[node_off + idx]
@@ -221,13 +223,19 @@ def check_kept(kept, flat, n_rays_per_tri, rng, max_tris=None):
     accepted = culled = 0
     worst = []
     todo = []
+    kinst = kept.array(capi.ARRAY_INSTANCES, F).reshape(-1, 32)
+    seen = set()
     for leaf in range(len(leaves)):
         lf = leaves[leaf]
-        node_off, tri_off, gid_base = int(lf[12:13].view(U)[0]), int(lf[13:14].view(U)[0]), int(lf[15:16].view(U)[0])
-        if node_off not in blas_paths:
-            blas_paths[node_off] = decode_tree(nodes, node_off)
-        for k in blas_paths[node_off]:
-            todo.append((leaf, node_off, tri_off, gid_base, k))
+        node_off, tri_off, ii, start = (int(lf[12 + c:13 + c].view(U)[0]) for c in range(4))
+        gid_base = int(kinst[ii, 23:24].view(U)[0])
+        if (node_off, start) not in blas_paths:
+            blas_paths[(node_off, start)] = decode_tree(nodes, node_off, start)
+        for k in blas_paths[(node_off, start)]:
+            assert (ii, k) not in seen, "a triangle of an instance is reachable from two top-level leaf records"
+            seen.add((ii, k))
+            todo.append((leaf, (node_off, start), tri_off, gid_base, k))
+    assert len(seen) == flat.info().n_triangles, "the top-level leaf records do not cover every instance-triangle"
     if max_tris is not None and len(todo) > max_tris:
         todo = [todo[i] for i in rng.choice(len(todo), size=max_tris, replace=False)]
     for leaf, node_off, tri_off, gid_base, k in todo:
@@ -250,7 +258,7 @@ def check_kept(kept, flat, n_rays_per_tri, rng, max_tris=None):
             oo = np.stack([(dot3(lf[4 * r:4 * r + 3], o) + lf[4 * r + 3]).astype(F) for r in range(3)], axis=1)
             od = np.stack([dot3(lf[4 * r:4 * r + 3], d) for r in range(3)], axis=1)
         pt = entry_box_params(nodes, 0, tlas_paths[leaf])
-        pb = entry_box_params(nodes, node_off, blas_paths[node_off][k])
+        pb = entry_box_params(nodes, node_off[0], blas_paths[node_off][k])
         bad = np.zeros(len(o), bool)
         for ulp in (-1, 0, 1):
             bad |= ~slab_pass(o, d, z, t, pt, ulp).all(axis=1)

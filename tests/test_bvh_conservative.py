@@ -15,10 +15,10 @@ from tests import bvh_model
 from tests.helpers import extreme_instanced_scene, far_modelled_mesh_scene, grid_scene, instanced_scene, shift_scene
 
 
-def both_scenes(sd):
+def both_scenes(sd, rebraid=1):
     with capi.options(instancing=0, force_bvh=1):
         flat = capi.Scene(None, sd)
-    with capi.options(instancing=1):
+    with capi.options(instancing=1, rebraid=rebraid):
         kept = capi.Scene(None, sd)
     assert flat.info().uses_bvh == 1 and kept.info().uses_bvh == 2
     return flat, kept
@@ -34,6 +34,19 @@ def test_extreme_transforms_no_accepted_pair_is_culled(hip_lib, seed):
     assert a > 1000 and c == 0, (a, c, worst[:5])
     a, c, worst = bvh_model.check_kept(kept, flat, 64, rng, max_tris=600)
     assert a > 1000 and c == 0, (a, c, worst[:5])
+
+
+@pytest.mark.parametrize("rebraid", [4, 16])
+def test_rebraided_top_level_tree(hip_lib, rebraid):
+    """Option rebraid: the top-level tree over (instance, subtree) pairs. check_kept asserts that the pairs' subtrees partition every
+    instance's triangles, then the usual property from each pair's entry node down."""
+    from akari_render_amd import procedural
+    sd = procedural.instanced_forest(12, 3000, width=64, height=64)
+    flat, kept = both_scenes(sd, rebraid)
+    n_leaves = len(kept.array(capi.ARRAY_INST_LEAVES, np.float32)) // 16
+    assert 14 * rebraid // 2 < n_leaves <= 14 * rebraid  # 12 plants + ground + sky
+    a, c, worst = bvh_model.check_kept(kept, flat, 32, np.random.default_rng(3), max_tris=500)
+    assert a > 3000 and c == 0, (a, c, worst[:5])
 
 
 @pytest.mark.parametrize("offset", [1e3, 1e5])

@@ -207,6 +207,57 @@ def test_wavefront_schedule_on_a_kept_scene(ctx, root, case):
         assert st[k] == ost[k], k
 
 
+def test_rebraided_top_level_tree_and_slot_groups_change_no_bit(ctx, root):
+    """Option rebraid (the top-level tree over (instance, subtree) pairs, the largest boxes opened first) and option wf_groups (the wavefront
+    schedule's slots as groups on streams of their own) change which boxes cull and which launch traces a ray -- never a film float."""
+    sd = procedural.instanced_forest(40, 3000, width=512, height=288)
+    sd.ggx_table = _table(root)
+    cfg = make_config(spp=4, spp_per_pass=4, max_depth=6)
+    films, visits, leaves = {}, {}, {}
+    for key, opts in {"plain": dict(wavefront=0), "rebraid": dict(wavefront=0, rebraid=8), "groups": dict(wavefront=1, wf_groups=2),
+                      "both": dict(wavefront=1, wf_groups=2, rebraid=8)}.items():
+        with capi.options(instancing=1, **opts):
+            scene = capi.Scene(ctx, sd)
+            assert scene.info().uses_bvh == 2
+            leaves[key] = len(scene.array(capi.ARRAY_INST_LEAVES, np.float32)) // 16
+            film = capi.Film(ctx, 512, 288)
+            se = capi.PtSession(ctx, scene, cfg, film)
+            se.passes(1, blocking=True)
+            visits[key] = se.end()["n_node_visits"]
+        films[key] = film.read()
+    assert leaves["plain"] == 42 and 42 * 4 < leaves["rebraid"] <= 42 * 8  # (40 plants + ground + sky; the two quads cannot be opened)
+    assert visits["rebraid"] != visits["plain"]
+    for key in ("rebraid", "groups", "both"):
+        assert n_bit_diff(films[key], films["plain"]) == 0, key
+
+
+def test_the_library_picks_the_wavefront_schedule_for_large_kept_frames(ctx, root):
+    """Option wavefront = -1 (default): pt sessions of >= 2 M pixels on an untextured kept scene run the wavefront schedule (api_pt.cpp
+    choose_wavefront: 1080p forest 163 -> 228 Msamples/s), smaller ones and aov sessions the megakernel; same film either way."""
+    assert capi.get_option("wavefront") == -1
+    sd = procedural.instanced_forest(12, 2000, width=1920, height=1080)
+    sd.ggx_table = _table(root)
+    cfg = make_config(spp=1, spp_per_pass=1, max_depth=5)
+    films = {}
+    with capi.options(instancing=1):
+        scene = capi.Scene(ctx, sd)
+        for mode in (-1, 0):
+            with capi.options(wavefront=mode):
+                film = capi.Film(ctx, 1920, 1080)
+                se = capi.PtSession(ctx, scene, cfg, film)
+                assert ("wavefront" in se.kernel_info()["status"]) == (mode == -1)
+                se.passes(1, blocking=True)
+                se.end()
+                films[mode] = film.read()
+        sd_small = procedural.instanced_forest(12, 2000, width=256, height=256)
+        sd_small.ggx_table = sd.ggx_table
+        small = capi.Scene(ctx, sd_small)
+        se = capi.PtSession(ctx, small, cfg, capi.Film(ctx, 256, 256))
+        assert "wavefront" not in se.kernel_info()["status"]
+        se.end()
+    assert n_bit_diff(films[-1], films[0]) == 0
+
+
 def test_forest_of_ten_million_instance_triangles_on_a_tile_shard(ctx, root):
     """1000 instances x 10 k triangles, oracle with its checker-side tree (pinned to the exhaustive loop in test_oracle_accel.py and
     test_gpu_fullsize.py), one tile shard of a 512x288 frame."""

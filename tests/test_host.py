@@ -358,7 +358,7 @@ def test_options_are_a_table_not_the_environment(hip_lib, cbox_path, monkeypatch
         assert capi.get_option("force_bvh") == 1
         assert capi.Scene(None, cbox_path).info().uses_bvh == 1
     assert capi.get_option("force_bvh") == before
-    assert capi.get_option("defer_metal") == -1 and capi.get_option("wavefront") == 0
+    assert capi.get_option("defer_metal") == -1 and capi.get_option("wavefront") == -1
     with pytest.raises(capi.AkariError):
         capi.set_option("no_such_option", 1)
 

@@ -35,8 +35,8 @@ kernel = None
 for f in sorted(glob.glob(out + "/**/*counter_collection.csv", recursive=True)):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0]
-        if "k_pt_pass" not in k and "akr_pt_pass_spec" not in k: continue  # (k_pt_pass, k_pt_pass_inst, and a per-scene kernel's wrapper)
-        kernel = k
+        if "k_pt_pass" not in k and "akr_pt_pass_spec" not in k and "k_wf_" not in k: continue  # (k_pt_pass, k_pt_pass_inst, a per-scene kernel's wrapper; the wavefront schedule's kernels together)
+        kernel = k if kernel is None or kernel == k else " + ".join(sorted(set(kernel.split(" + ")) | {k}))
         res[row["Counter_Name"]] += float(row["Counter_Value"]); disp[row["Counter_Name"]].add(row["Dispatch_Id"])
 bench = json.loads(open(out + "/set1.out").read().strip().splitlines()[-1])
 n_launch = max(len(v) for v in disp.values())
