@@ -237,7 +237,7 @@ static void wf_allocate(akr_pt_session* se, uint32_t n_slots) {
 }
 
 // One launch group of the wavefront schedule = `fused` passes for every slot: init, then trace/shade iterations until
-// no slot is active. The host only looks at the device every kCheckEvery iterations.
+// no slot is active. The host only looks at the device every 16 iterations (every 4 once few slots are left).
 static void wf_run(akr_pt_session* se) {
     hipStream_t main_st = se->ctx->stream;
     const PtParams& p = se->params;
@@ -262,7 +262,7 @@ static void wf_run(akr_pt_session* se) {
         }
     } join{se, streams, main_st};
     for (uint32_t g = 0; g < groups; g++) HIP_CHECK(launch_wf_init(p, se->wf_group[g], streams[g]));
-    const int kCheckEvery = 16;
+    int check_every = 16, since_check = 0;  // iterations between two looks at the device (every look drains the stream)
     uint32_t q = 0;
     std::vector<uint8_t> done(groups, 0);
     for (uint64_t iter = 0;; iter++) {
@@ -282,10 +282,8 @@ static void wf_run(akr_pt_session* se) {
             if (done[g]) continue;
             const WfBuffers& wg = se->wf_group[g];
             hipStream_t st = streams[g];
-            uint32_t* ctrl = wg.qcount;
-            // queue q holds the rays to trace; reset the head, the other queue's counts and the active counter
-            HIP_CHECK(hipMemsetAsync(ctrl + 2 * (1 - q), 0, 2 * sizeof(uint32_t), st));
-            HIP_CHECK(hipMemsetAsync(ctrl + 4, 0, 2 * sizeof(uint32_t), st));
+            // queue q holds the rays to trace. (The head, the other queue's counts and the active counter are reset by the kernels themselves:
+            // k_wf_trace zeroes n_active, k_wf_shade the counts of the queue just traced and the head.)
             if (sort_now) {
                 WfBuffers sorted = wg;
                 HIP_CHECK(wf_sort_pairs(se->wf_sort_tmp.p, se->wf_sort_tmp.bytes, wg.key_closest[q], se->wf_sorted_keys, wg.queue_closest[q], se->wf_sorted_closest, nc, st));
@@ -299,7 +297,8 @@ static void wf_run(akr_pt_session* se) {
             HIP_CHECK(launch_wf_shade(p, wg, 1 - q, st));
         }
         q = 1 - q;
-        if (!se->wf_sort && (iter + 1) % kCheckEvery == 0) {
+        if (!se->wf_sort && ++since_check >= check_every) {
+            since_check = 0;
             std::vector<uint32_t> n_active(groups, 0);
             for (uint32_t g = 0; g < groups; g++)
                 if (!done[g]) HIP_CHECK(hipMemcpyAsync(&n_active[g], se->wf_group[g].n_active, sizeof(uint32_t), hipMemcpyDeviceToHost, streams[g]));
@@ -310,6 +309,10 @@ static void wf_run(akr_pt_session* se) {
                 if (n_active[g] == 0) done[g] = 1; else all = false;
             }
             if (all) break;
+            // the last slots' paths: launches with next to nothing to do -- look more often, so that fewer of them run for nothing
+            uint64_t left = 0;
+            for (uint32_t g = 0; g < groups; g++) left += n_active[g];
+            check_every = left * 64 < se->wf_slots ? 4 : 16;
         }
         if (iter > (1ull << 26)) throw RenderError("wavefront schedule did not terminate");
     }

@@ -155,6 +155,13 @@ __global__ __launch_bounds__(256, TEX ? 1 : AKR_WF_SHADE_WAVES) void k_wf_shade(
         path_step<-1, TEX, PMJ, 0, 0u, INST>(p, r, hit, found, occluded, pix, sx, sy);
         wf_store(wf, slot, r);
     }
+    // the queue the trace launch before this one emptied is the next shade launch's to fill: its counts and the queue head back to zero
+    // (that launch is complete -- stream order -- and nothing in this one reads them; two hipMemsetAsync per iteration did this until round 6)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        wf.qcount[2u * (1u - q_out)] = 0u;
+        wf.qcount[2u * (1u - q_out) + 1u] = 0u;
+        *wf.qhead = 0u;
+    }
     wf_enqueue(p, wf, q_out, slot, r);
     flush_counters(p, r, TraceCounters{0, 0, 0}, true);
 }
@@ -184,6 +191,7 @@ __global__ __launch_bounds__(256, INST ? AKR_WF_TRACE_INST_WAVES : 1) void k_wf_
     const DScene& sc = p.sc;
     const uint32_t n_closest = wf.qcount[2 * q_in + 0], n_total = n_closest + wf.qcount[2 * q_in + 1];
     const uint32_t lane = threadIdx.x & 63u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *wf.n_active = 0u;  // (the shade launch after this one counts the slots still active; the host reads it after that)
     TraceCounters cnt{0, 0, 0};
     bool has = false, exhausted = false, any = false;
     uint32_t slot = 0;
