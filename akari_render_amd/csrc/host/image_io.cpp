@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -971,7 +972,7 @@ void decode_jpeg(const uint8_t* data, size_t n, uint32_t& width, uint32_t& heigh
 // ------------------------------------------------------------------------------------------------ OpenEXR reader
 // Single-part scanline files with NO / RLE / ZIPS / ZIP compression and HALF / FLOAT / UINT channels: what the reference
 // gets from `image` (exr crate 1.6.4) as `to_rgba32f()` for an "exr" texture (load.rs:583-611): R, G, B (a lone Y is
-// replicated), A = 1 when absent. Tiled, multi-part, deep and PIZ / PXR24 / B44 / DWA files are rejected. Rows in file order
+// replicated), A = 1 when absent. Round 6: tiled files, PIZ, PXR24, B44 / B44A. Multi-part, deep and DWA files are rejected. Rows in file order
 // of the data window (top first).
 namespace {
 float half_to_float(uint16_t h) {
@@ -1202,6 +1203,100 @@ std::vector<uint8_t> piz_decode(const uint8_t* src, size_t n, const std::vector<
     return raw;
 }
 
+// B44 / B44A (lossy, HALF channels only; what the exr crate behind load.rs:586-600 reads as well): a block's channels one after the other;
+// a HALF channel in 4 x 4 pixel blocks (the right and bottom edges padded) of 14 bytes each -- the first pixel's 16 bits in an ordered
+// representation (sign bit flipped, negative values complemented), a 6-bit shift, fifteen 6-bit running differences, biased by 32,
+// down the first column and along the rows, in units of 2^shift -- or, B44A, 3 bytes for a block of one value (shift field >= 13);
+// FLOAT and UINT channels are stored as they are. A channel flagged pLinear was packed as 8 log(x): exp(x / 8) of every value.
+uint16_t float_to_half_rne(float f) {
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0u));
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);  // rounds to infinity
+    if (x < 0x33000001u) return (uint16_t)sign;                // rounds to zero
+    const int e = (int)(x >> 23) - 127;
+    uint32_t m = (x & 0x7fffffu) | 0x800000u;
+    int shift = e < -14 ? 13 + (-14 - e) : 13;  // subnormal halves lose more bits
+    uint32_t h = e < -14 ? 0u : (uint32_t)(e + 15) << 10;
+    const uint32_t kept = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    uint32_t r = (e < -14 ? kept : (kept & 0x3ffu));
+    h |= r;
+    if (rem > half || (rem == half && (kept & 1u))) h++;  // (a carry out of the mantissa moves into the exponent: still the right bits)
+    return (uint16_t)(sign | h);
+}
+const uint16_t* b44_exp_table() {  // exp(x / 8) per half bit pattern, as OpenEXR tabulates it (0 for NaN / infinity, HALF_MAX where it overflows)
+    static std::vector<uint16_t> t;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        t.resize(65536);
+        for (uint32_t i = 0; i < 65536; i++) {
+            const float h = half_to_float((uint16_t)i);
+            if ((i & 0x7c00u) == 0x7c00u) t[i] = 0;
+            else if (h >= 8.0f * (float)std::log(65504.0)) t[i] = 0x7bff;
+            else t[i] = float_to_half_rne((float)std::exp((double)h / 8.0));
+        }
+    });
+    return t.data();
+}
+std::vector<uint8_t> b44_decode(const uint8_t* src, size_t n, const std::vector<uint32_t>& types, const std::vector<uint8_t>& p_linear, size_t cols, size_t rows) {
+    std::vector<std::vector<uint8_t>> plane(types.size());  // per channel, rows x cols values, little-endian
+    size_t pos = 0;
+    for (size_t c = 0; c < types.size(); c++) {
+        if (types[c] != 1) {
+            const size_t bytes = 4 * cols * rows;
+            if (pos + bytes > n) throw std::runtime_error("exr: B44 block too short");
+            plane[c].assign(src + pos, src + pos + bytes);
+            pos += bytes;
+            continue;
+        }
+        plane[c].resize(2 * cols * rows);
+        const uint16_t* table = p_linear[c] ? b44_exp_table() : nullptr;
+        for (size_t y = 0; y < rows; y += 4)
+            for (size_t x = 0; x < cols; x += 4) {
+                if (pos + 3 > n) throw std::runtime_error("exr: B44 block too short");
+                const uint8_t* b = src + pos;
+                uint16_t s[16];
+                if (b[2] >= (13u << 2)) {  // one value for the sixteen pixels
+                    for (int i = 0; i < 16; i++) s[i] = (uint16_t)((b[0] << 8) | b[1]);
+                    pos += 3;
+                } else {
+                    if (pos + 14 > n) throw std::runtime_error("exr: B44 block too short");
+                    const uint32_t shift = b[2] >> 2, bias = 0x20u << shift;
+                    // the fifteen 6-bit fields after the shift, most significant bit first
+                    uint32_t r[15];
+                    for (int k = 0; k < 15; k++) {
+                        const uint32_t bit = 22u + 6u * (uint32_t)k;  // (bits 0-15 the first pixel, 16-21 the shift)
+                        const uint32_t w = ((uint32_t)b[bit >> 3] << 8) | (uint32_t)b[(bit >> 3) + 1 < 14 ? (bit >> 3) + 1 : 13];
+                        r[k] = (w >> (10u - (bit & 7u))) & 0x3fu;
+                    }
+                    auto step = [&](uint16_t from, uint32_t rk) { return (uint16_t)(from + (rk << shift) - bias); };
+                    s[0] = (uint16_t)((b[0] << 8) | b[1]);
+                    s[4] = step(s[0], r[0]); s[8] = step(s[4], r[1]); s[12] = step(s[8], r[2]);          // down the first column
+                    for (int col = 1; col < 4; col++)                                                        // then along the four rows
+                        for (int row = 0; row < 4; row++) s[4 * row + col] = step(s[4 * row + col - 1], r[3 + 4 * (col - 1) + row]);
+                    pos += 14;
+                }
+                for (int i = 0; i < 16; i++) {
+                    s[i] = (s[i] & 0x8000u) ? (uint16_t)(s[i] & 0x7fffu) : (uint16_t)~s[i];  // back from the ordered representation
+                    if (table) s[i] = table[s[i]];
+                }
+                for (size_t yy = 0; yy < 4 && y + yy < rows; yy++)
+                    for (size_t xx = 0; xx < 4 && x + xx < cols; xx++) std::memcpy(&plane[c][2 * ((y + yy) * cols + x + xx)], &s[4 * yy + xx], 2);
+            }
+    }
+    if (pos != n) throw std::runtime_error("exr: B44 block has the wrong size");
+    // scanline layout: row by row, channel by channel
+    std::vector<uint8_t> raw;
+    for (size_t y = 0; y < rows; y++)
+        for (size_t c = 0; c < types.size(); c++) {
+            const size_t sz = types[c] == 1 ? 2 : 4;
+            raw.insert(raw.end(), plane[c].begin() + sz * y * cols, plane[c].begin() + sz * (y + 1) * cols);
+        }
+    return raw;
+}
+
 std::vector<uint8_t> exr_rle_decode(const uint8_t* p, size_t n, size_t expect) {
     std::vector<uint8_t> out;
     size_t i = 0;
@@ -1232,7 +1327,7 @@ void decode_exr(const uint8_t* data, size_t n, uint32_t& width, uint32_t& height
     const bool tiled = (version & 0x200u) != 0;  // single-part tiled file (round 6; the exr crate behind load.rs:586-600 reads them)
     if (version & 0x1800u) throw std::runtime_error("unsupported: deep / multi-part OpenEXR file");
     size_t pos = 8;
-    struct Chan { std::string name; uint32_t type; };
+    struct Chan { std::string name; uint32_t type; bool p_linear; };
     std::vector<Chan> chans;
     int compression = -1, line_order = 0;
     int32_t dw[4] = {0, 0, -1, -1};
@@ -1251,10 +1346,11 @@ void decode_exr(const uint8_t* data, size_t n, uint32_t& width, uint32_t& height
             while (q < size && v[q]) {
                 size_t s0 = q;
                 while (q < size && v[q]) q++;
-                Chan c{std::string((const char*)v + s0, q - s0), 0};
+                Chan c{std::string((const char*)v + s0, q - s0), 0, false};
                 q++;
                 if (q + 16 > size) throw std::runtime_error("exr: bad channel list");
                 std::memcpy(&c.type, v + q, 4);
+                c.p_linear = v[q + 4] != 0;  // (B44: the channel's values were packed on a logarithmic scale)
                 uint32_t xs, ys;
                 std::memcpy(&xs, v + q + 8, 4);
                 std::memcpy(&ys, v + q + 12, 4);
@@ -1279,8 +1375,8 @@ void decode_exr(const uint8_t* data, size_t n, uint32_t& width, uint32_t& height
         pos += size;
     }
     if (chans.empty() || dw[2] < dw[0] || dw[3] < dw[1]) throw std::runtime_error("exr: missing channels or data window");
-    if (compression < 0 || compression > 5)
-        throw std::runtime_error("unsupported: OpenEXR compression method " + std::to_string(compression) + " (none, RLE, ZIPS, ZIP, PIZ and PXR24 are read; B44 and DWA are not)");
+    if (compression < 0 || compression > 7)
+        throw std::runtime_error("unsupported: OpenEXR compression method " + std::to_string(compression) + " (none, RLE, ZIPS, ZIP, PIZ, PXR24, B44 and B44A are read; DWA is not)");
     if (tiled && (tile_w == 0 || tile_h == 0 || tile_w > 65535 || tile_h > 65535)) throw std::runtime_error("exr: tiled file without a valid tile size");
     if (tiled && (tile_mode & 0xfu) > 2u) throw std::runtime_error("exr: bad tile level mode");
     (void)line_order;  // the offset table is indexed by scanline block in increasing y whatever the order on disk
@@ -1288,7 +1384,7 @@ void decode_exr(const uint8_t* data, size_t n, uint32_t& width, uint32_t& height
     if (W > 65535 || H > 65535 || W * H > (1ull << 28)) throw std::runtime_error("exr: image too large");
     width = (uint32_t)W;
     height = (uint32_t)H;
-    const uint32_t lines_per_block = compression == 4 ? 32u : ((compression == 3 || compression == 5) ? 16u : 1u);
+    const uint32_t lines_per_block = (compression == 4 || compression >= 6) ? 32u : ((compression == 3 || compression == 5) ? 16u : 1u);
     // chunks: blocks of scanlines, or -- tiled -- the tiles of the full-resolution level (level (0, 0); mip / rip levels follow it in the
     // offset table and are not read), row-major
     const uint64_t tiles_x = tiled ? (W + tile_w - 1) / tile_w : 1, tiles_y = tiled ? (H + tile_h - 1) / tile_h : 0;
@@ -1348,6 +1444,11 @@ void decode_exr(const uint8_t* data, size_t n, uint32_t& width, uint32_t& height
             std::vector<uint32_t> types;
             for (const Chan& c : chans) types.push_back(c.type);
             raw = piz_decode(src_bytes, csize, types, (size_t)cols, (size_t)rows);
+        } else if (compression >= 6) {
+            std::vector<uint32_t> types;
+            std::vector<uint8_t> plin;
+            for (const Chan& c : chans) { types.push_back(c.type); plin.push_back(c.p_linear ? 1 : 0); }
+            raw = b44_decode(src_bytes, csize, types, plin, (size_t)cols, (size_t)rows);
         } else if (compression == 5) {
             // PXR24 (lossy for FLOAT channels: 24 bits kept): zlib over, per scanline and channel, the byte PLANES (most significant first) of the
             // running differences of the pixel values -- 4 planes for UINT, 2 for HALF, 3 for FLOAT (the low byte is dropped)

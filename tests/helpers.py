@@ -453,13 +453,109 @@ def piz_compress(rows_of_planes, n_rows: int, names_per_row: int, use_runs: bool
     return head + struct.pack("<i", len(huf)) + huf
 
 
-def make_exr(planes: dict, compression: int = 3, line_order: int = 0, tiles=None, mipmap: bool = False) -> bytes:
+def _b44_ordered(s: np.ndarray) -> np.ndarray:
+    """half bit patterns -> B44's ordered 16-bit representation (larger value = larger number; NaN / infinity -> 0x8000)."""
+    s = s.astype(np.int64)
+    t = np.where(s & 0x8000, (~s) & 0xffff, s | 0x8000)
+    return np.where((s & 0x7c00) == 0x7c00, 0x8000, t)
+
+
+def b44_pack_block(s16: np.ndarray, flat_fields: bool) -> bytes:
+    """One 4 x 4 block of half bit patterns (row-major, 16 values) -> 14 bytes (or 3: B44A, all sixteen equal), from the format's
+    description: the first value in the ordered representation, the smallest shift for which the fifteen running differences (down the first
+    column, then along the rows), in units of 2^shift and rounded, fit 6 bits around a bias of 32."""
+    t = _b44_ordered(np.asarray(s16))
+    t_max = int(t.max())
+    shift = -1
+    while True:
+        shift += 1
+        # distance from the block's maximum in units of 2^shift, rounded to nearest, ties to even
+        x2 = (t_max - t) << 1
+        d = (x2 + ((1 << shift) - 1) + ((x2 >> (shift + 1)) & 1)) >> (shift + 1)
+        pairs = [(0, 4), (4, 8), (8, 12)] + [(4 * r + c - 1, 4 * r + c) for c in (1, 2, 3) for r in range(4)]
+        r = [int(d[i] - d[j]) + 0x20 for i, j in pairs]
+        if min(r) >= 0 and max(r) <= 0x3f:
+            break
+    if flat_fields and min(r) == 0x20 and max(r) == 0x20:
+        return bytes([int(t[0]) >> 8, int(t[0]) & 255, 0xfc])
+    t0 = t_max - (int(d[0]) << shift)  # the first value as the decoder will rebuild the others from it
+    bits = (t0 & 0xffff) << (6 + 90) | shift << 90
+    for k, rk in enumerate(r):
+        bits |= rk << (90 - 6 * (k + 1))
+    return bits.to_bytes(14, "big")
+
+
+def b44_unpack_block(b: bytes):
+    """-> (16 half bit patterns, bytes consumed): the inverse, written from the same description (tests' own reference decoder)."""
+    if b[2] >= 13 << 2:
+        t = [(b[0] << 8) | b[1]] * 16
+        used = 3
+    else:
+        bits = int.from_bytes(b[:14], "big")
+        shift = (bits >> 90) & 0x3f
+        r = [(bits >> (90 - 6 * (k + 1))) & 0x3f for k in range(15)]
+        t = [0] * 16
+        t[0] = bits >> 96
+        pairs = [(0, 4), (4, 8), (8, 12)] + [(4 * rr + c - 1, 4 * rr + c) for c in (1, 2, 3) for rr in range(4)]
+        for (i, j), rk in zip(pairs, r):
+            t[j] = (t[i] + (rk << shift) - (0x20 << shift)) & 0xffff
+        used = 14
+    return [(v & 0x7fff) if v & 0x8000 else (~v) & 0xffff for v in t], used
+
+
+def b44_compress(planes_in_order, flat_fields: bool, p_linear=()) -> bytes:
+    """A block's channels one after the other: HALF channels as 4 x 4 blocks (edges padded by repetition), the others raw."""
+    out = bytearray()
+    for k, pl in enumerate(planes_in_order):
+        if pl.dtype != np.float16:
+            out += np.ascontiguousarray(pl).tobytes()
+            continue
+        v = pl.view(np.uint16)
+        if k in p_linear:  # the writer's side of pLinear: 8 log(x), 0 for negative or non-finite values
+            f = pl.astype(np.float64)
+            with np.errstate(all="ignore"):
+                g = np.where(np.isfinite(f) & (f >= 0), 8.0 * np.log(f), 0.0)
+            v = np.where(np.isfinite(g), g, 0.0).astype(np.float32).astype(np.float16).view(np.uint16)
+        h, w = v.shape
+        for y in range(0, h, 4):
+            for x in range(0, w, 4):
+                ys = np.minimum(np.arange(y, y + 4), h - 1)
+                xs = np.minimum(np.arange(x, x + 4), w - 1)
+                out += b44_pack_block(v[np.ix_(ys, xs)].reshape(16), flat_fields)
+    return bytes(out)
+
+
+def b44_reference_decode(blob: bytes, dtypes, shape, exp_table=None, p_linear=()):
+    """The planes a reader must get from one block's B44 data (tests' reference; exp_table: the 65536-entry pLinear table)."""
+    h, w = shape
+    pos, out = 0, []
+    for k, dt in enumerate(dtypes):
+        if dt != np.float16:
+            out.append(np.frombuffer(blob, dtype=dt, count=h * w, offset=pos).reshape(h, w).copy())
+            pos += 4 * h * w
+            continue
+        pl = np.zeros((h, w), np.uint16)
+        for y in range(0, h, 4):
+            for x in range(0, w, 4):
+                s, used = b44_unpack_block(blob[pos:pos + 14])
+                pos += used
+                blk = np.array(s, np.uint16).reshape(4, 4)
+                if k in p_linear:
+                    blk = exp_table[blk]
+                pl[y:y + 4, x:x + 4] = blk[:min(4, h - y), :min(4, w - x)]
+        out.append(pl.view(np.float16))
+    assert pos == len(blob)
+    return out
+
+
+def make_exr(planes: dict, compression: int = 3, line_order: int = 0, tiles=None, mipmap: bool = False, p_linear=(), blobs_out=None) -> bytes:
     """Single-part OpenEXR from {channel name: (H, W) array of float16 / float32 / uint32}; compression 0 none,
     1 RLE, 2 ZIPS, 3 ZIP (the file-format definitions: per block, channel rows one after the other, byte de-interleave,
     delta predictor, then RLE / deflate; a block that does not shrink is stored raw), 5 PXR24 (per row and channel the byte planes,
     most significant first, of the running differences of the values -- FLOAT cut to 24 bits -- deflated). tiles = (w, h): a TILED
     file (version flag 0x200, `tiles` attribute, one chunk per tile in row-major order: tile x, tile y, level x, level y, size);
-    mipmap: the level mode says MIPMAP and a half-resolution level's tiles follow level 0's (readers of the full resolution skip them)."""
+    mipmap: the level mode says MIPMAP and a half-resolution level's tiles follow level 0's (readers of the full resolution skip them).
+    6 / 7: B44 / B44A (b44_compress; p_linear = names of the channels flagged pLinear; blobs_out collects (compressed bytes or None, region))."""
     import struct
     import zlib
 
@@ -470,7 +566,7 @@ def make_exr(planes: dict, compression: int = 3, line_order: int = 0, tiles=None
     def attr(name, ty, v):
         return name.encode() + b"\0" + ty.encode() + b"\0" + struct.pack("<I", len(v)) + v
 
-    chl = b"".join(n.encode() + b"\0" + struct.pack("<IIII", tcode[planes[n].dtype], 0, 1, 1) for n in names) + b"\0"
+    chl = b"".join(n.encode() + b"\0" + struct.pack("<IIII", tcode[planes[n].dtype], 1 if n in p_linear else 0, 1, 1) for n in names) + b"\0"
     head = struct.pack("<II", 20000630, 2 | (0x200 if tiles else 0))
     head += attr("channels", "chlist", chl) + attr("compression", "compression", bytes([compression]))
     if tiles:
@@ -479,7 +575,7 @@ def make_exr(planes: dict, compression: int = 3, line_order: int = 0, tiles=None
     head += attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", bytes([line_order]))
     head += attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0))
     head += attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
-    lpb = 32 if compression == 4 else (16 if compression in (3, 5) else 1)
+    lpb = 32 if compression in (4, 6, 7) else (16 if compression in (3, 5) else 1)
 
     def pxr24(rows_of_planes):  # [(channel array row), ...] in file order
         out = bytearray()
@@ -511,7 +607,12 @@ def make_exr(planes: dict, compression: int = 3, line_order: int = 0, tiles=None
         rows = [np.ascontiguousarray(planes[n][y, x0:x1]) for y in range(y0, y1) for n in names]
         raw = b"".join(r.tobytes() for r in rows)
         blob = raw
-        if compression == 5:
+        if compression in (6, 7):
+            comp = b44_compress([np.ascontiguousarray(planes[n][y0:y1, x0:x1]) for n in names], compression == 7, [k for k, n in enumerate(names) if n in p_linear])
+            blob = comp if len(comp) < len(raw) else raw
+            if blobs_out is not None:
+                blobs_out.append((comp if blob is comp else None, (x0, x1, y0, y1)))
+        elif compression == 5:
             comp = pxr24(rows)
             blob = comp if len(comp) < len(raw) else raw
         elif compression == 4:

@@ -553,6 +553,52 @@ def test_exr_reader_piz(layout, tiles):
             capi.host_decode_exr(data[:cut])
 
 
+@pytest.mark.parametrize("variant", ["b44", "b44a", "b44a_tiles", "b44_plinear"])
+def test_exr_reader_b44(variant):
+    """B44 / B44A (OpenEXR's fixed-rate lossy method for HALF channels; the exr crate behind load.rs:586-600 reads both): 4 x 4 blocks of
+    14 bytes -- first value, a shift, fifteen 6-bit running differences -- or 3 bytes for a block of one value (B44A); FLOAT / UINT channels
+    stored as they are; pLinear channels through the exp(x / 8) table. The reader against the tests' own encoder AND reference decoder
+    (tests/helpers.py b44_*), both written from the format's description: bit for bit what the reference decoder makes of the same bytes,
+    and within the block's quantisation step of what was written."""
+    from tests.helpers import b44_reference_decode, make_exr
+
+    rng = np.random.default_rng(len(variant))
+    h, w = 45, 30  # two blocks of 32 scanlines; neither size a multiple of 4
+    smooth = (np.linspace(0.1, 3, w)[None, :] * np.linspace(0.5, 2, h)[:, None])
+    planes = {"R": (smooth + rng.random((h, w)) * 0.02).astype(np.float16), "G": (rng.standard_normal((h, w)) * 40).astype(np.float16),
+              "B": np.full((h, w), 0.375, np.float16), "A": rng.random((h, w)).astype(np.float32)}
+    planes["B"][20:24, 8:12] = np.float16(-2.0)            # a flat block of another value, and blocks that straddle the step
+    planes["G"][3, 5] = np.float16(np.inf)                  # non-finite values pack as the ordered representation's 0x8000
+    p_linear = ("R",) if variant == "b44_plinear" else ()
+    blobs = []
+    data = make_exr(planes, 7 if variant.startswith("b44a") else 6, tiles=(16, 20) if variant.endswith("tiles") else None, p_linear=p_linear, blobs_out=blobs)
+    got = capi.host_decode_exr(data)
+    assert got.shape == (h, w, 4)
+    # the tests' reference decode of the very bytes in the file
+    hb = np.arange(65536, dtype=np.uint16).view(np.float16).astype(np.float64)
+    with np.errstate(all="ignore"):
+        et = np.where(~np.isfinite(hb), 0.0, np.where(hb >= 8 * np.log(65504.0), 65504.0, np.exp(hb / 8.0)))
+    exp_table = et.astype(np.float32).astype(np.float16).view(np.uint16)
+    names = sorted(planes)
+    want = np.zeros((h, w, 4), np.float32)
+    assert all(b is not None for b, _ in blobs)  # (every block shrank: none stored raw)
+    for blob, (x0, x1, y0, y1) in blobs:
+        dec = b44_reference_decode(blob, [planes[n].dtype for n in names], (y1 - y0, x1 - x0), exp_table, [k for k, n in enumerate(names) if n in p_linear])
+        for n, pl in zip(names, dec):
+            want[y0:y1, x0:x1, "RGBA".index(n)] = pl.astype(np.float32)
+    assert n_bit_diff(got, want) == 0
+    # ... and it is the image that was written, to the method's precision
+    assert np.array_equal(got[:, :, 3], planes["A"])                                   # FLOAT channels are not touched
+    if variant == "b44a":
+        assert np.array_equal(got[:, :, 2], planes["B"].astype(np.float32))            # flat blocks are exact
+        assert len(data) < len(make_exr(planes, 6))                                    # ... and three bytes instead of fourteen
+    r = planes["R"].astype(np.float32)
+    assert np.max(np.abs(got[:, :, 0] - r) / r) < (0.25 if p_linear else 0.05)  # (a steep 4 x 4 block shares one step size: coarse for its small values)
+    for cut in (len(data) - 5, len(data) - 300):
+        with pytest.raises(capi.AkariError):
+            capi.host_decode_exr(data[:cut])
+
+
 def test_exr_reader_reads_the_writer_and_rejects_what_it_cannot_read(tmp_path):
     rgb = np.random.default_rng(0).random((9, 14, 3)).astype(np.float32)
     path = str(tmp_path / "out.exr")
@@ -563,7 +609,7 @@ def test_exr_reader_reads_the_writer_and_rejects_what_it_cannot_read(tmp_path):
 
     data = bytearray(make_exr({"R": np.zeros((4, 4), np.float32)}, 2))
     i = data.index(b"compression\0compression\0") + len(b"compression\0compression\0") + 4
-    data[i] = 6  # B44
+    data[i] = 8  # DWAA: refused by name (B44 / B44A are read since round 6)
     with pytest.raises(capi.AkariError) as e:
         capi.host_decode_exr(bytes(data))
     assert e.value.code == -6
