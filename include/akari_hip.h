@@ -619,7 +619,11 @@ AKR_API uint32_t akr_struct_size(int32_t which);
  *   "force_bvh"    (AKR_FORCE_BVH=1)        scenes of <= 64 triangles get a BVH as well
  *   "bvh_balanced" (AKR_BVH_BALANCED=1)     median-split fallback builder instead of binned SAH
  *   "defer_metal"  (AKR_PT_DEFER_METAL=m)   -1 the library decides; 0 off; m > 0: conductor hits shaded when (iteration & m) == 0
- *   "wavefront"    (AKR_PT_MODE=wavefront)  1 = pt sessions on BVH scenes run the wavefront schedule
+ *   "wavefront"    (AKR_PT_MODE=wavefront|megakernel|auto)  pt sessions on scenes with a tree: 1 = the wavefront schedule, 0 = the megakernel,
+ *                                           -1 (default) = the library decides (wavefront for sessions of >= 2 M pixels on untextured scenes kept
+ *                                           as meshes + instances, else the megakernel). Films are the same bit for bit either way.
+ *   "wf_groups"    (AKR_WF_GROUPS=g)        wavefront schedule: the path slots run as g groups with queues and streams of their own; 0 = the
+ *                                           library decides
  *   "simple_kernels" (AKR_PT_SIMPLE=0)      0 = never pick the kernels specialised for scenes without coat / transmission / normal map / glass
  *   "defer_on"     (no environment hook)    BVH kernels of scenes with textures: which hits "defer_metal" puts off -- 0 / 1 the conductor
  *                                           lobe (default), 2 texture-fed materials, 3 both
@@ -633,8 +637,13 @@ AKR_API uint32_t akr_struct_size(int32_t which);
  *                                           instances -- a tree over the instances and one per mesh in object space, nothing stored per
  *                                           instance-triangle -- when the flattened records would pass 8 GB or 48 M triangles), 0 always
  *                                           flattened, 1 kept as meshes + instances whenever a mesh is shared. Films are the same bit for
- *                                           bit either way. Such a scene renders with akr_pt_* only: aov / gpt / mcmc_opt sessions and the
- *                                           probes need the flattened records and fail with AKR_ERR_UNSUPPORTED; "wavefront" is ignored. A singular instance transform means flattening whatever the option says.
+ *                                           bit either way, for every integrator and schedule. A singular instance transform means
+ *                                           flattening whatever the option says.
+ *   "rebraid"      (AKR_REBRAID=k)          scenes kept as meshes + instances: the tree over the instances is built over k x as many (instance,
+ *                                           subtree of its mesh's tree) pairs, the largest boxes opened first; 1 (default) = one pair per instance
+ *   "arith"        (AKR_ARITH=1)            pt megakernel of flattened scenes in the relaxed arithmetic tier (hardware rcp / sqrt / sin / cos /
+ *                                           log / exp, contraction): faster, NOT bit-identical to the reference arithmetic
+ *   "pad_percent"  (no environment hook)    test hook: padding of the acceleration structures' boxes in percent of the derived value
  * Values out of an option's range fail with AKR_ERR_INVALID_ARGUMENT.
  * A session reads the options once, when it begins (akr_pt_begin / akr_gpt_begin / ...): a later akr_option_set does not change it.
  * "wavefront" = 1 on a scene without a BVH renders with the megakernel. Unknown names fail with AKR_ERR_INVALID_ARGUMENT. */

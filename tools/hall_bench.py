@@ -10,7 +10,7 @@ t0 = time.time(); sd = procedural.sponza_like(n_tris, 1234, 1920, 1080); t1 = ti
 scene = capi.Scene(ctx, sd); t2 = time.time()
 info = scene.info()
 film = capi.Film(ctx, 1920, 1080)
-cfg = abi.PtConfig.default(); cfg.spp = spp * 2; cfg.spp_per_pass = spp; cfg.max_depth = 12; cfg.rr_depth = 5
+cfg = abi.PtConfig.default(); cfg.spp = spp * 2; cfg.spp_per_pass = spp; cfg.max_depth = int(os.environ.get("HB_DEPTH", "12")); cfg.rr_depth = 5
 se = capi.PtSession(ctx, scene, cfg, film)
 se.passes(1, blocking=True); s0 = se.stats()
 ta = time.perf_counter(); se.passes(1, blocking=True); tb = time.perf_counter()

@@ -18,7 +18,7 @@ for tris in [int(a) for a in sys.argv[1:]] or [10_000, 100_000]:
     for rb, wf, groups in combos:
         with capi.options(instancing=int(os.environ.get("KS_INSTANCING", "1")), wavefront=wf, rebraid=rb, wf_groups=groups):
             sc = capi.Scene(ctx, sd); f = capi.Film(ctx, W, H)
-            cfg = abi.PtConfig.default(); cfg.spp, cfg.spp_per_pass, cfg.max_depth, cfg.rr_depth = 2 * SPP, SPP, 12, 5
+            cfg = abi.PtConfig.default(); cfg.spp, cfg.spp_per_pass, cfg.max_depth, cfg.rr_depth = 2 * SPP, SPP, int(os.environ.get("KS_DEPTH", "12")), 5
             se = capi.PtSession(ctx, sc, cfg, f)
         se.passes(1, blocking=True); s0 = se.stats(); t = time.perf_counter(); se.passes(1, blocking=True); dt = time.perf_counter() - t; s1 = se.end()
         films[(rb, wf, groups)] = f.read()
