@@ -99,6 +99,7 @@ struct CompiledScene {
         std::vector<uint32_t> inst_mats;    // the instances' material lists, concatenated
         std::vector<uint32_t> inst_light;   // light id per instance or 0xffffffff
         uint32_t tlas_nodes = 0, tlas_depth = 0, blas_depth = 0, n_mesh_tris = 0;
+        uint32_t n_padding_classes = 0;    // per-mesh trees built: one per (mesh, padding class of its instances), scene_inst.cpp
     } instanced;
     bool has_textures = false;
     bool has_alpha = false;

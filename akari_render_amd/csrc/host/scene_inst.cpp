@@ -159,21 +159,8 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
     CompiledScene::Instanced& is = out.instanced;
     is = CompiledScene::Instanced();
     is.on = true;
-    const size_t n_inst = flat.instances.size(), n_mesh = flat.meshes.size();
+    const size_t n_inst = flat.instances.size(), n_src = flat.meshes.size();
     const TexScene host_tex{out.tex_nodes.data(), out.images.data(), out.texels.data(), out.mat_inputs.data(), 0, 0};
-    // ---- which meshes are used, their triangle bases
-    std::vector<uint8_t> used(n_mesh, 0);
-    for (const HostInstance& in : flat.instances) used[in.mesh] = 1;
-    std::vector<uint32_t> mesh_base(n_mesh, 0);
-    uint32_t n_mesh_tris = 0;
-    bool any_normals = false;
-    for (size_t m = 0; m < n_mesh; m++) {
-        mesh_base[m] = n_mesh_tris;
-        if (!used[m]) continue;
-        n_mesh_tris += flat.meshes[m].n_triangles();
-        if (!flat.meshes[m].normals.empty() || !flat.meshes[m].tangents.empty()) any_normals = true;
-    }
-    is.n_mesh_tris = n_mesh_tris;
     // ---- instance world boxes from the exactly transformed vertices (what the flattened triangles' boxes would span), scene box
     std::vector<float> inst_bounds(6 * n_inst);
     std::vector<std::string> errors(n_inst);
@@ -210,18 +197,22 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
     }
     // ---- per instance: the inverse transform (double -> f32; used for culling only) and its norm
     std::vector<double> inv(12 * n_inst);
-    std::vector<float> inv_norm(n_inst, 0.0f), mesh_inv_norm(n_mesh, 0.0f);
+    std::vector<float> inv_norm(n_inst, 0.0f);
     std::vector<float> inst_cond(n_inst, 1.0f);         // condition number of the instance's linear part (2-norm)
-    std::vector<float> mesh_back_reach(n_mesh, 0.0f);   // max over a mesh's instances of |M^-1| x (|M| x the mesh's own coordinates + |translation|)
-    std::vector<float> mesh_obj_reach(n_mesh, 0.0f);    // sum over the axes of the largest |object-space coordinate| of a mesh
-    std::vector<float> mesh_back_mag(n_mesh, 0.0f);     // max over a mesh's instances of |M^-1|_2 x (2-norm of the largest world coordinates of the instance)
-    for (size_t m = 0; m < n_mesh; m++) {
-        if (!used[m]) continue;
-        const HostMesh& g = flat.meshes[m];
-        float mx[3] = {0.0f, 0.0f, 0.0f};
-        for (size_t k = 0; k < g.indices.size(); k++)
-            for (int a = 0; a < 3; a++) mx[a] = max_f(mx[a], abs_f(g.vertices[3ull * g.indices[k] + a]));
-        mesh_obj_reach[m] = (mx[0] + mx[1]) + mx[2];
+    std::vector<float> inst_back_reach(n_inst, 0.0f);   // |M^-1| x (|M| x the mesh's own coordinates + |translation|)
+    std::vector<float> inst_back_mag(n_inst, 0.0f);     // |M^-1|_2 x (2-norm of the largest world coordinates of the instance)
+    std::vector<float> src_obj_reach(n_src, 0.0f);      // sum over the axes of the largest |object-space coordinate| of a mesh
+    {
+        std::vector<uint8_t> used_src(n_src, 0);
+        for (const HostInstance& in : flat.instances) used_src[in.mesh] = 1;
+        for (size_t m = 0; m < n_src; m++) {
+            if (!used_src[m]) continue;
+            const HostMesh& g = flat.meshes[m];
+            float mx[3] = {0.0f, 0.0f, 0.0f};
+            for (size_t k = 0; k < g.indices.size(); k++)
+                for (int a = 0; a < 3; a++) mx[a] = max_f(mx[a], abs_f(g.vertices[3ull * g.indices[k] + a]));
+            src_obj_reach[m] = (mx[0] + mx[1]) + mx[2];
+        }
     }
     for (size_t i = 0; i < n_inst; i++) {
         const float* m = flat.instances[i].transform;
@@ -249,15 +240,63 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
             }
         }
         inv_norm[i] = norm;
-        const uint32_t mesh = flat.instances[i].mesh;
-        mesh_inv_norm[mesh] = max_f(mesh_inv_norm[mesh], norm);
         // how large the numbers are that cancel when a ray goes through M^-1 and a vertex through M: a mesh modelled far from its own
         // origin and moved back by the instance's translation has world coordinates ~ 1 and both of these ~ 1e4
         float fwd = 0.0f;  // largest absolute row sum of the linear part
         for (int row = 0; row < 3; row++) fwd = max_f(fwd, (float)(std::fabs(a[row][0]) + std::fabs(a[row][1]) + std::fabs(a[row][2])));
         const float tl = (float)(std::fabs(t[0]) + std::fabs(t[1]) + std::fabs(t[2]));
-        mesh_back_reach[mesh] = max_f(mesh_back_reach[mesh], norm * (fwd * mesh_obj_reach[mesh] + tl));
-        mesh_back_mag[mesh] = max_f(mesh_back_mag[mesh], norm * box_magnitude(&inst_bounds[6 * i], &inst_bounds[6 * i + 3]));
+        inst_back_reach[i] = norm * (fwd * src_obj_reach[flat.instances[i].mesh] + tl);
+        inst_back_mag[i] = norm * box_magnitude(&inst_bounds[6 * i], &inst_bounds[6 * i + 3]);
+    }
+    // ---- padding classes: a mesh's tree is padded for the WORST of its instances -- |M^-1| scales every term -- so one tiny
+    // (or far away) copy among a thousand ordinary ones used to inflate the boxes of all of them until the tree stopped culling: correct, and
+    // a performance cliff nothing reported. The instances of a mesh are therefore sorted into up to four classes by what their own
+    // transform asks for (within 8 x, 64 x, 512 x the mesh's median, beyond), and each class that occurs gets a tree -- and a copy of the
+    // mesh's triangle records in that tree's order -- of its own: a "virtual mesh". Ordinary scenes have one class per mesh and compile to
+    // the bytes they always did.
+    std::vector<uint32_t> vmesh_of(n_inst, 0), vsrc;  // instance -> virtual mesh; virtual mesh -> the mesh whose geometry it is
+    {
+        std::vector<std::vector<uint32_t>> by_mesh(n_src);
+        for (size_t i = 0; i < n_inst; i++) by_mesh[flat.instances[i].mesh].push_back((uint32_t)i);
+        auto ask = [&](uint32_t i) { return inv_norm[i] * scene_mag + inst_back_reach[i] + inst_back_mag[i]; };
+        for (size_t m = 0; m < n_src; m++) {
+            if (by_mesh[m].empty()) continue;
+            std::vector<float> asks;
+            for (uint32_t i : by_mesh[m]) asks.push_back(ask(i));
+            std::nth_element(asks.begin(), asks.begin() + (asks.size() - 1) / 2, asks.end());
+            const float med = asks[(asks.size() - 1) / 2];  // (the lower median: of two copies the ordinary one sets the scale)
+            int vid[4] = {-1, -1, -1, -1};
+            for (int c = 0; c < 4; c++)
+                for (uint32_t i : by_mesh[m]) {
+                    const float q = ask(i);
+                    const int cls = !(q > 8.0f * med) ? 0 : (!(q > 64.0f * med) ? 1 : (!(q > 512.0f * med) ? 2 : 3));
+                    if (cls != c) continue;
+                    if (vid[c] < 0) { vid[c] = (int)vsrc.size(); vsrc.push_back((uint32_t)m); }
+                    vmesh_of[i] = (uint32_t)vid[c];
+                }
+        }
+    }
+    const size_t n_mesh = vsrc.size();
+    is.n_padding_classes = (uint32_t)n_mesh;
+    std::vector<uint8_t> used(n_mesh, 1);
+    std::vector<uint32_t> mesh_base(n_mesh, 0);
+    uint32_t n_mesh_tris = 0;
+    bool any_normals = false;
+    for (size_t m = 0; m < n_mesh; m++) {
+        mesh_base[m] = n_mesh_tris;
+        const uint64_t total = (uint64_t)n_mesh_tris + flat.meshes[vsrc[m]].n_triangles();
+        if (total > 0xffffffffull) throw std::runtime_error("unsupported: more than 2^32 mesh triangles");
+        n_mesh_tris = (uint32_t)total;
+        if (!flat.meshes[vsrc[m]].normals.empty() || !flat.meshes[vsrc[m]].tangents.empty()) any_normals = true;
+    }
+    is.n_mesh_tris = n_mesh_tris;
+    std::vector<float> mesh_inv_norm(n_mesh, 0.0f), mesh_back_reach(n_mesh, 0.0f), mesh_back_mag(n_mesh, 0.0f), mesh_obj_reach(n_mesh, 0.0f);  // maxima over a virtual mesh's instances
+    for (size_t m = 0; m < n_mesh; m++) mesh_obj_reach[m] = src_obj_reach[vsrc[m]];
+    for (size_t i = 0; i < n_inst; i++) {
+        const uint32_t mesh = vmesh_of[i];
+        mesh_inv_norm[mesh] = max_f(mesh_inv_norm[mesh], inv_norm[i]);
+        mesh_back_reach[mesh] = max_f(mesh_back_reach[mesh], inst_back_reach[i]);
+        mesh_back_mag[mesh] = max_f(mesh_back_mag[mesh], inst_back_mag[i]);
     }
     // ---- per mesh: BLAS over object-space boxes, triangles in BLAS order, lookup by prim
     is.mesh_tris.assign(16ull * n_mesh_tris, 0.0f);
@@ -275,7 +314,7 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
     std::vector<std::vector<TreeNode>> mesh_tree(n_mesh);
     for (size_t m = 0; m < n_mesh; m++) {
         if (!used[m]) continue;
-        const HostMesh& g = flat.meshes[m];
+        const HostMesh& g = flat.meshes[vsrc[m]];
         const uint32_t nt = g.n_triangles();
         if (nt == 0) continue;
         std::vector<float> bounds(6ull * nt);
@@ -394,7 +433,7 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
         };
         std::vector<Cand> heap;
         for (const Prim& pr : prims) {
-            const TreeNode& t = mesh_tree[flat.instances[pr.inst].mesh][0];
+            const TreeNode& t = mesh_tree[vmesh_of[pr.inst]][0];
             heap.push_back({world_half_area(xf[pr.inst], t.lo, t.hi), pr.inst, 0u});
         }
         std::make_heap(heap.begin(), heap.end(), lower);
@@ -405,7 +444,7 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
             std::pop_heap(heap.begin(), heap.end(), lower);
             const Cand c = heap.back();
             heap.pop_back();
-            const std::vector<TreeNode>& tree = mesh_tree[flat.instances[c.inst].mesh];
+            const std::vector<TreeNode>& tree = mesh_tree[vmesh_of[c.inst]];
             const TreeNode& t = tree[c.node];
             if (t.n_leaf == 0 && t.n_inner > 0 && count + t.n_inner - 1u <= budget) {
                 count += t.n_inner - 1u;
@@ -430,11 +469,11 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
         parallel_chunks((unsigned)n_inst, n_inst > 16 ? host_threads() : 1u, [&](unsigned i) {
             const uint32_t p0 = first_of[i], p1 = first_of[i + 1];
             if (p0 == p1) return;
-            const uint32_t mesh = flat.instances[i].mesh;
+            const uint32_t mesh = vmesh_of[i];
             if (p1 - p0 == 1 && prims[p0].node == 0) {
                 for (int a = 0; a < 6; a++) tb[6ull * p0 + a] = inst_bounds[6 * i + a];
             } else {
-                const HostMesh& g = flat.meshes[mesh];
+                const HostMesh& g = flat.meshes[vsrc[mesh]];
                 const InstXf& x = xf[i];
                 const std::vector<TreeNode>& tree = mesh_tree[mesh];
                 const std::vector<uint32_t>& ord = mesh_order[mesh];
@@ -491,8 +530,8 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
         float* r = &is.tlas_leaves[16ull * k];
         for (int row = 0; row < 3; row++)
             for (int c = 0; c < 4; c++) r[4 * row + c] = (float)inv[12 * i + 4 * row + c];
-        r[12] = u2f(blas_node_off[in.mesh]);
-        r[13] = u2f(mesh_base[in.mesh]);
+        r[12] = u2f(blas_node_off[vmesh_of[i]]);
+        r[13] = u2f(mesh_base[vmesh_of[i]]);
         r[14] = u2f(i);
         r[15] = u2f(prims[tlas_order[k]].node);  // where in the mesh's tree this record starts (0 = the root)
     }
@@ -555,7 +594,7 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
     // the instance records' spare words: where the device finds an instance's mesh, materials, light and global ids (dinst.h)
     for (size_t i = 0; i < n_inst; i++) {
         float* r = &out.inst[32 * i];
-        r[7] = u2f(mesh_base[flat.instances[i].mesh]);
+        r[7] = u2f(mesh_base[vmesh_of[i]]);
         r[11] = u2f(mat_base[i]);
         r[15] = u2f(is.inst_light[i]);
         r[23] = u2f(out.inst_tri_offset[i]);
@@ -566,7 +605,7 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
         double f2 = 0.0;
         for (int c = 0; c < 3; c++)
             for (int rr = 0; rr < 3; rr++) f2 += (double)tm[4 * c + rr] * tm[4 * c + rr];
-        r[28] = (float)(std::sqrt(f2) * 1.0001) * mesh_size[flat.instances[i].mesh];
+        r[28] = (float)(std::sqrt(f2) * 1.0001) * mesh_size[vmesh_of[i]];
     }
 }
 

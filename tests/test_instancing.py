@@ -190,3 +190,49 @@ def test_more_instance_triangles_than_ids_are_refused(hip_lib):
     with pytest.raises(capi.AkariError) as ei:
         capi.Scene(None, sd)
     assert ei.value.code == capi.ERR_UNSUPPORTED and "32 bits" in str(ei.value)
+
+
+def test_one_tiny_instance_does_not_inflate_the_trees_of_the_others(hip_lib):
+    """a mesh's tree is padded for the worst of its instances (|M^-1| scales every term), so one copy scaled to 1e-4 among
+    ordinary ones used to inflate the boxes of all of them until the tree stopped culling. The instances of a mesh are now sorted into
+    padding classes and each class that occurs gets a tree of its own: the ordinary copies' tree is, byte for byte, the tree of the scene
+    without the tiny copy; the tiny copy's own tree is the padded one; and no accepted (ray, triangle) pair is culled in either."""
+    import copy
+
+    from tests import bvh_model
+
+    base = instanced_scene(n_inst=10, n=8)
+    blob = next(i for i in base.instances if sum(1 for j in base.instances if j.mesh == i.mesh) > 1)
+    tiny = copy.deepcopy(blob)
+    m = np.array(tiny.transform, dtype=np.float32).reshape(4, 4).T.copy()  # (column-major in, row-major here)
+    m[:3, :3] *= np.float32(1e-4)
+    m[:3, 3] = np.float32(0.25)  # inside the scene's box: the scene's magnitude terms do not move
+    tiny.transform = m.T.reshape(16).copy()
+    with_tiny = copy.deepcopy(base)
+    with_tiny.instances = list(base.instances) + [tiny]
+
+    def trees(sd):
+        with capi.options(instancing=1):
+            sc = capi.Scene(None, sd)
+        nodes = sc.array(capi.ARRAY_BVH_NODES, np.uint32).reshape(-1, 16)
+        leaves = sc.array(capi.ARRAY_INST_LEAVES, np.float32).reshape(-1, 16)
+        off = leaves[:, 12].view(np.uint32)
+        inst = leaves[:, 14].view(np.uint32)
+        return sc, nodes, {int(i): int(o) for i, o in zip(inst, off)}, sorted(set(int(o) for o in off))
+
+    sc0, nodes0, off0, starts0 = trees(base)
+    sc1, nodes1, off1, starts1 = trees(with_tiny)
+    assert len(starts1) == len(starts0) + 1                      # one more per-mesh tree: the tiny copy's class
+    blob_ids = [k for k, i in enumerate(base.instances) if i.mesh == blob.mesh]
+    assert len({off1[k] for k in blob_ids}) == 1 and off1[len(base.instances)] not in {off1[k] for k in blob_ids}
+
+    def tree_at(nodes, starts, o):  # the nodes of the tree that starts at node o
+        nxt = [x for x in starts if x > o]
+        return nodes[o:(nxt[0] if nxt else len(nodes))]
+
+    ordinary0, ordinary1 = tree_at(nodes0, starts0, off0[blob_ids[0]]), tree_at(nodes1, starts1, off1[blob_ids[0]])
+    assert ordinary0.shape == ordinary1.shape and np.array_equal(ordinary0, ordinary1)
+    with capi.options(instancing=0, force_bvh=1):
+        flat = capi.Scene(None, with_tiny)
+    a, c, worst = bvh_model.check_kept(sc1, flat, 48, np.random.default_rng(11), max_tris=700)
+    assert a > 3000 and c == 0, (a, c, worst[:5])
