@@ -15,12 +15,16 @@ namespace akr {
 
 // ----------------------------------------------------------------------------------------------------------
 // work distribution: item index -> pixel. Items enumerate the pixels of the tiles this rank owns
-// (tile t belongs to rank t % shard_count), tile by tile, and inside a tile in 8x8 blocks so that one wave
+// (kernels.h tile_owner: a tile's Morton code modulo the ranks; the session's owned_tiles lists them), tile by tile, and inside a tile in 8x8 blocks so that one wave
 // covers an 8x8 pixel square (coherent primary rays, one film cache line per row segment).
 AKR_D bool item_to_pixel(const PtParams& p, uint32_t item, uint32_t& px, uint32_t& py) {
     const uint32_t tile_px = p.tile_w * p.tile_h;
     uint32_t j = item / tile_px, within = item - j * tile_px;
-    uint32_t tile = p.shard_rank + j * p.shard_count;
+    uint32_t tile = j;  // one rank: every tile, row by row
+    if (p.shard_count > 1) {
+        if (item >= p.n_items) return false;
+        tile = p.owned_tiles[j];
+    }
     if (tile >= p.tiles_x * p.tiles_y) return false;
     uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     uint32_t block = within >> 6, lane = within & 63u;

@@ -161,7 +161,7 @@ AKR_D int gpt_sources(int32_t cp, int32_t o, uint32_t r, uint32_t out[3]) {
 // the primal / gradient sums and sums of squares.
 AKR_D bool gpt_owned(const GptParams& g, uint32_t x, uint32_t y) {
     if (g.shard_count <= 1) return true;
-    return ((y / g.tile_h) * g.tiles_x + x / g.tile_w) % g.shard_count == g.shard_rank;
+    return tile_owner(x / g.tile_w, y / g.tile_h, g.shard_count) == g.shard_rank;
 }
 __global__ __launch_bounds__(256) void k_gpt_update(const GptParams g, uint32_t W, uint32_t H, float* __restrict__ film) {
     const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);

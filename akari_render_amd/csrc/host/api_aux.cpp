@@ -142,9 +142,9 @@ AKR_API int32_t akr_gpt_begin(akr_context* ctx, akr_scene* scene, const akr_gpt_
             if (tw % 8 != 0 || th % 8 != 0) throw std::invalid_argument("akr_shard: tile sizes must be multiples of 8");
             const uint32_t tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th;
             g.shard_rank = shard->shard_rank; g.shard_count = shard->shard_count; g.tile_w = tw; g.tile_h = th; g.tiles_x = tiles_x;
-            auto owned = [&](uint32_t x, uint32_t y) { return ((y / th) * tiles_x + x / tw) % shard->shard_count == shard->shard_rank; };
+            auto owned = [&](uint32_t x, uint32_t y) { return tile_owner(x / tw, y / th, shard->shard_count) == shard->shard_rank; };
             std::vector<uint32_t> list;
-            for (uint32_t t = shard->shard_rank; t < tiles_x * tiles_y; t += shard->shard_count) {
+            for (uint32_t t : akr_api::owned_tiles(tiles_x, tiles_y, shard->shard_rank, shard->shard_count)) {
                 const uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
                 for (uint32_t by = 0; by < th / 8; by++)
                     for (uint32_t bx = 0; bx < tw / 8; bx++)

@@ -177,6 +177,8 @@ struct akr_pt_session {
     akr_film* film = nullptr;
     akr_pt_config cfg;
     DevBuf states, counters;
+    DevBuf owned_tiles;        // shard_count > 1: PtParams.owned_tiles
+    uint32_t n_owned_tiles = 0;
     // wavefront schedule (wf_kernels.hip): path state SoA + ray queues
     bool wavefront = false;
     DevBuf wf_state, wf_queues, wf_ctrl;
@@ -268,6 +270,8 @@ struct LaunchTimer {
 int32_t pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_config* cfg, akr_film* film, akr_pt_session** out, bool for_pt_kernel);
 void fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_pass_spp);
 uint32_t session_samples(const akr_pt_config& c);
+// the tiles (row-major ids) rank `rank` of `count` owns, in Morton order (kernels.h tile_owner)
+std::vector<uint32_t> owned_tiles(uint32_t tiles_x, uint32_t tiles_y, uint32_t rank, uint32_t count);
 // api_scene.cpp
 void scene_finish(akr_scene* s);
 void scene_spec_header(akr_scene* scene, std::string& out);

@@ -131,9 +131,29 @@ void akr_api::fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_p
     p.tile_h = c.tile_h ? c.tile_h : 32;
     p.tiles_x = (p.width + p.tile_w - 1) / p.tile_w;
     p.tiles_y = (p.height + p.tile_h - 1) / p.tile_h;
-    uint32_t n_tiles = p.tiles_x * p.tiles_y;
-    uint32_t owned = p.shard_rank < n_tiles ? (n_tiles - p.shard_rank + p.shard_count - 1) / p.shard_count : 0;
-    p.n_items = owned * p.tile_w * p.tile_h;
+    if (p.shard_count > 1) {
+        if (se->owned_tiles.p == nullptr && se->n_owned_tiles == 0) {  // once per session: the configuration does not change
+            const std::vector<uint32_t> list = owned_tiles(p.tiles_x, p.tiles_y, p.shard_rank, p.shard_count);
+            se->n_owned_tiles = (uint32_t)list.size();
+            if (!list.empty()) se->owned_tiles.upload(list);
+        }
+        p.owned_tiles = se->owned_tiles.as<uint32_t>();
+        p.n_items = se->n_owned_tiles * p.tile_w * p.tile_h;
+    } else {
+        p.owned_tiles = nullptr;
+        p.n_items = p.tiles_x * p.tiles_y * p.tile_w * p.tile_h;
+    }
+}
+std::vector<uint32_t> akr_api::owned_tiles(uint32_t tiles_x, uint32_t tiles_y, uint32_t rank, uint32_t count) {
+    std::vector<std::pair<uint32_t, uint32_t>> mine;  // (Morton code, tile)
+    for (uint32_t ty = 0; ty < tiles_y; ty++)
+        for (uint32_t tx = 0; tx < tiles_x; tx++)
+            if (tile_owner(tx, ty, count) == rank) mine.emplace_back(tile_morton(tx, ty), ty * tiles_x + tx);
+    std::sort(mine.begin(), mine.end());
+    std::vector<uint32_t> out;
+    out.reserve(mine.size());
+    for (const auto& m : mine) out.push_back(m.second);
+    return out;
 }
 
 // Which schedule renders this session: the persistent-lane megakernel (pt_kernels.hip, pt_inst_kernels.hip) or the wavefront schedule --
@@ -152,9 +172,12 @@ void akr_api::fill_params(akr_pt_session* se, uint32_t n_passes, uint32_t last_p
 constexpr uint32_t kWfAutoItems = 2000000;
 static uint32_t session_items(const akr_pt_config& c, uint32_t width, uint32_t height) {  // = fill_params' n_items
     const uint32_t tw = c.tile_w ? c.tile_w : 32, th = c.tile_h ? c.tile_h : 32;
-    const uint32_t n_tiles = ((width + tw - 1) / tw) * ((height + th - 1) / th);
-    const uint32_t rank = c.shard_count > 1 ? c.shard_rank : 0, count = c.shard_count > 1 ? c.shard_count : 1;
-    return (rank < n_tiles ? (n_tiles - rank + count - 1) / count : 0) * tw * th;
+    const uint32_t tiles_x = (width + tw - 1) / tw, tiles_y = (height + th - 1) / th;
+    if (c.shard_count <= 1) return tiles_x * tiles_y * tw * th;
+    uint32_t n = 0;
+    for (uint32_t ty = 0; ty < tiles_y; ty++)
+        for (uint32_t tx = 0; tx < tiles_x; tx++) n += tile_owner(tx, ty, c.shard_count) == c.shard_rank ? 1u : 0u;
+    return n * tw * th;
 }
 static bool choose_wavefront(const akr_scene* scene, const akr_pt_config& cfg, bool for_pt_kernel) {
     const int opt = tuning().wavefront;

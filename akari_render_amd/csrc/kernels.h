@@ -128,7 +128,24 @@ struct PtParams {
     uint32_t n_items;
     uint32_t shard_rank, shard_count;
     uint32_t tile_w, tile_h, tiles_x, tiles_y;
+    const uint32_t* owned_tiles;  // shard_count > 1: the tiles (row-major ids) this rank owns, in Morton order (tile_owner below); else null
 };
+
+// Which rank owns tile (tx, ty) of a frame shared by `count` ranks: its position on the Z-order (Morton) curve, modulo the ranks
+// ("tile t owned by GPU t mod G in Morton order"): 8 ranks each get one tile of every aligned 4 x 2 block of tiles, so every
+// rank sees the same mix of cheap and expensive regions whatever the row length is. One definition for the kernels (dpath.h
+// item_to_pixel through the session's owned_tiles list, gpt_kernels.hip), the host (api_pt.cpp, api_aux.cpp), and -- restated -- the
+// oracle (akr_oracle.c or_pixel_owned) and the Python mirror (distributed.owned_pixel_mask).
+AKR_HD uint32_t morton_spread16(uint32_t x) {
+    x &= 0xffffu;
+    x = (x | (x << 8)) & 0x00ff00ffu;
+    x = (x | (x << 4)) & 0x0f0f0f0fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+AKR_HD uint32_t tile_morton(uint32_t tx, uint32_t ty) { return morton_spread16(tx) | (morton_spread16(ty) << 1); }
+AKR_HD uint32_t tile_owner(uint32_t tx, uint32_t ty, uint32_t count) { return tile_morton(tx, ty) % count; }
 
 // Path state of the wavefront schedule (wf_kernels.hip): structure-of-arrays, one slot per pixel of the launch.
 struct WfBuffers {

@@ -2,7 +2,7 @@
 
 The reference has no multi-device code. Every pixel-sample of the path tracer is independent and
 the per-pixel sampler stream does not depend on which rank renders the pixel, so rank r simply renders the tiles
-t with t % world == r (akr_pt_config.shard_*) into a film that stays zero elsewhere; torch.distributed (backend
+(tx, ty) with morton(tx, ty) % world == r (akr_pt_config.shard_*) into a film that stays zero elsewhere; torch.distributed (backend
 "nccl" == RCCL over xGMI on ROCm, "gloo" on CPU) then sums the films onto rank 0. There is no collective inside
 the render itself.
 """
@@ -37,13 +37,24 @@ def shard_config(cfg: abi.PtConfig, rank: int, world: int, tile_w: int = 32, til
     return c
 
 
+def tile_morton(tx, ty):
+    """Position of tile (tx, ty) on the Z-order curve (csrc/kernels.h tile_morton): x in the even bits, y in the odd ones."""
+    def spread(v):
+        v = np.asarray(v, dtype=np.uint64) & np.uint64(0xffff)
+        v = (v | (v << np.uint64(8))) & np.uint64(0x00ff00ff)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x0f0f0f0f)
+        v = (v | (v << np.uint64(2))) & np.uint64(0x33333333)
+        v = (v | (v << np.uint64(1))) & np.uint64(0x55555555)
+        return v
+    return spread(tx) | (spread(ty) << np.uint64(1))
+
+
 def owned_pixel_mask(width: int, height: int, rank: int, world: int, tile_w: int = 32, tile_h: int = 32) -> np.ndarray:
-    """Host mirror of the kernels' tile ownership rule (pt_kernels.hip: item_to_pixel): bool[H, W]."""
+    """Host mirror of the kernels' tile ownership rule (csrc/kernels.h tile_owner: a tile's Morton code modulo the ranks): bool[H, W]."""
     if world <= 1:
         return np.ones((height, width), dtype=bool)
-    tiles_x = (width + tile_w - 1) // tile_w
     ty, tx = np.meshgrid(np.arange(height) // tile_h, np.arange(width) // tile_w, indexing="ij")
-    return ((ty * tiles_x + tx) % world) == rank
+    return (tile_morton(tx, ty) % world) == rank
 
 
 def owned_pixel_count(width: int, height: int, rank: int, world: int, tile_w: int = 32, tile_h: int = 32) -> int:

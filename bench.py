@@ -277,7 +277,7 @@ _SCENES = {}  # (config key, forced BVH) -> (scene, info): the 10 M-triangle hal
 def run_config(ctx, key, steps, warmup, rank, world, scaling, film_t, torch, dist, backend, dev, comm=None, passes_per_step=PASSES_PER_STEP,
                force_bvh=False, keep_scene=False, split="tiles", sampler="independent"):
     """Times `steps` steps of configuration `key` on this rank. Returns (elapsed_s, per-rank counter deltas, extra info).
-    split = "tiles": rank r renders the pixel tiles t % world == r. split = "samples" (index-based samplers only): rank r renders
+    split = "tiles": rank r renders the pixel tiles whose Morton code % world == r. split = "samples" (index-based samplers only): rank r renders
     samples [r S / world, (r + 1) S / world) of EVERY pixel, S = the run's total spp (akr_pt_config.sample_begin / sample_count)."""
     from akari_render_amd import abi, capi, distributed
 

@@ -205,8 +205,9 @@ typedef struct {
     uint32_t sampler_type;
     uint32_t color;           /* akr_color_pipeline_bits; 0 = sRGB / sRGB */
     uint64_t sampler_seed;
-    /* Multi-GPU sharding (no reference counterpart): rank r of n renders the pixel tiles t with
-     * t % n == r (tiles of tile_w x tile_h in row-major tile order; 0 = 32). shard_count <= 1 renders all.
+    /* Multi-GPU sharding (no reference counterpart): rank r of n renders the pixel tiles (tx, ty) with
+     * morton(tx, ty) % n == r -- tiles of tile_w x tile_h (0 = 32) dealt along the Z-order curve (x in the even bits of the code), so that
+     * 8 ranks each own one tile of every aligned 4 x 2 block of tiles. shard_count <= 1 renders all.
      * Pixels a rank does not own are left untouched in its film, so a sum-reduce assembles the frame. */
     uint32_t shard_rank, shard_count, tile_w, tile_h;
     /* Sample-range split (SURVEY.md 8b "sample range", 8e "sample-range split"; no reference counterpart): the session renders

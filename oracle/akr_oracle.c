@@ -841,12 +841,19 @@ typedef struct {
     char pad[128]; /* one cache line (and its neighbour) per worker: the counters are bumped per ray */
 } __attribute__((aligned(128))) or_job;
 
+/* Tile sharding (no reference counterpart: SURVEY 8e's multi-GPU split): the tile of a pixel belongs to rank (Morton code of the tile's
+ * coordinates) mod shard_count -- the product's definition (csrc/kernels.h tile_owner), restated. */
+static uint32_t or_spread16(uint32_t x) {
+    x &= 0xffffu;
+    x = (x | (x << 8)) & 0x00ff00ffu; x = (x | (x << 4)) & 0x0f0f0f0fu; x = (x | (x << 2)) & 0x33333333u; x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
 static int or_pixel_owned(const or_pt_config *cfg, uint32_t width, uint32_t x, uint32_t y) {
+    (void)width;
     if (cfg->shard_count <= 1) return 1;
     uint32_t tw = cfg->tile_w ? cfg->tile_w : 32, th = cfg->tile_h ? cfg->tile_h : 32;
-    uint32_t tiles_x = (width + tw - 1) / tw;
-    uint32_t t = (y / th) * tiles_x + (x / tw);
-    return (t % cfg->shard_count) == cfg->shard_rank;
+    uint32_t code = or_spread16(x / tw) | (or_spread16(y / th) << 1);
+    return (code % cfg->shard_count) == cfg->shard_rank;
 }
 static void or_render_pixel(or_job *j, uint32_t x, uint32_t y) { /* kernel body, pt.rs:1077-1102 */
     const or_scene *sc = j->sc; const or_pt_config *cfg = j->cfg;

@@ -6,7 +6,7 @@ depend on which tiles are rendered with it (akr_pt_config.shard_* on the GPU sid
 pt.rs:1075-1103: one thread per pixel, no cross-pixel state). So the GPU renders tile shard k of n of the real frame with
 the real spp / depth / filter, the oracle renders the same shard, and the two 7 N-float films must be identical -- inside
 the shard (all samples of all owned pixels) and outside it (zeros). The shard is a few tiles spread over the frame
-(tile t belongs to shard t % n), so it mixes background, walls, boxes and light.
+(a tile belongs to shard morton(tx, ty) % n), so it mixes background, walls, boxes and light.
 
 C4 (10 M triangles): the oracle's exhaustive loop is the definition of a hit; it runs here on one 8x8 tile at 1 spp. The
 1024-spp shard uses the oracle-side BVH of oracle/or_accel.h, which is pinned to the exhaustive loop ray by ray on the CPU

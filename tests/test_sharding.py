@@ -21,6 +21,25 @@ def test_ownership_mask_partitions_the_frame():
     assert max(counts) / min(counts) < 1.08
 
 
+def test_tiles_are_dealt_along_the_morton_curve():
+    """"tile t owned by GPU t mod G in Morton order". Over 8 ranks every aligned 4 x 2 block of tiles holds one tile of each
+    rank, so at 1080p (60 x 34 tiles of 32 x 32: 15 x 17 whole blocks) every rank owns exactly 255 tiles, whatever the row length."""
+    m = [distributed.owned_pixel_mask(1920, 1080, r, 8) for r in range(8)]
+    for r in range(8):
+        tiles = m[r][::32, ::32]  # one sample per tile (the last tile row is 24 pixels high: still sampled at its first row)
+        assert tiles.shape == (34, 60) and int(tiles.sum()) == 255
+        blocks = tiles.reshape(17, 2, 15, 4).transpose(0, 2, 1, 3).reshape(17 * 15, 8)
+        assert np.all(blocks.sum(axis=1) == 1)
+    # the curve itself: x in the even bits, y in the odd ones
+    assert [int(distributed.tile_morton(x, y)) for x, y in [(0, 0), (1, 0), (0, 1), (1, 1), (2, 0), (3, 5), (255, 255)]] == [0, 1, 2, 3, 4, 0b100111, 0xffff]
+    # rank = code mod world for any world size
+    ty, tx = np.meshgrid(np.arange(9), np.arange(13), indexing="ij")
+    for world in (2, 3, 5, 7):
+        owner = (distributed.tile_morton(tx, ty) % np.uint64(world)).astype(int)
+        for r in range(world):
+            assert np.array_equal(distributed.owned_pixel_mask(13 * 16, 9 * 8, r, world, 16, 8)[::8, ::16], owner == r)
+
+
 def test_oracle_shards_follow_the_mask(oracle_lib, cbox_path):
     sd = scene_json.load_scene(cbox_path, 72, 40)
     sc = pyoracle.OracleScene(sd)

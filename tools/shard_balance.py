@@ -2,7 +2,7 @@
 rank of an N-way tile sharding (each on the whole GPU) and compares max-over-ranks kernel time with T1 / N.
 python tools/shard_balance.py [N=8] [steps=16] [--fd | --full] [--4k] [--split samples [--sampler sobol|pmj02bn]]
 (--fd = C2, force_diffuse, the default; --full = C3; --split samples: rank r renders samples [r S / N, (r + 1) S / N) of EVERY pixel --
-akr_pt_config.sample_begin / sample_count, index-based samplers only -- instead of the pixel tiles t % N == r)
+akr_pt_config.sample_begin / sample_count, index-based samplers only -- instead of the pixel tiles morton(tx, ty) % N == r)
 No multi-GPU hardware is involved: what this measures is how well 1/N of the frame fills ONE GPU -- the kernel-side term of
 strong scaling. The film reduce (one ncclReduce of 7 W H floats) and launch overheads come on top."""
 import json, os, sys
