@@ -87,8 +87,20 @@ AKR_D void resolve_pending(const DScene& sc, TravI& s, bool any_hit) {
     const vec3 c0 = xyz(m[0]), c1 = xyz(m[1]), c2 = xyz(m[2]), tr = xyz(m[3]);
     const vec3 A = xf_point(c0, c1, c2, tr, xyz(q0)), B = xf_point(c0, c1, c2, tr, xyz(q1)), C = xf_point(c0, c1, c2, tr, xyz(q2));
     float wr[12];
+#if defined(AKR_INST_FAKE_EXACT)  // timing only: f32 rows (films differ)
+    {
+        const vec3 e1 = B - A, e2 = C - A, n = cross(e1, e2);
+        const float det = dot(n, n), inv = 1.0f / det;
+        const vec3 r0 = cross(e2, n) * inv, r1 = cross(n, e1) * inv, r2 = n * inv;
+        wr[0] = r0.x; wr[1] = r0.y; wr[2] = r0.z; wr[3] = -dot(r0, A);
+        wr[4] = r1.x; wr[5] = r1.y; wr[6] = r1.z; wr[7] = -dot(r1, A);
+        wr[8] = r2.x; wr[9] = r2.y; wr[10] = r2.z; wr[11] = -dot(r2, A);
+    }
+    if (false) {
+#else
     woop_precompute(A, B, C, wr);
-    if (prim & 1u) {  // the coplanar-neighbour rule: the even triangle's plane row, if this one lies in it
+    if (prim & 1u) {
+#endif  // the coplanar-neighbour rule: the even triangle's plane row, if this one lies in it
         const float4* nb = sc.in2.mesh_tris + (size_t)(tri_off + sc.in2.mesh_pos[tri_off + prim - 1u]) * 4;
         const vec3 na = xf_point(c0, c1, c2, tr, xyz(nb[0])), nbv = xf_point(c0, c1, c2, tr, xyz(nb[1])), nc = xf_point(c0, c1, c2, tr, xyz(nb[2]));
         float ra[4];
