@@ -8,7 +8,7 @@ OUT=gpurun_out/close
 rm -rf $OUT; mkdir -p $OUT
 HASH=$(python -c "import bench; print(bench.csrc_hash())")
 { echo "# python -m pytest tests -m gpu -q on MI355X, round 6 closing sources (csrc hash $HASH)"
-  ( time python -m pytest tests -m gpu -q 2>&1 | tail -1 ) 2>&1 | grep -E "passed|failed|real"
+  ( time python -m pytest tests -m gpu -q 2>&1 | grep -E " passed| failed" ) 2>&1 | grep -E "passed|failed|real"
   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1; } > $OUT/gputest_summary.txt
 { python tools/soak.py 1500 0; python tools/soak.py 300 20000 inst; python tools/soak.py 200 30000 wavefront; } 2>&1 | grep "cases from" > $OUT/soak.txt
 python tools/inst_extreme_check.py 400 0 oracle 2>&1 | tail -1 > $OUT/inst_extreme_400.txt
