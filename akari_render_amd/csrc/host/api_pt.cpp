@@ -166,7 +166,8 @@ std::vector<uint32_t> akr_api::owned_tiles(uint32_t tiles_x, uint32_t tiles_y, u
 //     trace kernel refills a wave's idle lanes where the megakernel's wait: 1080p forest 1000 x 10 k triangles 163 -> 228 Msamples/s, 4K
 //     177 -> 282 (x 100 k: 113 -> 136 with two slot groups, 4K 125 -> 179). Below that size the persistent trace kernel's 262 k lanes
 //     are not filled and the megakernel wins (1024 x 1024, x 100 k: 124 against 85) -- profiles/r6_kept_schedules.txt. Kept scenes with
-//     texture-fed materials stay on the megakernel (its per-scene kernels evaluate the shader graphs; k_wf_shade interprets them).
+//     texture-fed materials as well: k_wf_shade interprets the shader graphs where the megakernel has its per-scene kernels, and still
+//     the same forest with image-textured leaves and bark renders at 193 against 157 Msamples/s (x 100 k: 123 against 100).
 // The option is process-wide and aov / gpt / mcmc_opt sessions come through here too: they render with their own kernels; a scene without a
 // tree (64 triangles or fewer, no force_bvh) has no wavefront kernels and renders with the megakernel whatever the option says.
 constexpr uint32_t kWfAutoItems = 2000000;
@@ -184,7 +185,7 @@ static bool choose_wavefront(const akr_scene* scene, const akr_pt_config& cfg, b
     const bool can = !scene->cs.bvh_nodes.empty() || scene->cs.instanced.on;
     if (opt == 0 || !can) return false;
     if (opt > 0) return true;
-    return for_pt_kernel && scene->cs.instanced.on && !scene->cs.has_textures &&
+    return for_pt_kernel && scene->cs.instanced.on &&
            session_items(cfg, scene->flat.camera.width, scene->flat.camera.height) >= kWfAutoItems;
 }
 

@@ -232,7 +232,7 @@ def test_rebraided_top_level_tree_and_slot_groups_change_no_bit(ctx, root):
 
 
 def test_the_library_picks_the_wavefront_schedule_for_large_kept_frames(ctx, root):
-    """Option wavefront = -1 (default): pt sessions of >= 2 M pixels on an untextured kept scene run the wavefront schedule (api_pt.cpp
+    """Option wavefront = -1 (default): pt sessions of >= 2 M pixels on a kept scene run the wavefront schedule (api_pt.cpp
     choose_wavefront: 1080p forest 163 -> 228 Msamples/s), smaller ones and aov sessions the megakernel; same film either way."""
     assert capi.get_option("wavefront") == -1
     sd = procedural.instanced_forest(12, 2000, width=1920, height=1080)
@@ -255,7 +255,19 @@ def test_the_library_picks_the_wavefront_schedule_for_large_kept_frames(ctx, roo
         se = capi.PtSession(ctx, small, cfg, capi.Film(ctx, 256, 256))
         assert "wavefront" not in se.kernel_info()["status"]
         se.end()
+        # texture-fed materials do not change the choice (k_wf_shade interprets the graphs: forest with image-textured leaves 157 -> 193)
+        tex = capi.Scene(ctx, _kept_scene_data(root, True, 2048, 1024))
+        assert tex.info().uses_bvh == 2
+        for mode in (-1, 0):
+            with capi.options(wavefront=mode):
+                film = capi.Film(ctx, 2048, 1024)
+                se = capi.PtSession(ctx, tex, cfg, film)
+                assert ("wavefront" in se.kernel_info()["status"]) == (mode == -1)
+                se.passes(1, blocking=True)
+                se.end()
+                films["tex", mode] = film.read()
     assert n_bit_diff(films[-1], films[0]) == 0
+    assert n_bit_diff(films["tex", -1], films["tex", 0]) == 0
 
 
 def test_forest_of_ten_million_instance_triangles_on_a_tile_shard(ctx, root):
