@@ -91,6 +91,23 @@ AKR_HD void woop_precompute(vec3 A, vec3 B, vec3 C, float* w) {
     w[4] = (float)r1x; w[5] = (float)r1y; w[6] = (float)r1z; w[7] = (float)(-(r1x * ax + r1y * ay + r1z * az));
     w[8] = (float)r2x; w[9] = (float)r2y; w[10] = (float)r2z; w[11] = (float)(-(r2x * ax + r2y * ay + r2z * az));
 }
+// the first two rows alone, bit for bit woop_precompute's (the device's exact test of a kept scene takes the third from woop_plane_row of
+// either this triangle or the even neighbour whose plane it shares: dinst_trav.h resolve_pending)
+AKR_HD void woop_edge_rows(vec3 A, vec3 B, vec3 C, float* w) {
+    double ax = A.x, ay = A.y, az = A.z;
+    double e1x = (double)B.x - ax, e1y = (double)B.y - ay, e1z = (double)B.z - az;
+    double e2x = (double)C.x - ax, e2y = (double)C.y - ay, e2z = (double)C.z - az;
+    double nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
+    double det = nx * nx + ny * ny + nz * nz;
+    if (!(det > 0.0)) {
+        for (int i = 0; i < 8; i++) w[i] = 0.0f;
+        return;
+    }
+    double r0x = (e2y * nz - e2z * ny) / det, r0y = (e2z * nx - e2x * nz) / det, r0z = (e2x * ny - e2y * nx) / det;
+    double r1x = (ny * e1z - nz * e1y) / det, r1y = (nz * e1x - nx * e1z) / det, r1z = (nx * e1y - ny * e1x) / det;
+    w[0] = (float)r0x; w[1] = (float)r0y; w[2] = (float)r0z; w[3] = (float)(-(r0x * ax + r0y * ay + r0z * az));
+    w[4] = (float)r1x; w[5] = (float)r1y; w[6] = (float)r1z; w[7] = (float)(-(r1x * ax + r1y * ay + r1z * az));
+}
 // the third row alone (what share_plane_row needs of the even neighbour)
 AKR_HD void woop_plane_row(vec3 A, vec3 B, vec3 C, float* r2) {
     double ax = A.x, ay = A.y, az = A.z;
@@ -113,16 +130,19 @@ AKR_HD void woop_plane_row(vec3 A, vec3 B, vec3 C, float* r2) {
 // solve the plane once per quad (disect.h). A data-level definition: the oracle applies the same rule when it builds its
 // scene (oracle/akr_oracle.c: or_share_plane_row); nothing in either tracer depends on it.
 // ra = the even triangle's third row (4 floats), rb = the odd one's (overwritten if shared), vb = the odd one's world vertices.
-AKR_HD void share_plane_row(const float* ra, float* rb, const vec3 vb[3]) {
+AKR_HD bool plane_row_is_shared(const float* ra, const float* rb, const vec3 vb[3]) {
     const double rx = ra[0], ry = ra[1], rz = ra[2], c = ra[3];
     const double len = __builtin_sqrt(rx * rx + ry * ry + rz * rz);  // = 1 / |n| = 1 / (2 area)
-    if (!(len > 0.0) || (rb[0] == 0.0f && rb[1] == 0.0f && rb[2] == 0.0f)) return;  // a degenerate triangle on either side
+    if (!(len > 0.0) || (rb[0] == 0.0f && rb[1] == 0.0f && rb[2] == 0.0f)) return false;  // a degenerate triangle on either side
     const double tol = 1e-6 * __builtin_sqrt(len);  // height / sqrt(|n|) <= 1e-6
     for (int i = 0; i < 3; i++) {
         const double s = ((rx * (double)vb[i].x + ry * (double)vb[i].y) + rz * (double)vb[i].z) + c;
-        if (!(__builtin_fabs(s) <= tol)) return;
+        if (!(__builtin_fabs(s) <= tol)) return false;
     }
-    rb[0] = ra[0]; rb[1] = ra[1]; rb[2] = ra[2]; rb[3] = ra[3];
+    return true;
+}
+AKR_HD void share_plane_row(const float* ra, float* rb, const vec3 vb[3]) {
+    if (plane_row_is_shared(ra, rb, vb)) { rb[0] = ra[0]; rb[1] = ra[1]; rb[2] = ra[2]; rb[3] = ra[3]; }
 }
 
 

@@ -83,7 +83,7 @@ AKR_D void resolve_pending(const DScene& sc, TravI& s, bool any_hit) {
     const float4* rec = sc.in2.mesh_tris + (size_t)s.pend_rec * 4;
     s.pend_rec = kInvalid;
     const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-    const uint32_t tri_off = f2u(m[1].w), prim = f2u(q3.w), gid = f2u(m[5].w) + prim;
+    const uint32_t tri_off = f2u(m[1].w), prim = f2u(q3.w) & kMeshPrimMask, gid = f2u(m[5].w) + prim;
     const vec3 c0 = xyz(m[0]), c1 = xyz(m[1]), c2 = xyz(m[2]), tr = xyz(m[3]);
     const vec3 A = xf_point(c0, c1, c2, tr, xyz(q0)), B = xf_point(c0, c1, c2, tr, xyz(q1)), C = xf_point(c0, c1, c2, tr, xyz(q2));
     float wr[12];
@@ -96,18 +96,20 @@ AKR_D void resolve_pending(const DScene& sc, TravI& s, bool any_hit) {
         wr[4] = r1.x; wr[5] = r1.y; wr[6] = r1.z; wr[7] = -dot(r1, A);
         wr[8] = r2.x; wr[9] = r2.y; wr[10] = r2.z; wr[11] = -dot(r2, A);
     }
-    if (false) {
 #else
-    woop_precompute(A, B, C, wr);
-    if (prim & 1u) {
-#endif  // the coplanar-neighbour rule: the even triangle's plane row, if this one lies in it
+    // The coplanar-neighbour rule (dinst.h share_plane_row: an odd triangle lying in its even neighbour's plane carries that neighbour's plane
+    // row) was decided once per scene for every instance-triangle (k_inst_share_bits: inst_pair_shares below). Here the third row is computed
+    // from the neighbour's vertices instead of the triangle's own -- one code path, no test at the candidate; a triangle that does not share
+    // never reads its neighbour (two dependent gathers less), and one that shares in no instance of its mesh (kMeshTriShares clear in its
+    // record: every triangle of a mesh that is not made of quads) not even its bit. 1080p forest x 10 k / x 100 k: wavefront schedule 229 -> 239 / 137 -> 146 Msamples/s, megakernel 162 -> 177 / 112 -> 123.
+    vec3 P0 = A, P1 = B, P2 = C;
+    if ((f2u(q3.w) & kMeshTriShares) && ((sc.in2.share_bits[gid >> 5] >> (gid & 31u)) & 1u)) {
         const float4* nb = sc.in2.mesh_tris + (size_t)(tri_off + sc.in2.mesh_pos[tri_off + prim - 1u]) * 4;
-        const vec3 na = xf_point(c0, c1, c2, tr, xyz(nb[0])), nbv = xf_point(c0, c1, c2, tr, xyz(nb[1])), nc = xf_point(c0, c1, c2, tr, xyz(nb[2]));
-        float ra[4];
-        woop_plane_row(na, nbv, nc, ra);
-        const vec3 vb[3] = {A, B, C};
-        share_plane_row(ra, wr + 8, vb);
+        P0 = xf_point(c0, c1, c2, tr, xyz(nb[0])); P1 = xf_point(c0, c1, c2, tr, xyz(nb[1])); P2 = xf_point(c0, c1, c2, tr, xyz(nb[2]));
     }
+    woop_edge_rows(A, B, C, wr);
+    woop_plane_row(P0, P1, P2, wr + 8);
+#endif
     float t, u, v;
     bool h = tri_test(s.wo, s.wd, make_float4(wr[0], wr[1], wr[2], wr[3]), make_float4(wr[4], wr[5], wr[6], wr[7]), make_float4(wr[8], wr[9], wr[10], wr[11]), s.tmin, s.tmax,
                       t, u, v);
@@ -125,6 +127,24 @@ AKR_D void resolve_pending(const DScene& sc, TravI& s, bool any_hit) {
             if (better) { s.best_t = t; s.best_u = u; s.best_v = v; s.best = gid; }
         }
     }
+}
+
+// share_plane_row for the odd triangle `prim` of instance `inst`, outside a traversal (k_inst_share_bits): the flattening compiler's decision
+// (host/scene_build.cpp) from the same functions on the same values.
+AKR_D bool inst_pair_shares(const DScene& sc, uint32_t inst, uint32_t prim, uint32_t& rec_pos) {
+    const float4* m = sc.inst + (size_t)inst * INST_ROWS;
+    const uint32_t tri_off = f2u(m[1].w);
+    rec_pos = tri_off + sc.in2.mesh_pos[tri_off + prim];
+    const float4* rec = sc.in2.mesh_tris + (size_t)rec_pos * 4;
+    const float4* nb = sc.in2.mesh_tris + (size_t)(tri_off + sc.in2.mesh_pos[tri_off + prim - 1u]) * 4;
+    const vec3 c0 = xyz(m[0]), c1 = xyz(m[1]), c2 = xyz(m[2]), tr = xyz(m[3]);
+    const vec3 A = xf_point(c0, c1, c2, tr, xyz(rec[0])), B = xf_point(c0, c1, c2, tr, xyz(rec[1])), C = xf_point(c0, c1, c2, tr, xyz(rec[2]));
+    const vec3 na = xf_point(c0, c1, c2, tr, xyz(nb[0])), nbv = xf_point(c0, c1, c2, tr, xyz(nb[1])), nc = xf_point(c0, c1, c2, tr, xyz(nb[2]));
+    float wr[12], ra[4];
+    woop_precompute(A, B, C, wr);
+    woop_plane_row(na, nbv, nc, ra);
+    const vec3 vb[3] = {A, B, C};
+    return plane_row_is_shared(ra, wr + 8, vb);
 }
 
 // One step of one lane, in up to four stages -- whatever the lane's state allows, in this order: pop a stack entry (possibly the
@@ -233,7 +253,7 @@ AKR_D bool trav_step_inst(const DScene& sc, TravI& s, uint32_t* __restrict__ sta
         const uint4* p = (const uint4*)sc.in2.mesh_tris + (size_t)(s.tri_off + s.tbase + leaf_bit) * 4;
         const uint4 w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3];
         cnt.tris++;
-        const uint32_t prim = w3.w, gid = s.gid_base + prim;
+        const uint32_t prim = w3.w & kMeshPrimMask, gid = s.gid_base + prim;
         if ((gid != s.ex0) & (gid != s.ex1)) {
             const float4* m = sc.inst + (size_t)s.inst * INST_ROWS;
             const vec3 c0 = xyz(m[0]), c1 = xyz(m[1]), c2 = xyz(m[2]), tr = xyz(m[3]);
@@ -241,7 +261,7 @@ AKR_D bool trav_step_inst(const DScene& sc, TravI& s, uint32_t* __restrict__ sta
             const vec3 C = xf_point(c0, c1, c2, tr, mk3(u2f(w2.x), u2f(w2.y), u2f(w2.z)));
             // (an odd triangle may carry its even neighbour's plane row: that plane is within 1e-6 sqrt(|n_even|) of its vertices;
             // m[7].x bounds sqrt(|n|) over the instance's triangles -- scene_inst.cpp)
-            const float shift = (prim & 1u) ? 2e-6f * m[7].x : 0.0f;
+            const float shift = (w3.w & kMeshTriShares) ? 2e-6f * m[7].x : 0.0f;
 #if defined(AKR_INST_PRETEST_CHECK)  // measurement / test builds: every candidate takes the exact test, which reports a wrong reject
             const bool may = tri_may_hit(s.wo, s.wd, A, B, C, s.tmin, s.best_t, shift);
             if (s.pend_rec == kInvalid && s.check_t != -2.0f) s.check_t = may ? -1.0f : s.best_t;

@@ -41,13 +41,17 @@ struct LightRec {  // one light = one emissive instance: where its triangles sit
 
 // A scene kept as meshes + instances (host/scene_inst.cpp; two-level traversal: disect.h trav_step_inst). When `on`, the per
 // instance-triangle arrays of DScene (woop, shade, normals, tri_gid) are null and bvh_nodes holds the TLAS followed by the BLASes.
+// the last word of a mesh_tris record: the triangle's index in its mesh, and (set by k_inst_share_bits once the scene is on the device) whether
+// SOME instance of the mesh gives it its even neighbour's plane row -- share_bits then says which
+constexpr uint32_t kMeshPrimMask = 0x7fffffffu, kMeshTriShares = 0x80000000u;
 struct DInst {
     const uint4* __restrict__ tlas_leaves;     // 64 B per top-level leaf entry (one or more per instance, TLAS order): world->object rows | BLAS node offset, mesh triangle base, instance, entry node
-    const float4* __restrict__ mesh_tris;      // 64 B per mesh triangle in BLAS order: v0 | uv0.x, v1 | uv0.y, v2 | uv1.x, uv1.y uv2.x uv2.y | prim
+    const float4* __restrict__ mesh_tris;      // 64 B per mesh triangle in BLAS order: v0 | uv0.x, v1 | uv0.y, v2 | uv1.x, uv1.y uv2.x uv2.y | prim (| kMeshTriShares, set on the device)
     const uint32_t* __restrict__ mesh_pos;     // mesh order -> position in mesh_tris (relative to the mesh's base)
     const uint32_t* __restrict__ mesh_meta;    // mesh order: material slot | TRI_HAS_* << 30
     const float4* __restrict__ mesh_normals;   // 6 x float4 per mesh triangle, mesh order, or nullptr
     const uint32_t* __restrict__ inst_mats;    // the instances' material lists
+    const uint32_t* __restrict__ share_bits;   // one bit per instance-triangle (global id): it takes its even neighbour's plane row (dinst.h share_plane_row; k_inst_share_bits)
     uint32_t on, n_instances;
 };
 

@@ -144,7 +144,7 @@ struct akr_scene {
     DevBuf light_alias, area_alias, lights;
     DevBuf woop, tri_gid, shade, normals, inst, materials, ggx_table, light_entries, light_pdf, light_inst, light_tri_offset,
         light_n_tris, area_entries, area_pdf, inst_tri_offset, bvh_nodes, tex_nodes, tex_images, tex_texels, tex_mat_inputs;
-    DevBuf in2_tlas_leaves, in2_mesh_tris, in2_mesh_pos, in2_mesh_meta, in2_mesh_normals, in2_inst_mats;  // meshes + instances (scene_inst.cpp)
+    DevBuf in2_tlas_leaves, in2_mesh_tris, in2_mesh_pos, in2_mesh_meta, in2_mesh_normals, in2_inst_mats, in2_share_bits;  // meshes + instances (scene_inst.cpp)
     std::vector<float> ggx_host;
     // materials / node lists / raw inputs re-compiled for a non-default colour pipeline (akr_pt_config.color), by pipeline
     struct ColorSet {

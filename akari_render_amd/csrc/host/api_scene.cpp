@@ -134,11 +134,19 @@ void akr_api::scene_finish(akr_scene* s) {
         d.tex.texels = s->tex_texels.as<uint32_t>();
         d.tex.mat_inputs = s->tex_mat_inputs.as<MatInputs>();
     }
+    if (cs.instanced.on) {  // which instance-triangles take their even neighbour's plane row: one bit each, decided on the device (dinst_trav.h resolve_pending)
+        const size_t words = ((size_t)cs.n_tris + 31u) / 32u;
+        s->in2_share_bits.alloc(std::max<size_t>(words, 1u) * 4u);
+        HIP_CHECK(hipMemsetAsync(s->in2_share_bits.p, 0, s->in2_share_bits.bytes, ctx->stream));
+        HIP_CHECK(launch_inst_share_bits(d, s->in2_share_bits.as<uint32_t>(), s->in2_mesh_tris.as<uint32_t>(), ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        d.in2.share_bits = s->in2_share_bits.as<uint32_t>();
+    }
     s->device_bytes = 0;
     for (const DevBuf* b : {&s->woop, &s->tri_gid, &s->shade, &s->normals, &s->inst, &s->materials, &s->ggx_table, &s->light_entries,
                             &s->light_pdf, &s->light_inst, &s->light_tri_offset, &s->light_n_tris, &s->area_entries, &s->area_pdf,
                             &s->inst_tri_offset, &s->light_alias, &s->area_alias, &s->lights, &s->bvh_nodes, &s->tex_nodes, &s->tex_images, &s->tex_texels, &s->tex_mat_inputs,
-                            &s->in2_tlas_leaves, &s->in2_mesh_tris, &s->in2_mesh_pos, &s->in2_mesh_meta, &s->in2_mesh_normals, &s->in2_inst_mats})
+                            &s->in2_tlas_leaves, &s->in2_mesh_tris, &s->in2_mesh_pos, &s->in2_mesh_meta, &s->in2_mesh_normals, &s->in2_inst_mats, &s->in2_share_bits})
         s->device_bytes += b->bytes;
 }
 
@@ -150,7 +158,7 @@ static uint64_t compiled_scene_bytes(const CompiledScene& cs) {
                  16ull * (cs.light_entries.size() + cs.area_entries.size() + cs.n_lights) + b(cs.bvh_nodes) + b(cs.tex_nodes) + b(cs.images) + b(cs.texels) +
                  b(cs.mat_inputs);
     const CompiledScene::Instanced& is = cs.instanced;
-    return n + b(is.nodes) + b(is.tlas_leaves) + b(is.mesh_tris) + b(is.mesh_pos) + b(is.mesh_meta) + b(is.mesh_normals) + b(is.inst_mats);
+    return n + b(is.nodes) + b(is.tlas_leaves) + b(is.mesh_tris) + b(is.mesh_pos) + b(is.mesh_meta) + b(is.mesh_normals) + b(is.inst_mats) + (is.on ? std::max<uint64_t>(((uint64_t)cs.n_tris + 31u) / 32u, 1u) * 4u : 0u);
 }
 
 extern "C" {

@@ -286,6 +286,7 @@ void compile_instanced_geometry(const FlatScene& flat, const std::vector<InstXf>
         mesh_base[m] = n_mesh_tris;
         const uint64_t total = (uint64_t)n_mesh_tris + flat.meshes[vsrc[m]].n_triangles();
         if (total > 0xffffffffull) throw std::runtime_error("unsupported: more than 2^32 mesh triangles");
+        if (flat.meshes[vsrc[m]].n_triangles() > kMeshPrimMask) throw std::runtime_error("unsupported: a mesh of more than 2^31 triangles");
         n_mesh_tris = (uint32_t)total;
         if (!flat.meshes[vsrc[m]].normals.empty() || !flat.meshes[vsrc[m]].tangents.empty()) any_normals = true;
     }

@@ -223,6 +223,7 @@ inline PtParams with_tex_slots(const PtParams& p, size_t base_bytes, size_t& lds
 #if !defined(__HIPCC_RTC__)
 // LDS layout of a k_pt_pass launch (pt_kernels.hip): the parameter block with the offsets filled in, the dynamic LDS size, the grid
 PtParams pt_pass_layout(const PtParams& p, size_t& lds_bytes, uint32_t& blocks);
+hipError_t launch_inst_share_bits(const DScene& sc, uint32_t* bits, uint32_t* mesh_tri_words, hipStream_t stream);  // pt_inst_kernels.hip: once per kept scene (DInst::share_bits)
 hipError_t launch_pt_pass_inst(const PtParams& p, hipStream_t stream);  // pt_inst_kernels.hip: scenes kept as meshes + instances
 // spec_fn: the per-scene kernel of the session (host/specialise.cpp) instead of the precompiled instantiation, or nullptr
 hipError_t launch_pt_pass(const PtParams& p, hipStream_t stream, hipFunction_t spec_fn = nullptr);

@@ -17,6 +17,31 @@ __global__ __launch_bounds__(256, TEX ? AKR_PT_MIN_WAVES_INST_TEX : AKR_PT_MIN_W
     pt_pass_body<true, FD, TEX, PMJ, false, false, 0u, true>(p);
 }
 
+// One thread per instance-triangle, once per scene: the bit of an odd triangle that takes its even neighbour's plane row (dinst.h
+// share_plane_row) -- what the flattening compiler decides per instance-triangle and resolve_pending used to decide at every candidate.
+__global__ __launch_bounds__(256) void k_inst_share_bits(const DScene sc, uint32_t* __restrict__ bits, uint32_t* __restrict__ mesh_tri_words) {
+    const uint32_t n_inst = sc.in2.n_instances;
+    for (uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x; gid < sc.n_tris; gid += (uint64_t)gridDim.x * 256u) {
+        uint32_t lo = 0, hi = n_inst;  // the instance of gid: the last one whose first id is <= gid (inst_tri_offset has n_inst + 1 entries)
+        while (hi - lo > 1u) {
+            const uint32_t mid = lo + (hi - lo) / 2u;
+            if (sc.inst_tri_offset[mid] <= gid) lo = mid; else hi = mid;
+        }
+        const uint32_t prim = (uint32_t)gid - sc.inst_tri_offset[lo];
+        uint32_t pos;
+        if ((prim & 1u) && inst_pair_shares(sc, lo, prim, pos)) {
+            atomicOr(&bits[gid >> 5], 1u << ((uint32_t)gid & 31u));
+            atomicOr(&mesh_tri_words[16ull * pos + 15u], kMeshTriShares);  // (nothing here reads that word)
+        }
+    }
+}
+hipError_t launch_inst_share_bits(const DScene& sc, uint32_t* bits, uint32_t* mesh_tri_words, hipStream_t stream) {
+    if (sc.n_tris == 0 || sc.in2.n_instances == 0) return hipSuccess;
+    const uint64_t blocks = ((uint64_t)sc.n_tris + 255u) / 256u;
+    hipLaunchKernelGGL(k_inst_share_bits, dim3((uint32_t)(blocks < (1u << 20) ? blocks : (1u << 20))), dim3(256), 0, stream, sc, bits, mesh_tri_words);
+    return hipGetLastError();
+}
+
 hipError_t launch_pt_pass_inst(const PtParams& p, hipStream_t stream) {
     size_t lds;
     uint32_t blocks;

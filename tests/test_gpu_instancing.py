@@ -207,6 +207,65 @@ def test_wavefront_schedule_on_a_kept_scene(ctx, root, case):
         assert st[k] == ost[k], k
 
 
+def _quad_panels(seed=2):
+    """A mesh of 40 quads (triangles 2j, 2j+1 = the halves of quad j) standing around a ring: half of them planar up to the f32 rounding of
+    their corners, the others with the fourth corner lifted out of the plane by 0.1 ... 10 times the sharing rule's tolerance (dinst.h
+    share_plane_row: 1e-6 of the triangle's size) -- whether such a pair shares its plane row depends on what the instance's transform does
+    to height and area."""
+    rng = np.random.default_rng(seed)
+    verts, idx = [], []
+    for j in range(40):
+        a = 2 * np.pi * j / 40
+        c = np.array([1.2 * np.cos(a), 0.0, 1.2 * np.sin(a)])
+        u = np.array([-np.sin(a), 0.3 * rng.normal(), np.cos(a)]) * 0.11
+        v = np.array([0.2 * rng.normal(), 1.0, 0.2 * rng.normal()]) * (0.3 + 0.5 * rng.random())
+        n = np.cross(u, v)
+        n /= np.linalg.norm(n)
+        lift = 0.0 if j % 2 == 0 else 1e-6 * np.sqrt(np.linalg.norm(np.cross(u, v)) * 4) * 10 ** rng.uniform(-1, 1)
+        q = [c - u - v, c + u - v, c + u + v, c - u + v + lift * n]
+        b = len(verts)
+        verts += q
+        idx += [[b, b + 1, b + 2], [b, b + 2, b + 3]]
+    idx = np.array(idx, dtype=np.uint32)
+    return abi.MeshData(vertices=np.array(verts, dtype=np.float32), indices=idx, material_slots=(np.arange(len(idx)) // 2 % 3 == 0).astype(np.uint32))
+
+
+@pytest.mark.parametrize("schedule", ["megakernel", "wavefront"])
+def test_quads_of_a_kept_scene_share_their_plane_rows(ctx, root, schedule):
+    """The coplanar-neighbour rule on a kept scene: decided once per instance-triangle on the device (k_inst_share_bits), applied at the candidate
+    (dinst_trav.h resolve_pending). Quads whose halves share in every instance, in none, and in some of the twelve instances only: the film is
+    the flattened scene's and the oracle's bit for bit."""
+    sd = instanced_scene(width=64, height=48, n_inst=12, n=4, emissive_instances=1, with_normals=False, with_uvs=False)
+    sd.meshes[0] = _quad_panels()
+    sd.ggx_table = _table(root)
+    for k, inst in enumerate(sd.instances[2:]):  # stretch the copies differently along their axes: height over size is not invariant
+        M = inst.transform.reshape(4, 4).T.copy()
+        M[:3, :3] = M[:3, :3] @ np.diag([1.0 + 0.4 * k, 1.0, 1.0 / (1.0 + 0.3 * k)]).astype(np.float32)
+        inst.transform = M.T.reshape(16).astype(np.float32).copy()
+    # how the flattening compiler decided, from its records: an odd record that repeats its predecessor's plane row
+    with capi.options(instancing=0):
+        flat = capi.Scene(None, sd)
+    gid = flat.array(capi.ARRAY_TRI_GID, np.uint32)      # traversal order -> global id; a record = 12 floats of rows + 4 words
+    off = flat.array(capi.ARRAY_INST_TRI_OFFSET, np.uint32)
+    rows = np.empty((len(gid), 12), dtype=np.float32)
+    rows[gid] = flat.array(capi.ARRAY_WOOP, np.float32)[:16 * len(gid)].reshape(-1, 16)[:, :12]
+    shares = np.zeros((12, 40), dtype=bool)
+    for i in range(12):
+        r = rows[off[2 + i]:off[3 + i]]
+        shares[i] = np.all(r[1::2, 8:].view(np.uint32) == r[0::2, 8:].view(np.uint32), axis=1)
+    per_quad = shares.sum(axis=0)
+    assert (per_quad == 0).any() and (per_quad == 12).sum() >= 8 and ((per_quad > 0) & (per_quad < 12)).sum() >= 8, per_quad
+    cfg = make_config(spp=8, spp_per_pass=4, max_depth=6)
+    with capi.options(wavefront=1 if schedule == "wavefront" else 0):
+        kept, kst, _ = _render(ctx, sd, cfg, 1)
+        flattened, fst, _ = _render(ctx, sd, cfg, 0)
+    assert n_bit_diff(kept, flattened) == 0
+    o, ost = _oracle(sd, cfg)
+    assert n_bit_diff(kept, o) == 0
+    for k in ("n_samples", "n_closest", "n_shadow", "n_shaded"):
+        assert kst[k] == ost[k], k
+
+
 def test_rebraided_top_level_tree_and_slot_groups_change_no_bit(ctx, root):
     """Option rebraid (the top-level tree over (instance, subtree) pairs, the largest boxes opened first) and option wf_groups (the wavefront
     schedule's slots as groups on streams of their own) change which boxes cull and which launch traces a ray -- never a film float."""

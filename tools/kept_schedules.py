@@ -2,7 +2,7 @@
 launch timed; films compared bit for bit.  python tools/kept_schedules.py [tris_per_mesh ...]   (needs a GPU)
 KS_REBRAID=1,4,16: the same for each value of option rebraid (top-level tree over that many (instance, subtree) pairs per instance);
 KS_GROUPS=1,4,8: ... of option wf_groups; KS_SIZE=WxH; KS_INSTANCING=0: the forest flattened."""
-import os, sys, time, json
+import zlib, os, sys, time, json
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -39,4 +39,5 @@ for tris in [int(a) for a in sys.argv[1:]] or [10_000, 100_000]:
                           "rays_per_s_G": rays / dt / 1e9, "nodes_per_ray": (s1["n_node_visits"] - s0["n_node_visits"]) / rays, "candidates_per_ray": (s1["n_tri_tests"] - s0["n_tri_tests"]) / rays}), flush=True)
         del se, f, sc
     ref = next(iter(films.values())).view(np.uint32)
-    print(json.dumps({"tris_per_mesh": tris, "films_identical": bool(all(np.array_equal(ref, f.view(np.uint32)) for f in films.values()))}), flush=True)
+    print(json.dumps({"tris_per_mesh": tris, "films_identical": bool(all(np.array_equal(ref, f.view(np.uint32)) for f in films.values())),
+                      "film_crc32": "%08x" % zlib.crc32(ref.tobytes())}), flush=True)
