@@ -161,7 +161,7 @@ std::vector<uint32_t> akr_api::owned_tiles(uint32_t tiles_x, uint32_t tiles_y, u
 // 0 = never, -1 (default) = the library decides:
 //   * flattened scenes: the megakernel, which measured faster on every one (on the 10 M-triangle hall both schedules
 //     are bound by the memory system's rate for random 64-byte records, and the wavefront schedule pays for streaming the path state on top);
-//   * scenes kept as meshes + instances: the WAVEFRONT schedule for pt sessions of at least kWfAutoItems pixels (round 6). The two-level
+//   * scenes kept as meshes + instances: the WAVEFRONT schedule for pt sessions of at least wf_auto_items() pixels (round 6). The two-level
 //     traversal with its exact test spills 172 registers inside the megakernel (one lane = one whole path) and none in k_wf_trace, and the
 //     trace kernel refills a wave's idle lanes where the megakernel's wait: 1080p forest 1000 x 10 k triangles 163 -> 228 Msamples/s, 4K
 //     177 -> 282 (x 100 k: 113 -> 136 with two slot groups, 4K 125 -> 179). Below that size the persistent trace kernel's 262 k lanes
@@ -170,7 +170,14 @@ std::vector<uint32_t> akr_api::owned_tiles(uint32_t tiles_x, uint32_t tiles_y, u
 //     the same forest with image-textured leaves and bark renders at 193 against 157 Msamples/s (x 100 k: 123 against 100).
 // The option is process-wide and aov / gpt / mcmc_opt sessions come through here too: they render with their own kernels; a scene without a
 // tree (64 triangles or fewer, no force_bvh) has no wavefront kernels and renders with the megakernel whatever the option says.
-constexpr uint32_t kWfAutoItems = 2000000;
+// How large: the persistent trace kernel wants its 262 k lanes refilled many times over, and the larger the meshes the longer a launch's tail of
+// rays deep in some tree. Measured crossovers (tools/kept_schedules.py at eleven frame sizes, profiles/r6_kept_schedules.txt): 0.7 M pixels for
+// the forest of 10 k-triangle meshes (1.7 MB of per-mesh data; 1024 x 768: 163 -> 176), about 0.95 M for 30 k-triangle ones (5 MB), 1.45 M for
+// 100 k-triangle ones (17 MB); 2 M, the constant of the first version, beyond what was measured.
+static uint32_t wf_auto_items(const akr_scene* scene) {
+    const uint64_t mesh_bytes = ((uint64_t)scene->cs.instanced.nodes.size() + scene->cs.instanced.mesh_tris.size()) * 4u;
+    return (uint32_t)std::min<uint64_t>(2000000u, 700000u + mesh_bytes / 18u);
+}
 static uint32_t session_items(const akr_pt_config& c, uint32_t width, uint32_t height) {  // = fill_params' n_items
     const uint32_t tw = c.tile_w ? c.tile_w : 32, th = c.tile_h ? c.tile_h : 32;
     const uint32_t tiles_x = (width + tw - 1) / tw, tiles_y = (height + th - 1) / th;
@@ -186,7 +193,7 @@ static bool choose_wavefront(const akr_scene* scene, const akr_pt_config& cfg, b
     if (opt == 0 || !can) return false;
     if (opt > 0) return true;
     return for_pt_kernel && scene->cs.instanced.on &&
-           session_items(cfg, scene->flat.camera.width, scene->flat.camera.height) >= kWfAutoItems;
+           session_items(cfg, scene->flat.camera.width, scene->flat.camera.height) >= wf_auto_items(scene);
 }
 
 static void wf_allocate(akr_pt_session* se, uint32_t n_slots) {

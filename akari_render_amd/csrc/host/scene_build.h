@@ -170,7 +170,7 @@ void build_alias_table(const std::vector<float>& weights, std::vector<AliasEntry
 //   bvh_balanced AKR_BVH_BALANCED=1       the median-split fallback builder instead of SAH
 //   defer_metal  AKR_PT_DEFER_METAL=<m>   -1 = the library decides (default); 0 = off; m > 0 = iterations with (i & m) != 0 put conductor hits off
 //   wavefront    AKR_PT_MODE=wavefront|megakernel   the wavefront schedule (wf_kernels.hip) instead of the megakernel: 1 = wherever it can run, 0 = never,
-//                                         -1 = the library decides (default: pt sessions of >= 2 M pixels on scenes kept as meshes + instances)
+//                                         -1 = the library decides (default: pt sessions of >= 0.7 M ... 2 M pixels, by mesh size, on scenes kept as meshes + instances)
 //   simple_kernels AKR_PT_SIMPLE=0        0 = never use the SIMPLE instantiations (scenes without coat / transmission / normal map / glass)
 //   defer_on     (no environment hook)   BVH kernels of textured scenes: which hits the deferral puts off (0 / 1 conductor lobe, 2 texture-fed, 3 both)
 //   specialise   AKR_SPECIALISE=<v>       per-scene kernels for scenes with texture-fed materials (host/specialise.cpp): -1 = the library decides (a cached

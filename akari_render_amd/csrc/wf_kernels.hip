@@ -179,6 +179,9 @@ AKR_D void wf_trav_begin(T& s, vec3 o, vec3 d, float tmin, float tmax, uint32_t 
 #ifndef AKR_WF_REFILL_IDLE
 #define AKR_WF_REFILL_IDLE 20  // refill when at least this many of the 64 lanes are idle
 #endif
+#ifndef AKR_WF_REFILL_IDLE_INST
+#define AKR_WF_REFILL_IDLE_INST 8  // ... on a scene kept as meshes + instances (an iteration of its loop costs more: 1 / 4 / 8 / 20 / 32 idle lanes: 232 / 243 / 245 / 241 / 230 Msamples/s, 1080p forest)
+#endif
 // INST (round 6): the scene is kept as meshes + instances -- the two-level traversal of dinst_trav.h: a lane's candidates wait in its
 // pending slot and the wave takes the exact test in batches, as trace_inst does.
 #ifndef AKR_WF_TRACE_INST_WAVES
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(256, INST ? AKR_WF_TRACE_INST_WAVES : 1) void k_wf_
             }
             const uint32_t n_idle = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(!has));
             if (n_idle == 64u) break;
-            if (!exhausted && n_idle >= AKR_WF_REFILL_IDLE) break;
+            if (!exhausted && n_idle >= (INST ? AKR_WF_REFILL_IDLE_INST : AKR_WF_REFILL_IDLE)) break;
         }
     }
     // traversal counters

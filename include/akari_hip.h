@@ -621,7 +621,7 @@ AKR_API uint32_t akr_struct_size(int32_t which);
  *   "bvh_balanced" (AKR_BVH_BALANCED=1)     median-split fallback builder instead of binned SAH
  *   "defer_metal"  (AKR_PT_DEFER_METAL=m)   -1 the library decides; 0 off; m > 0: conductor hits shaded when (iteration & m) == 0
  *   "wavefront"    (AKR_PT_MODE=wavefront|megakernel|auto)  pt sessions on scenes with a tree: 1 = the wavefront schedule, 0 = the megakernel,
- *                                           -1 (default) = the library decides (wavefront for sessions of >= 2 M pixels on scenes kept
+ *                                           -1 (default) = the library decides (wavefront for sessions of >= 0.7 M ... 2 M pixels, by mesh size, on scenes kept
  *                                           as meshes + instances, else the megakernel). Films are the same bit for bit either way.
  *   "wf_groups"    (AKR_WF_GROUPS=g)        wavefront schedule: the path slots run as g groups with queues and streams of their own; 0 = the
  *                                           library decides

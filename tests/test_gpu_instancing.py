@@ -291,8 +291,9 @@ def test_rebraided_top_level_tree_and_slot_groups_change_no_bit(ctx, root):
 
 
 def test_the_library_picks_the_wavefront_schedule_for_large_kept_frames(ctx, root):
-    """Option wavefront = -1 (default): pt sessions of >= 2 M pixels on a kept scene run the wavefront schedule (api_pt.cpp
-    choose_wavefront: 1080p forest 163 -> 228 Msamples/s), smaller ones and aov sessions the megakernel; same film either way."""
+    """Option wavefront = -1 (default): pt sessions of large frames on a kept scene run the wavefront schedule (api_pt.cpp choose_wavefront:
+    1080p forest 163 -> 239 Msamples/s; "large" = from 0.7 M pixels for meshes that fit the L2s to 2 M, wf_auto_items), smaller ones and aov
+    sessions the megakernel; same film either way."""
     assert capi.get_option("wavefront") == -1
     sd = procedural.instanced_forest(12, 2000, width=1920, height=1080)
     sd.ggx_table = _table(root)
@@ -308,12 +309,13 @@ def test_the_library_picks_the_wavefront_schedule_for_large_kept_frames(ctx, roo
                 se.passes(1, blocking=True)
                 se.end()
                 films[mode] = film.read()
-        sd_small = procedural.instanced_forest(12, 2000, width=256, height=256)
-        sd_small.ggx_table = sd.ggx_table
-        small = capi.Scene(ctx, sd_small)
-        se = capi.PtSession(ctx, small, cfg, capi.Film(ctx, 256, 256))
-        assert "wavefront" not in se.kernel_info()["status"]
-        se.end()
+        for (w, h), wavefront in {(256, 256): False, (800, 600): False, (1024, 768): True}.items():  # (small meshes: from 0.7 M pixels)
+            sd_small = procedural.instanced_forest(12, 2000, width=w, height=h)
+            sd_small.ggx_table = sd.ggx_table
+            small = capi.Scene(ctx, sd_small)
+            se = capi.PtSession(ctx, small, cfg, capi.Film(ctx, w, h))
+            assert ("wavefront" in se.kernel_info()["status"]) == wavefront, (w, h)
+            se.end()
         # texture-fed materials do not change the choice (k_wf_shade interprets the graphs: forest with image-textured leaves 157 -> 193)
         tex = capi.Scene(ctx, _kept_scene_data(root, True, 2048, 1024))
         assert tex.info().uses_bvh == 2

@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT
 for v in "${@:-product}"; do
   echo "== variant $v"
   if [ "$v" != product ]; then export AKR_HIP_LIB=$PWD/akari_render_amd/variants/libakari_hip_$v.so; else unset AKR_HIP_LIB; fi
-  KS_GROUPS=${KS_GROUPS:-2} python tools/kept_schedules.py 10000 100000 2>&1 | python -c "
+  KS_GROUPS=${KS_GROUPS:-2} python tools/kept_schedules.py ${KS_TRIS:-10000 100000} 2>&1 | python -c "
 import sys, json
 for l in sys.stdin:
     try: d = json.loads(l)
