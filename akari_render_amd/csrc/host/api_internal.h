@@ -181,7 +181,7 @@ struct akr_pt_session {
     uint32_t n_owned_tiles = 0;
     // wavefront schedule (wf_kernels.hip): path state SoA + ray queues
     bool wavefront = false;
-    DevBuf wf_state, wf_queues, wf_ctrl;
+    DevBuf wf_state, wf_queues, wf_ctrl, wf_pend, wf_carry;
     // option wf_sort: keys of the queue entries, the sorted copies the trace kernel reads, rocPRIM's scratch
     bool wf_sort = false;
     DevBuf wf_keys, wf_sorted, wf_sort_tmp;

@@ -170,13 +170,15 @@ std::vector<uint32_t> akr_api::owned_tiles(uint32_t tiles_x, uint32_t tiles_y, u
 //     the same forest with image-textured leaves and bark renders at 193 against 157 Msamples/s (x 100 k: 123 against 100).
 // The option is process-wide and aov / gpt / mcmc_opt sessions come through here too: they render with their own kernels; a scene without a
 // tree (64 triangles or fewer, no force_bvh) has no wavefront kernels and renders with the megakernel whatever the option says.
-// How large: the persistent trace kernel wants its 262 k lanes refilled many times over, and the larger the meshes the longer a launch's tail of
-// rays deep in some tree. Measured crossovers (tools/kept_schedules.py at eleven frame sizes, profiles/r6_kept_schedules.txt): 0.7 M pixels for
-// the forest of 10 k-triangle meshes (1.7 MB of per-mesh data; 1024 x 768: 163 -> 176), about 0.95 M for 30 k-triangle ones (5 MB), 1.45 M for
-// 100 k-triangle ones (17 MB); 2 M, the constant of the first version, beyond what was measured.
+// How large: the persistent trace kernel wants its 262 k lanes refilled many times over, and the larger the meshes the longer a launch's last
+// rays take. Measured crossovers (tools/kept_schedules.py at seven frame sizes, profiles/r6_kept_schedules.txt), with a launch's last rays carried
+// into the next one (option wf_carry, the default): 0.5 M pixels for the forest of 10 k-triangle meshes (1.7 MB of per-mesh data; 800 x 600: 145 vs
+// 147, 1024 x 768: 167 -> 189), 0.8 M for 100 k-triangle ones (17 MB; 1024 x 768: 118 vs 122, 1024 x 1024: 138 -> 150). Without carried rays: 0.7 M
+// and 1.45 M. 2 M, the constant of the first version, beyond what was measured.
 static uint32_t wf_auto_items(const akr_scene* scene) {
     const uint64_t mesh_bytes = ((uint64_t)scene->cs.instanced.nodes.size() + scene->cs.instanced.mesh_tris.size()) * 4u;
-    return (uint32_t)std::min<uint64_t>(2000000u, 700000u + mesh_bytes / 18u);
+    const bool carry = tuning().wf_carry != 0 && tuning().wf_sort == 0;
+    return (uint32_t)std::min<uint64_t>(2000000u, carry ? 500000u + mesh_bytes / 55u : 700000u + mesh_bytes / 18u);
 }
 static uint32_t session_items(const akr_pt_config& c, uint32_t width, uint32_t height) {  // = fill_params' n_items
     const uint32_t tw = c.tile_w ? c.tile_w : 32, th = c.tile_h ? c.tile_h : 32;
@@ -210,6 +212,20 @@ static void wf_allocate(akr_pt_session* se, uint32_t n_slots) {
     uint32_t* q = (uint32_t*)se->wf_queues.p;
     w.queue_closest[0] = q; w.queue_closest[1] = q + n; w.queue_shadow[0] = q + 2 * n; w.queue_shadow[1] = q + 3 * n;
     w.key_closest[0] = w.key_closest[1] = w.key_shadow[0] = w.key_shadow[1] = nullptr;
+    // carried rays (wf_kernels.hip): a record per (kind, slot) = 12 words + this scene's traversal stack. Not with option wf_sort (a carried ray has no key).
+    w.pend = nullptr; w.carry = nullptr; w.carry_words = 0; w.n_slots = n_slots;
+    // (option values above 1 = test hook: that launch size, and waves hand over early and nearly whole -- small frames carry thousands of rays)
+    const bool carry_test = tuning().wf_carry > 1;
+    w.carry_queue = carry_test ? (uint32_t)tuning().wf_carry : 65536u;
+    w.carry_lanes = carry_test ? 56u : 16u;
+    w.carry_steps = carry_test ? 4u : 48u;
+    if (tuning().wf_carry != 0 && !se->wf_sort && n_slots > 0) {
+        w.carry_words = (12u + se->params.sc.bvh_stack_depth + 3u) & ~3u;  // (16-byte aligned records)
+        se->wf_pend.alloc(n * sizeof(uint32_t));
+        se->wf_carry.alloc(2 * n * (size_t)w.carry_words * sizeof(uint32_t));
+        w.pend = (uint32_t*)se->wf_pend.p;
+        w.carry = (uint32_t*)se->wf_carry.p;
+    }
     if (se->wf_sort) {
         se->wf_keys.alloc(4 * n * sizeof(uint32_t));
         uint32_t* k = (uint32_t*)se->wf_keys.p;
@@ -232,7 +248,9 @@ static void wf_allocate(akr_pt_session* se, uint32_t n_slots) {
     const akr_scene* sc = se->scene;
     const size_t mesh_bytes = sc->cs.instanced.on ? (sc->cs.instanced.nodes.size() + sc->cs.instanced.mesh_tris.size()) * 4 : 0;
     const int opt_groups = tuning().wf_groups;
-    uint32_t groups = se->wf_sort ? 1u : (opt_groups > 0 ? (uint32_t)opt_groups : (mesh_bytes > (16u << 20) ? 2u : 1u));
+    // With carried rays (option wf_carry, the default since the end of round 6) a launch has no such tail and one group wins at every size measured
+    // (1080p, x 100 k: 175 against 158 with two; 4K: 220 against 203): the automatic choice is two groups only without them.
+    uint32_t groups = se->wf_sort ? 1u : (opt_groups > 0 ? (uint32_t)opt_groups : (mesh_bytes > (16u << 20) && w.carry == nullptr ? 2u : 1u));
     groups = std::min(groups, std::max(1u, n_slots / 65536u));  // (small frames: a group should still be a few waves per CU)
     se->wf_ctrl.alloc((size_t)groups * 8 * sizeof(uint32_t));  // per group: qcount[4], qhead, n_active
     se->wf_group.clear();
@@ -611,6 +629,15 @@ AKR_API int32_t akr_pt_kernel_info(akr_pt_session* se, akr_kernel_info* info) {
             info->load_ms = se->spec->load_ms;
         }
         std::snprintf(info->status, sizeof info->status, "%s", se->spec_status.c_str());
+        if (se->wavefront && se->wf.carry != nullptr && se->counters.p) {  // what the launches so far carried over (wf_kernels.hip; counter 7)
+            se->ctx->bind();
+            HIP_CHECK(hipStreamSynchronize(se->ctx->stream));
+            std::vector<uint64_t> stripes(8 * kStatStripes);
+            HIP_CHECK(hipMemcpy(stripes.data(), se->counters.p, stripes.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            uint64_t carried = 0;
+            for (uint32_t k = 0; k < kStatStripes; k++) carried += stripes[8 * k + 7];
+            std::snprintf(info->status, sizeof info->status, "%s; %llu rays carried into a later trace launch", se->spec_status.c_str(), (unsigned long long)carried);
+        }
     });
 }AKR_API int32_t akr_pt_end(akr_pt_session* se, akr_pt_stats* stats) {
     if (!se) return AKR_OK;

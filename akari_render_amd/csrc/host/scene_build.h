@@ -170,7 +170,7 @@ void build_alias_table(const std::vector<float>& weights, std::vector<AliasEntry
 //   bvh_balanced AKR_BVH_BALANCED=1       the median-split fallback builder instead of SAH
 //   defer_metal  AKR_PT_DEFER_METAL=<m>   -1 = the library decides (default); 0 = off; m > 0 = iterations with (i & m) != 0 put conductor hits off
 //   wavefront    AKR_PT_MODE=wavefront|megakernel   the wavefront schedule (wf_kernels.hip) instead of the megakernel: 1 = wherever it can run, 0 = never,
-//                                         -1 = the library decides (default: pt sessions of >= 0.7 M ... 2 M pixels, by mesh size, on scenes kept as meshes + instances)
+//                                         -1 = the library decides (default: pt sessions of >= 0.5 M ... 2 M pixels, by mesh size, on scenes kept as meshes + instances)
 //   simple_kernels AKR_PT_SIMPLE=0        0 = never use the SIMPLE instantiations (scenes without coat / transmission / normal map / glass)
 //   defer_on     (no environment hook)   BVH kernels of textured scenes: which hits the deferral puts off (0 / 1 conductor lobe, 2 texture-fed, 3 both)
 //   specialise   AKR_SPECIALISE=<v>       per-scene kernels for scenes with texture-fed materials (host/specialise.cpp): -1 = the library decides (a cached
@@ -184,6 +184,9 @@ void build_alias_table(const std::vector<float>& weights, std::vector<AliasEntry
 //   pad_percent  (no environment hook)    test hook: box padding in percent of the derived value (100)
 //   wf_sort      AKR_WF_SORT=1            wavefront schedule: ray queues sorted by origin cell + direction octant before each trace launch
 //   wf_groups    AKR_WF_GROUPS=<g>        wavefront schedule: the slots run as g groups with queues and streams of their own (api_pt.cpp wf_run); 0 = the library decides
+//   wf_carry     AKR_WF_CARRY=0           wavefront schedule: 0 = every trace launch traces its rays to the end (1, default: a wave that finds the queue empty and
+//                                         has few lanes left hands their traversals to the next launch -- wf_kernels.hip; launches of >= 65 536 rays only;
+//                                         a value n > 1 = test hook: launches of >= n rays, and waves hand over after 4 steps with up to 56 lanes left)
 //   max_fused_passes (no environment hook)     most passes akr_pt_passes fuses into one launch: 0 = adaptive (16, up to 64 once a pass has been timed), else 1..64
 struct TuningOptions {
     int force_bvh = 0, bvh_balanced = 0, defer_metal = -1, wavefront = -1, simple_kernels = 1;
@@ -198,6 +201,7 @@ struct TuningOptions {
     int pad_percent = 100;  // test hook: the padding of the acceleration structures' boxes (flat part and needle part) in percent of what the compiler derives --
                             // tests/test_bvh_conservative.py shows with it how far the derived padding is from the first lost hit
     int wf_groups = 0;  // wavefront schedule: slot groups whose init / trace / shade chains run side by side on streams of their own (1 = one chain, 0 = the library decides)
+    int wf_carry = 1;  // wavefront schedule: 1 = the last rays of a trace launch are carried into the next one (wf_kernels.hip), 0 = every launch traces to the end
     int wf_sort = 0;  // wavefront schedule: 1 = the ray queues are sorted by (Morton code of the origin, octant) before every trace launch (wf_sort.hip)
 };
 constexpr uint64_t kSpecAutoSamples = 1ull << 31;  // option specialise = -1: a first-use compile (about a second; 20-30 % of the render to win) has to be worth it

@@ -162,6 +162,13 @@ struct WfBuffers {
     uint32_t* qcount;               // [4]: closest/shadow counts of queue 0, of queue 1
     uint32_t* qhead;                // next unclaimed ray id of the queue being traced
     uint32_t* n_active;             // slots still active after the last shade
+    // Rays a trace launch did not finish (wf_kernels.hip: "carried rays"): a wave that finds the queue empty and has few lanes left saves those
+    // lanes' traversals and ends; the ray goes on in the next trace launch, its slot is not shaded meanwhile. nullptr = every launch traces to the end.
+    uint32_t* pend;                 // per slot: bit 0 = its closest-hit ray is carried, bit 1 = its shadow ray
+    uint32_t* carry;                // per (kind, slot) carry_words words: best t, u, v, id | G, T, tbase, sp | leaf, pend_rec, pend_inst, - | the stack
+    uint32_t carry_words, n_slots;  // (record of kind k, slot s at carry + (k * n_slots + s) * carry_words)
+    uint32_t carry_queue;           // launches of fewer rays than this trace to the end
+    uint32_t carry_lanes, carry_steps;  // a wave hands over when at most carry_lanes lanes are left and each has had carry_steps steps (16, 48; tests: 56, 4)
     // The slots [slot_base, slot_end) this set of queues and counters serves: a session's slots are divided into GROUPS, each with its own
     // queues, counters and stream, so that one group's kernels fill the chip while another's trace launch waits for its last rays
     // (host/api_pt.cpp wf_run). The state arrays above are the session's, indexed by slot.

@@ -80,10 +80,14 @@ AKR_D uint32_t wf_ray_key(const PtParams& p, vec3 o, vec3 d) {
     const uint32_t oct = (d.x >= 0.0f ? 1u : 0u) | (d.y >= 0.0f ? 2u : 0u) | (d.z >= 0.0f ? 4u : 0u);
     return ((wf_spread7(cx) | (wf_spread7(cy) << 1) | (wf_spread7(cz) << 2)) << 3) | oct;
 }
-AKR_D void wf_enqueue(const PtParams& p, const WfBuffers& wf, uint32_t q, uint32_t slot, PathRegs& r) {
+// `resume` != 0: the slot's rays of the last trace launch are not all finished (WfBuffers::pend: bit 0 closest-hit ray, bit 1 shadow ray); the
+// unfinished ones go back into the queues marked kWfResume -- the trace kernel continues them from their carry records -- and are not counted again.
+constexpr uint32_t kWfResume = 0x80000000u;
+AKR_D void wf_enqueue(const PtParams& p, const WfBuffers& wf, uint32_t q, uint32_t slot, PathRegs& r, uint32_t resume = 0u) {
     // closest-hit rays and shadow rays go to separate queues so that waves of the trace kernel are homogeneous
     __shared__ uint32_t sh_cnt[4][3], sh_base[3];
-    const bool want_c = r.active && r.has_ray, want_s = r.active && r.has_shadow;
+    const bool want_c = r.active && (resume ? (resume & 1u) != 0u : r.has_ray), want_s = r.active && (resume ? (resume & 2u) != 0u : r.has_shadow);
+    const uint32_t entry = slot | (resume ? kWfResume : 0u);
     const uint64_t mc = __builtin_amdgcn_ballot_w64(want_c), ms = __builtin_amdgcn_ballot_w64(want_s), ma = __builtin_amdgcn_ballot_w64(r.active);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (lane == 0) {
@@ -103,15 +107,15 @@ AKR_D void wf_enqueue(const PtParams& p, const WfBuffers& wf, uint32_t q, uint32
     const uint64_t below = (1ull << lane) - 1ull;
     if (want_c) {
         const uint32_t at = bc + (uint32_t)__builtin_popcountll(mc & below);
-        wf.queue_closest[q][at] = slot;
+        wf.queue_closest[q][at] = entry;
         if (p.wf_sort) wf.key_closest[q][at] = wf_ray_key(p, r.ro, r.rd);
-        r.c_closest++;
+        if (!resume) r.c_closest++;
     }
     if (want_s) {
         const uint32_t at = bs + (uint32_t)__builtin_popcountll(ms & below);
-        wf.queue_shadow[q][at] = slot;
+        wf.queue_shadow[q][at] = entry;
         if (p.wf_sort) wf.key_shadow[q][at] = wf_ray_key(p, r.s_o, r.s_d);
-        r.c_shadow++;
+        if (!resume) r.c_shadow++;
     }
 }
 
@@ -125,7 +129,10 @@ __global__ __launch_bounds__(256) void k_wf_init(const PtParams p, const WfBuffe
     shifted_pixel(p, px, py, sx, sy);
     PathRegs r;
     path_regs_init<PMJ>(r, p, in_frame, pix, sx, sy);
-    if (slot < wf.slot_end) wf_store(wf, slot, r);
+    if (slot < wf.slot_end) {
+        wf_store(wf, slot, r);
+        if (wf.pend) wf.pend[slot] = 0u;
+    }
     wf_enqueue(p, wf, 0, slot, r);
     flush_counters(p, r, TraceCounters{0, 0, 0}, true);
 }
@@ -141,7 +148,11 @@ __global__ __launch_bounds__(256, TEX ? 1 : AKR_WF_SHADE_WAVES) void k_wf_shade(
     r.c_samples = r.c_closest = r.c_shadow = r.c_shaded = 0;
     bool live = false;
     if (slot < wf.slot_end) live = (f2u(wf.base[slot].w) & WF_ACTIVE) != 0;
-    if (live) {
+    // a slot one of whose rays the trace launch carried over is not shaded this time: its state stays as it is and the unfinished rays are queued again
+    uint32_t resume = 0u;
+    if (live && wf.pend) resume = wf.pend[slot];
+    if (resume) r.active = true;
+    if (live && !resume) {
         uint32_t px = 0, py = 0;
         item_to_pixel(p, slot, px, py);
         const uint32_t pix = px + py * p.width;
@@ -162,7 +173,7 @@ __global__ __launch_bounds__(256, TEX ? 1 : AKR_WF_SHADE_WAVES) void k_wf_shade(
         wf.qcount[2u * (1u - q_out) + 1u] = 0u;
         *wf.qhead = 0u;
     }
-    wf_enqueue(p, wf, q_out, slot, r);
+    wf_enqueue(p, wf, q_out, slot, r, resume);
     flush_counters(p, r, TraceCounters{0, 0, 0}, true);
 }
 
@@ -173,6 +184,41 @@ AKR_D void wf_trav_begin(T& s, vec3 o, vec3 d, float tmin, float tmax, uint32_t 
     if constexpr (INST) trav_begin_inst(s, o, d, tmin, tmax, ex0, ex1);
     else trav_begin(s, o, d, tmin, tmax, ex0, ex1);
 }
+// Carried rays. A trace launch used to end with its slowest rays -- a hundred dependent fetches deep, in waves with a handful of lanes left -- while
+// the rest of the chip idled: 19 of 73 ms per 8 spp on the kept 1080p forest, 69 of 144 ms with 100 k-triangle meshes (HISTORY R6.6). Now a wave that
+// has found the queue empty, is down to WfBuffers::carry_lanes (16) lanes and has given each of them carry_steps (48) steps since it started or resumed (progress
+// is guaranteed) writes those lanes' traversals -- best hit, position in the tree, the stack -- into the rays' carry records, marks the slots
+// (WfBuffers::pend) and ends. k_wf_shade leaves a marked slot alone and queues its unfinished rays again (kWfResume); the next trace launch
+// picks them up with everything else. Launches with fewer than WfBuffers::carry_queue rays (65 536) trace to the end as before (the last iterations of a launch
+// group must drain, and a launch of its own per fifty steps would cost more than the tail). Nothing a path computes changes -- the iteration in
+// which a vertex is shaded does, as with the megakernel's stragglers (pt_pass.h). Measured with 8 / 16 / 32 / 48 lanes and 16 / 48 / 128 steps: all
+// within 2 % of each other (1080p forest x 100 k: 172 -- 177 Msamples/s against 124 without).
+template <bool INST, class T>
+AKR_D void wf_carry_save(const WfBuffers& wf, const T& s, const uint32_t* __restrict__ stack, uint32_t slot, bool any) {
+    uint32_t* c = wf.carry + ((size_t)(any ? wf.n_slots : 0u) + slot) * wf.carry_words;  // (carry_words is a multiple of 4: 16-byte aligned records)
+    ((uint4*)c)[0] = make_uint4(f2u(s.best_t), f2u(s.best_u), f2u(s.best_v), s.best);
+    ((uint4*)c)[1] = make_uint4(s.G, s.T, s.tbase, s.sp);
+    if constexpr (INST) ((uint4*)c)[2] = make_uint4(s.leaf, s.pend_rec, s.pend_inst, 0u);
+    for (uint32_t k = 0; k < s.sp; k++) c[12u + k] = stack[k * 256u];
+}
+template <bool INST, class T>
+AKR_D void wf_carry_restore(const DScene& sc, const WfBuffers& wf, T& s, uint32_t* __restrict__ stack, uint32_t slot, bool any) {  // (after wf_trav_begin on the slot's ray)
+    const uint32_t* c = wf.carry + ((size_t)(any ? wf.n_slots : 0u) + slot) * wf.carry_words;
+    const uint4 a = ((const uint4*)c)[0], b = ((const uint4*)c)[1];
+    s.best_t = u2f(a.x); s.best_u = u2f(a.y); s.best_v = u2f(a.z); s.best = a.w;
+    s.G = b.x; s.T = b.y; s.tbase = b.z; s.sp = b.w;
+    for (uint32_t k = 0; k < s.sp; k++) stack[k * 256u] = c[12u + k];
+    if constexpr (INST) {
+        const uint4 d = ((const uint4*)c)[2];
+        s.leaf = d.x; s.pend_rec = d.y; s.pend_inst = d.z;
+        if (s.leaf != kInvalid) {
+            const uint4* lf = sc.in2.tlas_leaves + (size_t)s.leaf * 4;
+            trav_into_instance(sc, s, lf[0], lf[1], lf[2], lf[3]);
+        }
+    }
+    s.active = (s.T != 0) | ((s.G >> 24) != 0) | (s.sp != 0);
+}
+
 // Persistent traversal kernel. Ray id = slot; ids [0, n_closest) come from the closest-hit queue, the rest from the
 // shadow queue. A lane that finishes its ray writes the result and becomes idle; when enough lanes of the wave are
 // idle (or all), the wave refills them from the queue head.
@@ -196,8 +242,9 @@ __global__ __launch_bounds__(256, INST ? AKR_WF_TRACE_INST_WAVES : 1) void k_wf_
     const uint32_t lane = threadIdx.x & 63u;
     if (blockIdx.x == 0 && threadIdx.x == 0) *wf.n_active = 0u;  // (the shade launch after this one counts the slots still active; the host reads it after that)
     TraceCounters cnt{0, 0, 0};
-    bool has = false, exhausted = false, any = false;
-    uint32_t slot = 0;
+    bool has = false, exhausted = false, any = false, resumed = false;
+    uint32_t slot = 0, steps = 0, n_carried = 0;
+    const bool carry = wf.carry != nullptr && n_total >= wf.carry_queue;
     // 128 ray ids per claim. (ADVICE round 3 suggested 64 -- one wave-fill -- so that near the end of a queue no wave sits on ids that
     // idle waves could have traced; measured in round 4: twice the atomics on the queue head cost more than the shorter tail gains,
     // cbox with a forced BVH 398 against 576 Msamples/s, 10 M-triangle hall 211 against 219.)
@@ -225,12 +272,16 @@ __global__ __launch_bounds__(256, INST ? AKR_WF_TRACE_INST_WAVES : 1) void k_wf_
             const uint32_t my = c_next + (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
             if (!has && my < c_end) {
                 any = my >= n_closest;
-                slot = any ? wf.queue_shadow[q_in][my - n_closest] : wf.queue_closest[q_in][my];
+                const uint32_t entry = any ? wf.queue_shadow[q_in][my - n_closest] : wf.queue_closest[q_in][my];
+                slot = entry & ~kWfResume;
+                resumed = (entry & kWfResume) != 0u;
                 float4 a = any ? wf.sh_o[slot] : wf.ray_o[slot];
                 float4 b = any ? wf.sh_d[slot] : wf.ray_d[slot];
                 wf_trav_begin<INST>(s, xyz(a), xyz(b), 0.0f, any ? b.w : 1e20f, f2u(a.w), any ? f2u(wf.sh_c[slot].w) : kInvalid);
+                if (resumed) wf_carry_restore<INST>(sc, wf, s, stack, slot, any);
                 has = true;
                 blocked = false;
+                steps = 0;
             }
             const uint32_t n = (uint32_t)__builtin_popcountll(idle);
             c_next = c_next + n < c_end ? c_next + n : c_end;
@@ -242,6 +293,7 @@ __global__ __launch_bounds__(256, INST ? AKR_WF_TRACE_INST_WAVES : 1) void k_wf_
                 bool pending = false, wait = false;
                 if (has) {
                     if (s.pend_rec == kInvalid) blocked = false;
+                    steps++;
                     if (s.active & !blocked) blocked = trav_step_inst<TEX>(sc, s, stack, cnt);
                     pending = s.pend_rec != kInvalid;
                     wait = pending & (blocked | !s.active);  // cannot go on without the verdict
@@ -256,7 +308,7 @@ __global__ __launch_bounds__(256, INST ? AKR_WF_TRACE_INST_WAVES : 1) void k_wf_
                 }
                 finished = has && !s.active && s.pend_rec == kInvalid;
             } else {
-                if (has && s.active) trav_step<2, TEX>(sc, s, stack, cnt, any);
+                if (has && s.active) { steps++; trav_step<2, TEX>(sc, s, stack, cnt, any); }
                 finished = has && !s.active;
             }
             if (finished) {  // ray finished: publish the result for k_wf_shade
@@ -266,10 +318,20 @@ __global__ __launch_bounds__(256, INST ? AKR_WF_TRACE_INST_WAVES : 1) void k_wf_
                 } else {
                     hp[0] = u2f(s.best); hp[1] = s.best_u; hp[2] = s.best_v;
                 }
+                if (resumed) atomicAnd(&wf.pend[slot], any ? ~2u : ~1u);
                 has = false;
             }
             const uint32_t n_idle = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(!has));
             if (n_idle == 64u) break;
+            if (carry && exhausted && n_idle >= 64u - wf.carry_lanes && __builtin_amdgcn_ballot_w64(has && steps < wf.carry_steps) == 0) {
+                if (has) {  // the wave's last rays go on in the next launch
+                    wf_carry_save<INST>(wf, s, stack, slot, any);
+                    atomicOr(&wf.pend[slot], any ? 2u : 1u);
+                    has = false;
+                    n_carried++;
+                }
+                break;
+            }
             if (!exhausted && n_idle >= (INST ? AKR_WF_REFILL_IDLE_INST : AKR_WF_REFILL_IDLE)) break;
         }
     }
@@ -281,6 +343,10 @@ __global__ __launch_bounds__(256, INST ? AKR_WF_TRACE_INST_WAVES : 1) void k_wf_
             if (nn) atomicAdd((unsigned long long*)&ctr[4], (unsigned long long)nn);
             if (nt) atomicAdd((unsigned long long*)&ctr[5], (unsigned long long)nt);
             if (ov) atomicAdd((unsigned long long*)&ctr[6], (unsigned long long)ov);
+        }
+        if (carry) {
+            const uint32_t nc = wave_sum_u32(n_carried);
+            if (lane == 0 && nc) atomicAdd((unsigned long long*)&ctr[7], (unsigned long long)nc);
         }
     }
 }

@@ -621,10 +621,13 @@ AKR_API uint32_t akr_struct_size(int32_t which);
  *   "bvh_balanced" (AKR_BVH_BALANCED=1)     median-split fallback builder instead of binned SAH
  *   "defer_metal"  (AKR_PT_DEFER_METAL=m)   -1 the library decides; 0 off; m > 0: conductor hits shaded when (iteration & m) == 0
  *   "wavefront"    (AKR_PT_MODE=wavefront|megakernel|auto)  pt sessions on scenes with a tree: 1 = the wavefront schedule, 0 = the megakernel,
- *                                           -1 (default) = the library decides (wavefront for sessions of >= 0.7 M ... 2 M pixels, by mesh size, on scenes kept
+ *                                           -1 (default) = the library decides (wavefront for sessions of >= 0.5 M ... 2 M pixels, by mesh size, on scenes kept
  *                                           as meshes + instances, else the megakernel). Films are the same bit for bit either way.
  *   "wf_groups"    (AKR_WF_GROUPS=g)        wavefront schedule: the path slots run as g groups with queues and streams of their own; 0 = the
  *                                           library decides
+ *   "wf_carry"     (AKR_WF_CARRY=0)         wavefront schedule: 1 (default) = the last rays of a trace launch -- the few lanes a wave has left once the
+ *                                           queue is empty -- are carried into the next launch instead of being waited for; 0 = every launch
+ *                                           traces all its rays to the end. Films are the same bit for bit either way.
  *   "simple_kernels" (AKR_PT_SIMPLE=0)      0 = never pick the kernels specialised for scenes without coat / transmission / normal map / glass
  *   "defer_on"     (no environment hook)    BVH kernels of scenes with textures: which hits "defer_metal" puts off -- 0 / 1 the conductor
  *                                           lobe (default), 2 texture-fed materials, 3 both

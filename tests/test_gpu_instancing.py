@@ -184,14 +184,15 @@ def test_per_scene_kernel_of_a_kept_scene(ctx, root, sampler):
     assert n_bit_diff(films[1], o) == 0
 
 
-@pytest.mark.parametrize("case", ["constant", "textured_alpha", "sobol_fd", "sorted"])
+@pytest.mark.parametrize("case", ["constant", "textured_alpha", "sobol_fd", "sorted", "carried"])
 def test_wavefront_schedule_on_a_kept_scene(ctx, root, case):
     """Round 6: the persistent trace kernel walks the two-level structure too (k_wf_trace<.., INST>: candidates wait in the lane's pending
     slot, the wave takes the exact test in batches); the shade kernel rebuilds the hit from mesh triangle + instance. Same film as the
     megakernel's and the oracle's."""
     sd = _kept_scene_data(root, case == "textured_alpha", 48, 40)
     cfg = make_config(spp=8, spp_per_pass=4, max_depth=8, **({"sampler_type": abi.SAMPLER_SOBOL, "sampler_seed": 5, "force_diffuse": 1} if case == "sobol_fd" else {}))
-    with capi.options(instancing=1, wavefront=1, wf_sort=1 if case == "sorted" else 0):
+    # ("carried": option wf_carry = the launch size from which a trace launch hands its last rays to the next one -- 2: every launch of this small frame)
+    with capi.options(instancing=1, wavefront=1, wf_sort=1 if case == "sorted" else 0, wf_carry=2 if case == "carried" else 1):
         scene = capi.Scene(ctx, sd)
         assert scene.info().uses_bvh == 2
         film = capi.Film(ctx, 48, 40)
@@ -201,6 +202,8 @@ def test_wavefront_schedule_on_a_kept_scene(ctx, root, case):
         st = se.end()
     if case == "textured_alpha":
         assert "wavefront" in status, status  # (the reason a textured session has no per-scene kernel: the wavefront schedule runs it)
+    if case == "carried":
+        assert int(status.split("; ")[1].split()[0]) > 50, status
     o, ost = _oracle(sd, cfg)
     assert n_bit_diff(film.read(), o) == 0
     for k in ("n_samples", "n_closest", "n_shadow", "n_shaded"):
@@ -288,6 +291,47 @@ def test_rebraided_top_level_tree_and_slot_groups_change_no_bit(ctx, root):
     assert visits["rebraid"] != visits["plain"]
     for key in ("rebraid", "groups", "both"):
         assert n_bit_diff(films[key], films["plain"]) == 0, key
+
+
+@pytest.mark.parametrize("kept", [1, 0], ids=["kept", "flattened"])
+def test_rays_carried_from_one_trace_launch_into_the_next_change_no_bit(ctx, root, kept):
+    """Option wf_carry (default 1): a wave of k_wf_trace that finds the queue empty and has few lanes left saves their traversals -- best hit, place in
+    the tree(s), the stack, a candidate waiting for its exact test -- and ends; k_wf_shade leaves such a slot alone, the next trace launch resumes the
+    ray. Launches of >= 65 536 rays only: the frame is large enough for it to happen (asserted), and film and counters are those of the schedule
+    that traces every launch to the end, of the megakernel, and (a tile shard) of the oracle."""
+    import re
+    sd = procedural.instanced_forest(60, 3000, width=640, height=360)
+    sd.ggx_table = _table(root)
+    cfg = make_config(spp=4, spp_per_pass=2, max_depth=7)
+    films, stats, carried = {}, {}, {}
+    with capi.options(instancing=kept):
+        scene = capi.Scene(ctx, sd)
+        assert scene.info().uses_bvh == (2 if kept else 1)
+        for key, opts in {"megakernel": dict(wavefront=0), "to_the_end": dict(wavefront=1, wf_carry=0), "carried": dict(wavefront=1, wf_carry=1),
+                          "carried_2_groups": dict(wavefront=1, wf_carry=1, wf_groups=2)}.items():
+            with capi.options(**opts):
+                film = capi.Film(ctx, 640, 360)
+                se = capi.PtSession(ctx, scene, cfg, film)
+                se.passes(2, blocking=True)
+                m = re.search(r"(\d+) rays carried", se.kernel_info()["status"])
+                carried[key] = int(m.group(1)) if m else None
+                stats[key] = se.end()
+            films[key] = film.read()
+    assert carried["megakernel"] is None and carried["to_the_end"] is None
+    assert carried["carried"] > 100 and carried["carried_2_groups"] > 100, carried
+    for key in ("to_the_end", "carried", "carried_2_groups"):
+        assert n_bit_diff(films[key], films["megakernel"]) == 0, key
+        for k in ("n_samples", "n_closest", "n_shadow", "n_shaded"):
+            assert stats[key][k] == stats["megakernel"][k], (key, k)
+    if not kept:  # a carried ray goes on where it stopped: not one node more. (Kept scenes: WHEN a wave takes its lanes' exact tests -- and so how
+        for k in ("n_node_visits", "n_tri_tests"):  # early a closer hit shortens a ray -- depends on the wave's other lanes, under every schedule.)
+            assert stats["carried"][k] == stats["to_the_end"][k], k
+    shard = distributed.shard_config(cfg, 3, 64, 8, 8)
+    with capi.options(instancing=kept, wavefront=1):
+        film = capi.Film(ctx, 640, 360)
+        capi.pt_render(ctx, scene, shard, film)
+    o, _ = _oracle(sd, shard, bvh=True)
+    assert n_bit_diff(film.read(), o) == 0
 
 
 def test_the_library_picks_the_wavefront_schedule_for_large_kept_frames(ctx, root):

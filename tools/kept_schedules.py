@@ -27,7 +27,7 @@ for tris in [int(a) for a in sys.argv[1:]] or [10_000, 100_000]:
     combos = [(rb, 0, 1) for rb in [int(a) for a in os.environ.get("KS_REBRAID", "1").split(",")]]
     combos += [(rb, 1, g) for rb, _, _ in list(combos) for g in [int(a) for a in os.environ.get("KS_GROUPS", "4").split(",")]]
     for rb, wf, groups in combos:
-        with capi.options(instancing=int(os.environ.get("KS_INSTANCING", "1")), wavefront=wf, rebraid=rb, wf_groups=groups, specialise=int(os.environ.get("KS_SPECIALISE", "-1"))):
+        with capi.options(instancing=int(os.environ.get("KS_INSTANCING", "1")), wavefront=wf, rebraid=rb, wf_groups=groups, specialise=int(os.environ.get("KS_SPECIALISE", "-1")), wf_carry=int(os.environ.get("KS_CARRY", "1"))):
             sc = capi.Scene(ctx, sd); f = capi.Film(ctx, W, H)
             cfg = abi.PtConfig.default(); cfg.spp, cfg.spp_per_pass, cfg.max_depth, cfg.rr_depth = 2 * SPP, SPP, int(os.environ.get("KS_DEPTH", "12")), 5
             se = capi.PtSession(ctx, sc, cfg, f)

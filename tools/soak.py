@@ -1,7 +1,7 @@
 """Randomised parity soak: random small scenes (random triangle soups + a few quads, random materials drawn from edge values,
 random emitters, cameras, samplers, configs, colour pipelines; a third of them with random images and random shader-graph DAGs
 feeding random inputs), the HIP path tracer against the oracle, film accumulators and
-counters bit for bit. Prints the seeds that differ. python tools/soak.py [n_cases] [first_seed] [tex] [big] [aov | gpt | mcmc | shard | wavefront | inst]   (needs a GPU; uses oracle/)"""
+counters bit for bit. Prints the seeds that differ. python tools/soak.py [n_cases] [first_seed] [tex] [big] [aov | gpt | mcmc | shard | wavefront [carry] | inst]   (needs a GPU; uses oracle/)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -262,6 +262,8 @@ def main():
     if "wavefront" in opts:  # the path tracer's wavefront schedule instead of the megakernel
         capi.set_option("wavefront", 1)
         capi.set_option("force_bvh", 1)
+        if "carry" in opts:  # rays carried from one trace launch into the next on these small frames too (option wf_carry: the launch size it starts at)
+            capi.set_option("wf_carry", 2)
     table = np.fromfile(os.path.join(ROOT, "tests/golden/ggx_dielectric_s.f32"), dtype=np.float32)
     ctx = capi.Context(0)
     pyoracle.set_pmj_tables(*capi.host_pmj02bn_tables())
