@@ -10,7 +10,7 @@ HASH=$(python -c "import bench; print(bench.csrc_hash())")
 { echo "# python -m pytest tests -m gpu -q on MI355X, round 6 closing sources (csrc hash $HASH)"
   ( time python -m pytest tests -m gpu -q 2>&1 | grep -E " passed| failed" ) 2>&1 | grep -E "passed|failed|real"
   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1; } > $OUT/gputest_summary.txt
-{ python tools/soak.py 1500 0; python tools/soak.py 1500 20000 inst; python tools/soak.py 300 30000 wavefront; } 2>&1 | grep "cases from" > $OUT/soak.txt
+{ python tools/soak.py 1500 0; python tools/soak.py 1500 20000 inst; python tools/soak.py 300 30000 wavefront; python tools/soak.py 600 40000 wavefront carry; python tools/soak.py 600 50000 wavefront carry inst; python tools/soak.py 300 60000 wavefront carry inst tex; } 2>&1 | grep "cases from" > $OUT/soak.txt
 for s in 800x600 1024x768 1024x1024 1600x900 1920x1080 3840x2160; do KS_SIZE=$s KS_GROUPS=1,2 python tools/kept_schedules.py 10000 100000; done > $OUT/kept_schedules.txt 2>&1
 python tools/inst_extreme_check.py 400 0 oracle 2>&1 | tail -1 > $OUT/inst_extreme_400.txt
 bash tools/pmc_all.sh > $OUT/pmc_all.txt 2>&1
