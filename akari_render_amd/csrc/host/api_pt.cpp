@@ -282,7 +282,15 @@ static void wf_allocate(akr_pt_session* se, uint32_t n_slots) {
         if (!se->wf_fork) HIP_CHECK(hipEventCreateWithFlags(&se->wf_fork, hipEventDisableTiming));
     }
     // persistent trace kernel: as many workgroups as the CUs hold at once (occupancy API: registers + this tree's LDS stacks)
-    se->wf_trace_blocks = (uint32_t)se->ctx->props.multiProcessorCount * wf_trace_blocks_per_cu(se->params);
+    // ... but no more than the scene's data can feed: every resident wave is 64 more rays gathering from the tree, and past the L2s and the
+    // 256 MB infinity cache more rays in flight only evict each other's nodes (the trace kernel of a flattened scene fits six waves per SIMD,
+    // the megakernel runs four). Measured, workgroups per CU 4 / 5 / 6: hall of 0.1 M triangles (21 MB on the device) 337 / 353 / 356 Msamples/s,
+    // 1 M (214 MB) 300 / 310 / 307, 3 M (642 MB) 273 / 281 / 265, 10 M (2.1 GB) 253 / 247 / 228, flattened forest of 10 M (2.6 GB) 370 / 366 / 351.
+    uint32_t per_cu = wf_trace_blocks_per_cu(se->params);
+    const uint64_t scene_bytes = sc->device_bytes;
+    per_cu = std::min(per_cu, scene_bytes > (1200ull << 20) ? 4u : (scene_bytes > (400ull << 20) ? 5u : 8u));
+    if (const char* e = std::getenv("AKR_WF_TRACE_BLOCKS_PER_CU")) per_cu = (uint32_t)std::max(1, std::min(8, std::atoi(e)));  // (measurement hook)
+    se->wf_trace_blocks = (uint32_t)se->ctx->props.multiProcessorCount * per_cu;
 }
 
 // One launch group of the wavefront schedule = `fused` passes for every slot: init, then trace/shade iterations until
