@@ -181,6 +181,7 @@ struct akr_pt_session {
     uint32_t n_owned_tiles = 0;
     // wavefront schedule (wf_kernels.hip): path state SoA + ray queues
     bool wavefront = false;
+    int sched_trial = 0;  // flattened scenes, option wavefront = -1: 1 = the first blocking akr_pt_passes call times both schedules and keeps the faster (api_pt.cpp), 2 = done
     DevBuf wf_state, wf_queues, wf_ctrl, wf_pend, wf_carry;
     // option wf_sort: keys of the queue entries, the sorted copies the trace kernel reads, rocPRIM's scratch
     bool wf_sort = false;

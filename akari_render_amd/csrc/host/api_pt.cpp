@@ -375,6 +375,31 @@ static void wf_run(akr_pt_session* se) {
     }
 }
 
+// Flattened scenes under option wavefront = -1. Which schedule is faster there depends on the scene -- 1080p, 10 M triangles: the closed hall 308
+// (megakernel) against 252 Msamples/s (wavefront), the open forest 309 against 369 -- through how much the lengths of a wave's traversals differ, which
+// no number the compiler has predicts. So a render that can pay for it MEASURES: the first blocking akr_pt_passes call runs two passes under the
+// megakernel, two under the wavefront schedule (HIP-event time per sample of each), and the session goes on with the faster one. Films are the same
+// bit for bit under either schedule and under any sequence of them (both start a launch from, and leave behind, the session's sampler states and
+// film). "Can pay": a pt session without textures / relaxed tier / ray sort on a scene with a tree of >= 256 MB (small scenes: the megakernel wins
+// by up to 2 x), >= 1 M pixels (the persistent trace kernel wants its lanes refilled), >= 16 passes to render; a scene whose paths practically
+// never end at a light or in the open (shaded vertices per closest-hit ray >= 0.97 in the megakernel's two passes: the hall 0.999) skips the
+// wavefront half -- it has measured slower on every such scene. Option sched_trial: 0 = never, 1 = every session on a scene with a tree (tests).
+static bool schedule_trial_eligible(const akr_pt_session* se, bool for_pt_kernel) {
+    const TuningOptions t = tuning();
+    const akr_scene* sc = se->scene;
+    if (t.wavefront != -1 || t.sched_trial == 0 || !for_pt_kernel || se->wavefront || se->arith_relaxed || se->spec_active) return false;
+    if (sc->cs.instanced.on || sc->cs.bvh_nodes.empty() || t.wf_sort != 0) return false;
+    if (t.sched_trial == 1) return true;
+    const uint64_t passes = (session_samples(se->cfg) + se->cfg.spp_per_pass - 1) / se->cfg.spp_per_pass;
+    return !sc->cs.has_textures && sc->device_bytes >= (256ull << 20) && passes >= 16 &&
+           session_items(se->cfg, sc->flat.camera.width, sc->flat.camera.height) >= 1000000u;
+}
+static void read_stats(akr_pt_session* se, akr_pt_stats* stats);
+static void wf_release(akr_pt_session* se) {
+    for (DevBuf* b : {&se->wf_state, &se->wf_queues, &se->wf_ctrl, &se->wf_pend, &se->wf_carry, &se->wf_keys, &se->wf_sorted, &se->wf_sort_tmp}) b->release();
+    se->wf_group.clear();
+}
+
 static void validate_config(const akr_pt_config& c) {
     if (c.spp_per_pass == 0) throw std::invalid_argument("akr_pt_config: spp_per_pass must be > 0");
     if (c.filter_type > AKR_FILTER_GAUSSIAN) throw std::invalid_argument("akr_pt_config: unknown filter_type");
@@ -528,6 +553,7 @@ int32_t akr_api::pt_begin(akr_context* ctx, akr_scene* scene, const akr_pt_confi
             fill_params(se.get(), 1, cfg->spp_per_pass);  // for n_items
             wf_allocate(se.get(), se->params.n_items);
         }
+        se->sched_trial = schedule_trial_eligible(se.get(), for_pt_kernel) ? 1 : 0;
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         *out = se.release();
     });
@@ -559,9 +585,9 @@ AKR_API int32_t akr_pt_passes(akr_pt_session* se, uint32_t n_passes, int32_t blo
         }
         uint32_t left = n_passes;
         const uint32_t total = session_samples(se->cfg);
-        while (left > 0 && se->spp_done < total) {
+        auto launch = [&](uint32_t max_fused) {  // one launch (group) of up to max_fused of the passes left
             uint32_t fused = 0, last = 0, done = se->spp_done;
-            while (fused < kMaxFusedPasses && fused < left && done < total) {
+            while (fused < max_fused && fused < left && done < total) {
                 last = std::min(total - done, se->cfg.spp_per_pass);
                 done += last;
                 fused++;
@@ -576,7 +602,41 @@ AKR_API int32_t akr_pt_passes(akr_pt_session* se, uint32_t n_passes, int32_t blo
             se->n_launches++;
             se->passes_launched += fused;
             left -= fused;
+        };
+        if (se->sched_trial == 1 && blocking && left >= 4 && total - se->spp_done >= 4 * se->cfg.spp_per_pass) {  // (schedule_trial_eligible)
+            se->sched_trial = 2;
+            auto timed = [&](double& ms_per_sample, double& shaded_per_closest) {  // two passes under the current schedule
+                HIP_CHECK(hipStreamSynchronize(se->ctx->stream));
+                akr_pt_stats a, b;
+                read_stats(se, &a);
+                launch(2);
+                read_stats(se, &b);
+                ms_per_sample = (b.kernel_ms - a.kernel_ms) / (double)std::max<uint64_t>(1, b.n_samples - a.n_samples);
+                shaded_per_closest = (double)(b.n_shaded - a.n_shaded) / (double)std::max<uint64_t>(1, b.n_closest - a.n_closest);
+            };
+            double mk = 0.0, wf = 0.0, ratio = 0.0, unused = 0.0;
+            timed(mk, ratio);
+            char msg[200];
+            if (ratio >= 0.97 && tuning().sched_trial != 1) {
+                std::snprintf(msg, sizeof msg, "megakernel (no trial of the other schedule: %.3f shaded vertices per closest-hit ray, a closed scene)", ratio);
+            } else {
+                se->wavefront = true;
+                fill_params(se, 1, se->cfg.spp_per_pass);  // for n_items
+                wf_allocate(se, se->params.n_items);
+                timed(wf, unused);
+                const bool keep = wf < 0.95 * mk;
+                // (a session on the megakernel never says "wavefront": callers tell the schedule by that word)
+                std::snprintf(msg, sizeof msg, keep ? "wavefront schedule (timed trial, 2 passes each: %.3g ns per sample against the megakernel's %.3g)"
+                                                    : "megakernel (timed trial, 2 passes each: %.3g ns per sample against the other schedule's %.3g)",
+                              (keep ? wf : mk) * 1e6, (keep ? mk : wf) * 1e6);
+                if (!keep) {
+                    se->wavefront = false;
+                    wf_release(se);
+                }
+            }
+            se->spec_status = msg;
         }
+        while (left > 0 && se->spp_done < total) launch(kMaxFusedPasses);
         if (blocking) HIP_CHECK(hipStreamSynchronize(se->ctx->stream));
         if (spp_done) *spp_done = se->spp_done;
     });

@@ -825,6 +825,7 @@ void tuning_init_locked() {
     if (const char* e = std::getenv("AKR_INSTANCING")) g_tuning.instancing = std::atoi(e);
     if (const char* e = std::getenv("AKR_WF_GROUPS")) g_tuning.wf_groups = std::max(0, std::min(32, std::atoi(e)));
     if (const char* e = std::getenv("AKR_WF_CARRY")) g_tuning.wf_carry = std::max(0, std::min(1 << 30, std::atoi(e)));
+    if (const char* e = std::getenv("AKR_SCHED_TRIAL")) g_tuning.sched_trial = std::max(-1, std::min(1, std::atoi(e)));
     if (const char* e = std::getenv("AKR_REBRAID")) g_tuning.rebraid = std::max(1, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("AKR_ARITH")) g_tuning.arith = std::atoi(e) != 0 ? 1 : 0;
 }
@@ -845,6 +846,7 @@ int* tuning_field(const char* name) {
     if (n == "rebraid") return &g_tuning.rebraid;
     if (n == "wf_groups") return &g_tuning.wf_groups;
     if (n == "wf_carry") return &g_tuning.wf_carry;
+    if (n == "sched_trial") return &g_tuning.sched_trial;
     if (n == "pad_percent") return &g_tuning.pad_percent;
     return nullptr;
 }
@@ -869,6 +871,7 @@ bool tuning_set(const char* name, int value) {
     if (f == &g_tuning.rebraid && (value < 1 || value > 64)) return false;
     if (f == &g_tuning.wf_groups && (value < 0 || value > 32)) return false;
     if (f == &g_tuning.wf_carry && (value < 0 || value > (1 << 30))) return false;
+    if (f == &g_tuning.sched_trial && (value < -1 || value > 1)) return false;
     if (f == &g_tuning.wavefront && (value < -1 || value > 1)) return false;
     if (f == &g_tuning.pad_percent && (value < 1 || value > 10000)) return false;
     *f = value;

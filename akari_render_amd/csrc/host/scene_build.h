@@ -187,6 +187,8 @@ void build_alias_table(const std::vector<float>& weights, std::vector<AliasEntry
 //   wf_carry     AKR_WF_CARRY=0           wavefront schedule: 0 = every trace launch traces its rays to the end (1, default: a wave that finds the queue empty and
 //                                         has few lanes left hands their traversals to the next launch -- wf_kernels.hip; launches of >= 65 536 rays only;
 //                                         a value n > 1 = test hook: launches of >= n rays, and waves hand over after 4 steps with up to 56 lanes left)
+//   sched_trial  AKR_SCHED_TRIAL=<v>      flattened scenes, option wavefront = -1: -1 (default) = a long render of a large frame of a large untextured scene starts with two passes
+//                                         under each schedule and goes on with the faster; 0 = never (the megakernel); 1 = every pt session on a scene with a tree (tests)
 //   max_fused_passes (no environment hook)     most passes akr_pt_passes fuses into one launch: 0 = adaptive (16, up to 64 once a pass has been timed), else 1..64
 struct TuningOptions {
     int force_bvh = 0, bvh_balanced = 0, defer_metal = -1, wavefront = -1, simple_kernels = 1;
@@ -202,6 +204,8 @@ struct TuningOptions {
                             // tests/test_bvh_conservative.py shows with it how far the derived padding is from the first lost hit
     int wf_groups = 0;  // wavefront schedule: slot groups whose init / trace / shade chains run side by side on streams of their own (1 = one chain, 0 = the library decides)
     int wf_carry = 1;  // wavefront schedule: 1 = the last rays of a trace launch are carried into the next one (wf_kernels.hip), 0 = every launch traces to the end
+    int sched_trial = -1;  // flattened scenes under option wavefront = -1: a timed trial of both schedules at the start of a long render (api_pt.cpp schedule_trial):
+                           // -1 = for the sessions it can pay for (large frame, large scene, many passes), 0 = never, 1 = every pt session on a scene with a tree (tests)
     int wf_sort = 0;  // wavefront schedule: 1 = the ray queues are sorted by (Morton code of the origin, octant) before every trace launch (wf_sort.hip)
 };
 constexpr uint64_t kSpecAutoSamples = 1ull << 31;  // option specialise = -1: a first-use compile (about a second; 20-30 % of the render to win) has to be worth it

@@ -565,7 +565,7 @@ def instanced_forest_leg(ctx, only=None):
                                              "device_MB": info.device_bytes / 1e6, "compile_upload_s": t_load, "rays_per_s_G": rays / dt / 1e9,
                                              "node_visits_per_ray": d["n_node_visits"] / rays, "candidates_per_ray": d["n_tri_tests"] / rays,
                                              "roofline": {k: rl.get(k) for k in _LEG_ROOFLINE_KEYS if k in rl}, "total_samples": s1["n_samples"]}
-            if mode == "kept" and not only:  # the other schedule on the same scene (not under a profiler: --leg runs the chosen one alone)
+            if not only:  # the other schedule on the same scene, kept or flattened (not under a profiler: --leg runs the chosen one alone)
                 d2, dt2, _, film2, _ = run(wavefront=0 if schedule == "wavefront" else 1)
                 out[f"{tris // 1000}k_{mode}"]["other_schedule"] = {"schedule": "megakernel" if schedule == "wavefront" else "wavefront", "value": d2["n_samples"] / dt2 / 1e6,
                                                                   "film_identical": bool(np.array_equal(film2.view(np.uint32), films[mode].view(np.uint32)))}

@@ -628,6 +628,10 @@ AKR_API uint32_t akr_struct_size(int32_t which);
  *   "wf_carry"     (AKR_WF_CARRY=0)         wavefront schedule: 1 (default) = the last rays of a trace launch -- the few lanes a wave has left once the
  *                                           queue is empty -- are carried into the next launch instead of being waited for; 0 = every launch
  *                                           traces all its rays to the end. Films are the same bit for bit either way.
+ *   "sched_trial"  (AKR_SCHED_TRIAL=v)      flattened scenes under "wavefront" = -1: -1 (default) = a long render (>= 16 passes) of a large frame (>= 1 M pixels) of
+ *                                           a large untextured scene (>= 256 MB on the device) starts with two passes under each schedule and goes on with the
+ *                                           faster one (skipped for closed scenes, where the megakernel always measured faster); 0 = never; 1 = every pt
+ *                                           session on a scene with a tree (tests). akr_pt_kernel_info's status names the outcome. Same film either way.
  *   "simple_kernels" (AKR_PT_SIMPLE=0)      0 = never pick the kernels specialised for scenes without coat / transmission / normal map / glass
  *   "defer_on"     (no environment hook)    BVH kernels of scenes with textures: which hits "defer_metal" puts off -- 0 / 1 the conductor
  *                                           lobe (default), 2 texture-fed materials, 3 both

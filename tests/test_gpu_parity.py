@@ -253,6 +253,42 @@ def test_wavefront_schedule_matches_oracle(ctx, cbox_path, root, wavefront_mode,
     assert np.array_equal(gs, os_)
 
 
+@pytest.mark.parametrize("case", ["cbox_full", "hall", "hall_sobol"])
+def test_a_session_that_times_both_schedules_renders_the_same_film(ctx, cbox_path, case):
+    """Option sched_trial (api_pt.cpp: a long render of a large flattened scene starts with two passes under each schedule and keeps the faster one;
+    1 = every session on a scene with a tree): megakernel launches and wavefront launch groups in ONE session, each starting from the sampler
+    states and the film the other left -- film, sampler states and counters are the oracle's, whichever schedule the trial kept."""
+    if case == "cbox_full":
+        sd, cfg = scene_json.load_scene(cbox_path, 96, 72), make_config(spp=26, spp_per_pass=4, max_depth=8)
+    else:
+        from akari_render_amd import procedural
+        sd = procedural.sponza_like(20_000, seed=1234, width=96, height=54)
+        cfg = make_config(spp=12, spp_per_pass=2, max_depth=5, **({"sampler_type": abi.SAMPLER_SOBOL, "sampler_seed": 9} if case == "hall_sobol" else {}))
+    w, h = sd.camera.width, sd.camera.height
+    with capi.options(force_bvh=1, sched_trial=1):
+        scene = capi.Scene(ctx, sd)
+        film = capi.Film(ctx, w, h)
+        se = capi.PtSession(ctx, scene, cfg, film)
+        assert "timed trial" not in se.kernel_info()["status"]
+        se.passes(1, blocking=False)                          # (a non-blocking call never runs the trial)
+        se.passes(5, blocking=True)                           # the trial (4 passes) + one more
+        status = se.kernel_info()["status"]
+        assert "timed trial" in status and status.split()[0] in ("megakernel", "wavefront"), status
+        se.passes((cfg.spp + cfg.spp_per_pass - 1) // cfg.spp_per_pass, blocking=True)  # the rest
+        gs = se.sampler_states(w * h) if cfg.sampler_type == 0 else None
+        gst = se.end()
+    osc = pyoracle.OracleScene(sd)
+    if cfg.sampler_type == 0:
+        os_ = pyoracle.init_pcg32_states(w * h, cfg.sampler_seed)
+        o, ost = osc.render(cfg, states=os_)
+        assert np.array_equal(gs, os_)
+    else:
+        pyoracle.set_pmj_tables(*capi.host_pmj02bn_tables())
+        from tests.test_gpu_instancing import _index_states
+        o, ost = osc.render(cfg, states=_index_states(w, h))
+    assert_parity(film.read(), o, w, h, gst, ost)
+
+
 @pytest.mark.parametrize("case", ["cbox_full", "hall"])
 def test_wavefront_with_sorted_ray_queues_changes_no_bit(ctx, cbox_path, wavefront_mode, case):
     """option wf_sort (wf_sort.hip): the trace kernel reads its ray queues sorted by origin cell + direction octant. A ray's result is
