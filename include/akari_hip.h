@@ -324,7 +324,8 @@ typedef enum {
     /* a scene kept as meshes + instances (akr_scene_info.uses_bvh == 2; csrc/host/scene_inst.cpp, empty otherwise). AKR_ARRAY_BVH_NODES
      * then holds the top-level tree over the instances followed by every mesh's own tree; WOOP / TRI_GID / SHADE are empty */
     AKR_ARRAY_INST_LEAVES = 17,  /* f32[16 * top-level leaf entries] (one or more per instance with triangles): world->object rows | tree, mesh, instance, entry node */
-    AKR_ARRAY_MESH_TRIS = 18,    /* f32[16 * mesh triangles] object-space vertices and uvs in each mesh's traversal order */
+    AKR_ARRAY_MESH_TRIS = 18,    /* f32[16 * mesh triangles] object-space vertices and uvs in each mesh's traversal order (the host's copy: on the device the top
+                                    bit of a record's last word says that some instance gives the triangle its even neighbour's plane row) */
     AKR_ARRAY_MESH_POS = 19,     /* u32[mesh triangles] mesh order -> position in MESH_TRIS */
     AKR_ARRAY_MESH_META = 20,    /* u32[mesh triangles] material slot | flags << 30 */
     AKR_ARRAY_MESH_NORMALS = 21  /* f32[24 * mesh triangles] corner normals / tangents (empty if no mesh has any) */
