@@ -361,6 +361,14 @@ def test_options_are_a_table_not_the_environment(hip_lib, cbox_path, monkeypatch
     assert capi.get_option("defer_metal") == -1 and capi.get_option("wavefront") == -1
     with pytest.raises(capi.AkariError):
         capi.set_option("no_such_option", 1)
+    # the schedule options of round 6's last session: defaults, and values out of range are refused
+    assert capi.get_option("wf_carry") == 1 and capi.get_option("sched_trial") == -1 and capi.get_option("wf_groups") == 0
+    for name, bad in (("wf_carry", -1), ("sched_trial", 2), ("sched_trial", -2), ("wf_groups", 33), ("wavefront", 2)):
+        with pytest.raises(capi.AkariError):
+            capi.set_option(name, bad)
+    with capi.options(wf_carry=4096, sched_trial=1):  # (wf_carry above 1: the launch size from which rays are carried -- the tests' hook)
+        assert capi.get_option("wf_carry") == 4096 and capi.get_option("sched_trial") == 1
+    assert capi.get_option("wf_carry") == 1 and capi.get_option("sched_trial") == -1
 
 
 def test_scene_compile_does_not_depend_on_the_thread_count(hip_lib, monkeypatch):
