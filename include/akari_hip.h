@@ -643,7 +643,7 @@ AKR_API uint32_t akr_struct_size(int32_t which);
  *   "wf_sort"      (AKR_WF_SORT=1)          wavefront schedule: the ray queues are sorted by (Morton code of the origin, octant of the
  *                                           direction) before every trace launch (films unchanged; measurement in DESIGN.md)
  *   "instancing"   (AKR_INSTANCING=v)       scenes in which a mesh has several instances: -1 the library decides (kept as meshes +
- *                                           instances -- a tree over the instances and one per mesh in object space, nothing stored per
+ *                                           instances -- a tree over the instances and one per mesh in object space, one BIT stored per
  *                                           instance-triangle -- when the flattened records would pass 8 GB or 48 M triangles), 0 always
  *                                           flattened, 1 kept as meshes + instances whenever a mesh is shared. Films are the same bit for
  *                                           bit either way, for every integrator and schedule. A singular instance transform means
